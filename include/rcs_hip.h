@@ -1,0 +1,248 @@
+/*
+ * rcs_hip.h -- C-ABI of the MI355X batched simulation backend (librcs_hip.so).
+ *
+ * Drop-in boundary for the RCS simulation hot path.  Each entry point is the
+ * N-environment form of one method the reference exposes through its pybind11
+ * module `rcs._core.sim` / `rcs._core.common` (reference src/pybind/rcs.cpp);
+ * the reference method it replaces is cited on every declaration.  A reference
+ * maintainer binds these exactly like the existing C++ classes (INTEGRATION.md
+ * shows the pybind11 and ctypes stubs).
+ *
+ * Conventions
+ *  - plain C: opaque handle, caller-owned buffers, no exceptions.  Every call
+ *    returns RCSH_OK or an error code; rcsh_last_error() gives the message of the
+ *    last failure on the calling thread.  The Python shim maps
+ *    RCSH_ERR_NAME -> RuntimeError and RCSH_ERR_ARG -> ValueError, the exception
+ *    types the reference raises (SimRobot.cpp:57-93, SimGripper.cpp:80-83).
+ *  - arrays are row-major, environment-major: q[N][dof], pose[N][7] = x y z qx qy qz qw
+ *    (Eigen coeff order, reference Pose.cpp:115), flags uint8 (0/1).
+ *  - `mask` (uint8[N], may be NULL = all) selects the environments a call acts on.
+ *  - entry points without a suffix take HOST pointers and synchronise; `_dev`
+ *    entry points take DEVICE pointers, enqueue on the handle's HIP stream and
+ *    return immediately (rcsh_sim_synchronize() or a stream wait orders them).
+ *  - the library never falls back to the CPU: without a usable gfx950 device
+ *    rcsh_sim_create fails with RCSH_ERR_DEVICE.
+ */
+#ifndef RCS_HIP_H
+#define RCS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCSH_ABI_VERSION 1
+
+enum {
+  RCSH_OK = 0,
+  RCSH_ERR_ARG = 1,       /* std::invalid_argument in the reference */
+  RCSH_ERR_NAME = 2,      /* std::runtime_error("No joint named ...") in the reference */
+  RCSH_ERR_MODEL = 3,     /* scene outside the compiled archetypes / MJCF subset */
+  RCSH_ERR_DEVICE = 4,    /* no gfx950 device, HIP failure */
+  RCSH_ERR_STATE = 5      /* call order violated (e.g. robot not added) */
+};
+
+/* Flat scene tables; field names follow mjModel.  Stands where the reference hands
+ * `mjModel*` to `Sim(mjmdl, mjdata)` (reference src/pybind/rcs.cpp:493-497). */
+typedef struct rcsh_model_desc {
+  int32_t nbody, njnt, nu, ntendon, nwrap, neq, nsite;
+  double timestep;
+  double gravity[3];
+  const int32_t* body_parentid;   /* [nbody] */
+  const int32_t* body_jntadr;     /* [nbody] joint id or -1 */
+  const int32_t* body_jntnum;     /* [nbody] */
+  const double* body_pos;         /* [nbody][3] */
+  const double* body_quat;        /* [nbody][4] wxyz */
+  const double* body_ipos;        /* [nbody][3] */
+  const double* body_iquat;       /* [nbody][4] */
+  const double* body_mass;        /* [nbody] */
+  const double* body_inertia;     /* [nbody][3] principal */
+  const double* body_gravcomp;    /* [nbody] */
+  const int32_t* jnt_type;        /* [njnt] 2 slide, 3 hinge */
+  const int32_t* jnt_bodyid;      /* [njnt] */
+  const double* jnt_pos;          /* [njnt][3] */
+  const double* jnt_axis;         /* [njnt][3] */
+  const int32_t* jnt_limited;     /* [njnt] */
+  const double* jnt_range;        /* [njnt][2] */
+  const double* jnt_margin;       /* [njnt] */
+  const double* jnt_solref;       /* [njnt][2] */
+  const double* jnt_solimp;       /* [njnt][5] */
+  const int32_t* jnt_actfrclimited;
+  const double* jnt_actfrcrange;  /* [njnt][2] */
+  const int32_t* jnt_actgravcomp;
+  const double* dof_armature;     /* [njnt] */
+  const double* dof_damping;      /* [njnt] */
+  const double* dof_frictionloss; /* [njnt] must be 0 in this revision */
+  const double* qpos0;            /* [njnt] */
+  const int32_t* tendon_adr;      /* [ntendon] */
+  const int32_t* tendon_num;      /* [ntendon] */
+  const int32_t* wrap_objid;      /* [nwrap] joint ids */
+  const double* wrap_prm;         /* [nwrap] coefficients */
+  const int32_t* eq_obj1id;       /* [neq] joint ids */
+  const int32_t* eq_obj2id;
+  const int32_t* eq_active0;
+  const double* eq_data;          /* [neq][5] polycoef */
+  const double* eq_solref;        /* [neq][2] */
+  const double* eq_solimp;        /* [neq][5] */
+  const int32_t* actuator_trntype;   /* [nu] 0 joint, 3 tendon */
+  const int32_t* actuator_trnid;
+  const double* actuator_gear;       /* [nu] */
+  const double* actuator_gainprm;    /* [nu][3] */
+  const double* actuator_biasprm;    /* [nu][3] */
+  const int32_t* actuator_biastype;  /* [nu] 0 none, 1 affine */
+  const int32_t* actuator_ctrllimited;
+  const double* actuator_ctrlrange;  /* [nu][2] */
+  const int32_t* actuator_forcelimited;
+  const double* actuator_forcerange; /* [nu][2] */
+  const int32_t* site_bodyid;        /* [nsite] */
+  const double* site_pos;            /* [nsite][3] */
+  const double* site_quat;           /* [nsite][4] */
+} rcsh_model_desc;
+
+/* SimRobotConfig after name -> id lookup (reference src/sim/SimRobot.h:14-47, SimRobot.cpp:52-94). */
+typedef struct rcsh_robot_desc {
+  int32_t dof;
+  const int32_t* joint_ids;     /* [dof] */
+  const int32_t* actuator_ids;  /* [dof] */
+  int32_t attachment_site;
+  int32_t base_body;
+  const double* q_home;         /* [dof] robots_meta_config.q_home, reference include/rcs/Robot.h:24-95 */
+  double tcp_offset[7];         /* pose, xyzw quaternion */
+  double joint_rotational_tolerance; /* SimRobot.h:15 */
+  double seconds_between_callbacks;  /* SimRobot.h:17 */
+  int32_t register_convergence_callback;
+} rcsh_robot_desc;
+
+/* SimGripperConfig after name -> id lookup (reference src/sim/SimGripper.h:15-45). */
+typedef struct rcsh_gripper_desc {
+  int32_t joint_id;
+  int32_t actuator_id;
+  double epsilon_inner, epsilon_outer;
+  double seconds_between_callbacks;
+  double max_actuator_width, min_actuator_width;
+  double max_joint_width, min_joint_width;
+} rcsh_gripper_desc;
+
+/* Gymnasium-loop configuration of the fused env-step (reference python/rcs/envs/creators.py:43-128). */
+enum { RCSH_MODE_JOINTS = 0, RCSH_MODE_CARTESIAN_TRPY = 1, RCSH_MODE_CARTESIAN_TQUAT = 2 };
+enum { RCSH_REL_NONE = 0, RCSH_REL_LAST_STEP = 1, RCSH_REL_CONFIGURED_ORIGIN = 2 };
+typedef struct rcsh_env_desc {
+  int32_t control_mode;
+  int32_t relative_to;
+  double max_mov[2];            /* joints: [0]; cartesian: translation, rotation */
+  int32_t binary_gripper;       /* GripperWrapper(binary=True) */
+  const double* joint_low;      /* [dof] robots_meta_config.joint_limits */
+  const double* joint_high;
+} rcsh_env_desc;
+
+typedef struct rcsh_sim rcsh_sim;
+
+const char* rcsh_last_error(void);
+int rcsh_abi_version(void);
+int rcsh_device_count(void);
+
+/* rcs._core.sim.Sim(mjmdl, mjdata)  -- rcs.cpp:493-497; one handle = n_envs independent mjData */
+int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device, rcsh_sim** out);
+void rcsh_sim_destroy(rcsh_sim* sim);
+int rcsh_sim_num_envs(const rcsh_sim* sim);
+int rcsh_sim_synchronize(rcsh_sim* sim);
+/* the HIP stream (hipStream_t) all work of this handle is enqueued on */
+void* rcsh_sim_stream(rcsh_sim* sim);
+
+/* Sim.set_config / get_config -- rcs.cpp:500-501, sim.cpp:27-32; SimConfig sim.h:29-34 */
+int rcsh_sim_set_config(rcsh_sim* sim, int32_t async_control, int32_t realtime, int32_t frequency,
+                        int32_t max_convergence_steps);
+int rcsh_sim_get_config(const rcsh_sim* sim, int32_t* async_control, int32_t* realtime, int32_t* frequency,
+                        int32_t* max_convergence_steps);
+/* Sim.step(k) -- rcs.cpp:503, sim.cpp:108-115 */
+int rcsh_sim_step(rcsh_sim* sim, int64_t k);
+/* Sim.step_until_convergence() -- rcs.cpp:498-499, sim.cpp:84-106 */
+int rcsh_sim_step_until_convergence(rcsh_sim* sim);
+/* Sim.is_converged() -- rcs.cpp:502, sim.cpp:83; also the substeps the last call took per env */
+int rcsh_sim_is_converged(rcsh_sim* sim, uint8_t* converged, int32_t* convergence_steps);
+/* Sim.reset() -- rcs.cpp:504, sim.cpp:117-138 */
+int rcsh_sim_reset(rcsh_sim* sim, const uint8_t* mask);
+
+/* SimRobot(sim, ik, cfg, register_convergence_callback) -- rcs.cpp:516-527, SimRobot.cpp:27-43 */
+int rcsh_sim_add_robot(rcsh_sim* sim, const rcsh_robot_desc* robot);
+/* Robot.set_joint_position -- rcs.cpp:358-360, SimRobot.cpp:123-131 */
+int rcsh_robot_set_joint_position(rcsh_sim* sim, const double* q, const uint8_t* mask);
+/* Robot.get_joint_position -- rcs.cpp:361, SimRobot.cpp:133-139 */
+int rcsh_robot_get_joint_position(rcsh_sim* sim, double* q);
+/* Robot.get_cartesian_position -- rcs.cpp:357, SimRobot.cpp:114-121 */
+int rcsh_robot_get_cartesian_position(rcsh_sim* sim, double* pose);
+/* Robot.get_base_pose_in_world_coordinates -- rcs.cpp:374, SimRobot.cpp:207-213 */
+int rcsh_robot_get_base_pose(rcsh_sim* sim, double* pose);
+/* Robot.set_cartesian_position -- rcs.cpp:366-367, SimRobot.cpp:145-155 (Pin CLIK, Kinematics.cpp:28-68) */
+int rcsh_robot_set_cartesian_position(rcsh_sim* sim, const double* pose, const uint8_t* mask);
+/* SimRobot.set_joints_hard -- rcs.cpp:525, SimRobot.cpp:198-205 */
+int rcsh_robot_set_joints_hard(rcsh_sim* sim, const double* q, const uint8_t* mask);
+/* Robot.reset / move_home -- rcs.cpp:362-365, SimRobot.cpp:47-50,193-196 */
+int rcsh_robot_reset(rcsh_sim* sim, const uint8_t* mask);
+int rcsh_robot_move_home(rcsh_sim* sim, const uint8_t* mask);
+/* SimRobot.get_state -- rcs.cpp:523, SimRobotState SimRobot.h:49-57; any pointer may be NULL */
+int rcsh_robot_get_state(rcsh_sim* sim, uint8_t* ik_success, uint8_t* collision, uint8_t* is_moving,
+                         uint8_t* is_arrived, double* previous_angles, double* target_angles);
+/* Kinematics.inverse / forward on the robot's own chain -- rcs.cpp:285-300, Kinematics.cpp:28-82.
+ * q0 [N][dof] -> q [N][nq] (nq = model dofs, quirk Q7), success [N], iterations [N] (may be NULL) */
+int rcsh_ik_inverse(rcsh_sim* sim, const double* pose, const double* q0, const double* tcp_offset7, double* q,
+                    uint8_t* success, int32_t* iterations);
+int rcsh_ik_forward(rcsh_sim* sim, const double* q0, const double* tcp_offset7, double* pose);
+
+/* SimGripper(sim, cfg) -- rcs.cpp:508-515, SimGripper.cpp:13-39 */
+int rcsh_sim_add_gripper(rcsh_sim* sim, const rcsh_gripper_desc* gripper);
+/* Gripper.set_normalized_width -- rcs.cpp:381-383, SimGripper.cpp:79-92 (RCSH_ERR_ARG outside [0,1] / force<0) */
+int rcsh_gripper_set_normalized_width(rcsh_sim* sim, const double* width, double force, const uint8_t* mask);
+/* Gripper.get_normalized_width -- rcs.cpp:384, SimGripper.cpp:93-106 */
+int rcsh_gripper_get_normalized_width(rcsh_sim* sim, double* width);
+/* Gripper.is_grasped -- rcs.cpp:385, SimGripper.cpp:132-141 */
+int rcsh_gripper_is_grasped(rcsh_sim* sim, uint8_t* grasped);
+/* Gripper.reset -- rcs.cpp:395-396, SimGripper.cpp:158-165 */
+int rcsh_gripper_reset(rcsh_sim* sim, const uint8_t* mask);
+/* SimGripper.get_state -- rcs.cpp:513, SimGripperState SimGripper.h:47-52 */
+int rcsh_gripper_get_state(rcsh_sim* sim, double* last_commanded_width, uint8_t* is_moving, double* last_width,
+                           uint8_t* collision);
+
+/* mjData views the reference reads directly (python/rcs/envs/sim.py:343-411): qpos, qvel, ctrl, time */
+int rcsh_sim_get_qpos(rcsh_sim* sim, double* qpos);  /* [N][nq] */
+int rcsh_sim_get_qvel(rcsh_sim* sim, double* qvel);
+int rcsh_sim_get_ctrl(rcsh_sim* sim, double* ctrl);  /* [N][nu] */
+int rcsh_sim_get_time(rcsh_sim* sim, double* time);  /* [N] */
+int rcsh_sim_set_qpos(rcsh_sim* sim, const double* qpos, const uint8_t* mask);
+int rcsh_sim_set_qvel(rcsh_sim* sim, const double* qvel, const uint8_t* mask);
+int rcsh_sim_nq(const rcsh_sim* sim);
+int rcsh_sim_nu(const rcsh_sim* sim);
+
+/* ---- fused Gymnasium loop: SimEnvCreator()(...).reset() / .step(action) for N environments in one launch.
+ * Wrapper stack restated in the kernel (reference python/rcs/envs/base.py:246-304,469-565,680-735;
+ * envs/sim.py:49-76,119-131).  Observation row: tquat[7] joints[dof] xyzrpy[6] gripper[1]
+ * (obs_width = 14 + dof); info row (uint8[8]): collision, ik_success, is_sim_converged, is_grasped,
+ * truncated, gripper_collision, 0, 0; gripper_width[N] (double). */
+int rcsh_env_configure(rcsh_sim* sim, const rcsh_env_desc* env);
+int rcsh_env_obs_width(const rcsh_sim* sim);
+int rcsh_env_action_width(const rcsh_sim* sim);
+int rcsh_env_reset(rcsh_sim* sim, const uint8_t* mask, double* obs, uint8_t* info, double* gripper_width);
+int rcsh_env_step(rcsh_sim* sim, const double* action, const float* gripper, double* obs, uint8_t* info,
+                  double* gripper_width, int32_t* substeps);
+/* device-pointer forms used by the rollout loop (nothing crosses PCIe) */
+int rcsh_env_reset_dev(rcsh_sim* sim, const uint8_t* mask_dev, double* obs_dev, uint8_t* info_dev,
+                       double* gripper_width_dev);
+int rcsh_env_step_dev(rcsh_sim* sim, const double* action_dev, const float* gripper_dev, double* obs_dev,
+                      uint8_t* info_dev, double* gripper_width_dev, int32_t* substeps_dev);
+
+/* device allocation helpers so a host language without a HIP binding can keep rollouts resident */
+int rcsh_dev_alloc(rcsh_sim* sim, size_t bytes, void** ptr);
+int rcsh_dev_free(rcsh_sim* sim, void* ptr);
+int rcsh_dev_upload(rcsh_sim* sim, void* dst_dev, const void* src_host, size_t bytes);
+int rcsh_dev_download(rcsh_sim* sim, void* dst_host, const void* src_dev, size_t bytes);
+
+/* kernel timing hooks for bench.py: HIP events on the handle's stream around each fused env-step launch */
+int rcsh_prof_enable(rcsh_sim* sim, int32_t enable);
+int rcsh_prof_read(rcsh_sim* sim, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCS_HIP_H */

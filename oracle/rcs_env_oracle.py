@@ -1,0 +1,164 @@
+"""Single-environment restatement of the reference Gymnasium loop (TEST INFRASTRUCTURE).
+
+Collapses the wrapper stack that ``SimEnvCreator`` builds (reference
+python/rcs/envs/creators.py:79-128) into one class whose ``reset`` / ``step``
+perform the same side effects in the same order:
+
+    RelativeActionSpace   base.py:365-565
+      GripperWrapperSim   envs/sim.py:119-131
+        GripperWrapper    base.py:680-735
+          RobotSimWrapper envs/sim.py:35-76
+            RobotEnv      base.py:191-304
+
+The physics / adapter calls go to the C oracle (oracle/rcs_oracle.py).
+"""
+
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+import rcs_oracle as O
+
+JOINTS, CARTESIAN_TRPY, CARTESIAN_TQUAT = "joints", "xyzrpy", "tquat"
+LAST_STEP, CONFIGURED_ORIGIN = "last_step", "configured_origin"
+
+FR3_Q_HOME = np.array([0.0, -np.pi / 4, 0.0, -3.0 * np.pi / 4, 0.0, np.pi / 2, np.pi / 4])  # Robot.h:29-31
+FR3_LOW = np.array([-2.3093, -1.5133, -2.4937, -2.7478, -2.4800, 0.8521, -2.6895])  # Robot.h:36-40
+FR3_HIGH = np.array([2.3093, 1.5133, 2.4937, -0.4461, 2.4800, 4.2094, 2.6895])
+TRPY_LOW = np.array([-0.855, -0.855, 0.0])  # base.py:31-38
+TRPY_HIGH = np.array([0.855, 0.855, 1.188])
+
+
+class OracleEnv:
+    def __init__(self, cm, control_mode=JOINTS, gripper=True, max_relative_movement=None, relative_to=LAST_STEP,
+                 async_control=False, frequency=30, max_convergence_steps=500, tcp_offset: O.Pose | None = None,
+                 idx="0"):
+        arm = [f"fr3_joint{i}_{idx}" for i in range(1, 8)]  # SimRobot.h:23-30 + add_id
+        self.sim = O.Sim(
+            cm, arm, arm, f"attachment_site_{idx}", f"base_{idx}", FR3_Q_HOME, tcp_offset,
+            gripper_joint=f"finger_joint1_{idx}" if gripper else None,
+            gripper_actuator=f"actuator8_{idx}" if gripper else None,
+        )
+        self.sim.set_config(async_control=async_control, frequency=frequency, max_convergence_steps=max_convergence_steps)
+        self.timestep = cm.timestep
+        self.mode = control_mode
+        self.has_gripper = gripper
+        self.max_mov = max_relative_movement
+        if self.max_mov is not None and control_mode != JOINTS and not isinstance(self.max_mov, tuple):
+            self.max_mov = (float(self.max_mov), np.deg2rad(90))  # base.py:381-385
+        self.relative_to = relative_to
+        self.prev_action = None  # RobotEnv.prev_action, base.py:227 (never cleared, quirk Q2)
+        self._last_gripper_cmd = None
+        self._origin = None
+        self._last_action = None
+
+    # ------------------------------------------------------------------ obs
+    def _get_obs(self):  # base.py:246-253
+        pose = self.sim.get_cartesian_position()
+        return {
+            "tquat": np.concatenate([pose.translation(), pose.rotation_q()]),
+            "joints": self.sim.get_joint_position(),
+            "xyzrpy": pose.xyzrpy(),
+        }
+
+    def _set_origin_to_current(self):  # base.py:455-459
+        self._origin = self.sim.get_joint_position() if self.mode == JOINTS else self.sim.get_cartesian_position()
+
+    def _gripper_obs(self, obs, info):
+        if not self.has_gripper:
+            return obs, info
+        obs = dict(obs)
+        obs["gripper"] = self._last_gripper_cmd if self._last_gripper_cmd is not None else 1  # base.py:710-715
+        s = self.sim.s  # envs/sim.py:125-131
+        if "collision" not in info or not info["collision"]:
+            info["collision"] = bool(s.grp_collision)
+        w = self.sim.gripper_get_normalized_width()
+        info["gripper_width"] = w
+        info["is_grasped"] = 0.01 < w < 0.99
+        return obs, info
+
+    # ---------------------------------------------------------------- reset
+    def reset(self):
+        if self.has_gripper:  # GripperWrapper.reset, base.py:703-708 (before sim.reset, quirk Q1)
+            self.sim.gripper_reset()
+            self._last_gripper_cmd = None
+        self.sim.reset()  # RobotSimWrapper.reset, envs/sim.py:68-76
+        self.sim.robot_reset()  # RobotEnv.reset, base.py:290-304
+        self.sim.step(1)
+        obs, info = self._gripper_obs(self._get_obs(), {})
+        if self.max_mov is not None:  # RelativeActionSpace.reset, base.py:461-466
+            self._set_origin_to_current()
+            self._last_action = None
+        return obs, info
+
+    # ----------------------------------------------------------------- step
+    def _relative_action(self, action):  # RelativeActionSpace.action, base.py:468-565
+        if self.relative_to == LAST_STEP:
+            self._set_origin_to_current()
+        action = copy.deepcopy(action)
+        fresh = self.relative_to == LAST_STEP or self._last_action is None
+        if self.mode == JOINTS:
+            a = np.asarray(action["joints"], dtype=np.float64)
+            if fresh:
+                limited = np.clip(a, -self.max_mov, self.max_mov)
+            else:
+                limited = np.clip(a - self._last_action, -self.max_mov, self.max_mov) + self._last_action
+            self._last_action = limited
+            action["joints"] = np.clip(self._origin + limited, FR3_LOW, FR3_HIGH)
+            return action
+        key = self.mode
+        a = np.asarray(action[key], dtype=np.float64)
+        given = O.Pose(translation=a[:3], rpy_vector=a[3:]) if key == CARTESIAN_TRPY else O.Pose(translation=a[:3], quaternion=a[3:])
+        if fresh:
+            offset = given.limit_translation_length(self.max_mov[0]).limit_rotation_angle(self.max_mov[1])
+        else:
+            diff = given * self._last_action.inverse()
+            offset = diff.limit_translation_length(self.max_mov[0]).limit_rotation_angle(self.max_mov[1]) * self._last_action
+        self._last_action = offset
+        rot = offset * self._origin
+        t = self._origin.translation() + offset.translation()
+        if key == CARTESIAN_TRPY:
+            unclipped = O.Pose(translation=t, rpy_vector=rot.rotation_rpy())
+            action[key] = np.concatenate([np.clip(unclipped.translation(), TRPY_LOW, TRPY_HIGH), unclipped.rotation_rpy()])
+        else:
+            unclipped = O.Pose(translation=t, quaternion=rot.rotation_q())
+            action[key] = np.concatenate([np.clip(unclipped.translation(), TRPY_LOW, TRPY_HIGH), unclipped.rotation_q()])
+        return action
+
+    def step(self, action):
+        if self.max_mov is not None:
+            action = self._relative_action(action)
+        else:
+            action = copy.deepcopy(action)
+        if self.has_gripper:  # GripperWrapper.action, base.py:721-735
+            g = np.clip(np.round(action["gripper"]), 0.0, 1.0)
+            if g == 0:
+                self.sim.gripper_grasp()
+            else:
+                self.sim.gripper_open()
+            self._last_gripper_cmd = g
+            del action["gripper"]
+        # RobotEnv.step, base.py:255-288
+        key = self.mode
+        a = np.asarray(action[key], dtype=np.float64)
+        changed = self.prev_action is None or not np.allclose(a, self.prev_action[key], atol=1e-3, rtol=0)
+        if changed:
+            if key == JOINTS:
+                self.sim.set_joint_position(a)
+            elif key == CARTESIAN_TRPY:
+                self.sim.set_cartesian_position(O.Pose(translation=a[:3], rpy_vector=a[3:]))
+            else:
+                self.sim.set_cartesian_position(O.Pose(translation=a[:3], quaternion=a[3:]))
+        self.prev_action = copy.deepcopy(action)
+        # RobotSimWrapper.step, envs/sim.py:49-66
+        s = self.sim.s
+        if s.async_control:
+            self.sim.step(round(1 / s.frequency / self.timestep))
+        else:
+            self.sim.step_until_convergence()
+        info = {"collision": bool(s.robot_collision), "ik_success": bool(s.ik_success), "is_sim_converged": self.sim.is_converged()}
+        truncated = bool(s.robot_collision) or not bool(s.ik_success)
+        obs, info = self._gripper_obs(self._get_obs(), info)
+        return obs, 0, False, truncated, info

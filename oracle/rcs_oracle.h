@@ -1,0 +1,242 @@
+/*
+ * rcs_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar double-precision CPU restatement of the reference hot path
+ * (rcs.sim.Sim.step / step_until_convergence + SimRobot + SimGripper + Pose +
+ * Pin CLIK).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; nothing under robot-control-stack_amd/ links,
+ * imports or calls it.
+ *
+ * PARITY UNPINNED for the physics: the arithmetic of mj_step1/mj_step2 lives in
+ * third-party MuJoCo 3.2.6 (reference pyproject.toml:23), absent from
+ * /root/reference and from this image.  orc_step1/orc_step2 restate MuJoCo's
+ * published forward-dynamics pipeline (kinematics, comPos, CRBA, RNE, passive,
+ * actuation, soft constraints, implicitfast) for the RCS scenes and are pinned
+ * only by the reference's own tests (tests/test_oracle_pins.py lists them).
+ * The RCS-side semantics (callback scheduler, SimRobot, SimGripper, Pose) are
+ * restated line by line from sources that ARE under /root/reference; each
+ * function cites the file:line it follows.
+ */
+#ifndef RCS_ORACLE_H
+#define RCS_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAXBODY 32
+#define ORC_MAXV 16
+#define ORC_MAXU 16
+#define ORC_MAXEQ 4
+#define ORC_MAXTENDON 4
+#define ORC_MAXWRAP 8
+#define ORC_MAXSITE 8
+#define ORC_MAXEFC (ORC_MAXEQ + 2 * ORC_MAXV)
+#define ORC_MAXARM 8
+
+enum { ORC_JNT_SLIDE = 2, ORC_JNT_HINGE = 3 };
+enum { ORC_TRN_JOINT = 0, ORC_TRN_TENDON = 3 };
+enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1 };
+
+/* ---- model constants (mjModel subset; filled by the Python side from the compiled scene) */
+typedef struct orc_model {
+  int nbody, njnt, nu, ntendon, nwrap, neq, nsite;
+  double timestep;
+  double gravity[3];
+  /* bodies */
+  int body_parentid[ORC_MAXBODY];
+  int body_rootid[ORC_MAXBODY];
+  int body_jntadr[ORC_MAXBODY]; /* -1: welded to parent */
+  double body_pos[ORC_MAXBODY][3];
+  double body_quat[ORC_MAXBODY][4]; /* wxyz */
+  double body_ipos[ORC_MAXBODY][3];
+  double body_iquat[ORC_MAXBODY][4];
+  double body_mass[ORC_MAXBODY];
+  double body_inertia[ORC_MAXBODY][3];
+  double body_gravcomp[ORC_MAXBODY];
+  /* joints == dofs (hinge / slide only) */
+  int jnt_type[ORC_MAXV];
+  int jnt_bodyid[ORC_MAXV];
+  double jnt_pos[ORC_MAXV][3];
+  double jnt_axis[ORC_MAXV][3];
+  int jnt_limited[ORC_MAXV];
+  double jnt_range[ORC_MAXV][2];
+  double jnt_margin[ORC_MAXV];
+  double jnt_solref[ORC_MAXV][2];
+  double jnt_solimp[ORC_MAXV][5];
+  int jnt_actfrclimited[ORC_MAXV];
+  double jnt_actfrcrange[ORC_MAXV][2];
+  int jnt_actgravcomp[ORC_MAXV];
+  double dof_armature[ORC_MAXV];
+  double dof_damping[ORC_MAXV];
+  double qpos0[ORC_MAXV];
+  /* fixed tendons */
+  int tendon_adr[ORC_MAXTENDON];
+  int tendon_num[ORC_MAXTENDON];
+  int wrap_objid[ORC_MAXWRAP];
+  double wrap_prm[ORC_MAXWRAP];
+  /* joint equalities */
+  int eq_obj1id[ORC_MAXEQ];
+  int eq_obj2id[ORC_MAXEQ];
+  int eq_active0[ORC_MAXEQ];
+  double eq_data[ORC_MAXEQ][5];
+  double eq_solref[ORC_MAXEQ][2];
+  double eq_solimp[ORC_MAXEQ][5];
+  /* actuators */
+  int actuator_trntype[ORC_MAXU];
+  int actuator_trnid[ORC_MAXU];
+  double actuator_gear[ORC_MAXU];
+  double actuator_gainprm[ORC_MAXU][3];
+  double actuator_biasprm[ORC_MAXU][3];
+  int actuator_biastype[ORC_MAXU];
+  int actuator_ctrllimited[ORC_MAXU];
+  double actuator_ctrlrange[ORC_MAXU][2];
+  int actuator_forcelimited[ORC_MAXU];
+  double actuator_forcerange[ORC_MAXU][2];
+  /* sites */
+  int site_bodyid[ORC_MAXSITE];
+  double site_pos[ORC_MAXSITE][3];
+  double site_quat[ORC_MAXSITE][4];
+  /* derived by orc_set0 */
+  double dof_invweight0[ORC_MAXV];
+} orc_model;
+
+/* ---- per-environment state + scratch (mjData subset) */
+typedef struct orc_data {
+  double time;
+  double qpos[ORC_MAXV], qvel[ORC_MAXV], ctrl[ORC_MAXU];
+  double qacc[ORC_MAXV], qacc_warmstart[ORC_MAXV];
+  /* position stage */
+  double xpos[ORC_MAXBODY][3], xquat[ORC_MAXBODY][4], xmat[ORC_MAXBODY][9];
+  double xipos[ORC_MAXBODY][3], ximat[ORC_MAXBODY][9];
+  double xanchor[ORC_MAXV][3], xaxis[ORC_MAXV][3];
+  double site_xpos[ORC_MAXSITE][3], site_xmat[ORC_MAXSITE][9];
+  double subtree_com[ORC_MAXBODY][3];
+  double cinert[ORC_MAXBODY][10];
+  double cdof[ORC_MAXV][6];
+  double qM[ORC_MAXV][ORC_MAXV];
+  double ten_length[ORC_MAXTENDON];
+  double actuator_length[ORC_MAXU];
+  /* velocity stage */
+  double cvel[ORC_MAXBODY][6], cdof_dot[ORC_MAXV][6];
+  double actuator_velocity[ORC_MAXU];
+  double qfrc_bias[ORC_MAXV], qfrc_passive[ORC_MAXV], qfrc_gravcomp[ORC_MAXV];
+  /* actuation / acceleration */
+  double actuator_force[ORC_MAXU];
+  double qfrc_actuator[ORC_MAXV], qfrc_smooth[ORC_MAXV], qacc_smooth[ORC_MAXV];
+  /* constraints */
+  int nefc, ncon;
+  int efc_type[ORC_MAXEFC];
+  double efc_J[ORC_MAXEFC][ORC_MAXV];
+  double efc_pos[ORC_MAXEFC], efc_margin[ORC_MAXEFC], efc_vel[ORC_MAXEFC];
+  double efc_D[ORC_MAXEFC], efc_aref[ORC_MAXEFC], efc_force[ORC_MAXEFC];
+  double efc_K[ORC_MAXEFC], efc_B[ORC_MAXEFC], efc_I[ORC_MAXEFC];
+  double qfrc_constraint[ORC_MAXV];
+  int solver_niter;
+} orc_data;
+
+void orc_set0(orc_model* m);
+void orc_reset_data(const orc_model* m, orc_data* d);
+void orc_step1(const orc_model* m, orc_data* d);
+void orc_step2(const orc_model* m, orc_data* d);
+/* position-stage pieces exposed for known-answer tests */
+void orc_kinematics(const orc_model* m, orc_data* d);
+void orc_mass_matrix(const orc_model* m, orc_data* d);
+
+/* ---- Pose (reference: include/rcs/Pose.h, src/rcs/Pose.cpp); quaternion order xyzw */
+typedef struct orc_pose {
+  double t[3];
+  double q[4];
+} orc_pose;
+
+void orc_pose_identity(orc_pose* p);
+void orc_pose_from_matrix4(const double* m16_rowmajor, orc_pose* out);
+void orc_pose_from_rotm_t(const double* r9_rowmajor, const double* t3, orc_pose* out);
+void orc_pose_from_quat_t(const double* q4_xyzw, const double* t3, orc_pose* out);
+void orc_pose_from_rpy_t(const double* rpy3, const double* t3, orc_pose* out);
+void orc_pose_rotation_m(const orc_pose* p, double* r9_rowmajor);
+void orc_pose_matrix(const orc_pose* p, double* m16_rowmajor);
+void orc_pose_rpy(const orc_pose* p, double* rpy3);
+void orc_pose_xyzrpy(const orc_pose* p, double* out6);
+void orc_pose_mul(const orc_pose* a, const orc_pose* b, orc_pose* out);
+void orc_pose_inverse(const orc_pose* a, orc_pose* out);
+double orc_pose_total_angle(const orc_pose* a);
+void orc_pose_limit_rotation_angle(const orc_pose* a, double max_angle, orc_pose* out);
+void orc_pose_limit_translation_length(const orc_pose* a, double max_length, orc_pose* out);
+void orc_pose_interpolate(const orc_pose* a, const orc_pose* dest, double progress, orc_pose* out);
+int orc_pose_is_close(const orc_pose* a, const orc_pose* b, double eps_r, double eps_t);
+void orc_franka_hand_tcp_offset(orc_pose* out);
+
+/* ---- Pin CLIK (reference: src/rcs/Kinematics.cpp:28-82) on the compiled chain */
+typedef struct orc_ik {
+  const orc_model* m;
+  int site; /* frame = this site */
+} orc_ik;
+int orc_ik_inverse(const orc_ik* ik, const orc_pose* pose, const double* q0, int nq0, const orc_pose* tcp_offset,
+                   double* q_out /* m->njnt */, int* iterations);
+void orc_ik_forward(const orc_ik* ik, const double* q0, int nq0, const orc_pose* tcp_offset, orc_pose* out);
+
+/* ---- Sim + SimRobot + SimGripper (reference: src/sim/sim.cpp, SimRobot.cpp, SimGripper.cpp) */
+typedef struct orc_sim {
+  orc_model* m;
+  orc_data d;
+  /* SimConfig (sim.h:29-34) */
+  int async_control, realtime, frequency, max_convergence_steps;
+  long convergence_steps;
+  int converged;
+  /* callback bookkeeping, in registration order of SimEnvCreator (creators.py:88,105):
+     plain: [robot.is_arrived, robot.is_moving]
+     any:   [robot.collision, gripper.collision]
+     all:   [robot.convergence, gripper.convergence] */
+  int has_robot, robot_conv_registered, has_gripper;
+  double cb_last[2];
+  double any_last[2], all_last[2];
+  int any_ret[2], all_ret[2];
+  /* SimRobot (SimRobot.h) */
+  int arm_n;
+  int arm_jnt[ORC_MAXARM], arm_act[ORC_MAXARM];
+  int attachment_site, base_body;
+  double joint_rotational_tolerance, robot_period;
+  orc_pose tcp_offset;
+  double q_home[ORC_MAXARM];
+  double previous_angles[ORC_MAXARM], target_angles[ORC_MAXARM];
+  int ik_success, robot_collision, is_moving, is_arrived;
+  orc_ik ik;
+  int last_ik_iterations;
+  /* SimGripper (SimGripper.h) */
+  int grp_jnt, grp_act;
+  double grp_period, max_actuator_width, min_actuator_width, max_joint_width, min_joint_width;
+  double epsilon_inner, epsilon_outer;
+  double last_commanded_width, last_width;
+  int grp_is_moving, grp_collision;
+} orc_sim;
+
+void orc_sim_init(orc_sim* s, orc_model* m);
+void orc_sim_add_robot(orc_sim* s, int n, const int* jnt_ids, const int* act_ids, int site, int base_body,
+                       const double* q_home, const orc_pose* tcp_offset, int register_convergence_callback);
+void orc_sim_add_gripper(orc_sim* s, int jnt, int act);
+void orc_sim_step(orc_sim* s, long k);
+void orc_sim_step_until_convergence(orc_sim* s);
+void orc_sim_reset(orc_sim* s);
+/* SimRobot */
+void orc_robot_set_joint_position(orc_sim* s, const double* q);
+void orc_robot_get_joint_position(const orc_sim* s, double* q);
+void orc_robot_get_cartesian_position(const orc_sim* s, orc_pose* out);
+void orc_robot_get_base_pose(const orc_sim* s, orc_pose* out);
+void orc_robot_set_cartesian_position(orc_sim* s, const orc_pose* pose);
+void orc_robot_set_joints_hard(orc_sim* s, const double* q);
+void orc_robot_reset(orc_sim* s);
+void orc_robot_move_home(orc_sim* s);
+/* SimGripper */
+int orc_gripper_set_normalized_width(orc_sim* s, double width, double force);
+double orc_gripper_get_normalized_width(const orc_sim* s);
+int orc_gripper_is_grasped(const orc_sim* s);
+void orc_gripper_reset(orc_sim* s);
+
+unsigned long orc_sizeof_model(void);
+unsigned long orc_sizeof_sim(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,498 @@
+// dyn.h -- per-environment rigid-body dynamics of one robot archetype, written for
+// one GPU thread per environment with every per-link quantity in registers.
+//
+// What it computes is what mj_step1 / mj_step2 compute for the RCS scenes
+// (reference call sites src/sim/sim.cpp:110,112): kinematics, mass matrix, bias
+// forces, gravity compensation, affine actuators with force clamps, the
+// soft-constraint solve (finger coupling equality + joint limits) and the
+// implicitfast integrator.  How it computes it is chosen for CDNA4:
+//
+//  * welded bodies are folded into links on the host (model.cpp), so the loops run
+//    over NL = 9 links instead of 14 bodies;
+//  * all spatial quantities are Pluecker vectors about the WORLD ORIGIN.  With one
+//    common reference point the composite-inertia and force recursions are plain
+//    sums -- no frame transforms on the backward pass;
+//  * the archetype (chain length, gripper or not) is a template parameter, so every
+//    loop unrolls and every array index is a compile-time constant: the arrays
+//    live in VGPR/AGPR, model constants arrive through scalar loads;
+//  * the constraint Hessian differs from M only on the diagonal (limit rows are
+//    +-e_i) and in the 2x2 finger block (coupling row), so the Newton solve is a
+//    packed 9x9 LDL^T with a handful of diagonal updates.
+//
+// The same templates are instantiated on the host by model.cpp for one purpose only:
+// dof_invweight0 = diag(M(qpos0)^-1) at model-finalise time (MuJoCo computes the same
+// constant when it compiles a model).  No stepping entry point runs on the CPU.
+#pragma once
+#include <cmath>
+
+#include "model.h"
+
+#if defined(__HIP__)
+#define RCSH_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define RCSH_HD inline
+#endif
+
+namespace rcsh {
+
+template <int NARM_, bool GRIP_>
+struct Topo {
+  static constexpr int NARM = NARM_;
+  static constexpr bool GRIP = GRIP_;
+  static constexpr int NL = NARM_ + (GRIP_ ? 2 : 0);
+  static constexpr int NU = NARM_ + (GRIP_ ? 1 : 0);
+  static constexpr int NTRI = NL * (NL + 1) / 2;
+  RCSH_HD static constexpr int parent(int i) { return i < NARM_ ? i - 1 : NARM_ - 1; }
+};
+
+RCSH_HD constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
+
+constexpr double kMinVal = 1e-15;
+constexpr double kMinImp = 0.0001;
+constexpr double kMaxImp = 0.9999;
+
+RCSH_HD double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+RCSH_HD void cross3(const double* a, const double* b, double* r) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+RCSH_HD double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+RCSH_HD double dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+// r = A(3x3 row-major) * v
+RCSH_HD void mulmv(const double* A, const double* v, double* r) {
+  double x = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
+  double y = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+  double z = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+// C = A * B (3x3 row-major)
+RCSH_HD void mulmm(const double* A, const double* B, double* C) {
+  double t[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) C[k] = t[k];
+}
+// spatial inertia about the world origin (Ixx Iyy Izz Ixy Ixz Iyz, m*c, m) times motion vector [w; v]
+RCSH_HD void inert_mul(const double* I, const double* v, double* r) {
+  r[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2] - I[8] * v[4] + I[7] * v[5];
+  r[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2] + I[8] * v[3] - I[6] * v[5];
+  r[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2] - I[7] * v[3] + I[6] * v[4];
+  r[3] = I[8] * v[1] - I[7] * v[2] + I[9] * v[3];
+  r[4] = I[6] * v[2] - I[8] * v[0] + I[9] * v[4];
+  r[5] = I[7] * v[0] - I[6] * v[1] + I[9] * v[5];
+}
+RCSH_HD void cross_motion(const double* vel, const double* s, double* r) {
+  double a[3], b[3];
+  cross3(vel, s, r);
+  cross3(vel, s + 3, a);
+  cross3(vel + 3, s, b);
+  r[3] = a[0] + b[0]; r[4] = a[1] + b[1]; r[5] = a[2] + b[2];
+}
+RCSH_HD void cross_force(const double* vel, const double* f, double* r) {
+  double a[3], b[3];
+  cross3(vel, f, a);
+  cross3(vel + 3, f + 3, b);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  cross3(vel, f + 3, r + 3);
+}
+
+// ---- results of the position + velocity stage that the rest of the substep consumes
+template <class T>
+struct Smooth {
+  double M[T::NTRI];    // joint-space inertia incl. armature, packed lower triangle
+  double bias[T::NL];   // Coriolis + centrifugal + gravity
+  double gc[T::NL];     // gravity-compensation generalized force
+  double linkR[9];      // world frame of the link carrying the attachment site
+  double linkP[3];
+};
+
+// Position + velocity stage.  Forward sweep root->leaves builds, per link, the world frame, the
+// motion axis S, the spatial inertia I and the bias wrench f; the backward sweep leaves->root sums
+// composite inertias / wrenches and projects them on the axes.
+template <class T>
+RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* qd, Smooth<T>& out) {
+  constexpr int NL = T::NL;
+  double S[NL][6], I[NL][10], f[NL][6], hg[NL][3];
+  // frames of the arm chain tip are reused by both fingers, so one running copy suffices
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+  double vel[6] = {0, 0, 0, 0, 0, 0};
+  double acc[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+  double Rt[9], pt[3], velt[6], acct[6];  // arm tip, kept for the fingers
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    if (T::GRIP && i == T::NARM) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rt[k] = R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pt[k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { velt[k] = vel[k]; acct[k] = acc[k]; }
+    }
+    if (T::GRIP && i > T::NARM) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = Rt[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = pt[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { vel[k] = velt[k]; acc[k] = acct[k]; }
+    }
+    // frame at qpos0
+    double o[3], R0[9];
+    mulmv(R, m.pos0[i], o);
+    o[0] += p[0]; o[1] += p[1]; o[2] += p[2];
+    mulmm(R, m.rot0[i], R0);
+    double ax[3];
+    mulmv(R0, m.axis[i], ax);
+    const double dq = q[i] - m.qpos0[i];
+    double* Si = S[i];
+    if (m.jtype[i] == kSlide) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = R0[k];
+      p[0] = o[0] + ax[0] * dq; p[1] = o[1] + ax[1] * dq; p[2] = o[2] + ax[2] * dq;
+      Si[0] = 0; Si[1] = 0; Si[2] = 0; Si[3] = ax[0]; Si[4] = ax[1]; Si[5] = ax[2];
+    } else {
+      // Rodrigues rotation about the link-frame axis
+      double s, c;
+      sincos(dq, &s, &c);
+      const double* a = m.axis[i];
+      const double t = 1.0 - c;
+      double Q[9] = {c + t * a[0] * a[0],        t * a[0] * a[1] - s * a[2], t * a[0] * a[2] + s * a[1],
+                     t * a[0] * a[1] + s * a[2], c + t * a[1] * a[1],        t * a[1] * a[2] - s * a[0],
+                     t * a[0] * a[2] - s * a[1], t * a[1] * a[2] + s * a[0], c + t * a[2] * a[2]};
+      double anchor[3], rj[3];
+      mulmv(R0, m.jpos[i], anchor);
+      anchor[0] += o[0]; anchor[1] += o[1]; anchor[2] += o[2];
+      mulmm(R0, Q, R);
+      mulmv(R, m.jpos[i], rj);
+      p[0] = anchor[0] - rj[0]; p[1] = anchor[1] - rj[1]; p[2] = anchor[2] - rj[2];
+      Si[0] = ax[0]; Si[1] = ax[1]; Si[2] = ax[2];
+      cross3(anchor, ax, Si + 3);
+    }
+    if (i == m.site_link) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) out.linkR[k] = R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) out.linkP[k] = p[k];
+    }
+    // spatial inertia about the world origin
+    double c[3], cg[3];
+    mulmv(R, m.com[i], c);
+    c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+    mulmv(R, m.gccom[i], cg);
+    hg[i][0] = m.gcm[i] * (cg[0] + p[0]);
+    hg[i][1] = m.gcm[i] * (cg[1] + p[1]);
+    hg[i][2] = m.gcm[i] * (cg[2] + p[2]);
+    {
+      const double* J = m.inertia[i];
+      const double Jm[9] = {J[0], J[3], J[4], J[3], J[1], J[5], J[4], J[5], J[2]};
+      double Tm[9];
+      mulmm(R, Jm, Tm);
+      const double ms = m.mass[i];
+      double* Ii = I[i];
+      Ii[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2] + ms * (c[1] * c[1] + c[2] * c[2]);
+      Ii[1] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5] + ms * (c[0] * c[0] + c[2] * c[2]);
+      Ii[2] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8] + ms * (c[0] * c[0] + c[1] * c[1]);
+      Ii[3] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5] - ms * c[0] * c[1];
+      Ii[4] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8] - ms * c[0] * c[2];
+      Ii[5] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8] - ms * c[1] * c[2];
+      Ii[6] = ms * c[0]; Ii[7] = ms * c[1]; Ii[8] = ms * c[2];
+      Ii[9] = ms;
+    }
+    // velocity, bias acceleration (S x S = 0, so the parent's velocity is enough), bias wrench
+    double sd[6];
+    cross_motion(vel, Si, sd);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      vel[k] += Si[k] * qd[i];
+      acc[k] += sd[k] * qd[i];
+    }
+    double Ia[6], Iv[6], vf[6];
+    inert_mul(I[i], acc, Ia);
+    inert_mul(I[i], vel, Iv);
+    cross_force(vel, Iv, vf);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[i][k] = Ia[k] + vf[k];
+  }
+  // backward sweep
+  const double* g = m.gravity;
+#pragma unroll
+  for (int i = NL - 1; i >= 0; --i) {
+    double F[6];
+    inert_mul(I[i], S[i], F);
+    out.M[tri(i, i)] = dot6(S[i], F) + m.armature[i];
+    // ancestors: for the arm that is every j < i; a finger's ancestors are all arm links
+#pragma unroll
+    for (int j = (i >= T::NARM ? T::NARM - 1 : i - 1); j >= 0; --j) out.M[tri(i, j)] = dot6(S[j], F);
+    if (T::GRIP && i == T::NARM + 1) out.M[tri(i, i - 1)] = 0.0;  // the fingers are siblings
+    out.bias[i] = dot6(S[i], f[i]);
+    // gravity compensation wrench of the subtree: force -g*sum(gcm), moment sum(gcm*c) x (-g)
+    {
+      double w[6];
+      const double msub = m.gcm_sub[i];
+      double ng[3] = {-g[0], -g[1], -g[2]};
+      cross3(hg[i], ng, w);
+      w[3] = msub * ng[0]; w[4] = msub * ng[1]; w[5] = msub * ng[2];
+      out.gc[i] = dot6(S[i], w);
+    }
+    const int pa = T::parent(i);
+    if (pa >= 0) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) I[pa][k] += I[i][k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f[pa][k] += f[i][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hg[pa][k] += hg[i][k];
+    }
+  }
+}
+
+// packed LDL^T of an SPD matrix, in place: strict lower part <- L, diagonal <- 1/D
+template <int N>
+RCSH_HD void ldl_factor(double* A) {
+  double D[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double w[N];
+    double d = A[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      w[k] = A[tri(j, k)] * D[k];
+      d -= A[tri(j, k)] * w[k];
+    }
+    D[j] = d;
+    const double inv = 1.0 / d;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double t = A[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= A[tri(i, k)] * w[k];
+      A[tri(i, j)] = t * inv;
+    }
+    A[tri(j, j)] = inv;
+  }
+}
+template <int N>
+RCSH_HD void ldl_solve(const double* A, double* x) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int k = 0; k < i; ++k) x[i] -= A[tri(i, k)] * x[k];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] *= A[tri(i, i)];
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) x[i] -= A[tri(k, i)] * x[k];
+  }
+}
+
+// solimp -> impedance at distance |pos - margin| (the sigmoid MuJoCo documents for solimp)
+RCSH_HD double impedance(const double* solimp, double pos, double margin) {
+  double d0 = clampd(solimp[0], kMinImp, kMaxImp), d1 = clampd(solimp[1], kMinImp, kMaxImp);
+  double width = solimp[2] < 0 ? 0 : solimp[2];
+  double mid = clampd(solimp[3], kMinImp, kMaxImp);
+  double power = solimp[4] < 1 ? 1 : solimp[4];
+  if (d0 == d1 || width <= kMinVal) return 0.5 * (d0 + d1);
+  double x = fabs((pos - margin) / width);
+  if (x >= 1) return d1;
+  if (x <= 0) return d0;
+  double y;
+  if (power == 1) y = x;
+  else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  return d0 + y * (d1 - d0);
+}
+// solref -> stiffness K and damping B of the reference acceleration
+RCSH_HD void ref_kb(const double* solref, const double* solimp, double timestep, double& K, double& B) {
+  double dmax = clampd(solimp[1], kMinImp, kMaxImp);
+  double tc = solref[0], dr = solref[1];
+  if (tc > 0) {
+    if (tc < 2 * timestep) tc = 2 * timestep;
+    double kd = dmax * dmax * tc * tc * dr * dr, bd = dmax * tc;
+    K = 1.0 / (kd > kMinVal ? kd : kMinVal);
+    B = 2.0 / (bd > kMinVal ? bd : kMinVal);
+  } else {
+    K = -tc / (dmax * dmax);
+    B = -dr / dmax;
+  }
+}
+
+// One physics substep: advances q, qd by one timestep under controls `ctrl`.
+// `sm` carries the frames of the site link computed from the PRE-step q (the reference reads
+// site_xpos/xmat of the last mj_step1).
+template <class T>
+RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctrl, Smooth<T>& sm) {
+  constexpr int NL = T::NL;
+  constexpr int NA = T::NARM;
+  const double h = m.timestep;
+  smooth_dynamics<T>(m, q, qd, sm);
+
+  // ---- actuation: affine actuators, force limits, actuator-side gravity compensation, joint clamp
+  double tau[NL];      // qfrc_actuator
+  double dact[NL];     // -d(qfrc_actuator)/d(qd), diagonal part
+  double smooth[NL];   // qfrc_smooth
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { tau[i] = 0; dact[i] = 0; }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    if (!m.arm_has_act[i]) continue;
+    double c = ctrl[i];
+    if (m.arm_ctrllimited[i]) c = clampd(c, m.arm_ctrlrange[i][0], m.arm_ctrlrange[i][1]);
+    const double gear = m.arm_gear[i];
+    double force = m.arm_gain[i] * c;
+    if (m.arm_biasaffine[i]) force += m.arm_bias[i][0] + m.arm_bias[i][1] * (gear * q[i]) + m.arm_bias[i][2] * (gear * qd[i]);
+    bool clamped = false;
+    if (m.arm_forcelimited[i]) {
+      clamped = force <= m.arm_forcerange[i][0] || force >= m.arm_forcerange[i][1];
+      force = clampd(force, m.arm_forcerange[i][0], m.arm_forcerange[i][1]);
+    }
+    tau[i] = gear * force;
+    if (m.arm_biasaffine[i] && !clamped) dact[i] = -gear * gear * m.arm_bias[i][2];
+  }
+  double gblock = 0.0;  // -bias_vel of the gripper actuator (2x2 block coef_a * coef_b * gblock)
+  if (T::GRIP && m.grp_has_act) {
+    double c = ctrl[NA];
+    if (m.grp_ctrllimited) c = clampd(c, m.grp_ctrlrange[0], m.grp_ctrlrange[1]);
+    const double len = m.grp_coef[0] * q[NA] + m.grp_coef[1] * q[NA + 1];
+    const double vel = m.grp_coef[0] * qd[NA] + m.grp_coef[1] * qd[NA + 1];
+    double force = m.grp_gain * c;
+    if (m.grp_biasaffine) force += m.grp_bias[0] + m.grp_bias[1] * len + m.grp_bias[2] * vel;
+    bool clamped = false;
+    if (m.grp_forcelimited) {
+      clamped = force <= m.grp_forcerange[0] || force >= m.grp_forcerange[1];
+      force = clampd(force, m.grp_forcerange[0], m.grp_forcerange[1]);
+    }
+    tau[NA] += m.grp_coef[0] * force;
+    tau[NA + 1] += m.grp_coef[1] * force;
+    if (m.grp_biasaffine && !clamped) gblock = -m.grp_bias[2];
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    double passive = -m.damping[i] * qd[i];
+    if (m.actgravcomp[i]) tau[i] += sm.gc[i]; else passive += sm.gc[i];
+    if (m.actfrclimited[i]) tau[i] = clampd(tau[i], m.actfrcrange[i][0], m.actfrcrange[i][1]);
+    smooth[i] = passive - sm.bias[i] + tau[i];
+  }
+
+  // ---- constraint rows: finger coupling (equality, always active) and joint limits (one-sided)
+  double eqD = 0, eqAref = 0, eqJ1 = 0;  // row = e_f1 + eqJ1 * e_f2
+  if (T::GRIP && m.eq_active) {
+    const double* pc = m.eq_polycoef;
+    const double dif = q[NA + 1] - m.qpos0[NA + 1];
+    const double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
+    const double deriv = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
+    const double pos = q[NA] - m.qpos0[NA] - poly;
+    eqJ1 = -deriv;
+    double K, B;
+    ref_kb(m.eq_solref, m.eq_solimp, h, K, B);
+    const double imp = impedance(m.eq_solimp, pos, 0.0);
+    double Rr = (1 - imp) / imp * (m.invweight0[NA] + m.invweight0[NA + 1]);
+    if (Rr < kMinVal) Rr = kMinVal;
+    eqD = 1.0 / Rr;
+    eqAref = -K * imp * pos - B * (qd[NA] + eqJ1 * qd[NA + 1]);
+  }
+  double limD[NL], limAref[NL], limSign[NL];  // limSign 0: no row
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    limD[i] = 0; limAref[i] = 0; limSign[i] = 0;
+    if (!m.limited[i]) continue;
+    const double dlo = q[i] - m.range[i][0], dhi = m.range[i][1] - q[i];
+    double dist = 0, sgn = 0;
+    if (dlo < m.margin[i]) { dist = dlo; sgn = 1; }
+    else if (dhi < m.margin[i]) { dist = dhi; sgn = -1; }
+    if (sgn != 0) {
+      double K, B;
+      ref_kb(m.lim_solref[i], m.lim_solimp[i], h, K, B);
+      const double imp = impedance(m.lim_solimp[i], dist, m.margin[i]);
+      double Rr = (1 - imp) / imp * m.invweight0[i];
+      if (Rr < kMinVal) Rr = kMinVal;
+      limD[i] = 1.0 / Rr;
+      limAref[i] = -K * imp * (dist - m.margin[i]) - B * (sgn * qd[i]);
+      limSign[i] = sgn;
+    }
+  }
+
+  // ---- qacc = argmin 1/2 |qacc - M^-1 smooth|_M^2 + sum s_i(J_i qacc - aref_i): active-set Newton.
+  // A Newton step under a guessed active set is exact if the set it lands in equals the guess.
+  double qacc[NL];
+  bool act[NL];
+  bool anylim = false;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { act[i] = limSign[i] != 0; anylim = anylim || act[i]; }
+  double fc[NL];  // qfrc_constraint
+#pragma unroll
+  for (int i = 0; i < NL; ++i) fc[i] = 0;
+  const bool have_rows = (T::GRIP && m.eq_active) || anylim;
+  if (have_rows) {
+    for (int iter = 0; iter < 8; ++iter) {
+      double H[T::NTRI];
+#pragma unroll
+      for (int k = 0; k < T::NTRI; ++k) H[k] = sm.M[k];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        qacc[i] = smooth[i];
+        if (act[i]) { H[tri(i, i)] += limD[i]; qacc[i] += limSign[i] * limD[i] * limAref[i]; }
+      }
+      if (T::GRIP && m.eq_active) {
+        H[tri(NA, NA)] += eqD;
+        H[tri(NA + 1, NA)] += eqD * eqJ1;
+        H[tri(NA + 1, NA + 1)] += eqD * eqJ1 * eqJ1;
+        qacc[NA] += eqD * eqAref;
+        qacc[NA + 1] += eqD * eqAref * eqJ1;
+      }
+      ldl_factor<NL>(H);
+      ldl_solve<NL>(H, qacc);
+      bool same = true;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const bool on = limSign[i] != 0 && (limSign[i] * qacc[i] - limAref[i] < 0);
+        same = same && (on == act[i]);
+        act[i] = on;
+      }
+      if (same) break;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (act[i]) fc[i] = -limSign[i] * limD[i] * (limSign[i] * qacc[i] - limAref[i]);
+    if (T::GRIP && m.eq_active) {
+      const double fe = -eqD * (qacc[NA] + eqJ1 * qacc[NA + 1] - eqAref);
+      fc[NA] += fe;
+      fc[NA + 1] += fe * eqJ1;
+    }
+  }
+
+  // ---- implicitfast: (M - h dF/dqd) qacc = smooth + constraint, then semi-implicit Euler
+  {
+    double A[T::NTRI];
+#pragma unroll
+    for (int k = 0; k < T::NTRI; ++k) A[k] = sm.M[k];
+    double rhs[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      A[tri(i, i)] += h * (m.damping[i] + dact[i]);
+      rhs[i] = smooth[i] + fc[i];
+    }
+    if (T::GRIP) {
+      A[tri(NA, NA)] += h * gblock * m.grp_coef[0] * m.grp_coef[0];
+      A[tri(NA + 1, NA)] += h * gblock * m.grp_coef[0] * m.grp_coef[1];
+      A[tri(NA + 1, NA + 1)] += h * gblock * m.grp_coef[1] * m.grp_coef[1];
+    }
+    ldl_factor<NL>(A);
+    ldl_solve<NL>(A, rhs);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      qd[i] += h * rhs[i];
+      q[i] += h * qd[i];
+    }
+  }
+}
+
+}  // namespace rcsh

@@ -1,0 +1,321 @@
+// model.cpp -- host-side model finalisation: mjModel-like tables -> link tables (model.h).
+//
+// Replaces, for the supported scene family, the part of MuJoCo's model compiler that
+// runs after parsing: body-tree bookkeeping and the qpos0 constants (dof_invweight0).
+// It additionally folds every body without a joint into the nearest moving ancestor,
+// which MuJoCo does not do at run time; the dynamics are identical (a rigid union of
+// rigid bodies) and the device loops shrink from 14 bodies to 9 links.
+#include "model_host.h"
+
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+#include "dyn.h"
+
+namespace rcsh {
+
+namespace {
+
+struct Xf {  // rigid transform child -> parent: x_parent = R x_child + p
+  double R[9];
+  double p[3];
+};
+
+Xf xf_identity() { return Xf{{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}}; }
+
+void quat_to_mat(const double* q, double* m) {  // wxyz, normalised by the scene compiler
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+
+Xf xf_from(const double* pos, const double* quat) {
+  Xf t;
+  quat_to_mat(quat, t.R);
+  std::memcpy(t.p, pos, sizeof(t.p));
+  return t;
+}
+
+Xf xf_mul(const Xf& a, const Xf& b) {  // a o b
+  Xf r;
+  mulmm(a.R, b.R, r.R);
+  mulmv(a.R, b.p, r.p);
+  for (int k = 0; k < 3; ++k) r.p[k] += a.p[k];
+  return r;
+}
+
+void mat_to_quat_wxyz(const double* m, double* q) {
+  const double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    const double s = std::sqrt(t + 1.0) * 2;
+    q[0] = 0.25 * s; q[1] = (m[7] - m[5]) / s; q[2] = (m[2] - m[6]) / s; q[3] = (m[3] - m[1]) / s;
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    const double s = std::sqrt(1.0 + m[0] - m[4] - m[8]) * 2;
+    q[0] = (m[7] - m[5]) / s; q[1] = 0.25 * s; q[2] = (m[1] + m[3]) / s; q[3] = (m[2] + m[6]) / s;
+  } else if (m[4] > m[8]) {
+    const double s = std::sqrt(1.0 + m[4] - m[0] - m[8]) * 2;
+    q[0] = (m[2] - m[6]) / s; q[1] = (m[1] + m[3]) / s; q[2] = 0.25 * s; q[3] = (m[5] + m[7]) / s;
+  } else {
+    const double s = std::sqrt(1.0 + m[8] - m[0] - m[4]) * 2;
+    q[0] = (m[3] - m[1]) / s; q[1] = (m[2] + m[6]) / s; q[2] = (m[5] + m[7]) / s; q[3] = 0.25 * s;
+  }
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; ++k) q[k] /= n;
+}
+
+template <class T>
+void compute_invweight0(DevModel& m) {
+  double q[T::NL], qd[T::NL];
+  for (int i = 0; i < T::NL; ++i) { q[i] = m.qpos0[i]; qd[i] = 0; }
+  Smooth<T> sm;
+  smooth_dynamics<T>(m, q, qd, sm);
+  ldl_factor<T::NL>(sm.M);
+  for (int j = 0; j < T::NL; ++j) {
+    double e[T::NL];
+    for (int i = 0; i < T::NL; ++i) e[i] = i == j ? 1.0 : 0.0;
+    ldl_solve<T::NL>(sm.M, e);
+    m.invweight0[j] = e[j];
+  }
+}
+
+}  // namespace
+
+void HostModel::copy_from(const rcsh_model_desc& d) {
+  nbody = d.nbody; njnt = d.njnt; nu = d.nu; ntendon = d.ntendon; nwrap = d.nwrap; neq = d.neq; nsite = d.nsite;
+  timestep = d.timestep;
+  std::memcpy(gravity, d.gravity, sizeof(gravity));
+  auto cpi = [](std::vector<int32_t>& v, const int32_t* p, size_t n) { v.assign(p, p + n); };
+  auto cpd = [](std::vector<double>& v, const double* p, size_t n) { v.assign(p, p + n); };
+  cpi(body_parentid, d.body_parentid, nbody); cpi(body_jntadr, d.body_jntadr, nbody); cpi(body_jntnum, d.body_jntnum, nbody);
+  cpd(body_pos, d.body_pos, 3 * nbody); cpd(body_quat, d.body_quat, 4 * nbody);
+  cpd(body_ipos, d.body_ipos, 3 * nbody); cpd(body_iquat, d.body_iquat, 4 * nbody);
+  cpd(body_mass, d.body_mass, nbody); cpd(body_inertia, d.body_inertia, 3 * nbody); cpd(body_gravcomp, d.body_gravcomp, nbody);
+  cpi(jnt_type, d.jnt_type, njnt); cpi(jnt_bodyid, d.jnt_bodyid, njnt);
+  cpd(jnt_pos, d.jnt_pos, 3 * njnt); cpd(jnt_axis, d.jnt_axis, 3 * njnt);
+  cpi(jnt_limited, d.jnt_limited, njnt); cpd(jnt_range, d.jnt_range, 2 * njnt); cpd(jnt_margin, d.jnt_margin, njnt);
+  cpd(jnt_solref, d.jnt_solref, 2 * njnt); cpd(jnt_solimp, d.jnt_solimp, 5 * njnt);
+  cpi(jnt_actfrclimited, d.jnt_actfrclimited, njnt); cpd(jnt_actfrcrange, d.jnt_actfrcrange, 2 * njnt);
+  cpi(jnt_actgravcomp, d.jnt_actgravcomp, njnt);
+  cpd(dof_armature, d.dof_armature, njnt); cpd(dof_damping, d.dof_damping, njnt); cpd(dof_frictionloss, d.dof_frictionloss, njnt);
+  cpd(qpos0, d.qpos0, njnt);
+  cpi(tendon_adr, d.tendon_adr, ntendon); cpi(tendon_num, d.tendon_num, ntendon);
+  cpi(wrap_objid, d.wrap_objid, nwrap); cpd(wrap_prm, d.wrap_prm, nwrap);
+  cpi(eq_obj1id, d.eq_obj1id, neq); cpi(eq_obj2id, d.eq_obj2id, neq); cpi(eq_active0, d.eq_active0, neq);
+  cpd(eq_data, d.eq_data, 5 * neq); cpd(eq_solref, d.eq_solref, 2 * neq); cpd(eq_solimp, d.eq_solimp, 5 * neq);
+  cpi(actuator_trntype, d.actuator_trntype, nu); cpi(actuator_trnid, d.actuator_trnid, nu);
+  cpd(actuator_gear, d.actuator_gear, nu); cpd(actuator_gainprm, d.actuator_gainprm, 3 * nu);
+  cpd(actuator_biasprm, d.actuator_biasprm, 3 * nu); cpi(actuator_biastype, d.actuator_biastype, nu);
+  cpi(actuator_ctrllimited, d.actuator_ctrllimited, nu); cpd(actuator_ctrlrange, d.actuator_ctrlrange, 2 * nu);
+  cpi(actuator_forcelimited, d.actuator_forcelimited, nu); cpd(actuator_forcerange, d.actuator_forcerange, 2 * nu);
+  cpi(site_bodyid, d.site_bodyid, nsite); cpd(site_pos, d.site_pos, 3 * nsite); cpd(site_quat, d.site_quat, 4 * nsite);
+}
+
+// Transform of every body frame relative to the link (moving ancestor-or-self) that owns it, or
+// relative to the world for static bodies.
+static void body_owner_frames(const HostModel& h, std::vector<int>& owner, std::vector<Xf>& rel) {
+  owner.assign(h.nbody, -1);
+  rel.assign(h.nbody, xf_identity());
+  for (int b = 1; b < h.nbody; ++b) {
+    if (h.body_jntnum[b] > 0) {
+      owner[b] = h.body_jntadr[b];  // link index == dof index == joint index
+      rel[b] = xf_identity();
+    } else {
+      const int p = h.body_parentid[b];
+      owner[b] = owner[p];
+      rel[b] = xf_mul(rel[p], xf_from(&h.body_pos[3 * b], &h.body_quat[4 * b]));
+    }
+  }
+}
+
+std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& act_slot) {
+  std::memset(&m, 0, sizeof(m));
+  std::ostringstream err;
+  if (h.njnt < 1 || h.njnt > kMaxLinks) return "scene has an unsupported number of joints";
+  for (int b = 0; b < h.nbody; ++b)
+    if (h.body_jntnum[b] > 1) return "bodies with more than one joint are outside the supported archetypes";
+  for (int j = 0; j < h.njnt; ++j) {
+    if (h.jnt_type[j] != kSlide && h.jnt_type[j] != kHinge) return "only hinge and slide joints are supported";
+    if (h.dof_frictionloss[j] != 0) return "joint frictionloss is not supported in this revision";
+    if (h.body_jntadr[h.jnt_bodyid[j]] != j) return "joint/body addressing is inconsistent";
+  }
+  std::vector<int> owner;
+  std::vector<Xf> rel;
+  body_owner_frames(h, owner, rel);
+  const int nl = h.njnt;
+  // link parents
+  std::vector<int> lparent(nl);
+  for (int i = 0; i < nl; ++i) lparent[i] = owner[h.body_parentid[h.jnt_bodyid[i]]];
+  // archetype: serial arm [0, narm), optionally two slide fingers hanging off the last arm link
+  int narm = 0;
+  while (narm < nl && lparent[narm] == narm - 1 && h.jnt_type[narm] == kHinge) ++narm;
+  bool grip = false;
+  if (narm == nl) {
+    grip = false;
+  } else if (nl == narm + 2 && lparent[narm] == narm - 1 && lparent[narm + 1] == narm - 1 &&
+             h.jnt_type[narm] == kSlide && h.jnt_type[narm + 1] == kSlide) {
+    grip = true;
+  } else {
+    return "scene does not match a compiled archetype (serial hinge arm, optional two-finger slide gripper)";
+  }
+  if (narm < 1 || narm > kMaxArm) return "arm length outside the compiled range";
+  m.nl = nl; m.narm = narm; m.has_gripper = grip ? 1 : 0;
+  m.timestep = h.timestep;
+  std::memcpy(m.gravity, h.gravity, sizeof(m.gravity));
+  m.site_link = -1;
+
+  for (int i = 0; i < nl; ++i) {
+    const int b = h.jnt_bodyid[i];
+    const int pb = h.body_parentid[b];
+    const Xf t = xf_mul(rel[pb], xf_from(&h.body_pos[3 * b], &h.body_quat[4 * b]));
+    std::memcpy(m.pos0[i], t.p, sizeof(t.p));
+    std::memcpy(m.rot0[i], t.R, sizeof(t.R));
+    std::memcpy(m.axis[i], &h.jnt_axis[3 * i], 3 * sizeof(double));
+    std::memcpy(m.jpos[i], &h.jnt_pos[3 * i], 3 * sizeof(double));
+    m.jtype[i] = h.jnt_type[i];
+    m.qpos0[i] = h.qpos0[i];
+    m.armature[i] = h.dof_armature[i];
+    m.damping[i] = h.dof_damping[i];
+    m.limited[i] = h.jnt_limited[i];
+    m.range[i][0] = h.jnt_range[2 * i]; m.range[i][1] = h.jnt_range[2 * i + 1];
+    m.margin[i] = h.jnt_margin[i];
+    std::memcpy(m.lim_solref[i], &h.jnt_solref[2 * i], 2 * sizeof(double));
+    std::memcpy(m.lim_solimp[i], &h.jnt_solimp[5 * i], 5 * sizeof(double));
+    m.actfrclimited[i] = h.jnt_actfrclimited[i];
+    m.actfrcrange[i][0] = h.jnt_actfrcrange[2 * i]; m.actfrcrange[i][1] = h.jnt_actfrcrange[2 * i + 1];
+    m.actgravcomp[i] = h.jnt_actgravcomp[i];
+  }
+  // composite inertials
+  for (int i = 0; i < nl; ++i) {
+    double mass = 0, mc[3] = {0, 0, 0}, gcm = 0, gmc[3] = {0, 0, 0};
+    for (int b = 1; b < h.nbody; ++b) {
+      if (owner[b] != i) continue;
+      double c[3];
+      mulmv(rel[b].R, &h.body_ipos[3 * b], c);
+      for (int k = 0; k < 3; ++k) c[k] += rel[b].p[k];
+      const double mb = h.body_mass[b], gb = h.body_gravcomp[b] * mb;
+      mass += mb; gcm += gb;
+      for (int k = 0; k < 3; ++k) { mc[k] += mb * c[k]; gmc[k] += gb * c[k]; }
+    }
+    double com[3] = {0, 0, 0};
+    if (mass > 0) for (int k = 0; k < 3; ++k) com[k] = mc[k] / mass;
+    double J[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 1; b < h.nbody; ++b) {
+      if (owner[b] != i) continue;
+      double Rq[9], Rb[9], tmp[9], Jb[9];
+      quat_to_mat(&h.body_iquat[4 * b], Rq);
+      mulmm(rel[b].R, Rq, Rb);
+      const double* I3 = &h.body_inertia[3 * b];
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) tmp[3 * r + cc] = Rb[3 * r + cc] * I3[cc];
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc)
+          Jb[3 * r + cc] = tmp[3 * r] * Rb[3 * cc] + tmp[3 * r + 1] * Rb[3 * cc + 1] + tmp[3 * r + 2] * Rb[3 * cc + 2];
+      double c[3], dd[3];
+      mulmv(rel[b].R, &h.body_ipos[3 * b], c);
+      for (int k = 0; k < 3; ++k) dd[k] = c[k] + rel[b].p[k] - com[k];
+      const double mb = h.body_mass[b], d2 = dot3(dd, dd);
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) J[3 * r + cc] += Jb[3 * r + cc] + mb * ((r == cc ? d2 : 0.0) - dd[r] * dd[cc]);
+    }
+    m.mass[i] = mass;
+    std::memcpy(m.com[i], com, sizeof(com));
+    m.inertia[i][0] = J[0]; m.inertia[i][1] = J[4]; m.inertia[i][2] = J[8];
+    m.inertia[i][3] = J[1]; m.inertia[i][4] = J[2]; m.inertia[i][5] = J[5];
+    m.gcm[i] = gcm;
+    for (int k = 0; k < 3; ++k) m.gccom[i][k] = gcm != 0 ? gmc[k] / gcm : 0.0;
+  }
+  // subtree gravcomp mass (constant): the link and all of its descendants
+  for (int i = 0; i < nl; ++i) {
+    double s = 0;
+    for (int k = i; k < nl; ++k) {
+      int a = k;
+      while (a >= 0 && a != i) a = lparent[a];
+      if (a == i) s += m.gcm[k];
+    }
+    m.gcm_sub[i] = s;
+  }
+  // actuators
+  act_slot.assign(h.nu, -1);
+  for (int u = 0; u < h.nu; ++u) {
+    const double* gp = &h.actuator_gainprm[3 * u];
+    const double* bp = &h.actuator_biasprm[3 * u];
+    if (h.actuator_trntype[u] == 0) {
+      const int j = h.actuator_trnid[u];
+      if (j < 0 || j >= narm) return "joint-transmission actuators are supported on arm joints only";
+      if (m.arm_has_act[j]) return "more than one actuator on an arm joint";
+      m.arm_has_act[j] = 1;
+      m.arm_gear[j] = h.actuator_gear[u];
+      m.arm_gain[j] = gp[0];
+      std::memcpy(m.arm_bias[j], bp, 3 * sizeof(double));
+      m.arm_biasaffine[j] = h.actuator_biastype[u];
+      m.arm_ctrllimited[j] = h.actuator_ctrllimited[u];
+      m.arm_ctrlrange[j][0] = h.actuator_ctrlrange[2 * u]; m.arm_ctrlrange[j][1] = h.actuator_ctrlrange[2 * u + 1];
+      m.arm_forcelimited[j] = h.actuator_forcelimited[u];
+      m.arm_forcerange[j][0] = h.actuator_forcerange[2 * u]; m.arm_forcerange[j][1] = h.actuator_forcerange[2 * u + 1];
+      act_slot[u] = j;
+    } else if (h.actuator_trntype[u] == 3) {
+      if (!grip || m.grp_has_act) return "tendon actuator without a matching two-finger gripper";
+      const int t = h.actuator_trnid[u];
+      double coef[2] = {0, 0};
+      for (int w = 0; w < h.tendon_num[t]; ++w) {
+        const int k = h.tendon_adr[t] + w;
+        const int j = h.wrap_objid[k];
+        if (j != narm && j != narm + 1) return "gripper tendon must run over the two finger joints";
+        coef[j - narm] += h.wrap_prm[k];
+      }
+      m.grp_has_act = 1;
+      m.grp_coef[0] = h.actuator_gear[u] * coef[0];
+      m.grp_coef[1] = h.actuator_gear[u] * coef[1];
+      m.grp_gain = gp[0];
+      std::memcpy(m.grp_bias, bp, 3 * sizeof(double));
+      m.grp_biasaffine = h.actuator_biastype[u];
+      m.grp_ctrllimited = h.actuator_ctrllimited[u];
+      m.grp_ctrlrange[0] = h.actuator_ctrlrange[2 * u]; m.grp_ctrlrange[1] = h.actuator_ctrlrange[2 * u + 1];
+      m.grp_forcelimited = h.actuator_forcelimited[u];
+      m.grp_forcerange[0] = h.actuator_forcerange[2 * u]; m.grp_forcerange[1] = h.actuator_forcerange[2 * u + 1];
+      act_slot[u] = narm;
+    } else {
+      return "unsupported actuator transmission";
+    }
+  }
+  // equality: finger coupling only
+  for (int e = 0; e < h.neq; ++e) {
+    if (!grip || h.eq_obj1id[e] != narm || h.eq_obj2id[e] != narm + 1 || m.eq_active)
+      return "only one joint equality coupling finger 1 to finger 2 is supported";
+    m.eq_active = h.eq_active0[e];
+    std::memcpy(m.eq_polycoef, &h.eq_data[5 * e], 5 * sizeof(double));
+    std::memcpy(m.eq_solref, &h.eq_solref[2 * e], 2 * sizeof(double));
+    std::memcpy(m.eq_solimp, &h.eq_solimp[5 * e], 5 * sizeof(double));
+  }
+  // qpos0 constants
+  bool ok = dispatch_topology(narm, grip, [&](auto topo) {
+    using T = decltype(topo);
+    compute_invweight0<T>(m);
+  });
+  if (!ok) return "arm length / gripper combination is not instantiated";
+  return "";
+}
+
+std::string attach_robot_frames(const HostModel& h, DevModel& m, int site, int base_body) {
+  std::vector<int> owner;
+  std::vector<Xf> rel;
+  body_owner_frames(h, owner, rel);
+  if (site < 0 || site >= h.nsite) return "attachment site id out of range";
+  if (base_body < 0 || base_body >= h.nbody) return "base body id out of range";
+  const int sb = h.site_bodyid[site];
+  if (owner[sb] < 0) return "attachment site must ride on a moving link";
+  const Xf ts = xf_mul(rel[sb], xf_from(&h.site_pos[3 * site], &h.site_quat[4 * site]));
+  m.site_link = owner[sb];
+  std::memcpy(m.site_pos, ts.p, sizeof(ts.p));
+  std::memcpy(m.site_rot, ts.R, sizeof(ts.R));
+  if (owner[base_body] >= 0) return "robot base body must be static";
+  std::memcpy(m.base_pos, rel[base_body].p, sizeof(m.base_pos));
+  // MuJoCo keeps xquat as the product of body quaternions; for a static body that is the quaternion
+  // of the accumulated rotation (sign chosen by the conversion below, w >= 0 for the RCS scenes)
+  mat_to_quat_wxyz(rel[base_body].R, m.base_quat);
+  return "";
+}
+
+}  // namespace rcsh

@@ -1,0 +1,89 @@
+// model.h -- device-side model tables for the batched simulation backend.
+//
+// The scene arrives across the C-ABI as flat mjModel-like tables
+// (include/rcs_hip.h: rcsh_model_desc).  finalize_model() folds welded bodies
+// into "links" (one 1-dof joint each), checks that the scene matches one of the
+// compiled robot archetypes (serial arm of NARM hinges, optionally a two-finger
+// parallel gripper on the last link) and produces the constant tables the
+// kernels read with wave-uniform (scalar) loads.
+#pragma once
+#include <cstdint>
+
+namespace rcsh {
+
+constexpr int kMaxLinks = 12;
+constexpr int kMaxArm = 8;
+
+enum JointKind : int32_t { kSlide = 2, kHinge = 3 };
+
+// All members are wave-uniform in the kernels.  Fixed maximum sizes keep the struct a POD that is
+// copied to HBM once per GPU (a few KB); kernels template on the real sizes.
+struct DevModel {
+  int32_t nl;    // links == dofs
+  int32_t narm;  // arm dofs; a gripper (if any) occupies dofs narm, narm+1
+  int32_t has_gripper;
+  int32_t pad0;
+  double timestep;
+  double gravity[3];
+  // ---- link tree (link i's parent is i-1 for the arm; both fingers hang off link narm-1)
+  double pos0[kMaxLinks][3];   // origin of link frame in parent link frame at q = qpos0
+  double rot0[kMaxLinks][9];   // parent-link <- link rotation at q = qpos0 (row-major)
+  double axis[kMaxLinks][3];   // joint axis, link frame
+  double jpos[kMaxLinks][3];   // joint anchor, link frame
+  int32_t jtype[kMaxLinks];
+  double qpos0[kMaxLinks];
+  // composite inertial of the link with everything welded to it, link frame
+  double mass[kMaxLinks];
+  double com[kMaxLinks][3];
+  double inertia[kMaxLinks][6];  // about com: xx yy zz xy xz yz
+  double gcm[kMaxLinks];         // sum of gravcomp * mass over the welded bodies
+  double gccom[kMaxLinks][3];    // gcm-weighted centre (link frame)
+  double gcm_sub[kMaxLinks];     // gcm summed over the link and its descendants
+  double armature[kMaxLinks];
+  double damping[kMaxLinks];
+  // joint limits (soft constraint rows)
+  int32_t limited[kMaxLinks];
+  double range[kMaxLinks][2];
+  double margin[kMaxLinks];
+  double lim_solref[kMaxLinks][2];
+  double lim_solimp[kMaxLinks][5];
+  double invweight0[kMaxLinks];
+  // joint-level actuator force clamp and gravity compensation routing
+  int32_t actfrclimited[kMaxLinks];
+  double actfrcrange[kMaxLinks][2];
+  int32_t actgravcomp[kMaxLinks];
+  // ---- arm actuators: one affine actuator per arm dof (ctrl slot i), joint transmission
+  int32_t arm_has_act[kMaxArm];
+  double arm_gear[kMaxArm];
+  double arm_gain[kMaxArm];
+  double arm_bias[kMaxArm][3];
+  int32_t arm_biasaffine[kMaxArm];
+  int32_t arm_ctrllimited[kMaxArm];
+  double arm_ctrlrange[kMaxArm][2];
+  int32_t arm_forcelimited[kMaxArm];
+  double arm_forcerange[kMaxArm][2];
+  // ---- gripper: tendon actuator (ctrl slot narm) over the two finger dofs + coupling equality
+  int32_t grp_has_act;
+  int32_t grp_biasaffine;
+  int32_t grp_ctrllimited;
+  int32_t grp_forcelimited;
+  double grp_coef[2];  // moment of the actuator on finger dofs (gear * tendon coefficients)
+  double grp_gain;
+  double grp_bias[3];
+  double grp_ctrlrange[2];
+  double grp_forcerange[2];
+  int32_t eq_active;
+  int32_t pad1;
+  double eq_polycoef[5];
+  double eq_solref[2];
+  double eq_solimp[5];
+  // ---- frames read by SimRobot
+  int32_t site_link;  // link carrying the attachment site (-1: static)
+  int32_t pad2;
+  double site_pos[3];
+  double site_rot[9];
+  double base_pos[3];   // world pose of the robot base body (static)
+  double base_quat[4];  // wxyz
+};
+
+}  // namespace rcsh

@@ -1,0 +1,46 @@
+// model_host.h -- host-side copy of the scene tables and the finalisation entry points.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/rcs_hip.h"
+#include "dyn.h"
+#include "model.h"
+
+namespace rcsh {
+
+// Deep copy of rcsh_model_desc (the caller's arrays need not outlive rcsh_sim_create).
+struct HostModel {
+  int nbody = 0, njnt = 0, nu = 0, ntendon = 0, nwrap = 0, neq = 0, nsite = 0;
+  double timestep = 0.002;
+  double gravity[3] = {0, 0, -9.81};
+  std::vector<int32_t> body_parentid, body_jntadr, body_jntnum;
+  std::vector<double> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_gravcomp;
+  std::vector<int32_t> jnt_type, jnt_bodyid, jnt_limited, jnt_actfrclimited, jnt_actgravcomp;
+  std::vector<double> jnt_pos, jnt_axis, jnt_range, jnt_margin, jnt_solref, jnt_solimp, jnt_actfrcrange;
+  std::vector<double> dof_armature, dof_damping, dof_frictionloss, qpos0;
+  std::vector<int32_t> tendon_adr, tendon_num, wrap_objid;
+  std::vector<double> wrap_prm;
+  std::vector<int32_t> eq_obj1id, eq_obj2id, eq_active0;
+  std::vector<double> eq_data, eq_solref, eq_solimp;
+  std::vector<int32_t> actuator_trntype, actuator_trnid, actuator_biastype, actuator_ctrllimited, actuator_forcelimited;
+  std::vector<double> actuator_gear, actuator_gainprm, actuator_biasprm, actuator_ctrlrange, actuator_forcerange;
+  std::vector<int32_t> site_bodyid;
+  std::vector<double> site_pos, site_quat;
+  void copy_from(const rcsh_model_desc& d);
+};
+
+// Calls fn(Topo<NARM, GRIP>{}) for the compiled archetype matching (narm, grip); false if none does.
+template <class F>
+bool dispatch_topology(int narm, bool grip, F&& fn) {
+  if (narm == 7 && grip) { fn(Topo<7, true>{}); return true; }
+  if (narm == 7 && !grip) { fn(Topo<7, false>{}); return true; }
+  if (narm == 6 && !grip) { fn(Topo<6, false>{}); return true; }
+  return false;
+}
+
+// Returns "" on success, else the reason the scene is rejected.  act_slot[u] = ctrl slot of mj actuator u.
+std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& act_slot);
+std::string attach_robot_frames(const HostModel& h, DevModel& m, int site, int base_body);
+
+}  // namespace rcsh

@@ -1,0 +1,709 @@
+// rcs_hip.hip -- C-ABI (include/rcs_hip.h) over the batched kernels.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rcs_hip.h"
+#include "model_host.h"
+#include "sim_kernels.h"
+
+using namespace rcsh;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(RCSH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+  } while (0)
+
+constexpr int kBlock = 64;  // one wave per workgroup: each environment-wave gets a CU to itself
+constexpr int kProfRing = 4096;
+
+}  // namespace
+
+struct rcsh_sim {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n = 0;
+  HostModel hm;
+  DevModel dm;
+  DevModel* d_model = nullptr;
+  std::vector<int> act_slot;
+  int narm = 0, nl = 0, nu = 0;
+  bool grip = false;
+  int nfields = 0;
+  double* S = nullptr;
+  uint32_t* flags = nullptr;
+  int32_t* conv = nullptr;
+  SimCfg sim{0, 0, 30, 500};
+  RobotCfg robot{};
+  GripperCfg gripcfg{};
+  EnvCfg env{};
+  bool env_configured = false;
+  // staging for the host-pointer entry points
+  double* d_stage = nullptr;   // n * 32 doubles
+  double* d_stage2 = nullptr;  // n * 32 doubles
+  uint8_t* d_bytes = nullptr;  // n * 16 bytes
+  uint8_t* d_mask = nullptr;   // n bytes
+  int32_t* d_ints = nullptr;   // n ints
+  float* d_floats = nullptr;   // n floats
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev_start, ev_stop;
+  int prof_pending = 0;
+  double prof_ms = 0;
+  int64_t prof_launches = 0;
+};
+
+namespace {
+
+int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+Params make_params(rcsh_sim* s) {
+  Params P;
+  P.model = s->d_model;
+  P.S = s->S;
+  P.flags = s->flags;
+  P.conv_steps = s->conv;
+  P.n = s->n;
+  P.sim = s->sim;
+  P.robot = s->robot;
+  P.grip = s->gripcfg;
+  P.env = s->env;
+  return P;
+}
+
+int upload_model(rcsh_sim* s) {
+  HIP_TRY(hipMemcpyAsync(s->d_model, &s->dm, sizeof(DevModel), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int prof_flush(rcsh_sim* s) {
+  for (int i = 0; i < s->prof_pending; ++i) {
+    float ms = 0;
+    HIP_TRY(hipEventSynchronize(s->ev_stop[i]));
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_start[i], s->ev_stop[i]));
+    s->prof_ms += ms;
+  }
+  s->prof_launches += s->prof_pending;
+  s->prof_pending = 0;
+  return RCSH_OK;
+}
+
+int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
+  Params P = make_params(s);
+  hipError_t err = hipSuccess;
+  if (timed && s->prof) {
+    if (s->prof_pending == kProfRing) {
+      int rc = prof_flush(s);
+      if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(s->ev_start[s->prof_pending], s->stream));
+  }
+  bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
+    using T = decltype(topo);
+    hipLaunchKernelGGL(k_run<T>, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, P, op);
+    err = hipGetLastError();
+  });
+  if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
+  if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_run launch: ") + hipGetErrorString(err));
+  if (timed && s->prof) {
+    HIP_TRY(hipEventRecord(s->ev_stop[s->prof_pending], s->stream));
+    s->prof_pending++;
+  }
+  return RCSH_OK;
+}
+
+template <class F>
+auto with_layout(rcsh_sim* s, F&& fn) {
+  int out = -1;
+  dispatch_topology(s->narm, s->grip, [&](auto topo) { out = fn(topo); });
+  return out;
+}
+
+int field_of(rcsh_sim* s, const char* name) {
+  return with_layout(s, [&](auto topo) {
+    using L = Lay<decltype(topo)>;
+    std::string f(name);
+    if (f == "qpos") return (int)L::QPOS;
+    if (f == "qvel") return (int)L::QVEL;
+    if (f == "ctrl") return (int)L::CTRL;
+    if (f == "time") return (int)L::TIME;
+    if (f == "cb") return (int)L::CB;
+    if (f == "prevq") return (int)L::PREVQ;
+    if (f == "target") return (int)L::TARGET;
+    if (f == "grip") return (int)L::GRIP;
+    if (f == "site") return (int)L::SITE;
+    if (f == "preva") return (int)L::PREVA;
+    if (f == "origin") return (int)L::ORIGIN;
+    if (f == "lasta") return (int)L::LASTA;
+    return -1;
+  });
+}
+
+int upload_mask(rcsh_sim* s, const uint8_t* mask, const uint8_t** dev) {
+  *dev = nullptr;
+  if (!mask) return RCSH_OK;
+  HIP_TRY(hipMemcpyAsync(s->d_mask, mask, s->n, hipMemcpyHostToDevice, s->stream));
+  *dev = s->d_mask;
+  return RCSH_OK;
+}
+
+// host [n][width] -> state fields
+int scatter_host(rcsh_sim* s, int field0, int width, const double* src, const uint8_t* mask) {
+  const uint8_t* dm = nullptr;
+  int rc = upload_mask(s, mask, &dm);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_stage, src, sizeof(double) * s->n * width, hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_scatter, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, s->S, s->n, field0, width, s->d_stage, dm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int gather_host(rcsh_sim* s, int field0, int width, double* dst) {
+  hipLaunchKernelGGL(k_gather, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, (const double*)s->S, s->n, field0, width, s->d_stage);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dst, s->d_stage, sizeof(double) * s->n * width, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int flag_host(rcsh_sim* s, uint32_t bit, uint8_t* dst) {
+  if (!dst) return RCSH_OK;
+  hipLaunchKernelGGL(k_flags_to_bytes, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, (const uint32_t*)s->flags, s->n, bit, s->d_bytes);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dst, s->d_bytes, s->n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+// flags |= set, &= ~clear for masked environments (host-side read-modify-write; construction-time only)
+int flags_update_host(rcsh_sim* s, uint32_t set, uint32_t clear, const uint8_t* mask) {
+  std::vector<uint32_t> f(s->n);
+  HIP_TRY(hipMemcpy(f.data(), s->flags, sizeof(uint32_t) * s->n, hipMemcpyDeviceToHost));
+  for (int e = 0; e < s->n; ++e)
+    if (!mask || mask[e]) f[e] = (f[e] | set) & ~clear;
+  HIP_TRY(hipMemcpy(s->flags, f.data(), sizeof(uint32_t) * s->n, hipMemcpyHostToDevice));
+  return RCSH_OK;
+}
+
+std::vector<double> tile(const double* row, int width, int n) {
+  std::vector<double> v((size_t)n * width);
+  for (int e = 0; e < n; ++e) std::memcpy(&v[(size_t)e * width], row, sizeof(double) * width);
+  return v;
+}
+
+#define REQUIRE_SIM(s) \
+  if (!(s)) return fail(RCSH_ERR_ARG, "null sim handle")
+#define REQUIRE_ROBOT(s) \
+  if (!(s)->robot.present) return fail(RCSH_ERR_STATE, "no robot attached: call rcsh_sim_add_robot first")
+#define REQUIRE_GRIPPER(s) \
+  if (!(s)->gripcfg.present) return fail(RCSH_ERR_STATE, "no gripper attached: call rcsh_sim_add_gripper first")
+
+}  // namespace
+
+extern "C" {
+
+const char* rcsh_last_error(void) { return g_err.c_str(); }
+int rcsh_abi_version(void) { return RCSH_ABI_VERSION; }
+int rcsh_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device, rcsh_sim** out) {
+  if (!model || !out || n_envs < 1) return fail(RCSH_ERR_ARG, "rcsh_sim_create: bad arguments");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(RCSH_ERR_DEVICE, "no HIP device available: the batched backend has no CPU path");
+  if (device < 0 || device >= count) return fail(RCSH_ERR_DEVICE, "device index out of range");
+  rcsh_sim* s = new rcsh_sim();
+  s->hm.copy_from(*model);
+  std::string why = finalize_model(s->hm, s->dm, s->act_slot);
+  if (!why.empty()) {
+    delete s;
+    return fail(RCSH_ERR_MODEL, why);
+  }
+  s->device = device;
+  s->n = n_envs;
+  s->narm = s->dm.narm; s->nl = s->dm.nl; s->grip = s->dm.has_gripper != 0;
+  s->nu = s->narm + (s->grip ? 1 : 0);
+  s->nfields = with_layout(s, [&](auto topo) { return (int)Lay<decltype(topo)>::COUNT; });
+  auto cleanup = [&](int code, const std::string& msg) {
+    rcsh_sim_destroy(s);
+    return fail(code, msg);
+  };
+#define HIP_NEW(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) return cleanup(RCSH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+  HIP_NEW(hipSetDevice(device));
+  HIP_NEW(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  const size_t n = (size_t)n_envs;
+  HIP_NEW(hipMalloc(&s->d_model, sizeof(DevModel)));
+  HIP_NEW(hipMalloc(&s->S, sizeof(double) * n * s->nfields));
+  HIP_NEW(hipMalloc(&s->flags, sizeof(uint32_t) * n));
+  HIP_NEW(hipMalloc(&s->conv, sizeof(int32_t) * n));
+  HIP_NEW(hipMalloc(&s->d_stage, sizeof(double) * n * 32));
+  HIP_NEW(hipMalloc(&s->d_stage2, sizeof(double) * n * 32));
+  HIP_NEW(hipMalloc(&s->d_bytes, n * 16));
+  HIP_NEW(hipMalloc(&s->d_mask, n));
+  HIP_NEW(hipMalloc(&s->d_ints, sizeof(int32_t) * n));
+  HIP_NEW(hipMalloc(&s->d_floats, sizeof(float) * n));
+  HIP_NEW(hipMemsetAsync(s->S, 0, sizeof(double) * n * s->nfields, s->stream));
+  HIP_NEW(hipMemsetAsync(s->conv, 0, sizeof(int32_t) * n, s->stream));
+  // Sim::converged starts true (reference src/sim/sim.h:70); SimRobotState.ik_success starts true
+  {
+    std::vector<uint32_t> f(n, kConverged | kIkSuccess);
+    HIP_NEW(hipMemcpyAsync(s->flags, f.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s->stream));
+    HIP_NEW(hipStreamSynchronize(s->stream));
+  }
+  // mjData starts at qpos0
+  {
+    std::vector<double> q0 = tile(s->dm.qpos0, s->nl, n_envs);
+    int rc = scatter_host(s, field_of(s, "qpos"), s->nl, q0.data(), nullptr);
+    if (rc) return cleanup(rc, g_err);
+  }
+  if (upload_model(s)) return cleanup(RCSH_ERR_DEVICE, g_err);
+#undef HIP_NEW
+  *out = s;
+  return RCSH_OK;
+}
+
+void rcsh_sim_destroy(rcsh_sim* s) {
+  if (!s) return;
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  for (auto e : s->ev_start) hipEventDestroy(e);
+  for (auto e : s->ev_stop) hipEventDestroy(e);
+  hipFree(s->d_model); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
+  hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int rcsh_sim_num_envs(const rcsh_sim* s) { return s ? s->n : 0; }
+int rcsh_sim_nq(const rcsh_sim* s) { return s ? s->nl : 0; }
+int rcsh_sim_nu(const rcsh_sim* s) { return s ? (int)s->act_slot.size() : 0; }
+void* rcsh_sim_stream(rcsh_sim* s) { return s ? (void*)s->stream : nullptr; }
+
+int rcsh_sim_synchronize(rcsh_sim* s) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_sim_set_config(rcsh_sim* s, int32_t async_control, int32_t realtime, int32_t frequency, int32_t max_convergence_steps) {
+  REQUIRE_SIM(s);
+  s->sim = SimCfg{async_control, realtime, frequency, max_convergence_steps};
+  return RCSH_OK;
+}
+int rcsh_sim_get_config(const rcsh_sim* s, int32_t* a, int32_t* r, int32_t* f, int32_t* m) {
+  REQUIRE_SIM(s);
+  if (a) *a = s->sim.async_control;
+  if (r) *r = s->sim.realtime;
+  if (f) *f = s->sim.frequency;
+  if (m) *m = s->sim.max_convergence_steps;
+  return RCSH_OK;
+}
+
+int rcsh_sim_step(rcsh_sim* s, int64_t k) {
+  REQUIRE_SIM(s);
+  if (k < 0) return fail(RCSH_ERR_ARG, "step count must be non-negative");
+  HIP_TRY(hipSetDevice(s->device));
+  RunOp op{};
+  op.nsteps = (int32_t)k;
+  int rc = launch_run(s, op, false);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_sim_step_until_convergence(rcsh_sim* s) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipSetDevice(s->device));
+  RunOp op{};
+  op.nsteps = -1;
+  int rc = launch_run(s, op, false);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_sim_is_converged(rcsh_sim* s, uint8_t* converged, int32_t* steps) {
+  REQUIRE_SIM(s);
+  int rc = flag_host(s, kConverged, converged);
+  if (rc) return rc;
+  if (steps) HIP_TRY(hipMemcpy(steps, s->conv, sizeof(int32_t) * s->n, hipMemcpyDeviceToHost));
+  return RCSH_OK;
+}
+
+int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
+  REQUIRE_SIM(s);
+  // mj_resetData: qpos := qpos0, qvel := 0, ctrl := 0, time := 0; reset_callbacks: timestamps := 0
+  std::vector<double> z((size_t)s->n * 32, 0.0);
+  std::vector<double> q0 = tile(s->dm.qpos0, s->nl, s->n);
+  int rc = scatter_host(s, field_of(s, "qpos"), s->nl, q0.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "qvel"), s->nl, z.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "ctrl"), s->nu, z.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "time"), 1, z.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "cb"), 6, z.data(), mask);
+  return rc;
+}
+
+int rcsh_sim_add_robot(rcsh_sim* s, const rcsh_robot_desc* r) {
+  REQUIRE_SIM(s);
+  if (!r) return fail(RCSH_ERR_ARG, "null robot description");
+  if (s->robot.present) return fail(RCSH_ERR_STATE, "a robot is already attached to this sim");
+  if (r->dof != s->narm) return fail(RCSH_ERR_MODEL, "robot dof does not match the arm chain of the scene");
+  for (int i = 0; i < r->dof; ++i) {
+    if (r->joint_ids[i] != i) return fail(RCSH_ERR_MODEL, "robot joints must be the arm chain in order");
+    const int u = r->actuator_ids[i];
+    if (u < 0 || u >= (int)s->act_slot.size() || s->act_slot[u] != i)
+      return fail(RCSH_ERR_MODEL, "robot actuators must drive the arm joints one to one");
+  }
+  std::string why = attach_robot_frames(s->hm, s->dm, r->attachment_site, r->base_body);
+  if (!why.empty()) return fail(RCSH_ERR_MODEL, why);
+  int rc = upload_model(s);
+  if (rc) return rc;
+  s->robot.present = 1;
+  s->robot.conv_registered = r->register_convergence_callback;
+  s->robot.tolerance = r->joint_rotational_tolerance;
+  s->robot.period = r->seconds_between_callbacks;
+  std::memcpy(s->robot.tcp, r->tcp_offset, sizeof(s->robot.tcp));
+  for (int i = 0; i < r->dof; ++i) s->robot.q_home[i] = r->q_home[i];
+  return rcsh_robot_reset(s, nullptr);  // SimRobot ctor ends with m_reset()
+}
+
+int rcsh_robot_set_joints_hard(rcsh_sim* s, const double* q, const uint8_t* mask) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  int rc = scatter_host(s, field_of(s, "qpos"), s->narm, q, mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "ctrl"), s->narm, q, mask);
+  return rc;
+}
+
+int rcsh_robot_reset(rcsh_sim* s, const uint8_t* mask) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  std::vector<double> q = tile(s->robot.q_home, s->narm, s->n);
+  return rcsh_robot_set_joints_hard(s, q.data(), mask);
+}
+
+int rcsh_robot_set_joint_position(rcsh_sim* s, const double* q, const uint8_t* mask) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  // target := q, previous := current q, ctrl := q, is_moving := true, is_arrived := false
+  std::vector<double> cur((size_t)s->n * s->narm);
+  int rc = gather_host(s, field_of(s, "qpos"), s->narm, cur.data());
+  if (!rc) rc = scatter_host(s, field_of(s, "target"), s->narm, q, mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "prevq"), s->narm, cur.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "ctrl"), s->narm, q, mask);
+  if (!rc) rc = flags_update_host(s, kIsMoving, kIsArrived, mask);
+  return rc;
+}
+
+int rcsh_robot_move_home(rcsh_sim* s, const uint8_t* mask) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  std::vector<double> q = tile(s->robot.q_home, s->narm, s->n);
+  return rcsh_robot_set_joint_position(s, q.data(), mask);
+}
+
+int rcsh_robot_get_joint_position(rcsh_sim* s, double* q) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  return gather_host(s, field_of(s, "qpos"), s->narm, q);
+}
+
+int rcsh_robot_get_cartesian_position(rcsh_sim* s, double* pose) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  HIP_TRY(hipSetDevice(s->device));
+  RunOp op{};
+  op.nsteps = 0;
+  op.write_obs = 1;
+  op.obs = s->d_stage2;
+  int rc = launch_run(s, op, false);
+  if (rc) return rc;
+  const int ow = 14 + s->narm;
+  std::vector<double> obs((size_t)s->n * ow);
+  HIP_TRY(hipMemcpyAsync(obs.data(), s->d_stage2, sizeof(double) * obs.size(), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  for (int e = 0; e < s->n; ++e) std::memcpy(pose + 7 * e, &obs[(size_t)e * ow], 7 * sizeof(double));
+  return RCSH_OK;
+}
+
+int rcsh_robot_get_base_pose(rcsh_sim* s, double* pose) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  for (int e = 0; e < s->n; ++e) {
+    double* p = pose + 7 * e;
+    p[0] = s->dm.base_pos[0]; p[1] = s->dm.base_pos[1]; p[2] = s->dm.base_pos[2];
+    p[3] = s->dm.base_quat[1]; p[4] = s->dm.base_quat[2]; p[5] = s->dm.base_quat[3]; p[6] = s->dm.base_quat[0];
+  }
+  return RCSH_OK;
+}
+
+int rcsh_robot_set_cartesian_position(rcsh_sim*, const double*, const uint8_t*) {
+  return fail(RCSH_ERR_STATE, "rcsh_robot_set_cartesian_position: IK kernel not built in this revision");
+}
+int rcsh_ik_inverse(rcsh_sim*, const double*, const double*, const double*, double*, uint8_t*, int32_t*) {
+  return fail(RCSH_ERR_STATE, "rcsh_ik_inverse: IK kernel not built in this revision");
+}
+int rcsh_ik_forward(rcsh_sim*, const double*, const double*, double*) {
+  return fail(RCSH_ERR_STATE, "rcsh_ik_forward: IK kernel not built in this revision");
+}
+
+int rcsh_robot_get_state(rcsh_sim* s, uint8_t* ik_success, uint8_t* collision, uint8_t* is_moving, uint8_t* is_arrived,
+                         double* previous_angles, double* target_angles) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  int rc = flag_host(s, kIkSuccess, ik_success);
+  if (!rc) rc = flag_host(s, kRobotCollision, collision);
+  if (!rc) rc = flag_host(s, kIsMoving, is_moving);
+  if (!rc) rc = flag_host(s, kIsArrived, is_arrived);
+  if (!rc && previous_angles) rc = gather_host(s, field_of(s, "prevq"), s->narm, previous_angles);
+  if (!rc && target_angles) rc = gather_host(s, field_of(s, "target"), s->narm, target_angles);
+  return rc;
+}
+
+int rcsh_sim_add_gripper(rcsh_sim* s, const rcsh_gripper_desc* g) {
+  REQUIRE_SIM(s);
+  if (!g) return fail(RCSH_ERR_ARG, "null gripper description");
+  if (!s->grip) return fail(RCSH_ERR_MODEL, "scene has no two-finger gripper");
+  if (s->gripcfg.present) return fail(RCSH_ERR_STATE, "a gripper is already attached to this sim");
+  if (g->joint_id != s->narm && g->joint_id != s->narm + 1) return fail(RCSH_ERR_MODEL, "gripper joint must be a finger joint");
+  if (g->actuator_id < 0 || g->actuator_id >= (int)s->act_slot.size() || s->act_slot[g->actuator_id] != s->narm)
+    return fail(RCSH_ERR_MODEL, "gripper actuator must be the finger tendon actuator");
+  s->gripcfg.present = 1;
+  s->gripcfg.finger = g->joint_id - s->narm;
+  s->gripcfg.eps_inner = g->epsilon_inner; s->gripcfg.eps_outer = g->epsilon_outer;
+  s->gripcfg.period = g->seconds_between_callbacks;
+  s->gripcfg.max_act = g->max_actuator_width; s->gripcfg.min_act = g->min_actuator_width;
+  s->gripcfg.max_joint = g->max_joint_width; s->gripcfg.min_joint = g->min_joint_width;
+  return rcsh_gripper_reset(s, nullptr);  // SimGripper ctor ends with m_reset()
+}
+
+int rcsh_gripper_reset(rcsh_sim* s, const uint8_t* mask) {
+  REQUIRE_SIM(s); REQUIRE_GRIPPER(s);
+  std::vector<double> z((size_t)s->n * 2, 0.0);
+  std::vector<double> qj((size_t)s->n, s->gripcfg.max_joint), ca((size_t)s->n, s->gripcfg.max_act);
+  int rc = scatter_host(s, field_of(s, "grip"), 2, z.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "qpos") + s->narm + s->gripcfg.finger, 1, qj.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "ctrl") + s->narm, 1, ca.data(), mask);
+  if (!rc) rc = flags_update_host(s, 0, kGripMoving | kGripCollision, mask);
+  return rc;
+}
+
+int rcsh_gripper_set_normalized_width(rcsh_sim* s, const double* width, double force, const uint8_t* mask) {
+  REQUIRE_SIM(s); REQUIRE_GRIPPER(s);
+  if (force < 0) return fail(RCSH_ERR_ARG, "width must be between 0 and 1, force must be positive");
+  std::vector<double> c((size_t)s->n);
+  for (int e = 0; e < s->n; ++e) {
+    if (mask && !mask[e]) continue;
+    if (width[e] < 0 || width[e] > 1) return fail(RCSH_ERR_ARG, "width must be between 0 and 1, force must be positive");
+    c[e] = width[e] * (s->gripcfg.max_act - s->gripcfg.min_act) + s->gripcfg.min_act;
+  }
+  int rc = scatter_host(s, field_of(s, "grip"), 1, width, mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "ctrl") + s->narm, 1, c.data(), mask);
+  return rc;
+}
+
+int rcsh_gripper_get_normalized_width(rcsh_sim* s, double* width) {
+  REQUIRE_SIM(s); REQUIRE_GRIPPER(s);
+  int rc = gather_host(s, field_of(s, "qpos") + s->narm + s->gripcfg.finger, 1, width);
+  if (rc) return rc;
+  for (int e = 0; e < s->n; ++e) {
+    double w = (width[e] - s->gripcfg.min_joint) / (s->gripcfg.max_joint - s->gripcfg.min_joint);
+    width[e] = w < 0 ? 0 : (w > 1 ? 1 : w);
+  }
+  return RCSH_OK;
+}
+
+int rcsh_gripper_is_grasped(rcsh_sim* s, uint8_t* grasped) {
+  REQUIRE_SIM(s); REQUIRE_GRIPPER(s);
+  std::vector<double> w(s->n), st((size_t)s->n * 2);
+  int rc = rcsh_gripper_get_normalized_width(s, w.data());
+  if (!rc) rc = gather_host(s, field_of(s, "grip"), 2, st.data());
+  if (rc) return rc;
+  for (int e = 0; e < s->n; ++e) {
+    const double lc = st[2 * e];
+    grasped[e] = (lc - s->gripcfg.eps_inner < w[e]) && (w[e] < lc + s->gripcfg.eps_outer);
+  }
+  return RCSH_OK;
+}
+
+int rcsh_gripper_get_state(rcsh_sim* s, double* last_commanded_width, uint8_t* is_moving, double* last_width, uint8_t* collision) {
+  REQUIRE_SIM(s); REQUIRE_GRIPPER(s);
+  std::vector<double> st((size_t)s->n * 2);
+  int rc = gather_host(s, field_of(s, "grip"), 2, st.data());
+  if (rc) return rc;
+  for (int e = 0; e < s->n; ++e) {
+    if (last_commanded_width) last_commanded_width[e] = st[2 * e];
+    if (last_width) last_width[e] = st[2 * e + 1];
+  }
+  rc = flag_host(s, kGripMoving, is_moving);
+  if (!rc) rc = flag_host(s, kGripCollision, collision);
+  return rc;
+}
+
+int rcsh_sim_get_qpos(rcsh_sim* s, double* q) { REQUIRE_SIM(s); return gather_host(s, field_of(s, "qpos"), s->nl, q); }
+int rcsh_sim_get_qvel(rcsh_sim* s, double* q) { REQUIRE_SIM(s); return gather_host(s, field_of(s, "qvel"), s->nl, q); }
+int rcsh_sim_get_time(rcsh_sim* s, double* t) { REQUIRE_SIM(s); return gather_host(s, field_of(s, "time"), 1, t); }
+int rcsh_sim_get_ctrl(rcsh_sim* s, double* c) {
+  REQUIRE_SIM(s);
+  std::vector<double> slots((size_t)s->n * s->nu);
+  int rc = gather_host(s, field_of(s, "ctrl"), s->nu, slots.data());
+  if (rc) return rc;
+  const int nu = (int)s->act_slot.size();
+  for (int e = 0; e < s->n; ++e)
+    for (int u = 0; u < nu; ++u) c[(size_t)e * nu + u] = slots[(size_t)e * s->nu + s->act_slot[u]];
+  return RCSH_OK;
+}
+int rcsh_sim_set_qpos(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); return scatter_host(s, field_of(s, "qpos"), s->nl, q, mask); }
+int rcsh_sim_set_qvel(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); return scatter_host(s, field_of(s, "qvel"), s->nl, q, mask); }
+
+// ---- fused Gymnasium loop
+
+int rcsh_env_configure(rcsh_sim* s, const rcsh_env_desc* env) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!env) return fail(RCSH_ERR_ARG, "null env description");
+  if (env->control_mode != RCSH_MODE_JOINTS)
+    return fail(RCSH_ERR_STATE, "fused env-step: only ControlMode.JOINTS is built in this revision");
+  if (env->relative_to < 0 || env->relative_to > 2) return fail(RCSH_ERR_ARG, "bad relative_to");
+  s->env.mode = env->control_mode;
+  s->env.relative_to = env->relative_to;
+  s->env.binary_gripper = env->binary_gripper;
+  s->env.max_mov[0] = env->max_mov[0]; s->env.max_mov[1] = env->max_mov[1];
+  for (int i = 0; i < s->narm; ++i) {
+    s->env.low[i] = env->joint_low ? env->joint_low[i] : -INFINITY;
+    s->env.high[i] = env->joint_high ? env->joint_high[i] : INFINITY;
+  }
+  s->env_configured = true;
+  return RCSH_OK;
+}
+
+int rcsh_env_obs_width(const rcsh_sim* s) { return s ? 14 + s->narm : 0; }
+int rcsh_env_action_width(const rcsh_sim* s) { return s ? s->narm : 0; }
+
+int rcsh_env_reset_dev(rcsh_sim* s, const uint8_t* mask_dev, double* obs_dev, uint8_t* info_dev, double* gw_dev) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!s->env_configured) return fail(RCSH_ERR_STATE, "call rcsh_env_configure first");
+  HIP_TRY(hipSetDevice(s->device));
+  RunOp op{};
+  op.do_reset = 1;
+  op.nsteps = 1;
+  op.write_obs = obs_dev != nullptr;
+  op.mask = mask_dev;
+  op.obs = obs_dev; op.info = info_dev; op.gripper_width = gw_dev;
+  return launch_run(s, op, false);
+}
+
+int rcsh_env_step_dev(rcsh_sim* s, const double* action_dev, const float* gripper_dev, double* obs_dev, uint8_t* info_dev,
+                      double* gw_dev, int32_t* substeps_dev) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!s->env_configured) return fail(RCSH_ERR_STATE, "call rcsh_env_configure first");
+  if (!action_dev) return fail(RCSH_ERR_ARG, "null action");
+  HIP_TRY(hipSetDevice(s->device));
+  RunOp op{};
+  op.apply_action = 1;
+  // RobotSimWrapper.step (reference python/rcs/envs/sim.py:49-59)
+  op.nsteps = s->sim.async_control ? (int32_t)std::lround(1.0 / s->sim.frequency / s->dm.timestep) : -1;
+  op.write_obs = obs_dev != nullptr;
+  op.action = action_dev; op.gripper = gripper_dev;
+  op.obs = obs_dev; op.info = info_dev; op.gripper_width = gw_dev; op.substeps = substeps_dev;
+  return launch_run(s, op, true);
+}
+
+int rcsh_env_reset(rcsh_sim* s, const uint8_t* mask, double* obs, uint8_t* info, double* gw) {
+  REQUIRE_SIM(s);
+  const uint8_t* dm = nullptr;
+  int rc = upload_mask(s, mask, &dm);
+  if (rc) return rc;
+  rc = rcsh_env_reset_dev(s, dm, s->d_stage2, s->d_bytes, s->d_stage);
+  if (rc) return rc;
+  const int ow = 14 + s->narm;
+  if (obs) HIP_TRY(hipMemcpyAsync(obs, s->d_stage2, sizeof(double) * s->n * ow, hipMemcpyDeviceToHost, s->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, s->d_bytes, (size_t)s->n * 8, hipMemcpyDeviceToHost, s->stream));
+  if (gw) HIP_TRY(hipMemcpyAsync(gw, s->d_stage, sizeof(double) * s->n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_env_step(rcsh_sim* s, const double* action, const float* gripper, double* obs, uint8_t* info, double* gw, int32_t* substeps) {
+  REQUIRE_SIM(s);
+  if (!action) return fail(RCSH_ERR_ARG, "null action");
+  const int aw = s->narm, ow = 14 + s->narm;
+  double* d_action = s->d_stage + (size_t)s->n;  // d_stage[0..n) carries gripper widths
+  HIP_TRY(hipMemcpyAsync(d_action, action, sizeof(double) * s->n * aw, hipMemcpyHostToDevice, s->stream));
+  if (gripper) HIP_TRY(hipMemcpyAsync(s->d_floats, gripper, sizeof(float) * s->n, hipMemcpyHostToDevice, s->stream));
+  int rc = rcsh_env_step_dev(s, d_action, gripper ? s->d_floats : nullptr, s->d_stage2, s->d_bytes, s->d_stage, s->d_ints);
+  if (rc) return rc;
+  if (obs) HIP_TRY(hipMemcpyAsync(obs, s->d_stage2, sizeof(double) * s->n * ow, hipMemcpyDeviceToHost, s->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, s->d_bytes, (size_t)s->n * 8, hipMemcpyDeviceToHost, s->stream));
+  if (gw) HIP_TRY(hipMemcpyAsync(gw, s->d_stage, sizeof(double) * s->n, hipMemcpyDeviceToHost, s->stream));
+  if (substeps) HIP_TRY(hipMemcpyAsync(substeps, s->d_ints, sizeof(int32_t) * s->n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_dev_alloc(rcsh_sim* s, size_t bytes, void** ptr) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMalloc(ptr, bytes));
+  return RCSH_OK;
+}
+int rcsh_dev_free(rcsh_sim* s, void* ptr) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipFree(ptr));
+  return RCSH_OK;
+}
+int rcsh_dev_upload(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+int rcsh_dev_download(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_prof_enable(rcsh_sim* s, int32_t enable) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipSetDevice(s->device));
+  if (enable && s->ev_start.empty()) {
+    s->ev_start.resize(kProfRing);
+    s->ev_stop.resize(kProfRing);
+    for (int i = 0; i < kProfRing; ++i) {
+      HIP_TRY(hipEventCreate(&s->ev_start[i]));
+      HIP_TRY(hipEventCreate(&s->ev_stop[i]));
+    }
+  }
+  s->prof = enable != 0;
+  s->prof_pending = 0; s->prof_ms = 0; s->prof_launches = 0;
+  return RCSH_OK;
+}
+int rcsh_prof_read(rcsh_sim* s, double* total_ms, int64_t* launches) {
+  REQUIRE_SIM(s);
+  int rc = prof_flush(s);
+  if (rc) return rc;
+  if (total_ms) *total_ms = s->prof_ms;
+  if (launches) *launches = s->prof_launches;
+  return RCSH_OK;
+}
+
+}  // extern "C"

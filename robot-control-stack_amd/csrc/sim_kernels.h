@@ -1,0 +1,447 @@
+// sim_kernels.h -- the batched Sim / SimRobot / SimGripper / Gymnasium-loop kernels.
+//
+// One GPU thread owns one environment for the whole launch: it loads the environment's
+// state from the SoA arrays ([field][env], so a wave's 64 loads of one field are one
+// contiguous 512-byte segment), keeps it in registers across all physics substeps of
+// the call, and writes it back once.  The reference's per-substep callback scheduler
+// (reference src/sim/sim.cpp:14-61) is evaluated in-register with the same
+// double-precision timestamps and strict '>' compares, so callback cadence -- and with
+// it every flag and substep count -- follows the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "dyn.h"
+#include "pose.h"
+
+namespace rcsh {
+
+// ---- per-environment flag word
+enum : uint32_t {
+  kAnyRet0 = 1u << 0,   // last_return_value of any_callbacks[0] (robot collision)
+  kAnyRet1 = 1u << 1,   // any_callbacks[1] (gripper collision)
+  kAllRet0 = 1u << 2,   // all_callbacks[0] (robot convergence)
+  kAllRet1 = 1u << 3,   // all_callbacks[1] (gripper convergence)
+  kConverged = 1u << 4,
+  kIkSuccess = 1u << 5,
+  kRobotCollision = 1u << 6,
+  kIsMoving = 1u << 7,
+  kIsArrived = 1u << 8,
+  kGripMoving = 1u << 9,
+  kGripCollision = 1u << 10,
+  kHasPrevAction = 1u << 11,
+  kHasGripCmd = 1u << 12,
+  kGripCmd = 1u << 13,
+  kHasLastAction = 1u << 14,
+};
+
+struct SimCfg {
+  int32_t async_control, realtime, frequency, max_convergence_steps;
+};
+struct RobotCfg {
+  int32_t present, conv_registered;
+  double tolerance, period;
+  double tcp[7];  // xyz + xyzw
+  double q_home[kMaxArm];
+};
+struct GripperCfg {
+  int32_t present, finger;  // finger: 0/1 = which finger dof is the gripper joint
+  double eps_inner, eps_outer, period;
+  double max_act, min_act, max_joint, min_joint;
+};
+struct EnvCfg {
+  int32_t mode, relative_to, binary_gripper, pad;
+  double max_mov[2];
+  double low[kMaxArm], high[kMaxArm];
+};
+
+// SoA layout: field f of environment e lives at base[(f) * n + e]
+template <class T>
+struct Lay {
+  static constexpr int QPOS = 0;
+  static constexpr int QVEL = QPOS + T::NL;
+  static constexpr int CTRL = QVEL + T::NL;
+  static constexpr int TIME = CTRL + T::NU;
+  static constexpr int CB = TIME + 1;            // plain0 plain1 any0 any1 all0 all1 last_call_timestamp
+  static constexpr int PREVQ = CB + 6;           // SimRobotState.previous_angles
+  static constexpr int TARGET = PREVQ + T::NARM; // SimRobotState.target_angles
+  static constexpr int GRIP = TARGET + T::NARM;  // last_commanded_width, last_width
+  static constexpr int SITE = GRIP + 2;          // frame of the site link at the last mj_step1: R(9) p(3)
+  static constexpr int PREVA = SITE + 12;        // RobotEnv.prev_action (7 wide: joints or tquat)
+  static constexpr int ORIGIN = PREVA + 7;       // RelativeActionSpace._origin
+  static constexpr int LASTA = ORIGIN + 7;       // RelativeActionSpace._last_action
+  static constexpr int COUNT = LASTA + 7;
+};
+
+struct RunOp {
+  int32_t do_reset;       // env.reset(): gripper reset, sim reset, robot reset (then nsteps = 1)
+  int32_t apply_action;   // env.step(): wrappers' action() + RobotEnv.step
+  int32_t nsteps;         // >= 0: Sim.step(nsteps); < 0: Sim.step_until_convergence()
+  int32_t write_obs;
+  const uint8_t* mask;    // optional, device
+  const double* action;   // [n][action_width], device
+  const float* gripper;   // [n], device
+  double* obs;            // [n][obs_width]
+  uint8_t* info;          // [n][8]
+  double* gripper_width;  // [n]
+  int32_t* substeps;      // [n]
+};
+
+struct Params {
+  const DevModel* model;
+  double* S;
+  uint32_t* flags;
+  int32_t* conv_steps;
+  int32_t n;
+  SimCfg sim;
+  RobotCfg robot;
+  GripperCfg grip;
+  EnvCfg env;
+};
+
+// ---- everything one environment keeps in registers during a launch
+template <class T>
+struct EnvRegs {
+  double q[T::NL], qd[T::NL], ctrl[T::NU];
+  double time;
+  double cb[6];
+  double prevq[T::NARM], target[T::NARM];
+  double last_cmd_width, last_width;
+  uint32_t flags;
+  int32_t conv_steps;
+};
+
+template <class T>
+__device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T>& r) {
+  using L = Lay<T>;
+  const int n = P.n;
+  const double* S = P.S;
+#pragma unroll
+  for (int i = 0; i < T::NL; ++i) { r.q[i] = S[(L::QPOS + i) * n + e]; r.qd[i] = S[(L::QVEL + i) * n + e]; }
+#pragma unroll
+  for (int i = 0; i < T::NU; ++i) r.ctrl[i] = S[(L::CTRL + i) * n + e];
+  r.time = S[L::TIME * n + e];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r.cb[i] = S[(L::CB + i) * n + e];
+#pragma unroll
+  for (int i = 0; i < T::NARM; ++i) { r.prevq[i] = S[(L::PREVQ + i) * n + e]; r.target[i] = S[(L::TARGET + i) * n + e]; }
+  r.last_cmd_width = S[(L::GRIP + 0) * n + e];
+  r.last_width = S[(L::GRIP + 1) * n + e];
+  r.flags = P.flags[e];
+  r.conv_steps = P.conv_steps[e];
+}
+
+template <class T>
+__device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<T>& r) {
+  using L = Lay<T>;
+  const int n = P.n;
+  double* S = P.S;
+#pragma unroll
+  for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.q[i]; S[(L::QVEL + i) * n + e] = r.qd[i]; }
+#pragma unroll
+  for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.ctrl[i];
+  S[L::TIME * n + e] = r.time;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) S[(L::CB + i) * n + e] = r.cb[i];
+#pragma unroll
+  for (int i = 0; i < T::NARM; ++i) { S[(L::PREVQ + i) * n + e] = r.prevq[i]; S[(L::TARGET + i) * n + e] = r.target[i]; }
+  S[(L::GRIP + 0) * n + e] = r.last_cmd_width;
+  S[(L::GRIP + 1) * n + e] = r.last_width;
+  P.flags[e] = r.flags;
+  P.conv_steps[e] = r.conv_steps;
+}
+
+__device__ __forceinline__ void set_flag(uint32_t& f, uint32_t bit, bool v) { f = v ? (f | bit) : (f & ~bit); }
+
+// SimGripper::get_normalized_width, reference src/sim/SimGripper.cpp:93-106
+template <class T>
+__device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T>& r) {
+  const double qf = P.grip.finger ? r.q[T::NL - 1] : r.q[T::NL - 2];
+  double w = (qf - P.grip.min_joint) / (P.grip.max_joint - P.grip.min_joint);
+  return w < 0 ? 0 : (w > 1 ? 1 : w);
+}
+
+// Sim::invoke_callbacks, reference src/sim/sim.cpp:38-47, with SimRobot::is_arrived_callback /
+// is_moving_callback (src/sim/SimRobot.cpp:156-170) as the two registered callbacks
+template <class T>
+__device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T>& r) {
+  if (!(P.robot.present && P.robot.conv_registered)) return;
+  if (r.time - r.cb[0] > P.robot.period) {
+    double mx = 0;
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) mx = fmax(mx, fabs(r.q[i] - r.target[i]));
+    set_flag(r.flags, kIsArrived, mx < P.robot.tolerance);
+    r.cb[0] = r.time;
+  }
+  if (r.time - r.cb[1] > P.robot.period) {
+    double mx = 0;
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) { mx = fmax(mx, fabs(r.q[i] - r.prevq[i])); r.prevq[i] = r.q[i]; }
+    set_flag(r.flags, kIsMoving, mx > 0.0001);
+    r.cb[1] = r.time;
+  }
+}
+
+// Sim::invoke_condition_callbacks, reference src/sim/sim.cpp:14-23,49-61.  Callback bodies:
+// SimRobot::collision_callback / convergence_callback (SimRobot.cpp:172-191),
+// SimGripper::collision_callback / convergence_callback (SimGripper.cpp:108-130,143-151).
+// No contact-capable pair exists in this revision, so ncon == 0 and both collision scans return false.
+template <class T>
+__device__ __forceinline__ bool condition_callbacks(const Params& P, EnvRegs<T>& r) {
+  const bool has_g = T::GRIP && P.grip.present;
+  if (P.robot.present && r.time - r.cb[2] > P.robot.period) {
+    set_flag(r.flags, kRobotCollision, false);
+    set_flag(r.flags, kAnyRet0, false);
+    r.cb[2] = r.time;
+  }
+  if (has_g && r.time - r.cb[3] > P.grip.period) {
+    set_flag(r.flags, kGripCollision, false);
+    set_flag(r.flags, kAnyRet1, false);
+    r.cb[3] = r.time;
+  }
+  if (P.robot.present && P.robot.conv_registered && r.time - r.cb[4] > P.robot.period) {
+    const bool conv = !(r.flags & kIkSuccess) || ((r.flags & kIsArrived) && !(r.flags & kIsMoving));
+    set_flag(r.flags, kAllRet0, conv);
+    r.cb[4] = r.time;
+  }
+  if (has_g && r.time - r.cb[5] > P.grip.period) {
+    const double w = gripper_width<T>(P, r);
+    const bool moving = fabs(r.last_width - w) > 0.001 * (P.grip.max_act - P.grip.min_act);
+    set_flag(r.flags, kGripMoving, moving);
+    r.last_width = w;
+    set_flag(r.flags, kAllRet1, !moving);
+    r.cb[5] = r.time;
+  }
+  bool any = false, all = true;
+  if (P.robot.present) any = any || (r.flags & kAnyRet0);
+  if (has_g) any = any || (r.flags & kAnyRet1);
+  if (P.robot.present && P.robot.conv_registered) all = all && (r.flags & kAllRet0);
+  if (has_g) all = all && (r.flags & kAllRet1);
+  return any || all;
+}
+
+// SimRobot::set_joint_position, reference src/sim/SimRobot.cpp:123-131
+template <class T>
+__device__ __forceinline__ void robot_set_joint_position(EnvRegs<T>& r, const double* a) {
+#pragma unroll
+  for (int i = 0; i < T::NARM; ++i) {
+    r.target[i] = a[i];
+    r.prevq[i] = r.q[i];
+    r.ctrl[i] = a[i];
+  }
+  r.flags = (r.flags | kIsMoving) & ~kIsArrived;
+}
+
+// SimGripper::set_normalized_width, reference src/sim/SimGripper.cpp:79-92
+template <class T>
+__device__ __forceinline__ void gripper_set_width(const Params& P, EnvRegs<T>& r, double w) {
+  r.last_cmd_width = w;
+  r.ctrl[T::NU - 1] = w * (P.grip.max_act - P.grip.min_act) + P.grip.min_act;
+}
+
+// SimRobot::get_cartesian_position, reference src/sim/SimRobot.cpp:114-121 + src/rcs/Robot.cpp:5-9
+__device__ __forceinline__ void cartesian_position(const DevModel& m, const RobotCfg& rc, const double* linkR,
+                                                   const double* linkP, Pose& out) {
+  double sp[3], sR[9];
+  mulmv(linkR, m.site_pos, sp);
+  sp[0] += linkP[0]; sp[1] += linkP[1]; sp[2] += linkP[2];
+  mulmm(linkR, m.site_rot, sR);
+  Pose site, base, base_inv, in_robot, tcp;
+  pose_from_mat(sR, sp, site);
+  const double bq[4] = {m.base_quat[1], m.base_quat[2], m.base_quat[3], m.base_quat[0]};
+  pose_from_quat(bq, m.base_pos, base);
+  pose_inverse(base, base_inv);
+  pose_mul(base_inv, site, in_robot);
+  tcp.t[0] = rc.tcp[0]; tcp.t[1] = rc.tcp[1]; tcp.t[2] = rc.tcp[2];
+  tcp.q[0] = rc.tcp[3]; tcp.q[1] = rc.tcp[4]; tcp.q[2] = rc.tcp[5]; tcp.q[3] = rc.tcp[6];
+  pose_mul(in_robot, tcp, out);
+}
+
+// The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step.
+template <class T>
+__global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
+  using L = Lay<T>;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n) return;
+  if (op.mask && !op.mask[e]) return;
+  const DevModel& m = *P.model;
+  const int n = P.n;
+  EnvRegs<T> r;
+  load_env<T>(P, e, r);
+  Smooth<T> sm;
+  bool have_frames = false;
+
+  if (op.do_reset) {
+    // GripperWrapper.reset -> SimGripper::m_reset (python/rcs/envs/base.py:703-708, SimGripper.cpp:158-165)
+    if (T::GRIP && P.grip.present) {
+      r.last_cmd_width = 0; r.last_width = 0;
+      r.flags &= ~(kGripMoving | kGripCollision | kHasGripCmd | kGripCmd);
+    }
+    // RobotSimWrapper.reset -> Sim::reset = mj_resetData + reset_callbacks (envs/sim.py:68-76, sim.cpp:117-138);
+    // it overwrites what the gripper reset just wrote to qpos / ctrl
+#pragma unroll
+    for (int i = 0; i < T::NL; ++i) { r.q[i] = m.qpos0[i]; r.qd[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < T::NU; ++i) r.ctrl[i] = 0;
+    r.time = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.cb[i] = 0;
+    // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) { r.q[i] = P.robot.q_home[i]; r.ctrl[i] = P.robot.q_home[i]; }
+  }
+
+  if (op.apply_action) {
+    // ---- RelativeActionSpace.action (python/rcs/envs/base.py:468-488), JOINTS mode
+    double a[T::NARM];
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) a[i] = op.action[e * T::NARM + i];
+    if (P.env.relative_to != 0) {
+      const bool last_step = P.env.relative_to == 1;
+      const bool fresh = last_step || !(r.flags & kHasLastAction);
+#pragma unroll
+      for (int i = 0; i < T::NARM; ++i) {
+        double origin = last_step ? r.q[i] : P.S[(L::ORIGIN + i) * n + e];
+        double lim;
+        if (fresh) {
+          lim = clampd(a[i], -P.env.max_mov[0], P.env.max_mov[0]);
+        } else {
+          const double la = P.S[(L::LASTA + i) * n + e];
+          lim = clampd(a[i] - la, -P.env.max_mov[0], P.env.max_mov[0]) + la;
+        }
+        if (last_step) P.S[(L::ORIGIN + i) * n + e] = origin;
+        P.S[(L::LASTA + i) * n + e] = lim;
+        a[i] = clampd(origin + lim, P.env.low[i], P.env.high[i]);
+      }
+      r.flags |= kHasLastAction;
+    }
+    // ---- GripperWrapper.action (base.py:721-735)
+    if (T::GRIP && P.grip.present && op.gripper) {
+      float g = op.gripper[e];
+      if (P.env.binary_gripper) g = rintf(g);  // np.round: half to even
+      g = fminf(fmaxf(g, 0.0f), 1.0f);
+      if (P.env.binary_gripper) {
+        gripper_set_width<T>(P, r, g == 0.0f ? 0.0 : 1.0);  // grasp() = shut() : open()
+        set_flag(r.flags, kGripCmd, g != 0.0f);
+      } else {
+        gripper_set_width<T>(P, r, (double)g);
+        set_flag(r.flags, kGripCmd, g >= 0.5f);
+      }
+      r.flags |= kHasGripCmd;
+    }
+    // ---- RobotEnv.step (base.py:255-288): command only when the action moved by more than atol = 1e-3
+    bool changed = !(r.flags & kHasPrevAction);
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) {
+      const double pa = P.S[(L::PREVA + i) * n + e];
+      changed = changed || !(fabs(a[i] - pa) <= 1e-3);
+      P.S[(L::PREVA + i) * n + e] = a[i];
+    }
+    if (changed) robot_set_joint_position<T>(r, a);
+    r.flags |= kHasPrevAction;
+  }
+
+  // ---- Sim::step(k) / Sim::step_until_convergence (src/sim/sim.cpp:84-115)
+  int nsteps = op.nsteps;
+  if (op.do_reset) nsteps = 1;
+  if (nsteps >= 0) {
+    for (int s = 0; s < nsteps; ++s) {
+      plain_callbacks<T>(P, r);
+      substep<T>(m, r.q, r.qd, r.ctrl, sm);
+      r.time += m.timestep;
+      have_frames = true;
+    }
+  } else {
+    r.conv_steps = 0;
+    r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
+    const int cap = P.sim.max_convergence_steps;
+    bool converged = false;
+    while (!converged && (cap == -1 || r.conv_steps < cap)) {
+      plain_callbacks<T>(P, r);
+      substep<T>(m, r.q, r.qd, r.ctrl, sm);
+      r.time += m.timestep;
+      have_frames = true;
+      r.conv_steps++;
+      converged = condition_callbacks<T>(P, r);
+    }
+    set_flag(r.flags, kConverged, converged);
+  }
+  if (have_frames) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.S[(L::SITE + k) * n + e] = sm.linkR[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P.S[(L::SITE + 9 + k) * n + e] = sm.linkP[k];
+  } else if (op.write_obs) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sm.linkR[k] = P.S[(L::SITE + k) * n + e];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sm.linkP[k] = P.S[(L::SITE + 9 + k) * n + e];
+  }
+  if (op.do_reset && P.env.relative_to != 0) {
+    // RelativeActionSpace.reset (base.py:461-466): origin := current, _last_action := None
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) P.S[(L::ORIGIN + i) * n + e] = r.q[i];
+    r.flags &= ~kHasLastAction;
+  }
+  store_env<T>(P, e, r);
+
+  if (op.write_obs) {
+    // RobotEnv.get_obs (base.py:246-253) + GripperWrapper.observation (base.py:710-719) +
+    // RobotSimWrapper.step info (envs/sim.py:60-66) + GripperWrapperSim.observation (envs/sim.py:125-131)
+    constexpr int OW = 14 + T::NARM;
+    Pose tcp;
+    cartesian_position(m, P.robot, sm.linkR, sm.linkP, tcp);
+    double* o = op.obs + (size_t)e * OW;
+    o[0] = tcp.t[0]; o[1] = tcp.t[1]; o[2] = tcp.t[2];
+    o[3] = tcp.q[0]; o[4] = tcp.q[1]; o[5] = tcp.q[2]; o[6] = tcp.q[3];
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) o[7 + i] = r.q[i];
+    double rpy[3];
+    pose_rpy(tcp, rpy);
+    o[7 + T::NARM + 0] = tcp.t[0]; o[7 + T::NARM + 1] = tcp.t[1]; o[7 + T::NARM + 2] = tcp.t[2];
+    o[7 + T::NARM + 3] = rpy[0]; o[7 + T::NARM + 4] = rpy[1]; o[7 + T::NARM + 5] = rpy[2];
+    double gobs = 1.0, w = 0.0;
+    const bool has_g = T::GRIP && P.grip.present;
+    if (has_g) {
+      w = gripper_width<T>(P, r);
+      if (P.env.binary_gripper) gobs = (r.flags & kHasGripCmd) ? ((r.flags & kGripCmd) ? 1.0 : 0.0) : 1.0;
+      else gobs = w;
+    }
+    o[13 + T::NARM] = gobs;
+    if (op.info) {
+      uint8_t* inf = op.info + (size_t)e * 8;
+      const bool rc = r.flags & kRobotCollision, ik = r.flags & kIkSuccess, gc = has_g && (r.flags & kGripCollision);
+      inf[0] = rc || gc;
+      inf[1] = ik;
+      inf[2] = (r.flags & kConverged) != 0;
+      inf[3] = has_g && (w > 0.01 && w < 0.99);
+      inf[4] = rc || !ik;
+      inf[5] = gc;
+      inf[6] = 0; inf[7] = 0;
+    }
+    if (op.gripper_width) op.gripper_width[e] = w;
+    if (op.substeps) op.substeps[e] = nsteps >= 0 ? nsteps : r.conv_steps;
+  }
+}
+
+// ---- small elementwise kernels behind the 1:1 SimRobot / SimGripper / mjData accessors
+
+// dst[e][i] = S[field0 + i][e]
+__global__ void k_gather(const double* S, int n, int field0, int width, double* dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  for (int i = 0; i < width; ++i) dst[(size_t)e * width + i] = S[(size_t)(field0 + i) * n + e];
+}
+// S[field0 + i][e] = src[e][i] where mask
+__global__ void k_scatter(double* S, int n, int field0, int width, const double* src, const uint8_t* mask) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || (mask && !mask[e])) return;
+  for (int i = 0; i < width; ++i) S[(size_t)(field0 + i) * n + e] = src[(size_t)e * width + i];
+}
+__global__ void k_flags_to_bytes(const uint32_t* flags, int n, uint32_t bit, uint8_t* dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) dst[e] = (flags[e] & bit) != 0;
+}
+
+}  // namespace rcsh

@@ -1,0 +1,143 @@
+"""``SimEnvCreator`` for N environments (reference python/rcs/envs/creators.py:43-128).
+
+The reference builds one Gymnasium env out of nested wrappers around one MuJoCo
+instance.  Here the same constructor arguments produce a :class:`VecSimEnv`:
+``reset()`` / ``step(action)`` have the Gymnasium signatures, but every array
+carries a leading ``n_envs`` axis and one call is one kernel launch that performs
+the wrappers' side effects, the physics substeps and the observation for all
+environments (csrc/sim_kernels.h: k_run).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+
+from .. import _lib, common, sim
+from .base import ControlMode, RelativeTo
+
+_MODE = {ControlMode.JOINTS: 0, ControlMode.CARTESIAN_TRPY: 1, ControlMode.CARTESIAN_TQuat: 2}
+_REL = {None: 0, RelativeTo.LAST_STEP: 1, RelativeTo.CONFIGURED_ORIGIN: 2}
+_ACTION_KEY = {ControlMode.JOINTS: "joints", ControlMode.CARTESIAN_TRPY: "xyzrpy", ControlMode.CARTESIAN_TQuat: "tquat"}
+
+DEFAULT_MAX_CART_MOV = 0.5  # reference base.py:366-368
+DEFAULT_MAX_CART_ROT = np.deg2rad(90)
+DEFAULT_MAX_JOINT_MOV = np.deg2rad(5)
+
+
+class VecSimEnv:
+    """N-environment ``gym.Env`` look-alike returned by :class:`SimEnvCreator`.
+
+    obs dict: ``tquat [N,7]``, ``joints [N,dof]``, ``xyzrpy [N,6]`` (+ ``gripper [N]``);
+    info dict: ``collision``, ``ik_success``, ``is_sim_converged`` (+ ``gripper_width``, ``is_grasped``), all ``[N]``;
+    ``step`` returns ``(obs, reward [N] = 0, terminated [N] = False, truncated [N], info)``.
+    """
+
+    def __init__(self, simulation: sim.Sim, robot: sim.SimRobot, gripper: sim.SimGripper | None,
+                 control_mode: ControlMode, max_relative_movement, relative_to: RelativeTo):
+        self.sim = simulation
+        self.robot = robot
+        self.gripper = gripper
+        self.control_mode = control_mode
+        self.n_envs = simulation.n_envs
+        self.dof = robot.dof
+        self._L = simulation._L
+        meta = common.robots_meta_config(robot.get_config().robot_type)
+        self._low = np.ascontiguousarray(meta.joint_limits[0][: self.dof], dtype=np.float64)
+        self._high = np.ascontiguousarray(meta.joint_limits[1][: self.dof], dtype=np.float64)
+        rel = 0
+        max_mov = [0.0, 0.0]
+        if max_relative_movement is not None:
+            rel = _REL[relative_to]
+            if control_mode == ControlMode.JOINTS:
+                assert isinstance(max_relative_movement, float), "joint-space max_mov must be a float (rad)"
+                max_mov = [float(max_relative_movement), 0.0]
+            elif isinstance(max_relative_movement, tuple):
+                max_mov = [float(max_relative_movement[0]), float(max_relative_movement[1])]
+            else:
+                max_mov = [float(max_relative_movement), float(DEFAULT_MAX_CART_ROT)]
+        self.max_mov = max_mov
+        self.relative_to = relative_to if rel else None
+        d = _lib.EnvDesc()
+        d.control_mode = _MODE[control_mode]
+        d.relative_to = rel
+        d.max_mov[:] = max_mov
+        d.binary_gripper = 1
+        d.joint_low = self._low.ctypes.data_as(C.POINTER(C.c_double))
+        d.joint_high = self._high.ctypes.data_as(C.POINTER(C.c_double))
+        _lib.check(self._L.rcsh_env_configure(simulation._h, C.byref(d)))
+        self.obs_width = self._L.rcsh_env_obs_width(simulation._h)
+        self.action_width = self._L.rcsh_env_action_width(simulation._h)
+        self.action_key = _ACTION_KEY[control_mode]
+
+    # ---- host-array interface (Gymnasium-shaped)
+    def _unpack(self, obs, info, gw) -> tuple[dict[str, Any], dict[str, Any]]:
+        d = self.dof
+        o: dict[str, Any] = {"tquat": obs[:, 0:7].copy(), "joints": obs[:, 7 : 7 + d].copy(), "xyzrpy": obs[:, 7 + d : 13 + d].copy()}
+        i: dict[str, Any] = {}
+        if self.gripper is not None:
+            o["gripper"] = obs[:, 13 + d].copy()
+        return o, i
+
+    def reset(self, seed: int | None = None, options: dict | None = None, mask=None):
+        n = self.n_envs
+        obs = np.zeros((n, self.obs_width))
+        info = np.zeros((n, 8), dtype=np.uint8)
+        gw = np.zeros(n)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        _lib.check(self._L.rcsh_env_reset(self.sim._h, _lib.ptr(m), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw)))
+        o, i = self._unpack(obs, info, gw)
+        if self.gripper is not None:  # GripperWrapperSim.observation runs on reset too (envs/sim.py:125-131)
+            i["collision"] = info[:, 5].astype(bool)
+            i["gripper_width"] = gw
+            i["is_grasped"] = info[:, 3].astype(bool)
+        return o, i
+
+    def step(self, action: dict[str, Any]):
+        n = self.n_envs
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(action[self.action_key], dtype=np.float64), (n, self.action_width)))
+        g = None
+        if self.gripper is not None:
+            assert "gripper" in action, "Gripper action not found."
+            g = np.ascontiguousarray(np.broadcast_to(np.asarray(action["gripper"], dtype=np.float32), (n,)))
+        obs = np.zeros((n, self.obs_width))
+        info = np.zeros((n, 8), dtype=np.uint8)
+        gw = np.zeros(n)
+        sub = np.zeros(n, dtype=np.int32)
+        _lib.check(self._L.rcsh_env_step(self.sim._h, _lib.ptr(a), _lib.ptr(g), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw), _lib.ptr(sub)))
+        o, i = self._unpack(obs, info, gw)
+        i["collision"] = info[:, 0].astype(bool)
+        i["ik_success"] = info[:, 1].astype(bool)
+        i["is_sim_converged"] = info[:, 2].astype(bool)
+        if self.gripper is not None:
+            i["gripper_width"] = gw
+            i["is_grasped"] = info[:, 3].astype(bool)
+        i["substeps"] = sub
+        truncated = info[:, 4].astype(bool)
+        return o, np.zeros(n), np.zeros(n, dtype=bool), truncated, i
+
+    # ---- device-pointer interface for resident rollouts (pointers are integers / c_void_p)
+    def reset_dev(self, obs_ptr, info_ptr=None, gw_ptr=None, mask_ptr=None) -> None:
+        _lib.check(self._L.rcsh_env_reset_dev(self.sim._h, C.c_void_p(mask_ptr), C.c_void_p(obs_ptr), C.c_void_p(info_ptr), C.c_void_p(gw_ptr)))
+
+    def step_dev(self, action_ptr, gripper_ptr, obs_ptr, info_ptr=None, gw_ptr=None, substeps_ptr=None) -> None:
+        _lib.check(self._L.rcsh_env_step_dev(self.sim._h, C.c_void_p(action_ptr), C.c_void_p(gripper_ptr), C.c_void_p(obs_ptr),
+                                             C.c_void_p(info_ptr), C.c_void_p(gw_ptr), C.c_void_p(substeps_ptr)))
+
+    def close(self) -> None:
+        self.sim.close()
+
+
+class SimEnvCreator:
+    def __call__(self, control_mode: ControlMode, robot_cfg: sim.SimRobotConfig, collision_guard: bool = False,
+                 gripper_cfg: sim.SimGripperConfig | None = None, sim_cfg: sim.SimConfig | None = None,
+                 hand_cfg=None, cameras=None, max_relative_movement: float | tuple[float, float] | None = None,
+                 relative_to: RelativeTo = RelativeTo.LAST_STEP, sim_wrapper=None, n_envs: int = 1, device: int = 0) -> VecSimEnv:
+        if hand_cfg is not None or cameras is not None or sim_wrapper is not None or collision_guard:
+            raise NotImplementedError("hands, cameras, sim_wrapper and collision_guard are outside this backend's hot path")
+        simulation = sim.Sim(robot_cfg.mjcf_scene_path, sim_cfg, n_envs=n_envs, device=device)
+        robot = sim.SimRobot(simulation, None, robot_cfg)
+        gripper = sim.SimGripper(simulation, gripper_cfg) if gripper_cfg is not None else None
+        return VecSimEnv(simulation, robot, gripper, control_mode, max_relative_movement, relative_to)

@@ -1,0 +1,360 @@
+"""Batched mirror of ``rcs.sim`` (reference python/rcs/sim/sim.py, src/pybind/rcs.cpp:421-527).
+
+``Sim`` / ``SimRobot`` / ``SimGripper`` keep the reference's class, method and
+config-field names; every method acts on all ``n_envs`` environments of the
+handle (arrays carry a leading environment axis, ``mask`` selects a subset).
+The state lives in HBM; these classes only marshal arguments across the C-ABI.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from os import PathLike
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib, common
+from .mjcf import Model, compile_mjcf
+
+
+@dataclass
+class SimConfig:  # reference src/sim/sim.h:29-34
+    async_control: bool = False
+    realtime: bool = False
+    frequency: int = 30
+    max_convergence_steps: int = 500
+
+
+def _mask(mask, n):
+    if mask is None:
+        return None
+    m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+    assert m.shape == (n,)
+    return m
+
+
+class Sim:
+    """``rcs.sim.Sim(mjmdl, cfg)`` for ``n_envs`` independent copies of the scene (reference sim.py:44-62).
+
+    ``mjmdl`` is the scene ``.xml`` path (MuJoCo's private ``.mjb`` binaries cannot be read without MuJoCo).
+    ``model`` is the compiled scene (``opt_timestep`` etc.), the stand-in for ``mujoco.MjModel``.
+    """
+
+    def __init__(self, mjmdl: str | PathLike, cfg: SimConfig | None = None, n_envs: int = 1, device: int = 0):
+        path = Path(mjmdl)
+        if path.suffix == ".mjb":
+            path = path.with_suffix(".xml")  # scenes are registered by their .mjb name in the reference
+        if path.suffix != ".xml":
+            raise RuntimeError(f"Filetype {path.suffix} is unknown")
+        self.model: Model = compile_mjcf(str(path))
+        self.n_envs = int(n_envs)
+        self.device = int(device)
+        self._L = _lib.load()
+        desc, self._keep = _lib.make_model_desc(self.model)
+        self._h = C.c_void_p()
+        _lib.check(self._L.rcsh_sim_create(C.byref(desc), self.n_envs, self.device, C.byref(self._h)))
+        self._cfg = SimConfig()
+        if cfg is not None:
+            self.set_config(cfg)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._L.rcsh_sim_destroy(h)
+            self._h = C.c_void_p()
+
+    close = __del__
+
+    # -- reference Sim API (rcs.cpp:493-506)
+    def set_config(self, cfg: SimConfig) -> bool:
+        self._cfg = SimConfig(cfg.async_control, cfg.realtime, cfg.frequency, cfg.max_convergence_steps)
+        _lib.check(self._L.rcsh_sim_set_config(self._h, int(cfg.async_control), int(cfg.realtime), int(cfg.frequency),
+                                               int(cfg.max_convergence_steps)))
+        return True
+
+    def get_config(self) -> SimConfig:
+        return SimConfig(self._cfg.async_control, self._cfg.realtime, self._cfg.frequency, self._cfg.max_convergence_steps)
+
+    def step(self, k: int) -> None:
+        _lib.check(self._L.rcsh_sim_step(self._h, int(k)))
+
+    def step_until_convergence(self) -> None:
+        _lib.check(self._L.rcsh_sim_step_until_convergence(self._h))
+
+    def is_converged(self) -> np.ndarray:
+        out = np.zeros(self.n_envs, dtype=np.uint8)
+        _lib.check(self._L.rcsh_sim_is_converged(self._h, _lib.ptr(out), None))
+        return out.astype(bool)
+
+    def convergence_steps(self) -> np.ndarray:
+        out = np.zeros(self.n_envs, dtype=np.uint8)
+        steps = np.zeros(self.n_envs, dtype=np.int32)
+        _lib.check(self._L.rcsh_sim_is_converged(self._h, _lib.ptr(out), _lib.ptr(steps)))
+        return steps
+
+    def reset(self, mask=None) -> None:
+        _lib.check(self._L.rcsh_sim_reset(self._h, _lib.ptr(_mask(mask, self.n_envs))))
+
+    def synchronize(self) -> None:
+        _lib.check(self._L.rcsh_sim_synchronize(self._h))
+
+    # -- mjData views (reference python/rcs/envs/sim.py:343-411 reads data.joint(name).qpos)
+    def _get(self, fn, width, dtype=np.float64):
+        out = np.zeros((self.n_envs, width), dtype=dtype)
+        _lib.check(fn(self._h, _lib.ptr(out)))
+        return out
+
+    @property
+    def qpos(self) -> np.ndarray:
+        return self._get(self._L.rcsh_sim_get_qpos, self.model.nq)
+
+    @property
+    def qvel(self) -> np.ndarray:
+        return self._get(self._L.rcsh_sim_get_qvel, self.model.nv)
+
+    @property
+    def ctrl(self) -> np.ndarray:
+        return self._get(self._L.rcsh_sim_get_ctrl, self.model.nu)
+
+    @property
+    def time(self) -> np.ndarray:
+        return self._get(self._L.rcsh_sim_get_time, 1)[:, 0]
+
+    def set_qpos(self, qpos, mask=None) -> None:
+        q = np.ascontiguousarray(np.broadcast_to(np.asarray(qpos, dtype=np.float64), (self.n_envs, self.model.nq)))
+        _lib.check(self._L.rcsh_sim_set_qpos(self._h, _lib.ptr(q), _lib.ptr(_mask(mask, self.n_envs))))
+
+    def set_qvel(self, qvel, mask=None) -> None:
+        q = np.ascontiguousarray(np.broadcast_to(np.asarray(qvel, dtype=np.float64), (self.n_envs, self.model.nv)))
+        _lib.check(self._L.rcsh_sim_set_qvel(self._h, _lib.ptr(q), _lib.ptr(_mask(mask, self.n_envs))))
+
+
+@dataclass
+class SimRobotConfig(common.RobotConfig):  # reference src/sim/SimRobot.h:14-47
+    joint_rotational_tolerance: float = 0.05 * (math.pi / 180.0)
+    seconds_between_callbacks: float = 0.1
+    trajectory_trace: bool = False
+    arm_collision_geoms: list[str] = field(default_factory=lambda: [f"fr3_link{i}_collision" for i in range(8)])
+    joints: list[str] = field(default_factory=lambda: [f"fr3_joint{i}" for i in range(1, 8)])
+    actuators: list[str] = field(default_factory=lambda: [f"fr3_joint{i}" for i in range(1, 8)])
+    base: str = "base"
+    mjcf_scene_path: str = "assets/scenes/fr3_empty_world/scene.xml"
+
+    def add_id(self, id: str) -> None:  # noqa: A002  (reference name)
+        self.arm_collision_geoms = [f"{s}_{id}" for s in self.arm_collision_geoms]
+        self.joints = [f"{s}_{id}" for s in self.joints]
+        self.actuators = [f"{s}_{id}" for s in self.actuators]
+        self.attachment_site = f"{self.attachment_site}_{id}"
+        self.base = f"{self.base}_{id}"
+
+
+@dataclass
+class SimRobotState:  # SimRobot.h:49-57, one entry per environment
+    previous_angles: np.ndarray
+    target_angles: np.ndarray
+    inverse_tcp_offset: common.Pose
+    ik_success: np.ndarray
+    collision: np.ndarray
+    is_moving: np.ndarray
+    is_arrived: np.ndarray
+
+
+def _lookup(model: Model, kind: str, name: str, label: str) -> int:
+    i = model.name2id(kind, name)
+    if i < 0:
+        raise RuntimeError(f"No {label} named {name}")  # SimRobot.cpp:57-93
+    return i
+
+
+class SimRobot:
+    """``rcs.sim.SimRobot(sim, ik, cfg, register_convergence_callback=True)`` (rcs.cpp:516-527)."""
+
+    def __init__(self, sim: Sim, ik, cfg: SimRobotConfig, register_convergence_callback: bool = True):
+        self.sim = sim
+        self._ik = ik
+        self._cfg = cfg
+        self._L = sim._L
+        m = sim.model
+        for g in cfg.arm_collision_geoms:
+            _lookup(m, "geom", g, "geom")
+        site = _lookup(m, "site", cfg.attachment_site, "site")
+        base = _lookup(m, "body", cfg.base, "body")
+        joints = np.array([_lookup(m, "jnt", j, "joint") for j in cfg.joints], dtype=np.int32)
+        acts = np.array([_lookup(m, "actuator", a, "actuator") for a in cfg.actuators], dtype=np.int32)
+        meta = common.robots_meta_config(cfg.robot_type)
+        self.dof = len(joints)
+        q_home = np.ascontiguousarray(meta.q_home[: self.dof], dtype=np.float64)
+        d = _lib.RobotDesc()
+        d.dof = self.dof
+        d.joint_ids = joints.ctypes.data_as(C.POINTER(C.c_int32))
+        d.actuator_ids = acts.ctypes.data_as(C.POINTER(C.c_int32))
+        d.attachment_site, d.base_body = site, base
+        d.q_home = q_home.ctypes.data_as(C.POINTER(C.c_double))
+        d.tcp_offset[:] = [float(x) for x in cfg.tcp_offset.as_vec7()]
+        d.joint_rotational_tolerance = cfg.joint_rotational_tolerance
+        d.seconds_between_callbacks = cfg.seconds_between_callbacks
+        d.register_convergence_callback = int(register_convergence_callback)
+        _lib.check(self._L.rcsh_sim_add_robot(sim._h, C.byref(d)))
+
+    @property
+    def n_envs(self) -> int:
+        return self.sim.n_envs
+
+    def _q(self, q):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(q, dtype=np.float64)[..., : self.dof], (self.n_envs, self.dof)))
+
+    def get_config(self) -> SimRobotConfig:
+        return self._cfg
+
+    def get_state(self) -> SimRobotState:
+        n = self.n_envs
+        ik, col, mov, arr = (np.zeros(n, dtype=np.uint8) for _ in range(4))
+        prev, tgt = np.zeros((n, self.dof)), np.zeros((n, self.dof))
+        _lib.check(self._L.rcsh_robot_get_state(self.sim._h, _lib.ptr(ik), _lib.ptr(col), _lib.ptr(mov), _lib.ptr(arr),
+                                                _lib.ptr(prev), _lib.ptr(tgt)))
+        return SimRobotState(prev, tgt, self._cfg.tcp_offset.inverse(), ik.astype(bool), col.astype(bool), mov.astype(bool),
+                             arr.astype(bool))
+
+    def get_cartesian_position(self) -> np.ndarray:
+        """[n_envs, 7] x y z qx qy qz qw, robot frame, TCP offset applied (SimRobot.cpp:114-121)."""
+        out = np.zeros((self.n_envs, 7))
+        _lib.check(self._L.rcsh_robot_get_cartesian_position(self.sim._h, _lib.ptr(out)))
+        return out
+
+    def get_cartesian_pose(self, env: int = 0) -> common.Pose:
+        v = self.get_cartesian_position()[env]
+        return common.Pose(translation=v[:3], quaternion=v[3:])
+
+    def set_joint_position(self, q, mask=None) -> None:
+        _lib.check(self._L.rcsh_robot_set_joint_position(self.sim._h, _lib.ptr(self._q(q)), _lib.ptr(_mask(mask, self.n_envs))))
+
+    def get_joint_position(self) -> np.ndarray:
+        out = np.zeros((self.n_envs, self.dof))
+        _lib.check(self._L.rcsh_robot_get_joint_position(self.sim._h, _lib.ptr(out)))
+        return out
+
+    def move_home(self, mask=None) -> None:
+        _lib.check(self._L.rcsh_robot_move_home(self.sim._h, _lib.ptr(_mask(mask, self.n_envs))))
+
+    def reset(self, mask=None) -> None:
+        _lib.check(self._L.rcsh_robot_reset(self.sim._h, _lib.ptr(_mask(mask, self.n_envs))))
+
+    def close(self) -> None:
+        pass
+
+    def set_cartesian_position(self, pose, mask=None) -> None:
+        if isinstance(pose, common.Pose):
+            pose = pose.as_vec7()
+        p = np.ascontiguousarray(np.broadcast_to(np.asarray(pose, dtype=np.float64), (self.n_envs, 7)))
+        _lib.check(self._L.rcsh_robot_set_cartesian_position(self.sim._h, _lib.ptr(p), _lib.ptr(_mask(mask, self.n_envs))))
+
+    def get_ik(self):
+        return self._ik
+
+    def get_base_pose_in_world_coordinates(self) -> common.Pose:
+        out = np.zeros((self.n_envs, 7))
+        _lib.check(self._L.rcsh_robot_get_base_pose(self.sim._h, _lib.ptr(out)))
+        return common.Pose(translation=out[0, :3], quaternion=out[0, 3:])
+
+    def to_pose_in_robot_coordinates(self, pose_in_world_coordinates: common.Pose) -> common.Pose:
+        return self.get_base_pose_in_world_coordinates().inverse() * pose_in_world_coordinates
+
+    def to_pose_in_world_coordinates(self, pose_in_robot_coordinates: common.Pose) -> common.Pose:
+        return self.get_base_pose_in_world_coordinates() * pose_in_robot_coordinates
+
+    def set_joints_hard(self, q, mask=None) -> None:
+        _lib.check(self._L.rcsh_robot_set_joints_hard(self.sim._h, _lib.ptr(self._q(q)), _lib.ptr(_mask(mask, self.n_envs))))
+
+
+@dataclass
+class SimGripperConfig:  # reference src/sim/SimGripper.h:15-45
+    epsilon_inner: float = 0.005
+    epsilon_outer: float = 0.005
+    seconds_between_callbacks: float = 0.05
+    max_actuator_width: float = 255
+    min_actuator_width: float = 0
+    max_joint_width: float = 0.04
+    min_joint_width: float = 0.0
+    ignored_collision_geoms: list[str] = field(default_factory=list)
+    collision_geoms: list[str] = field(default_factory=lambda: ["hand_c", "d435i_collision", "finger_0_left", "finger_0_right"])
+    collision_geoms_fingers: list[str] = field(default_factory=lambda: ["finger_0_left", "finger_0_right"])
+    joint: str = "finger_joint1"
+    actuator: str = "actuator8"
+
+    def add_id(self, id: str) -> None:  # noqa: A002
+        self.collision_geoms = [f"{s}_{id}" for s in self.collision_geoms]
+        self.collision_geoms_fingers = [f"{s}_{id}" for s in self.collision_geoms_fingers]
+        self.ignored_collision_geoms = [f"{s}_{id}" for s in self.ignored_collision_geoms]
+        self.joint = f"{self.joint}_{id}"
+        self.actuator = f"{self.actuator}_{id}"
+
+
+@dataclass
+class SimGripperState:  # SimGripper.h:47-52, one entry per environment
+    last_commanded_width: np.ndarray
+    is_moving: np.ndarray
+    last_width: np.ndarray
+    collision: np.ndarray
+
+
+class SimGripper:
+    """``rcs.sim.SimGripper(sim, cfg)`` (rcs.cpp:508-515)."""
+
+    def __init__(self, sim: Sim, cfg: SimGripperConfig):
+        self.sim = sim
+        self._cfg = cfg
+        self._L = sim._L
+        m = sim.model
+        act = _lookup(m, "actuator", cfg.actuator, "actuator")
+        jnt = _lookup(m, "jnt", cfg.joint, "joint")
+        for g in list(cfg.collision_geoms) + list(cfg.collision_geoms_fingers):
+            _lookup(m, "geom", g, "geom")
+        d = _lib.GripperDesc(jnt, act, cfg.epsilon_inner, cfg.epsilon_outer, cfg.seconds_between_callbacks,
+                             cfg.max_actuator_width, cfg.min_actuator_width, cfg.max_joint_width, cfg.min_joint_width)
+        _lib.check(self._L.rcsh_sim_add_gripper(sim._h, C.byref(d)))
+
+    @property
+    def n_envs(self) -> int:
+        return self.sim.n_envs
+
+    def get_config(self) -> SimGripperConfig:
+        return self._cfg
+
+    def get_state(self) -> SimGripperState:
+        n = self.n_envs
+        lc, lw = np.zeros(n), np.zeros(n)
+        mv, col = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        _lib.check(self._L.rcsh_gripper_get_state(self.sim._h, _lib.ptr(lc), _lib.ptr(mv), _lib.ptr(lw), _lib.ptr(col)))
+        return SimGripperState(lc, mv.astype(bool), lw, col.astype(bool))
+
+    def set_normalized_width(self, width, force: float = 0.0, mask=None) -> None:
+        w = np.ascontiguousarray(np.broadcast_to(np.asarray(width, dtype=np.float64), (self.n_envs,)))
+        _lib.check(self._L.rcsh_gripper_set_normalized_width(self.sim._h, _lib.ptr(w), float(force), _lib.ptr(_mask(mask, self.n_envs))))
+
+    def get_normalized_width(self) -> np.ndarray:
+        out = np.zeros(self.n_envs)
+        _lib.check(self._L.rcsh_gripper_get_normalized_width(self.sim._h, _lib.ptr(out)))
+        return out
+
+    def is_grasped(self) -> np.ndarray:
+        out = np.zeros(self.n_envs, dtype=np.uint8)
+        _lib.check(self._L.rcsh_gripper_is_grasped(self.sim._h, _lib.ptr(out)))
+        return out.astype(bool)
+
+    def grasp(self, mask=None) -> None:
+        self.shut(mask)
+
+    def open(self, mask=None) -> None:
+        self.set_normalized_width(1.0, mask=mask)
+
+    def shut(self, mask=None) -> None:
+        self.set_normalized_width(0.0, mask=mask)
+
+    def reset(self, mask=None) -> None:
+        _lib.check(self._L.rcsh_gripper_reset(self.sim._h, _lib.ptr(_mask(mask, self.n_envs))))
+
+    def close(self) -> None:
+        pass
