@@ -148,8 +148,10 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
 void rcsh_sim_destroy(rcsh_sim* sim);
 int rcsh_sim_num_envs(const rcsh_sim* sim);
 int rcsh_sim_synchronize(rcsh_sim* sim);
-/* the HIP stream (hipStream_t) all work of this handle is enqueued on */
+/* the HIP stream (hipStream_t) all work of this handle is enqueued on; set_stream adopts a caller-owned
+ * stream (e.g. the host framework's current stream, so its collectives order after the env-step kernel) */
 void* rcsh_sim_stream(rcsh_sim* sim);
+int rcsh_sim_set_stream(rcsh_sim* sim, void* hip_stream);
 
 /* Sim.set_config / get_config -- rcs.cpp:500-501, sim.cpp:27-32; SimConfig sim.h:29-34 */
 int rcsh_sim_set_config(rcsh_sim* sim, int32_t async_control, int32_t realtime, int32_t frequency,

@@ -37,6 +37,7 @@ constexpr int kProfRing = 4096;
 struct rcsh_sim {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
   int n = 0;
   HostModel hm;
   DevModel dm;
@@ -255,7 +256,8 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
     if (_e != hipSuccess) return cleanup(RCSH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
   HIP_NEW(hipSetDevice(device));
-  HIP_NEW(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_NEW(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+  s->stream = s->own_stream;
   const size_t n = (size_t)n_envs;
   HIP_NEW(hipMalloc(&s->d_model, sizeof(DevModel)));
   HIP_NEW(hipMalloc(&s->S, sizeof(double) * n * s->nfields));
@@ -295,7 +297,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
-  if (s->stream) hipStreamDestroy(s->stream);
+  if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
 }
 
@@ -303,6 +305,13 @@ int rcsh_sim_num_envs(const rcsh_sim* s) { return s ? s->n : 0; }
 int rcsh_sim_nq(const rcsh_sim* s) { return s ? s->nl : 0; }
 int rcsh_sim_nu(const rcsh_sim* s) { return s ? (int)s->act_slot.size() : 0; }
 void* rcsh_sim_stream(rcsh_sim* s) { return s ? (void*)s->stream : nullptr; }
+
+int rcsh_sim_set_stream(rcsh_sim* s, void* hip_stream) {
+  REQUIRE_SIM(s);
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  return RCSH_OK;
+}
 
 int rcsh_sim_synchronize(rcsh_sim* s) {
   REQUIRE_SIM(s);

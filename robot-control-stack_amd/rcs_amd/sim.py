@@ -98,6 +98,10 @@ class Sim:
     def reset(self, mask=None) -> None:
         _lib.check(self._L.rcsh_sim_reset(self._h, _lib.ptr(_mask(mask, self.n_envs))))
 
+    def set_stream(self, hip_stream: int | None) -> None:
+        """Enqueue all further work on a caller-owned HIP stream (None: back to the handle's own stream)."""
+        _lib.check(self._L.rcsh_sim_set_stream(self._h, C.c_void_p(hip_stream)))
+
     def synchronize(self) -> None:
         _lib.check(self._L.rcsh_sim_synchronize(self._h))
 
