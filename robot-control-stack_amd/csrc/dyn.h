@@ -52,6 +52,8 @@ constexpr double kMinImp = 0.0001;
 constexpr double kMaxImp = 0.9999;
 
 RCSH_HD double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+RCSH_HD double fast_rcp(double x);
+RCSH_HD void fast_sincos(double x, double* sn, double* cs);
 
 RCSH_HD void cross3(const double* a, const double* b, double* r) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
@@ -102,10 +104,34 @@ RCSH_HD void cross_force(const double* vel, const double* f, double* r) {
   cross3(vel, f + 3, r + 3);
 }
 
+// ---- staging area for what must survive from the forward to the backward sweep (per-link spatial
+// inertia, bias wrench, gravity-compensation moment) plus the mass matrix, which two factorisations
+// consume.  On the GPU it is one column of an LDS array laid out [slot][lane] (STRIDE = 64: a wave's
+// accesses to one slot are 64 consecutive 8-byte words, conflict-free, and the slot index is an
+// immediate offset); on the host (model finalisation) it is a plain array (STRIDE = 1).
+template <class T, int STRIDE>
+struct Stage {
+  static constexpr int I0 = 0;
+  static constexpr int F0 = I0 + 10 * T::NL;
+  static constexpr int H0 = F0 + 6 * T::NL;
+  static constexpr int M0 = H0 + 3 * T::NL;
+  static constexpr int S0 = M0 + T::NTRI;
+  static constexpr int X0 = S0 + 6 * T::NL;   // caller's slots (sim_kernels.h parks rarely-touched state here)
+  static constexpr int NX = 6 + 2 * T::NARM;
+  static constexpr int COUNT = X0 + NX;
+  double* base;
+  RCSH_HD double& S(int i, int k) const { return base[(S0 + 6 * i + k) * STRIDE]; }
+  RCSH_HD double& X(int k) const { return base[(X0 + k) * STRIDE]; }
+  RCSH_HD double& I(int i, int k) const { return base[(I0 + 10 * i + k) * STRIDE]; }
+  RCSH_HD double& f(int i, int k) const { return base[(F0 + 6 * i + k) * STRIDE]; }
+  RCSH_HD double& hg(int i, int k) const { return base[(H0 + 3 * i + k) * STRIDE]; }
+  RCSH_HD double& M(int k) const { return base[(M0 + k) * STRIDE]; }  // packed lower triangle, incl. armature
+};
+
 // ---- results of the position + velocity stage that the rest of the substep consumes
+// (the mass matrix goes to Stage::M)
 template <class T>
 struct Smooth {
-  double M[T::NTRI];    // joint-space inertia incl. armature, packed lower triangle
   double bias[T::NL];   // Coriolis + centrifugal + gravity
   double gc[T::NL];     // gravity-compensation generalized force
   double linkR[9];      // world frame of the link carrying the attachment site
@@ -113,12 +139,12 @@ struct Smooth {
 };
 
 // Position + velocity stage.  Forward sweep root->leaves builds, per link, the world frame, the
-// motion axis S, the spatial inertia I and the bias wrench f; the backward sweep leaves->root sums
-// composite inertias / wrenches and projects them on the axes.
-template <class T>
-RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* qd, Smooth<T>& out) {
+// motion axis S (kept in registers), the spatial inertia I and the bias wrench f (staged); the backward
+// sweep leaves->root carries running subtree sums in registers and projects them on the axes.
+template <class T, int STRIDE>
+RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* qd, const Stage<T, STRIDE>& st,
+                             Smooth<T>& out) {
   constexpr int NL = T::NL;
-  double S[NL][6], I[NL][10], f[NL][6], hg[NL][3];
   // frames of the arm chain tip are reused by both fingers, so one running copy suffices
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
   double vel[6] = {0, 0, 0, 0, 0, 0};
@@ -150,7 +176,7 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
     double ax[3];
     mulmv(R0, m.axis[i], ax);
     const double dq = q[i] - m.qpos0[i];
-    double* Si = S[i];
+    double Si[6];
     if (m.jtype[i] == kSlide) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) R[k] = R0[k];
@@ -159,7 +185,7 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
     } else {
       // Rodrigues rotation about the link-frame axis
       double s, c;
-      sincos(dq, &s, &c);
+      fast_sincos(dq, &s, &c);
       const double* a = m.axis[i];
       const double t = 1.0 - c;
       double Q[9] = {c + t * a[0] * a[0],        t * a[0] * a[1] - s * a[2], t * a[0] * a[2] + s * a[1],
@@ -185,16 +211,16 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
     mulmv(R, m.com[i], c);
     c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
     mulmv(R, m.gccom[i], cg);
-    hg[i][0] = m.gcm[i] * (cg[0] + p[0]);
-    hg[i][1] = m.gcm[i] * (cg[1] + p[1]);
-    hg[i][2] = m.gcm[i] * (cg[2] + p[2]);
+    st.hg(i, 0) = m.gcm[i] * (cg[0] + p[0]);
+    st.hg(i, 1) = m.gcm[i] * (cg[1] + p[1]);
+    st.hg(i, 2) = m.gcm[i] * (cg[2] + p[2]);
+    double Ii[10];
     {
       const double* J = m.inertia[i];
       const double Jm[9] = {J[0], J[3], J[4], J[3], J[1], J[5], J[4], J[5], J[2]};
       double Tm[9];
       mulmm(R, Jm, Tm);
       const double ms = m.mass[i];
-      double* Ii = I[i];
       Ii[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2] + ms * (c[1] * c[1] + c[2] * c[2]);
       Ii[1] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5] + ms * (c[0] * c[0] + c[2] * c[2]);
       Ii[2] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8] + ms * (c[0] * c[0] + c[1] * c[1]);
@@ -203,7 +229,11 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
       Ii[5] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8] - ms * c[1] * c[2];
       Ii[6] = ms * c[0]; Ii[7] = ms * c[1]; Ii[8] = ms * c[2];
       Ii[9] = ms;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) st.I(i, k) = Ii[k];
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st.S(i, k) = Si[k];
     // velocity, bias acceleration (S x S = 0, so the parent's velocity is enough), bias wrench
     double sd[6];
     cross_motion(vel, Si, sd);
@@ -213,42 +243,51 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
       acc[k] += sd[k] * qd[i];
     }
     double Ia[6], Iv[6], vf[6];
-    inert_mul(I[i], acc, Ia);
-    inert_mul(I[i], vel, Iv);
+    inert_mul(Ii, acc, Ia);
+    inert_mul(Ii, vel, Iv);
     cross_force(vel, Iv, vf);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) f[i][k] = Ia[k] + vf[k];
+    for (int k = 0; k < 6; ++k) st.f(i, k) = Ia[k] + vf[k];
   }
-  // backward sweep
+  // backward sweep: Ic / fs / hs are the sums over the links visited so far.  Links are visited
+  // leaves first (fingers, then the arm from tip to base), so for an arm link the running sums are
+  // exactly its subtree; a finger is a leaf and projects its own values only.
   const double* g = m.gravity;
+  const double ng[3] = {-g[0], -g[1], -g[2]};
+  double Ic[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fs[6] = {0, 0, 0, 0, 0, 0}, hs[3] = {0, 0, 0};
 #pragma unroll
   for (int i = NL - 1; i >= 0; --i) {
-    double F[6];
-    inert_mul(I[i], S[i], F);
-    out.M[tri(i, i)] = dot6(S[i], F) + m.armature[i];
+    double Il[10], fl[6], hl[3];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { Il[k] = st.I(i, k); Ic[k] += Il[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { fl[k] = st.f(i, k); fs[k] += fl[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { hl[k] = st.hg(i, k); hs[k] += hl[k]; }
+    const bool leaf = T::GRIP && i >= T::NARM;
+    const double* Iu = leaf ? Il : Ic;
+    const double* fu = leaf ? fl : fs;
+    const double* hu = leaf ? hl : hs;
+    double F[6], Sl[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Sl[k] = st.S(i, k);
+    inert_mul(Iu, Sl, F);
+    st.M(tri(i, i)) = dot6(Sl, F) + m.armature[i];
     // ancestors: for the arm that is every j < i; a finger's ancestors are all arm links
 #pragma unroll
-    for (int j = (i >= T::NARM ? T::NARM - 1 : i - 1); j >= 0; --j) out.M[tri(i, j)] = dot6(S[j], F);
-    if (T::GRIP && i == T::NARM + 1) out.M[tri(i, i - 1)] = 0.0;  // the fingers are siblings
-    out.bias[i] = dot6(S[i], f[i]);
-    // gravity compensation wrench of the subtree: force -g*sum(gcm), moment sum(gcm*c) x (-g)
-    {
-      double w[6];
-      const double msub = m.gcm_sub[i];
-      double ng[3] = {-g[0], -g[1], -g[2]};
-      cross3(hg[i], ng, w);
-      w[3] = msub * ng[0]; w[4] = msub * ng[1]; w[5] = msub * ng[2];
-      out.gc[i] = dot6(S[i], w);
+    for (int j = (i >= T::NARM ? T::NARM - 1 : i - 1); j >= 0; --j) {
+      double Sj[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Sj[k] = st.S(j, k);
+      st.M(tri(i, j)) = dot6(Sj, F);
     }
-    const int pa = T::parent(i);
-    if (pa >= 0) {
-#pragma unroll
-      for (int k = 0; k < 10; ++k) I[pa][k] += I[i][k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) f[pa][k] += f[i][k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) hg[pa][k] += hg[i][k];
-    }
+    if (T::GRIP && i == T::NARM + 1) st.M(tri(i, i - 1)) = 0.0;  // the fingers are siblings
+    out.bias[i] = dot6(Sl, fu);
+    // gravity compensation wrench of the subtree: force -g * sum(gcm), moment sum(gcm * c) x (-g)
+    double w[6];
+    cross3(hu, ng, w);
+    w[3] = m.gcm_sub[i] * ng[0]; w[4] = m.gcm_sub[i] * ng[1]; w[5] = m.gcm_sub[i] * ng[2];
+    out.gc[i] = dot6(Sl, w);
   }
 }
 
@@ -266,7 +305,7 @@ RCSH_HD void ldl_factor(double* A) {
       d -= A[tri(j, k)] * w[k];
     }
     D[j] = d;
-    const double inv = 1.0 / d;
+    const double inv = fast_rcp(d);
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
       double t = A[tri(i, j)];
@@ -293,47 +332,83 @@ RCSH_HD void ldl_solve(const double* A, double* x) {
   }
 }
 
-// solimp -> impedance at distance |pos - margin| (the sigmoid MuJoCo documents for solimp)
-RCSH_HD double impedance(const double* solimp, double pos, double margin) {
-  double d0 = clampd(solimp[0], kMinImp, kMaxImp), d1 = clampd(solimp[1], kMinImp, kMaxImp);
-  double width = solimp[2] < 0 ? 0 : solimp[2];
-  double mid = clampd(solimp[3], kMinImp, kMaxImp);
-  double power = solimp[4] < 1 ? 1 : solimp[4];
-  if (d0 == d1 || width <= kMinVal) return 0.5 * (d0 + d1);
-  double x = fabs((pos - margin) / width);
-  if (x >= 1) return d1;
-  if (x <= 0) return d0;
-  double y;
-  if (power == 1) y = x;
-  else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
-  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
-  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
-  return d0 + y * (d1 - d0);
+// 1/x to full double precision without the IEEE division sequence (hardware seed + two Newton steps)
+RCSH_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
 }
-// solref -> stiffness K and damping B of the reference acceleration
-RCSH_HD void ref_kb(const double* solref, const double* solimp, double timestep, double& K, double& B) {
-  double dmax = clampd(solimp[1], kMinImp, kMaxImp);
-  double tc = solref[0], dr = solref[1];
-  if (tc > 0) {
-    if (tc < 2 * timestep) tc = 2 * timestep;
-    double kd = dmax * dmax * tc * tc * dr * dr, bd = dmax * tc;
-    K = 1.0 / (kd > kMinVal ? kd : kMinVal);
-    B = 2.0 / (bd > kMinVal ? bd : kMinVal);
-  } else {
-    K = -tc / (dmax * dmax);
-    B = -dr / dmax;
-  }
+
+// sin and cos of a joint angle.  Cody-Waite reduction by pi/2 (33-bit pieces, exact for |x| < 2^20)
+// followed by the classic minimax kernels on [-pi/4, pi/4]; < 1 ulp, no table, no slow path.
+RCSH_HD void fast_sincos(double x, double* sn, double* cs) {
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  const double r = fma(-fn, 1.57079632673412561417e+00, x);
+  const double w = fn * 6.07710050650619224932e-11;
+  const double y0 = r - w;
+  const double y1 = (r - y0) - w;
+  const double z = y0 * y0;
+  // sin kernel
+  const double v = z * y0;
+  const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                    z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+  // cos kernel
+  const double w2 = z * z;
+  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                    (w2 * w2) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+  const double hz = 0.5 * z;
+  const double w1 = 1.0 - hz;
+  const double kc = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
+  const int n = ((int)fn) & 3;
+  const double s_ = (n & 1) ? kc : ks;
+  const double c_ = (n & 1) ? ks : kc;
+  *sn = (n & 2) ? -s_ : s_;
+  *cs = ((n + 1) & 2) ? -c_ : c_;
+}
+
+// general-power branch of the impedance sigmoid, kept out of line: the RCS scenes use power 2
+#if defined(__HIP__)
+__host__ __device__ __attribute__((noinline))
+#endif
+inline double impedance_general(const Imp& p, double x) {
+  if (x <= p.mid) return pow(x, p.power) / pow(p.mid, p.power - 1);
+  return 1 - pow(1 - x, p.power) / pow(1 - p.mid, p.power - 1);
+}
+
+// solimp -> impedance at distance |pos - margin| (the sigmoid MuJoCo documents for solimp)
+RCSH_HD double impedance(const Imp& p, double pos, double margin) {
+  if (p.mode == 0) return 0.5 * (p.d0 + p.d1);
+  const double x = fabs((pos - margin) * p.inv_width);
+  if (x >= 1) return p.d1;
+  if (x <= 0) return p.d0;
+  double y;
+  if (p.mode == 1) y = x;
+  else if (p.mode == 2) y = x <= p.mid ? x * x * p.inv_mid : 1 - (1 - x) * (1 - x) * p.inv_1mmid;
+  else y = impedance_general(p, x);
+  return p.d0 + y * (p.d1 - p.d0);
+}
+// regulariser R = (1 - imp) / imp * diagApprox, floored; returns D = 1 / R
+RCSH_HD double row_D(double imp, double invweight) {
+  const double num = (1 - imp) * invweight;
+  return num < kMinVal * imp ? 1.0 / kMinVal : imp * fast_rcp(num);
 }
 
 // One physics substep: advances q, qd by one timestep under controls `ctrl`.
 // `sm` carries the frames of the site link computed from the PRE-step q (the reference reads
 // site_xpos/xmat of the last mj_step1).
-template <class T>
-RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctrl, Smooth<T>& sm) {
+template <class T, int STRIDE>
+RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctrl, const Stage<T, STRIDE>& st,
+                     Smooth<T>& sm) {
   constexpr int NL = T::NL;
   constexpr int NA = T::NARM;
   const double h = m.timestep;
-  smooth_dynamics<T>(m, q, qd, sm);
+  smooth_dynamics<T, STRIDE>(m, q, qd, st, sm);
 
   // ---- actuation: affine actuators, force limits, actuator-side gravity compensation, joint clamp
   double tau[NL];      // qfrc_actuator
@@ -391,13 +466,9 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
     const double deriv = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
     const double pos = q[NA] - m.qpos0[NA] - poly;
     eqJ1 = -deriv;
-    double K, B;
-    ref_kb(m.eq_solref, m.eq_solimp, h, K, B);
-    const double imp = impedance(m.eq_solimp, pos, 0.0);
-    double Rr = (1 - imp) / imp * (m.invweight0[NA] + m.invweight0[NA + 1]);
-    if (Rr < kMinVal) Rr = kMinVal;
-    eqD = 1.0 / Rr;
-    eqAref = -K * imp * pos - B * (qd[NA] + eqJ1 * qd[NA + 1]);
+    const double imp = impedance(m.eq_imp, pos, 0.0);
+    eqD = row_D(imp, m.invweight0[NA] + m.invweight0[NA + 1]);
+    eqAref = -m.eq_K * imp * pos - m.eq_B * (qd[NA] + eqJ1 * qd[NA + 1]);
   }
   double limD[NL], limAref[NL], limSign[NL];  // limSign 0: no row
 #pragma unroll
@@ -409,13 +480,9 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
     if (dlo < m.margin[i]) { dist = dlo; sgn = 1; }
     else if (dhi < m.margin[i]) { dist = dhi; sgn = -1; }
     if (sgn != 0) {
-      double K, B;
-      ref_kb(m.lim_solref[i], m.lim_solimp[i], h, K, B);
-      const double imp = impedance(m.lim_solimp[i], dist, m.margin[i]);
-      double Rr = (1 - imp) / imp * m.invweight0[i];
-      if (Rr < kMinVal) Rr = kMinVal;
-      limD[i] = 1.0 / Rr;
-      limAref[i] = -K * imp * (dist - m.margin[i]) - B * (sgn * qd[i]);
+      const double imp = impedance(m.lim_imp[i], dist, m.margin[i]);
+      limD[i] = row_D(imp, m.invweight0[i]);
+      limAref[i] = -m.lim_K[i] * imp * (dist - m.margin[i]) - m.lim_B[i] * (sgn * qd[i]);
       limSign[i] = sgn;
     }
   }
@@ -435,7 +502,7 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
     for (int iter = 0; iter < 8; ++iter) {
       double H[T::NTRI];
 #pragma unroll
-      for (int k = 0; k < T::NTRI; ++k) H[k] = sm.M[k];
+      for (int k = 0; k < T::NTRI; ++k) H[k] = st.M(k);
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         qacc[i] = smooth[i];
@@ -473,7 +540,7 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
   {
     double A[T::NTRI];
 #pragma unroll
-    for (int k = 0; k < T::NTRI; ++k) A[k] = sm.M[k];
+    for (int k = 0; k < T::NTRI; ++k) A[k] = st.M(k);
     double rhs[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {

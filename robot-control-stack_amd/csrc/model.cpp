@@ -65,17 +65,55 @@ void mat_to_quat_wxyz(const double* m, double* q) {
   for (int k = 0; k < 4; ++k) q[k] /= n;
 }
 
+// solimp -> kernel-side form (clamps follow MuJoCo's: d0, d1, midpoint in [0.0001, 0.9999], width >= 0, power >= 1)
+Imp make_imp(const double* solimp) {
+  Imp p;
+  p.d0 = clampd(solimp[0], kMinImp, kMaxImp);
+  p.d1 = clampd(solimp[1], kMinImp, kMaxImp);
+  const double width = solimp[2] < 0 ? 0 : solimp[2];
+  p.mid = clampd(solimp[3], kMinImp, kMaxImp);
+  p.power = solimp[4] < 1 ? 1 : solimp[4];
+  p.inv_width = width > kMinVal ? 1.0 / width : 0.0;
+  p.inv_mid = 1.0 / p.mid;
+  p.inv_1mmid = 1.0 / (1.0 - p.mid);
+  p.pad = 0;
+  if (p.d0 == p.d1 || width <= kMinVal) p.mode = 0;
+  else if (p.power == 1) p.mode = 1;
+  else if (p.power == 2) p.mode = 2;
+  else p.mode = 3;
+  return p;
+}
+
+// solref -> stiffness K and damping B of the reference acceleration (timeconst floored at 2 timesteps)
+void make_kb(const double* solref, const double* solimp, double timestep, double& K, double& B) {
+  const double dmax = clampd(solimp[1], kMinImp, kMaxImp);
+  double tc = solref[0];
+  const double dr = solref[1];
+  if (tc > 0) {
+    if (tc < 2 * timestep) tc = 2 * timestep;
+    const double kd = dmax * dmax * tc * tc * dr * dr, bd = dmax * tc;
+    K = 1.0 / (kd > kMinVal ? kd : kMinVal);
+    B = 2.0 / (bd > kMinVal ? bd : kMinVal);
+  } else {
+    K = -tc / (dmax * dmax);
+    B = -dr / dmax;
+  }
+}
+
 template <class T>
 void compute_invweight0(DevModel& m) {
   double q[T::NL], qd[T::NL];
   for (int i = 0; i < T::NL; ++i) { q[i] = m.qpos0[i]; qd[i] = 0; }
   Smooth<T> sm;
-  smooth_dynamics<T>(m, q, qd, sm);
-  ldl_factor<T::NL>(sm.M);
+  double buf[Stage<T, 1>::COUNT];
+  Stage<T, 1> st{buf};
+  smooth_dynamics<T, 1>(m, q, qd, st, sm);
+  double* M = &st.M(0);
+  ldl_factor<T::NL>(M);
   for (int j = 0; j < T::NL; ++j) {
     double e[T::NL];
     for (int i = 0; i < T::NL; ++i) e[i] = i == j ? 1.0 : 0.0;
-    ldl_solve<T::NL>(sm.M, e);
+    ldl_solve<T::NL>(M, e);
     m.invweight0[j] = e[j];
   }
 }
@@ -180,8 +218,10 @@ std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& ac
     m.limited[i] = h.jnt_limited[i];
     m.range[i][0] = h.jnt_range[2 * i]; m.range[i][1] = h.jnt_range[2 * i + 1];
     m.margin[i] = h.jnt_margin[i];
-    std::memcpy(m.lim_solref[i], &h.jnt_solref[2 * i], 2 * sizeof(double));
-    std::memcpy(m.lim_solimp[i], &h.jnt_solimp[5 * i], 5 * sizeof(double));
+    m.lim_imp[i] = make_imp(&h.jnt_solimp[5 * i]);
+    make_kb(&h.jnt_solref[2 * i], &h.jnt_solimp[5 * i], h.timestep, m.lim_K[i], m.lim_B[i]);
+    m.axis_z[i] = h.jnt_type[i] == kHinge && m.axis[i][0] == 0 && m.axis[i][1] == 0 && m.axis[i][2] == 1 &&
+                  m.jpos[i][0] == 0 && m.jpos[i][1] == 0 && m.jpos[i][2] == 0;
     m.actfrclimited[i] = h.jnt_actfrclimited[i];
     m.actfrcrange[i][0] = h.jnt_actfrcrange[2 * i]; m.actfrcrange[i][1] = h.jnt_actfrcrange[2 * i + 1];
     m.actgravcomp[i] = h.jnt_actgravcomp[i];
@@ -225,6 +265,9 @@ std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& ac
     m.inertia[i][3] = J[1]; m.inertia[i][4] = J[2]; m.inertia[i][5] = J[5];
     m.gcm[i] = gcm;
     for (int k = 0; k < 3; ++k) m.gccom[i][k] = gcm != 0 ? gmc[k] / gcm : 0.0;
+    m.gc_same_com[i] = 1;
+    for (int k = 0; k < 3; ++k)
+      if (m.gccom[i][k] != m.com[i][k]) m.gc_same_com[i] = 0;
   }
   // subtree gravcomp mass (constant): the link and all of its descendants
   for (int i = 0; i < nl; ++i) {
@@ -286,8 +329,8 @@ std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& ac
       return "only one joint equality coupling finger 1 to finger 2 is supported";
     m.eq_active = h.eq_active0[e];
     std::memcpy(m.eq_polycoef, &h.eq_data[5 * e], 5 * sizeof(double));
-    std::memcpy(m.eq_solref, &h.eq_solref[2 * e], 2 * sizeof(double));
-    std::memcpy(m.eq_solimp, &h.eq_solimp[5 * e], 5 * sizeof(double));
+    m.eq_imp = make_imp(&h.eq_solimp[5 * e]);
+    make_kb(&h.eq_solref[2 * e], &h.eq_solimp[5 * e], h.timestep, m.eq_K, m.eq_B);
   }
   // qpos0 constants
   bool ok = dispatch_topology(narm, grip, [&](auto topo) {

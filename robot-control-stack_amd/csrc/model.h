@@ -16,6 +16,16 @@ constexpr int kMaxArm = 8;
 
 enum JointKind : int32_t { kSlide = 2, kHinge = 3 };
 
+// solimp, preprocessed on the host so the kernel evaluates the impedance sigmoid without divisions
+struct Imp {
+  double d0, d1;        // impedance at zero / full penetration (clamped to [0.0001, 0.9999])
+  double inv_width;     // 1 / width
+  double mid, inv_mid, inv_1mmid;
+  double power;
+  int32_t mode;         // 0 constant (0.5 (d0 + d1)), 1 linear, 2 quadratic, 3 general power
+  int32_t pad;
+};
+
 // All members are wave-uniform in the kernels.  Fixed maximum sizes keep the struct a POD that is
 // copied to HBM once per GPU (a few KB); kernels template on the real sizes.
 struct DevModel {
@@ -45,8 +55,8 @@ struct DevModel {
   int32_t limited[kMaxLinks];
   double range[kMaxLinks][2];
   double margin[kMaxLinks];
-  double lim_solref[kMaxLinks][2];
-  double lim_solimp[kMaxLinks][5];
+  Imp lim_imp[kMaxLinks];
+  double lim_K[kMaxLinks], lim_B[kMaxLinks];  // reference-acceleration stiffness / damping (from solref)
   double invweight0[kMaxLinks];
   // joint-level actuator force clamp and gravity compensation routing
   int32_t actfrclimited[kMaxLinks];
@@ -75,8 +85,10 @@ struct DevModel {
   int32_t eq_active;
   int32_t pad1;
   double eq_polycoef[5];
-  double eq_solref[2];
-  double eq_solimp[5];
+  Imp eq_imp;
+  double eq_K, eq_B;
+  int32_t axis_z[kMaxLinks];    // joint axis is +z and the anchor is the link origin (every FR3 / xArm7 hinge)
+  int32_t gc_same_com[kMaxLinks];  // gccom == com (uniform gravcomp over the welded bodies)
   // ---- frames read by SimRobot
   int32_t site_link;  // link carrying the attachment site (-1: static)
   int32_t pad2;

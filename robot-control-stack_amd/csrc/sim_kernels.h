@@ -88,8 +88,14 @@ struct RunOp {
   int32_t* substeps;      // [n]
 };
 
+// Model tables live in the constant address space: every access is wave-uniform, so the compiler
+// fetches them with scalar loads into SGPRs instead of spending vector-memory instructions on them.
+// One slot per live rcsh_sim handle on a device.
+constexpr int kModelSlots = 8;
+__constant__ DevModel c_models[kModelSlots];
+
 struct Params {
-  const DevModel* model;
+  int32_t model_slot;
   double* S;
   uint32_t* flags;
   int32_t* conv_steps;
@@ -105,9 +111,13 @@ template <class T>
 struct EnvRegs {
   double q[T::NL], qd[T::NL], ctrl[T::NU];
   double time;
-  double cb[6];
-  double prevq[T::NARM], target[T::NARM];
   double last_cmd_width, last_width;
+  // callback timestamps, previous_angles and target_angles are touched once per 25-50 substeps:
+  // they live in the lane's LDS column (Stage::X), not in registers
+  Stage<T, 64> st;
+  __device__ __forceinline__ double& cb(int i) const { return st.X(i); }
+  __device__ __forceinline__ double& prevq(int i) const { return st.X(6 + i); }
+  __device__ __forceinline__ double& target(int i) const { return st.X(6 + T::NARM + i); }
   uint32_t flags;
   int32_t conv_steps;
 };
@@ -123,9 +133,9 @@ __device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T>& r) 
   for (int i = 0; i < T::NU; ++i) r.ctrl[i] = S[(L::CTRL + i) * n + e];
   r.time = S[L::TIME * n + e];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) r.cb[i] = S[(L::CB + i) * n + e];
+  for (int i = 0; i < 6; ++i) r.cb(i) = S[(L::CB + i) * n + e];
 #pragma unroll
-  for (int i = 0; i < T::NARM; ++i) { r.prevq[i] = S[(L::PREVQ + i) * n + e]; r.target[i] = S[(L::TARGET + i) * n + e]; }
+  for (int i = 0; i < T::NARM; ++i) { r.prevq(i) = S[(L::PREVQ + i) * n + e]; r.target(i) = S[(L::TARGET + i) * n + e]; }
   r.last_cmd_width = S[(L::GRIP + 0) * n + e];
   r.last_width = S[(L::GRIP + 1) * n + e];
   r.flags = P.flags[e];
@@ -143,9 +153,9 @@ __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<
   for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.ctrl[i];
   S[L::TIME * n + e] = r.time;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) S[(L::CB + i) * n + e] = r.cb[i];
+  for (int i = 0; i < 6; ++i) S[(L::CB + i) * n + e] = r.cb(i);
 #pragma unroll
-  for (int i = 0; i < T::NARM; ++i) { S[(L::PREVQ + i) * n + e] = r.prevq[i]; S[(L::TARGET + i) * n + e] = r.target[i]; }
+  for (int i = 0; i < T::NARM; ++i) { S[(L::PREVQ + i) * n + e] = r.prevq(i); S[(L::TARGET + i) * n + e] = r.target(i); }
   S[(L::GRIP + 0) * n + e] = r.last_cmd_width;
   S[(L::GRIP + 1) * n + e] = r.last_width;
   P.flags[e] = r.flags;
@@ -167,19 +177,19 @@ __device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T
 template <class T>
 __device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T>& r) {
   if (!(P.robot.present && P.robot.conv_registered)) return;
-  if (r.time - r.cb[0] > P.robot.period) {
+  if (r.time - r.cb(0) > P.robot.period) {
     double mx = 0;
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) mx = fmax(mx, fabs(r.q[i] - r.target[i]));
+    for (int i = 0; i < T::NARM; ++i) mx = fmax(mx, fabs(r.q[i] - r.target(i)));
     set_flag(r.flags, kIsArrived, mx < P.robot.tolerance);
-    r.cb[0] = r.time;
+    r.cb(0) = r.time;
   }
-  if (r.time - r.cb[1] > P.robot.period) {
+  if (r.time - r.cb(1) > P.robot.period) {
     double mx = 0;
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) { mx = fmax(mx, fabs(r.q[i] - r.prevq[i])); r.prevq[i] = r.q[i]; }
+    for (int i = 0; i < T::NARM; ++i) { mx = fmax(mx, fabs(r.q[i] - r.prevq(i))); r.prevq(i) = r.q[i]; }
     set_flag(r.flags, kIsMoving, mx > 0.0001);
-    r.cb[1] = r.time;
+    r.cb(1) = r.time;
   }
 }
 
@@ -190,28 +200,28 @@ __device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T>& r) 
 template <class T>
 __device__ __forceinline__ bool condition_callbacks(const Params& P, EnvRegs<T>& r) {
   const bool has_g = T::GRIP && P.grip.present;
-  if (P.robot.present && r.time - r.cb[2] > P.robot.period) {
+  if (P.robot.present && r.time - r.cb(2) > P.robot.period) {
     set_flag(r.flags, kRobotCollision, false);
     set_flag(r.flags, kAnyRet0, false);
-    r.cb[2] = r.time;
+    r.cb(2) = r.time;
   }
-  if (has_g && r.time - r.cb[3] > P.grip.period) {
+  if (has_g && r.time - r.cb(3) > P.grip.period) {
     set_flag(r.flags, kGripCollision, false);
     set_flag(r.flags, kAnyRet1, false);
-    r.cb[3] = r.time;
+    r.cb(3) = r.time;
   }
-  if (P.robot.present && P.robot.conv_registered && r.time - r.cb[4] > P.robot.period) {
+  if (P.robot.present && P.robot.conv_registered && r.time - r.cb(4) > P.robot.period) {
     const bool conv = !(r.flags & kIkSuccess) || ((r.flags & kIsArrived) && !(r.flags & kIsMoving));
     set_flag(r.flags, kAllRet0, conv);
-    r.cb[4] = r.time;
+    r.cb(4) = r.time;
   }
-  if (has_g && r.time - r.cb[5] > P.grip.period) {
+  if (has_g && r.time - r.cb(5) > P.grip.period) {
     const double w = gripper_width<T>(P, r);
     const bool moving = fabs(r.last_width - w) > 0.001 * (P.grip.max_act - P.grip.min_act);
     set_flag(r.flags, kGripMoving, moving);
     r.last_width = w;
     set_flag(r.flags, kAllRet1, !moving);
-    r.cb[5] = r.time;
+    r.cb(5) = r.time;
   }
   bool any = false, all = true;
   if (P.robot.present) any = any || (r.flags & kAnyRet0);
@@ -226,8 +236,8 @@ template <class T>
 __device__ __forceinline__ void robot_set_joint_position(EnvRegs<T>& r, const double* a) {
 #pragma unroll
   for (int i = 0; i < T::NARM; ++i) {
-    r.target[i] = a[i];
-    r.prevq[i] = r.q[i];
+    r.target(i) = a[i];
+    r.prevq(i) = r.q[i];
     r.ctrl[i] = a[i];
   }
   r.flags = (r.flags | kIsMoving) & ~kIsArrived;
@@ -265,9 +275,13 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= P.n) return;
   if (op.mask && !op.mask[e]) return;
-  const DevModel& m = *P.model;
+  const DevModel& m = c_models[P.model_slot];
   const int n = P.n;
+  // LDS staging column of this lane (dyn.h: Stage), [slot][lane]
+  __shared__ double lds[Stage<T, 64>::COUNT * 64];
+  const Stage<T, 64> st{lds + threadIdx.x};
   EnvRegs<T> r;
+  r.st = st;
   load_env<T>(P, e, r);
   Smooth<T> sm;
   bool have_frames = false;
@@ -286,7 +300,7 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
     for (int i = 0; i < T::NU; ++i) r.ctrl[i] = 0;
     r.time = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r.cb[i] = 0;
+    for (int i = 0; i < 6; ++i) r.cb(i) = 0;
     // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
 #pragma unroll
     for (int i = 0; i < T::NARM; ++i) { r.q[i] = P.robot.q_home[i]; r.ctrl[i] = P.robot.q_home[i]; }
@@ -348,7 +362,7 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
   if (nsteps >= 0) {
     for (int s = 0; s < nsteps; ++s) {
       plain_callbacks<T>(P, r);
-      substep<T>(m, r.q, r.qd, r.ctrl, sm);
+      substep<T, 64>(m, r.q, r.qd, r.ctrl, st, sm);
       r.time += m.timestep;
       have_frames = true;
     }
@@ -359,7 +373,7 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
     bool converged = false;
     while (!converged && (cap == -1 || r.conv_steps < cap)) {
       plain_callbacks<T>(P, r);
-      substep<T>(m, r.q, r.qd, r.ctrl, sm);
+      substep<T, 64>(m, r.q, r.qd, r.ctrl, st, sm);
       r.time += m.timestep;
       have_frames = true;
       r.conv_steps++;
