@@ -240,6 +240,10 @@ int rcsh_dev_free(rcsh_sim* sim, void* ptr);
 int rcsh_dev_upload(rcsh_sim* sim, void* dst_dev, const void* src_host, size_t bytes);
 int rcsh_dev_download(rcsh_sim* sim, void* dst_host, const void* src_dev, size_t bytes);
 
+/* development hook: copies the finalised device model tables (csrc/model.h DevModel) to `buf`; used by
+ * tools/kbench to replay the exact FR3 tables in kernel micro-benchmarks */
+int rcsh_debug_dump_model(rcsh_sim* sim, void* buf, size_t cap, size_t* size);
+
 /* kernel timing hooks for bench.py: HIP events on the handle's stream around each fused env-step launch */
 int rcsh_prof_enable(rcsh_sim* sim, int32_t enable);
 int rcsh_prof_read(rcsh_sim* sim, double* total_ms, int64_t* launches);

@@ -52,6 +52,14 @@ constexpr double kMinImp = 0.0001;
 constexpr double kMaxImp = 0.9999;
 
 RCSH_HD double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// Compiler-only fence (no instruction): values parked in the LDS staging area must really be
+// re-read after it, otherwise store-to-load forwarding keeps them alive in registers and the
+// staging buys nothing.
+RCSH_HD void stage_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");
+#endif
+}
 RCSH_HD double fast_rcp(double x);
 RCSH_HD void fast_sincos(double x, double* sn, double* cs);
 
@@ -249,6 +257,7 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
 #pragma unroll
     for (int k = 0; k < 6; ++k) st.f(i, k) = Ia[k] + vf[k];
   }
+  stage_fence();
   // backward sweep: Ic / fs / hs are the sums over the links visited so far.  Links are visited
   // leaves first (fingers, then the arm from tip to base), so for an arm link the running sums are
   // exactly its subtree; a finger is a leaf and projects its own values only.
@@ -409,6 +418,7 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
   constexpr int NA = T::NARM;
   const double h = m.timestep;
   smooth_dynamics<T, STRIDE>(m, q, qd, st, sm);
+  stage_fence();
 
   // ---- actuation: affine actuators, force limits, actuator-side gravity compensation, joint clamp
   double tau[NL];      // qfrc_actuator
@@ -537,6 +547,7 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
   }
 
   // ---- implicitfast: (M - h dF/dqd) qacc = smooth + constraint, then semi-implicit Euler
+  stage_fence();
   {
     double A[T::NTRI];
 #pragma unroll

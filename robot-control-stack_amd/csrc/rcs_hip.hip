@@ -41,7 +41,7 @@ struct rcsh_sim {
   int n = 0;
   HostModel hm;
   DevModel dm;
-  int model_slot = -1;
+  DevModel* d_model = nullptr;
   std::vector<int> act_slot;
   int narm = 0, nl = 0, nu = 0;
   bool grip = false;
@@ -75,7 +75,7 @@ int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 
 Params make_params(rcsh_sim* s) {
   Params P;
-  P.model_slot = s->model_slot;
+  P.model = s->d_model;
   P.S = s->S;
   P.flags = s->flags;
   P.conv_steps = s->conv;
@@ -87,14 +87,9 @@ Params make_params(rcsh_sim* s) {
   return P;
 }
 
-// constant-memory slots in use, per device
-bool g_slot_used[16][kModelSlots];
-
 int upload_model(rcsh_sim* s) {
+  HIP_TRY(hipMemcpyAsync(s->d_model, &s->dm, sizeof(DevModel), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_models), &s->dm, sizeof(DevModel), sizeof(DevModel) * s->model_slot,
-                            hipMemcpyHostToDevice));
-  HIP_TRY(hipDeviceSynchronize());
   return RCSH_OK;
 }
 
@@ -264,9 +259,7 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   HIP_NEW(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   const size_t n = (size_t)n_envs;
-  for (int k = 0; k < kModelSlots && device < 16; ++k)
-    if (!g_slot_used[device][k]) { s->model_slot = k; g_slot_used[device][k] = true; break; }
-  if (s->model_slot < 0) return cleanup(RCSH_ERR_DEVICE, "too many live sims on this device (model slots exhausted)");
+  HIP_NEW(hipMalloc(&s->d_model, sizeof(DevModel)));
   HIP_NEW(hipMalloc(&s->S, sizeof(double) * n * s->nfields));
   HIP_NEW(hipMalloc(&s->flags, sizeof(uint32_t) * n));
   HIP_NEW(hipMalloc(&s->conv, sizeof(int32_t) * n));
@@ -302,8 +295,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
-  if (s->model_slot >= 0 && s->device < 16) g_slot_used[s->device][s->model_slot] = false;
-  hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
+  hipFree(s->d_model); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
@@ -696,6 +688,13 @@ int rcsh_dev_download(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
   REQUIRE_SIM(s);
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_debug_dump_model(rcsh_sim* s, void* buf, size_t cap, size_t* size) {
+  REQUIRE_SIM(s);
+  if (size) *size = sizeof(DevModel);
+  if (buf && cap >= sizeof(DevModel)) std::memcpy(buf, &s->dm, sizeof(DevModel));
   return RCSH_OK;
 }
 

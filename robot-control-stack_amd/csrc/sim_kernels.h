@@ -88,14 +88,8 @@ struct RunOp {
   int32_t* substeps;      // [n]
 };
 
-// Model tables live in the constant address space: every access is wave-uniform, so the compiler
-// fetches them with scalar loads into SGPRs instead of spending vector-memory instructions on them.
-// One slot per live rcsh_sim handle on a device.
-constexpr int kModelSlots = 8;
-__constant__ DevModel c_models[kModelSlots];
-
 struct Params {
-  int32_t model_slot;
+  const DevModel* model;  // HBM copy; each workgroup stages it into LDS once per launch
   double* S;
   uint32_t* flags;
   int32_t* conv_steps;
@@ -272,10 +266,21 @@ __device__ __forceinline__ void cartesian_position(const DevModel& m, const Robo
 template <class T>
 __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
   using L = Lay<T>;
+  // Model tables: staged into LDS once per launch and read back with broadcast ds_reads.  (Scalar
+  // loads from constant memory were measured 2.2x slower here: ~800 doubles of tables cannot stay in
+  // ~100 SGPRs, and SMEM returns share -- and serialise -- the LDS wait counter.)
+  __shared__ DevModel lm;
+  {
+    constexpr int kWords = sizeof(DevModel) / 8;
+    const double* src = reinterpret_cast<const double*>(P.model);
+    double* dst = reinterpret_cast<double*>(&lm);
+    for (int k = threadIdx.x; k < kWords; k += 64) dst[k] = src[k];
+    __syncthreads();
+  }
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= P.n) return;
   if (op.mask && !op.mask[e]) return;
-  const DevModel& m = c_models[P.model_slot];
+  const DevModel& m = lm;
   const int n = P.n;
   // LDS staging column of this lane (dyn.h: Stage), [slot][lane]
   __shared__ double lds[Stage<T, 64>::COUNT * 64];
@@ -356,31 +361,31 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
     r.flags |= kHasPrevAction;
   }
 
-  // ---- Sim::step(k) / Sim::step_until_convergence (src/sim/sim.cpp:84-115)
+  // ---- Sim::step(k) / Sim::step_until_convergence (src/sim/sim.cpp:84-115).  One loop serves both so the
+  // (large, fully unrolled) substep body exists once in the instruction stream.
   int nsteps = op.nsteps;
   if (op.do_reset) nsteps = 1;
-  if (nsteps >= 0) {
-    for (int s = 0; s < nsteps; ++s) {
-      plain_callbacks<T>(P, r);
-      substep<T, 64>(m, r.q, r.qd, r.ctrl, st, sm);
-      r.time += m.timestep;
-      have_frames = true;
-    }
-  } else {
+  const bool until_conv = nsteps < 0;
+  int budget = nsteps;
+  if (until_conv) {
     r.conv_steps = 0;
     r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
     const int cap = P.sim.max_convergence_steps;
-    bool converged = false;
-    while (!converged && (cap == -1 || r.conv_steps < cap)) {
-      plain_callbacks<T>(P, r);
-      substep<T, 64>(m, r.q, r.qd, r.ctrl, st, sm);
-      r.time += m.timestep;
-      have_frames = true;
+    budget = cap == -1 ? 0x7fffffff : cap;
+  }
+  bool converged = false;
+  while (budget > 0 && !converged) {
+    plain_callbacks<T>(P, r);
+    substep<T, 64>(m, r.q, r.qd, r.ctrl, st, sm);
+    r.time += m.timestep;
+    have_frames = true;
+    --budget;
+    if (until_conv) {
       r.conv_steps++;
       converged = condition_callbacks<T>(P, r);
     }
-    set_flag(r.flags, kConverged, converged);
   }
+  if (until_conv) set_flag(r.flags, kConverged, converged);
   if (have_frames) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) P.S[(L::SITE + k) * n + e] = sm.linkR[k];

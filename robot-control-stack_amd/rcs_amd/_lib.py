@@ -91,6 +91,7 @@ EXPORTS = (
     "rcsh_sim_set_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
+    "rcsh_debug_dump_model",
 )
 
 _lib = None
@@ -121,6 +122,7 @@ def load() -> C.CDLL:
     L.rcsh_gripper_set_normalized_width.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     L.rcsh_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     L.rcsh_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.rcsh_debug_dump_model.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.rcsh_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.rcsh_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = L
