@@ -24,6 +24,7 @@
 // constant when it compiles a model).  No stepping entry point runs on the CPU.
 #pragma once
 #include <cmath>
+#include <cstdint>
 
 #include "model.h"
 
@@ -124,10 +125,20 @@ struct Stage {
   static constexpr int H0 = F0 + 6 * T::NL;
   static constexpr int M0 = H0 + 3 * T::NL;
   static constexpr int S0 = M0 + T::NTRI;
-  static constexpr int X0 = S0 + 6 * T::NL;   // caller's slots (sim_kernels.h parks rarely-touched state here)
+  static constexpr int Q0 = S0 + 6 * T::NL;   // qpos
+  static constexpr int V0 = Q0 + T::NL;       // qvel
+  static constexpr int C0 = V0 + T::NL;       // ctrl
+  static constexpr int L0 = C0 + T::NU;       // limit rows: D, aref, sign per joint
+  static constexpr int K0 = L0 + 3 * T::NL;   // frame of the site link at the last position stage: R(9) p(3)
+  static constexpr int X0 = K0 + 12;          // caller's slots (sim_kernels.h parks rarely-touched state here)
   static constexpr int NX = 6 + 2 * T::NARM;
   static constexpr int COUNT = X0 + NX;
   double* base;
+  RCSH_HD double& q(int i) const { return base[(Q0 + i) * STRIDE]; }
+  RCSH_HD double& v(int i) const { return base[(V0 + i) * STRIDE]; }
+  RCSH_HD double& c(int i) const { return base[(C0 + i) * STRIDE]; }
+  RCSH_HD double& lim(int i, int k) const { return base[(L0 + 3 * i + k) * STRIDE]; }
+  RCSH_HD double& link(int k) const { return base[(K0 + k) * STRIDE]; }
   RCSH_HD double& S(int i, int k) const { return base[(S0 + 6 * i + k) * STRIDE]; }
   RCSH_HD double& X(int k) const { return base[(X0 + k) * STRIDE]; }
   RCSH_HD double& I(int i, int k) const { return base[(I0 + 10 * i + k) * STRIDE]; }
@@ -408,107 +419,112 @@ RCSH_HD double row_D(double imp, double invweight) {
   return num < kMinVal * imp ? 1.0 / kMinVal : imp * fast_rcp(num);
 }
 
-// One physics substep: advances q, qd by one timestep under controls `ctrl`.
-// `sm` carries the frames of the site link computed from the PRE-step q (the reference reads
-// site_xpos/xmat of the last mj_step1).
+// One physics substep on the environment parked in `st`: reads qpos / qvel / ctrl from the staging
+// column, advances them by one timestep and writes them back, together with the world frame of the
+// attachment-site link computed from the PRE-step qpos (the reference reads site_xpos / site_xmat of
+// the last mj_step1).  Everything that is not needed between two phases is parked in
+// the column, so the register allocator only ever sees one phase's working set.
 template <class T, int STRIDE>
-RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctrl, const Stage<T, STRIDE>& st,
-                     Smooth<T>& sm) {
+RCSH_HD void substep(const DevModel& m, const Stage<T, STRIDE>& st) {
   constexpr int NL = T::NL;
   constexpr int NA = T::NARM;
   const double h = m.timestep;
-  smooth_dynamics<T, STRIDE>(m, q, qd, st, sm);
+  double smooth[NL];        // qfrc_smooth
+  uint32_t clampmask = 0;   // bit i: arm actuator i saturated its forcerange (no velocity derivative)
+  double gblock = 0.0;      // -bias_vel of the gripper actuator (2x2 block coef_a * coef_b * gblock)
+  double eqD = 0, eqAref = 0, eqJ1 = 0;  // coupling row = e_f1 + eqJ1 * e_f2
+  uint32_t limrows = 0;     // bit i: joint i has a limit row this substep
+  {
+    double q[NL], qd[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { q[i] = st.q(i); qd[i] = st.v(i); }
+    Smooth<T> sm;
+    smooth_dynamics<T, STRIDE>(m, q, qd, st, sm);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st.link(k) = sm.linkR[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st.link(9 + k) = sm.linkP[k];
+
+    // ---- actuation: affine actuators, force limits, actuator-side gravity compensation, joint clamp
+    double tau[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) tau[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (!m.arm_has_act[i]) continue;
+      double c = st.c(i);
+      if (m.arm_ctrllimited[i]) c = clampd(c, m.arm_ctrlrange[i][0], m.arm_ctrlrange[i][1]);
+      const double gear = m.arm_gear[i];
+      double force = m.arm_gain[i] * c;
+      if (m.arm_biasaffine[i]) force += m.arm_bias[i][0] + m.arm_bias[i][1] * (gear * q[i]) + m.arm_bias[i][2] * (gear * qd[i]);
+      if (m.arm_forcelimited[i]) {
+        if (force <= m.arm_forcerange[i][0] || force >= m.arm_forcerange[i][1]) clampmask |= 1u << i;
+        force = clampd(force, m.arm_forcerange[i][0], m.arm_forcerange[i][1]);
+      }
+      tau[i] = gear * force;
+    }
+    if (T::GRIP && m.grp_has_act) {
+      double c = st.c(NA);
+      if (m.grp_ctrllimited) c = clampd(c, m.grp_ctrlrange[0], m.grp_ctrlrange[1]);
+      const double len = m.grp_coef[0] * q[NA] + m.grp_coef[1] * q[NA + 1];
+      const double vel = m.grp_coef[0] * qd[NA] + m.grp_coef[1] * qd[NA + 1];
+      double force = m.grp_gain * c;
+      if (m.grp_biasaffine) force += m.grp_bias[0] + m.grp_bias[1] * len + m.grp_bias[2] * vel;
+      bool clamped = false;
+      if (m.grp_forcelimited) {
+        clamped = force <= m.grp_forcerange[0] || force >= m.grp_forcerange[1];
+        force = clampd(force, m.grp_forcerange[0], m.grp_forcerange[1]);
+      }
+      tau[NA] += m.grp_coef[0] * force;
+      tau[NA + 1] += m.grp_coef[1] * force;
+      if (m.grp_biasaffine && !clamped) gblock = -m.grp_bias[2];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      double passive = -m.damping[i] * qd[i];
+      if (m.actgravcomp[i]) tau[i] += sm.gc[i]; else passive += sm.gc[i];
+      if (m.actfrclimited[i]) tau[i] = clampd(tau[i], m.actfrcrange[i][0], m.actfrcrange[i][1]);
+      smooth[i] = passive - sm.bias[i] + tau[i];
+    }
+
+    // ---- constraint rows: finger coupling (equality, always active) and joint limits (one-sided)
+    if (T::GRIP && m.eq_active) {
+      const double* pc = m.eq_polycoef;
+      const double dif = q[NA + 1] - m.qpos0[NA + 1];
+      const double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
+      const double deriv = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
+      const double pos = q[NA] - m.qpos0[NA] - poly;
+      eqJ1 = -deriv;
+      const double imp = impedance(m.eq_imp, pos, 0.0);
+      eqD = row_D(imp, m.invweight0[NA] + m.invweight0[NA + 1]);
+      eqAref = -m.eq_K * imp * pos - m.eq_B * (qd[NA] + eqJ1 * qd[NA + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if (!m.limited[i]) continue;
+      const double dlo = q[i] - m.range[i][0], dhi = m.range[i][1] - q[i];
+      double dist = 0, sgn = 0;
+      if (dlo < m.margin[i]) { dist = dlo; sgn = 1; }
+      else if (dhi < m.margin[i]) { dist = dhi; sgn = -1; }
+      if (sgn != 0) {
+        const double imp = impedance(m.lim_imp[i], dist, m.margin[i]);
+        st.lim(i, 0) = row_D(imp, m.invweight0[i]);
+        st.lim(i, 1) = -m.lim_K[i] * imp * (dist - m.margin[i]) - m.lim_B[i] * (sgn * qd[i]);
+        st.lim(i, 2) = sgn;
+        limrows |= 1u << i;
+      }
+    }
+  }
   stage_fence();
-
-  // ---- actuation: affine actuators, force limits, actuator-side gravity compensation, joint clamp
-  double tau[NL];      // qfrc_actuator
-  double dact[NL];     // -d(qfrc_actuator)/d(qd), diagonal part
-  double smooth[NL];   // qfrc_smooth
-#pragma unroll
-  for (int i = 0; i < NL; ++i) { tau[i] = 0; dact[i] = 0; }
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    if (!m.arm_has_act[i]) continue;
-    double c = ctrl[i];
-    if (m.arm_ctrllimited[i]) c = clampd(c, m.arm_ctrlrange[i][0], m.arm_ctrlrange[i][1]);
-    const double gear = m.arm_gear[i];
-    double force = m.arm_gain[i] * c;
-    if (m.arm_biasaffine[i]) force += m.arm_bias[i][0] + m.arm_bias[i][1] * (gear * q[i]) + m.arm_bias[i][2] * (gear * qd[i]);
-    bool clamped = false;
-    if (m.arm_forcelimited[i]) {
-      clamped = force <= m.arm_forcerange[i][0] || force >= m.arm_forcerange[i][1];
-      force = clampd(force, m.arm_forcerange[i][0], m.arm_forcerange[i][1]);
-    }
-    tau[i] = gear * force;
-    if (m.arm_biasaffine[i] && !clamped) dact[i] = -gear * gear * m.arm_bias[i][2];
-  }
-  double gblock = 0.0;  // -bias_vel of the gripper actuator (2x2 block coef_a * coef_b * gblock)
-  if (T::GRIP && m.grp_has_act) {
-    double c = ctrl[NA];
-    if (m.grp_ctrllimited) c = clampd(c, m.grp_ctrlrange[0], m.grp_ctrlrange[1]);
-    const double len = m.grp_coef[0] * q[NA] + m.grp_coef[1] * q[NA + 1];
-    const double vel = m.grp_coef[0] * qd[NA] + m.grp_coef[1] * qd[NA + 1];
-    double force = m.grp_gain * c;
-    if (m.grp_biasaffine) force += m.grp_bias[0] + m.grp_bias[1] * len + m.grp_bias[2] * vel;
-    bool clamped = false;
-    if (m.grp_forcelimited) {
-      clamped = force <= m.grp_forcerange[0] || force >= m.grp_forcerange[1];
-      force = clampd(force, m.grp_forcerange[0], m.grp_forcerange[1]);
-    }
-    tau[NA] += m.grp_coef[0] * force;
-    tau[NA + 1] += m.grp_coef[1] * force;
-    if (m.grp_biasaffine && !clamped) gblock = -m.grp_bias[2];
-  }
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    double passive = -m.damping[i] * qd[i];
-    if (m.actgravcomp[i]) tau[i] += sm.gc[i]; else passive += sm.gc[i];
-    if (m.actfrclimited[i]) tau[i] = clampd(tau[i], m.actfrcrange[i][0], m.actfrcrange[i][1]);
-    smooth[i] = passive - sm.bias[i] + tau[i];
-  }
-
-  // ---- constraint rows: finger coupling (equality, always active) and joint limits (one-sided)
-  double eqD = 0, eqAref = 0, eqJ1 = 0;  // row = e_f1 + eqJ1 * e_f2
-  if (T::GRIP && m.eq_active) {
-    const double* pc = m.eq_polycoef;
-    const double dif = q[NA + 1] - m.qpos0[NA + 1];
-    const double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
-    const double deriv = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
-    const double pos = q[NA] - m.qpos0[NA] - poly;
-    eqJ1 = -deriv;
-    const double imp = impedance(m.eq_imp, pos, 0.0);
-    eqD = row_D(imp, m.invweight0[NA] + m.invweight0[NA + 1]);
-    eqAref = -m.eq_K * imp * pos - m.eq_B * (qd[NA] + eqJ1 * qd[NA + 1]);
-  }
-  double limD[NL], limAref[NL], limSign[NL];  // limSign 0: no row
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    limD[i] = 0; limAref[i] = 0; limSign[i] = 0;
-    if (!m.limited[i]) continue;
-    const double dlo = q[i] - m.range[i][0], dhi = m.range[i][1] - q[i];
-    double dist = 0, sgn = 0;
-    if (dlo < m.margin[i]) { dist = dlo; sgn = 1; }
-    else if (dhi < m.margin[i]) { dist = dhi; sgn = -1; }
-    if (sgn != 0) {
-      const double imp = impedance(m.lim_imp[i], dist, m.margin[i]);
-      limD[i] = row_D(imp, m.invweight0[i]);
-      limAref[i] = -m.lim_K[i] * imp * (dist - m.margin[i]) - m.lim_B[i] * (sgn * qd[i]);
-      limSign[i] = sgn;
-    }
-  }
 
   // ---- qacc = argmin 1/2 |qacc - M^-1 smooth|_M^2 + sum s_i(J_i qacc - aref_i): active-set Newton.
   // A Newton step under a guessed active set is exact if the set it lands in equals the guess.
-  double qacc[NL];
-  bool act[NL];
-  bool anylim = false;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) { act[i] = limSign[i] != 0; anylim = anylim || act[i]; }
   double fc[NL];  // qfrc_constraint
 #pragma unroll
   for (int i = 0; i < NL; ++i) fc[i] = 0;
-  const bool have_rows = (T::GRIP && m.eq_active) || anylim;
-  if (have_rows) {
+  if ((T::GRIP && m.eq_active) || limrows) {
+    double qacc[NL];
+    uint32_t act = limrows;
     for (int iter = 0; iter < 8; ++iter) {
       double H[T::NTRI];
 #pragma unroll
@@ -516,7 +532,11 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         qacc[i] = smooth[i];
-        if (act[i]) { H[tri(i, i)] += limD[i]; qacc[i] += limSign[i] * limD[i] * limAref[i]; }
+        if (act & (1u << i)) {
+          const double D = st.lim(i, 0);
+          H[tri(i, i)] += D;
+          qacc[i] += st.lim(i, 2) * D * st.lim(i, 1);
+        }
       }
       if (T::GRIP && m.eq_active) {
         H[tri(NA, NA)] += eqD;
@@ -527,27 +547,29 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
       }
       ldl_factor<NL>(H);
       ldl_solve<NL>(H, qacc);
-      bool same = true;
+      uint32_t now = 0;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const bool on = limSign[i] != 0 && (limSign[i] * qacc[i] - limAref[i] < 0);
-        same = same && (on == act[i]);
-        act[i] = on;
-      }
+      for (int i = 0; i < NL; ++i)
+        if ((limrows & (1u << i)) && st.lim(i, 2) * qacc[i] - st.lim(i, 1) < 0) now |= 1u << i;
+      const bool same = now == act;
+      act = now;
       if (same) break;
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-      if (act[i]) fc[i] = -limSign[i] * limD[i] * (limSign[i] * qacc[i] - limAref[i]);
+      if (act & (1u << i)) {
+        const double sgn = st.lim(i, 2);
+        fc[i] = -sgn * st.lim(i, 0) * (sgn * qacc[i] - st.lim(i, 1));
+      }
     if (T::GRIP && m.eq_active) {
       const double fe = -eqD * (qacc[NA] + eqJ1 * qacc[NA + 1] - eqAref);
       fc[NA] += fe;
       fc[NA + 1] += fe * eqJ1;
     }
   }
+  stage_fence();
 
   // ---- implicitfast: (M - h dF/dqd) qacc = smooth + constraint, then semi-implicit Euler
-  stage_fence();
   {
     double A[T::NTRI];
 #pragma unroll
@@ -555,7 +577,10 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
     double rhs[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      A[tri(i, i)] += h * (m.damping[i] + dact[i]);
+      double d = m.damping[i];
+      if (i < NA && m.arm_has_act[i] && m.arm_biasaffine[i] && !(clampmask & (1u << i)))
+        d -= m.arm_gear[i] * m.arm_gear[i] * m.arm_bias[i][2];
+      A[tri(i, i)] += h * d;
       rhs[i] = smooth[i] + fc[i];
     }
     if (T::GRIP) {
@@ -567,10 +592,12 @@ RCSH_HD void substep(const DevModel& m, double* q, double* qd, const double* ctr
     ldl_solve<NL>(A, rhs);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      qd[i] += h * rhs[i];
-      q[i] += h * qd[i];
+      const double v = st.v(i) + h * rhs[i];
+      st.v(i) = v;
+      st.q(i) += h * v;
     }
   }
+  stage_fence();
 }
 
 }  // namespace rcsh

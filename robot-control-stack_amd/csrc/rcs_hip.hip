@@ -29,7 +29,7 @@ int fail(int code, const std::string& msg) {
       return fail(RCSH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
   } while (0)
 
-constexpr int kBlock = 64;  // one wave per workgroup: each environment-wave gets a CU to itself
+constexpr int kBlock = kLanes;  // one (partially filled) wave per workgroup: each gets a CU to itself
 constexpr int kProfRing = 4096;
 
 }  // namespace

@@ -17,6 +17,10 @@
 
 namespace rcsh {
 
+// lanes (= environments) per workgroup.  32 keeps the per-lane LDS staging column (~2.8 KB) plus the model
+// tables inside one CU's 160 KB; at 4096 environments that is 128 single-wave workgroups on 128 CUs.
+constexpr int kLanes = 32;
+
 // ---- per-environment flag word
 enum : uint32_t {
   kAnyRet0 = 1u << 0,   // last_return_value of any_callbacks[0] (robot collision)
@@ -103,12 +107,11 @@ struct Params {
 // ---- everything one environment keeps in registers during a launch
 template <class T>
 struct EnvRegs {
-  double q[T::NL], qd[T::NL], ctrl[T::NU];
   double time;
   double last_cmd_width, last_width;
   // callback timestamps, previous_angles and target_angles are touched once per 25-50 substeps:
   // they live in the lane's LDS column (Stage::X), not in registers
-  Stage<T, 64> st;
+  Stage<T, kLanes> st;
   __device__ __forceinline__ double& cb(int i) const { return st.X(i); }
   __device__ __forceinline__ double& prevq(int i) const { return st.X(6 + i); }
   __device__ __forceinline__ double& target(int i) const { return st.X(6 + T::NARM + i); }
@@ -122,9 +125,9 @@ __device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T>& r) 
   const int n = P.n;
   const double* S = P.S;
 #pragma unroll
-  for (int i = 0; i < T::NL; ++i) { r.q[i] = S[(L::QPOS + i) * n + e]; r.qd[i] = S[(L::QVEL + i) * n + e]; }
+  for (int i = 0; i < T::NL; ++i) { r.st.q(i) = S[(L::QPOS + i) * n + e]; r.st.v(i) = S[(L::QVEL + i) * n + e]; }
 #pragma unroll
-  for (int i = 0; i < T::NU; ++i) r.ctrl[i] = S[(L::CTRL + i) * n + e];
+  for (int i = 0; i < T::NU; ++i) r.st.c(i) = S[(L::CTRL + i) * n + e];
   r.time = S[L::TIME * n + e];
 #pragma unroll
   for (int i = 0; i < 6; ++i) r.cb(i) = S[(L::CB + i) * n + e];
@@ -142,9 +145,9 @@ __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<
   const int n = P.n;
   double* S = P.S;
 #pragma unroll
-  for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.q[i]; S[(L::QVEL + i) * n + e] = r.qd[i]; }
+  for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.st.q(i); S[(L::QVEL + i) * n + e] = r.st.v(i); }
 #pragma unroll
-  for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.ctrl[i];
+  for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.st.c(i);
   S[L::TIME * n + e] = r.time;
 #pragma unroll
   for (int i = 0; i < 6; ++i) S[(L::CB + i) * n + e] = r.cb(i);
@@ -161,7 +164,7 @@ __device__ __forceinline__ void set_flag(uint32_t& f, uint32_t bit, bool v) { f 
 // SimGripper::get_normalized_width, reference src/sim/SimGripper.cpp:93-106
 template <class T>
 __device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T>& r) {
-  const double qf = P.grip.finger ? r.q[T::NL - 1] : r.q[T::NL - 2];
+  const double qf = P.grip.finger ? r.st.q(T::NL - 1) : r.st.q(T::NL - 2);
   double w = (qf - P.grip.min_joint) / (P.grip.max_joint - P.grip.min_joint);
   return w < 0 ? 0 : (w > 1 ? 1 : w);
 }
@@ -174,14 +177,14 @@ __device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T>& r) 
   if (r.time - r.cb(0) > P.robot.period) {
     double mx = 0;
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) mx = fmax(mx, fabs(r.q[i] - r.target(i)));
+    for (int i = 0; i < T::NARM; ++i) mx = fmax(mx, fabs(r.st.q(i) - r.target(i)));
     set_flag(r.flags, kIsArrived, mx < P.robot.tolerance);
     r.cb(0) = r.time;
   }
   if (r.time - r.cb(1) > P.robot.period) {
     double mx = 0;
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) { mx = fmax(mx, fabs(r.q[i] - r.prevq(i))); r.prevq(i) = r.q[i]; }
+    for (int i = 0; i < T::NARM; ++i) { mx = fmax(mx, fabs(r.st.q(i) - r.prevq(i))); r.prevq(i) = r.st.q(i); }
     set_flag(r.flags, kIsMoving, mx > 0.0001);
     r.cb(1) = r.time;
   }
@@ -231,8 +234,8 @@ __device__ __forceinline__ void robot_set_joint_position(EnvRegs<T>& r, const do
 #pragma unroll
   for (int i = 0; i < T::NARM; ++i) {
     r.target(i) = a[i];
-    r.prevq(i) = r.q[i];
-    r.ctrl[i] = a[i];
+    r.prevq(i) = r.st.q(i);
+    r.st.c(i) = a[i];
   }
   r.flags = (r.flags | kIsMoving) & ~kIsArrived;
 }
@@ -241,7 +244,7 @@ __device__ __forceinline__ void robot_set_joint_position(EnvRegs<T>& r, const do
 template <class T>
 __device__ __forceinline__ void gripper_set_width(const Params& P, EnvRegs<T>& r, double w) {
   r.last_cmd_width = w;
-  r.ctrl[T::NU - 1] = w * (P.grip.max_act - P.grip.min_act) + P.grip.min_act;
+  r.st.c(T::NU - 1) = w * (P.grip.max_act - P.grip.min_act) + P.grip.min_act;
 }
 
 // SimRobot::get_cartesian_position, reference src/sim/SimRobot.cpp:114-121 + src/rcs/Robot.cpp:5-9
@@ -264,7 +267,7 @@ __device__ __forceinline__ void cartesian_position(const DevModel& m, const Robo
 
 // The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step.
 template <class T>
-__global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
+__global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   using L = Lay<T>;
   // Model tables: staged into LDS once per launch and read back with broadcast ds_reads.  (Scalar
   // loads from constant memory were measured 2.2x slower here: ~800 doubles of tables cannot stay in
@@ -274,7 +277,11 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
     constexpr int kWords = sizeof(DevModel) / 8;
     const double* src = reinterpret_cast<const double*>(P.model);
     double* dst = reinterpret_cast<double*>(&lm);
-    for (int k = threadIdx.x; k < kWords; k += 64) dst[k] = src[k];
+#pragma unroll
+    for (int it = 0; it < (kWords + kLanes - 1) / kLanes; ++it) {
+      const int k = it * kLanes + threadIdx.x;
+      if (k < kWords) dst[k] = src[k];
+    }
     __syncthreads();
   }
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,12 +290,11 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
   const DevModel& m = lm;
   const int n = P.n;
   // LDS staging column of this lane (dyn.h: Stage), [slot][lane]
-  __shared__ double lds[Stage<T, 64>::COUNT * 64];
-  const Stage<T, 64> st{lds + threadIdx.x};
+  __shared__ double lds[Stage<T, kLanes>::COUNT * kLanes];
+  const Stage<T, kLanes> st{lds + threadIdx.x};
   EnvRegs<T> r;
   r.st = st;
   load_env<T>(P, e, r);
-  Smooth<T> sm;
   bool have_frames = false;
 
   if (op.do_reset) {
@@ -300,15 +306,15 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
     // RobotSimWrapper.reset -> Sim::reset = mj_resetData + reset_callbacks (envs/sim.py:68-76, sim.cpp:117-138);
     // it overwrites what the gripper reset just wrote to qpos / ctrl
 #pragma unroll
-    for (int i = 0; i < T::NL; ++i) { r.q[i] = m.qpos0[i]; r.qd[i] = 0; }
+    for (int i = 0; i < T::NL; ++i) { r.st.q(i) = m.qpos0[i]; r.st.v(i) = 0; }
 #pragma unroll
-    for (int i = 0; i < T::NU; ++i) r.ctrl[i] = 0;
+    for (int i = 0; i < T::NU; ++i) r.st.c(i) = 0;
     r.time = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) r.cb(i) = 0;
     // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) { r.q[i] = P.robot.q_home[i]; r.ctrl[i] = P.robot.q_home[i]; }
+    for (int i = 0; i < T::NARM; ++i) { r.st.q(i) = P.robot.q_home[i]; r.st.c(i) = P.robot.q_home[i]; }
   }
 
   if (op.apply_action) {
@@ -321,7 +327,7 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
       const bool fresh = last_step || !(r.flags & kHasLastAction);
 #pragma unroll
       for (int i = 0; i < T::NARM; ++i) {
-        double origin = last_step ? r.q[i] : P.S[(L::ORIGIN + i) * n + e];
+        double origin = last_step ? r.st.q(i) : P.S[(L::ORIGIN + i) * n + e];
         double lim;
         if (fresh) {
           lim = clampd(a[i], -P.env.max_mov[0], P.env.max_mov[0]);
@@ -376,7 +382,7 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
   bool converged = false;
   while (budget > 0 && !converged) {
     plain_callbacks<T>(P, r);
-    substep<T, 64>(m, r.q, r.qd, r.ctrl, st, sm);
+    substep<T, kLanes>(m, st);
     r.time += m.timestep;
     have_frames = true;
     --budget;
@@ -388,19 +394,15 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
   if (until_conv) set_flag(r.flags, kConverged, converged);
   if (have_frames) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) P.S[(L::SITE + k) * n + e] = sm.linkR[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) P.S[(L::SITE + 9 + k) * n + e] = sm.linkP[k];
+    for (int k = 0; k < 12; ++k) P.S[(L::SITE + k) * n + e] = st.link(k);
   } else if (op.write_obs) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) sm.linkR[k] = P.S[(L::SITE + k) * n + e];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sm.linkP[k] = P.S[(L::SITE + 9 + k) * n + e];
+    for (int k = 0; k < 12; ++k) st.link(k) = P.S[(L::SITE + k) * n + e];
   }
   if (op.do_reset && P.env.relative_to != 0) {
     // RelativeActionSpace.reset (base.py:461-466): origin := current, _last_action := None
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) P.S[(L::ORIGIN + i) * n + e] = r.q[i];
+    for (int i = 0; i < T::NARM; ++i) P.S[(L::ORIGIN + i) * n + e] = r.st.q(i);
     r.flags &= ~kHasLastAction;
   }
   store_env<T>(P, e, r);
@@ -410,12 +412,17 @@ __global__ void __launch_bounds__(64) k_run(Params P, RunOp op) {
     // RobotSimWrapper.step info (envs/sim.py:60-66) + GripperWrapperSim.observation (envs/sim.py:125-131)
     constexpr int OW = 14 + T::NARM;
     Pose tcp;
-    cartesian_position(m, P.robot, sm.linkR, sm.linkP, tcp);
+    double linkR[9], linkP[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) linkR[k] = st.link(k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) linkP[k] = st.link(9 + k);
+    cartesian_position(m, P.robot, linkR, linkP, tcp);
     double* o = op.obs + (size_t)e * OW;
     o[0] = tcp.t[0]; o[1] = tcp.t[1]; o[2] = tcp.t[2];
     o[3] = tcp.q[0]; o[4] = tcp.q[1]; o[5] = tcp.q[2]; o[6] = tcp.q[3];
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) o[7 + i] = r.q[i];
+    for (int i = 0; i < T::NARM; ++i) o[7 + i] = r.st.q(i);
     double rpy[3];
     pose_rpy(tcp, rpy);
     o[7 + T::NARM + 0] = tcp.t[0]; o[7 + T::NARM + 1] = tcp.t[1]; o[7 + T::NARM + 2] = tcp.t[2];

@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(BLOCK) k_steps(const DevModel* gm, double* S, 
   const int e = blockIdx.x * BLOCK + threadIdx.x;
   if (SRC == kLds) {
     const int words = sizeof(DevModel) / 8;
-    for (int k = threadIdx.x; k < words; k += BLOCK) ((double*)&lm)[k] = ((const double*)gm)[k];
+#pragma unroll
+    for (int it = 0; it < (words + BLOCK - 1) / BLOCK; ++it) { const int k = it * BLOCK + threadIdx.x; if (k < words) ((double*)&lm)[k] = ((const double*)gm)[k]; }
     __syncthreads();
   }
   if (e >= n) return;
@@ -41,7 +42,11 @@ __global__ void __launch_bounds__(BLOCK) k_steps(const DevModel* gm, double* S, 
   for (int i = 0; i < T::NL; ++i) { q[i] = S[i * n + e]; qd[i] = S[(16 + i) * n + e]; }
   for (int i = 0; i < T::NU; ++i) c[i] = S[(32 + i) * n + e];
   Smooth<T> sm;
-  for (int s = 0; s < nsteps; ++s) substep<T, BLOCK>(m, q, qd, c, st, sm);
+  for (int i = 0; i < T::NL; ++i) { st.q(i) = q[i]; st.v(i) = qd[i]; }
+  for (int i = 0; i < T::NU; ++i) st.c(i) = c[i];
+  for (int s = 0; s < nsteps; ++s) substep<T, BLOCK>(m, st);
+  for (int i = 0; i < T::NL; ++i) { q[i] = st.q(i); qd[i] = st.v(i); }
+  sm.linkP[0] = st.link(9);
   for (int i = 0; i < T::NL; ++i) { S[i * n + e] = q[i]; S[(16 + i) * n + e] = qd[i]; }
   S[48 * n + e] = sm.linkP[0];
 }
@@ -92,12 +97,12 @@ int main(int argc, char** argv) {
   double* dS;
   CK(hipMalloc(&dS, init.size() * 8));
   const int iters = 30;
-  run<64, kConst>("const-mem model", dm, dS, init, n, nsteps, iters);
+  run<32, kConst>("const-mem model", dm, dS, init, n, nsteps, iters);
   run<32, kConst>("const-mem model", dm, dS, init, n, nsteps, iters);
   run<16, kConst>("const-mem model", dm, dS, init, n, nsteps, iters);
-  run<64, kLds>("LDS model", dm, dS, init, n, nsteps, iters);
+  run<8, kLds>("LDS model", dm, dS, init, n, nsteps, iters);
   run<32, kLds>("LDS model", dm, dS, init, n, nsteps, iters);
   run<16, kLds>("LDS model", dm, dS, init, n, nsteps, iters);
-  run<64, kGlobal>("global-pointer model", dm, dS, init, n, nsteps, iters);
+  run<32, kGlobal>("global-pointer model", dm, dS, init, n, nsteps, iters);
   return 0;
 }
