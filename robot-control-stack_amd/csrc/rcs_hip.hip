@@ -464,14 +464,78 @@ int rcsh_robot_get_base_pose(rcsh_sim* s, double* pose) {
   return RCSH_OK;
 }
 
-int rcsh_robot_set_cartesian_position(rcsh_sim*, const double*, const uint8_t*) {
-  return fail(RCSH_ERR_STATE, "rcsh_robot_set_cartesian_position: IK kernel not built in this revision");
+namespace {
+int launch_cartesian(rcsh_sim* s, const CartOp& op) {
+  Params P = make_params(s);
+  hipError_t err = hipSuccess;
+  bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
+    using T = decltype(topo);
+    hipLaunchKernelGGL(k_cartesian<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, op);
+    err = hipGetLastError();
+  });
+  if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
+  if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_cartesian launch: ") + hipGetErrorString(err));
+  return RCSH_OK;
 }
-int rcsh_ik_inverse(rcsh_sim*, const double*, const double*, const double*, double*, uint8_t*, int32_t*) {
-  return fail(RCSH_ERR_STATE, "rcsh_ik_inverse: IK kernel not built in this revision");
+}  // namespace
+
+int rcsh_robot_set_cartesian_position(rcsh_sim* s, const double* pose, const uint8_t* mask) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!pose) return fail(RCSH_ERR_ARG, "null pose");
+  HIP_TRY(hipSetDevice(s->device));
+  const uint8_t* dm = nullptr;
+  int rc = upload_mask(s, mask, &dm);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_stage, pose, sizeof(double) * s->n * 7, hipMemcpyHostToDevice, s->stream));
+  CartOp op{};
+  op.env_layer = 0;
+  op.mask = dm;
+  op.action = s->d_stage;
+  rc = launch_cartesian(s, op);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
 }
-int rcsh_ik_forward(rcsh_sim*, const double*, const double*, double*) {
-  return fail(RCSH_ERR_STATE, "rcsh_ik_forward: IK kernel not built in this revision");
+
+namespace {
+int run_ik(rcsh_sim* s, const double* pose, const double* q0, const double* tcp7, double* out, int out_width, uint8_t* success,
+           int32_t* iterations, int forward) {
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t n = s->n;
+  double* d_pose = s->d_stage;            // n*7
+  double* d_q0 = s->d_stage + n * 8;      // n*narm
+  double* d_tcp = s->d_stage + n * 16;    // 7
+  double* d_out = s->d_stage2;            // n*out_width
+  if (pose) HIP_TRY(hipMemcpyAsync(d_pose, pose, sizeof(double) * n * 7, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(d_q0, q0, sizeof(double) * n * s->narm, hipMemcpyHostToDevice, s->stream));
+  if (tcp7) HIP_TRY(hipMemcpyAsync(d_tcp, tcp7, sizeof(double) * 7, hipMemcpyHostToDevice, s->stream));
+  Params P = make_params(s);
+  hipError_t err = hipSuccess;
+  dispatch_topology(s->narm, s->grip, [&](auto topo) {
+    using T = decltype(topo);
+    hipLaunchKernelGGL(k_ik<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, (const double*)d_pose, (const double*)d_q0,
+                       tcp7 ? (const double*)d_tcp : (const double*)nullptr, d_out, s->d_bytes, s->d_ints, forward);
+    err = hipGetLastError();
+  });
+  if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_ik launch: ") + hipGetErrorString(err));
+  HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * n * out_width, hipMemcpyDeviceToHost, s->stream));
+  if (success) HIP_TRY(hipMemcpyAsync(success, s->d_bytes, n, hipMemcpyDeviceToHost, s->stream));
+  if (iterations) HIP_TRY(hipMemcpyAsync(iterations, s->d_ints, sizeof(int32_t) * n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+}  // namespace
+
+int rcsh_ik_inverse(rcsh_sim* s, const double* pose, const double* q0, const double* tcp7, double* q, uint8_t* success,
+                    int32_t* iterations) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!pose || !q0 || !q) return fail(RCSH_ERR_ARG, "null argument");
+  return run_ik(s, pose, q0, tcp7, q, s->nl, success, iterations, 0);
+}
+int rcsh_ik_forward(rcsh_sim* s, const double* q0, const double* tcp7, double* pose) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!q0 || !pose) return fail(RCSH_ERR_ARG, "null argument");
+  return run_ik(s, nullptr, q0, tcp7, pose, 7, nullptr, nullptr, 1);
 }
 
 int rcsh_robot_get_state(rcsh_sim* s, uint8_t* ik_success, uint8_t* collision, uint8_t* is_moving, uint8_t* is_arrived,
@@ -587,8 +651,8 @@ int rcsh_sim_set_qvel(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUI
 int rcsh_env_configure(rcsh_sim* s, const rcsh_env_desc* env) {
   REQUIRE_SIM(s); REQUIRE_ROBOT(s);
   if (!env) return fail(RCSH_ERR_ARG, "null env description");
-  if (env->control_mode != RCSH_MODE_JOINTS)
-    return fail(RCSH_ERR_STATE, "fused env-step: only ControlMode.JOINTS is built in this revision");
+  if (env->control_mode < RCSH_MODE_JOINTS || env->control_mode > RCSH_MODE_CARTESIAN_TQUAT)
+    return fail(RCSH_ERR_ARG, "bad control_mode");
   if (env->relative_to < 0 || env->relative_to > 2) return fail(RCSH_ERR_ARG, "bad relative_to");
   s->env.mode = env->control_mode;
   s->env.relative_to = env->relative_to;
@@ -603,7 +667,10 @@ int rcsh_env_configure(rcsh_sim* s, const rcsh_env_desc* env) {
 }
 
 int rcsh_env_obs_width(const rcsh_sim* s) { return s ? 14 + s->narm : 0; }
-int rcsh_env_action_width(const rcsh_sim* s) { return s ? s->narm : 0; }
+int rcsh_env_action_width(const rcsh_sim* s) {
+  if (!s) return 0;
+  return s->env.mode == RCSH_MODE_JOINTS ? s->narm : (s->env.mode == RCSH_MODE_CARTESIAN_TRPY ? 6 : 7);
+}
 
 int rcsh_env_reset_dev(rcsh_sim* s, const uint8_t* mask_dev, double* obs_dev, uint8_t* info_dev, double* gw_dev) {
   REQUIRE_SIM(s); REQUIRE_ROBOT(s);
@@ -626,6 +693,16 @@ int rcsh_env_step_dev(rcsh_sim* s, const double* action_dev, const float* grippe
   HIP_TRY(hipSetDevice(s->device));
   RunOp op{};
   op.apply_action = 1;
+  if (s->env.mode != RCSH_MODE_JOINTS) {
+    // Cartesian modes: wrappers' action() + IK run in their own launch, the stepping launch follows on the stream
+    CartOp cop{};
+    cop.env_layer = 1;
+    cop.action = action_dev;
+    cop.gripper = gripper_dev;
+    int rc = launch_cartesian(s, cop);
+    if (rc) return rc;
+    op.apply_action = 0;
+  }
   // RobotSimWrapper.step (reference python/rcs/envs/sim.py:49-59)
   op.nsteps = s->sim.async_control ? (int32_t)std::lround(1.0 / s->sim.frequency / s->dm.timestep) : -1;
   op.write_obs = obs_dev != nullptr;
@@ -652,7 +729,7 @@ int rcsh_env_reset(rcsh_sim* s, const uint8_t* mask, double* obs, uint8_t* info,
 int rcsh_env_step(rcsh_sim* s, const double* action, const float* gripper, double* obs, uint8_t* info, double* gw, int32_t* substeps) {
   REQUIRE_SIM(s);
   if (!action) return fail(RCSH_ERR_ARG, "null action");
-  const int aw = s->narm, ow = 14 + s->narm;
+  const int aw = rcsh_env_action_width(s), ow = 14 + s->narm;
   double* d_action = s->d_stage + (size_t)s->n;  // d_stage[0..n) carries gripper widths
   HIP_TRY(hipMemcpyAsync(d_action, action, sizeof(double) * s->n * aw, hipMemcpyHostToDevice, s->stream));
   if (gripper) HIP_TRY(hipMemcpyAsync(s->d_floats, gripper, sizeof(float) * s->n, hipMemcpyHostToDevice, s->stream));

@@ -401,8 +401,22 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   }
   if (op.do_reset && P.env.relative_to != 0) {
     // RelativeActionSpace.reset (base.py:461-466): origin := current, _last_action := None
+    if (P.env.mode == 0) {
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) P.S[(L::ORIGIN + i) * n + e] = r.st.q(i);
+      for (int i = 0; i < T::NARM; ++i) P.S[(L::ORIGIN + i) * n + e] = r.st.q(i);
+    } else {
+      double oR[9], oP[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) oR[k] = st.link(k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) oP[k] = st.link(9 + k);
+      Pose origin;
+      cartesian_position(m, P.robot, oR, oP, origin);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) P.S[(L::ORIGIN + k) * n + e] = origin.t[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) P.S[(L::ORIGIN + 3 + k) * n + e] = origin.q[k];
+    }
     r.flags &= ~kHasLastAction;
   }
   store_env<T>(P, e, r);
@@ -468,6 +482,189 @@ __global__ void k_scatter(double* S, int n, int field0, int width, const double*
 __global__ void k_flags_to_bytes(const uint32_t* flags, int n, uint32_t bit, uint8_t* dst) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) dst[e] = (flags[e] & bit) != 0;
+}
+
+}  // namespace rcsh
+
+// ---------------------------------------------------------------------------------------------------------
+// Cartesian control path (reference python/rcs/envs/base.py:273-286,490-565 and src/sim/SimRobot.cpp:145-155).
+// These kernels work directly on the SoA state: one thread per environment, no staging, IK in registers.
+#include "ik.h"
+
+namespace rcsh {
+
+struct CartOp {
+  int32_t env_layer;        // 1: wrappers' action() + RobotEnv.step; 0: bare SimRobot::set_cartesian_position
+  const uint8_t* mask;
+  const double* action;     // env_layer: [n][6|7] xyzrpy / tquat action; else [n][7] target pose (xyz + xyzw)
+  const float* gripper;     // env_layer only, may be null
+};
+
+template <class T>
+__device__ __forceinline__ void load_pose7(const double* S, int n, int e, int field0, Pose& p) {
+  p.t[0] = S[(field0 + 0) * n + e]; p.t[1] = S[(field0 + 1) * n + e]; p.t[2] = S[(field0 + 2) * n + e];
+  p.q[0] = S[(field0 + 3) * n + e]; p.q[1] = S[(field0 + 4) * n + e]; p.q[2] = S[(field0 + 5) * n + e];
+  p.q[3] = S[(field0 + 6) * n + e];
+}
+template <class T>
+__device__ __forceinline__ void store_pose7(double* S, int n, int e, int field0, const Pose& p) {
+  S[(field0 + 0) * n + e] = p.t[0]; S[(field0 + 1) * n + e] = p.t[1]; S[(field0 + 2) * n + e] = p.t[2];
+  S[(field0 + 3) * n + e] = p.q[0]; S[(field0 + 4) * n + e] = p.q[1]; S[(field0 + 5) * n + e] = p.q[2];
+  S[(field0 + 6) * n + e] = p.q[3];
+}
+
+template <class T>
+__global__ void __launch_bounds__(64) k_cartesian(Params P, CartOp op) {
+  using L = Lay<T>;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n) return;
+  if (op.mask && !op.mask[e]) return;
+  const DevModel& m = *P.model;
+  const int n = P.n;
+  double* S = P.S;
+  uint32_t flags = P.flags[e];
+  Pose tcp;
+  tcp.t[0] = P.robot.tcp[0]; tcp.t[1] = P.robot.tcp[1]; tcp.t[2] = P.robot.tcp[2];
+  tcp.q[0] = P.robot.tcp[3]; tcp.q[1] = P.robot.tcp[4]; tcp.q[2] = P.robot.tcp[5]; tcp.q[3] = P.robot.tcp[6];
+  Pose target;
+  bool command = true;
+  if (!op.env_layer) {
+    const double* a = op.action + (size_t)e * 7;
+    pose_from_quat(a + 3, a, target);
+  } else {
+    const bool trpy = P.env.mode == 1;
+    const int aw = trpy ? 6 : 7;
+    double a[7];
+    for (int i = 0; i < aw; ++i) a[i] = op.action[(size_t)e * aw + i];
+    if (P.env.relative_to != 0) {
+      // RelativeActionSpace.action, Cartesian branches (base.py:490-565)
+      const bool last_step = P.env.relative_to == 1;
+      Pose origin;
+      if (last_step) {
+        double linkR[9], linkP[3];
+        for (int k = 0; k < 9; ++k) linkR[k] = S[(L::SITE + k) * n + e];
+        for (int k = 0; k < 3; ++k) linkP[k] = S[(L::SITE + 9 + k) * n + e];
+        cartesian_position(m, P.robot, linkR, linkP, origin);
+        store_pose7<T>(S, n, e, L::ORIGIN, origin);
+      } else {
+        load_pose7<T>(S, n, e, L::ORIGIN, origin);
+      }
+      Pose given, offset, tmp;
+      if (trpy) pose_from_rpy(a + 3, a, given); else pose_from_quat(a + 3, a, given);
+      if (last_step || !(flags & kHasLastAction)) {
+        pose_limit_translation_length(given, P.env.max_mov[0], tmp);
+        pose_limit_rotation_angle(tmp, P.env.max_mov[1], offset);
+      } else {
+        Pose last, last_inv, diff, lim;
+        load_pose7<T>(S, n, e, L::LASTA, last);
+        pose_inverse(last, last_inv);
+        pose_mul(given, last_inv, diff);
+        pose_limit_translation_length(diff, P.env.max_mov[0], tmp);
+        pose_limit_rotation_angle(tmp, P.env.max_mov[1], lim);
+        pose_mul(lim, last, offset);
+      }
+      store_pose7<T>(S, n, e, L::LASTA, offset);
+      flags |= kHasLastAction;
+      Pose rot;
+      pose_mul(offset, origin, rot);
+      const double t[3] = {origin.t[0] + offset.t[0], origin.t[1] + offset.t[1], origin.t[2] + offset.t[2]};
+      const double lo[3] = {-0.855, -0.855, 0.0}, hi[3] = {0.855, 0.855, 1.188};  // base.py:31-38
+      Pose unclipped;
+      if (trpy) {
+        double rpy[3];
+        pose_rpy(rot, rpy);
+        pose_from_rpy(rpy, t, unclipped);
+        pose_rpy(unclipped, a + 3);
+      } else {
+        pose_from_quat(rot.q, t, unclipped);
+        a[3] = unclipped.q[0]; a[4] = unclipped.q[1]; a[5] = unclipped.q[2]; a[6] = unclipped.q[3];
+      }
+      for (int k = 0; k < 3; ++k) a[k] = clampd(unclipped.t[k], lo[k], hi[k]);
+    }
+    // GripperWrapper.action (base.py:721-735)
+    if (T::GRIP && P.grip.present && op.gripper) {
+      float g = op.gripper[e];
+      if (P.env.binary_gripper) g = rintf(g);
+      g = fminf(fmaxf(g, 0.0f), 1.0f);
+      const double w = P.env.binary_gripper ? (g == 0.0f ? 0.0 : 1.0) : (double)g;
+      S[(L::GRIP + 0) * n + e] = w;
+      S[(L::CTRL + T::NU - 1) * n + e] = w * (P.grip.max_act - P.grip.min_act) + P.grip.min_act;
+      set_flag(flags, kGripCmd, P.env.binary_gripper ? g != 0.0f : g >= 0.5f);
+      flags |= kHasGripCmd;
+    }
+    // RobotEnv.step (base.py:255-288)
+    command = !(flags & kHasPrevAction);
+    for (int i = 0; i < aw; ++i) {
+      const double pa = S[(L::PREVA + i) * n + e];
+      command = command || !(fabs(a[i] - pa) <= 1e-3);
+      S[(L::PREVA + i) * n + e] = a[i];
+    }
+    flags |= kHasPrevAction;
+    if (trpy) pose_from_rpy(a + 3, a, target); else pose_from_quat(a + 3, a, target);
+  }
+  if (command) {
+    // SimRobot::set_cartesian_position (SimRobot.cpp:145-155)
+    double q[T::NARM];
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) q[i] = S[(L::QPOS + i) * n + e];
+    int iters = 0;
+    const bool ok = clik<T>(m, target, tcp, q, &iters);
+    if (ok) {
+      flags |= kIkSuccess;
+#pragma unroll
+      for (int i = 0; i < T::NARM; ++i) {  // set_joint_position(joint_vals)
+        S[(L::TARGET + i) * n + e] = q[i];
+        S[(L::PREVQ + i) * n + e] = S[(L::QPOS + i) * n + e];
+        S[(L::CTRL + i) * n + e] = q[i];
+      }
+      flags = (flags | kIsMoving) & ~kIsArrived;
+    } else {
+      flags &= ~kIkSuccess;
+    }
+  }
+  P.flags[e] = flags;
+}
+
+// Kinematics.inverse / forward on caller-supplied configurations (reference src/rcs/Kinematics.cpp:28-82)
+template <class T>
+__global__ void __launch_bounds__(64) k_ik(Params P, const double* pose, const double* q0, const double* tcp7, double* q_out,
+                                           uint8_t* success, int32_t* iterations, int forward) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n) return;
+  const DevModel& m = *P.model;
+  Pose tcp;
+  const double* tv = tcp7 ? tcp7 : P.robot.tcp;
+  tcp.t[0] = tv[0]; tcp.t[1] = tv[1]; tcp.t[2] = tv[2];
+  tcp.q[0] = tv[3]; tcp.q[1] = tv[4]; tcp.q[2] = tv[5]; tcp.q[3] = tv[6];
+  quat_normalize(tcp.q);
+  double q[T::NARM];
+#pragma unroll
+  for (int i = 0; i < T::NARM; ++i) q[i] = q0[(size_t)e * T::NARM + i];
+  if (forward) {
+    // Pin::forward returns frame * tcp_offset.inverse() (reference quirk Q7), in robot coordinates
+    double Rs[9], ps[3];
+    site_fk<T>(m, q, Rs, ps, nullptr, nullptr);
+    Pose site, base, base_inv, in_robot, tinv, out;
+    pose_from_mat(Rs, ps, site);
+    const double bq[4] = {m.base_quat[1], m.base_quat[2], m.base_quat[3], m.base_quat[0]};
+    pose_from_quat(bq, m.base_pos, base);
+    pose_inverse(base, base_inv);
+    pose_mul(base_inv, site, in_robot);
+    pose_inverse(tcp, tinv);
+    pose_mul(in_robot, tinv, out);
+    double* o = q_out + (size_t)e * 7;
+    o[0] = out.t[0]; o[1] = out.t[1]; o[2] = out.t[2]; o[3] = out.q[0]; o[4] = out.q[1]; o[5] = out.q[2]; o[6] = out.q[3];
+    return;
+  }
+  Pose target;
+  pose_from_quat(pose + (size_t)e * 7 + 3, pose + (size_t)e * 7, target);
+  int iters = 0;
+  const bool ok = clik<T>(m, target, tcp, q, &iters);
+  double* o = q_out + (size_t)e * T::NL;
+#pragma unroll
+  for (int i = 0; i < T::NL; ++i) o[i] = i < T::NARM ? q[i] : 0.0;  // model.nq entries, fingers zero (quirk Q7)
+  if (success) success[e] = ok;
+  if (iterations) iterations[e] = iters;
 }
 
 }  // namespace rcsh

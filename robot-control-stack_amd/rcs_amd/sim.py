@@ -173,6 +173,44 @@ def _lookup(model: Model, kind: str, name: str, label: str) -> int:
     return i
 
 
+class DeviceKinematics:
+    """``rcs.common.Kinematics`` (rcs.cpp:289-295) on the simulated chain: batched CLIK / FK kernels (csrc/ik.h).
+
+    The reference builds a separate pinocchio model from the robot's MJCF (``common.Pin``, creators.py:81-85); here the
+    IK frame and chain are the scene's own link tables, so no second model is loaded.
+    """
+
+    def __init__(self, sim: "Sim", dof: int):
+        self.sim, self.dof = sim, dof
+
+    def _tcp(self, tcp_offset):
+        if tcp_offset is None:
+            return None
+        v = tcp_offset.as_vec7() if isinstance(tcp_offset, common.Pose) else np.asarray(tcp_offset, dtype=np.float64)
+        return np.ascontiguousarray(v.reshape(7))
+
+    def inverse(self, pose, q0, tcp_offset=None):
+        """pose [N,7] (or Pose), q0 [N,dof] -> (q [N,nq], success [N], iterations [N]); failed rows of q are unspecified."""
+        n = self.sim.n_envs
+        if isinstance(pose, common.Pose):
+            pose = pose.as_vec7()
+        p = np.ascontiguousarray(np.broadcast_to(np.asarray(pose, dtype=np.float64), (n, 7)))
+        q0 = np.ascontiguousarray(np.broadcast_to(np.asarray(q0, dtype=np.float64)[..., : self.dof], (n, self.dof)))
+        q = np.zeros((n, self.sim.model.nq))
+        ok = np.zeros(n, dtype=np.uint8)
+        it = np.zeros(n, dtype=np.int32)
+        _lib.check(self.sim._L.rcsh_ik_inverse(self.sim._h, _lib.ptr(p), _lib.ptr(q0), _lib.ptr(self._tcp(tcp_offset)), _lib.ptr(q),
+                                               _lib.ptr(ok), _lib.ptr(it)))
+        return q, ok.astype(bool), it
+
+    def forward(self, q0, tcp_offset=None) -> np.ndarray:
+        n = self.sim.n_envs
+        q0 = np.ascontiguousarray(np.broadcast_to(np.asarray(q0, dtype=np.float64)[..., : self.dof], (n, self.dof)))
+        out = np.zeros((n, 7))
+        _lib.check(self.sim._L.rcsh_ik_forward(self.sim._h, _lib.ptr(q0), _lib.ptr(self._tcp(tcp_offset)), _lib.ptr(out)))
+        return out
+
+
 class SimRobot:
     """``rcs.sim.SimRobot(sim, ik, cfg, register_convergence_callback=True)`` (rcs.cpp:516-527)."""
 
@@ -202,6 +240,8 @@ class SimRobot:
         d.seconds_between_callbacks = cfg.seconds_between_callbacks
         d.register_convergence_callback = int(register_convergence_callback)
         _lib.check(self._L.rcsh_sim_add_robot(sim._h, C.byref(d)))
+        if self._ik is None:
+            self._ik = DeviceKinematics(sim, self.dof)
 
     @property
     def n_envs(self) -> int:

@@ -109,3 +109,61 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
             rep["steps"] += 1
     venv.close()
     return rep
+
+
+def cartesian_actions(n_envs: int, n_steps: int, seed: int = 0):
+    """xyz ~ U(+-0.05)^3 m, rpy ~ U(+-0.1)^3 rad, gripper toggled every 10 steps."""
+    act = np.zeros((n_steps, n_envs, 6))
+    grip = np.zeros((n_steps, n_envs), dtype=np.float32)
+    for e in range(n_envs):
+        rng = np.random.default_rng(seed + e)
+        act[:, e, :3] = rng.uniform(-0.05, 0.05, size=(n_steps, 3))
+        act[:, e, 3:] = rng.uniform(-0.1, 0.1, size=(n_steps, 3))
+        grip[:, e] = ((np.arange(n_steps) // 10) % 2).astype(np.float32)
+    return act, grip
+
+
+def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=0, mode="xyzrpy", relative=True, gripper=True):
+    """Cartesian control (relative TRPY / TQuat actions -> CLIK -> joint targets): HIP path vs the oracle."""
+    from rcs_amd.envs import ControlMode
+
+    cm = ControlMode.CARTESIAN_TRPY if mode == "xyzrpy" else ControlMode.CARTESIAN_TQuat
+    mm = (0.2, float(np.deg2rad(45)))
+    venv = make_vec_env(n_envs, async_control, gripper=gripper, relative=relative, control_mode=cm, max_relative_movement=mm)
+    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, relative=relative, mode=mode, max_relative_movement=mm)
+    act6, grip = cartesian_actions(n_envs, n_steps, seed)
+    rep = {"max_abs_qpos": 0.0, "max_abs_tquat": 0.0, "max_abs_target": 0.0, "flag_mismatches": 0, "steps": 0, "ik_fail": 0}
+    obs, info = venv.reset()
+    ores = [oe.reset() for oe in oenvs]
+    for t in range(n_steps):
+        if mode == "xyzrpy":
+            a_all = act6[t]
+        else:  # relative tquat action: translation + quaternion of the small rpy rotation
+            from rcs_amd.common import Pose
+
+            a_all = np.stack([np.concatenate([act6[t, e, :3], Pose(rpy_vector=act6[t, e, 3:]).rotation_q()]) for e in range(n_envs)])
+        if not relative:  # absolute target = current pose shifted
+            base = obs["xyzrpy"] if mode == "xyzrpy" else obs["tquat"]
+            a_all = base.copy()
+            a_all[:, :3] += act6[t, :, :3]
+        action = {mode: a_all}
+        if gripper:
+            action["gripper"] = grip[t]
+        obs, _, _, trunc, info = venv.step(action)
+        st = venv.robot.get_state()
+        q = venv.sim.qpos
+        for e, oe in enumerate(oenvs):
+            a = {mode: a_all[e]}
+            if gripper:
+                a["gripper"] = grip[t, e]
+            oo, _, _, otr, oi = oe.step(a)
+            rep["flag_mismatches"] += int(bool(trunc[e]) != bool(otr))
+            for k in ("collision", "ik_success", "is_sim_converged"):
+                rep["flag_mismatches"] += int(bool(info[k][e]) != bool(oi[k]))
+            rep["ik_fail"] += int(not oi["ik_success"])
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - oe.sim.qpos).max()))
+            rep["max_abs_tquat"] = max(rep["max_abs_tquat"], float(np.abs(obs["tquat"][e] - oo["tquat"]).max()))
+            rep["max_abs_target"] = max(rep["max_abs_target"], float(np.abs(st.target_angles[e] - np.array(oe.sim.s.target_angles[:7])).max()))
+        rep["steps"] += 1
+    venv.close()
+    return rep

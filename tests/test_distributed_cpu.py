@@ -1,0 +1,62 @@
+"""CPU, world_size 2, gloo: the N > 1 path of the rollout -- contiguous env shards per rank, one all-gather of the
+observation tensor per env-step, max-over-ranks timing reduction (what bench.py does over RCCL)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rcs_amd.envs.sharding import gather_observations, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n, w in [(4096, 1), (4096, 2), (4096, 8), (32768, 8), (10, 4), (3, 4)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def _worker(rank, world, port, n_total, width, steps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard_range(n_total, rank, world)
+    obs_all = None
+    ok = True
+    for t in range(steps):
+        ids = torch.arange(a, b, dtype=torch.float64).unsqueeze(1)
+        obs_local = ids * 100.0 + torch.arange(width, dtype=torch.float64).unsqueeze(0) + 0.001 * t  # "observation" of env id
+        obs_all = gather_observations(obs_local, obs_all)
+        expect = torch.arange(n_total, dtype=torch.float64).unsqueeze(1) * 100.0 + torch.arange(width, dtype=torch.float64).unsqueeze(0) + 0.001 * t
+        ok = ok and bool(torch.equal(obs_all, expect))
+    elapsed = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    ok = ok and float(elapsed) == 0.5 + world - 1
+    dist.barrier()
+    out.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_observation_all_gather():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 64, 21, 3, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    results = dict(out.get(timeout=5) for _ in range(2))
+    assert results == {0: True, 1: True}
+    _ = np

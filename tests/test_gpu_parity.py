@@ -7,7 +7,7 @@ run the same FP64 algorithm in different formulations), every flag and substep c
 import numpy as np
 import pytest
 
-from parity_util import run_joint_rollout_parity
+from parity_util import run_cartesian_rollout_parity, run_joint_rollout_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -31,3 +31,44 @@ def test_two_episodes_reset_quirks():
     # prev_action survives reset (Q2), gripper reset is overwritten by sim.reset (Q1)
     rep = run_joint_rollout_parity(n_envs=33, n_steps=4, async_control=True, seed=3, gripper=True, episodes=2)
     assert rep["max_abs_qpos"] < TOL and rep["flag_mismatches"] == 0, rep
+
+
+@pytest.mark.parametrize("mode", ["xyzrpy", "tquat"])
+def test_cartesian_relative_clik(mode):
+    # tolerance: the CLIK stops at |err| < 1e-4 after ~70-100 damped steps; both sides run the same iteration, so the
+    # solutions agree far below that (differences come from sin/cos implementations only)
+    rep = run_cartesian_rollout_parity(n_envs=32, n_steps=5, async_control=True, seed=11, mode=mode)
+    assert rep["max_abs_target"] < 1e-9 and rep["max_abs_qpos"] < 1e-9 and rep["max_abs_tquat"] < 1e-9, rep
+    assert rep["flag_mismatches"] == 0, rep
+
+
+def test_cartesian_absolute_until_convergence():
+    rep = run_cartesian_rollout_parity(n_envs=16, n_steps=2, async_control=False, seed=5, mode="xyzrpy", relative=False, gripper=False)
+    assert rep["max_abs_target"] < 1e-9 and rep["max_abs_qpos"] < 1e-9, rep
+    assert rep["flag_mismatches"] == 0, rep
+
+
+def test_ik_kernels_match_oracle_and_round_trip():
+    import rcs_oracle as O
+    from parity_util import make_vec_env
+
+    venv = make_vec_env(8, True, gripper=False, relative=False)
+    venv.reset()
+    ik = venv.robot.get_ik()
+    rng = np.random.default_rng(0)
+    q0 = np.tile(venv.robot.get_joint_position()[0], (8, 1))
+    qt = q0 + rng.uniform(-0.3, 0.3, size=q0.shape)
+    tcp = O.franka_hand_tcp_offset()
+    tcp7 = np.concatenate([tcp.translation(), tcp.rotation_q()])
+    pose = ik.forward(qt, tcp7)  # Pin::forward semantics: frame * tcp^-1
+    # target for inverse(): frame * tcp, so that inverse() recovers the frame (reference quirk Q7)
+    from rcs_amd.common import Pose
+
+    target = np.stack([(Pose(translation=p[:3], quaternion=p[3:]) * Pose(translation=tcp7[:3], quaternion=tcp7[3:]) *
+                        Pose(translation=tcp7[:3], quaternion=tcp7[3:])).as_vec7() for p in pose])
+    q, ok, iters = ik.inverse(target, q0, tcp7)
+    assert ok.all() and (iters > 5).all()
+    back = ik.forward(q[:, :7], tcp7)
+    assert np.abs(back[:, :3] - pose[:, :3]).max() < 2e-4
+    assert np.abs(q[:, 7:]).max() == 0.0
+    venv.close()

@@ -1,0 +1,144 @@
+"""CPU: scene compiler, host-side Pose mirror, C-ABI library surface, error mapping.  No GPU compute calls."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rcs_oracle as O
+from parity_util import ROOT, SCENE
+from rcs_amd import _lib, common
+from rcs_amd.mjcf import MjcfError, compile_mjcf
+
+REF_SCENE = "/root/reference/assets/scenes/fr3_empty_world/scene.xml"
+
+
+@pytest.fixture(scope="module")
+def cm():
+    return compile_mjcf(SCENE)
+
+
+def test_scene_sizes_and_names(cm):
+    assert (cm.nbody, cm.njnt, cm.nq, cm.nv, cm.nu, cm.ntendon, cm.neq) == (14, 9, 9, 9, 8, 1, 1)
+    assert cm.ngeom == 24 and cm.ncam == 2
+    for name in [f"fr3_joint{i}_0" for i in range(1, 8)] + ["finger_joint1_0", "finger_joint2_0"]:
+        assert cm.name2id("jnt", name) >= 0
+    for name in [f"fr3_link{i}_collision_0" for i in range(8)] + ["hand_c_0", "d435i_collision_0", "finger_0_left_0", "finger_0_right_0", "floor"]:
+        assert cm.name2id("geom", name) >= 0
+    assert cm.name2id("site", "attachment_site_0") >= 0 and cm.name2id("body", "base_0") >= 0
+    assert cm.name2id("actuator", "actuator8_0") == 7 and cm.name2id("cam", "wrist_0") >= 0
+
+
+def test_scene_constants_match_appendix_a(cm):
+    assert cm.timestep == 0.002 and cm.integrator == "implicitfast" and cm.cone == "elliptic"
+    assert cm.impratio == 20 and cm.noslip_iterations == 5
+    assert np.allclose(cm.gravity, [0, 0, -9.81])
+    j = cm.arrays
+    assert np.allclose(j["jnt_range"][:7], [[-2.7437, 2.7437], [-1.7837, 1.7837], [-2.9007, 2.9007], [-3.0421, -0.1518],
+                                            [-2.8065, 2.8065], [0.5445, 4.5169], [-3.0159, 3.0159]])
+    assert np.allclose(j["jnt_range"][7:], [[0, 0.04], [0, 0.04]]) and list(j["jnt_type"]) == [3] * 7 + [2, 2]
+    assert np.allclose(j["jnt_actfrcrange"][:7, 1], [87, 87, 87, 87, 12, 12, 12]) and list(j["jnt_actgravcomp"]) == [1] * 7 + [0, 0]
+    assert np.allclose(j["dof_armature"], 0.1) and np.allclose(j["dof_damping"], 1.0)
+    assert np.allclose(j["actuator_gainprm"][:7, 0], [4500, 4500, 3500, 3500, 2000, 2000, 2000])
+    assert np.allclose(j["actuator_biasprm"][:7, 1], -j["actuator_gainprm"][:7, 0])
+    assert np.allclose(j["actuator_biasprm"][:7, 2], [-450, -450, -350, -350, -200, -200, -200])
+    # position actuators inherit the joint range as ctrlrange; the gripper keeps 0..255 and an affine bias
+    assert np.allclose(j["actuator_ctrlrange"][:7], j["jnt_range"][:7]) and np.allclose(j["actuator_ctrlrange"][7], [0, 255])
+    assert list(j["actuator_biastype"]) == [1] * 8 and np.allclose(j["actuator_biasprm"][7], [0, -100, -10])
+    assert np.allclose(j["actuator_gainprm"][7, 0], 0.01568627451) and np.allclose(j["actuator_forcerange"][7], [-100, 100])
+    assert np.allclose(j["eq_solimp"][0, :3], [0.95, 0.99, 0.001]) and np.allclose(j["eq_solref"][0], [0.005, 1])
+    assert np.allclose(j["body_mass"][3:10], [2.92747, 2.93554, 2.2449, 2.6156, 2.32712, 1.81704, 0.627143])
+    assert np.allclose(j["body_gravcomp"][1:], 1.0) and np.allclose(j["wrap_prm"], [0.5, 0.5])
+    # quaternions are normalised by the compiler: "1 -1 0 0" -> 90 deg about -x
+    assert np.allclose(j["body_quat"][4], np.array([1, -1, 0, 0]) / np.sqrt(2))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SCENE), reason="reference checkout not present (GPU box)")
+def test_own_scene_equals_reference_scene_tables():
+    """The repository's physics-only scene compiles to the same tables as the reference's MJCF (include, default
+    classes, childclass, actuator-default inheritance), except the one documented approximation (d435i_0 inertia)."""
+    own, ref = compile_mjcf(SCENE), compile_mjcf(REF_SCENE)
+    skip_rows = {"body_ipos": [11], "body_mass": [11], "body_inertia": [11], "body_iquat": [11]}
+    for key, a in own.arrays.items():
+        if key.startswith(("geom_", "cam_")):
+            continue
+        b = ref.arrays[key]
+        assert a.shape == b.shape, key
+        mask = np.ones(a.shape[0], dtype=bool) if a.ndim else None
+        for r in skip_rows.get(key, []):
+            mask[r] = False
+        assert np.allclose(a[mask], b[mask]), key
+    assert own.jnt_names == ref.jnt_names and own.actuator_names == ref.actuator_names and own.body_names == ref.body_names
+    assert set(own.geom_names) <= set(ref.geom_names) | {"camera_mount_collision_0"}
+
+
+def test_compiler_rejects_unknown_filetype(tmp_path):
+    with pytest.raises(MjcfError):
+        compile_mjcf(str(tmp_path / "scene.mjb"))
+
+
+def test_host_pose_matches_oracle_pose():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        t, rpy = rng.uniform(-1, 1, 3), rng.uniform(-np.pi, np.pi, 3)
+        hp, op = common.Pose(translation=t, rpy_vector=rpy), O.Pose(translation=t, rpy_vector=rpy)
+        assert np.allclose(hp.rotation_q(), op.rotation_q(), atol=1e-15) and np.allclose(hp.pose_matrix(), op.pose_matrix(), atol=1e-15)
+        assert np.allclose(hp.xyzrpy(), op.xyzrpy(), atol=1e-12)
+        t2, q2 = rng.uniform(-1, 1, 3), rng.normal(size=4)
+        h2, o2 = common.Pose(translation=t2, quaternion=q2), O.Pose(translation=t2, quaternion=q2)
+        assert np.allclose((hp * h2).as_vec7(), np.concatenate([(op * o2).translation(), (op * o2).rotation_q()]), atol=1e-14)
+        assert np.allclose(hp.inverse().as_vec7(), np.concatenate([op.inverse().translation(), op.inverse().rotation_q()]), atol=1e-14)
+        assert abs(hp.total_angle() - op.total_angle()) < 1e-13
+        for lim in (0.05, 0.5):
+            a, b = hp.limit_rotation_angle(lim).limit_translation_length(lim), op.limit_rotation_angle(lim).limit_translation_length(lim)
+            assert np.allclose(a.as_vec7(), np.concatenate([b.translation(), b.rotation_q()]), atol=1e-13)
+        m = hp.pose_matrix()
+        assert np.allclose(common.Pose(pose_matrix=m).as_vec7(), np.concatenate([O.Pose(pose_matrix=m).translation(), O.Pose(pose_matrix=m).rotation_q()]), atol=1e-13)
+    tcp_h, tcp_o = common.Pose(pose_matrix=common.FrankaHandTCPOffset()), O.franka_hand_tcp_offset()
+    assert np.allclose(tcp_h.as_vec7(), np.concatenate([tcp_o.translation(), tcp_o.rotation_q()]), atol=1e-15)
+
+
+def test_robots_meta_config_values():
+    fr3 = common.robots_meta_config(common.RobotType.FR3)
+    assert fr3.dof == 7 and np.allclose(fr3.q_home, [0, -np.pi / 4, 0, -3 * np.pi / 4, 0, np.pi / 2, np.pi / 4])
+    assert np.allclose(fr3.joint_limits[0], [-2.3093, -1.5133, -2.4937, -2.7478, -2.4800, 0.8521, -2.6895])
+    assert common.robots_meta_config(common.RobotType.UR5e).dof == 6 and common.robots_meta_config(common.RobotType.SO101).dof == 5
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function include/rcs_hip.h declares is exported by librcs_hip.so (built by __graft_entry__.build())."""
+    header = open(os.path.join(ROOT, "include", "rcs_hip.h")).read()
+    declared = set(re.findall(r"\b(rcsh_[a-z0-9_]+)\s*\(", header))
+    declared -= {"rcsh_model_desc", "rcsh_robot_desc", "rcsh_gripper_desc", "rcsh_env_desc", "rcsh_sim"}
+    L = _lib.load()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) == declared
+    assert L.rcsh_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device Sim creation fails loudly (RuntimeError), it never steps on the CPU."""
+    L = _lib.load()
+    if L.rcsh_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from rcs_amd import sim
+
+    with pytest.raises(RuntimeError, match="no HIP device|hip"):
+        sim.Sim(SCENE, n_envs=4)
+
+
+def test_config_mirrors_reference_defaults():
+    from rcs_amd import sim
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+
+    c = sim.SimConfig()
+    assert (c.async_control, c.realtime, c.frequency, c.max_convergence_steps) == (False, False, 30, 500)
+    r = default_sim_robot_cfg()
+    assert r.joints == [f"fr3_joint{i}_0" for i in range(1, 8)] and r.attachment_site == "attachment_site_0" and r.base == "base_0"
+    assert abs(r.joint_rotational_tolerance - 0.05 * np.pi / 180) < 1e-18 and r.seconds_between_callbacks == 0.1
+    g = default_sim_gripper_cfg()
+    assert g.joint == "finger_joint1_0" and g.actuator == "actuator8_0" and g.seconds_between_callbacks == 0.05
+    assert (g.max_actuator_width, g.min_actuator_width, g.max_joint_width, g.min_joint_width) == (255, 0, 0.04, 0.0)

@@ -1,0 +1,173 @@
+"""CPU: the oracle against every pin the reference's own tests / sources hold for this path.
+
+These are the only anchors the third-party physics (MuJoCo) has here; the oracle header says "parity unpinned"
+beyond them.  Expected values live in tests/golden/reference_pins.json.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rcs_oracle as O
+from parity_util import SCENE
+from rcs_amd.mjcf import compile_mjcf
+from rcs_env_oracle import CARTESIAN_TQUAT, CARTESIAN_TRPY, JOINTS, OracleEnv
+
+PINS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_pins.json")))
+
+
+@pytest.fixture(scope="module")
+def cm():
+    return compile_mjcf(SCENE)
+
+
+def _pose(m):
+    return O.Pose(pose_matrix=np.array(m, dtype=np.float64))
+
+
+# ---- (vi) Pose known answers, test_common.py (exact where the reference asserts array_equal)
+def test_identity_quaternion_is_xyzw():
+    assert np.array_equal(O.Pose().rotation_q(), [0, 0, 0, 1])
+
+
+def test_pose_is_close_cases():
+    for c in PINS["pose_is_close_cases"]:
+        assert _pose(c["a"]).is_close(_pose(c["b"]), eps_t=c["eps_t"]) == c["expected"]
+
+
+def test_pose_multiply_inverse_matrix_exact():
+    c = PINS["pose_multiply"]
+    assert np.array_equal((_pose(c["a"]) * _pose(c["b"])).pose_matrix(), np.array(c["expected"], dtype=float))
+    c = PINS["pose_inverse"]
+    assert np.array_equal(_pose(c["a"]).inverse().pose_matrix(), np.array(c["expected"], dtype=float))
+    p = O.Pose(quaternion=[0, 0, 0, 1.0], translation=[1.0, 1.0, 1.0])
+    assert np.array_equal(p.pose_matrix(), [[1, 0, 0, 1], [0, 1, 0, 1], [0, 0, 1, 1], [0, 0, 0, 1]])
+
+
+def test_interpolate_full_progress():
+    a = O.Pose(rotation=np.eye(3), translation=[0, 0, 0])
+    b = O.Pose(rotation=np.eye(3), translation=[1.0, 1.0, 1.0])
+    r = a.interpolate(b, 1.0)
+    assert np.array_equal(r.rotation_m(), np.eye(3)) and np.array_equal(r.translation(), [1.0, 1.0, 1.0])
+
+
+# ---- (iv) home_m: xyzrpy round trip (test_common.py:198-218)
+def test_home_m_rpy_round_trip():
+    home_m = np.array(PINS["home_m"])
+    home = _pose(home_m)
+    assert np.allclose(home.pose_matrix(), home_m)
+    trpy = home.xyzrpy()
+    assert np.allclose(trpy[:3], home.translation())
+    home2 = O.Pose(translation=trpy[:3], rpy_vector=trpy[3:])
+    assert home.is_close(home2) and np.allclose(home_m, home2.pose_matrix())
+    assert O.Pose(translation=[0, 0, 0], rpy_vector=[0, 0, 0]).is_close(O.Pose())
+
+
+def test_home_fk_matches_hand_fk_and_settled_reading(cm):
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=False, tcp_offset=O.franka_hand_tcp_offset())
+    env.reset()
+    tcp = env.sim.get_cartesian_position()
+    assert np.allclose(tcp.translation(), PINS["home_fk_tcp"], atol=1e-8)
+    # the reference's home_m is a settled-simulation reading of the same pose: agrees to ~1e-3
+    assert np.allclose(tcp.translation(), np.array(PINS["home_m"])[:3, 3], atol=1e-3)
+    assert tcp.is_close(_pose(PINS["home_m"]), eps_r=5e-3, eps_t=2e-3)
+    env2 = OracleEnv(cm, control_mode=JOINTS, gripper=False)
+    env2.reset()
+    assert np.allclose(env2.sim.get_cartesian_position().translation(), PINS["home_fk_site"], atol=1e-8)
+
+
+# ---- (i) JOINTS integration pins, test_sim_envs.py:304-345
+def test_joints_zero_and_nonzero_action_reach_target(cm):
+    tol = PINS["env_tolerances"]["joints_atol"]
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=False)
+    obs0, _ = env.reset()
+    obs, _, _, _, info = env.step({"joints": obs0["joints"].copy()})
+    assert info["ik_success"] and np.allclose(obs["joints"], obs0["joints"], atol=tol, rtol=0)
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=False)
+    obs0, _ = env.reset()
+    target = obs0["joints"] + np.array([0.1, 0.1, 0.1, 0.1, -0.1, -0.1, 0.1], dtype=np.float32)
+    obs, _, _, _, info = env.step({"joints": target})
+    assert info["ik_success"] and np.allclose(obs["joints"], target, atol=tol, rtol=0)
+
+
+def test_double_reset_and_relative_zero_action(cm):
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=True, max_relative_movement=0.5)
+    env.reset()
+    obs0, _ = env.reset()
+    obs, _, _, _, info = env.step({"joints": np.zeros(7, dtype=np.float32), "gripper": 1})
+    assert info["ik_success"]
+    a = O.Pose(translation=obs["tquat"][:3], quaternion=obs["tquat"][3:])
+    b = O.Pose(translation=obs0["tquat"][:3], quaternion=obs0["tquat"][3:])
+    assert a.is_close(b, PINS["env_tolerances"]["pose_eps_r"], PINS["env_tolerances"]["pose_eps_t"])
+
+
+# ---- (ii) Cartesian pins, test_sim_envs.py:70-134,202-250
+@pytest.mark.parametrize("mode,dx", [(CARTESIAN_TRPY, 0.2), (CARTESIAN_TQUAT, 0.3)])
+def test_cartesian_absolute_move(cm, mode, dx):
+    env = OracleEnv(cm, control_mode=mode, gripper=False)
+    obs0, _ = env.reset()
+    if mode == CARTESIAN_TRPY:
+        t = obs0["tquat"][:3].copy()
+        t[0] += dx
+        act = {"xyzrpy": np.concatenate([t, O.Pose(translation=t, quaternion=obs0["tquat"][3:]).rotation_rpy()])}
+    else:
+        a = obs0["tquat"].copy()
+        a[0] += dx
+        act = {"tquat": a}
+    obs, _, _, _, info = env.step(act)
+    assert info["ik_success"]
+    expected = obs0["tquat"].copy()
+    expected[0] += dx
+    out = O.Pose(translation=obs["tquat"][:3], quaternion=obs["tquat"][3:])
+    exp = O.Pose(translation=expected[:3], quaternion=expected[3:])
+    assert out.is_close(exp, PINS["env_tolerances"]["pose_eps_r"], PINS["env_tolerances"]["pose_eps_t"])
+
+
+def test_cartesian_relative_move_with_gripper(cm):
+    env = OracleEnv(cm, control_mode=CARTESIAN_TRPY, gripper=True, max_relative_movement=0.5)
+    obs0, _ = env.reset()
+    obs, _, _, _, info = env.step({"xyzrpy": np.array([0.2, 0, 0, 0, 0, 0.0]), "gripper": 0})
+    assert info["ik_success"]
+    expected = obs0["tquat"].copy()
+    expected[0] += 0.2
+    out = O.Pose(translation=obs["tquat"][:3], quaternion=obs["tquat"][3:])
+    exp = O.Pose(translation=expected[:3], quaternion=expected[3:])
+    assert out.is_close(exp, PINS["env_tolerances"]["pose_eps_r"], PINS["env_tolerances"]["pose_eps_t"])
+
+
+# ---- (v) src/sim/test.cpp: IK reaches the sample target; arrival within 3 deg / 1.875 cm after convergence
+def test_ik_sample_target(cm):
+    s = PINS["ik_sample"]
+    tcp = O.Pose(translation=s["tcp_offset_translation"])
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=False, tcp_offset=tcp)
+    env.reset()
+    target = _pose(s["target_matrix"])
+    env.sim.set_cartesian_position(target)
+    assert env.sim.s.ik_success
+    # a 2.8 rad move of joint 7 under its 12 Nm clamp outlasts one 500-substep budget; the reference loop calls
+    # step_until_convergence once per target, from wherever the previous target left the arm
+    for _ in range(3):
+        env.sim.step_until_convergence()
+        if env.sim.s.converged:
+            break
+    reached = env.sim.get_cartesian_position()
+    assert target.is_close(reached, np.deg2rad(s["arrival_rtol_deg"]), s["arrival_ttol_m"])
+    assert env.sim.s.is_arrived and not env.sim.s.is_moving
+    # (the joint values printed in the same source comment belong to an older robot model: fed through this
+    # chain they land 14 cm from the printed target, so they are not used as a pin)
+
+
+# ---- callback cadence, SURVEY quirk Q3: 10 Hz predicates fire on accumulated double time
+def test_callback_cadence_follows_accumulated_time(cm):
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=False)
+    obs0, _ = env.reset()
+    env.step({"joints": obs0["joints"].copy()})
+    # The env-step starts at substep n = 2 (reset ran n = 1).  set_joint_position cleared is_arrived; the plain
+    # callbacks first re-sample it at n = 51 (time - 0 > 0.1 needs 51 additions of 0.002), one substep AFTER the
+    # convergence predicate was evaluated at n = 50, so the predicate only sees it at n = 100: 99 substeps.
+    assert env.sim.s.convergence_steps == 99
+    env.step({"joints": obs0["joints"] + 0.05})
+    n = env.sim.s.convergence_steps
+    assert n % 50 in (0, 1) and n >= 100
