@@ -153,7 +153,7 @@ int rcsh_sim_synchronize(rcsh_sim* sim);
 void* rcsh_sim_stream(rcsh_sim* sim);
 int rcsh_sim_set_stream(rcsh_sim* sim, void* hip_stream);
 
-/* Sim.set_config / get_config -- rcs.cpp:500-501, sim.cpp:27-32; SimConfig sim.h:29-34 */
+/* Sim.set_config / get_config -- rcs.cpp:501-502, sim.cpp:27-32; SimConfig sim.h:29-34 */
 int rcsh_sim_set_config(rcsh_sim* sim, int32_t async_control, int32_t realtime, int32_t frequency,
                         int32_t max_convergence_steps);
 int rcsh_sim_get_config(const rcsh_sim* sim, int32_t* async_control, int32_t* realtime, int32_t* frequency,
@@ -162,32 +162,32 @@ int rcsh_sim_get_config(const rcsh_sim* sim, int32_t* async_control, int32_t* re
 int rcsh_sim_step(rcsh_sim* sim, int64_t k);
 /* Sim.step_until_convergence() -- rcs.cpp:498-499, sim.cpp:84-106 */
 int rcsh_sim_step_until_convergence(rcsh_sim* sim);
-/* Sim.is_converged() -- rcs.cpp:502, sim.cpp:83; also the substeps the last call took per env */
+/* Sim.is_converged() -- rcs.cpp:500, sim.cpp:83; also the substeps the last call took per env */
 int rcsh_sim_is_converged(rcsh_sim* sim, uint8_t* converged, int32_t* convergence_steps);
 /* Sim.reset() -- rcs.cpp:504, sim.cpp:117-138 */
 int rcsh_sim_reset(rcsh_sim* sim, const uint8_t* mask);
 
 /* SimRobot(sim, ik, cfg, register_convergence_callback) -- rcs.cpp:516-527, SimRobot.cpp:27-43 */
 int rcsh_sim_add_robot(rcsh_sim* sim, const rcsh_robot_desc* robot);
-/* Robot.set_joint_position -- rcs.cpp:358-360, SimRobot.cpp:123-131 */
+/* Robot.set_joint_position -- rcs.cpp:358-359, SimRobot.cpp:123-131 */
 int rcsh_robot_set_joint_position(rcsh_sim* sim, const double* q, const uint8_t* mask);
-/* Robot.get_joint_position -- rcs.cpp:361, SimRobot.cpp:133-139 */
+/* Robot.get_joint_position -- rcs.cpp:360, SimRobot.cpp:133-139 */
 int rcsh_robot_get_joint_position(rcsh_sim* sim, double* q);
-/* Robot.get_cartesian_position -- rcs.cpp:357, SimRobot.cpp:114-121 */
+/* Robot.get_cartesian_position -- rcs.cpp:356-357, SimRobot.cpp:114-121 */
 int rcsh_robot_get_cartesian_position(rcsh_sim* sim, double* pose);
-/* Robot.get_base_pose_in_world_coordinates -- rcs.cpp:374, SimRobot.cpp:207-213 */
+/* Robot.get_base_pose_in_world_coordinates -- rcs.cpp:369-370, SimRobot.cpp:207-213 */
 int rcsh_robot_get_base_pose(rcsh_sim* sim, double* pose);
-/* Robot.set_cartesian_position -- rcs.cpp:366-367, SimRobot.cpp:145-155 (Pin CLIK, Kinematics.cpp:28-68) */
+/* Robot.set_cartesian_position -- rcs.cpp:365-367, SimRobot.cpp:145-155 (Pin CLIK, Kinematics.cpp:28-68) */
 int rcsh_robot_set_cartesian_position(rcsh_sim* sim, const double* pose, const uint8_t* mask);
 /* SimRobot.set_joints_hard -- rcs.cpp:525, SimRobot.cpp:198-205 */
 int rcsh_robot_set_joints_hard(rcsh_sim* sim, const double* q, const uint8_t* mask);
-/* Robot.reset / move_home -- rcs.cpp:362-365, SimRobot.cpp:47-50,193-196 */
+/* Robot.reset / move_home -- rcs.cpp:361-363, SimRobot.cpp:47-50,193-196 */
 int rcsh_robot_reset(rcsh_sim* sim, const uint8_t* mask);
 int rcsh_robot_move_home(rcsh_sim* sim, const uint8_t* mask);
-/* SimRobot.get_state -- rcs.cpp:523, SimRobotState SimRobot.h:49-57; any pointer may be NULL */
+/* SimRobot.get_state -- rcs.cpp:527, SimRobotState SimRobot.h:49-57; any pointer may be NULL */
 int rcsh_robot_get_state(rcsh_sim* sim, uint8_t* ik_success, uint8_t* collision, uint8_t* is_moving,
                          uint8_t* is_arrived, double* previous_angles, double* target_angles);
-/* Kinematics.inverse / forward on the robot's own chain -- rcs.cpp:285-300, Kinematics.cpp:28-82.
+/* Kinematics.inverse / forward on the robot's own chain -- rcs.cpp:289-300, Kinematics.cpp:28-82.
  * q0 [N][dof] -> q [N][nq] (nq = model dofs, quirk Q7), success [N], iterations [N] (may be NULL) */
 int rcsh_ik_inverse(rcsh_sim* sim, const double* pose, const double* q0, const double* tcp_offset7, double* q,
                     uint8_t* success, int32_t* iterations);
@@ -195,15 +195,15 @@ int rcsh_ik_forward(rcsh_sim* sim, const double* q0, const double* tcp_offset7, 
 
 /* SimGripper(sim, cfg) -- rcs.cpp:508-515, SimGripper.cpp:13-39 */
 int rcsh_sim_add_gripper(rcsh_sim* sim, const rcsh_gripper_desc* gripper);
-/* Gripper.set_normalized_width -- rcs.cpp:381-383, SimGripper.cpp:79-92 (RCSH_ERR_ARG outside [0,1] / force<0) */
+/* Gripper.set_normalized_width -- rcs.cpp:383-384, SimGripper.cpp:79-92 (RCSH_ERR_ARG outside [0,1] / force<0) */
 int rcsh_gripper_set_normalized_width(rcsh_sim* sim, const double* width, double force, const uint8_t* mask);
-/* Gripper.get_normalized_width -- rcs.cpp:384, SimGripper.cpp:93-106 */
+/* Gripper.get_normalized_width -- rcs.cpp:385, SimGripper.cpp:93-106 */
 int rcsh_gripper_get_normalized_width(rcsh_sim* sim, double* width);
-/* Gripper.is_grasped -- rcs.cpp:385, SimGripper.cpp:132-141 */
+/* Gripper.is_grasped -- rcs.cpp:388, SimGripper.cpp:132-141 */
 int rcsh_gripper_is_grasped(rcsh_sim* sim, uint8_t* grasped);
-/* Gripper.reset -- rcs.cpp:395-396, SimGripper.cpp:158-165 */
+/* Gripper.reset -- rcs.cpp:395, SimGripper.cpp:158-165 */
 int rcsh_gripper_reset(rcsh_sim* sim, const uint8_t* mask);
-/* SimGripper.get_state -- rcs.cpp:513, SimGripperState SimGripper.h:47-52 */
+/* SimGripper.get_state -- rcs.cpp:514, SimGripperState SimGripper.h:47-52 */
 int rcsh_gripper_get_state(rcsh_sim* sim, double* last_commanded_width, uint8_t* is_moving, double* last_width,
                            uint8_t* collision);
 

@@ -15,4 +15,6 @@ rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_SMEM SQ_INSTS_LDS SQ
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc3" -o pmc3 -- $CMD > "$OUT/bench_pmc3.log" 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc4" -o pmc4 -- $CMD > "$OUT/bench_pmc4.log" 2>&1
 python profiles/summarize.py "$OUT" > "$OUT/summary.txt" 2>&1
+python tools/host_rate.py >> "$OUT/summary.txt" 2>&1
+tail -1 "$OUT/bench_stats.log" >> "$OUT/summary.txt"
 cat "$OUT/summary.txt"

@@ -15,7 +15,9 @@ def find(pattern):
 for f in find("*kernel_stats.csv"):
     print("== kernel stats:", f)
     for row in list(csv.DictReader(open(f)))[:6]:
-        print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+        d = {k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+        d["Name"] = d["Name"][:70]
+        print(d)
 
 for f in find("*counter_collection.csv"):
     print("== counters:", f)
