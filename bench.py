@@ -142,10 +142,12 @@ def main() -> None:
     sub = torch.zeros((n,), device="cuda", dtype=torch.int32)
     obs_all = torch.zeros((world * n, ow), device="cuda", dtype=torch.float64) if world > 1 else None
 
+    from rcs_amd.envs.sharding import gather_observations
+
     def one_step(t: int) -> None:
         env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), obs.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(obs_all, obs)
+            gather_observations(obs, obs_all)
 
     env.reset_dev(obs.data_ptr(), info.data_ptr(), gw.data_ptr())
     for t in range(args.warmup):
@@ -185,6 +187,11 @@ def main() -> None:
         algo_bytes = ALGO_BYTES_PER_ENV_STEP * n
         achieved_gbs = algo_bytes / (kernel_ms * 1e-3) / 1e9
         substeps_per_launch = mean_sub * n
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath) and args.mode == "async" and n == N_ENVS:
+            tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
+            traffic = (tj["fetch_size_kb_per_dispatch"] + tj["write_size_kb_per_dispatch"]) * 1024
         out = {
             "metric": "env-steps/sec (whole node), fr3_empty_world JOINTS mode, 4096 envs per GPU",
             "value": value,
@@ -213,7 +220,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "rocprofv3 FETCH_SIZE + WRITE_SIZE, separate PMC passes (profiles/r1_traffic.json)" if traffic else None,
                 "kernel": "k_run<Topo<7,true>> (fused env-step)",
                 "kernel_ms_avg": kernel_ms,
                 "launches_timed": int(launches.value),
