@@ -193,16 +193,32 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
     o[0] += p[0]; o[1] += p[1]; o[2] += p[2];
     mulmm(R, m.rot0[i], R0);
     double ax[3];
-    mulmv(R0, m.axis[i], ax);
     const double dq = q[i] - m.qpos0[i];
     double Si[6];
-    if (m.jtype[i] == kSlide) {
+    if (m.axis_z[i]) {
+      // hinge about the link's +z through the link origin (every FR3 / xArm7 joint): the rotation only mixes
+      // the first two columns of R0, the world axis is its third column, the anchor is the origin
+      double s, c;
+      fast_sincos(dq, &s, &c);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        R[3 * r + 0] = c * R0[3 * r + 0] + s * R0[3 * r + 1];
+        R[3 * r + 1] = c * R0[3 * r + 1] - s * R0[3 * r + 0];
+        R[3 * r + 2] = R0[3 * r + 2];
+        ax[r] = R0[3 * r + 2];
+        p[r] = o[r];
+      }
+      Si[0] = ax[0]; Si[1] = ax[1]; Si[2] = ax[2];
+      cross3(o, ax, Si + 3);
+    } else if (m.jtype[i] == kSlide) {
+      mulmv(R0, m.axis[i], ax);
 #pragma unroll
       for (int k = 0; k < 9; ++k) R[k] = R0[k];
       p[0] = o[0] + ax[0] * dq; p[1] = o[1] + ax[1] * dq; p[2] = o[2] + ax[2] * dq;
       Si[0] = 0; Si[1] = 0; Si[2] = 0; Si[3] = ax[0]; Si[4] = ax[1]; Si[5] = ax[2];
     } else {
-      // Rodrigues rotation about the link-frame axis
+      // general hinge: Rodrigues rotation about the link-frame axis
+      mulmv(R0, m.axis[i], ax);
       double s, c;
       fast_sincos(dq, &s, &c);
       const double* a = m.axis[i];
@@ -229,10 +245,15 @@ RCSH_HD void smooth_dynamics(const DevModel& m, const double* q, const double* q
     double c[3], cg[3];
     mulmv(R, m.com[i], c);
     c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
-    mulmv(R, m.gccom[i], cg);
-    st.hg(i, 0) = m.gcm[i] * (cg[0] + p[0]);
-    st.hg(i, 1) = m.gcm[i] * (cg[1] + p[1]);
-    st.hg(i, 2) = m.gcm[i] * (cg[2] + p[2]);
+    if (m.gc_same_com[i]) {  // uniform gravcomp over the link: its centre is the centre of mass
+      cg[0] = c[0]; cg[1] = c[1]; cg[2] = c[2];
+    } else {
+      mulmv(R, m.gccom[i], cg);
+      cg[0] += p[0]; cg[1] += p[1]; cg[2] += p[2];
+    }
+    st.hg(i, 0) = m.gcm[i] * cg[0];
+    st.hg(i, 1) = m.gcm[i] * cg[1];
+    st.hg(i, 2) = m.gcm[i] * cg[2];
     double Ii[10];
     {
       const double* J = m.inertia[i];
@@ -517,52 +538,126 @@ RCSH_HD void substep(const DevModel& m, const Stage<T, STRIDE>& st) {
   }
   stage_fence();
 
-  // ---- qacc = argmin 1/2 |qacc - M^-1 smooth|_M^2 + sum s_i(J_i qacc - aref_i): active-set Newton.
-  // A Newton step under a guessed active set is exact if the set it lands in equals the guess.
+  // ---- qacc = argmin 1/2 |qacc - M^-1 smooth|_M^2 + sum s_i(J_i qacc - aref_i), s_i quadratic (coupling
+  // row) or one-sided quadratic (limit rows).  Newton on the piecewise-quadratic cost: the minimiser under a
+  // guessed active set is the answer if the set it lands in equals the guess; otherwise an exact line search
+  // along the Newton direction is taken from the current iterate and the step repeated (finite convergence).
   double fc[NL];  // qfrc_constraint
 #pragma unroll
   for (int i = 0; i < NL; ++i) fc[i] = 0;
   if ((T::GRIP && m.eq_active) || limrows) {
-    double qacc[NL];
-    uint32_t act = limrows;
-    for (int iter = 0; iter < 8; ++iter) {
-      double H[T::NTRI];
+    const bool has_eq = T::GRIP && m.eq_active;
+    double x[NL];
+    uint32_t act = limrows;  // first guess: every limit row that exists is active
+    bool have_x = false;
+    for (int iter = 0; iter < 16; ++iter) {
+      double xn[NL];
+      {
+        double H[T::NTRI];
 #pragma unroll
-      for (int k = 0; k < T::NTRI; ++k) H[k] = st.M(k);
+        for (int k = 0; k < T::NTRI; ++k) H[k] = st.M(k);
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        qacc[i] = smooth[i];
-        if (act & (1u << i)) {
-          const double D = st.lim(i, 0);
-          H[tri(i, i)] += D;
-          qacc[i] += st.lim(i, 2) * D * st.lim(i, 1);
+        for (int i = 0; i < NL; ++i) {
+          xn[i] = smooth[i];
+          if (act & (1u << i)) {
+            const double D = st.lim(i, 0);
+            H[tri(i, i)] += D;
+            xn[i] += st.lim(i, 2) * D * st.lim(i, 1);
+          }
         }
+        if (has_eq) {
+          H[tri(NA, NA)] += eqD;
+          H[tri(NA + 1, NA)] += eqD * eqJ1;
+          H[tri(NA + 1, NA + 1)] += eqD * eqJ1 * eqJ1;
+          xn[NA] += eqD * eqAref;
+          xn[NA + 1] += eqD * eqAref * eqJ1;
+        }
+        ldl_factor<NL>(H);
+        ldl_solve<NL>(H, xn);
       }
-      if (T::GRIP && m.eq_active) {
-        H[tri(NA, NA)] += eqD;
-        H[tri(NA + 1, NA)] += eqD * eqJ1;
-        H[tri(NA + 1, NA + 1)] += eqD * eqJ1 * eqJ1;
-        qacc[NA] += eqD * eqAref;
-        qacc[NA + 1] += eqD * eqAref * eqJ1;
-      }
-      ldl_factor<NL>(H);
-      ldl_solve<NL>(H, qacc);
       uint32_t now = 0;
 #pragma unroll
       for (int i = 0; i < NL; ++i)
-        if ((limrows & (1u << i)) && st.lim(i, 2) * qacc[i] - st.lim(i, 1) < 0) now |= 1u << i;
-      const bool same = now == act;
-      act = now;
-      if (same) break;
+        if ((limrows & (1u << i)) && st.lim(i, 2) * xn[i] - st.lim(i, 1) < 0) now |= 1u << i;
+      if (now == act || !have_x) {
+        // either the exact minimiser, or the starting point of the line-search iteration
+#pragma unroll
+        for (int i = 0; i < NL; ++i) x[i] = xn[i];
+        have_x = true;
+        if (now == act) break;
+        act = now;
+        continue;
+      }
+      // exact line search from x along d = xn - x:
+      // phi'(a) = p0 + a p1 + sum_{rows active at a} D_i jd_i (jar_i + a jd_i)
+      double d[NL], jar[NL], jd[NL];
+      double p0 = 0, p1 = 0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) d[i] = xn[i] - x[i];
+#pragma unroll
+      for (int r = 0; r < NL; ++r) {
+        double mx = -smooth[r], md = 0;
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+          const double mrc = st.M(r >= c ? tri(r, c) : tri(c, r));
+          mx += mrc * x[c];
+          md += mrc * d[c];
+        }
+        p0 += mx * d[r];
+        p1 += md * d[r];
+      }
+      if (has_eq) {
+        const double je = x[NA] + eqJ1 * x[NA + 1] - eqAref, jde = d[NA] + eqJ1 * d[NA + 1];
+        p0 += eqD * je * jde;
+        p1 += eqD * jde * jde;
+      }
+      uint32_t on = 0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        jar[i] = 0; jd[i] = 0;
+        if (limrows & (1u << i)) {
+          const double sgn = st.lim(i, 2);
+          jar[i] = sgn * x[i] - st.lim(i, 1);
+          jd[i] = sgn * d[i];
+          if (jar[i] < 0 || (jar[i] == 0 && jd[i] < 0)) on |= 1u << i;
+        }
+      }
+      double alpha = 0;
+      for (int guard = 0; guard < NL + 2; ++guard) {
+        double c0 = p0, c1 = p1, a_next = INFINITY;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          if (!(limrows & (1u << i))) continue;
+          const double D = st.lim(i, 0);
+          if (on & (1u << i)) { c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
+          if (jd[i] != 0) {
+            const double ab = -jar[i] / jd[i];
+            if (ab > alpha && ab < a_next) a_next = ab;
+          }
+        }
+        const double a_star = -c0 / c1;
+        if (a_star <= a_next) { if (a_star > alpha) alpha = a_star; break; }
+        alpha = a_next;
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+          if ((limrows & (1u << i)) && jd[i] != 0 && -jar[i] / jd[i] == a_next) on ^= 1u << i;
+      }
+      act = 0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        x[i] += alpha * d[i];
+        if ((limrows & (1u << i)) && st.lim(i, 2) * x[i] - st.lim(i, 1) < 0) act |= 1u << i;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NL; ++i)
-      if (act & (1u << i)) {
+      if ((limrows & (1u << i))) {
         const double sgn = st.lim(i, 2);
-        fc[i] = -sgn * st.lim(i, 0) * (sgn * qacc[i] - st.lim(i, 1));
+        const double r = sgn * x[i] - st.lim(i, 1);
+        if (r < 0) fc[i] = -sgn * st.lim(i, 0) * r;
       }
-    if (T::GRIP && m.eq_active) {
-      const double fe = -eqD * (qacc[NA] + eqJ1 * qacc[NA + 1] - eqAref);
+    if (has_eq) {
+      const double fe = -eqD * (x[NA] + eqJ1 * x[NA + 1] - eqAref);
       fc[NA] += fe;
       fc[NA + 1] += fe * eqJ1;
     }

@@ -8,6 +8,7 @@
 #include "model_host.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 

@@ -64,7 +64,8 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
     venv = make_vec_env(n_envs, async_control, gripper=gripper)
     oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper)
     joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed)
-    rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}
+    rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_finger": 0.0, "max_abs_gripper_width": 0.0,
+           "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}
 
     def compare(obs, info, oracle_results, substeps=None):
         for e, (oo, oi) in enumerate(oracle_results):
@@ -76,14 +77,18 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
                                      rpy_distance(obs["xyzrpy"][e][3:], oo["xyzrpy"][3:]))
             if gripper:
                 rep["flag_mismatches"] += int(float(obs["gripper"][e]) != float(oo["gripper"]))
-                rep["max_abs_obs"] = max(rep["max_abs_obs"], abs(float(info["gripper_width"][e]) - oi["gripper_width"]))
+                rep["max_abs_gripper_width"] = max(rep["max_abs_gripper_width"], abs(float(info["gripper_width"][e]) - oi["gripper_width"]))
             for k in ("collision", "ik_success", "is_sim_converged", "is_grasped"):
                 if k in oi and k in info:
                     rep["flag_mismatches"] += int(bool(info[k][e]) != bool(oi[k]))
         q, v = venv.sim.qpos, venv.sim.qvel
         for e, oe in enumerate(oenvs):
-            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - oe.sim.qpos).max()))
-            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - oe.sim.qvel).max()))
+            # arm joints and finger slides are reported separately: the fingers rest exactly on a joint limit with zero
+            # actuator force (the reference model's gripper equilibrium IS the limit), where the sign of round-off decides
+            # whether a limit row exists in a substep, so their trajectories are only reproducible to ~1e-5 m
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:7] - oe.sim.qpos[:7]).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e][:7] - oe.sim.qvel[:7]).max()))
+            rep["max_abs_finger"] = max(rep["max_abs_finger"], float(np.abs(q[e][7:] - oe.sim.qpos[7:]).max()))
             if substeps is not None and not async_control:
                 rep["substep_mismatches"] += int(int(substeps[e]) != int(oe.sim.s.convergence_steps))
 
@@ -161,9 +166,53 @@ def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=
             for k in ("collision", "ik_success", "is_sim_converged"):
                 rep["flag_mismatches"] += int(bool(info[k][e]) != bool(oi[k]))
             rep["ik_fail"] += int(not oi["ik_success"])
-            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - oe.sim.qpos).max()))
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:7] - oe.sim.qpos[:7]).max()))
             rep["max_abs_tquat"] = max(rep["max_abs_tquat"], float(np.abs(obs["tquat"][e] - oo["tquat"]).max()))
             rep["max_abs_target"] = max(rep["max_abs_target"], float(np.abs(st.target_angles[e] - np.array(oe.sim.s.target_angles[:7])).max()))
         rep["steps"] += 1
     venv.close()
+    return rep
+
+
+def run_physics_parity_mid_stroke(n_envs=64, n_calls=6, k=17, seed=0):
+    """Sim.step(k) through the fine-grained API with the fingers held mid-stroke (no limit row ever switches):
+    every joint must then agree with the oracle to round-off."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    from rcs_env_oracle import FR3_Q_HOME
+
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    q0 = np.tile(np.concatenate([FR3_Q_HOME, [0.02, 0.02]]), (n_envs, 1))
+    q0[:, :7] += rng.uniform(-0.2, 0.2, size=(n_envs, 7))
+    simu.set_qpos(q0)
+    grip.set_normalized_width(np.full(n_envs, 0.5))
+    for e, o in enumerate(osims):
+        for i in range(9):
+            o.s.d.qpos[i] = q0[e, i]
+        o.gripper_set_normalized_width(0.5)
+    rep = {"max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_cart": 0.0, "flag_mismatches": 0}
+    for _ in range(n_calls):
+        tgt = q0[:, :7] + rng.uniform(-0.1, 0.1, size=(n_envs, 7))
+        robot.set_joint_position(tgt)
+        simu.step(k)
+        q, v, cart, st = simu.qpos, simu.qvel, robot.get_cartesian_position(), robot.get_state()
+        for e, o in enumerate(osims):
+            o.set_joint_position(tgt[e])
+            o.step(k)
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - o.qpos).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - o.qvel).max()))
+            p = o.get_cartesian_position()
+            rep["max_abs_cart"] = max(rep["max_abs_cart"], float(np.abs(cart[e] - np.concatenate([p.translation(), p.rotation_q()])).max()))
+            rep["flag_mismatches"] += int(bool(st.is_moving[e]) != bool(o.s.is_moving)) + int(bool(st.is_arrived[e]) != bool(o.s.is_arrived))
+    simu.close()
     return rep
