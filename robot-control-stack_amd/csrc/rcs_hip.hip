@@ -29,7 +29,8 @@ int fail(int code, const std::string& msg) {
       return fail(RCSH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
   } while (0)
 
-constexpr int kBlock = kLanes;  // one (partially filled) wave per workgroup: each gets a CU to itself
+constexpr int kBlock = 64;     // accessor kernels
+constexpr int kRunLanes = 16;  // environments per workgroup of k_run
 constexpr int kProfRing = 4096;
 
 }  // namespace
@@ -115,9 +116,13 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
     }
     HIP_TRY(hipEventRecord(s->ev_start[s->prof_pending], s->stream));
   }
+  // 16 environments per workgroup (one quarter-filled wave each).  The launch is latency-bound per wave, so
+  // what counts is how many waves are in flight: 4096 environments are 256 workgroups = one per CU, and for
+  // larger batches the 52 KB of LDS per workgroup (staging columns + model tables) lets three share a CU
+  // (measured at 32768 environments: 26.2 M env-steps/s with 16 lanes, 18.4 M with 32).
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    hipLaunchKernelGGL(k_run<T>, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, P, op);
+    hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);
     err = hipGetLastError();
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");

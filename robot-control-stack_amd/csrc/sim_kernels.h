@@ -17,10 +17,6 @@
 
 namespace rcsh {
 
-// lanes (= environments) per workgroup.  32 keeps the per-lane LDS staging column (~2.8 KB) plus the model
-// tables inside one CU's 160 KB; at 4096 environments that is 128 single-wave workgroups on 128 CUs.
-constexpr int kLanes = 32;
-
 // ---- per-environment flag word
 enum : uint32_t {
   kAnyRet0 = 1u << 0,   // last_return_value of any_callbacks[0] (robot collision)
@@ -105,7 +101,7 @@ struct Params {
 };
 
 // ---- everything one environment keeps in registers during a launch
-template <class T>
+template <class T, int kLanes>
 struct EnvRegs {
   double time;
   double last_cmd_width, last_width;
@@ -119,8 +115,8 @@ struct EnvRegs {
   int32_t conv_steps;
 };
 
-template <class T>
-__device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T>& r) {
+template <class T, int kLanes>
+__device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T, kLanes>& r) {
   using L = Lay<T>;
   const int n = P.n;
   const double* S = P.S;
@@ -139,8 +135,8 @@ __device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T>& r) 
   r.conv_steps = P.conv_steps[e];
 }
 
-template <class T>
-__device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<T>& r) {
+template <class T, int kLanes>
+__device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<T, kLanes>& r) {
   using L = Lay<T>;
   const int n = P.n;
   double* S = P.S;
@@ -162,8 +158,8 @@ __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<
 __device__ __forceinline__ void set_flag(uint32_t& f, uint32_t bit, bool v) { f = v ? (f | bit) : (f & ~bit); }
 
 // SimGripper::get_normalized_width, reference src/sim/SimGripper.cpp:93-106
-template <class T>
-__device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T>& r) {
+template <class T, int kLanes>
+__device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T, kLanes>& r) {
   const double qf = P.grip.finger ? r.st.q(T::NL - 1) : r.st.q(T::NL - 2);
   double w = (qf - P.grip.min_joint) / (P.grip.max_joint - P.grip.min_joint);
   return w < 0 ? 0 : (w > 1 ? 1 : w);
@@ -171,8 +167,8 @@ __device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T
 
 // Sim::invoke_callbacks, reference src/sim/sim.cpp:38-47, with SimRobot::is_arrived_callback /
 // is_moving_callback (src/sim/SimRobot.cpp:156-170) as the two registered callbacks
-template <class T>
-__device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T>& r) {
+template <class T, int kLanes>
+__device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T, kLanes>& r) {
   if (!(P.robot.present && P.robot.conv_registered)) return;
   if (r.time - r.cb(0) > P.robot.period) {
     double mx = 0;
@@ -194,8 +190,8 @@ __device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T>& r) 
 // SimRobot::collision_callback / convergence_callback (SimRobot.cpp:172-191),
 // SimGripper::collision_callback / convergence_callback (SimGripper.cpp:108-130,143-151).
 // No contact-capable pair exists in this revision, so ncon == 0 and both collision scans return false.
-template <class T>
-__device__ __forceinline__ bool condition_callbacks(const Params& P, EnvRegs<T>& r) {
+template <class T, int kLanes>
+__device__ __forceinline__ bool condition_callbacks(const Params& P, EnvRegs<T, kLanes>& r) {
   const bool has_g = T::GRIP && P.grip.present;
   if (P.robot.present && r.time - r.cb(2) > P.robot.period) {
     set_flag(r.flags, kRobotCollision, false);
@@ -213,7 +209,7 @@ __device__ __forceinline__ bool condition_callbacks(const Params& P, EnvRegs<T>&
     r.cb(4) = r.time;
   }
   if (has_g && r.time - r.cb(5) > P.grip.period) {
-    const double w = gripper_width<T>(P, r);
+    const double w = gripper_width<T, kLanes>(P, r);
     const bool moving = fabs(r.last_width - w) > 0.001 * (P.grip.max_act - P.grip.min_act);
     set_flag(r.flags, kGripMoving, moving);
     r.last_width = w;
@@ -229,8 +225,8 @@ __device__ __forceinline__ bool condition_callbacks(const Params& P, EnvRegs<T>&
 }
 
 // SimRobot::set_joint_position, reference src/sim/SimRobot.cpp:123-131
-template <class T>
-__device__ __forceinline__ void robot_set_joint_position(EnvRegs<T>& r, const double* a) {
+template <class T, int kLanes>
+__device__ __forceinline__ void robot_set_joint_position(EnvRegs<T, kLanes>& r, const double* a) {
 #pragma unroll
   for (int i = 0; i < T::NARM; ++i) {
     r.target(i) = a[i];
@@ -241,8 +237,8 @@ __device__ __forceinline__ void robot_set_joint_position(EnvRegs<T>& r, const do
 }
 
 // SimGripper::set_normalized_width, reference src/sim/SimGripper.cpp:79-92
-template <class T>
-__device__ __forceinline__ void gripper_set_width(const Params& P, EnvRegs<T>& r, double w) {
+template <class T, int kLanes>
+__device__ __forceinline__ void gripper_set_width(const Params& P, EnvRegs<T, kLanes>& r, double w) {
   r.last_cmd_width = w;
   r.st.c(T::NU - 1) = w * (P.grip.max_act - P.grip.min_act) + P.grip.min_act;
 }
@@ -266,7 +262,7 @@ __device__ __forceinline__ void cartesian_position(const DevModel& m, const Robo
 }
 
 // The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step.
-template <class T>
+template <class T, int kLanes>
 __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   using L = Lay<T>;
   // Model tables: staged into LDS once per launch and read back with broadcast ds_reads.  (Scalar
@@ -292,9 +288,9 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   // LDS staging column of this lane (dyn.h: Stage), [slot][lane]
   __shared__ double lds[Stage<T, kLanes>::COUNT * kLanes];
   const Stage<T, kLanes> st{lds + threadIdx.x};
-  EnvRegs<T> r;
+  EnvRegs<T, kLanes> r;
   r.st = st;
-  load_env<T>(P, e, r);
+  load_env<T, kLanes>(P, e, r);
   bool have_frames = false;
 
   if (op.do_reset) {
@@ -347,10 +343,10 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
       if (P.env.binary_gripper) g = rintf(g);  // np.round: half to even
       g = fminf(fmaxf(g, 0.0f), 1.0f);
       if (P.env.binary_gripper) {
-        gripper_set_width<T>(P, r, g == 0.0f ? 0.0 : 1.0);  // grasp() = shut() : open()
+        gripper_set_width<T, kLanes>(P, r, g == 0.0f ? 0.0 : 1.0);  // grasp() = shut() : open()
         set_flag(r.flags, kGripCmd, g != 0.0f);
       } else {
-        gripper_set_width<T>(P, r, (double)g);
+        gripper_set_width<T, kLanes>(P, r, (double)g);
         set_flag(r.flags, kGripCmd, g >= 0.5f);
       }
       r.flags |= kHasGripCmd;
@@ -363,7 +359,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
       changed = changed || !(fabs(a[i] - pa) <= 1e-3);
       P.S[(L::PREVA + i) * n + e] = a[i];
     }
-    if (changed) robot_set_joint_position<T>(r, a);
+    if (changed) robot_set_joint_position<T, kLanes>(r, a);
     r.flags |= kHasPrevAction;
   }
 
@@ -381,14 +377,14 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   }
   bool converged = false;
   while (budget > 0 && !converged) {
-    plain_callbacks<T>(P, r);
+    plain_callbacks<T, kLanes>(P, r);
     substep<T, kLanes>(m, st);
     r.time += m.timestep;
     have_frames = true;
     --budget;
     if (until_conv) {
       r.conv_steps++;
-      converged = condition_callbacks<T>(P, r);
+      converged = condition_callbacks<T, kLanes>(P, r);
     }
   }
   if (until_conv) set_flag(r.flags, kConverged, converged);
@@ -419,7 +415,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
     }
     r.flags &= ~kHasLastAction;
   }
-  store_env<T>(P, e, r);
+  store_env<T, kLanes>(P, e, r);
 
   if (op.write_obs) {
     // RobotEnv.get_obs (base.py:246-253) + GripperWrapper.observation (base.py:710-719) +
@@ -444,7 +440,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
     double gobs = 1.0, w = 0.0;
     const bool has_g = T::GRIP && P.grip.present;
     if (has_g) {
-      w = gripper_width<T>(P, r);
+      w = gripper_width<T, kLanes>(P, r);
       if (P.env.binary_gripper) gobs = (r.flags & kHasGripCmd) ? ((r.flags & kGripCmd) ? 1.0 : 0.0) : 1.0;
       else gobs = w;
     }
