@@ -99,6 +99,18 @@ typedef struct rcsh_model_desc {
   const int32_t* site_bodyid;        /* [nsite] */
   const double* site_pos;            /* [nsite][3] */
   const double* site_quat;           /* [nsite][4] */
+  /* collision geoms (contact DETECTION against the static plane geoms; flags only) */
+  int32_t ngeom, nmeshvert;
+  const int32_t* geom_type;          /* [ngeom] mjtGeom: 0 plane, 2 sphere, 3 capsule, 6 box, 7 mesh */
+  const int32_t* geom_bodyid;        /* [ngeom] */
+  const int32_t* geom_contype;       /* [ngeom] */
+  const int32_t* geom_conaffinity;   /* [ngeom] */
+  const double* geom_pos;            /* [ngeom][3] */
+  const double* geom_quat;           /* [ngeom][4] */
+  const double* geom_size;           /* [ngeom][3] */
+  const int32_t* geom_vertadr;       /* [ngeom] first row of mesh_vert */
+  const int32_t* geom_vertnum;       /* [ngeom] 0: no vertex set (geom never reports contacts) */
+  const double* mesh_vert;           /* [nmeshvert][3] convex-hull vertices, geom frame */
 } rcsh_model_desc;
 
 /* SimRobotConfig after name -> id lookup (reference src/sim/SimRobot.h:14-47, SimRobot.cpp:52-94). */
@@ -113,6 +125,8 @@ typedef struct rcsh_robot_desc {
   double joint_rotational_tolerance; /* SimRobot.h:15 */
   double seconds_between_callbacks;  /* SimRobot.h:17 */
   int32_t register_convergence_callback;
+  int32_t n_collision_geoms;         /* SimRobotConfig.arm_collision_geoms after name lookup (SimRobot.cpp:55-62) */
+  const int32_t* collision_geom_ids;
 } rcsh_robot_desc;
 
 /* SimGripperConfig after name -> id lookup (reference src/sim/SimGripper.h:15-45). */
@@ -123,6 +137,11 @@ typedef struct rcsh_gripper_desc {
   double seconds_between_callbacks;
   double max_actuator_width, min_actuator_width;
   double max_joint_width, min_joint_width;
+  /* SimGripperConfig.collision_geoms / collision_geoms_fingers / ignored_collision_geoms (SimGripper.cpp:31-33,57-63) */
+  int32_t n_collision_geoms, n_finger_geoms, n_ignored_geoms;
+  const int32_t* collision_geom_ids;
+  const int32_t* finger_geom_ids;
+  const int32_t* ignored_geom_ids;
 } rcsh_gripper_desc;
 
 /* Gymnasium-loop configuration of the fused env-step (reference python/rcs/envs/creators.py:43-128). */

@@ -33,6 +33,9 @@ extern "C" {
 #define ORC_MAXSITE 8
 #define ORC_MAXEFC (ORC_MAXEQ + 2 * ORC_MAXV)
 #define ORC_MAXARM 8
+#define ORC_MAXGEOM 32
+#define ORC_MAXCON 32
+#define ORC_MAXCGEOM 16
 
 enum { ORC_JNT_SLIDE = 2, ORC_JNT_HINGE = 3 };
 enum { ORC_TRN_JOINT = 0, ORC_TRN_TENDON = 3 };
@@ -97,6 +100,15 @@ typedef struct orc_model {
   int site_bodyid[ORC_MAXSITE];
   double site_pos[ORC_MAXSITE][3];
   double site_quat[ORC_MAXSITE][4];
+  /* collision geoms (plane vs convex contact detection only) */
+  int ngeom;
+  int geom_type[ORC_MAXGEOM];       /* mjtGeom: 0 plane, 2 sphere, 3 capsule, 6 box, 7 mesh */
+  int geom_bodyid[ORC_MAXGEOM];
+  int geom_contype[ORC_MAXGEOM], geom_conaffinity[ORC_MAXGEOM];
+  int geom_vertadr[ORC_MAXGEOM], geom_vertnum[ORC_MAXGEOM];
+  double geom_pos[ORC_MAXGEOM][3], geom_quat[ORC_MAXGEOM][4], geom_size[ORC_MAXGEOM][3];
+  const double* mesh_vert;          /* [nvert][3] hull vertices, geom frame (owned by the caller) */
+  int body_weldid[ORC_MAXBODY];
   /* derived by orc_set0 */
   double dof_invweight0[ORC_MAXV];
 } orc_model;
@@ -133,6 +145,7 @@ typedef struct orc_data {
   double efc_K[ORC_MAXEFC], efc_B[ORC_MAXEFC], efc_I[ORC_MAXEFC];
   double qfrc_constraint[ORC_MAXV];
   int solver_niter;
+  int contact_geom[ORC_MAXCON][2];  /* d->contact[i].geom, i < ncon */
 } orc_data;
 
 void orc_set0(orc_model* m);
@@ -203,18 +216,22 @@ typedef struct orc_sim {
   int ik_success, robot_collision, is_moving, is_arrived;
   orc_ik ik;
   int last_ik_iterations;
+  int arm_ncgeom, arm_cgeom[ORC_MAXCGEOM];
   /* SimGripper (SimGripper.h) */
   int grp_jnt, grp_act;
   double grp_period, max_actuator_width, min_actuator_width, max_joint_width, min_joint_width;
   double epsilon_inner, epsilon_outer;
   double last_commanded_width, last_width;
   int grp_is_moving, grp_collision;
+  int grp_ncgeom, grp_cgeom[ORC_MAXCGEOM], grp_ncfgeom, grp_cfgeom[ORC_MAXCGEOM], grp_nignored, grp_ignored[ORC_MAXCGEOM];
 } orc_sim;
 
 void orc_sim_init(orc_sim* s, orc_model* m);
 void orc_sim_add_robot(orc_sim* s, int n, const int* jnt_ids, const int* act_ids, int site, int base_body,
                        const double* q_home, const orc_pose* tcp_offset, int register_convergence_callback);
 void orc_sim_add_gripper(orc_sim* s, int jnt, int act);
+void orc_sim_set_robot_cgeoms(orc_sim* s, int n, const int* ids);
+void orc_sim_set_gripper_cgeoms(orc_sim* s, int n, const int* cgeom, int nf, const int* cfgeom, int ni, const int* ignored);
 void orc_sim_step(orc_sim* s, long k);
 void orc_sim_step_until_convergence(orc_sim* s);
 void orc_sim_reset(orc_sim* s);

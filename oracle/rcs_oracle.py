@@ -16,6 +16,7 @@ _SO = os.path.join(_HERE, "_build", "librcs_oracle.so")
 
 MAXBODY, MAXV, MAXU, MAXEQ, MAXTENDON, MAXWRAP, MAXSITE, MAXARM = 32, 16, 16, 4, 4, 8, 8, 8
 MAXEFC = MAXEQ + 2 * MAXV
+MAXGEOM, MAXCON, MAXCGEOM = 32, 32, 16
 D = C.c_double
 I = C.c_int
 
@@ -49,6 +50,10 @@ class OrcModel(C.Structure):
         ("actuator_ctrllimited", I * MAXU), ("actuator_ctrlrange", D * 2 * MAXU),
         ("actuator_forcelimited", I * MAXU), ("actuator_forcerange", D * 2 * MAXU),
         ("site_bodyid", I * MAXSITE), ("site_pos", D * 3 * MAXSITE), ("site_quat", D * 4 * MAXSITE),
+        ("ngeom", I), ("geom_type", I * MAXGEOM), ("geom_bodyid", I * MAXGEOM),
+        ("geom_contype", I * MAXGEOM), ("geom_conaffinity", I * MAXGEOM), ("geom_vertadr", I * MAXGEOM), ("geom_vertnum", I * MAXGEOM),
+        ("geom_pos", D * 3 * MAXGEOM), ("geom_quat", D * 4 * MAXGEOM), ("geom_size", D * 3 * MAXGEOM),
+        ("mesh_vert", C.POINTER(D)), ("body_weldid", I * MAXBODY),
         ("dof_invweight0", D * MAXV),
     ]
 
@@ -69,7 +74,7 @@ class OrcData(C.Structure):
         ("efc_pos", D * MAXEFC), ("efc_margin", D * MAXEFC), ("efc_vel", D * MAXEFC),
         ("efc_D", D * MAXEFC), ("efc_aref", D * MAXEFC), ("efc_force", D * MAXEFC),
         ("efc_K", D * MAXEFC), ("efc_B", D * MAXEFC), ("efc_I", D * MAXEFC),
-        ("qfrc_constraint", D * MAXV), ("solver_niter", I),
+        ("qfrc_constraint", D * MAXV), ("solver_niter", I), ("contact_geom", I * 2 * MAXCON),
     ]
 
 
@@ -104,11 +109,13 @@ class OrcSim(C.Structure):
         ("joint_rotational_tolerance", D), ("robot_period", D), ("tcp_offset", OrcPose), ("q_home", D * MAXARM),
         ("previous_angles", D * MAXARM), ("target_angles", D * MAXARM),
         ("ik_success", I), ("robot_collision", I), ("is_moving", I), ("is_arrived", I),
-        ("ik", OrcIk), ("last_ik_iterations", I),
+        ("ik", OrcIk), ("last_ik_iterations", I), ("arm_ncgeom", I), ("arm_cgeom", I * MAXCGEOM),
         ("grp_jnt", I), ("grp_act", I), ("grp_period", D),
         ("max_actuator_width", D), ("min_actuator_width", D), ("max_joint_width", D), ("min_joint_width", D),
         ("epsilon_inner", D), ("epsilon_outer", D), ("last_commanded_width", D), ("last_width", D),
         ("grp_is_moving", I), ("grp_collision", I),
+        ("grp_ncgeom", I), ("grp_cgeom", I * MAXCGEOM), ("grp_ncfgeom", I), ("grp_cfgeom", I * MAXCGEOM),
+        ("grp_nignored", I), ("grp_ignored", I * MAXCGEOM),
     ]
 
 
@@ -172,6 +179,19 @@ def make_model(cm) -> OrcModel:
                  "actuator_forcelimited", "site_bodyid"):
         _fill(getattr(m, name), i32(name))
     _fill(m.body_parentid, i32("body_parentid"))
+    _fill(m.body_weldid, i32("body_weldid"))
+    if cm.ngeom > MAXGEOM:
+        raise ValueError("scene exceeds oracle geom table size")
+    m.ngeom = cm.ngeom
+    for name in ("geom_type", "geom_bodyid", "geom_contype", "geom_conaffinity", "geom_vertadr", "geom_vertnum"):
+        _fill(getattr(m, name), i32(name))
+    for name in ("geom_pos", "geom_quat", "geom_size"):
+        _fill(getattr(m, name), f64(name))
+    verts = np.ascontiguousarray(cm.arrays["mesh_vert"], dtype=np.float64).reshape(-1)
+    if verts.size == 0:
+        verts = np.zeros(3)
+    m._verts = verts  # keep alive
+    m.mesh_vert = verts.ctypes.data_as(C.POINTER(D))
     if np.any(cm.arrays["dof_frictionloss"] != 0):
         raise ValueError("frictionloss rows are not restated in this oracle revision")
     lib().orc_set0(C.byref(m))
@@ -277,7 +297,7 @@ class Sim:
 
     def __init__(self, cm, robot_joints, robot_actuators, attachment_site, base, q_home, tcp_offset: Pose | None = None,
                  gripper_joint: str | None = None, gripper_actuator: str | None = None,
-                 register_convergence_callback: bool = True):
+                 register_convergence_callback: bool = True, idx: str = "0"):
         L = lib()
         self.cm = cm
         self.model = make_model(cm)
@@ -295,6 +315,13 @@ class Sim:
             L.orc_sim_add_gripper(C.byref(self.s), self._id("jnt", gripper_joint, "joint"),
                                   self._id("actuator", gripper_actuator, "actuator"))
         self.n = n
+        # SimRobotConfig.arm_collision_geoms / SimGripperConfig collision geom lists (SimRobot.h:19-22, SimGripper.h:24-29)
+        arm_g = [self._id("geom", f"fr3_link{i}_collision_{idx}", "geom") for i in range(8)]
+        L.orc_sim_set_robot_cgeoms(C.byref(self.s), len(arm_g), (I * len(arm_g))(*arm_g))
+        if gripper_joint is not None:
+            cg = [self._id("geom", f"{g}_{idx}", "geom") for g in ("hand_c", "d435i_collision", "finger_0_left", "finger_0_right")]
+            cf = [self._id("geom", f"{g}_{idx}", "geom") for g in ("finger_0_left", "finger_0_right")]
+            L.orc_sim_set_gripper_cgeoms(C.byref(self.s), len(cg), (I * len(cg))(*cg), len(cf), (I * len(cf))(*cf), 0, (I * 1)(0))
 
     def _id(self, kind, name, label):
         i = self.cm.name2id(kind, name)

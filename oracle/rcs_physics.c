@@ -393,6 +393,89 @@ static void make_constraint(const orc_model* m, orc_data* d) {
   d->nefc = n;
 }
 
+/* mj_collision restricted to plane-vs-convex pairs: a contact exists when the deepest point of the convex geom
+   is below the plane (margin 0).  Pair filters as MuJoCo applies them: bodies welded together never collide,
+   contype/conaffinity masks must match, parent-child pairs are skipped unless the parent is the world. */
+static void collision(const orc_model* m, orc_data* d) {
+  d->ncon = 0;
+  for (int pg = 0; pg < m->ngeom; pg++) {
+    if (m->geom_type[pg] != 0) continue;
+    int pb = m->geom_bodyid[pg];
+    double pq[4], pR[9], pp[3], vec[3];
+    q_mul(pq, d->xquat[pb], m->geom_quat[pg]);
+    q_to_mat(pR, pq);
+    m3_mulvec(vec, d->xmat[pb], m->geom_pos[pg]);
+    v3_add(pp, vec, d->xpos[pb]);
+    double n[3] = {pR[2], pR[5], pR[8]};
+    for (int g = 0; g < m->ngeom; g++) {
+      if (g == pg || m->geom_type[g] == 0) continue;
+      int b = m->geom_bodyid[g];
+      if (m->body_weldid[b] == m->body_weldid[pb]) continue;
+      if (!((m->geom_contype[g] & m->geom_conaffinity[pg]) || (m->geom_contype[pg] & m->geom_conaffinity[g]))) continue;
+      {
+        int w1 = m->body_weldid[pb], w2 = m->body_weldid[b];
+        int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
+        if ((w1 && w1 == pw2) || (w2 && w2 == pw1)) continue;
+      }
+      double gq[4], gR[9], gp[3];
+      q_mul(gq, d->xquat[b], m->geom_quat[g]);
+      q_to_mat(gR, gq);
+      m3_mulvec(vec, d->xmat[b], m->geom_pos[g]);
+      v3_add(gp, vec, d->xpos[b]);
+      double dist = INFINITY;
+      const double* sz = m->geom_size[g];
+      { /* broad phase (MuJoCo: geom_rbound vs plane): skip geoms whose bounding sphere clears the plane */
+        double rb = 0, x[3];
+        if (m->geom_type[g] == 7) {
+          for (int v = 0; v < m->geom_vertnum[g]; v++) {
+            const double* w = m->mesh_vert + 3 * (m->geom_vertadr[g] + v);
+            double r2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+            if (r2 > rb) rb = r2;
+          }
+          rb = sqrt(rb);
+        } else if (m->geom_type[g] == 6) rb = sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+        else if (m->geom_type[g] == 3) rb = sz[0] + sz[1];
+        else rb = sz[0];
+        v3_sub(x, gp, pp);
+        if (v3_dot(n, x) - rb > 0) continue;
+      }
+      if (m->geom_type[g] == 7) {
+        for (int v = 0; v < m->geom_vertnum[g]; v++) {
+          double w[3], x[3];
+          m3_mulvec(w, gR, m->mesh_vert + 3 * (m->geom_vertadr[g] + v));
+          v3_add(x, w, gp);
+          v3_sub(x, x, pp);
+          double dd = v3_dot(n, x);
+          if (dd < dist) dist = dd;
+        }
+      } else if (m->geom_type[g] == 6) {
+        for (int c = 0; c < 8; c++) {
+          double loc[3] = {(c & 1 ? sz[0] : -sz[0]), (c & 2 ? sz[1] : -sz[1]), (c & 4 ? sz[2] : -sz[2])}, w[3], x[3];
+          m3_mulvec(w, gR, loc);
+          v3_add(x, w, gp);
+          v3_sub(x, x, pp);
+          double dd = v3_dot(n, x);
+          if (dd < dist) dist = dd;
+        }
+      } else if (m->geom_type[g] == 3 || m->geom_type[g] == 2) {
+        for (int e = 0; e < (m->geom_type[g] == 3 ? 2 : 1); e++) {
+          double loc[3] = {0, 0, m->geom_type[g] == 3 ? (e ? -sz[1] : sz[1]) : 0}, w[3], x[3];
+          m3_mulvec(w, gR, loc);
+          v3_add(x, w, gp);
+          v3_sub(x, x, pp);
+          double dd = v3_dot(n, x) - sz[0];
+          if (dd < dist) dist = dd;
+        }
+      }
+      if (dist < 0 && d->ncon < ORC_MAXCON) {
+        d->contact_geom[d->ncon][0] = pg;
+        d->contact_geom[d->ncon][1] = g;
+        d->ncon++;
+      }
+    }
+  }
+}
+
 /* ------------------------------------------------------------- velocity stage */
 
 /* mj_comVel */
@@ -474,7 +557,7 @@ void orc_step1(const orc_model* m, orc_data* d) {
   com_pos(m, d);
   tendon_and_transmission(m, d);
   crb(m, d);
-  d->ncon = 0; /* mj_collision: no contact-capable pair in this revision */
+  collision(m, d); /* mj_collision: detection only -- contacts raise flags, they apply no force in this revision */
   make_constraint(m, d);
   /* mj_fwdVelocity */
   for (int u = 0; u < m->nu; u++) {

@@ -71,8 +71,18 @@ static void robot_is_moving_cb(orc_sim* s) { /* SimRobot.cpp:156-163 */
   }
   s->is_moving = mx > 0.0001;
 }
+static int in_set(const int* set, int n, int g) {
+  for (int i = 0; i < n; i++) if (set[i] == g) return 1;
+  return 0;
+}
 static int robot_collision_cb(orc_sim* s) { /* SimRobot.cpp:172-182: scan of d->contact[0..ncon) */
-  s->robot_collision = 0; /* ncon == 0 in this revision */
+  s->robot_collision = 0;
+  for (int i = 0; i < s->d.ncon; i++) {
+    if (in_set(s->arm_cgeom, s->arm_ncgeom, s->d.contact_geom[i][0]) || in_set(s->arm_cgeom, s->arm_ncgeom, s->d.contact_geom[i][1])) {
+      s->robot_collision = 1;
+      break;
+    }
+  }
   return s->robot_collision;
 }
 static int robot_convergence_cb(orc_sim* s) { /* SimRobot.cpp:184-191 */
@@ -87,7 +97,16 @@ static int gripper_convergence_cb(orc_sim* s) { /* SimGripper.cpp:143-151 */
   return !s->grp_is_moving;
 }
 static int gripper_collision_cb(orc_sim* s) { /* SimGripper.cpp:108-130 */
-  s->grp_collision = 0; /* ncon == 0 in this revision */
+  s->grp_collision = 0;
+  for (int i = 0; i < s->d.ncon; i++) {
+    int g0 = s->d.contact_geom[i][0], g1 = s->d.contact_geom[i][1];
+    if (in_set(s->grp_cfgeom, s->grp_ncfgeom, g0) && in_set(s->grp_cfgeom, s->grp_ncfgeom, g1)) continue; /* finger-finger */
+    if ((in_set(s->grp_cgeom, s->grp_ncgeom, g0) || in_set(s->grp_cgeom, s->grp_ncgeom, g1)) &&
+        !(in_set(s->grp_ignored, s->grp_nignored, g1) || in_set(s->grp_ignored, s->grp_nignored, g1))) { /* geom[1] twice: Q6 */
+      s->grp_collision = 1;
+      break;
+    }
+  }
   return s->grp_collision;
 }
 
@@ -230,6 +249,17 @@ void orc_gripper_reset(orc_sim* s) { /* SimGripper.cpp:158-165 */
   s->last_commanded_width = 0; s->grp_is_moving = 0; s->last_width = 0; s->grp_collision = 0;
   s->d.qpos[s->grp_jnt] = s->max_joint_width;
   s->d.ctrl[s->grp_act] = s->max_actuator_width;
+}
+
+void orc_sim_set_robot_cgeoms(orc_sim* s, int n, const int* ids) { /* SimRobot::init_ids, SimRobot.cpp:55-62 */
+  s->arm_ncgeom = n;
+  for (int i = 0; i < n; i++) s->arm_cgeom[i] = ids[i];
+}
+void orc_sim_set_gripper_cgeoms(orc_sim* s, int n, const int* cgeom, int nf, const int* cfgeom, int ni, const int* ignored) {
+  s->grp_ncgeom = n; s->grp_ncfgeom = nf; s->grp_nignored = ni; /* SimGripper.cpp:31-33,57-63 */
+  for (int i = 0; i < n; i++) s->grp_cgeom[i] = cgeom[i];
+  for (int i = 0; i < nf; i++) s->grp_cfgeom[i] = cfgeom[i];
+  for (int i = 0; i < ni; i++) s->grp_ignored[i] = ignored[i];
 }
 
 unsigned long orc_sizeof_model(void) { return sizeof(orc_model); }

@@ -113,6 +113,36 @@ RCSH_HD void cross_force(const double* vel, const double* f, double* r) {
   cross3(vel, f + 3, r + 3);
 }
 
+// World frame of link i from its parent link's frame (R, p are updated in place): the kinematic step of the
+// forward sweep on its own, for code that needs frames only (contact detection, IK).
+RCSH_HD void advance_link_frame(const DevModel& m, int i, double qi, double* R, double* p) {
+  double o[3], R0[9];
+  mulmv(R, m.pos0[i], o);
+  o[0] += p[0]; o[1] += p[1]; o[2] += p[2];
+  mulmm(R, m.rot0[i], R0);
+  const double dq = qi - m.qpos0[i];
+  if (m.jtype[i] == kSlide) {
+    double ax[3];
+    mulmv(R0, m.axis[i], ax);
+    for (int k = 0; k < 9; ++k) R[k] = R0[k];
+    p[0] = o[0] + ax[0] * dq; p[1] = o[1] + ax[1] * dq; p[2] = o[2] + ax[2] * dq;
+    return;
+  }
+  double s, c;
+  fast_sincos(dq, &s, &c);
+  const double* a = m.axis[i];
+  const double t = 1.0 - c;
+  const double Q[9] = {c + t * a[0] * a[0],        t * a[0] * a[1] - s * a[2], t * a[0] * a[2] + s * a[1],
+                       t * a[0] * a[1] + s * a[2], c + t * a[1] * a[1],        t * a[1] * a[2] - s * a[0],
+                       t * a[0] * a[2] - s * a[1], t * a[1] * a[2] + s * a[0], c + t * a[2] * a[2]};
+  double anchor[3], rj[3];
+  mulmv(R0, m.jpos[i], anchor);
+  anchor[0] += o[0]; anchor[1] += o[1]; anchor[2] += o[2];
+  mulmm(R0, Q, R);
+  mulmv(R, m.jpos[i], rj);
+  p[0] = anchor[0] - rj[0]; p[1] = anchor[1] - rj[1]; p[2] = anchor[2] - rj[2];
+}
+
 // ---- staging area for what must survive from the forward to the backward sweep (per-link spatial
 // inertia, bias wrench, gravity-compensation moment) plus the mass matrix, which two factorisations
 // consume.  On the GPU it is one column of an LDS array laid out [slot][lane] (STRIDE = 64: a wave's
@@ -130,7 +160,8 @@ struct Stage {
   static constexpr int C0 = V0 + T::NL;       // ctrl
   static constexpr int L0 = C0 + T::NU;       // limit rows: D, aref, sign per joint
   static constexpr int K0 = L0 + 3 * T::NL;   // frame of the site link at the last position stage: R(9) p(3)
-  static constexpr int X0 = K0 + 12;          // caller's slots (sim_kernels.h parks rarely-touched state here)
+  static constexpr int P0 = K0 + 12;          // qpos before the last integration (what the last mj_step1 saw)
+  static constexpr int X0 = P0 + T::NL;       // caller's slots (sim_kernels.h parks rarely-touched state here)
   static constexpr int NX = 6 + 2 * T::NARM;
   static constexpr int COUNT = X0 + NX;
   double* base;
@@ -139,6 +170,7 @@ struct Stage {
   RCSH_HD double& c(int i) const { return base[(C0 + i) * STRIDE]; }
   RCSH_HD double& lim(int i, int k) const { return base[(L0 + 3 * i + k) * STRIDE]; }
   RCSH_HD double& link(int k) const { return base[(K0 + k) * STRIDE]; }
+  RCSH_HD double& qpre(int i) const { return base[(P0 + i) * STRIDE]; }
   RCSH_HD double& S(int i, int k) const { return base[(S0 + 6 * i + k) * STRIDE]; }
   RCSH_HD double& X(int k) const { return base[(X0 + k) * STRIDE]; }
   RCSH_HD double& I(int i, int k) const { return base[(I0 + 10 * i + k) * STRIDE]; }
@@ -458,7 +490,7 @@ RCSH_HD void substep(const DevModel& m, const Stage<T, STRIDE>& st) {
   {
     double q[NL], qd[NL];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) { q[i] = st.q(i); qd[i] = st.v(i); }
+    for (int i = 0; i < NL; ++i) { q[i] = st.q(i); qd[i] = st.v(i); st.qpre(i) = q[i]; }
     Smooth<T> sm;
     smooth_dynamics<T, STRIDE>(m, q, qd, st, sm);
 #pragma unroll

@@ -149,6 +149,12 @@ void HostModel::copy_from(const rcsh_model_desc& d) {
   cpi(actuator_ctrllimited, d.actuator_ctrllimited, nu); cpd(actuator_ctrlrange, d.actuator_ctrlrange, 2 * nu);
   cpi(actuator_forcelimited, d.actuator_forcelimited, nu); cpd(actuator_forcerange, d.actuator_forcerange, 2 * nu);
   cpi(site_bodyid, d.site_bodyid, nsite); cpd(site_pos, d.site_pos, 3 * nsite); cpd(site_quat, d.site_quat, 4 * nsite);
+  ngeom = d.ngeom; nmeshvert = d.nmeshvert;
+  cpi(geom_type, d.geom_type, ngeom); cpi(geom_bodyid, d.geom_bodyid, ngeom);
+  cpi(geom_contype, d.geom_contype, ngeom); cpi(geom_conaffinity, d.geom_conaffinity, ngeom);
+  cpd(geom_pos, d.geom_pos, 3 * ngeom); cpd(geom_quat, d.geom_quat, 4 * ngeom); cpd(geom_size, d.geom_size, 3 * ngeom);
+  cpi(geom_vertadr, d.geom_vertadr, ngeom); cpi(geom_vertnum, d.geom_vertnum, ngeom);
+  cpd(mesh_vert, d.mesh_vert, 3 * (size_t)nmeshvert);
 }
 
 // Transform of every body frame relative to the link (moving ancestor-or-self) that owns it, or
@@ -339,6 +345,90 @@ std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& ac
     compute_invweight0<T>(m);
   });
   if (!ok) return "arm length / gripper combination is not instantiated";
+  return "";
+}
+
+// Plane contacts only: the first static plane geom against every collision geom on a moving body that passes
+// MuJoCo's pair filters (contype / conaffinity masks; bodies welded together never collide -- both are trivially
+// satisfied or excluded here because the plane is on the world body).
+std::string build_collision_points(const HostModel& h, CollisionPoints& out) {
+  std::vector<int> owner;
+  std::vector<Xf> rel;
+  body_owner_frames(h, owner, rel);
+  out = CollisionPoints();
+  const int nl = h.njnt;
+  for (int g = 0; g < h.ngeom; ++g) {
+    if (h.geom_type[g] != 0 || owner[h.geom_bodyid[g]] >= 0) continue;
+    if (h.geom_contype[g] == 0 && h.geom_conaffinity[g] == 0) continue;
+    const Xf t = xf_mul(rel[h.geom_bodyid[g]], xf_from(&h.geom_pos[3 * g], &h.geom_quat[4 * g]));
+    out.has_plane = true;
+    out.plane_geom = g;
+    for (int k = 0; k < 3; ++k) out.plane_n[k] = t.R[3 * k + 2];
+    out.plane_d = dot3(out.plane_n, t.p);
+    break;
+  }
+  std::vector<std::vector<double>> pts(nl);
+  std::vector<std::vector<int32_t>> ids(nl);
+  if (out.has_plane) {
+    const int pg = out.plane_geom;
+    for (int g = 0; g < h.ngeom; ++g) {
+      const int link = owner[h.geom_bodyid[g]];
+      if (link < 0) continue;
+      const bool mask_ok = (h.geom_contype[g] & h.geom_conaffinity[pg]) || (h.geom_contype[pg] & h.geom_conaffinity[g]);
+      if (!mask_ok) continue;
+      const Xf t = xf_mul(rel[h.geom_bodyid[g]], xf_from(&h.geom_pos[3 * g], &h.geom_quat[4 * g]));
+      auto add = [&](const double* local, double r) {
+        double w[3];
+        mulmv(t.R, local, w);
+        for (int k = 0; k < 3; ++k) pts[link].push_back(w[k] + t.p[k]);
+        pts[link].push_back(r);
+        ids[link].push_back(g);
+      };
+      const double* sz = &h.geom_size[3 * g];
+      switch (h.geom_type[g]) {
+        case 7:  // mesh: hull vertices
+          for (int v = 0; v < h.geom_vertnum[g]; ++v) add(&h.mesh_vert[3 * (size_t)(h.geom_vertadr[g] + v)], 0.0);
+          break;
+        case 6:  // box: corners
+          for (int c = 0; c < 8; ++c) {
+            const double p[3] = {(c & 1 ? sz[0] : -sz[0]), (c & 2 ? sz[1] : -sz[1]), (c & 4 ? sz[2] : -sz[2])};
+            add(p, 0.0);
+          }
+          break;
+        case 3: {  // capsule: segment end points, radius
+          const double a[3] = {0, 0, sz[1]}, b[3] = {0, 0, -sz[1]};
+          add(a, sz[0]); add(b, sz[0]);
+          break;
+        }
+        case 2: {  // sphere
+          const double c[3] = {0, 0, 0};
+          add(c, sz[0]);
+          break;
+        }
+        default:
+          break;  // other primitives: not in the RCS scenes
+      }
+    }
+  }
+  out.link_adr.assign(nl + 1, 0);
+  out.link_sphere.assign(4 * (size_t)nl, 0.0);
+  for (int i = 0; i < nl; ++i) {
+    // broad phase: sphere around the centroid of the link's sample points
+    const size_t np = ids[i].size();
+    if (np) {
+      double c[3] = {0, 0, 0}, rad = 0;
+      for (size_t k = 0; k < np; ++k) for (int a = 0; a < 3; ++a) c[a] += pts[i][4 * k + a] / (double)np;
+      for (size_t k = 0; k < np; ++k) {
+        const double dx = pts[i][4 * k] - c[0], dy = pts[i][4 * k + 1] - c[1], dz = pts[i][4 * k + 2] - c[2];
+        rad = std::fmax(rad, std::sqrt(dx * dx + dy * dy + dz * dz) + pts[i][4 * k + 3]);
+      }
+      for (int a = 0; a < 3; ++a) out.link_sphere[4 * i + a] = c[a];
+      out.link_sphere[4 * i + 3] = rad;
+    }
+    out.link_adr[i + 1] = out.link_adr[i] + (int)ids[i].size();
+    out.xyzr.insert(out.xyzr.end(), pts[i].begin(), pts[i].end());
+    out.geom.insert(out.geom.end(), ids[i].begin(), ids[i].end());
+  }
   return "";
 }
 

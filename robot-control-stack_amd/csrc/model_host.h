@@ -27,8 +27,25 @@ struct HostModel {
   std::vector<double> actuator_gear, actuator_gainprm, actuator_biasprm, actuator_ctrlrange, actuator_forcerange;
   std::vector<int32_t> site_bodyid;
   std::vector<double> site_pos, site_quat;
+  int ngeom = 0, nmeshvert = 0;
+  std::vector<int32_t> geom_type, geom_bodyid, geom_contype, geom_conaffinity, geom_vertadr, geom_vertnum;
+  std::vector<double> geom_pos, geom_quat, geom_size, mesh_vert;
   void copy_from(const rcsh_model_desc& d);
 };
+
+// Contact detection tables: sample points (hull vertices, box corners, capsule / sphere centres with a radius) of
+// every collision geom riding on a moving link, in link coordinates, tested against the scene's static plane.
+struct CollisionPoints {
+  std::vector<double> xyzr;       // [npts][4]
+  std::vector<int32_t> geom;      // [npts] geom id the point belongs to
+  std::vector<int32_t> link_adr;  // [nl + 1] points of link i are [link_adr[i], link_adr[i+1])
+  std::vector<double> link_sphere;  // [nl][4] bounding sphere (centre, radius) of link i's points, link frame
+  bool has_plane = false;
+  int plane_geom = -1;
+  double plane_n[3] = {0, 0, 1};
+  double plane_d = 0;             // plane: n . x = d
+};
+std::string build_collision_points(const HostModel& h, CollisionPoints& out);
 
 // Calls fn(Topo<NARM, GRIP>{}) for the compiled archetype matching (narm, grip); false if none does.
 template <class F>

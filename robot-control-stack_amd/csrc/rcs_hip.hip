@@ -43,6 +43,10 @@ struct rcsh_sim {
   HostModel hm;
   DevModel dm;
   DevModel* d_model = nullptr;
+  CollisionPoints cp;
+  std::vector<uint8_t> cp_class;
+  double* d_coll_xyzr = nullptr;
+  uint8_t* d_coll_cls = nullptr;
   std::vector<int> act_slot;
   int narm = 0, nl = 0, nu = 0;
   bool grip = false;
@@ -77,6 +81,14 @@ int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
 Params make_params(rcsh_sim* s) {
   Params P;
   P.model = s->d_model;
+  P.coll.xyzr = s->d_coll_xyzr;
+  P.coll.cls = s->d_coll_cls;
+  for (int i = 0; i <= kMaxLinks; ++i) P.coll.link_adr[i] = i < (int)s->cp.link_adr.size() ? s->cp.link_adr[i] : (s->cp.link_adr.empty() ? 0 : s->cp.link_adr.back());
+  for (int i = 0; i < kMaxLinks; ++i)
+    for (int a = 0; a < 4; ++a) P.coll.link_sphere[i][a] = (size_t)(4 * i + a) < s->cp.link_sphere.size() ? s->cp.link_sphere[4 * i + a] : 0.0;
+  P.coll.has_plane = s->cp.has_plane && !s->cp.geom.empty();
+  for (int k = 0; k < 3; ++k) P.coll.plane_n[k] = s->cp.plane_n[k];
+  P.coll.plane_d = s->cp.plane_d;
   P.S = s->S;
   P.flags = s->flags;
   P.conv_steps = s->conv;
@@ -90,6 +102,14 @@ Params make_params(rcsh_sim* s) {
 
 int upload_model(rcsh_sim* s) {
   HIP_TRY(hipMemcpyAsync(s->d_model, &s->dm, sizeof(DevModel), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+// class bits of the contact sample points: bit 0 arm collision geoms, bit 1 gripper collision geoms
+int upload_coll_classes(rcsh_sim* s) {
+  if (s->cp.geom.empty()) return RCSH_OK;
+  HIP_TRY(hipMemcpyAsync(s->d_coll_cls, s->cp_class.data(), s->cp_class.size(), hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
 }
@@ -265,6 +285,17 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   s->stream = s->own_stream;
   const size_t n = (size_t)n_envs;
   HIP_NEW(hipMalloc(&s->d_model, sizeof(DevModel)));
+  {
+    std::string cwhy = build_collision_points(s->hm, s->cp);
+    if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);
+    s->cp_class.assign(s->cp.geom.size(), 0);
+    if (!s->cp.geom.empty()) {
+      HIP_NEW(hipMalloc(&s->d_coll_xyzr, sizeof(double) * s->cp.xyzr.size()));
+      HIP_NEW(hipMalloc(&s->d_coll_cls, s->cp_class.size()));
+      HIP_NEW(hipMemcpy(s->d_coll_xyzr, s->cp.xyzr.data(), sizeof(double) * s->cp.xyzr.size(), hipMemcpyHostToDevice));
+      HIP_NEW(hipMemcpy(s->d_coll_cls, s->cp_class.data(), s->cp_class.size(), hipMemcpyHostToDevice));
+    }
+  }
   HIP_NEW(hipMalloc(&s->S, sizeof(double) * n * s->nfields));
   HIP_NEW(hipMalloc(&s->flags, sizeof(uint32_t) * n));
   HIP_NEW(hipMalloc(&s->conv, sizeof(int32_t) * n));
@@ -300,7 +331,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
-  hipFree(s->d_model); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
+  hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
@@ -403,6 +434,14 @@ int rcsh_sim_add_robot(rcsh_sim* s, const rcsh_robot_desc* r) {
   s->robot.period = r->seconds_between_callbacks;
   std::memcpy(s->robot.tcp, r->tcp_offset, sizeof(s->robot.tcp));
   for (int i = 0; i < r->dof; ++i) s->robot.q_home[i] = r->q_home[i];
+  for (int c = 0; c < r->n_collision_geoms; ++c) {
+    const int g = r->collision_geom_ids[c];
+    if (g < 0 || g >= s->hm.ngeom) return fail(RCSH_ERR_NAME, "arm collision geom id out of range");
+    for (size_t k = 0; k < s->cp.geom.size(); ++k)
+      if (s->cp.geom[k] == g) s->cp_class[k] |= 1u;
+  }
+  rc = upload_coll_classes(s);
+  if (rc) return rc;
   return rcsh_robot_reset(s, nullptr);  // SimRobot ctor ends with m_reset()
 }
 
@@ -569,6 +608,22 @@ int rcsh_sim_add_gripper(rcsh_sim* s, const rcsh_gripper_desc* g) {
   s->gripcfg.period = g->seconds_between_callbacks;
   s->gripcfg.max_act = g->max_actuator_width; s->gripcfg.min_act = g->min_actuator_width;
   s->gripcfg.max_joint = g->max_joint_width; s->gripcfg.min_joint = g->min_joint_width;
+  // SimGripper::collision_callback (SimGripper.cpp:108-130) on plane contacts {geom[0] = plane, geom[1] = robot geom}:
+  // counted when geom[1] is a gripper collision geom and not in the ignore list (the finger-finger skip cannot
+  // apply: the plane is no finger geom; the ignore test reads geom[1] twice, reference quirk Q6 -- same set here)
+  for (int c = 0; c < g->n_collision_geoms; ++c) {
+    const int gid = g->collision_geom_ids[c];
+    if (gid < 0 || gid >= s->hm.ngeom) return fail(RCSH_ERR_NAME, "gripper collision geom id out of range");
+    bool ignored = false;
+    for (int q = 0; q < g->n_ignored_geoms; ++q) ignored = ignored || g->ignored_geom_ids[q] == gid;
+    if (ignored) continue;
+    for (size_t k = 0; k < s->cp.geom.size(); ++k)
+      if (s->cp.geom[k] == gid) s->cp_class[k] |= 2u;
+  }
+  {
+    int rc = upload_coll_classes(s);
+    if (rc) return rc;
+  }
   return rcsh_gripper_reset(s, nullptr);  // SimGripper ctor ends with m_reset()
 }
 

@@ -88,8 +88,19 @@ struct RunOp {
   int32_t* substeps;      // [n]
 };
 
+// Contact detection against the scene's static plane (flags only): sample points of the collision geoms, link frame
+struct CollTable {
+  const double* xyzr;      // [npts][4]
+  const uint8_t* cls;      // [npts] bit 0: geom is one of SimRobot's arm collision geoms; bit 1: SimGripper's
+  int32_t link_adr[kMaxLinks + 1];
+  double link_sphere[kMaxLinks][4];  // broad phase: bounding sphere of the link's points (link frame)
+  int32_t has_plane;
+  double plane_n[3], plane_d;
+};
+
 struct Params {
   const DevModel* model;  // HBM copy; each workgroup stages it into LDS once per launch
+  CollTable coll;
   double* S;
   uint32_t* flags;
   int32_t* conv_steps;
@@ -186,22 +197,66 @@ __device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T, kLan
   }
 }
 
+// d->contact of the last mj_step1, reduced to what the two collision callbacks ask of it: which geom classes touch
+// the plane.  MuJoCo reports a plane-convex contact when the deepest hull point is below the plane (margin 0).
+// Frames are those of the qpos the last mj_step1 saw (Stage::qpre).
+template <class T, int kLanes>
+__device__ __noinline__ uint32_t plane_contacts(const DevModel& m, const Params& P, const Stage<T, kLanes>& st) {
+  uint32_t hit = 0;
+  if (!P.coll.has_plane) return hit;
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+  double Rt[9], pt[3];
+  const double* n = P.coll.plane_n;
+  for (int i = 0; i < T::NL; ++i) {
+    if (T::GRIP && i == T::NARM) {
+      for (int k = 0; k < 9; ++k) Rt[k] = R[k];
+      for (int k = 0; k < 3; ++k) pt[k] = p[k];
+    }
+    if (T::GRIP && i > T::NARM) {
+      for (int k = 0; k < 9; ++k) R[k] = Rt[k];
+      for (int k = 0; k < 3; ++k) p[k] = pt[k];
+    }
+    advance_link_frame(m, i, st.qpre(i), R, p);
+    // signed distance of a link-frame point v with radius r: n.(p + R v) - d - r = b + a.v - r
+    const double a[3] = {R[0] * n[0] + R[3] * n[1] + R[6] * n[2], R[1] * n[0] + R[4] * n[1] + R[7] * n[2],
+                         R[2] * n[0] + R[5] * n[1] + R[8] * n[2]};
+    const double b = dot3(n, p) - P.coll.plane_d;
+    // broad phase (per lane): the link's bounding sphere clears the plane -> none of its points can touch it
+    const double* sph = P.coll.link_sphere[i];
+    const bool near = b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < 0;
+    if (!__any(near)) continue;
+    // narrow phase: the table is read through the constant address space (wave-uniform index -> scalar loads)
+    typedef const __attribute__((address_space(4))) double* cptr;
+    const cptr tab = (cptr)(uintptr_t)P.coll.xyzr;
+    for (int k = P.coll.link_adr[i]; k < P.coll.link_adr[i + 1]; ++k) {
+      const double vx = tab[4 * (size_t)k], vy = tab[4 * (size_t)k + 1], vz = tab[4 * (size_t)k + 2], vr = tab[4 * (size_t)k + 3];
+      if (near && b + a[0] * vx + a[1] * vy + a[2] * vz - vr < 0) hit |= P.coll.cls[k];
+    }
+  }
+  return hit;
+}
+
 // Sim::invoke_condition_callbacks, reference src/sim/sim.cpp:14-23,49-61.  Callback bodies:
 // SimRobot::collision_callback / convergence_callback (SimRobot.cpp:172-191),
 // SimGripper::collision_callback / convergence_callback (SimGripper.cpp:108-130,143-151).
-// No contact-capable pair exists in this revision, so ncon == 0 and both collision scans return false.
+// Contacts: plane (floor) against the collision geoms only; geom-geom pairs are not detected in this revision.
 template <class T, int kLanes>
-__device__ __forceinline__ bool condition_callbacks(const Params& P, EnvRegs<T, kLanes>& r) {
+__device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Params& P, EnvRegs<T, kLanes>& r) {
   const bool has_g = T::GRIP && P.grip.present;
-  if (P.robot.present && r.time - r.cb(2) > P.robot.period) {
-    set_flag(r.flags, kRobotCollision, false);
-    set_flag(r.flags, kAnyRet0, false);
-    r.cb(2) = r.time;
-  }
-  if (has_g && r.time - r.cb(3) > P.grip.period) {
-    set_flag(r.flags, kGripCollision, false);
-    set_flag(r.flags, kAnyRet1, false);
-    r.cb(3) = r.time;
+  const bool fire_r = P.robot.present && r.time - r.cb(2) > P.robot.period;
+  const bool fire_g = has_g && r.time - r.cb(3) > P.grip.period;
+  if (fire_r || fire_g) {
+    const uint32_t hit = plane_contacts<T, kLanes>(m, P, r.st);
+    if (fire_r) {
+      set_flag(r.flags, kRobotCollision, hit & 1u);
+      set_flag(r.flags, kAnyRet0, hit & 1u);
+      r.cb(2) = r.time;
+    }
+    if (fire_g) {
+      set_flag(r.flags, kGripCollision, hit & 2u);
+      set_flag(r.flags, kAnyRet1, hit & 2u);
+      r.cb(3) = r.time;
+    }
   }
   if (P.robot.present && P.robot.conv_registered && r.time - r.cb(4) > P.robot.period) {
     const bool conv = !(r.flags & kIkSuccess) || ((r.flags & kIsArrived) && !(r.flags & kIsMoving));
@@ -384,7 +439,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
     --budget;
     if (until_conv) {
       r.conv_steps++;
-      converged = condition_callbacks<T, kLanes>(P, r);
+      converged = condition_callbacks<T, kLanes>(m, P, r);
     }
   }
   if (until_conv) set_flag(r.flags, kConverged, converged);

@@ -49,6 +49,10 @@ class ModelDesc(C.Structure):
         ("actuator_ctrllimited", _I32P), ("actuator_ctrlrange", _F64P),
         ("actuator_forcelimited", _I32P), ("actuator_forcerange", _F64P),
         ("site_bodyid", _I32P), ("site_pos", _F64P), ("site_quat", _F64P),
+        ("ngeom", C.c_int32), ("nmeshvert", C.c_int32),
+        ("geom_type", _I32P), ("geom_bodyid", _I32P), ("geom_contype", _I32P), ("geom_conaffinity", _I32P),
+        ("geom_pos", _F64P), ("geom_quat", _F64P), ("geom_size", _F64P),
+        ("geom_vertadr", _I32P), ("geom_vertnum", _I32P), ("mesh_vert", _F64P),
     ]
 
 
@@ -58,6 +62,7 @@ class RobotDesc(C.Structure):
         ("attachment_site", C.c_int32), ("base_body", C.c_int32), ("q_home", _F64P),
         ("tcp_offset", C.c_double * 7), ("joint_rotational_tolerance", C.c_double),
         ("seconds_between_callbacks", C.c_double), ("register_convergence_callback", C.c_int32),
+        ("n_collision_geoms", C.c_int32), ("collision_geom_ids", _I32P),
     ]
 
 
@@ -67,6 +72,8 @@ class GripperDesc(C.Structure):
         ("epsilon_inner", C.c_double), ("epsilon_outer", C.c_double), ("seconds_between_callbacks", C.c_double),
         ("max_actuator_width", C.c_double), ("min_actuator_width", C.c_double),
         ("max_joint_width", C.c_double), ("min_joint_width", C.c_double),
+        ("n_collision_geoms", C.c_int32), ("n_finger_geoms", C.c_int32), ("n_ignored_geoms", C.c_int32),
+        ("collision_geom_ids", _I32P), ("finger_geom_ids", _I32P), ("ignored_geom_ids", _I32P),
     ]
 
 
@@ -156,6 +163,7 @@ def make_model_desc(cm) -> tuple[ModelDesc, list[np.ndarray]]:
     d = ModelDesc()
     d.nbody, d.njnt, d.nu = cm.nbody, cm.njnt, cm.nu
     d.ntendon, d.nwrap, d.neq, d.nsite = cm.ntendon, cm.nwrap, cm.neq, cm.nsite
+    d.ngeom, d.nmeshvert = cm.ngeom, int(cm.arrays["mesh_vert"].shape[0])
     d.timestep = cm.timestep
     d.gravity[:] = [float(x) for x in cm.gravity]
     keep: list[np.ndarray] = []

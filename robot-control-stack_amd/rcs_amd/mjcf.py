@@ -782,6 +782,19 @@ class _Compiler:
         A["geom_gap"] = np.array([g["gap"] for g in self.geoms], dtype=np.float64)
         m.arrays = A
         m.geom_mesh = [g["mesh"] for g in self.geoms]  # type: ignore[attr-defined]
+        # collision vertex sets of mesh geoms (hull vertices, numbers only; tools/make_collision_vertices.py)
+        vadr, vnum, verts = [], [], []
+        vfile = os.path.join(os.path.dirname(self.path), "collision_vertices.npz")
+        table = dict(np.load(vfile)) if os.path.exists(vfile) else {}
+        for g in self.geoms:
+            v = table.get(g["mesh"]) if g["type"] == GEOM_MESH else None
+            vadr.append(sum(len(x) for x in verts))
+            vnum.append(0 if v is None else len(v))
+            if v is not None:
+                verts.append(np.asarray(v, dtype=np.float64))
+        A["geom_vertadr"] = np.array(vadr, dtype=np.int32)
+        A["geom_vertnum"] = np.array(vnum, dtype=np.int32)
+        A["mesh_vert"] = np.concatenate(verts).reshape(-1, 3) if verts else np.zeros((0, 3))
 
         ns = len(self.sites)
         A["site_bodyid"] = np.array([s["body"] for s in self.sites], dtype=np.int32)

@@ -220,8 +220,7 @@ class SimRobot:
         self._cfg = cfg
         self._L = sim._L
         m = sim.model
-        for g in cfg.arm_collision_geoms:
-            _lookup(m, "geom", g, "geom")
+        cgeoms = np.array([_lookup(m, "geom", g, "geom") for g in cfg.arm_collision_geoms], dtype=np.int32)
         site = _lookup(m, "site", cfg.attachment_site, "site")
         base = _lookup(m, "body", cfg.base, "body")
         joints = np.array([_lookup(m, "jnt", j, "joint") for j in cfg.joints], dtype=np.int32)
@@ -239,6 +238,8 @@ class SimRobot:
         d.joint_rotational_tolerance = cfg.joint_rotational_tolerance
         d.seconds_between_callbacks = cfg.seconds_between_callbacks
         d.register_convergence_callback = int(register_convergence_callback)
+        d.n_collision_geoms = len(cgeoms)
+        d.collision_geom_ids = cgeoms.ctypes.data_as(C.POINTER(C.c_int32))
         _lib.check(self._L.rcsh_sim_add_robot(sim._h, C.byref(d)))
         if self._ik is None:
             self._ik = DeviceKinematics(sim, self.dof)
@@ -354,10 +355,13 @@ class SimGripper:
         m = sim.model
         act = _lookup(m, "actuator", cfg.actuator, "actuator")
         jnt = _lookup(m, "jnt", cfg.joint, "joint")
-        for g in list(cfg.collision_geoms) + list(cfg.collision_geoms_fingers):
-            _lookup(m, "geom", g, "geom")
+        ids = lambda names: np.array([_lookup(m, "geom", g, "geom") for g in names] or [0], dtype=np.int32)  # noqa: E731
+        cg, cf, ig = ids(cfg.collision_geoms), ids(cfg.collision_geoms_fingers), ids(cfg.ignored_collision_geoms)
+        i32p = C.POINTER(C.c_int32)
         d = _lib.GripperDesc(jnt, act, cfg.epsilon_inner, cfg.epsilon_outer, cfg.seconds_between_callbacks,
-                             cfg.max_actuator_width, cfg.min_actuator_width, cfg.max_joint_width, cfg.min_joint_width)
+                             cfg.max_actuator_width, cfg.min_actuator_width, cfg.max_joint_width, cfg.min_joint_width,
+                             len(cfg.collision_geoms), len(cfg.collision_geoms_fingers), len(cfg.ignored_collision_geoms),
+                             cg.ctypes.data_as(i32p), cf.ctypes.data_as(i32p), ig.ctypes.data_as(i32p))
         _lib.check(self._L.rcsh_sim_add_gripper(sim._h, C.byref(d)))
 
     @property

@@ -89,3 +89,43 @@ def test_ik_kernels_match_oracle_and_round_trip():
     assert np.abs(back[:, :3] - pose[:, :3]).max() < 2e-4
     assert np.abs(q[:, 7:]).max() == 0.0
     venv.close()
+
+
+def test_collision_flags_match_oracle():
+    """Reference collision pins (test_sim_envs.py:136-151,347-360) through the HIP path: folded arm in JOINTS mode,
+    TCP target below the ground in Cartesian mode; every flag and substep count equals the oracle's."""
+    from parity_util import make_oracle_envs, make_vec_env
+    from rcs_amd.envs import ControlMode
+
+    n = 8
+    venv = make_vec_env(n, False, gripper=True, relative=False)
+    oenvs = make_oracle_envs(n, False, gripper=True, relative=False)
+    venv.reset()
+    [o.reset() for o in oenvs]
+    rng = np.random.default_rng(0)
+    for step in range(3):
+        a = np.tile(np.array([0, 1.78, 0, -1.45, 0, 0, 0.0]), (n, 1)) + rng.uniform(-0.02, 0.02, size=(n, 7)) * (np.arange(n)[:, None] > 0)
+        g = np.ones(n, dtype=np.float32)
+        _, _, _, trunc, info = venv.step({"joints": a, "gripper": g})
+        for e, o in enumerate(oenvs):
+            _, _, _, otr, oi = o.step({"joints": a[e], "gripper": g[e]})
+            assert bool(trunc[e]) == bool(otr) and bool(info["collision"][e]) == bool(oi["collision"])
+            assert int(info["substeps"][e]) == int(o.sim.s.convergence_steps)
+        if step == 0:
+            assert info["collision"].all() and info["ik_success"].all()
+    assert trunc.all()
+    venv.close()
+
+    venv = make_vec_env(n, False, gripper=True, relative=False, control_mode=ControlMode.CARTESIAN_TRPY)
+    oenvs = make_oracle_envs(n, False, gripper=True, relative=False, mode="xyzrpy")
+    obs, _ = venv.reset()
+    [o.reset() for o in oenvs]
+    a = obs["xyzrpy"].copy()
+    a[:, 0], a[:, 2] = 0.4, -0.05
+    _, _, _, trunc, info = venv.step({"xyzrpy": a, "gripper": np.zeros(n, dtype=np.float32)})
+    assert info["collision"].all() and info["ik_success"].all()
+    for e, o in enumerate(oenvs):
+        _, _, _, otr, oi = o.step({"xyzrpy": a[e], "gripper": 0})
+        assert bool(trunc[e]) == bool(otr) and bool(info["collision"][e]) == bool(oi["collision"])
+        assert int(info["substeps"][e]) == int(o.sim.s.convergence_steps)
+    venv.close()

@@ -171,3 +171,46 @@ def test_callback_cadence_follows_accumulated_time(cm):
     env.step({"joints": obs0["joints"] + 0.05})
     n = env.sim.s.convergence_steps
     assert n % 50 in (0, 1) and n >= 100
+
+
+# ---- (iii) collision flag pins, test_sim_envs.py:136-151,252-271,347-360 (contact DETECTION against the floor plane)
+def _assert_collision(info):
+    assert info["ik_success"] and info["collision"]
+
+
+def test_collision_trpy_below_ground(cm):
+    env = OracleEnv(cm, control_mode=CARTESIAN_TRPY, gripper=True)
+    obs, _ = env.reset()
+    a = obs["xyzrpy"].copy()
+    a[0], a[2] = 0.4, -0.05
+    _, _, _, truncated, info = env.step({"xyzrpy": a, "gripper": 0})
+    _assert_collision(info)
+
+
+def test_collision_tquat_below_ground(cm):
+    env = OracleEnv(cm, control_mode=CARTESIAN_TQUAT, gripper=True)
+    obs, _ = env.reset()
+    a = obs["tquat"].copy()
+    a[0], a[2] = 0.4, -0.05
+    _, _, _, _, info = env.step({"tquat": a, "gripper": 0})
+    _assert_collision(info)
+
+
+def test_collision_joints_folded_arm(cm):
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=True)
+    env.reset()
+    _, _, _, truncated, info = env.step({"joints": np.array([0, 1.78, 0, -1.45, 0, 0, 0], dtype=np.float32), "gripper": 1})
+    _assert_collision(info)
+    # the env-step ends at the gripper's 20 Hz collision sample (hand / camera geoms on the floor); the arm's own
+    # 10 Hz sample, which drives `truncated`, sees links 6-7 on the floor one env-step later
+    _, _, _, truncated, info = env.step({"joints": np.array([0, 1.78, 0, -1.45, 0, 0, 0], dtype=np.float32), "gripper": 1})
+    assert truncated and info["collision"]
+
+
+def test_no_collision_at_home_and_small_moves(cm):
+    env = OracleEnv(cm, control_mode=JOINTS, gripper=True, max_relative_movement=float(np.deg2rad(5)))
+    env.reset()
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        _, _, _, truncated, info = env.step({"joints": rng.uniform(-0.08, 0.08, 7), "gripper": 1})
+        assert not info["collision"] and not truncated
