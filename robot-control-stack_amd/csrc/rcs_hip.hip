@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -140,9 +141,13 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   // what counts is how many waves are in flight: 4096 environments are 256 workgroups = one per CU, and for
   // larger batches the 52 KB of LDS per workgroup (staging columns + model tables) lets three share a CU
   // (measured at 32768 environments: 26.2 M env-steps/s with 16 lanes, 18.4 M with 32).
+  static const bool four_wave = [] { const char* v = getenv("RCSH_FOUR_WAVE"); return v && v[0] == '1'; }();
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);
+    if (four_wave)
+      hipLaunchKernelGGL((k_run4<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(256), 0, s->stream, P, op);
+    else
+      hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);
     err = hipGetLastError();
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
@@ -827,6 +832,13 @@ int rcsh_dev_download(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
 }
+
+#ifdef RCSH_PHASE_TIMING
+extern "C" int rcsh_debug_phase_cycles(unsigned long long* out32) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int rcsh_debug_dump_model(rcsh_sim* s, void* buf, size_t cap, size_t* size) {
   REQUIRE_SIM(s);

@@ -13,6 +13,7 @@
 #include <cstdint>
 
 #include "dyn.h"
+#include "dyn4.h"
 #include "pose.h"
 
 namespace rcsh {
@@ -112,13 +113,13 @@ struct Params {
 };
 
 // ---- everything one environment keeps in registers during a launch
-template <class T, int kLanes>
+template <class T, class ST>
 struct EnvRegs {
   double time;
   double last_cmd_width, last_width;
   // callback timestamps, previous_angles and target_angles are touched once per 25-50 substeps:
   // they live in the lane's LDS column (Stage::X), not in registers
-  Stage<T, kLanes> st;
+  ST st;
   __device__ __forceinline__ double& cb(int i) const { return st.X(i); }
   __device__ __forceinline__ double& prevq(int i) const { return st.X(6 + i); }
   __device__ __forceinline__ double& target(int i) const { return st.X(6 + T::NARM + i); }
@@ -126,8 +127,8 @@ struct EnvRegs {
   int32_t conv_steps;
 };
 
-template <class T, int kLanes>
-__device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T, kLanes>& r) {
+template <class T, class ST>
+__device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T, ST>& r) {
   using L = Lay<T>;
   const int n = P.n;
   const double* S = P.S;
@@ -146,8 +147,8 @@ __device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T, kLan
   r.conv_steps = P.conv_steps[e];
 }
 
-template <class T, int kLanes>
-__device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<T, kLanes>& r) {
+template <class T, class ST>
+__device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<T, ST>& r) {
   using L = Lay<T>;
   const int n = P.n;
   double* S = P.S;
@@ -169,8 +170,8 @@ __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<
 __device__ __forceinline__ void set_flag(uint32_t& f, uint32_t bit, bool v) { f = v ? (f | bit) : (f & ~bit); }
 
 // SimGripper::get_normalized_width, reference src/sim/SimGripper.cpp:93-106
-template <class T, int kLanes>
-__device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T, kLanes>& r) {
+template <class T, class ST>
+__device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T, ST>& r) {
   const double qf = P.grip.finger ? r.st.q(T::NL - 1) : r.st.q(T::NL - 2);
   double w = (qf - P.grip.min_joint) / (P.grip.max_joint - P.grip.min_joint);
   return w < 0 ? 0 : (w > 1 ? 1 : w);
@@ -178,8 +179,8 @@ __device__ __forceinline__ double gripper_width(const Params& P, const EnvRegs<T
 
 // Sim::invoke_callbacks, reference src/sim/sim.cpp:38-47, with SimRobot::is_arrived_callback /
 // is_moving_callback (src/sim/SimRobot.cpp:156-170) as the two registered callbacks
-template <class T, int kLanes>
-__device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T, kLanes>& r) {
+template <class T, class ST>
+__device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T, ST>& r) {
   if (!(P.robot.present && P.robot.conv_registered)) return;
   if (r.time - r.cb(0) > P.robot.period) {
     double mx = 0;
@@ -200,8 +201,8 @@ __device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T, kLan
 // d->contact of the last mj_step1, reduced to what the two collision callbacks ask of it: which geom classes touch
 // the plane.  MuJoCo reports a plane-convex contact when the deepest hull point is below the plane (margin 0).
 // Frames are those of the qpos the last mj_step1 saw (Stage::qpre).
-template <class T, int kLanes>
-__device__ __noinline__ uint32_t plane_contacts(const DevModel& m, const Params& P, const Stage<T, kLanes>& st) {
+template <class T, class ST>
+__device__ __noinline__ uint32_t plane_contacts(const DevModel& m, const Params& P, const ST& st) {
   uint32_t hit = 0;
   if (!P.coll.has_plane) return hit;
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
@@ -240,13 +241,13 @@ __device__ __noinline__ uint32_t plane_contacts(const DevModel& m, const Params&
 // SimRobot::collision_callback / convergence_callback (SimRobot.cpp:172-191),
 // SimGripper::collision_callback / convergence_callback (SimGripper.cpp:108-130,143-151).
 // Contacts: plane (floor) against the collision geoms only; geom-geom pairs are not detected in this revision.
-template <class T, int kLanes>
-__device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Params& P, EnvRegs<T, kLanes>& r) {
+template <class T, class ST>
+__device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Params& P, EnvRegs<T, ST>& r) {
   const bool has_g = T::GRIP && P.grip.present;
   const bool fire_r = P.robot.present && r.time - r.cb(2) > P.robot.period;
   const bool fire_g = has_g && r.time - r.cb(3) > P.grip.period;
   if (fire_r || fire_g) {
-    const uint32_t hit = plane_contacts<T, kLanes>(m, P, r.st);
+    const uint32_t hit = plane_contacts<T, ST>(m, P, r.st);
     if (fire_r) {
       set_flag(r.flags, kRobotCollision, hit & 1u);
       set_flag(r.flags, kAnyRet0, hit & 1u);
@@ -264,7 +265,7 @@ __device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Par
     r.cb(4) = r.time;
   }
   if (has_g && r.time - r.cb(5) > P.grip.period) {
-    const double w = gripper_width<T, kLanes>(P, r);
+    const double w = gripper_width<T, ST>(P, r);
     const bool moving = fabs(r.last_width - w) > 0.001 * (P.grip.max_act - P.grip.min_act);
     set_flag(r.flags, kGripMoving, moving);
     r.last_width = w;
@@ -280,8 +281,8 @@ __device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Par
 }
 
 // SimRobot::set_joint_position, reference src/sim/SimRobot.cpp:123-131
-template <class T, int kLanes>
-__device__ __forceinline__ void robot_set_joint_position(EnvRegs<T, kLanes>& r, const double* a) {
+template <class T, class ST>
+__device__ __forceinline__ void robot_set_joint_position(EnvRegs<T, ST>& r, const double* a) {
 #pragma unroll
   for (int i = 0; i < T::NARM; ++i) {
     r.target(i) = a[i];
@@ -292,8 +293,8 @@ __device__ __forceinline__ void robot_set_joint_position(EnvRegs<T, kLanes>& r, 
 }
 
 // SimGripper::set_normalized_width, reference src/sim/SimGripper.cpp:79-92
-template <class T, int kLanes>
-__device__ __forceinline__ void gripper_set_width(const Params& P, EnvRegs<T, kLanes>& r, double w) {
+template <class T, class ST>
+__device__ __forceinline__ void gripper_set_width(const Params& P, EnvRegs<T, ST>& r, double w) {
   r.last_cmd_width = w;
   r.st.c(T::NU - 1) = w * (P.grip.max_act - P.grip.min_act) + P.grip.min_act;
 }
@@ -316,38 +317,12 @@ __device__ __forceinline__ void cartesian_position(const DevModel& m, const Robo
   pose_mul(in_robot, tcp, out);
 }
 
-// The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step.
-template <class T, int kLanes>
-__global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
+// Wrappers' reset() / action() side effects on one environment: everything env.reset() / env.step() do before
+// the simulator is stepped (reference python/rcs/envs/base.py, envs/sim.py; see the inline citations).
+template <class T, class ST>
+__device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, const DevModel& m, int e, EnvRegs<T, ST>& r) {
   using L = Lay<T>;
-  // Model tables: staged into LDS once per launch and read back with broadcast ds_reads.  (Scalar
-  // loads from constant memory were measured 2.2x slower here: ~800 doubles of tables cannot stay in
-  // ~100 SGPRs, and SMEM returns share -- and serialise -- the LDS wait counter.)
-  __shared__ DevModel lm;
-  {
-    constexpr int kWords = sizeof(DevModel) / 8;
-    const double* src = reinterpret_cast<const double*>(P.model);
-    double* dst = reinterpret_cast<double*>(&lm);
-#pragma unroll
-    for (int it = 0; it < (kWords + kLanes - 1) / kLanes; ++it) {
-      const int k = it * kLanes + threadIdx.x;
-      if (k < kWords) dst[k] = src[k];
-    }
-    __syncthreads();
-  }
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= P.n) return;
-  if (op.mask && !op.mask[e]) return;
-  const DevModel& m = lm;
   const int n = P.n;
-  // LDS staging column of this lane (dyn.h: Stage), [slot][lane]
-  __shared__ double lds[Stage<T, kLanes>::COUNT * kLanes];
-  const Stage<T, kLanes> st{lds + threadIdx.x};
-  EnvRegs<T, kLanes> r;
-  r.st = st;
-  load_env<T, kLanes>(P, e, r);
-  bool have_frames = false;
-
   if (op.do_reset) {
     // GripperWrapper.reset -> SimGripper::m_reset (python/rcs/envs/base.py:703-708, SimGripper.cpp:158-165)
     if (T::GRIP && P.grip.present) {
@@ -398,10 +373,10 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
       if (P.env.binary_gripper) g = rintf(g);  // np.round: half to even
       g = fminf(fmaxf(g, 0.0f), 1.0f);
       if (P.env.binary_gripper) {
-        gripper_set_width<T, kLanes>(P, r, g == 0.0f ? 0.0 : 1.0);  // grasp() = shut() : open()
+        gripper_set_width<T, ST>(P, r, g == 0.0f ? 0.0 : 1.0);  // grasp() = shut() : open()
         set_flag(r.flags, kGripCmd, g != 0.0f);
       } else {
-        gripper_set_width<T, kLanes>(P, r, (double)g);
+        gripper_set_width<T, ST>(P, r, (double)g);
         set_flag(r.flags, kGripCmd, g >= 0.5f);
       }
       r.flags |= kHasGripCmd;
@@ -414,35 +389,19 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
       changed = changed || !(fabs(a[i] - pa) <= 1e-3);
       P.S[(L::PREVA + i) * n + e] = a[i];
     }
-    if (changed) robot_set_joint_position<T, kLanes>(r, a);
+    if (changed) robot_set_joint_position<T, ST>(r, a);
     r.flags |= kHasPrevAction;
   }
 
-  // ---- Sim::step(k) / Sim::step_until_convergence (src/sim/sim.cpp:84-115).  One loop serves both so the
-  // (large, fully unrolled) substep body exists once in the instruction stream.
-  int nsteps = op.nsteps;
-  if (op.do_reset) nsteps = 1;
-  const bool until_conv = nsteps < 0;
-  int budget = nsteps;
-  if (until_conv) {
-    r.conv_steps = 0;
-    r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
-    const int cap = P.sim.max_convergence_steps;
-    budget = cap == -1 ? 0x7fffffff : cap;
-  }
-  bool converged = false;
-  while (budget > 0 && !converged) {
-    plain_callbacks<T, kLanes>(P, r);
-    substep<T, kLanes>(m, st);
-    r.time += m.timestep;
-    have_frames = true;
-    --budget;
-    if (until_conv) {
-      r.conv_steps++;
-      converged = condition_callbacks<T, kLanes>(m, P, r);
-    }
-  }
-  if (until_conv) set_flag(r.flags, kConverged, converged);
+}
+
+// After stepping: park the site frame, refresh the relative-action origin on reset, write the state back and
+// produce observation + info (RobotEnv.get_obs, GripperWrapper.observation, RobotSimWrapper.step, GripperWrapperSim).
+template <class T, class ST>
+__device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, const DevModel& m, int e, EnvRegs<T, ST>& r,
+                                             const ST& st, bool have_frames, int nsteps) {
+  using L = Lay<T>;
+  const int n = P.n;
   if (have_frames) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) P.S[(L::SITE + k) * n + e] = st.link(k);
@@ -470,7 +429,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
     }
     r.flags &= ~kHasLastAction;
   }
-  store_env<T, kLanes>(P, e, r);
+  store_env<T, ST>(P, e, r);
 
   if (op.write_obs) {
     // RobotEnv.get_obs (base.py:246-253) + GripperWrapper.observation (base.py:710-719) +
@@ -495,7 +454,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
     double gobs = 1.0, w = 0.0;
     const bool has_g = T::GRIP && P.grip.present;
     if (has_g) {
-      w = gripper_width<T, kLanes>(P, r);
+      w = gripper_width<T, ST>(P, r);
       if (P.env.binary_gripper) gobs = (r.flags & kHasGripCmd) ? ((r.flags & kGripCmd) ? 1.0 : 0.0) : 1.0;
       else gobs = w;
     }
@@ -513,6 +472,200 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
     }
     if (op.gripper_width) op.gripper_width[e] = w;
     if (op.substeps) op.substeps[e] = nsteps >= 0 ? nsteps : r.conv_steps;
+  }
+}
+
+// The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step.
+template <class T, int kLanes>
+__global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
+  using L = Lay<T>;
+  // Model tables: staged into LDS once per launch and read back with broadcast ds_reads.  (Scalar
+  // loads from constant memory were measured 2.2x slower here: ~800 doubles of tables cannot stay in
+  // ~100 SGPRs, and SMEM returns share -- and serialise -- the LDS wait counter.)
+  __shared__ DevModel lm;
+  {
+    constexpr int kWords = sizeof(DevModel) / 8;
+    const double* src = reinterpret_cast<const double*>(P.model);
+    double* dst = reinterpret_cast<double*>(&lm);
+#pragma unroll
+    for (int it = 0; it < (kWords + kLanes - 1) / kLanes; ++it) {
+      const int k = it * kLanes + threadIdx.x;
+      if (k < kWords) dst[k] = src[k];
+    }
+    __syncthreads();
+  }
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n) return;
+  if (op.mask && !op.mask[e]) return;
+  const DevModel& m = lm;
+  const int n = P.n;
+  // LDS staging column of this lane (dyn.h: Stage), [slot][lane]
+  __shared__ double lds[Stage<T, kLanes>::COUNT * kLanes];
+  using ST = Stage<T, kLanes>;
+  const ST st{lds + threadIdx.x};
+  EnvRegs<T, ST> r;
+  r.st = st;
+  load_env<T, ST>(P, e, r);
+  bool have_frames = false;
+
+  env_prologue<T, ST>(P, op, m, e, r);
+
+  // ---- Sim::step(k) / Sim::step_until_convergence (src/sim/sim.cpp:84-115).  One loop serves both so the
+  // (large, fully unrolled) substep body exists once in the instruction stream.
+  int nsteps = op.nsteps;
+  if (op.do_reset) nsteps = 1;
+  const bool until_conv = nsteps < 0;
+  int budget = nsteps;
+  if (until_conv) {
+    r.conv_steps = 0;
+    r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
+    const int cap = P.sim.max_convergence_steps;
+    budget = cap == -1 ? 0x7fffffff : cap;
+  }
+  bool converged = false;
+  while (budget > 0 && !converged) {
+    plain_callbacks<T, ST>(P, r);
+    substep<T, kLanes>(m, st);
+    r.time += m.timestep;
+    have_frames = true;
+    --budget;
+    if (until_conv) {
+      r.conv_steps++;
+      converged = condition_callbacks<T, ST>(m, P, r);
+    }
+  }
+  if (until_conv) set_flag(r.flags, kConverged, converged);
+  env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
+}
+
+#ifdef RCSH_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[4][8];
+#define PHASE_MARK(idx)                                                                   \
+  if (blockIdx.x == 0 && lane == 0) {                                                     \
+    const unsigned long long now_ = __builtin_readcyclecounter();                        \
+    g_phase_cycles[w][idx] += now_ - t_mark;                                              \
+    t_mark = now_;                                                                        \
+  }
+#else
+#define PHASE_MARK(idx)
+#endif
+
+// The same entry point with the substep split across the four waves of the workgroup (dyn4.h).  Wave 0 also owns
+// the RCS bookkeeping (wrappers, callback scheduler, observation); waves 1-3 only run their physics roles.
+template <class T, int kLanes>
+__global__ void __launch_bounds__(256) k_run4(Params P, RunOp op) {
+  using ST = Stage4<T, kLanes>;
+  __shared__ DevModel lm;
+  __shared__ double lds[ST::COUNT * kLanes];
+  {
+    constexpr int kWords = sizeof(DevModel) / 8;
+    const double* src = reinterpret_cast<const double*>(P.model);
+    double* dst = reinterpret_cast<double*>(&lm);
+#pragma unroll
+    for (int it = 0; it < (kWords + 255) / 256; ++it) {
+      const int k = it * 256 + threadIdx.x;
+      if (k < kWords) dst[k] = src[k];
+    }
+    __syncthreads();
+  }
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = blockIdx.x * kLanes + lane;
+  const bool live = lane < kLanes && e < P.n && !(op.mask && !op.mask[lane < kLanes && e < P.n ? e : 0]);
+  const DevModel& m = lm;
+  const ST st{lds + (lane < kLanes ? lane : 0)};
+  EnvRegs<T, ST> r;  // meaningful in wave 0 only
+  r.st = st;
+  r.time = 0; r.last_cmd_width = 0; r.last_width = 0; r.flags = 0; r.conv_steps = 0;
+  bool have_frames = false;
+  int nsteps = op.do_reset ? 1 : op.nsteps;
+  const bool until_conv = nsteps < 0;
+  int budget = 0;
+  bool converged = false;
+  if (w == 0 && live) {
+    load_env<T, ST>(P, e, r);
+    env_prologue<T, ST>(P, op, m, e, r);
+    budget = nsteps;
+    if (until_conv) {
+      r.conv_steps = 0;
+      r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
+      const int cap = P.sim.max_convergence_steps;
+      budget = cap == -1 ? 0x7fffffff : cap;
+    }
+    st.active() = budget > 0 ? 1.0 : 0.0;
+  }
+  int go = __syncthreads_or(w == 0 && live && budget > 0);
+#ifdef RCSH_PHASE_TIMING
+  unsigned long long t_mark = __builtin_readcyclecounter();
+#endif
+  while (go) {
+    const bool stepping = live && st.active() != 0.0;
+    if (w == 0 && stepping) plain_callbacks<T, ST>(P, r);
+    if (live) {
+      if (w == 0) phaseA_inertia<T, kLanes, 0>(m, st, stepping);
+      else if (w == 1) phaseA_inertia<T, kLanes, 1>(m, st, stepping);
+      else if (w == 2) phaseA_inertia<T, kLanes, 2>(m, st, stepping);
+      else phaseA_motion<T, kLanes>(m, st, stepping);
+    }
+    PHASE_MARK(0)
+    __syncthreads();
+    PHASE_MARK(7)
+    if (live) {
+      if (w == 0) phaseB_wrench<T, kLanes, 0>(st);
+      else if (w == 1) phaseB_wrench<T, kLanes, 1>(st);
+      else if (w == 2) phaseB_wrench<T, kLanes, 2>(st);
+      else phaseB_wrench<T, kLanes, 3>(st);
+    }
+    PHASE_MARK(1)
+    __syncthreads();
+    PHASE_MARK(7)
+    if (live) {
+      if (w == 0) phaseC_rows<T, kLanes, 0>(m, st);
+      else if (w == 1) phaseC_rows<T, kLanes, 1>(m, st);
+      else if (w == 2) phaseC_rows<T, kLanes, 2>(m, st);
+      else phaseC_rows<T, kLanes, 3>(m, st);
+    }
+    PHASE_MARK(2)
+    __syncthreads();
+    PHASE_MARK(7)
+    double A[T::NTRI];
+    Rows<T, kLanes> rows;
+    if (live) {
+      if (w == 3) phaseD_actuation<T, kLanes>(m, st);
+      else if (w == 0) phaseD_implicit_factor<T, kLanes>(m, st, A);
+      else if (w == 1) {
+        phaseD_rows<T, kLanes>(m, st, rows);
+        if (rows.has_eq || rows.limrows) build_factor_H<T, kLanes>(st, rows, rows.limrows, A);
+      }
+    }
+    PHASE_MARK(3)
+    __syncthreads();
+    PHASE_MARK(7)
+    if (live && w == 1) phaseD_constraint_solve<T, kLanes>(st, rows, A);
+    PHASE_MARK(4)
+    __syncthreads();
+    PHASE_MARK(7)
+    bool more = false;
+    if (w == 0 && live) {
+      phaseD_integrate<T, kLanes>(m, st, A);
+      if (stepping) {
+        r.time += m.timestep;
+        have_frames = true;
+        --budget;
+        if (until_conv) {
+          r.conv_steps++;
+          converged = condition_callbacks<T, ST>(m, P, r);
+        }
+      }
+      more = stepping && budget > 0 && !converged;
+      st.active() = more ? 1.0 : 0.0;
+    }
+    PHASE_MARK(5)
+    go = __syncthreads_or(more);
+    PHASE_MARK(7)
+  }
+  if (w == 0 && live) {
+    if (until_conv) set_flag(r.flags, kConverged, converged);
+    env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
   }
 }
 
