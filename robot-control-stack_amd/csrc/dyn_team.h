@@ -1,0 +1,599 @@
+// dyn_team.h -- one physics substep computed by a TEAM of 16 lanes per environment (team.h), lane t owning
+// link / joint t.  Same physics as dyn.h's substep (what mj_step1 / mj_step2 compute for the RCS scenes,
+// reference call sites src/sim/sim.cpp:110,112); a different decomposition:
+//
+//  * every per-link quantity (local frame, spatial inertia, bias wrench, actuator force, limit row) is computed
+//    by the link's own lane, all links at once;
+//  * root->leaf recursions (world frames, velocities, bias accelerations) are Hillis-Steele scans over the team
+//    with DPP row shifts: 3 rounds for the 8-link chain + one round that hands the second finger its parent;
+//  * leaf->root recursions (composite inertia, subtree wrench, gravity-compensation moment) are the mirrored
+//    scans -- in world-origin Pluecker coordinates they are plain sums;
+//  * the 9x9 factorisations do not parallelise over 9 lanes (a distributed LDL^T costs more exchange than it
+//    saves), so the lanes factor DIFFERENT matrices instead: lane s < 2^k solves the constraint problem under the
+//    s-th guess of the active set of the k joint-limit rows, lane 15 factors the implicit-integrator matrix.  The
+//    cost is convex piecewise quadratic, so the guess whose solution reproduces its own active set IS the
+//    minimiser: the Newton / line-search iteration of dyn.h collapses into one factorisation slot.  (k > 3 or no
+//    self-consistent guess -- ties -- falls back to that iteration, run redundantly by the team.)
+//
+// Exchange between lanes that is not a shift (motion axes for the mass-matrix rows, the matrix itself, the
+// solver result) goes through the environment's LDS block (StageTeam), [slot] contiguous per environment.
+#pragma once
+#include "team.h"
+
+namespace rcsh {
+
+#if defined(__HIP__)
+
+constexpr int even_up(int x) { return (x + 1) & ~1; }
+
+// LDS block of one environment.  The first slots (q .. X) are the interface sim_kernels.h' environment code
+// uses (same accessor names as Stage / Stage4); the rest is the team's exchange area.
+template <class T>
+struct StageTeam {
+  static constexpr int NL = T::NL;
+  static constexpr int NLP = even_up(NL);
+  static constexpr int Q0 = 0;                       // qpos
+  static constexpr int V0 = Q0 + NLP;                // qvel
+  static constexpr int C0 = V0 + NLP;                // ctrl
+  static constexpr int P0 = C0 + even_up(T::NU);     // qpos seen by the last position stage
+  static constexpr int K0 = P0 + NLP;                // frame of the site link: R(9) p(3)
+  static constexpr int A0 = K0 + 12;                 // 1.0 while the environment still steps in this launch
+  static constexpr int X0 = A0 + 2;                  // caller's slots
+  static constexpr int NX = 6 + 2 * T::NARM;
+  static constexpr int S0 = X0 + even_up(NX);        // motion axes [NL][6]
+  static constexpr int MROW = NLP;                   // row stride of the mass matrix (rows 16-byte aligned)
+  static constexpr int M0 = S0 + 6 * NL + (NL & 1) * 0;  // mass matrix rows (lower triangle valid)
+  static constexpr int SM0 = even_up(M0 + MROW * NL);    // qfrc_smooth
+  static constexpr int LD0 = SM0 + NLP;              // limit rows: D (0 = no row)
+  static constexpr int LA0 = LD0 + NLP;              // limit rows: aref
+  static constexpr int LS0 = LA0 + NLP;              // limit rows: sign of the Jacobian entry
+  static constexpr int DG0 = LS0 + NLP;              // diagonal of -h dF/dqd (implicitfast)
+  static constexpr int E0 = DG0 + NLP;               // eqD, eqAref, eqJ1, gblock
+  static constexpr int XS0 = E0 + 4;                 // solver result (constrained qacc of the soft problem)
+  static constexpr int QA0 = XS0 + NLP;              // qacc of the implicit solve
+  static constexpr int COUNT = QA0 + NLP;
+  double* base;
+  RCSH_D double& at(int k) const { return base[k]; }
+  RCSH_D double& q(int i) const { return base[Q0 + i]; }
+  RCSH_D double& v(int i) const { return base[V0 + i]; }
+  RCSH_D double& c(int i) const { return base[C0 + i]; }
+  RCSH_D double& qpre(int i) const { return base[P0 + i]; }
+  RCSH_D double& link(int k) const { return base[K0 + k]; }
+  RCSH_D double& active() const { return base[A0]; }
+  RCSH_D double& X(int k) const { return base[X0 + k]; }
+  RCSH_D double& S(int i, int k) const { return base[S0 + 6 * i + k]; }
+  RCSH_D double& M(int i, int j) const { return base[M0 + MROW * i + j]; }
+  RCSH_D double& smooth(int i) const { return base[SM0 + i]; }
+  RCSH_D double& limD(int i) const { return base[LD0 + i]; }
+  RCSH_D double& limA(int i) const { return base[LA0 + i]; }
+  RCSH_D double& limS(int i) const { return base[LS0 + i]; }
+  RCSH_D double& dg(int i) const { return base[DG0 + i]; }
+  RCSH_D double& eq(int k) const { return base[E0 + k]; }
+  RCSH_D double& xs(int i) const { return base[XS0 + i]; }
+  RCSH_D double& qacc(int i) const { return base[QA0 + i]; }
+};
+
+// LDS traffic of one wave is ordered; the barrier is there for the compiler (and costs nothing with one wave)
+RCSH_D void team_sync() { __syncthreads(); }
+
+// ---- scans over the link tree.  BANKS_CHAIN / the extra round implement "both fingers hang off the last arm
+// link": lanes 0..7 scan as a chain, lane 8 (second finger) is kept out of the chain rounds and receives its
+// parent (two lanes up) in a round of its own.
+
+// inclusive sum over a link's ancestors and itself
+template <class T>
+RCSH_D double scan_from_root(double x) {
+  if (T::GRIP) {
+    x += row_up_banks<1, 0x3>(x);
+    x += row_up_banks<2, 0x3>(x);
+    x += row_up_banks<4, 0x3>(x);
+    x += row_up_banks<2, 0x4>(x);
+  } else {
+    x += row_up<1>(x);
+    x += row_up<2>(x);
+    x += row_up<4>(x);
+  }
+  return x;
+}
+
+// sum over a link's subtree (itself and all descendants).  Lanes >= NL must hold zero.
+template <class T>
+RCSH_D double scan_from_leaves(double x, bool first_finger) {
+  double y = x;
+  y += row_down<1>(y);
+  y += row_down<2>(y);
+  y += row_down<4>(y);
+  if (T::NL > 8) y += row_down<8>(y);
+  // the first finger is a leaf but sits below the second in lane order
+  if (T::GRIP) y = first_finger ? x : y;
+  return y;
+}
+
+// world frame of every link from the local frames: X_t = X_parent(t) * A_t
+template <int N, int BANKS>
+RCSH_D void compose_round(double* R, double* p) {
+  double Rq[9], pq[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rq[k] = row_up_or_banks<N, BANKS>((k == 0 || k == 4 || k == 8) ? 1.0 : 0.0, R[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pq[k] = row_up_or_banks<N, BANKS>(0.0, p[k]);
+  double pn[3];
+  mulmv(Rq, p, pn);
+  p[0] = pn[0] + pq[0]; p[1] = pn[1] + pq[1]; p[2] = pn[2] + pq[2];
+  mulmm(Rq, R, R);
+}
+template <class T>
+RCSH_D void scan_frames(double* R, double* p) {
+  if (T::GRIP) {
+    compose_round<1, 0x3>(R, p);
+    compose_round<2, 0x3>(R, p);
+    compose_round<4, 0x3>(R, p);
+    compose_round<2, 0x4>(R, p);
+  } else {
+    compose_round<1, 0xf>(R, p);
+    compose_round<2, 0xf>(R, p);
+    compose_round<4, 0xf>(R, p);
+  }
+}
+
+// Newton iteration with exact line search over the soft rows (dyn.h's loop), run redundantly by every lane of a
+// team from the LDS copy of the problem.  Only reached when more than 3 limit rows exist or no active-set guess
+// was self-consistent.
+template <class T>
+RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, double eqD, double eqAref, double eqJ1,
+                        double* x) {
+  constexpr int NL = T::NL, NA = T::NARM;
+  uint32_t act = limrows;
+  bool have_x = false;
+  for (int iter = 0; iter < 16; ++iter) {
+    double xn[NL];
+    {
+      double H[T::NTRI];
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) H[tri(i, j)] = st.M(i, j);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        xn[i] = st.smooth(i);
+        if (act & (1u << i)) {
+          const double D = st.limD(i);
+          H[tri(i, i)] += D;
+          xn[i] += st.limS(i) * D * st.limA(i);
+        }
+      }
+      if (has_eq) {
+        H[tri(NA, NA)] += eqD;
+        H[tri(NA + 1, NA)] += eqD * eqJ1;
+        H[tri(NA + 1, NA + 1)] += eqD * eqJ1 * eqJ1;
+        xn[NA] += eqD * eqAref;
+        xn[NA + 1] += eqD * eqAref * eqJ1;
+      }
+      ldl_factor<NL>(H);
+      ldl_solve<NL>(H, xn);
+    }
+    uint32_t now = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if ((limrows & (1u << i)) && st.limS(i) * xn[i] - st.limA(i) < 0) now |= 1u << i;
+    if (now == act || !have_x) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) x[i] = xn[i];
+      have_x = true;
+      if (now == act) break;
+      act = now;
+      continue;
+    }
+    double d[NL], jar[NL], jd[NL];
+    double p0 = 0, p1 = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = xn[i] - x[i];
+    for (int r = 0; r < NL; ++r) {
+      double mx = -st.smooth(r), md = 0, dr = 0;
+#pragma unroll
+      for (int c = 0; c < NL; ++c) {
+        const double mrc = r >= c ? st.M(r, c) : st.M(c, r);
+        mx += mrc * x[c];
+        md += mrc * d[c];
+        dr = c == r ? d[c] : dr;
+      }
+      p0 += mx * dr;
+      p1 += md * dr;
+    }
+    if (has_eq) {
+      const double je = x[NA] + eqJ1 * x[NA + 1] - eqAref, jde = d[NA] + eqJ1 * d[NA + 1];
+      p0 += eqD * je * jde;
+      p1 += eqD * jde * jde;
+    }
+    uint32_t on = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      jar[i] = 0; jd[i] = 0;
+      if (limrows & (1u << i)) {
+        const double sgn = st.limS(i);
+        jar[i] = sgn * x[i] - st.limA(i);
+        jd[i] = sgn * d[i];
+        if (jar[i] < 0 || (jar[i] == 0 && jd[i] < 0)) on |= 1u << i;
+      }
+    }
+    double alpha = 0;
+    for (int guard = 0; guard < NL + 2; ++guard) {
+      double c0 = p0, c1 = p1, a_next = INFINITY;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        if (!(limrows & (1u << i))) continue;
+        const double D = st.limD(i);
+        if (on & (1u << i)) { c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
+        if (jd[i] != 0) {
+          const double ab = -jar[i] / jd[i];
+          if (ab > alpha && ab < a_next) a_next = ab;
+        }
+      }
+      const double a_star = -c0 / c1;
+      if (a_star <= a_next) { if (a_star > alpha) alpha = a_star; break; }
+      alpha = a_next;
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        if ((limrows & (1u << i)) && jd[i] != 0 && -jar[i] / jd[i] == a_next) on ^= 1u << i;
+    }
+    act = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      x[i] += alpha * d[i];
+      if ((limrows & (1u << i)) && st.limS(i) * x[i] - st.limA(i) < 0) act |= 1u << i;
+    }
+  }
+}
+
+// One substep of the environment whose LDS block is `st`, executed by its 16 lanes together (t = lane in team).
+// Reads qpos / qvel / ctrl from the block and, if `stepping`, writes the advanced qpos / qvel, the pre-step qpos
+// and the pre-step world frame of the attachment-site link back (same contract as dyn.h's substep).
+// Contains team_sync()s: every lane of the wave must call it.
+template <class T>
+RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool stepping) {
+  static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
+  static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
+  constexpr int NL = T::NL, NA = T::NARM;
+  const bool valid = t < NL;
+  const int tl = valid ? t : NL - 1;
+  const double h = m.timestep;
+  const double q = st.q(tl), qd = st.v(tl);
+  const bool is_slide = m.jtype[tl] == kSlide;
+
+  // ---- local frame of the link in its parent link's frame
+  double R[9], p[3];
+  {
+    const double dq = q - m.qpos0[tl];
+    const double* r0 = m.rot0[tl];
+    const double* p0 = m.pos0[tl];
+    if (m.axis_z[tl]) {
+      double s, c;
+      fast_sincos(dq, &s, &c);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        R[3 * r + 0] = c * r0[3 * r + 0] + s * r0[3 * r + 1];
+        R[3 * r + 1] = c * r0[3 * r + 1] - s * r0[3 * r + 0];
+        R[3 * r + 2] = r0[3 * r + 2];
+        p[r] = p0[r];
+      }
+    } else if (is_slide) {
+      double ax[3];
+      mulmv(r0, m.axis[tl], ax);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = r0[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = p0[k] + ax[k] * dq;
+    } else {
+      double s, c;
+      fast_sincos(dq, &s, &c);
+      const double* a = m.axis[tl];
+      const double u = 1.0 - c;
+      const double Q[9] = {c + u * a[0] * a[0],        u * a[0] * a[1] - s * a[2], u * a[0] * a[2] + s * a[1],
+                           u * a[0] * a[1] + s * a[2], c + u * a[1] * a[1],        u * a[1] * a[2] - s * a[0],
+                           u * a[0] * a[2] - s * a[1], u * a[1] * a[2] + s * a[0], c + u * a[2] * a[2]};
+      double anchor[3], rj[3];
+      mulmv(r0, m.jpos[tl], anchor);
+      mulmm(r0, Q, R);
+      mulmv(R, m.jpos[tl], rj);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = p0[k] + anchor[k] - rj[k];
+    }
+  }
+  scan_frames<T>(R, p);  // now the world frame
+  if (stepping && valid) st.qpre(tl) = q;
+  if (stepping && t == m.site_link) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st.link(k) = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st.link(9 + k) = p[k];
+  }
+
+  // ---- motion axis about the world origin, velocity and bias acceleration of the link
+  double S[6];
+  {
+    double ax[3], anchor[3];
+    mulmv(R, m.axis[tl], ax);
+    mulmv(R, m.jpos[tl], anchor);
+    anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
+    double mom[3];
+    cross3(anchor, ax, mom);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      S[k] = is_slide ? 0.0 : ax[k];
+      S[3 + k] = is_slide ? ax[k] : mom[k];
+    }
+  }
+  double vel[6], acc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vel[k] = scan_from_root<T>(S[k] * qd);
+  {
+    double sd[6];
+    cross_motion(vel, S, sd);  // S x S = 0: the link's own joint velocity does not contribute
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = scan_from_root<T>(sd[k] * qd);
+    acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
+  }
+
+  // ---- spatial inertia about the world origin, bias wrench, gravity-compensation first moment
+  double Ic[10], F[6], hs[3];
+  {
+    const double ms = valid ? m.mass[tl] : 0.0;
+    const double gcm = valid ? m.gcm[tl] : 0.0;
+    double c[3], cg[3];
+    mulmv(R, m.com[tl], c);
+    c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+    if (m.gc_same_com[tl]) {
+      cg[0] = c[0]; cg[1] = c[1]; cg[2] = c[2];
+    } else {
+      mulmv(R, m.gccom[tl], cg);
+      cg[0] += p[0]; cg[1] += p[1]; cg[2] += p[2];
+    }
+    const double* J = m.inertia[tl];
+    const double vz = valid ? 1.0 : 0.0;
+    const double Jm[9] = {vz * J[0], vz * J[3], vz * J[4], vz * J[3], vz * J[1], vz * J[5], vz * J[4], vz * J[5], vz * J[2]};
+    double Tm[9];
+    mulmm(R, Jm, Tm);
+    double Ii[10];
+    Ii[0] = Tm[0] * R[0] + Tm[1] * R[1] + Tm[2] * R[2] + ms * (c[1] * c[1] + c[2] * c[2]);
+    Ii[1] = Tm[3] * R[3] + Tm[4] * R[4] + Tm[5] * R[5] + ms * (c[0] * c[0] + c[2] * c[2]);
+    Ii[2] = Tm[6] * R[6] + Tm[7] * R[7] + Tm[8] * R[8] + ms * (c[0] * c[0] + c[1] * c[1]);
+    Ii[3] = Tm[0] * R[3] + Tm[1] * R[4] + Tm[2] * R[5] - ms * c[0] * c[1];
+    Ii[4] = Tm[0] * R[6] + Tm[1] * R[7] + Tm[2] * R[8] - ms * c[0] * c[2];
+    Ii[5] = Tm[3] * R[6] + Tm[4] * R[7] + Tm[5] * R[8] - ms * c[1] * c[2];
+    Ii[6] = ms * c[0]; Ii[7] = ms * c[1]; Ii[8] = ms * c[2];
+    Ii[9] = ms;
+    double Ia[6], Iv[6], vf[6];
+    inert_mul(Ii, acc, Ia);
+    inert_mul(Ii, vel, Iv);
+    cross_force(vel, Iv, vf);
+    const bool ff = T::GRIP && t == NA;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) Ic[k] = scan_from_leaves<T>(Ii[k], ff);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) F[k] = scan_from_leaves<T>(Ia[k] + vf[k], ff);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) hs[k] = scan_from_leaves<T>(gcm * cg[k], ff);
+  }
+
+  // ---- mass-matrix row of the link: M[t][j] = S_j . (Ic_t S_t) for the ancestors j (and itself)
+  double G[6];
+  inert_mul(Ic, S, G);
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st.S(tl, k) = S[k];
+  }
+  team_sync();
+  {
+    double row[StageTeam<T>::MROW];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      double Sj[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Sj[k] = st.S(j, k);
+      row[j] = dot6(Sj, G);
+    }
+    if (T::GRIP) row[NA] = t == NA + 1 ? 0.0 : row[NA];  // the fingers are siblings
+    const double arm = m.armature[tl];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) row[j] += j == tl ? arm : 0.0;
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < NL; ++j) st.M(tl, j) = row[j];  // entries right of the diagonal are never read
+    }
+  }
+  const double bias = dot6(S, F);
+  double gc;
+  {
+    const double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    double w[6];
+    cross3(hs, ng, w);
+    const double gs = m.gcm_sub[tl];
+    w[3] = gs * ng[0]; w[4] = gs * ng[1]; w[5] = gs * ng[2];
+    gc = dot6(S, w);
+  }
+
+  // ---- actuation (lane t: actuator of joint t; the gripper actuator pulls on both finger lanes)
+  double tau = 0.0;
+  bool unclamped_affine = false;  // arm actuator contributes its velocity derivative to the implicit matrix
+  if (t < NA && m.arm_has_act[tl]) {
+    double c = st.c(tl);
+    if (m.arm_ctrllimited[tl]) c = clampd(c, m.arm_ctrlrange[tl][0], m.arm_ctrlrange[tl][1]);
+    const double gear = m.arm_gear[tl];
+    double force = m.arm_gain[tl] * c;
+    if (m.arm_biasaffine[tl]) force += m.arm_bias[tl][0] + m.arm_bias[tl][1] * (gear * q) + m.arm_bias[tl][2] * (gear * qd);
+    bool clamped = false;
+    if (m.arm_forcelimited[tl]) {
+      clamped = force <= m.arm_forcerange[tl][0] || force >= m.arm_forcerange[tl][1];
+      force = clampd(force, m.arm_forcerange[tl][0], m.arm_forcerange[tl][1]);
+    }
+    tau = gear * force;
+    unclamped_affine = m.arm_biasaffine[tl] && !clamped;
+  }
+  double gblock = 0.0, eqD = 0.0, eqAref = 0.0, eqJ1 = 0.0;
+  if (T::GRIP) {
+    // both finger lanes see both fingers' state
+    const bool f1 = t == NA;
+    const double q_up = row_up<1>(q), q_dn = row_down<1>(q), v_up = row_up<1>(qd), v_dn = row_down<1>(qd);
+    const double q1 = f1 ? q : q_up, q2 = f1 ? q_dn : q, v1 = f1 ? qd : v_up, v2 = f1 ? v_dn : qd;
+    if (t == NA || t == NA + 1) {
+      if (m.grp_has_act) {
+        double c = st.c(NA);
+        if (m.grp_ctrllimited) c = clampd(c, m.grp_ctrlrange[0], m.grp_ctrlrange[1]);
+        const double len = m.grp_coef[0] * q1 + m.grp_coef[1] * q2;
+        const double lv = m.grp_coef[0] * v1 + m.grp_coef[1] * v2;
+        double force = m.grp_gain * c;
+        if (m.grp_biasaffine) force += m.grp_bias[0] + m.grp_bias[1] * len + m.grp_bias[2] * lv;
+        bool clamped = false;
+        if (m.grp_forcelimited) {
+          clamped = force <= m.grp_forcerange[0] || force >= m.grp_forcerange[1];
+          force = clampd(force, m.grp_forcerange[0], m.grp_forcerange[1]);
+        }
+        tau += m.grp_coef[f1 ? 0 : 1] * force;
+        if (m.grp_biasaffine && !clamped) gblock = -m.grp_bias[2];
+      }
+      if (m.eq_active) {
+        const double* pc = m.eq_polycoef;
+        const double dif = q2 - m.qpos0[NA + 1];
+        const double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
+        const double deriv = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
+        const double pos = q1 - m.qpos0[NA] - poly;
+        eqJ1 = -deriv;
+        const double imp = impedance(m.eq_imp, pos, 0.0);
+        eqD = row_D(imp, m.invweight0[NA] + m.invweight0[NA + 1]);
+        eqAref = -m.eq_K * imp * pos - m.eq_B * (v1 + eqJ1 * v2);
+      }
+      if (f1) { st.eq(0) = eqD; st.eq(1) = eqAref; st.eq(2) = eqJ1; st.eq(3) = gblock; }
+    }
+  }
+  double smooth;
+  {
+    double passive = -m.damping[tl] * qd;
+    if (m.actgravcomp[tl]) tau += gc; else passive += gc;
+    if (m.actfrclimited[tl]) tau = clampd(tau, m.actfrcrange[tl][0], m.actfrcrange[tl][1]);
+    smooth = passive - bias + tau;
+  }
+  // ---- joint-limit row of the lane's joint
+  double lD = 0.0, lA = 0.0, lS = 0.0;
+  if (m.limited[tl]) {
+    const double dlo = q - m.range[tl][0], dhi = m.range[tl][1] - q;
+    const double mg = m.margin[tl];
+    double dist = 0, sgn = 0;
+    if (dlo < mg) { dist = dlo; sgn = 1; }
+    else if (dhi < mg) { dist = dhi; sgn = -1; }
+    if (sgn != 0) {
+      const double imp = impedance(m.lim_imp[tl], dist, mg);
+      lD = row_D(imp, m.invweight0[tl]);
+      lA = -m.lim_K[tl] * imp * (dist - mg) - m.lim_B[tl] * (sgn * qd);
+      lS = sgn;
+    }
+  }
+  const uint32_t limrows = team_ballot(valid && lS != 0.0);
+  if (valid) {
+    double d = m.damping[tl];
+    if (unclamped_affine) d -= m.arm_gear[tl] * m.arm_gear[tl] * m.arm_bias[tl][2];
+    st.smooth(tl) = smooth;
+    st.limD(tl) = lD;
+    st.limA(tl) = lA;
+    st.limS(tl) = lS;
+    st.dg(tl) = h * d;
+  }
+  team_sync();
+
+  // ---- the factorisation slot
+  const bool has_eq = T::GRIP && m.eq_active;
+  if (T::GRIP) { eqD = st.eq(0); eqAref = st.eq(1); eqJ1 = st.eq(2); gblock = st.eq(3); }
+  const int nrows = __popc(limrows);
+  const bool implicit_lane = t == kTeamLanes - 1;
+  // lane s guesses: the s-th subset of the existing limit rows is active
+  uint32_t act = 0;
+  {
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const bool exists = (limrows >> i) & 1u;
+      if (exists && ((t >> c) & 1)) act |= 1u << i;
+      c += exists ? 1 : 0;
+    }
+  }
+  const bool fast = nrows <= 3;
+  const bool solver_lane = fast && t < (1 << nrows);
+  double H[T::NTRI], x[NL], sm[NL], lDv[NL], lAv[NL], lSv[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) H[tri(i, j)] = st.M(i, j);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    sm[i] = st.smooth(i);
+    lDv[i] = st.limD(i);
+    lAv[i] = st.limA(i);
+    lSv[i] = st.limS(i);
+    const double dgi = st.dg(i);
+    const bool on = (act >> i) & 1u;
+    const double dsolve = on ? lDv[i] : 0.0;
+    H[tri(i, i)] += implicit_lane ? dgi : dsolve;
+    x[i] = sm[i] + (on ? lSv[i] * lDv[i] * lAv[i] : 0.0);
+  }
+  if (T::GRIP) {
+    const double c0 = m.grp_coef[0], c1 = m.grp_coef[1], hg = h * gblock;
+    const double e = has_eq ? eqD : 0.0;
+    H[tri(NA, NA)] += implicit_lane ? hg * c0 * c0 : e;
+    H[tri(NA + 1, NA)] += implicit_lane ? hg * c0 * c1 : e * eqJ1;
+    H[tri(NA + 1, NA + 1)] += implicit_lane ? hg * c1 * c1 : e * eqJ1 * eqJ1;
+    x[NA] += e * eqAref;
+    x[NA + 1] += e * eqAref * eqJ1;
+  }
+  ldl_factor<NL>(H);
+  ldl_solve<NL>(H, x);  // meaningless on the implicit lane, which solves below
+  uint32_t now = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    if (((limrows >> i) & 1u) && lSv[i] * x[i] - lAv[i] < 0) now |= 1u << i;
+  const uint32_t winners = team_ballot(solver_lane && now == act);
+  if (winners) {
+    if (t == __ffs(winners) - 1) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) st.xs(i) = x[i];
+    }
+  } else {
+    double xs[NL];
+    newton_rows<T>(st, limrows, has_eq, eqD, eqAref, eqJ1, xs);
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) st.xs(i) = xs[i];
+    }
+  }
+  team_sync();
+
+  // ---- implicitfast: (M - h dF/dqd) qacc = smooth + constraint force, solved by the lane that factored it
+  if (implicit_lane) {
+    double xs[NL], rhs[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) xs[i] = st.xs(i);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      double fc = 0.0;
+      const double r = lSv[i] * xs[i] - lAv[i];
+      if (((limrows >> i) & 1u) && r < 0) fc = -lSv[i] * lDv[i] * r;
+      rhs[i] = sm[i] + fc;
+    }
+    if (has_eq) {
+      const double fe = -eqD * (xs[NA] + eqJ1 * xs[NA + 1] - eqAref);
+      rhs[NA] += fe;
+      rhs[NA + 1] += fe * eqJ1;
+    }
+    ldl_solve<NL>(H, rhs);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) st.qacc(i) = rhs[i];
+  }
+  team_sync();
+  if (stepping && valid) {
+    const double vn = qd + h * st.qacc(tl);
+    st.v(tl) = vn;
+    st.q(tl) = q + h * vn;
+  }
+}
+
+#endif  // __HIP__
+
+}  // namespace rcsh

@@ -142,9 +142,12 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   // larger batches the 52 KB of LDS per workgroup (staging columns + model tables) lets three share a CU
   // (measured at 32768 environments: 26.2 M env-steps/s with 16 lanes, 18.4 M with 32).
   static const bool four_wave = [] { const char* v = getenv("RCSH_FOUR_WAVE"); return v && v[0] == '1'; }();
+  static const bool team = [] { const char* v = getenv("RCSH_TEAM"); return v && v[0] == '1'; }();
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    if (four_wave)
+    if (team)
+      hipLaunchKernelGGL((k_run_team<T>), dim3((s->n + 3) / 4), dim3(64), 0, s->stream, P, op);
+    else if (four_wave)
       hipLaunchKernelGGL((k_run4<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(256), 0, s->stream, P, op);
     else
       hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);

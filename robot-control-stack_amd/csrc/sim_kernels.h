@@ -14,6 +14,7 @@
 
 #include "dyn.h"
 #include "dyn4.h"
+#include "dyn_team.h"
 #include "pose.h"
 
 namespace rcsh {
@@ -664,6 +665,82 @@ __global__ void __launch_bounds__(256) k_run4(Params P, RunOp op) {
     PHASE_MARK(7)
   }
   if (w == 0 && live) {
+    if (until_conv) set_flag(r.flags, kConverged, converged);
+    env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
+  }
+}
+
+// The same entry point with one TEAM of 16 lanes per environment (dyn_team.h): four environments per wavefront,
+// one wavefront per workgroup.  Lane 0 of a team (the leader) owns the RCS bookkeeping -- wrappers, callback
+// scheduler, observation -- through the same helpers as k_run; all 16 lanes run the physics.
+template <class T>
+__global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
+  using ST = StageTeam<T>;
+  constexpr int kTeams = 64 / kTeamLanes;
+  __shared__ DevModel lm;
+  __shared__ __attribute__((aligned(16))) double lds[ST::COUNT * kTeams];
+  {
+    constexpr int kWords = sizeof(DevModel) / 8;
+    const double* src = reinterpret_cast<const double*>(P.model);
+    double* dst = reinterpret_cast<double*>(&lm);
+#pragma unroll
+    for (int it = 0; it < (kWords + 63) / 64; ++it) {
+      const int k = it * 64 + threadIdx.x;
+      if (k < kWords) dst[k] = src[k];
+    }
+    for (int k = threadIdx.x; k < ST::COUNT * kTeams; k += 64) lds[k] = 0.0;
+    __syncthreads();
+  }
+  const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
+  const int e = blockIdx.x * kTeams + team;
+  const bool live = e < P.n && !(op.mask && !op.mask[e < P.n ? e : 0]);
+  const bool leader = t == 0 && live;
+  const DevModel& m = lm;
+  const ST st{lds + team * ST::COUNT};
+  EnvRegs<T, ST> r;  // meaningful on the leader only
+  r.st = st;
+  r.time = 0; r.last_cmd_width = 0; r.last_width = 0; r.flags = 0; r.conv_steps = 0;
+  bool have_frames = false;
+  int nsteps = op.do_reset ? 1 : op.nsteps;
+  const bool until_conv = nsteps < 0;
+  int budget = 0;
+  bool converged = false;
+  if (leader) {
+    load_env<T, ST>(P, e, r);
+    env_prologue<T, ST>(P, op, m, e, r);
+    budget = nsteps;
+    if (until_conv) {
+      r.conv_steps = 0;
+      r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
+      const int cap = P.sim.max_convergence_steps;
+      budget = cap == -1 ? 0x7fffffff : cap;
+    }
+    st.active() = budget > 0 ? 1.0 : 0.0;
+  }
+  int go = __syncthreads_or(leader && budget > 0);
+  while (go) {
+    const bool stepping = st.active() != 0.0;
+    if (leader && stepping) plain_callbacks<T, ST>(P, r);
+    __syncthreads();
+    team_substep<T>(m, st, t, stepping);
+    __syncthreads();
+    bool more = false;
+    if (leader) {
+      if (stepping) {
+        r.time += m.timestep;
+        have_frames = true;
+        --budget;
+        if (until_conv) {
+          r.conv_steps++;
+          converged = condition_callbacks<T, ST>(m, P, r);
+        }
+      }
+      more = stepping && budget > 0 && !converged;
+      st.active() = more ? 1.0 : 0.0;
+    }
+    go = __syncthreads_or(more);
+  }
+  if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
     env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
   }
