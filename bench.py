@@ -222,13 +222,13 @@ def main() -> None:
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 FETCH_SIZE + WRITE_SIZE, separate PMC passes (profiles/r1_traffic.json)" if traffic else None,
-                "kernel": "k_run<Topo<7,true>> (fused env-step)",
+                "kernel": ("k_run_team" if n < 131072 else "k_run") + "<Topo<7,true>> (fused env-step)",
                 "kernel_ms_avg": kernel_ms,
                 "launches_timed": int(launches.value),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "fp64_algorithmic_tflops": substeps_per_launch * ALGO_FLOP_PER_SUBSTEP / (kernel_ms * 1e-3) / 1e12,
                 "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                "note": "path is FP64-VALU/latency bound, not HBM bound (SURVEY F7): HBM fraction is reported as the contract asks",
+                "note": "path is FP64 VALU-issue bound, not HBM bound (SURVEY F7; profiles/README.md: every SIMD holds one wavefront that issues ~1 VALU instruction per 5 cycles): the HBM fraction is reported as the contract asks",
             },
         }
         if cpu_base is not None:

@@ -171,6 +171,11 @@ int rcsh_sim_synchronize(rcsh_sim* sim);
  * stream (e.g. the host framework's current stream, so its collectives order after the env-step kernel) */
 void* rcsh_sim_stream(rcsh_sim* sim);
 int rcsh_sim_set_stream(rcsh_sim* sim, void* hip_stream);
+/* Which kernel computes step / step_until_convergence / env step (no reference counterpart: the reference has
+ * one CPU code path).  RCSH_KERNEL_AUTO picks by batch size; the other two pin a variant (parity tests run
+ * both).  The environment variable RCSH_KERNEL=team|lane sets the default of new handles. */
+enum { RCSH_KERNEL_AUTO = 0, RCSH_KERNEL_TEAM = 1, RCSH_KERNEL_LANE = 2 };
+int rcsh_sim_set_kernel(rcsh_sim* sim, int32_t variant);
 
 /* Sim.set_config / get_config -- rcs.cpp:501-502, sim.cpp:27-32; SimConfig sim.h:29-34 */
 int rcsh_sim_set_config(rcsh_sim* sim, int32_t async_control, int32_t realtime, int32_t frequency,

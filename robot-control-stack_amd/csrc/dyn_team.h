@@ -73,6 +73,19 @@ struct StageTeam {
   RCSH_D double& qacc(int i) const { return base[QA0 + i]; }
 };
 
+#ifdef RCSH_PHASE_TIMING
+__device__ unsigned long long g_team_cycles[16];
+__device__ unsigned long long g_team_mark;
+#define TEAM_MARK(idx)                                            \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    g_team_cycles[idx] += now_ - g_team_mark;                     \
+    g_team_mark = now_;                                           \
+  }
+#else
+#define TEAM_MARK(idx)
+#endif
+
 // LDS traffic of one wave is ordered; the barrier is there for the compiler (and costs nothing with one wave)
 RCSH_D void team_sync() { __syncthreads(); }
 
@@ -162,7 +175,7 @@ RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, d
           xn[i] += st.limS(i) * D * st.limA(i);
         }
       }
-      if (has_eq) {
+      if constexpr (T::GRIP) if (has_eq) {
         H[tri(NA, NA)] += eqD;
         H[tri(NA + 1, NA)] += eqD * eqJ1;
         H[tri(NA + 1, NA + 1)] += eqD * eqJ1 * eqJ1;
@@ -200,7 +213,7 @@ RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, d
       p0 += mx * dr;
       p1 += md * dr;
     }
-    if (has_eq) {
+    if constexpr (T::GRIP) if (has_eq) {
       const double je = x[NA] + eqJ1 * x[NA + 1] - eqAref, jde = d[NA] + eqJ1 * d[NA + 1];
       p0 += eqD * je * jde;
       p1 += eqD * jde * jde;
@@ -245,28 +258,83 @@ RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, d
   }
 }
 
+// ---- per-lane model constants, fetched from the LDS model tables in one batch per phase.  A batch is issued
+// BEFORE the compute of the previous phase (sched_fence keeps it there), so its LDS latency hides behind that
+// compute: the wave is alone on its SIMD and nothing else would.
+struct KinK {
+  double qpos0, rot0[9], pos0[3], axis[3], jpos[3];
+  int32_t axis_z, jtype;
+  RCSH_D void load(const DevModel& m, int tl) {
+    qpos0 = m.qpos0[tl];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rot0[k] = m.rot0[tl][k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pos0[k] = m.pos0[tl][k]; axis[k] = m.axis[tl][k]; jpos[k] = m.jpos[tl][k]; }
+    axis_z = m.axis_z[tl];
+    jtype = m.jtype[tl];
+  }
+};
+struct InertK {
+  double mass, gcm, com[3], J[6];
+  int32_t gc_same_com;
+  RCSH_D void load(const DevModel& m, int tl) {
+    mass = m.mass[tl];
+    gcm = m.gcm[tl];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) com[k] = m.com[tl][k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) J[k] = m.inertia[tl][k];
+    gc_same_com = m.gc_same_com[tl];
+  }
+};
+struct ActK {
+  int32_t has_act, ctrllimited, biasaffine, forcelimited, actgravcomp, actfrclimited, limited;
+  double ctrlrange[2], gear, gain, bias[3], forcerange[2];
+  double damping, actfrcrange[2], armature, gcm_sub, range[2], margin;
+  RCSH_D void load(const DevModel& m, int tl, int ta) {
+    has_act = m.arm_has_act[ta]; ctrllimited = m.arm_ctrllimited[ta]; biasaffine = m.arm_biasaffine[ta];
+    forcelimited = m.arm_forcelimited[ta];
+    ctrlrange[0] = m.arm_ctrlrange[ta][0]; ctrlrange[1] = m.arm_ctrlrange[ta][1];
+    gear = m.arm_gear[ta]; gain = m.arm_gain[ta];
+    bias[0] = m.arm_bias[ta][0]; bias[1] = m.arm_bias[ta][1]; bias[2] = m.arm_bias[ta][2];
+    forcerange[0] = m.arm_forcerange[ta][0]; forcerange[1] = m.arm_forcerange[ta][1];
+    actgravcomp = m.actgravcomp[tl]; actfrclimited = m.actfrclimited[tl]; limited = m.limited[tl];
+    damping = m.damping[tl];
+    actfrcrange[0] = m.actfrcrange[tl][0]; actfrcrange[1] = m.actfrcrange[tl][1];
+    armature = m.armature[tl]; gcm_sub = m.gcm_sub[tl];
+    range[0] = m.range[tl][0]; range[1] = m.range[tl][1]; margin = m.margin[tl];
+  }
+};
+
 // One substep of the environment whose LDS block is `st`, executed by its 16 lanes together (t = lane in team).
 // Reads qpos / qvel / ctrl from the block and, if `stepping`, writes the advanced qpos / qvel, the pre-step qpos
 // and the pre-step world frame of the attachment-site link back (same contract as dyn.h's substep).
+// `on_frame(R, p)` is called on every lane with the world frame of the lane's link at the pre-step qpos (what the
+// contact detection of the last mj_step1 sees).
 // Contains team_sync()s: every lane of the wave must call it.
-template <class T>
-RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool stepping) {
+template <class T, class FrameFn>
+RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool stepping, FrameFn&& on_frame) {
   static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
   constexpr int NL = T::NL, NA = T::NARM;
   const bool valid = t < NL;
   const int tl = valid ? t : NL - 1;
+  const int ta = t < NA ? t : 0;
   const double h = m.timestep;
+  KinK kk;
+  kk.load(m, tl);
   const double q = st.q(tl), qd = st.v(tl);
-  const bool is_slide = m.jtype[tl] == kSlide;
+  const double ctrl = st.c(ta);
+  sched_fence();
+  const bool is_slide = kk.jtype == kSlide;
 
   // ---- local frame of the link in its parent link's frame
   double R[9], p[3];
   {
-    const double dq = q - m.qpos0[tl];
-    const double* r0 = m.rot0[tl];
-    const double* p0 = m.pos0[tl];
-    if (m.axis_z[tl]) {
+    const double dq = q - kk.qpos0;
+    const double* r0 = kk.rot0;
+    const double* p0 = kk.pos0;
+    if (kk.axis_z) {
       double s, c;
       fast_sincos(dq, &s, &c);
 #pragma unroll
@@ -278,7 +346,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
       }
     } else if (is_slide) {
       double ax[3];
-      mulmv(r0, m.axis[tl], ax);
+      mulmv(r0, kk.axis, ax);
 #pragma unroll
       for (int k = 0; k < 9; ++k) R[k] = r0[k];
 #pragma unroll
@@ -286,20 +354,26 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     } else {
       double s, c;
       fast_sincos(dq, &s, &c);
-      const double* a = m.axis[tl];
+      const double* a = kk.axis;
       const double u = 1.0 - c;
       const double Q[9] = {c + u * a[0] * a[0],        u * a[0] * a[1] - s * a[2], u * a[0] * a[2] + s * a[1],
                            u * a[0] * a[1] + s * a[2], c + u * a[1] * a[1],        u * a[1] * a[2] - s * a[0],
                            u * a[0] * a[2] - s * a[1], u * a[1] * a[2] + s * a[0], c + u * a[2] * a[2]};
       double anchor[3], rj[3];
-      mulmv(r0, m.jpos[tl], anchor);
+      mulmv(r0, kk.jpos, anchor);
       mulmm(r0, Q, R);
-      mulmv(R, m.jpos[tl], rj);
+      mulmv(R, kk.jpos, rj);
 #pragma unroll
       for (int k = 0; k < 3; ++k) p[k] = p0[k] + anchor[k] - rj[k];
     }
   }
+  TEAM_MARK(0)
+  InertK ik;
+  ik.load(m, tl);
+  sched_fence();
   scan_frames<T>(R, p);  // now the world frame
+  TEAM_MARK(1)
+  on_frame(R, p);
   if (stepping && valid) st.qpre(tl) = q;
   if (stepping && t == m.site_link) {
 #pragma unroll
@@ -312,8 +386,8 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
   double S[6];
   {
     double ax[3], anchor[3];
-    mulmv(R, m.axis[tl], ax);
-    mulmv(R, m.jpos[tl], anchor);
+    mulmv(R, kk.axis, ax);
+    mulmv(R, kk.jpos, anchor);
     anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
     double mom[3];
     cross3(anchor, ax, mom);
@@ -322,6 +396,10 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
       S[k] = is_slide ? 0.0 : ax[k];
       S[3 + k] = is_slide ? ax[k] : mom[k];
     }
+  }
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st.S(tl, k) = S[k];
   }
   double vel[6], acc[6];
 #pragma unroll
@@ -333,22 +411,26 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     for (int k = 0; k < 6; ++k) acc[k] = scan_from_root<T>(sd[k] * qd);
     acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
   }
+  TEAM_MARK(2)
+  ActK ak;
+  ak.load(m, tl, ta);
+  sched_fence();
 
   // ---- spatial inertia about the world origin, bias wrench, gravity-compensation first moment
   double Ic[10], F[6], hs[3];
   {
-    const double ms = valid ? m.mass[tl] : 0.0;
-    const double gcm = valid ? m.gcm[tl] : 0.0;
+    const double ms = valid ? ik.mass : 0.0;
+    const double gcm = valid ? ik.gcm : 0.0;
     double c[3], cg[3];
-    mulmv(R, m.com[tl], c);
+    mulmv(R, ik.com, c);
     c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
-    if (m.gc_same_com[tl]) {
+    if (ik.gc_same_com) {
       cg[0] = c[0]; cg[1] = c[1]; cg[2] = c[2];
     } else {
       mulmv(R, m.gccom[tl], cg);
       cg[0] += p[0]; cg[1] += p[1]; cg[2] += p[2];
     }
-    const double* J = m.inertia[tl];
+    const double* J = ik.J;
     const double vz = valid ? 1.0 : 0.0;
     const double Jm[9] = {vz * J[0], vz * J[3], vz * J[4], vz * J[3], vz * J[1], vz * J[5], vz * J[4], vz * J[5], vz * J[2]};
     double Tm[9];
@@ -374,28 +456,28 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
 #pragma unroll
     for (int k = 0; k < 3; ++k) hs[k] = scan_from_leaves<T>(gcm * cg[k], ff);
   }
+  TEAM_MARK(3)
 
   // ---- mass-matrix row of the link: M[t][j] = S_j . (Ic_t S_t) for the ancestors j (and itself)
   double G[6];
   inert_mul(Ic, S, G);
-  if (valid) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) st.S(tl, k) = S[k];
-  }
-  team_sync();
+  team_sync();  // every lane's S is in the block
   {
     double row[StageTeam<T>::MROW];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      double Sj[6];
+    for (int j0 = 0; j0 < NL; j0 += 3) {
+      double Sj[3][6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Sj[k] = st.S(j, k);
-      row[j] = dot6(Sj, G);
+      for (int j = j0; j < j0 + 3 && j < NL; ++j)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Sj[j - j0][k] = st.S(j, k);
+      sched_fence();
+#pragma unroll
+      for (int j = j0; j < j0 + 3 && j < NL; ++j) row[j] = dot6(Sj[j - j0], G);
     }
     if (T::GRIP) row[NA] = t == NA + 1 ? 0.0 : row[NA];  // the fingers are siblings
-    const double arm = m.armature[tl];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) row[j] += j == tl ? arm : 0.0;
+    for (int j = 0; j < NL; ++j) row[j] += j == tl ? ak.armature : 0.0;
     if (valid) {
 #pragma unroll
       for (int j = 0; j < NL; ++j) st.M(tl, j) = row[j];  // entries right of the diagonal are never read
@@ -407,27 +489,26 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     const double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
     double w[6];
     cross3(hs, ng, w);
-    const double gs = m.gcm_sub[tl];
-    w[3] = gs * ng[0]; w[4] = gs * ng[1]; w[5] = gs * ng[2];
+    w[3] = ak.gcm_sub * ng[0]; w[4] = ak.gcm_sub * ng[1]; w[5] = ak.gcm_sub * ng[2];
     gc = dot6(S, w);
   }
+  TEAM_MARK(4)
 
   // ---- actuation (lane t: actuator of joint t; the gripper actuator pulls on both finger lanes)
   double tau = 0.0;
   bool unclamped_affine = false;  // arm actuator contributes its velocity derivative to the implicit matrix
-  if (t < NA && m.arm_has_act[tl]) {
-    double c = st.c(tl);
-    if (m.arm_ctrllimited[tl]) c = clampd(c, m.arm_ctrlrange[tl][0], m.arm_ctrlrange[tl][1]);
-    const double gear = m.arm_gear[tl];
-    double force = m.arm_gain[tl] * c;
-    if (m.arm_biasaffine[tl]) force += m.arm_bias[tl][0] + m.arm_bias[tl][1] * (gear * q) + m.arm_bias[tl][2] * (gear * qd);
+  if (t < NA && ak.has_act) {
+    double c = ctrl;
+    if (ak.ctrllimited) c = clampd(c, ak.ctrlrange[0], ak.ctrlrange[1]);
+    double force = ak.gain * c;
+    if (ak.biasaffine) force += ak.bias[0] + ak.bias[1] * (ak.gear * q) + ak.bias[2] * (ak.gear * qd);
     bool clamped = false;
-    if (m.arm_forcelimited[tl]) {
-      clamped = force <= m.arm_forcerange[tl][0] || force >= m.arm_forcerange[tl][1];
-      force = clampd(force, m.arm_forcerange[tl][0], m.arm_forcerange[tl][1]);
+    if (ak.forcelimited) {
+      clamped = force <= ak.forcerange[0] || force >= ak.forcerange[1];
+      force = clampd(force, ak.forcerange[0], ak.forcerange[1]);
     }
-    tau = gear * force;
-    unclamped_affine = m.arm_biasaffine[tl] && !clamped;
+    tau = ak.gear * force;
+    unclamped_affine = ak.biasaffine && !clamped;
   }
   double gblock = 0.0, eqD = 0.0, eqAref = 0.0, eqJ1 = 0.0;
   if (T::GRIP) {
@@ -436,61 +517,75 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     const double q_up = row_up<1>(q), q_dn = row_down<1>(q), v_up = row_up<1>(qd), v_dn = row_down<1>(qd);
     const double q1 = f1 ? q : q_up, q2 = f1 ? q_dn : q, v1 = f1 ? qd : v_up, v2 = f1 ? v_dn : qd;
     if (t == NA || t == NA + 1) {
-      if (m.grp_has_act) {
-        double c = st.c(NA);
-        if (m.grp_ctrllimited) c = clampd(c, m.grp_ctrlrange[0], m.grp_ctrlrange[1]);
-        const double len = m.grp_coef[0] * q1 + m.grp_coef[1] * q2;
-        const double lv = m.grp_coef[0] * v1 + m.grp_coef[1] * v2;
-        double force = m.grp_gain * c;
-        if (m.grp_biasaffine) force += m.grp_bias[0] + m.grp_bias[1] * len + m.grp_bias[2] * lv;
+      // gripper constants: one batch
+      const int32_t g_has = m.grp_has_act, g_cl = m.grp_ctrllimited, g_ba = m.grp_biasaffine, g_fl = m.grp_forcelimited;
+      const int32_t e_on = m.eq_active;
+      const double g_c0 = m.grp_coef[0], g_c1 = m.grp_coef[1], g_gain = m.grp_gain;
+      const double g_b0 = m.grp_bias[0], g_b1 = m.grp_bias[1], g_b2 = m.grp_bias[2];
+      const double g_cr0 = m.grp_ctrlrange[0], g_cr1 = m.grp_ctrlrange[1], g_fr0 = m.grp_forcerange[0], g_fr1 = m.grp_forcerange[1];
+      const double gctrl = st.c(NA);
+      const double pc0 = m.eq_polycoef[0], pc1 = m.eq_polycoef[1], pc2 = m.eq_polycoef[2], pc3 = m.eq_polycoef[3], pc4 = m.eq_polycoef[4];
+      const double q0a = m.qpos0[NA], q0b = m.qpos0[NA + 1], iwa = m.invweight0[NA], iwb = m.invweight0[NA + 1];
+      const double eK = m.eq_K, eB = m.eq_B;
+      const Imp eimp = m.eq_imp;
+      sched_fence();
+      if (g_has) {
+        double c = gctrl;
+        if (g_cl) c = clampd(c, g_cr0, g_cr1);
+        const double len = g_c0 * q1 + g_c1 * q2;
+        const double lv = g_c0 * v1 + g_c1 * v2;
+        double force = g_gain * c;
+        if (g_ba) force += g_b0 + g_b1 * len + g_b2 * lv;
         bool clamped = false;
-        if (m.grp_forcelimited) {
-          clamped = force <= m.grp_forcerange[0] || force >= m.grp_forcerange[1];
-          force = clampd(force, m.grp_forcerange[0], m.grp_forcerange[1]);
+        if (g_fl) {
+          clamped = force <= g_fr0 || force >= g_fr1;
+          force = clampd(force, g_fr0, g_fr1);
         }
-        tau += m.grp_coef[f1 ? 0 : 1] * force;
-        if (m.grp_biasaffine && !clamped) gblock = -m.grp_bias[2];
+        tau += (f1 ? g_c0 : g_c1) * force;
+        if (g_ba && !clamped) gblock = -g_b2;
       }
-      if (m.eq_active) {
-        const double* pc = m.eq_polycoef;
-        const double dif = q2 - m.qpos0[NA + 1];
-        const double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
-        const double deriv = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
-        const double pos = q1 - m.qpos0[NA] - poly;
+      if (e_on) {
+        const double dif = q2 - q0b;
+        const double poly = pc0 + dif * (pc1 + dif * (pc2 + dif * (pc3 + dif * pc4)));
+        const double deriv = pc1 + dif * (2 * pc2 + dif * (3 * pc3 + dif * 4 * pc4));
+        const double pos = q1 - q0a - poly;
         eqJ1 = -deriv;
-        const double imp = impedance(m.eq_imp, pos, 0.0);
-        eqD = row_D(imp, m.invweight0[NA] + m.invweight0[NA + 1]);
-        eqAref = -m.eq_K * imp * pos - m.eq_B * (v1 + eqJ1 * v2);
+        const double imp = impedance(eimp, pos, 0.0);
+        eqD = row_D(imp, iwa + iwb);
+        eqAref = -eK * imp * pos - eB * (v1 + eqJ1 * v2);
       }
       if (f1) { st.eq(0) = eqD; st.eq(1) = eqAref; st.eq(2) = eqJ1; st.eq(3) = gblock; }
     }
   }
   double smooth;
   {
-    double passive = -m.damping[tl] * qd;
-    if (m.actgravcomp[tl]) tau += gc; else passive += gc;
-    if (m.actfrclimited[tl]) tau = clampd(tau, m.actfrcrange[tl][0], m.actfrcrange[tl][1]);
+    double passive = -ak.damping * qd;
+    if (ak.actgravcomp) tau += gc; else passive += gc;
+    if (ak.actfrclimited) tau = clampd(tau, ak.actfrcrange[0], ak.actfrcrange[1]);
     smooth = passive - bias + tau;
   }
   // ---- joint-limit row of the lane's joint
   double lD = 0.0, lA = 0.0, lS = 0.0;
-  if (m.limited[tl]) {
-    const double dlo = q - m.range[tl][0], dhi = m.range[tl][1] - q;
-    const double mg = m.margin[tl];
+  if (ak.limited) {
+    const double dlo = q - ak.range[0], dhi = ak.range[1] - q;
+    const double mg = ak.margin;
     double dist = 0, sgn = 0;
     if (dlo < mg) { dist = dlo; sgn = 1; }
     else if (dhi < mg) { dist = dhi; sgn = -1; }
     if (sgn != 0) {
-      const double imp = impedance(m.lim_imp[tl], dist, mg);
-      lD = row_D(imp, m.invweight0[tl]);
-      lA = -m.lim_K[tl] * imp * (dist - mg) - m.lim_B[tl] * (sgn * qd);
+      const Imp limp = m.lim_imp[tl];
+      const double lK = m.lim_K[tl], lB = m.lim_B[tl], iw = m.invweight0[tl];
+      sched_fence();
+      const double imp = impedance(limp, dist, mg);
+      lD = row_D(imp, iw);
+      lA = -lK * imp * (dist - mg) - lB * (sgn * qd);
       lS = sgn;
     }
   }
   const uint32_t limrows = team_ballot(valid && lS != 0.0);
   if (valid) {
-    double d = m.damping[tl];
-    if (unclamped_affine) d -= m.arm_gear[tl] * m.arm_gear[tl] * m.arm_bias[tl][2];
+    double d = ak.damping;
+    if (unclamped_affine) d -= ak.gear * ak.gear * ak.bias[2];
     st.smooth(tl) = smooth;
     st.limD(tl) = lD;
     st.limA(tl) = lA;
@@ -498,10 +593,10 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     st.dg(tl) = h * d;
   }
   team_sync();
+  TEAM_MARK(5)
 
   // ---- the factorisation slot
   const bool has_eq = T::GRIP && m.eq_active;
-  if (T::GRIP) { eqD = st.eq(0); eqAref = st.eq(1); eqJ1 = st.eq(2); gblock = st.eq(3); }
   const int nrows = __popc(limrows);
   const bool implicit_lane = t == kTeamLanes - 1;
   // lane s guesses: the s-th subset of the existing limit rows is active
@@ -517,24 +612,26 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
   }
   const bool fast = nrows <= 3;
   const bool solver_lane = fast && t < (1 << nrows);
-  double H[T::NTRI], x[NL], sm[NL], lDv[NL], lAv[NL], lSv[NL];
+  double H[T::NTRI], x[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i)
 #pragma unroll
     for (int j = 0; j <= i; ++j) H[tri(i, j)] = st.M(i, j);
+  {
+    double sm[NL], lDv[NL], lAv[NL], lSv[NL], dgv[NL];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    sm[i] = st.smooth(i);
-    lDv[i] = st.limD(i);
-    lAv[i] = st.limA(i);
-    lSv[i] = st.limS(i);
-    const double dgi = st.dg(i);
-    const bool on = (act >> i) & 1u;
-    const double dsolve = on ? lDv[i] : 0.0;
-    H[tri(i, i)] += implicit_lane ? dgi : dsolve;
-    x[i] = sm[i] + (on ? lSv[i] * lDv[i] * lAv[i] : 0.0);
+    for (int i = 0; i < NL; ++i) { sm[i] = st.smooth(i); lDv[i] = st.limD(i); lAv[i] = st.limA(i); lSv[i] = st.limS(i); dgv[i] = st.dg(i); }
+    if (T::GRIP) { eqD = st.eq(0); eqAref = st.eq(1); eqJ1 = st.eq(2); gblock = st.eq(3); }
+    sched_fence();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const bool on = (act >> i) & 1u;
+      const double dsolve = on ? lDv[i] : 0.0;
+      H[tri(i, i)] += implicit_lane ? dgv[i] : dsolve;
+      x[i] = sm[i] + (on ? lSv[i] * lDv[i] * lAv[i] : 0.0);
+    }
   }
-  if (T::GRIP) {
+  if constexpr (T::GRIP) {
     const double c0 = m.grp_coef[0], c1 = m.grp_coef[1], hg = h * gblock;
     const double e = has_eq ? eqD : 0.0;
     H[tri(NA, NA)] += implicit_lane ? hg * c0 * c0 : e;
@@ -546,9 +643,15 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
   ldl_factor<NL>(H);
   ldl_solve<NL>(H, x);  // meaningless on the implicit lane, which solves below
   uint32_t now = 0;
+  {
+    double lAv[NL], lSv[NL];
 #pragma unroll
-  for (int i = 0; i < NL; ++i)
-    if (((limrows >> i) & 1u) && lSv[i] * x[i] - lAv[i] < 0) now |= 1u << i;
+    for (int i = 0; i < NL; ++i) { lAv[i] = st.limA(i); lSv[i] = st.limS(i); }
+    sched_fence();
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if (((limrows >> i) & 1u) && lSv[i] * x[i] - lAv[i] < 0) now |= 1u << i;
+  }
   const uint32_t winners = team_ballot(solver_lane && now == act);
   if (winners) {
     if (t == __ffs(winners) - 1) {
@@ -564,20 +667,20 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     }
   }
   team_sync();
+  TEAM_MARK(6)
 
   // ---- implicitfast: (M - h dF/dqd) qacc = smooth + constraint force, solved by the lane that factored it
   if (implicit_lane) {
-    double xs[NL], rhs[NL];
+    double xs[NL], rhs[NL], lDv[NL], lAv[NL], lSv[NL];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) xs[i] = st.xs(i);
+    for (int i = 0; i < NL; ++i) { xs[i] = st.xs(i); rhs[i] = st.smooth(i); lDv[i] = st.limD(i); lAv[i] = st.limA(i); lSv[i] = st.limS(i); }
+    sched_fence();
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      double fc = 0.0;
       const double r = lSv[i] * xs[i] - lAv[i];
-      if (((limrows >> i) & 1u) && r < 0) fc = -lSv[i] * lDv[i] * r;
-      rhs[i] = sm[i] + fc;
+      if (((limrows >> i) & 1u) && r < 0) rhs[i] -= lSv[i] * lDv[i] * r;
     }
-    if (has_eq) {
+    if constexpr (T::GRIP) if (has_eq) {
       const double fe = -eqD * (xs[NA] + eqJ1 * xs[NA + 1] - eqAref);
       rhs[NA] += fe;
       rhs[NA + 1] += fe * eqJ1;
@@ -592,6 +695,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     st.v(tl) = vn;
     st.q(tl) = q + h * vn;
   }
+  TEAM_MARK(7)
 }
 
 #endif  // __HIP__

@@ -31,13 +31,15 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int kBlock = 64;     // accessor kernels
-constexpr int kRunLanes = 16;  // environments per workgroup of k_run
+constexpr int kRunLanes = 16;                // environments per workgroup of k_run
+constexpr int kTeamKernelMaxEnvs = 131072;  // crossover of k_run_team and k_run (tools/sweep_envs.sh)
 constexpr int kProfRing = 4096;
 
 }  // namespace
 
 struct rcsh_sim {
   int device = 0;
+  int kernel = RCSH_KERNEL_AUTO;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
   int n = 0;
@@ -137,18 +139,18 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
     }
     HIP_TRY(hipEventRecord(s->ev_start[s->prof_pending], s->stream));
   }
-  // 16 environments per workgroup (one quarter-filled wave each).  The launch is latency-bound per wave, so
-  // what counts is how many waves are in flight: 4096 environments are 256 workgroups = one per CU, and for
-  // larger batches the 52 KB of LDS per workgroup (staging columns + model tables) lets three share a CU
-  // (measured at 32768 environments: 26.2 M env-steps/s with 16 lanes, 18.4 M with 32).
-  static const bool four_wave = [] { const char* v = getenv("RCSH_FOUR_WAVE"); return v && v[0] == '1'; }();
-  static const bool team = [] { const char* v = getenv("RCSH_TEAM"); return v && v[0] == '1'; }();
+  // Two kernels compute the same launch (sim_kernels.h):
+  //  * k_run_team: 16 lanes per environment, 4 environments per wavefront.  4096 environments are 1024
+  //    wavefronts = one per SIMD of the chip; measured 23-28 M env-steps/s from 4096 to 65536 environments.
+  //  * k_run: one lane per environment, 16 environments per workgroup (the 52 KB LDS staging block per workgroup
+  //    caps it at three workgroups per CU).  2.5x slower at 4096 environments (9.5 M), ahead only once the
+  //    chip is oversubscribed (30 M vs 28 M at 262144).
+  // rcsh_sim_set_kernel / RCSH_KERNEL=team|lane pin the choice (parity tests run both).
+  const bool team = s->kernel ? s->kernel == RCSH_KERNEL_TEAM : s->n < kTeamKernelMaxEnvs;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
     if (team)
       hipLaunchKernelGGL((k_run_team<T>), dim3((s->n + 3) / 4), dim3(64), 0, s->stream, P, op);
-    else if (four_wave)
-      hipLaunchKernelGGL((k_run4<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(256), 0, s->stream, P, op);
     else
       hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);
     err = hipGetLastError();
@@ -276,6 +278,8 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   }
   s->device = device;
   s->n = n_envs;
+  if (const char* v = getenv("RCSH_KERNEL"))
+    s->kernel = std::strcmp(v, "team") == 0 ? RCSH_KERNEL_TEAM : (std::strcmp(v, "lane") == 0 ? RCSH_KERNEL_LANE : RCSH_KERNEL_AUTO);
   s->narm = s->dm.narm; s->nl = s->dm.nl; s->grip = s->dm.has_gripper != 0;
   s->nu = s->narm + (s->grip ? 1 : 0);
   s->nfields = with_layout(s, [&](auto topo) { return (int)Lay<decltype(topo)>::COUNT; });
@@ -354,6 +358,13 @@ int rcsh_sim_set_stream(rcsh_sim* s, void* hip_stream) {
   REQUIRE_SIM(s);
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  return RCSH_OK;
+}
+
+int rcsh_sim_set_kernel(rcsh_sim* s, int32_t variant) {
+  REQUIRE_SIM(s);
+  if (variant < RCSH_KERNEL_AUTO || variant > RCSH_KERNEL_LANE) return fail(RCSH_ERR_ARG, "unknown kernel variant");
+  s->kernel = variant;
   return RCSH_OK;
 }
 
@@ -837,9 +848,9 @@ int rcsh_dev_download(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
 }
 
 #ifdef RCSH_PHASE_TIMING
-extern "C" int rcsh_debug_phase_cycles(unsigned long long* out32) {
+extern "C" int rcsh_debug_team_cycles(unsigned long long* out16) {
   hipDeviceSynchronize();
-  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_cycles), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -13,7 +13,6 @@
 #include <cstdint>
 
 #include "dyn.h"
-#include "dyn4.h"
 #include "dyn_team.h"
 #include "pose.h"
 
@@ -242,13 +241,14 @@ __device__ __noinline__ uint32_t plane_contacts(const DevModel& m, const Params&
 // SimRobot::collision_callback / convergence_callback (SimRobot.cpp:172-191),
 // SimGripper::collision_callback / convergence_callback (SimGripper.cpp:108-130,143-151).
 // Contacts: plane (floor) against the collision geoms only; geom-geom pairs are not detected in this revision.
-template <class T, class ST>
-__device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Params& P, EnvRegs<T, ST>& r) {
+// `contacts()` returns the plane-contact classes of the last position stage (bit 0 arm geoms, bit 1 gripper geoms).
+template <class T, class ST, class HitFn>
+__device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Params& P, EnvRegs<T, ST>& r, HitFn&& contacts) {
   const bool has_g = T::GRIP && P.grip.present;
   const bool fire_r = P.robot.present && r.time - r.cb(2) > P.robot.period;
   const bool fire_g = has_g && r.time - r.cb(3) > P.grip.period;
   if (fire_r || fire_g) {
-    const uint32_t hit = plane_contacts<T, ST>(m, P, r.st);
+    const uint32_t hit = contacts();
     if (fire_r) {
       set_flag(r.flags, kRobotCollision, hit & 1u);
       set_flag(r.flags, kAnyRet0, hit & 1u);
@@ -532,142 +532,11 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
     --budget;
     if (until_conv) {
       r.conv_steps++;
-      converged = condition_callbacks<T, ST>(m, P, r);
+      converged = condition_callbacks<T, ST>(m, P, r, [&] { return plane_contacts<T, ST>(m, P, r.st); });
     }
   }
   if (until_conv) set_flag(r.flags, kConverged, converged);
   env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
-}
-
-#ifdef RCSH_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[4][8];
-#define PHASE_MARK(idx)                                                                   \
-  if (blockIdx.x == 0 && lane == 0) {                                                     \
-    const unsigned long long now_ = __builtin_readcyclecounter();                        \
-    g_phase_cycles[w][idx] += now_ - t_mark;                                              \
-    t_mark = now_;                                                                        \
-  }
-#else
-#define PHASE_MARK(idx)
-#endif
-
-// The same entry point with the substep split across the four waves of the workgroup (dyn4.h).  Wave 0 also owns
-// the RCS bookkeeping (wrappers, callback scheduler, observation); waves 1-3 only run their physics roles.
-template <class T, int kLanes>
-__global__ void __launch_bounds__(256) k_run4(Params P, RunOp op) {
-  using ST = Stage4<T, kLanes>;
-  __shared__ DevModel lm;
-  __shared__ double lds[ST::COUNT * kLanes];
-  {
-    constexpr int kWords = sizeof(DevModel) / 8;
-    const double* src = reinterpret_cast<const double*>(P.model);
-    double* dst = reinterpret_cast<double*>(&lm);
-#pragma unroll
-    for (int it = 0; it < (kWords + 255) / 256; ++it) {
-      const int k = it * 256 + threadIdx.x;
-      if (k < kWords) dst[k] = src[k];
-    }
-    __syncthreads();
-  }
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int e = blockIdx.x * kLanes + lane;
-  const bool live = lane < kLanes && e < P.n && !(op.mask && !op.mask[lane < kLanes && e < P.n ? e : 0]);
-  const DevModel& m = lm;
-  const ST st{lds + (lane < kLanes ? lane : 0)};
-  EnvRegs<T, ST> r;  // meaningful in wave 0 only
-  r.st = st;
-  r.time = 0; r.last_cmd_width = 0; r.last_width = 0; r.flags = 0; r.conv_steps = 0;
-  bool have_frames = false;
-  int nsteps = op.do_reset ? 1 : op.nsteps;
-  const bool until_conv = nsteps < 0;
-  int budget = 0;
-  bool converged = false;
-  if (w == 0 && live) {
-    load_env<T, ST>(P, e, r);
-    env_prologue<T, ST>(P, op, m, e, r);
-    budget = nsteps;
-    if (until_conv) {
-      r.conv_steps = 0;
-      r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
-      const int cap = P.sim.max_convergence_steps;
-      budget = cap == -1 ? 0x7fffffff : cap;
-    }
-    st.active() = budget > 0 ? 1.0 : 0.0;
-  }
-  int go = __syncthreads_or(w == 0 && live && budget > 0);
-#ifdef RCSH_PHASE_TIMING
-  unsigned long long t_mark = __builtin_readcyclecounter();
-#endif
-  while (go) {
-    const bool stepping = live && st.active() != 0.0;
-    if (w == 0 && stepping) plain_callbacks<T, ST>(P, r);
-    if (live) {
-      if (w == 0) phaseA_inertia<T, kLanes, 0>(m, st, stepping);
-      else if (w == 1) phaseA_inertia<T, kLanes, 1>(m, st, stepping);
-      else if (w == 2) phaseA_inertia<T, kLanes, 2>(m, st, stepping);
-      else phaseA_motion<T, kLanes>(m, st, stepping);
-    }
-    PHASE_MARK(0)
-    __syncthreads();
-    PHASE_MARK(7)
-    if (live) {
-      if (w == 0) phaseB_wrench<T, kLanes, 0>(st);
-      else if (w == 1) phaseB_wrench<T, kLanes, 1>(st);
-      else if (w == 2) phaseB_wrench<T, kLanes, 2>(st);
-      else phaseB_wrench<T, kLanes, 3>(st);
-    }
-    PHASE_MARK(1)
-    __syncthreads();
-    PHASE_MARK(7)
-    if (live) {
-      if (w == 0) phaseC_rows<T, kLanes, 0>(m, st);
-      else if (w == 1) phaseC_rows<T, kLanes, 1>(m, st);
-      else if (w == 2) phaseC_rows<T, kLanes, 2>(m, st);
-      else phaseC_rows<T, kLanes, 3>(m, st);
-    }
-    PHASE_MARK(2)
-    __syncthreads();
-    PHASE_MARK(7)
-    double A[T::NTRI];
-    Rows<T, kLanes> rows;
-    if (live) {
-      if (w == 3) phaseD_actuation<T, kLanes>(m, st);
-      else if (w == 0) phaseD_implicit_factor<T, kLanes>(m, st, A);
-      else if (w == 1) {
-        phaseD_rows<T, kLanes>(m, st, rows);
-        if (rows.has_eq || rows.limrows) build_factor_H<T, kLanes>(st, rows, rows.limrows, A);
-      }
-    }
-    PHASE_MARK(3)
-    __syncthreads();
-    PHASE_MARK(7)
-    if (live && w == 1) phaseD_constraint_solve<T, kLanes>(st, rows, A);
-    PHASE_MARK(4)
-    __syncthreads();
-    PHASE_MARK(7)
-    bool more = false;
-    if (w == 0 && live) {
-      phaseD_integrate<T, kLanes>(m, st, A);
-      if (stepping) {
-        r.time += m.timestep;
-        have_frames = true;
-        --budget;
-        if (until_conv) {
-          r.conv_steps++;
-          converged = condition_callbacks<T, ST>(m, P, r);
-        }
-      }
-      more = stepping && budget > 0 && !converged;
-      st.active() = more ? 1.0 : 0.0;
-    }
-    PHASE_MARK(5)
-    go = __syncthreads_or(more);
-    PHASE_MARK(7)
-  }
-  if (w == 0 && live) {
-    if (until_conv) set_flag(r.flags, kConverged, converged);
-    env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
-  }
 }
 
 // The same entry point with one TEAM of 16 lanes per environment (dyn_team.h): four environments per wavefront,
@@ -678,7 +547,13 @@ __global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
   __shared__ DevModel lm;
+  __shared__ CollTable lc;  // indexed per lane (link) below, which a kernel argument cannot be
   __shared__ __attribute__((aligned(16))) double lds[ST::COUNT * kTeams];
+  {
+    static_assert(sizeof(CollTable) % 8 == 0, "copied in 8-byte words");
+    for (int k = threadIdx.x; k < (int)(sizeof(CollTable) / 8); k += 64)
+      reinterpret_cast<double*>(&lc)[k] = reinterpret_cast<const double*>(&P.coll)[k];
+  }
   {
     constexpr int kWords = sizeof(DevModel) / 8;
     const double* src = reinterpret_cast<const double*>(P.model);
@@ -715,35 +590,68 @@ __global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
       const int cap = P.sim.max_convergence_steps;
       budget = cap == -1 ? 0x7fffffff : cap;
     }
-    st.active() = budget > 0 ? 1.0 : 0.0;
   }
-  int go = __syncthreads_or(leader && budget > 0);
-  while (go) {
-    const bool stepping = st.active() != 0.0;
-    if (leader && stepping) plain_callbacks<T, ST>(P, r);
+  // Which teams still step is decided by their leaders and spread with a ballot (no LDS flag, no barrier); the
+  // two plain callbacks fire every `period` of simulated time, so the leader only looks at them when the earlier
+  // of their two timestamps is due.
+  bool more = leader && budget > 0;
+  double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
+  const bool has_cb = P.robot.present && P.robot.conv_registered;
+  uint64_t going = __ballot(more);
+  TEAM_MARK(11)
+  while (going) {
+    const bool stepping = (going >> (threadIdx.x & 48)) & 1u;
+    if (leader && stepping && has_cb && r.time - cb_due > P.robot.period) {
+      plain_callbacks<T, ST>(P, r);
+      cb_due = fmin(r.cb(0), r.cb(1));
+    }
     __syncthreads();
-    team_substep<T>(m, st, t, stepping);
-    __syncthreads();
-    bool more = false;
-    if (leader) {
-      if (stepping) {
-        r.time += m.timestep;
-        have_frames = true;
-        --budget;
-        if (until_conv) {
-          r.conv_steps++;
-          converged = condition_callbacks<T, ST>(m, P, r);
+    TEAM_MARK(8)
+    // plane contacts of the position stage: every lane tests its own link with the frame the substep just built,
+    // in the substeps after which a collision callback is due (condition_callbacks, same comparisons)
+    bool due = false;
+    if (leader && stepping && until_conv && lc.has_plane) {
+      const double t_next = r.time + m.timestep;
+      due = (P.robot.present && t_next - r.cb(2) > P.robot.period) || (T::GRIP && P.grip.present && t_next - r.cb(3) > P.grip.period);
+    }
+    const bool want_contacts = team_ballot(due) != 0;
+    uint32_t hit = 0;
+    team_substep<T>(m, st, t, stepping, [&](const double* R, const double* p) {
+      if (!want_contacts) return;
+      const double* nrm = lc.plane_n;
+      const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
+                           R[2] * nrm[0] + R[5] * nrm[1] + R[8] * nrm[2]};
+      const double b = dot3(nrm, p) - lc.plane_d;
+      const int tl = t < T::NL ? t : T::NL - 1;
+      const double* sph = lc.link_sphere[tl];
+      uint32_t mine = 0;
+      if (t < T::NL && b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < 0) {
+        for (int k = lc.link_adr[tl]; k < lc.link_adr[tl + 1]; ++k) {
+          const double* v = lc.xyzr + 4 * (size_t)k;
+          if (b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3] < 0) mine |= lc.cls[k];
         }
       }
-      more = stepping && budget > 0 && !converged;
-      st.active() = more ? 1.0 : 0.0;
+      hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
+    });
+    __syncthreads();
+    if (leader && stepping) {
+      r.time += m.timestep;
+      have_frames = true;
+      --budget;
+      if (until_conv) {
+        r.conv_steps++;
+        converged = condition_callbacks<T, ST>(m, P, r, [&] { return hit; });
+      }
+      more = budget > 0 && !converged;
     }
-    go = __syncthreads_or(more);
+    going = __ballot(more);
+    TEAM_MARK(9)
   }
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
     env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
   }
+  TEAM_MARK(10)
 }
 
 // ---- small elementwise kernels behind the 1:1 SimRobot / SimGripper / mjData accessors

@@ -102,6 +102,10 @@ class Sim:
         """Enqueue all further work on a caller-owned HIP stream (None: back to the handle's own stream)."""
         _lib.check(self._L.rcsh_sim_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def set_kernel(self, variant: str) -> None:
+        """Pin the kernel variant: "auto" (by batch size), "team" (16 lanes per environment) or "lane" (one)."""
+        _lib.check(self._L.rcsh_sim_set_kernel(self._h, {"auto": 0, "team": 1, "lane": 2}[variant]))
+
     def synchronize(self) -> None:
         _lib.check(self._L.rcsh_sim_synchronize(self._h))
 

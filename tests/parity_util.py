@@ -30,6 +30,10 @@ def synthetic_actions(n_envs: int, n_steps: int, seed: int = 0, dof: int = 7):
     return joints, grip
 
 
+# kernel variant every make_vec_env() pins (the GPU tests run each of them, see test_gpu_parity.py)
+KERNEL = "auto"
+
+
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
                  max_relative_movement=None):
     from rcs_amd import sim
@@ -39,11 +43,13 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    return SimEnvCreator()(
+    venv = SimEnvCreator()(
         mode, default_sim_robot_cfg("fr3_empty_world"), gripper_cfg=default_sim_gripper_cfg() if gripper else None,
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None, relative_to=RelativeTo.LAST_STEP,
         n_envs=n_envs, device=device,
     )
+    venv.sim.set_kernel(KERNEL)
+    return venv
 
 
 def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, mode: str = "joints",

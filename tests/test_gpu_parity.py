@@ -22,6 +22,16 @@ TOL = 1e-6
 FINGER_TOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["team", "lane"])
+def kernel(request):
+    """Every test runs once per kernel variant (rcsh_sim_set_kernel): 16 lanes per environment / one lane."""
+    import parity_util
+
+    parity_util.KERNEL = request.param
+    yield request.param
+    parity_util.KERNEL = "auto"
+
+
 @pytest.mark.parametrize("gripper", [True, False])
 def test_joints_async_17_substeps(gripper):
     rep = run_joint_rollout_parity(n_envs=96, n_steps=6, async_control=True, seed=1, gripper=gripper)

@@ -1,0 +1,27 @@
+"""dev tool: per-phase cycle counts of the team kernel (library built with -DRCSH_PHASE_TIMING)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "robot-control-stack_amd"), os.path.join(ROOT, "tests")]
+os.environ["RCSH_KERNEL"] = "team"
+import rcs_amd._lib as lib
+lib.LIB_PATH = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "librcs_hip_timing.so")
+import numpy as np
+from parity_util import make_vec_env, synthetic_actions
+n, T = 4096, 20
+env = make_vec_env(n, True)
+j, g = synthetic_actions(64, T, 0)
+j = np.tile(j, (1, n // 64, 1)); g = np.tile(g, (1, n // 64))
+env.reset()
+out = (C.c_ulonglong * 16)()
+env._L.rcsh_debug_team_cycles(out)
+base = np.array(out[:], dtype=np.float64)
+for t in range(T): env.step({"joints": j[t], "gripper": g[t]})
+env._L.rcsh_debug_team_cycles(out)
+a = (np.array(out[:], dtype=np.float64) - base)
+names = ["local frame", "frame scan", "axis+vel+acc scans", "inertia+wrench+leaf scans", "M row (S exchange)", "actuation+rows", "factor slot",
+         "implicit solve+integrate", "callbacks+sync", "leader post + loop sync", "epilogue", "prologue"]
+sub = T * 17
+print("team kernel, block 0 lane 0, cycles per substep:")
+for i in range(10): print(f"  {names[i]:28s} {a[i] / sub:9.0f}")
+print(f"  {'substep total':28s} {a[:10].sum() / sub:9.0f}")
+print(f"per launch: prologue {a[11] / T:.0f}  epilogue {a[10] / T:.0f}  substeps {a[:10].sum() / T:.0f}")
