@@ -150,7 +150,7 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
     if (team)
-      hipLaunchKernelGGL((k_run_team<T>), dim3((s->n + 3) / 4), dim3(64), 0, s->stream, P, op);
+      hipLaunchKernelGGL((k_run_team<T>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     else
       hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);
     err = hipGetLastError();

@@ -567,7 +567,11 @@ __global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
     __syncthreads();
   }
   const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
-  const int e = blockIdx.x * kTeams + team;
+  // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  Give
+  // every XCD one contiguous range of environments, so a 128-byte line of a state field ([field][env], 16
+  // environments) is fetched into one L2 instead of four.  The grid is rounded up to a multiple of 8.
+  const int per_xcd = gridDim.x / 8;
+  const int e = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * kTeams + team;
   const bool live = e < P.n && !(op.mask && !op.mask[e < P.n ? e : 0]);
   const bool leader = t == 0 && live;
   const DevModel& m = lm;
