@@ -96,6 +96,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=N_ENVS, help="environments per GPU (headline: 4096)")
     ap.add_argument("--mode", choices=["async", "convergence"], default="async")
+    ap.add_argument("--control", choices=["joints", "cartesian"], default="joints",
+                    help="cartesian = BASELINE configs[2]: relative TRPY actions -> CLIK -> joint targets (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
     args = ap.parse_args()
@@ -126,14 +128,24 @@ def main() -> None:
 
     n = args.envs
     T = args.steps + args.warmup
-    env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank)
+    if args.control == "cartesian":
+        from rcs_amd.envs import ControlMode
+
+        env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank,
+                           control_mode=ControlMode.CARTESIAN_TRPY, max_relative_movement=(0.2, float(np.deg2rad(45))))
+    else:
+        env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank)
     env.sim.set_stream(torch.cuda.current_stream().cuda_stream)
     L, h = env._L, env.sim._h
 
     # synthetic actions, resident in HBM (joints ~ U(+-5 deg)^7 f64, gripper ~ U(0,1) f32)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
-    joints = (torch.rand((T, n, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV
+    if args.control == "cartesian":  # xyz ~ U(+-0.05 m)^3, rpy ~ U(+-0.1 rad)^3
+        scale = torch.tensor([0.05, 0.05, 0.05, 0.1, 0.1, 0.1], device="cuda", dtype=torch.float64)
+        joints = (torch.rand((T, n, 6), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * scale
+    else:
+        joints = (torch.rand((T, n, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV
     grip = torch.rand((T, n), generator=gen, device="cuda", dtype=torch.float32)
     ow = env.obs_width
     obs = torch.zeros((n, ow), device="cuda", dtype=torch.float64)
@@ -206,7 +218,9 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off",
+                "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off"
+                             if args.control == "joints" else
+                             f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"),
                 "mode": "async_control 30Hz (17 substeps/env-step)" if args.mode == "async" else "step_until_convergence (cap 500)",
                 "envs_per_gpu": n,
                 "substeps_per_env_step": mean_sub,

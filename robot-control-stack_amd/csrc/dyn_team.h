@@ -274,6 +274,45 @@ struct KinK {
     jtype = m.jtype[tl];
   }
 };
+// frame of a link in its parent link's frame at joint position q (kinematic part of mj_kinematics for one joint)
+RCSH_D void link_local_frame(const KinK& kk, double q, double* R, double* p) {
+  const double dq = q - kk.qpos0;
+  const double* r0 = kk.rot0;
+  const double* p0 = kk.pos0;
+  if (kk.axis_z) {
+    double s, c;
+    fast_sincos(dq, &s, &c);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      R[3 * r + 0] = c * r0[3 * r + 0] + s * r0[3 * r + 1];
+      R[3 * r + 1] = c * r0[3 * r + 1] - s * r0[3 * r + 0];
+      R[3 * r + 2] = r0[3 * r + 2];
+      p[r] = p0[r];
+    }
+  } else if (kk.jtype == kSlide) {
+    double ax[3];
+    mulmv(r0, kk.axis, ax);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = r0[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = p0[k] + ax[k] * dq;
+  } else {
+    double s, c;
+    fast_sincos(dq, &s, &c);
+    const double* a = kk.axis;
+    const double u = 1.0 - c;
+    const double Q[9] = {c + u * a[0] * a[0],        u * a[0] * a[1] - s * a[2], u * a[0] * a[2] + s * a[1],
+                         u * a[0] * a[1] + s * a[2], c + u * a[1] * a[1],        u * a[1] * a[2] - s * a[0],
+                         u * a[0] * a[2] - s * a[1], u * a[1] * a[2] + s * a[0], c + u * a[2] * a[2]};
+    double anchor[3], rj[3];
+    mulmv(r0, kk.jpos, anchor);
+    mulmm(r0, Q, R);
+    mulmv(R, kk.jpos, rj);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = p0[k] + anchor[k] - rj[k];
+  }
+}
+
 struct InertK {
   double mass, gcm, com[3], J[6];
   int32_t gc_same_com;
@@ -330,43 +369,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
 
   // ---- local frame of the link in its parent link's frame
   double R[9], p[3];
-  {
-    const double dq = q - kk.qpos0;
-    const double* r0 = kk.rot0;
-    const double* p0 = kk.pos0;
-    if (kk.axis_z) {
-      double s, c;
-      fast_sincos(dq, &s, &c);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        R[3 * r + 0] = c * r0[3 * r + 0] + s * r0[3 * r + 1];
-        R[3 * r + 1] = c * r0[3 * r + 1] - s * r0[3 * r + 0];
-        R[3 * r + 2] = r0[3 * r + 2];
-        p[r] = p0[r];
-      }
-    } else if (is_slide) {
-      double ax[3];
-      mulmv(r0, kk.axis, ax);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) R[k] = r0[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) p[k] = p0[k] + ax[k] * dq;
-    } else {
-      double s, c;
-      fast_sincos(dq, &s, &c);
-      const double* a = kk.axis;
-      const double u = 1.0 - c;
-      const double Q[9] = {c + u * a[0] * a[0],        u * a[0] * a[1] - s * a[2], u * a[0] * a[2] + s * a[1],
-                           u * a[0] * a[1] + s * a[2], c + u * a[1] * a[1],        u * a[1] * a[2] - s * a[0],
-                           u * a[0] * a[2] - s * a[1], u * a[1] * a[2] + s * a[0], c + u * a[2] * a[2]};
-      double anchor[3], rj[3];
-      mulmv(r0, kk.jpos, anchor);
-      mulmm(r0, Q, R);
-      mulmv(R, kk.jpos, rj);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) p[k] = p0[k] + anchor[k] - rj[k];
-    }
-  }
+  link_local_frame(kk, q, R, p);
   TEAM_MARK(0)
   InertK ik;
   ik.load(m, tl);

@@ -533,7 +533,10 @@ int launch_cartesian(rcsh_sim* s, const CartOp& op) {
   hipError_t err = hipSuccess;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    hipLaunchKernelGGL(k_cartesian<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, op);
+    if (s->kernel ? s->kernel == RCSH_KERNEL_TEAM : s->n < kTeamKernelMaxEnvs)
+      hipLaunchKernelGGL(k_cartesian_team<T>, dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+    else
+      hipLaunchKernelGGL(k_cartesian<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, op);
     err = hipGetLastError();
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");

@@ -683,6 +683,7 @@ __global__ void k_flags_to_bytes(const uint32_t* flags, int n, uint32_t bit, uin
 // Cartesian control path (reference python/rcs/envs/base.py:273-286,490-565 and src/sim/SimRobot.cpp:145-155).
 // These kernels work directly on the SoA state: one thread per environment, no staging, IK in registers.
 #include "ik.h"
+#include "ik_team.h"
 
 namespace rcsh {
 
@@ -706,20 +707,14 @@ __device__ __forceinline__ void store_pose7(double* S, int n, int e, int field0,
   S[(field0 + 6) * n + e] = p.q[3];
 }
 
+// Everything of a Cartesian env-step that precedes the IK (wrappers' action(), RobotEnv.step bookkeeping): returns
+// whether a new target is commanded and, if so, the TCP target in robot coordinates.  env_layer 0: the bare
+// SimRobot::set_cartesian_position target.
 template <class T>
-__global__ void __launch_bounds__(64) k_cartesian(Params P, CartOp op) {
+__device__ __forceinline__ bool cart_prepare(const Params& P, const CartOp& op, const DevModel& m, int e, uint32_t& flags, Pose& target) {
   using L = Lay<T>;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= P.n) return;
-  if (op.mask && !op.mask[e]) return;
-  const DevModel& m = *P.model;
   const int n = P.n;
   double* S = P.S;
-  uint32_t flags = P.flags[e];
-  Pose tcp;
-  tcp.t[0] = P.robot.tcp[0]; tcp.t[1] = P.robot.tcp[1]; tcp.t[2] = P.robot.tcp[2];
-  tcp.q[0] = P.robot.tcp[3]; tcp.q[1] = P.robot.tcp[4]; tcp.q[2] = P.robot.tcp[5]; tcp.q[3] = P.robot.tcp[6];
-  Pose target;
   bool command = true;
   if (!op.env_layer) {
     const double* a = op.action + (size_t)e * 7;
@@ -795,6 +790,24 @@ __global__ void __launch_bounds__(64) k_cartesian(Params P, CartOp op) {
     flags |= kHasPrevAction;
     if (trpy) pose_from_rpy(a + 3, a, target); else pose_from_quat(a + 3, a, target);
   }
+  return command;
+}
+
+template <class T>
+__global__ void __launch_bounds__(64) k_cartesian(Params P, CartOp op) {
+  using L = Lay<T>;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= P.n) return;
+  if (op.mask && !op.mask[e]) return;
+  const DevModel& m = *P.model;
+  const int n = P.n;
+  double* S = P.S;
+  uint32_t flags = P.flags[e];
+  Pose tcp;
+  tcp.t[0] = P.robot.tcp[0]; tcp.t[1] = P.robot.tcp[1]; tcp.t[2] = P.robot.tcp[2];
+  tcp.q[0] = P.robot.tcp[3]; tcp.q[1] = P.robot.tcp[4]; tcp.q[2] = P.robot.tcp[5]; tcp.q[3] = P.robot.tcp[6];
+  Pose target;
+  const bool command = cart_prepare<T>(P, op, m, e, flags, target);
   if (command) {
     // SimRobot::set_cartesian_position (SimRobot.cpp:145-155)
     double q[T::NARM];
@@ -816,6 +829,70 @@ __global__ void __launch_bounds__(64) k_cartesian(Params P, CartOp op) {
     }
   }
   P.flags[e] = flags;
+}
+
+// The same launch with a team of 16 lanes per environment (ik_team.h): the leader lane runs the wrapper logic, the
+// team the CLIK, lane t commits joint t.
+template <class T>
+__global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
+  using L = Lay<T>;
+  constexpr int kTeams = 64 / kTeamLanes;
+  __shared__ DevModel lm;
+  __shared__ IkTeamBlock<T> blocks[kTeams];
+  __shared__ double desired[kTeams][12];
+  {
+    constexpr int kWords = sizeof(DevModel) / 8;
+    const double* src = reinterpret_cast<const double*>(P.model);
+    double* dst = reinterpret_cast<double*>(&lm);
+#pragma unroll
+    for (int it = 0; it < (kWords + 63) / 64; ++it) {
+      const int k = it * 64 + threadIdx.x;
+      if (k < kWords) dst[k] = src[k];
+    }
+    __syncthreads();
+  }
+  const DevModel& m = lm;
+  const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
+  const int per_xcd = gridDim.x / 8;  // XCD-contiguous environment ranges, as in k_run_team
+  const int e = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * kTeams + team;
+  const bool live = e < P.n && !(op.mask && !op.mask[e < P.n ? e : 0]);
+  const bool leader = t == 0 && live;
+  const int n = P.n;
+  double* S = P.S;
+  uint32_t flags = 0;
+  bool command = false;
+  if (leader) {
+    flags = P.flags[e];
+    Pose tcp, target;
+    tcp.t[0] = P.robot.tcp[0]; tcp.t[1] = P.robot.tcp[1]; tcp.t[2] = P.robot.tcp[2];
+    tcp.q[0] = P.robot.tcp[3]; tcp.q[1] = P.robot.tcp[4]; tcp.q[2] = P.robot.tcp[5]; tcp.q[3] = P.robot.tcp[6];
+    command = cart_prepare<T>(P, op, m, e, flags, target);
+    if (command) clik_desired(m, target, tcp, desired[team], desired[team] + 9);
+  }
+  const bool run = team_ballot(command) != 0;
+  __syncthreads();
+  double Rd[9], td[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rd[k] = desired[team][k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) td[k] = desired[team][9 + k];
+  const bool joint = run && t < T::NARM;
+  const double q_now = joint ? S[(L::QPOS + t) * n + e] : 0.0;
+  double q = q_now;
+  int iters = 0;
+  const bool ok = clik_team<T>(m, blocks[team], t, run, Rd, td, q, &iters);
+  if (joint && ok) {  // SimRobot::set_joint_position(joint_vals), SimRobot.cpp:123-131,145-155
+    S[(L::TARGET + t) * n + e] = q;
+    S[(L::PREVQ + t) * n + e] = q_now;
+    S[(L::CTRL + t) * n + e] = q;
+  }
+  if (leader) {
+    if (command) {
+      if (ok) flags = (flags | kIkSuccess | kIsMoving) & ~kIsArrived;
+      else flags &= ~kIkSuccess;
+    }
+    P.flags[e] = flags;
+  }
 }
 
 // Kinematics.inverse / forward on caller-supplied configurations (reference src/rcs/Kinematics.cpp:28-82)
