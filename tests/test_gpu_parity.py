@@ -139,3 +139,43 @@ def test_collision_flags_match_oracle():
         assert bool(trunc[e]) == bool(otr) and bool(info["collision"][e]) == bool(oi["collision"])
         assert int(info["substeps"][e]) == int(o.sim.s.convergence_steps)
     venv.close()
+
+
+@pytest.mark.parametrize("n_envs", [1, 5, 33])
+def test_ragged_batch_sizes(n_envs):
+    """Batches that do not fill a wavefront / a team group / the 8-workgroup XCD rounding."""
+    rep = run_joint_rollout_parity(n_envs=n_envs, n_steps=3, async_control=True, seed=21, gripper=True)
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_finger"] < FINGER_TOL and rep["flag_mismatches"] == 0, rep
+
+
+def test_headline_batch_is_position_independent():
+    """BASELINE configs[1] size (4096 environments), size-independent property: an environment's trajectory depends
+    on its own inputs only.  64 distinct action streams are tiled 64x over the batch; every copy must equal the first
+    BIT FOR BIT wherever it sits (lane, team, wavefront, XCD), a masked reset must leave the unmasked environments
+    untouched, and the first 64 environments are checked against the oracle."""
+    from parity_util import make_oracle_envs, make_vec_env, synthetic_actions
+
+    n, base, steps = 4096, 64, 4
+    joints, grip = synthetic_actions(base, steps, 5)
+    venv = make_vec_env(n, True)
+    oenvs = make_oracle_envs(base, True)
+    venv.reset()
+    [o.reset() for o in oenvs]
+    for t in range(steps):
+        obs, _, _, _, info = venv.step({"joints": np.tile(joints[t], (n // base, 1)), "gripper": np.tile(grip[t], n // base)})
+        q, v = venv.sim.qpos, venv.sim.qvel
+        for arr in (q, v, obs["tquat"], obs["joints"], info["gripper_width"]):
+            a = np.asarray(arr).reshape(n // base, base, -1)
+            assert np.array_equal(a, np.broadcast_to(a[0], a.shape)), "replicas diverged"
+        for e, o in enumerate(oenvs):
+            o.step({"joints": joints[t, e], "gripper": grip[t, e]})
+            assert np.abs(q[e][:7] - o.sim.qpos[:7]).max() < TOL and np.abs(q[e][7:] - o.sim.qpos[7:]).max() < FINGER_TOL
+    # masked reset: only every third environment restarts
+    before_q = venv.sim.qpos.copy()
+    mask = (np.arange(n) % 3 == 0)
+    venv.reset(mask=mask)
+    after_q = venv.sim.qpos
+    assert np.array_equal(after_q[~mask], before_q[~mask])
+    assert np.array_equal(after_q[mask], np.broadcast_to(after_q[0], after_q[mask].shape))
+    assert not np.array_equal(after_q[0], before_q[0])
+    venv.close()
