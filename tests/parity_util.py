@@ -190,6 +190,7 @@ def run_physics_parity_mid_stroke(n_envs=64, n_calls=6, k=17, seed=0):
 
     cfg = default_sim_robot_cfg("fr3_empty_world")
     simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    simu.set_kernel(KERNEL)
     robot = S.SimRobot(simu, None, cfg)
     grip = S.SimGripper(simu, default_sim_gripper_cfg())
     cm = compile_mjcf(SCENE)
@@ -220,5 +221,49 @@ def run_physics_parity_mid_stroke(n_envs=64, n_calls=6, k=17, seed=0):
             p = o.get_cartesian_position()
             rep["max_abs_cart"] = max(rep["max_abs_cart"], float(np.abs(cart[e] - np.concatenate([p.translation(), p.rotation_q()])).max()))
             rep["flag_mismatches"] += int(bool(st.is_moving[e]) != bool(o.s.is_moving)) + int(bool(st.is_arrived[e]) != bool(o.s.is_arrived))
+    simu.close()
+    return rep
+
+
+def run_physics_parity_at_joint_limits(n_envs=32, n_calls=8, k=17, seed=0, n_over=6):
+    """Sim.step(k) with `n_over` arm joints started BEYOND their range (penetrating limit rows, all active at once) and
+    commanded to the range end: exercises the many-row path of the constraint solve (team kernel: more than three limit
+    rows -> Newton with line search instead of the active-set vote).  Fingers mid-stroke, as in the mid-stroke test."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    simu.set_kernel(KERNEL)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    hi = np.asarray(cm.jnt_range)[:7, 1]
+    q0 = np.tile(np.concatenate([FR3_Q_HOME, [0.02, 0.02]]), (n_envs, 1))
+    q0[:, :n_over] = hi[:n_over] + rng.uniform(0.002, 0.02, size=(n_envs, n_over))
+    simu.set_qpos(q0)
+    grip.set_normalized_width(np.full(n_envs, 0.5))
+    for e, o in enumerate(osims):
+        for i in range(9):
+            o.s.d.qpos[i] = q0[e, i]
+        o.gripper_set_normalized_width(0.5)
+    rep = {"max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_rows": 0}
+    tgt = np.tile(np.concatenate([hi[:n_over], FR3_Q_HOME[n_over:]]), (n_envs, 1))
+    for _ in range(n_calls):
+        robot.set_joint_position(tgt)
+        simu.step(k)
+        q, v = simu.qpos, simu.qvel
+        for e, o in enumerate(osims):
+            rep["max_rows"] = max(rep["max_rows"], int((np.asarray(o.qpos)[:7] > hi).sum()))
+            o.set_joint_position(tgt[e])
+            o.step(k)
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - o.qpos).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - o.qvel).max()))
     simu.close()
     return rep

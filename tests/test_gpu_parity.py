@@ -48,6 +48,16 @@ def test_physics_all_joints_round_off():
     assert rep["flag_mismatches"] == 0, rep
 
 
+@pytest.mark.parametrize("n_over", [2, 6])
+def test_physics_many_limit_rows(n_over):
+    """2 penetrating arm limit rows: the team kernel's active-set vote; 6: its Newton + line-search path."""
+    from parity_util import run_physics_parity_at_joint_limits
+
+    rep = run_physics_parity_at_joint_limits(n_envs=32, n_calls=8, k=17, seed=4, n_over=n_over)
+    assert rep["max_rows"] >= n_over, rep
+    assert rep["max_abs_qpos"] < 1e-9 and rep["max_abs_qvel"] < 1e-7, rep
+
+
 def test_joints_until_convergence():
     rep = run_joint_rollout_parity(n_envs=40, n_steps=3, async_control=False, seed=7, gripper=True)
     assert rep["max_abs_qpos"] < TOL and rep["max_abs_obs"] < TOL and rep["max_abs_finger"] < FINGER_TOL, rep
