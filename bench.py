@@ -99,6 +99,7 @@ def main() -> None:
     ap.add_argument("--control", choices=["joints", "cartesian"], default="joints",
                     help="cartesian = BASELINE configs[2]: relative TRPY actions -> CLIK -> joint targets (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -119,10 +120,15 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the batched backend has no CPU execution path")
+    if args.dist_backend != "nccl":
+        local_rank %= torch.cuda.device_count()  # functional check only: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from parity_util import MAX_JOINT_MOV, make_vec_env
 
@@ -152,14 +158,15 @@ def main() -> None:
     info = torch.zeros((n, 8), device="cuda", dtype=torch.uint8)
     gw = torch.zeros((n,), device="cuda", dtype=torch.float64)
     sub = torch.zeros((n,), device="cuda", dtype=torch.int32)
-    obs_all = torch.zeros((world * n, ow), device="cuda", dtype=torch.float64) if world > 1 else None
+    from rcs_amd.envs.sharding import ObservationExchange
 
-    from rcs_amd.envs.sharding import gather_observations
+    exchange = ObservationExchange(n, ow, torch.float64, "cuda") if world > 1 else None
 
     def one_step(t: int) -> None:
-        env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), obs.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
-        if world > 1:
-            gather_observations(obs, obs_all)
+        o = exchange.local(t) if exchange else obs
+        env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
+        if exchange:
+            exchange.post(t)  # overlaps with the next env-step
 
     env.reset_dev(obs.data_ptr(), info.data_ptr(), gw.data_ptr())
     for t in range(args.warmup):
@@ -176,6 +183,9 @@ def main() -> None:
         one_step(t)
         if args.mode == "convergence":
             substeps_total += 0  # per-step counts stay on the device; read once after the timed region
+    if exchange:
+        exchange.drain()
+        obs = exchange.gathered(T - 1)[rank * n:(rank + 1) * n]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -225,7 +235,7 @@ def main() -> None:
                 "envs_per_gpu": n,
                 "substeps_per_env_step": mean_sub,
                 "physics_substeps_per_s": value * mean_sub,
-                "exchange": "RCCL all_gather_into_tensor of obs [N,21] f64 per step" if world > 1 else "none (1 GPU)",
+                "exchange": "RCCL all_gather_into_tensor of obs [N,21] f64 per step, double-buffered, overlapped with the next env-step" if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
             },
             "roofline": {

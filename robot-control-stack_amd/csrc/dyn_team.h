@@ -93,14 +93,15 @@ RCSH_D void team_sync() { __syncthreads(); }
 // link": lanes 0..7 scan as a chain, lane 8 (second finger) is kept out of the chain rounds and receives its
 // parent (two lanes up) in a round of its own.
 
-// inclusive sum over a link's ancestors and itself
+// inclusive sum over a link's ancestors and itself.  `chain` is 1.0 on lanes 0..7 and `second` 1.0 on lane 8 (else
+// 0.0): the shifts run unmasked with zero fill (no destination to initialise) and the masks ride in the FMA.
 template <class T>
-RCSH_D double scan_from_root(double x) {
+RCSH_D double scan_from_root(double x, double chain, double second) {
   if (T::GRIP) {
-    x += row_up_banks<1, 0x3>(x);
-    x += row_up_banks<2, 0x3>(x);
-    x += row_up_banks<4, 0x3>(x);
-    x += row_up_banks<2, 0x4>(x);
+    x = fma(row_up<1>(x), chain, x);
+    x = fma(row_up<2>(x), chain, x);
+    x = fma(row_up<4>(x), chain, x);
+    x = fma(row_up<2>(x), second, x);
   } else {
     x += row_up<1>(x);
     x += row_up<2>(x);
@@ -405,13 +406,14 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     for (int k = 0; k < 6; ++k) st.S(tl, k) = S[k];
   }
   double vel[6], acc[6];
+  const double chain = t < 8 ? 1.0 : 0.0, second = t == 8 ? 1.0 : 0.0;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) vel[k] = scan_from_root<T>(S[k] * qd);
+  for (int k = 0; k < 6; ++k) vel[k] = scan_from_root<T>(S[k] * qd, chain, second);
   {
     double sd[6];
     cross_motion(vel, S, sd);  // S x S = 0: the link's own joint velocity does not contribute
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k] = scan_from_root<T>(sd[k] * qd);
+    for (int k = 0; k < 6; ++k) acc[k] = scan_from_root<T>(sd[k] * qd, chain, second);
     acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
   }
   TEAM_MARK(2)

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from rcs_amd.envs.sharding import gather_observations, shard_range
+from rcs_amd.envs.sharding import ObservationExchange, gather_observations, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -37,6 +37,18 @@ def _worker(rank, world, port, n_total, width, steps, out):
         obs_all = gather_observations(obs_local, obs_all)
         expect = torch.arange(n_total, dtype=torch.float64).unsqueeze(1) * 100.0 + torch.arange(width, dtype=torch.float64).unsqueeze(0) + 0.001 * t
         ok = ok and bool(torch.equal(obs_all, expect))
+    # the overlapped form bench.py uses: double-buffered, gather of step t retired when step t+2 needs the buffer
+    ex = ObservationExchange(b - a, width, torch.float64, "cpu")
+    ids = torch.arange(a, b, dtype=torch.float64).unsqueeze(1)
+    all_ids = torch.arange(n_total, dtype=torch.float64).unsqueeze(1)
+    cols = torch.arange(width, dtype=torch.float64).unsqueeze(0)
+    for t in range(steps + 2):
+        ex.local(t).copy_(ids * 100.0 + cols + 0.001 * t)
+        ex.post(t)
+        if t >= 1:
+            ok = ok and bool(torch.equal(ex.gathered(t - 1), all_ids * 100.0 + cols + 0.001 * (t - 1)))
+    ex.drain()
+    ok = ok and bool(torch.equal(ex.gathered(steps + 1), all_ids * 100.0 + cols + 0.001 * (steps + 1)))
     elapsed = torch.tensor([0.5 + rank], dtype=torch.float64)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     ok = ok and float(elapsed) == 0.5 + world - 1
