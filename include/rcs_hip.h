@@ -74,7 +74,7 @@ typedef struct rcsh_model_desc {
   const int32_t* jnt_actgravcomp;
   const double* dof_armature;     /* [njnt] */
   const double* dof_damping;      /* [njnt] */
-  const double* dof_frictionloss; /* [njnt] must be 0 in this revision */
+  const double* dof_frictionloss; /* [njnt] dry joint friction (soft row per dof, team kernel only) */
   const double* qpos0;            /* [njnt] */
   const int32_t* tendon_adr;      /* [ntendon] */
   const int32_t* tendon_num;      /* [ntendon] */
@@ -111,6 +111,8 @@ typedef struct rcsh_model_desc {
   const int32_t* geom_vertadr;       /* [ngeom] first row of mesh_vert */
   const int32_t* geom_vertnum;       /* [ngeom] 0: no vertex set (geom never reports contacts) */
   const double* mesh_vert;           /* [nmeshvert][3] convex-hull vertices, geom frame */
+  const double* dof_solref;          /* [njnt][2] solreffriction */
+  const double* dof_solimp;          /* [njnt][5] solimpfriction */
 } rcsh_model_desc;
 
 /* SimRobotConfig after name -> id lookup (reference src/sim/SimRobot.h:14-47, SimRobot.cpp:52-94). */

@@ -27,6 +27,16 @@ LAST_STEP, CONFIGURED_ORIGIN = "last_step", "configured_origin"
 FR3_Q_HOME = np.array([0.0, -np.pi / 4, 0.0, -3.0 * np.pi / 4, 0.0, np.pi / 2, np.pi / 4])  # Robot.h:29-31
 FR3_LOW = np.array([-2.3093, -1.5133, -2.4937, -2.7478, -2.4800, 0.8521, -2.6895])  # Robot.h:36-40
 FR3_HIGH = np.array([2.3093, 1.5133, 2.4937, -0.4461, 2.4800, 4.2094, 2.6895])
+# robot descriptions: names as the reference configures them, home pose and joint limits from robots_meta_config
+FR3 = dict(joints=[f"fr3_joint{i}_0" for i in range(1, 8)], actuators=[f"fr3_joint{i}_0" for i in range(1, 8)],
+           site="attachment_site_0", base="base_0", q_home=FR3_Q_HOME, low=FR3_LOW, high=FR3_HIGH,
+           gripper_joint="finger_joint1_0", gripper_actuator="actuator8_0")
+XARM7 = dict(  # examples/xarm7/xarm7_env_joint_control.py:41-64; include/rcs/Robot.h (XArm7 entry)
+    joints=[f"joint{i}" for i in range(1, 8)], actuators=[f"act{i}" for i in range(1, 8)], site="attachment_site", base="base",
+    q_home=np.array([0, -45.0 / 180.0 * np.pi, 0, 15.0 / 180.0 * np.pi, 0, -25.0 / 180.0 * np.pi, 0]),
+    low=np.array([-2 * np.pi, -2.094395, -2 * np.pi, -3.92699, -2 * np.pi, -np.pi, -2 * np.pi]),
+    high=np.array([2 * np.pi, 2.059488, 2 * np.pi, 0.191986, 2 * np.pi, 1.692969, 2 * np.pi]),
+    gripper_joint=None, gripper_actuator=None, arm_collision_geoms=[])
 TRPY_LOW = np.array([-0.855, -0.855, 0.0])  # base.py:31-38
 TRPY_HIGH = np.array([0.855, 0.855, 1.188])
 
@@ -34,12 +44,15 @@ TRPY_HIGH = np.array([0.855, 0.855, 1.188])
 class OracleEnv:
     def __init__(self, cm, control_mode=JOINTS, gripper=True, max_relative_movement=None, relative_to=LAST_STEP,
                  async_control=False, frequency=30, max_convergence_steps=500, tcp_offset: O.Pose | None = None,
-                 idx="0"):
-        arm = [f"fr3_joint{i}_{idx}" for i in range(1, 8)]  # SimRobot.h:23-30 + add_id
+                 robot: dict | None = None):
+        robot = FR3 if robot is None else robot  # SimRobot.h:23-30 + add_id("0")
+        gripper = gripper and robot["gripper_joint"] is not None
+        self.robot = robot
         self.sim = O.Sim(
-            cm, arm, arm, f"attachment_site_{idx}", f"base_{idx}", FR3_Q_HOME, tcp_offset,
-            gripper_joint=f"finger_joint1_{idx}" if gripper else None,
-            gripper_actuator=f"actuator8_{idx}" if gripper else None,
+            cm, robot["joints"], robot["actuators"], robot["site"], robot["base"], robot["q_home"], tcp_offset,
+            gripper_joint=robot["gripper_joint"] if gripper else None,
+            gripper_actuator=robot["gripper_actuator"] if gripper else None,
+            arm_collision_geoms=robot.get("arm_collision_geoms"),
         )
         self.sim.set_config(async_control=async_control, frequency=frequency, max_convergence_steps=max_convergence_steps)
         self.timestep = cm.timestep
@@ -106,7 +119,7 @@ class OracleEnv:
             else:
                 limited = np.clip(a - self._last_action, -self.max_mov, self.max_mov) + self._last_action
             self._last_action = limited
-            action["joints"] = np.clip(self._origin + limited, FR3_LOW, FR3_HIGH)
+            action["joints"] = np.clip(self._origin + limited, self.robot["low"], self.robot["high"])
             return action
         key = self.mode
         a = np.asarray(action[key], dtype=np.float64)

@@ -31,7 +31,7 @@ extern "C" {
 #define ORC_MAXTENDON 4
 #define ORC_MAXWRAP 8
 #define ORC_MAXSITE 8
-#define ORC_MAXEFC (ORC_MAXEQ + 2 * ORC_MAXV)
+#define ORC_MAXEFC (ORC_MAXEQ + 3 * ORC_MAXV)
 #define ORC_MAXARM 8
 #define ORC_MAXGEOM 32
 #define ORC_MAXCON 32
@@ -39,7 +39,7 @@ extern "C" {
 
 enum { ORC_JNT_SLIDE = 2, ORC_JNT_HINGE = 3 };
 enum { ORC_TRN_JOINT = 0, ORC_TRN_TENDON = 3 };
-enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1 };
+enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1, ORC_EFC_FRICTION = 2 };
 
 /* ---- model constants (mjModel subset; filled by the Python side from the compiled scene) */
 typedef struct orc_model {
@@ -111,6 +111,10 @@ typedef struct orc_model {
   int body_weldid[ORC_MAXBODY];
   /* derived by orc_set0 */
   double dof_invweight0[ORC_MAXV];
+  /* dry joint friction (mjModel dof_frictionloss, dof_solref, dof_solimp) */
+  double dof_frictionloss[ORC_MAXV];
+  double dof_solref[ORC_MAXV][2];
+  double dof_solimp[ORC_MAXV][5];
 } orc_model;
 
 /* ---- per-environment state + scratch (mjData subset) */
@@ -143,6 +147,7 @@ typedef struct orc_data {
   double efc_pos[ORC_MAXEFC], efc_margin[ORC_MAXEFC], efc_vel[ORC_MAXEFC];
   double efc_D[ORC_MAXEFC], efc_aref[ORC_MAXEFC], efc_force[ORC_MAXEFC];
   double efc_K[ORC_MAXEFC], efc_B[ORC_MAXEFC], efc_I[ORC_MAXEFC];
+  double efc_frictionloss[ORC_MAXEFC];
   double qfrc_constraint[ORC_MAXV];
   int solver_niter;
   int contact_geom[ORC_MAXCON][2];  /* d->contact[i].geom, i < ncon */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librcs_oracle.so")
 
 MAXBODY, MAXV, MAXU, MAXEQ, MAXTENDON, MAXWRAP, MAXSITE, MAXARM = 32, 16, 16, 4, 4, 8, 8, 8
-MAXEFC = MAXEQ + 2 * MAXV
+MAXEFC = MAXEQ + 3 * MAXV
 MAXGEOM, MAXCON, MAXCGEOM = 32, 32, 16
 D = C.c_double
 I = C.c_int
@@ -55,6 +55,7 @@ class OrcModel(C.Structure):
         ("geom_pos", D * 3 * MAXGEOM), ("geom_quat", D * 4 * MAXGEOM), ("geom_size", D * 3 * MAXGEOM),
         ("mesh_vert", C.POINTER(D)), ("body_weldid", I * MAXBODY),
         ("dof_invweight0", D * MAXV),
+        ("dof_frictionloss", D * MAXV), ("dof_solref", D * 2 * MAXV), ("dof_solimp", D * 5 * MAXV),
     ]
 
 
@@ -73,7 +74,7 @@ class OrcData(C.Structure):
         ("nefc", I), ("ncon", I), ("efc_type", I * MAXEFC), ("efc_J", D * MAXV * MAXEFC),
         ("efc_pos", D * MAXEFC), ("efc_margin", D * MAXEFC), ("efc_vel", D * MAXEFC),
         ("efc_D", D * MAXEFC), ("efc_aref", D * MAXEFC), ("efc_force", D * MAXEFC),
-        ("efc_K", D * MAXEFC), ("efc_B", D * MAXEFC), ("efc_I", D * MAXEFC),
+        ("efc_K", D * MAXEFC), ("efc_B", D * MAXEFC), ("efc_I", D * MAXEFC), ("efc_frictionloss", D * MAXEFC),
         ("qfrc_constraint", D * MAXV), ("solver_niter", I), ("contact_geom", I * 2 * MAXCON),
     ]
 
@@ -192,8 +193,8 @@ def make_model(cm) -> OrcModel:
         verts = np.zeros(3)
     m._verts = verts  # keep alive
     m.mesh_vert = verts.ctypes.data_as(C.POINTER(D))
-    if np.any(cm.arrays["dof_frictionloss"] != 0):
-        raise ValueError("frictionloss rows are not restated in this oracle revision")
+    for name in ("dof_frictionloss", "dof_solref", "dof_solimp"):
+        _fill(getattr(m, name), f64(name))
     lib().orc_set0(C.byref(m))
     return m
 
@@ -297,7 +298,7 @@ class Sim:
 
     def __init__(self, cm, robot_joints, robot_actuators, attachment_site, base, q_home, tcp_offset: Pose | None = None,
                  gripper_joint: str | None = None, gripper_actuator: str | None = None,
-                 register_convergence_callback: bool = True, idx: str = "0"):
+                 register_convergence_callback: bool = True, idx: str = "0", arm_collision_geoms: list[str] | None = None):
         L = lib()
         self.cm = cm
         self.model = make_model(cm)
@@ -316,8 +317,10 @@ class Sim:
                                   self._id("actuator", gripper_actuator, "actuator"))
         self.n = n
         # SimRobotConfig.arm_collision_geoms / SimGripperConfig collision geom lists (SimRobot.h:19-22, SimGripper.h:24-29)
-        arm_g = [self._id("geom", f"fr3_link{i}_collision_{idx}", "geom") for i in range(8)]
-        L.orc_sim_set_robot_cgeoms(C.byref(self.s), len(arm_g), (I * len(arm_g))(*arm_g))
+        if arm_collision_geoms is None:
+            arm_collision_geoms = [f"fr3_link{i}_collision_{idx}" for i in range(8)]
+        arm_g = [self._id("geom", g, "geom") for g in arm_collision_geoms]
+        L.orc_sim_set_robot_cgeoms(C.byref(self.s), len(arm_g), (I * max(len(arm_g), 1))(*arm_g))
         if gripper_joint is not None:
             cg = [self._id("geom", f"{g}_{idx}", "geom") for g in ("hand_c", "d435i_collision", "finger_0_left", "finger_0_right")]
             cf = [self._id("geom", f"{g}_{idx}", "geom") for g in ("finger_0_left", "finger_0_right")]

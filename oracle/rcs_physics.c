@@ -360,6 +360,34 @@ static void make_constraint(const orc_model* m, orc_data* d) {
     d->efc_D[n] = 1 / R;
     n++;
   }
+  /* mj_instantiateFriction: one row per dof with frictionloss > 0; J = e_j, pos = 0.  mj_makeImpedance sets the
+     stiffness of friction rows to zero, so aref = -B * velocity; the impedance is solimp's value at distance 0 */
+  for (int j = 0; j < m->njnt; j++) {
+    if (m->dof_frictionloss[j] <= 0) continue;
+    memset(d->efc_J[n], 0, sizeof(d->efc_J[n]));
+    d->efc_J[n][j] = 1;
+    d->efc_type[n] = ORC_EFC_FRICTION;
+    d->efc_pos[n] = 0;
+    d->efc_margin[n] = 0;
+    d->efc_frictionloss[n] = m->dof_frictionloss[j];
+    double imp = impedance(m->dof_solimp[j], 0, 0);
+    double dmax = m->dof_solimp[j][1];
+    if (dmax < MINIMP) dmax = MINIMP; if (dmax > MAXIMP) dmax = MAXIMP;
+    double tc = m->dof_solref[j][0], dr = m->dof_solref[j][1];
+    if (tc > 0) {
+      if (tc < 2 * m->timestep) tc = 2 * m->timestep;
+      double bd = dmax * tc;
+      B[n] = 2 / (bd > MINVAL ? bd : MINVAL);
+    } else {
+      B[n] = -dr / dmax;
+    }
+    K[n] = 0;
+    I[n] = imp;
+    double R = (1 - imp) / imp * m->dof_invweight0[j];
+    if (R < MINVAL) R = MINVAL;
+    d->efc_D[n] = 1 / R;
+    n++;
+  }
   for (int j = 0; j < m->njnt; j++) {
     if (!m->jnt_limited[j]) continue;
     for (int side = 0; side < 2; side++) {
@@ -606,16 +634,35 @@ static void fwd_actuation(const orc_model* m, orc_data* d) {
 }
 
 /* Primal constraint solve: qacc = argmin 1/2 |qacc - qacc_smooth|_M^2 + sum_i s_i(J_i qacc - aref_i)
- * with s_i quadratic (equality) or one-sided quadratic (limit).  Newton on the piecewise-quadratic
+ * with s_i quadratic (equality), one-sided quadratic (limit) or Huber (dry joint friction: quadratic inside
+ * |J qacc - aref| < R * frictionloss, linear outside).  Newton on the piecewise-quadratic
  * cost: a full step that leaves the active set unchanged lands on the exact minimiser; otherwise an
  * exact line search along the Newton direction is taken and the step repeated.  (MuJoCo's Newton
  * solver stops at tolerance 1e-8 of the same problem.) */
-static void efc_residual(const orc_model* m, const orc_data* d, const double* x, double* jar, int* active) {
+/* Row states (mj_constraintUpdate): 0 off (satisfied limit), 1 quadratic, 2 linear-negative (friction row pushing
+ * with +frictionloss), 3 linear-positive (-frictionloss).  `dir` breaks ties on a zone boundary during the line search
+ * (which side the iterate is about to enter); 0 applies MuJoCo's own comparisons. */
+enum { ST_OFF = 0, ST_QUAD = 1, ST_LINNEG = 2, ST_LINPOS = 3 };
+static int row_state(const orc_data* d, int i, double jar, double dir) {
+  if (d->efc_type[i] == ORC_EFC_EQUALITY) return ST_QUAD;
+  if (d->efc_type[i] == ORC_EFC_LIMIT) return (jar < 0 || (jar == 0 && dir < 0)) ? ST_QUAD : ST_OFF;
+  double rf = d->efc_frictionloss[i] / d->efc_D[i];
+  if (jar < -rf || (jar == -rf && dir <= 0)) return ST_LINNEG;
+  if (jar > rf || (jar == rf && dir >= 0)) return ST_LINPOS;
+  return ST_QUAD;
+}
+static double row_force(const orc_data* d, int i, double jar, int state) {
+  if (state == ST_QUAD) return -d->efc_D[i] * jar;
+  if (state == ST_LINNEG) return d->efc_frictionloss[i];
+  if (state == ST_LINPOS) return -d->efc_frictionloss[i];
+  return 0;
+}
+static void efc_residual(const orc_model* m, const orc_data* d, const double* x, double* jar, int* state) {
   for (int i = 0; i < d->nefc; i++) {
     double v = -d->efc_aref[i];
     for (int j = 0; j < m->njnt; j++) v += d->efc_J[i][j] * x[j];
     jar[i] = v;
-    active[i] = d->efc_type[i] == ORC_EFC_EQUALITY || v < 0;
+    state[i] = row_state(d, i, v, 0);
   }
 }
 
@@ -631,9 +678,11 @@ static void solve_constraints(const orc_model* m, orc_data* d) {
   d->solver_niter = 0;
   if (ne == 0) return;
   double jar[ORC_MAXEFC];
-  int active[ORC_MAXEFC];
-  for (int iter = 0; iter < 30; iter++) {
-    efc_residual(m, d, d->qacc, jar, active);
+  int state[ORC_MAXEFC];
+  for (int iter = 0; iter < 50; iter++) {
+    efc_residual(m, d, d->qacc, jar, state);
+    /* Newton step of the cost with the rows frozen in their current zones: quadratic rows enter the Hessian,
+       linear rows push with a constant force */
     double H[ORC_MAXV][ORC_MAXV], g[ORC_MAXV], dq[ORC_MAXV];
     memcpy(H, d->qM, sizeof(H));
     for (int r = 0; r < nv; r++) {
@@ -642,11 +691,13 @@ static void solve_constraints(const orc_model* m, orc_data* d) {
       g[r] = v;
     }
     for (int i = 0; i < ne; i++) {
-      if (!active[i]) continue;
+      if (state[i] == ST_OFF) continue;
+      double f = row_force(d, i, jar[i], state[i]);
       for (int r = 0; r < nv; r++) {
         if (d->efc_J[i][r] == 0) continue;
-        g[r] += d->efc_D[i] * jar[i] * d->efc_J[i][r];
-        for (int c = 0; c < nv; c++) H[r][c] += d->efc_D[i] * d->efc_J[i][r] * d->efc_J[i][c];
+        g[r] -= f * d->efc_J[i][r];
+        if (state[i] == ST_QUAD)
+          for (int c = 0; c < nv; c++) H[r][c] += d->efc_D[i] * d->efc_J[i][r] * d->efc_J[i][c];
       }
     }
     for (int r = 0; r < nv; r++) dq[r] = -g[r];
@@ -655,12 +706,12 @@ static void solve_constraints(const orc_model* m, orc_data* d) {
     d->solver_niter = iter + 1;
     /* full step */
     double xt[ORC_MAXV], jar_t[ORC_MAXEFC];
-    int active_t[ORC_MAXEFC], same = 1;
+    int state_t[ORC_MAXEFC], same = 1;
     for (int r = 0; r < nv; r++) xt[r] = d->qacc[r] + dq[r];
-    efc_residual(m, d, xt, jar_t, active_t);
-    for (int i = 0; i < ne; i++) if (active_t[i] != active[i]) same = 0;
+    efc_residual(m, d, xt, jar_t, state_t);
+    for (int i = 0; i < ne; i++) if (state_t[i] != state[i]) same = 0;
     if (same) { memcpy(d->qacc, xt, sizeof(double) * nv); break; }
-    /* exact line search: phi'(a) = p0 + a p1 + sum_{i active at a} D_i jd_i (jar_i + a jd_i) */
+    /* exact line search along dq: phi'(a) = p0 + a p1 - sum_i f_i(a) jd_i is piecewise linear; walk its pieces */
     double jd[ORC_MAXEFC], p0 = 0, p1 = 0;
     for (int r = 0; r < nv; r++) {
       double md = 0, gm = -d->qfrc_smooth[r];
@@ -673,33 +724,50 @@ static void solve_constraints(const orc_model* m, orc_data* d) {
       for (int j = 0; j < nv; j++) v += d->efc_J[i][j] * dq[j];
       jd[i] = v;
     }
-    int act[ORC_MAXEFC];
-    for (int i = 0; i < ne; i++)
-      act[i] = d->efc_type[i] == ORC_EFC_EQUALITY || jar[i] < 0 || (jar[i] == 0 && jd[i] < 0);
+    int st[ORC_MAXEFC];
+    for (int i = 0; i < ne; i++) st[i] = row_state(d, i, jar[i], jd[i]);
     double alpha = 0;
-    for (int guard = 0; guard < ne + 2; guard++) {
-      double c0 = p0, c1 = p1;
-      for (int i = 0; i < ne; i++)
-        if (act[i]) { c0 += d->efc_D[i] * jar[i] * jd[i]; c1 += d->efc_D[i] * jd[i] * jd[i]; }
-      double a_star = -c0 / c1;
-      double a_next = INFINITY;
+    for (int guard = 0; guard < 3 * ne + 2; guard++) {
+      double c0 = p0, c1 = p1, a_next = INFINITY;
       for (int i = 0; i < ne; i++) {
+        if (st[i] == ST_QUAD) { c0 += d->efc_D[i] * jar[i] * jd[i]; c1 += d->efc_D[i] * jd[i] * jd[i]; }
+        else if (st[i] != ST_OFF) c0 -= row_force(d, i, 0, st[i]) * jd[i];
         if (d->efc_type[i] == ORC_EFC_EQUALITY || jd[i] == 0) continue;
-        double ab = -jar[i] / jd[i];
+        /* the zone boundary this row crosses next while moving in direction jd */
+        double bound;
+        if (d->efc_type[i] == ORC_EFC_LIMIT) bound = 0;
+        else {
+          double rf = d->efc_frictionloss[i] / d->efc_D[i];
+          if (jd[i] > 0) { if (st[i] == ST_LINPOS) continue; bound = st[i] == ST_LINNEG ? -rf : rf; }
+          else { if (st[i] == ST_LINNEG) continue; bound = st[i] == ST_LINPOS ? rf : -rf; }
+        }
+        double ab = (bound - jar[i]) / jd[i];
         if (ab > alpha && ab < a_next) a_next = ab;
       }
+      double a_star = -c0 / c1;
       if (a_star <= a_next) { if (a_star > alpha) alpha = a_star; break; }
       alpha = a_next;
       for (int i = 0; i < ne; i++) {
         if (d->efc_type[i] == ORC_EFC_EQUALITY || jd[i] == 0) continue;
-        if (-jar[i] / jd[i] == a_next) act[i] = !act[i];
+        if (d->efc_type[i] == ORC_EFC_LIMIT) {
+          if (-jar[i] / jd[i] == a_next) st[i] = st[i] == ST_QUAD ? ST_OFF : ST_QUAD;
+        } else {
+          double rf = d->efc_frictionloss[i] / d->efc_D[i];
+          if (jd[i] > 0) {
+            if (st[i] == ST_LINNEG && (-rf - jar[i]) / jd[i] == a_next) st[i] = ST_QUAD;
+            else if (st[i] == ST_QUAD && (rf - jar[i]) / jd[i] == a_next) st[i] = ST_LINPOS;
+          } else {
+            if (st[i] == ST_LINPOS && (rf - jar[i]) / jd[i] == a_next) st[i] = ST_QUAD;
+            else if (st[i] == ST_QUAD && (-rf - jar[i]) / jd[i] == a_next) st[i] = ST_LINNEG;
+          }
+        }
       }
     }
     for (int r = 0; r < nv; r++) d->qacc[r] += alpha * dq[r];
   }
-  efc_residual(m, d, d->qacc, jar, active);
+  efc_residual(m, d, d->qacc, jar, state);
   for (int i = 0; i < ne; i++) {
-    d->efc_force[i] = active[i] ? -d->efc_D[i] * jar[i] : 0;
+    d->efc_force[i] = row_force(d, i, jar[i], state[i]);
     for (int j = 0; j < nv; j++) d->qfrc_constraint[j] += d->efc_J[i][j] * d->efc_force[i];
   }
 }

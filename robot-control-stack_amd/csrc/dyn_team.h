@@ -51,7 +51,8 @@ struct StageTeam {
   static constexpr int E0 = DG0 + NLP;               // eqD, eqAref, eqJ1, gblock
   static constexpr int XS0 = E0 + 4;                 // solver result (constrained qacc of the soft problem)
   static constexpr int QA0 = XS0 + NLP;              // qacc of the implicit solve
-  static constexpr int COUNT = QA0 + NLP;
+  static constexpr int FA0 = QA0 + NLP;              // dry-friction rows: aref (-B * qvel)
+  static constexpr int COUNT = FA0 + NLP;
   double* base;
   RCSH_D double& at(int k) const { return base[k]; }
   RCSH_D double& q(int i) const { return base[Q0 + i]; }
@@ -71,6 +72,7 @@ struct StageTeam {
   RCSH_D double& eq(int k) const { return base[E0 + k]; }
   RCSH_D double& xs(int i) const { return base[XS0 + i]; }
   RCSH_D double& qacc(int i) const { return base[QA0 + i]; }
+  RCSH_D double& fa(int i) const { return base[FA0 + i]; }
 };
 
 #ifdef RCSH_PHASE_TIMING
@@ -150,16 +152,41 @@ RCSH_D void scan_frames(double* R, double* p) {
   }
 }
 
-// Newton iteration with exact line search over the soft rows (dyn.h's loop), run redundantly by every lane of a
-// team from the LDS copy of the problem.  Only reached when more than 3 limit rows exist or no active-set guess
-// was self-consistent.
-template <class T>
-RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, double eqD, double eqAref, double eqJ1,
-                        double* x) {
+// Newton iteration with exact line search over the soft rows, run redundantly by every lane of a team from the LDS
+// copy of the problem: the coupling equality (quadratic), the existing joint-limit rows (one-sided quadratic) and the
+// dry-friction rows (Huber: quadratic inside |x_i - aref_i| < R * frictionloss, linear outside).  An iteration
+// freezes every row in its current zone, solves the resulting linear system, and accepts the solution if it lands
+// in the same zones (then it is the exact minimiser of the convex cost); otherwise it line-searches exactly along
+// the step -- phi' is piecewise linear -- and repeats.  Reached when more than 3 limit rows exist, when no
+// active-set guess was self-consistent, and always for models with dry friction (3 zones per row: too many
+// guesses to enumerate).  Same algorithm as the oracle's solve_constraints (oracle/rcs_physics.c).
+// FRIC = false compiles the friction rows out (frows is the constant 0), leaving dyn.h's loop.
+template <class T, bool FRIC>
+RCSH_D void newton_rows(const DevModel& m, const StageTeam<T>& st, uint32_t limrows, bool has_eq, double eqD, double eqAref,
+                        double eqJ1, double* x) {
   constexpr int NL = T::NL, NA = T::NARM;
-  uint32_t act = limrows;
+  // dry-friction rows: D, frictionloss, aref, half-width of the quadratic zone
+  double fD[NL], fF[NL], fA[NL], fR[NL];
+  uint32_t frows = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    fF[i] = 0; fD[i] = 0; fA[i] = 0; fR[i] = 0;
+    if constexpr (FRIC) {
+      fF[i] = m.fl_floss[i]; fD[i] = m.fl_D[i]; fA[i] = st.fa(i);
+      fR[i] = fF[i] > 0 ? fF[i] / fD[i] : 0.0;
+      if (fF[i] > 0) frows |= 1u << i;
+    }
+  }
+  uint32_t act = limrows;      // limit rows in their quadratic zone (first guess: all)
+  uint32_t fneg = 0, fpos = 0; // friction rows in the linear zones (first guess: the zones of qacc = 0)
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+    if (frows & (1u << i)) {
+      if (-fA[i] <= -fR[i]) fneg |= 1u << i;
+      else if (-fA[i] >= fR[i]) fpos |= 1u << i;
+    }
   bool have_x = false;
-  for (int iter = 0; iter < 16; ++iter) {
+  for (int iter = 0; iter < 32; ++iter) {
     double xn[NL];
     {
       double H[T::NTRI];
@@ -175,6 +202,11 @@ RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, d
           H[tri(i, i)] += D;
           xn[i] += st.limS(i) * D * st.limA(i);
         }
+        if (frows & (1u << i)) {
+          if (fneg & (1u << i)) xn[i] += fF[i];
+          else if (fpos & (1u << i)) xn[i] -= fF[i];
+          else { H[tri(i, i)] += fD[i]; xn[i] += fD[i] * fA[i]; }
+        }
       }
       if constexpr (T::GRIP) if (has_eq) {
         H[tri(NA, NA)] += eqD;
@@ -186,18 +218,26 @@ RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, d
       ldl_factor<NL>(H);
       ldl_solve<NL>(H, xn);
     }
-    uint32_t now = 0;
+    uint32_t now = 0, nneg = 0, npos = 0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
+    for (int i = 0; i < NL; ++i) {
       if ((limrows & (1u << i)) && st.limS(i) * xn[i] - st.limA(i) < 0) now |= 1u << i;
-    if (now == act || !have_x) {
+      if (frows & (1u << i)) {
+        const double jf = xn[i] - fA[i];
+        if (jf <= -fR[i]) nneg |= 1u << i;
+        else if (jf >= fR[i]) npos |= 1u << i;
+      }
+    }
+    const bool same = now == act && nneg == fneg && npos == fpos;
+    if (same || !have_x) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) x[i] = xn[i];
       have_x = true;
-      if (now == act) break;
-      act = now;
+      if (same) break;
+      act = now; fneg = nneg; fpos = npos;
       continue;
     }
+    // exact line search from x along d = xn - x
     double d[NL], jar[NL], jd[NL];
     double p0 = 0, p1 = 0;
 #pragma unroll
@@ -219,7 +259,7 @@ RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, d
       p0 += eqD * je * jde;
       p1 += eqD * jde * jde;
     }
-    uint32_t on = 0;
+    uint32_t on = 0, wneg = 0, wpos = 0;  // zones just past alpha while walking the line
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       jar[i] = 0; jd[i] = 0;
@@ -229,32 +269,67 @@ RCSH_D void newton_rows(const StageTeam<T>& st, uint32_t limrows, bool has_eq, d
         jd[i] = sgn * d[i];
         if (jar[i] < 0 || (jar[i] == 0 && jd[i] < 0)) on |= 1u << i;
       }
+      if (frows & (1u << i)) {
+        const double jf = x[i] - fA[i];
+        if (jf < -fR[i] || (jf == -fR[i] && d[i] <= 0)) wneg |= 1u << i;
+        else if (jf > fR[i] || (jf == fR[i] && d[i] >= 0)) wpos |= 1u << i;
+      }
     }
     double alpha = 0;
-    for (int guard = 0; guard < NL + 2; ++guard) {
+    for (int guard = 0; guard < 3 * NL + 2; ++guard) {
       double c0 = p0, c1 = p1, a_next = INFINITY;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        if (!(limrows & (1u << i))) continue;
-        const double D = st.limD(i);
-        if (on & (1u << i)) { c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
-        if (jd[i] != 0) {
-          const double ab = -jar[i] / jd[i];
-          if (ab > alpha && ab < a_next) a_next = ab;
+        if (limrows & (1u << i)) {
+          const double D = st.limD(i);
+          if (on & (1u << i)) { c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
+          if (jd[i] != 0) {
+            const double ab = -jar[i] / jd[i];
+            if (ab > alpha && ab < a_next) a_next = ab;
+          }
+        }
+        if (frows & (1u << i)) {
+          const double jf = x[i] - fA[i];
+          const bool ln = wneg & (1u << i), lp = wpos & (1u << i);
+          if (ln) c0 -= fF[i] * d[i];
+          else if (lp) c0 += fF[i] * d[i];
+          else { c0 += fD[i] * jf * d[i]; c1 += fD[i] * d[i] * d[i]; }
+          if (d[i] != 0 && !(d[i] > 0 ? lp : ln)) {
+            const double bound = d[i] > 0 ? (ln ? -fR[i] : fR[i]) : (lp ? fR[i] : -fR[i]);
+            const double ab = (bound - jf) / d[i];
+            if (ab > alpha && ab < a_next) a_next = ab;
+          }
         }
       }
       const double a_star = -c0 / c1;
       if (a_star <= a_next) { if (a_star > alpha) alpha = a_star; break; }
       alpha = a_next;
 #pragma unroll
-      for (int i = 0; i < NL; ++i)
+      for (int i = 0; i < NL; ++i) {
         if ((limrows & (1u << i)) && jd[i] != 0 && -jar[i] / jd[i] == a_next) on ^= 1u << i;
+        if ((frows & (1u << i)) && d[i] != 0) {
+          const double jf = x[i] - fA[i];
+          const bool ln = wneg & (1u << i), lp = wpos & (1u << i);
+          if (d[i] > 0) {
+            if (ln && (-fR[i] - jf) / d[i] == a_next) wneg &= ~(1u << i);
+            else if (!ln && !lp && (fR[i] - jf) / d[i] == a_next) wpos |= 1u << i;
+          } else {
+            if (lp && (fR[i] - jf) / d[i] == a_next) wpos &= ~(1u << i);
+            else if (!ln && !lp && (-fR[i] - jf) / d[i] == a_next) wneg |= 1u << i;
+          }
+        }
+      }
     }
-    act = 0;
+    act = 0; fneg = 0; fpos = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       x[i] += alpha * d[i];
       if ((limrows & (1u << i)) && st.limS(i) * x[i] - st.limA(i) < 0) act |= 1u << i;
+      if (frows & (1u << i)) {
+        const double jf = x[i] - fA[i];
+        if (jf <= -fR[i]) fneg |= 1u << i;
+        else if (jf >= fR[i]) fpos |= 1u << i;
+      }
     }
   }
 }
@@ -352,7 +427,9 @@ struct ActK {
 // `on_frame(R, p)` is called on every lane with the world frame of the lane's link at the pre-step qpos (what the
 // contact detection of the last mj_step1 sees).
 // Contains team_sync()s: every lane of the wave must call it.
-template <class T, class FrameFn>
+// FRIC: the model has dry joint friction rows (dof_frictionloss); a separate instantiation so that models without
+// them carry none of that code.
+template <class T, bool FRIC, class FrameFn>
 RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool stepping, FrameFn&& on_frame) {
   static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
@@ -596,6 +673,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     st.limA(tl) = lA;
     st.limS(tl) = lS;
     st.dg(tl) = h * d;
+    if constexpr (FRIC) st.fa(tl) = -m.fl_B[tl] * qd;  // dry-friction row of the joint: aref (zero stiffness)
   }
   team_sync();
   TEAM_MARK(5)
@@ -615,7 +693,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
       c += exists ? 1 : 0;
     }
   }
-  const bool fast = nrows <= 3;
+  const bool fast = nrows <= 3 && !FRIC;
   const bool solver_lane = fast && t < (1 << nrows);
   double H[T::NTRI], x[NL];
 #pragma unroll
@@ -665,7 +743,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     }
   } else {
     double xs[NL];
-    newton_rows<T>(st, limrows, has_eq, eqD, eqAref, eqJ1, xs);
+    newton_rows<T, FRIC>(m, st, limrows, has_eq, eqD, eqAref, eqJ1, xs);
     if (t == 0) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) st.xs(i) = xs[i];
@@ -684,6 +762,16 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     for (int i = 0; i < NL; ++i) {
       const double r = lSv[i] * xs[i] - lAv[i];
       if (((limrows >> i) & 1u) && r < 0) rhs[i] -= lSv[i] * lDv[i] * r;
+    }
+    if constexpr (FRIC) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const double fF = m.fl_floss[i], fD = m.fl_D[i];
+        if (fF > 0) {
+          const double jf = xs[i] - st.fa(i), fR = fF / fD;
+          rhs[i] += jf <= -fR ? fF : (jf >= fR ? -fF : -fD * jf);
+        }
+      }
     }
     if constexpr (T::GRIP) if (has_eq) {
       const double fe = -eqD * (xs[NA] + eqJ1 * xs[NA + 1] - eqAref);

@@ -138,6 +138,7 @@ void HostModel::copy_from(const rcsh_model_desc& d) {
   cpi(jnt_actfrclimited, d.jnt_actfrclimited, njnt); cpd(jnt_actfrcrange, d.jnt_actfrcrange, 2 * njnt);
   cpi(jnt_actgravcomp, d.jnt_actgravcomp, njnt);
   cpd(dof_armature, d.dof_armature, njnt); cpd(dof_damping, d.dof_damping, njnt); cpd(dof_frictionloss, d.dof_frictionloss, njnt);
+  cpd(dof_solref, d.dof_solref, 2 * njnt); cpd(dof_solimp, d.dof_solimp, 5 * njnt);
   cpd(qpos0, d.qpos0, njnt);
   cpi(tendon_adr, d.tendon_adr, ntendon); cpi(tendon_num, d.tendon_num, ntendon);
   cpi(wrap_objid, d.wrap_objid, nwrap); cpd(wrap_prm, d.wrap_prm, nwrap);
@@ -182,7 +183,7 @@ std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& ac
     if (h.body_jntnum[b] > 1) return "bodies with more than one joint are outside the supported archetypes";
   for (int j = 0; j < h.njnt; ++j) {
     if (h.jnt_type[j] != kSlide && h.jnt_type[j] != kHinge) return "only hinge and slide joints are supported";
-    if (h.dof_frictionloss[j] != 0) return "joint frictionloss is not supported in this revision";
+    if (h.dof_frictionloss[j] < 0) return "negative joint frictionloss";
     if (h.body_jntadr[h.jnt_bodyid[j]] != j) return "joint/body addressing is inconsistent";
   }
   std::vector<int> owner;
@@ -345,6 +346,20 @@ std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& ac
     compute_invweight0<T>(m);
   });
   if (!ok) return "arm length / gripper combination is not instantiated";
+  // dry joint friction rows (need invweight0): mj_makeImpedance gives friction rows zero stiffness and the impedance
+  // at distance 0; R = (1 - imp) / imp * dof_invweight0, floored like every regulariser
+  m.has_friction = 0;
+  m.pad3 = 0;
+  for (int i = 0; i < kMaxLinks; ++i) { m.fl_floss[i] = 0; m.fl_D[i] = 0; m.fl_B[i] = 0; }
+  for (int i = 0; i < nl; ++i) {
+    m.fl_floss[i] = h.dof_frictionloss[i];
+    if (h.dof_frictionloss[i] <= 0) continue;
+    m.has_friction = 1;
+    const double imp = impedance(make_imp(&h.dof_solimp[5 * i]), 0.0, 0.0);
+    m.fl_D[i] = row_D(imp, m.invweight0[i]);
+    double K;
+    make_kb(&h.dof_solref[2 * i], &h.dof_solimp[5 * i], h.timestep, K, m.fl_B[i]);
+  }
   return "";
 }
 

@@ -96,6 +96,13 @@ struct DevModel {
   double site_rot[9];
   double base_pos[3];   // world pose of the robot base body (static)
   double base_quat[4];  // wxyz
+  // ---- dry joint friction (dof_frictionloss): one soft row per joint with a Huber cost.  The row's position is 0,
+  // so its regulariser is a model constant: D = 1/R, R = (1 - imp(0)) / imp(0) * invweight0; aref = -B * qvel
+  int32_t has_friction;  // any fl_floss > 0
+  int32_t pad3;
+  double fl_floss[kMaxLinks];
+  double fl_D[kMaxLinks];
+  double fl_B[kMaxLinks];
 };
 
 }  // namespace rcsh

@@ -18,7 +18,7 @@ struct HostModel {
   std::vector<double> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_gravcomp;
   std::vector<int32_t> jnt_type, jnt_bodyid, jnt_limited, jnt_actfrclimited, jnt_actgravcomp;
   std::vector<double> jnt_pos, jnt_axis, jnt_range, jnt_margin, jnt_solref, jnt_solimp, jnt_actfrcrange;
-  std::vector<double> dof_armature, dof_damping, dof_frictionloss, qpos0;
+  std::vector<double> dof_armature, dof_damping, dof_frictionloss, dof_solref, dof_solimp, qpos0;
   std::vector<int32_t> tendon_adr, tendon_num, wrap_objid;
   std::vector<double> wrap_prm;
   std::vector<int32_t> eq_obj1id, eq_obj2id, eq_active0;

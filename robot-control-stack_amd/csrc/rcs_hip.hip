@@ -146,11 +146,14 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   //    caps it at three workgroups per CU).  2.5x slower at 4096 environments (9.5 M), ahead only once the
   //    chip is oversubscribed (30 M vs 28 M at 262144).
   // rcsh_sim_set_kernel / RCSH_KERNEL=team|lane pin the choice (parity tests run both).
-  const bool team = s->kernel ? s->kernel == RCSH_KERNEL_TEAM : s->n < kTeamKernelMaxEnvs;
+  // (dry joint friction rows exist in the team kernel only; rcsh_sim_set_kernel refuses the lane kernel for such models)
+  const bool team = s->dm.has_friction || (s->kernel ? s->kernel == RCSH_KERNEL_TEAM : s->n < kTeamKernelMaxEnvs);
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    if (team)
-      hipLaunchKernelGGL((k_run_team<T>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+    if (team && s->dm.has_friction)
+      hipLaunchKernelGGL((k_run_team<T, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+    else if (team)
+      hipLaunchKernelGGL((k_run_team<T, false>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     else
       hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);
     err = hipGetLastError();
@@ -364,6 +367,8 @@ int rcsh_sim_set_stream(rcsh_sim* s, void* hip_stream) {
 int rcsh_sim_set_kernel(rcsh_sim* s, int32_t variant) {
   REQUIRE_SIM(s);
   if (variant < RCSH_KERNEL_AUTO || variant > RCSH_KERNEL_LANE) return fail(RCSH_ERR_ARG, "unknown kernel variant");
+  if (variant == RCSH_KERNEL_LANE && s->dm.has_friction)
+    return fail(RCSH_ERR_MODEL, "the lane kernel has no dry-friction (frictionloss) rows; this model needs the team kernel");
   s->kernel = variant;
   return RCSH_OK;
 }

@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
 // The same entry point with one TEAM of 16 lanes per environment (dyn_team.h): four environments per wavefront,
 // one wavefront per workgroup.  Lane 0 of a team (the leader) owns the RCS bookkeeping -- wrappers, callback
 // scheduler, observation -- through the same helpers as k_run; all 16 lanes run the physics.
-template <class T>
+template <class T, bool FRIC>
 __global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
     }
     const bool want_contacts = team_ballot(due) != 0;
     uint32_t hit = 0;
-    team_substep<T>(m, st, t, stepping, [&](const double* R, const double* p) {
+    team_substep<T, FRIC>(m, st, t, stepping, [&](const double* R, const double* p) {
       if (!want_contacts) return;
       const double* nrm = lc.plane_n;
       const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],

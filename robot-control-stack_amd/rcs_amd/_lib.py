@@ -53,6 +53,7 @@ class ModelDesc(C.Structure):
         ("geom_type", _I32P), ("geom_bodyid", _I32P), ("geom_contype", _I32P), ("geom_conaffinity", _I32P),
         ("geom_pos", _F64P), ("geom_quat", _F64P), ("geom_size", _F64P),
         ("geom_vertadr", _I32P), ("geom_vertnum", _I32P), ("mesh_vert", _F64P),
+     ("dof_solref", _F64P), ("dof_solimp", _F64P),
     ]
 
 

@@ -428,6 +428,8 @@ class _Compiler:
                     actgravcomp=ja.get("actuatorgravcomp", "false") == "true",
                     solref=_floats(ja.get("solreflimit"), 2, DEFAULT_SOLREF),
                     solimp=_floats(ja.get("solimplimit"), 5, DEFAULT_SOLIMP),
+                    solreffriction=_floats(ja.get("solreffriction"), 2, DEFAULT_SOLREF),
+                    solimpfriction=_floats(ja.get("solimpfriction"), 5, DEFAULT_SOLIMP),
                     margin=float(ja.get("margin", 0)),
                 )
                 body["joints"].append(len(self.joints))
@@ -736,7 +738,7 @@ class _Compiler:
         A["jnt_actfrcrange"] = np.array([j["actfrcrange"] for j in self.joints], dtype=np.float64).reshape(nj, 2)
         A["jnt_actgravcomp"] = np.array([j["actgravcomp"] for j in self.joints], dtype=np.int32)
         # per-dof copies (1-dof joints: identical indexing; free joints expand)
-        dof_jnt, dof_body, arm, damp, floss = [], [], [], [], []
+        dof_jnt, dof_body, arm, damp, floss, fsolref, fsolimp = [], [], [], [], [], [], []
         for ji, j in enumerate(self.joints):
             n = {JNT_FREE: 6, JNT_BALL: 3}.get(j["type"], 1)
             for _ in range(n):
@@ -745,11 +747,15 @@ class _Compiler:
                 arm.append(j["armature"])
                 damp.append(j["damping"])
                 floss.append(j["frictionloss"])
+                fsolref.append(j["solreffriction"])
+                fsolimp.append(j["solimpfriction"])
         A["dof_jntid"] = np.array(dof_jnt, dtype=np.int32)
         A["dof_bodyid"] = np.array(dof_body, dtype=np.int32)
         A["dof_armature"] = np.array(arm, dtype=np.float64)
         A["dof_damping"] = np.array(damp, dtype=np.float64)
         A["dof_frictionloss"] = np.array(floss, dtype=np.float64)
+        A["dof_solref"] = np.array(fsolref, dtype=np.float64).reshape(len(floss), 2)
+        A["dof_solimp"] = np.array(fsolimp, dtype=np.float64).reshape(len(floss), 5)
         qpos0 = np.zeros(nq)
         for j, qa in zip(self.joints, qadr):
             if j["type"] == JNT_FREE:

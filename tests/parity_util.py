@@ -34,17 +34,23 @@ def synthetic_actions(n_envs: int, n_steps: int, seed: int = 0, dof: int = 7):
 KERNEL = "auto"
 
 
+XARM7_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "xarm7_empty_world", "scene.xml")
+
+
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
-                 max_relative_movement=None):
+                 max_relative_movement=None, robot: str = "fr3"):
     from rcs_amd import sim
-    from rcs_amd.envs import ControlMode, RelativeTo, SimEnvCreator, default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.envs import ControlMode, RelativeTo, SimEnvCreator, default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg
 
     cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=30)
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
+    if robot == "xarm7":
+        gripper = False
     venv = SimEnvCreator()(
-        mode, default_sim_robot_cfg("fr3_empty_world"), gripper_cfg=default_sim_gripper_cfg() if gripper else None,
+        mode, xarm7_sim_robot_cfg() if robot == "xarm7" else default_sim_robot_cfg("fr3_empty_world"),
+        gripper_cfg=default_sim_gripper_cfg() if gripper else None,
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None, relative_to=RelativeTo.LAST_STEP,
         n_envs=n_envs, device=device,
     )
@@ -53,22 +59,23 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
 
 
 def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, mode: str = "joints",
-                     max_relative_movement=None):
+                     max_relative_movement=None, robot: str = "fr3"):
     from rcs_amd.mjcf import compile_mjcf
-    from rcs_env_oracle import OracleEnv
+    from rcs_env_oracle import XARM7, OracleEnv
 
-    cm = compile_mjcf(SCENE)
+    cm = compile_mjcf(XARM7_SCENE if robot == "xarm7" else SCENE)
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    return [OracleEnv(cm, control_mode=mode, gripper=gripper, max_relative_movement=max_relative_movement if relative else None,
-                      async_control=async_control) for _ in range(n_envs)]
+    return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot == "fr3", max_relative_movement=max_relative_movement if relative else None,
+                      async_control=async_control, robot=XARM7 if robot == "xarm7" else None) for _ in range(n_envs)]
 
 
 def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: bool = True, seed: int = 0, gripper: bool = True,
-                             episodes: int = 1):
+                             episodes: int = 1, robot: str = "fr3"):
     """Fused HIP env-step vs the oracle on the same seeded actions; returns max abs differences + flag mismatches."""
-    venv = make_vec_env(n_envs, async_control, gripper=gripper)
-    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper)
+    gripper = gripper and robot == "fr3"
+    venv = make_vec_env(n_envs, async_control, gripper=gripper, robot=robot)
+    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot)
     joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed)
     rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_finger": 0.0, "max_abs_gripper_width": 0.0,
            "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}
@@ -94,7 +101,8 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
             # whether a limit row exists in a substep, so their trajectories are only reproducible to ~1e-5 m
             rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:7] - oe.sim.qpos[:7]).max()))
             rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e][:7] - oe.sim.qvel[:7]).max()))
-            rep["max_abs_finger"] = max(rep["max_abs_finger"], float(np.abs(q[e][7:] - oe.sim.qpos[7:]).max()))
+            if q.shape[1] > 7:
+                rep["max_abs_finger"] = max(rep["max_abs_finger"], float(np.abs(q[e][7:] - oe.sim.qpos[7:]).max()))
             if substeps is not None and not async_control:
                 rep["substep_mismatches"] += int(int(substeps[e]) != int(oe.sim.s.convergence_steps))
 

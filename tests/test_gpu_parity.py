@@ -151,6 +151,21 @@ def test_collision_flags_match_oracle():
     venv.close()
 
 
+@pytest.mark.parametrize("async_control", [True, False])
+def test_xarm7_joints_with_dry_friction(async_control, kernel):
+    """Second archetype: 7-dof xArm7, <general> affine actuators with force ranges, no gripper, and a
+    dry-friction row (frictionloss = 1) on every joint -- the Huber-cost rows of the constraint solve.  Team kernel only."""
+    if kernel == "lane":
+        from parity_util import make_vec_env
+
+        with pytest.raises(RuntimeError, match="lane kernel"):
+            make_vec_env(4, async_control, robot="xarm7")
+        return
+    rep = run_joint_rollout_parity(n_envs=48, n_steps=6 if async_control else 3, async_control=async_control, seed=9, robot="xarm7")
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < 1e-4 and rep["max_abs_obs"] < TOL, rep
+    assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
+
+
 @pytest.mark.parametrize("n_envs", [1, 5, 33])
 def test_ragged_batch_sizes(n_envs):
     """Batches that do not fill a wavefront / a team group / the 8-workgroup XCD rounding."""

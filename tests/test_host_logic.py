@@ -74,6 +74,69 @@ def test_own_scene_equals_reference_scene_tables():
     assert set(own.geom_names) <= set(ref.geom_names) | {"camera_mount_collision_0"}
 
 
+XARM7_SCENE = os.path.join(os.path.dirname(SCENE), "..", "xarm7_empty_world", "scene.xml")
+REF_XARM7_SCENE = "/root/reference/assets/scenes/xarm7_empty_world/scene.xml"
+
+
+def test_xarm7_scene_constants():
+    """The xArm7 scene's physics constants as the reference model states them (assets/xarm7/mjcf/xarm7.xml:45-61,161-169)."""
+    cm = compile_mjcf(XARM7_SCENE)
+    a = cm.arrays
+    assert (cm.nbody, cm.njnt, cm.nu, cm.neq, cm.ntendon) == (9, 7, 7, 0, 0)
+    assert np.all(a["dof_frictionloss"] == 1.0) and np.all(a["dof_armature"] == 0.1)
+    assert a["dof_damping"].tolist() == [10, 10, 5, 5, 5, 2, 2]
+    assert a["actuator_gainprm"][:, 0].tolist() == [1500, 1500, 1000, 1000, 1000, 800, 800]
+    assert np.all(a["actuator_biasprm"][:, 1] == -a["actuator_gainprm"][:, 0]) and np.all(a["actuator_biastype"] == 1)
+    assert a["actuator_forcerange"][:, 1].tolist() == [50, 50, 30, 30, 30, 20, 20] and np.all(a["actuator_forcelimited"] == 1)
+    assert np.allclose(a["jnt_range"][1], [-2.059, 2.0944]) and np.allclose(a["actuator_ctrlrange"][3], [-0.19198, 3.927])
+    assert np.all(a["jnt_actgravcomp"] == 1) and np.all(a["body_gravcomp"][1:] == 1.0)
+    assert np.allclose(a["dof_solref"], [0.02, 1.0]) and np.allclose(a["dof_solimp"], [0.9, 0.95, 0.001, 0.5, 2.0])
+    assert cm.jnt_names == [f"joint{i}" for i in range(1, 8)] and cm.actuator_names == [f"act{i}" for i in range(1, 8)]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_XARM7_SCENE), reason="reference checkout not present (GPU box)")
+def test_own_xarm7_scene_equals_reference_scene_tables():
+    own, ref = compile_mjcf(XARM7_SCENE), compile_mjcf(REF_XARM7_SCENE)
+    for key, a in own.arrays.items():
+        if key.startswith(("geom_", "cam_", "mesh_")):
+            continue
+        b = ref.arrays[key]
+        assert a.shape == b.shape, key
+        rows = slice(1, None) if key.startswith("body_i") or key in ("body_mass", "body_inertia") else slice(None)
+        # (row 0: the reference's world body carries the mass of its pedestal cylinder geom; static, never read)
+        assert np.allclose(a[rows], b[rows]), key
+    assert own.jnt_names == ref.jnt_names and own.actuator_names == ref.actuator_names and own.body_names == ref.body_names
+
+
+def test_oracle_dry_friction_rows():
+    """Properties of the Huber friction rows (oracle/rcs_physics.c solve_constraints) on the xArm7 model:
+    the constraint force on a dof never exceeds frictionloss, saturates against a fast-moving joint, and an arm at rest
+    under gravity compensation stays at rest when commanded to stay (stiction)."""
+    from rcs_env_oracle import XARM7
+
+    cm = compile_mjcf(XARM7_SCENE)
+    s = O.Sim(cm, XARM7["joints"], XARM7["actuators"], XARM7["site"], XARM7["base"], XARM7["q_home"], None, arm_collision_geoms=[])
+    s.reset()
+    s.robot_reset()
+    for _ in range(50):
+        s.step(1)
+        assert np.all(np.abs(np.asarray(s.s.d.qfrc_constraint[:7])) <= 1.0 + 1e-12)
+    q_rest = np.asarray(s.qpos).copy()
+    s.step(200)
+    assert np.abs(np.asarray(s.qpos) - q_rest).max() < 1e-4 and np.abs(np.asarray(s.qvel)).max() < 1e-4
+    # every row obeys the Huber law force = clip(-D * (qacc - aref), +-frictionloss), and a fast joint saturates it
+    for i in range(7):
+        s.s.d.qvel[i] = 0.5 * (-1) ** i
+    s.step(1)
+    dd = s.s.d
+    assert dd.nefc == 7 and all(dd.efc_type[i] == 2 for i in range(7))
+    jar = np.array([dd.qacc_warmstart[i] - dd.efc_aref[i] for i in range(7)])  # qacc of the constraint solve
+    D = np.array(dd.efc_D[:7])
+    f = np.array(dd.efc_force[:7])
+    assert np.allclose(f, np.clip(-D * jar, -1.0, 1.0), atol=1e-9), (f, jar)
+    assert np.all(np.abs(np.abs(f) - 1.0) < 1e-12)
+
+
 def test_compiler_rejects_unknown_filetype(tmp_path):
     with pytest.raises(MjcfError):
         compile_mjcf(str(tmp_path / "scene.mjb"))
