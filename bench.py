@@ -98,6 +98,7 @@ def main() -> None:
     ap.add_argument("--mode", choices=["async", "convergence"], default="async")
     ap.add_argument("--control", choices=["joints", "cartesian"], default="joints",
                     help="cartesian = BASELINE configs[2]: relative TRPY actions -> CLIK -> joint targets (not the headline)")
+    ap.add_argument("--robot", choices=["fr3", "xarm7"], default="fr3", help="xarm7: 7-dof arm with dry joint friction, no gripper (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
@@ -138,9 +139,9 @@ def main() -> None:
         from rcs_amd.envs import ControlMode
 
         env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank,
-                           control_mode=ControlMode.CARTESIAN_TRPY, max_relative_movement=(0.2, float(np.deg2rad(45))))
+                           control_mode=ControlMode.CARTESIAN_TRPY, max_relative_movement=(0.2, float(np.deg2rad(45))), robot=args.robot)
     else:
-        env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank)
+        env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=args.robot)
     env.sim.set_stream(torch.cuda.current_stream().cuda_stream)
     L, h = env._L, env.sim._h
 
@@ -230,7 +231,8 @@ def main() -> None:
             "config": {
                 "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off"
                              if args.control == "joints" else
-                             f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"),
+                             f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
+                             ).replace("fr3_empty_world", f"{args.robot}_empty_world"),
                 "mode": "async_control 30Hz (17 substeps/env-step)" if args.mode == "async" else "step_until_convergence (cap 500)",
                 "envs_per_gpu": n,
                 "substeps_per_env_step": mean_sub,

@@ -172,18 +172,21 @@ RCSH_D void newton_rows(const DevModel& m, const StageTeam<T>& st, uint32_t limr
   for (int i = 0; i < NL; ++i) {
     fF[i] = 0; fD[i] = 0; fA[i] = 0; fR[i] = 0;
     if constexpr (FRIC) {
-      fF[i] = m.fl_floss[i]; fD[i] = m.fl_D[i]; fA[i] = st.fa(i);
-      fR[i] = fF[i] > 0 ? fF[i] / fD[i] : 0.0;
+      fF[i] = m.fl_floss[i]; fD[i] = m.fl_D[i]; fA[i] = st.fa(i); fR[i] = m.fl_R[i];
       if (fF[i] > 0) frows |= 1u << i;
     }
   }
   uint32_t act = limrows;      // limit rows in their quadratic zone (first guess: all)
-  uint32_t fneg = 0, fpos = 0; // friction rows in the linear zones (first guess: the zones of qacc = 0)
+  // friction rows in the linear zones.  First guess: the zones of the previous substep's solution, which the
+  // environment's block still holds (zero at the first substep of a launch) -- MuJoCo warm-starts its solver the same
+  // way (qacc_warmstart); the minimiser found does not depend on the guess, the iteration count does.
+  uint32_t fneg = 0, fpos = 0;
 #pragma unroll
   for (int i = 0; i < NL; ++i)
     if (frows & (1u << i)) {
-      if (-fA[i] <= -fR[i]) fneg |= 1u << i;
-      else if (-fA[i] >= fR[i]) fpos |= 1u << i;
+      const double jf = st.xs(i) - fA[i];
+      if (jf <= -fR[i]) fneg |= 1u << i;
+      else if (jf >= fR[i]) fpos |= 1u << i;
     }
   bool have_x = false;
   for (int iter = 0; iter < 32; ++iter) {
@@ -768,7 +771,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
       for (int i = 0; i < NL; ++i) {
         const double fF = m.fl_floss[i], fD = m.fl_D[i];
         if (fF > 0) {
-          const double jf = xs[i] - st.fa(i), fR = fF / fD;
+          const double jf = xs[i] - st.fa(i), fR = m.fl_R[i];
           rhs[i] += jf <= -fR ? fF : (jf >= fR ? -fF : -fD * jf);
         }
       }

@@ -350,13 +350,14 @@ std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& ac
   // at distance 0; R = (1 - imp) / imp * dof_invweight0, floored like every regulariser
   m.has_friction = 0;
   m.pad3 = 0;
-  for (int i = 0; i < kMaxLinks; ++i) { m.fl_floss[i] = 0; m.fl_D[i] = 0; m.fl_B[i] = 0; }
+  for (int i = 0; i < kMaxLinks; ++i) { m.fl_floss[i] = 0; m.fl_D[i] = 0; m.fl_B[i] = 0; m.fl_R[i] = 0; }
   for (int i = 0; i < nl; ++i) {
     m.fl_floss[i] = h.dof_frictionloss[i];
     if (h.dof_frictionloss[i] <= 0) continue;
     m.has_friction = 1;
     const double imp = impedance(make_imp(&h.dof_solimp[5 * i]), 0.0, 0.0);
     m.fl_D[i] = row_D(imp, m.invweight0[i]);
+    m.fl_R[i] = m.fl_floss[i] / m.fl_D[i];
     double K;
     make_kb(&h.dof_solref[2 * i], &h.dof_solimp[5 * i], h.timestep, K, m.fl_B[i]);
   }

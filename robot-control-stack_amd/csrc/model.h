@@ -103,6 +103,7 @@ struct DevModel {
   double fl_floss[kMaxLinks];
   double fl_D[kMaxLinks];
   double fl_B[kMaxLinks];
+  double fl_R[kMaxLinks];  // half-width of the quadratic zone: frictionloss / D
 };
 
 }  // namespace rcsh
