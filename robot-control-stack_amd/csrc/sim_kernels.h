@@ -543,20 +543,30 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
 // one wavefront per workgroup.  Lane 0 of a team (the leader) owns the RCS bookkeeping -- wrappers, callback
 // scheduler, observation -- through the same helpers as k_run; all 16 lanes run the physics.
 template <class T, bool FRIC>
-__global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
+__global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
   __shared__ DevModel lm;
-  __shared__ CollTable lc;  // indexed per lane (link) below, which a kernel argument cannot be
+  // The kernel arguments move to LDS too.  As arguments they sit in ~100 SGPRs that the leader-only code (wrappers,
+  // callbacks, observation) keeps alive across the whole substep loop, and the loop then spills and reloads them
+  // around its own scalar needs every iteration; from LDS they are read where that rare code runs.  (The
+  // collision table inside is also indexed per lane, which a kernel argument cannot be.)
+  __shared__ Params lp;
+  __shared__ RunOp lop;
   __shared__ __attribute__((aligned(16))) double lds[ST::COUNT * kTeams];
   {
-    static_assert(sizeof(CollTable) % 8 == 0, "copied in 8-byte words");
-    for (int k = threadIdx.x; k < (int)(sizeof(CollTable) / 8); k += 64)
-      reinterpret_cast<double*>(&lc)[k] = reinterpret_cast<const double*>(&P.coll)[k];
+    static_assert(sizeof(Params) % 8 == 0 && sizeof(RunOp) % 8 == 0, "copied in 8-byte words");
+    for (int k = threadIdx.x; k < (int)(sizeof(Params) / 8); k += 64)
+      reinterpret_cast<double*>(&lp)[k] = reinterpret_cast<const double*>(&Pk)[k];
+    for (int k = threadIdx.x; k < (int)(sizeof(RunOp) / 8); k += 64)
+      reinterpret_cast<double*>(&lop)[k] = reinterpret_cast<const double*>(&opk)[k];
   }
+  const Params& P = lp;
+  const RunOp& op = lop;
+  const CollTable& lc = lp.coll;
   {
     constexpr int kWords = sizeof(DevModel) / 8;
-    const double* src = reinterpret_cast<const double*>(P.model);
+    const double* src = reinterpret_cast<const double*>(Pk.model);
     double* dst = reinterpret_cast<double*>(&lm);
 #pragma unroll
     for (int it = 0; it < (kWords + 63) / 64; ++it) {
@@ -585,8 +595,8 @@ __global__ void __launch_bounds__(64) k_run_team(Params P, RunOp op) {
   int budget = 0;
   bool converged = false;
   if (leader) {
-    load_env<T, ST>(P, e, r);
-    env_prologue<T, ST>(P, op, m, e, r);
+    load_env<T, ST>(Pk, e, r);  // (prologue: straight from the arguments, they are still in registers)
+    env_prologue<T, ST>(Pk, opk, m, e, r);
     budget = nsteps;
     if (until_conv) {
       r.conv_steps = 0;
