@@ -343,14 +343,14 @@ RCSH_D void newton_rows(const DevModel& m, const StageTeam<T>& st, uint32_t limr
 struct KinK {
   double qpos0, rot0[9], pos0[3], axis[3], jpos[3];
   int32_t axis_z, jtype;
-  RCSH_D void load(const DevModel& m, int tl) {
-    qpos0 = m.qpos0[tl];
+  RCSH_D void load(const LinkRec& r) {
+    qpos0 = r.qpos0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) rot0[k] = m.rot0[tl][k];
+    for (int k = 0; k < 9; ++k) rot0[k] = r.rot0[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { pos0[k] = m.pos0[tl][k]; axis[k] = m.axis[tl][k]; jpos[k] = m.jpos[tl][k]; }
-    axis_z = m.axis_z[tl];
-    jtype = m.jtype[tl];
+    for (int k = 0; k < 3; ++k) { pos0[k] = r.pos0[k]; axis[k] = r.axis[k]; jpos[k] = r.jpos[k]; }
+    axis_z = r.axis_z;
+    jtype = r.jtype;
   }
 };
 // frame of a link in its parent link's frame at joint position q (kinematic part of mj_kinematics for one joint)
@@ -395,32 +395,31 @@ RCSH_D void link_local_frame(const KinK& kk, double q, double* R, double* p) {
 struct InertK {
   double mass, gcm, com[3], J[6];
   int32_t gc_same_com;
-  RCSH_D void load(const DevModel& m, int tl) {
-    mass = m.mass[tl];
-    gcm = m.gcm[tl];
+  RCSH_D void load(const LinkRec& r) {
+    mass = r.mass;
+    gcm = r.gcm;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) com[k] = m.com[tl][k];
+    for (int k = 0; k < 3; ++k) com[k] = r.com[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) J[k] = m.inertia[tl][k];
-    gc_same_com = m.gc_same_com[tl];
+    for (int k = 0; k < 6; ++k) J[k] = r.inertia[k];
+    gc_same_com = r.gc_same_com;
   }
 };
 struct ActK {
   int32_t has_act, ctrllimited, biasaffine, forcelimited, actgravcomp, actfrclimited, limited;
   double ctrlrange[2], gear, gain, bias[3], forcerange[2];
   double damping, actfrcrange[2], armature, gcm_sub, range[2], margin;
-  RCSH_D void load(const DevModel& m, int tl, int ta) {
-    has_act = m.arm_has_act[ta]; ctrllimited = m.arm_ctrllimited[ta]; biasaffine = m.arm_biasaffine[ta];
-    forcelimited = m.arm_forcelimited[ta];
-    ctrlrange[0] = m.arm_ctrlrange[ta][0]; ctrlrange[1] = m.arm_ctrlrange[ta][1];
-    gear = m.arm_gear[ta]; gain = m.arm_gain[ta];
-    bias[0] = m.arm_bias[ta][0]; bias[1] = m.arm_bias[ta][1]; bias[2] = m.arm_bias[ta][2];
-    forcerange[0] = m.arm_forcerange[ta][0]; forcerange[1] = m.arm_forcerange[ta][1];
-    actgravcomp = m.actgravcomp[tl]; actfrclimited = m.actfrclimited[tl]; limited = m.limited[tl];
-    damping = m.damping[tl];
-    actfrcrange[0] = m.actfrcrange[tl][0]; actfrcrange[1] = m.actfrcrange[tl][1];
-    armature = m.armature[tl]; gcm_sub = m.gcm_sub[tl];
-    range[0] = m.range[tl][0]; range[1] = m.range[tl][1]; margin = m.margin[tl];
+  RCSH_D void load(const LinkRec& r) {
+    has_act = r.arm_has_act; ctrllimited = r.arm_ctrllimited; biasaffine = r.arm_biasaffine; forcelimited = r.arm_forcelimited;
+    ctrlrange[0] = r.arm_ctrlrange[0]; ctrlrange[1] = r.arm_ctrlrange[1];
+    gear = r.arm_gear; gain = r.arm_gain;
+    bias[0] = r.arm_bias[0]; bias[1] = r.arm_bias[1]; bias[2] = r.arm_bias[2];
+    forcerange[0] = r.arm_forcerange[0]; forcerange[1] = r.arm_forcerange[1];
+    actgravcomp = r.actgravcomp; actfrclimited = r.actfrclimited; limited = r.limited;
+    damping = r.damping;
+    actfrcrange[0] = r.actfrcrange[0]; actfrcrange[1] = r.actfrcrange[1];
+    armature = r.armature; gcm_sub = r.gcm_sub;
+    range[0] = r.range[0]; range[1] = r.range[1]; margin = r.margin;
   }
 };
 
@@ -433,7 +432,7 @@ struct ActK {
 // FRIC: the model has dry joint friction rows (dof_frictionloss); a separate instantiation so that models without
 // them carry none of that code.
 template <class T, bool FRIC, class FrameFn>
-RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool stepping, FrameFn&& on_frame) {
+RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping, FrameFn&& on_frame) {
   static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
   constexpr int NL = T::NL, NA = T::NARM;
@@ -441,8 +440,9 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
   const int tl = valid ? t : NL - 1;
   const int ta = t < NA ? t : 0;
   const double h = m.timestep;
+  const LinkRec& lk = links[tl];
   KinK kk;
-  kk.load(m, tl);
+  kk.load(lk);
   const double q = st.q(tl), qd = st.v(tl);
   const double ctrl = st.c(ta);
   sched_fence();
@@ -453,7 +453,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
   link_local_frame(kk, q, R, p);
   TEAM_MARK(0)
   InertK ik;
-  ik.load(m, tl);
+  ik.load(lk);
   sched_fence();
   scan_frames<T>(R, p);  // now the world frame
   TEAM_MARK(1)
@@ -498,7 +498,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
   }
   TEAM_MARK(2)
   ActK ak;
-  ak.load(m, tl, ta);
+  ak.load(lk);
   sched_fence();
 
   // ---- spatial inertia about the world origin, bias wrench, gravity-compensation first moment
@@ -512,7 +512,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     if (ik.gc_same_com) {
       cg[0] = c[0]; cg[1] = c[1]; cg[2] = c[2];
     } else {
-      mulmv(R, m.gccom[tl], cg);
+      mulmv(R, lk.gccom, cg);
       cg[0] += p[0]; cg[1] += p[1]; cg[2] += p[2];
     }
     const double* J = ik.J;
@@ -658,8 +658,8 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     if (dlo < mg) { dist = dlo; sgn = 1; }
     else if (dhi < mg) { dist = dhi; sgn = -1; }
     if (sgn != 0) {
-      const Imp limp = m.lim_imp[tl];
-      const double lK = m.lim_K[tl], lB = m.lim_B[tl], iw = m.invweight0[tl];
+      const Imp limp = lk.lim_imp;
+      const double lK = lk.lim_K, lB = lk.lim_B, iw = lk.invweight0;
       sched_fence();
       const double imp = impedance(limp, dist, mg);
       lD = row_D(imp, iw);
@@ -676,7 +676,7 @@ RCSH_D void team_substep(const DevModel& m, const StageTeam<T>& st, int t, bool 
     st.limA(tl) = lA;
     st.limS(tl) = lS;
     st.dg(tl) = h * d;
-    if constexpr (FRIC) st.fa(tl) = -m.fl_B[tl] * qd;  // dry-friction row of the joint: aref (zero stiffness)
+    if constexpr (FRIC) st.fa(tl) = -lk.fl_B * qd;  // dry-friction row of the joint: aref (zero stiffness)
   }
   team_sync();
   TEAM_MARK(5)

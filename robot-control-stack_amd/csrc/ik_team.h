@@ -106,13 +106,13 @@ RCSH_D void se3_log_and_jlog_inverse(const double* R, const double* p, double* e
 // world placement of the site (same values on all lanes of the team); q: lane t's joint angle, in / out.
 // Returns success (uniform within the team); *iterations as Pin::inverse counts them.
 template <class T>
-RCSH_D bool clik_team(const DevModel& m, IkTeamBlock<T>& blk, int t, bool run, const double* Rd, const double* td, double& q,
-                      int* iterations) {
+RCSH_D bool clik_team(const DevModel& m, const LinkRec* links, IkTeamBlock<T>& blk, int t, bool run, const double* Rd,
+                      const double* td, double& q, int* iterations) {
   constexpr int NA = T::NARM;
   const bool joint = t < NA;
   const int tl = joint ? t : NA - 1;
   KinK kk;
-  kk.load(m, tl);
+  kk.load(links[tl]);
   double site_rot[9], site_pos[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) site_rot[k] = m.site_rot[k];

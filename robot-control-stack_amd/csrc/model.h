@@ -8,6 +8,7 @@
 // kernels read with wave-uniform (scalar) loads.
 #pragma once
 #include <cstdint>
+#include <cstring>
 
 namespace rcsh {
 
@@ -105,5 +106,51 @@ struct DevModel {
   double fl_B[kMaxLinks];
   double fl_R[kMaxLinks];  // half-width of the quadratic zone: frictionloss / D
 };
+
+// Per-link constants of the team kernels (dyn_team.h, ik_team.h) as an array of structures: lane t reads link t's
+// record through ONE base address with immediate offsets, and neighbouring fields merge into 16-byte LDS reads -- with
+// DevModel's per-field tables every table costs its own per-lane address register.  560 bytes: the records of links
+// 0..8 start in distinct LDS banks.  Filled from a DevModel by fill_link_records(); stored right behind the DevModel in
+// device memory.
+struct LinkRec {
+  double qpos0, rot0[9], pos0[3], axis[3], jpos[3];
+  double mass, gcm, com[3], inertia[6], gccom[3];
+  double damping, armature, gcm_sub, actfrcrange[2], range[2], margin;
+  double arm_ctrlrange[2], arm_gear, arm_gain, arm_bias[3], arm_forcerange[2];  // arm dofs only, else zero
+  double lim_K, lim_B, invweight0;
+  double fl_floss, fl_D, fl_B, fl_R;
+  Imp lim_imp;
+  int32_t axis_z, jtype, gc_same_com, arm_has_act, arm_ctrllimited, arm_biasaffine, arm_forcelimited, actgravcomp,
+      actfrclimited, limited;
+};
+static_assert(sizeof(LinkRec) == 560, "LDS bank spread of the records relies on this size");
+
+inline void fill_link_records(const DevModel& m, LinkRec* out) {
+  for (int i = 0; i < kMaxLinks; ++i) {
+    LinkRec& k = out[i];
+    std::memset(&k, 0, sizeof(k));
+    k.qpos0 = m.qpos0[i];
+    for (int j = 0; j < 9; ++j) k.rot0[j] = m.rot0[i][j];
+    for (int j = 0; j < 3; ++j) { k.pos0[j] = m.pos0[i][j]; k.axis[j] = m.axis[i][j]; k.jpos[j] = m.jpos[i][j]; k.com[j] = m.com[i][j]; k.gccom[j] = m.gccom[i][j]; }
+    for (int j = 0; j < 6; ++j) k.inertia[j] = m.inertia[i][j];
+    k.mass = m.mass[i]; k.gcm = m.gcm[i]; k.gcm_sub = m.gcm_sub[i];
+    k.damping = m.damping[i]; k.armature = m.armature[i];
+    k.actfrcrange[0] = m.actfrcrange[i][0]; k.actfrcrange[1] = m.actfrcrange[i][1];
+    k.range[0] = m.range[i][0]; k.range[1] = m.range[i][1]; k.margin = m.margin[i];
+    k.lim_K = m.lim_K[i]; k.lim_B = m.lim_B[i]; k.invweight0 = m.invweight0[i];
+    k.fl_floss = m.fl_floss[i]; k.fl_D = m.fl_D[i]; k.fl_B = m.fl_B[i]; k.fl_R = m.fl_R[i];
+    k.lim_imp = m.lim_imp[i];
+    k.axis_z = m.axis_z[i]; k.jtype = m.jtype[i]; k.gc_same_com = m.gc_same_com[i];
+    k.actgravcomp = m.actgravcomp[i]; k.actfrclimited = m.actfrclimited[i]; k.limited = m.limited[i];
+    if (i < m.narm && i < kMaxArm) {
+      k.arm_has_act = m.arm_has_act[i]; k.arm_ctrllimited = m.arm_ctrllimited[i]; k.arm_biasaffine = m.arm_biasaffine[i];
+      k.arm_forcelimited = m.arm_forcelimited[i];
+      k.arm_ctrlrange[0] = m.arm_ctrlrange[i][0]; k.arm_ctrlrange[1] = m.arm_ctrlrange[i][1];
+      k.arm_gear = m.arm_gear[i]; k.arm_gain = m.arm_gain[i];
+      for (int j = 0; j < 3; ++j) k.arm_bias[j] = m.arm_bias[i][j];
+      k.arm_forcerange[0] = m.arm_forcerange[i][0]; k.arm_forcerange[1] = m.arm_forcerange[i][1];
+    }
+  }
+}
 
 }  // namespace rcsh

@@ -45,7 +45,8 @@ struct rcsh_sim {
   int n = 0;
   HostModel hm;
   DevModel dm;
-  DevModel* d_model = nullptr;
+  DevModel* d_model = nullptr;     // DevModel followed by LinkRec[kMaxLinks]
+  std::vector<LinkRec> links;
   CollisionPoints cp;
   std::vector<uint8_t> cp_class;
   double* d_coll_xyzr = nullptr;
@@ -105,6 +106,11 @@ Params make_params(rcsh_sim* s) {
 
 int upload_model(rcsh_sim* s) {
   HIP_TRY(hipMemcpyAsync(s->d_model, &s->dm, sizeof(DevModel), hipMemcpyHostToDevice, s->stream));
+  // the team kernels' per-link records live right behind the DevModel
+  s->links.resize(kMaxLinks);
+  fill_link_records(s->dm, s->links.data());
+  HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(s->d_model) + sizeof(DevModel), s->links.data(), sizeof(LinkRec) * kMaxLinks,
+                         hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
 }
@@ -299,7 +305,7 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   HIP_NEW(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   const size_t n = (size_t)n_envs;
-  HIP_NEW(hipMalloc(&s->d_model, sizeof(DevModel)));
+  HIP_NEW(hipMalloc(&s->d_model, sizeof(DevModel) + sizeof(LinkRec) * kMaxLinks));
   {
     std::string cwhy = build_collision_points(s->hm, s->cp);
     if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);

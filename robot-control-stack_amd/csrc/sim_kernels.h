@@ -564,6 +564,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   const Params& P = lp;
   const RunOp& op = lop;
   const CollTable& lc = lp.coll;
+  __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
   {
     constexpr int kWords = sizeof(DevModel) / 8;
     const double* src = reinterpret_cast<const double*>(Pk.model);
@@ -572,6 +573,13 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     for (int it = 0; it < (kWords + 63) / 64; ++it) {
       const int k = it * 64 + threadIdx.x;
       if (k < kWords) dst[k] = src[k];
+    }
+    constexpr int kRecWords = sizeof(LinkRec) * T::NL / 8;
+    double* rdst = reinterpret_cast<double*>(llinks);
+#pragma unroll
+    for (int it = 0; it < (kRecWords + 63) / 64; ++it) {
+      const int k = it * 64 + threadIdx.x;
+      if (k < kRecWords) rdst[k] = src[kWords + k];
     }
     for (int k = threadIdx.x; k < ST::COUNT * kTeams; k += 64) lds[k] = 0.0;
     __syncthreads();
@@ -630,7 +638,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     }
     const bool want_contacts = team_ballot(due) != 0;
     uint32_t hit = 0;
-    team_substep<T, FRIC>(m, st, t, stepping, [&](const double* R, const double* p) {
+    team_substep<T, FRIC>(m, llinks, st, t, stepping, [&](const double* R, const double* p) {
       if (!want_contacts) return;
       const double* nrm = lc.plane_n;
       const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
@@ -848,6 +856,7 @@ __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
   using L = Lay<T>;
   constexpr int kTeams = 64 / kTeamLanes;
   __shared__ DevModel lm;
+  __shared__ LinkRec llinks[T::NARM];
   __shared__ IkTeamBlock<T> blocks[kTeams];
   __shared__ double desired[kTeams][12];
   {
@@ -858,6 +867,13 @@ __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
     for (int it = 0; it < (kWords + 63) / 64; ++it) {
       const int k = it * 64 + threadIdx.x;
       if (k < kWords) dst[k] = src[k];
+    }
+    constexpr int kRecWords = sizeof(LinkRec) * T::NARM / 8;
+    double* rdst = reinterpret_cast<double*>(llinks);
+#pragma unroll
+    for (int it = 0; it < (kRecWords + 63) / 64; ++it) {
+      const int k = it * 64 + threadIdx.x;
+      if (k < kRecWords) rdst[k] = src[kWords + k];
     }
     __syncthreads();
   }
@@ -890,7 +906,7 @@ __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
   const double q_now = joint ? S[(L::QPOS + t) * n + e] : 0.0;
   double q = q_now;
   int iters = 0;
-  const bool ok = clik_team<T>(m, blocks[team], t, run, Rd, td, q, &iters);
+  const bool ok = clik_team<T>(m, llinks, blocks[team], t, run, Rd, td, q, &iters);
   if (joint && ok) {  // SimRobot::set_joint_position(joint_vals), SimRobot.cpp:123-131,145-155
     S[(L::TARGET + t) * n + e] = q;
     S[(L::PREVQ + t) * n + e] = q_now;
