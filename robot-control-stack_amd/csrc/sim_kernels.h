@@ -564,6 +564,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   const Params& P = lp;
   const RunOp& op = lop;
   const CollTable& lc = lp.coll;
+  TEAM_CLOCK_START()
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
   {
     constexpr int kWords = sizeof(DevModel) / 8;
@@ -584,6 +585,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     for (int k = threadIdx.x; k < ST::COUNT * kTeams; k += 64) lds[k] = 0.0;
     __syncthreads();
   }
+  TEAM_MARK(12)
   const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
   // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  Give
   // every XCD one contiguous range of environments, so a 128-byte line of a state field ([field][env], 16
@@ -604,7 +606,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   bool converged = false;
   if (leader) {
     load_env<T, ST>(Pk, e, r);  // (prologue: straight from the arguments, they are still in registers)
+    TEAM_MARK(13)
     env_prologue<T, ST>(Pk, opk, m, e, r);
+    TEAM_MARK(14)
     budget = nsteps;
     if (until_conv) {
       r.conv_steps = 0;
@@ -674,6 +678,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
   }
   TEAM_MARK(10)
+  TEAM_CLOCK_FLUSH()
 }
 
 // ---- small elementwise kernels behind the 1:1 SimRobot / SimGripper / mjData accessors
