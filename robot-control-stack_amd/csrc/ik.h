@@ -163,7 +163,7 @@ RCSH_HD void site_fk(const DevModel& m, const double* q, double* Rs, double* ps,
 
 // 6x6 SPD solve, LDL^T in place (A row-major full), x <- A^-1 x
 RCSH_HD void ldl6_solve(double* A, double* x) {
-  double L[36], D[6];
+  double L[36], D[6], Dinv[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     double s = A[6 * j + j];
@@ -171,6 +171,7 @@ RCSH_HD void ldl6_solve(double* A, double* x) {
     for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k] * D[k];
     D[j] = s;
     const double inv = fast_rcp(s);
+    Dinv[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double t = A[6 * i + j];
@@ -184,7 +185,7 @@ RCSH_HD void ldl6_solve(double* A, double* x) {
 #pragma unroll
     for (int k = 0; k < i; ++k) x[i] -= L[6 * i + k] * x[k];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] *= fast_rcp(D[i]);
+  for (int i = 0; i < 6; ++i) x[i] *= Dinv[i];
 #pragma unroll
   for (int i = 5; i >= 0; --i)
 #pragma unroll
