@@ -27,7 +27,7 @@ namespace rcsh {
 constexpr int even_up(int x) { return (x + 1) & ~1; }
 
 // LDS block of one environment.  The first slots (q .. X) are the interface sim_kernels.h' environment code
-// uses (same accessor names as Stage / Stage4); the rest is the team's exchange area.
+// uses (same accessor names as dyn.h's Stage); the rest is the team's exchange area.
 template <class T>
 struct StageTeam {
   static constexpr int NL = T::NL;
@@ -37,8 +37,7 @@ struct StageTeam {
   static constexpr int C0 = V0 + NLP;                // ctrl
   static constexpr int P0 = C0 + even_up(T::NU);     // qpos seen by the last position stage
   static constexpr int K0 = P0 + NLP;                // frame of the site link: R(9) p(3)
-  static constexpr int A0 = K0 + 12;                 // 1.0 while the environment still steps in this launch
-  static constexpr int X0 = A0 + 2;                  // caller's slots
+  static constexpr int X0 = K0 + 12;                 // caller's slots
   static constexpr int NX = 6 + 2 * T::NARM;
   static constexpr int S0 = X0 + even_up(NX);        // motion axes [NL][6]
   static constexpr int MROW = NLP;                   // row stride of the mass matrix (rows 16-byte aligned)
@@ -60,7 +59,6 @@ struct StageTeam {
   RCSH_D double& c(int i) const { return base[C0 + i]; }
   RCSH_D double& qpre(int i) const { return base[P0 + i]; }
   RCSH_D double& link(int k) const { return base[K0 + k]; }
-  RCSH_D double& active() const { return base[A0]; }
   RCSH_D double& X(int k) const { return base[X0 + k]; }
   RCSH_D double& S(int i, int k) const { return base[S0 + 6 * i + k]; }
   RCSH_D double& M(int i, int j) const { return base[M0 + MROW * i + j]; }
