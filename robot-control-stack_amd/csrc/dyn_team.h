@@ -434,16 +434,26 @@ struct ActK {
   }
 };
 
+// true when every link's gravity-compensated mass and centre are its mass and centre of mass (gravcomp = 1 on all
+// bodies): then two of the leaf->root scans of team_substep are redundant.  Same answer on every lane of the wave.
+template <class T>
+RCSH_D bool team_gc_is_mass(const LinkRec* links, int t) {
+  const int tl = t < T::NL ? t : T::NL - 1;
+  return __ballot(!(links[tl].gcm == links[tl].mass && links[tl].gc_same_com)) == 0;
+}
+
 // One substep of the environment whose LDS block is `st`, executed by its 16 lanes together (t = lane in team).
 // Reads qpos / qvel / ctrl from the block and, if `stepping`, writes the advanced qpos / qvel, the pre-step qpos
 // and the pre-step world frame of the attachment-site link back (same contract as dyn.h's substep).
 // `on_frame(R, p)` is called on every lane with the world frame of the lane's link at the pre-step qpos (what the
 // contact detection of the last mj_step1 sees).
 // Contains team_sync()s: every lane of the wave must call it.
+// `gc_is_mass` (wave-uniform, see team_gc_is_mass): shortcut for fully gravity-compensated models.
 // FRIC: the model has dry joint friction rows (dof_frictionloss); a separate instantiation so that models without
 // them carry none of that code.
 template <class T, bool FRIC, class FrameFn>
-RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping, FrameFn&& on_frame) {
+RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping, bool gc_is_mass,
+                         FrameFn&& on_frame) {
   static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
   constexpr int NL = T::NL, NA = T::NARM;
@@ -546,11 +556,19 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
     cross_force(vel, Iv, vf);
     const bool ff = T::GRIP && t == NA;
 #pragma unroll
-    for (int k = 0; k < 10; ++k) Ic[k] = scan_from_leaves<T>(Ii[k], ff);
+    for (int k = 0; k < 9; ++k) Ic[k] = scan_from_leaves<T>(Ii[k], ff);
 #pragma unroll
     for (int k = 0; k < 6; ++k) F[k] = scan_from_leaves<T>(Ia[k] + vf[k], ff);
+    if (gc_is_mass) {
+      // every body fully gravity-compensated (gravcomp = 1, the RCS scenes): the compensated first moment IS the
+      // first moment of the composite inertia, and the subtree mass is the model constant gcm_sub
+      Ic[9] = valid ? ak.gcm_sub : 0.0;
+      hs[0] = Ic[6]; hs[1] = Ic[7]; hs[2] = Ic[8];
+    } else {
+      Ic[9] = scan_from_leaves<T>(Ii[9], ff);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) hs[k] = scan_from_leaves<T>(gcm * cg[k], ff);
+      for (int k = 0; k < 3; ++k) hs[k] = scan_from_leaves<T>(gcm * cg[k], ff);
+    }
   }
   TEAM_MARK(3)
 
