@@ -174,8 +174,8 @@ int rcsh_sim_synchronize(rcsh_sim* sim);
 void* rcsh_sim_stream(rcsh_sim* sim);
 int rcsh_sim_set_stream(rcsh_sim* sim, void* hip_stream);
 /* Which kernel computes step / step_until_convergence / env step (no reference counterpart: the reference has
- * one CPU code path).  RCSH_KERNEL_AUTO picks by batch size; the other two pin a variant (parity tests run
- * both).  The environment variable RCSH_KERNEL=team|lane sets the default of new handles. */
+ * one CPU code path).  RCSH_KERNEL_AUTO is the team kernel (16 lanes per environment; the faster one at every batch
+ * size measured); RCSH_KERNEL_LANE pins the one-lane-per-environment kernel (parity tests run both).  The environment variable RCSH_KERNEL=team|lane sets the default of new handles. */
 enum { RCSH_KERNEL_AUTO = 0, RCSH_KERNEL_TEAM = 1, RCSH_KERNEL_LANE = 2 };
 int rcsh_sim_set_kernel(rcsh_sim* sim, int32_t variant);
 

@@ -32,7 +32,6 @@ int fail(int code, const std::string& msg) {
 
 constexpr int kBlock = 64;     // accessor kernels
 constexpr int kRunLanes = 16;                // environments per workgroup of k_run
-constexpr int kTeamKernelMaxEnvs = 131072;  // crossover of k_run_team and k_run (tools/sweep_envs.sh)
 constexpr int kProfRing = 4096;
 
 }  // namespace
@@ -146,14 +145,13 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
     HIP_TRY(hipEventRecord(s->ev_start[s->prof_pending], s->stream));
   }
   // Two kernels compute the same launch (sim_kernels.h):
-  //  * k_run_team: 16 lanes per environment, 4 environments per wavefront.  4096 environments are 1024
-  //    wavefronts = one per SIMD of the chip; measured 23-28 M env-steps/s from 4096 to 65536 environments.
+  //  * k_run_team (the default): 16 lanes per environment, 4 environments per wavefront.  4096 environments are 1024
+  //    wavefronts = one per SIMD of the chip; measured 29 M env-steps/s at 4096 environments, 33 M from 65536 up.
   //  * k_run: one lane per environment, 16 environments per workgroup (the 52 KB LDS staging block per workgroup
-  //    caps it at three workgroups per CU).  2.5x slower at 4096 environments (9.5 M), ahead only once the
-  //    chip is oversubscribed (30 M vs 28 M at 262144).
-  // rcsh_sim_set_kernel / RCSH_KERNEL=team|lane pin the choice (parity tests run both).
-  // (dry joint friction rows exist in the team kernel only; rcsh_sim_set_kernel refuses the lane kernel for such models)
-  const bool team = s->dm.has_friction || (s->kernel ? s->kernel == RCSH_KERNEL_TEAM : s->n < kTeamKernelMaxEnvs);
+  //    caps it at three workgroups per CU): 9.5 M at 4096 environments, 30 M at 524288.  It no longer wins at any
+  //    batch size (tools/sweep_envs.sh); it stays as an independent second formulation that the parity tests run
+  //    against the same oracle (rcsh_sim_set_kernel / RCSH_KERNEL=lane).  It has no dry-friction rows.
+  const bool team = s->dm.has_friction || s->kernel != RCSH_KERNEL_LANE;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
     if (team && s->dm.has_friction)
@@ -544,7 +542,7 @@ int launch_cartesian(rcsh_sim* s, const CartOp& op) {
   hipError_t err = hipSuccess;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    if (s->kernel ? s->kernel == RCSH_KERNEL_TEAM : s->n < kTeamKernelMaxEnvs)
+    if (s->kernel != RCSH_KERNEL_LANE)
       hipLaunchKernelGGL(k_cartesian_team<T>, dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     else
       hipLaunchKernelGGL(k_cartesian<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, op);

@@ -103,7 +103,7 @@ class Sim:
         _lib.check(self._L.rcsh_sim_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def set_kernel(self, variant: str) -> None:
-        """Pin the kernel variant: "auto" (by batch size), "team" (16 lanes per environment) or "lane" (one)."""
+        """Pin the kernel variant: "auto" / "team" (16 lanes per environment, the default) or "lane" (one lane)."""
         _lib.check(self._L.rcsh_sim_set_kernel(self._h, {"auto": 0, "team": 1, "lane": 2}[variant]))
 
     def synchronize(self) -> None:

@@ -54,7 +54,8 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None, relative_to=RelativeTo.LAST_STEP,
         n_envs=n_envs, device=device,
     )
-    venv.sim.set_kernel(KERNEL)
+    if KERNEL != "auto":  # "auto" leaves the handle's default (batch-size rule, or the RCSH_KERNEL environment variable)
+        venv.sim.set_kernel(KERNEL)
     return venv
 
 
@@ -198,7 +199,8 @@ def run_physics_parity_mid_stroke(n_envs=64, n_calls=6, k=17, seed=0):
 
     cfg = default_sim_robot_cfg("fr3_empty_world")
     simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
-    simu.set_kernel(KERNEL)
+    if KERNEL != "auto":
+        simu.set_kernel(KERNEL)
     robot = S.SimRobot(simu, None, cfg)
     grip = S.SimGripper(simu, default_sim_gripper_cfg())
     cm = compile_mjcf(SCENE)
@@ -245,7 +247,8 @@ def run_physics_parity_at_joint_limits(n_envs=32, n_calls=8, k=17, seed=0, n_ove
 
     cfg = default_sim_robot_cfg("fr3_empty_world")
     simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
-    simu.set_kernel(KERNEL)
+    if KERNEL != "auto":
+        simu.set_kernel(KERNEL)
     robot = S.SimRobot(simu, None, cfg)
     grip = S.SimGripper(simu, default_sim_gripper_cfg())
     cm = compile_mjcf(SCENE)
