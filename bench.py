@@ -130,6 +130,10 @@ def main() -> None:
     ap.add_argument("--mode", choices=["async", "convergence"], default="async")
     ap.add_argument("--control", choices=["joints", "cartesian"], default="joints",
                     help="cartesian = BASELINE configs[2]: relative TRPY actions -> CLIK -> joint targets (not the headline)")
+    ap.add_argument("--episode-length", type=int, default=None,
+                    help="env.reset() every this many steps (inside the timed region; resets are not counted as env-steps). "
+                         "Default: none for joints; 10 for cartesian, as the reference's examples loop (reset + 10 steps) -- a longer "
+                         "random walk of Cartesian targets leaves the workspace and the CLIK then runs to its 1000-iteration cap")
     ap.add_argument("--robot", choices=["fr3", "xarm7"], default="fr3", help="xarm7: 7-dof arm with dry joint friction, no gripper (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
@@ -195,7 +199,11 @@ def main() -> None:
 
     exchange = ObservationExchange(n, ow, torch.float64, "cuda") if world > 1 else None
 
+    episode = args.episode_length if args.episode_length is not None else (10 if args.control == "cartesian" else 0)
+
     def one_step(t: int) -> None:
+        if episode and t % episode == 0:
+            env.reset_dev(obs.data_ptr(), info.data_ptr(), gw.data_ptr())
         o = exchange.local(t) if exchange else obs
         env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
         if exchange:
@@ -269,6 +277,7 @@ def main() -> None:
                 "envs_per_gpu": n,
                 "substeps_per_env_step": mean_sub,
                 "physics_substeps_per_s": value * mean_sub,
+                "episode_length": episode or None,
                 "exchange": "RCCL all_gather_into_tensor of obs [N,21] f64 per step, double-buffered, overlapped with the next env-step" if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
             },
