@@ -38,7 +38,7 @@ XARM7_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes",
 
 
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
-                 max_relative_movement=None, robot: str = "fr3"):
+                 max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step"):
     from rcs_amd import sim
     from rcs_amd.envs import ControlMode, RelativeTo, SimEnvCreator, default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg
 
@@ -51,7 +51,8 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
     venv = SimEnvCreator()(
         mode, xarm7_sim_robot_cfg() if robot == "xarm7" else default_sim_robot_cfg("fr3_empty_world"),
         gripper_cfg=default_sim_gripper_cfg() if gripper else None,
-        sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None, relative_to=RelativeTo.LAST_STEP,
+        sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None,
+        relative_to=RelativeTo.LAST_STEP if relative_to == "last_step" else RelativeTo.CONFIGURED_ORIGIN,
         n_envs=n_envs, device=device,
     )
     if KERNEL != "auto":  # "auto" leaves the handle's default (batch-size rule, or the RCSH_KERNEL environment variable)
@@ -60,7 +61,7 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
 
 
 def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, mode: str = "joints",
-                     max_relative_movement=None, robot: str = "fr3"):
+                     max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step"):
     from rcs_amd.mjcf import compile_mjcf
     from rcs_env_oracle import XARM7, OracleEnv
 
@@ -68,15 +69,15 @@ def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, rel
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
     return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot == "fr3", max_relative_movement=max_relative_movement if relative else None,
-                      async_control=async_control, robot=XARM7 if robot == "xarm7" else None) for _ in range(n_envs)]
+                      async_control=async_control, robot=XARM7 if robot == "xarm7" else None, relative_to=relative_to) for _ in range(n_envs)]
 
 
 def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: bool = True, seed: int = 0, gripper: bool = True,
-                             episodes: int = 1, robot: str = "fr3"):
+                             episodes: int = 1, robot: str = "fr3", relative_to: str = "last_step"):
     """Fused HIP env-step vs the oracle on the same seeded actions; returns max abs differences + flag mismatches."""
     gripper = gripper and robot == "fr3"
-    venv = make_vec_env(n_envs, async_control, gripper=gripper, robot=robot)
-    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot)
+    venv = make_vec_env(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to)
+    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to)
     joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed)
     rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_finger": 0.0, "max_abs_gripper_width": 0.0,
            "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}
@@ -143,14 +144,17 @@ def cartesian_actions(n_envs: int, n_steps: int, seed: int = 0):
     return act, grip
 
 
-def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=0, mode="xyzrpy", relative=True, gripper=True):
+def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=0, mode="xyzrpy", relative=True, gripper=True,
+                                 relative_to: str = "last_step"):
     """Cartesian control (relative TRPY / TQuat actions -> CLIK -> joint targets): HIP path vs the oracle."""
     from rcs_amd.envs import ControlMode
 
     cm = ControlMode.CARTESIAN_TRPY if mode == "xyzrpy" else ControlMode.CARTESIAN_TQuat
     mm = (0.2, float(np.deg2rad(45)))
-    venv = make_vec_env(n_envs, async_control, gripper=gripper, relative=relative, control_mode=cm, max_relative_movement=mm)
-    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, relative=relative, mode=mode, max_relative_movement=mm)
+    venv = make_vec_env(n_envs, async_control, gripper=gripper, relative=relative, control_mode=cm, max_relative_movement=mm,
+                        relative_to=relative_to)
+    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, relative=relative, mode=mode, max_relative_movement=mm,
+                             relative_to=relative_to)
     act6, grip = cartesian_actions(n_envs, n_steps, seed)
     rep = {"max_abs_qpos": 0.0, "max_abs_tquat": 0.0, "max_abs_target": 0.0, "flag_mismatches": 0, "steps": 0, "ik_fail": 0}
     obs, info = venv.reset()

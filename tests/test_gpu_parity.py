@@ -79,6 +79,19 @@ def test_cartesian_relative_clik(mode):
     assert rep["flag_mismatches"] == 0, rep
 
 
+@pytest.mark.parametrize("mode", ["joints", "xyzrpy", "tquat"])
+def test_relative_to_configured_origin(mode):
+    """RelativeTo.CONFIGURED_ORIGIN (base.py:490-565): actions are offsets from the origin fixed at reset, and the step
+    limit applies to the CHANGE of the offset (`_last_action`), not to the offset itself."""
+    if mode == "joints":
+        rep = run_joint_rollout_parity(n_envs=32, n_steps=6, async_control=True, seed=13, relative_to="configured_origin")
+        assert rep["max_abs_obs"] < TOL and rep["max_abs_finger"] < FINGER_TOL, rep
+    else:
+        rep = run_cartesian_rollout_parity(n_envs=24, n_steps=6, async_control=True, seed=13, mode=mode, relative_to="configured_origin")
+        assert rep["max_abs_target"] < TOL and rep["max_abs_tquat"] < TOL, rep
+    assert rep["max_abs_qpos"] < TOL and rep["flag_mismatches"] == 0, rep
+
+
 def test_cartesian_absolute_until_convergence():
     rep = run_cartesian_rollout_parity(n_envs=16, n_steps=2, async_control=False, seed=5, mode="xyzrpy", relative=False, gripper=False)
     assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL, rep
