@@ -51,7 +51,8 @@ struct StageTeam {
   static constexpr int XS0 = E0 + 4;                 // solver result (constrained qacc of the soft problem)
   static constexpr int QA0 = XS0 + NLP;              // qacc of the implicit solve
   static constexpr int FA0 = QA0 + NLP;              // dry-friction rows: aref (-B * qvel)
-  static constexpr int COUNT = FA0 + NLP;
+  static constexpr int Y0 = FA0 + NLP;               // helper lanes' solutions with the implicit matrix, [5][NLP]
+  static constexpr int COUNT = Y0 + 5 * NLP;
   double* base;
   RCSH_D double& at(int k) const { return base[k]; }
   RCSH_D double& q(int i) const { return base[Q0 + i]; }
@@ -71,6 +72,7 @@ struct StageTeam {
   RCSH_D double& xs(int i) const { return base[XS0 + i]; }
   RCSH_D double& qacc(int i) const { return base[QA0 + i]; }
   RCSH_D double& fa(int i) const { return base[FA0 + i]; }
+  RCSH_D double& Y(int k, int i) const { return base[Y0 + NLP * k + i]; }
 };
 
 #ifdef RCSH_PHASE_TIMING
@@ -710,18 +712,27 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   team_sync();
   TEAM_MARK(5)
 
-  // ---- the factorisation slot
+  // ---- the factorisation slot.  Roles by lane (all run the same instructions on different matrices / right-hand sides):
+  //   solver lanes s < 2^k   H = M + rows of the s-th active-set guess,        rhs = qfrc_smooth + row terms
+  //   helper lanes 11..15    H = A = M - h dF/dqd (the implicitfast matrix),   rhs = qfrc_smooth (15), the coupling
+  //                          row's Jacobian (14), the unit vectors of the up-to-3 limit-row joints (13, 12, 11)
+  // The constraint force is a combination of those Jacobians, so once the winning guess is known
+  //   qacc = A^-1 (qfrc_smooth + qfrc_constraint) = y15 + fe y14 + c0 y13 + c1 y12 + c2 y11
+  // is five multiply-adds per lane -- no second, serial solve.  (Models with dry friction put a force on every joint:
+  // they keep one implicit lane, 15, that solves again after the constraint solve; so does the rare fallback.)
   const bool has_eq = T::GRIP && m.eq_active;
   const int nrows = __popc(limrows);
-  const bool implicit_lane = t == kTeamLanes - 1;
-  // lane s guesses: the s-th subset of the existing limit rows is active
+  const bool helper_lane = FRIC ? t == kTeamLanes - 1 : t >= kTeamLanes - 5;
+  // lane s guesses: the s-th subset of the existing limit rows is active; idx0..2: the joints of the first three rows
   uint32_t act = 0;
+  int idx0 = -1, idx1 = -1, idx2 = -1;
   {
     int c = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const bool exists = (limrows >> i) & 1u;
       if (exists && ((t >> c) & 1)) act |= 1u << i;
+      if (exists) { if (c == 0) idx0 = i; else if (c == 1) idx1 = i; else if (c == 2) idx2 = i; }
       c += exists ? 1 : 0;
     }
   }
@@ -738,25 +749,31 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
     for (int i = 0; i < NL; ++i) { sm[i] = st.smooth(i); lDv[i] = st.limD(i); lAv[i] = st.limA(i); lSv[i] = st.limS(i); dgv[i] = st.dg(i); }
     if (T::GRIP) { eqD = st.eq(0); eqAref = st.eq(1); eqJ1 = st.eq(2); gblock = st.eq(3); }
     sched_fence();
+    // unit-vector helpers: which joint; the coupling helper: e_NA + eqJ1 e_NA+1
+    const int unit = t == kTeamLanes - 3 ? idx0 : (t == kTeamLanes - 4 ? idx1 : (t == kTeamLanes - 5 ? idx2 : -1));
+    const bool smooth_helper = t == kTeamLanes - 1, eq_helper = !FRIC && t == kTeamLanes - 2;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const bool on = (act >> i) & 1u;
       const double dsolve = on ? lDv[i] : 0.0;
-      H[tri(i, i)] += implicit_lane ? dgv[i] : dsolve;
-      x[i] = sm[i] + (on ? lSv[i] * lDv[i] * lAv[i] : 0.0);
+      H[tri(i, i)] += helper_lane ? dgv[i] : dsolve;
+      const double xsolve = sm[i] + (on ? lSv[i] * lDv[i] * lAv[i] : 0.0);
+      double xhelp = smooth_helper ? sm[i] : (i == unit ? 1.0 : 0.0);
+      if (T::GRIP && eq_helper) xhelp = i == NA ? 1.0 : (i == NA + 1 ? eqJ1 : 0.0);
+      x[i] = helper_lane ? xhelp : xsolve;
     }
   }
   if constexpr (T::GRIP) {
     const double c0 = m.grp_coef[0], c1 = m.grp_coef[1], hg = h * gblock;
     const double e = has_eq ? eqD : 0.0;
-    H[tri(NA, NA)] += implicit_lane ? hg * c0 * c0 : e;
-    H[tri(NA + 1, NA)] += implicit_lane ? hg * c0 * c1 : e * eqJ1;
-    H[tri(NA + 1, NA + 1)] += implicit_lane ? hg * c1 * c1 : e * eqJ1 * eqJ1;
-    x[NA] += e * eqAref;
-    x[NA + 1] += e * eqAref * eqJ1;
+    H[tri(NA, NA)] += helper_lane ? hg * c0 * c0 : e;
+    H[tri(NA + 1, NA)] += helper_lane ? hg * c0 * c1 : e * eqJ1;
+    H[tri(NA + 1, NA + 1)] += helper_lane ? hg * c1 * c1 : e * eqJ1 * eqJ1;
+    x[NA] += helper_lane ? 0.0 : e * eqAref;
+    x[NA + 1] += helper_lane ? 0.0 : e * eqAref * eqJ1;
   }
   ldl_factor<NL>(H);
-  ldl_solve<NL>(H, x);  // meaningless on the implicit lane, which solves below
+  ldl_solve<NL>(H, x);
   uint32_t now = 0;
   {
     double lAv[NL], lSv[NL];
@@ -768,10 +785,14 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
       if (((limrows >> i) & 1u) && lSv[i] * x[i] - lAv[i] < 0) now |= 1u << i;
   }
   const uint32_t winners = team_ballot(solver_lane && now == act);
+  const bool superpose = !FRIC && winners != 0;  // uniform within the team
   if (winners) {
-    if (t == __ffs(winners) - 1) {
+    const bool winner = t == __ffs(winners) - 1;
+    if (winner || (!FRIC && helper_lane)) {
+      // the winner publishes x, the helpers their solutions y (row t - 11 of Y)
+      double* dst = winner ? &st.xs(0) : &st.Y(t - (kTeamLanes - 5), 0);
 #pragma unroll
-      for (int i = 0; i < NL; ++i) st.xs(i) = x[i];
+      for (int i = 0; i < NL; ++i) dst[i] = x[i];
     }
   } else {
     double xs[NL];
@@ -784,39 +805,76 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   team_sync();
   TEAM_MARK(6)
 
-  // ---- implicitfast: (M - h dF/dqd) qacc = smooth + constraint force, solved by the lane that factored it
-  if (implicit_lane) {
-    double xs[NL], rhs[NL], lDv[NL], lAv[NL], lSv[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { xs[i] = st.xs(i); rhs[i] = st.smooth(i); lDv[i] = st.limD(i); lAv[i] = st.limA(i); lSv[i] = st.limS(i); }
-    sched_fence();
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const double r = lSv[i] * xs[i] - lAv[i];
-      if (((limrows >> i) & 1u) && r < 0) rhs[i] -= lSv[i] * lDv[i] * r;
+  // ---- implicitfast: (M - h dF/dqd) qacc = qfrc_smooth + qfrc_constraint
+  double qacc = 0.0;
+  if (superpose) {
+    // qacc_t = y15[t] + fe y14[t] + sum_k c_k y(13-k)[t], the coefficients from the winner's x (every lane recomputes
+    // the same four numbers; the joints of the limit rows are run-time indices into the LDS block)
+    qacc = st.Y(4, tl);
+    if constexpr (T::GRIP) if (has_eq) {
+      const double fe = -eqD * (st.xs(NA) + eqJ1 * st.xs(NA + 1) - eqAref);
+      qacc += fe * st.Y(3, tl);
     }
-    if constexpr (FRIC) {
+    const int idx[3] = {idx0, idx1, idx2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (idx[k] < 0) continue;
+      const int i = idx[k];
+      const double sgn = st.limS(i), r = sgn * st.xs(i) - st.limA(i);
+      if (r < 0) qacc += -sgn * st.limD(i) * r * st.Y(2 - k, tl);
+    }
+  } else {
+    // one lane solves after the constraint solve (models with dry friction; fallback of the others, which must
+    // factor A again because the slot's factor is gone)
+    if (t == kTeamLanes - 1) {
+      double xs[NL], rhs[NL], lDv[NL], lAv[NL], lSv[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) { xs[i] = st.xs(i); rhs[i] = st.smooth(i); lDv[i] = st.limD(i); lAv[i] = st.limA(i); lSv[i] = st.limS(i); }
+      sched_fence();
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const double fF = m.fl_floss[i], fD = m.fl_D[i];
-        if (fF > 0) {
-          const double jf = xs[i] - st.fa(i), fR = m.fl_R[i];
-          rhs[i] += jf <= -fR ? fF : (jf >= fR ? -fF : -fD * jf);
+        const double r = lSv[i] * xs[i] - lAv[i];
+        if (((limrows >> i) & 1u) && r < 0) rhs[i] -= lSv[i] * lDv[i] * r;
+      }
+      if constexpr (FRIC) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const double fF = m.fl_floss[i], fD = m.fl_D[i];
+          if (fF > 0) {
+            const double jf = xs[i] - st.fa(i), fR = m.fl_R[i];
+            rhs[i] += jf <= -fR ? fF : (jf >= fR ? -fF : -fD * jf);
+          }
         }
       }
-    }
-    if constexpr (T::GRIP) if (has_eq) {
-      const double fe = -eqD * (xs[NA] + eqJ1 * xs[NA + 1] - eqAref);
-      rhs[NA] += fe;
-      rhs[NA + 1] += fe * eqJ1;
-    }
-    ldl_solve<NL>(H, rhs);
+      if constexpr (T::GRIP) if (has_eq) {
+        const double fe = -eqD * (xs[NA] + eqJ1 * xs[NA + 1] - eqAref);
+        rhs[NA] += fe;
+        rhs[NA + 1] += fe * eqJ1;
+      }
+      if constexpr (!FRIC) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) st.qacc(i) = rhs[i];
+        for (int i = 0; i < NL; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) H[tri(i, j)] = st.M(i, j);
+          H[tri(i, i)] += st.dg(i);
+        }
+        if constexpr (T::GRIP) {
+          const double c0 = m.grp_coef[0], c1 = m.grp_coef[1], hg = h * gblock;
+          H[tri(NA, NA)] += hg * c0 * c0;
+          H[tri(NA + 1, NA)] += hg * c0 * c1;
+          H[tri(NA + 1, NA + 1)] += hg * c1 * c1;
+        }
+        ldl_factor<NL>(H);
+      }
+      ldl_solve<NL>(H, rhs);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) st.qacc(i) = rhs[i];
+    }
+    team_sync();
+    qacc = st.qacc(tl);
   }
-  team_sync();
   if (stepping && valid) {
-    const double vn = qd + h * st.qacc(tl);
+    const double vn = qd + h * qacc;
     st.v(tl) = vn;
     st.q(tl) = q + h * vn;
   }
