@@ -239,6 +239,25 @@ void orc_franka_hand_tcp_offset(orc_pose* out) { /* Pose.cpp:11-15 fed to Pose(M
 /* ---------------------------------------------------------------------- CLIK */
 
 /* world placement (R row-major, p) of the IK frame and its LOCAL 6 x nv Jacobian [linear; angular] */
+/* pinocchio places the ROOT body of the parsed tree at the universe (urdf / mjcf visitors' addRootJoint: identity
+   placement), so a root body that the file offsets from its world -- xArm7's `base` sits 0.12 m up -- has that offset
+   dropped: the IK frame is the root body's frame, the frame get_cartesian_position reports in.  (FR3: root body at
+   the origin, no-op.)  A Jacobian expressed in the site frame does not change. */
+static void ik_to_root_frame(const orc_model* m, const orc_data* d, int site, double* R, double* p) {
+  int root = m->site_bodyid[site];
+  while (root > 0 && m->body_parentid[root] > 0) root = m->body_parentid[root];
+  if (root <= 0) return;
+  const double* Rb = d->xmat[root];
+  const double* pb = d->xpos[root];
+  double Rn[9], dp[3] = {p[0] - pb[0], p[1] - pb[1], p[2] - pb[2]}, pn[3];
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) Rn[3 * r + c] = Rb[r] * R[c] + Rb[3 + r] * R[3 + c] + Rb[6 + r] * R[6 + c];
+    pn[r] = Rb[r] * dp[0] + Rb[3 + r] * dp[1] + Rb[6 + r] * dp[2];
+  }
+  memcpy(R, Rn, sizeof(Rn));
+  memcpy(p, pn, sizeof(pn));
+}
+
 static void ik_fk(const orc_ik* ik, const double* q, double* R, double* p, double J[6][ORC_MAXV]) {
   const orc_model* m = ik->m;
   orc_data d;
@@ -247,7 +266,7 @@ static void ik_fk(const orc_ik* ik, const double* q, double* R, double* p, doubl
   orc_kinematics(m, &d);
   memcpy(R, d.site_xmat[ik->site], 9 * sizeof(double));
   memcpy(p, d.site_xpos[ik->site], 3 * sizeof(double));
-  if (!J) return;
+  if (!J) { ik_to_root_frame(m, &d, ik->site, R, p); return; }
   for (int r = 0; r < 6; r++) memset(J[r], 0, sizeof(J[r]));
   int b = m->site_bodyid[ik->site];
   while (b > 0) {
@@ -272,6 +291,7 @@ static void ik_fk(const orc_ik* ik, const double* q, double* R, double* p, doubl
     }
     b = m->body_parentid[b];
   }
+  ik_to_root_frame(m, &d, ik->site, R, p);
 }
 
 #define TAYLOR_PREC 1.220703125e-04 /* eps^(1/4), pinocchio's TaylorSeriesExpansion precision<3> */

@@ -145,16 +145,17 @@ def cartesian_actions(n_envs: int, n_steps: int, seed: int = 0):
 
 
 def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=0, mode="xyzrpy", relative=True, gripper=True,
-                                 relative_to: str = "last_step"):
+                                 relative_to: str = "last_step", robot: str = "fr3"):
     """Cartesian control (relative TRPY / TQuat actions -> CLIK -> joint targets): HIP path vs the oracle."""
     from rcs_amd.envs import ControlMode
 
     cm = ControlMode.CARTESIAN_TRPY if mode == "xyzrpy" else ControlMode.CARTESIAN_TQuat
     mm = (0.2, float(np.deg2rad(45)))
+    gripper = gripper and robot == "fr3"
     venv = make_vec_env(n_envs, async_control, gripper=gripper, relative=relative, control_mode=cm, max_relative_movement=mm,
-                        relative_to=relative_to)
+                        relative_to=relative_to, robot=robot)
     oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, relative=relative, mode=mode, max_relative_movement=mm,
-                             relative_to=relative_to)
+                             relative_to=relative_to, robot=robot)
     act6, grip = cartesian_actions(n_envs, n_steps, seed)
     rep = {"max_abs_qpos": 0.0, "max_abs_tquat": 0.0, "max_abs_target": 0.0, "flag_mismatches": 0, "steps": 0, "ik_fail": 0}
     obs, info = venv.reset()

@@ -179,6 +179,15 @@ def test_xarm7_joints_with_dry_friction(async_control, kernel):
     assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
 
 
+def test_xarm7_cartesian_relative_clik(kernel):
+    """The CLIK on the xArm7 chain (7 joints, attachment site on link7) + its friction-row physics."""
+    if kernel == "lane":
+        pytest.skip("the lane kernel has no dry-friction rows")
+    rep = run_cartesian_rollout_parity(n_envs=24, n_steps=5, async_control=True, seed=17, mode="xyzrpy", robot="xarm7")
+    assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL and rep["max_abs_tquat"] < TOL, rep
+    assert rep["flag_mismatches"] == 0, rep
+
+
 @pytest.mark.parametrize("n_envs", [1, 5, 33])
 def test_ragged_batch_sizes(n_envs):
     """Batches that do not fill a wavefront / a team group / the 8-workgroup XCD rounding."""
