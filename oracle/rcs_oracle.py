@@ -366,6 +366,23 @@ class Sim:
     def set_cartesian_position(self, pose: Pose):
         lib().orc_robot_set_cartesian_position(C.byref(self.s), C.byref(pose.p))
 
+    # common.Kinematics (Pin) on the robot's chain
+    def ik_inverse(self, pose: Pose, q0, tcp_offset: Pose | None = None):
+        """Pin::inverse: (q[model.nq] or None, iterations)."""
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        out = (D * MAXV)()
+        it = I(0)
+        off = (tcp_offset or Pose()).p
+        ok = lib().orc_ik_inverse(C.byref(self.s.ik), C.byref(pose.p), (D * len(q0))(*q0), len(q0), C.byref(off), out, C.byref(it))
+        return (np.array(out[: self.model.njnt]) if ok else None), int(it.value)
+
+    def ik_forward(self, q0, tcp_offset: Pose | None = None) -> Pose:
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        out = OrcPose()
+        off = (tcp_offset or Pose()).p
+        lib().orc_ik_forward(C.byref(self.s.ik), (D * len(q0))(*q0), len(q0), C.byref(off), C.byref(out))
+        return Pose(_raw=out)
+
     def set_joints_hard(self, q):
         lib().orc_robot_set_joints_hard(C.byref(self.s), (D * self.n)(*np.asarray(q, dtype=np.float64)))
 
