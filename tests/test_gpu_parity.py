@@ -157,6 +157,97 @@ def test_kinematics_api_matches_oracle(robot, kernel):
     venv.close()
 
 
+def test_fine_grained_api_sequence_with_masks(kernel):
+    """The 1:1 Sim / SimRobot / SimGripper surface (boundary row b) driven call by call, half of the environments
+    masked out of some calls, against one oracle per environment doing exactly the calls its mask lets through:
+    step(k), step_until_convergence, set_joint_position, set_joints_hard, move_home, robot reset, gripper shut / open /
+    set_normalized_width / reset, sim reset; states, flags and convergence step counts compared after every stage."""
+    import parity_util as pu
+    import rcs_oracle as O
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    from rcs_env_oracle import FR3_Q_HOME
+
+    n = 12
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+    simu.set_kernel(kernel)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(pu.SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n)]
+    rng = np.random.default_rng(8)
+    odd = np.arange(n) % 2 == 1
+
+    def check(stage, conv=False):
+        q, v, st, gs = simu.qpos, simu.qvel, robot.get_state(), grip.get_state()
+        w, grasped = grip.get_normalized_width(), grip.is_grasped()
+        steps = simu.convergence_steps() if conv else None
+        done = simu.is_converged() if conv else None
+        for e, o in enumerate(osims):
+            assert np.abs(q[e][:7] - np.asarray(o.qpos)[:7]).max() < TOL and np.abs(q[e][7:] - np.asarray(o.qpos)[7:]).max() < FINGER_TOL, (stage, e)
+            assert np.abs(v[e][:7] - np.asarray(o.qvel)[:7]).max() < 1e-4, (stage, e)
+            assert bool(st.is_moving[e]) == bool(o.s.is_moving) and bool(st.is_arrived[e]) == bool(o.s.is_arrived), (stage, e)
+            assert bool(st.ik_success[e]) == bool(o.s.ik_success) and bool(st.collision[e]) == bool(o.s.robot_collision), (stage, e)
+            assert np.abs(st.target_angles[e] - np.asarray(o.s.target_angles[:7])).max() < TOL, (stage, e)
+            assert abs(w[e] - o.gripper_get_normalized_width()) < 1e-2 and bool(grasped[e]) == o.gripper_is_grasped(), (stage, e)
+            assert abs(gs.last_commanded_width[e] - o.s.last_commanded_width) < 1e-15, (stage, e)
+            if conv:
+                assert int(steps[e]) == int(o.s.convergence_steps) and bool(done[e]) == bool(o.s.converged), (stage, e)
+
+    # reset everything, then home the robot (RobotEnv.reset order)
+    simu.reset(); robot.reset(); grip.reset()
+    for o in osims:
+        o.reset(); o.robot_reset(); o.gripper_reset()
+    simu.step(1)
+    [o.step(1) for o in osims]
+    check("reset")
+    # joint targets on the odd environments only, gripper shut on the even ones
+    tgt = np.tile(FR3_Q_HOME, (n, 1)) + rng.uniform(-0.08, 0.08, size=(n, 7))
+    robot.set_joint_position(tgt, mask=odd)
+    grip.shut(mask=~odd)
+    for e, o in enumerate(osims):
+        if odd[e]:
+            o.set_joint_position(tgt[e])
+        else:
+            o.gripper_grasp()
+    simu.step(34)
+    [o.step(34) for o in osims]
+    check("masked targets")
+    simu.step_until_convergence()
+    [o.step_until_convergence() for o in osims]
+    check("until convergence", conv=True)
+    # hard joint reset on the even ones, move_home on the odd ones, a half-open gripper everywhere
+    hard = np.tile(FR3_Q_HOME, (n, 1)) + rng.uniform(-0.2, 0.2, size=(n, 7))
+    robot.set_joints_hard(hard, mask=~odd)
+    robot.move_home(mask=odd)
+    grip.set_normalized_width(np.full(n, 0.5))
+    for e, o in enumerate(osims):
+        if odd[e]:
+            o.move_home()
+        else:
+            o.set_joints_hard(hard[e])
+        o.gripper_set_normalized_width(0.5)
+    simu.step(51)
+    [o.step(51) for o in osims]
+    check("hard reset / move_home")
+    # sim reset of the odd environments only
+    simu.reset(mask=odd)
+    robot.reset(mask=odd)
+    grip.open(mask=odd)
+    for e, o in enumerate(osims):
+        if odd[e]:
+            o.reset(); o.robot_reset(); o.gripper_open()
+    simu.step(17)
+    [o.step(17) for o in osims]
+    check("masked sim reset")
+    with pytest.raises(ValueError):
+        grip.set_normalized_width(1.5)
+    simu.close()
+
+
 def test_collision_flags_match_oracle():
     """Reference collision pins (test_sim_envs.py:136-151,347-360) through the HIP path: folded arm in JOINTS mode,
     TCP target below the ground in Cartesian mode; every flag and substep count equals the oracle's."""
