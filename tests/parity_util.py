@@ -38,11 +38,12 @@ XARM7_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes",
 
 
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
-                 max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step"):
+                 max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
+                 max_convergence_steps: int = 500):
     from rcs_amd import sim
     from rcs_amd.envs import ControlMode, RelativeTo, SimEnvCreator, default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg
 
-    cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=30)
+    cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=frequency, max_convergence_steps=max_convergence_steps)
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
@@ -61,7 +62,8 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
 
 
 def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, mode: str = "joints",
-                     max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step"):
+                     max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
+                     max_convergence_steps: int = 500):
     from rcs_amd.mjcf import compile_mjcf
     from rcs_env_oracle import XARM7, OracleEnv
 
@@ -69,15 +71,19 @@ def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, rel
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
     return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot == "fr3", max_relative_movement=max_relative_movement if relative else None,
-                      async_control=async_control, robot=XARM7 if robot == "xarm7" else None, relative_to=relative_to) for _ in range(n_envs)]
+                      async_control=async_control, robot=XARM7 if robot == "xarm7" else None, relative_to=relative_to,
+                      frequency=frequency, max_convergence_steps=max_convergence_steps) for _ in range(n_envs)]
 
 
 def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: bool = True, seed: int = 0, gripper: bool = True,
-                             episodes: int = 1, robot: str = "fr3", relative_to: str = "last_step"):
+                             episodes: int = 1, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
+                             max_convergence_steps: int = 500):
     """Fused HIP env-step vs the oracle on the same seeded actions; returns max abs differences + flag mismatches."""
     gripper = gripper and robot == "fr3"
-    venv = make_vec_env(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to)
-    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to)
+    venv = make_vec_env(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to, frequency=frequency,
+                        max_convergence_steps=max_convergence_steps)
+    oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to, frequency=frequency,
+                             max_convergence_steps=max_convergence_steps)
     joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed)
     rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_finger": 0.0, "max_abs_gripper_width": 0.0,
            "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}

@@ -64,6 +64,16 @@ def test_joints_until_convergence():
     assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
 
 
+def test_sim_config_variants():
+    """SimConfig fields other than the defaults: 10 Hz async control (50 substeps per env-step, envs/sim.py:52-53) and a
+    convergence cap of 77 substeps that every environment hits (sim.cpp:84-106: converged stays false)."""
+    rep = run_joint_rollout_parity(n_envs=20, n_steps=3, async_control=True, seed=23, frequency=10)
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_finger"] < FINGER_TOL and rep["flag_mismatches"] == 0, rep
+    rep = run_joint_rollout_parity(n_envs=20, n_steps=3, async_control=False, seed=23, max_convergence_steps=77)
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_finger"] < FINGER_TOL, rep
+    assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
+
+
 def test_two_episodes_reset_quirks():
     # prev_action survives reset (Q2), gripper reset is overwritten by sim.reset (Q1)
     rep = run_joint_rollout_parity(n_envs=33, n_steps=4, async_control=True, seed=3, gripper=True, episodes=2)
