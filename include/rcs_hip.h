@@ -243,6 +243,15 @@ int rcsh_sim_set_qvel(rcsh_sim* sim, const double* qvel, const uint8_t* mask);
 int rcsh_sim_nq(const rcsh_sim* sim);
 int rcsh_sim_nu(const rcsh_sim* sim);
 
+/* Snapshot / restore of EVERYTHING that evolves (the mjData fields above, the callback scheduler's timestamps and
+ * return values, SimRobot / SimGripper state, the wrappers' prev_action / origin / last_action, flags): the reference's
+ * closest facility is the GUI bridge's mjSTATE_FULLPHYSICS copy (src/sim/gui_server.cpp:49-60).  The blob is opaque,
+ * `rcsh_sim_state_bytes` long, and valid for handles created from the same scene with the same n_envs; restoring
+ * and re-running the same calls reproduces the continuation bit for bit. */
+size_t rcsh_sim_state_bytes(const rcsh_sim* sim);
+int rcsh_sim_get_state(rcsh_sim* sim, void* blob);
+int rcsh_sim_set_state(rcsh_sim* sim, const void* blob);
+
 /* ---- fused Gymnasium loop: SimEnvCreator()(...).reset() / .step(action) for N environments in one launch.
  * Wrapper stack restated in the kernel (reference python/rcs/envs/base.py:246-304,469-565,680-735;
  * envs/sim.py:49-76,119-131).  Observation row: tquat[7] joints[dof] xyzrpy[6] gripper[1]

@@ -737,6 +737,35 @@ int rcsh_sim_get_ctrl(rcsh_sim* s, double* c) {
 int rcsh_sim_set_qpos(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); return scatter_host(s, field_of(s, "qpos"), s->nl, q, mask); }
 int rcsh_sim_set_qvel(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); return scatter_host(s, field_of(s, "qvel"), s->nl, q, mask); }
 
+size_t rcsh_sim_state_bytes(const rcsh_sim* s) {
+  if (!s) return 0;
+  return (size_t)s->n * (sizeof(double) * s->nfields + sizeof(uint32_t) + sizeof(int32_t));
+}
+int rcsh_sim_get_state(rcsh_sim* s, void* blob) {
+  REQUIRE_SIM(s);
+  if (!blob) return fail(RCSH_ERR_ARG, "null state blob");
+  HIP_TRY(hipSetDevice(s->device));
+  char* b = static_cast<char*>(blob);
+  const size_t ns = sizeof(double) * (size_t)s->n * s->nfields, nf = sizeof(uint32_t) * (size_t)s->n, nc = sizeof(int32_t) * (size_t)s->n;
+  HIP_TRY(hipMemcpyAsync(b, s->S, ns, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(b + ns, s->flags, nf, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipMemcpyAsync(b + ns + nf, s->conv, nc, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+int rcsh_sim_set_state(rcsh_sim* s, const void* blob) {
+  REQUIRE_SIM(s);
+  if (!blob) return fail(RCSH_ERR_ARG, "null state blob");
+  HIP_TRY(hipSetDevice(s->device));
+  const char* b = static_cast<const char*>(blob);
+  const size_t ns = sizeof(double) * (size_t)s->n * s->nfields, nf = sizeof(uint32_t) * (size_t)s->n, nc = sizeof(int32_t) * (size_t)s->n;
+  HIP_TRY(hipMemcpyAsync(s->S, b, ns, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->flags, b + ns, nf, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->conv, b + ns + nf, nc, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
 // ---- fused Gymnasium loop
 
 int rcsh_env_configure(rcsh_sim* s, const rcsh_env_desc* env) {

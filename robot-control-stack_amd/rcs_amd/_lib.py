@@ -96,7 +96,7 @@ EXPORTS = (
     "rcsh_ik_inverse", "rcsh_ik_forward", "rcsh_sim_add_gripper", "rcsh_gripper_set_normalized_width",
     "rcsh_gripper_get_normalized_width", "rcsh_gripper_is_grasped", "rcsh_gripper_reset", "rcsh_gripper_get_state",
     "rcsh_sim_get_qpos", "rcsh_sim_get_qvel", "rcsh_sim_get_ctrl", "rcsh_sim_get_time", "rcsh_sim_set_qpos",
-    "rcsh_sim_set_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_env_configure", "rcsh_env_obs_width",
+    "rcsh_sim_set_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
@@ -124,6 +124,10 @@ def load() -> C.CDLL:
     L.rcsh_sim_stream.argtypes = [C.c_void_p]
     L.rcsh_sim_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.rcsh_sim_set_kernel.argtypes = [C.c_void_p, C.c_int32]
+    L.rcsh_sim_state_bytes.restype = C.c_size_t
+    L.rcsh_sim_state_bytes.argtypes = [C.c_void_p]
+    L.rcsh_sim_get_state.argtypes = [C.c_void_p, C.c_void_p]
+    L.rcsh_sim_set_state.argtypes = [C.c_void_p, C.c_void_p]
     L.rcsh_sim_create.argtypes = [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.rcsh_sim_destroy.argtypes = [C.c_void_p]
     L.rcsh_sim_destroy.restype = None

@@ -106,6 +106,18 @@ class Sim:
         """Pin the kernel variant: "auto" / "team" (16 lanes per environment, the default) or "lane" (one lane)."""
         _lib.check(self._L.rcsh_sim_set_kernel(self._h, {"auto": 0, "team": 1, "lane": 2}[variant]))
 
+    def get_state(self) -> np.ndarray:
+        """Opaque snapshot of everything that evolves (physics, callback scheduler, robot / gripper / wrapper state)."""
+        blob = np.empty(int(self._L.rcsh_sim_state_bytes(self._h)), dtype=np.uint8)
+        _lib.check(self._L.rcsh_sim_get_state(self._h, C.c_void_p(blob.ctypes.data)))
+        return blob
+
+    def set_state(self, blob: np.ndarray) -> None:
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        if blob.size != int(self._L.rcsh_sim_state_bytes(self._h)):
+            raise ValueError("state blob of a different scene or batch size")
+        _lib.check(self._L.rcsh_sim_set_state(self._h, C.c_void_p(blob.ctypes.data)))
+
     def synchronize(self) -> None:
         _lib.check(self._L.rcsh_sim_synchronize(self._h))
 
