@@ -723,19 +723,12 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   const bool has_eq = T::GRIP && m.eq_active;
   const int nrows = __popc(limrows);
   const bool helper_lane = FRIC ? t == kTeamLanes - 1 : t >= kTeamLanes - 5;
-  // lane s guesses: the s-th subset of the existing limit rows is active; idx0..2: the joints of the first three rows
-  uint32_t act = 0;
-  int idx0 = -1, idx1 = -1, idx2 = -1;
-  {
-    int c = 0;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const bool exists = (limrows >> i) & 1u;
-      if (exists && ((t >> c) & 1)) act |= 1u << i;
-      if (exists) { if (c == 0) idx0 = i; else if (c == 1) idx1 = i; else if (c == 2) idx2 = i; }
-      c += exists ? 1 : 0;
-    }
-  }
+  // idx0..2: the joints of the first three limit rows (-1: no such row); lane s guesses that the rows whose bit is set
+  // in s are the active ones (only read when there are at most three rows)
+  const uint32_t rows1 = limrows & (limrows - 1), rows2 = rows1 & (rows1 - 1);
+  const int idx0 = __ffs(limrows) - 1, idx1 = __ffs(rows1) - 1, idx2 = __ffs(rows2) - 1;
+  const uint32_t act = ((t & 1) && idx0 >= 0 ? 1u << idx0 : 0u) | ((t & 2) && idx1 >= 0 ? 1u << idx1 : 0u) |
+                       ((t & 4) && idx2 >= 0 ? 1u << idx2 : 0u);
   const bool fast = nrows <= 3 && !FRIC;
   const bool solver_lane = fast && t < (1 << nrows);
   double H[T::NTRI], x[NL];
