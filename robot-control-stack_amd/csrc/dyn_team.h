@@ -742,28 +742,32 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
     for (int i = 0; i < NL; ++i) { sm[i] = st.smooth(i); lDv[i] = st.limD(i); lAv[i] = st.limA(i); lSv[i] = st.limS(i); dgv[i] = st.dg(i); }
     if (T::GRIP) { eqD = st.eq(0); eqAref = st.eq(1); eqJ1 = st.eq(2); gblock = st.eq(3); }
     sched_fence();
-    // unit-vector helpers: which joint; the coupling helper: e_NA + eqJ1 e_NA+1
-    const int unit = t == kTeamLanes - 3 ? idx0 : (t == kTeamLanes - 4 ? idx1 : (t == kTeamLanes - 5 ? idx2 : -1));
-    const bool smooth_helper = t == kTeamLanes - 1, eq_helper = !FRIC && t == kTeamLanes - 2;
+    // Role by arithmetic instead of selects: wh = 1 on helper lanes (their diagonal term), ws = 1 where the right-hand
+    // side starts from qfrc_smooth (solver lanes and the smooth helper); the guess `act` is empty on helper lanes, so
+    // the row terms vanish there by themselves.  Unit-vector helpers: which joint; coupling helper: e_NA + eqJ1 e_NA+1.
+    const int unit = FRIC ? -1 : (t == kTeamLanes - 3 ? idx0 : (t == kTeamLanes - 4 ? idx1 : (t == kTeamLanes - 5 ? idx2 : -1)));
+    const bool eq_helper = !FRIC && T::GRIP && t == kTeamLanes - 2;
+    const double wh = helper_lane ? 1.0 : 0.0, ws = (!helper_lane || t == kTeamLanes - 1) ? 1.0 : 0.0;
+    const uint32_t guess = helper_lane ? 0u : act;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const bool on = (act >> i) & 1u;
+      const bool on = (guess >> i) & 1u;
       const double dsolve = on ? lDv[i] : 0.0;
-      H[tri(i, i)] += helper_lane ? dgv[i] : dsolve;
-      const double xsolve = sm[i] + (on ? lSv[i] * lDv[i] * lAv[i] : 0.0);
-      double xhelp = smooth_helper ? sm[i] : (i == unit ? 1.0 : 0.0);
-      if (T::GRIP && eq_helper) xhelp = i == NA ? 1.0 : (i == NA + 1 ? eqJ1 : 0.0);
-      x[i] = helper_lane ? xhelp : xsolve;
+      H[tri(i, i)] += fma(wh, dgv[i], dsolve);
+      double xi = fma(ws, sm[i], dsolve * (lSv[i] * lAv[i]));
+      if (i == unit) xi = 1.0;
+      if (T::GRIP && eq_helper && (i == NA || i == NA + 1)) xi = i == NA ? 1.0 : eqJ1;
+      x[i] = xi;
     }
   }
   if constexpr (T::GRIP) {
     const double c0 = m.grp_coef[0], c1 = m.grp_coef[1], hg = h * gblock;
-    const double e = has_eq ? eqD : 0.0;
-    H[tri(NA, NA)] += helper_lane ? hg * c0 * c0 : e;
-    H[tri(NA + 1, NA)] += helper_lane ? hg * c0 * c1 : e * eqJ1;
-    H[tri(NA + 1, NA + 1)] += helper_lane ? hg * c1 * c1 : e * eqJ1 * eqJ1;
-    x[NA] += helper_lane ? 0.0 : e * eqAref;
-    x[NA + 1] += helper_lane ? 0.0 : e * eqAref * eqJ1;
+    const double e = has_eq && !helper_lane ? eqD : 0.0, g = helper_lane ? hg : 0.0;
+    H[tri(NA, NA)] += fma(g * c0, c0, e);
+    H[tri(NA + 1, NA)] += fma(g * c0, c1, e * eqJ1);
+    H[tri(NA + 1, NA + 1)] += fma(g * c1, c1, e * eqJ1 * eqJ1);
+    x[NA] += e * eqAref;
+    x[NA + 1] += e * eqAref * eqJ1;
   }
   ldl_factor<NL>(H);
   ldl_solve<NL>(H, x);
