@@ -419,20 +419,18 @@ struct InertK {
   }
 };
 struct ActK {
-  int32_t has_act, ctrllimited, biasaffine, forcelimited, actgravcomp, actfrclimited, limited;
   double ctrlrange[2], gear, gain, bias[3], forcerange[2];
-  double damping, actfrcrange[2], armature, gcm_sub, range[2], margin;
+  double damping, actfrcrange[2], armature, gcm_sub, range[2], margin, actgravcomp_w;
   RCSH_D void load(const LinkRec& r) {
-    has_act = r.arm_has_act; ctrllimited = r.arm_ctrllimited; biasaffine = r.arm_biasaffine; forcelimited = r.arm_forcelimited;
     ctrlrange[0] = r.arm_ctrlrange[0]; ctrlrange[1] = r.arm_ctrlrange[1];
     gear = r.arm_gear; gain = r.arm_gain;
     bias[0] = r.arm_bias[0]; bias[1] = r.arm_bias[1]; bias[2] = r.arm_bias[2];
     forcerange[0] = r.arm_forcerange[0]; forcerange[1] = r.arm_forcerange[1];
-    actgravcomp = r.actgravcomp; actfrclimited = r.actfrclimited; limited = r.limited;
     damping = r.damping;
     actfrcrange[0] = r.actfrcrange[0]; actfrcrange[1] = r.actfrcrange[1];
     armature = r.armature; gcm_sub = r.gcm_sub;
     range[0] = r.range[0]; range[1] = r.range[1]; margin = r.margin;
+    actgravcomp_w = r.actgravcomp_w;
   }
 };
 
@@ -611,20 +609,15 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   TEAM_MARK(4)
 
   // ---- actuation (lane t: actuator of joint t; the gripper actuator pulls on both finger lanes)
-  double tau = 0.0;
-  bool unclamped_affine = false;  // arm actuator contributes its velocity derivative to the implicit matrix
-  if (t < NA && ak.has_act) {
-    double c = ctrl;
-    if (ak.ctrllimited) c = clampd(c, ak.ctrlrange[0], ak.ctrlrange[1]);
-    double force = ak.gain * c;
-    if (ak.biasaffine) force += ak.bias[0] + ak.bias[1] * (ak.gear * q) + ak.bias[2] * (ak.gear * qd);
-    bool clamped = false;
-    if (ak.forcelimited) {
-      clamped = force <= ak.forcerange[0] || force >= ak.forcerange[1];
-      force = clampd(force, ak.forcerange[0], ak.forcerange[1]);
-    }
-    tau = ak.gear * force;
-    unclamped_affine = ak.biasaffine && !clamped;
+  // (one formula for every lane: LinkRec holds zero coefficients / infinite ranges where the model has no actuator, no
+  // bias, no limit)
+  double tau;
+  bool unclamped;  // the actuator's velocity derivative enters the implicit matrix unless forcerange saturates it
+  {
+    const double c = clampd(ctrl, ak.ctrlrange[0], ak.ctrlrange[1]);
+    const double force = ak.gain * c + (ak.bias[0] + ak.bias[1] * (ak.gear * q) + ak.bias[2] * (ak.gear * qd));
+    unclamped = !(force <= ak.forcerange[0] || force >= ak.forcerange[1]);
+    tau = ak.gear * clampd(force, ak.forcerange[0], ak.forcerange[1]);
   }
   double gblock = 0.0, eqD = 0.0, eqAref = 0.0, eqJ1 = 0.0;
   if (T::GRIP) {
@@ -675,14 +668,13 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   }
   double smooth;
   {
-    double passive = -ak.damping * qd;
-    if (ak.actgravcomp) tau += gc; else passive += gc;
-    if (ak.actfrclimited) tau = clampd(tau, ak.actfrcrange[0], ak.actfrcrange[1]);
+    const double passive = -ak.damping * qd + (1.0 - ak.actgravcomp_w) * gc;
+    tau = clampd(tau + ak.actgravcomp_w * gc, ak.actfrcrange[0], ak.actfrcrange[1]);
     smooth = passive - bias + tau;
   }
   // ---- joint-limit row of the lane's joint
   double lD = 0.0, lA = 0.0, lS = 0.0;
-  if (ak.limited) {
+  {
     const double dlo = q - ak.range[0], dhi = ak.range[1] - q;
     const double mg = ak.margin;
     double dist = 0, sgn = 0;
@@ -700,8 +692,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   }
   const uint32_t limrows = team_ballot(valid && lS != 0.0);
   if (valid) {
-    double d = ak.damping;
-    if (unclamped_affine) d -= ak.gear * ak.gear * ak.bias[2];
+    const double d = ak.damping - (unclamped ? ak.gear * ak.gear * ak.bias[2] : 0.0);
     st.smooth(tl) = smooth;
     st.limD(tl) = lD;
     st.limA(tl) = lA;

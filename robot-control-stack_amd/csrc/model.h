@@ -8,6 +8,7 @@
 // kernels read with wave-uniform (scalar) loads.
 #pragma once
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 
 namespace rcsh {
@@ -116,12 +117,16 @@ struct LinkRec {
   double qpos0, rot0[9], pos0[3], axis[3], jpos[3];
   double mass, gcm, com[3], inertia[6], gccom[3];
   double damping, armature, gcm_sub, actfrcrange[2], range[2], margin;
-  double arm_ctrlrange[2], arm_gear, arm_gain, arm_bias[3], arm_forcerange[2];  // arm dofs only, else zero
+  // The on/off flags of the model are folded into the numbers, so the kernels run one branch-free formula on every
+  // lane: an absent limit is an infinite range, an absent bias / actuator is zero coefficients, actuator-side gravity
+  // compensation is a 0/1 weight.  (Clamping to +-inf and adding 0 * x are exact.)
+  double arm_ctrlrange[2], arm_gear, arm_gain, arm_bias[3], arm_forcerange[2];  // arm dofs only, else zero / infinite
   double lim_K, lim_B, invweight0;
   double fl_floss, fl_D, fl_B, fl_R;
   Imp lim_imp;
-  int32_t axis_z, jtype, gc_same_com, arm_has_act, arm_ctrllimited, arm_biasaffine, arm_forcelimited, actgravcomp,
-      actfrclimited, limited;
+  double actgravcomp_w;  // 1: gravity compensation goes through the actuator (before the joint-level force clamp)
+  int32_t axis_z, jtype, gc_same_com, pad0;
+  double pad1[2];
 };
 static_assert(sizeof(LinkRec) == 560, "LDS bank spread of the records relies on this size");
 
@@ -141,14 +146,18 @@ inline void fill_link_records(const DevModel& m, LinkRec* out) {
     k.fl_floss = m.fl_floss[i]; k.fl_D = m.fl_D[i]; k.fl_B = m.fl_B[i]; k.fl_R = m.fl_R[i];
     k.lim_imp = m.lim_imp[i];
     k.axis_z = m.axis_z[i]; k.jtype = m.jtype[i]; k.gc_same_com = m.gc_same_com[i];
-    k.actgravcomp = m.actgravcomp[i]; k.actfrclimited = m.actfrclimited[i]; k.limited = m.limited[i];
-    if (i < m.narm && i < kMaxArm) {
-      k.arm_has_act = m.arm_has_act[i]; k.arm_ctrllimited = m.arm_ctrllimited[i]; k.arm_biasaffine = m.arm_biasaffine[i];
-      k.arm_forcelimited = m.arm_forcelimited[i];
-      k.arm_ctrlrange[0] = m.arm_ctrlrange[i][0]; k.arm_ctrlrange[1] = m.arm_ctrlrange[i][1];
+    const double inf = HUGE_VAL;
+    k.actgravcomp_w = m.actgravcomp[i] ? 1.0 : 0.0;
+    if (!m.actfrclimited[i]) { k.actfrcrange[0] = -inf; k.actfrcrange[1] = inf; }
+    if (!m.limited[i]) { k.range[0] = -inf; k.range[1] = inf; }
+    k.arm_ctrlrange[0] = -inf; k.arm_ctrlrange[1] = inf;
+    k.arm_forcerange[0] = -inf; k.arm_forcerange[1] = inf;
+    if (i < m.narm && i < kMaxArm && m.arm_has_act[i]) {
+      if (m.arm_ctrllimited[i]) { k.arm_ctrlrange[0] = m.arm_ctrlrange[i][0]; k.arm_ctrlrange[1] = m.arm_ctrlrange[i][1]; }
       k.arm_gear = m.arm_gear[i]; k.arm_gain = m.arm_gain[i];
-      for (int j = 0; j < 3; ++j) k.arm_bias[j] = m.arm_bias[i][j];
-      k.arm_forcerange[0] = m.arm_forcerange[i][0]; k.arm_forcerange[1] = m.arm_forcerange[i][1];
+      if (m.arm_biasaffine[i])
+        for (int j = 0; j < 3; ++j) k.arm_bias[j] = m.arm_bias[i][j];
+      if (m.arm_forcelimited[i]) { k.arm_forcerange[0] = m.arm_forcerange[i][0]; k.arm_forcerange[1] = m.arm_forcerange[i][1]; }
     }
   }
 }
