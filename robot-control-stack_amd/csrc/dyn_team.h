@@ -175,7 +175,7 @@ RCSH_D void scan_frames(double* R, double* p) {
 // guesses to enumerate).  Same algorithm as the oracle's solve_constraints (oracle/rcs_physics.c).
 // FRIC = false compiles the friction rows out (frows is the constant 0), leaving dyn.h's loop.
 template <class T, bool FRIC>
-RCSH_D void newton_rows(const DevModel& m, const StageTeam<T>& st, uint32_t limrows, bool has_eq, double eqD, double eqAref,
+RCSH_D void newton_rows(const LinkRec* links, const StageTeam<T>& st, uint32_t limrows, bool has_eq, double eqD, double eqAref,
                         double eqJ1, double* x) {
   constexpr int NL = T::NL, NA = T::NARM;
   // dry-friction rows: D, frictionloss, aref, half-width of the quadratic zone
@@ -185,7 +185,7 @@ RCSH_D void newton_rows(const DevModel& m, const StageTeam<T>& st, uint32_t limr
   for (int i = 0; i < NL; ++i) {
     fF[i] = 0; fD[i] = 0; fA[i] = 0; fR[i] = 0;
     if constexpr (FRIC) {
-      fF[i] = m.fl_floss[i]; fD[i] = m.fl_D[i]; fA[i] = st.fa(i); fR[i] = m.fl_R[i];
+      fF[i] = links[i].fl_floss; fD[i] = links[i].fl_D; fA[i] = st.fa(i); fR[i] = links[i].fl_R;
       if (fF[i] > 0) frows |= 1u << i;
     }
   }
@@ -634,7 +634,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
       const double g_cr0 = m.grp_ctrlrange[0], g_cr1 = m.grp_ctrlrange[1], g_fr0 = m.grp_forcerange[0], g_fr1 = m.grp_forcerange[1];
       const double gctrl = st.c(NA);
       const double pc0 = m.eq_polycoef[0], pc1 = m.eq_polycoef[1], pc2 = m.eq_polycoef[2], pc3 = m.eq_polycoef[3], pc4 = m.eq_polycoef[4];
-      const double q0a = m.qpos0[NA], q0b = m.qpos0[NA + 1], iwa = m.invweight0[NA], iwb = m.invweight0[NA + 1];
+      const double q0a = links[NA].qpos0, q0b = links[NA + 1].qpos0, iwa = links[NA].invweight0, iwb = links[NA + 1].invweight0;
       const double eK = m.eq_K, eB = m.eq_B;
       const Imp eimp = m.eq_imp;
       sched_fence();
@@ -784,7 +784,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
     }
   } else {
     double xs[NL];
-    newton_rows<T, FRIC>(m, st, limrows, has_eq, eqD, eqAref, eqJ1, xs);
+    newton_rows<T, FRIC>(links, st, limrows, has_eq, eqD, eqAref, eqJ1, xs);
     if (t == 0) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) st.xs(i) = xs[i];
@@ -827,9 +827,9 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
       if constexpr (FRIC) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-          const double fF = m.fl_floss[i], fD = m.fl_D[i];
+          const double fF = links[i].fl_floss, fD = links[i].fl_D;
           if (fF > 0) {
-            const double jf = xs[i] - st.fa(i), fR = m.fl_R[i];
+            const double jf = xs[i] - st.fa(i), fR = links[i].fl_R;
             rhs[i] += jf <= -fR ? fF : (jf >= fR ? -fF : -fD * jf);
           }
         }

@@ -567,14 +567,22 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   TEAM_CLOCK_START()
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
   {
+    // Of the DevModel only what is not per link is read here: options, gripper + coupling constants, site / base
+    // frames -- and qpos0 (Sim::reset); the per-link tables are superseded by the records.  Four ranges, 67 of its
+    // 802 words: every workgroup of the launch fetches these same lines from L2 at the same moment.
     constexpr int kWords = sizeof(DevModel) / 8;
     const double* src = reinterpret_cast<const double*>(Pk.model);
     double* dst = reinterpret_cast<double*>(&lm);
+    constexpr int kRange[4][2] = {{0, (int)offsetof(DevModel, pos0) / 8},
+                                  {(int)offsetof(DevModel, qpos0) / 8, (int)offsetof(DevModel, mass) / 8},
+                                  {(int)offsetof(DevModel, grp_has_act) / 8, (int)offsetof(DevModel, axis_z) / 8},
+                                  {(int)offsetof(DevModel, site_link) / 8, (int)offsetof(DevModel, fl_floss) / 8}};
+    static_assert(offsetof(DevModel, pos0) % 8 == 0 && offsetof(DevModel, qpos0) % 8 == 0 && offsetof(DevModel, mass) % 8 == 0 &&
+                  offsetof(DevModel, grp_has_act) % 8 == 0 && offsetof(DevModel, axis_z) % 8 == 0 &&
+                  offsetof(DevModel, site_link) % 8 == 0 && offsetof(DevModel, fl_floss) % 8 == 0, "ranges copied in 8-byte words");
 #pragma unroll
-    for (int it = 0; it < (kWords + 63) / 64; ++it) {
-      const int k = it * 64 + threadIdx.x;
-      if (k < kWords) dst[k] = src[k];
-    }
+    for (int rg = 0; rg < 4; ++rg)
+      for (int k = kRange[rg][0] + threadIdx.x; k < kRange[rg][1]; k += 64) dst[k] = src[k];
     constexpr int kRecWords = sizeof(LinkRec) * T::NL / 8;
     double* rdst = reinterpret_cast<double*>(llinks);
 #pragma unroll
