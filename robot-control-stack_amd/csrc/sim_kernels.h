@@ -539,6 +539,34 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
 }
 
+// Stages the model into a workgroup's LDS for the team kernels (64 threads).  Of the DevModel only what is not per link
+// is read there: options, gripper + coupling constants, site / base frames -- and qpos0 (Sim::reset); the per-link
+// tables are superseded by the LinkRec records stored right behind it.  Four ranges, 67 of its 802 words: every
+// workgroup of the launch fetches these same lines from L2 at the same moment.
+template <int NREC>
+__device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModel& lm, LinkRec* llinks) {
+  constexpr int kWords = sizeof(DevModel) / 8;
+  const double* src = reinterpret_cast<const double*>(gm);
+  double* dst = reinterpret_cast<double*>(&lm);
+  constexpr int kRange[4][2] = {{0, (int)offsetof(DevModel, pos0) / 8},
+                                {(int)offsetof(DevModel, qpos0) / 8, (int)offsetof(DevModel, mass) / 8},
+                                {(int)offsetof(DevModel, grp_has_act) / 8, (int)offsetof(DevModel, axis_z) / 8},
+                                {(int)offsetof(DevModel, site_link) / 8, (int)offsetof(DevModel, fl_floss) / 8}};
+  static_assert(offsetof(DevModel, pos0) % 8 == 0 && offsetof(DevModel, qpos0) % 8 == 0 && offsetof(DevModel, mass) % 8 == 0 &&
+                offsetof(DevModel, grp_has_act) % 8 == 0 && offsetof(DevModel, axis_z) % 8 == 0 &&
+                offsetof(DevModel, site_link) % 8 == 0 && offsetof(DevModel, fl_floss) % 8 == 0, "ranges copied in 8-byte words");
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg)
+    for (int k = kRange[rg][0] + threadIdx.x; k < kRange[rg][1]; k += 64) dst[k] = src[k];
+  constexpr int kRecWords = sizeof(LinkRec) * NREC / 8;
+  double* rdst = reinterpret_cast<double*>(llinks);
+#pragma unroll
+  for (int it = 0; it < (kRecWords + 63) / 64; ++it) {
+    const int k = it * 64 + threadIdx.x;
+    if (k < kRecWords) rdst[k] = src[kWords + k];
+  }
+}
+
 // The same entry point with one TEAM of 16 lanes per environment (dyn_team.h): four environments per wavefront,
 // one wavefront per workgroup.  Lane 0 of a team (the leader) owns the RCS bookkeeping -- wrappers, callback
 // scheduler, observation -- through the same helpers as k_run; all 16 lanes run the physics.
@@ -567,29 +595,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   TEAM_CLOCK_START()
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
   {
-    // Of the DevModel only what is not per link is read here: options, gripper + coupling constants, site / base
-    // frames -- and qpos0 (Sim::reset); the per-link tables are superseded by the records.  Four ranges, 67 of its
-    // 802 words: every workgroup of the launch fetches these same lines from L2 at the same moment.
-    constexpr int kWords = sizeof(DevModel) / 8;
-    const double* src = reinterpret_cast<const double*>(Pk.model);
-    double* dst = reinterpret_cast<double*>(&lm);
-    constexpr int kRange[4][2] = {{0, (int)offsetof(DevModel, pos0) / 8},
-                                  {(int)offsetof(DevModel, qpos0) / 8, (int)offsetof(DevModel, mass) / 8},
-                                  {(int)offsetof(DevModel, grp_has_act) / 8, (int)offsetof(DevModel, axis_z) / 8},
-                                  {(int)offsetof(DevModel, site_link) / 8, (int)offsetof(DevModel, fl_floss) / 8}};
-    static_assert(offsetof(DevModel, pos0) % 8 == 0 && offsetof(DevModel, qpos0) % 8 == 0 && offsetof(DevModel, mass) % 8 == 0 &&
-                  offsetof(DevModel, grp_has_act) % 8 == 0 && offsetof(DevModel, axis_z) % 8 == 0 &&
-                  offsetof(DevModel, site_link) % 8 == 0 && offsetof(DevModel, fl_floss) % 8 == 0, "ranges copied in 8-byte words");
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg)
-      for (int k = kRange[rg][0] + threadIdx.x; k < kRange[rg][1]; k += 64) dst[k] = src[k];
-    constexpr int kRecWords = sizeof(LinkRec) * T::NL / 8;
-    double* rdst = reinterpret_cast<double*>(llinks);
-#pragma unroll
-    for (int it = 0; it < (kRecWords + 63) / 64; ++it) {
-      const int k = it * 64 + threadIdx.x;
-      if (k < kRecWords) rdst[k] = src[kWords + k];
-    }
+    stage_team_model<T::NL>(Pk.model, lm, llinks);
     for (int k = threadIdx.x; k < ST::COUNT * kTeams; k += 64) lds[k] = 0.0;
     __syncthreads();
   }
@@ -874,21 +880,7 @@ __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
   __shared__ IkTeamBlock<T> blocks[kTeams];
   __shared__ double desired[kTeams][12];
   {
-    constexpr int kWords = sizeof(DevModel) / 8;
-    const double* src = reinterpret_cast<const double*>(P.model);
-    double* dst = reinterpret_cast<double*>(&lm);
-#pragma unroll
-    for (int it = 0; it < (kWords + 63) / 64; ++it) {
-      const int k = it * 64 + threadIdx.x;
-      if (k < kWords) dst[k] = src[k];
-    }
-    constexpr int kRecWords = sizeof(LinkRec) * T::NARM / 8;
-    double* rdst = reinterpret_cast<double*>(llinks);
-#pragma unroll
-    for (int it = 0; it < (kRecWords + 63) / 64; ++it) {
-      const int k = it * 64 + threadIdx.x;
-      if (k < kRecWords) rdst[k] = src[kWords + k];
-    }
+    stage_team_model<T::NARM>(P.model, lm, llinks);
     __syncthreads();
   }
   const DevModel& m = lm;
