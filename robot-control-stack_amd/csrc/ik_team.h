@@ -37,12 +37,28 @@ RCSH_D void clik_desired(const DevModel& m, const Pose& target, const Pose& tcp,
 // so3 log serves both: log(R^T) = -log(R), same angle, so the angle's acos / sin / cos are evaluated once
 // (ik.h's se3_log + se3_jlog evaluate them three times).
 RCSH_D void se3_log_and_jlog_inverse(const double* R, const double* p, double* err, double* Jlog) {
-  double w[3];
-  const double t = so3_log(R, w), t2 = t * t;
+  // so3 log as ik.h's so3_log, with the angle's sine taken from the one fast_sincos below instead of a libm call
+  const double pi = 3.141592653589793238462643383279502884;
+  const double tr = R[0] + R[4] + R[8];
+  const double t = tr >= 3.0 ? 0.0 : (tr <= -1.0 ? pi : acos((tr - 1.0) / 2.0)), t2 = t * t;
   const bool small = t < kTaylor;
   double st = 0.0, ct = 1.0;
   if (!small) fast_sincos(t, &st, &ct);
   const double tinv = small ? 0.0 : fast_rcp(t), t2inv = tinv * tinv;
+  double w[3];
+  if (t >= pi - 1e-2) {
+    const double cphi = -(tr - 1.0) / 2.0;
+    const double beta = t2 / (1.0 + cphi);
+    const double t0 = (R[0] + cphi) * beta, t1 = (R[4] + cphi) * beta, t2b = (R[8] + cphi) * beta;
+    w[0] = (R[7] > R[5] ? 1.0 : -1.0) * (t0 > 0 ? sqrt(t0) : 0);
+    w[1] = (R[2] > R[6] ? 1.0 : -1.0) * (t1 > 0 ? sqrt(t1) : 0);
+    w[2] = (R[3] > R[1] ? 1.0 : -1.0) * (t2b > 0 ? sqrt(t2b) : 0);
+  } else {
+    const double k = 0.5 * (small ? 1.0 : t * fast_rcp(st));
+    w[0] = k * (R[7] - R[5]);
+    w[1] = k * (R[2] - R[6]);
+    w[2] = k * (R[3] - R[1]);
+  }
   const double i1c = small ? 0.0 : fast_rcp(1.0 - ct);  // 1 / (1 - cos t)
   // ---- log6
   {
