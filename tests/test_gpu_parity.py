@@ -291,6 +291,45 @@ def test_snapshot_restore_replays_bit_for_bit(async_control):
     venv.close()
 
 
+def test_error_behaviour_of_the_boundary():
+    """SURVEY 8b "Errors": bad names raise RuntimeError with the reference's wording (SimRobot.cpp:57-93,
+    SimGripper.cpp:16-28), width / force out of range raises ValueError (SimGripper.cpp:80-83), IK failure is NOT an error
+    (ik_success = False in the state), an unsupported scene is refused at construction, handles survive errors."""
+    import dataclasses
+
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=4)
+    bad = dataclasses.replace(cfg, joints=[*cfg.joints[:-1], "no_such_joint"])
+    with pytest.raises(RuntimeError, match="No joint named no_such_joint"):
+        S.SimRobot(simu, None, bad)
+    bad = dataclasses.replace(cfg, attachment_site="no_such_site")
+    with pytest.raises(RuntimeError, match="No site named no_such_site"):
+        S.SimRobot(simu, None, bad)
+    robot = S.SimRobot(simu, None, cfg)  # the handle is still usable
+    gcfg = default_sim_gripper_cfg()
+    with pytest.raises(RuntimeError, match="No actuator named"):
+        S.SimGripper(simu, dataclasses.replace(gcfg, actuator="no_such_actuator"))
+    grip = S.SimGripper(simu, gcfg)
+    for w, f in ((1.2, 0.0), (-0.1, 0.0), (0.5, -1.0)):
+        with pytest.raises(ValueError):
+            grip.set_normalized_width(w, f)
+    simu.reset(); robot.reset(); grip.reset(); simu.step(1)
+    # an unreachable Cartesian target: no exception, ik_success False, joint targets untouched
+    before = robot.get_state().target_angles.copy()
+    far = np.tile(np.array([3.0, 0.0, 0.5, 0.0, 0.0, 0.0, 1.0]), (4, 1))
+    robot.set_cartesian_position(far)
+    st = robot.get_state()
+    assert not st.ik_success.any() and np.array_equal(st.target_angles, before)
+    simu.step(5)
+    assert np.isfinite(simu.qpos).all()
+    with pytest.raises((RuntimeError, ValueError)):
+        S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=0)
+    simu.close()
+
+
 def test_collision_flags_match_oracle():
     """Reference collision pins (test_sim_envs.py:136-151,347-360) through the HIP path: folded arm in JOINTS mode,
     TCP target below the ground in Cartesian mode; every flag and substep count equals the oracle's."""
