@@ -637,12 +637,15 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   bool more = leader && budget > 0;
   double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
   const bool has_cb = P.robot.present && P.robot.conv_registered;
+  // the few scalars the loop control reads every substep, out of LDS once
+  const double robot_period = P.robot.period, grip_period = P.grip.period, timestep = m.timestep;
+  const bool robot_present = P.robot.present, grip_present = T::GRIP && P.grip.present, has_plane = lc.has_plane;
   uint64_t going = __ballot(more);
   const bool gc_is_mass = team_gc_is_mass<T>(llinks, t);
   TEAM_MARK(11)
   while (going) {
     const bool stepping = (going >> (threadIdx.x & 48)) & 1u;
-    if (leader && stepping && has_cb && r.time - cb_due > P.robot.period) {
+    if (leader && stepping && has_cb && r.time - cb_due > robot_period) {
       plain_callbacks<T, ST>(P, r);
       cb_due = fmin(r.cb(0), r.cb(1));
     }
@@ -651,9 +654,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     // plane contacts of the position stage: every lane tests its own link with the frame the substep just built,
     // in the substeps after which a collision callback is due (condition_callbacks, same comparisons)
     bool due = false;
-    if (leader && stepping && until_conv && lc.has_plane) {
-      const double t_next = r.time + m.timestep;
-      due = (P.robot.present && t_next - r.cb(2) > P.robot.period) || (T::GRIP && P.grip.present && t_next - r.cb(3) > P.grip.period);
+    if (leader && stepping && until_conv && has_plane) {
+      const double t_next = r.time + timestep;
+      due = (robot_present && t_next - r.cb(2) > robot_period) || (grip_present && t_next - r.cb(3) > grip_period);
     }
     const bool want_contacts = team_ballot(due) != 0;
     uint32_t hit = 0;
@@ -676,7 +679,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     });
     __syncthreads();
     if (leader && stepping) {
-      r.time += m.timestep;
+      r.time += timestep;
       have_frames = true;
       --budget;
       if (until_conv) {
