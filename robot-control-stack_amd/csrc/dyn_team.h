@@ -442,6 +442,18 @@ RCSH_D bool team_gc_is_mass(const LinkRec* links, int t) {
   return __ballot(!(links[tl].gcm == links[tl].mass && links[tl].gc_same_com)) == 0;
 }
 
+// wave-uniform model scalars team_substep reads every substep, fetched from the LDS copy once per launch
+struct SubstepK {
+  double h, gravity[3], grp_c0, grp_c1;
+  int32_t site_link, eq_active;
+  RCSH_D void load(const DevModel& m) {
+    h = m.timestep;
+    gravity[0] = m.gravity[0]; gravity[1] = m.gravity[1]; gravity[2] = m.gravity[2];
+    grp_c0 = m.grp_coef[0]; grp_c1 = m.grp_coef[1];
+    site_link = m.site_link; eq_active = m.eq_active;
+  }
+};
+
 // One substep of the environment whose LDS block is `st`, executed by its 16 lanes together (t = lane in team).
 // Reads qpos / qvel / ctrl from the block and, if `stepping`, writes the advanced qpos / qvel, the pre-step qpos
 // and the pre-step world frame of the attachment-site link back (same contract as dyn.h's substep).
@@ -452,15 +464,15 @@ RCSH_D bool team_gc_is_mass(const LinkRec* links, int t) {
 // FRIC: the model has dry joint friction rows (dof_frictionloss); a separate instantiation so that models without
 // them carry none of that code.
 template <class T, bool FRIC, class FrameFn>
-RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping, bool gc_is_mass,
-                         FrameFn&& on_frame) {
+RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping,
+                         bool gc_is_mass, FrameFn&& on_frame) {
   static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
   constexpr int NL = T::NL, NA = T::NARM;
   const bool valid = t < NL;
   const int tl = valid ? t : NL - 1;
   const int ta = t < NA ? t : 0;
-  const double h = m.timestep;
+  const double h = sk.h;
   const LinkRec& lk = links[tl];
   KinK kk;
   kk.load(lk);
@@ -480,7 +492,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   TEAM_MARK(1)
   on_frame(R, p);
   if (stepping && valid) st.qpre(tl) = q;
-  if (stepping && t == m.site_link) {
+  if (stepping && t == sk.site_link) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) st.link(k) = R[k];
 #pragma unroll
@@ -515,7 +527,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
     cross_motion(vel, S, sd);  // S x S = 0: the link's own joint velocity does not contribute
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc[k] = scan_from_root<T>(sd[k] * qd, chain, second);
-    acc[3] -= m.gravity[0]; acc[4] -= m.gravity[1]; acc[5] -= m.gravity[2];
+    acc[3] -= sk.gravity[0]; acc[4] -= sk.gravity[1]; acc[5] -= sk.gravity[2];
   }
   TEAM_MARK(2)
   ActK ak;
@@ -600,7 +612,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   const double bias = dot6(S, F);
   double gc;
   {
-    const double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    const double ng[3] = {-sk.gravity[0], -sk.gravity[1], -sk.gravity[2]};
     double w[6];
     cross3(hs, ng, w);
     w[3] = ak.gcm_sub * ng[0]; w[4] = ak.gcm_sub * ng[1]; w[5] = ak.gcm_sub * ng[2];
@@ -628,8 +640,8 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
     if (t == NA || t == NA + 1) {
       // gripper constants: one batch
       const int32_t g_has = m.grp_has_act, g_cl = m.grp_ctrllimited, g_ba = m.grp_biasaffine, g_fl = m.grp_forcelimited;
-      const int32_t e_on = m.eq_active;
-      const double g_c0 = m.grp_coef[0], g_c1 = m.grp_coef[1], g_gain = m.grp_gain;
+      const int32_t e_on = sk.eq_active;
+      const double g_c0 = sk.grp_c0, g_c1 = sk.grp_c1, g_gain = m.grp_gain;
       const double g_b0 = m.grp_bias[0], g_b1 = m.grp_bias[1], g_b2 = m.grp_bias[2];
       const double g_cr0 = m.grp_ctrlrange[0], g_cr1 = m.grp_ctrlrange[1], g_fr0 = m.grp_forcerange[0], g_fr1 = m.grp_forcerange[1];
       const double gctrl = st.c(NA);
@@ -711,7 +723,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
   //   qacc = A^-1 (qfrc_smooth + qfrc_constraint) = y15 + fe y14 + c0 y13 + c1 y12 + c2 y11
   // is five multiply-adds per lane -- no second, serial solve.  (Models with dry friction put a force on every joint:
   // they keep one implicit lane, 15, that solves again after the constraint solve; so does the rare fallback.)
-  const bool has_eq = T::GRIP && m.eq_active;
+  const bool has_eq = T::GRIP && sk.eq_active;
   const int nrows = __popc(limrows);
   const bool helper_lane = FRIC ? t == kTeamLanes - 1 : t >= kTeamLanes - 5;
   // idx0..2: the joints of the first three limit rows (-1: no such row); lane s guesses that the rows whose bit is set
@@ -752,7 +764,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
     }
   }
   if constexpr (T::GRIP) {
-    const double c0 = m.grp_coef[0], c1 = m.grp_coef[1], hg = h * gblock;
+    const double c0 = sk.grp_c0, c1 = sk.grp_c1, hg = h * gblock;
     const double e = has_eq && !helper_lane ? eqD : 0.0, g = helper_lane ? hg : 0.0;
     H[tri(NA, NA)] += fma(g * c0, c0, e);
     H[tri(NA + 1, NA)] += fma(g * c0, c1, e * eqJ1);
@@ -847,7 +859,7 @@ RCSH_D void team_substep(const DevModel& m, const LinkRec* links, const StageTea
           H[tri(i, i)] += st.dg(i);
         }
         if constexpr (T::GRIP) {
-          const double c0 = m.grp_coef[0], c1 = m.grp_coef[1], hg = h * gblock;
+          const double c0 = sk.grp_c0, c1 = sk.grp_c1, hg = h * gblock;
           H[tri(NA, NA)] += hg * c0 * c0;
           H[tri(NA + 1, NA)] += hg * c0 * c1;
           H[tri(NA + 1, NA + 1)] += hg * c1 * c1;

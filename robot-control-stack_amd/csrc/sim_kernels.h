@@ -642,6 +642,8 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   const bool robot_present = P.robot.present, grip_present = T::GRIP && P.grip.present, has_plane = lc.has_plane;
   uint64_t going = __ballot(more);
   const bool gc_is_mass = team_gc_is_mass<T>(llinks, t);
+  SubstepK sk;
+  sk.load(m);
   TEAM_MARK(11)
   while (going) {
     const bool stepping = (going >> (threadIdx.x & 48)) & 1u;
@@ -660,7 +662,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     }
     const bool want_contacts = team_ballot(due) != 0;
     uint32_t hit = 0;
-    team_substep<T, FRIC>(m, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
+    team_substep<T, FRIC>(m, sk, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
       if (!want_contacts) return;
       const double* nrm = lc.plane_n;
       const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
