@@ -10,10 +10,13 @@
 //    scans -- in world-origin Pluecker coordinates they are plain sums;
 //  * the 9x9 factorisations do not parallelise over 9 lanes (a distributed LDL^T costs more exchange than it
 //    saves), so the lanes factor DIFFERENT matrices instead: lane s < 2^k solves the constraint problem under the
-//    s-th guess of the active set of the k joint-limit rows, lane 15 factors the implicit-integrator matrix.  The
-//    cost is convex piecewise quadratic, so the guess whose solution reproduces its own active set IS the
-//    minimiser: the Newton / line-search iteration of dyn.h collapses into one factorisation slot.  (k > 3 or no
-//    self-consistent guess -- ties -- falls back to that iteration, run redundantly by the team.)
+//    s-th guess of the active set of the k joint-limit rows, lanes 11..15 factor the implicit-integrator matrix,
+//    each with another right-hand side (qfrc_smooth and the Jacobians of the rows).  The cost is convex piecewise
+//    quadratic, so the guess whose solution reproduces its own active set IS the minimiser: the Newton /
+//    line-search iteration of dyn.h collapses into one factorisation slot, and the implicit solve for
+//    qfrc_smooth + qfrc_constraint is a superposition of the helpers' solutions.  (k > 3 or no self-consistent
+//    guess -- ties -- falls back to the iteration, run redundantly by the team; models with dry joint friction,
+//    three zones per row, always iterate.)
 //
 // Exchange between lanes that is not a shift (motion axes for the mass-matrix rows, the matrix itself, the
 // solver result) goes through the environment's LDS block (StageTeam), [slot] contiguous per environment.
