@@ -681,6 +681,7 @@ RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* l
       if (f1) { st.eq(0) = eqD; st.eq(1) = eqAref; st.eq(2) = eqJ1; st.eq(3) = gblock; }
     }
   }
+  TEAM_MARK(15)
   double smooth;
   {
     const double passive = -ak.damping * qd + (1.0 - ak.actgravcomp_w) * gc;

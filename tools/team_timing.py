@@ -24,4 +24,5 @@ sub = T * 17
 print("team kernel, block 0 lane 0, cycles per substep:")
 for i in range(10): print(f"  {names[i]:28s} {a[i] / sub:9.0f}")
 print(f"  {'substep total':28s} {a[:10].sum() / sub:9.0f}")
+print(f"  (of actuation+rows: through the gripper / coupling block {a[15] / sub:.0f})")
 print(f"per launch: tables -> LDS {a[12] / T:.0f}  load_env {a[13] / T:.0f}  env_prologue {a[14] / T:.0f}  rest of prologue {a[11] / T:.0f}  epilogue {a[10] / T:.0f}  substeps {a[:10].sum() / T:.0f}")
