@@ -243,6 +243,33 @@ int rcsh_sim_set_qvel(rcsh_sim* sim, const double* qvel, const uint8_t* mask);
 int rcsh_sim_nq(const rcsh_sim* sim);
 int rcsh_sim_nu(const rcsh_sim* sim);
 
+/* One free-floating box on the floor plane -- the `box_geom` body of the reference's pick-up scene
+ * (assets/scenes/fr3_simple_pick_up/scene.xml:30-33), whose free joint the task wrappers write and read through
+ * mjData: RandomCubePos `sim.data.joint("box_joint").qpos = [...]` (python/rcs/envs/sim.py:379-383),
+ * PickCubeSuccessWrapper `sim.data.joint("box_joint").qpos[2]` / `[:3]` (sim.py:399-412).  The description carries
+ * the mjModel constants of that body and of its contact pair with the floor (mj_contactParam already applied:
+ * friction = element-wise max, solref / solimp mixed) plus the solver options the contact solve reads
+ * (assets/fr3/mjcf/fr3_common.xml:3).  qpos is [x y z qw qx qy qz], qvel [linear (world), angular (body frame)].
+ * Robot-box contacts are not built: the box touches the floor only.  FR3 + hand archetype, team kernel. */
+typedef struct rcsh_free_box_desc {
+  double qpos0[7];
+  double mass, inertia[3];   /* centre of mass at the body origin, principal axes = body axes */
+  double size[3];            /* half extents of the box geom */
+  double friction[3];        /* of the floor / box pair */
+  double solref[2], solimp[5];
+  double plane_z;            /* floor: z = plane_z, normal +z */
+  double impratio;           /* mjOption.impratio */
+  double noslip_tolerance;   /* mjOption.noslip_tolerance */
+  int32_t noslip_iterations; /* mjOption.noslip_iterations */
+  int32_t cone_elliptic;     /* mjOption.cone == mjCONE_ELLIPTIC (the only cone type built) */
+} rcsh_free_box_desc;
+int rcsh_sim_add_free_box(rcsh_sim* sim, const rcsh_free_box_desc* box);
+int rcsh_sim_reset_free_box(rcsh_sim* sim);
+int rcsh_sim_get_free_qpos(rcsh_sim* sim, double* qpos);  /* [N][7] */
+int rcsh_sim_get_free_qvel(rcsh_sim* sim, double* qvel);  /* [N][6] */
+int rcsh_sim_set_free_qpos(rcsh_sim* sim, const double* qpos, const uint8_t* mask);
+int rcsh_sim_set_free_qvel(rcsh_sim* sim, const double* qvel, const uint8_t* mask);
+
 /* Snapshot / restore of EVERYTHING that evolves (the mjData fields above, the callback scheduler's timestamps and
  * return values, SimRobot / SimGripper state, the wrappers' prev_action / origin / last_action, flags): the reference's
  * closest facility is the GUI bridge's mjSTATE_FULLPHYSICS copy (src/sim/gui_server.cpp:49-60).  The blob is opaque,

@@ -41,6 +41,33 @@ enum { ORC_JNT_SLIDE = 2, ORC_JNT_HINGE = 3 };
 enum { ORC_TRN_JOINT = 0, ORC_TRN_TENDON = 3 };
 enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1, ORC_EFC_FRICTION = 2 };
 
+/* ---- one free rigid box on the floor plane (rcs_object.c) */
+typedef struct orc_box {
+  int present;
+  double qpos0[7];         /* x y z, qw qx qy qz (free joint) */
+  double mass, inertia[3]; /* centre of mass at the body origin, principal axes = body axes */
+  double size[3];          /* half extents of the box geom */
+  double friction[3];      /* mixed with the plane geom: element-wise maximum (equal priority) */
+  double solref[2], solimp[5];
+  double plane_z;          /* floor plane z = plane_z, normal +z */
+  double impratio, noslip_tolerance;
+  int noslip_iterations, nv_total; /* nv of the whole scene (robot + 6) */
+  double meaninertia;              /* mjModel.stat.meaninertia of the whole scene; derived by orc_set0 */
+} orc_box;
+
+typedef struct orc_box_data {
+  double qpos[7], qvel[6], qacc[6], qacc_warmstart[6];
+  double qfrc_smooth[6], qacc_smooth[6];
+  int ncon, zone[4]; /* zone: 0 top (separating), 1 middle (sliding), 2 bottom (sticking) */
+  double con_dist[4], con_pos[4][3], con_mu[4];
+  double J[12][6], aref[12], D[12], R[12], force[12];
+  int newton_iter, noslip_iter;
+} orc_box_data;
+
+void orc_box_reset(const orc_box* b, orc_box_data* d);
+void orc_box_step1(const orc_box* b, orc_box_data* d, double timestep);
+void orc_box_step2(const orc_box* b, orc_box_data* d, const double* gravity, double h, double improvement0);
+
 /* ---- model constants (mjModel subset; filled by the Python side from the compiled scene) */
 typedef struct orc_model {
   int nbody, njnt, nu, ntendon, nwrap, neq, nsite;
@@ -115,6 +142,7 @@ typedef struct orc_model {
   double dof_frictionloss[ORC_MAXV];
   double dof_solref[ORC_MAXV][2];
   double dof_solimp[ORC_MAXV][5];
+  orc_box box;
 } orc_model;
 
 /* ---- per-environment state + scratch (mjData subset) */
@@ -151,6 +179,7 @@ typedef struct orc_data {
   double qfrc_constraint[ORC_MAXV];
   int solver_niter;
   int contact_geom[ORC_MAXCON][2];  /* d->contact[i].geom, i < ncon */
+  orc_box_data box;
 } orc_data;
 
 void orc_set0(orc_model* m);

@@ -23,10 +23,28 @@ I = C.c_int
 
 def build(force: bool = False) -> str:
     """Compile oracle/*.c into oracle/_build/librcs_oracle.so (gcc, seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rcs_physics.c", "rcs_pose_ik.c", "rcs_sim.c", "rcs_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("rcs_physics.c", "rcs_pose_ik.c", "rcs_sim.c", "rcs_object.c", "rcs_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _SO
+
+
+class OrcBox(C.Structure):
+    _fields_ = [
+        ("present", I), ("qpos0", D * 7), ("mass", D), ("inertia", D * 3), ("size", D * 3), ("friction", D * 3),
+        ("solref", D * 2), ("solimp", D * 5), ("plane_z", D), ("impratio", D), ("noslip_tolerance", D),
+        ("noslip_iterations", I), ("nv_total", I), ("meaninertia", D),
+    ]
+
+
+class OrcBoxData(C.Structure):
+    _fields_ = [
+        ("qpos", D * 7), ("qvel", D * 6), ("qacc", D * 6), ("qacc_warmstart", D * 6),
+        ("qfrc_smooth", D * 6), ("qacc_smooth", D * 6), ("ncon", I), ("zone", I * 4),
+        ("con_dist", D * 4), ("con_pos", D * 3 * 4), ("con_mu", D * 4),
+        ("J", D * 6 * 12), ("aref", D * 12), ("D", D * 12), ("R", D * 12), ("force", D * 12),
+        ("newton_iter", I), ("noslip_iter", I),
+    ]
 
 
 class OrcModel(C.Structure):
@@ -56,6 +74,7 @@ class OrcModel(C.Structure):
         ("mesh_vert", C.POINTER(D)), ("body_weldid", I * MAXBODY),
         ("dof_invweight0", D * MAXV),
         ("dof_frictionloss", D * MAXV), ("dof_solref", D * 2 * MAXV), ("dof_solimp", D * 5 * MAXV),
+        ("box", OrcBox),
     ]
 
 
@@ -76,6 +95,7 @@ class OrcData(C.Structure):
         ("efc_D", D * MAXEFC), ("efc_aref", D * MAXEFC), ("efc_force", D * MAXEFC),
         ("efc_K", D * MAXEFC), ("efc_B", D * MAXEFC), ("efc_I", D * MAXEFC), ("efc_frictionloss", D * MAXEFC),
         ("qfrc_constraint", D * MAXV), ("solver_niter", I), ("contact_geom", I * 2 * MAXCON),
+        ("box", OrcBoxData),
     ]
 
 
@@ -195,6 +215,20 @@ def make_model(cm) -> OrcModel:
     m.mesh_vert = verts.ctypes.data_as(C.POINTER(D))
     for name in ("dof_frictionloss", "dof_solref", "dof_solimp"):
         _fill(getattr(m, name), f64(name))
+    free = getattr(cm, "free_bodies", [])
+    if len(free) > 1:
+        raise ValueError("oracle supports one free box")
+    if free:
+        fb = free[0]
+        m.box.present = 1
+        for name in ("qpos0", "inertia", "size", "friction", "solref", "solimp"):
+            _fill(getattr(m.box, name), np.asarray(fb[name], dtype=np.float64))
+        m.box.mass, m.box.plane_z = fb["mass"], fb["plane_z"]
+        m.box.impratio = cm.impratio
+        m.box.noslip_iterations = cm.noslip_iterations if cm.cone == "elliptic" else 0
+        m.box.noslip_tolerance = 1e-6  # mjOption default
+        if cm.cone != "elliptic":
+            raise ValueError("oracle contacts: elliptic cones only")
     lib().orc_set0(C.byref(m))
     return m
 
@@ -348,6 +382,23 @@ class Sim:
 
     def reset(self):
         lib().orc_sim_reset(C.byref(self.s))
+
+    # mjData.joint("box_joint").qpos / .qvel of the scene's free box
+    @property
+    def box_qpos(self) -> np.ndarray:
+        return np.array(self.s.d.box.qpos[:])
+
+    @box_qpos.setter
+    def box_qpos(self, q):
+        self.s.d.box.qpos[:] = [float(x) for x in q]
+
+    @property
+    def box_qvel(self) -> np.ndarray:
+        return np.array(self.s.d.box.qvel[:])
+
+    @box_qvel.setter
+    def box_qvel(self, v):
+        self.s.d.box.qvel[:] = [float(x) for x in v]
 
     # SimRobot
     def set_joint_position(self, q):

@@ -604,6 +604,7 @@ void orc_step1(const orc_model* m, orc_data* d) {
     d->efc_vel[i] = v;
     d->efc_aref[i] = -d->efc_K[i] * d->efc_I[i] * (d->efc_pos[i] - d->efc_margin[i]) - d->efc_B[i] * v;
   }
+  if (m->box.present) orc_box_step1(&m->box, &d->box, m->timestep);
 }
 
 /* --------------------------------------------------- acceleration / constraint */
@@ -780,6 +781,14 @@ void orc_step2(const orc_model* m, orc_data* d) {
   /* mj_fwdConstraint (noslip has no friction rows to act on without contacts / frictionloss) */
   solve_constraints(m, d);
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  if (m->box.present) {
+    /* the box's block of mj_fwdConstraint + integration; the first noslip sweep's improvement counts the cost
+       0.5 f^2 R of every non-equality row of the scene, i.e. the robot's too */
+    double imp0 = 0;
+    for (int i = 0; i < d->nefc; i++)
+      if (d->efc_type[i] != ORC_EFC_EQUALITY) imp0 += 0.5 * d->efc_force[i] * d->efc_force[i] / d->efc_D[i];
+    orc_box_step2(&m->box, &d->box, m->gravity, m->timestep, imp0);
+  }
   /* mj_implicit, implicitfast: (M - h dF/dv) qacc = qfrc_smooth + qfrc_constraint with
      dF/dv = -damping (passive) + moment^T bias_vel moment (actuators not clamped by forcerange) */
   double A[ORC_MAXV][ORC_MAXV], rhs[ORC_MAXV];
@@ -811,6 +820,7 @@ void orc_step2(const orc_model* m, orc_data* d) {
 void orc_reset_data(const orc_model* m, orc_data* d) {
   memset(d, 0, sizeof(*d));
   for (int j = 0; j < m->njnt; j++) d->qpos[j] = m->qpos0[j];
+  if (m->box.present) orc_box_reset(&m->box, &d->box);
 }
 
 /* mj_setConst / set0: dof_invweight0 = diag(M(qpos0)^-1) */
@@ -827,5 +837,11 @@ void orc_set0(orc_model* m) {
     e[j] = 1;
     chol_solve(L, m->njnt, e);
     m->dof_invweight0[j] = e[j];
+  }
+  if (m->box.present) { /* mj_setConst: stat.meaninertia = mean diagonal of M(qpos0) over all dofs */
+    double s = 3 * m->box.mass + m->box.inertia[0] + m->box.inertia[1] + m->box.inertia[2];
+    for (int j = 0; j < m->njnt; j++) s += d.qM[j][j];
+    m->box.nv_total = m->njnt + 6;
+    m->box.meaninertia = s / m->box.nv_total;
   }
 }

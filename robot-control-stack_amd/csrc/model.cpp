@@ -66,6 +66,8 @@ void mat_to_quat_wxyz(const double* m, double* q) {
   for (int k = 0; k < 4; ++k) q[k] /= n;
 }
 
+}  // namespace
+
 // solimp -> kernel-side form (clamps follow MuJoCo's: d0, d1, midpoint in [0.0001, 0.9999], width >= 0, power >= 1)
 Imp make_imp(const double* solimp) {
   Imp p;
@@ -101,6 +103,8 @@ void make_kb(const double* solref, const double* solimp, double timestep, double
   }
 }
 
+namespace {
+
 template <class T>
 void compute_invweight0(DevModel& m) {
   double q[T::NL], qd[T::NL];
@@ -110,6 +114,8 @@ void compute_invweight0(DevModel& m) {
   Stage<T, 1> st{buf};
   smooth_dynamics<T, 1>(m, q, qd, st, sm);
   double* M = &st.M(0);
+  m.inertia_diag_sum = 0;
+  for (int j = 0; j < T::NL; ++j) m.inertia_diag_sum += st.M(tri(j, j));
   ldl_factor<T::NL>(M);
   for (int j = 0; j < T::NL; ++j) {
     double e[T::NL];

@@ -106,6 +106,7 @@ struct DevModel {
   double fl_D[kMaxLinks];
   double fl_B[kMaxLinks];
   double fl_R[kMaxLinks];  // half-width of the quadratic zone: frictionloss / D
+  double inertia_diag_sum;  // trace of M(qpos0) (host side: mjModel.stat.meaninertia of scenes with free bodies)
 };
 
 // Per-link constants of the team kernels (dyn_team.h, ik_team.h) as an array of structures: lane t reads link t's

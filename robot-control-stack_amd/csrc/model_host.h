@@ -56,6 +56,10 @@ bool dispatch_topology(int narm, bool grip, F&& fn) {
   return false;
 }
 
+// solimp / solref in the kernels' form (mj_makeImpedance's clamps; time constant floored at 2 timesteps)
+Imp make_imp(const double* solimp);
+void make_kb(const double* solref, const double* solimp, double timestep, double& K, double& B);
+
 // Returns "" on success, else the reason the scene is rejected.  act_slot[u] = ctrl slot of mj actuator u.
 std::string finalize_model(const HostModel& h, DevModel& m, std::vector<int>& act_slot);
 std::string attach_robot_frames(const HostModel& h, DevModel& m, int site, int base_body);

@@ -61,6 +61,7 @@ struct rcsh_sim {
   RobotCfg robot{};
   GripperCfg gripcfg{};
   EnvCfg env{};
+  BoxCfg box{};
   bool env_configured = false;
   // staging for the host-pointer entry points
   double* d_stage = nullptr;   // n * 32 doubles
@@ -100,6 +101,7 @@ Params make_params(rcsh_sim* s) {
   P.robot = s->robot;
   P.grip = s->gripcfg;
   P.env = s->env;
+  P.box = s->box;
   return P;
 }
 
@@ -151,10 +153,14 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   //    caps it at three workgroups per CU): 9.5 M at 4096 environments, 30 M at 524288.  It no longer wins at any
   //    batch size (tools/sweep_envs.sh); it stays as an independent second formulation that the parity tests run
   //    against the same oracle (rcsh_sim_set_kernel / RCSH_KERNEL=lane).  It has no dry-friction rows.
-  const bool team = s->dm.has_friction || s->kernel != RCSH_KERNEL_LANE;
+  const bool team = s->dm.has_friction || s->box.present || s->kernel != RCSH_KERNEL_LANE;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    if (team && s->dm.has_friction)
+    if (s->box.present) {
+      // scenes with a free box: the FR3 + hand archetype only (rcsh_sim_add_free_box checks)
+      if constexpr (T::NARM == 7 && T::GRIP)
+        hipLaunchKernelGGL((k_run_team<T, false, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+    } else if (team && s->dm.has_friction)
       hipLaunchKernelGGL((k_run_team<T, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     else if (team)
       hipLaunchKernelGGL((k_run_team<T, false>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
@@ -194,6 +200,7 @@ int field_of(rcsh_sim* s, const char* name) {
     if (f == "preva") return (int)L::PREVA;
     if (f == "origin") return (int)L::ORIGIN;
     if (f == "lasta") return (int)L::LASTA;
+    if (f == "box") return (int)L::BOX;
     return -1;
   });
 }
@@ -373,6 +380,8 @@ int rcsh_sim_set_kernel(rcsh_sim* s, int32_t variant) {
   if (variant < RCSH_KERNEL_AUTO || variant > RCSH_KERNEL_LANE) return fail(RCSH_ERR_ARG, "unknown kernel variant");
   if (variant == RCSH_KERNEL_LANE && s->dm.has_friction)
     return fail(RCSH_ERR_MODEL, "the lane kernel has no dry-friction (frictionloss) rows; this model needs the team kernel");
+  if (variant == RCSH_KERNEL_LANE && s->box.present)
+    return fail(RCSH_ERR_MODEL, "the lane kernel does not step free bodies; this scene needs the team kernel");
   s->kernel = variant;
   return RCSH_OK;
 }
@@ -438,6 +447,12 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   if (!rc) rc = scatter_host(s, field_of(s, "ctrl"), s->nu, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "time"), 1, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "cb"), 6, z.data(), mask);
+  if (!rc && s->box.present) {
+    std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
+    for (int e = 0; e < s->n; ++e)
+      for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = s->box.qpos0[k];
+    rc = scatter_host(s, field_of(s, "box"), kBoxState, b0.data(), mask);
+  }
   return rc;
 }
 
@@ -736,6 +751,51 @@ int rcsh_sim_get_ctrl(rcsh_sim* s, double* c) {
 }
 int rcsh_sim_set_qpos(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); return scatter_host(s, field_of(s, "qpos"), s->nl, q, mask); }
 int rcsh_sim_set_qvel(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); return scatter_host(s, field_of(s, "qvel"), s->nl, q, mask); }
+
+// ---- free box of the scene (reference: mjData.joint("box_joint").qpos, python/rcs/envs/sim.py:379-383,399,412)
+int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
+  REQUIRE_SIM(s);
+  if (!d) return fail(RCSH_ERR_ARG, "null free-box description");
+  if (s->box.present) return fail(RCSH_ERR_STATE, "a free box is already attached to this sim");
+  if (!(s->narm == 7 && s->grip)) return fail(RCSH_ERR_MODEL, "free bodies are compiled for the FR3 + hand archetype only");
+  if (s->dm.has_friction) return fail(RCSH_ERR_MODEL, "free bodies are not compiled for models with dry joint friction");
+  if (s->kernel == RCSH_KERNEL_LANE) return fail(RCSH_ERR_MODEL, "the lane kernel does not step free bodies");
+  if (!d->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
+  if (!(d->mass > 0) || !(d->inertia[0] > 0) || !(d->inertia[1] > 0) || !(d->inertia[2] > 0) || !(d->impratio > 0))
+    return fail(RCSH_ERR_ARG, "free box: mass, inertia and impratio must be positive");
+  BoxCfg b{};
+  b.present = 1;
+  b.noslip_iterations = d->noslip_iterations;
+  for (int k = 0; k < 7; ++k) b.qpos0[k] = d->qpos0[k];
+  b.mass = d->mass; b.inv_mass = 1.0 / d->mass;
+  for (int k = 0; k < 3; ++k) { b.inertia[k] = d->inertia[k]; b.inv_inertia[k] = 1.0 / d->inertia[k]; b.size[k] = d->size[k]; }
+  b.fr = d->friction[0];
+  make_kb(d->solref, d->solimp, s->dm.timestep, b.K, b.B);
+  b.imp = make_imp(d->solimp);
+  b.inv_impratio = 1.0 / d->impratio;
+  b.plane_z = d->plane_z;
+  // mjModel.stat.meaninertia: mean diagonal of M(qpos0) over all dofs of the scene
+  const int nv = s->nl + 6;
+  const double meaninertia = (s->dm.inertia_diag_sum + 3 * d->mass + d->inertia[0] + d->inertia[1] + d->inertia[2]) / nv;
+  b.scale = 1.0 / (meaninertia * nv);
+  b.noslip_tolerance = d->noslip_tolerance;
+  s->box = b;
+  return rcsh_sim_reset_free_box(s);
+}
+int rcsh_sim_reset_free_box(rcsh_sim* s) {
+  REQUIRE_SIM(s);
+  if (!s->box.present) return fail(RCSH_ERR_STATE, "no free box attached: call rcsh_sim_add_free_box first");
+  std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
+  for (int e = 0; e < s->n; ++e)
+    for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = s->box.qpos0[k];
+  return scatter_host(s, field_of(s, "box"), kBoxState, b0.data(), nullptr);
+}
+#define REQUIRE_BOX(s) \
+  if (!(s)->box.present) return fail(RCSH_ERR_STATE, "no free box attached: call rcsh_sim_add_free_box first")
+int rcsh_sim_get_free_qpos(rcsh_sim* s, double* q) { REQUIRE_SIM(s); REQUIRE_BOX(s); return gather_host(s, field_of(s, "box") + kBoxQ, 7, q); }
+int rcsh_sim_get_free_qvel(rcsh_sim* s, double* v) { REQUIRE_SIM(s); REQUIRE_BOX(s); return gather_host(s, field_of(s, "box") + kBoxV, 6, v); }
+int rcsh_sim_set_free_qpos(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); REQUIRE_BOX(s); return scatter_host(s, field_of(s, "box") + kBoxQ, 7, q, mask); }
+int rcsh_sim_set_free_qvel(rcsh_sim* s, const double* v, const uint8_t* mask) { REQUIRE_SIM(s); REQUIRE_BOX(s); return scatter_host(s, field_of(s, "box") + kBoxV, 6, v, mask); }
 
 size_t rcsh_sim_state_bytes(const rcsh_sim* s) {
   if (!s) return 0;

@@ -12,6 +12,7 @@
 
 #include <cstdint>
 
+#include "box_team.h"
 #include "dyn.h"
 #include "dyn_team.h"
 #include "pose.h"
@@ -72,7 +73,8 @@ struct Lay {
   static constexpr int PREVA = SITE + 12;        // RobotEnv.prev_action (7 wide: joints or tquat)
   static constexpr int ORIGIN = PREVA + 7;       // RelativeActionSpace._origin
   static constexpr int LASTA = ORIGIN + 7;       // RelativeActionSpace._last_action
-  static constexpr int COUNT = LASTA + 7;
+  static constexpr int BOX = LASTA + 7;           // free box (box_team.h): qpos 7, qvel 6, qacc_warmstart 6
+  static constexpr int COUNT = BOX + kBoxState;
 };
 
 struct RunOp {
@@ -110,6 +112,7 @@ struct Params {
   RobotCfg robot;
   GripperCfg grip;
   EnvCfg env;
+  BoxCfg box;
 };
 
 // ---- everything one environment keeps in registers during a launch
@@ -570,7 +573,7 @@ __device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModel& l
 // The same entry point with one TEAM of 16 lanes per environment (dyn_team.h): four environments per wavefront,
 // one wavefront per workgroup.  Lane 0 of a team (the leader) owns the RCS bookkeeping -- wrappers, callback
 // scheduler, observation -- through the same helpers as k_run; all 16 lanes run the physics.
-template <class T, bool FRIC>
+template <class T, bool FRIC, bool BOX = false>
 __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
@@ -634,6 +637,16 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // Which teams still step is decided by their leaders and spread with a ballot (no LDS flag, no barrier); the
   // two plain callbacks fire every `period` of simulated time, so the leader only looks at them when the earlier
   // of their two timestamps is due.
+  // the free box of the scene: its state sits in the team's LDS block between substeps (box_team.h)
+  __shared__ double lbox[BOX ? kBoxLds * kTeams : 1];
+  double* const bs = lbox + (BOX ? team * kBoxLds : 0);
+  if constexpr (BOX) {
+    if (live) {
+      using L = Lay<T>;
+      for (int k = t; k < kBoxState; k += kTeamLanes)
+        bs[k] = op.do_reset ? (k < 7 ? P.box.qpos0[k] : 0.0) : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
+    }
+  }
   bool more = leader && budget > 0;
   double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
   const bool has_cb = P.robot.present && P.robot.conv_registered;
@@ -680,6 +693,20 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
     });
     __syncthreads();
+    if constexpr (BOX) {
+      if (stepping) {
+        // 0.5 f^2 R of the robot's active joint-limit rows at the constrained solution (f = -D r, R = 1 / D)
+        const int tl = t < T::NL ? t : T::NL - 1;
+        const double rr = st.limS(tl) * st.xs(tl) - st.limA(tl);
+        double imp0 = t < T::NL && st.limS(tl) != 0.0 && rr < 0 ? 0.5 * st.limD(tl) * rr * rr : 0.0;
+        imp0 = quad_sum(imp0);  // sum over the team's 16 lanes: quads, then rotations by 4 and 8 within the row
+        imp0 += row_rotate<4>(imp0);
+        imp0 += row_rotate<8>(imp0);
+        imp0 = lane_get(imp0, threadIdx.x & 48);  // one lane's bits for the whole team
+        box_substep(P.box, bs, m.gravity, timestep, imp0, t);
+      }
+      __syncthreads();
+    }
     if (leader && stepping) {
       r.time += timestep;
       have_frames = true;
@@ -696,6 +723,12 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
     env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
+  }
+  if constexpr (BOX) {
+    if (live) {
+      using L = Lay<T>;
+      for (int k = t; k < kBoxState; k += kTeamLanes) P.S[(size_t)(L::BOX + k) * P.n + e] = bs[k];
+    }
   }
   TEAM_MARK(10)
   TEAM_CLOCK_FLUSH()

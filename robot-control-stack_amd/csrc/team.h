@@ -60,6 +60,13 @@ RCSH_D double row_up_or_banks(double old, double x) {
   const int hi = __builtin_amdgcn_update_dpp(hi32(old), hi32(x), 0x110 + N, 0xf, BANKS, false);
   return mk64(hi, lo);
 }
+// value of lane (t - N) mod 16 of the same row
+template <int N>
+RCSH_D double row_rotate(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, lo32(x), 0x120 + N, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, hi32(x), 0x120 + N, 0xf, 0xf, true);
+  return mk64(hi, lo);
+}
 // arbitrary lane of the wave (LDS crossbar, no memory): src is an absolute lane index
 RCSH_D double lane_get(double x, int src) {
   const int lo = __builtin_amdgcn_ds_bpermute(src << 2, lo32(x));

@@ -36,6 +36,7 @@ def _scene(name: str, robot_type: common.RobotType) -> Scene:
 
 scenes: dict[str, Scene] = {
     "fr3_empty_world": _scene("fr3_empty_world", common.RobotType.FR3),
+    "fr3_simple_pick_up": _scene("fr3_simple_pick_up", common.RobotType.FR3),
     "xarm7_empty_world": _scene("xarm7_empty_world", common.RobotType.XArm7),
 }
 

@@ -57,6 +57,33 @@ class ModelDesc(C.Structure):
     ]
 
 
+class FreeBoxDesc(C.Structure):
+    _fields_ = [
+        ("qpos0", C.c_double * 7), ("mass", C.c_double), ("inertia", C.c_double * 3), ("size", C.c_double * 3),
+        ("friction", C.c_double * 3), ("solref", C.c_double * 2), ("solimp", C.c_double * 5), ("plane_z", C.c_double),
+        ("impratio", C.c_double), ("noslip_tolerance", C.c_double), ("noslip_iterations", C.c_int32),
+        ("cone_elliptic", C.c_int32),
+    ]
+
+
+def make_free_box_desc(cm) -> FreeBoxDesc | None:
+    """rcsh_free_box_desc of a compiled scene's free body (None: the scene has none)."""
+    free = getattr(cm, "free_bodies", [])
+    if not free:
+        return None
+    if len(free) > 1:
+        raise RuntimeError("scenes with more than one free body are not supported")
+    fb = free[0]
+    d = FreeBoxDesc()
+    for name in ("qpos0", "inertia", "size", "friction", "solref", "solimp"):
+        getattr(d, name)[:] = [float(x) for x in fb[name]]
+    d.mass, d.plane_z = float(fb["mass"]), float(fb["plane_z"])
+    d.impratio, d.noslip_iterations = float(cm.impratio), int(cm.noslip_iterations)
+    d.noslip_tolerance = 1e-6  # mjOption default; the MJCF subset has no attribute for it
+    d.cone_elliptic = int(cm.cone == "elliptic")
+    return d
+
+
 class RobotDesc(C.Structure):
     _fields_ = [
         ("dof", C.c_int32), ("joint_ids", _I32P), ("actuator_ids", _I32P),
@@ -96,7 +123,8 @@ EXPORTS = (
     "rcsh_ik_inverse", "rcsh_ik_forward", "rcsh_sim_add_gripper", "rcsh_gripper_set_normalized_width",
     "rcsh_gripper_get_normalized_width", "rcsh_gripper_is_grasped", "rcsh_gripper_reset", "rcsh_gripper_get_state",
     "rcsh_sim_get_qpos", "rcsh_sim_get_qvel", "rcsh_sim_get_ctrl", "rcsh_sim_get_time", "rcsh_sim_set_qpos",
-    "rcsh_sim_set_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
+    "rcsh_sim_set_qvel", "rcsh_sim_add_free_box", "rcsh_sim_reset_free_box", "rcsh_sim_get_free_qpos", "rcsh_sim_get_free_qvel",
+    "rcsh_sim_set_free_qpos", "rcsh_sim_set_free_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
@@ -129,6 +157,12 @@ def load() -> C.CDLL:
     L.rcsh_sim_get_state.argtypes = [C.c_void_p, C.c_void_p]
     L.rcsh_sim_set_state.argtypes = [C.c_void_p, C.c_void_p]
     L.rcsh_sim_create.argtypes = [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.rcsh_sim_add_free_box.argtypes = [C.c_void_p, C.POINTER(FreeBoxDesc)]
+    L.rcsh_sim_reset_free_box.argtypes = [C.c_void_p]
+    for fn in (L.rcsh_sim_get_free_qpos, L.rcsh_sim_get_free_qvel):
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+    for fn in (L.rcsh_sim_set_free_qpos, L.rcsh_sim_set_free_qvel):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_sim_destroy.argtypes = [C.c_void_p]
     L.rcsh_sim_destroy.restype = None
     L.rcsh_sim_step.argtypes = [C.c_void_p, C.c_int64]

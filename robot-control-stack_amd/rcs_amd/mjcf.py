@@ -663,9 +663,60 @@ class _Compiler:
                         item["body"] = 0
                     elif item["body"] > tmp_start:
                         item["body"] -= 1
+        self._split_free_bodies()
         self._sort_bodies_depth_first()
         self._parse_rest()
-        return self._emit()
+        m = self._emit()
+        m.free_bodies = self.free_bodies  # type: ignore[attr-defined]
+        return m
+
+    def _split_free_bodies(self):
+        """Take free-floating objects (a child of the world with one free joint and one box geom, e.g. the cube of
+        ``fr3_simple_pick_up``) out of the articulated tables: they are simulated as separate rigid bodies that
+        touch the floor plane.  They must come last in the file, as in the reference's scenes."""
+        self.free_bodies: list[dict] = []
+        while len(self.bodies) > 1:
+            b = self.bodies[-1]
+            if not (b["joints"] and self.joints[b["joints"][0]]["type"] == JNT_FREE):
+                break
+            bid = len(self.bodies) - 1
+            if b["parent"] != 0 or len(b["joints"]) != 1 or b["joints"][0] != len(self.joints) - 1:
+                raise MjcfError(f"free body {b['name']!r}: only top-level bodies with a single free joint are supported")
+            gids = b["geoms"]
+            if len(gids) != 1 or self.geoms[gids[0]]["type"] != GEOM_BOX or gids[0] != len(self.geoms) - 1:
+                raise MjcfError(f"free body {b['name']!r}: exactly one box geom is supported")
+            if any(x["body"] == bid for x in self.sites + self.cams):
+                raise MjcfError(f"free body {b['name']!r}: sites / cameras on free bodies are not supported")
+            g = self.geoms[gids[0]]
+            if np.any(g["pos"] != 0) or np.any(quat_normalize(g["quat"]) != np.array([1.0, 0, 0, 0])):
+                raise MjcfError(f"free body {b['name']!r}: the box geom must sit at the body frame")
+            inert = b["inertial"] if b["inertial"] is not None else None
+            if inert is not None:
+                raise MjcfError(f"free body {b['name']!r}: explicit <inertial> is not supported")
+            mass, diag = self._geom_mass_inertia(g)
+            planes = [p for p in self.geoms if p["type"] == GEOM_PLANE and p["body"] == 0]
+            if len(planes) != 1:
+                raise MjcfError("free bodies need exactly one floor plane in the world body")
+            pl = planes[0]
+            if np.any(quat_normalize(pl["quat"]) != np.array([1.0, 0, 0, 0])):
+                raise MjcfError("the floor plane must be horizontal")
+            if pl["priority"] != g["priority"] or pl["condim"] != 3 or g["condim"] != 3:
+                raise MjcfError("floor / box contact: equal priority and condim 3 are supported")
+            if pl["margin"] or pl["gap"] or g["margin"] or g["gap"]:
+                raise MjcfError("floor / box contact: margin and gap are not supported")
+            j = self.joints[b["joints"][0]]
+            self.free_bodies.insert(0, dict(
+                name=b["name"], joint_name=j["name"], geom_name=g["name"],
+                qpos0=np.concatenate([b["pos"], quat_normalize(b["quat"])]),
+                mass=float(mass), inertia=np.asarray(diag, dtype=np.float64), size=g["size"].copy(),
+                # mj_contactParam, equal priority: friction element-wise max, solref / solimp mixed 50:50 (solmix 1:1)
+                friction=np.maximum(pl["friction"], g["friction"]),
+                solref=0.5 * (pl["solref"] + g["solref"]), solimp=0.5 * (pl["solimp"] + g["solimp"]),
+                plane_z=float(pl["pos"][2]),
+            ))
+            self.bodies.pop()
+            self.joints.pop()
+            self.geoms.pop()
 
     def _sort_bodies_depth_first(self):
         # _parse_body already emits parents before children in depth-first order, which is the

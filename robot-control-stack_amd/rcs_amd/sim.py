@@ -56,6 +56,9 @@ class Sim:
         desc, self._keep = _lib.make_model_desc(self.model)
         self._h = C.c_void_p()
         _lib.check(self._L.rcsh_sim_create(C.byref(desc), self.n_envs, self.device, C.byref(self._h)))
+        box = _lib.make_free_box_desc(self.model)
+        if box is not None:
+            _lib.check(self._L.rcsh_sim_add_free_box(self._h, C.byref(box)))
         self._cfg = SimConfig()
         if cfg is not None:
             self.set_config(cfg)
@@ -146,6 +149,32 @@ class Sim:
     def set_qpos(self, qpos, mask=None) -> None:
         q = np.ascontiguousarray(np.broadcast_to(np.asarray(qpos, dtype=np.float64), (self.n_envs, self.model.nq)))
         _lib.check(self._L.rcsh_sim_set_qpos(self._h, _lib.ptr(q), _lib.ptr(_mask(mask, self.n_envs))))
+
+    # ``sim.data.joint(name).qpos`` of a free joint (reference python/rcs/envs/sim.py:379-383,399-412)
+    def _free_joint(self, name: str) -> dict:
+        for fb in getattr(self.model, "free_bodies", []):
+            if fb["joint_name"] == name:
+                return fb
+        raise KeyError(f"Invalid name '{name}'. Valid free joints: {[fb['joint_name'] for fb in getattr(self.model, 'free_bodies', [])]}")
+
+    def free_joint_qpos(self, name: str) -> np.ndarray:
+        """[n_envs, 7]: x y z qw qx qy qz."""
+        self._free_joint(name)
+        return self._get(self._L.rcsh_sim_get_free_qpos, 7)
+
+    def free_joint_qvel(self, name: str) -> np.ndarray:
+        self._free_joint(name)
+        return self._get(self._L.rcsh_sim_get_free_qvel, 6)
+
+    def set_free_joint_qpos(self, name: str, qpos, mask=None) -> None:
+        self._free_joint(name)
+        q = np.ascontiguousarray(np.broadcast_to(np.asarray(qpos, dtype=np.float64), (self.n_envs, 7)))
+        _lib.check(self._L.rcsh_sim_set_free_qpos(self._h, _lib.ptr(q), _lib.ptr(_mask(mask, self.n_envs))))
+
+    def set_free_joint_qvel(self, name: str, qvel, mask=None) -> None:
+        self._free_joint(name)
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(qvel, dtype=np.float64), (self.n_envs, 6)))
+        _lib.check(self._L.rcsh_sim_set_free_qvel(self._h, _lib.ptr(v), _lib.ptr(_mask(mask, self.n_envs))))
 
     def set_qvel(self, qvel, mask=None) -> None:
         q = np.ascontiguousarray(np.broadcast_to(np.asarray(qvel, dtype=np.float64), (self.n_envs, self.model.nv)))

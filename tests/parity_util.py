@@ -37,6 +37,66 @@ KERNEL = "auto"
 XARM7_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "xarm7_empty_world", "scene.xml")
 
 
+PICKUP_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "fr3_simple_pick_up", "scene.xml")
+
+
+def run_free_box_parity(n_envs=32, n_calls=10, k=25, seed=0, kick=True):
+    """The free box of the pick-up scene, kernel vs oracle: every environment starts the box at a random pose near the
+    floor (some penetrating, some tilted, some in the air) with a random twist, the arm holds its home pose; Sim.step(k)
+    n_calls times.  Returns max abs differences of the box state and the largest contact count / zones seen."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = default_sim_robot_cfg("fr3_simple_pick_up")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    robot = S.SimRobot(simu, None, cfg)
+    S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(PICKUP_SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    qb = np.zeros((n_envs, 7))
+    qb[:, 0] = 0.45 + rng.uniform(-0.1, 0.1, n_envs)
+    qb[:, 1] = rng.uniform(-0.1, 0.1, n_envs)
+    qb[:, 2] = rng.uniform(0.0144, 0.06, n_envs)        # RandomCubePos drops it 14.4 mm INTO the floor (sim.py:377)
+    qb[:, 3:] = rng.normal(size=(n_envs, 4)) * np.array([1.0, 0.15, 0.15, 1.0])  # unnormalised, mostly yaw
+    qb[: n_envs // 4, 3:] = np.array([2 * rng.uniform(size=n_envs // 4) - 1, 0 * qb[: n_envs // 4, 0], 0 * qb[: n_envs // 4, 0], 1 + 0 * qb[: n_envs // 4, 0]]).T
+    vb = np.zeros((n_envs, 6))
+    if kick:
+        vb[:, :3] = rng.uniform(-0.5, 0.5, (n_envs, 3))
+        vb[:, 3:] = rng.uniform(-3, 3, (n_envs, 3))
+    simu.set_free_joint_qpos("box_joint", qb)
+    simu.set_free_joint_qvel("box_joint", vb)
+    for e, o in enumerate(osims):
+        o.box_qpos, o.box_qvel = qb[e], vb[e]
+    rep = {"max_abs_pos": 0.0, "max_abs_quat": 0.0, "max_abs_vel": 0.0, "max_abs_robot_qpos": 0.0, "max_ncon": 0, "zones": set(),
+           "max_newton": 0, "max_noslip": 0, "final_speed": 0.0}
+    home = np.tile(FR3_Q_HOME, (n_envs, 1))
+    for _ in range(n_calls):
+        robot.set_joint_position(home)
+        simu.step(k)
+        qk, vk, qr = simu.free_joint_qpos("box_joint"), simu.free_joint_qvel("box_joint"), simu.qpos
+        for e, o in enumerate(osims):
+            o.set_joint_position(home[e])
+            o.step(k)
+            bd = o.s.d.box
+            rep["max_ncon"] = max(rep["max_ncon"], int(bd.ncon))
+            rep["zones"].update(int(z) for z in bd.zone[: bd.ncon])
+            rep["max_newton"] = max(rep["max_newton"], int(bd.newton_iter))
+            rep["max_noslip"] = max(rep["max_noslip"], int(bd.noslip_iter))
+            rep["max_abs_pos"] = max(rep["max_abs_pos"], float(np.abs(qk[e, :3] - o.box_qpos[:3]).max()))
+            rep["max_abs_quat"] = max(rep["max_abs_quat"], float(np.abs(qk[e, 3:] - o.box_qpos[3:]).max()))
+            rep["max_abs_vel"] = max(rep["max_abs_vel"], float(np.abs(vk[e] - o.box_qvel).max()))
+            rep["max_abs_robot_qpos"] = max(rep["max_abs_robot_qpos"], float(np.abs(qr[e] - o.qpos).max()))
+    rep["final_speed"] = float(np.abs(vk).max())
+    rep["final_z"] = qk[:, 2].copy()
+    simu.close()
+    return rep
+
+
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500):

@@ -432,3 +432,17 @@ def test_headline_batch_is_position_independent():
     assert np.array_equal(after_q[mask], np.broadcast_to(after_q[0], after_q[mask].shape))
     assert not np.array_equal(after_q[0], before_q[0])
     venv.close()
+
+
+def test_free_box_matches_oracle(kernel):
+    """The free box of fr3_simple_pick_up (plane-box contacts, elliptic cones, noslip) against the oracle: tumbling,
+    sliding, popping out of the floor and coming to rest.  The contact problem is strictly convex, both sides solve it
+    to ~1e-13; what is left is round-off amplified by impacts."""
+    import parity_util as pu
+
+    if kernel == "lane":
+        pytest.skip("free bodies are stepped by the team kernel only")
+    rep = pu.run_free_box_parity(n_envs=32, n_calls=12, k=25, seed=3)
+    assert rep["max_ncon"] == 4 and rep["zones"] == {0, 1, 2}, rep  # separating, sliding and sticking contacts all occurred
+    assert rep["max_abs_pos"] < 1e-6 and rep["max_abs_quat"] < 1e-5 and rep["max_abs_vel"] < 1e-3, rep
+    assert rep["max_abs_robot_qpos"] < 1e-9, rep
