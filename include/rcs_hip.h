@@ -296,6 +296,29 @@ int rcsh_env_reset_dev(rcsh_sim* sim, const uint8_t* mask_dev, double* obs_dev, 
 int rcsh_env_step_dev(rcsh_sim* sim, const double* action_dev, const float* gripper_dev, double* obs_dev,
                       uint8_t* info_dev, double* gripper_width_dev, int32_t* substeps_dev);
 
+/* Task layer of the pick-up scene: SimTaskEnvCreator()(...) = SimEnvCreator with RandomCubePos under the
+ * RobotSimWrapper and PickCubeSuccessWrapper on top (python/rcs/envs/creators.py:131-187; the registered gym id
+ * rcs/FR3SimplePickUpSim-v0, python/rcs/__init__.py:67-70).
+ *  - reset: RandomCubePos.reset (python/rcs/envs/sim.py:365-383) runs the inner reset, steps once, writes the box
+ *    pose and the RobotSimWrapper steps once more; `box_qpos` [N][7] is the pose each environment writes (the
+ *    reference draws x, y and the quaternion's w from numpy's global generator; the caller draws them here).
+ *  - step: PickCubeSuccessWrapper.step (sim.py:396-431); `task` [N][9] receives the box pose (7), the reward and
+ *    success (0/1 -- the wrapper returns it as `terminated` and info["success"]).
+ * ee_home / success_height are the wrapper's constants EE_HOME and 0.15 + 0.852. */
+typedef struct rcsh_pick_task_desc {
+  double ee_home[3];
+  double success_height;
+} rcsh_pick_task_desc;
+int rcsh_env_configure_pick_task(rcsh_sim* sim, const rcsh_pick_task_desc* task);
+int rcsh_env_reset_task(rcsh_sim* sim, const uint8_t* mask, const double* box_qpos, double* obs, uint8_t* info, double* gripper_width);
+int rcsh_env_step_task(rcsh_sim* sim, const double* action, const float* gripper, double* obs, uint8_t* info, double* gripper_width,
+                       int32_t* substeps, double* task);
+int rcsh_env_reset_task_dev(rcsh_sim* sim, const uint8_t* mask_dev, const double* box_qpos_dev, double* obs_dev, uint8_t* info_dev,
+                            double* gripper_width_dev);
+int rcsh_env_step_task_dev(rcsh_sim* sim, const double* action_dev, const float* gripper_dev, double* obs_dev, uint8_t* info_dev,
+                           double* gripper_width_dev, int32_t* substeps_dev, double* task_dev);
+
+
 /* device allocation helpers so a host language without a HIP binding can keep rollouts resident */
 int rcsh_dev_alloc(rcsh_sim* sim, size_t bytes, void** ptr);
 int rcsh_dev_free(rcsh_sim* sim, void* ptr);

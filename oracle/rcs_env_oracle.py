@@ -175,3 +175,62 @@ class OracleEnv:
         truncated = bool(s.robot_collision) or not bool(s.ik_success)
         obs, info = self._gripper_obs(self._get_obs(), info)
         return obs, 0, False, truncated, info
+
+
+class OraclePickCubeEnv(OracleEnv):
+    """``SimTaskEnvCreator()(...)`` with the default gripper (reference creators.py:131-187): ``RandomCubePos`` sits
+    between the RobotSimWrapper and the RobotEnv, ``PickCubeSuccessWrapper`` outermost.
+
+        PickCubeSuccessWrapper   envs/sim.py:386-431
+          RelativeActionSpace
+            GripperWrapperSim / GripperWrapper
+              RobotSimWrapper
+                RandomCubePos    envs/sim.py:358-383
+                  RobotEnv
+    """
+
+    EE_HOME = np.array([0.34169773, 0.00047028, 0.4309004])
+
+    def __init__(self, cm, control_mode=CARTESIAN_TRPY, delta_actions=True, async_control=True, frequency=30,
+                 tcp_offset: O.Pose | None = None, include_rotation=True):
+        super().__init__(cm, control_mode=control_mode, gripper=True,
+                         max_relative_movement=(0.2, np.deg2rad(45)) if delta_actions else None, relative_to=LAST_STEP,
+                         async_control=async_control, frequency=frequency, tcp_offset=tcp_offset)
+        self.include_rotation = include_rotation
+
+    def reset(self, box_qpos=None):
+        # GripperWrapper.reset -> RobotSimWrapper.reset: sim.reset() -> RandomCubePos.reset: RobotEnv.reset,
+        # sim.step(1), box_joint qpos := placement -> RobotSimWrapper: sim.step(1), observe
+        self.sim.gripper_reset()
+        self._last_gripper_cmd = None
+        self.sim.reset()
+        self.sim.robot_reset()
+        self.sim.step(1)
+        if box_qpos is None:  # sim.py:371-383 (global numpy generator, this order of draws)
+            iso = (self.sim.get_base_pose() * O.Pose(translation=[0.498, 0.0, 0.226], rpy_vector=[0, 0, 0])).translation()
+            x = iso[0] + np.random.random() * 0.2 - 0.1
+            y = iso[1] + np.random.random() * 0.2 - 0.1
+            box_qpos = [x, y, 0.0288 / 2, 2 * np.random.random() - 1 if self.include_rotation else 0, 0, 0, 1]
+        self.sim.box_qpos = box_qpos
+        self.sim.step(1)
+        obs, info = self._gripper_obs(self._get_obs(), {})
+        if self.max_mov is not None:
+            self._set_origin_to_current()
+            self._last_action = None
+        return obs, info
+
+    def step(self, action):
+        obs, reward, _, truncated, info = super().step(action)
+        box = self.sim.box_qpos
+        success = bool(box[2] > 0.15 + 0.852 and obs["gripper"] == 0)  # BINARY_GRIPPER_CLOSED
+        info["success"] = success
+        if success:
+            reward = 5
+        else:
+            tcp_to_obj = np.linalg.norm(box[:3] - self.sim.get_cartesian_position().translation())
+            obj_to_goal = np.linalg.norm(box[:3] - self.EE_HOME)
+            reward = 1 - np.tanh(5 * tcp_to_obj)
+            reward += info["is_grasped"]
+            reward += (1 - np.tanh(5 * obj_to_goal)) * info["is_grasped"]
+        reward /= 5
+        return obs, reward, success, truncated, info

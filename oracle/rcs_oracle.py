@@ -414,6 +414,11 @@ class Sim:
         lib().orc_robot_get_cartesian_position(C.byref(self.s), C.byref(out))
         return Pose(_raw=out)
 
+    def get_base_pose(self) -> Pose:
+        out = OrcPose()
+        lib().orc_robot_get_base_pose(C.byref(self.s), C.byref(out))
+        return Pose(_raw=out)
+
     def set_cartesian_position(self, pose: Pose):
         lib().orc_robot_set_cartesian_position(C.byref(self.s), C.byref(pose.p))
 

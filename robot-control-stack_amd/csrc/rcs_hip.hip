@@ -62,7 +62,10 @@ struct rcsh_sim {
   GripperCfg gripcfg{};
   EnvCfg env{};
   BoxCfg box{};
+  TaskCfg task{};
   bool env_configured = false;
+  BoxTaskCfg* d_boxtask = nullptr;  // device copy of {box, task} (scenes with a free box)
+  double* pending_task = nullptr;  // task output of the env-step being enqueued (rcsh_env_step_task*)
   // staging for the host-pointer entry points
   double* d_stage = nullptr;   // n * 32 doubles
   double* d_stage2 = nullptr;  // n * 32 doubles
@@ -101,8 +104,16 @@ Params make_params(rcsh_sim* s) {
   P.robot = s->robot;
   P.grip = s->gripcfg;
   P.env = s->env;
-  P.box = s->box;
+  P.boxtask = s->d_boxtask;
   return P;
+}
+
+int upload_boxtask(rcsh_sim* s) {
+  BoxTaskCfg bt{s->box, s->task};
+  if (!s->d_boxtask) HIP_TRY(hipMalloc(&s->d_boxtask, sizeof(BoxTaskCfg)));
+  HIP_TRY(hipMemcpyAsync(s->d_boxtask, &bt, sizeof(bt), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
 }
 
 int upload_model(rcsh_sim* s) {
@@ -358,6 +369,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
+  hipFree(s->d_boxtask);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
@@ -780,6 +792,8 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   b.scale = 1.0 / (meaninertia * nv);
   b.noslip_tolerance = d->noslip_tolerance;
   s->box = b;
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = upload_boxtask(s)) return rc;
   return rcsh_sim_reset_free_box(s);
 }
 int rcsh_sim_reset_free_box(rcsh_sim* s) {
@@ -888,7 +902,82 @@ int rcsh_env_step_dev(rcsh_sim* s, const double* action_dev, const float* grippe
   op.write_obs = obs_dev != nullptr;
   op.action = action_dev; op.gripper = gripper_dev;
   op.obs = obs_dev; op.info = info_dev; op.gripper_width = gw_dev; op.substeps = substeps_dev;
+  op.task = s->pending_task;
   return launch_run(s, op, true);
+}
+
+// ---- task layer of the pick-up scene: SimTaskEnvCreator = SimEnvCreator + RandomCubePos under the RobotSimWrapper +
+// PickCubeSuccessWrapper on top (reference python/rcs/envs/creators.py:131-187)
+int rcsh_env_configure_pick_task(rcsh_sim* s, const rcsh_pick_task_desc* t) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!t) return fail(RCSH_ERR_ARG, "null task description");
+  if (!s->box.present) return fail(RCSH_ERR_STATE, "the pick task needs the scene's free box: call rcsh_sim_add_free_box first");
+  s->task.pick_cube = 1;
+  for (int k = 0; k < 3; ++k) s->task.ee_home[k] = t->ee_home[k];
+  s->task.success_z = t->success_height;
+  HIP_TRY(hipSetDevice(s->device));
+  return upload_boxtask(s);
+}
+
+int rcsh_env_reset_task_dev(rcsh_sim* s, const uint8_t* mask_dev, const double* box_qpos_dev, double* obs_dev, uint8_t* info_dev,
+                            double* gw_dev) {
+  REQUIRE_SIM(s); REQUIRE_ROBOT(s);
+  if (!s->env_configured) return fail(RCSH_ERR_STATE, "call rcsh_env_configure first");
+  if (!s->task.pick_cube) return fail(RCSH_ERR_STATE, "call rcsh_env_configure_pick_task first");
+  if (!box_qpos_dev) return fail(RCSH_ERR_ARG, "null box pose");
+  HIP_TRY(hipSetDevice(s->device));
+  RunOp op{};
+  op.do_reset = 1;
+  op.nsteps = 1;
+  op.write_obs = obs_dev != nullptr;
+  op.mask = mask_dev;
+  op.box_qpos = box_qpos_dev;
+  op.obs = obs_dev; op.info = info_dev; op.gripper_width = gw_dev;
+  return launch_run(s, op, false);
+}
+
+int rcsh_env_step_task_dev(rcsh_sim* s, const double* action_dev, const float* gripper_dev, double* obs_dev, uint8_t* info_dev,
+                           double* gw_dev, int32_t* substeps_dev, double* task_dev) {
+  REQUIRE_SIM(s);
+  if (!s->task.pick_cube) return fail(RCSH_ERR_STATE, "call rcsh_env_configure_pick_task first");
+  s->pending_task = task_dev;
+  int rc = rcsh_env_step_dev(s, action_dev, gripper_dev, obs_dev, info_dev, gw_dev, substeps_dev);
+  s->pending_task = nullptr;
+  return rc;
+}
+
+int rcsh_env_reset_task(rcsh_sim* s, const uint8_t* mask, const double* box_qpos, double* obs, uint8_t* info, double* gw) {
+  REQUIRE_SIM(s);
+  if (!box_qpos) return fail(RCSH_ERR_ARG, "null box pose");
+  const uint8_t* dm = nullptr;
+  int rc = upload_mask(s, mask, &dm);
+  if (rc) return rc;
+  double* d_box = s->d_stage + (size_t)s->n * 16;
+  HIP_TRY(hipMemcpyAsync(d_box, box_qpos, sizeof(double) * s->n * 7, hipMemcpyHostToDevice, s->stream));
+  rc = rcsh_env_reset_task_dev(s, dm, d_box, s->d_stage2, s->d_bytes, s->d_stage);
+  if (rc) return rc;
+  const int ow = 14 + s->narm;
+  if (obs) HIP_TRY(hipMemcpyAsync(obs, s->d_stage2, sizeof(double) * s->n * ow, hipMemcpyDeviceToHost, s->stream));
+  if (info) HIP_TRY(hipMemcpyAsync(info, s->d_bytes, (size_t)s->n * 8, hipMemcpyDeviceToHost, s->stream));
+  if (gw) HIP_TRY(hipMemcpyAsync(gw, s->d_stage, sizeof(double) * s->n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int rcsh_env_step_task(rcsh_sim* s, const double* action, const float* gripper, double* obs, uint8_t* info, double* gw,
+                       int32_t* substeps, double* task) {
+  REQUIRE_SIM(s);
+  if (!s->task.pick_cube) return fail(RCSH_ERR_STATE, "call rcsh_env_configure_pick_task first");
+  double* d_task = s->d_stage + (size_t)s->n * 16;
+  s->pending_task = d_task;
+  int rc = rcsh_env_step(s, action, gripper, obs, info, gw, substeps);
+  s->pending_task = nullptr;
+  if (rc) return rc;
+  if (task) {
+    HIP_TRY(hipMemcpyAsync(task, d_task, sizeof(double) * s->n * 9, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
+  return RCSH_OK;
 }
 
 int rcsh_env_reset(rcsh_sim* s, const uint8_t* mask, double* obs, uint8_t* info, double* gw) {

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "box_team.h"
 #include "dyn.h"
@@ -77,6 +78,13 @@ struct Lay {
   static constexpr int COUNT = BOX + kBoxState;
 };
 
+// PickCubeSuccessWrapper (reference python/rcs/envs/sim.py:386-431)
+struct TaskCfg {
+  int32_t pick_cube, pad;
+  double ee_home[3];
+  double success_z;  // the cube counts as lifted above this world height
+};
+
 struct RunOp {
   int32_t do_reset;       // env.reset(): gripper reset, sim reset, robot reset (then nsteps = 1)
   int32_t apply_action;   // env.step(): wrappers' action() + RobotEnv.step
@@ -89,6 +97,8 @@ struct RunOp {
   uint8_t* info;          // [n][8]
   double* gripper_width;  // [n]
   int32_t* substeps;      // [n]
+  const double* box_qpos; // [n][7] env.reset() of the task env: RandomCubePos places the box (null: it stays at qpos0)
+  double* task;           // [n][9] box qpos 7, reward, success (PickCubeSuccessWrapper.step)
 };
 
 // Contact detection against the scene's static plane (flags only): sample points of the collision geoms, link frame
@@ -112,7 +122,11 @@ struct Params {
   RobotCfg robot;
   GripperCfg grip;
   EnvCfg env;
+  const struct BoxTaskCfg* boxtask;  // scenes with a free box: its constants and the task layer's (HBM; staged by k_run_team<.., BOX>)
+};
+struct BoxTaskCfg {
   BoxCfg box;
+  TaskCfg task;
 };
 
 // ---- everything one environment keeps in registers during a launch
@@ -597,7 +611,13 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   const CollTable& lc = lp.coll;
   TEAM_CLOCK_START()
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
+  __shared__ std::conditional_t<BOX, BoxTaskCfg, char> lbt[1];
   {
+    if constexpr (BOX) {
+      static_assert(sizeof(BoxTaskCfg) % 8 == 0, "copied in 8-byte words");
+      for (int k = threadIdx.x; k < (int)(sizeof(BoxTaskCfg) / 8); k += 64)
+        reinterpret_cast<double*>(&lbt[0])[k] = reinterpret_cast<const double*>(Pk.boxtask)[k];
+    }
     stage_team_model<T::NL>(Pk.model, lm, llinks);
     for (int k = threadIdx.x; k < ST::COUNT * kTeams; k += 64) lds[k] = 0.0;
     __syncthreads();
@@ -617,7 +637,11 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   r.st = st;
   r.time = 0; r.last_cmd_width = 0; r.last_width = 0; r.flags = 0; r.conv_steps = 0;
   bool have_frames = false;
-  int nsteps = op.do_reset ? 1 : op.nsteps;
+  // env.reset() steps once (RobotSimWrapper.reset, envs/sim.py:72-79); with RandomCubePos under it twice, the box
+  // being placed in between (sim.py:365-383): super().reset(), sim.step(1), qpos of box_joint := ..., then the
+  // RobotSimWrapper's own sim.step(1)
+  const bool place_box = BOX && op.do_reset && op.box_qpos != nullptr;
+  int nsteps = op.do_reset ? (place_box ? 2 : 1) : op.nsteps;
   const bool until_conv = nsteps < 0;
   int budget = 0;
   bool converged = false;
@@ -644,9 +668,10 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     if (live) {
       using L = Lay<T>;
       for (int k = t; k < kBoxState; k += kTeamLanes)
-        bs[k] = op.do_reset ? (k < 7 ? P.box.qpos0[k] : 0.0) : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
+        bs[k] = op.do_reset ? (k < 7 ? lbt[0].box.qpos0[k] : 0.0) : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
     }
   }
+  bool have_frames_box = false;  // the first substep of this launch is done (placement of the box on reset)
   bool more = leader && budget > 0;
   double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
   const bool has_cb = P.robot.present && P.robot.conv_registered;
@@ -703,9 +728,13 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
         imp0 += row_rotate<4>(imp0);
         imp0 += row_rotate<8>(imp0);
         imp0 = lane_get(imp0, threadIdx.x & 48);  // one lane's bits for the whole team
-        box_substep(P.box, bs, m.gravity, timestep, imp0, t);
+        box_substep(lbt[0].box, bs, m.gravity, timestep, imp0, t);
       }
       __syncthreads();
+      if (place_box && live && !have_frames_box) {
+        if (t < 7) bs[kBoxQ + t] = op.box_qpos[(size_t)e * 7 + t];  // position only: velocity and warm start stay
+        have_frames_box = true;
+      }
     }
     if (leader && stepping) {
       r.time += timestep;
@@ -728,6 +757,35 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     if (live) {
       using L = Lay<T>;
       for (int k = t; k < kBoxState; k += kTeamLanes) P.S[(size_t)(L::BOX + k) * P.n + e] = bs[k];
+    }
+    if (leader && op.task && lbt[0].task.pick_cube) {
+      // PickCubeSuccessWrapper.step (sim.py:396-431): success, else the ManiSkill-style shaped reward; both / 5
+      Pose tcp;
+      double linkR[9], linkP[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) linkR[k] = st.link(k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) linkP[k] = st.link(9 + k);
+      cartesian_position(m, P.robot, linkR, linkP, tcp);
+      const bool has_g = T::GRIP && P.grip.present;
+      const double w = has_g ? gripper_width<T, ST>(P, r) : 0.0;
+      const bool grasped = has_g && (w > 0.01 && w < 0.99);
+      const bool closed = has_g && (r.flags & kHasGripCmd) && !(r.flags & kGripCmd);  // obs["gripper"] == BINARY_GRIPPER_CLOSED
+      const double bx = bs[kBoxQ], by = bs[kBoxQ + 1], bz = bs[kBoxQ + 2];
+      const bool success = bz > lbt[0].task.success_z && closed;
+      double reward = 5.0;
+      if (!success) {
+        const double d1 = sqrt((bx - tcp.t[0]) * (bx - tcp.t[0]) + (by - tcp.t[1]) * (by - tcp.t[1]) + (bz - tcp.t[2]) * (bz - tcp.t[2]));
+        const double* eh = lbt[0].task.ee_home;
+        const double d2 = sqrt((bx - eh[0]) * (bx - eh[0]) + (by - eh[1]) * (by - eh[1]) + (bz - eh[2]) * (bz - eh[2]));
+        const double g = grasped ? 1.0 : 0.0;
+        reward = (1 - tanh(5 * d1)) + g + (1 - tanh(5 * d2)) * g;
+      }
+      double* o = op.task + (size_t)e * 9;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) o[k] = bs[kBoxQ + k];
+      o[7] = reward / 5;
+      o[8] = success ? 1.0 : 0.0;
     }
   }
   TEAM_MARK(10)

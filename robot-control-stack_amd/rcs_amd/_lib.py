@@ -84,6 +84,10 @@ def make_free_box_desc(cm) -> FreeBoxDesc | None:
     return d
 
 
+class PickTaskDesc(C.Structure):
+    _fields_ = [("ee_home", C.c_double * 3), ("success_height", C.c_double)]
+
+
 class RobotDesc(C.Structure):
     _fields_ = [
         ("dof", C.c_int32), ("joint_ids", _I32P), ("actuator_ids", _I32P),
@@ -126,6 +130,7 @@ EXPORTS = (
     "rcsh_sim_set_qvel", "rcsh_sim_add_free_box", "rcsh_sim_reset_free_box", "rcsh_sim_get_free_qpos", "rcsh_sim_get_free_qvel",
     "rcsh_sim_set_free_qpos", "rcsh_sim_set_free_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
+    "rcsh_env_configure_pick_task", "rcsh_env_reset_task", "rcsh_env_step_task", "rcsh_env_reset_task_dev", "rcsh_env_step_task_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
 )
@@ -163,6 +168,11 @@ def load() -> C.CDLL:
         fn.argtypes = [C.c_void_p, C.c_void_p]
     for fn in (L.rcsh_sim_set_free_qpos, L.rcsh_sim_set_free_qvel):
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rcsh_env_configure_pick_task.argtypes = [C.c_void_p, C.POINTER(PickTaskDesc)]
+    L.rcsh_env_reset_task.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.rcsh_env_step_task.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    L.rcsh_env_reset_task_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.rcsh_env_step_task_dev.argtypes = [C.c_void_p] + [C.c_void_p] * 7
     L.rcsh_sim_destroy.argtypes = [C.c_void_p]
     L.rcsh_sim_destroy.restype = None
     L.rcsh_sim_step.argtypes = [C.c_void_p, C.c_int64]

@@ -1,5 +1,5 @@
 """Batched counterpart of ``rcs.envs`` (reference python/rcs/envs)."""
 
 from .base import ControlMode, RelativeTo  # noqa: F401
-from .creators import SimEnvCreator, VecSimEnv  # noqa: F401
+from .creators import FR3SimplePickUpSimEnvCreator, SimEnvCreator, SimTaskEnvCreator, VecPickCubeEnv, VecSimEnv  # noqa: F401
 from .utils import default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg  # noqa: F401

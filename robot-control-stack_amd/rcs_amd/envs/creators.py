@@ -130,6 +130,90 @@ class VecSimEnv:
         self.sim.close()
 
 
+class VecPickCubeEnv(VecSimEnv):
+    """``SimTaskEnvCreator()(...)`` of the reference for N environments: the :class:`VecSimEnv` of the pick-up scene
+    with ``RandomCubePos`` under the simulation wrapper and ``PickCubeSuccessWrapper`` on top (reference
+    python/rcs/envs/sim.py:358-431, creators.py:131-187).
+
+    ``reset`` places each environment's cube (one draw of x, y and -- with ``include_rotation`` -- the quaternion's w per
+    environment from numpy's global generator, in the reference's order; or the poses given as
+    ``options={"box_qpos": [N, 7]}``); ``step`` returns the wrapper's shaped reward, ``terminated = success`` and
+    ``info["success"]``; the cube pose of the step is ``info["box_qpos"]``.
+    """
+
+    EE_HOME = np.array([0.34169773, 0.00047028, 0.4309004])  # PickCubeSuccessWrapper.EE_HOME
+    SUCCESS_HEIGHT = 0.15 + 0.852
+    ISO_CUBE = np.array([0.498, 0.0, 0.226])  # RandomCubePos.reset, robot coordinates
+
+    def __init__(self, *args, include_rotation: bool = True, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert self.gripper is not None, "PickCubeSuccessWrapper reads the gripper observation"
+        self.include_rotation = include_rotation
+        t = _lib.PickTaskDesc()
+        t.ee_home[:] = [float(x) for x in self.EE_HOME]
+        t.success_height = float(self.SUCCESS_HEIGHT)
+        _lib.check(self._L.rcsh_env_configure_pick_task(self.sim._h, C.byref(t)))
+        self.task_width = 9
+
+    def draw_box_qpos(self) -> np.ndarray:
+        """RandomCubePos.reset's placement (sim.py:371-383) for every environment."""
+        iso = self.robot.to_pose_in_world_coordinates(common.Pose(translation=self.ISO_CUBE, rpy_vector=np.zeros(3))).translation()
+        q = np.zeros((self.n_envs, 7))
+        for e in range(self.n_envs):
+            x = iso[0] + np.random.random() * 0.2 - 0.1
+            y = iso[1] + np.random.random() * 0.2 - 0.1
+            w = 2 * np.random.random() - 1 if self.include_rotation else 0.0
+            q[e] = [x, y, 0.0288 / 2, w, 0, 0, 1]
+        return q
+
+    def reset(self, seed: int | None = None, options: dict | None = None, mask=None):
+        n = self.n_envs
+        box = None if options is None else options.get("box_qpos")
+        box = self.draw_box_qpos() if box is None else np.ascontiguousarray(np.broadcast_to(np.asarray(box, dtype=np.float64), (n, 7)))
+        obs = np.zeros((n, self.obs_width))
+        info = np.zeros((n, 8), dtype=np.uint8)
+        gw = np.zeros(n)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        _lib.check(self._L.rcsh_env_reset_task(self.sim._h, _lib.ptr(m), _lib.ptr(box), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw)))
+        o, i = self._unpack(obs, info, gw)
+        i["collision"] = info[:, 5].astype(bool)
+        i["gripper_width"] = gw
+        i["is_grasped"] = info[:, 3].astype(bool)
+        return o, i
+
+    def step(self, action: dict[str, Any]):
+        n = self.n_envs
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(action[self.action_key], dtype=np.float64), (n, self.action_width)))
+        assert "gripper" in action, "Gripper action not found."
+        g = np.ascontiguousarray(np.broadcast_to(np.asarray(action["gripper"], dtype=np.float32), (n,)))
+        obs = np.zeros((n, self.obs_width))
+        info = np.zeros((n, 8), dtype=np.uint8)
+        gw = np.zeros(n)
+        sub = np.zeros(n, dtype=np.int32)
+        task = np.zeros((n, self.task_width))
+        _lib.check(self._L.rcsh_env_step_task(self.sim._h, _lib.ptr(a), _lib.ptr(g), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw),
+                                              _lib.ptr(sub), _lib.ptr(task)))
+        o, i = self._unpack(obs, info, gw)
+        i["collision"] = info[:, 0].astype(bool)
+        i["ik_success"] = info[:, 1].astype(bool)
+        i["is_sim_converged"] = info[:, 2].astype(bool)
+        i["gripper_width"] = gw
+        i["is_grasped"] = info[:, 3].astype(bool)
+        i["substeps"] = sub
+        i["box_qpos"] = task[:, :7].copy()
+        success = task[:, 8] != 0
+        i["success"] = success
+        return o, task[:, 7].copy(), success, info[:, 4].astype(bool), i
+
+    def step_task_dev(self, action_ptr, gripper_ptr, obs_ptr, info_ptr=None, gw_ptr=None, substeps_ptr=None, task_ptr=None) -> None:
+        _lib.check(self._L.rcsh_env_step_task_dev(self.sim._h, C.c_void_p(action_ptr), C.c_void_p(gripper_ptr), C.c_void_p(obs_ptr),
+                                                  C.c_void_p(info_ptr), C.c_void_p(gw_ptr), C.c_void_p(substeps_ptr), C.c_void_p(task_ptr)))
+
+    def reset_task_dev(self, box_qpos_ptr, obs_ptr, info_ptr=None, gw_ptr=None, mask_ptr=None) -> None:
+        _lib.check(self._L.rcsh_env_reset_task_dev(self.sim._h, C.c_void_p(mask_ptr), C.c_void_p(box_qpos_ptr), C.c_void_p(obs_ptr),
+                                                   C.c_void_p(info_ptr), C.c_void_p(gw_ptr)))
+
+
 class SimEnvCreator:
     def __call__(self, control_mode: ControlMode, robot_cfg: sim.SimRobotConfig, collision_guard: bool = False,
                  gripper_cfg: sim.SimGripperConfig | None = None, sim_cfg: sim.SimConfig | None = None,
@@ -141,3 +225,44 @@ class SimEnvCreator:
         robot = sim.SimRobot(simulation, None, robot_cfg)
         gripper = sim.SimGripper(simulation, gripper_cfg) if gripper_cfg is not None else None
         return VecSimEnv(simulation, robot, gripper, control_mode, max_relative_movement, relative_to)
+
+
+class SimTaskEnvCreator:
+    """Reference python/rcs/envs/creators.py:131-187: the pick-up task on top of ``SimEnvCreator`` (RandomCubePos +
+    PickCubeSuccessWrapper).  ``render_mode`` is accepted for signature compatibility; this backend has no viewer."""
+
+    def __call__(self, robot_cfg: sim.SimRobotConfig, render_mode: str = "rgb_array", control_mode: ControlMode = ControlMode.CARTESIAN_TRPY,
+                 delta_actions: bool = True, cameras=None, hand_cfg=None, gripper_cfg: sim.SimGripperConfig | None = None,
+                 sim_cfg: sim.SimConfig | None = None, random_pos_args: dict | None = None, n_envs: int = 1, device: int = 0) -> VecPickCubeEnv:
+        from .utils import default_sim_gripper_cfg
+
+        if hand_cfg is not None or cameras or random_pos_args is not None:
+            raise NotImplementedError("hands, cameras and RandomObjectPos are outside this backend's hot path")
+        if gripper_cfg is None:
+            gripper_cfg = default_sim_gripper_cfg()
+        simulation = sim.Sim(robot_cfg.mjcf_scene_path, sim_cfg, n_envs=n_envs, device=device)
+        robot = sim.SimRobot(simulation, None, robot_cfg)
+        gripper = sim.SimGripper(simulation, gripper_cfg)
+        return VecPickCubeEnv(simulation, robot, gripper, control_mode,
+                              (0.2, float(np.deg2rad(45))) if delta_actions else None, RelativeTo.LAST_STEP)
+
+
+class FR3SimplePickUpSimEnvCreator:
+    """Reference creators.py:190-224 (gym id ``rcs/FR3SimplePickUpSim-v0``): the pick-up scene at 30 Hz async control
+    with the reference's TCP offset."""
+
+    def __call__(self, render_mode: str = "rgb_array", control_mode: ControlMode = ControlMode.CARTESIAN_TRPY,
+                 resolution: tuple[int, int] | None = None, frame_rate: int = 0, delta_actions: bool = True,
+                 cam_list: list[str] | None = None, n_envs: int = 1, device: int = 0) -> VecPickCubeEnv:
+        from .utils import default_sim_robot_cfg
+
+        if cam_list:
+            raise NotImplementedError("camera rendering is outside this backend's hot path")
+        robot_cfg = default_sim_robot_cfg(scene="fr3_simple_pick_up")
+        robot_cfg.tcp_offset = common.Pose(translation=np.array([0.0, 0.0, 0.1034]),
+                                           rotation=np.array([[0.707, 0.707, 0], [-0.707, 0.707, 0], [0, 0, 1]]))
+        sim_cfg = sim.SimConfig()
+        sim_cfg.realtime = False
+        sim_cfg.async_control = True
+        sim_cfg.frequency = 30
+        return SimTaskEnvCreator()(robot_cfg, render_mode, control_mode, delta_actions, None, sim_cfg=sim_cfg, n_envs=n_envs, device=device)

@@ -97,6 +97,50 @@ def run_free_box_parity(n_envs=32, n_calls=10, k=25, seed=0, kick=True):
     return rep
 
 
+def run_pick_task_parity(n_envs=16, n_steps=6, seed=0, episodes=2):
+    """FR3SimplePickUpSimEnvCreator()(...) (30 Hz async control, relative TRPY actions, RandomCubePos, PickCubeSuccessWrapper)
+    against the oracle's restatement of that wrapper stack on the same actions and the same cube placements."""
+    from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import OraclePickCubeEnv
+
+    venv = FR3SimplePickUpSimEnvCreator()(n_envs=n_envs)
+    cm = compile_mjcf(PICKUP_SCENE)
+    tcp = O.Pose(translation=[0.0, 0.0, 0.1034], rotation=np.array([[0.707, 0.707, 0], [-0.707, 0.707, 0], [0, 0, 1]]))
+    oenvs = [OraclePickCubeEnv(cm, tcp_offset=tcp) for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    rep = {"max_abs_obs": 0.0, "max_abs_box": 0.0, "max_abs_reward": 0.0, "flag_mismatches": 0, "min_reward": 9.0, "max_reward": -9.0,
+           "grasped_seen": 0}
+    for _ in range(episodes):
+        np.random.seed(int(rng.integers(1 << 30)))
+        box = venv.draw_box_qpos()
+        obs, info = venv.reset(options={"box_qpos": box})
+        for e, oe in enumerate(oenvs):
+            oo, oi = oe.reset(box_qpos=box[e])
+            rep["max_abs_obs"] = max(rep["max_abs_obs"], float(np.abs(obs["tquat"][e] - oo["tquat"]).max()), float(np.abs(obs["joints"][e] - oo["joints"]).max()))
+            rep["flag_mismatches"] += int(bool(info["is_grasped"][e]) != bool(oi["is_grasped"]))
+        kb = venv.sim.free_joint_qpos("box_joint")
+        for e, oe in enumerate(oenvs):
+            rep["max_abs_box"] = max(rep["max_abs_box"], float(np.abs(kb[e] - oe.sim.box_qpos).max()))
+        for t in range(n_steps):
+            # reach down towards the cube while closing / opening the gripper at random
+            a = np.concatenate([rng.uniform(-0.05, 0.05, (n_envs, 2)), rng.uniform(-0.08, 0.01, (n_envs, 1)), rng.uniform(-0.1, 0.1, (n_envs, 3))], axis=1)
+            g = rng.uniform(0, 1, n_envs).astype(np.float32)
+            obs, reward, term, trunc, info = venv.step({"xyzrpy": a, "gripper": g})
+            for e, oe in enumerate(oenvs):
+                oo, orw, oterm, otrunc, oi = oe.step({"xyzrpy": a[e], "gripper": g[e]})
+                rep["max_abs_obs"] = max(rep["max_abs_obs"], float(np.abs(obs["tquat"][e] - oo["tquat"]).max()), float(np.abs(obs["joints"][e] - oo["joints"]).max()))
+                rep["max_abs_box"] = max(rep["max_abs_box"], float(np.abs(info["box_qpos"][e] - oe.sim.box_qpos).max()))
+                rep["max_abs_reward"] = max(rep["max_abs_reward"], abs(float(reward[e]) - float(orw)))
+                rep["flag_mismatches"] += int(bool(term[e]) != bool(oterm)) + int(bool(trunc[e]) != bool(otrunc)) + int(bool(info["success"][e]) != bool(oi["success"]))
+                rep["flag_mismatches"] += int(bool(info["is_grasped"][e]) != bool(oi["is_grasped"])) + int(float(obs["gripper"][e]) != float(oo["gripper"]))
+                rep["grasped_seen"] += int(bool(oi["is_grasped"]))
+            rep["min_reward"], rep["max_reward"] = min(rep["min_reward"], float(reward.min())), max(rep["max_reward"], float(reward.max()))
+    venv.close()
+    return rep
+
+
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500):

@@ -446,3 +446,16 @@ def test_free_box_matches_oracle(kernel):
     assert rep["max_ncon"] == 4 and rep["zones"] == {0, 1, 2}, rep  # separating, sliding and sticking contacts all occurred
     assert rep["max_abs_pos"] < 1e-6 and rep["max_abs_quat"] < 1e-5 and rep["max_abs_vel"] < 1e-3, rep
     assert rep["max_abs_robot_qpos"] < 1e-9, rep
+
+
+def test_pick_task_env_matches_oracle(kernel):
+    """rcs/FR3SimplePickUpSim-v0 (FR3SimplePickUpSimEnvCreator: RandomCubePos reset, relative TRPY control through the
+    CLIK, PickCubeSuccessWrapper reward / success) against the oracle's restatement of that wrapper stack."""
+    import parity_util as pu
+
+    if kernel == "lane":
+        pytest.skip("free bodies are stepped by the team kernel only")
+    rep = pu.run_pick_task_parity(n_envs=16, n_steps=6, seed=1, episodes=2)
+    assert rep["flag_mismatches"] == 0, rep
+    assert rep["max_abs_obs"] < TOL and rep["max_abs_box"] < 1e-6 and rep["max_abs_reward"] < 1e-6, rep
+    assert 0.0 < rep["min_reward"] and rep["max_reward"] < 1.0, rep
