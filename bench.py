@@ -135,6 +135,10 @@ def main() -> None:
                          "Default: none for joints; 10 for cartesian, as the reference's examples loop (reset + 10 steps) -- a longer "
                          "random walk of Cartesian targets leaves the workspace and the CLIK then runs to its 1000-iteration cap")
     ap.add_argument("--robot", choices=["fr3", "xarm7"], default="fr3", help="xarm7: 7-dof arm with dry joint friction, no gripper (not the headline)")
+    ap.add_argument("--task", choices=["none", "pick_up"], default="none",
+                    help="pick_up = the registered gym task rcs/FR3SimplePickUpSim-v0 (fr3_simple_pick_up scene: free cube on the floor with "
+                         "elliptic-cone contacts + noslip, RandomCubePos on reset, PickCubeSuccessWrapper reward; relative TRPY control, 30 Hz); "
+                         "not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
@@ -171,7 +175,12 @@ def main() -> None:
 
     n = args.envs
     T = args.steps + args.warmup
-    if args.control == "cartesian":
+    if args.task == "pick_up":
+        from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
+
+        args.control, args.mode = "cartesian", "async"
+        env = FR3SimplePickUpSimEnvCreator()(n_envs=n, device=local_rank)
+    elif args.control == "cartesian":
         from rcs_amd.envs import ControlMode
 
         env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank,
@@ -201,15 +210,37 @@ def main() -> None:
 
     episode = args.episode_length if args.episode_length is not None else (10 if args.control == "cartesian" else 0)
 
+    task_out = box_pose = None
+    if args.task == "pick_up":
+        # RandomCubePos placements of every reset, resident: x, y ~ iso_cube +- 0.1 m, z = 14.4 mm, quaternion (w ~ U(-1, 1), 0, 0, 1)
+        n_resets = T // max(episode, 1) + 2
+        box_pose = torch.zeros((n_resets, n, 7), device="cuda", dtype=torch.float64)
+        u = torch.rand((n_resets, n, 3), generator=gen, device="cuda", dtype=torch.float64)
+        box_pose[..., 0] = 0.498 + u[..., 0] * 0.2 - 0.1
+        box_pose[..., 1] = u[..., 1] * 0.2 - 0.1
+        box_pose[..., 2] = 0.0288 / 2
+        box_pose[..., 3] = 2 * u[..., 2] - 1
+        box_pose[..., 6] = 1.0
+        task_out = torch.zeros((n, 9), device="cuda", dtype=torch.float64)
+
+    def do_reset(t: int) -> None:
+        if box_pose is not None:
+            env.reset_task_dev(box_pose[t // max(episode, 1)].data_ptr(), obs.data_ptr(), info.data_ptr(), gw.data_ptr())
+        else:
+            env.reset_dev(obs.data_ptr(), info.data_ptr(), gw.data_ptr())
+
     def one_step(t: int) -> None:
         if episode and t % episode == 0:
-            env.reset_dev(obs.data_ptr(), info.data_ptr(), gw.data_ptr())
+            do_reset(t)
         o = exchange.local(t) if exchange else obs
-        env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
+        if task_out is not None:
+            env.step_task_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr(), task_out.data_ptr())
+        else:
+            env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
         if exchange:
             exchange.post(t)  # overlaps with the next env-step
 
-    env.reset_dev(obs.data_ptr(), info.data_ptr(), gw.data_ptr())
+    do_reset(0)
     for t in range(args.warmup):
         one_step(t)
     from rcs_amd import _lib
@@ -243,6 +274,8 @@ def main() -> None:
     kernel_ms = ms.value / max(launches.value, 1)
     mean_sub = float(sub.to(torch.float64).mean().item())
     finite = bool(torch.isfinite(obs).all().item())
+    if task_out is not None:
+        finite = finite and bool(torch.isfinite(task_out).all().item())
 
     if rank == 0:
         total_env_steps = world * n * args.steps
@@ -272,7 +305,8 @@ def main() -> None:
                 "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off"
                              if args.control == "joints" else
                              f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
-                             ).replace("fr3_empty_world", f"{args.robot}_empty_world"),
+                             ).replace("fr3_empty_world", f"{args.robot}_empty_world" if args.task == "none" else
+                                       "fr3_simple_pick_up (free cube: plane-box contacts, elliptic cones, noslip; RandomCubePos + PickCubeSuccessWrapper)"),
                 "mode": "async_control 30Hz (17 substeps/env-step)" if args.mode == "async" else "step_until_convergence (cap 500)",
                 "envs_per_gpu": n,
                 "substeps_per_env_step": mean_sub,
@@ -289,7 +323,7 @@ def main() -> None:
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 FETCH_SIZE + WRITE_SIZE, separate PMC passes (profiles/r1_traffic.json)" if traffic else None,
-                "kernel": ("k_run" if os.environ.get("RCSH_KERNEL") == "lane" else "k_run_team") + "<Topo<7,true>> (fused env-step)",
+                "kernel": ("k_run" if os.environ.get("RCSH_KERNEL") == "lane" else "k_run_team") + "<Topo<7,true>> (fused env-step)" + (" + free box" if args.task != "none" else ""),
                 "kernel_ms_avg": kernel_ms,
                 "launches_timed": int(launches.value),
                 "algorithmic_bytes_per_launch": algo_bytes,

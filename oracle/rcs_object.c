@@ -233,7 +233,8 @@ static void chol6_solve(double A[6][6], double* x) {
   }
 }
 
-/* Newton with a safeguarded exact line search on the strictly convex primal cost */
+/* Newton with a safeguarded line search (1-D Newton on phi', to 1e-3: the outer gradient test sets the accuracy) on the
+   strictly convex primal cost */
 static void box_newton(const orc_box* b, orc_box_data* d) {
   primal P, Q;
   double x[6], xs[6];
@@ -259,7 +260,7 @@ static void box_newton(const orc_box* b, orc_box_data* d) {
     for (int j = 0; j < 6; j++) dphi0 += P.grad[j] * p[j];
     if (!(dphi0 < 0)) break;
     double best = 1;
-    for (int ls = 0; ls < 40; ls++) {
+    for (int ls = 0; ls < 20; ls++) {
       double xa[6];
       for (int j = 0; j < 6; j++) xa[j] = x[j] + a * p[j];
       primal_eval(b, d, xa, &Q, 1);
@@ -269,11 +270,12 @@ static void box_newton(const orc_box* b, orc_box_data* d) {
         for (int k = 0; k < 6; k++) ddphi += p[j] * Q.H[j][k] * p[k];
       }
       best = a;
-      if (fabs(dphi) <= 1e-12 * fabs(dphi0)) break;
+      if (fabs(dphi) <= 1e-3 * fabs(dphi0)) break;
       if (dphi < 0) lo = a; else hi = a;
       double an = a - dphi / ddphi;
       if (hi > 0 && !(an > lo && an < hi)) an = 0.5 * (lo + hi);
       if (hi < 0 && !(an > lo)) an = 2 * a;
+      if (fabs(an - a) <= 1e-3 * a) break;
       a = an;
     }
     for (int j = 0; j < 6; j++) x[j] += best * p[j];

@@ -17,6 +17,7 @@
 // issued for the wave anyway).  The noslip sweep is sequential by nature: contact c's owner computes, quad_perm
 // broadcasts.
 #pragma once
+#include "dyn_team.h"
 #include "ik.h"
 #include "team.h"
 
@@ -84,13 +85,13 @@ RCSH_D double box_cone(const BoxContact& c, double fr, const double* jar, double
     Hc[0] = c.D[0]; Hc[2] = c.D[1]; Hc[5] = c.D[2];
     return cost;
   }
-  const double Dm = c.D[0] / (mu * mu * (1 + mu * mu));
+  const double Dm = c.D[0] * fast_rcp(mu * mu * (1 + mu * mu));
   const double NmT = N - mu * T;
-  const double u1 = U1 / T, u2 = U2 / T;
+  const double iT = fast_rcp(T), u1 = U1 * iT, u2 = U2 * iT;
   f[0] = -mu * (Dm * NmT);
   f[1] = fr * (Dm * NmT * mu * u1);
   f[2] = fr * (Dm * NmT * mu * u2);
-  const double k = -Dm * NmT * mu / T;  // > 0
+  const double k = -Dm * NmT * mu * iT;  // > 0
   Hc[0] = mu * mu * Dm;
   Hc[1] = mu * fr * (-Dm * mu * u1);
   Hc[3] = mu * fr * (-Dm * mu * u2);
@@ -126,18 +127,19 @@ RCSH_D bool box_qcqp2(double* res, double A00, double A01, double A11, double b0
   const double S11 = A00 * d * d, S22 = A11 * d * d, S12 = A01 * d * d;
   double la = 0, v1 = 0, v2 = 0;
   for (int iter = 0; iter < 20; ++iter) {
+    TEAM_COUNT(23)
     const double det = (S11 + la) * (S22 + la) - S12 * S12;
     if (det < 1e-10) {
       res[0] = res[1] = 0;
       return false;
     }
-    const double di = 1 / det, P11 = (S22 + la) * di, P22 = (S11 + la) * di, P12 = -S12 * di;
+    const double di = fast_rcp(det), P11 = (S22 + la) * di, P22 = (S11 + la) * di, P12 = -S12 * di;
     v1 = -P11 * s1 - P12 * s2;
     v2 = -P12 * s1 - P22 * s2;
     const double val = v1 * v1 + v2 * v2 - r * r;
     if (val < 1e-10) break;
     const double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
-    const double delta = -val / deriv;
+    const double delta = -val * fast_rcp(deriv);
     if (delta < 1e-10) break;
     la += delta;
   }
@@ -157,6 +159,7 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
   for (int k = 0; k < 4; ++k) q[k] = bs[kBoxQ + 3 + k];
 #pragma unroll
   for (int k = 0; k < 6; ++k) { v[k] = bs[kBoxV + k]; warm[k] = bs[kBoxW + k]; }
+  TEAM_MARK(9)
   // ---- mj_kinematics: normalise the quaternion in qpos, frame of the box
   {
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -247,6 +250,7 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
   double x[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) x[j] = xs[j];
+  TEAM_MARK(16)
   if (ncon > 0) {
     // ---- Newton on the primal cost; warm start = the cheaper of qacc_warmstart and qacc_smooth
     if (!(box_cost(b, c, Md, xs, xs) < box_cost(b, c, Md, xs, warm))) {
@@ -254,12 +258,22 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
       for (int j = 0; j < 6; ++j) x[j] = warm[j];
     }
     double f[3];
+    TEAM_MARK(17)
     for (int it = 0; it < 50; ++it) {
+      TEAM_COUNT(21)
       double jar[3], Hc[6], grad[6], H[36];
       box_jar(c, x, jar);
       box_cone(c, b.fr, jar, f, Hc);
+      // gradient first: the Hessian is only assembled when another step follows
+      double g2 = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        grad[i] = Md[i] * (x[i] - xs[i]) - quad_sum(c.J[0][i] * f[0] + c.J[1][i] * f[1] + c.J[2][i] * f[2]);
+        g2 += grad[i] * grad[i];
+      }
+      if (b.scale * sqrt(g2) < 1e-13) break;
       {
-        // the lane's J' Hc J and -J' f, then the quad sums
+        // the lane's J' Hc J, then the quad sums
         double W[3][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -268,17 +282,11 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
           W[2][j] = Hc[3] * c.J[0][j] + Hc[4] * c.J[1][j] + Hc[5] * c.J[2][j];
         }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
           for (int j = 0; j <= i; ++j)
             H[6 * i + j] = quad_sum(c.J[0][i] * W[0][j] + c.J[1][i] * W[1][j] + c.J[2][i] * W[2][j]) + (i == j ? Md[i] : 0.0);
-          grad[i] = Md[i] * (x[i] - xs[i]) - quad_sum(c.J[0][i] * f[0] + c.J[1][i] * f[1] + c.J[2][i] * f[2]);
-        }
       }
-      double g2 = 0;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) g2 += grad[j] * grad[j];
-      if (b.scale * sqrt(g2) < 1e-13) break;
       double d[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) d[j] = -grad[j];
@@ -287,7 +295,8 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
 #pragma unroll
       for (int j = 0; j < 6; ++j) { dphi0 += grad[j] * d[j]; dMd += Md[j] * d[j] * d[j]; }
       if (!(dphi0 < 0)) break;
-      // exact line search: root of phi'(a) by safeguarded 1-D Newton; a = 1 is exact unless a contact changes zone
+      // line search: root of phi'(a) by safeguarded 1-D Newton, to 1e-3 (the outer loop's gradient test sets the accuracy
+      // of the solution; MuJoCo's own line search stops at ls_tolerance = 0.01); a = 1 is exact unless a contact changes zone
       double jd[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -297,7 +306,8 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
         jd[k] = s;
       }
       double lo = 0, hi = -1, a = 1, best = 1;
-      for (int ls = 0; ls < 40; ++ls) {
+      for (int ls = 0; ls < 20; ++ls) {
+        TEAM_COUNT(22)
         double ja[3], fa[3], Ha[6];
 #pragma unroll
         for (int k = 0; k < 3; ++k) ja[k] = jar[k] + a * jd[k];
@@ -310,11 +320,12 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
 #pragma unroll
         for (int j = 0; j < 6; ++j) dphi += Md[j] * (x[j] + a * d[j] - xs[j]) * d[j];
         best = a;
-        if (fabs(dphi) <= 1e-12 * fabs(dphi0)) break;
+        if (fabs(dphi) <= 1e-3 * fabs(dphi0)) break;
         if (dphi < 0) lo = a; else hi = a;
-        double an = a - dphi / ddphi;
+        double an = a - dphi * fast_rcp(ddphi);
         if (hi > 0 && !(an > lo && an < hi)) an = 0.5 * (lo + hi);
         if (hi < 0 && !(an > lo)) an = 2 * a;
+        if (fabs(an - a) <= 1e-3 * a) break;
         a = an;
       }
 #pragma unroll
@@ -325,6 +336,7 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
       box_jar(c, x, jar);
       box_cone(c, b.fr, jar, f, Hc);  // forces at the solution
     }
+    TEAM_MARK(18)
     if (b.noslip_iterations > 0) {
       // ---- mj_solNoSlip on the friction rows.  The lane's rows of A = J M^-1 J' (no regulariser) and of
       // b = J qacc_smooth - aref; all 12 forces on every lane.
@@ -349,7 +361,6 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
         force[k] = quad_bcast<0>(f[k]); force[3 + k] = quad_bcast<1>(f[k]);
         force[6 + k] = quad_bcast<2>(f[k]); force[9 + k] = quad_bcast<3>(f[k]);
       }
-      const int i0 = 3 * (t & 3);
       int iter = 0;
       while (iter < b.noslip_iterations) {
         double improvement = 0;
@@ -358,8 +369,9 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
         auto sweep = [&](auto slot_c) {
           constexpr int C = decltype(slot_c)::value;
           if (C >= ncon) return;
-          // every lane runs the update on its own rows; the owner's result is the one that is kept
-          double res[3], old[3], nf[3];
+          // the owner of contact C (lane C of every quad) runs the update on its rows; the others wait
+          double res[3], old[3], nf[3] = {0, 0, 0}, change = 0;
+          if ((t & 3) == C) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             double s = bb[k];
@@ -367,30 +379,30 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
             for (int j = 0; j < 12; ++j) s += A[k][j] * force[j];
             res[k] = s;
           }
-          old[0] = nf[0] = force[i0]; old[1] = force[i0 + 1]; old[2] = force[i0 + 2];
+          old[0] = nf[0] = force[3 * C]; old[1] = force[3 * C + 1]; old[2] = force[3 * C + 2];
           if (old[0] < kMin) {
             nf[0] = nf[1] = nf[2] = 0;
           } else {
-            const double A11 = A[1][i0 + 1], A12 = A[1][i0 + 2], A22 = A[2][i0 + 2];
-            const double b1 = res[1] - A11 * old[1] - A12 * old[2], b2 = res[2] - A[2][i0 + 1] * old[1] - A22 * old[2];
+            const double A11 = A[1][3 * C + 1], A12 = A[1][3 * C + 2], A22 = A[2][3 * C + 2];
+            const double b1 = res[1] - A11 * old[1] - A12 * old[2], b2 = res[2] - A[2][3 * C + 1] * old[1] - A22 * old[2];
             double vv[2];
             if (box_qcqp2(vv, A11, A12, A22, b1, b2, b.fr, old[0])) {
               double s = (vv[0] * vv[0] + vv[1] * vv[1]) / (b.fr * b.fr);
-              s = sqrt(old[0] * old[0] / (s > kMin ? s : kMin));
+              s = sqrt(old[0] * old[0] * fast_rcp(s > kMin ? s : kMin));
               vv[0] *= s; vv[1] *= s;
             }
             nf[1] = vv[0]; nf[2] = vv[1];
           }
           // costChange(): a step that raises the dual cost is undone
           const double dl[3] = {nf[0] - old[0], nf[1] - old[1], nf[2] - old[2]};
-          double change = 0;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
 #pragma unroll
-            for (int l = 0; l < 3; ++l) change += 0.5 * dl[k] * A[k][i0 + l] * dl[l];
+            for (int l = 0; l < 3; ++l) change += 0.5 * dl[k] * A[k][3 * C + l] * dl[l];
             change += dl[k] * res[k];
           }
           if (change > 1e-10) { nf[0] = old[0]; nf[1] = old[1]; nf[2] = old[2]; change = 0; }
+          }
           improvement -= quad_bcast<C>(change);
 #pragma unroll
           for (int k = 0; k < 3; ++k) force[3 * C + k] = quad_bcast<C>(nf[k]);
@@ -404,11 +416,15 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
         if (improvement < b.noslip_tolerance) break;
       }
       // dualFinish: qacc = qacc_smooth + M^-1 J' force
-      const double fo[3] = {force[i0], force[i0 + 1], force[i0 + 2]};
+      const int sl = t & 3;
+      double fo[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fo[k] = sl == 0 ? force[k] : (sl == 1 ? force[3 + k] : (sl == 2 ? force[6 + k] : force[9 + k]));
 #pragma unroll
       for (int j = 0; j < 6; ++j) x[j] = xs[j] + Mi[j] * quad_sum(c.J[0][j] * fo[0] + c.J[1][j] * fo[1] + c.J[2][j] * fo[2]);
     }
   }
+  TEAM_MARK(19)
   // ---- integrate: velocity, position, quaternion (mju_quatIntegrate with the new angular velocity)
 #pragma unroll
   for (int j = 0; j < 6; ++j) v[j] += h * x[j];
@@ -427,6 +443,7 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
       for (int k = 0; k < 4; ++k) q[k] = o[k] * sc;
     }
   }
+  TEAM_MARK(20)
   if (t == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) bs[kBoxQ + k] = p[k];

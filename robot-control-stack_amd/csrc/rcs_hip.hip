@@ -1038,9 +1038,9 @@ int rcsh_dev_download(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
 }
 
 #ifdef RCSH_PHASE_TIMING
-extern "C" int rcsh_debug_team_cycles(unsigned long long* out16) {
+extern "C" int rcsh_debug_team_cycles(unsigned long long* out16 /* 24 slots */) {
   hipDeviceSynchronize();
-  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : 1;
 }
 #endif
 

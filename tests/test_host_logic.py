@@ -205,3 +205,136 @@ def test_config_mirrors_reference_defaults():
     g = default_sim_gripper_cfg()
     assert g.joint == "finger_joint1_0" and g.actuator == "actuator8_0" and g.seconds_between_callbacks == 0.05
     assert (g.max_actuator_width, g.min_actuator_width, g.max_joint_width, g.min_joint_width) == (255, 0, 0.04, 0.0)
+
+
+# ---------------------------------------------------------------- fr3_simple_pick_up: the free box and the task layer
+PICKUP_SCENE = os.path.join(os.path.dirname(SCENE), "..", "fr3_simple_pick_up", "scene.xml")
+REF_PICKUP_SCENE = "/root/reference/assets/scenes/fr3_simple_pick_up/scene.xml"
+
+
+def test_pick_up_scene_free_box_constants():
+    """The cube of assets/scenes/fr3_simple_pick_up/scene.xml:30-33: half extents, density 50, friction mixed with the
+    floor (element-wise max), spawn pose; the robot tables are the empty-world ones."""
+    cm, empty = compile_mjcf(PICKUP_SCENE), compile_mjcf(SCENE)
+    for k, a in empty.arrays.items():
+        assert np.array_equal(a, cm.arrays[k]), k
+    assert (cm.nq, cm.nv, cm.njnt) == (9, 9, 9) and len(cm.free_bodies) == 1 and empty.free_bodies == []
+    fb = cm.free_bodies[0]
+    assert (fb["name"], fb["joint_name"], fb["geom_name"]) == ("box_geom", "box_joint", "box_geom")
+    assert np.allclose(fb["size"], [0.032, 0.016, 0.0288]) and np.allclose(fb["qpos0"], [0.44, 0.1, 0.03, 0, 0, 0, 1])
+    vol = 8 * 0.032 * 0.016 * 0.0288
+    assert np.isclose(fb["mass"], 50 * vol, rtol=1e-14)
+    m = fb["mass"]
+    assert np.allclose(fb["inertia"], [m / 3 * (0.016**2 + 0.0288**2), m / 3 * (0.032**2 + 0.0288**2), m / 3 * (0.032**2 + 0.016**2)], rtol=1e-14)
+    assert np.allclose(fb["friction"], [1, 0.3, 0.1]) and np.allclose(fb["solref"], [0.02, 1]) and fb["plane_z"] == 0.0
+    d = _lib.make_free_box_desc(cm)
+    assert d.cone_elliptic == 1 and d.noslip_iterations == 5 and d.impratio == 20.0 and _lib.make_free_box_desc(empty) is None
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PICKUP_SCENE), reason="reference checkout not present (GPU box)")
+def test_own_pick_up_scene_equals_reference_scene():
+    own, ref = compile_mjcf(PICKUP_SCENE), compile_mjcf(REF_PICKUP_SCENE)
+    (a,), (b,) = own.free_bodies, ref.free_bodies
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]) if isinstance(a[k], np.ndarray) else a[k] == b[k], k
+    assert own.jnt_names == ref.jnt_names and own.body_names == ref.body_names
+    for key in ("body_pos", "body_quat", "jnt_range", "actuator_gainprm", "actuator_biasprm", "qpos0"):
+        assert np.allclose(own.arrays[key], ref.arrays[key]), key
+
+
+def test_compiler_rejects_unsupported_free_bodies(tmp_path):
+    bad = tmp_path / "s.xml"
+    bad.write_text('<mujoco><worldbody><geom type="plane" size="0 0 1"/><body><freejoint/><geom type="sphere" size="0.1"/></body></worldbody></mujoco>')
+    with pytest.raises(MjcfError, match="exactly one box geom"):
+        compile_mjcf(str(bad))
+    bad.write_text('<mujoco><worldbody><body><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    with pytest.raises(MjcfError, match="floor plane"):
+        compile_mjcf(str(bad))
+
+
+def _box_oracle():
+    cm = compile_mjcf(PICKUP_SCENE)
+    m = O.make_model(cm)
+    L = O.lib()
+    L.orc_box_step1.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+    L.orc_box_step2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+    d = O.OrcBoxData()
+    L.orc_box_reset(C.byref(m.box), C.byref(d))
+    g = (C.c_double * 3)(0, 0, -9.81)
+
+    def step(n=1):
+        for _ in range(n):
+            L.orc_box_step1(C.byref(m.box), C.byref(d), 0.002)
+            L.orc_box_step2(C.byref(m.box), C.byref(d), g, 0.002, 0.0)
+
+    return m, d, step
+
+
+def test_oracle_box_rests_where_the_soft_contact_balances_gravity():
+    """Four sticking corner contacts carry m g: the penetration solves m g / 4 = D0 K imp(r) r with D0 = imp / ((1 - imp) / m),
+    i.e. r = g (1 - imp) / (4 K imp^2) -- independent of the mass.  No drift, no rotation, warm-started Newton converges at once."""
+    m, d, step = _box_oracle()
+    assert abs(m.box.meaninertia - 0.3195339856057694) < 1e-12 and m.box.nv_total == 15
+    step(600)
+    assert d.ncon == 4 and list(d.zone) == [2, 2, 2, 2] and d.newton_iter <= 1
+    r = 0.0288 - d.qpos[2]
+    K = 1 / (0.95**2 * 0.02**2)
+    x = r / 0.001
+    imp = 0.9 + 0.05 * (x * x / 0.5 if x <= 0.5 else 1 - (1 - x) ** 2 / 0.5)
+    assert abs(r - 9.81 * (1 - imp) / (4 * K * imp * imp)) < 1e-9, r
+    assert np.abs(np.array(d.qvel[:])).max() < 1e-9
+    assert np.allclose(d.qpos[:2], [0.44, 0.1], atol=1e-12) and np.allclose(np.abs(d.qpos[3:]), [0, 0, 0, 1], atol=1e-12)
+    assert abs(sum(d.force[3 * c] for c in range(4)) - m.box.mass * 9.81) < 1e-9   # normal forces carry the weight
+    assert max(abs(d.force[3 * c + k]) for c in range(4) for k in (1, 2)) < 1e-9
+
+
+def test_oracle_box_slides_to_a_stop_under_coulomb_friction():
+    """A resting box kicked sideways at 0.5 m/s decelerates at ~mu g (mu = 1, sliding zone of the cone) and sticks;
+    the stopping distance is v^2 / (2 mu g) up to the soft-contact transients; it never gains energy."""
+    m, d, step = _box_oracle()
+    step(600)
+    x0 = d.qpos[0]
+    d.qvel[0] = 0.5
+    zones, speeds = set(), []
+    for _ in range(200):
+        step(1)
+        zones.update(d.zone[: d.ncon])
+        speeds.append(float(np.linalg.norm(d.qvel[:3])))
+    assert 1 in zones and list(d.zone) == [2, 2, 2, 2]          # slid, then stuck
+    assert max(speeds) <= 0.5 + 1e-12 and speeds[-1] < 1e-4
+    assert abs((d.qpos[0] - x0) - 0.25 / (2 * 9.81)) < 1.5e-3, d.qpos[0] - x0
+
+
+def test_oracle_box_pops_out_of_the_floor_after_random_cube_pos():
+    """RandomCubePos writes z = 0.0288 / 2 -- the cube's centre 14.4 mm too low (python/rcs/envs/sim.py:377): the
+    contact pushes it out; it ends at its rest height, upright, at the same x / y."""
+    m, d, step = _box_oracle()
+    d.qpos[:] = [0.5, -0.03, 0.0144, 0.3, 0, 0, 1]
+    step(1)
+    assert abs(np.linalg.norm(d.qpos[3:]) - 1) < 1e-15      # mj_kinematics normalised the quaternion in qpos
+    yaw0 = 2 * np.arctan2(d.qpos[6], d.qpos[3])
+    step(1500)
+    assert abs(d.qpos[2] - 0.028692) < 2e-6 and np.abs(np.array(d.qvel[:])).max() < 1e-6
+    assert abs(d.qpos[0] - 0.5) < 1e-3 and abs(d.qpos[1] + 0.03) < 1e-3
+    assert abs(2 * np.arctan2(d.qpos[6], d.qpos[3]) - yaw0) < 1e-2 and abs(d.qpos[4]) < 1e-6 and abs(d.qpos[5]) < 1e-6
+
+
+def test_oracle_box_free_flight_and_gyroscopic_term():
+    """Above the floor: ballistic centre of mass, angular momentum conserved in the world frame (torque-free tumbling)."""
+    m, d, step = _box_oracle()
+    d.qpos[:] = [0, 0, 1.0, 1, 0, 0, 0]
+    d.qvel[:] = [0.1, -0.2, 0.3, 3.0, -2.0, 1.0]
+    I = np.array(m.box.inertia[:])
+
+    def L_world():
+        q = np.array(d.qpos[3:])
+        R = common.Pose(quaternion=np.array([q[1], q[2], q[3], q[0]])).rotation_m()
+        return R @ (I * np.array(d.qvel[3:]))
+
+    L0 = L_world()
+    step(100)
+    assert d.ncon == 0
+    assert np.allclose(d.qpos[:2], [0.1 * 0.2, -0.2 * 0.2], atol=1e-12)
+    assert abs(d.qpos[2] - (1.0 + 0.3 * 0.2 - 0.5 * 9.81 * 0.2 * 0.202)) < 1e-9   # semi-implicit Euler: sum of k h^2 g
+    assert np.allclose(L_world(), L0, rtol=2e-3)

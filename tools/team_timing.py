@@ -12,7 +12,7 @@ env = make_vec_env(n, True)
 j, g = synthetic_actions(64, T, 0)
 j = np.tile(j, (1, n // 64, 1)); g = np.tile(g, (1, n // 64))
 env.reset()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 env._L.rcsh_debug_team_cycles(out)
 base = np.array(out[:], dtype=np.float64)
 for t in range(T): env.step({"joints": j[t], "gripper": g[t]})
