@@ -56,3 +56,47 @@ def test_oracle_matches_mujoco_on_joint_rollout(scene, robot):
         assert np.abs(np.asarray(md.qpos)[jadr] - np.asarray(s.qpos)[: len(jadr)]).max() < 1e-5
         assert np.abs(np.asarray(md.qvel)[jadr] - np.asarray(s.qvel)[: len(jadr)]).max() < 1e-5
     assert os.path.exists(scene)
+
+
+def test_oracle_free_box_matches_mujoco():
+    """The cube of fr3_simple_pick_up against MuJoCo: contact count, the regularised friction of the elliptic cone, the
+    pop-out after RandomCubePos' placement, a kicked slide and the rest pose.  With its mesh geoms removed the robot
+    cannot touch the cube in MuJoCo either, which is the configuration the oracle restates (floor contacts only)."""
+    from parity_util import PICKUP_SCENE
+
+    xml = open(PICKUP_SCENE).read()
+    inc = open(os.path.join(os.path.dirname(PICKUP_SCENE), "..", "fr3_empty_world", "scene.xml")).read()
+    inc = re.sub(r"<geom[^>]*\bmesh=\"[^\"]*\"[^>]*/>", "", inc)
+    # the pads are box geoms and would collide with the cube in MuJoCo: take them out of the collision set as well
+    inc = re.sub(r"(<default class=\"pad\d\"><geom )", r"\1contype=\"0\" conaffinity=\"0\" ", inc)
+    body = re.search(r"<mujoco[^>]*>(.*)</mujoco>", inc, re.S).group(1)
+    xml = xml.replace('<include file="../fr3_empty_world/scene.xml"/>', body)
+    mm = mujoco.MjModel.from_xml_string(xml)
+    md = mujoco.MjData(mm)
+    cm = compile_mjcf(PICKUP_SCENE)
+    s = O.Sim(cm, FR3["joints"], FR3["actuators"], FR3["site"], FR3["base"], FR3["q_home"], None,
+              gripper_joint=FR3["gripper_joint"], gripper_actuator=FR3["gripper_actuator"])
+    assert abs(mm.stat.meaninertia - s.model.box.meaninertia) < 1e-9
+    badr = mm.joint("box_joint").qposadr[0]
+    vadr = mm.joint("box_joint").dofadr[0]
+    jadr = [mm.joint(n).qposadr[0] for n in FR3["joints"]]
+    for i, a in zip(jadr, FR3["q_home"]):
+        md.qpos[i] = a
+        s.s.d.qpos[i] = a
+    for n, a in zip(FR3["actuators"], FR3["q_home"]):
+        md.ctrl[mm.actuator(n).id] = a
+    s.set_joint_position(FR3["q_home"])
+    place = [0.5, -0.03, 0.0288 / 2, 0.3, 0, 0, 1]
+    md.qpos[badr:badr + 7] = place
+    s.box_qpos = place
+    for k in range(600):
+        if k == 300:  # kick the resting cube sideways
+            md.qvel[vadr:vadr + 3] = [0.4, 0.2, 0]
+            v = s.box_qvel
+            v[:3] = [0.4, 0.2, 0]
+            s.box_qvel = v
+        mujoco.mj_step(mm, md)
+        s.step(1)
+        assert md.ncon == s.s.d.box.ncon, k
+        assert np.abs(np.asarray(md.qpos)[badr:badr + 7] - s.box_qpos).max() < 1e-5, k
+        assert np.abs(np.asarray(md.qvel)[vadr:vadr + 6] - s.box_qvel).max() < 1e-4, k
