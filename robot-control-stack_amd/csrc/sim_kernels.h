@@ -164,25 +164,52 @@ __device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T, ST>&
   r.conv_steps = P.conv_steps[e];
 }
 
-template <class T, class ST>
+// kStaged false: only the fields EnvRegs holds in registers (the team kernel moves the LDS-staged ones with all
+// 16 lanes of the team, team_staged_fields)
+template <class T, class ST, bool kStaged = true>
 __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<T, ST>& r) {
   using L = Lay<T>;
   const int n = P.n;
   double* S = P.S;
+  if constexpr (kStaged) {
 #pragma unroll
-  for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.st.q(i); S[(L::QVEL + i) * n + e] = r.st.v(i); }
+    for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.st.q(i); S[(L::QVEL + i) * n + e] = r.st.v(i); }
 #pragma unroll
-  for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.st.c(i);
+    for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.st.c(i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S[(L::CB + i) * n + e] = r.cb(i);
+#pragma unroll
+    for (int i = 0; i < T::NARM; ++i) { S[(L::PREVQ + i) * n + e] = r.prevq(i); S[(L::TARGET + i) * n + e] = r.target(i); }
+  }
   S[L::TIME * n + e] = r.time;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) S[(L::CB + i) * n + e] = r.cb(i);
-#pragma unroll
-  for (int i = 0; i < T::NARM; ++i) { S[(L::PREVQ + i) * n + e] = r.prevq(i); S[(L::TARGET + i) * n + e] = r.target(i); }
   S[(L::GRIP + 0) * n + e] = r.last_cmd_width;
   S[(L::GRIP + 1) * n + e] = r.last_width;
   P.flags[e] = r.flags;
   P.conv_steps[e] = r.conv_steps;
 }
+
+// The state fields that live in the team's LDS block during a launch (qpos, qvel, ctrl, callback timestamps,
+// previous / target angles), as a list: entry k is HBM field `field` <-> LDS slot `slot`.  The team kernel moves them
+// with all 16 lanes (three rounds) instead of one lane issuing them one after the other.
+template <class T, class ST>
+struct TeamStagedFields {
+  using L = Lay<T>;
+  static constexpr int kCount = 2 * T::NL + T::NU + 6 + 2 * T::NARM;
+  static constexpr int kRounds = (kCount + kTeamLanes - 1) / kTeamLanes;
+  __device__ __forceinline__ static void locate(int k, int& field, int& slot) {
+    if (k < T::NL) { field = L::QPOS + k; slot = ST::Q0 + k; return; }
+    k -= T::NL;
+    if (k < T::NL) { field = L::QVEL + k; slot = ST::V0 + k; return; }
+    k -= T::NL;
+    if (k < T::NU) { field = L::CTRL + k; slot = ST::C0 + k; return; }
+    k -= T::NU;
+    if (k < 6) { field = L::CB + k; slot = ST::X0 + k; return; }
+    k -= 6;
+    if (k < T::NARM) { field = L::PREVQ + k; slot = ST::X0 + 6 + k; return; }
+    k -= T::NARM;
+    field = L::TARGET + k; slot = ST::X0 + 6 + T::NARM + k;
+  }
+};
 
 __device__ __forceinline__ void set_flag(uint32_t& f, uint32_t bit, bool v) { f = v ? (f | bit) : (f & ~bit); }
 
@@ -415,7 +442,7 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
 
 // After stepping: park the site frame, refresh the relative-action origin on reset, write the state back and
 // produce observation + info (RobotEnv.get_obs, GripperWrapper.observation, RobotSimWrapper.step, GripperWrapperSim).
-template <class T, class ST>
+template <class T, class ST, bool kStoreStaged = true>
 __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, const DevModel& m, int e, EnvRegs<T, ST>& r,
                                              const ST& st, bool have_frames, int nsteps) {
   using L = Lay<T>;
@@ -447,7 +474,7 @@ __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, c
     }
     r.flags &= ~kHasLastAction;
   }
-  store_env<T, ST>(P, e, r);
+  store_env<T, ST, kStoreStaged>(P, e, r);
 
   if (op.write_obs) {
     // RobotEnv.get_obs (base.py:246-253) + GripperWrapper.observation (base.py:710-719) +
@@ -610,6 +637,38 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   const RunOp& op = lop;
   const CollTable& lc = lp.coll;
   TEAM_CLOCK_START()
+  const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
+  // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  Give
+  // every XCD one contiguous range of environments, so a 128-byte line of a state field ([field][env], 16
+  // environments) is fetched into one L2 instead of four.  The grid is rounded up to a multiple of 8.
+  const int per_xcd = gridDim.x / 8;
+  const int e = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * kTeams + team;
+  const bool live = e < Pk.n && !(opk.mask && !opk.mask[e < Pk.n ? e : 0]);
+  const bool leader = t == 0 && live;
+  // The environment's state goes out first -- every lane asks for up to three of the fields that are staged in LDS,
+  // the leader for the five it keeps in registers -- so that the model staging below hides the round trip to HBM.
+  using SF = TeamStagedFields<T, ST>;
+  double staged[SF::kRounds];
+  double pre_time = 0, pre_cmd = 0, pre_width = 0;
+  uint32_t pre_flags = 0;
+  int32_t pre_conv = 0;
+  if (live) {
+#pragma unroll
+    for (int rd = 0; rd < SF::kRounds; ++rd) {
+      const int k = t + rd * kTeamLanes;
+      int field = 0, slot = 0;
+      SF::locate(k < SF::kCount ? k : 0, field, slot);
+      staged[rd] = Pk.S[(size_t)field * Pk.n + e];
+    }
+    if (t == 0) {
+      using L = Lay<T>;
+      pre_time = Pk.S[(size_t)L::TIME * Pk.n + e];
+      pre_cmd = Pk.S[(size_t)(L::GRIP + 0) * Pk.n + e];
+      pre_width = Pk.S[(size_t)(L::GRIP + 1) * Pk.n + e];
+      pre_flags = Pk.flags[e];
+      pre_conv = Pk.conv_steps[e];
+    }
+  }
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
   __shared__ std::conditional_t<BOX, BoxTaskCfg, char> lbt[1];
   {
@@ -623,14 +682,6 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     __syncthreads();
   }
   TEAM_MARK(12)
-  const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
-  // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  Give
-  // every XCD one contiguous range of environments, so a 128-byte line of a state field ([field][env], 16
-  // environments) is fetched into one L2 instead of four.  The grid is rounded up to a multiple of 8.
-  const int per_xcd = gridDim.x / 8;
-  const int e = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * kTeams + team;
-  const bool live = e < P.n && !(op.mask && !op.mask[e < P.n ? e : 0]);
-  const bool leader = t == 0 && live;
   const DevModel& m = lm;
   const ST st{lds + team * ST::COUNT};
   EnvRegs<T, ST> r;  // meaningful on the leader only
@@ -645,10 +696,20 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   const bool until_conv = nsteps < 0;
   int budget = 0;
   bool converged = false;
+  if (live) {
+#pragma unroll
+    for (int rd = 0; rd < SF::kRounds; ++rd) {
+      const int k = t + rd * kTeamLanes;
+      int field = 0, slot = 0;
+      SF::locate(k < SF::kCount ? k : 0, field, slot);
+      if (k < SF::kCount) st.at(slot) = staged[rd];
+    }
+  }
+  __syncthreads();
   if (leader) {
-    load_env<T, ST>(Pk, e, r);  // (prologue: straight from the arguments, they are still in registers)
+    r.time = pre_time; r.last_cmd_width = pre_cmd; r.last_width = pre_width; r.flags = pre_flags; r.conv_steps = pre_conv;
     TEAM_MARK(13)
-    env_prologue<T, ST>(Pk, opk, m, e, r);
+    env_prologue<T, ST>(Pk, opk, m, e, r);  // (straight from the arguments: they are still in registers here)
     TEAM_MARK(14)
     budget = nsteps;
     if (until_conv) {
@@ -751,7 +812,18 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   }
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
-    env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
+    env_epilogue<T, ST, false>(P, op, m, e, r, st, have_frames, nsteps);
+  }
+  __syncthreads();
+  if (live) {
+    // the LDS-staged state fields go back with all lanes
+#pragma unroll
+    for (int rd = 0; rd < SF::kRounds; ++rd) {
+      const int k = t + rd * kTeamLanes;
+      int field = 0, slot = 0;
+      SF::locate(k < SF::kCount ? k : 0, field, slot);
+      if (k < SF::kCount) P.S[(size_t)field * P.n + e] = st.at(slot);
+    }
   }
   if constexpr (BOX) {
     if (live) {
