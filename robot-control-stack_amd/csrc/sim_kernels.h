@@ -362,10 +362,43 @@ __device__ __forceinline__ void cartesian_position(const DevModel& m, const Robo
   pose_mul(in_robot, tcp, out);
 }
 
+// What env.step() reads per environment before the simulator is stepped: the action, the gripper command and the
+// wrappers' remembered vectors.  StepInGlobal fetches from HBM where the value is used (lane kernel); the team kernel
+// has its 16 lanes fetch all of it ahead of time into LDS (StepInStaged; entry k of the list is `fetch(k)`).
+template <class T>
+struct StepInGlobal {
+  using L = Lay<T>;
+  const Params& P;
+  const RunOp& op;
+  int e;
+  static constexpr int kCount = 4 * T::NARM + 1;
+  __device__ __forceinline__ double action(int i) const { return op.action[e * T::NARM + i]; }
+  __device__ __forceinline__ double origin(int i) const { return P.S[(L::ORIGIN + i) * P.n + e]; }
+  __device__ __forceinline__ double lasta(int i) const { return P.S[(L::LASTA + i) * P.n + e]; }
+  __device__ __forceinline__ double preva(int i) const { return P.S[(L::PREVA + i) * P.n + e]; }
+  __device__ __forceinline__ float gripper() const { return op.gripper[e]; }
+  __device__ __forceinline__ double fetch(int k) const {
+    if (k < T::NARM) return action(k);
+    if (k < 2 * T::NARM) return origin(k - T::NARM);
+    if (k < 3 * T::NARM) return lasta(k - 2 * T::NARM);
+    if (k < 4 * T::NARM) return preva(k - 3 * T::NARM);
+    return op.gripper ? (double)op.gripper[e] : 0.0;
+  }
+};
+template <class T>
+struct StepInStaged {
+  const double* s;  // LDS, kCount entries in fetch() order
+  __device__ __forceinline__ double action(int i) const { return s[i]; }
+  __device__ __forceinline__ double origin(int i) const { return s[T::NARM + i]; }
+  __device__ __forceinline__ double lasta(int i) const { return s[2 * T::NARM + i]; }
+  __device__ __forceinline__ double preva(int i) const { return s[3 * T::NARM + i]; }
+  __device__ __forceinline__ float gripper() const { return (float)s[4 * T::NARM]; }
+};
+
 // Wrappers' reset() / action() side effects on one environment: everything env.reset() / env.step() do before
 // the simulator is stepped (reference python/rcs/envs/base.py, envs/sim.py; see the inline citations).
-template <class T, class ST>
-__device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, const DevModel& m, int e, EnvRegs<T, ST>& r) {
+template <class T, class ST, class In>
+__device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, const DevModel& m, int e, EnvRegs<T, ST>& r, const In& in) {
   using L = Lay<T>;
   const int n = P.n;
   if (op.do_reset) {
@@ -392,18 +425,18 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
     // ---- RelativeActionSpace.action (python/rcs/envs/base.py:468-488), JOINTS mode
     double a[T::NARM];
 #pragma unroll
-    for (int i = 0; i < T::NARM; ++i) a[i] = op.action[e * T::NARM + i];
+    for (int i = 0; i < T::NARM; ++i) a[i] = in.action(i);
     if (P.env.relative_to != 0) {
       const bool last_step = P.env.relative_to == 1;
       const bool fresh = last_step || !(r.flags & kHasLastAction);
 #pragma unroll
       for (int i = 0; i < T::NARM; ++i) {
-        double origin = last_step ? r.st.q(i) : P.S[(L::ORIGIN + i) * n + e];
+        double origin = last_step ? r.st.q(i) : in.origin(i);
         double lim;
         if (fresh) {
           lim = clampd(a[i], -P.env.max_mov[0], P.env.max_mov[0]);
         } else {
-          const double la = P.S[(L::LASTA + i) * n + e];
+          const double la = in.lasta(i);
           lim = clampd(a[i] - la, -P.env.max_mov[0], P.env.max_mov[0]) + la;
         }
         if (last_step) P.S[(L::ORIGIN + i) * n + e] = origin;
@@ -414,7 +447,7 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
     }
     // ---- GripperWrapper.action (base.py:721-735)
     if (T::GRIP && P.grip.present && op.gripper) {
-      float g = op.gripper[e];
+      float g = in.gripper();
       if (P.env.binary_gripper) g = rintf(g);  // np.round: half to even
       g = fminf(fmaxf(g, 0.0f), 1.0f);
       if (P.env.binary_gripper) {
@@ -430,7 +463,7 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
     bool changed = !(r.flags & kHasPrevAction);
 #pragma unroll
     for (int i = 0; i < T::NARM; ++i) {
-      const double pa = P.S[(L::PREVA + i) * n + e];
+      const double pa = in.preva(i);
       changed = changed || !(fabs(a[i] - pa) <= 1e-3);
       P.S[(L::PREVA + i) * n + e] = a[i];
     }
@@ -553,7 +586,7 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   load_env<T, ST>(P, e, r);
   bool have_frames = false;
 
-  env_prologue<T, ST>(P, op, m, e, r);
+  env_prologue<T, ST>(P, op, m, e, r, StepInGlobal<T>{P, op, e});
 
   // ---- Sim::step(k) / Sim::step_until_convergence (src/sim/sim.cpp:84-115).  One loop serves both so the
   // (large, fully unrolled) substep body exists once in the instruction stream.
@@ -649,6 +682,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // the leader for the five it keeps in registers -- so that the model staging below hides the round trip to HBM.
   using SF = TeamStagedFields<T, ST>;
   double staged[SF::kRounds];
+  constexpr int kInRounds = (StepInGlobal<T>::kCount + kTeamLanes - 1) / kTeamLanes;
+  double step_in[kInRounds] = {};
+  static_assert(StepInGlobal<T>::kCount <= 5 * ST::NLP, "the env-step inputs are parked in the helpers' block of the LDS stage");
   double pre_time = 0, pre_cmd = 0, pre_width = 0;
   uint32_t pre_flags = 0;
   int32_t pre_conv = 0;
@@ -659,6 +695,14 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       int field = 0, slot = 0;
       SF::locate(k < SF::kCount ? k : 0, field, slot);
       staged[rd] = Pk.S[(size_t)field * Pk.n + e];
+    }
+    if (opk.apply_action) {
+      const StepInGlobal<T> gin{Pk, opk, e};
+#pragma unroll
+      for (int rd = 0; rd < kInRounds; ++rd) {
+        const int k = t + rd * kTeamLanes;
+        step_in[rd] = gin.fetch(k < StepInGlobal<T>::kCount ? k : 0);
+      }
     }
     if (t == 0) {
       using L = Lay<T>;
@@ -704,12 +748,17 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       SF::locate(k < SF::kCount ? k : 0, field, slot);
       if (k < SF::kCount) st.at(slot) = staged[rd];
     }
+#pragma unroll
+    for (int rd = 0; rd < kInRounds; ++rd) {
+      const int k = t + rd * kTeamLanes;
+      if (k < StepInGlobal<T>::kCount) st.at(ST::Y0 + k) = step_in[rd];  // (the helpers' block is idle until the first substep)
+    }
   }
   __syncthreads();
   if (leader) {
     r.time = pre_time; r.last_cmd_width = pre_cmd; r.last_width = pre_width; r.flags = pre_flags; r.conv_steps = pre_conv;
     TEAM_MARK(13)
-    env_prologue<T, ST>(Pk, opk, m, e, r);  // (straight from the arguments: they are still in registers here)
+    env_prologue<T, ST>(Pk, opk, m, e, r, StepInStaged<T>{&st.at(ST::Y0)});  // (Pk, opk: still in registers here)
     TEAM_MARK(14)
     budget = nsteps;
     if (until_conv) {
