@@ -379,6 +379,8 @@ struct StepInGlobal {
   __device__ __forceinline__ float gripper() const { return op.gripper[e]; }
   __device__ __forceinline__ double fetch(int k) const {
     if (k < T::NARM) return action(k);
+    // origin / last action are only read back with RelativeTo.CONFIGURED_ORIGIN (LAST_STEP re-derives both every step)
+    if (k < 3 * T::NARM && P.env.relative_to != 2) return 0.0;
     if (k < 2 * T::NARM) return origin(k - T::NARM);
     if (k < 3 * T::NARM) return lasta(k - 2 * T::NARM);
     if (k < 4 * T::NARM) return preva(k - 3 * T::NARM);
