@@ -97,7 +97,7 @@ def run_free_box_parity(n_envs=32, n_calls=10, k=25, seed=0, kick=True):
     return rep
 
 
-def run_pick_task_parity(n_envs=16, n_steps=6, seed=0, episodes=2):
+def run_pick_task_parity(n_envs=16, n_steps=6, seed=0, episodes=2, async_control=True):
     """FR3SimplePickUpSimEnvCreator()(...) (30 Hz async control, relative TRPY actions, RandomCubePos, PickCubeSuccessWrapper)
     against the oracle's restatement of that wrapper stack on the same actions and the same cube placements."""
     from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
@@ -105,10 +105,18 @@ def run_pick_task_parity(n_envs=16, n_steps=6, seed=0, episodes=2):
     import rcs_oracle as O
     from rcs_env_oracle import OraclePickCubeEnv
 
-    venv = FR3SimplePickUpSimEnvCreator()(n_envs=n_envs)
     cm = compile_mjcf(PICKUP_SCENE)
     tcp = O.Pose(translation=[0.0, 0.0, 0.1034], rotation=np.array([[0.707, 0.707, 0], [-0.707, 0.707, 0], [0, 0, 1]]))
-    oenvs = [OraclePickCubeEnv(cm, tcp_offset=tcp) for _ in range(n_envs)]
+    if async_control:
+        venv = FR3SimplePickUpSimEnvCreator()(n_envs=n_envs)
+    else:  # SimTaskEnvCreator with the reference's default SimConfig: step_until_convergence
+        from rcs_amd import common, sim
+        from rcs_amd.envs import SimTaskEnvCreator, default_sim_robot_cfg
+
+        rc = default_sim_robot_cfg(scene="fr3_simple_pick_up")
+        rc.tcp_offset = common.Pose(translation=np.array([0.0, 0.0, 0.1034]), rotation=np.array([[0.707, 0.707, 0], [-0.707, 0.707, 0], [0, 0, 1]]))
+        venv = SimTaskEnvCreator()(rc, sim_cfg=sim.SimConfig(), n_envs=n_envs)
+    oenvs = [OraclePickCubeEnv(cm, tcp_offset=tcp, async_control=async_control) for _ in range(n_envs)]
     rng = np.random.default_rng(seed)
     rep = {"max_abs_obs": 0.0, "max_abs_box": 0.0, "max_abs_reward": 0.0, "flag_mismatches": 0, "min_reward": 9.0, "max_reward": -9.0,
            "grasped_seen": 0}
@@ -136,6 +144,8 @@ def run_pick_task_parity(n_envs=16, n_steps=6, seed=0, episodes=2):
                 rep["flag_mismatches"] += int(bool(term[e]) != bool(oterm)) + int(bool(trunc[e]) != bool(otrunc)) + int(bool(info["success"][e]) != bool(oi["success"]))
                 rep["flag_mismatches"] += int(bool(info["is_grasped"][e]) != bool(oi["is_grasped"])) + int(float(obs["gripper"][e]) != float(oo["gripper"]))
                 rep["grasped_seen"] += int(bool(oi["is_grasped"]))
+                if not async_control:
+                    rep["flag_mismatches"] += int(int(info["substeps"][e]) != int(oe.sim.s.convergence_steps)) + int(bool(info["is_sim_converged"][e]) != bool(oi["is_sim_converged"]))
             rep["min_reward"], rep["max_reward"] = min(rep["min_reward"], float(reward.min())), max(rep["max_reward"], float(reward.max()))
     venv.close()
     return rep

@@ -448,14 +448,15 @@ def test_free_box_matches_oracle(kernel):
     assert rep["max_abs_robot_qpos"] < 1e-9, rep
 
 
-def test_pick_task_env_matches_oracle(kernel):
+@pytest.mark.parametrize("async_control", [True, False])
+def test_pick_task_env_matches_oracle(kernel, async_control):
     """rcs/FR3SimplePickUpSim-v0 (FR3SimplePickUpSimEnvCreator: RandomCubePos reset, relative TRPY control through the
     CLIK, PickCubeSuccessWrapper reward / success) against the oracle's restatement of that wrapper stack."""
     import parity_util as pu
 
     if kernel == "lane":
         pytest.skip("free bodies are stepped by the team kernel only")
-    rep = pu.run_pick_task_parity(n_envs=16, n_steps=6, seed=1, episodes=2)
+    rep = pu.run_pick_task_parity(n_envs=16, n_steps=6 if async_control else 3, seed=1, episodes=2, async_control=async_control)
     assert rep["flag_mismatches"] == 0, rep
     assert rep["max_abs_obs"] < TOL and rep["max_abs_box"] < 1e-6 and rep["max_abs_reward"] < 1e-6, rep
     assert 0.0 < rep["min_reward"] and rep["max_reward"] < 1.0, rep
