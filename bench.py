@@ -245,7 +245,9 @@ def main() -> None:
         one_step(t)
     from rcs_amd import _lib
 
-    _lib.check(L.rcsh_prof_enable(h, 1))
+    # HIP events on the launch stream around every 8th env-step launch of the timed region: a pair of event records
+    # around every launch would put ~8 us of dispatch gap into each step of the run it is measuring
+    _lib.check(L.rcsh_prof_enable(h, 8))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -329,7 +329,8 @@ int rcsh_dev_download(rcsh_sim* sim, void* dst_host, const void* src_dev, size_t
  * tools/kbench to replay the exact FR3 tables in kernel micro-benchmarks */
 int rcsh_debug_dump_model(rcsh_sim* sim, void* buf, size_t cap, size_t* size);
 
-/* kernel timing hooks for bench.py: HIP events on the handle's stream around each fused env-step launch */
+/* kernel timing hooks for bench.py: HIP events on the handle's stream around every `enable`-th fused env-step launch
+ * (1: every launch; 0: off).  A pair of event records around EVERY launch costs ~8 us of dispatch gap per step. */
 int rcsh_prof_enable(rcsh_sim* sim, int32_t enable);
 int rcsh_prof_read(rcsh_sim* sim, double* total_ms, int64_t* launches);
 

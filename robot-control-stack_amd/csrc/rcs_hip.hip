@@ -77,6 +77,8 @@ struct rcsh_sim {
   bool prof = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
   int prof_pending = 0;
+  int prof_every = 1;       // HIP events around every prof_every-th stepping launch
+  int64_t prof_seen = 0;
   double prof_ms = 0;
   int64_t prof_launches = 0;
 };
@@ -150,7 +152,8 @@ int prof_flush(rcsh_sim* s) {
 int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   Params P = make_params(s);
   hipError_t err = hipSuccess;
-  if (timed && s->prof) {
+  const bool sample = timed && s->prof && (s->prof_seen++ % s->prof_every) == 0;
+  if (sample) {
     if (s->prof_pending == kProfRing) {
       int rc = prof_flush(s);
       if (rc) return rc;
@@ -181,7 +184,7 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_run launch: ") + hipGetErrorString(err));
-  if (timed && s->prof) {
+  if (sample) {
     HIP_TRY(hipEventRecord(s->ev_stop[s->prof_pending], s->stream));
     s->prof_pending++;
   }
@@ -1063,6 +1066,8 @@ int rcsh_prof_enable(rcsh_sim* s, int32_t enable) {
     }
   }
   s->prof = enable != 0;
+  s->prof_every = enable > 1 ? enable : 1;
+  s->prof_seen = 0;
   s->prof_pending = 0; s->prof_ms = 0; s->prof_launches = 0;
   return RCSH_OK;
 }

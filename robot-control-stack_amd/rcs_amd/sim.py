@@ -67,7 +67,7 @@ class Sim:
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             self._L.rcsh_sim_destroy(h)
-            self._h = C.c_void_p()
+            self._h = None
 
     close = __del__
 
