@@ -319,6 +319,39 @@ int rcsh_env_step_task_dev(rcsh_sim* sim, const double* action_dev, const float*
                            double* gripper_width_dev, int32_t* substeps_dev, double* task_dev);
 
 
+/* Depth images: the pixel path of SimCameraSet (reference src/sim/camera.cpp:86-140 render_single -> mjv_updateScene,
+ * mjr_render, mjr_readPixels; python/rcs/camera/sim.py:45-115 for the row flip, the conversion to metres and the
+ * uint16 millimetre image, the intrinsics and the extrinsics).  The reference rasterises MuJoCo's visual geoms with
+ * OpenGL; this backend casts one ray per pixel against the shapes given here (floor plane, boxes, convex hulls of the
+ * collision meshes), expressed in the frame of the link they ride on (-1: world, -2: the free box).  No colour image.
+ * Frames are those of the last position stage, as mjData.geom_xpos / cam_xpos are. */
+typedef struct rcsh_render_scene_desc {
+  int32_t nshape, nplanes;
+  const int32_t* shape;      /* [nshape] 0 plane (z = 0 of the shape frame, seen from +z), 1 box, 2 convex hull */
+  const int32_t* link;       /* [nshape] */
+  const double* pos;         /* [nshape][3] shape frame in the link frame */
+  const double* rot;         /* [nshape][9] row-major */
+  const double* size;        /* [nshape][3] box half extents */
+  const int32_t* plane_adr;  /* [nshape] hulls: first row of `planes` */
+  const int32_t* plane_num;  /* [nshape] */
+  const double* sphere;      /* [nshape][4] bounding sphere, shape frame: centre, radius (< 0: unbounded) */
+  const double* planes;      /* [nplanes][4] n . x <= d */
+  double znear, zfar;        /* mjModel.vis.map.znear / zfar times mjModel.stat.extent */
+} rcsh_render_scene_desc;
+typedef struct rcsh_camera_desc {
+  int32_t link, width, height;  /* mjModel.cam_bodyid folded to its link; resolution of SimCameraConfig */
+  double pos[3], rot[9];        /* camera frame in the link frame (mjModel.cam_pos / cam_quat) */
+  double fovy_deg;              /* mjModel.cam_fovy */
+} rcsh_camera_desc;
+int rcsh_sim_set_render_scene(rcsh_sim* sim, const rcsh_render_scene_desc* scene);
+int rcsh_sim_add_camera(rcsh_sim* sim, const rcsh_camera_desc* cam, int32_t* cam_id);
+/* One image per environment.  depth_gl: [N][H][W] f32 in [0, 1], rows bottom-up, what mjr_readPixels returns;
+ * depth_mm: [N][H][W] u16, rows top-down, millimetres: DataFrame.data of SimCameraSet(physical_units=True);
+ * cam_pose: [N][12] mjData.cam_xmat (9) + cam_xpos (3).  Each may be NULL.  _dev: device pointers, enqueued on the
+ * handle's stream. */
+int rcsh_camera_render(rcsh_sim* sim, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose);
+int rcsh_camera_render_dev(rcsh_sim* sim, int32_t cam_id, float* depth_gl_dev, uint16_t* depth_mm_dev, double* cam_pose_dev);
+
 /* device allocation helpers so a host language without a HIP binding can keep rollouts resident */
 int rcsh_dev_alloc(rcsh_sim* sim, size_t bytes, void** ptr);
 int rcsh_dev_free(rcsh_sim* sim, void* ptr);

@@ -58,6 +58,8 @@ static void normalize4(double* q) {
 void orc_box_reset(const orc_box* b, orc_box_data* d) {
   memset(d, 0, sizeof(*d));
   memcpy(d->qpos, b->qpos0, sizeof(d->qpos));
+  memcpy(d->xpos, b->qpos0, sizeof(d->xpos));
+  memcpy(d->xquat, b->qpos0 + 3, sizeof(d->xquat));
 }
 
 /* getimpedance() of mj_makeImpedance: impedance at constraint violation |pos - margin| */
@@ -83,6 +85,8 @@ static double impedance(const double* solimp, double x) {
    mj_makeImpedance, mj_referenceConstraint */
 void orc_box_step1(const orc_box* b, orc_box_data* d, double timestep) {
   normalize4(d->qpos + 3);
+  memcpy(d->xpos, d->qpos, sizeof(d->xpos));
+  memcpy(d->xquat, d->qpos + 3, sizeof(d->xquat));
   double R[9];
   quat2mat(d->qpos + 3, R);
   const double* p = d->qpos;

@@ -58,6 +58,7 @@ typedef struct orc_box {
 typedef struct orc_box_data {
   double qpos[7], qvel[6], qacc[6], qacc_warmstart[6];
   double qfrc_smooth[6], qacc_smooth[6];
+  double xpos[3], xquat[4]; /* pose the last position stage saw (mjData.xpos / xquat of the body) */
   int ncon, zone[4]; /* zone: 0 top (separating), 1 middle (sliding), 2 bottom (sticking) */
   double con_dist[4], con_pos[4][3], con_mu[4];
   double J[12][6], aref[12], D[12], R[12], force[12];

@@ -40,7 +40,7 @@ class OrcBox(C.Structure):
 class OrcBoxData(C.Structure):
     _fields_ = [
         ("qpos", D * 7), ("qvel", D * 6), ("qacc", D * 6), ("qacc_warmstart", D * 6),
-        ("qfrc_smooth", D * 6), ("qacc_smooth", D * 6), ("ncon", I), ("zone", I * 4),
+        ("qfrc_smooth", D * 6), ("qacc_smooth", D * 6), ("xpos", D * 3), ("xquat", D * 4), ("ncon", I), ("zone", I * 4),
         ("con_dist", D * 4), ("con_pos", D * 3 * 4), ("con_mu", D * 4),
         ("J", D * 6 * 12), ("aref", D * 12), ("D", D * 12), ("R", D * 12), ("force", D * 12),
         ("newton_iter", I), ("noslip_iter", I),

@@ -39,7 +39,8 @@ struct BoxCfg {
 };
 
 // per-team LDS block: qpos 7, qvel 6, qacc_warmstart 6, then the 12 x 6 contact Jacobian for the noslip pass
-constexpr int kBoxQ = 0, kBoxV = 7, kBoxW = 13, kBoxState = 19, kBoxJ = 20, kBoxLds = kBoxJ + 72;
+// (and the pose the last position stage saw: what the renderer draws)
+constexpr int kBoxQ = 0, kBoxV = 7, kBoxW = 13, kBoxPre = 19, kBoxState = 26, kBoxJ = 26, kBoxLds = kBoxJ + 72;
 
 #if defined(__HIP__)
 
@@ -169,6 +170,12 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
 #pragma unroll
       for (int k = 0; k < 4; ++k) q[k] *= s;
     }
+  }
+  if (t == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bs[kBoxPre + k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bs[kBoxPre + 3 + k] = q[k];
   }
   double R[9];
   {

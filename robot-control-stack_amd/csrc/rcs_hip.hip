@@ -11,6 +11,7 @@
 #include "../../include/rcs_hip.h"
 #include "model_host.h"
 #include "sim_kernels.h"
+#include "render.h"
 
 using namespace rcsh;
 
@@ -64,7 +65,15 @@ struct rcsh_sim {
   BoxCfg box{};
   TaskCfg task{};
   bool env_configured = false;
-  BoxTaskCfg* d_boxtask = nullptr;  // device copy of {box, task} (scenes with a free box)
+  BoxTaskCfg* d_boxtask = nullptr;
+  // depth renderer (render.h)
+  RenderScene rscene{};
+  RenderShape* d_rshapes = nullptr;
+  double* d_rplanes = nullptr;
+  double* d_frames = nullptr;
+  std::vector<RenderCam> cams;
+  void* d_image = nullptr;  // staging for the host-pointer render call
+  size_t image_cap = 0;  // device copy of {box, task} (scenes with a free box)
   double* pending_task = nullptr;  // task output of the env-step being enqueued (rcsh_env_step_task*)
   // staging for the host-pointer entry points
   double* d_stage = nullptr;   // n * 32 doubles
@@ -215,6 +224,7 @@ int field_of(rcsh_sim* s, const char* name) {
     if (f == "origin") return (int)L::ORIGIN;
     if (f == "lasta") return (int)L::LASTA;
     if (f == "box") return (int)L::BOX;
+    if (f == "qpre") return (int)L::QPRE;
     return -1;
   });
 }
@@ -357,6 +367,7 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   {
     std::vector<double> q0 = tile(s->dm.qpos0, s->nl, n_envs);
     int rc = scatter_host(s, field_of(s, "qpos"), s->nl, q0.data(), nullptr);
+    if (!rc) rc = scatter_host(s, field_of(s, "qpre"), s->nl, q0.data(), nullptr);
     if (rc) return cleanup(rc, g_err);
   }
   if (upload_model(s)) return cleanup(RCSH_ERR_DEVICE, g_err);
@@ -372,7 +383,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
-  hipFree(s->d_boxtask);
+  hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_image);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
@@ -458,6 +469,7 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   std::vector<double> z((size_t)s->n * 32, 0.0);
   std::vector<double> q0 = tile(s->dm.qpos0, s->nl, s->n);
   int rc = scatter_host(s, field_of(s, "qpos"), s->nl, q0.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "qpre"), s->nl, q0.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "qvel"), s->nl, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "ctrl"), s->nu, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "time"), 1, z.data(), mask);
@@ -465,7 +477,7 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   if (!rc && s->box.present) {
     std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
     for (int e = 0; e < s->n; ++e)
-      for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = s->box.qpos0[k];
+      for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = b0[(size_t)e * kBoxState + kBoxPre + k] = s->box.qpos0[k];
     rc = scatter_host(s, field_of(s, "box"), kBoxState, b0.data(), mask);
   }
   return rc;
@@ -804,7 +816,7 @@ int rcsh_sim_reset_free_box(rcsh_sim* s) {
   if (!s->box.present) return fail(RCSH_ERR_STATE, "no free box attached: call rcsh_sim_add_free_box first");
   std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
   for (int e = 0; e < s->n; ++e)
-    for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = s->box.qpos0[k];
+    for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = b0[(size_t)e * kBoxState + kBoxPre + k] = s->box.qpos0[k];
   return scatter_host(s, field_of(s, "box"), kBoxState, b0.data(), nullptr);
 }
 #define REQUIRE_BOX(s) \
@@ -1011,6 +1023,111 @@ int rcsh_env_step(rcsh_sim* s, const double* action, const float* gripper, doubl
   if (info) HIP_TRY(hipMemcpyAsync(info, s->d_bytes, (size_t)s->n * 8, hipMemcpyDeviceToHost, s->stream));
   if (gw) HIP_TRY(hipMemcpyAsync(gw, s->d_stage, sizeof(double) * s->n, hipMemcpyDeviceToHost, s->stream));
   if (substeps) HIP_TRY(hipMemcpyAsync(substeps, s->d_ints, sizeof(int32_t) * s->n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+// ---- depth renderer
+int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
+  REQUIRE_SIM(s);
+  if (!d || d->nshape < 1 || d->nshape > kMaxShapes) return fail(RCSH_ERR_ARG, "render scene: between 1 and 32 shapes");
+  if (!(d->znear > 0) || !(d->zfar > d->znear)) return fail(RCSH_ERR_ARG, "render scene: need 0 < znear < zfar");
+  std::vector<RenderShape> sh(d->nshape);
+  for (int i = 0; i < d->nshape; ++i) {
+    RenderShape& r = sh[i];
+    r.shape = d->shape[i]; r.link = d->link[i]; r.plane_adr = d->plane_adr[i]; r.plane_num = d->plane_num[i];
+    if (r.shape < kShapePlane || r.shape > kShapeHull) return fail(RCSH_ERR_ARG, "render scene: unknown shape type");
+    if (r.link < kLinkFreeBody || r.link >= s->nl) return fail(RCSH_ERR_ARG, "render scene: link index out of range");
+    if (r.link == kLinkFreeBody && !s->box.present) return fail(RCSH_ERR_STATE, "render scene: no free box attached");
+    if (r.shape == kShapeHull && (r.plane_adr < 0 || r.plane_num < 4 || r.plane_adr + r.plane_num > d->nplanes))
+      return fail(RCSH_ERR_ARG, "render scene: hull plane range out of bounds");
+    for (int k = 0; k < 3; ++k) { r.pos[k] = d->pos[3 * i + k]; r.size[k] = d->size[3 * i + k]; }
+    for (int k = 0; k < 9; ++k) r.rot[k] = d->rot[9 * i + k];
+    for (int k = 0; k < 4; ++k) r.sphere[k] = d->sphere[4 * i + k];
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames);
+  s->d_rshapes = nullptr; s->d_rplanes = nullptr; s->d_frames = nullptr;
+  const int np = d->nplanes > 0 ? d->nplanes : 1;
+  HIP_TRY(hipMalloc(&s->d_rshapes, sizeof(RenderShape) * d->nshape));
+  HIP_TRY(hipMalloc(&s->d_rplanes, sizeof(double) * 4 * np));
+  HIP_TRY(hipMalloc(&s->d_frames, sizeof(double) * 12 * (size_t)(s->nl + 1) * s->n));
+  HIP_TRY(hipMemcpyAsync(s->d_rshapes, sh.data(), sizeof(RenderShape) * d->nshape, hipMemcpyHostToDevice, s->stream));
+  if (d->nplanes > 0) HIP_TRY(hipMemcpyAsync(s->d_rplanes, d->planes, sizeof(double) * 4 * d->nplanes, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->rscene.nshape = d->nshape; s->rscene.nframes = s->nl + 1;
+  s->rscene.znear = d->znear; s->rscene.zfar = d->zfar;
+  s->rscene.shapes = s->d_rshapes; s->rscene.planes = s->d_rplanes;
+  return RCSH_OK;
+}
+
+int rcsh_sim_add_camera(rcsh_sim* s, const rcsh_camera_desc* c, int32_t* cam_id) {
+  REQUIRE_SIM(s);
+  if (!c || !cam_id) return fail(RCSH_ERR_ARG, "null camera description");
+  if (c->width < 1 || c->height < 1 || !(c->fovy_deg > 0 && c->fovy_deg < 180)) return fail(RCSH_ERR_ARG, "camera: bad resolution or field of view");
+  if (c->link < kLinkFreeBody || c->link >= s->nl) return fail(RCSH_ERR_ARG, "camera: link index out of range");
+  RenderCam rc{};
+  rc.link = c->link; rc.width = c->width; rc.height = c->height;
+  for (int k = 0; k < 3; ++k) rc.pos[k] = c->pos[k];
+  for (int k = 0; k < 9; ++k) rc.rot[k] = c->rot[k];
+  rc.tan_half_fovy = std::tan(c->fovy_deg * 3.14159265358979323846 / 360.0);
+  s->cams.push_back(rc);
+  *cam_id = (int32_t)s->cams.size() - 1;
+  return RCSH_OK;
+}
+
+int rcsh_camera_render_dev(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
+  REQUIRE_SIM(s);
+  if (!s->d_frames) return fail(RCSH_ERR_STATE, "no render scene: call rcsh_sim_set_render_scene first");
+  if (cam_id < 0 || cam_id >= (int)s->cams.size()) return fail(RCSH_ERR_ARG, "unknown camera id");
+  HIP_TRY(hipSetDevice(s->device));
+  const RenderCam& cam = s->cams[cam_id];
+  hipError_t err = hipSuccess;
+  bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
+    using T = decltype(topo);
+    hipLaunchKernelGGL((k_link_frames<T>), dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, s->d_model, s->S, s->n,
+                       (int)Lay<T>::QPRE, (int)Lay<T>::BOX, (int)s->box.present, s->d_frames);
+    err = hipGetLastError();
+  });
+  if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
+  if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_link_frames launch: ") + hipGetErrorString(err));
+  const int blocks_per_env = (cam.width * cam.height + 255) / 256;
+  hipLaunchKernelGGL(k_render_depth, dim3((unsigned)blocks_per_env * (unsigned)s->n), dim3(256), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
+                     depth_gl, depth_mm, cam_pose);
+  err = hipGetLastError();
+  if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_render_depth launch: ") + hipGetErrorString(err));
+  return RCSH_OK;
+}
+
+int rcsh_camera_render(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
+  REQUIRE_SIM(s);
+  if (cam_id < 0 || cam_id >= (int)s->cams.size()) return fail(RCSH_ERR_ARG, "unknown camera id");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t px = (size_t)s->n * s->cams[cam_id].width * s->cams[cam_id].height;
+  const size_t need = px * (sizeof(float) + sizeof(uint16_t)) + sizeof(double) * 12 * s->n;
+  if (need > s->image_cap) {
+    hipFree(s->d_image);
+    s->d_image = nullptr; s->image_cap = 0;
+    HIP_TRY(hipMalloc(&s->d_image, need));
+    s->image_cap = need;
+  }
+  float* dgl = static_cast<float*>(s->d_image);
+  uint16_t* dmm = reinterpret_cast<uint16_t*>(dgl + px);
+  double* dpose = reinterpret_cast<double*>(static_cast<char*>(s->d_image) + ((px * (sizeof(float) + sizeof(uint16_t)) + 7) / 8) * 8);
+  if (need + 8 > s->image_cap) {  // room for the alignment of the pose block
+    hipFree(s->d_image);
+    s->d_image = nullptr; s->image_cap = 0;
+    HIP_TRY(hipMalloc(&s->d_image, need + 8));
+    s->image_cap = need + 8;
+    dgl = static_cast<float*>(s->d_image);
+    dmm = reinterpret_cast<uint16_t*>(dgl + px);
+    dpose = reinterpret_cast<double*>(static_cast<char*>(s->d_image) + ((px * (sizeof(float) + sizeof(uint16_t)) + 7) / 8) * 8);
+  }
+  int rc = rcsh_camera_render_dev(s, cam_id, depth_gl ? dgl : nullptr, depth_mm ? dmm : nullptr, cam_pose ? dpose : nullptr);
+  if (rc) return rc;
+  if (depth_gl) HIP_TRY(hipMemcpyAsync(depth_gl, dgl, px * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  if (depth_mm) HIP_TRY(hipMemcpyAsync(depth_mm, dmm, px * sizeof(uint16_t), hipMemcpyDeviceToHost, s->stream));
+  if (cam_pose) HIP_TRY(hipMemcpyAsync(cam_pose, dpose, sizeof(double) * 12 * s->n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
 }

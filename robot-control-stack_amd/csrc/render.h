@@ -1,0 +1,229 @@
+// render.h -- depth images of the batched scenes by ray casting: the counterpart of the reference's SimCameraSet
+// pixel path (src/sim/camera.cpp:86-140: mjv_updateScene + mjr_render + mjr_readPixels on MuJoCo's OpenGL context).
+//
+// What is kept from the reference: the pinhole camera of MuJoCo (vertical field of view `fovy`, looking down -z, +y
+// up; pixel centres on the viewport's grid), the frames of the LAST position stage (mjv_updateScene reads mjData.xpos /
+// geom_xpos / cam_xpos, i.e. kinematics of the qpos the last mj_step1 saw), the OpenGL depth encoding
+// d = (1/near - 1/z) / (1/near - 1/far) in [0, 1] as float32 with near / far = vis.map.znear / zfar times
+// stat.extent, the bottom-up row order of glReadPixels, and the conversion the Python layer applies
+// (python/rcs/camera/sim.py:57-86: row flip, z = near / (1 - d (1 - near / far)) in float32, x 1000, uint16).
+// What differs: the pixels come from one ray per pixel against analytic shapes -- the floor plane, boxes, the convex
+// hulls of the robot's collision meshes (rcs_amd/render.py) -- not from a rasteriser over the visual meshes, and there
+// is no colour image.
+//
+// Two kernels: k_link_frames (one thread per environment: forward kinematics of the stored pre-step qpos, frames of
+// all links and of the free box to HBM, 12 doubles each) and k_render_depth (one thread per pixel, 256 pixels of one
+// environment per workgroup; the environment's shape frames are composed once per workgroup into LDS; per ray a
+// bounding-sphere test per shape, then slabs / hull planes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "box_team.h"
+#include "dyn.h"
+#include "model.h"
+
+namespace rcsh {
+
+constexpr int kMaxShapes = 32;
+enum : int32_t { kShapePlane = 0, kShapeBox = 1, kShapeHull = 2 };
+enum : int32_t { kLinkWorld = -1, kLinkFreeBody = -2 };
+
+struct RenderShape {
+  int32_t shape, link, plane_adr, plane_num;
+  double pos[3], rot[9];  // shape frame in its link's frame
+  double size[3];
+  double sphere[4];       // bounding sphere: centre (shape frame), radius (< 0: unbounded)
+};
+struct RenderCam {
+  int32_t link, width, height, pad;
+  double pos[3], rot[9];  // camera frame in its link's frame
+  double tan_half_fovy;
+};
+struct RenderScene {
+  int32_t nshape, nframes;  // nframes = links + 1 (the last entry is the free box, identity if the scene has none)
+  double znear, zfar;
+  const RenderShape* shapes;
+  const double* planes;  // [.][4] n . x <= d
+};
+
+#if defined(__HIP__)
+
+// frames[e][i] = R(9) p(3) of link i for the qpos the last position stage saw; entry nl: the free box
+template <class T>
+__global__ void k_link_frames(const DevModel* gm, const double* S, int n, int qpre_field, int box_field, int has_box, double* frames) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const DevModel& m = *gm;
+  double* out = frames + (size_t)e * (T::NL + 1) * 12;
+  double Ra[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pa[3] = {0, 0, 0};  // frame of the arm link processed last
+  for (int i = 0; i < T::NL; ++i) {
+    // parent: the previous arm link; both fingers hang off the last arm link (Ra / pa stop advancing there)
+    const double q = S[(size_t)(qpre_field + i) * n + e] - m.qpos0[i];
+    double o[3], R0[9], R[9], p[3];
+    mulmv(Ra, m.pos0[i], o);
+    o[0] += pa[0]; o[1] += pa[1]; o[2] += pa[2];
+    mulmm(Ra, m.rot0[i], R0);
+    if (m.jtype[i] == kHinge) {
+      double s, c;
+      fast_sincos(q, &s, &c);
+      const double* u = m.axis[i];
+      const double t = 1.0 - c;
+      const double Q[9] = {c + t * u[0] * u[0],        t * u[0] * u[1] - s * u[2], t * u[0] * u[2] + s * u[1],
+                           t * u[0] * u[1] + s * u[2], c + t * u[1] * u[1],        t * u[1] * u[2] - s * u[0],
+                           t * u[0] * u[2] - s * u[1], t * u[1] * u[2] + s * u[0], c + t * u[2] * u[2]};
+      double an[3], rj[3];
+      mulmv(R0, m.jpos[i], an);
+      mulmm(R0, Q, R);
+      mulmv(R, m.jpos[i], rj);
+      for (int k = 0; k < 3; ++k) p[k] = an[k] + o[k] - rj[k];
+    } else {
+      double a[3];
+      mulmv(R0, m.axis[i], a);
+      for (int k = 0; k < 9; ++k) R[k] = R0[k];
+      for (int k = 0; k < 3; ++k) p[k] = o[k] + q * a[k];
+    }
+    for (int k = 0; k < 9; ++k) out[12 * i + k] = R[k];
+    for (int k = 0; k < 3; ++k) out[12 * i + 9 + k] = p[k];
+    if (i < T::NARM) {
+      for (int k = 0; k < 9; ++k) Ra[k] = R[k];
+      for (int k = 0; k < 3; ++k) pa[k] = p[k];
+    }
+  }
+  double* b = out + 12 * T::NL;
+  if (has_box) {
+    const double w = S[(size_t)(box_field + kBoxPre + 3) * n + e], x = S[(size_t)(box_field + kBoxPre + 4) * n + e],
+                 y = S[(size_t)(box_field + kBoxPre + 5) * n + e], z = S[(size_t)(box_field + kBoxPre + 6) * n + e];
+    b[0] = w * w + x * x - y * y - z * z; b[4] = w * w - x * x + y * y - z * z; b[8] = w * w - x * x - y * y + z * z;
+    b[1] = 2 * (x * y - w * z); b[2] = 2 * (x * z + w * y); b[3] = 2 * (x * y + w * z);
+    b[5] = 2 * (y * z - w * x); b[6] = 2 * (x * z - w * y); b[7] = 2 * (y * z + w * x);
+    for (int k = 0; k < 3; ++k) b[9 + k] = S[(size_t)(box_field + kBoxPre + k) * n + e];
+  } else {
+    for (int k = 0; k < 12; ++k) b[k] = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+  }
+}
+
+// world frame of something given in a link's frame
+__device__ __forceinline__ void in_world(const double* frames, int link, int nframes, const double* pos, const double* rot, double* R, double* p) {
+  if (link == kLinkWorld) {
+    for (int k = 0; k < 9; ++k) R[k] = rot[k];
+    for (int k = 0; k < 3; ++k) p[k] = pos[k];
+    return;
+  }
+  const double* f = frames + 12 * (link == kLinkFreeBody ? nframes - 1 : link);
+  mulmm(f, rot, R);
+  mulmv(f, pos, p);
+  p[0] += f[9]; p[1] += f[10]; p[2] += f[11];
+}
+
+// depth_gl: [n][H][W] float32 in [0, 1], rows bottom-up (mjr_readPixels); depth_mm: [n][H][W] uint16, rows top-down,
+// millimetres (SimCameraSet with physical_units); cam_pose: [n][12] world rotation (9) and position (3) of the camera
+// (mjData.cam_xmat / cam_xpos).  Any of the three may be null.
+__global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam cam, const double* frames, int n, float* depth_gl,
+                                                      uint16_t* depth_mm, double* cam_pose) {
+  __shared__ double wR[kMaxShapes][9], wp[kMaxShapes][3], wc[kMaxShapes][4], cR[9], cp[3];
+  const int W = cam.width, H = cam.height;
+  const int blocks_per_env = (W * H + 255) / 256;
+  const int e = blockIdx.x / blocks_per_env;
+  const int pix = (blockIdx.x % blocks_per_env) * 256 + threadIdx.x;
+  const double* fe = frames + (size_t)e * sc.nframes * 12;
+  if (threadIdx.x < sc.nshape) {
+    const RenderShape& sh = sc.shapes[threadIdx.x];
+    double R[9], p[3];
+    in_world(fe, sh.link, sc.nframes, sh.pos, sh.rot, R, p);
+    for (int k = 0; k < 9; ++k) wR[threadIdx.x][k] = R[k];
+    for (int k = 0; k < 3; ++k) wp[threadIdx.x][k] = p[k];
+    double c[3];
+    mulmv(R, sh.sphere, c);
+    for (int k = 0; k < 3; ++k) wc[threadIdx.x][k] = c[k] + p[k];
+    wc[threadIdx.x][3] = sh.sphere[3];
+  }
+  if (threadIdx.x == 64) {
+    double R[9], p[3];
+    in_world(fe, cam.link, sc.nframes, cam.pos, cam.rot, R, p);
+    for (int k = 0; k < 9; ++k) cR[k] = R[k];
+    for (int k = 0; k < 3; ++k) cp[k] = p[k];
+    if (cam_pose && blockIdx.x % blocks_per_env == 0) {
+      for (int k = 0; k < 9; ++k) cam_pose[(size_t)e * 12 + k] = R[k];
+      for (int k = 0; k < 3; ++k) cam_pose[(size_t)e * 12 + 9 + k] = p[k];
+    }
+  }
+  __syncthreads();
+  if (pix >= W * H) return;
+  const int row = pix / W, col = pix % W;  // row 0 = bottom of the image (OpenGL window coordinates)
+  // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
+  const double ty = cam.tan_half_fovy, tx = ty * (double)W / (double)H;
+  const double dc[3] = {(2.0 * (col + 0.5) / W - 1.0) * tx, (2.0 * (row + 0.5) / H - 1.0) * ty, -1.0};
+  double d[3];
+  mulmv(cR, dc, d);
+  const double o[3] = {cp[0], cp[1], cp[2]};
+  const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  double best = sc.zfar;
+  bool hit = false;
+  for (int g = 0; g < sc.nshape; ++g) {
+    const RenderShape& sh = sc.shapes[g];
+    if (wc[g][3] >= 0) {
+      // bounding sphere: closest approach of the ray to the centre
+      const double oc[3] = {wc[g][0] - o[0], wc[g][1] - o[1], wc[g][2] - o[2]};
+      const double b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
+      const double c2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
+      if (c2 * dd - b * b > wc[g][3] * wc[g][3] * dd) continue;
+    }
+    // ray in the shape's frame
+    const double* R = wR[g];
+    const double om[3] = {o[0] - wp[g][0], o[1] - wp[g][1], o[2] - wp[g][2]};
+    const double lo[3] = {R[0] * om[0] + R[3] * om[1] + R[6] * om[2], R[1] * om[0] + R[4] * om[1] + R[7] * om[2], R[2] * om[0] + R[5] * om[1] + R[8] * om[2]};
+    const double ld[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2], R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
+    double t0 = sc.znear, t1 = best;
+    if (sh.shape == kShapePlane) {
+      // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
+      if (!(ld[2] < 0 && lo[2] > 0)) continue;
+      const double t = -lo[2] / ld[2];
+      if (t >= t0 && t < t1) { best = t; hit = true; }
+      continue;
+    }
+    bool ok = true;
+    if (sh.shape == kShapeBox) {
+      for (int k = 0; k < 3 && ok; ++k) {
+        if (ld[k] == 0) { ok = fabs(lo[k]) <= sh.size[k]; continue; }
+        const double inv = 1.0 / ld[k];
+        double ta = (-sh.size[k] - lo[k]) * inv, tb = (sh.size[k] - lo[k]) * inv;
+        if (ta > tb) { const double x = ta; ta = tb; tb = x; }
+        t0 = ta > t0 ? ta : t0;
+        t1 = tb < t1 ? tb : t1;
+        ok = t0 <= t1;
+      }
+    } else {
+      const double* pl = sc.planes + 4 * (size_t)sh.plane_adr;
+      for (int k = 0; k < sh.plane_num && ok; ++k, pl += 4) {
+        const double nd = pl[0] * ld[0] + pl[1] * ld[1] + pl[2] * ld[2];
+        const double no = pl[3] - (pl[0] * lo[0] + pl[1] * lo[1] + pl[2] * lo[2]);  // >= 0: origin inside this half space
+        if (nd == 0) { ok = no >= 0; continue; }
+        const double t = no / nd;
+        if (nd < 0) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
+        ok = t0 <= t1;
+      }
+    }
+    // a camera inside a shape sees its inside faces culled (back faces): only entry points count
+    if (ok && t0 > sc.znear && t0 < best) { best = t0; hit = true; }
+  }
+  const double inv_near = 1.0 / sc.znear, inv_far = 1.0 / sc.zfar;
+  const float dgl = hit ? (float)((inv_near - 1.0 / best) / (inv_near - inv_far)) : 1.0f;
+  const size_t img = (size_t)e * W * H;
+  if (depth_gl) depth_gl[img + (size_t)row * W + col] = dgl;
+  if (depth_mm) {
+    // python/rcs/camera/sim.py:74-86 in float32: z = near / (1 - d (1 - near / far)); uint16(z * 1000)
+#pragma clang fp contract(off)  // numpy rounds the product before the subtraction: no fused multiply-add here
+    const float nearf = (float)sc.znear;
+    const float k1 = (float)(1.0 - sc.znear / sc.zfar);
+    const float prod = dgl * k1;
+    const float z = nearf / (1.0f - prod);
+    const float mm = z * 1000.0f;
+    depth_mm[img + (size_t)(H - 1 - row) * W + col] = (uint16_t)mm;
+  }
+}
+
+#endif  // __HIP__
+
+}  // namespace rcsh

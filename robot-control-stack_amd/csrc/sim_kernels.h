@@ -74,8 +74,9 @@ struct Lay {
   static constexpr int PREVA = SITE + 12;        // RobotEnv.prev_action (7 wide: joints or tquat)
   static constexpr int ORIGIN = PREVA + 7;       // RelativeActionSpace._origin
   static constexpr int LASTA = ORIGIN + 7;       // RelativeActionSpace._last_action
-  static constexpr int BOX = LASTA + 7;           // free box (box_team.h): qpos 7, qvel 6, qacc_warmstart 6
-  static constexpr int COUNT = BOX + kBoxState;
+  static constexpr int BOX = LASTA + 7;           // free box (box_team.h): qpos 7, qvel 6, qacc_warmstart 6, pose seen by the last position stage 7
+  static constexpr int QPRE = BOX + kBoxState;    // qpos seen by the last mj_step1 (what mjData.xpos / geom_xpos / cam_xpos derive from: the renderer's frames)
+  static constexpr int COUNT = QPRE + T::NL;
 };
 
 // PickCubeSuccessWrapper (reference python/rcs/envs/sim.py:386-431)
@@ -150,7 +151,7 @@ __device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T, ST>&
   const int n = P.n;
   const double* S = P.S;
 #pragma unroll
-  for (int i = 0; i < T::NL; ++i) { r.st.q(i) = S[(L::QPOS + i) * n + e]; r.st.v(i) = S[(L::QVEL + i) * n + e]; }
+  for (int i = 0; i < T::NL; ++i) { r.st.q(i) = S[(L::QPOS + i) * n + e]; r.st.v(i) = S[(L::QVEL + i) * n + e]; r.st.qpre(i) = S[(L::QPRE + i) * n + e]; }
 #pragma unroll
   for (int i = 0; i < T::NU; ++i) r.st.c(i) = S[(L::CTRL + i) * n + e];
   r.time = S[L::TIME * n + e];
@@ -173,7 +174,7 @@ __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<
   double* S = P.S;
   if constexpr (kStaged) {
 #pragma unroll
-    for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.st.q(i); S[(L::QVEL + i) * n + e] = r.st.v(i); }
+    for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.st.q(i); S[(L::QVEL + i) * n + e] = r.st.v(i); S[(L::QPRE + i) * n + e] = r.st.qpre(i); }
 #pragma unroll
     for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.st.c(i);
 #pragma unroll
@@ -194,7 +195,7 @@ __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<
 template <class T, class ST>
 struct TeamStagedFields {
   using L = Lay<T>;
-  static constexpr int kCount = 2 * T::NL + T::NU + 6 + 2 * T::NARM;
+  static constexpr int kCount = 3 * T::NL + T::NU + 6 + 2 * T::NARM;
   static constexpr int kRounds = (kCount + kTeamLanes - 1) / kTeamLanes;
   __device__ __forceinline__ static void locate(int k, int& field, int& slot) {
     if (k < T::NL) { field = L::QPOS + k; slot = ST::Q0 + k; return; }
@@ -207,7 +208,9 @@ struct TeamStagedFields {
     k -= 6;
     if (k < T::NARM) { field = L::PREVQ + k; slot = ST::X0 + 6 + k; return; }
     k -= T::NARM;
-    field = L::TARGET + k; slot = ST::X0 + 6 + T::NARM + k;
+    if (k < T::NARM) { field = L::TARGET + k; slot = ST::X0 + 6 + T::NARM + k; return; }
+    k -= T::NARM;
+    field = L::QPRE + k; slot = ST::P0 + k;
   }
 };
 
@@ -780,7 +783,8 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     if (live) {
       using L = Lay<T>;
       for (int k = t; k < kBoxState; k += kTeamLanes)
-        bs[k] = op.do_reset ? (k < 7 ? lbt[0].box.qpos0[k] : 0.0) : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
+        bs[k] = op.do_reset ? (k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre ? lbt[0].box.qpos0[k - kBoxPre] : 0.0))
+                            : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
     }
   }
   bool have_frames_box = false;  // the first substep of this launch is done (placement of the box on reset)

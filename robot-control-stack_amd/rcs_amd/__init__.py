@@ -9,7 +9,7 @@ from __future__ import annotations
 import os
 from dataclasses import dataclass
 
-from . import _lib, common, mjcf, sim  # noqa: F401
+from . import _lib, camera, common, mjcf, render, sim  # noqa: F401
 from . import envs  # noqa: F401,E402
 
 __version__ = "0.1.0"
@@ -40,4 +40,4 @@ scenes: dict[str, Scene] = {
     "xarm7_empty_world": _scene("xarm7_empty_world", common.RobotType.XArm7),
 }
 
-__all__ = ["__version__", "common", "sim", "envs", "scenes", "mjcf"]
+__all__ = ["__version__", "common", "sim", "envs", "scenes", "mjcf", "camera", "render"]

@@ -84,6 +84,19 @@ def make_free_box_desc(cm) -> FreeBoxDesc | None:
     return d
 
 
+class RenderSceneDesc(C.Structure):
+    _fields_ = [
+        ("nshape", C.c_int32), ("nplanes", C.c_int32), ("shape", _I32P), ("link", _I32P), ("pos", _F64P), ("rot", _F64P),
+        ("size", _F64P), ("plane_adr", _I32P), ("plane_num", _I32P), ("sphere", _F64P), ("planes", _F64P),
+        ("znear", C.c_double), ("zfar", C.c_double),
+    ]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("link", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("pos", C.c_double * 3), ("rot", C.c_double * 9),
+                ("fovy_deg", C.c_double)]
+
+
 class PickTaskDesc(C.Structure):
     _fields_ = [("ee_home", C.c_double * 3), ("success_height", C.c_double)]
 
@@ -130,6 +143,7 @@ EXPORTS = (
     "rcsh_sim_set_qvel", "rcsh_sim_add_free_box", "rcsh_sim_reset_free_box", "rcsh_sim_get_free_qpos", "rcsh_sim_get_free_qvel",
     "rcsh_sim_set_free_qpos", "rcsh_sim_set_free_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
+    "rcsh_sim_set_render_scene", "rcsh_sim_add_camera", "rcsh_camera_render", "rcsh_camera_render_dev",
     "rcsh_env_configure_pick_task", "rcsh_env_reset_task", "rcsh_env_step_task", "rcsh_env_reset_task_dev", "rcsh_env_step_task_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
@@ -168,6 +182,10 @@ def load() -> C.CDLL:
         fn.argtypes = [C.c_void_p, C.c_void_p]
     for fn in (L.rcsh_sim_set_free_qpos, L.rcsh_sim_set_free_qvel):
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rcsh_sim_set_render_scene.argtypes = [C.c_void_p, C.POINTER(RenderSceneDesc)]
+    L.rcsh_sim_add_camera.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(C.c_int32)]
+    L.rcsh_camera_render.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rcsh_camera_render_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_env_configure_pick_task.argtypes = [C.c_void_p, C.POINTER(PickTaskDesc)]
     L.rcsh_env_reset_task.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.rcsh_env_step_task.argtypes = [C.c_void_p] + [C.c_void_p] * 7

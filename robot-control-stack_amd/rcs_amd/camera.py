@@ -1,0 +1,215 @@
+"""``SimCameraSet`` for N environments: depth images by ray casting (reference src/sim/camera.cpp,
+python/rcs/camera/sim.py, python/rcs/camera/interface.py).
+
+Kept from the reference: the configuration type, the frame-set buffer with its timestamp rule (frames rendered at the
+same simulation time share one frame set; ``clear_buffer`` forgets the last timestamp), render-on-demand,
+the conversion of the depth buffer (row flip, metres with ``physical_units``, ``DEPTH_SCALE``, uint16), intrinsics and
+extrinsics.  Different: the pixels are ray-cast against analytic shapes (``rcs_amd/render.py``), there is no colour image
+(``DataFrame.data`` of ``color`` is ``None``), ``render_on_demand=False`` (rendering from inside ``Sim.step`` at the
+cameras' frame rate) is not built, and the buffer keeps the last ``max_framesets`` frame sets instead of growing until
+the next reset (one frame set of 4096 environments at 256 x 256 is 0.5 GB).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from enum import IntEnum
+from typing import Any
+
+import numpy as np
+
+from . import _lib, common, render
+from . import sim as _sim
+
+
+class CameraType(IntEnum):  # src/sim/camera.h:19-24
+    free = 0
+    tracking = 1
+    fixed = 2
+    default_free = 3
+
+
+@dataclass(kw_only=True)
+class SimCameraConfig:  # src/sim/camera.h:26-34, common::BaseCameraConfig
+    identifier: str
+    frame_rate: int = 0
+    resolution_width: int = 256
+    resolution_height: int = 256
+    type: CameraType = CameraType.fixed
+
+
+@dataclass(kw_only=True)
+class DataFrame:  # python/rcs/camera/interface.py:14-20
+    data: Any
+    timestamp: Any = None
+    intrinsics: np.ndarray | None = None
+    extrinsics: np.ndarray | None = None
+
+
+@dataclass(kw_only=True)
+class CameraFrame:
+    color: DataFrame
+    ir: DataFrame | None = None
+    depth: DataFrame | None = None
+    temperature: float | None = None
+
+
+@dataclass(kw_only=True)
+class Frame:
+    camera: CameraFrame
+    imu: Any = None
+    avg_timestamp: Any = None
+
+
+@dataclass(kw_only=True)
+class FrameSet:
+    frames: dict[str, Frame]
+    avg_timestamp: Any
+
+
+class SimCameraSet:
+    DEPTH_SCALE: int = 1000  # BaseCameraSet.DEPTH_SCALE
+
+    def __init__(self, simulation: _sim.Sim, cameras: dict[str, SimCameraConfig], physical_units: bool = False,
+                 render_on_demand: bool = True, max_framesets: int = 2):
+        if not render_on_demand:
+            raise NotImplementedError("rendering from inside Sim.step at the cameras' frame rate is not built: use render_on_demand=True")
+        self._sim = simulation
+        self.cameras = cameras
+        self.physical_units = physical_units
+        self.render_on_demand = render_on_demand
+        self.max_framesets = max_framesets
+        self._L = simulation._L
+        cm = simulation.model
+        self._scene = render.build_render_scene(cm, os.path.dirname(simulation.scene_path))
+        rs = self._scene
+        d = _lib.RenderSceneDesc()
+        d.nshape, d.nplanes, d.znear, d.zfar = len(rs.shape), len(rs.planes), rs.znear, rs.zfar
+        self._keep = []
+        for name in ("shape", "link", "pos", "rot", "size", "plane_adr", "plane_num", "sphere", "planes"):
+            a = np.ascontiguousarray(getattr(rs, name)).reshape(-1)
+            self._keep.append(a)
+            setattr(d, name, a.ctypes.data_as(_lib._I32P if a.dtype == np.int32 else _lib._F64P))
+        _lib.check(self._L.rcsh_sim_set_render_scene(simulation._h, C.byref(d)))
+        self._ids: dict[str, int] = {}
+        self._fovy: dict[str, float] = {}
+        for name, cfg in cameras.items():
+            if cfg.type != CameraType.fixed:
+                raise NotImplementedError("only fixed cameras (named MJCF cameras) are built")
+            link, pos, rot, fovy = render.camera_in_link(cm, cfg.identifier)
+            c = _lib.CameraDesc()
+            c.link, c.width, c.height, c.fovy_deg = link, cfg.resolution_width, cfg.resolution_height, fovy
+            c.pos[:] = [float(x) for x in pos]
+            c.rot[:] = [float(x) for x in rot]
+            cid = C.c_int32(-1)
+            _lib.check(self._L.rcsh_sim_add_camera(simulation._h, C.byref(c), C.byref(cid)))
+            self._ids[name] = cid.value
+            self._fovy[name] = fovy
+        self._buffer: list[dict] = []
+        self._last_ts = None
+
+    # ---- SimCameraSet (src/sim/camera.cpp:54-83)
+    def buffer_size(self) -> int:
+        return len(self._buffer)
+
+    def clear_buffer(self) -> None:
+        self._last_ts = None  # "when we clear the buffer, there is no last image timestep"
+        self._buffer.clear()
+
+    def render_raw(self, name: str):
+        """(depth buffer [N,H,W] f32 rows bottom-up as mjr_readPixels returns it, cam_xmat [N,3,3], cam_xpos [N,3])."""
+        cfg = self.cameras[name]
+        n = self._sim.n_envs
+        depth = np.zeros((n, cfg.resolution_height, cfg.resolution_width), dtype=np.float32)
+        pose = np.zeros((n, 12))
+        _lib.check(self._L.rcsh_camera_render(self._sim._h, self._ids[name], _lib.ptr(depth), None, _lib.ptr(pose)))
+        return depth, pose[:, :9].reshape(n, 3, 3), pose[:, 9:]
+
+    def render_depth_mm(self, name: str) -> np.ndarray:
+        """The fused device path: [N,H,W] uint16 millimetres, rows top-down (physical units)."""
+        cfg = self.cameras[name]
+        out = np.zeros((self._sim.n_envs, cfg.resolution_height, cfg.resolution_width), dtype=np.uint16)
+        _lib.check(self._L.rcsh_camera_render(self._sim._h, self._ids[name], None, _lib.ptr(out), None))
+        return out
+
+    def render_depth_mm_dev(self, name: str, out_ptr: int) -> None:
+        _lib.check(self._L.rcsh_camera_render_dev(self._sim._h, self._ids[name], None, C.c_void_p(out_ptr), None))
+
+    def _render_all(self) -> None:  # render_all + render_single (camera.cpp:86-140)
+        ts = self._sim.time
+        same = self._last_ts is not None and np.array_equal(ts, self._last_ts)
+        if not same:
+            self._buffer.append({"timestamp": ts, "depth": {}, "pose": {}})
+            del self._buffer[: max(0, len(self._buffer) - self.max_framesets)]
+            self._last_ts = ts
+        fs = self._buffer[-1]
+        for name in self.cameras:
+            depth, xmat, xpos = self.render_raw(name)
+            fs["depth"][name] = depth
+            fs["pose"][name] = (xmat, xpos)
+
+    def get_latest_frames(self) -> FrameSet | None:
+        if self.render_on_demand:
+            self._render_all()
+        if not self._buffer:
+            return None
+        return self._to_frames(self._buffer[-1])
+
+    def get_timestamp_frames(self, ts) -> FrameSet | None:
+        for fs in reversed(self._buffer):
+            if np.array_equal(fs["timestamp"], ts):
+                return self._to_frames(fs)
+        return None
+
+    # ---- python/rcs/camera/sim.py:45-115
+    def _to_frames(self, fs: dict) -> FrameSet:
+        frames: dict[str, Frame] = {}
+        for name, raw in fs["depth"].items():
+            depth = raw[:, ::-1, :, None]  # glReadPixels rows are bottom-up
+            if self.physical_units:
+                near, far = self._scene.znear, self._scene.zfar
+                depth = near / (1 - depth * (1 - near / far))
+            xmat, xpos = fs["pose"][name]
+            frames[name] = Frame(
+                camera=CameraFrame(
+                    color=DataFrame(data=None, timestamp=fs["timestamp"], intrinsics=self._intrinsics(name), extrinsics=self._extrinsics(xmat, xpos)),
+                    depth=DataFrame(data=(depth * self.DEPTH_SCALE).astype(np.uint16), timestamp=fs["timestamp"],
+                                    intrinsics=self._intrinsics(name), extrinsics=self._extrinsics(xmat, xpos)),
+                ),
+                avg_timestamp=fs["timestamp"],
+            )
+        return FrameSet(frames=frames, avg_timestamp=fs["timestamp"])
+
+    def _intrinsics(self, camera_name: str) -> np.ndarray:
+        cfg = self.cameras[camera_name]
+        fx = fy = 0.5 * cfg.resolution_height / np.tan(self._fovy[camera_name] * np.pi / 360)
+        return np.array([[fx, 0, (cfg.resolution_width - 1) / 2, 0], [0, fy, (cfg.resolution_height - 1) / 2, 0], [0, 0, 1, 0]])
+
+    @staticmethod
+    def _extrinsics(xmat: np.ndarray, xpos: np.ndarray) -> np.ndarray:
+        """[N,4,4]: inverse of (camera pose * a half turn about x that puts the z axis in front)."""
+        flip = common.Pose(rpy_vector=np.array([np.pi, 0, 0]), translation=np.zeros(3))
+        out = np.zeros((len(xpos), 4, 4))
+        for e in range(len(xpos)):
+            cam = common.Pose(rotation=xmat[e], translation=xpos[e]) * flip
+            out[e] = cam.inverse().pose_matrix()
+        return out
+
+    def calibrate(self) -> bool:
+        return True
+
+    def config(self, camera_name: str) -> SimCameraConfig:
+        return self.cameras[camera_name]
+
+    def close(self) -> None:
+        pass
+
+    @property
+    def camera_names(self) -> list[str]:
+        return list(self.cameras.keys())
+
+    @property
+    def name_to_identifier(self) -> dict[str, str]:
+        return {name: cfg.identifier for name, cfg in self.cameras.items()}

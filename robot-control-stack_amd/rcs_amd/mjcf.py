@@ -193,6 +193,11 @@ class Model:
     cone: str = "pyramidal"
     impratio: float = 1.0
     noslip_iterations: int = 0
+    # rendering: mjModel.stat.extent (None: not given -- MuJoCo would derive it from the model's bounding box),
+    # mjModel.vis.map.znear / zfar (fractions of extent)
+    stat_extent: float | None = None
+    vis_znear: float = 0.01
+    vis_zfar: float = 50.0
     # sizes
     nbody: int = 0
     njnt: int = 0
@@ -734,6 +739,13 @@ class _Compiler:
         m.cone = o.get("cone", "pyramidal")
         m.impratio = float(o.get("impratio", 1))
         m.noslip_iterations = int(o.get("noslip_iterations", 0))
+        for st in self.root.findall("statistic"):
+            if "extent" in st.attrib:
+                m.stat_extent = float(st.attrib["extent"])
+        for vis in self.root.findall("visual"):
+            for mp in vis.findall("map"):
+                m.vis_znear = float(mp.attrib.get("znear", m.vis_znear))
+                m.vis_zfar = float(mp.attrib.get("zfar", m.vis_zfar))
 
         nb = len(self.bodies)
         A: dict[str, np.ndarray] = {}
@@ -837,6 +849,7 @@ class _Compiler:
         A["geom_solimp"] = np.array([g["solimp"] for g in self.geoms], dtype=np.float64).reshape(ng, 5)
         A["geom_margin"] = np.array([g["margin"] for g in self.geoms], dtype=np.float64)
         A["geom_gap"] = np.array([g["gap"] for g in self.geoms], dtype=np.float64)
+        A["geom_group"] = np.array([g["group"] for g in self.geoms], dtype=np.int32)
         m.arrays = A
         m.geom_mesh = [g["mesh"] for g in self.geoms]  # type: ignore[attr-defined]
         # collision vertex sets of mesh geoms (hull vertices, numbers only; tools/make_collision_vertices.py)

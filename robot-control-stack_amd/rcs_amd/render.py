@@ -1,0 +1,111 @@
+"""Scene description for the depth ray-caster (csrc/render.h), built from a compiled scene.
+
+The reference renders with MuJoCo's OpenGL rasteriser through ``SimCameraSet`` (src/sim/camera.cpp:86-140): every geom
+of the visible groups (0-2: the floor, free objects, the robot's *visual* meshes) ends up in the depth buffer.  This
+backend casts one ray per pixel against analytic shapes instead: the floor plane, boxes (the free cube, the camera
+body), and the convex hulls of the robot's *collision* meshes (``render_hulls.npz``; the visual OBJ meshes -- 59 files
+for the FR3 -- are not used, so the robot's silhouette is that of its collision hulls, a few millimetres fatter).  The
+camera model, the depth encoding and everything above the pixels follow the reference.
+
+Geoms and cameras are expressed in the frame of the *link* they ride on (the body that carries the joint; welded
+children fold into it), which is what the kernels track per environment.
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .mjcf import GEOM_BOX, GEOM_MESH, GEOM_PLANE, Model, quat_mul, quat_to_mat
+
+LINK_WORLD, LINK_FREE_BODY = -1, -2
+SHAPE_PLANE, SHAPE_BOX, SHAPE_HULL = 0, 1, 2
+
+
+def _compose(pa, qa, pb, qb):
+    """Pose b given in frame a, with a given in some frame: returns b in that frame (positions, wxyz quaternions)."""
+    return pa + quat_to_mat(qa) @ pb, quat_mul(qa, qb)
+
+
+def _pose_in_link(cm: Model, body: int, pos, quat):
+    """(link, pos, quat): the pose relative to the link (jointed body) that `body` is welded to; link -1 = world."""
+    A = cm.arrays
+    weld = int(A["body_weldid"][body])
+    p, q = np.asarray(pos, dtype=np.float64), np.asarray(quat, dtype=np.float64)
+    b = body
+    while b != weld:
+        p, q = _compose(A["body_pos"][b], A["body_quat"][b], p, q)
+        b = int(A["body_parentid"][b])
+    if weld == 0:
+        return LINK_WORLD, p, q
+    return int(A["body_jntadr"][weld]), p, q
+
+
+@dataclass
+class RenderScene:
+    """Flat tables of the ray-caster: one row per shape, hull planes concatenated."""
+
+    shape: np.ndarray      # [ng] SHAPE_*
+    link: np.ndarray       # [ng] link index, LINK_WORLD or LINK_FREE_BODY
+    pos: np.ndarray        # [ng, 3] shape frame in its link's frame
+    rot: np.ndarray        # [ng, 9] row-major
+    size: np.ndarray       # [ng, 3] box half extents
+    plane_adr: np.ndarray  # [ng] first row of `planes` (hulls)
+    plane_num: np.ndarray  # [ng]
+    sphere: np.ndarray     # [ng, 4] bounding sphere: centre (shape frame), radius; radius < 0: unbounded (plane)
+    planes: np.ndarray     # [np, 4] n . x <= d, shape frame
+    names: list[str] = field(default_factory=list)
+    znear: float = 0.01
+    zfar: float = 50.0
+
+
+def build_render_scene(cm: Model, scene_dir: str) -> RenderScene:
+    A = cm.arrays
+    hull_file = os.path.join(scene_dir, "render_hulls.npz")
+    hulls = dict(np.load(hull_file)) if os.path.exists(hull_file) else {}
+    rows, planes, names = [], [], []
+
+    def add(shape, link, p, q, size=(0, 0, 0), pl=None, sphere=(0, 0, 0, -1.0), name=""):
+        adr = sum(len(x) for x in planes)
+        if pl is not None:
+            planes.append(pl)
+        rows.append((shape, link, p, quat_to_mat(q).reshape(9), np.asarray(size, dtype=np.float64), adr, 0 if pl is None else len(pl),
+                     np.asarray(sphere, dtype=np.float64)))
+        names.append(name)
+
+    for g in range(cm.ngeom):
+        t = int(A["geom_type"][g])
+        link, p, q = _pose_in_link(cm, int(A["geom_bodyid"][g]), A["geom_pos"][g], A["geom_quat"][g])
+        if t == GEOM_PLANE:
+            add(SHAPE_PLANE, link, p, q, name=cm.geom_names[g])
+        elif t == GEOM_BOX:
+            s = A["geom_size"][g]
+            add(SHAPE_BOX, link, p, q, size=s, sphere=(0, 0, 0, float(np.linalg.norm(s))), name=cm.geom_names[g])
+        elif t == GEOM_MESH and cm.geom_mesh[g] in hulls:
+            pl = hulls[cm.geom_mesh[g]]
+            v = A["mesh_vert"][A["geom_vertadr"][g]: A["geom_vertadr"][g] + A["geom_vertnum"][g]]
+            c = 0.5 * (v.min(axis=0) + v.max(axis=0))
+            add(SHAPE_HULL, link, p, q, pl=pl, sphere=(*c, float(np.linalg.norm(v - c, axis=1).max())), name=cm.geom_names[g])
+        # other geom types (and meshes without hull data) are not drawn
+    for fb in getattr(cm, "free_bodies", []):
+        s = fb["size"]
+        add(SHAPE_BOX, LINK_FREE_BODY, np.zeros(3), np.array([1.0, 0, 0, 0]), size=s, sphere=(0, 0, 0, float(np.linalg.norm(s))), name=fb["geom_name"])
+    if cm.stat_extent is None:
+        raise RuntimeError("rendering needs <statistic extent=...> in the scene (near / far clip planes are fractions of it)")
+    col = lambda i, dt: np.ascontiguousarray(np.array([r[i] for r in rows], dtype=dt))  # noqa: E731
+    return RenderScene(shape=col(0, np.int32), link=col(1, np.int32), pos=col(2, np.float64), rot=col(3, np.float64), size=col(4, np.float64),
+                       plane_adr=col(5, np.int32), plane_num=col(6, np.int32), sphere=col(7, np.float64),
+                       planes=np.ascontiguousarray(np.concatenate(planes) if planes else np.zeros((1, 4))), names=names,
+                       znear=cm.vis_znear * cm.stat_extent, zfar=cm.vis_zfar * cm.stat_extent)
+
+
+def camera_in_link(cm: Model, name: str):
+    """(link, pos, rot[9], fovy_deg) of the MJCF camera `name`."""
+    cid = cm.name2id("cam", name)
+    if cid < 0:
+        raise RuntimeError(f"No camera named {name}")
+    A = cm.arrays
+    link, p, q = _pose_in_link(cm, int(A["cam_bodyid"][cid]), A["cam_pos"][cid], A["cam_quat"][cid])
+    return link, p, quat_to_mat(q).reshape(9), float(A["cam_fovy"][cid])

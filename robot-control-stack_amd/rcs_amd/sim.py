@@ -49,6 +49,7 @@ class Sim:
             path = path.with_suffix(".xml")  # scenes are registered by their .mjb name in the reference
         if path.suffix != ".xml":
             raise RuntimeError(f"Filetype {path.suffix} is unknown")
+        self.scene_path = str(path)
         self.model: Model = compile_mjcf(str(path))
         self.n_envs = int(n_envs)
         self.device = int(device)

@@ -97,6 +97,70 @@ def run_free_box_parity(n_envs=32, n_calls=10, k=25, seed=0, kick=True):
     return rep
 
 
+def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wrist_0", "bird_eye_cam"), n_calls=3, k=17):
+    """Depth images of the pick-up scene (floor, cube, robot hulls) from the wrist and the bird's-eye camera: ray-casting
+    kernel vs the numpy restatement on the oracle's frames, after random joint moves and cube placements."""
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    from rcs_amd import render
+    import rcs_oracle as O
+    import rcs_render_oracle as RO
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = default_sim_robot_cfg("fr3_simple_pick_up")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    robot = S.SimRobot(simu, None, cfg)
+    S.SimGripper(simu, default_sim_gripper_cfg())
+    cams = {c: SimCameraConfig(identifier=c, frame_rate=0, resolution_width=width, resolution_height=height) for c in cameras}
+    cs = SimCameraSet(simu, cams, physical_units=True, render_on_demand=True)
+    cm = compile_mjcf(PICKUP_SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    qb = np.tile(np.array([0.5, 0.0, 0.0288, 1, 0, 0, 0.0]), (n_envs, 1))
+    qb[:, 0] += rng.uniform(-0.1, 0.1, n_envs)
+    qb[:, 1] += rng.uniform(-0.1, 0.1, n_envs)
+    qb[:, 6] = rng.uniform(-1, 1, n_envs)
+    simu.set_free_joint_qpos("box_joint", qb)
+    for e, o in enumerate(osims):
+        o.box_qpos = qb[e]
+    rep = {"pixels": 0, "mismatched_mm": 0, "max_mm_diff": 0, "max_abs_depth_gl": 0.0, "max_abs_extrinsics": 0.0, "robot_pixels": 0,
+           "cube_pixels": 0, "floor_pixels": 0, "background_pixels": 0, "fused_mismatch": 0}
+    for _ in range(n_calls):
+        tgt = FR3_Q_HOME + rng.uniform(-0.4, 0.4, (n_envs, 7))
+        robot.set_joint_position(tgt)
+        simu.step(k)
+        for e, o in enumerate(osims):
+            o.set_joint_position(tgt[e])
+            o.step(k)
+        frames = cs.get_latest_frames()
+        for name in cameras:
+            raw, xmat, xpos = cs.render_raw(name)
+            fused = cs.render_depth_mm(name)
+            data = frames.frames[name].camera.depth.data
+            rep["fused_mismatch"] += int((fused != data[..., 0]).sum())
+            link, pos, rot, fovy = render.camera_in_link(cm, name)
+            for e, o in enumerate(osims):
+                dgl, mm, cR, cp = RO.render_depth(cs._scene, (link, pos, rot, fovy, width, height), RO.oracle_frames(o, cm))
+                diff = np.abs(data[e, ..., 0].astype(np.int64) - mm.astype(np.int64))
+                rep["pixels"] += diff.size
+                rep["mismatched_mm"] += int((diff != 0).sum())
+                rep["max_mm_diff"] = max(rep["max_mm_diff"], int(diff.max()))
+                rep["max_abs_depth_gl"] = max(rep["max_abs_depth_gl"], float(np.abs(raw[e] - dgl).max()))
+                ext = np.linalg.inv(np.block([[cR @ np.diag([1.0, -1.0, -1.0]), cp[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]]))
+                rep["max_abs_extrinsics"] = max(rep["max_abs_extrinsics"], float(np.abs(frames.frames[name].camera.depth.extrinsics[e] - ext).max()))
+                rep["background_pixels"] += int((dgl == 1.0).sum())
+                if name == "bird_eye_cam":
+                    rep["robot_pixels"] += int((mm < 1900).sum())  # nearer than the floor: robot and cube seen from above
+                else:
+                    rep["wrist_min_mm"] = min(rep.get("wrist_min_mm", 65535), int(mm.min()))
+    rep["sample"] = data[0, ::8, ::8, 0]
+    simu.close()
+    return rep
+
+
 def run_pick_task_parity(n_envs=16, n_steps=6, seed=0, episodes=2, async_control=True):
     """FR3SimplePickUpSimEnvCreator()(...) (30 Hz async control, relative TRPY actions, RandomCubePos, PickCubeSuccessWrapper)
     against the oracle's restatement of that wrapper stack on the same actions and the same cube placements."""

@@ -460,3 +460,56 @@ def test_pick_task_env_matches_oracle(kernel, async_control):
     assert rep["flag_mismatches"] == 0, rep
     assert rep["max_abs_obs"] < TOL and rep["max_abs_box"] < 1e-6 and rep["max_abs_reward"] < 1e-6, rep
     assert 0.0 < rep["min_reward"] and rep["max_reward"] < 1.0, rep
+
+
+def test_depth_render_matches_oracle(kernel):
+    """SimCameraSet depth images (wrist camera on the moving hand, fixed bird's-eye camera) of the pick-up scene: the
+    ray-casting kernel against the numpy restatement on the oracle's frames.  Pixels on a silhouette edge may fall on
+    either side (a ray grazing a hull face decides by round-off), everything else is identical to the millimetre; the
+    fused uint16 path equals the reference's Python conversion of the raw depth buffer bit for bit."""
+    import parity_util as pu
+
+    if kernel == "lane":
+        pytest.skip("scene with a free body: team kernel only")
+    rep = pu.run_depth_render_parity(n_envs=6, width=64, height=48, seed=2)
+    assert rep["fused_mismatch"] == 0, rep
+    assert rep["mismatched_mm"] <= 2e-4 * rep["pixels"], rep
+    assert rep["max_abs_extrinsics"] < 1e-12, rep
+    assert rep["robot_pixels"] > 100 and rep["wrist_min_mm"] < 700, rep  # robot and cube from above; the floor under the hand in the wrist view
+
+
+def test_camera_set_semantics():
+    """Frame-set buffer and geometry of SimCameraSet (src/sim/camera.cpp:54-140, python/rcs/camera/sim.py:88-115): frames
+    rendered at one simulation time share a frame set, clear_buffer forgets it, intrinsics follow fovy and the
+    resolution, the bird's-eye view of an empty floor is the plane's depth along each pixel's ray."""
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_robot_cfg
+
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=3)
+    S.SimRobot(simu, None, cfg)
+    W, H = 40, 30
+    cs = SimCameraSet(simu, {"top": SimCameraConfig(identifier="bird_eye_cam", resolution_width=W, resolution_height=H)}, physical_units=True)
+    assert cs.buffer_size() == 0 and cs.camera_names == ["top"] and cs.name_to_identifier == {"top": "bird_eye_cam"}
+    f1 = cs.get_latest_frames()
+    f2 = cs.get_latest_frames()
+    assert cs.buffer_size() == 1  # same simulation time: the frame set is overwritten, not appended
+    simu.step(1)
+    f3 = cs.get_latest_frames()
+    assert cs.buffer_size() == 2 and float(f3.avg_timestamp[0]) == 0.002
+    assert cs.get_timestamp_frames(f1.avg_timestamp) is not None and cs.get_timestamp_frames(np.full(3, 7.0)) is None
+    cs.clear_buffer()
+    assert cs.buffer_size() == 0
+    d = f1.frames["top"].camera.depth
+    assert d.data.shape == (3, H, W, 1) and d.data.dtype == np.uint16 and f1.frames["top"].camera.color.data is None
+    assert np.array_equal(d.data, f2.frames["top"].camera.depth.data)
+    K = d.intrinsics
+    assert np.isclose(K[0, 0], 0.5 * H / np.tan(np.deg2rad(45) / 2)) and K[0, 0] == K[1, 1] and K[0, 2] == (W - 1) / 2 and K[1, 2] == (H - 1) / 2
+    # corner pixels see only floor: depth along the view axis of the plane z = 0 from the camera pose in the extrinsics
+    E = np.linalg.inv(d.extrinsics[0])  # camera (z forward, y down) in the world
+    for (r, c) in ((0, 0), (0, W - 1), (H - 1, 0)):
+        ray = E[:3, :3] @ np.array([(c - K[0, 2]) / K[0, 0], (r - K[1, 2]) / K[1, 1], 1.0])
+        z = -E[2, 3] / ray[2]
+        assert abs(int(d.data[0, r, c, 0]) - 1000 * z) <= 1.0, (r, c, d.data[0, r, c, 0], z)
+    simu.close()
