@@ -139,6 +139,9 @@ def main() -> None:
                     help="pick_up = the registered gym task rcs/FR3SimplePickUpSim-v0 (fr3_simple_pick_up scene: free cube on the floor with "
                          "elliptic-cone contacts + noslip, RandomCubePos on reset, PickCubeSuccessWrapper reward; relative TRPY control, 30 Hz); "
                          "not the headline")
+    ap.add_argument("--cameras", default="", help="comma-separated MJCF camera names: one depth frame (uint16 mm, ray-cast) per camera per "
+                                                 "env-step, inside the timed region (SimCameraSet, render on demand); not the headline")
+    ap.add_argument("--resolution", default="256x256", help="WxH of the depth frames (FR3SimplePickUpSimEnvCreator default 256x256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
@@ -223,6 +226,15 @@ def main() -> None:
         box_pose[..., 6] = 1.0
         task_out = torch.zeros((n, 9), device="cuda", dtype=torch.float64)
 
+    cam_set, cam_out = None, {}
+    if args.cameras:
+        from rcs_amd.camera import SimCameraConfig, SimCameraSet
+
+        rw, rh = (int(x) for x in args.resolution.split("x"))
+        cam_set = SimCameraSet(env.sim, {c: SimCameraConfig(identifier=c, resolution_width=rw, resolution_height=rh) for c in args.cameras.split(",")},
+                               physical_units=True)
+        cam_out = {c: torch.zeros((n, rh, rw), device="cuda", dtype=torch.uint16) for c in cam_set.camera_names}
+
     def do_reset(t: int) -> None:
         if box_pose is not None:
             env.reset_task_dev(box_pose[t // max(episode, 1)].data_ptr(), obs.data_ptr(), info.data_ptr(), gw.data_ptr())
@@ -237,6 +249,8 @@ def main() -> None:
             env.step_task_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr(), task_out.data_ptr())
         else:
             env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
+        for c, buf in cam_out.items():
+            cam_set.render_depth_mm_dev(c, buf.data_ptr())
         if exchange:
             exchange.post(t)  # overlaps with the next env-step
 
@@ -314,6 +328,8 @@ def main() -> None:
                 "substeps_per_env_step": mean_sub,
                 "physics_substeps_per_s": value * mean_sub,
                 "episode_length": episode or None,
+                "depth_frames": (f"{args.cameras} at {args.resolution}, one ray-cast uint16 frame per camera per env-step "
+                                 f"({len(cam_out) * n * int(args.resolution.split('x')[0]) * int(args.resolution.split('x')[1]) / (elapsed / args.steps) / 1e9:.2f} G rays/s incl. the physics)") if cam_out else None,
                 "exchange": "RCCL all_gather_into_tensor of obs [N,21] f64 per step, double-buffered, overlapped with the next env-step" if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
             },

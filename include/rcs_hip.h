@@ -331,7 +331,7 @@ typedef struct rcsh_render_scene_desc {
   const int32_t* link;       /* [nshape] */
   const double* pos;         /* [nshape][3] shape frame in the link frame */
   const double* rot;         /* [nshape][9] row-major */
-  const double* size;        /* [nshape][3] box half extents */
+  const double* size;        /* [nshape][3] box half extents; hulls: half extents of the bounding box centred at sphere[0..2] */
   const int32_t* plane_adr;  /* [nshape] hulls: first row of `planes` */
   const int32_t* plane_num;  /* [nshape] */
   const double* sphere;      /* [nshape][4] bounding sphere, shape frame: centre, radius (< 0: unbounded) */

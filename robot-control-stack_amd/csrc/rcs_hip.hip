@@ -1091,7 +1091,7 @@ int rcsh_camera_render_dev(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_link_frames launch: ") + hipGetErrorString(err));
-  const int blocks_per_env = (cam.width * cam.height + 255) / 256;
+  const int blocks_per_env = ((cam.width + 15) / 16) * ((cam.height + 15) / 16);
   hipLaunchKernelGGL(k_render_depth, dim3((unsigned)blocks_per_env * (unsigned)s->n), dim3(256), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
                      depth_gl, depth_mm, cam_pose);
   err = hipGetLastError();

@@ -124,9 +124,15 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
                                                       uint16_t* depth_mm, double* cam_pose) {
   __shared__ double wR[kMaxShapes][9], wp[kMaxShapes][3], wc[kMaxShapes][4], cR[9], cp[3];
   const int W = cam.width, H = cam.height;
-  const int blocks_per_env = (W * H + 255) / 256;
+  // a workgroup is a 16 x 16 pixel tile, each of its four wavefronts an 8 x 8 sub-tile: the rays of a wavefront stay
+  // together, so they mostly agree on which shapes they have to look at
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  const int blocks_per_env = tiles_x * tiles_y;
   const int e = blockIdx.x / blocks_per_env;
-  const int pix = (blockIdx.x % blocks_per_env) * 256 + threadIdx.x;
+  const int tile = blockIdx.x % blocks_per_env;
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int col = (tile % tiles_x) * 16 + (wave % 2) * 8 + lane % 8;
+  const int row = (tile / tiles_x) * 16 + (wave / 2) * 8 + lane / 8;  // row 0 = bottom of the image (OpenGL window coordinates)
   const double* fe = frames + (size_t)e * sc.nframes * 12;
   if (threadIdx.x < sc.nshape) {
     const RenderShape& sh = sc.shapes[threadIdx.x];
@@ -144,14 +150,13 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     in_world(fe, cam.link, sc.nframes, cam.pos, cam.rot, R, p);
     for (int k = 0; k < 9; ++k) cR[k] = R[k];
     for (int k = 0; k < 3; ++k) cp[k] = p[k];
-    if (cam_pose && blockIdx.x % blocks_per_env == 0) {
+    if (cam_pose && tile == 0) {
       for (int k = 0; k < 9; ++k) cam_pose[(size_t)e * 12 + k] = R[k];
       for (int k = 0; k < 3; ++k) cam_pose[(size_t)e * 12 + 9 + k] = p[k];
     }
   }
   __syncthreads();
-  if (pix >= W * H) return;
-  const int row = pix / W, col = pix % W;  // row 0 = bottom of the image (OpenGL window coordinates)
+  if (col >= W || row >= H) return;
   // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
   const double ty = cam.tan_half_fovy, tx = ty * (double)W / (double)H;
   const double dc[3] = {(2.0 * (col + 0.5) / W - 1.0) * tx, (2.0 * (row + 0.5) / H - 1.0) * ty, -1.0};
@@ -184,25 +189,43 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       continue;
     }
     bool ok = true;
-    if (sh.shape == kShapeBox) {
+    // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
+    // `size`): most rays that pass the sphere of an elongated link miss the link
+    const double cen[3] = {sh.shape == kShapeHull ? sh.sphere[0] : 0.0, sh.shape == kShapeHull ? sh.sphere[1] : 0.0, sh.shape == kShapeHull ? sh.sphere[2] : 0.0};
+    {
+      double b0 = t0, b1 = t1;
       for (int k = 0; k < 3 && ok; ++k) {
-        if (ld[k] == 0) { ok = fabs(lo[k]) <= sh.size[k]; continue; }
-        const double inv = 1.0 / ld[k];
-        double ta = (-sh.size[k] - lo[k]) * inv, tb = (sh.size[k] - lo[k]) * inv;
+        const double lk = lo[k] - cen[k];
+        if (ld[k] == 0) { ok = fabs(lk) <= sh.size[k]; continue; }
+        const double inv = fast_rcp(ld[k]);
+        double ta = (-sh.size[k] - lk) * inv, tb = (sh.size[k] - lk) * inv;
         if (ta > tb) { const double x = ta; ta = tb; tb = x; }
-        t0 = ta > t0 ? ta : t0;
-        t1 = tb < t1 ? tb : t1;
-        ok = t0 <= t1;
+        b0 = ta > b0 ? ta : b0;
+        b1 = tb < b1 ? tb : b1;
+        ok = b0 <= b1;
       }
-    } else {
+      if (sh.shape == kShapeBox) { t0 = b0; t1 = b1; }
+    }
+    if (ok && sh.shape == kShapeHull) {
+      // four planes per round: their loads go out together (a plane a round would wait for L1 every time); the tail
+      // round repeats the last plane, which changes nothing
       const double* pl = sc.planes + 4 * (size_t)sh.plane_adr;
-      for (int k = 0; k < sh.plane_num && ok; ++k, pl += 4) {
-        const double nd = pl[0] * ld[0] + pl[1] * ld[1] + pl[2] * ld[2];
-        const double no = pl[3] - (pl[0] * lo[0] + pl[1] * lo[1] + pl[2] * lo[2]);  // >= 0: origin inside this half space
-        if (nd == 0) { ok = no >= 0; continue; }
-        const double t = no / nd;
-        if (nd < 0) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
-        ok = t0 <= t1;
+      for (int k = 0; k < sh.plane_num && ok; k += 4) {
+        double q4[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double* src = pl + 4 * (size_t)(k + j < sh.plane_num ? k + j : sh.plane_num - 1);
+          q4[j][0] = src[0]; q4[j][1] = src[1]; q4[j][2] = src[2]; q4[j][3] = src[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
+          const double no = q4[j][3] - (q4[j][0] * lo[0] + q4[j][1] * lo[1] + q4[j][2] * lo[2]);  // >= 0: origin inside this half space
+          if (nd == 0) { ok = ok && no >= 0; continue; }
+          const double t = no * fast_rcp(nd);
+          if (nd < 0) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
+        }
+        ok = ok && t0 <= t1;
       }
     }
     // a camera inside a shape sees its inside faces culled (back faces): only entry points count

@@ -36,7 +36,8 @@ class VecSimEnv:
     """
 
     def __init__(self, simulation: sim.Sim, robot: sim.SimRobot, gripper: sim.SimGripper | None,
-                 control_mode: ControlMode, max_relative_movement, relative_to: RelativeTo):
+                 control_mode: ControlMode, max_relative_movement, relative_to: RelativeTo, camera_set=None):
+        self.camera_set = camera_set  # CameraSetWrapper(env, camera_set, include_depth=True), base.py:585-677
         self.sim = simulation
         self.robot = robot
         self.gripper = gripper
@@ -79,6 +80,18 @@ class VecSimEnv:
         i: dict[str, Any] = {}
         if self.gripper is not None:
             o["gripper"] = obs[:, 13 + d].copy()
+        if self.camera_set is not None:
+            # CameraSetWrapper.observation (base.py:633-674): depth only -- this backend renders no colour image
+            frameset = self.camera_set.get_latest_frames()
+            if frameset is None:
+                o["frames"] = {}
+                i["camera_available"] = False
+            else:
+                o["frames"] = {name: {"depth": {"data": f.camera.depth.data, "intrinsics": f.camera.depth.intrinsics,
+                                                "extrinsics": f.camera.depth.extrinsics}} for name, f in frameset.frames.items()}
+                i["camera_available"] = True
+                if frameset.avg_timestamp is not None:
+                    i["frame_timestamp"] = frameset.avg_timestamp
         return o, i
 
     def reset(self, seed: int | None = None, options: dict | None = None, mask=None):
@@ -87,6 +100,8 @@ class VecSimEnv:
         info = np.zeros((n, 8), dtype=np.uint8)
         gw = np.zeros(n)
         m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        if self.camera_set is not None:
+            self.camera_set.clear_buffer()  # CameraSetWrapper.reset
         _lib.check(self._L.rcsh_env_reset(self.sim._h, _lib.ptr(m), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw)))
         o, i = self._unpack(obs, info, gw)
         if self.gripper is not None:  # GripperWrapperSim.observation runs on reset too (envs/sim.py:125-131)
@@ -174,6 +189,8 @@ class VecPickCubeEnv(VecSimEnv):
         info = np.zeros((n, 8), dtype=np.uint8)
         gw = np.zeros(n)
         m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        if self.camera_set is not None:
+            self.camera_set.clear_buffer()
         _lib.check(self._L.rcsh_env_reset_task(self.sim._h, _lib.ptr(m), _lib.ptr(box), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw)))
         o, i = self._unpack(obs, info, gw)
         i["collision"] = info[:, 5].astype(bool)
@@ -219,12 +236,17 @@ class SimEnvCreator:
                  gripper_cfg: sim.SimGripperConfig | None = None, sim_cfg: sim.SimConfig | None = None,
                  hand_cfg=None, cameras=None, max_relative_movement: float | tuple[float, float] | None = None,
                  relative_to: RelativeTo = RelativeTo.LAST_STEP, sim_wrapper=None, n_envs: int = 1, device: int = 0) -> VecSimEnv:
-        if hand_cfg is not None or cameras is not None or sim_wrapper is not None or collision_guard:
-            raise NotImplementedError("hands, cameras, sim_wrapper and collision_guard are outside this backend's hot path")
+        if hand_cfg is not None or sim_wrapper is not None or collision_guard:
+            raise NotImplementedError("hands, sim_wrapper and collision_guard are outside this backend's hot path")
         simulation = sim.Sim(robot_cfg.mjcf_scene_path, sim_cfg, n_envs=n_envs, device=device)
         robot = sim.SimRobot(simulation, None, robot_cfg)
         gripper = sim.SimGripper(simulation, gripper_cfg) if gripper_cfg is not None else None
-        return VecSimEnv(simulation, robot, gripper, control_mode, max_relative_movement, relative_to)
+        camera_set = None
+        if cameras is not None:  # creators.py:92-96
+            from ..camera import SimCameraSet
+
+            camera_set = SimCameraSet(simulation, cameras, physical_units=True, render_on_demand=True)
+        return VecSimEnv(simulation, robot, gripper, control_mode, max_relative_movement, relative_to, camera_set=camera_set)
 
 
 class SimTaskEnvCreator:
@@ -236,15 +258,20 @@ class SimTaskEnvCreator:
                  sim_cfg: sim.SimConfig | None = None, random_pos_args: dict | None = None, n_envs: int = 1, device: int = 0) -> VecPickCubeEnv:
         from .utils import default_sim_gripper_cfg
 
-        if hand_cfg is not None or cameras or random_pos_args is not None:
-            raise NotImplementedError("hands, cameras and RandomObjectPos are outside this backend's hot path")
+        if hand_cfg is not None or random_pos_args is not None:
+            raise NotImplementedError("hands and RandomObjectPos are outside this backend's hot path")
         if gripper_cfg is None:
             gripper_cfg = default_sim_gripper_cfg()
         simulation = sim.Sim(robot_cfg.mjcf_scene_path, sim_cfg, n_envs=n_envs, device=device)
         robot = sim.SimRobot(simulation, None, robot_cfg)
         gripper = sim.SimGripper(simulation, gripper_cfg)
+        camera_set = None
+        if cameras:
+            from ..camera import SimCameraSet
+
+            camera_set = SimCameraSet(simulation, cameras, physical_units=True, render_on_demand=True)
         return VecPickCubeEnv(simulation, robot, gripper, control_mode,
-                              (0.2, float(np.deg2rad(45))) if delta_actions else None, RelativeTo.LAST_STEP)
+                              (0.2, float(np.deg2rad(45))) if delta_actions else None, RelativeTo.LAST_STEP, camera_set=camera_set)
 
 
 class FR3SimplePickUpSimEnvCreator:
@@ -256,8 +283,12 @@ class FR3SimplePickUpSimEnvCreator:
                  cam_list: list[str] | None = None, n_envs: int = 1, device: int = 0) -> VecPickCubeEnv:
         from .utils import default_sim_robot_cfg
 
-        if cam_list:
-            raise NotImplementedError("camera rendering is outside this backend's hot path")
+        from ..camera import CameraType, SimCameraConfig
+
+        if resolution is None:
+            resolution = (256, 256)
+        cameras = {cam: SimCameraConfig(identifier=cam, type=CameraType.fixed, resolution_height=resolution[1], resolution_width=resolution[0],
+                                        frame_rate=frame_rate) for cam in (cam_list or [])}
         robot_cfg = default_sim_robot_cfg(scene="fr3_simple_pick_up")
         robot_cfg.tcp_offset = common.Pose(translation=np.array([0.0, 0.0, 0.1034]),
                                            rotation=np.array([[0.707, 0.707, 0], [-0.707, 0.707, 0], [0, 0, 1]]))
@@ -265,4 +296,4 @@ class FR3SimplePickUpSimEnvCreator:
         sim_cfg.realtime = False
         sim_cfg.async_control = True
         sim_cfg.frequency = 30
-        return SimTaskEnvCreator()(robot_cfg, render_mode, control_mode, delta_actions, None, sim_cfg=sim_cfg, n_envs=n_envs, device=device)
+        return SimTaskEnvCreator()(robot_cfg, render_mode, control_mode, delta_actions, cameras, sim_cfg=sim_cfg, n_envs=n_envs, device=device)

@@ -51,7 +51,7 @@ class RenderScene:
     link: np.ndarray       # [ng] link index, LINK_WORLD or LINK_FREE_BODY
     pos: np.ndarray        # [ng, 3] shape frame in its link's frame
     rot: np.ndarray        # [ng, 9] row-major
-    size: np.ndarray       # [ng, 3] box half extents
+    size: np.ndarray       # [ng, 3] box half extents; hulls: half extents of the bounding box centred at sphere[:3]
     plane_adr: np.ndarray  # [ng] first row of `planes` (hulls)
     plane_num: np.ndarray  # [ng]
     sphere: np.ndarray     # [ng, 4] bounding sphere: centre (shape frame), radius; radius < 0: unbounded (plane)
@@ -87,7 +87,9 @@ def build_render_scene(cm: Model, scene_dir: str) -> RenderScene:
             pl = hulls[cm.geom_mesh[g]]
             v = A["mesh_vert"][A["geom_vertadr"][g]: A["geom_vertadr"][g] + A["geom_vertnum"][g]]
             c = 0.5 * (v.min(axis=0) + v.max(axis=0))
-            add(SHAPE_HULL, link, p, q, pl=pl, sphere=(*c, float(np.linalg.norm(v - c, axis=1).max())), name=cm.geom_names[g])
+            # bounding sphere about the centre of the hull's bounding box; `size` = half extents of that box
+            add(SHAPE_HULL, link, p, q, size=0.5 * (v.max(axis=0) - v.min(axis=0)), pl=pl, sphere=(*c, float(np.linalg.norm(v - c, axis=1).max())),
+                name=cm.geom_names[g])
         # other geom types (and meshes without hull data) are not drawn
     for fb in getattr(cm, "free_bodies", []):
         s = fb["size"]

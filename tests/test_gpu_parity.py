@@ -513,3 +513,23 @@ def test_camera_set_semantics():
         z = -E[2, 3] / ray[2]
         assert abs(int(d.data[0, r, c, 0]) - 1000 * z) <= 1.0, (r, c, d.data[0, r, c, 0], z)
     simu.close()
+
+
+def test_env_with_cameras_returns_depth_frames(kernel):
+    """SimEnvCreator(cameras=...) / FR3SimplePickUpSimEnvCreator(cam_list=...): the observation carries the cameras'
+    depth frames (CameraSetWrapper.observation, base.py:633-674), rendered on demand at the step's simulation time."""
+    from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
+
+    if kernel == "lane":
+        pytest.skip("scene with a free body: team kernel only")
+    env = FR3SimplePickUpSimEnvCreator()(n_envs=4, resolution=(32, 24), cam_list=["wrist_0", "bird_eye_cam"])
+    obs, info = env.reset()
+    assert info["camera_available"] and set(obs["frames"]) == {"wrist_0", "bird_eye_cam"}
+    d0 = obs["frames"]["bird_eye_cam"]["depth"]
+    assert d0["data"].shape == (4, 24, 32, 1) and d0["data"].dtype == np.uint16 and d0["extrinsics"].shape == (4, 4, 4)
+    rng = np.random.default_rng(0)
+    obs, reward, term, trunc, info = env.step({"xyzrpy": rng.uniform(-0.05, 0.05, (4, 6)), "gripper": np.ones(4)})
+    assert np.allclose(info["frame_timestamp"], 2 * 0.002 + 17 * 0.002) and env.camera_set.buffer_size() == 2
+    w0, w1 = obs["frames"]["wrist_0"]["depth"], d0
+    assert not np.array_equal(w0["extrinsics"], env.camera_set.get_timestamp_frames(np.full(4, 0.004)).frames["wrist_0"].camera.depth.extrinsics)  # the hand moved
+    env.close()

@@ -338,3 +338,65 @@ def test_oracle_box_free_flight_and_gyroscopic_term():
     assert np.allclose(d.qpos[:2], [0.1 * 0.2, -0.2 * 0.2], atol=1e-12)
     assert abs(d.qpos[2] - (1.0 + 0.3 * 0.2 - 0.5 * 9.81 * 0.2 * 0.202)) < 1e-9   # semi-implicit Euler: sum of k h^2 g
     assert np.allclose(L_world(), L0, rtol=2e-3)
+
+
+# ---------------------------------------------------------------- depth renderer: scene tables and the numpy restatement
+def test_render_scene_tables():
+    """rcs_amd.render: one shape per drawn geom, in the frame of the link it rides on; hull planes contain their hulls."""
+    from rcs_amd import render
+
+    d = os.path.dirname(PICKUP_SCENE)
+    cm = compile_mjcf(PICKUP_SCENE)
+    rs = render.build_render_scene(cm, d)
+    assert (rs.znear, rs.zfar) == (0.01, 50.0)  # vis.map defaults x statistic extent = 1
+    names = dict(zip(rs.names, range(len(rs.names))))
+    assert rs.shape[names["floor"]] == render.SHAPE_PLANE and rs.link[names["floor"]] == render.LINK_WORLD
+    assert rs.shape[names["box_geom"]] == render.SHAPE_BOX and rs.link[names["box_geom"]] == render.LINK_FREE_BODY
+    assert np.allclose(rs.size[names["box_geom"]], [0.032, 0.016, 0.0288])
+    for i in range(1, 8):  # link i's collision hull rides on link i - 1 (joint i), link0's on the world
+        assert rs.link[names[f"fr3_link{i}_collision_0"]] == i - 1
+    assert rs.link[names["fr3_link0_collision_0"]] == render.LINK_WORLD and rs.link[names["hand_c_0"]] == 6
+    assert rs.link[names["finger_0_left_0"]] == 7 and rs.link[names["finger_0_right_0"]] == 8
+    assert np.allclose(rs.pos[names["hand_c_0"]], [0, 0, 0.107])  # fr3_link8 + hand flange folded into link 7's frame
+    verts = dict(np.load(os.path.join(d, "collision_vertices.npz")))
+    for g, name in enumerate(rs.names):
+        if rs.shape[g] != render.SHAPE_HULL:
+            continue
+        pl = rs.planes[rs.plane_adr[g]: rs.plane_adr[g] + rs.plane_num[g]]
+        v = verts[cm.geom_mesh[cm.name2id("geom", name)]]
+        slack = v @ pl[:, :3].T - pl[:, 3]
+        assert slack.max() < 1e-9 and np.allclose(np.linalg.norm(pl[:, :3], axis=1), 1)  # every hull vertex inside every plane
+        assert np.abs(slack).min(axis=0).max() < 1e-9                                   # and every plane touches the hull
+        c, r = rs.sphere[g][:3], rs.sphere[g][3]
+        assert (np.linalg.norm(v - c, axis=1) <= r + 1e-12).all() and (np.abs(v - c) <= rs.size[g] + 1e-12).all()
+    link, pos, rot, fovy = render.camera_in_link(cm, "bird_eye_cam")
+    assert link == render.LINK_WORLD and np.allclose(pos, [0.271, 0, 2.08]) and fovy == 45.0
+    assert render.camera_in_link(cm, "wrist_0")[0] == 6
+    with pytest.raises(RuntimeError, match="No camera named"):
+        render.camera_in_link(cm, "nope")
+
+
+def test_oracle_depth_render_known_answers():
+    """The numpy ray-caster on hand-made frames: a camera looking straight down at the floor and at a box."""
+    import rcs_render_oracle as RO
+    from rcs_amd import render
+
+    rs = render.RenderScene(
+        shape=np.array([0, 1], dtype=np.int32), link=np.array([-1, -2], dtype=np.int32), pos=np.zeros((2, 3)), rot=np.tile(np.eye(3).reshape(9), (2, 1)),
+        size=np.array([[0, 0, 0], [0.1, 0.2, 0.05]]), plane_adr=np.zeros(2, dtype=np.int32), plane_num=np.zeros(2, dtype=np.int32),
+        sphere=np.array([[0, 0, 0, -1.0], [0, 0, 0, 0.3]]), planes=np.zeros((1, 4)), znear=0.01, zfar=50.0)
+    frames = {-1: (np.eye(3), np.zeros(3)), -2: (np.eye(3), np.array([0.0, 0.0, 0.05]))}  # box resting on the floor
+    down = np.eye(3).reshape(9)  # a MuJoCo camera looks along -z of its frame: world axes = looking straight down
+    W = H = 21
+    dgl, mm, cR, cp = RO.render_depth(rs, (-1, np.array([0.0, 0.0, 1.0]), down, 90.0, W, H), frames)
+    assert mm.dtype == np.uint16 and dgl.dtype == np.float32 and mm.shape == (H, W)
+    assert mm[H // 2, W // 2] in (899, 900)              # top of the box, 0.9 m below the camera (uint16 truncates the float32 metres)
+    assert mm[0, 0] in (999, 1000) and mm[H - 1, W - 1] in (999, 1000)  # view depth of the floor is 1 m on every ray that misses the box
+    box = (mm < 950)
+    assert box.sum() == 3 * 5 or box.sum() == 3 * 4 + 0 or 9 <= box.sum() <= 20  # 0.2 x 0.4 m footprint at 0.9 m under a 90 degree view
+    assert np.array_equal(box, box[::-1]) and np.array_equal(box, box[:, ::-1])
+    # OpenGL encoding of the raw buffer: d = (1/near - 1/z) / (1/near - 1/far), rows bottom-up
+    assert abs(float(dgl[0, 0]) - (100 - 1 / 1.0) / (100 - 0.02)) < 1e-6
+    # a camera above the far plane's reach sees background: depth buffer 1, ~far in millimetres
+    dgl2, mm2, _, _ = RO.render_depth(rs, (-1, np.array([0.0, 0.0, 60.0]), down, 10.0, 3, 3), frames)
+    assert (dgl2 == 1.0).all() and (mm2 > 49900).all()
