@@ -533,3 +533,49 @@ def test_env_with_cameras_returns_depth_frames(kernel):
     w0, w1 = obs["frames"]["wrist_0"]["depth"], d0
     assert not np.array_equal(w0["extrinsics"], env.camera_set.get_timestamp_frames(np.full(4, 0.004)).frames["wrist_0"].camera.depth.extrinsics)  # the hand moved
     env.close()
+
+
+def test_error_behaviour_of_free_body_task_and_camera_calls():
+    """The entry points added for the pick-up scene refuse what they cannot do, with the reference's exception types:
+    unknown names -> the KeyError / RuntimeError the mujoco bindings / mj_name2id wrappers raise, wrong call order ->
+    RuntimeError, out-of-range arguments -> ValueError; handles stay usable."""
+    import ctypes as C
+
+    from rcs_amd import _lib
+    from rcs_amd import sim as S
+    from rcs_amd.camera import CameraType, SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+
+    empty = S.Sim(default_sim_robot_cfg("fr3_empty_world").mjcf_scene_path, S.SimConfig(), n_envs=2)
+    with pytest.raises(KeyError, match="box_joint"):       # sim.data.joint("box_joint") on a scene without it
+        empty.free_joint_qpos("box_joint")
+    L = empty._L
+    q = np.zeros((2, 7))
+    assert L.rcsh_sim_get_free_qpos(empty._h, _lib.ptr(q)) == _lib.RCSH_ERR_STATE
+    t = _lib.PickTaskDesc()
+    S.SimRobot(empty, None, default_sim_robot_cfg("fr3_empty_world"))
+    assert L.rcsh_env_configure_pick_task(empty._h, C.byref(t)) == _lib.RCSH_ERR_STATE   # no free box in this scene
+    assert L.rcsh_camera_render(empty._h, 0, None, None, None) == _lib.RCSH_ERR_ARG      # no such camera
+    with pytest.raises(RuntimeError, match="No camera named nope"):
+        SimCameraSet(empty, {"x": SimCameraConfig(identifier="nope")})
+    with pytest.raises(NotImplementedError):
+        SimCameraSet(empty, {"x": SimCameraConfig(identifier="bird_eye_cam")}, render_on_demand=False)
+    with pytest.raises(NotImplementedError):
+        SimCameraSet(empty, {"x": SimCameraConfig(identifier="bird_eye_cam", type=CameraType.free)})
+    empty.step(1)
+    empty.close()
+
+    cfg = default_sim_robot_cfg("fr3_simple_pick_up")
+    pick = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=2)
+    with pytest.raises(RuntimeError, match="team kernel"):  # free bodies are stepped by the team kernel only
+        pick.set_kernel("lane")
+    box = _lib.make_free_box_desc(pick.model)
+    assert L.rcsh_sim_add_free_box(pick._h, C.byref(box)) == _lib.RCSH_ERR_STATE          # already attached by Sim()
+    S.SimRobot(pick, None, cfg)
+    S.SimGripper(pick, default_sim_gripper_cfg())
+    obs = np.zeros((2, 21))
+    assert L.rcsh_env_reset_task(pick._h, None, _lib.ptr(q), _lib.ptr(obs), None, None) == _lib.RCSH_ERR_STATE  # rcsh_env_configure first
+    pick.set_free_joint_qpos("box_joint", [0.5, 0.0, 0.1, 1, 0, 0, 0])
+    pick.step(3)
+    assert np.isfinite(pick.free_joint_qpos("box_joint")).all() and (pick.free_joint_qvel("box_joint")[:, 2] < 0).all()  # falling
+    pick.close()
