@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev tool: env-steps/s of each kernel variant over batch sizes
 cd "$GRAFT_REPO_ROOT"
-for n in 64 1024 4096 8192 16384 32768 65536 131072 262144; do
+for n in 64 1024 4096 8192 16384 32768 65536 131072 262144 524288; do
   for k in 0 1; do
     RCSH_KERNEL=$([ $k = 1 ] && echo team || echo lane) python bench.py --no-cpu-baseline --steps 30 --warmup 5 --envs $n | python -c "
 import json,sys
