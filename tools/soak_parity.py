@@ -1,0 +1,13 @@
+"""dev tool: longer / wider runs of the free-box and pick-task parity checks than the test suite affords."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "robot-control-stack_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import parity_util as pu
+for seed in range(4):
+    rep = pu.run_free_box_parity(n_envs=64, n_calls=20, k=25, seed=seed)
+    print("box", seed, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items() if k not in ("final_z", "zones")})
+for seed in range(3):
+    rep = pu.run_pick_task_parity(n_envs=32, n_steps=15, seed=seed, episodes=2)
+    print("task", seed, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
+rep = pu.run_depth_render_parity(n_envs=8, width=96, height=64, seed=5, n_calls=4)
+print("depth", {k: v for k, v in rep.items() if k != "sample"})
