@@ -160,10 +160,15 @@ class VecPickCubeEnv(VecSimEnv):
     SUCCESS_HEIGHT = 0.15 + 0.852
     ISO_CUBE = np.array([0.498, 0.0, 0.226])  # RandomCubePos.reset, robot coordinates
 
-    def __init__(self, *args, include_rotation: bool = True, **kwargs):
+    def __init__(self, *args, include_rotation: bool = True, random_pos_args: dict | None = None, **kwargs):
         super().__init__(*args, **kwargs)
         assert self.gripper is not None, "PickCubeSuccessWrapper reads the gripper observation"
         self.include_rotation = include_rotation
+        # RandomObjectPos instead of RandomCubePos (creators.py:160-167): joint_name, init_object_pose, include_position, include_rotation
+        self.random_pos_args = random_pos_args
+        if random_pos_args is not None:
+            self.sim._free_joint(random_pos_args["joint_name"])  # KeyError for an unknown joint, like mjData.joint()
+            self.init_object_pose = random_pos_args["init_object_pose"]
         t = _lib.PickTaskDesc()
         t.ee_home[:] = [float(x) for x in self.EE_HOME]
         t.success_height = float(self.SUCCESS_HEIGHT)
@@ -171,7 +176,11 @@ class VecPickCubeEnv(VecSimEnv):
         self.task_width = 9
 
     def draw_box_qpos(self) -> np.ndarray:
-        """RandomCubePos.reset's placement (sim.py:371-383) for every environment."""
+        """RandomCubePos.reset's placement (sim.py:371-383) -- or RandomObjectPos.reset's (sim.py:331-354) -- for every
+        environment, drawing from numpy's global generator in the reference's order."""
+        if self.random_pos_args is not None:
+            return random_object_qpos(self.init_object_pose, self.n_envs, self.random_pos_args.get("include_position", True),
+                                      self.random_pos_args.get("include_rotation", False))
         iso = self.robot.to_pose_in_world_coordinates(common.Pose(translation=self.ISO_CUBE, rpy_vector=np.zeros(3))).translation()
         q = np.zeros((self.n_envs, 7))
         for e in range(self.n_envs):
@@ -183,6 +192,9 @@ class VecPickCubeEnv(VecSimEnv):
 
     def reset(self, seed: int | None = None, options: dict | None = None, mask=None):
         n = self.n_envs
+        if options is not None and "RandomObjectPos.init_object_pose" in options and self.random_pos_args is not None:
+            assert isinstance(options["RandomObjectPos.init_object_pose"], common.Pose), "RandomObjectPos.init_object_pose must be a rcs.common.Pose"
+            self.init_object_pose = options["RandomObjectPos.init_object_pose"]  # sticks for later resets, as in the reference
         box = None if options is None else options.get("box_qpos")
         box = self.draw_box_qpos() if box is None else np.ascontiguousarray(np.broadcast_to(np.asarray(box, dtype=np.float64), (n, 7)))
         obs = np.zeros((n, self.obs_width))
@@ -231,6 +243,20 @@ class VecPickCubeEnv(VecSimEnv):
                                                    C.c_void_p(info_ptr), C.c_void_p(gw_ptr)))
 
 
+def random_object_qpos(init_object_pose: common.Pose, n_envs: int, include_position: bool = True, include_rotation: bool = False) -> np.ndarray:
+    """RandomObjectPos.reset (reference python/rcs/envs/sim.py:331-354) for n_envs environments: x, y +- 0.1 m around the
+    initial pose, z and orientation kept -- with include_rotation the quaternion's w becomes ``2 u - w`` (unnormalised;
+    mj_kinematics normalises it).  Draw order per environment: x, y, then w."""
+    t, q = init_object_pose.translation(), init_object_pose.rotation_q()  # xyzw
+    out = np.zeros((n_envs, 7))
+    for e in range(n_envs):
+        x = t[0] + np.random.random() * 0.2 - 0.1 if include_position else t[0]
+        y = t[1] + np.random.random() * 0.2 - 0.1 if include_position else t[1]
+        w = 2 * np.random.random() - q[3] if include_rotation else q[3]
+        out[e] = [x, y, t[2], w, q[0], q[1], q[2]]
+    return out
+
+
 class SimEnvCreator:
     def __call__(self, control_mode: ControlMode, robot_cfg: sim.SimRobotConfig, collision_guard: bool = False,
                  gripper_cfg: sim.SimGripperConfig | None = None, sim_cfg: sim.SimConfig | None = None,
@@ -258,8 +284,12 @@ class SimTaskEnvCreator:
                  sim_cfg: sim.SimConfig | None = None, random_pos_args: dict | None = None, n_envs: int = 1, device: int = 0) -> VecPickCubeEnv:
         from .utils import default_sim_gripper_cfg
 
-        if hand_cfg is not None or random_pos_args is not None:
-            raise NotImplementedError("hands and RandomObjectPos are outside this backend's hot path")
+        if hand_cfg is not None:
+            raise NotImplementedError("hands are outside this backend's hot path")
+        if random_pos_args is not None:
+            missing = [k for k in ("joint_name", "init_object_pose") if k not in random_pos_args]
+            if missing:
+                raise TypeError(f"RandomObjectPos.__init__() missing required arguments: {missing}")  # partial(RandomObjectPos, **args) would fail here
         if gripper_cfg is None:
             gripper_cfg = default_sim_gripper_cfg()
         simulation = sim.Sim(robot_cfg.mjcf_scene_path, sim_cfg, n_envs=n_envs, device=device)
@@ -271,7 +301,8 @@ class SimTaskEnvCreator:
 
             camera_set = SimCameraSet(simulation, cameras, physical_units=True, render_on_demand=True)
         return VecPickCubeEnv(simulation, robot, gripper, control_mode,
-                              (0.2, float(np.deg2rad(45))) if delta_actions else None, RelativeTo.LAST_STEP, camera_set=camera_set)
+                              (0.2, float(np.deg2rad(45))) if delta_actions else None, RelativeTo.LAST_STEP, camera_set=camera_set,
+                              random_pos_args=random_pos_args)
 
 
 class FR3SimplePickUpSimEnvCreator:

@@ -579,3 +579,28 @@ def test_error_behaviour_of_free_body_task_and_camera_calls():
     pick.step(3)
     assert np.isfinite(pick.free_joint_qpos("box_joint")).all() and (pick.free_joint_qvel("box_joint")[:, 2] < 0).all()  # falling
     pick.close()
+
+
+def test_task_env_with_random_object_pos(kernel):
+    """SimTaskEnvCreator(random_pos_args=...) (creators.py:160-167): RandomObjectPos places the cube around the given pose
+    instead of RandomCubePos' ISO-cube centre; options["RandomObjectPos.init_object_pose"] replaces the pose for good."""
+    from rcs_amd import common
+    from rcs_amd.envs import SimTaskEnvCreator, default_sim_robot_cfg
+
+    if kernel == "lane":
+        pytest.skip("scene with a free body: team kernel only")
+    rc = default_sim_robot_cfg(scene="fr3_simple_pick_up")
+    with pytest.raises(TypeError):
+        SimTaskEnvCreator()(rc, random_pos_args={"joint_name": "box_joint"}, n_envs=2)
+    with pytest.raises(KeyError):
+        SimTaskEnvCreator()(rc, random_pos_args={"joint_name": "no_such_joint", "init_object_pose": common.Pose()}, n_envs=2)
+    pose = common.Pose(translation=np.array([0.55, -0.05, 0.0288]), quaternion=np.array([0.0, 0.0, 0.0, 1.0]))
+    env = SimTaskEnvCreator()(rc, random_pos_args={"joint_name": "box_joint", "init_object_pose": pose, "include_position": False}, n_envs=3)
+    env.reset()
+    q = env.sim.free_joint_qpos("box_joint")
+    assert np.allclose(q[:, :2], [0.55, -0.05], atol=1e-6) and np.allclose(q[:, 3:], [1, 0, 0, 0], atol=1e-9) and (np.abs(q[:, 2] - 0.0288) < 1e-3).all()
+    other = common.Pose(translation=np.array([0.4, 0.1, 0.0288]), quaternion=np.array([0.0, 0.0, 0.0, 1.0]))
+    env.reset(options={"RandomObjectPos.init_object_pose": other})
+    env.reset()
+    assert np.allclose(env.sim.free_joint_qpos("box_joint")[:, :2], [0.4, 0.1], atol=1e-6)
+    env.close()

@@ -400,3 +400,24 @@ def test_oracle_depth_render_known_answers():
     # a camera above the far plane's reach sees background: depth buffer 1, ~far in millimetres
     dgl2, mm2, _, _ = RO.render_depth(rs, (-1, np.array([0.0, 0.0, 60.0]), down, 10.0, 3, 3), frames)
     assert (dgl2 == 1.0).all() and (mm2 > 49900).all()
+
+
+def test_random_object_pos_draws_follow_the_reference():
+    """RandomObjectPos.reset (python/rcs/envs/sim.py:331-354): draw order x, y, (w); z and the rest of the quaternion kept;
+    mjData's free-joint layout is [x y z qw qx qy qz] while Pose.rotation_q() is xyzw."""
+    from rcs_amd.envs.creators import random_object_qpos
+
+    pose = common.Pose(translation=np.array([0.5, 0.1, 0.03]), quaternion=np.array([0.0, 0.0, np.sin(0.3), np.cos(0.3)]))
+    np.random.seed(7)
+    got = random_object_qpos(pose, 3, include_position=True, include_rotation=True)
+    np.random.seed(7)
+    for e in range(3):
+        x = 0.5 + np.random.random() * 0.2 - 0.1
+        y = 0.1 + np.random.random() * 0.2 - 0.1
+        w = 2 * np.random.random() - np.cos(0.3)
+        assert np.allclose(got[e], [x, y, 0.03, w, 0, 0, np.sin(0.3)], atol=1e-15)
+    np.random.seed(7)
+    state = np.random.get_state()[1].copy()
+    fixed = random_object_qpos(pose, 2, include_position=False, include_rotation=False)
+    assert np.array_equal(np.random.get_state()[1], state)  # nothing drawn
+    assert np.allclose(fixed, np.tile([0.5, 0.1, 0.03, np.cos(0.3), 0, 0, np.sin(0.3)], (2, 1)))
