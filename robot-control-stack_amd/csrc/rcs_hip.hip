@@ -180,9 +180,11 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
     if (s->box.present) {
-      // scenes with a free box: the FR3 + hand archetype only (rcsh_sim_add_free_box checks)
+      // scenes with a free box: FR3 + hand, and the 7-dof arm with dry joint friction (rcsh_sim_add_free_box checks)
       if constexpr (T::NARM == 7 && T::GRIP)
         hipLaunchKernelGGL((k_run_team<T, false, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+      else if constexpr (T::NARM == 7)
+        hipLaunchKernelGGL((k_run_team<T, true, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     } else if (team && s->dm.has_friction)
       hipLaunchKernelGGL((k_run_team<T, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     else if (team)
@@ -784,8 +786,11 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   REQUIRE_SIM(s);
   if (!d) return fail(RCSH_ERR_ARG, "null free-box description");
   if (s->box.present) return fail(RCSH_ERR_STATE, "a free box is already attached to this sim");
-  if (!(s->narm == 7 && s->grip)) return fail(RCSH_ERR_MODEL, "free bodies are compiled for the FR3 + hand archetype only");
-  if (s->dm.has_friction) return fail(RCSH_ERR_MODEL, "free bodies are not compiled for models with dry joint friction");
+  if (!(s->narm == 7 && (s->grip ? !s->dm.has_friction : s->dm.has_friction != 0)))
+    return fail(RCSH_ERR_MODEL, "free bodies are compiled for two archetypes: 7-dof arm + two-finger gripper without dry joint friction (FR3), "
+                                "7-dof arm without gripper with it (xArm7)");
+  if (s->dm.has_friction && d->noslip_iterations > 0)
+    return fail(RCSH_ERR_MODEL, "the noslip pass over dry joint friction rows is not built: scenes with frictionloss need noslip_iterations = 0");
   if (s->kernel == RCSH_KERNEL_LANE) return fail(RCSH_ERR_MODEL, "the lane kernel does not step free bodies");
   if (!d->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
   if (!(d->mass > 0) || !(d->inertia[0] > 0) || !(d->inertia[1] > 0) || !(d->inertia[2] > 0) || !(d->impratio > 0))

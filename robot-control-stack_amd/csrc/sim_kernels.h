@@ -839,6 +839,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
         // 0.5 f^2 R of the robot's active joint-limit rows at the constrained solution (f = -D r, R = 1 / D)
         const int tl = t < T::NL ? t : T::NL - 1;
         const double rr = st.limS(tl) * st.xs(tl) - st.limA(tl);
+        // (models with dry friction rows run without the noslip pass, the only reader of this sum: rcsh_sim_add_free_box)
         double imp0 = t < T::NL && st.limS(tl) != 0.0 && rr < 0 ? 0.5 * st.limD(tl) * rr * rr : 0.0;
         imp0 = quad_sum(imp0);  // sum over the team's 16 lanes: quads, then rotations by 4 and 8 within the row
         imp0 += row_rotate<4>(imp0);

@@ -38,6 +38,7 @@ scenes: dict[str, Scene] = {
     "fr3_empty_world": _scene("fr3_empty_world", common.RobotType.FR3),
     "fr3_simple_pick_up": _scene("fr3_simple_pick_up", common.RobotType.FR3),
     "xarm7_empty_world": _scene("xarm7_empty_world", common.RobotType.XArm7),
+    "xarm7_box_world": _scene("xarm7_box_world", common.RobotType.XArm7),
 }
 
 __all__ = ["__version__", "common", "sim", "envs", "scenes", "mjcf", "camera", "render"]

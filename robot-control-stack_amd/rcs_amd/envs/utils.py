@@ -16,7 +16,7 @@ def default_sim_robot_cfg(scene: str = "fr3_empty_world", idx: str = "0") -> sim
     return cfg
 
 
-def xarm7_sim_robot_cfg() -> sim.SimRobotConfig:
+def xarm7_sim_robot_cfg(scene: str = "xarm7_empty_world") -> sim.SimRobotConfig:
     """The xArm7 configuration of the reference's example (examples/xarm7/xarm7_env_joint_control.py:41-64): plain
     joint / actuator names (no add_id suffix), no collision geoms, no gripper."""
     import rcs_amd
@@ -28,8 +28,8 @@ def xarm7_sim_robot_cfg() -> sim.SimRobotConfig:
     cfg.robot_type = rcs_amd.common.RobotType.XArm7
     cfg.attachment_site = "attachment_site"
     cfg.arm_collision_geoms = []
-    cfg.mjcf_scene_path = rcs_amd.scenes["xarm7_empty_world"].mjb
-    cfg.kinematic_model_path = rcs_amd.scenes["xarm7_empty_world"].mjcf_robot
+    cfg.mjcf_scene_path = rcs_amd.scenes[scene].mjb
+    cfg.kinematic_model_path = rcs_amd.scenes[scene].mjcf_robot
     return cfg
 
 

@@ -40,6 +40,61 @@ XARM7_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes",
 PICKUP_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "fr3_simple_pick_up", "scene.xml")
 
 
+def run_xarm7_box_parity(n_envs=16, n_calls=8, k=25, seed=0, width=48, height=32):
+    """xarm7_box_world: the 7-dof arm with dry joint friction next to the free cube (elliptic cones, no noslip pass), kernel vs
+    oracle, plus a depth frame of the fixed camera (floor, cube; the xArm7 scene carries no robot shapes)."""
+    from rcs_amd import render
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import xarm7_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    import rcs_render_oracle as RO
+    from rcs_env_oracle import XARM7
+
+    scene = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "xarm7_box_world", "scene.xml")
+    cfg = xarm7_sim_robot_cfg("xarm7_box_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    robot = S.SimRobot(simu, None, cfg)
+    cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", resolution_width=width, resolution_height=height)}, physical_units=True)
+    cm = compile_mjcf(scene)
+    osims = [O.Sim(cm, XARM7["joints"], XARM7["actuators"], XARM7["site"], XARM7["base"], XARM7["q_home"], None, arm_collision_geoms=[]) for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    qb = np.zeros((n_envs, 7))
+    qb[:, 0] = 0.45 + rng.uniform(-0.1, 0.1, n_envs)
+    qb[:, 1] = rng.uniform(-0.1, 0.1, n_envs)
+    qb[:, 2] = rng.uniform(0.0144, 0.08, n_envs)
+    qb[:, 3:] = rng.normal(size=(n_envs, 4)) * np.array([1.0, 0.2, 0.2, 1.0])
+    vb = np.concatenate([rng.uniform(-0.4, 0.4, (n_envs, 3)), rng.uniform(-3, 3, (n_envs, 3))], axis=1)
+    simu.set_free_joint_qpos("box_joint", qb)
+    simu.set_free_joint_qvel("box_joint", vb)
+    for e, o in enumerate(osims):
+        o.box_qpos, o.box_qvel = qb[e], vb[e]
+    rep = {"max_abs_box": 0.0, "max_abs_robot_qpos": 0.0, "max_ncon": 0, "zones": set(), "depth_mismatch": 0, "cube_pixels": 0}
+    for _ in range(n_calls):
+        tgt = np.asarray(XARM7["q_home"]) + rng.uniform(-0.2, 0.2, (n_envs, 7))
+        robot.set_joint_position(tgt)
+        simu.step(k)
+        qk, qr = simu.free_joint_qpos("box_joint"), simu.qpos
+        for e, o in enumerate(osims):
+            o.set_joint_position(tgt[e])
+            o.step(k)
+            bd = o.s.d.box
+            rep["max_ncon"] = max(rep["max_ncon"], int(bd.ncon))
+            rep["zones"].update(int(z) for z in bd.zone[: bd.ncon])
+            rep["max_abs_box"] = max(rep["max_abs_box"], float(np.abs(qk[e] - o.box_qpos).max()))
+            rep["max_abs_robot_qpos"] = max(rep["max_abs_robot_qpos"], float(np.abs(qr[e] - o.qpos[:7]).max()))
+    data = cs.get_latest_frames().frames["side"].camera.depth.data
+    link, pos, rot, fovy = render.camera_in_link(cm, "side_cam")
+    for e, o in enumerate(osims):
+        dgl, mm, _, _ = RO.render_depth(cs._scene, (link, pos, rot, fovy, width, height), RO.oracle_frames(o, cm))
+        rep["depth_mismatch"] += int((data[e, ..., 0] != mm).sum())
+        floor_only = RO.render_depth(cs._scene, (link, pos, rot, fovy, width, height), {**RO.oracle_frames(o, cm), -2: (np.eye(3), np.array([0, 0, -9.0]))})[1]
+        rep["cube_pixels"] += int((mm != floor_only).sum())
+    simu.close()
+    return rep
+
+
 def run_free_box_parity(n_envs=32, n_calls=10, k=25, seed=0, kick=True):
     """The free box of the pick-up scene, kernel vs oracle: every environment starts the box at a random pose near the
     floor (some penetrating, some tilted, some in the air) with a random twist, the arm holds its home pose; Sim.step(k)
@@ -225,10 +280,10 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    if robot == "xarm7":
+    if robot.startswith("xarm7"):
         gripper = False
     venv = SimEnvCreator()(
-        mode, xarm7_sim_robot_cfg() if robot == "xarm7" else default_sim_robot_cfg("fr3_empty_world"),
+        mode, xarm7_sim_robot_cfg("xarm7_box_world" if robot == "xarm7_box" else "xarm7_empty_world") if robot.startswith("xarm7") else default_sim_robot_cfg("fr3_empty_world"),
         gripper_cfg=default_sim_gripper_cfg() if gripper else None,
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None,
         relative_to=RelativeTo.LAST_STEP if relative_to == "last_step" else RelativeTo.CONFIGURED_ORIGIN,

@@ -604,3 +604,16 @@ def test_task_env_with_random_object_pos(kernel):
     env.reset()
     assert np.allclose(env.sim.free_joint_qpos("box_joint")[:, :2], [0.4, 0.1], atol=1e-6)
     env.close()
+
+
+def test_xarm7_with_free_box_and_camera(kernel):
+    """The builder-authored xArm7 + cube scene (no reference scene exists): friction-row Newton for the
+    arm and the cube's contact solve in one launch, and a depth frame of both."""
+    import parity_util as pu
+
+    if kernel == "lane":
+        pytest.skip("scene with a free body: team kernel only")
+    rep = pu.run_xarm7_box_parity(n_envs=16, n_calls=8, k=25, seed=4)
+    assert rep["max_ncon"] == 4 and {1, 2} <= rep["zones"], rep
+    assert rep["max_abs_box"] < 1e-6 and rep["max_abs_robot_qpos"] < 1e-6, rep
+    assert rep["depth_mismatch"] <= 3 and rep["cube_pixels"] > 16, rep
