@@ -134,9 +134,10 @@ def main() -> None:
                     help="env.reset() every this many steps (inside the timed region; resets are not counted as env-steps). "
                          "Default: none for joints; 10 for cartesian, as the reference's examples loop (reset + 10 steps) -- a longer "
                          "random walk of Cartesian targets leaves the workspace and the CLIK then runs to its 1000-iteration cap")
-    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box"], default="fr3",
+    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box", "mixed"], default="fr3",
                     help="xarm7: 7-dof arm with dry joint friction, no gripper; xarm7_box: the same next to a free cube with floor contacts "
-                         "(builder-authored scene xarm7_box_world, camera side_cam) (not the headline)")
+                         "(builder-authored scene xarm7_box_world, camera side_cam); mixed: even ranks FR3, odd ranks xArm7 -- sharding by robot type, "
+                         "one specialised kernel per GPU, as BASELINE configs[4] asks (not the headline)")
     ap.add_argument("--task", choices=["none", "pick_up"], default="none",
                     help="pick_up = the registered gym task rcs/FR3SimplePickUpSim-v0 (fr3_simple_pick_up scene: free cube on the floor with "
                          "elliptic-cone contacts + noslip, RandomCubePos on reset, PickCubeSuccessWrapper reward; relative TRPY control, 30 Hz); "
@@ -180,6 +181,9 @@ def main() -> None:
 
     n = args.envs
     T = args.steps + args.warmup
+    mixed = args.robot == "mixed"
+    if mixed:
+        args.robot = "fr3" if rank % 2 == 0 else "xarm7"  # same observation width (21), so one all-gather serves both
     if args.task == "pick_up":
         from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
 
@@ -323,7 +327,7 @@ def main() -> None:
                 "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off"
                              if args.control == "joints" else
                              f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
-                             ).replace("fr3_empty_world", {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)"}[args.robot] if args.task == "none" else
+                             ).replace("fr3_empty_world", ("fr3_empty_world on even ranks / xarm7_empty_world on odd ranks" if mixed else {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)"}[args.robot]) if args.task == "none" else
                                        "fr3_simple_pick_up (free cube: plane-box contacts, elliptic cones, noslip; RandomCubePos + PickCubeSuccessWrapper)"),
                 "mode": "async_control 30Hz (17 substeps/env-step)" if args.mode == "async" else "step_until_convergence (cap 500)",
                 "envs_per_gpu": n,
