@@ -1,12 +1,11 @@
 // sim_kernels.h -- the batched Sim / SimRobot / SimGripper / Gymnasium-loop kernels.
 //
-// One GPU thread owns one environment for the whole launch: it loads the environment's
-// state from the SoA arrays ([field][env], so a wave's 64 loads of one field are one
-// contiguous 512-byte segment), keeps it in registers across all physics substeps of
-// the call, and writes it back once.  The reference's per-substep callback scheduler
-// (reference src/sim/sim.cpp:14-61) is evaluated in-register with the same
-// double-precision timestamps and strict '>' compares, so callback cadence -- and with
-// it every flag and substep count -- follows the reference.
+// One launch is one call of the reference's API for every environment: a team of 16 lanes (k_run_team, the default)
+// or one lane (k_run) owns an environment for the whole launch, loads its state from the SoA arrays ([field][env]),
+// keeps it in LDS / registers across all physics substeps of the call, and writes it back once.  The reference's
+// per-substep callback scheduler (reference src/sim/sim.cpp:14-61) is evaluated by the environment's leader lane with
+// the same double-precision timestamps and strict '>' compares, so callback cadence -- and with it every flag and
+// substep count -- follows the reference.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -787,7 +786,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
                             : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
     }
   }
-  bool have_frames_box = false;  // the first substep of this launch is done (placement of the box on reset)
+  bool box_placed = false;  // env.reset() with RandomCubePos: the box got its pose after the first of the two substeps
   bool more = leader && budget > 0;
   double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
   const bool has_cb = P.robot.present && P.robot.conv_registered;
@@ -848,9 +847,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
         box_substep(lbt[0].box, bs, m.gravity, timestep, imp0, t);
       }
       __syncthreads();
-      if (place_box && live && !have_frames_box) {
+      if (place_box && live && !box_placed) {
         if (t < 7) bs[kBoxQ + t] = op.box_qpos[(size_t)e * 7 + t];  // position only: velocity and warm start stay
-        have_frames_box = true;
+        box_placed = true;
       }
     }
     if (leader && stepping) {
