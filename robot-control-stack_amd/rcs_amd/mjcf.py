@@ -237,8 +237,18 @@ class Model:
 # ------------------------------------------------------------------------ compiler
 
 
+def find_data_file(dirs: list[str], name: str) -> str | None:
+    """First of `dirs` (the scene's own directory, then those of the files it includes) that holds `name`."""
+    for d in dirs:
+        f = os.path.join(d, name)
+        if os.path.exists(f):
+            return f
+    return None
+
+
 class _Compiler:
     def __init__(self, path: str):
+        self.data_dirs = [os.path.dirname(os.path.abspath(path))]
         self.path = os.path.abspath(path)
         self.root = self._load(self.path)
         self.angle_deg = True  # MuJoCo default: degrees
@@ -270,6 +280,7 @@ class _Compiler:
         for child in children:
             if child.tag == "include":
                 inc_path = os.path.join(base, child.attrib["file"])
+                self.data_dirs.append(os.path.dirname(os.path.abspath(inc_path)))  # mesh-derived tables may live beside an included file
                 inc_root = ET.parse(inc_path).getroot()
                 self._expand_includes(inc_root, os.path.dirname(inc_path))
                 idx = list(elem).index(child)
@@ -673,6 +684,7 @@ class _Compiler:
         self._parse_rest()
         m = self._emit()
         m.free_bodies = self.free_bodies  # type: ignore[attr-defined]
+        m.data_dirs = list(self.data_dirs)  # type: ignore[attr-defined]
         return m
 
     def _split_free_bodies(self):
@@ -854,8 +866,8 @@ class _Compiler:
         m.geom_mesh = [g["mesh"] for g in self.geoms]  # type: ignore[attr-defined]
         # collision vertex sets of mesh geoms (hull vertices, numbers only; tools/make_collision_vertices.py)
         vadr, vnum, verts = [], [], []
-        vfile = os.path.join(os.path.dirname(self.path), "collision_vertices.npz")
-        table = dict(np.load(vfile)) if os.path.exists(vfile) else {}
+        vfile = find_data_file(self.data_dirs, "collision_vertices.npz")
+        table = dict(np.load(vfile)) if vfile else {}
         for g in self.geoms:
             v = table.get(g["mesh"]) if g["type"] == GEOM_MESH else None
             vadr.append(sum(len(x) for x in verts))

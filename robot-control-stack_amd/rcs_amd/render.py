@@ -18,7 +18,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .mjcf import GEOM_BOX, GEOM_MESH, GEOM_PLANE, Model, quat_mul, quat_to_mat
+from .mjcf import GEOM_BOX, GEOM_MESH, GEOM_PLANE, Model, find_data_file, quat_mul, quat_to_mat
 
 LINK_WORLD, LINK_FREE_BODY = -1, -2
 SHAPE_PLANE, SHAPE_BOX, SHAPE_HULL = 0, 1, 2
@@ -63,8 +63,8 @@ class RenderScene:
 
 def build_render_scene(cm: Model, scene_dir: str) -> RenderScene:
     A = cm.arrays
-    hull_file = os.path.join(scene_dir, "render_hulls.npz")
-    hulls = dict(np.load(hull_file)) if os.path.exists(hull_file) else {}
+    hull_file = find_data_file([scene_dir, *getattr(cm, "data_dirs", [])], "render_hulls.npz")
+    hulls = dict(np.load(hull_file)) if hull_file else {}
     rows, planes, names = [], [], []
 
     def add(shape, link, p, q, size=(0, 0, 0), pl=None, sphere=(0, 0, 0, -1.0), name=""):

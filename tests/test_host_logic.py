@@ -358,7 +358,10 @@ def test_render_scene_tables():
     assert rs.link[names["fr3_link0_collision_0"]] == render.LINK_WORLD and rs.link[names["hand_c_0"]] == 6
     assert rs.link[names["finger_0_left_0"]] == 7 and rs.link[names["finger_0_right_0"]] == 8
     assert np.allclose(rs.pos[names["hand_c_0"]], [0, 0, 0.107])  # fr3_link8 + hand flange folded into link 7's frame
-    verts = dict(np.load(os.path.join(d, "collision_vertices.npz")))
+    from rcs_amd.mjcf import find_data_file
+
+    assert os.path.dirname(find_data_file(cm.data_dirs, "collision_vertices.npz")).endswith("fr3_empty_world")  # beside the included file
+    verts = dict(np.load(find_data_file(cm.data_dirs, "collision_vertices.npz")))
     for g, name in enumerate(rs.names):
         if rs.shape[g] != render.SHAPE_HULL:
             continue
