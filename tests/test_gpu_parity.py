@@ -617,3 +617,38 @@ def test_xarm7_with_free_box_and_camera(kernel):
     assert rep["max_ncon"] == 4 and {1, 2} <= rep["zones"], rep
     assert rep["max_abs_box"] < 1e-6 and rep["max_abs_robot_qpos"] < 1e-6, rep
     assert rep["depth_mismatch"] <= 3 and rep["cube_pixels"] > 16, rep
+
+
+def test_pick_task_batch_is_position_independent(kernel):
+    """The pick-up task at BASELINE's batch size (4096 environments): 32 distinct (cube placement, action stream) pairs tiled
+    128x over the batch; every copy equals the first BIT FOR BIT wherever it sits (lane, team, wavefront, XCD) -- robot,
+    cube, reward, depth pixels -- and a masked reset leaves the unmasked environments' cubes untouched."""
+    from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
+
+    if kernel == "lane":
+        pytest.skip("scene with a free body: team kernel only")
+    n, base, steps = 4096, 32, 3
+    env = FR3SimplePickUpSimEnvCreator()(n_envs=n, resolution=(16, 12), cam_list=["wrist_0"])
+    rng = np.random.default_rng(11)
+    np.random.seed(3)
+    box = np.tile(env.draw_box_qpos()[:base], (n // base, 1))
+    obs, info = env.reset(options={"box_qpos": box})
+
+    def tiled(arr):
+        a = np.asarray(arr).reshape(n // base, base, -1)
+        return np.array_equal(a, np.broadcast_to(a[0], a.shape))
+
+    assert tiled(obs["frames"]["wrist_0"]["depth"]["data"]) and tiled(env.sim.free_joint_qpos("box_joint"))
+    for t in range(steps):
+        a = np.tile(np.concatenate([rng.uniform(-0.05, 0.05, (base, 3)), rng.uniform(-0.1, 0.1, (base, 3))], axis=1), (n // base, 1))
+        g = np.tile(rng.uniform(0, 1, base).astype(np.float32), n // base)
+        obs, reward, term, trunc, info = env.step({"xyzrpy": a, "gripper": g})
+        for arr in (env.sim.qpos, env.sim.qvel, env.sim.free_joint_qpos("box_joint"), env.sim.free_joint_qvel("box_joint"), reward,
+                    info["box_qpos"], obs["tquat"], obs["frames"]["wrist_0"]["depth"]["data"]):
+            assert tiled(arr), "replicas diverged"
+    before = env.sim.free_joint_qpos("box_joint").copy()
+    mask = np.arange(n) % 5 == 0
+    env.reset(options={"box_qpos": box}, mask=mask)
+    after = env.sim.free_joint_qpos("box_joint")
+    assert np.array_equal(after[~mask], before[~mask]) and not np.array_equal(after[mask], before[mask])
+    env.close()
