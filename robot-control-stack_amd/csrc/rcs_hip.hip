@@ -71,6 +71,7 @@ struct rcsh_sim {
   RenderShape* d_rshapes = nullptr;
   double* d_rplanes = nullptr;
   double* d_frames = nullptr;
+  double* d_wframes = nullptr;  // world frames of the shapes + camera per environment (k_shape_frames)
   std::vector<RenderCam> cams;
   void* d_image = nullptr;  // staging for the host-pointer render call
   size_t image_cap = 0;  // device copy of {box, task} (scenes with a free box)
@@ -385,7 +386,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
-  hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_image);
+  hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
@@ -1051,12 +1052,13 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
     for (int k = 0; k < 4; ++k) r.sphere[k] = d->sphere[4 * i + k];
   }
   HIP_TRY(hipSetDevice(s->device));
-  hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames);
-  s->d_rshapes = nullptr; s->d_rplanes = nullptr; s->d_frames = nullptr;
+  hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes);
+  s->d_rshapes = nullptr; s->d_rplanes = nullptr; s->d_frames = nullptr; s->d_wframes = nullptr;
   const int np = d->nplanes > 0 ? d->nplanes : 1;
   HIP_TRY(hipMalloc(&s->d_rshapes, sizeof(RenderShape) * d->nshape));
   HIP_TRY(hipMalloc(&s->d_rplanes, sizeof(double) * 4 * np));
   HIP_TRY(hipMalloc(&s->d_frames, sizeof(double) * 12 * (size_t)(s->nl + 1) * s->n));
+  HIP_TRY(hipMalloc(&s->d_wframes, sizeof(double) * kShapeFrameDoubles * (size_t)(d->nshape + 1) * s->n));
   HIP_TRY(hipMemcpyAsync(s->d_rshapes, sh.data(), sizeof(RenderShape) * d->nshape, hipMemcpyHostToDevice, s->stream));
   if (d->nplanes > 0) HIP_TRY(hipMemcpyAsync(s->d_rplanes, d->planes, sizeof(double) * 4 * d->nplanes, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1096,8 +1098,10 @@ int rcsh_camera_render_dev(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_link_frames launch: ") + hipGetErrorString(err));
+  hipLaunchKernelGGL(k_shape_frames, dim3(grid_for(s->n * (s->rscene.nshape + 1))), dim3(kBlock), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
+                     s->d_wframes);
   const int blocks_per_env = ((cam.width + 15) / 16) * ((cam.height + 15) / 16);
-  hipLaunchKernelGGL(k_render_depth, dim3((unsigned)blocks_per_env * (unsigned)s->n), dim3(256), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
+  hipLaunchKernelGGL(k_render_depth, dim3((unsigned)blocks_per_env * (unsigned)s->n), dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n,
                      depth_gl, depth_mm, cam_pose);
   err = hipGetLastError();
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_render_depth launch: ") + hipGetErrorString(err));

@@ -117,12 +117,39 @@ __device__ __forceinline__ void in_world(const double* frames, int link, int nfr
   p[0] += f[9]; p[1] += f[10]; p[2] += f[11];
 }
 
+// world frames of the scene's shapes and of one camera for every environment: wf[e][g] = R (9) p (3) sphere centre (3)
+// radius (1), g < nshape; entry nshape is the camera (R, p).  One thread per (environment, entry).
+constexpr int kShapeFrameDoubles = 16;
+__global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* frames, int n, double* wf) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_env = sc.nshape + 1;
+  if (idx >= n * per_env) return;
+  const int e = idx / per_env, g = idx % per_env;
+  const double* fe = frames + (size_t)e * sc.nframes * 12;
+  double* out = wf + (size_t)idx * kShapeFrameDoubles;
+  double R[9], p[3];
+  if (g == sc.nshape) {
+    in_world(fe, cam.link, sc.nframes, cam.pos, cam.rot, R, p);
+    for (int k = 0; k < 4; ++k) out[12 + k] = 0.0;
+  } else {
+    const RenderShape& sh = sc.shapes[g];
+    in_world(fe, sh.link, sc.nframes, sh.pos, sh.rot, R, p);
+    double c[3];
+    mulmv(R, sh.sphere, c);
+    for (int k = 0; k < 3; ++k) out[12 + k] = c[k] + p[k];
+    out[15] = sh.sphere[3];
+  }
+  for (int k = 0; k < 9; ++k) out[k] = R[k];
+  for (int k = 0; k < 3; ++k) out[9 + k] = p[k];
+}
+
 // depth_gl: [n][H][W] float32 in [0, 1], rows bottom-up (mjr_readPixels); depth_mm: [n][H][W] uint16, rows top-down,
 // millimetres (SimCameraSet with physical_units); cam_pose: [n][12] world rotation (9) and position (3) of the camera
 // (mjData.cam_xmat / cam_xpos).  Any of the three may be null.
-__global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam cam, const double* frames, int n, float* depth_gl,
+__global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam cam, const double* wf, int n, float* depth_gl,
                                                       uint16_t* depth_mm, double* cam_pose) {
-  __shared__ double wR[kMaxShapes][9], wp[kMaxShapes][3], wc[kMaxShapes][4], cR[9], cp[3];
+  __shared__ double lw[(kMaxShapes + 1) * kShapeFrameDoubles];  // this environment's rows of wf (k_shape_frames)
+  __shared__ uint32_t tile_shapes;  // bit g: shape g can be seen from this tile
   const int W = cam.width, H = cam.height;
   // a workgroup is a 16 x 16 pixel tile, each of its four wavefronts an 8 x 8 sub-tile: the rays of a wavefront stay
   // together, so they mostly agree on which shapes they have to look at
@@ -133,32 +160,44 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
   const int col = (tile % tiles_x) * 16 + (wave % 2) * 8 + lane % 8;
   const int row = (tile / tiles_x) * 16 + (wave / 2) * 8 + lane / 8;  // row 0 = bottom of the image (OpenGL window coordinates)
-  const double* fe = frames + (size_t)e * sc.nframes * 12;
-  if (threadIdx.x < sc.nshape) {
-    const RenderShape& sh = sc.shapes[threadIdx.x];
-    double R[9], p[3];
-    in_world(fe, sh.link, sc.nframes, sh.pos, sh.rot, R, p);
-    for (int k = 0; k < 9; ++k) wR[threadIdx.x][k] = R[k];
-    for (int k = 0; k < 3; ++k) wp[threadIdx.x][k] = p[k];
-    double c[3];
-    mulmv(R, sh.sphere, c);
-    for (int k = 0; k < 3; ++k) wc[threadIdx.x][k] = c[k] + p[k];
-    wc[threadIdx.x][3] = sh.sphere[3];
+  const double ty = cam.tan_half_fovy, tx = ty * (double)W / (double)H;
+  {
+    const int words = (sc.nshape + 1) * kShapeFrameDoubles;
+    const double* src = wf + (size_t)e * words;
+    for (int k = threadIdx.x; k < words; k += 256) lw[k] = src[k];
   }
-  if (threadIdx.x == 64) {
-    double R[9], p[3];
-    in_world(fe, cam.link, sc.nframes, cam.pos, cam.rot, R, p);
-    for (int k = 0; k < 9; ++k) cR[k] = R[k];
-    for (int k = 0; k < 3; ++k) cp[k] = p[k];
-    if (cam_pose && tile == 0) {
-      for (int k = 0; k < 9; ++k) cam_pose[(size_t)e * 12 + k] = R[k];
-      for (int k = 0; k < 3; ++k) cam_pose[(size_t)e * 12 + 9 + k] = p[k];
+  __syncthreads();
+  const double* cR = lw + sc.nshape * kShapeFrameDoubles;
+  const double* cp = cR + 9;
+  if (threadIdx.x < 64) {
+    // wavefront 0, thread g: does shape g's bounding sphere reach into the pyramid of this tile's rays (four planes
+    // through the camera, and the near plane)?
+    bool visible = false;
+    if (threadIdx.x < sc.nshape) {
+      const double* w = lw + threadIdx.x * kShapeFrameDoubles;
+      const double r = w[15];
+      visible = true;
+      if (r >= 0) {
+        // sphere centre in the camera frame; the tile spans x in [xl, xr] (-z), y in [yb, yt] (-z)
+        const double q[3] = {w[12] - cp[0], w[13] - cp[1], w[14] - cp[2]};
+        const double x = cR[0] * q[0] + cR[3] * q[1] + cR[6] * q[2], y = cR[1] * q[0] + cR[4] * q[1] + cR[7] * q[2], z = cR[2] * q[0] + cR[5] * q[1] + cR[8] * q[2];
+        const int c0 = (tile % tiles_x) * 16, r0 = (tile / tiles_x) * 16;
+        const double xl = (2.0 * c0 / W - 1.0) * tx, xr = (2.0 * (c0 + 16) / W - 1.0) * tx;
+        const double yb = (2.0 * r0 / H - 1.0) * ty, yt = (2.0 * (r0 + 16) / H - 1.0) * ty;
+        visible = -z + r >= sc.znear && x + xl * z >= -r * sqrt(1 + xl * xl) && -x - xr * z >= -r * sqrt(1 + xr * xr) &&
+                  y + yb * z >= -r * sqrt(1 + yb * yb) && -y - yt * z >= -r * sqrt(1 + yt * yt);
+      }
+    }
+    const uint64_t m = __ballot(visible);
+    if (threadIdx.x == 0) {
+      tile_shapes = (uint32_t)m;
+      if (cam_pose && tile == 0)
+        for (int k = 0; k < 12; ++k) cam_pose[(size_t)e * 12 + k] = cR[k];
     }
   }
   __syncthreads();
   if (col >= W || row >= H) return;
   // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
-  const double ty = cam.tan_half_fovy, tx = ty * (double)W / (double)H;
   const double dc[3] = {(2.0 * (col + 0.5) / W - 1.0) * tx, (2.0 * (row + 0.5) / H - 1.0) * ty, -1.0};
   double d[3];
   mulmv(cR, dc, d);
@@ -166,18 +205,20 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   double best = sc.zfar;
   bool hit = false;
-  for (int g = 0; g < sc.nshape; ++g) {
+  for (uint32_t todo = tile_shapes; todo; todo &= todo - 1) {
+    const int g = __ffs(todo) - 1;
     const RenderShape& sh = sc.shapes[g];
-    if (wc[g][3] >= 0) {
+    const double* w = lw + g * kShapeFrameDoubles;  // R (9) p (3) sphere centre (3) radius
+    if (w[15] >= 0) {
       // bounding sphere: closest approach of the ray to the centre
-      const double oc[3] = {wc[g][0] - o[0], wc[g][1] - o[1], wc[g][2] - o[2]};
+      const double oc[3] = {w[12] - o[0], w[13] - o[1], w[14] - o[2]};
       const double b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
       const double c2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
-      if (c2 * dd - b * b > wc[g][3] * wc[g][3] * dd) continue;
+      if (c2 * dd - b * b > w[15] * w[15] * dd) continue;
     }
     // ray in the shape's frame
-    const double* R = wR[g];
-    const double om[3] = {o[0] - wp[g][0], o[1] - wp[g][1], o[2] - wp[g][2]};
+    const double* R = w;
+    const double om[3] = {o[0] - w[9], o[1] - w[10], o[2] - w[11]};
     const double lo[3] = {R[0] * om[0] + R[3] * om[1] + R[6] * om[2], R[1] * om[0] + R[4] * om[1] + R[7] * om[2], R[2] * om[0] + R[5] * om[1] + R[8] * om[2]};
     const double ld[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2], R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
     double t0 = sc.znear, t1 = best;
