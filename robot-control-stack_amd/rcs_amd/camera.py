@@ -96,9 +96,12 @@ class SimCameraSet:
         self._ids: dict[str, int] = {}
         self._fovy: dict[str, float] = {}
         for name, cfg in cameras.items():
-            if cfg.type != CameraType.fixed:
-                raise NotImplementedError("only fixed cameras (named MJCF cameras) are built")
-            link, pos, rot, fovy = render.camera_in_link(cm, cfg.identifier)
+            if cfg.type == CameraType.default_free:  # camera.cpp:41-42: mjv_defaultFreeCamera
+                link, pos, rot, fovy = render.default_free_camera(cm)
+            elif cfg.type == CameraType.fixed:
+                link, pos, rot, fovy = render.camera_in_link(cm, cfg.identifier)
+            else:
+                raise NotImplementedError("free / tracking cameras driven by an mjvCamera are not built (fixed and default_free are)")
             c = _lib.CameraDesc()
             c.link, c.width, c.height, c.fovy_deg = link, cfg.resolution_width, cfg.resolution_height, fovy
             c.pos[:] = [float(x) for x in pos]

@@ -37,3 +37,13 @@ def default_sim_gripper_cfg(idx: str = "0") -> sim.SimGripperConfig:
     cfg = sim.SimGripperConfig()
     cfg.add_id(idx)
     return cfg
+
+
+def default_mujoco_cameraset_cfg():
+    """Reference python/rcs/envs/utils.py:60-70 (256 x 256: "needed for VLAs")."""
+    from ..camera import CameraType, SimCameraConfig
+
+    return {
+        "wrist": SimCameraConfig(identifier="wrist_0", type=CameraType.fixed, frame_rate=10, resolution_width=256, resolution_height=256),
+        "default_free": SimCameraConfig(identifier="", type=CameraType.default_free, frame_rate=10, resolution_width=256, resolution_height=256),
+    }

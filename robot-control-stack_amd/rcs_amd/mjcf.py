@@ -196,8 +196,13 @@ class Model:
     # rendering: mjModel.stat.extent (None: not given -- MuJoCo would derive it from the model's bounding box),
     # mjModel.vis.map.znear / zfar (fractions of extent)
     stat_extent: float | None = None
+    stat_center: np.ndarray | None = None
     vis_znear: float = 0.01
     vis_zfar: float = 50.0
+    # mjModel.vis.global: orientation of the default free camera, its field of view
+    vis_azimuth: float = 90.0
+    vis_elevation: float = -45.0
+    vis_fovy: float = 45.0
     # sizes
     nbody: int = 0
     njnt: int = 0
@@ -754,7 +759,13 @@ class _Compiler:
         for st in self.root.findall("statistic"):
             if "extent" in st.attrib:
                 m.stat_extent = float(st.attrib["extent"])
+            if "center" in st.attrib:
+                m.stat_center = _floats(st.attrib["center"], 3)
         for vis in self.root.findall("visual"):
+            for gl in vis.findall("global"):
+                m.vis_azimuth = float(gl.attrib.get("azimuth", m.vis_azimuth))
+                m.vis_elevation = float(gl.attrib.get("elevation", m.vis_elevation))
+                m.vis_fovy = float(gl.attrib.get("fovy", m.vis_fovy))
             for mp in vis.findall("map"):
                 m.vis_znear = float(mp.attrib.get("znear", m.vis_znear))
                 m.vis_zfar = float(mp.attrib.get("zfar", m.vis_zfar))

@@ -111,3 +111,19 @@ def camera_in_link(cm: Model, name: str):
     A = cm.arrays
     link, p, q = _pose_in_link(cm, int(A["cam_bodyid"][cid]), A["cam_pos"][cid], A["cam_quat"][cid])
     return link, p, quat_to_mat(q).reshape(9), float(A["cam_fovy"][cid])
+
+
+def default_free_camera(cm: Model):
+    """(link, pos, rot[9], fovy_deg) of MuJoCo's default free camera (mjv_defaultFreeCamera + mjv_updateCamera): it looks
+    at stat.center from 1.5 x stat.extent away, along the direction given by vis.global.azimuth / elevation.
+    (MuJoCo's conventions restated from memory -- "verify": forward = (cos el cos az, cos el sin az, sin el),
+    up = (-sin el cos az, -sin el sin az, cos el); the camera frame has -z forward and +y up.)"""
+    if cm.stat_extent is None or cm.stat_center is None:
+        raise RuntimeError("the default free camera needs <statistic center=... extent=...> in the scene")
+    az, el = np.deg2rad(cm.vis_azimuth), np.deg2rad(cm.vis_elevation)
+    forward = np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    up = np.array([-np.sin(el) * np.cos(az), -np.sin(el) * np.sin(az), np.cos(el)])
+    right = np.cross(forward, up)
+    rot = np.stack([right, up, -forward], axis=1)  # columns: camera x, y, z in the world
+    pos = np.asarray(cm.stat_center) - 1.5 * cm.stat_extent * forward
+    return LINK_WORLD, pos, rot.reshape(9), float(cm.vis_fovy)

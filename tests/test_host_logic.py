@@ -424,3 +424,20 @@ def test_random_object_pos_draws_follow_the_reference():
     fixed = random_object_qpos(pose, 2, include_position=False, include_rotation=False)
     assert np.array_equal(np.random.get_state()[1], state)  # nothing drawn
     assert np.allclose(fixed, np.tile([0.5, 0.1, 0.03, np.cos(0.3), 0, 0, np.sin(0.3)], (2, 1)))
+
+
+def test_default_free_camera_pose():
+    """mjv_defaultFreeCamera as rcs_amd.render restates it: looks at stat.center from 1.5 x extent away, along the
+    scene's vis.global azimuth / elevation (fr3 scenes: 120 / -20 degrees), camera -z forward and +y up."""
+    from rcs_amd import render
+
+    cm = compile_mjcf(SCENE)
+    assert np.allclose(cm.stat_center, [0.3, 0, 0.4]) and (cm.vis_azimuth, cm.vis_elevation, cm.vis_fovy) == (120.0, -20.0, 45.0)
+    link, pos, rot, fovy = render.default_free_camera(cm)
+    R = rot.reshape(3, 3)
+    assert link == render.LINK_WORLD and fovy == 45.0
+    assert np.allclose(R.T @ R, np.eye(3), atol=1e-12) and np.isclose(np.linalg.det(R), 1.0)
+    forward = -R[:, 2]
+    assert np.allclose(pos + 1.5 * forward, [0.3, 0, 0.4])            # the optical axis passes through the centre, 1.5 m away
+    assert np.isclose(np.degrees(np.arcsin(forward[2])), -20.0) and np.isclose(np.degrees(np.arctan2(forward[1], forward[0])), 120.0)
+    assert R[2, 1] > 0 and abs(R[2, 0]) < 1e-12                       # +y of the camera points up, +x is horizontal
