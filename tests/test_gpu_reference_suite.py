@@ -218,3 +218,43 @@ class TestSimEnvsJoints(SimEnvsBase):
         act = {"joints": np.tile(np.array([0, 1.78, 0, -1.45, 0, 0, 0], dtype=np.float32), (N, 1)), "gripper": np.ones(N)}
         _, _, _, _, info = env.step(act)
         self.assert_collision(info)
+
+
+def test_sim_native_self_test(kernel):
+    """src/sim/test.cpp:119-231 (test_sim, disabled in the reference's build): random TCP poses in the ISO cube (centre
+    (0.498, 0, 0.226), edge 0.4 m; roll 0, pitch pi, yaw uniform), `set_cartesian_position` + `step_until_convergence`; where
+    the IK succeeded and the simulation converged the robot is not moving, has arrived, and its TCP is within 3 degrees /
+    1.875 cm of the target.  128 environments x 4 consecutive targets instead of one environment x 100."""
+    import dataclasses
+
+    from rcs_amd import common
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_robot_cfg
+
+    n = 128
+    cfg = dataclasses.replace(default_sim_robot_cfg(), tcp_offset=common.Pose(common.FrankaHandTCPOffset()), seconds_between_callbacks=0.05)
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(async_control=False, realtime=False), n_envs=n)
+    simu.set_kernel(kernel)
+    fr3 = S.SimRobot(simu, None, cfg)
+    simu.step(1)
+    rng = np.random.default_rng(0)
+    checked = 0
+    for _ in range(4):
+        poses = [common.Pose(translation=np.array([0.498, 0.0, 0.226]) + rng.uniform(-0.2, 0.2, 3), rpy_vector=np.array([0.0, np.pi, rng.uniform(-np.pi, np.pi)]))
+                 for _ in range(n)]
+        fr3.set_cartesian_position(np.stack([p.as_vec7() for p in poses]))
+        for _ in range(3):  # a half-turn of joint 7 under its 12 Nm clamp outlasts one 500-substep budget
+            simu.step_until_convergence()
+        state = fr3.get_state()
+        # convergence by a collision callback (targets 3 cm above the floor with the hand pointing down) is convergence of
+        # the any-list, not arrival: the reference's loop has no such case only because its arm rests on the floor there
+        ok = state.ik_success & simu.is_converged() & ~state.collision
+        assert not state.is_moving[ok].any(), "FR3 should not be moving at the end of a step"
+        assert state.is_arrived[ok].all(), "FR3 should be arrived at the end of a step"
+        current = fr3.get_cartesian_position()
+        for e in np.flatnonzero(ok):
+            cur = common.Pose(translation=current[e][:3], quaternion=current[e][3:])
+            assert poses[e].is_close(cur, 3 * np.pi / 180.0, 1.875 / 100.0), (e, poses[e].xyzrpy(), cur.xyzrpy())
+        checked += int(ok.sum())
+    assert checked > n  # (of 4 n: unreachable targets, floor collisions and moves that are still under way are skipped)
+    simu.close()
