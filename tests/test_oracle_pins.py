@@ -23,46 +23,57 @@ def cm():
     return compile_mjcf(SCENE)
 
 
-def _pose(m):
-    return O.Pose(pose_matrix=np.array(m, dtype=np.float64))
+def _pose(m, P=None):
+    return (P or O.Pose)(pose_matrix=np.array(m, dtype=np.float64))
+
+
+@pytest.fixture(params=["oracle", "host"])
+def P(request):
+    """The Pose class under test: the oracle's restatement, and the host-side mirror a user of rcs_amd works with
+    (rcs_amd.common.Pose) -- the reference's test_common.py cases hold for both."""
+    if request.param == "oracle":
+        return O.Pose
+    from rcs_amd import common
+
+    return common.Pose
 
 
 # ---- (vi) Pose known answers, test_common.py (exact where the reference asserts array_equal)
-def test_identity_quaternion_is_xyzw():
-    assert np.array_equal(O.Pose().rotation_q(), [0, 0, 0, 1])
+def test_identity_quaternion_is_xyzw(P):
+    assert np.array_equal(P().rotation_q(), [0, 0, 0, 1])
 
 
-def test_pose_is_close_cases():
+def test_pose_is_close_cases(P):
     for c in PINS["pose_is_close_cases"]:
-        assert _pose(c["a"]).is_close(_pose(c["b"]), eps_t=c["eps_t"]) == c["expected"]
+        assert _pose(c["a"], P).is_close(_pose(c["b"], P), eps_t=c["eps_t"]) == c["expected"]
 
 
-def test_pose_multiply_inverse_matrix_exact():
+def test_pose_multiply_inverse_matrix_exact(P):
     c = PINS["pose_multiply"]
-    assert np.array_equal((_pose(c["a"]) * _pose(c["b"])).pose_matrix(), np.array(c["expected"], dtype=float))
+    assert np.array_equal((_pose(c["a"], P) * _pose(c["b"], P)).pose_matrix(), np.array(c["expected"], dtype=float))
     c = PINS["pose_inverse"]
-    assert np.array_equal(_pose(c["a"]).inverse().pose_matrix(), np.array(c["expected"], dtype=float))
-    p = O.Pose(quaternion=[0, 0, 0, 1.0], translation=[1.0, 1.0, 1.0])
+    assert np.array_equal(_pose(c["a"], P).inverse().pose_matrix(), np.array(c["expected"], dtype=float))
+    p = P(quaternion=np.array([0, 0, 0, 1.0]), translation=np.array([1.0, 1.0, 1.0]))
     assert np.array_equal(p.pose_matrix(), [[1, 0, 0, 1], [0, 1, 0, 1], [0, 0, 1, 1], [0, 0, 0, 1]])
 
 
-def test_interpolate_full_progress():
-    a = O.Pose(rotation=np.eye(3), translation=[0, 0, 0])
-    b = O.Pose(rotation=np.eye(3), translation=[1.0, 1.0, 1.0])
+def test_interpolate_full_progress(P):
+    a = P(rotation=np.eye(3), translation=np.zeros(3))
+    b = P(rotation=np.eye(3), translation=np.array([1.0, 1.0, 1.0]))
     r = a.interpolate(b, 1.0)
     assert np.array_equal(r.rotation_m(), np.eye(3)) and np.array_equal(r.translation(), [1.0, 1.0, 1.0])
 
 
 # ---- (iv) home_m: xyzrpy round trip (test_common.py:198-218)
-def test_home_m_rpy_round_trip():
+def test_home_m_rpy_round_trip(P):
     home_m = np.array(PINS["home_m"])
-    home = _pose(home_m)
+    home = _pose(home_m, P)
     assert np.allclose(home.pose_matrix(), home_m)
     trpy = home.xyzrpy()
     assert np.allclose(trpy[:3], home.translation())
-    home2 = O.Pose(translation=trpy[:3], rpy_vector=trpy[3:])
+    home2 = P(translation=trpy[:3], rpy_vector=trpy[3:])
     assert home.is_close(home2) and np.allclose(home_m, home2.pose_matrix())
-    assert O.Pose(translation=[0, 0, 0], rpy_vector=[0, 0, 0]).is_close(O.Pose())
+    assert P(translation=np.zeros(3), rpy_vector=np.zeros(3)).is_close(P())
 
 
 def test_home_fk_matches_hand_fk_and_settled_reading(cm):
