@@ -446,6 +446,9 @@ def test_free_box_matches_oracle(kernel):
     assert rep["max_ncon"] == 4 and rep["zones"] == {0, 1, 2}, rep  # separating, sliding and sticking contacts all occurred
     assert rep["max_abs_pos"] < 1e-6 and rep["max_abs_quat"] < 1e-5 and rep["max_abs_vel"] < 1e-3, rep
     assert rep["max_abs_robot_qpos"] < 1e-9, rep
+    # a batch that fills neither a wavefront (4 environments) nor a grid row (8 workgroups)
+    rep = pu.run_free_box_parity(n_envs=5, n_calls=6, k=25, seed=9)
+    assert rep["max_abs_pos"] < 1e-6 and rep["max_abs_quat"] < 1e-5 and rep["max_abs_vel"] < 1e-3 and rep["max_abs_robot_qpos"] < 1e-9, rep
 
 
 @pytest.mark.parametrize("async_control", [True, False])
