@@ -37,6 +37,13 @@ XARM7 = dict(  # examples/xarm7/xarm7_env_joint_control.py:41-64; include/rcs/Ro
     low=np.array([-2 * np.pi, -2.094395, -2 * np.pi, -3.92699, -2 * np.pi, -np.pi, -2 * np.pi]),
     high=np.array([2 * np.pi, 2.059488, 2 * np.pi, 0.191986, 2 * np.pi, 1.692969, 2 * np.pi]),
     gripper_joint=None, gripper_actuator=None, arm_collision_geoms=[])
+ARM6 = dict(  # scenes/arm6_empty_world (builder-authored 6-dof arm); home pose and limits: Robot.h's UR5e entry
+    joints=["shoulder_pan", "shoulder_lift", "elbow", "wrist_1", "wrist_2", "wrist_3"], actuators=[f"act{i}" for i in range(1, 7)],
+    site="attachment_site", base="base",
+    q_home=np.array([-0.4488354, -2.02711196, 1.64630026, -1.18999615, -1.57079762, -2.01963249]),
+    low=np.array([-2 * np.pi, -2 * np.pi, -np.pi, -2 * np.pi, -2 * np.pi, -2 * np.pi]),
+    high=np.array([2 * np.pi, 2 * np.pi, np.pi, 2 * np.pi, 2 * np.pi, 2 * np.pi]),
+    gripper_joint=None, gripper_actuator=None, arm_collision_geoms=[])
 TRPY_LOW = np.array([-0.855, -0.855, 0.0])  # base.py:31-38
 TRPY_HIGH = np.array([0.855, 0.855, 1.188])
 

@@ -33,6 +33,23 @@ def xarm7_sim_robot_cfg(scene: str = "xarm7_empty_world") -> sim.SimRobotConfig:
     return cfg
 
 
+def arm6_sim_robot_cfg() -> sim.SimRobotConfig:
+    """The builder-authored 6-dof arm (scenes/arm6_empty_world: UR5e-class proportions, NOT a vendor model), configured the
+    way the reference's xArm7 example configures its robot; joint limits and home pose are robots_meta_config's UR5e entry."""
+    import rcs_amd
+
+    cfg = sim.SimRobotConfig()
+    cfg.actuators = [f"act{i}" for i in range(1, 7)]
+    cfg.joints = ["shoulder_pan", "shoulder_lift", "elbow", "wrist_1", "wrist_2", "wrist_3"]
+    cfg.base = "base"
+    cfg.robot_type = rcs_amd.common.RobotType.UR5e
+    cfg.attachment_site = "attachment_site"
+    cfg.arm_collision_geoms = []
+    cfg.mjcf_scene_path = rcs_amd.scenes["arm6_empty_world"].mjb
+    cfg.kinematic_model_path = rcs_amd.scenes["arm6_empty_world"].mjcf_robot
+    return cfg
+
+
 def default_sim_gripper_cfg(idx: str = "0") -> sim.SimGripperConfig:
     cfg = sim.SimGripperConfig()
     cfg.add_id(idx)

@@ -35,6 +35,7 @@ KERNEL = "auto"
 
 
 XARM7_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "xarm7_empty_world", "scene.xml")
+ARM6_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "arm6_empty_world", "scene.xml")
 
 
 PICKUP_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "fr3_simple_pick_up", "scene.xml")
@@ -274,16 +275,16 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500):
     from rcs_amd import sim
-    from rcs_amd.envs import ControlMode, RelativeTo, SimEnvCreator, default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg
+    from rcs_amd.envs import ControlMode, RelativeTo, SimEnvCreator, arm6_sim_robot_cfg, default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg
 
     cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=frequency, max_convergence_steps=max_convergence_steps)
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    if robot.startswith("xarm7"):
+    if robot.startswith("xarm7") or robot == "arm6":
         gripper = False
     venv = SimEnvCreator()(
-        mode, xarm7_sim_robot_cfg("xarm7_box_world" if robot == "xarm7_box" else "xarm7_empty_world") if robot.startswith("xarm7") else default_sim_robot_cfg("fr3_empty_world"),
+        mode, arm6_sim_robot_cfg() if robot == "arm6" else xarm7_sim_robot_cfg("xarm7_box_world" if robot == "xarm7_box" else "xarm7_empty_world") if robot.startswith("xarm7") else default_sim_robot_cfg("fr3_empty_world"),
         gripper_cfg=default_sim_gripper_cfg() if gripper else None,
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None,
         relative_to=RelativeTo.LAST_STEP if relative_to == "last_step" else RelativeTo.CONFIGURED_ORIGIN,
@@ -298,13 +299,13 @@ def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, rel
                      max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                      max_convergence_steps: int = 500):
     from rcs_amd.mjcf import compile_mjcf
-    from rcs_env_oracle import XARM7, OracleEnv
+    from rcs_env_oracle import ARM6, XARM7, OracleEnv
 
-    cm = compile_mjcf(XARM7_SCENE if robot == "xarm7" else SCENE)
+    cm = compile_mjcf({"xarm7": XARM7_SCENE, "arm6": ARM6_SCENE}.get(robot, SCENE))
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
     return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot == "fr3", max_relative_movement=max_relative_movement if relative else None,
-                      async_control=async_control, robot=XARM7 if robot == "xarm7" else None, relative_to=relative_to,
+                      async_control=async_control, robot={"xarm7": XARM7, "arm6": ARM6}.get(robot), relative_to=relative_to,
                       frequency=frequency, max_convergence_steps=max_convergence_steps) for _ in range(n_envs)]
 
 
@@ -317,7 +318,8 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
                         max_convergence_steps=max_convergence_steps)
     oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to, frequency=frequency,
                              max_convergence_steps=max_convergence_steps)
-    joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed)
+    dof = 6 if robot == "arm6" else 7
+    joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed, dof=dof)
     rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_finger": 0.0, "max_abs_gripper_width": 0.0,
            "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}
 
@@ -340,8 +342,8 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
             # arm joints and finger slides are reported separately: the fingers rest exactly on a joint limit with zero
             # actuator force (the reference model's gripper equilibrium IS the limit), where the sign of round-off decides
             # whether a limit row exists in a substep, so their trajectories are only reproducible to ~1e-5 m
-            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:7] - oe.sim.qpos[:7]).max()))
-            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e][:7] - oe.sim.qvel[:7]).max()))
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:dof] - oe.sim.qpos[:dof]).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e][:dof] - oe.sim.qvel[:dof]).max()))
             if q.shape[1] > 7:
                 rep["max_abs_finger"] = max(rep["max_abs_finger"], float(np.abs(q[e][7:] - oe.sim.qpos[7:]).max()))
             if substeps is not None and not async_control:
@@ -425,9 +427,9 @@ def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=
             for k in ("collision", "ik_success", "is_sim_converged"):
                 rep["flag_mismatches"] += int(bool(info[k][e]) != bool(oi[k]))
             rep["ik_fail"] += int(not oi["ik_success"])
-            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:7] - oe.sim.qpos[:7]).max()))
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:venv.dof] - oe.sim.qpos[:venv.dof]).max()))
             rep["max_abs_tquat"] = max(rep["max_abs_tquat"], float(np.abs(obs["tquat"][e] - oo["tquat"]).max()))
-            rep["max_abs_target"] = max(rep["max_abs_target"], float(np.abs(st.target_angles[e] - np.array(oe.sim.s.target_angles[:7])).max()))
+            rep["max_abs_target"] = max(rep["max_abs_target"], float(np.abs(st.target_angles[e] - np.array(oe.sim.s.target_angles[:venv.dof])).max()))
         rep["steps"] += 1
     venv.close()
     return rep

@@ -655,3 +655,19 @@ def test_pick_task_batch_is_position_independent(kernel):
     after = env.sim.free_joint_qpos("box_joint")
     assert np.array_equal(after[~mask], before[~mask]) and not np.array_equal(after[mask], before[mask])
     env.close()
+
+
+@pytest.mark.parametrize("async_control", [True, False])
+def test_arm6_joints(async_control, kernel):
+    """Third archetype, `Topo<6, false>`: the builder-authored 6-dof arm (scenes/arm6_empty_world).  Its joints turn about
+    y and about a skew axis, with anchors off the link origin -- the general-axis path that no FR3 / xArm7 joint takes."""
+    rep = run_joint_rollout_parity(n_envs=40, n_steps=6 if async_control else 3, async_control=async_control, seed=13, robot="arm6")
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < 1e-4 and rep["max_abs_obs"] < TOL, rep
+    assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
+
+
+def test_arm6_cartesian_relative_clik(kernel):
+    """The CLIK on the 6-dof chain (6 Jacobian columns, attachment site on the last link)."""
+    rep = run_cartesian_rollout_parity(n_envs=24, n_steps=5, async_control=True, seed=19, mode="xyzrpy", robot="arm6")
+    assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL and rep["max_abs_tquat"] < TOL, rep
+    assert rep["flag_mismatches"] == 0, rep
