@@ -134,9 +134,9 @@ def main() -> None:
                     help="env.reset() every this many steps (inside the timed region; resets are not counted as env-steps). "
                          "Default: none for joints; 10 for cartesian, as the reference's examples loop (reset + 10 steps) -- a longer "
                          "random walk of Cartesian targets leaves the workspace and the CLIK then runs to its 1000-iteration cap")
-    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box", "mixed"], default="fr3",
+    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box", "arm6", "mixed"], default="fr3",
                     help="xarm7: 7-dof arm with dry joint friction, no gripper; xarm7_box: the same next to a free cube with floor contacts "
-                         "(builder-authored scene xarm7_box_world, camera side_cam); mixed: even ranks FR3, odd ranks xArm7 -- sharding by robot type, "
+                         "(builder-authored scene xarm7_box_world, camera side_cam); arm6: builder-authored 6-dof arm (Topo<6,false>); mixed: even ranks FR3, odd ranks xArm7 -- sharding by robot type, "
                          "one specialised kernel per GPU, as BASELINE configs[4] asks (not the headline)")
     ap.add_argument("--task", choices=["none", "pick_up"], default="none",
                     help="pick_up = the registered gym task rcs/FR3SimplePickUpSim-v0 (fr3_simple_pick_up scene: free cube on the floor with "
@@ -206,7 +206,7 @@ def main() -> None:
         scale = torch.tensor([0.05, 0.05, 0.05, 0.1, 0.1, 0.1], device="cuda", dtype=torch.float64)
         joints = (torch.rand((T, n, 6), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * scale
     else:
-        joints = (torch.rand((T, n, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV
+        joints = (torch.rand((T, n, env.dof), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV
     grip = torch.rand((T, n), generator=gen, device="cuda", dtype=torch.float32)
     ow = env.obs_width
     obs = torch.zeros((n, ow), device="cuda", dtype=torch.float64)
@@ -327,7 +327,7 @@ def main() -> None:
                 "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off"
                              if args.control == "joints" else
                              f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
-                             ).replace("fr3_empty_world", ("fr3_empty_world on even ranks / xarm7_empty_world on odd ranks" if mixed else {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)"}[args.robot]) if args.task == "none" else
+                             ).replace("fr3_empty_world", ("fr3_empty_world on even ranks / xarm7_empty_world on odd ranks" if mixed else {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)", "arm6": "arm6_empty_world (builder-authored 6-dof arm)"}[args.robot]) if args.task == "none" else
                                        "fr3_simple_pick_up (free cube: plane-box contacts, elliptic cones, noslip; RandomCubePos + PickCubeSuccessWrapper)"),
                 "mode": "async_control 30Hz (17 substeps/env-step)" if args.mode == "async" else "step_until_convergence (cap 500)",
                 "envs_per_gpu": n,
