@@ -271,6 +271,20 @@ def run_pick_task_parity(n_envs=16, n_steps=6, seed=0, episodes=2, async_control
     return rep
 
 
+def xarm7_frictionless_scene() -> str:
+    """The xArm7 scene with frictionloss = 0, written to a temporary file: a 7-dof arm without gripper and WITHOUT dry friction
+    rows -- the `Topo<7, false>` kernels without the friction variant, which no shipped scene selects."""
+    import tempfile
+
+    path = os.path.join(tempfile.gettempdir(), "rcs_amd_xarm7_frictionless", "scene.xml")
+    if not os.path.exists(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        xml = open(XARM7_SCENE).read()
+        assert 'frictionloss="1"' in xml
+        open(path, "w").write(xml.replace('frictionloss="1"', 'frictionloss="0"'))
+    return path
+
+
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500):
@@ -283,8 +297,12 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
         max_relative_movement = MAX_JOINT_MOV
     if robot.startswith("xarm7") or robot == "arm6":
         gripper = False
+    rcfg = None
+    if robot == "xarm7_nofric":
+        rcfg = xarm7_sim_robot_cfg()
+        rcfg.mjcf_scene_path = rcfg.kinematic_model_path = xarm7_frictionless_scene()
     venv = SimEnvCreator()(
-        mode, arm6_sim_robot_cfg() if robot == "arm6" else xarm7_sim_robot_cfg("xarm7_box_world" if robot == "xarm7_box" else "xarm7_empty_world") if robot.startswith("xarm7") else default_sim_robot_cfg("fr3_empty_world"),
+        mode, rcfg if rcfg is not None else arm6_sim_robot_cfg() if robot == "arm6" else xarm7_sim_robot_cfg("xarm7_box_world" if robot == "xarm7_box" else "xarm7_empty_world") if robot.startswith("xarm7") else default_sim_robot_cfg("fr3_empty_world"),
         gripper_cfg=default_sim_gripper_cfg() if gripper else None,
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None,
         relative_to=RelativeTo.LAST_STEP if relative_to == "last_step" else RelativeTo.CONFIGURED_ORIGIN,
@@ -301,11 +319,11 @@ def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, rel
     from rcs_amd.mjcf import compile_mjcf
     from rcs_env_oracle import ARM6, XARM7, OracleEnv
 
-    cm = compile_mjcf({"xarm7": XARM7_SCENE, "arm6": ARM6_SCENE}.get(robot, SCENE))
+    cm = compile_mjcf(xarm7_frictionless_scene() if robot == "xarm7_nofric" else {"xarm7": XARM7_SCENE, "arm6": ARM6_SCENE}.get(robot, SCENE))
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
     return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot == "fr3", max_relative_movement=max_relative_movement if relative else None,
-                      async_control=async_control, robot={"xarm7": XARM7, "arm6": ARM6}.get(robot), relative_to=relative_to,
+                      async_control=async_control, robot={"xarm7": XARM7, "xarm7_nofric": XARM7, "arm6": ARM6}.get(robot), relative_to=relative_to,
                       frequency=frequency, max_convergence_steps=max_convergence_steps) for _ in range(n_envs)]
 
 

@@ -671,3 +671,12 @@ def test_arm6_cartesian_relative_clik(kernel):
     rep = run_cartesian_rollout_parity(n_envs=24, n_steps=5, async_control=True, seed=19, mode="xyzrpy", robot="arm6")
     assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL and rep["max_abs_tquat"] < TOL, rep
     assert rep["flag_mismatches"] == 0, rep
+
+
+@pytest.mark.parametrize("async_control", [True, False])
+def test_seven_dof_arm_without_gripper_or_friction(async_control, kernel):
+    """`Topo<7, false>` without the friction variant (team kernel) and on the lane kernel: the xArm7 chain with
+    frictionloss = 0 -- a combination no shipped scene selects (the xArm7 has friction, the FR3 scene has fingers)."""
+    rep = run_joint_rollout_parity(n_envs=40, n_steps=5 if async_control else 3, async_control=async_control, seed=21, robot="xarm7_nofric")
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < 1e-4 and rep["max_abs_obs"] < TOL, rep
+    assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
