@@ -285,6 +285,28 @@ def xarm7_frictionless_scene() -> str:
     return path
 
 
+def scene_with_joint_friction(robot: str) -> str:
+    """The FR3 / arm6 scene with dry joint friction on every joint (frictionloss = 0.5), written to a temporary file: the
+    friction-row kernels for the archetypes whose shipped scenes have none -- FR3 + hand (friction rows next to the coupling
+    equality, the finger limits and the tendon actuator) and the 6-dof arm."""
+    import tempfile
+
+    src, old, new = {"fr3_fric": (SCENE, '<joint armature="0.1" damping="1"/>', '<joint armature="0.1" damping="1" frictionloss="0.5"/>'),
+                     "arm6_fric": (ARM6_SCENE, 'range="-6.28319 6.28319" damping="2"/>', 'range="-6.28319 6.28319" damping="2" frictionloss="0.5"/>')}[robot]
+    path = os.path.join(tempfile.gettempdir(), f"rcs_amd_{robot}", "scene.xml")
+    if not os.path.exists(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        xml = open(src).read()
+        assert old in xml
+        open(path, "w").write(xml.replace(old, new))
+        for extra in ("collision_vertices.npz",):
+            if os.path.exists(os.path.join(os.path.dirname(src), extra)):
+                import shutil
+
+                shutil.copy(os.path.join(os.path.dirname(src), extra), os.path.dirname(path))
+    return path
+
+
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500):
@@ -295,9 +317,12 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    if robot.startswith("xarm7") or robot == "arm6":
+    if robot.startswith("xarm7") or robot.startswith("arm6"):
         gripper = False
     rcfg = None
+    if robot in ("fr3_fric", "arm6_fric"):
+        rcfg = default_sim_robot_cfg("fr3_empty_world") if robot == "fr3_fric" else arm6_sim_robot_cfg()
+        rcfg.mjcf_scene_path = rcfg.kinematic_model_path = scene_with_joint_friction(robot)
     if robot == "xarm7_nofric":
         rcfg = xarm7_sim_robot_cfg()
         rcfg.mjcf_scene_path = rcfg.kinematic_model_path = xarm7_frictionless_scene()
@@ -319,11 +344,12 @@ def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, rel
     from rcs_amd.mjcf import compile_mjcf
     from rcs_env_oracle import ARM6, XARM7, OracleEnv
 
-    cm = compile_mjcf(xarm7_frictionless_scene() if robot == "xarm7_nofric" else {"xarm7": XARM7_SCENE, "arm6": ARM6_SCENE}.get(robot, SCENE))
+    cm = compile_mjcf(xarm7_frictionless_scene() if robot == "xarm7_nofric" else scene_with_joint_friction(robot) if robot.endswith("_fric")
+                      else {"xarm7": XARM7_SCENE, "arm6": ARM6_SCENE}.get(robot, SCENE))
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot == "fr3", max_relative_movement=max_relative_movement if relative else None,
-                      async_control=async_control, robot={"xarm7": XARM7, "xarm7_nofric": XARM7, "arm6": ARM6}.get(robot), relative_to=relative_to,
+    return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot in ("fr3", "fr3_fric"), max_relative_movement=max_relative_movement if relative else None,
+                      async_control=async_control, robot={"xarm7": XARM7, "xarm7_nofric": XARM7, "arm6": ARM6, "arm6_fric": ARM6}.get(robot), relative_to=relative_to,
                       frequency=frequency, max_convergence_steps=max_convergence_steps) for _ in range(n_envs)]
 
 
@@ -331,12 +357,12 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
                              episodes: int = 1, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                              max_convergence_steps: int = 500):
     """Fused HIP env-step vs the oracle on the same seeded actions; returns max abs differences + flag mismatches."""
-    gripper = gripper and robot == "fr3"
+    gripper = gripper and robot in ("fr3", "fr3_fric")
     venv = make_vec_env(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to, frequency=frequency,
                         max_convergence_steps=max_convergence_steps)
     oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to, frequency=frequency,
                              max_convergence_steps=max_convergence_steps)
-    dof = 6 if robot == "arm6" else 7
+    dof = 6 if robot.startswith("arm6") else 7
     joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed, dof=dof)
     rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_finger": 0.0, "max_abs_gripper_width": 0.0,
            "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}

@@ -680,3 +680,26 @@ def test_seven_dof_arm_without_gripper_or_friction(async_control, kernel):
     rep = run_joint_rollout_parity(n_envs=40, n_steps=5 if async_control else 3, async_control=async_control, seed=21, robot="xarm7_nofric")
     assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < 1e-4 and rep["max_abs_obs"] < TOL, rep
     assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
+
+
+@pytest.mark.parametrize("robot", ["fr3_fric", "arm6_fric"])
+def test_joint_friction_on_the_other_archetypes(robot, kernel):
+    """Dry joint friction where the shipped scenes have none: FR3 + hand (friction rows together with the fingers' coupling
+    equality, their limit rows and the tendon actuator -- `newton_rows<Topo<7,true>, FRIC>`) and the 6-dof arm."""
+    if kernel == "lane":
+        from parity_util import make_vec_env
+
+        with pytest.raises(RuntimeError, match="lane kernel"):
+            make_vec_env(4, True, robot=robot)
+        return
+    for async_control in (True, False):
+        rep = run_joint_rollout_parity(n_envs=32, n_steps=5 if async_control else 2, async_control=async_control, seed=23, robot=robot)
+        assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < 1e-4 and rep["max_abs_obs"] < TOL and rep["max_abs_finger"] < FINGER_TOL, rep
+        assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
+
+
+def test_seven_dof_arm_without_gripper_cartesian(kernel):
+    """The CLIK kernels of `Topo<7, false>` on both kernel variants (the shipped xArm7 scene only reaches the team one)."""
+    rep = run_cartesian_rollout_parity(n_envs=24, n_steps=4, async_control=True, seed=25, mode="tquat", robot="xarm7_nofric")
+    assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL and rep["max_abs_tquat"] < TOL, rep
+    assert rep["flag_mismatches"] == 0, rep
