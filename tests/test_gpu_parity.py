@@ -703,3 +703,68 @@ def test_seven_dof_arm_without_gripper_cartesian(kernel):
     rep = run_cartesian_rollout_parity(n_envs=24, n_steps=4, async_control=True, seed=25, mode="tquat", robot="xarm7_nofric")
     assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL and rep["max_abs_tquat"] < TOL, rep
     assert rep["flag_mismatches"] == 0, rep
+
+
+def test_device_pointer_forms_equal_host_forms(kernel):
+    """The resident-rollout entry points (`*_dev`, device pointers from rcsh_dev_alloc / upload / download -- what a host language
+    without a HIP binding uses) against the host-buffer forms of the same calls, bit for bit: task reset and step, a depth frame."""
+    import ctypes as C
+
+    from rcs_amd import _lib
+    from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
+
+    if kernel == "lane":
+        pytest.skip("scene with a free body: team kernel only")
+    n, W, H = 6, 24, 16
+    envs = [FR3SimplePickUpSimEnvCreator()(n_envs=n, resolution=(W, H), cam_list=["wrist_0"]) for _ in range(2)]
+    host, dev = envs
+    L, h = dev._L, dev.sim._h
+    assert L.rcsh_sim_num_envs(h) == n and L.rcsh_sim_stream(h) is not None
+    cfg = (C.c_int32 * 4)()
+    assert L.rcsh_sim_get_config(h, C.byref(cfg, 0), C.byref(cfg, 4), C.byref(cfg, 8), C.byref(cfg, 12)) == 0 and list(cfg) == [1, 0, 30, 500]
+
+    def dalloc(nbytes):
+        p = C.c_void_p()
+        _lib.check(L.rcsh_dev_alloc(h, nbytes, C.byref(p)))
+        return p
+
+    def up(p, a):
+        a = np.ascontiguousarray(a)
+        _lib.check(L.rcsh_dev_upload(h, p, C.c_void_p(a.ctypes.data), a.nbytes))
+
+    def down(p, a):
+        _lib.check(L.rcsh_dev_download(h, C.c_void_p(a.ctypes.data), p, a.nbytes))
+        return a
+
+    np.random.seed(5)
+    box = host.draw_box_qpos()
+    rng = np.random.default_rng(6)
+    act = np.concatenate([rng.uniform(-0.05, 0.05, (n, 3)), rng.uniform(-0.1, 0.1, (n, 3))], axis=1)
+    grip = rng.uniform(0, 1, n).astype(np.float32)
+    ow = dev.obs_width
+    d_box, d_act, d_grip = dalloc(n * 7 * 8), dalloc(n * 6 * 8), dalloc(n * 4)
+    d_obs, d_info, d_gw, d_sub, d_task, d_img = dalloc(n * ow * 8), dalloc(n * 8), dalloc(n * 8), dalloc(n * 4), dalloc(n * 9 * 8), dalloc(n * W * H * 2)
+    up(d_box, box); up(d_act, act); up(d_grip, grip)
+    # reset
+    h_obs, h_info = host.reset(options={"box_qpos": box})
+    _lib.check(L.rcsh_env_reset_task_dev(h, None, d_box, d_obs, d_info, d_gw))
+    obs = down(d_obs, np.zeros((n, ow)))
+    assert np.array_equal(obs[:, :7], h_obs["tquat"]) and np.array_equal(down(d_gw, np.zeros(n)), h_info["gripper_width"])
+    # step
+    h_obs, h_rew, h_term, h_trunc, h_info = host.step({"xyzrpy": act, "gripper": grip})
+    _lib.check(L.rcsh_env_step_task_dev(h, d_act, d_grip, d_obs, d_info, d_gw, d_sub, d_task))
+    obs, task = down(d_obs, np.zeros((n, ow))), down(d_task, np.zeros((n, 9)))
+    assert np.array_equal(obs[:, :7], h_obs["tquat"]) and np.array_equal(obs[:, 7:14], h_obs["joints"])
+    assert np.array_equal(task[:, :7], h_info["box_qpos"]) and np.array_equal(task[:, 7], h_rew) and np.array_equal(task[:, 8] != 0, h_term)
+    assert np.array_equal(down(d_sub, np.zeros(n, dtype=np.int32)), h_info["substeps"])
+    # depth frame of the same instant
+    _lib.check(L.rcsh_camera_render_dev(h, dev.camera_set._ids["wrist_0"], None, d_img, None))
+    _lib.check(L.rcsh_sim_synchronize(h))
+    img = down(d_img, np.zeros((n, H, W), dtype=np.uint16))
+    assert np.array_equal(img, h_obs["frames"]["wrist_0"]["depth"]["data"][..., 0])
+    # mj_resetData of the box alone
+    _lib.check(L.rcsh_sim_reset_free_box(h))
+    assert np.array_equal(dev.sim.free_joint_qpos("box_joint"), np.tile([0.44, 0.1, 0.03, 0, 0, 0, 1.0], (n, 1)))
+    for p in (d_box, d_act, d_grip, d_obs, d_info, d_gw, d_sub, d_task, d_img):
+        _lib.check(L.rcsh_dev_free(h, p))
+    [e.close() for e in envs]
