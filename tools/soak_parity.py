@@ -11,3 +11,18 @@ for seed in range(3):
     print("task", seed, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 rep = pu.run_depth_render_parity(n_envs=8, width=96, height=64, seed=5, n_calls=4)
 print("depth", {k: v for k, v in rep.items() if k != "sample"})
+import time
+for kernel in ("team", "lane"):
+    pu.KERNEL = kernel
+    t0 = time.time()
+    rep = pu.run_joint_rollout_parity(n_envs=192, n_steps=40, async_control=True, seed=100)
+    print(kernel, "joints async", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()}, f"{time.time() - t0:.0f}s")
+    rep = pu.run_joint_rollout_parity(n_envs=64, n_steps=6, async_control=False, seed=101)
+    print(kernel, "joints conv ", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
+    rep = pu.run_cartesian_rollout_parity(n_envs=96, n_steps=12, async_control=True, seed=102, mode="xyzrpy")
+    print(kernel, "cartesian   ", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
+pu.KERNEL = "team"
+rep = pu.run_joint_rollout_parity(n_envs=96, n_steps=20, async_control=True, seed=103, robot="xarm7")
+print("xarm7 async", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
+rep = pu.run_joint_rollout_parity(n_envs=96, n_steps=20, async_control=True, seed=104, robot="arm6")
+print("arm6 async", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
