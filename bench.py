@@ -307,7 +307,8 @@ def main() -> None:
         substeps_per_launch = mean_sub * n
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-        if os.path.exists(tpath) and args.mode == "async" and n == N_ENVS:
+        headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
+        if os.path.exists(tpath) and headline:  # the PMC passes profiled exactly this workload (profiles/run_profile.sh)
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
             traffic = (tj["fetch_size_kb_per_dispatch"] + tj["write_size_kb_per_dispatch"]) * 1024
         out = {
