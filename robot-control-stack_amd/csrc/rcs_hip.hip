@@ -112,6 +112,7 @@ Params make_params(rcsh_sim* s) {
   P.flags = s->flags;
   P.conv_steps = s->conv;
   P.n = s->n;
+  P.keep_qpre = s->d_frames != nullptr;
   P.sim = s->sim;
   P.robot = s->robot;
   P.grip = s->gripcfg;

@@ -118,6 +118,7 @@ struct Params {
   uint32_t* flags;
   int32_t* conv_steps;
   int32_t n;
+  int32_t keep_qpre;  // a render scene exists: keep the qpos the last position stage saw (Lay::QPRE) for its frames
   SimCfg sim;
   RobotCfg robot;
   GripperCfg grip;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void load_env(const Params& P, int e, EnvRegs<T, ST>&
   const int n = P.n;
   const double* S = P.S;
 #pragma unroll
-  for (int i = 0; i < T::NL; ++i) { r.st.q(i) = S[(L::QPOS + i) * n + e]; r.st.v(i) = S[(L::QVEL + i) * n + e]; r.st.qpre(i) = S[(L::QPRE + i) * n + e]; }
+  for (int i = 0; i < T::NL; ++i) { r.st.q(i) = S[(L::QPOS + i) * n + e]; r.st.v(i) = S[(L::QVEL + i) * n + e]; r.st.qpre(i) = P.keep_qpre ? S[(L::QPRE + i) * n + e] : 0.0; }
 #pragma unroll
   for (int i = 0; i < T::NU; ++i) r.st.c(i) = S[(L::CTRL + i) * n + e];
   r.time = S[L::TIME * n + e];
@@ -173,7 +174,11 @@ __device__ __forceinline__ void store_env(const Params& P, int e, const EnvRegs<
   double* S = P.S;
   if constexpr (kStaged) {
 #pragma unroll
-    for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.st.q(i); S[(L::QVEL + i) * n + e] = r.st.v(i); S[(L::QPRE + i) * n + e] = r.st.qpre(i); }
+    for (int i = 0; i < T::NL; ++i) { S[(L::QPOS + i) * n + e] = r.st.q(i); S[(L::QVEL + i) * n + e] = r.st.v(i); }
+    if (P.keep_qpre) {
+#pragma unroll
+      for (int i = 0; i < T::NL; ++i) S[(L::QPRE + i) * n + e] = r.st.qpre(i);
+    }
 #pragma unroll
     for (int i = 0; i < T::NU; ++i) S[(L::CTRL + i) * n + e] = r.st.c(i);
 #pragma unroll
@@ -685,6 +690,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // The environment's state goes out first -- every lane asks for up to three of the fields that are staged in LDS,
   // the leader for the five it keeps in registers -- so that the model staging below hides the round trip to HBM.
   using SF = TeamStagedFields<T, ST>;
+  const int nstaged = Pk.keep_qpre ? SF::kCount : SF::kCount - T::NL;  // (the QPRE entries are the list's last)
   double staged[SF::kRounds];
   constexpr int kInRounds = (StepInGlobal<T>::kCount + kTeamLanes - 1) / kTeamLanes;
   double step_in[kInRounds] = {};
@@ -697,7 +703,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     for (int rd = 0; rd < SF::kRounds; ++rd) {
       const int k = t + rd * kTeamLanes;
       int field = 0, slot = 0;
-      SF::locate(k < SF::kCount ? k : 0, field, slot);
+      SF::locate(k < nstaged ? k : 0, field, slot);
       staged[rd] = Pk.S[(size_t)field * Pk.n + e];
     }
     if (opk.apply_action) {
@@ -749,8 +755,8 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     for (int rd = 0; rd < SF::kRounds; ++rd) {
       const int k = t + rd * kTeamLanes;
       int field = 0, slot = 0;
-      SF::locate(k < SF::kCount ? k : 0, field, slot);
-      if (k < SF::kCount) st.at(slot) = staged[rd];
+      SF::locate(k < nstaged ? k : 0, field, slot);
+      if (k < nstaged) st.at(slot) = staged[rd];
     }
 #pragma unroll
     for (int rd = 0; rd < kInRounds; ++rd) {
@@ -876,8 +882,8 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     for (int rd = 0; rd < SF::kRounds; ++rd) {
       const int k = t + rd * kTeamLanes;
       int field = 0, slot = 0;
-      SF::locate(k < SF::kCount ? k : 0, field, slot);
-      if (k < SF::kCount) P.S[(size_t)field * P.n + e] = st.at(slot);
+      SF::locate(k < nstaged ? k : 0, field, slot);
+      if (k < nstaged) P.S[(size_t)field * P.n + e] = st.at(slot);
     }
   }
   if constexpr (BOX) {
