@@ -27,7 +27,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(ROOT, "robot-control-stack_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [os.path.join(ROOT, "robot-control-stack_amd")]
 
 N_ENVS = 4096
 SUBSTEPS = 17
@@ -40,7 +40,8 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 def cpu_baseline_worker(n_envs: int, n_steps: int, seed0: int) -> None:
     """Child process: steps `n_envs` oracle environments; prints the elapsed seconds of two legs."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    # (the checker lives under oracle/ and tests/; only this CPU-baseline leg of the benchmark touches either)
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
     import numpy as np
     from parity_util import make_oracle_envs, synthetic_actions
 
@@ -153,9 +154,22 @@ def main() -> None:
         cpu_baseline_worker(*(int(x) for x in args.cpu_baseline_worker))
         return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks, one per GPU (what the driver's
+        # `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` does)
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run `python bench.py --gpus N`, which spawns them)")
 
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -177,7 +191,7 @@ def main() -> None:
         else:
             dist.init_process_group(args.dist_backend)
 
-    from parity_util import MAX_JOINT_MOV, make_vec_env
+    from rcs_amd.envs import MAX_JOINT_MOV, make_vec_env
 
     n = args.envs
     T = args.steps + args.warmup
@@ -312,7 +326,11 @@ def main() -> None:
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
             traffic = (tj["fetch_size_kb_per_dispatch"] + tj["write_size_kb_per_dispatch"]) * 1024
         out = {
-            "metric": "env-steps/sec (whole node), fr3_empty_world JOINTS mode, 4096 envs per GPU",
+            "metric": "env-steps/sec (whole node), " + (
+                "fr3_simple_pick_up task (CARTESIAN_TRPY)" if args.task != "none" else
+                ("fr3_empty_world + xarm7_empty_world by rank" if mixed else {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world", "arm6": "arm6_empty_world"}[args.robot])
+                + (" JOINTS mode" if args.control == "joints" else " CARTESIAN_TRPY mode"))
+                + (", step_until_convergence" if args.mode == "convergence" else "") + f", {n} envs per GPU",
             "value": value,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -337,7 +355,7 @@ def main() -> None:
                 "episode_length": episode or None,
                 "depth_frames": (f"{args.cameras} at {args.resolution}, one ray-cast uint16 frame per camera per env-step "
                                  f"({len(cam_out) * n * int(args.resolution.split('x')[0]) * int(args.resolution.split('x')[1]) / (elapsed / args.steps) / 1e9:.2f} G rays/s incl. the physics)") if cam_out else None,
-                "exchange": "RCCL all_gather_into_tensor of obs [N,21] f64 per step, double-buffered, overlapped with the next env-step" if world > 1 else "none (1 GPU)",
+                "exchange": (("RCCL" if args.dist_backend == "nccl" else args.dist_backend) + f" all-gather of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
             },
             "roofline": {

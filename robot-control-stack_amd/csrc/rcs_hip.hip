@@ -270,14 +270,36 @@ int flag_host(rcsh_sim* s, uint32_t bit, uint8_t* dst) {
   return RCSH_OK;
 }
 
-// flags |= set, &= ~clear for masked environments (host-side read-modify-write; construction-time only)
+// flags |= set, &= ~clear for masked environments: a small kernel on the handle's stream, so that it is ordered with
+// everything the *_dev entry points enqueued there
 int flags_update_host(rcsh_sim* s, uint32_t set, uint32_t clear, const uint8_t* mask) {
-  std::vector<uint32_t> f(s->n);
-  HIP_TRY(hipMemcpy(f.data(), s->flags, sizeof(uint32_t) * s->n, hipMemcpyDeviceToHost));
-  for (int e = 0; e < s->n; ++e)
-    if (!mask || mask[e]) f[e] = (f[e] | set) & ~clear;
-  HIP_TRY(hipMemcpy(s->flags, f.data(), sizeof(uint32_t) * s->n, hipMemcpyHostToDevice));
+  const uint8_t* dm = nullptr;
+  int rc = upload_mask(s, mask, &dm);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_flags_update, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, s->flags, s->n, set, clear, dm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
+}
+
+// Host-buffer env.reset(mask): the reset launch writes observation / info / gripper width of the masked environments only,
+// the rows of the others in the shared staging buffers would be whatever an earlier call left there.  An observation-only
+// pass (no stepping) over the complement fills them with the environments' current observation.
+int observe_unmasked(rcsh_sim* s, const uint8_t* mask) {
+  if (!mask) return RCSH_OK;
+  std::vector<uint8_t> inv(s->n);
+  bool any = false;
+  for (int e = 0; e < s->n; ++e) { inv[e] = !mask[e]; any = any || inv[e]; }
+  if (!any) return RCSH_OK;
+  uint8_t* d_inv = s->d_bytes + (size_t)s->n * 8;  // (info occupies the first 8 n bytes)
+  HIP_TRY(hipMemcpyAsync(d_inv, inv.data(), s->n, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));  // `inv` goes out of scope
+  RunOp op{};
+  op.nsteps = 0;
+  op.write_obs = 1;
+  op.mask = d_inv;
+  op.obs = s->d_stage2; op.info = s->d_bytes; op.gripper_width = s->d_stage;
+  return launch_run(s, op, false);
 }
 
 std::vector<double> tile(const double* row, int width, int n) {
@@ -286,8 +308,10 @@ std::vector<double> tile(const double* row, int width, int n) {
   return v;
 }
 
-#define REQUIRE_SIM(s) \
-  if (!(s)) return fail(RCSH_ERR_ARG, "null sim handle")
+// every entry point works on the handle's own GPU, whatever device the calling thread had current
+#define REQUIRE_SIM(s)                                        \
+  if (!(s)) return fail(RCSH_ERR_ARG, "null sim handle"); \
+  HIP_TRY(hipSetDevice((s)->device))
 #define REQUIRE_ROBOT(s) \
   if (!(s)->robot.present) return fail(RCSH_ERR_STATE, "no robot attached: call rcsh_sim_add_robot first")
 #define REQUIRE_GRIPPER(s) \
@@ -424,6 +448,7 @@ int rcsh_sim_synchronize(rcsh_sim* s) {
 
 int rcsh_sim_set_config(rcsh_sim* s, int32_t async_control, int32_t realtime, int32_t frequency, int32_t max_convergence_steps) {
   REQUIRE_SIM(s);
+  if (frequency <= 0) return fail(RCSH_ERR_ARG, "SimConfig.frequency must be positive");
   s->sim = SimCfg{async_control, realtime, frequency, max_convergence_steps};
   return RCSH_OK;
 }
@@ -463,7 +488,10 @@ int rcsh_sim_is_converged(rcsh_sim* s, uint8_t* converged, int32_t* steps) {
   REQUIRE_SIM(s);
   int rc = flag_host(s, kConverged, converged);
   if (rc) return rc;
-  if (steps) HIP_TRY(hipMemcpy(steps, s->conv, sizeof(int32_t) * s->n, hipMemcpyDeviceToHost));
+  if (steps) {
+    HIP_TRY(hipMemcpyAsync(steps, s->conv, sizeof(int32_t) * s->n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   return RCSH_OK;
 }
 
@@ -920,7 +948,8 @@ int rcsh_env_step_dev(rcsh_sim* s, const double* action_dev, const float* grippe
     op.apply_action = 0;
   }
   // RobotSimWrapper.step (reference python/rcs/envs/sim.py:49-59)
-  op.nsteps = s->sim.async_control ? (int32_t)std::lround(1.0 / s->sim.frequency / s->dm.timestep) : -1;
+  // (Python's round(): half to even, as std::nearbyint under the default rounding mode)
+  op.nsteps = s->sim.async_control ? (int32_t)std::nearbyint(1.0 / s->sim.frequency / s->dm.timestep) : -1;
   op.write_obs = obs_dev != nullptr;
   op.action = action_dev; op.gripper = gripper_dev;
   op.obs = obs_dev; op.info = info_dev; op.gripper_width = gw_dev; op.substeps = substeps_dev;
@@ -977,6 +1006,7 @@ int rcsh_env_reset_task(rcsh_sim* s, const uint8_t* mask, const double* box_qpos
   double* d_box = s->d_stage + (size_t)s->n * 16;
   HIP_TRY(hipMemcpyAsync(d_box, box_qpos, sizeof(double) * s->n * 7, hipMemcpyHostToDevice, s->stream));
   rc = rcsh_env_reset_task_dev(s, dm, d_box, s->d_stage2, s->d_bytes, s->d_stage);
+  if (!rc) rc = observe_unmasked(s, mask);
   if (rc) return rc;
   const int ow = 14 + s->narm;
   if (obs) HIP_TRY(hipMemcpyAsync(obs, s->d_stage2, sizeof(double) * s->n * ow, hipMemcpyDeviceToHost, s->stream));
@@ -1008,6 +1038,7 @@ int rcsh_env_reset(rcsh_sim* s, const uint8_t* mask, double* obs, uint8_t* info,
   int rc = upload_mask(s, mask, &dm);
   if (rc) return rc;
   rc = rcsh_env_reset_dev(s, dm, s->d_stage2, s->d_bytes, s->d_stage);
+  if (!rc) rc = observe_unmasked(s, mask);
   if (rc) return rc;
   const int ow = 14 + s->narm;
   if (obs) HIP_TRY(hipMemcpyAsync(obs, s->d_stage2, sizeof(double) * s->n * ow, hipMemcpyDeviceToHost, s->stream));

@@ -939,6 +939,11 @@ __global__ void k_scatter(double* S, int n, int field0, int width, const double*
   if (e >= n || (mask && !mask[e])) return;
   for (int i = 0; i < width; ++i) S[(size_t)(field0 + i) * n + e] = src[(size_t)e * width + i];
 }
+// flags[e] = (flags[e] | set) & ~clear where mask
+__global__ void k_flags_update(uint32_t* flags, int n, uint32_t set, uint32_t clear, const uint8_t* mask) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n && (!mask || mask[e])) flags[e] = (flags[e] | set) & ~clear;
+}
 __global__ void k_flags_to_bytes(const uint32_t* flags, int n, uint32_t bit, uint8_t* dst) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) dst[e] = (flags[e] & bit) != 0;

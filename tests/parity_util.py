@@ -19,6 +19,18 @@ def rpy_distance(a, b) -> float:
     return float((pa * pb.inverse()).total_angle())
 
 
+def rpy_error(a, b) -> float:
+    """Difference of two roll-pitch-yaw observations: COMPONENT-WISE wherever that is meaningful.  The reference's Euler
+    extraction (Eigen eulerAngles(2,1,0): yaw in [0, pi], src/rcs/Pose.cpp) jumps by 2 pi / pi where a component sits on
+    +-pi or 0 -- at the FR3's home pose roll is exactly +-pi -- so a triple with a component within 1e-6 of such a seam is
+    compared as a rotation instead (round-off decides the side of the seam); everywhere else a different-but-equivalent
+    Euler branch on the device would show up here as an error of order 1."""
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    near_seam = any(min(abs(abs(x) - s) for s in (0.0, np.pi)) < 1e-6 for x in (*a, *b))
+    dist = rpy_distance(a, b)
+    return dist if near_seam else max(dist, float(np.abs(a - b).max()))
+
+
 def synthetic_actions(n_envs: int, n_steps: int, seed: int = 0, dof: int = 7):
     """SURVEY 8d action tensor: joints ~ U(+-5 deg)^dof f64, gripper ~ U(0,1) f32, one RNG stream per env."""
     joints = np.zeros((n_steps, n_envs, dof))
@@ -310,29 +322,19 @@ def scene_with_joint_friction(robot: str) -> str:
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500):
-    from rcs_amd import sim
-    from rcs_amd.envs import ControlMode, RelativeTo, SimEnvCreator, arm6_sim_robot_cfg, default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg
+    """rcs_amd.envs.make_vec_env plus the test-only scene variants (`*_fric`, `xarm7_nofric`) and the kernel pin."""
+    from rcs_amd import envs
 
-    cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=frequency, max_convergence_steps=max_convergence_steps)
-    mode = control_mode or ControlMode.JOINTS
-    if relative and max_relative_movement is None:
-        max_relative_movement = MAX_JOINT_MOV
-    if robot.startswith("xarm7") or robot.startswith("arm6"):
-        gripper = False
     rcfg = None
     if robot in ("fr3_fric", "arm6_fric"):
-        rcfg = default_sim_robot_cfg("fr3_empty_world") if robot == "fr3_fric" else arm6_sim_robot_cfg()
+        rcfg = envs.default_sim_robot_cfg("fr3_empty_world") if robot == "fr3_fric" else envs.arm6_sim_robot_cfg()
         rcfg.mjcf_scene_path = rcfg.kinematic_model_path = scene_with_joint_friction(robot)
     if robot == "xarm7_nofric":
-        rcfg = xarm7_sim_robot_cfg()
+        rcfg = envs.xarm7_sim_robot_cfg()
         rcfg.mjcf_scene_path = rcfg.kinematic_model_path = xarm7_frictionless_scene()
-    venv = SimEnvCreator()(
-        mode, rcfg if rcfg is not None else arm6_sim_robot_cfg() if robot == "arm6" else xarm7_sim_robot_cfg("xarm7_box_world" if robot == "xarm7_box" else "xarm7_empty_world") if robot.startswith("xarm7") else default_sim_robot_cfg("fr3_empty_world"),
-        gripper_cfg=default_sim_gripper_cfg() if gripper else None,
-        sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None,
-        relative_to=RelativeTo.LAST_STEP if relative_to == "last_step" else RelativeTo.CONFIGURED_ORIGIN,
-        n_envs=n_envs, device=device,
-    )
+    venv = envs.make_vec_env(n_envs, async_control, gripper=gripper, relative=relative, control_mode=control_mode, device=device,
+                             max_relative_movement=max_relative_movement, robot=robot if rcfg is None else robot.split("_")[0],
+                             relative_to=relative_to, frequency=frequency, max_convergence_steps=max_convergence_steps, robot_cfg=rcfg)
     if KERNEL != "auto":  # "auto" leaves the handle's default (batch-size rule, or the RCSH_KERNEL environment variable)
         venv.sim.set_kernel(KERNEL)
     return venv
@@ -374,7 +376,7 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
             # xyzrpy: the reference's Euler extraction (yaw in [0, pi], roll near +-pi at a downward-pointing TCP)
             # is discontinuous exactly where the arm lives, so 1e-16 of noise flips the triple; compare the rotation
             rep["max_abs_obs"] = max(rep["max_abs_obs"], float(np.abs(obs["xyzrpy"][e][:3] - oo["xyzrpy"][:3]).max()),
-                                     rpy_distance(obs["xyzrpy"][e][3:], oo["xyzrpy"][3:]))
+                                     rpy_error(obs["xyzrpy"][e][3:], oo["xyzrpy"][3:]))
             if gripper:
                 rep["flag_mismatches"] += int(float(obs["gripper"][e]) != float(oo["gripper"]))
                 rep["max_abs_gripper_width"] = max(rep["max_abs_gripper_width"], abs(float(info["gripper_width"][e]) - oi["gripper_width"]))
@@ -473,6 +475,10 @@ def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=
             rep["ik_fail"] += int(not oi["ik_success"])
             rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:venv.dof] - oe.sim.qpos[:venv.dof]).max()))
             rep["max_abs_tquat"] = max(rep["max_abs_tquat"], float(np.abs(obs["tquat"][e] - oo["tquat"]).max()))
+            rep["max_abs_xyzrpy"] = max(rep.get("max_abs_xyzrpy", 0.0), float(np.abs(obs["xyzrpy"][e][:3] - oo["xyzrpy"][:3]).max()),
+                                        rpy_error(obs["xyzrpy"][e][3:], oo["xyzrpy"][3:]))
+            near = any(min(abs(abs(x) - s_) for s_ in (0.0, np.pi)) < 1e-6 for x in oo["xyzrpy"][3:])
+            rep["rpy_componentwise"] = rep.get("rpy_componentwise", 0) + int(not near)
             rep["max_abs_target"] = max(rep["max_abs_target"], float(np.abs(st.target_angles[e] - np.array(oe.sim.s.target_angles[:venv.dof])).max()))
         rep["steps"] += 1
     venv.close()

@@ -87,6 +87,9 @@ def test_cartesian_relative_clik(mode):
     rep = run_cartesian_rollout_parity(n_envs=32, n_steps=5, async_control=True, seed=11, mode=mode)
     assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL and rep["max_abs_tquat"] < TOL, rep
     assert rep["flag_mismatches"] == 0, rep
+    # the xyzrpy observation, component by component: after +-0.1 rad steps the TCP is tilted away from the roll = +-pi
+    # seam of the reference's Euler extraction, where an equivalent-but-different branch would be an O(1) error
+    assert rep["max_abs_xyzrpy"] < TOL and rep["rpy_componentwise"] > rep["steps"] * 32 // 2, rep
 
 
 @pytest.mark.parametrize("mode", ["joints", "xyzrpy", "tquat"])
@@ -154,6 +157,11 @@ def test_kinematics_api_matches_oracle(robot, kernel):
     qt = q0 + rng.uniform(-0.25, 0.25, size=q0.shape)
     tcp = O.franka_hand_tcp_offset() if robot == "fr3" else O.Pose()
     tcp7 = np.concatenate([tcp.translation(), tcp.rotation_q()])
+    # the base frame (xArm7's base body sits 0.12 m above its world; the FR3's at the origin)
+    bp, obp = venv.robot.get_base_pose_in_world_coordinates(), o.sim.get_base_pose()
+    assert np.abs(bp.translation() - obp.translation()).max() < 1e-15 and np.abs(bp.rotation_q() - obp.rotation_q()).max() < 1e-15
+    if robot == "xarm7":
+        assert abs(bp.translation()[2] - 0.12) < 1e-12
     fwd = ik.forward(qt, tcp7)
     for e in range(n):
         of = o.sim.ik_forward(qt[e], tcp)
@@ -207,6 +215,9 @@ def test_fine_grained_api_sequence_with_masks(kernel):
             if conv:
                 assert int(steps[e]) == int(o.s.convergence_steps) and bool(done[e]) == bool(o.s.converged), (stage, e)
 
+    # SimRobot::get_base_pose_in_world_coordinates (SimRobot.cpp:207-213) and the two frame conversions built on it
+    bp, obp = robot.get_base_pose_in_world_coordinates(), osims[0].get_base_pose()
+    assert np.abs(bp.translation() - obp.translation()).max() < 1e-15 and np.abs(bp.rotation_q() - obp.rotation_q()).max() < 1e-15
     # reset everything, then home the robot (RobotEnv.reset order)
     simu.reset(); robot.reset(); grip.reset()
     for o in osims:
