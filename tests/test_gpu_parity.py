@@ -215,9 +215,6 @@ def test_fine_grained_api_sequence_with_masks(kernel):
             if conv:
                 assert int(steps[e]) == int(o.s.convergence_steps) and bool(done[e]) == bool(o.s.converged), (stage, e)
 
-    # SimRobot::get_base_pose_in_world_coordinates (SimRobot.cpp:207-213) and the two frame conversions built on it
-    bp, obp = robot.get_base_pose_in_world_coordinates(), osims[0].get_base_pose()
-    assert np.abs(bp.translation() - obp.translation()).max() < 1e-15 and np.abs(bp.rotation_q() - obp.rotation_q()).max() < 1e-15
     # reset everything, then home the robot (RobotEnv.reset order)
     simu.reset(); robot.reset(); grip.reset()
     for o in osims:
@@ -225,6 +222,9 @@ def test_fine_grained_api_sequence_with_masks(kernel):
     simu.step(1)
     [o.step(1) for o in osims]
     check("reset")
+    # SimRobot::get_base_pose_in_world_coordinates (SimRobot.cpp:207-213; mjData.xpos / xquat of the base body: valid after a step)
+    bp, obp = robot.get_base_pose_in_world_coordinates(), osims[0].get_base_pose()
+    assert np.abs(bp.translation() - obp.translation()).max() < 1e-15 and np.abs(bp.rotation_q() - obp.rotation_q()).max() < 1e-15
     # joint targets on the odd environments only, gripper shut on the even ones
     tgt = np.tile(FR3_Q_HOME, (n, 1)) + rng.uniform(-0.08, 0.08, size=(n, 7))
     robot.set_joint_position(tgt, mask=odd)
