@@ -392,9 +392,8 @@ static void box_noslip(const orc_box* b, orc_box_data* d, double improvement0) {
   }
 }
 
-/* acceleration stage + integration: mj_fwdAcceleration (gravity, gyroscopic bias), mj_fwdConstraint, implicitfast
-   (no velocity-dependent force on the box: plain semi-implicit Euler), mj_integratePos */
-void orc_box_step2(const orc_box* b, orc_box_data* d, const double* gravity, double h, double improvement0) {
+/* mj_fwdAcceleration of the box: gravity and the gyroscopic bias (angular velocity in the body frame) */
+void orc_box_smooth(const orc_box* b, orc_box_data* d, const double* gravity) {
   const double* w = d->qvel + 3;
   double Iw[3] = {b->inertia[0] * w[0], b->inertia[1] * w[1], b->inertia[2] * w[2]}, gyro[3];
   cross3(w, Iw, gyro);
@@ -404,17 +403,16 @@ void orc_box_step2(const orc_box* b, orc_box_data* d, const double* gravity, dou
     d->qacc_smooth[j] = gravity[j];
     d->qacc_smooth[3 + j] = -gyro[j] / b->inertia[j];
   }
-  if (d->ncon == 0) {
-    memcpy(d->qacc, d->qacc_smooth, sizeof(d->qacc));
-    d->newton_iter = d->noslip_iter = 0;
-  } else {
-    box_newton(b, d);
-    if (b->noslip_iterations > 0) box_noslip(b, d, improvement0);
-  }
+}
+
+/* integration of the box with the acceleration in d->qacc: implicitfast has no velocity-dependent force to treat
+   implicitly here (plain semi-implicit Euler), mj_integratePos with mju_quatIntegrate */
+void orc_box_integrate(const orc_box* b, orc_box_data* d, double h) {
+  (void)b;
+  const double* w = d->qvel + 3;
   memcpy(d->qacc_warmstart, d->qacc, sizeof(d->qacc));
   for (int j = 0; j < 6; j++) d->qvel[j] += h * d->qacc[j];
   for (int j = 0; j < 3; j++) d->qpos[j] += h * d->qvel[j];
-  /* mju_quatIntegrate */
   double ax[3] = {w[0], w[1], w[2]};
   double nrm = sqrt(dot3(ax, ax));
   double q[4] = {d->qpos[3], d->qpos[4], d->qpos[5], d->qpos[6]};
@@ -428,4 +426,18 @@ void orc_box_step2(const orc_box* b, orc_box_data* d, const double* gravity, dou
     normalize4(q);
   }
   memcpy(d->qpos + 3, q, sizeof(q));
+}
+
+/* acceleration stage + integration of the box on its own (no contact with the robot in this step): mj_fwdAcceleration,
+   mj_fwdConstraint restricted to the box's block, integration */
+void orc_box_step2(const orc_box* b, orc_box_data* d, const double* gravity, double h, double improvement0) {
+  orc_box_smooth(b, d, gravity);
+  if (d->ncon == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(d->qacc));
+    d->newton_iter = d->noslip_iter = 0;
+  } else {
+    box_newton(b, d);
+    if (b->noslip_iterations > 0) box_noslip(b, d, improvement0);
+  }
+  orc_box_integrate(b, d, h);
 }

@@ -31,15 +31,19 @@ extern "C" {
 #define ORC_MAXTENDON 4
 #define ORC_MAXWRAP 8
 #define ORC_MAXSITE 8
-#define ORC_MAXEFC (ORC_MAXEQ + 3 * ORC_MAXV)
+#define ORC_MAXCON 64
+#define ORC_MAXEFC (ORC_MAXEQ + 3 * ORC_MAXV + 3 * ORC_MAXCON)
+#define ORC_NVT (ORC_MAXV + 6) /* dofs of the coupled system: the robot's joints, then the free box's 6 */
 #define ORC_MAXARM 8
 #define ORC_MAXGEOM 32
-#define ORC_MAXCON 32
 #define ORC_MAXCGEOM 16
 
 enum { ORC_JNT_SLIDE = 2, ORC_JNT_HINGE = 3 };
 enum { ORC_TRN_JOINT = 0, ORC_TRN_TENDON = 3 };
-enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1, ORC_EFC_FRICTION = 2 };
+/* ORC_EFC_CONTACT: normal row of an elliptic-cone contact (condim 3); its two friction rows follow as ORC_EFC_CONTACT_T */
+enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1, ORC_EFC_FRICTION = 2, ORC_EFC_CONTACT = 3, ORC_EFC_CONTACT_T = 4 };
+/* body / geom id of the free box in contact records (the box is kept outside the robot's body and geom tables) */
+#define ORC_BODY_BOX (-2)
 
 /* ---- one free rigid box on the floor plane (rcs_object.c) */
 typedef struct orc_box {
@@ -48,6 +52,7 @@ typedef struct orc_box {
   double mass, inertia[3]; /* centre of mass at the body origin, principal axes = body axes */
   double size[3];          /* half extents of the box geom */
   double friction[3];      /* mixed with the plane geom: element-wise maximum (equal priority) */
+  double geom_friction[3]; /* the box geom's own coefficients (mixed with a robot geom's per contact) */
   double solref[2], solimp[5];
   double plane_z;          /* floor plane z = plane_z, normal +z */
   double impratio, noslip_tolerance;
@@ -68,6 +73,8 @@ typedef struct orc_box_data {
 void orc_box_reset(const orc_box* b, orc_box_data* d);
 void orc_box_step1(const orc_box* b, orc_box_data* d, double timestep);
 void orc_box_step2(const orc_box* b, orc_box_data* d, const double* gravity, double h, double improvement0);
+void orc_box_smooth(const orc_box* b, orc_box_data* d, const double* gravity);
+void orc_box_integrate(const orc_box* b, orc_box_data* d, double h);
 
 /* ---- model constants (mjModel subset; filled by the Python side from the compiled scene) */
 typedef struct orc_model {
@@ -135,16 +142,26 @@ typedef struct orc_model {
   int geom_contype[ORC_MAXGEOM], geom_conaffinity[ORC_MAXGEOM];
   int geom_vertadr[ORC_MAXGEOM], geom_vertnum[ORC_MAXGEOM];
   double geom_pos[ORC_MAXGEOM][3], geom_quat[ORC_MAXGEOM][4], geom_size[ORC_MAXGEOM][3];
+  double geom_friction[ORC_MAXGEOM][3];
   const double* mesh_vert;          /* [nvert][3] hull vertices, geom frame (owned by the caller) */
   int body_weldid[ORC_MAXBODY];
+  int resolve_contacts;             /* 1: contacts of robot geoms (with the floor, with the free box) enter the constraint solve */
   /* derived by orc_set0 */
   double dof_invweight0[ORC_MAXV];
+  double body_invweight0[ORC_MAXBODY]; /* translational component (mjModel.body_invweight0[.][0]) */
   /* dry joint friction (mjModel dof_frictionloss, dof_solref, dof_solimp) */
   double dof_frictionloss[ORC_MAXV];
   double dof_solref[ORC_MAXV][2];
   double dof_solimp[ORC_MAXV][5];
   orc_box box;
 } orc_model;
+
+/* one contact of the last position stage (mjContact subset); frame rows: normal (geom[0] -> geom[1]), two tangents */
+typedef struct orc_contact {
+  int geom[2], body[2]; /* robot geom / body ids; the free box: geom id = model ngeom, body ORC_BODY_BOX */
+  double pos[3], frame[9], dist, mu;
+  int efc_address, zone; /* first of its three rows in the coupled problem (-1: decoupled step); cone zone at the solution */
+} orc_contact;
 
 /* ---- per-environment state + scratch (mjData subset) */
 typedef struct orc_data {
@@ -172,18 +189,31 @@ typedef struct orc_data {
   /* constraints */
   int nefc, ncon;
   int efc_type[ORC_MAXEFC];
-  double efc_J[ORC_MAXEFC][ORC_MAXV];
+  double efc_J[ORC_MAXEFC][ORC_NVT];
   double efc_pos[ORC_MAXEFC], efc_margin[ORC_MAXEFC], efc_vel[ORC_MAXEFC];
   double efc_D[ORC_MAXEFC], efc_aref[ORC_MAXEFC], efc_force[ORC_MAXEFC];
   double efc_K[ORC_MAXEFC], efc_B[ORC_MAXEFC], efc_I[ORC_MAXEFC];
   double efc_frictionloss[ORC_MAXEFC];
-  double qfrc_constraint[ORC_MAXV];
-  int solver_niter;
+  double efc_R[ORC_MAXEFC], efc_mu[ORC_MAXEFC]; /* contact rows: regulariser; efc_mu on the normal row: the cone's regularised mu */
+  double qfrc_constraint[ORC_NVT];
+  int solver_niter, noslip_niter;
   int contact_geom[ORC_MAXCON][2];  /* d->contact[i].geom, i < ncon */
+  orc_contact contact[ORC_MAXCON];
+  int coupled; /* the last step solved robot and box in one problem (a contact involved a robot geom) */
   orc_box_data box;
 } orc_data;
 
 void orc_set0(orc_model* m);
+/* rcs_contact.c: contacts of the robot's geoms and the coupled constraint problem */
+void orc_collide(const orc_model* m, orc_data* d);
+void orc_make_coupled_rows(const orc_model* m, orc_data* d);
+void orc_solve_coupled(const orc_model* m, orc_data* d);
+double orc_impedance(const double* solimp, double pos, double margin);
+/* narrow-phase pieces exposed for known-answer tests: each returns the number of contacts written */
+int orc_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
+                double* pos /* [8][3] */, double* normal /* [8][3], box 1 -> box 2 */, double* dist /* [8] */);
+int orc_mpr_hull_box(const double* verts, int nvert, const double* ph, const double* Rh, const double* pb, const double* Rb,
+                     const double* sb, double* pos, double* normal /* hull -> box */, double* dist);
 void orc_reset_data(const orc_model* m, orc_data* d);
 void orc_step1(const orc_model* m, orc_data* d);
 void orc_step2(const orc_model* m, orc_data* d);

@@ -15,15 +15,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librcs_oracle.so")
 
 MAXBODY, MAXV, MAXU, MAXEQ, MAXTENDON, MAXWRAP, MAXSITE, MAXARM = 32, 16, 16, 4, 4, 8, 8, 8
-MAXEFC = MAXEQ + 3 * MAXV
-MAXGEOM, MAXCON, MAXCGEOM = 32, 32, 16
+MAXGEOM, MAXCON, MAXCGEOM = 32, 64, 16
+MAXEFC = MAXEQ + 3 * MAXV + 3 * MAXCON
+NVT = MAXV + 6
+BODY_BOX = -2
 D = C.c_double
 I = C.c_int
 
 
 def build(force: bool = False) -> str:
     """Compile oracle/*.c into oracle/_build/librcs_oracle.so (gcc, seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rcs_physics.c", "rcs_pose_ik.c", "rcs_sim.c", "rcs_object.c", "rcs_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("rcs_physics.c", "rcs_pose_ik.c", "rcs_sim.c", "rcs_object.c", "rcs_contact.c", "rcs_oracle.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _SO
@@ -31,7 +33,7 @@ def build(force: bool = False) -> str:
 
 class OrcBox(C.Structure):
     _fields_ = [
-        ("present", I), ("qpos0", D * 7), ("mass", D), ("inertia", D * 3), ("size", D * 3), ("friction", D * 3),
+        ("present", I), ("qpos0", D * 7), ("mass", D), ("inertia", D * 3), ("size", D * 3), ("friction", D * 3), ("geom_friction", D * 3),
         ("solref", D * 2), ("solimp", D * 5), ("plane_z", D), ("impratio", D), ("noslip_tolerance", D),
         ("noslip_iterations", I), ("nv_total", I), ("meaninertia", D),
     ]
@@ -71,11 +73,16 @@ class OrcModel(C.Structure):
         ("ngeom", I), ("geom_type", I * MAXGEOM), ("geom_bodyid", I * MAXGEOM),
         ("geom_contype", I * MAXGEOM), ("geom_conaffinity", I * MAXGEOM), ("geom_vertadr", I * MAXGEOM), ("geom_vertnum", I * MAXGEOM),
         ("geom_pos", D * 3 * MAXGEOM), ("geom_quat", D * 4 * MAXGEOM), ("geom_size", D * 3 * MAXGEOM),
-        ("mesh_vert", C.POINTER(D)), ("body_weldid", I * MAXBODY),
-        ("dof_invweight0", D * MAXV),
+        ("geom_friction", D * 3 * MAXGEOM),
+        ("mesh_vert", C.POINTER(D)), ("body_weldid", I * MAXBODY), ("resolve_contacts", I),
+        ("dof_invweight0", D * MAXV), ("body_invweight0", D * MAXBODY),
         ("dof_frictionloss", D * MAXV), ("dof_solref", D * 2 * MAXV), ("dof_solimp", D * 5 * MAXV),
         ("box", OrcBox),
     ]
+
+
+class OrcContact(C.Structure):
+    _fields_ = [("geom", I * 2), ("body", I * 2), ("pos", D * 3), ("frame", D * 9), ("dist", D), ("mu", D), ("efc_address", I), ("zone", I)]
 
 
 class OrcData(C.Structure):
@@ -90,11 +97,13 @@ class OrcData(C.Structure):
         ("cvel", D * 6 * MAXBODY), ("cdof_dot", D * 6 * MAXV), ("actuator_velocity", D * MAXU),
         ("qfrc_bias", D * MAXV), ("qfrc_passive", D * MAXV), ("qfrc_gravcomp", D * MAXV),
         ("actuator_force", D * MAXU), ("qfrc_actuator", D * MAXV), ("qfrc_smooth", D * MAXV), ("qacc_smooth", D * MAXV),
-        ("nefc", I), ("ncon", I), ("efc_type", I * MAXEFC), ("efc_J", D * MAXV * MAXEFC),
+        ("nefc", I), ("ncon", I), ("efc_type", I * MAXEFC), ("efc_J", D * NVT * MAXEFC),
         ("efc_pos", D * MAXEFC), ("efc_margin", D * MAXEFC), ("efc_vel", D * MAXEFC),
         ("efc_D", D * MAXEFC), ("efc_aref", D * MAXEFC), ("efc_force", D * MAXEFC),
         ("efc_K", D * MAXEFC), ("efc_B", D * MAXEFC), ("efc_I", D * MAXEFC), ("efc_frictionloss", D * MAXEFC),
-        ("qfrc_constraint", D * MAXV), ("solver_niter", I), ("contact_geom", I * 2 * MAXCON),
+        ("efc_R", D * MAXEFC), ("efc_mu", D * MAXEFC),
+        ("qfrc_constraint", D * NVT), ("solver_niter", I), ("noslip_niter", I), ("contact_geom", I * 2 * MAXCON),
+        ("contact", OrcContact * MAXCON), ("coupled", I),
         ("box", OrcBoxData),
     ]
 
@@ -175,8 +184,9 @@ def _fill(dst, src):
         ptr[i] = flat[i].item()
 
 
-def make_model(cm) -> OrcModel:
-    """Fill an ``orc_model`` from a compiled scene (``rcs_amd.mjcf.Model``) and run set0."""
+def make_model(cm, resolve_contacts: bool = True) -> OrcModel:
+    """Fill an ``orc_model`` from a compiled scene (``rcs_amd.mjcf.Model``) and run set0.  `resolve_contacts` False: contacts
+    of robot geoms are detected (collision flags) but exert no force."""
     if cm.nq != cm.nv or cm.nq != cm.njnt:
         raise ValueError("oracle supports hinge/slide joints only")
     if cm.nbody > MAXBODY or cm.nv > MAXV or cm.nu > MAXU:
@@ -206,8 +216,15 @@ def make_model(cm) -> OrcModel:
     m.ngeom = cm.ngeom
     for name in ("geom_type", "geom_bodyid", "geom_contype", "geom_conaffinity", "geom_vertadr", "geom_vertnum"):
         _fill(getattr(m, name), i32(name))
-    for name in ("geom_pos", "geom_quat", "geom_size"):
+    for name in ("geom_pos", "geom_quat", "geom_size", "geom_friction"):
         _fill(getattr(m, name), f64(name))
+    m.resolve_contacts = int(resolve_contacts)
+    # solver options and the default contact parameters (every geom of the RCS scenes keeps the default solref / solimp)
+    m.box.impratio = cm.impratio
+    m.box.noslip_iterations = cm.noslip_iterations if cm.cone == "elliptic" else 0
+    m.box.noslip_tolerance = 1e-6  # mjOption default
+    _fill(m.box.solref, np.array([0.02, 1.0]))
+    _fill(m.box.solimp, np.array([0.9, 0.95, 0.001, 0.5, 2.0]))
     verts = np.ascontiguousarray(cm.arrays["mesh_vert"], dtype=np.float64).reshape(-1)
     if verts.size == 0:
         verts = np.zeros(3)
@@ -221,6 +238,7 @@ def make_model(cm) -> OrcModel:
     if free:
         fb = free[0]
         m.box.present = 1
+        _fill(m.box.geom_friction, np.asarray(fb.get("geom_friction", fb["friction"]), dtype=np.float64))
         for name in ("qpos0", "inertia", "size", "friction", "solref", "solimp"):
             _fill(getattr(m.box, name), np.asarray(fb[name], dtype=np.float64))
         m.box.mass, m.box.plane_z = fb["mass"], fb["plane_z"]
@@ -327,15 +345,20 @@ def franka_hand_tcp_offset() -> Pose:
     return Pose(_raw=out)
 
 
+# contacts of the robot's geoms enter the constraint solve (False: they only raise the collision flags)
+DEFAULT_RESOLVE_CONTACTS = False
+
+
 class Sim:
     """One oracle environment: Sim + SimRobot (+ SimGripper), restating the reference objects."""
 
     def __init__(self, cm, robot_joints, robot_actuators, attachment_site, base, q_home, tcp_offset: Pose | None = None,
                  gripper_joint: str | None = None, gripper_actuator: str | None = None,
-                 register_convergence_callback: bool = True, idx: str = "0", arm_collision_geoms: list[str] | None = None):
+                 register_convergence_callback: bool = True, idx: str = "0", arm_collision_geoms: list[str] | None = None,
+                 resolve_contacts: bool | None = None):
         L = lib()
         self.cm = cm
-        self.model = make_model(cm)
+        self.model = make_model(cm, DEFAULT_RESOLVE_CONTACTS if resolve_contacts is None else resolve_contacts)
         self.s = OrcSim()
         L.orc_sim_init(C.byref(self.s), C.byref(self.model))
         n = len(robot_joints)

@@ -10,7 +10,7 @@
  *
  * Scope: kinematic trees of hinge / slide joints, fixed tendons, joint
  * equalities, joint limits, affine actuators, gravity compensation,
- * implicitfast.  No contacts (ncon == 0) in this revision.
+ * implicitfast.  Contacts: rcs_contact.c (robot geoms), rcs_object.c (the free box on the floor).
  */
 #include <math.h>
 #include <string.h>
@@ -293,7 +293,9 @@ static void actuator_moment(const orc_model* m, int u, double* row) {
 }
 
 /* solimp -> impedance at |pos - margin| (MuJoCo getimpedance) */
-static double impedance(const double* solimp_in, double pos, double margin) {
+double orc_impedance(const double* solimp_in, double pos, double margin);
+static double impedance(const double* solimp_in, double pos, double margin) { return orc_impedance(solimp_in, pos, margin); }
+double orc_impedance(const double* solimp_in, double pos, double margin) {
   double s[5];
   memcpy(s, solimp_in, sizeof(s));
   /* mj_assignImp range clamps */
@@ -421,89 +423,6 @@ static void make_constraint(const orc_model* m, orc_data* d) {
   d->nefc = n;
 }
 
-/* mj_collision restricted to plane-vs-convex pairs: a contact exists when the deepest point of the convex geom
-   is below the plane (margin 0).  Pair filters as MuJoCo applies them: bodies welded together never collide,
-   contype/conaffinity masks must match, parent-child pairs are skipped unless the parent is the world. */
-static void collision(const orc_model* m, orc_data* d) {
-  d->ncon = 0;
-  for (int pg = 0; pg < m->ngeom; pg++) {
-    if (m->geom_type[pg] != 0) continue;
-    int pb = m->geom_bodyid[pg];
-    double pq[4], pR[9], pp[3], vec[3];
-    q_mul(pq, d->xquat[pb], m->geom_quat[pg]);
-    q_to_mat(pR, pq);
-    m3_mulvec(vec, d->xmat[pb], m->geom_pos[pg]);
-    v3_add(pp, vec, d->xpos[pb]);
-    double n[3] = {pR[2], pR[5], pR[8]};
-    for (int g = 0; g < m->ngeom; g++) {
-      if (g == pg || m->geom_type[g] == 0) continue;
-      int b = m->geom_bodyid[g];
-      if (m->body_weldid[b] == m->body_weldid[pb]) continue;
-      if (!((m->geom_contype[g] & m->geom_conaffinity[pg]) || (m->geom_contype[pg] & m->geom_conaffinity[g]))) continue;
-      {
-        int w1 = m->body_weldid[pb], w2 = m->body_weldid[b];
-        int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
-        if ((w1 && w1 == pw2) || (w2 && w2 == pw1)) continue;
-      }
-      double gq[4], gR[9], gp[3];
-      q_mul(gq, d->xquat[b], m->geom_quat[g]);
-      q_to_mat(gR, gq);
-      m3_mulvec(vec, d->xmat[b], m->geom_pos[g]);
-      v3_add(gp, vec, d->xpos[b]);
-      double dist = INFINITY;
-      const double* sz = m->geom_size[g];
-      { /* broad phase (MuJoCo: geom_rbound vs plane): skip geoms whose bounding sphere clears the plane */
-        double rb = 0, x[3];
-        if (m->geom_type[g] == 7) {
-          for (int v = 0; v < m->geom_vertnum[g]; v++) {
-            const double* w = m->mesh_vert + 3 * (m->geom_vertadr[g] + v);
-            double r2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-            if (r2 > rb) rb = r2;
-          }
-          rb = sqrt(rb);
-        } else if (m->geom_type[g] == 6) rb = sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
-        else if (m->geom_type[g] == 3) rb = sz[0] + sz[1];
-        else rb = sz[0];
-        v3_sub(x, gp, pp);
-        if (v3_dot(n, x) - rb > 0) continue;
-      }
-      if (m->geom_type[g] == 7) {
-        for (int v = 0; v < m->geom_vertnum[g]; v++) {
-          double w[3], x[3];
-          m3_mulvec(w, gR, m->mesh_vert + 3 * (m->geom_vertadr[g] + v));
-          v3_add(x, w, gp);
-          v3_sub(x, x, pp);
-          double dd = v3_dot(n, x);
-          if (dd < dist) dist = dd;
-        }
-      } else if (m->geom_type[g] == 6) {
-        for (int c = 0; c < 8; c++) {
-          double loc[3] = {(c & 1 ? sz[0] : -sz[0]), (c & 2 ? sz[1] : -sz[1]), (c & 4 ? sz[2] : -sz[2])}, w[3], x[3];
-          m3_mulvec(w, gR, loc);
-          v3_add(x, w, gp);
-          v3_sub(x, x, pp);
-          double dd = v3_dot(n, x);
-          if (dd < dist) dist = dd;
-        }
-      } else if (m->geom_type[g] == 3 || m->geom_type[g] == 2) {
-        for (int e = 0; e < (m->geom_type[g] == 3 ? 2 : 1); e++) {
-          double loc[3] = {0, 0, m->geom_type[g] == 3 ? (e ? -sz[1] : sz[1]) : 0}, w[3], x[3];
-          m3_mulvec(w, gR, loc);
-          v3_add(x, w, gp);
-          v3_sub(x, x, pp);
-          double dd = v3_dot(n, x) - sz[0];
-          if (dd < dist) dist = dd;
-        }
-      }
-      if (dist < 0 && d->ncon < ORC_MAXCON) {
-        d->contact_geom[d->ncon][0] = pg;
-        d->contact_geom[d->ncon][1] = g;
-        d->ncon++;
-      }
-    }
-  }
-}
-
 /* ------------------------------------------------------------- velocity stage */
 
 /* mj_comVel */
@@ -585,8 +504,10 @@ void orc_step1(const orc_model* m, orc_data* d) {
   com_pos(m, d);
   tendon_and_transmission(m, d);
   crb(m, d);
-  collision(m, d); /* mj_collision: detection only -- contacts raise flags, they apply no force in this revision */
+  if (m->box.present) orc_box_step1(&m->box, &d->box, m->timestep); /* box frame, floor contacts, its rows */
+  orc_collide(m, d); /* mj_collision: d->contact; d->coupled when a robot geom touches something and contacts are resolved */
   make_constraint(m, d);
+  if (d->coupled) orc_make_coupled_rows(m, d);
   /* mj_fwdVelocity */
   for (int u = 0; u < m->nu; u++) {
     double row[ORC_MAXV], v = 0;
@@ -601,10 +522,10 @@ void orc_step1(const orc_model* m, orc_data* d) {
   for (int i = 0; i < d->nefc; i++) {
     double v = 0;
     for (int j = 0; j < m->njnt; j++) v += d->efc_J[i][j] * d->qvel[j];
+    if (m->box.present) for (int k = 0; k < 6; k++) v += d->efc_J[i][m->njnt + k] * d->box.qvel[k];
     d->efc_vel[i] = v;
     d->efc_aref[i] = -d->efc_K[i] * d->efc_I[i] * (d->efc_pos[i] - d->efc_margin[i]) - d->efc_B[i] * v;
   }
-  if (m->box.present) orc_box_step1(&m->box, &d->box, m->timestep);
 }
 
 /* --------------------------------------------------- acceleration / constraint */
@@ -778,16 +699,24 @@ void orc_step2(const orc_model* m, orc_data* d) {
   fwd_actuation(m, d);
   /* mj_fwdAcceleration */
   for (int j = 0; j < nv; j++) d->qfrc_smooth[j] = d->qfrc_passive[j] - d->qfrc_bias[j] + d->qfrc_actuator[j];
-  /* mj_fwdConstraint (noslip has no friction rows to act on without contacts / frictionloss) */
-  solve_constraints(m, d);
-  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
-  if (m->box.present) {
-    /* the box's block of mj_fwdConstraint + integration; the first noslip sweep's improvement counts the cost
-       0.5 f^2 R of every non-equality row of the scene, i.e. the robot's too */
-    double imp0 = 0;
-    for (int i = 0; i < d->nefc; i++)
-      if (d->efc_type[i] != ORC_EFC_EQUALITY) imp0 += 0.5 * d->efc_force[i] * d->efc_force[i] / d->efc_D[i];
-    orc_box_step2(&m->box, &d->box, m->gravity, m->timestep, imp0);
+  if (d->coupled) {
+    /* mj_fwdConstraint over robot + box in one problem (rcs_contact.c): Newton, then the noslip pass over all rows */
+    if (m->box.present) orc_box_smooth(&m->box, &d->box, m->gravity);
+    orc_solve_coupled(m, d);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+    if (m->box.present) orc_box_integrate(&m->box, &d->box, m->timestep);
+  } else {
+    /* mj_fwdConstraint (noslip has no friction rows to act on without contacts / frictionloss) */
+    solve_constraints(m, d);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+    if (m->box.present) {
+      /* the box's block of mj_fwdConstraint + integration; the first noslip sweep's improvement counts the cost
+         0.5 f^2 R of every non-equality row of the scene, i.e. the robot's too */
+      double imp0 = 0;
+      for (int i = 0; i < d->nefc; i++)
+        if (d->efc_type[i] != ORC_EFC_EQUALITY) imp0 += 0.5 * d->efc_force[i] * d->efc_force[i] / d->efc_D[i];
+      orc_box_step2(&m->box, &d->box, m->gravity, m->timestep, imp0);
+    }
   }
   /* mj_implicit, implicitfast: (M - h dF/dv) qacc = qfrc_smooth + qfrc_constraint with
      dF/dv = -damping (passive) + moment^T bias_vel moment (actuators not clamped by forcerange) */
@@ -838,10 +767,44 @@ void orc_set0(orc_model* m) {
     chol_solve(L, m->njnt, e);
     m->dof_invweight0[j] = e[j];
   }
-  if (m->box.present) { /* mj_setConst: stat.meaninertia = mean diagonal of M(qpos0) over all dofs */
-    double s = 3 * m->box.mass + m->box.inertia[0] + m->box.inertia[1] + m->box.inertia[2];
+  /* body_invweight0 (translational): mean diagonal of J M^-1 J' for the body's centre-of-mass Jacobian at qpos0 */
+  for (int b = 0; b < m->nbody; b++) {
+    m->body_invweight0[b] = 0;
+    if (m->body_weldid[b] == 0) continue; /* static */
+    double tr = 0;
+    for (int k = 0; k < 3; k++) {
+      double Jr[ORC_MAXV], y[ORC_MAXV], f[3] = {0, 0, 0};
+      f[k] = 1;
+      memset(Jr, 0, sizeof(Jr));
+      int bb = b;
+      while (bb > 0) {
+        int j = m->body_jntadr[bb];
+        if (j >= 0) {
+          double col[3];
+          if (m->jnt_type[j] == ORC_JNT_SLIDE) v3_copy(col, d.xaxis[j]);
+          else {
+            double r[3];
+            v3_sub(r, d.xipos[b], d.xanchor[j]);
+            v3_cross(col, d.xaxis[j], r);
+          }
+          Jr[j] = v3_dot(col, f);
+        }
+        bb = m->body_parentid[bb];
+      }
+      memcpy(y, Jr, sizeof(y));
+      chol_solve(L, m->njnt, y);
+      for (int j = 0; j < m->njnt; j++) tr += Jr[j] * y[j];
+    }
+    m->body_invweight0[b] = tr / 3;
+  }
+  { /* mj_setConst: stat.meaninertia = mean diagonal of M(qpos0) over all dofs */
+    double s = 0;
     for (int j = 0; j < m->njnt; j++) s += d.qM[j][j];
-    m->box.nv_total = m->njnt + 6;
+    m->box.nv_total = m->njnt;
+    if (m->box.present) {
+      s += 3 * m->box.mass + m->box.inertia[0] + m->box.inertia[1] + m->box.inertia[2];
+      m->box.nv_total += 6;
+    }
     m->box.meaninertia = s / m->box.nv_total;
   }
 }
