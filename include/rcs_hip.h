@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RCSH_ABI_VERSION 1
+#define RCSH_ABI_VERSION 2
 
 enum {
   RCSH_OK = 0,
@@ -99,7 +99,8 @@ typedef struct rcsh_model_desc {
   const int32_t* site_bodyid;        /* [nsite] */
   const double* site_pos;            /* [nsite][3] */
   const double* site_quat;           /* [nsite][4] */
-  /* collision geoms (contact DETECTION against the static plane geoms; flags only) */
+  /* collision geoms: detected against the static plane geom everywhere (collision flags); in scenes with a free box
+   * (rcsh_sim_add_free_box) their contacts with the floor and the box are resolved */
   int32_t ngeom, nmeshvert;
   const int32_t* geom_type;          /* [ngeom] mjtGeom: 0 plane, 2 sphere, 3 capsule, 6 box, 7 mesh */
   const int32_t* geom_bodyid;        /* [ngeom] */
@@ -113,6 +114,7 @@ typedef struct rcsh_model_desc {
   const double* mesh_vert;           /* [nmeshvert][3] convex-hull vertices, geom frame */
   const double* dof_solref;          /* [njnt][2] solreffriction */
   const double* dof_solimp;          /* [njnt][5] solimpfriction */
+  const double* geom_friction;       /* [ngeom][3] sliding, torsional, rolling (contacts are condim 3: only [0] is used) */
 } rcsh_model_desc;
 
 /* SimRobotConfig after name -> id lookup (reference src/sim/SimRobot.h:14-47, SimRobot.cpp:52-94). */
@@ -250,7 +252,9 @@ int rcsh_sim_nu(const rcsh_sim* sim);
  * the mjModel constants of that body and of its contact pair with the floor (mj_contactParam already applied:
  * friction = element-wise max, solref / solimp mixed) plus the solver options the contact solve reads
  * (assets/fr3/mjcf/fr3_common.xml:3).  qpos is [x y z qw qx qy qz], qvel [linear (world), angular (body frame)].
- * Robot-box contacts are not built: the box touches the floor only.  FR3 + hand archetype, team kernel. */
+ * With `resolve_robot_contacts` the robot's collision geoms (finger pads, finger / hand / link hulls, the camera capsule)
+ * collide with the box and with the floor, and one constraint problem couples the robot's joints with the box's 6 dofs
+ * (FR3 + hand archetype); without it the box touches the floor only. */
 typedef struct rcsh_free_box_desc {
   double qpos0[7];
   double mass, inertia[3];   /* centre of mass at the body origin, principal axes = body axes */
@@ -262,6 +266,10 @@ typedef struct rcsh_free_box_desc {
   double noslip_tolerance;   /* mjOption.noslip_tolerance */
   int32_t noslip_iterations; /* mjOption.noslip_iterations */
   int32_t cone_elliptic;     /* mjOption.cone == mjCONE_ELLIPTIC (the only cone type built) */
+  double geom_friction[3];   /* the box geom's own coefficients (mixed with a robot geom's per contact: element-wise max) */
+  double floor_friction[3];  /* the floor geom's */
+  int32_t resolve_robot_contacts;
+  int32_t reserved;
 } rcsh_free_box_desc;
 int rcsh_sim_add_free_box(rcsh_sim* sim, const rcsh_free_box_desc* box);
 int rcsh_sim_reset_free_box(rcsh_sim* sim);

@@ -345,8 +345,14 @@ def franka_hand_tcp_offset() -> Pose:
     return Pose(_raw=out)
 
 
-# contacts of the robot's geoms enter the constraint solve (False: they only raise the collision flags)
-DEFAULT_RESOLVE_CONTACTS = False
+# Contacts of the robot's geoms enter the constraint solve (False: they only raise the collision flags).  None = where the
+# HIP backend resolves them: scenes with a free body and without dry joint friction (rcsh_sim_add_free_box); elsewhere
+# robot contacts are DETECTED only, in the kernels and therefore here.
+DEFAULT_RESOLVE_CONTACTS = None
+
+
+def resolves_contacts(cm) -> bool:
+    return bool(getattr(cm, "free_bodies", [])) and not np.any(np.asarray(cm.arrays["dof_frictionloss"]) > 0)
 
 
 class Sim:
@@ -358,7 +364,9 @@ class Sim:
                  resolve_contacts: bool | None = None):
         L = lib()
         self.cm = cm
-        self.model = make_model(cm, DEFAULT_RESOLVE_CONTACTS if resolve_contacts is None else resolve_contacts)
+        if resolve_contacts is None:
+            resolve_contacts = resolves_contacts(cm) if DEFAULT_RESOLVE_CONTACTS is None else DEFAULT_RESOLVE_CONTACTS
+        self.model = make_model(cm, resolve_contacts)
         self.s = OrcSim()
         L.orc_sim_init(C.byref(self.s), C.byref(self.model))
         n = len(robot_joints)

@@ -29,7 +29,9 @@ struct BoxCfg {
   double qpos0[7];  // x y z, qw qx qy qz
   double mass, inertia[3], inv_mass, inv_inertia[3];
   double size[3];   // half extents
-  double fr;        // sliding friction coefficient of the pair (condim 3: both tangential directions)
+  double fr;        // sliding friction coefficient of the (floor, box) pair (condim 3: both tangential directions)
+  double geom_mu;   // the box geom's own sliding friction (mixed with a robot geom's per contact)
+  int32_t resolve, pad0;  // contacts of robot geoms enter the constraint solve (contact_team.h)
   double K, B;      // stiffness / damping of the reference acceleration (solref)
   Imp imp;          // solimp
   double inv_impratio;
@@ -40,7 +42,8 @@ struct BoxCfg {
 
 // per-team LDS block: qpos 7, qvel 6, qacc_warmstart 6, then the 12 x 6 contact Jacobian for the noslip pass
 // (and the pose the last position stage saw: what the renderer draws)
-constexpr int kBoxQ = 0, kBoxV = 7, kBoxW = 13, kBoxPre = 19, kBoxState = 26, kBoxJ = 26, kBoxLds = kBoxJ + 72;
+// (kBoxA: the box's acceleration out of a coupled robot + box solve)
+constexpr int kBoxQ = 0, kBoxV = 7, kBoxW = 13, kBoxPre = 19, kBoxState = 26, kBoxJ = 26, kBoxA = kBoxJ + 72, kBoxLds = kBoxA + 6;
 
 #if defined(__HIP__)
 
@@ -151,7 +154,9 @@ RCSH_D bool box_qcqp2(double* res, double A00, double A01, double A11, double b0
 
 // One substep of the box.  bs: the team's LDS block (kBoxLds doubles); improvement0: 0.5 f^2 R summed over the
 // robot's non-equality constraint rows (MuJoCo's first noslip sweep counts every such row of the scene).
-RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, double h, double improvement0, int t) {
+// coupled (team-uniform): the step's constraints were solved together with the robot's (contact_team.h), the box's
+// acceleration is in bs[kBoxA..]: only the position stage's bookkeeping and the integration are left.
+RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, double h, double improvement0, int t, bool coupled) {
   constexpr double kMin = 1e-15;
   double p[3], q[4], v[6], warm[6];
 #pragma unroll
@@ -258,7 +263,10 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
 #pragma unroll
   for (int j = 0; j < 6; ++j) x[j] = xs[j];
   TEAM_MARK(16)
-  if (ncon > 0) {
+  if (coupled) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) x[j] = bs[kBoxA + j];
+  } else if (ncon > 0) {
     // ---- Newton on the primal cost; warm start = the cheaper of qacc_warmstart and qacc_smooth
     if (!(box_cost(b, c, Md, xs, xs) < box_cost(b, c, Md, xs, warm))) {
 #pragma unroll

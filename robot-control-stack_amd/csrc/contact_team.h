@@ -1,0 +1,1356 @@
+// contact_team.h -- contacts of the robot's collision geoms (with the floor, with the free box) and the constraint
+// problem that couples the robot's joints with the box's six degrees of freedom: what makes a grasp hold.
+// Reference: finger pads assets/fr3/mjcf/fr3_0.xml:145-162 against the cube assets/scenes/fr3_simple_pick_up/scene.xml:30-33,
+// read by SimGripper::collision_callback / SimRobot::collision_callback (src/sim/SimGripper.cpp:108-130,
+// src/sim/SimRobot.cpp:172-182) and PickCubeSuccessWrapper (python/rcs/envs/sim.py:396-431).  Physics: MuJoCo's
+// collision + soft-constraint pipeline for these scenes (box-box by separating axes + face clipping, convex pairs by
+// Minkowski portal refinement, elliptic cones, Newton on the primal cost, the noslip pass), restated -- see DESIGN.md.
+//
+// THE WAVE GANGS UP ON ONE ENVIRONMENT.  A team's 16 lanes own an environment in the fast path (dyn_team.h); contacts
+// are rare (a gripper near the cube, an arm on the floor) and their working set -- up to 48 contacts of 3 rows, a
+// 15 x 15 Hessian -- does not fit four times into the LDS a workgroup may use without evicting its neighbours from the
+// CU.  So when a team's broad phase fires, ALL 64 lanes of the wavefront work on that one environment, teams taking
+// turns:
+//   * collision: lane g tests collision geom g (pad boxes by SAT + clipping, hulls / the capsule by MPR, everything
+//     against the floor plane), contacts are compacted into MuJoCo's order with a prefix over the lanes;
+//   * lane c then OWNS contact c for the rest of the solve: its frame, its 3 x 6 map G_c from spatial motion about the
+//     world origin to contact-frame velocity, reference accelerations, regularisers and force live in its registers;
+//   * the contact Jacobian is never formed.  J_c = G_c (S_B - S_A) with S_b the 6 x nv spatial Jacobian of body b, so
+//     J x = G_c (U_B - U_A) needs the bodies' spatial accelerations U_b = S_b x (9 links + the box: one lane each, the
+//     robot's by summing motion axes down the chain), J' f is a wrench per body pushed through the same leaf-to-root
+//     sums as the bias forces, and J' D J is a 6 x 6 contact stiffness per body PAIR folded into the mass matrix's own
+//     recursion (composite stiffness next to composite inertia): H = M + S'(K) S;
+//   * the 15 x 15 Hessian is assembled in LDS by 15 lanes, then every lane factors it (LDL', fully unrolled, registers)
+//     and solves -- redundancy is free, the instructions are issued for the wave anyway;
+//   * the noslip pass is Gauss-Seidel over the contacts in order: the owner lane solves its 2 x 2 friction QCQP, the
+//     change of its wrench is pushed into the bodies' accelerations through Y_b = M^-1 S_b' (held for the few links in
+//     contact), 9 + 1 lanes updating one body each.
+#pragma once
+#include "box_team.h"
+#include "contact_types.h"
+
+namespace rcsh {
+
+#if defined(__HIP__)
+
+// ---- wave-level helpers (64 lanes)
+RCSH_D double wave_sum(double x) {
+  x = quad_sum(x);
+  x += row_rotate<4>(x);
+  x += row_rotate<8>(x);
+  return (lane_get(x, 0) + lane_get(x, 16)) + (lane_get(x, 32) + lane_get(x, 48));
+}
+RCSH_D int wave_lane() { return threadIdx.x & 63; }
+
+template <class T>
+struct ContactArena {
+  static constexpr int NL = T::NL, NB = T::NL + 2, NV = T::NL + 6;
+  static constexpr int kBox = NL, kWorld = NL + 1;
+  double F[NL][12];        // world frames of the links: R(9) p(3)
+  double V[NB][6];         // spatial velocity of the bodies about the world origin [angular; linear]
+  double U[NB][6];         // spatial acceleration for the current iterate
+  double Up[NB][6];        // ... for the search direction
+  double W[NB][6];         // wrench on every body
+  double X[16], A0[16], P[16], Gd[16];
+  double H[NV * (NV + 1) / 2];
+  double KA[2 * kMaxActive + 1][21];  // contact stiffness: (link a, box) pairs, (world, link a) pairs, (world, box)
+  double stage[64][10];    // contact records out of the collision phase; later per-contact wrenches / stiffness batches / Y
+  int32_t cb[64];          // bodies of contact c: A | B << 8 | class bits << 16
+  int32_t cnt[64][2];      // per geom lane: plane contacts, box contacts
+  int32_t act[kMaxActive]; // links in contact
+  int32_t nact, ncon, hit, pad;
+};
+
+// is joint j an ancestor-or-self joint of link i?
+template <class T>
+RCSH_D bool is_anc(int j, int i) {
+  if (T::GRIP && i == T::NARM + 1 && j == T::NARM) return false;
+  return j <= i;
+}
+
+// mju_makeFrame
+RCSH_D void make_frame(const double* n, double* t1, double* t2) {
+  double y[3] = {0, 0, 0};
+  if (n[1] > -0.5 && n[1] < 0.5) y[1] = 1; else y[2] = 1;
+  const double s = dot3(n, y);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) y[k] -= s * n[k];
+  const double il = 1.0 / sqrt(dot3(y, y));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t1[k] = y[k] * il;
+  cross3(n, t1, t2);
+}
+RCSH_D void mulTv(const double* R, const double* v, double* o) {
+  const double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2], z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+
+// ------------------------------------------------------------------ box - box (oracle: orc_box_box)
+__device__ __noinline__ int dev_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
+                                       double* pos /* [8][3] */, double* nrm /* [3] */, double* dist /* [8] */) {
+  double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, t[3], R[3][3], Q[3][3];
+  mulTv(R1, d, t);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      R[i][j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+      Q[i][j] = fabs(R[i][j]);
+    }
+  double best = INFINITY;
+  int code = -1;
+  for (int i = 0; i < 3; ++i) {
+    const double pen = s1[i] + s2[0] * Q[i][0] + s2[1] * Q[i][1] + s2[2] * Q[i][2] - fabs(t[i]);
+    if (pen < 0) return 0;
+    if (pen < best) { best = pen; code = i; }
+  }
+  for (int j = 0; j < 3; ++j) {
+    const double tb = t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j];
+    const double pen = s2[j] + s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j] - fabs(tb);
+    if (pen < 0) return 0;
+    if (pen < best) { best = pen; code = 3 + j; }
+  }
+  double ebest = INFINITY;
+  int ecode = -1;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double l2 = 1 - R[i][j] * R[i][j];
+      if (l2 < 1e-6) continue;
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double ra = s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j];
+      const double rb = s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1];
+      const double tl = fabs(t[i2] * R[i1][j] - t[i1] * R[i2][j]);
+      const double pen = (ra + rb - tl) / sqrt(l2);
+      if (pen < 0) return 0;
+      if (pen < ebest) { ebest = pen; ecode = 3 * i + j; }
+    }
+  if (ecode >= 0 && ebest * 1.05 < best) {
+    const int i = ecode / 3, j = ecode % 3;
+    const double A[3] = {R1[i], R1[3 + i], R1[6 + i]}, B[3] = {R2[j], R2[3 + j], R2[6 + j]};
+    double n[3];
+    cross3(A, B, n);
+    const double l = sqrt(dot3(n, n));
+    for (int k = 0; k < 3; ++k) n[k] /= l;
+    if (dot3(n, d) < 0) for (int k = 0; k < 3; ++k) n[k] = -n[k];
+    double pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int k = 0; k < 3; ++k) {
+      if (k != i) {
+        const double Ak[3] = {R1[k], R1[3 + k], R1[6 + k]};
+        const double sg = dot3(n, Ak) > 0 ? s1[k] : -s1[k];
+        for (int c = 0; c < 3; ++c) pa[c] += sg * Ak[c];
+      }
+      if (k != j) {
+        const double Bk[3] = {R2[k], R2[3 + k], R2[6 + k]};
+        const double sg = dot3(n, Bk) > 0 ? -s2[k] : s2[k];
+        for (int c = 0; c < 3; ++c) pb[c] += sg * Bk[c];
+      }
+    }
+    const double p[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+    const double uaub = dot3(A, B), q1 = dot3(A, p), q2 = -dot3(B, p), dd = 1 - uaub * uaub;
+    double al = 0, be = 0;
+    if (dd > 1e-4) { al = (q1 + uaub * q2) / dd; be = (uaub * q1 + q2) / dd; }
+    for (int c = 0; c < 3; ++c) {
+      pos[c] = 0.5 * ((pa[c] + al * A[c]) + (pb[c] + be * B[c]));
+      nrm[c] = n[c];
+    }
+    dist[0] = -ebest;
+    return 1;
+  }
+  const bool ref1 = code < 3;
+  const int a = ref1 ? code : code - 3;
+  const double *Rr = ref1 ? R1 : R2, *pr = ref1 ? p1 : p2, *sr = ref1 ? s1 : s2;
+  const double *Ri = ref1 ? R2 : R1, *pi = ref1 ? p2 : p1, *si = ref1 ? s2 : s1;
+  const double ci[3] = {pi[0] - pr[0], pi[1] - pr[1], pi[2] - pr[2]};
+  const double Ar[3] = {Rr[a], Rr[3 + a], Rr[6 + a]};
+  const double sgn = dot3(ci, Ar) >= 0 ? 1.0 : -1.0;
+  const double n[3] = {sgn * Ar[0], sgn * Ar[1], sgn * Ar[2]};
+  int b = 0;
+  double bestdot = -1;
+  for (int k = 0; k < 3; ++k) {
+    const double Bk[3] = {Ri[k], Ri[3 + k], Ri[6 + k]};
+    const double v = fabs(dot3(n, Bk));
+    if (v > bestdot) { bestdot = v; b = k; }
+  }
+  const double Bb[3] = {Ri[b], Ri[3 + b], Ri[6 + b]};
+  const double sb = dot3(n, Bb) > 0 ? -si[b] : si[b];
+  const int u = (b + 1) % 3, v = (b + 2) % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+  const double Bu[3] = {Ri[u], Ri[3 + u], Ri[6 + u]}, Bv[3] = {Ri[v], Ri[3 + v], Ri[6 + v]};
+  double poly[2][16][3];
+  for (int q = 0; q < 4; ++q) {
+    const double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = q < 2 ? 1.0 : -1.0;
+    double w[3];
+    for (int c = 0; c < 3; ++c) w[c] = pi[c] + sb * Bb[c] + su * si[u] * Bu[c] + sv * si[v] * Bv[c] - pr[c];
+    mulTv(Rr, w, poly[0][q]);
+  }
+  int np = 4, cur = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int axis = pass < 2 ? a1 : a2;
+    const double sign = (pass & 1) ? -1.0 : 1.0, lim = sr[axis];
+    int m = 0;
+    for (int i = 0; i < np; ++i) {
+      const double* pa_ = poly[cur][i];
+      const double* pb_ = poly[cur][(i + 1) % np];
+      const double da = sign * pa_[axis] - lim, db = sign * pb_[axis] - lim;
+      if (da <= 0) { for (int c = 0; c < 3; ++c) poly[cur ^ 1][m][c] = pa_[c]; ++m; }
+      if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+        const double s = da / (da - db);
+        for (int c = 0; c < 3; ++c) poly[cur ^ 1][m][c] = pa_[c] + s * (pb_[c] - pa_[c]);
+        ++m;
+      }
+    }
+    np = m;
+    cur ^= 1;
+  }
+  int nc = 0;
+  for (int q = 0; q < np && nc < 8; ++q) {
+    const double depth = sr[a] - sgn * poly[cur][q][a];
+    if (depth < 0) continue;
+    double w[3];
+    mulmv(Rr, poly[cur][q], w);
+    for (int c = 0; c < 3; ++c) pos[3 * nc + c] = w[c] + pr[c] + n[c] * 0.5 * depth;
+    dist[nc] = -depth;
+    ++nc;
+  }
+  for (int c = 0; c < 3; ++c) nrm[c] = ref1 ? n[c] : -n[c];
+  return nc;
+}
+
+// ------------------------------------------------------------------ Minkowski portal refinement (oracle: mpr_penetration)
+struct Shape {
+  int type;              // 0 hull, 1 box, 2 capsule
+  const double *p, *R;   // world frame
+  const double* size;
+  const double* verts;
+  int nvert;
+  double center[3];
+};
+__device__ __noinline__ void shape_support(const Shape& s, const double* dir, double* out) {
+  double l[3], w[3] = {0, 0, 0};
+  mulTv(s.R, dir, l);
+  if (s.type == 0) {
+    double bestv = -INFINITY;
+    int bi = 0;
+    for (int i = 0; i < s.nvert; ++i) {
+      const double v = s.verts[3 * i] * l[0] + s.verts[3 * i + 1] * l[1] + s.verts[3 * i + 2] * l[2];
+      if (v > bestv) { bestv = v; bi = i; }
+    }
+    w[0] = s.verts[3 * bi]; w[1] = s.verts[3 * bi + 1]; w[2] = s.verts[3 * bi + 2];
+  } else if (s.type == 1) {
+    for (int k = 0; k < 3; ++k) w[k] = l[k] >= 0 ? s.size[k] : -s.size[k];
+  } else {
+    const double nl = sqrt(dot3(l, l));
+    w[2] = l[2] >= 0 ? s.size[1] : -s.size[1];
+    if (nl > kMinVal) for (int k = 0; k < 3; ++k) w[k] += s.size[0] * l[k] / nl;
+  }
+  mulmv(s.R, w, out);
+  out[0] += s.p[0]; out[1] += s.p[1]; out[2] += s.p[2];
+}
+struct MprPt { double v[3], v1[3], v2[3]; };
+RCSH_D void mpr_support(const Shape& a, const Shape& b, const double* dir, MprPt& o) {
+  const double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  shape_support(a, dir, o.v1);
+  shape_support(b, nd, o.v2);
+  for (int k = 0; k < 3; ++k) o.v[k] = o.v1[k] - o.v2[k];
+}
+RCSH_D void portal_dir(const MprPt& p1, const MprPt& p2, const MprPt& p3, double* dir) {
+  const double e1[3] = {p2.v[0] - p1.v[0], p2.v[1] - p1.v[1], p2.v[2] - p1.v[2]}, e2[3] = {p3.v[0] - p1.v[0], p3.v[1] - p1.v[1], p3.v[2] - p1.v[2]};
+  cross3(e1, e2, dir);
+  const double l = sqrt(dot3(dir, dir));
+  if (l > kMinVal) { dir[0] /= l; dir[1] /= l; dir[2] /= l; }
+}
+RCSH_D void expand_portal(const MprPt& p0, MprPt& p1, MprPt& p2, MprPt& p3, const MprPt& p4) {
+  double c[3];
+  cross3(p4.v, p0.v, c);
+  if (dot3(p1.v, c) > 0) {
+    if (dot3(p2.v, c) > 0) p1 = p4; else p3 = p4;
+  } else {
+    if (dot3(p3.v, c) > 0) p2 = p4; else p1 = p4;
+  }
+}
+RCSH_D double origin_tri_dist2(const double* a, const double* b, const double* c, double* witness) {
+  const double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, ap[3] = {-a[0], -a[1], -a[2]};
+  const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+  double s, t;
+  if (d1 <= 0 && d2 <= 0) { s = 0; t = 0; }
+  else {
+    const double bp[3] = {-b[0], -b[1], -b[2]}, d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    const double cp[3] = {-c[0], -c[1], -c[2]}, d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d3 >= 0 && d4 <= d3) { s = 1; t = 0; }
+    else if (vc <= 0 && d1 >= 0 && d3 <= 0) { s = d1 / (d1 - d3); t = 0; }
+    else if (d6 >= 0 && d5 <= d6) { s = 0; t = 1; }
+    else if (vb <= 0 && d2 >= 0 && d6 <= 0) { s = 0; t = d2 / (d2 - d6); }
+    else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { t = (d4 - d3) / ((d4 - d3) + (d5 - d6)); s = 1 - t; }
+    else { const double den = 1 / (va + vb + vc); s = vb * den; t = vc * den; }
+  }
+  for (int k = 0; k < 3; ++k) witness[k] = a[k] + s * ab[k] + t * ac[k];
+  return dot3(witness, witness);
+}
+__device__ __noinline__ int dev_mpr(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
+  constexpr double kTol = 1e-6;
+  constexpr int kIter = 50;
+  MprPt p0, p1, p2, p3, p4;
+  double dir[3], va[3], vb[3];
+  for (int k = 0; k < 3; ++k) { p0.v[k] = A.center[k] - B.center[k]; p0.v1[k] = A.center[k]; p0.v2[k] = B.center[k]; }
+  if (fabs(p0.v[0]) < kMinVal && fabs(p0.v[1]) < kMinVal && fabs(p0.v[2]) < kMinVal) p0.v[0] = 1e-5;
+  double l = sqrt(dot3(p0.v, p0.v));
+  for (int k = 0; k < 3; ++k) dir[k] = -p0.v[k] / l;
+  mpr_support(A, B, dir, p1);
+  if (dot3(p1.v, dir) <= 0) return 0;
+  cross3(p0.v, p1.v, dir);
+  l = sqrt(dot3(dir, dir));
+  if (l < 1e-12) {
+    *depth = sqrt(dot3(p1.v, p1.v));
+    const double l0 = sqrt(dot3(p0.v, p0.v));
+    for (int k = 0; k < 3; ++k) { dir_out[k] = *depth > kMinVal ? p1.v[k] / *depth : -p0.v[k] / l0; pos[k] = 0.5 * (p1.v1[k] + p1.v2[k]); }
+    return 1;
+  }
+  for (int k = 0; k < 3; ++k) dir[k] /= l;
+  mpr_support(A, B, dir, p2);
+  if (dot3(p2.v, dir) <= 0) return 0;
+  for (int k = 0; k < 3; ++k) { va[k] = p1.v[k] - p0.v[k]; vb[k] = p2.v[k] - p0.v[k]; }
+  cross3(va, vb, dir);
+  l = sqrt(dot3(dir, dir));
+  for (int k = 0; k < 3; ++k) dir[k] /= l;
+  if (dot3(dir, p0.v) > 0) {
+    const MprPt tmp = p1; p1 = p2; p2 = tmp;
+    for (int k = 0; k < 3; ++k) dir[k] = -dir[k];
+  }
+  for (int guard = 0;; ++guard) {
+    if (guard > 100) return 0;
+    mpr_support(A, B, dir, p3);
+    if (dot3(p3.v, dir) <= 0) return 0;
+    bool cont = false;
+    cross3(p1.v, p3.v, va);
+    if (dot3(va, p0.v) < -kMinVal) { p2 = p3; cont = true; }
+    if (!cont) {
+      cross3(p3.v, p2.v, va);
+      if (dot3(va, p0.v) < -kMinVal) { p1 = p3; cont = true; }
+    }
+    if (!cont) break;
+    for (int k = 0; k < 3; ++k) { va[k] = p1.v[k] - p0.v[k]; vb[k] = p2.v[k] - p0.v[k]; }
+    cross3(va, vb, dir);
+    l = sqrt(dot3(dir, dir));
+    for (int k = 0; k < 3; ++k) dir[k] /= l;
+  }
+  for (int it = 0;; ++it) {
+    portal_dir(p1, p2, p3, dir);
+    if (dot3(dir, p1.v) >= 0) break;
+    mpr_support(A, B, dir, p4);
+    const double dv4 = dot3(p4.v, dir);
+    const double dmax = fmax(dot3(p1.v, dir), fmax(dot3(p2.v, dir), dot3(p3.v, dir)));
+    if (dv4 < 0 || dv4 - dmax <= kTol || it > kIter) return 0;
+    expand_portal(p0, p1, p2, p3, p4);
+  }
+  for (int it = 0;; ++it) {
+    portal_dir(p1, p2, p3, dir);
+    mpr_support(A, B, dir, p4);
+    const double dv4 = dot3(p4.v, dir);
+    const double dmax = fmax(dot3(p1.v, dir), fmax(dot3(p2.v, dir), dot3(p3.v, dir)));
+    if (dv4 - dmax <= kTol || it > kIter) {
+      double w[3];
+      const double d2 = origin_tri_dist2(p1.v, p2.v, p3.v, w);
+      *depth = sqrt(d2);
+      if (*depth > kMinVal) for (int k = 0; k < 3; ++k) dir_out[k] = w[k] / *depth;
+      else for (int k = 0; k < 3; ++k) dir_out[k] = dir[k];
+      double bw[4], c[3];
+      cross3(p1.v, p2.v, c); bw[0] = dot3(c, p3.v);
+      cross3(p3.v, p2.v, c); bw[1] = dot3(c, p0.v);
+      cross3(p0.v, p1.v, c); bw[2] = dot3(c, p3.v);
+      cross3(p2.v, p1.v, c); bw[3] = dot3(c, p0.v);
+      double sum = bw[0] + bw[1] + bw[2] + bw[3];
+      if (sum <= 0) {
+        bw[0] = 0;
+        cross3(p2.v, p3.v, c); bw[1] = dot3(c, dir);
+        cross3(p3.v, p1.v, c); bw[2] = dot3(c, dir);
+        cross3(p1.v, p2.v, c); bw[3] = dot3(c, dir);
+        sum = bw[1] + bw[2] + bw[3];
+      }
+      for (int k = 0; k < 3; ++k) {
+        const double a1 = bw[0] * p0.v1[k] + bw[1] * p1.v1[k] + bw[2] * p2.v1[k] + bw[3] * p3.v1[k];
+        const double a2 = bw[0] * p0.v2[k] + bw[1] * p1.v2[k] + bw[2] * p2.v2[k] + bw[3] * p3.v2[k];
+        pos[k] = 0.5 * (a1 + a2) / sum;
+      }
+      return 1;
+    }
+    expand_portal(p0, p1, p2, p3, p4);
+  }
+}
+
+// elliptic cone of one contact at jar (mj_constraintUpdate): force f = -dcost/djar, Hessian (00 10 11 20 21 22), cost
+RCSH_D double cone_eval(const double* D, double mu, double fr, const double* jar, double* f, double* Hc) {
+  const double U0 = jar[0] * mu, U1 = jar[1] * fr, U2 = jar[2] * fr;
+  const double N = U0, T = sqrt(U1 * U1 + U2 * U2);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Hc[k] = 0.0;
+  f[0] = f[1] = f[2] = 0.0;
+  if (N >= mu * T) return 0.0;
+  if (mu * N + T <= 0) {
+    double cost = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cost += 0.5 * D[k] * jar[k] * jar[k]; f[k] = -D[k] * jar[k]; }
+    Hc[0] = D[0]; Hc[2] = D[1]; Hc[5] = D[2];
+    return cost;
+  }
+  const double Dm = D[0] / (mu * mu * (1 + mu * mu));
+  const double NmT = N - mu * T;
+  const double u1 = U1 / T, u2 = U2 / T;
+  f[0] = -mu * (Dm * NmT);
+  f[1] = fr * (Dm * NmT * mu * u1);
+  f[2] = fr * (Dm * NmT * mu * u2);
+  const double k = -Dm * NmT * mu / T;
+  Hc[0] = mu * mu * Dm;
+  Hc[1] = mu * fr * (-Dm * mu * u1);
+  Hc[3] = mu * fr * (-Dm * mu * u2);
+  Hc[2] = fr * fr * (Dm * mu * mu * u1 * u1 + k * (1 - u1 * u1));
+  Hc[4] = fr * fr * (Dm * mu * mu * u2 * u1 + k * (-u2 * u1));
+  Hc[5] = fr * fr * (Dm * mu * mu * u2 * u2 + k * (1 - u2 * u2));
+  return 0.5 * Dm * NmT * NmT;
+}
+
+// mju_QCQP2 with separate friction coefficients (oracle: qcqp2)
+RCSH_D bool qcqp2_dev(double* res, double A00, double A01, double A11, double b0, double b1, double d0, double d1, double r) {
+  const double s1 = b0 * d0, s2 = b1 * d1;
+  const double S11 = A00 * d0 * d0, S22 = A11 * d1 * d1, S12 = A01 * d0 * d1;
+  double la = 0, v1 = 0, v2 = 0;
+  for (int iter = 0; iter < 20; ++iter) {
+    const double det = (S11 + la) * (S22 + la) - S12 * S12;
+    if (det < 1e-10) { res[0] = res[1] = 0; return false; }
+    const double di = 1 / det, P11 = (S22 + la) * di, P22 = (S11 + la) * di, P12 = -S12 * di;
+    v1 = -P11 * s1 - P12 * s2;
+    v2 = -P12 * s1 - P22 * s2;
+    const double val = v1 * v1 + v2 * v2 - r * r;
+    if (val < 1e-10) break;
+    const double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+    const double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * d0;
+  res[1] = v2 * d1;
+  return la != 0;
+}
+
+// Spatial quantity S_b x of every body for a vector x over the dofs (LDS, NV entries): links by summing their ancestors'
+// motion axes (lane i < NL), the box from its frame (lane NL), the world zero (lane NL + 1).  out: [NB][6] in LDS.
+template <class T>
+RCSH_D void body_spatial(const StageTeam<T>& st, const double* x, const double* boxR, const double* boxp, double (*out)[6], int lane) {
+  constexpr int NL = T::NL;
+  if (lane < NL) {
+    double u[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < NL; ++j) {
+      if (!is_anc<T>(j, lane)) continue;
+      const double xj = x[j];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) u[k] += st.S(j, k) * xj;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[lane][k] = u[k];
+  } else if (lane == NL) {
+    double w[3], c[3];
+    mulmv(boxR, x + NL + 3, w);  // angular part is in the body frame
+    cross3(boxp, w, c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { out[NL][k] = w[k]; out[NL][3 + k] = x[NL + k] + c[k]; }
+  } else if (lane == NL + 1) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out[NL + 1][k] = 0.0;
+  }
+}
+
+// The contact phase of one environment, executed by the whole wavefront.  `st` / `bs`: the environment's LDS blocks
+// (robot: pre-step q, qd, motion axes S, mass matrix, qfrc_smooth, limit / equality rows of this substep; box: state).
+// Returns bit 0: coupled (a robot geom is in contact: st.fcon holds the robot's constraint force, bs[kBoxA..] the box's
+// acceleration); bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
+template <class T>
+__device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st,
+                                               double* bs, ContactArena<T>& ar, const double* gravity, double h) {
+  constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6, NB = NL + 2;
+  constexpr int kBox = NL, kWorld = NL + 1;
+  const int lane = wave_lane();
+  // ---- link frames at the pre-step configuration: lane i < NL walks the chain to link i
+  if (lane < NL) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    for (int i = 0; i < NL; ++i) {
+      if (!is_anc<T>(i, lane)) continue;
+      KinK kk;
+      kk.load(links[i]);
+      double Rl[9], pl[3], pn[3];
+      link_local_frame(kk, st.q(i), Rl, pl);
+      mulmv(R, pl, pn);
+      p[0] += pn[0]; p[1] += pn[1]; p[2] += pn[2];
+      mulmm(R, Rl, R);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ar.F[lane][k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ar.F[lane][9 + k] = p[k];
+  }
+  // ---- the box: frame (mj_kinematics normalises the quaternion), every lane
+  double bp[3], bq[4], bR[9], bv[6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) bp[k] = bs[kBoxQ + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bq[k] = bs[kBoxQ + 3 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bv[k] = bs[kBoxV + k];
+  {
+    const double n = sqrt(bq[0] * bq[0] + bq[1] * bq[1] + bq[2] * bq[2] + bq[3] * bq[3]);
+    if (n < kMinVal) { bq[0] = 1; bq[1] = bq[2] = bq[3] = 0; }
+    else if (fabs(n - 1) > kMinVal) {
+      const double s = 1 / n;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bq[k] *= s;
+    }
+    const double w = bq[0], x = bq[1], y = bq[2], z = bq[3];
+    bR[0] = w * w + x * x - y * y - z * z; bR[4] = w * w - x * x + y * y - z * z; bR[8] = w * w - x * x - y * y + z * z;
+    bR[1] = 2 * (x * y - w * z); bR[2] = 2 * (x * z + w * y); bR[3] = 2 * (x * y + w * z);
+    bR[5] = 2 * (y * z - w * x); bR[6] = 2 * (x * z - w * y); bR[7] = 2 * (y * z + w * x);
+  }
+  __syncthreads();
+
+  // ================================================================= collision
+  // lane g: collision geom g against the floor plane and against the box
+  double ppos[4][3], pdist[4], cpos[8][3], cdist[8], cn[3] = {0, 0, 0};
+  int nP = 0, nB = 0, boxfirst = 0;
+  ContactGeom cg;
+  const bool has_geom = lane < tab.ngeom;
+  if (has_geom) {
+    cg = tab.geoms[lane];
+    double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0};
+    if (cg.link >= 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rl[k] = ar.F[cg.link][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = ar.F[cg.link][9 + k];
+    }
+    double gR[9], gp[3];
+    mulmm(Rl, cg.rot, gR);
+    mulmv(Rl, cg.pos, gp);
+    gp[0] += pl[0]; gp[1] += pl[1]; gp[2] += pl[2];
+    const double* V = tab.verts + 3 * (size_t)cg.vert_adr;
+    // ---- floor
+    if (tab.has_plane && cg.plane_ok) {
+      const double* n = tab.plane_n;
+      const double cdst = dot3(n, gp) - tab.plane_d;
+      if (cdst - cg.rbound <= 0) {
+        if (cg.type == 7) {
+          double fr[9] = {n[0], n[1], n[2]};
+          make_frame(fr, fr + 3, fr + 6);
+          int chosen[4];
+          for (int q = 0; q < 4; ++q) {
+            double dir[3];
+            if (q == 0) { dir[0] = -n[0]; dir[1] = -n[1]; dir[2] = -n[2]; }
+            else {
+              const double ang = 2 * M_PI * (q - 1) / 3, cs = 1e-3 * cos(ang), sn = 1e-3 * sin(ang);
+              for (int k = 0; k < 3; ++k) dir[k] = -n[k] + cs * fr[3 + k] + sn * fr[6 + k];
+            }
+            double dl[3], bestv = -INFINITY;
+            mulTv(gR, dir, dl);
+            int bi = -1;
+            for (int v = 0; v < cg.vert_num; ++v) {
+              const double s = V[3 * v] * dl[0] + V[3 * v + 1] * dl[1] + V[3 * v + 2] * dl[2];
+              if (s > bestv) { bestv = s; bi = v; }
+            }
+            if (bi < 0) break;
+            bool dup = false;
+            for (int k = 0; k < nP; ++k) dup = dup || chosen[k] == bi;
+            if (dup) continue;
+            const double vl[3] = {V[3 * bi], V[3 * bi + 1], V[3 * bi + 2]};
+            double w[3];
+            mulmv(gR, vl, w);
+            const double xw[3] = {w[0] + gp[0], w[1] + gp[1], w[2] + gp[2]};
+            const double dist = dot3(n, xw) - tab.plane_d;
+            if (dist >= 0) { if (q == 0) break; else continue; }
+            chosen[nP] = bi;
+            for (int k = 0; k < 3; ++k) ppos[nP][k] = xw[k] - n[k] * dist * 0.5;
+            pdist[nP] = dist;
+            ++nP;
+          }
+        } else if (cg.type == 6) {
+          for (int c = 0; c < 8 && nP < 4; ++c) {
+            const double loc[3] = {(c & 1 ? cg.size[0] : -cg.size[0]), (c & 2 ? cg.size[1] : -cg.size[1]), (c & 4 ? cg.size[2] : -cg.size[2])};
+            double w[3];
+            mulmv(gR, loc, w);
+            const double ld = dot3(n, w);
+            if (cdst + ld > 0 || ld > 0) continue;
+            const double dist = cdst + ld;
+            for (int k = 0; k < 3; ++k) ppos[nP][k] = w[k] + gp[k] - n[k] * dist * 0.5;
+            pdist[nP] = dist;
+            ++nP;
+          }
+        } else if (cg.type == 3 || cg.type == 2) {
+          for (int e = 0; e < (cg.type == 3 ? 2 : 1); ++e) {
+            const double loc[3] = {0, 0, cg.type == 3 ? (e ? -cg.size[1] : cg.size[1]) : 0};
+            double w[3];
+            mulmv(gR, loc, w);
+            const double c[3] = {w[0] + gp[0], w[1] + gp[1], w[2] + gp[2]};
+            const double dist = dot3(n, c) - tab.plane_d - cg.size[0];
+            if (dist >= 0) continue;
+            for (int k = 0; k < 3; ++k) ppos[nP][k] = c[k] - n[k] * (cg.size[0] + dist * 0.5);
+            pdist[nP] = dist;
+            ++nP;
+          }
+        }
+      }
+    }
+    // ---- the box
+    if (!(cg.type == 7 && cg.vert_num == 0)) {
+      const double dx[3] = {gp[0] - bp[0], gp[1] - bp[1], gp[2] - bp[2]};
+      const double rsum = cg.rbound + sqrt(b.size[0] * b.size[0] + b.size[1] * b.size[1] + b.size[2] * b.size[2]);
+      if (dot3(dx, dx) <= rsum * rsum) {
+        if (cg.type == 6) {
+          nB = dev_box_box(gp, gR, cg.size, bp, bR, b.size, &cpos[0][0], cn, cdist);
+        } else {
+          Shape S{cg.type == 7 ? 0 : 2, gp, gR, cg.size, V, cg.vert_num, {gp[0], gp[1], gp[2]}};
+          Shape Bx{1, bp, bR, b.size, nullptr, 0, {bp[0], bp[1], bp[2]}};
+          if (cg.type == 7) {
+            double c[3];
+            mulmv(gR, cg.center, c);
+            for (int k = 0; k < 3; ++k) S.center[k] = c[k] + gp[k];
+          }
+          // the shapes cannot intersect when the hull's bounding box and the cube do not (separating axes of the two boxes)
+          bool may = true;
+          if (cg.type == 7) {
+            double oc[3], dummy_p[24], dummy_n[3], dummy_d[8];
+            mulmv(gR, cg.aabb_c, oc);
+            oc[0] += gp[0]; oc[1] += gp[1]; oc[2] += gp[2];
+            may = dev_box_box(oc, gR, cg.aabb_h, bp, bR, b.size, dummy_p, dummy_n, dummy_d) > 0;
+          }
+          double depth = 0;
+          if (may) {
+            if (cg.type == 7) { nB = dev_mpr(Bx, S, &depth, cn, cpos[0]); boxfirst = 1; }  // box (type 6) before mesh (type 7)
+            else nB = dev_mpr(S, Bx, &depth, cn, cpos[0]);
+          }
+          cdist[0] = -depth;
+        }
+      }
+    }
+  }
+  // the box against the floor (mjc_PlaneBox: corners in order, at most four): computed by lane 63
+  int nBP = 0;
+  double bppos[4][3], bpdist[4];
+  if (tab.has_plane) {
+    const double dist = bp[2] - b.plane_z;
+    for (int i = 0; i < 8 && nBP < 4; ++i) {
+      const double vec[3] = {i & 1 ? b.size[0] : -b.size[0], i & 2 ? b.size[1] : -b.size[1], i & 4 ? b.size[2] : -b.size[2]};
+      double corner[3];
+      mulmv(bR, vec, corner);
+      const double ld = corner[2];
+      if (dist + ld > 0 || ld > 0) continue;
+      bpdist[nBP] = dist + ld;
+      bppos[nBP][0] = corner[0] + bp[0]; bppos[nBP][1] = corner[1] + bp[1]; bppos[nBP][2] = corner[2] + bp[2] - 0.5 * (dist + ld);
+      ++nBP;
+    }
+  }
+  ar.cnt[lane][0] = nP;
+  ar.cnt[lane][1] = nB;
+  __syncthreads();
+  // ---- compaction into MuJoCo's order: (floor, robot geoms) by geom, (floor, box), (robot geoms, box) by geom
+  int offP = 0, offB = 0, totP = 0, totB = 0;
+  for (int g = 0; g < tab.ngeom; ++g) {
+    const int a = ar.cnt[g][0], c = ar.cnt[g][1];
+    if (g < lane) { offP += a; offB += c; }
+    totP += a; totB += c;
+  }
+  const int robot_contacts = totP + totB;
+  offB += totP + nBP;
+  int ncon = totP + nBP + totB;
+  if (ncon > kMaxCon) ncon = kMaxCon;
+  const int bcode = kBox, wcode = kWorld;
+  if (has_geom) {
+    const int lcode = cg.link >= 0 ? cg.link : kWorld;
+    for (int k = 0; k < nP; ++k) {
+      const int c = offP + k;
+      if (c >= kMaxCon) break;
+      double* r = ar.stage[c];
+      r[0] = ppos[k][0]; r[1] = ppos[k][1]; r[2] = ppos[k][2];
+      r[3] = tab.plane_n[0]; r[4] = tab.plane_n[1]; r[5] = tab.plane_n[2];
+      r[6] = pdist[k];
+      r[7] = fmax(tab.plane_mu, cg.mu);
+      r[8] = cg.invweight;
+      ar.cb[c] = wcode | (lcode << 8) | (cg.cls << 16);
+    }
+    for (int k = 0; k < nB; ++k) {
+      const int c = offB + k;
+      if (c >= kMaxCon) break;
+      double* r = ar.stage[c];
+      r[0] = cpos[k][0]; r[1] = cpos[k][1]; r[2] = cpos[k][2];
+      r[3] = cn[0]; r[4] = cn[1]; r[5] = cn[2];
+      r[6] = cdist[k];
+      r[7] = fmax(b.geom_mu, cg.mu);
+      r[8] = cg.invweight + b.inv_mass;
+      ar.cb[c] = (boxfirst ? (bcode | (lcode << 8)) : (lcode | (bcode << 8))) | (cg.cls << 16);
+    }
+  }
+  if (lane == 63) {
+    for (int k = 0; k < nBP; ++k) {
+      const int c = totP + k;
+      if (c >= kMaxCon) break;
+      double* r = ar.stage[c];
+      r[0] = bppos[k][0]; r[1] = bppos[k][1]; r[2] = bppos[k][2];
+      r[3] = 0; r[4] = 0; r[5] = 1;
+      r[6] = bpdist[k];
+      r[7] = b.fr;
+      r[8] = b.inv_mass;
+      ar.cb[c] = wcode | (bcode << 8);
+    }
+  }
+  __syncthreads();
+  // contact classes of this position stage (what the collision callbacks scan d->contact for)
+  uint32_t hit = 0;
+  {
+    int cls = 0;
+    if (lane < ncon) cls = (ar.cb[lane] >> 16) & 0xff;
+    // SimGripper::collision_callback ignores contacts between two finger geoms; none can occur here (no geom-geom pairs of the robot)
+    hit = (__ballot(cls & 1) ? 1u : 0u) | (__ballot(cls & 2) ? 2u : 0u);
+  }
+  if (robot_contacts == 0 || !b.resolve) return hit << 8;
+
+  // ================================================================= rows
+  // lane c owns contact c
+  const bool on = lane < ncon;
+  double G[3][6], aref[3] = {0, 0, 0}, D[3] = {0, 0, 0}, Rr[3] = {0, 0, 0}, mu = 0, fr = 0, f[3] = {0, 0, 0};
+  int cA = kWorld, cB = kWorld;
+  // spatial velocities of the bodies
+  {
+    double qd[16];
+    // (x of body_spatial is read from LDS: park qvel in ar.X)
+    if (lane < NL) ar.X[lane] = st.v(lane);
+    if (lane >= NL && lane < NV) ar.X[lane] = bv[lane - NL];
+    (void)qd;
+  }
+  __syncthreads();
+  body_spatial<T>(st, ar.X, bR, bp, ar.V, lane);
+  __syncthreads();
+  if (on) {
+    const double* r = ar.stage[lane];
+    const double pos[3] = {r[0], r[1], r[2]}, n[3] = {r[3], r[4], r[5]};
+    const double dist = r[6], iw = r[8];
+    fr = r[7];
+    cA = ar.cb[lane] & 0xff;
+    cB = (ar.cb[lane] >> 8) & 0xff;
+    double fk[3][3];
+    fk[0][0] = n[0]; fk[0][1] = n[1]; fk[0][2] = n[2];
+    make_frame(n, fk[1], fk[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double xf[3];
+      cross3(pos, fk[k], xf);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { G[k][c] = xf[c]; G[k][3 + c] = fk[k][c]; }
+    }
+    const double imp = impedance(b.imp, dist, 0.0);
+    double R0 = (1 - imp) / imp * iw;
+    if (R0 < kMinVal) R0 = kMinVal;
+    const double R1 = R0 * b.inv_impratio;
+    Rr[0] = R0; Rr[1] = R1; Rr[2] = R1;
+    mu = fr * sqrt(R1 / R0);
+    double rel[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rel[k] = ar.V[cB][k] - ar.V[cA][k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      D[k] = 1 / Rr[k];
+      const double vel = dot6(G[k], rel);
+      aref[k] = -b.B * vel - (k == 0 ? b.K * imp * dist : 0.0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) G[k][c] = 0.0;
+  }
+  // links in contact (the noslip pass keeps M^-1 S' for them)
+  if (lane == 0) {
+    int na = 0;
+    for (int c = 0; c < ncon; ++c) {
+      const int bb[2] = {ar.cb[c] & 0xff, (ar.cb[c] >> 8) & 0xff};
+      for (int s = 0; s < 2; ++s) {
+        if (bb[s] >= NL) continue;
+        bool have = false;
+        for (int k = 0; k < na; ++k) have = have || ar.act[k] == bb[s];
+        if (!have && na < kMaxActive) ar.act[na++] = bb[s];
+      }
+    }
+    ar.nact = na;
+  }
+  // ---- qacc_smooth: the robot's by its own factorisation (every lane), the box's in closed form
+  const double Mb[6] = {b.mass, b.mass, b.mass, b.inertia[0], b.inertia[1], b.inertia[2]};
+  const double Mbi[6] = {b.inv_mass, b.inv_mass, b.inv_mass, b.inv_inertia[0], b.inv_inertia[1], b.inv_inertia[2]};
+  double LM[T::NTRI];
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) LM[tri(i, j)] = st.M(i, j);
+  ldl_factor<NL>(LM);
+  {
+    double a0[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) a0[i] = st.smooth(i);
+    ldl_solve<NL>(LM, a0);
+    double xsb[6];
+    {
+      const double* w = bv + 3;
+      const double Iw[3] = {b.inertia[0] * w[0], b.inertia[1] * w[1], b.inertia[2] * w[2]};
+      double gyro[3];
+      cross3(w, Iw, gyro);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { xsb[j] = gravity[j]; xsb[3 + j] = -gyro[j] * b.inv_inertia[j]; }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) ar.A0[i] = a0[i];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ar.A0[NL + k] = xsb[k];
+    }
+  }
+  __syncthreads();
+  const int nact = ar.nact;
+  const bool has_eq = T::GRIP && st.eq(0) != 0.0;
+  const double eqD = T::GRIP ? st.eq(0) : 0.0, eqAref = T::GRIP ? st.eq(1) : 0.0, eqJ1 = T::GRIP ? st.eq(2) : 0.0;
+
+  // ---- evaluation of the primal cost at x = ar.X + alpha * ar.P (alpha = 0, use_p false: at ar.X): every row's force;
+  // returns the total cost (all lanes).  jar / Hc of the lane's contact are left in the out-parameters.
+  double jar[3] = {0, 0, 0}, Hc[6] = {0, 0, 0, 0, 0, 0};
+  auto eval_rows = [&](const double (*Ub)[6], double* jar_out, double* f_out, double* Hc_out) -> double {
+    double cost = 0;
+    if (on) {
+      double rel[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rel[k] = Ub[cB][k] - Ub[cA][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) jar_out[k] = dot6(G[k], rel) - aref[k];
+      cost = cone_eval(D, mu, fr, jar_out, f_out, Hc_out);
+    }
+    return cost;
+  };
+  // robot rows (limit rows, the finger coupling) and the Gauss term at x (LDS vector): lane t < NV computes its dof's
+  // gradient entry without the contacts' part; returns this lane's share of the cost
+  auto robot_terms = [&](const double* x, double* grad_out) -> double {
+    double cost = 0, g = 0;
+    if (lane < NL) {
+      double mx = 0;
+      for (int j = 0; j < NL; ++j) {
+        const double mij = lane >= j ? st.M(lane, j) : st.M(j, lane);
+        mx += mij * (x[j] - ar.A0[j]);
+      }
+      g = mx;
+      cost = 0.5 * (x[lane] - ar.A0[lane]) * mx;
+      const double sgn = st.limS(lane);
+      if (sgn != 0.0) {
+        const double r = sgn * x[lane] - st.limA(lane);
+        if (r < 0) { const double dd = st.limD(lane); cost += 0.5 * dd * r * r; g += sgn * dd * r; }
+      }
+      if (T::GRIP && has_eq && (lane == NA || lane == NA + 1)) {
+        const double je = x[NA] + eqJ1 * x[NA + 1] - eqAref;
+        if (lane == NA) { cost += 0.5 * eqD * je * je; g += eqD * je; }
+        else g += eqD * je * eqJ1;
+      }
+    } else if (lane < NV) {
+      const int k = lane - NL;
+      const double dx = x[lane] - ar.A0[lane];
+      g = Mb[k] * dx;
+      cost = 0.5 * Mb[k] * dx * dx;
+    }
+    *grad_out = g;
+    return cost;
+  };
+  // wrench of every body from the contact forces f (registers of the owner lanes) -> ar.W; then the generalised force
+  // J' f of dof `lane` (returned on lanes < NV)
+  auto contact_qfrc = [&](const double* fc) -> double {
+    if (lane < kMaxCon) {
+      double* wr = ar.stage[lane];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) wr[k] = on ? G[0][k] * fc[0] + G[1][k] * fc[1] + G[2][k] * fc[2] : 0.0;
+    }
+    __syncthreads();
+    {
+      // lane (body, component): sum over the contacts in order
+      const int bdy = lane / 6, k = lane % 6;
+      if (bdy < NB - 1) {  // (the world takes no force)
+        double s = 0;
+        for (int c = 0; c < ncon; ++c) {
+          const int cc = ar.cb[c];
+          const int A_ = cc & 0xff, B_ = (cc >> 8) & 0xff;
+          if (B_ == bdy) s += ar.stage[c][k];
+          if (A_ == bdy) s -= ar.stage[c][k];
+        }
+        ar.W[bdy][k] = s;
+      }
+    }
+    __syncthreads();
+    double q = 0;
+    if (lane < NL) {
+      double w[6] = {0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < NL; ++i) {
+        if (!is_anc<T>(lane, i)) continue;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w[k] += ar.W[i][k];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) q += st.S(lane, k) * w[k];
+    } else if (lane < NV) {
+      const int k = lane - NL;
+      const double* w = ar.W[kBox];
+      if (k < 3) q = w[3 + k];
+      else {
+        // column of S_box for the body-frame angular dof k - 3: [R e ; p x R e]
+        const double re[3] = {bR[k - 3], bR[3 + k - 3], bR[6 + k - 3]};
+        double c[3];
+        cross3(bp, re, c);
+        q = re[0] * w[0] + re[1] * w[1] + re[2] * w[2] + c[0] * w[3] + c[1] * w[4] + c[2] * w[5];
+      }
+    }
+    return q;
+  };
+
+  // ================================================================= Newton on the primal cost
+  // start: the cheaper of the warm start and qacc_smooth
+  double cost_x;
+  {
+    if (lane < NL) ar.P[lane] = st.xs(lane);
+    else if (lane < NV) ar.P[lane] = bs[kBoxW + lane - NL];
+    if (lane < NV) ar.X[lane] = ar.A0[lane];
+    __syncthreads();
+    body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
+    body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
+    __syncthreads();
+    double g;
+    double ja[3], fa[3], Ha[6];
+    const double c_smooth = wave_sum(eval_rows(ar.U, ja, fa, Ha) + robot_terms(ar.X, &g));
+    const double c_warm = wave_sum(eval_rows(ar.Up, ja, fa, Ha) + robot_terms(ar.P, &g));
+    __syncthreads();
+    if (c_warm < c_smooth) {
+      if (lane < NV) ar.X[lane] = ar.P[lane];
+      cost_x = c_warm;
+    } else cost_x = c_smooth;
+    __syncthreads();
+  }
+  (void)cost_x;
+  int newton_it = 0;
+  for (; newton_it < 100; ++newton_it) {
+    body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
+    __syncthreads();
+    eval_rows(ar.U, jar, f, Hc);
+    double gl;
+    robot_terms(ar.X, &gl);
+    const double qf = contact_qfrc(f);
+    if (lane < NV) { gl -= qf; ar.Gd[lane] = gl; }
+    const double g2 = wave_sum(lane < NV ? gl * gl : 0.0);
+    if (b.scale * sqrt(g2) < 1e-12) break;
+    // ---- contact stiffness K_c = G' Hc G (6 x 6 symmetric, 21 entries), summed per body pair through LDS in three
+    // batches of seven entries: accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
+    {
+      double Kc[21];
+      if (on) {
+        double Tm[3][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          Tm[0][c] = Hc[0] * G[0][c] + Hc[1] * G[1][c] + Hc[3] * G[2][c];
+          Tm[1][c] = Hc[1] * G[0][c] + Hc[2] * G[1][c] + Hc[4] * G[2][c];
+          Tm[2][c] = Hc[3] * G[0][c] + Hc[4] * G[1][c] + Hc[5] * G[2][c];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) Kc[tri(r, c)] = G[0][r] * Tm[0][c] + G[1][r] * Tm[1][c] + G[2][r] * Tm[2][c];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 21; ++e) Kc[e] = 0.0;
+      }
+      // which accumulator does contact c feed?  (slot index, or -1)
+      int slot = -1;
+      if (on) {
+        const int lk = cA < NL ? cA : (cB < NL ? cB : -1);
+        const bool with_box = cA == kBox || cB == kBox;
+        if (lk < 0) slot = 2 * kMaxActive;
+        else {
+          int a = -1;
+          for (int k = 0; k < nact; ++k) if (ar.act[k] == lk) a = k;
+          slot = a < 0 ? -1 : (with_box ? a : kMaxActive + a);
+        }
+      }
+#pragma unroll
+      for (int batch = 0; batch < 3; ++batch) {
+        __syncthreads();
+        if (lane < kMaxCon) {
+          double* wr = ar.stage[lane];
+#pragma unroll
+          for (int e = 0; e < 7; ++e) wr[e] = Kc[7 * batch + e];
+          wr[7] = (double)slot;
+        }
+        __syncthreads();
+        {
+          const int a = lane / 7, e = lane % 7;
+          if (a < 2 * kMaxActive + 1) {
+            double s = 0;
+            for (int c = 0; c < ncon; ++c)
+              if ((int)ar.stage[c][7] == a) s += ar.stage[c][e];
+            ar.KA[a][7 * batch + e] = s;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- Hessian H = M + rows' curvature + S' K S (lower triangle, LDS): lane t < NV writes row t
+    if (lane < NL) {
+      // composite stiffness below link `lane`: KD over (link, box) and (world, link) pairs, KX over (link, box) pairs
+      double KD[21], KX[21];
+#pragma unroll
+      for (int e = 0; e < 21; ++e) { KD[e] = 0.0; KX[e] = 0.0; }
+      for (int a = 0; a < nact; ++a) {
+        if (!is_anc<T>(lane, ar.act[a])) continue;
+#pragma unroll
+        for (int e = 0; e < 21; ++e) { KD[e] += ar.KA[a][e] + ar.KA[kMaxActive + a][e]; KX[e] += ar.KA[a][e]; }
+      }
+      double Sl[6], y[6], z[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Sl[k] = st.S(lane, k);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double sy = 0, sz = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int e = r >= c ? tri(r, c) : tri(c, r);
+          sy += KD[e] * Sl[c];
+          sz += KX[e] * Sl[c];
+        }
+        y[r] = sy; z[r] = sz;
+      }
+      for (int j = 0; j <= lane; ++j) {
+        double v = st.M(lane, j);
+        if (is_anc<T>(j, lane)) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v += st.S(j, k) * y[k];
+        }
+        if (j == lane) {
+          const double sgn = st.limS(lane);
+          if (sgn != 0.0 && sgn * ar.X[lane] - st.limA(lane) < 0) v += st.limD(lane);
+        }
+        if (T::GRIP && has_eq) {
+          if (lane == NA && j == NA) v += eqD;
+          if (lane == NA + 1 && j == NA) v += eqD * eqJ1;
+          if (lane == NA + 1 && j == NA + 1) v += eqD * eqJ1 * eqJ1;
+        }
+        ar.H[tri(lane, j)] = v;
+      }
+      // box rows' robot columns: H[NL + k][lane] = -S_box[:, k] . z
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        double v;
+        if (k < 3) v = z[3 + k];
+        else {
+          const double re[3] = {bR[k - 3], bR[3 + k - 3], bR[6 + k - 3]};
+          double c[3];
+          cross3(bp, re, c);
+          v = re[0] * z[0] + re[1] * z[1] + re[2] * z[2] + c[0] * z[3] + c[1] * z[4] + c[2] * z[5];
+        }
+        ar.H[tri(NL + k, lane)] = -v;
+      }
+    } else if (lane < NV) {
+      const int k = lane - NL;
+      double Kb[21];
+#pragma unroll
+      for (int e = 0; e < 21; ++e) Kb[e] = ar.KA[2 * kMaxActive][e];
+      for (int a = 0; a < nact; ++a)
+#pragma unroll
+        for (int e = 0; e < 21; ++e) Kb[e] += ar.KA[a][e];
+      auto sbox = [&](int kk, double* col) {
+        if (kk < 3) { col[0] = col[1] = col[2] = 0; col[3] = kk == 0; col[4] = kk == 1; col[5] = kk == 2; }
+        else {
+          const double re[3] = {bR[kk - 3], bR[3 + kk - 3], bR[6 + kk - 3]};
+          col[0] = re[0]; col[1] = re[1]; col[2] = re[2];
+          cross3(bp, re, col + 3);
+        }
+      };
+      double ck[6], y[6];
+      sbox(k, ck);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double s = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s += Kb[r >= c ? tri(r, c) : tri(c, r)] * ck[c];
+        y[r] = s;
+      }
+      for (int l = 0; l <= k; ++l) {
+        double cl[6];
+        sbox(l, cl);
+        ar.H[tri(NL + k, NL + l)] = dot6(cl, y) + (l == k ? Mb[k] : 0.0);
+      }
+    }
+    __syncthreads();
+    // ---- every lane: factor H, Newton direction
+    double p[NV];
+    {
+      double Hf[NV * (NV + 1) / 2];
+#pragma unroll
+      for (int e = 0; e < NV * (NV + 1) / 2; ++e) Hf[e] = ar.H[e];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) p[i] = -ar.Gd[i];
+      ldl_factor<NV>(Hf);
+      ldl_solve<NV>(Hf, p);
+    }
+    double dphi0 = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dphi0 += ar.Gd[i] * p[i];
+    if (!(dphi0 < 0)) break;
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) ar.P[i] = p[i];
+    }
+    __syncthreads();
+    body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
+    __syncthreads();
+    // ---- line search: root of phi'(a) by safeguarded 1-D Newton (a = 1 is exact while no row changes zone)
+    double jd[3] = {0, 0, 0};
+    if (on) {
+      double rel[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) rel[k] = ar.Up[cB][k] - ar.Up[cA][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) jd[k] = dot6(G[k], rel);
+    }
+    // Gauss term along the line: phi_M'(a) = gM0 + a pMp
+    double gM0l = 0, pMpl = 0;
+    if (lane < NL) {
+      double mx = 0, mp = 0;
+      for (int j = 0; j < NL; ++j) {
+        const double mij = lane >= j ? st.M(lane, j) : st.M(j, lane);
+        mx += mij * (ar.X[j] - ar.A0[j]);
+        mp += mij * p[j];
+      }
+      gM0l = mx * ar.P[lane]; pMpl = mp * ar.P[lane];
+    } else if (lane < NV) {
+      const int k = lane - NL;
+      gM0l = Mb[k] * (ar.X[lane] - ar.A0[lane]) * ar.P[lane];
+      pMpl = Mb[k] * ar.P[lane] * ar.P[lane];
+    }
+    const double gM0 = wave_sum(gM0l), pMp = wave_sum(pMpl);
+    double lo = 0, hi = -1, a = 1, best = 1;
+    for (int ls = 0; ls < 30; ++ls) {
+      double dl = 0, ddl = 0;
+      if (on) {
+        double ja[3], fa[3], Ha[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ja[k] = jar[k] + a * jd[k];
+        cone_eval(D, mu, fr, ja, fa, Ha);
+        dl = -(jd[0] * fa[0] + jd[1] * fa[1] + jd[2] * fa[2]);
+        ddl = jd[0] * (Ha[0] * jd[0] + Ha[1] * jd[1] + Ha[3] * jd[2]) + jd[1] * (Ha[1] * jd[0] + Ha[2] * jd[1] + Ha[4] * jd[2]) +
+              jd[2] * (Ha[3] * jd[0] + Ha[4] * jd[1] + Ha[5] * jd[2]);
+      }
+      if (lane < NL) {
+        const double sgn = st.limS(lane);
+        if (sgn != 0.0) {
+          const double r = sgn * (ar.X[lane] + a * ar.P[lane]) - st.limA(lane);
+          if (r < 0) { const double dd = st.limD(lane), jl = sgn * ar.P[lane]; dl += dd * r * jl; ddl += dd * jl * jl; }
+        }
+        if (T::GRIP && has_eq && lane == NA) {
+          const double je = (ar.X[NA] + a * ar.P[NA]) + eqJ1 * (ar.X[NA + 1] + a * ar.P[NA + 1]) - eqAref;
+          const double jde = ar.P[NA] + eqJ1 * ar.P[NA + 1];
+          dl += eqD * je * jde; ddl += eqD * jde * jde;
+        }
+      }
+      const double dphi = wave_sum(dl) + gM0 + a * pMp;
+      const double ddphi = wave_sum(ddl) + pMp;
+      best = a;
+      if (fabs(dphi) <= 1e-3 * fabs(dphi0)) break;
+      if (dphi < 0) lo = a; else hi = a;
+      double an = a - dphi / ddphi;
+      if (hi > 0 && !(an > lo && an < hi)) an = 0.5 * (lo + hi);
+      if (hi < 0 && !(an > lo)) an = 2 * a;
+      if (fabs(an - a) <= 1e-3 * a) break;
+      a = an;
+    }
+    __syncthreads();
+    if (lane < NV) ar.X[lane] += best * ar.P[lane];
+    __syncthreads();
+  }
+  // forces at the solution
+  body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
+  __syncthreads();
+  eval_rows(ar.U, jar, f, Hc);
+
+  // ================================================================= noslip (mj_solNoSlip over the contacts' friction rows)
+  if (b.noslip_iterations > 0) {
+    // Y_a = M^-1 S_a' for the links in contact (robot dofs x 6), [a][dof][k] in the stage area: lane (a, k) solves one column
+    double (*Y)[NL][6] = reinterpret_cast<double (*)[NL][6]>(&ar.stage[0][0]);
+    __syncthreads();
+    if (lane < 6 * nact) {
+      const int a = lane / 6, k = lane % 6, lk = ar.act[a];
+      double col[NL];
+#pragma unroll
+      for (int j = 0; j < NL; ++j) col[j] = is_anc<T>(j, lk) ? st.S(j, k) : 0.0;
+      ldl_solve<NL>(LM, col);
+#pragma unroll
+      for (int j = 0; j < NL; ++j) Y[a][j][k] = col[j];
+    }
+    __syncthreads();
+    // change of every body's spatial acceleration per unit wrench on body `src` (a link in contact, or the box):
+    // dU_b = S_b M^-1 S_src' w.  apply_wrench adds it to ar.U for wrench w (LDS, 6 doubles), sign +1 on B, -1 on A.
+    double* dw = ar.Gd;  // 6 doubles: the wrench change being broadcast; [8..] bodies
+    auto push = [&](int A_, int B_) {
+      // robot part: dx = Y_B dw - Y_A dw (lane j < NL), then links add sum_j S_j dx_j; box part: closed form
+      if (lane < NL) {
+        double dx = 0;
+        for (int a = 0; a < nact; ++a) {
+          const int lk = ar.act[a];
+          const double sgn = lk == B_ ? 1.0 : (lk == A_ ? -1.0 : 0.0);
+          if (sgn == 0.0) continue;
+          double s = 0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s += Y[a][lane][k] * dw[k];
+          dx += sgn * s;
+        }
+        ar.P[lane] = dx;
+      } else if (lane < NV) {
+        // box dofs: dx = M_box^-1 S_box' (+-dw)
+        const int k = lane - NL;
+        const double sgn = B_ == kBox ? 1.0 : (A_ == kBox ? -1.0 : 0.0);
+        double q;
+        if (k < 3) q = dw[3 + k];
+        else {
+          const double re[3] = {bR[k - 3], bR[3 + k - 3], bR[6 + k - 3]};
+          double c[3];
+          cross3(bp, re, c);
+          q = re[0] * dw[0] + re[1] * dw[1] + re[2] * dw[2] + c[0] * dw[3] + c[1] * dw[4] + c[2] * dw[5];
+        }
+        ar.P[lane] = sgn * Mbi[k] * q;
+      }
+      __syncthreads();
+      body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
+      __syncthreads();
+      if (lane < NB - 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ar.U[lane][k] += ar.Up[lane][k];
+      }
+      __syncthreads();
+    };
+    // the 2 x 2 friction block of A = J M^-1 J' (no regulariser) of every contact: response of the own rows to unit
+    // forces along the two tangents -- computed contact by contact with the same machinery (ncon pushes of a probe wrench)
+    double Ac[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Ac[r][c] = 0.0;
+    {
+      // save U (the accelerations at the Newton solution) in V: velocities are no longer needed
+      if (lane < NB) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ar.V[lane][k] = ar.U[lane][k];
+      }
+      __syncthreads();
+      for (int c = 0; c < ncon; ++c) {
+        const int cc = ar.cb[c], A_ = cc & 0xff, B_ = (cc >> 8) & 0xff;
+        for (int kk = 0; kk < 3; ++kk) {
+          if (lane < NB) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ar.U[lane][k] = 0.0;
+          }
+          if (lane == c) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dw[k] = G[kk][k];
+          }
+          __syncthreads();
+          push(A_, B_);
+          if (lane == c) {
+            double rel[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rel[k] = ar.U[cB][k] - ar.U[cA][k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Ac[r][kk] = dot6(G[r], rel);
+          }
+          __syncthreads();
+        }
+      }
+      if (lane < NB) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ar.U[lane][k] = ar.V[lane][k];
+      }
+      __syncthreads();
+    }
+    int iter = 0;
+    while (iter < b.noslip_iterations) {
+      double improvement = 0;
+      if (iter == 0) {
+        double s = on ? 0.5 * (f[0] * f[0] * Rr[0] + f[1] * f[1] * Rr[1] + f[2] * f[2] * Rr[2]) : 0.0;
+        if (lane < NL) {
+          const double sgn = st.limS(lane);
+          if (sgn != 0.0) {
+            const double r = sgn * ar.X[lane] - st.limA(lane);
+            if (r < 0) s += 0.5 * st.limD(lane) * r * r;  // 0.5 f^2 R with f = -D r
+          }
+        }
+        improvement = wave_sum(s);
+      }
+      for (int c = 0; c < ncon; ++c) {
+        const int cc = ar.cb[c], A_ = cc & 0xff, B_ = (cc >> 8) & 0xff;
+        double change = 0;
+        if (lane == c) {
+          double rel[6], res[3], old[3] = {f[0], f[1], f[2]};
+#pragma unroll
+          for (int k = 0; k < 6; ++k) rel[k] = ar.U[cB][k] - ar.U[cA][k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) res[k] = dot6(G[k], rel) - aref[k];
+          double nf[3] = {old[0], old[1], old[2]};
+          if (old[0] < kMinVal) {
+            nf[0] = nf[1] = nf[2] = 0;
+          } else {
+            const double b1 = res[1] - Ac[1][1] * old[1] - Ac[1][2] * old[2], b2 = res[2] - Ac[2][1] * old[1] - Ac[2][2] * old[2];
+            double vv[2];
+            if (qcqp2_dev(vv, Ac[1][1], Ac[1][2], Ac[2][2], b1, b2, fr, fr, old[0])) {
+              double s = vv[0] * vv[0] / (fr * fr) + vv[1] * vv[1] / (fr * fr);
+              s = sqrt(old[0] * old[0] / (s > kMinVal ? s : kMinVal));
+              vv[0] *= s; vv[1] *= s;
+            }
+            nf[1] = vv[0]; nf[2] = vv[1];
+          }
+          const double dl[3] = {nf[0] - old[0], nf[1] - old[1], nf[2] - old[2]};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int l = 0; l < 3; ++l) change += 0.5 * dl[k] * Ac[k][l] * dl[l];
+            change += dl[k] * res[k];
+          }
+          if (change > 1e-10) { nf[0] = old[0]; nf[1] = old[1]; nf[2] = old[2]; change = 0; }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) dw[k] = G[0][k] * (nf[0] - old[0]) + G[1][k] * (nf[1] - old[1]) + G[2][k] * (nf[2] - old[2]);
+          f[0] = nf[0]; f[1] = nf[1]; f[2] = nf[2];
+        }
+        __syncthreads();
+        push(A_, B_);
+        improvement -= lane_get(change, c);
+      }
+      improvement *= b.scale;
+      ++iter;
+      if (improvement < b.noslip_tolerance) break;
+    }
+    __syncthreads();
+  }
+
+  // ================================================================= results: qfrc_constraint of the robot, qacc of the box
+  {
+    const double qf = contact_qfrc(f);
+    if (lane < NL) {
+      double fc = qf;
+      const double sgn = st.limS(lane);
+      if (sgn != 0.0) {
+        const double r = sgn * ar.X[lane] - st.limA(lane);
+        if (r < 0) fc += -sgn * st.limD(lane) * r;
+      }
+      if (T::GRIP && has_eq && (lane == NA || lane == NA + 1)) {
+        const double fe = -eqD * (ar.X[NA] + eqJ1 * ar.X[NA + 1] - eqAref);
+        fc += lane == NA ? fe : fe * eqJ1;
+      }
+      st.fcon(lane) = fc;
+      st.xs(lane) = ar.X[lane];
+    } else if (lane < NV) {
+      const int k = lane - NL;
+      bs[kBoxA + k] = ar.A0[lane] + Mbi[k] * qf;
+    }
+  }
+  __syncthreads();
+  return 1u | (hit << 8);
+}
+
+#endif  // __HIP__
+
+}  // namespace rcsh

@@ -1,0 +1,36 @@
+// contact_types.h -- host-prepared tables of the contact phase (contact_team.h); plain data, shared with the host code.
+#pragma once
+#include <cstdint>
+
+namespace rcsh {
+
+constexpr int kMaxCon = 48;      // contacts per environment (oracle: ORC_MAXCON)
+constexpr int kMaxCGeom = 32;    // collision geoms of the robot
+constexpr int kMaxActive = 4;    // links in contact at once that the noslip pass keeps M^-1 S' for
+
+// one collision geom of the robot, host-prepared (model.cpp: build_contact_table), in MuJoCo's geom order
+struct ContactGeom {
+  int32_t link;          // link carrying the geom (-1: welded to the world)
+  int32_t type;          // mjtGeom: 3 capsule, 6 box, 7 mesh (convex hull)
+  int32_t cls;           // bit 0: SimRobot arm collision geom, bit 1: SimGripper collision geom, bit 2: finger geom
+  int32_t vert_adr, vert_num;
+  int32_t geom_id;       // mjModel geom id
+  int32_t plane_ok;      // the (floor, geom) pair passes MuJoCo's filters
+  int32_t pad;
+  double pos[3], rot[9]; // geom frame in the link frame
+  double size[3];
+  double center[3];      // hull: an interior point (vertex mean), geom frame
+  double aabb_c[3], aabb_h[3];  // hull: bounding box in the geom frame (centre, half extents)
+  double rbound;
+  double mu;             // geom_friction[0]
+  double invweight;      // body_invweight0 (translational) of the geom's body
+};
+
+struct ContactTable {
+  const ContactGeom* geoms;
+  const double* verts;   // [nvert][3] hull vertices, geom frame
+  int32_t ngeom, has_plane;
+  double plane_n[3], plane_d, plane_mu;
+};
+
+}  // namespace rcsh

@@ -55,7 +55,8 @@ struct StageTeam {
   static constexpr int QA0 = XS0 + NLP;              // qacc of the implicit solve
   static constexpr int FA0 = QA0 + NLP;              // dry-friction rows: aref (-B * qvel)
   static constexpr int Y0 = FA0 + NLP;               // helper lanes' solutions with the implicit matrix, [5][NLP]
-  static constexpr int COUNT = Y0 + 5 * NLP;
+  static constexpr int FC0 = Y0 + 5 * NLP;           // qfrc_constraint of a step whose contacts couple robot and box (contact_team.h)
+  static constexpr int COUNT = FC0 + NLP;
   double* base;
   RCSH_D double& at(int k) const { return base[k]; }
   RCSH_D double& q(int i) const { return base[Q0 + i]; }
@@ -76,6 +77,7 @@ struct StageTeam {
   RCSH_D double& qacc(int i) const { return base[QA0 + i]; }
   RCSH_D double& fa(int i) const { return base[FA0 + i]; }
   RCSH_D double& Y(int k, int i) const { return base[Y0 + NLP * k + i]; }
+  RCSH_D double& fcon(int i) const { return base[FC0 + i]; }
 };
 
 #ifdef RCSH_PHASE_TIMING
@@ -469,9 +471,12 @@ struct SubstepK {
 // `gc_is_mass` (wave-uniform, see team_gc_is_mass): shortcut for fully gravity-compensated models.
 // FRIC: the model has dry joint friction rows (dof_frictionloss); a separate instantiation so that models without
 // them carry none of that code.
-template <class T, bool FRIC, class FrameFn>
+// `pre_solve()` is called by every lane once the substep's rows and qfrc_smooth are in the block; it returns true (for the
+// whole team) when the contact phase solved the step's constraints itself (contact_team.h: st.fcon then holds
+// qfrc_constraint), which leaves only the implicit solve and the integration to this function.
+template <class T, bool FRIC, class FrameFn, class PreSolveFn>
 RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping,
-                         bool gc_is_mass, FrameFn&& on_frame) {
+                         bool gc_is_mass, FrameFn&& on_frame, PreSolveFn&& pre_solve) {
   static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
   constexpr int NL = T::NL, NA = T::NARM;
@@ -721,6 +726,7 @@ RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* l
   }
   team_sync();
   TEAM_MARK(5)
+  const bool coupled = pre_solve();
 
   // ---- the factorisation slot.  Roles by lane (all run the same instructions on different matrices / right-hand sides):
   //   solver lanes s < 2^k   H = M + rows of the s-th active-set guess,        rhs = qfrc_smooth + row terms
@@ -791,9 +797,11 @@ RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* l
     for (int i = 0; i < NL; ++i)
       if (((limrows >> i) & 1u) && lSv[i] * x[i] - lAv[i] < 0) now |= 1u << i;
   }
-  const uint32_t winners = team_ballot(solver_lane && now == act);
+  const uint32_t winners = coupled ? 0u : team_ballot(solver_lane && now == act);
   const bool superpose = !FRIC && winners != 0;  // uniform within the team
-  if (winners) {
+  if (coupled) {
+    // the contact phase solved the coupled problem: nothing to do here
+  } else if (winners) {
     const bool winner = t == __ffs(winners) - 1;
     if (winner || (!FRIC && helper_lane)) {
       // the winner publishes x, the helpers their solutions y (row t - 11 of Y)
@@ -838,10 +846,14 @@ RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* l
 #pragma unroll
       for (int i = 0; i < NL; ++i) { xs[i] = st.xs(i); rhs[i] = st.smooth(i); lDv[i] = st.limD(i); lAv[i] = st.limA(i); lSv[i] = st.limS(i); }
       sched_fence();
+      if (coupled) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) rhs[i] += st.fcon(i);
+      }
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const double r = lSv[i] * xs[i] - lAv[i];
-        if (((limrows >> i) & 1u) && r < 0) rhs[i] -= lSv[i] * lDv[i] * r;
+        if (!coupled && ((limrows >> i) & 1u) && r < 0) rhs[i] -= lSv[i] * lDv[i] * r;
       }
       if constexpr (FRIC) {
 #pragma unroll
@@ -853,7 +865,7 @@ RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* l
           }
         }
       }
-      if constexpr (T::GRIP) if (has_eq) {
+      if constexpr (T::GRIP) if (has_eq && !coupled) {
         const double fe = -eqD * (xs[NA] + eqJ1 * xs[NA + 1] - eqAref);
         rhs[NA] += fe;
         rhs[NA + 1] += fe * eqJ1;

@@ -160,6 +160,8 @@ void HostModel::copy_from(const rcsh_model_desc& d) {
   cpi(geom_type, d.geom_type, ngeom); cpi(geom_bodyid, d.geom_bodyid, ngeom);
   cpi(geom_contype, d.geom_contype, ngeom); cpi(geom_conaffinity, d.geom_conaffinity, ngeom);
   cpd(geom_pos, d.geom_pos, 3 * ngeom); cpd(geom_quat, d.geom_quat, 4 * ngeom); cpd(geom_size, d.geom_size, 3 * ngeom);
+  if (d.geom_friction) cpd(geom_friction, d.geom_friction, 3 * ngeom);
+  else geom_friction.assign(3 * (size_t)ngeom, 1.0);
   cpi(geom_vertadr, d.geom_vertadr, ngeom); cpi(geom_vertnum, d.geom_vertnum, ngeom);
   cpd(mesh_vert, d.mesh_vert, 3 * (size_t)nmeshvert);
 }
@@ -450,6 +452,122 @@ std::string build_collision_points(const HostModel& h, CollisionPoints& out) {
     out.link_adr[i + 1] = out.link_adr[i] + (int)ids[i].size();
     out.xyzr.insert(out.xyzr.end(), pts[i].begin(), pts[i].end());
     out.geom.insert(out.geom.end(), ids[i].begin(), ids[i].end());
+  }
+  return "";
+}
+
+namespace {
+
+// mjModel.body_invweight0[.][0] of every body: mean diagonal of J M^-1 J' for the translational Jacobian of the body's
+// centre of mass at qpos0 (mj_setConst); 0 for static bodies
+template <class T>
+void body_invweight0(const HostModel& h, const DevModel& m, const std::vector<int>& owner, const std::vector<Xf>& rel, std::vector<double>& out) {
+  constexpr int NL = T::NL;
+  double q[NL], qd[NL];
+  for (int i = 0; i < NL; ++i) { q[i] = m.qpos0[i]; qd[i] = 0; }
+  Smooth<T> sm;
+  double buf[Stage<T, 1>::COUNT];
+  Stage<T, 1> st{buf};
+  smooth_dynamics<T, 1>(m, q, qd, st, sm);
+  double* M = &st.M(0);
+  ldl_factor<NL>(M);
+  // link frames, joint axes and anchors in the world at qpos0
+  Xf F[NL];
+  double axis[NL][3], anchor[NL][3];
+  for (int i = 0; i < NL; ++i) {
+    const int par = T::parent(i);
+    Xf f = par >= 0 ? F[par] : xf_identity();
+    advance_link_frame(m, i, q[i], f.R, f.p);
+    F[i] = f;
+    mulmv(f.R, m.axis[i], axis[i]);
+    double a[3];
+    mulmv(f.R, m.jpos[i], a);
+    for (int k = 0; k < 3; ++k) anchor[i][k] = a[k] + f.p[k];
+  }
+  auto is_anc = [](int j, int i) {
+    if (T::GRIP && i == T::NARM + 1 && j == T::NARM) return false;
+    return j <= i;
+  };
+  out.assign(h.nbody, 0.0);
+  for (int b = 1; b < h.nbody; ++b) {
+    const int link = owner[b];
+    if (link < 0) continue;
+    const Xf bw = xf_mul(F[link], rel[b]);
+    double c[3];
+    mulmv(bw.R, &h.body_ipos[3 * b], c);
+    for (int k = 0; k < 3; ++k) c[k] += bw.p[k];
+    double tr = 0;
+    for (int k = 0; k < 3; ++k) {
+      double J[NL], y[NL];
+      for (int j = 0; j < NL; ++j) {
+        J[j] = 0;
+        if (!is_anc(j, link)) continue;
+        if (m.jtype[j] == kSlide) J[j] = axis[j][k];
+        else {
+          const double r[3] = {c[0] - anchor[j][0], c[1] - anchor[j][1], c[2] - anchor[j][2]};
+          double col[3];
+          cross3(axis[j], r, col);
+          J[j] = col[k];
+        }
+        y[j] = 0;
+      }
+      for (int j = 0; j < NL; ++j) y[j] = J[j];
+      ldl_solve<NL>(M, y);
+      for (int j = 0; j < NL; ++j) tr += J[j] * y[j];
+    }
+    out[b] = tr / 3;
+  }
+}
+
+}  // namespace
+
+std::string build_contact_table(const HostModel& h, const DevModel& m, int plane_geom, std::vector<ContactGeom>& geoms, std::vector<double>& verts) {
+  std::vector<int> owner;
+  std::vector<Xf> rel;
+  body_owner_frames(h, owner, rel);
+  std::vector<double> iw;
+  const bool ok = dispatch_topology(m.narm, m.has_gripper != 0, [&](auto topo) { body_invweight0<decltype(topo)>(h, m, owner, rel, iw); });
+  if (!ok) return "no archetype for the contact table";
+  geoms.clear();
+  verts = h.mesh_vert;
+  for (int g = 0; g < h.ngeom; ++g) {
+    const int type = h.geom_type[g];
+    if (type == 0) continue;
+    if (type != 3 && type != 6 && type != 7) continue;  // capsule, box, mesh: what the RCS scenes use
+    if (h.geom_contype[g] == 0 && h.geom_conaffinity[g] == 0) continue;
+    if ((int)geoms.size() >= kMaxCGeom) return "too many collision geoms for the contact phase";
+    ContactGeom cg;
+    std::memset(&cg, 0, sizeof(cg));
+    const int b = h.geom_bodyid[g];
+    cg.link = owner[b];
+    cg.type = type;
+    cg.geom_id = g;
+    cg.vert_adr = h.geom_vertadr[g];
+    cg.vert_num = type == 7 ? h.geom_vertnum[g] : 0;
+    const Xf t = xf_mul(rel[b], xf_from(&h.geom_pos[3 * g], &h.geom_quat[4 * g]));
+    for (int k = 0; k < 3; ++k) { cg.pos[k] = t.p[k]; cg.size[k] = h.geom_size[3 * g + k]; }
+    for (int k = 0; k < 9; ++k) cg.rot[k] = t.R[k];
+    cg.mu = h.geom_friction[3 * g];
+    cg.invweight = iw[b];
+    if (plane_geom >= 0 && cg.link >= 0)
+      cg.plane_ok = ((h.geom_contype[g] & h.geom_conaffinity[plane_geom]) || (h.geom_contype[plane_geom] & h.geom_conaffinity[g])) ? 1 : 0;
+    const double* sz = cg.size;
+    if (type == 7) {
+      double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL}, c[3] = {0, 0, 0}, rb = 0;
+      for (int v = 0; v < cg.vert_num; ++v) {
+        const double* w = &h.mesh_vert[3 * (size_t)(cg.vert_adr + v)];
+        for (int k = 0; k < 3; ++k) { lo[k] = std::fmin(lo[k], w[k]); hi[k] = std::fmax(hi[k], w[k]); c[k] += w[k]; }
+        rb = std::fmax(rb, w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      }
+      for (int k = 0; k < 3; ++k) {
+        cg.center[k] = cg.vert_num ? c[k] / cg.vert_num : 0.0;
+        cg.aabb_c[k] = cg.vert_num ? 0.5 * (lo[k] + hi[k]) : 0.0;
+        cg.aabb_h[k] = cg.vert_num ? 0.5 * (hi[k] - lo[k]) : 0.0;
+      }
+      cg.rbound = std::sqrt(rb);
+    } else if (type == 6) cg.rbound = std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+    else cg.rbound = sz[0] + sz[1];
+    geoms.push_back(cg);
   }
   return "";
 }

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "../../include/rcs_hip.h"
+#include "contact_types.h"
 #include "dyn.h"
 #include "model.h"
 
@@ -29,7 +30,7 @@ struct HostModel {
   std::vector<double> site_pos, site_quat;
   int ngeom = 0, nmeshvert = 0;
   std::vector<int32_t> geom_type, geom_bodyid, geom_contype, geom_conaffinity, geom_vertadr, geom_vertnum;
-  std::vector<double> geom_pos, geom_quat, geom_size, mesh_vert;
+  std::vector<double> geom_pos, geom_quat, geom_size, geom_friction, mesh_vert;
   void copy_from(const rcsh_model_desc& d);
 };
 
@@ -46,6 +47,10 @@ struct CollisionPoints {
   double plane_d = 0;             // plane: n . x = d
 };
 std::string build_collision_points(const HostModel& h, CollisionPoints& out);
+
+// The robot's collision geoms for the contact phase (contact_team.h), in geom order; `verts` are the hull vertices they
+// index (geom frame).  Class bits are filled in later from the SimRobot / SimGripper configurations.
+std::string build_contact_table(const HostModel& h, const DevModel& m, int plane_geom, std::vector<ContactGeom>& geoms, std::vector<double>& verts);
 
 // Calls fn(Topo<NARM, GRIP>{}) for the compiled archetype matching (narm, grip); false if none does.
 template <class F>

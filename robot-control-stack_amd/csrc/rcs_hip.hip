@@ -51,6 +51,12 @@ struct rcsh_sim {
   std::vector<uint8_t> cp_class;
   double* d_coll_xyzr = nullptr;
   uint8_t* d_coll_cls = nullptr;
+  // contact phase (contact_team.h): the robot's collision geoms and their hull vertices
+  std::vector<ContactGeom> cgeoms;
+  std::vector<double> cverts;
+  ContactGeom* d_cgeoms = nullptr;
+  double* d_cverts = nullptr;
+  double plane_mu = 1.0;
   std::vector<int> act_slot;
   int narm = 0, nl = 0, nu = 0;
   bool grip = false;
@@ -118,6 +124,13 @@ Params make_params(rcsh_sim* s) {
   P.grip = s->gripcfg;
   P.env = s->env;
   P.boxtask = s->d_boxtask;
+  P.ctab.geoms = s->d_cgeoms;
+  P.ctab.verts = s->d_cverts;
+  P.ctab.ngeom = s->box.present && s->box.resolve ? (int)s->cgeoms.size() : 0;
+  P.ctab.has_plane = s->cp.has_plane;
+  for (int k = 0; k < 3; ++k) P.ctab.plane_n[k] = s->cp.plane_n[k];
+  P.ctab.plane_d = s->cp.plane_d;
+  P.ctab.plane_mu = s->plane_mu;
   return P;
 }
 
@@ -144,6 +157,18 @@ int upload_model(rcsh_sim* s) {
 int upload_coll_classes(rcsh_sim* s) {
   if (s->cp.geom.empty()) return RCSH_OK;
   HIP_TRY(hipMemcpyAsync(s->d_coll_cls, s->cp_class.data(), s->cp_class.size(), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+int upload_contact_table(rcsh_sim* s) {
+  if (s->cgeoms.empty()) return RCSH_OK;
+  if (!s->d_cgeoms) HIP_TRY(hipMalloc(&s->d_cgeoms, sizeof(ContactGeom) * s->cgeoms.size()));
+  HIP_TRY(hipMemcpyAsync(s->d_cgeoms, s->cgeoms.data(), sizeof(ContactGeom) * s->cgeoms.size(), hipMemcpyHostToDevice, s->stream));
+  if (!s->d_cverts && !s->cverts.empty()) {
+    HIP_TRY(hipMalloc(&s->d_cverts, sizeof(double) * s->cverts.size()));
+    HIP_TRY(hipMemcpyAsync(s->d_cverts, s->cverts.data(), sizeof(double) * s->cverts.size(), hipMemcpyHostToDevice, s->stream));
+  }
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
 }
@@ -367,6 +392,9 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
     std::string cwhy = build_collision_points(s->hm, s->cp);
     if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);
     s->cp_class.assign(s->cp.geom.size(), 0);
+    cwhy = build_contact_table(s->hm, s->dm, s->cp.has_plane ? s->cp.plane_geom : -1, s->cgeoms, s->cverts);
+    if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);
+    if (s->cp.has_plane) s->plane_mu = s->hm.geom_friction[3 * (size_t)s->cp.plane_geom];
     if (!s->cp.geom.empty()) {
       HIP_NEW(hipMalloc(&s->d_coll_xyzr, sizeof(double) * s->cp.xyzr.size()));
       HIP_NEW(hipMalloc(&s->d_coll_cls, s->cp_class.size()));
@@ -411,6 +439,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
+  hipFree(s->d_cgeoms); hipFree(s->d_cverts);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
@@ -541,8 +570,11 @@ int rcsh_sim_add_robot(rcsh_sim* s, const rcsh_robot_desc* r) {
     if (g < 0 || g >= s->hm.ngeom) return fail(RCSH_ERR_NAME, "arm collision geom id out of range");
     for (size_t k = 0; k < s->cp.geom.size(); ++k)
       if (s->cp.geom[k] == g) s->cp_class[k] |= 1u;
+    for (auto& cg : s->cgeoms)
+      if (cg.geom_id == g) cg.cls |= 1;
   }
   rc = upload_coll_classes(s);
+  if (!rc) rc = upload_contact_table(s);
   if (rc) return rc;
   return rcsh_robot_reset(s, nullptr);  // SimRobot ctor ends with m_reset()
 }
@@ -724,9 +756,15 @@ int rcsh_sim_add_gripper(rcsh_sim* s, const rcsh_gripper_desc* g) {
     if (ignored) continue;
     for (size_t k = 0; k < s->cp.geom.size(); ++k)
       if (s->cp.geom[k] == gid) s->cp_class[k] |= 2u;
+    for (auto& cg : s->cgeoms)
+      if (cg.geom_id == gid) cg.cls |= 2;
   }
+  for (int c = 0; c < g->n_finger_geoms; ++c)
+    for (auto& cg : s->cgeoms)
+      if (cg.geom_id == g->finger_geom_ids[c]) cg.cls |= 4;
   {
     int rc = upload_coll_classes(s);
+    if (!rc) rc = upload_contact_table(s);
     if (rc) return rc;
   }
   return rcsh_gripper_reset(s, nullptr);  // SimGripper ctor ends with m_reset()
@@ -832,6 +870,9 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   b.mass = d->mass; b.inv_mass = 1.0 / d->mass;
   for (int k = 0; k < 3; ++k) { b.inertia[k] = d->inertia[k]; b.inv_inertia[k] = 1.0 / d->inertia[k]; b.size[k] = d->size[k]; }
   b.fr = d->friction[0];
+  b.geom_mu = d->geom_friction[0] > 0 ? d->geom_friction[0] : d->friction[0];
+  // contacts of the robot's geoms with the floor and the box: FR3 + hand archetype (the coupled solve has no dry-friction rows)
+  b.resolve = d->resolve_robot_contacts && s->grip && !s->dm.has_friction && !s->cgeoms.empty();
   make_kb(d->solref, d->solimp, s->dm.timestep, b.K, b.B);
   b.imp = make_imp(d->solimp);
   b.inv_impratio = 1.0 / d->impratio;
@@ -844,6 +885,7 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   s->box = b;
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = upload_boxtask(s)) return rc;
+  if (int rc = upload_contact_table(s)) return rc;
   return rcsh_sim_reset_free_box(s);
 }
 int rcsh_sim_reset_free_box(rcsh_sim* s) {

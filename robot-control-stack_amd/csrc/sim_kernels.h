@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "box_team.h"
+#include "contact_team.h"
 #include "dyn.h"
 #include "dyn_team.h"
 #include "pose.h"
@@ -124,6 +125,7 @@ struct Params {
   GripperCfg grip;
   EnvCfg env;
   const struct BoxTaskCfg* boxtask;  // scenes with a free box: its constants and the task layer's (HBM; staged by k_run_team<.., BOX>)
+  ContactTable ctab;                 // the robot's collision geoms for the contact phase (contact_team.h; scenes with a free box)
 };
 struct BoxTaskCfg {
   BoxCfg box;
@@ -783,6 +785,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // of their two timestamps is due.
   // the free box of the scene: its state sits in the team's LDS block between substeps (box_team.h)
   __shared__ double lbox[BOX ? kBoxLds * kTeams : 1];
+  __shared__ std::conditional_t<(BOX && !FRIC), ContactArena<T>, char> larena[1];  // the contact phase's workspace: one per wavefront
   double* const bs = lbox + (BOX ? team * kBoxLds : 0);
   if constexpr (BOX) {
     if (live) {
@@ -821,7 +824,22 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     }
     const bool want_contacts = team_ballot(due) != 0;
     uint32_t hit = 0;
+    bool near = false;  // broad phase of the contact phase: the lane's link may touch the floor or the box
+    bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
     team_substep<T, FRIC>(m, sk, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
+      if constexpr (BOX && !FRIC) {
+        if (stepping && t < T::NL && lp.ctab.ngeom > 0) {
+          const double* sph = lc.link_sphere[t];
+          double c[3];
+          mulmv(R, sph, c);
+          c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+          const BoxCfg& bc = lbt[0].box;
+          const double dx = c[0] - bs[kBoxQ], dy = c[1] - bs[kBoxQ + 1], dz = c[2] - bs[kBoxQ + 2];
+          const double rs = sph[3] + sqrt(bc.size[0] * bc.size[0] + bc.size[1] * bc.size[1] + bc.size[2] * bc.size[2]);
+          near = dx * dx + dy * dy + dz * dz <= rs * rs;
+          if (lc.has_plane) near = near || dot3(lc.plane_n, c) - lc.plane_d - sph[3] <= 0;
+        }
+      }
       if (!want_contacts) return;
       const double* nrm = lc.plane_n;
       const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
@@ -837,6 +855,24 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
         }
       }
       hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
+    }, [&]() -> bool {
+      bool coupled = false;
+      if constexpr (BOX && !FRIC) {
+        // teams whose broad phase fired take turns: the whole wavefront works on one environment's contacts (contact_team.h)
+        const uint64_t nearw = __ballot(near);
+        if (nearw) {
+          for (int k = 0; k < kTeams; ++k) {
+            if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
+            const uint32_t r = contact_phase<T>(lp.ctab, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity, timestep);
+            if (team == k) {
+              coupled = r & 1u;
+              hit |= (r >> 8) & 3u;
+            }
+          }
+        }
+      }
+      team_coupled = coupled;
+      return coupled;
     });
     __syncthreads();
     if constexpr (BOX) {
@@ -850,7 +886,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
         imp0 += row_rotate<4>(imp0);
         imp0 += row_rotate<8>(imp0);
         imp0 = lane_get(imp0, threadIdx.x & 48);  // one lane's bits for the whole team
-        box_substep(lbt[0].box, bs, m.gravity, timestep, imp0, t);
+        box_substep(lbt[0].box, bs, m.gravity, timestep, imp0, t, team_coupled);
       }
       __syncthreads();
       if (place_box && live && !box_placed) {

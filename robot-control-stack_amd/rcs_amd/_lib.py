@@ -53,7 +53,7 @@ class ModelDesc(C.Structure):
         ("geom_type", _I32P), ("geom_bodyid", _I32P), ("geom_contype", _I32P), ("geom_conaffinity", _I32P),
         ("geom_pos", _F64P), ("geom_quat", _F64P), ("geom_size", _F64P),
         ("geom_vertadr", _I32P), ("geom_vertnum", _I32P), ("mesh_vert", _F64P),
-     ("dof_solref", _F64P), ("dof_solimp", _F64P),
+     ("dof_solref", _F64P), ("dof_solimp", _F64P), ("geom_friction", _F64P),
     ]
 
 
@@ -62,11 +62,12 @@ class FreeBoxDesc(C.Structure):
         ("qpos0", C.c_double * 7), ("mass", C.c_double), ("inertia", C.c_double * 3), ("size", C.c_double * 3),
         ("friction", C.c_double * 3), ("solref", C.c_double * 2), ("solimp", C.c_double * 5), ("plane_z", C.c_double),
         ("impratio", C.c_double), ("noslip_tolerance", C.c_double), ("noslip_iterations", C.c_int32),
-        ("cone_elliptic", C.c_int32),
+        ("cone_elliptic", C.c_int32), ("geom_friction", C.c_double * 3), ("floor_friction", C.c_double * 3),
+        ("resolve_robot_contacts", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
-def make_free_box_desc(cm) -> FreeBoxDesc | None:
+def make_free_box_desc(cm, resolve_robot_contacts: bool = True) -> FreeBoxDesc | None:
     """rcsh_free_box_desc of a compiled scene's free body (None: the scene has none)."""
     free = getattr(cm, "free_bodies", [])
     if not free:
@@ -81,6 +82,9 @@ def make_free_box_desc(cm) -> FreeBoxDesc | None:
     d.impratio, d.noslip_iterations = float(cm.impratio), int(cm.noslip_iterations)
     d.noslip_tolerance = 1e-6  # mjOption default; the MJCF subset has no attribute for it
     d.cone_elliptic = int(cm.cone == "elliptic")
+    d.geom_friction[:] = [float(x) for x in fb.get("geom_friction", fb["friction"])]
+    d.floor_friction[:] = [float(x) for x in fb.get("floor_friction", (1.0, 0.005, 0.0001))]
+    d.resolve_robot_contacts = int(resolve_robot_contacts)
     return d
 
 

@@ -732,7 +732,7 @@ class _Compiler:
                 qpos0=np.concatenate([b["pos"], quat_normalize(b["quat"])]),
                 mass=float(mass), inertia=np.asarray(diag, dtype=np.float64), size=g["size"].copy(),
                 # mj_contactParam, equal priority: friction element-wise max, solref / solimp mixed 50:50 (solmix 1:1)
-                friction=np.maximum(pl["friction"], g["friction"]), geom_friction=g["friction"].copy(),
+                friction=np.maximum(pl["friction"], g["friction"]), geom_friction=g["friction"].copy(), floor_friction=pl["friction"].copy(),
                 solref=0.5 * (pl["solref"] + g["solref"]), solimp=0.5 * (pl["solimp"] + g["solimp"]),
                 plane_z=float(pl["pos"][2]),
             ))

@@ -43,7 +43,8 @@ class Sim:
     ``model`` is the compiled scene (``opt_timestep`` etc.), the stand-in for ``mujoco.MjModel``.
     """
 
-    def __init__(self, mjmdl: str | PathLike, cfg: SimConfig | None = None, n_envs: int = 1, device: int = 0):
+    def __init__(self, mjmdl: str | PathLike, cfg: SimConfig | None = None, n_envs: int = 1, device: int = 0,
+                 resolve_robot_contacts: bool = True):
         path = Path(mjmdl)
         if path.suffix == ".mjb":
             path = path.with_suffix(".xml")  # scenes are registered by their .mjb name in the reference
@@ -57,7 +58,8 @@ class Sim:
         desc, self._keep = _lib.make_model_desc(self.model)
         self._h = C.c_void_p()
         _lib.check(self._L.rcsh_sim_create(C.byref(desc), self.n_envs, self.device, C.byref(self._h)))
-        box = _lib.make_free_box_desc(self.model)
+        # scenes with a free body: the robot's collision geoms push against it and the floor (False: detection only)
+        box = _lib.make_free_box_desc(self.model, resolve_robot_contacts)
         if box is not None:
             _lib.check(self._L.rcsh_sim_add_free_box(self._h, C.byref(box)))
         self._cfg = SimConfig()
