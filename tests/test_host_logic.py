@@ -179,7 +179,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
     assert set(_lib.EXPORTS) == declared
-    assert L.rcsh_abi_version() == 1
+    assert L.rcsh_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
