@@ -574,3 +574,163 @@ def run_physics_parity_at_joint_limits(n_envs=32, n_calls=8, k=17, seed=0, n_ove
             rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - o.qvel).max()))
     simu.close()
     return rep
+
+
+def _pinch_placements(n_envs: int, seed: int):
+    """Cube poses a few millimetres / degrees off the gripper's closing axis (the scene's own pose first)."""
+    rng = np.random.default_rng(seed)
+    qb = np.tile(np.array([0.44, 0.1, 0.0288, 0, 0, 0, 1.0]), (n_envs, 1))
+    qb[1:, 0] += rng.uniform(-0.004, 0.004, n_envs - 1)
+    qb[1:, 1] += rng.uniform(-0.004, 0.004, n_envs - 1)
+    yaw = np.zeros(n_envs)
+    yaw[1:] = rng.uniform(-0.1, 0.1, n_envs - 1)
+    qb[:, 3], qb[:, 6] = np.cos((np.pi + yaw) / 2), np.sin((np.pi + yaw) / 2)
+    return qb
+
+
+def run_grasp_parity(n_envs=4, seed=0, swing_up=True):
+    """A scripted pinch through the 1:1 Sim / SimRobot / SimGripper API, kernel vs oracle: move over the cube, descend,
+    close the fingers on it (finger pads against the cube: box-box contacts, friction 2), lift, swing the arm up until
+    the cube is above PickCubeSuccessWrapper's success height (1.002 m), release.  Every stage compares joint and cube
+    state and the collision flags; returns the worst differences and what happened to the cube."""
+    import dataclasses
+
+    from rcs_amd import common
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = dataclasses.replace(default_sim_robot_cfg("fr3_simple_pick_up"), tcp_offset=common.Pose(common.FrankaHandTCPOffset()))
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    if KERNEL != "auto":
+        simu.set_kernel(KERNEL)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(PICKUP_SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, O.franka_hand_tcp_offset(), "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
+    assert osims[0].model.resolve_contacts == 1
+    qb = _pinch_placements(n_envs, seed)
+    simu.reset(); robot.reset(); grip.reset()
+    for o in osims:
+        o.reset(); o.robot_reset(); o.gripper_reset()
+    simu.set_free_joint_qpos("box_joint", qb)
+    for e, o in enumerate(osims):
+        o.box_qpos = qb[e]
+    rep = {"max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_box": 0.0, "max_abs_box_vel": 0.0, "flag_mismatches": 0, "max_ncon": 0,
+           "coupled_substeps": 0, "max_newton": 0, "max_noslip": 0, "stages": {}}
+
+    def advance(tag, k, conv=False):
+        if conv:
+            simu.step_until_convergence()
+            [o.step_until_convergence() for o in osims]
+        else:
+            simu.step(k)
+        q, v, bq, bv, st, gs = simu.qpos, simu.qvel, simu.free_joint_qpos("box_joint"), simu.free_joint_qvel("box_joint"), robot.get_state(), grip.get_state()
+        for e, o in enumerate(osims):
+            if not conv:
+                for _ in range(k):
+                    o.step(1)
+                    d = o.s.d
+                    rep["max_ncon"] = max(rep["max_ncon"], int(d.ncon))
+                    if d.coupled:
+                        rep["coupled_substeps"] += 1
+                        rep["max_newton"], rep["max_noslip"] = max(rep["max_newton"], int(d.solver_niter)), max(rep["max_noslip"], int(d.noslip_niter))
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - np.asarray(o.qpos)).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - np.asarray(o.qvel)).max()))
+            rep["max_abs_box"] = max(rep["max_abs_box"], float(np.abs(bq[e] - o.box_qpos).max()))
+            rep["max_abs_box_vel"] = max(rep["max_abs_box_vel"], float(np.abs(bv[e] - o.box_qvel).max()))
+            rep["flag_mismatches"] += int(bool(st.collision[e]) != bool(o.s.robot_collision)) + int(bool(gs.collision[e]) != bool(o.s.grp_collision))
+            rep["flag_mismatches"] += int(bool(grip.is_grasped()[e]) != o.gripper_is_grasped())
+            if conv:
+                rep["flag_mismatches"] += int(int(simu.convergence_steps()[e]) != int(o.s.convergence_steps))
+        rep["stages"][tag] = {"box_z": bq[:, 2].copy(), "width": grip.get_normalized_width().copy()}
+
+    home = osims[0].get_cartesian_position()
+
+    def move(xyz):
+        robot.set_cartesian_position(np.tile(np.concatenate([xyz, home.rotation_q()]), (n_envs, 1)))
+        for o in osims:
+            o.set_cartesian_position(O.Pose(translation=np.array(xyz), quaternion=home.rotation_q()))
+
+    simu.step(1); [o.step(1) for o in osims]
+    grip.open(); [o.gripper_open() for o in osims]
+    move([0.44, 0.1, 0.20]); advance("above", 400)
+    move([0.44, 0.1, 0.035]); advance("down", 600)
+    grip.shut(); [o.gripper_grasp() for o in osims]
+    advance("closed", 200)
+    move([0.44, 0.1, 0.30]); advance("lifted", 500)
+    if swing_up:
+        qg = robot.get_joint_position()
+        qup = np.array([0, 0, 0, -0.2, 0, 2.0, 0.785])
+        for k in range(1, 9):
+            tgt = qg + (qup - qg) * k / 8
+            robot.set_joint_position(tgt)
+            for e, o in enumerate(osims):
+                o.set_joint_position(tgt[e])
+            advance(f"swing{k}", 150)
+        advance("held", 200)
+        advance("converged", 0, conv=True)
+    grip.open(); [o.gripper_open() for o in osims]
+    advance("released", 300)
+    simu.close()
+    return rep
+
+
+def run_pick_success_parity(n_envs=3, seed=0):
+    """The registered pick-up task driven to SUCCESS: SimTaskEnvCreator with absolute joint actions (30 Hz async control), a
+    scripted pinch-lift-swing; reward, `success` / `terminated`, is_grasped and the cube pose against the oracle's wrapper
+    stack on the same actions.  Joint targets come from the oracle's IK, evaluated once on environment 0's trajectory."""
+    from rcs_amd import common, sim
+    from rcs_amd.envs import ControlMode, SimTaskEnvCreator, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import JOINTS, OraclePickCubeEnv
+
+    cm = compile_mjcf(PICKUP_SCENE)
+    tcp = O.Pose(translation=[0.0, 0.0, 0.1034], rotation=np.array([[0.707, 0.707, 0], [-0.707, 0.707, 0], [0, 0, 1]]))
+    rc = default_sim_robot_cfg(scene="fr3_simple_pick_up")
+    rc.tcp_offset = common.Pose(translation=np.array([0.0, 0.0, 0.1034]), rotation=np.array([[0.707, 0.707, 0], [-0.707, 0.707, 0], [0, 0, 1]]))
+    venv = SimTaskEnvCreator()(rc, control_mode=ControlMode.JOINTS, delta_actions=False,
+                               sim_cfg=sim.SimConfig(async_control=True, realtime=False, frequency=30), n_envs=n_envs)
+    if KERNEL != "auto":
+        venv.sim.set_kernel(KERNEL)
+    oenvs = [OraclePickCubeEnv(cm, control_mode=JOINTS, delta_actions=False, tcp_offset=tcp, async_control=True) for _ in range(n_envs)]
+    box = _pinch_placements(n_envs, seed)
+    obs, info = venv.reset(options={"box_qpos": box})
+    for e, oe in enumerate(oenvs):
+        oe.reset(box_qpos=box[e])
+    rep = {"max_abs_obs": 0.0, "max_abs_box": 0.0, "max_abs_reward": 0.0, "flag_mismatches": 0, "success_steps": 0, "grasped_steps": 0,
+           "max_box_z": 0.0, "steps": 0, "truncated": 0}
+    home = oenvs[0].sim.get_cartesian_position()
+    q = np.asarray(oenvs[0].sim.qpos[:7]).copy()
+    plan = []  # (joint target, gripper command, env-steps)
+    for xyz, g, k in (([0.44, 0.1, 0.20], 1.0, 14), ([0.44, 0.1, 0.035], 1.0, 20), ([0.44, 0.1, 0.035], 0.0, 8), ([0.44, 0.1, 0.30], 0.0, 16)):
+        sol, _ = oenvs[0].sim.ik_inverse(O.Pose(translation=np.array(xyz), quaternion=home.rotation_q()), q, tcp)
+        assert sol is not None
+        q = np.asarray(sol[:7]).copy()
+        plan.append((q.copy(), g, k))
+    qup = np.array([0, 0, 0, -0.2, 0, 2.0, 0.785])
+    for k in range(1, 9):
+        plan.append((q + (qup - q) * k / 8, 0.0, 5))
+    plan.append((qup, 0.0, 12))
+    for tgt, g, k in plan:
+        for _ in range(k):
+            a = {"joints": np.tile(tgt, (n_envs, 1)), "gripper": np.full(n_envs, g, dtype=np.float32)}
+            obs, reward, term, trunc, info = venv.step(a)
+            for e, oe in enumerate(oenvs):
+                oo, orw, oterm, otrunc, oi = oe.step({"joints": tgt, "gripper": np.float32(g)})
+                rep["max_abs_obs"] = max(rep["max_abs_obs"], float(np.abs(obs["tquat"][e] - oo["tquat"]).max()), float(np.abs(obs["joints"][e] - oo["joints"]).max()))
+                rep["max_abs_box"] = max(rep["max_abs_box"], float(np.abs(info["box_qpos"][e] - oe.sim.box_qpos).max()))
+                rep["max_abs_reward"] = max(rep["max_abs_reward"], abs(float(reward[e]) - float(orw)))
+                rep["flag_mismatches"] += int(bool(term[e]) != bool(oterm)) + int(bool(trunc[e]) != bool(otrunc)) + int(bool(info["success"][e]) != bool(oi["success"]))
+                rep["flag_mismatches"] += int(bool(info["is_grasped"][e]) != bool(oi["is_grasped"])) + int(float(obs["gripper"][e]) != float(oo["gripper"]))
+                rep["success_steps"] += int(bool(oi["success"]) and bool(term[e]))
+                rep["grasped_steps"] += int(bool(oi["is_grasped"]))
+                rep["truncated"] += int(bool(otrunc))
+            rep["max_box_z"] = max(rep["max_box_z"], float(info["box_qpos"][:, 2].min()))
+            rep["steps"] += 1
+    venv.close()
+    return rep
