@@ -648,14 +648,14 @@ def run_grasp_parity(n_envs=4, seed=0, swing_up=True):
                 rep["flag_mismatches"] += int(int(simu.convergence_steps()[e]) != int(o.s.convergence_steps))
         rep["stages"][tag] = {"box_z": bq[:, 2].copy(), "width": grip.get_normalized_width().copy()}
 
-    home = osims[0].get_cartesian_position()
+    simu.step(1); [o.step(1) for o in osims]
+    home = osims[0].get_cartesian_position()  # (the site frame is that of the last position stage: valid after a step)
 
     def move(xyz):
         robot.set_cartesian_position(np.tile(np.concatenate([xyz, home.rotation_q()]), (n_envs, 1)))
         for o in osims:
             o.set_cartesian_position(O.Pose(translation=np.array(xyz), quaternion=home.rotation_q()))
 
-    simu.step(1); [o.step(1) for o in osims]
     grip.open(); [o.gripper_open() for o in osims]
     move([0.44, 0.1, 0.20]); advance("above", 400)
     move([0.44, 0.1, 0.035]); advance("down", 600)

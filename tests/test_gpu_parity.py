@@ -781,13 +781,15 @@ def test_device_pointer_forms_equal_host_forms(kernel):
     [e.close() for e in envs]
 
 
-def test_grasp_lift_swing_matches_oracle():
+def test_grasp_lift_swing_matches_oracle(kernel):
     """Robot <-> cube contacts: a scripted pinch through the 1:1 API -- finger pads against the cube
     (box-box, up to 36 contacts), one constraint problem over the robot's 9 and the cube's 6 dofs, noslip -- then a lift and a
     swing above PickCubeSuccessWrapper's 1.002 m.  Kernel vs oracle stage by stage; flags (robot / gripper collision,
     is_grasped, convergence step counts) bit for bit."""
     from parity_util import run_grasp_parity
 
+    if kernel == "lane":
+        pytest.skip("free bodies are stepped by the team kernel only")
     rep = run_grasp_parity(n_envs=4, seed=0)
     assert rep["max_ncon"] >= 36 and rep["coupled_substeps"] > 1000 and rep["max_noslip"] >= 1, rep
     assert rep["max_abs_qpos"] < 1e-8 and rep["max_abs_qvel"] < 1e-6 and rep["max_abs_box"] < 1e-7 and rep["max_abs_box_vel"] < 1e-5, rep
@@ -798,11 +800,13 @@ def test_grasp_lift_swing_matches_oracle():
     assert ((st["held"]["width"] > 0.3) & (st["held"]["width"] < 0.5)).all(), st                  # fingers stopped by the 32 mm cube
 
 
-def test_pick_task_reaches_success():
+def test_pick_task_reaches_success(kernel):
     """rcs/FR3SimplePickUpSim-v0's wrapper stack (RandomCubePos, PickCubeSuccessWrapper) with absolute joint actions: the
     scripted pinch ends in `success` / `terminated` with reward 1, in the kernel and in the oracle alike."""
     from parity_util import run_pick_success_parity
 
+    if kernel == "lane":
+        pytest.skip("free bodies are stepped by the team kernel only")
     rep = run_pick_success_parity(n_envs=3, seed=1)
     assert rep["flag_mismatches"] == 0 and rep["truncated"] == 0, rep
     assert rep["success_steps"] >= 3 * 10 and rep["grasped_steps"] > 100 and rep["max_box_z"] > 1.002, rep
