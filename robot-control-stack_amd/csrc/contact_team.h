@@ -33,6 +33,17 @@ namespace rcsh {
 
 #if defined(__HIP__)
 
+// A pointer handed to a non-inlined function has lost its address space: the compiler would reach LDS through flat
+// instructions.  The round trip through an LDS-qualified pointer tells it (InferAddressSpaces) where the memory is.
+template <class P>
+RCSH_D P* in_lds(P* p) {
+  return (P*)(__attribute__((address_space(3))) P*)p;
+}
+
+// The contact phase is split into three non-inlined functions (collision, Newton, noslip) that hand their state over in
+// LDS: each gets a register allocation of its own instead of one that must hold everything at once.
+#define RCSH_CONTACT_FN __device__ __noinline__
+
 // ---- wave-level helpers (64 lanes)
 RCSH_D double wave_sum(double x) {
   x = quad_sum(x);
@@ -54,11 +65,12 @@ struct ContactArena {
   double X[16], A0[16], P[16], Gd[16];
   double H[NV * (NV + 1) / 2];
   double KA[2 * kMaxActive + 1][21];  // contact stiffness: (link a, box) pairs, (world, link a) pairs, (world, box)
-  double stage[64][10];    // contact records out of the collision phase; later per-contact wrenches / stiffness batches / Y
+  double rec[kMaxCon][14]; // contact records (con_load): what the phases hand to each other
+  double stage[64][8];     // scratch: clipping polygons of the box-box collider / per-contact wrenches / stiffness batches / Y
   int32_t cb[64];          // bodies of contact c: A | B << 8 | class bits << 16
   int32_t cnt[64][2];      // per geom lane: plane contacts, box contacts
   int32_t act[kMaxActive]; // links in contact
-  int32_t nact, ncon, hit, pad;
+  int32_t nact, ncon, pad[2];
 };
 
 // is joint j an ancestor-or-self joint of link i?
@@ -86,8 +98,9 @@ RCSH_D void mulTv(const double* R, const double* v, double* o) {
 }
 
 // ------------------------------------------------------------------ box - box (oracle: orc_box_box)
-__device__ __noinline__ int dev_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
-                                       double* pos /* [8][3] */, double* nrm /* [3] */, double* dist /* [8] */) {
+RCSH_CONTACT_FN int dev_box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
+                                       double* pos /* [8][3] */, double* nrm /* [3] */, double* dist /* [8] */,
+                                       double* poly_lds /* 48 doubles of LDS for the clipping polygons; null: overlap test only (returns 0 / 1) */) {
   double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, t[3], R[3][3], Q[3][3];
   mulTv(R1, d, t);
   for (int i = 0; i < 3; ++i)
@@ -122,6 +135,7 @@ __device__ __noinline__ int dev_box_box(const double* p1, const double* R1, cons
       if (pen < 0) return 0;
       if (pen < ebest) { ebest = pen; ecode = 3 * i + j; }
     }
+  if (!poly_lds) return 1;
   if (ecode >= 0 && ebest * 1.05 < best) {
     const int i = ecode / 3, j = ecode % 3;
     const double A[3] = {R1[i], R1[3 + i], R1[6 + i]}, B[3] = {R2[j], R2[3 + j], R2[6 + j]};
@@ -173,7 +187,7 @@ __device__ __noinline__ int dev_box_box(const double* p1, const double* R1, cons
   const double sb = dot3(n, Bb) > 0 ? -si[b] : si[b];
   const int u = (b + 1) % 3, v = (b + 2) % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
   const double Bu[3] = {Ri[u], Ri[3 + u], Ri[6 + u]}, Bv[3] = {Ri[v], Ri[3 + v], Ri[6 + v]};
-  double poly[2][16][3];
+  double (*poly)[8][3] = reinterpret_cast<double (*)[8][3]>(in_lds(poly_lds));  // (at most 8 vertices: a quad clipped by 4 half planes)
   for (int q = 0; q < 4; ++q) {
     const double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = q < 2 ? 1.0 : -1.0;
     double w[3];
@@ -222,7 +236,7 @@ struct Shape {
   int nvert;
   double center[3];
 };
-__device__ __noinline__ void shape_support(const Shape& s, const double* dir, double* out) {
+RCSH_D void shape_support(const Shape& s, const double* dir, double* out) {
   double l[3], w[3] = {0, 0, 0};
   mulTv(s.R, dir, l);
   if (s.type == 0) {
@@ -284,7 +298,7 @@ RCSH_D double origin_tri_dist2(const double* a, const double* b, const double* c
   for (int k = 0; k < 3; ++k) witness[k] = a[k] + s * ab[k] + t * ac[k];
   return dot3(witness, witness);
 }
-__device__ __noinline__ int dev_mpr(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
+RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
   constexpr double kTol = 1e-6;
   constexpr int kIter = 50;
   MprPt p0, p1, p2, p3, p4;
@@ -456,16 +470,142 @@ RCSH_D void body_spatial(const StageTeam<T>& st, const double* x, const double* 
   }
 }
 
-// The contact phase of one environment, executed by the whole wavefront.  `st` / `bs`: the environment's LDS blocks
-// (robot: pre-step q, qd, motion axes S, mass matrix, qfrc_smooth, limit / equality rows of this substep; box: state).
-// Returns bit 0: coupled (a robot geom is in contact: st.fcon holds the robot's constraint force, bs[kBoxA..] the box's
-// acceleration); bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
+// ---- the environment's box: frame of the current position stage (mj_kinematics normalises the quaternion) and velocity
+RCSH_D void box_frame(const double* bs, double* bp, double* bR, double* bv) {
+  double bq[4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) bp[k] = bs[kBoxQ + k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bq[k] = bs[kBoxQ + 3 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bv[k] = bs[kBoxV + k];
+  const double n = sqrt(bq[0] * bq[0] + bq[1] * bq[1] + bq[2] * bq[2] + bq[3] * bq[3]);
+  if (n < kMinVal) { bq[0] = 1; bq[1] = bq[2] = bq[3] = 0; }
+  else if (fabs(n - 1) > kMinVal) {
+    const double s = 1 / n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bq[k] *= s;
+  }
+  const double w = bq[0], x = bq[1], y = bq[2], z = bq[3];
+  bR[0] = w * w + x * x - y * y - z * z; bR[4] = w * w - x * x + y * y - z * z; bR[8] = w * w - x * x - y * y + z * z;
+  bR[1] = 2 * (x * y - w * z); bR[2] = 2 * (x * z + w * y); bR[3] = 2 * (x * y + w * z);
+  bR[5] = 2 * (y * z - w * x); bR[6] = 2 * (x * z - w * y); bR[7] = 2 * (y * z + w * x);
+}
+// column k of the box's spatial Jacobian about the world origin: linear dofs (0; e_k), body-frame angular dofs (R e; p x R e)
+RCSH_D void box_column(const double* bR, const double* bp, int k, double* col) {
+  if (k < 3) { col[0] = col[1] = col[2] = 0; col[3] = k == 0; col[4] = k == 1; col[5] = k == 2; }
+  else {
+    const double re[3] = {bR[k - 3], bR[3 + k - 3], bR[6 + k - 3]};
+    col[0] = re[0]; col[1] = re[1]; col[2] = re[2];
+    cross3(bp, re, col + 3);
+  }
+}
+
+// One contact as its owner lane sees it: the map G from spatial motion about the world origin to contact-frame velocity
+// (rows: normal, two tangents), reference accelerations, regularisers, cone parameters, the two bodies (force +f on B, -f on A).
+// Rebuilt from the contact's LDS record by every phase, so that nothing has to survive in registers between the phases.
+struct ConLane {
+  double G[3][6], aref[3], D[3], Rr[3], mu, fr, f[3];
+  int A, B;
+  bool on;
+};
+// record layout (ContactArena::rec): position 3, normal 3, [6] distance -> R0 once the rows exist, [7] friction of the pair,
+// [8] inverse weight of the pair -> [8..10] reference accelerations, [11..13] force
+template <class AR>
+RCSH_D void con_load(const AR& ar, const BoxCfg& b, int lane, int ncon, int world, ConLane& c) {
+  c.on = lane < ncon;
+  c.A = world; c.B = world;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    c.aref[k] = 0; c.D[k] = 0; c.Rr[k] = 0; c.f[k] = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) c.G[k][j] = 0.0;
+  }
+  c.mu = 0; c.fr = 0;
+  if (!c.on) return;
+  const double* r = ar.rec[lane];
+  const double pos[3] = {r[0], r[1], r[2]}, n[3] = {r[3], r[4], r[5]};
+  double fk[3][3];
+  fk[0][0] = n[0]; fk[0][1] = n[1]; fk[0][2] = n[2];
+  make_frame(n, fk[1], fk[2]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double xf[3];
+    cross3(pos, fk[k], xf);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { c.G[k][j] = xf[j]; c.G[k][3 + j] = fk[k][j]; }
+  }
+  const double R0 = r[6], R1 = R0 * b.inv_impratio;
+  c.Rr[0] = R0; c.Rr[1] = R1; c.Rr[2] = R1;
+  c.fr = r[7];
+  c.mu = c.fr * sqrt(R1 / R0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { c.D[k] = 1 / c.Rr[k]; c.aref[k] = r[8 + k]; c.f[k] = r[11 + k]; }
+  c.A = ar.cb[lane] & 0xff;
+  c.B = (ar.cb[lane] >> 8) & 0xff;
+}
+
+// Wrench of every body from the contact forces `fc` of the owner lanes -> ar.W; returns the generalised force J' f of dof
+// `lane` (lanes < NV).  Contains barriers: every lane calls it.
+template <class T, class AR>
+RCSH_D double contact_qfrc(AR& ar, const StageTeam<T>& st, const ConLane& c, const double* fc, int ncon, const double* bR, const double* bp, int lane) {
+  constexpr int NL = T::NL, NV = NL + 6, NB = NL + 2, kBox = NL;
+  if (lane < kMaxCon) {
+    double* wr = ar.stage[lane];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wr[k] = c.on ? c.G[0][k] * fc[0] + c.G[1][k] * fc[1] + c.G[2][k] * fc[2] : 0.0;
+  }
+  __syncthreads();
+  {
+    // lane (body, component): sum over the contacts in order
+    const int bdy = lane / 6, k = lane % 6;
+    if (bdy < NB - 1) {  // (the world takes no force)
+      double s = 0;
+      for (int cc = 0; cc < ncon; ++cc) {
+        const int code = ar.cb[cc];
+        if (((code >> 8) & 0xff) == bdy) s += ar.stage[cc][k];
+        if ((code & 0xff) == bdy) s -= ar.stage[cc][k];
+      }
+      ar.W[bdy][k] = s;
+    }
+  }
+  __syncthreads();
+  double q = 0;
+  if (lane < NL) {
+    double w[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < NL; ++i) {
+      if (!is_anc<T>(lane, i)) continue;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[k] += ar.W[i][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q += st.S(lane, k) * w[k];
+  } else if (lane < NV) {
+    double col[6];
+    box_column(bR, bp, lane - NL, col);
+    q = dot6(col, ar.W[kBox]);
+  }
+  return q;
+}
+
+// ================================================================= phase 1: collision
+// Lane g tests collision geom g against the floor and the box; the contacts are compacted into MuJoCo's order -- (floor,
+// robot geoms) by geom, (floor, box), (robot geoms, box) by geom -- and left as records in ar.rec / ar.cb.
+// Returns bit 0: a robot geom is in contact; bits 8-9: contact classes of this position stage (arm / gripper collision geoms).
 template <class T>
-__device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st,
-                                               double* bs, ContactArena<T>& ar, const double* gravity, double h) {
-  constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6, NB = NL + 2;
+RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg& b_, const LinkRec* links_, const StageTeam<T>& st_,
+                                         const double* bs_, ContactArena<T>& ar_) {
+  const ContactTable& tab = *in_lds(&tab_);
+  const BoxCfg& b = *in_lds(&b_);
+  const LinkRec* links = in_lds(links_);
+  const StageTeam<T> st{in_lds(st_.base)};
+  const double* bs = in_lds(bs_);
+  ContactArena<T>& ar = *in_lds(&ar_);
+  constexpr int NL = T::NL;
   constexpr int kBox = NL, kWorld = NL + 1;
   const int lane = wave_lane();
+  TEAM_MARK(24)
+  TEAM_COUNT(33)
   // ---- link frames at the pre-step configuration: lane i < NL walks the chain to link i
   if (lane < NL) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
@@ -484,31 +624,9 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
 #pragma unroll
     for (int k = 0; k < 3; ++k) ar.F[lane][9 + k] = p[k];
   }
-  // ---- the box: frame (mj_kinematics normalises the quaternion), every lane
-  double bp[3], bq[4], bR[9], bv[6];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) bp[k] = bs[kBoxQ + k];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) bq[k] = bs[kBoxQ + 3 + k];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) bv[k] = bs[kBoxV + k];
-  {
-    const double n = sqrt(bq[0] * bq[0] + bq[1] * bq[1] + bq[2] * bq[2] + bq[3] * bq[3]);
-    if (n < kMinVal) { bq[0] = 1; bq[1] = bq[2] = bq[3] = 0; }
-    else if (fabs(n - 1) > kMinVal) {
-      const double s = 1 / n;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bq[k] *= s;
-    }
-    const double w = bq[0], x = bq[1], y = bq[2], z = bq[3];
-    bR[0] = w * w + x * x - y * y - z * z; bR[4] = w * w - x * x + y * y - z * z; bR[8] = w * w - x * x - y * y + z * z;
-    bR[1] = 2 * (x * y - w * z); bR[2] = 2 * (x * z + w * y); bR[3] = 2 * (x * y + w * z);
-    bR[5] = 2 * (y * z - w * x); bR[6] = 2 * (x * z - w * y); bR[7] = 2 * (y * z + w * x);
-  }
+  double bp[3], bR[9], bv[6];
+  box_frame(bs, bp, bR, bv);
   __syncthreads();
-
-  // ================================================================= collision
-  // lane g: collision geom g against the floor plane and against the box
   double ppos[4][3], pdist[4], cpos[8][3], cdist[8], cn[3] = {0, 0, 0};
   int nP = 0, nB = 0, boxfirst = 0;
   ContactGeom cg;
@@ -529,19 +647,19 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     const double* V = tab.verts + 3 * (size_t)cg.vert_adr;
     // ---- floor
     if (tab.has_plane && cg.plane_ok) {
-      const double* n = tab.plane_n;
+      const double n[3] = {tab.plane_n[0], tab.plane_n[1], tab.plane_n[2]};
       const double cdst = dot3(n, gp) - tab.plane_d;
       if (cdst - cg.rbound <= 0) {
         if (cg.type == 7) {
-          double fr[9] = {n[0], n[1], n[2]};
-          make_frame(fr, fr + 3, fr + 6);
+          double t1[3], t2[3];
+          make_frame(n, t1, t2);
           int chosen[4];
           for (int q = 0; q < 4; ++q) {
             double dir[3];
             if (q == 0) { dir[0] = -n[0]; dir[1] = -n[1]; dir[2] = -n[2]; }
             else {
               const double ang = 2 * M_PI * (q - 1) / 3, cs = 1e-3 * cos(ang), sn = 1e-3 * sin(ang);
-              for (int k = 0; k < 3; ++k) dir[k] = -n[k] + cs * fr[3 + k] + sn * fr[6 + k];
+              for (int k = 0; k < 3; ++k) dir[k] = -n[k] + cs * t1[k] + sn * t2[k];
             }
             double dl[3], bestv = -INFINITY;
             mulTv(gR, dir, dl);
@@ -597,11 +715,12 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
       const double dx[3] = {gp[0] - bp[0], gp[1] - bp[1], gp[2] - bp[2]};
       const double rsum = cg.rbound + sqrt(b.size[0] * b.size[0] + b.size[1] * b.size[1] + b.size[2] * b.size[2]);
       if (dot3(dx, dx) <= rsum * rsum) {
+        const double bsz[3] = {b.size[0], b.size[1], b.size[2]};
         if (cg.type == 6) {
-          nB = dev_box_box(gp, gR, cg.size, bp, bR, b.size, &cpos[0][0], cn, cdist);
+          nB = dev_box_box(gp, gR, cg.size, bp, bR, bsz, &cpos[0][0], cn, cdist, &ar.stage[0][0] + 48 * cg.box_slot);
         } else {
           Shape S{cg.type == 7 ? 0 : 2, gp, gR, cg.size, V, cg.vert_num, {gp[0], gp[1], gp[2]}};
-          Shape Bx{1, bp, bR, b.size, nullptr, 0, {bp[0], bp[1], bp[2]}};
+          Shape Bx{1, bp, bR, bsz, nullptr, 0, {bp[0], bp[1], bp[2]}};
           if (cg.type == 7) {
             double c[3];
             mulmv(gR, cg.center, c);
@@ -610,10 +729,10 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
           // the shapes cannot intersect when the hull's bounding box and the cube do not (separating axes of the two boxes)
           bool may = true;
           if (cg.type == 7) {
-            double oc[3], dummy_p[24], dummy_n[3], dummy_d[8];
+            double oc[3];
             mulmv(gR, cg.aabb_c, oc);
             oc[0] += gp[0]; oc[1] += gp[1]; oc[2] += gp[2];
-            may = dev_box_box(oc, gR, cg.aabb_h, bp, bR, b.size, dummy_p, dummy_n, dummy_d) > 0;
+            may = dev_box_box(oc, gR, cg.aabb_h, bp, bR, bsz, nullptr, nullptr, nullptr, nullptr) != 0;
           }
           double depth = 0;
           if (may) {
@@ -625,7 +744,7 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
       }
     }
   }
-  // the box against the floor (mjc_PlaneBox: corners in order, at most four): computed by lane 63
+  // the box against the floor (mjc_PlaneBox: corners in order, at most four)
   int nBP = 0;
   double bppos[4][3], bpdist[4];
   if (tab.has_plane) {
@@ -644,7 +763,7 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
   ar.cnt[lane][0] = nP;
   ar.cnt[lane][1] = nB;
   __syncthreads();
-  // ---- compaction into MuJoCo's order: (floor, robot geoms) by geom, (floor, box), (robot geoms, box) by geom
+  TEAM_MARK(25)
   int offP = 0, offB = 0, totP = 0, totB = 0;
   for (int g = 0; g < tab.ngeom; ++g) {
     const int a = ar.cnt[g][0], c = ar.cnt[g][1];
@@ -655,111 +774,104 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
   offB += totP + nBP;
   int ncon = totP + nBP + totB;
   if (ncon > kMaxCon) ncon = kMaxCon;
-  const int bcode = kBox, wcode = kWorld;
   if (has_geom) {
     const int lcode = cg.link >= 0 ? cg.link : kWorld;
     for (int k = 0; k < nP; ++k) {
       const int c = offP + k;
       if (c >= kMaxCon) break;
-      double* r = ar.stage[c];
+      double* r = ar.rec[c];
       r[0] = ppos[k][0]; r[1] = ppos[k][1]; r[2] = ppos[k][2];
       r[3] = tab.plane_n[0]; r[4] = tab.plane_n[1]; r[5] = tab.plane_n[2];
       r[6] = pdist[k];
       r[7] = fmax(tab.plane_mu, cg.mu);
       r[8] = cg.invweight;
-      ar.cb[c] = wcode | (lcode << 8) | (cg.cls << 16);
+      ar.cb[c] = kWorld | (lcode << 8) | (cg.cls << 16);
     }
     for (int k = 0; k < nB; ++k) {
       const int c = offB + k;
       if (c >= kMaxCon) break;
-      double* r = ar.stage[c];
+      double* r = ar.rec[c];
       r[0] = cpos[k][0]; r[1] = cpos[k][1]; r[2] = cpos[k][2];
       r[3] = cn[0]; r[4] = cn[1]; r[5] = cn[2];
       r[6] = cdist[k];
       r[7] = fmax(b.geom_mu, cg.mu);
       r[8] = cg.invweight + b.inv_mass;
-      ar.cb[c] = (boxfirst ? (bcode | (lcode << 8)) : (lcode | (bcode << 8))) | (cg.cls << 16);
+      ar.cb[c] = (boxfirst ? (kBox | (lcode << 8)) : (lcode | (kBox << 8))) | (cg.cls << 16);
     }
   }
   if (lane == 63) {
     for (int k = 0; k < nBP; ++k) {
       const int c = totP + k;
       if (c >= kMaxCon) break;
-      double* r = ar.stage[c];
+      double* r = ar.rec[c];
       r[0] = bppos[k][0]; r[1] = bppos[k][1]; r[2] = bppos[k][2];
       r[3] = 0; r[4] = 0; r[5] = 1;
       r[6] = bpdist[k];
       r[7] = b.fr;
       r[8] = b.inv_mass;
-      ar.cb[c] = wcode | (bcode << 8);
+      ar.cb[c] = kWorld | (kBox << 8);
     }
+    ar.ncon = ncon;
   }
   __syncthreads();
-  // contact classes of this position stage (what the collision callbacks scan d->contact for)
-  uint32_t hit = 0;
-  {
-    int cls = 0;
-    if (lane < ncon) cls = (ar.cb[lane] >> 16) & 0xff;
-    // SimGripper::collision_callback ignores contacts between two finger geoms; none can occur here (no geom-geom pairs of the robot)
-    hit = (__ballot(cls & 1) ? 1u : 0u) | (__ballot(cls & 2) ? 2u : 0u);
-  }
-  if (robot_contacts == 0 || !b.resolve) return hit << 8;
+  // contact classes of this position stage (what the collision callbacks scan d->contact for).  SimGripper::collision_callback
+  // ignores contacts between two finger geoms; none can occur here (no geom-geom pairs of the robot).
+  int cls = 0;
+  if (lane < ncon) cls = (ar.cb[lane] >> 16) & 0xff;
+  const uint32_t hit = (__ballot(cls & 1) ? 1u : 0u) | (__ballot(cls & 2) ? 2u : 0u);
+  TEAM_MARK(26)
+  return (robot_contacts > 0 ? 1u : 0u) | (hit << 8);
+}
 
-  // ================================================================= rows
-  // lane c owns contact c
-  const bool on = lane < ncon;
-  double G[3][6], aref[3] = {0, 0, 0}, D[3] = {0, 0, 0}, Rr[3] = {0, 0, 0}, mu = 0, fr = 0, f[3] = {0, 0, 0};
-  int cA = kWorld, cB = kWorld;
-  // spatial velocities of the bodies
-  {
-    double qd[16];
-    // (x of body_spatial is read from LDS: park qvel in ar.X)
-    if (lane < NL) ar.X[lane] = st.v(lane);
-    if (lane >= NL && lane < NV) ar.X[lane] = bv[lane - NL];
-    (void)qd;
-  }
+// ================================================================= phase 2: rows + Newton on the primal cost
+// Lane c owns contact c.  Leaves the minimiser in ar.X, qacc_smooth in ar.A0, the rows' reference accelerations /
+// regularisers and the contact forces in the records.
+template <class T>
+RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, const double* bs_, ContactArena<T>& ar_, const double* gravity_) {
+  const BoxCfg& b = *in_lds(&b_);
+  const StageTeam<T> st{in_lds(st_.base)};
+  const double* bs = in_lds(bs_);
+  ContactArena<T>& ar = *in_lds(&ar_);
+  const double* gravity = in_lds(gravity_);
+  constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6;
+  constexpr int kBox = NL, kWorld = NL + 1;
+  const int lane = wave_lane();
+  TEAM_COUNT(34)
+  const int ncon = ar.ncon;
+  double bp[3], bR[9], bv[6];
+  box_frame(bs, bp, bR, bv);
+  // ---- spatial velocities of the bodies (qvel parked in ar.X)
+  if (lane < NL) ar.X[lane] = st.v(lane);
+  else if (lane < NV) ar.X[lane] = bv[lane - NL];
   __syncthreads();
   body_spatial<T>(st, ar.X, bR, bp, ar.V, lane);
   __syncthreads();
-  if (on) {
-    const double* r = ar.stage[lane];
+  // ---- rows of the lane's contact: regulariser, reference accelerations -> record
+  if (lane < ncon) {
+    double* r = ar.rec[lane];
     const double pos[3] = {r[0], r[1], r[2]}, n[3] = {r[3], r[4], r[5]};
     const double dist = r[6], iw = r[8];
-    fr = r[7];
-    cA = ar.cb[lane] & 0xff;
-    cB = (ar.cb[lane] >> 8) & 0xff;
+    const int A_ = ar.cb[lane] & 0xff, B_ = (ar.cb[lane] >> 8) & 0xff;
     double fk[3][3];
     fk[0][0] = n[0]; fk[0][1] = n[1]; fk[0][2] = n[2];
     make_frame(n, fk[1], fk[2]);
+    const double imp = impedance(b.imp, dist, 0.0);
+    double R0 = (1 - imp) / imp * iw;
+    if (R0 < kMinVal) R0 = kMinVal;
+    double rel[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rel[k] = ar.V[B_][k] - ar.V[A_][k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       double xf[3];
       cross3(pos, fk[k], xf);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { G[k][c] = xf[c]; G[k][3 + c] = fk[k][c]; }
+      const double vel = xf[0] * rel[0] + xf[1] * rel[1] + xf[2] * rel[2] + fk[k][0] * rel[3] + fk[k][1] * rel[4] + fk[k][2] * rel[5];
+      r[8 + k] = -b.B * vel - (k == 0 ? b.K * imp * dist : 0.0);
+      r[11 + k] = 0.0;
     }
-    const double imp = impedance(b.imp, dist, 0.0);
-    double R0 = (1 - imp) / imp * iw;
-    if (R0 < kMinVal) R0 = kMinVal;
-    const double R1 = R0 * b.inv_impratio;
-    Rr[0] = R0; Rr[1] = R1; Rr[2] = R1;
-    mu = fr * sqrt(R1 / R0);
-    double rel[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) rel[k] = ar.V[cB][k] - ar.V[cA][k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      D[k] = 1 / Rr[k];
-      const double vel = dot6(G[k], rel);
-      aref[k] = -b.B * vel - (k == 0 ? b.K * imp * dist : 0.0);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) G[k][c] = 0.0;
+    r[6] = R0;
   }
-  // links in contact (the noslip pass keeps M^-1 S' for them)
+  // links in contact (their composite contact stiffness enters the Hessian; the noslip pass keeps M^-1 S' for them)
   if (lane == 0) {
     int na = 0;
     for (int c = 0; c < ncon; ++c) {
@@ -775,15 +887,13 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
   }
   // ---- qacc_smooth: the robot's by its own factorisation (every lane), the box's in closed form
   const double Mb[6] = {b.mass, b.mass, b.mass, b.inertia[0], b.inertia[1], b.inertia[2]};
-  const double Mbi[6] = {b.inv_mass, b.inv_mass, b.inv_mass, b.inv_inertia[0], b.inv_inertia[1], b.inv_inertia[2]};
-  double LM[T::NTRI];
-#pragma unroll
-  for (int i = 0; i < NL; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j) LM[tri(i, j)] = st.M(i, j);
-  ldl_factor<NL>(LM);
   {
-    double a0[NL];
+    double LM[T::NTRI], a0[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) LM[tri(i, j)] = st.M(i, j);
+    ldl_factor<NL>(LM);
 #pragma unroll
     for (int i = 0; i < NL; ++i) a0[i] = st.smooth(i);
     ldl_solve<NL>(LM, a0);
@@ -804,22 +914,23 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     }
   }
   __syncthreads();
+  ConLane c;
+  con_load(ar, b, lane, ncon, kWorld, c);
   const int nact = ar.nact;
   const bool has_eq = T::GRIP && st.eq(0) != 0.0;
   const double eqD = T::GRIP ? st.eq(0) : 0.0, eqAref = T::GRIP ? st.eq(1) : 0.0, eqJ1 = T::GRIP ? st.eq(2) : 0.0;
 
-  // ---- evaluation of the primal cost at x = ar.X + alpha * ar.P (alpha = 0, use_p false: at ar.X): every row's force;
-  // returns the total cost (all lanes).  jar / Hc of the lane's contact are left in the out-parameters.
-  double jar[3] = {0, 0, 0}, Hc[6] = {0, 0, 0, 0, 0, 0};
+  // cost of the lane's contact at the bodies' accelerations Ub: force, cone Hessian, jar
+  double jar[3] = {0, 0, 0}, Hc[6] = {0, 0, 0, 0, 0, 0}, f[3] = {0, 0, 0};
   auto eval_rows = [&](const double (*Ub)[6], double* jar_out, double* f_out, double* Hc_out) -> double {
     double cost = 0;
-    if (on) {
+    if (c.on) {
       double rel[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) rel[k] = Ub[cB][k] - Ub[cA][k];
+      for (int k = 0; k < 6; ++k) rel[k] = Ub[c.B][k] - Ub[c.A][k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) jar_out[k] = dot6(G[k], rel) - aref[k];
-      cost = cone_eval(D, mu, fr, jar_out, f_out, Hc_out);
+      for (int k = 0; k < 3; ++k) jar_out[k] = dot6(c.G[k], rel) - c.aref[k];
+      cost = cone_eval(c.D, c.mu, c.fr, jar_out, f_out, Hc_out);
     }
     return cost;
   };
@@ -854,58 +965,9 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     *grad_out = g;
     return cost;
   };
-  // wrench of every body from the contact forces f (registers of the owner lanes) -> ar.W; then the generalised force
-  // J' f of dof `lane` (returned on lanes < NV)
-  auto contact_qfrc = [&](const double* fc) -> double {
-    if (lane < kMaxCon) {
-      double* wr = ar.stage[lane];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) wr[k] = on ? G[0][k] * fc[0] + G[1][k] * fc[1] + G[2][k] * fc[2] : 0.0;
-    }
-    __syncthreads();
-    {
-      // lane (body, component): sum over the contacts in order
-      const int bdy = lane / 6, k = lane % 6;
-      if (bdy < NB - 1) {  // (the world takes no force)
-        double s = 0;
-        for (int c = 0; c < ncon; ++c) {
-          const int cc = ar.cb[c];
-          const int A_ = cc & 0xff, B_ = (cc >> 8) & 0xff;
-          if (B_ == bdy) s += ar.stage[c][k];
-          if (A_ == bdy) s -= ar.stage[c][k];
-        }
-        ar.W[bdy][k] = s;
-      }
-    }
-    __syncthreads();
-    double q = 0;
-    if (lane < NL) {
-      double w[6] = {0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < NL; ++i) {
-        if (!is_anc<T>(lane, i)) continue;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) w[k] += ar.W[i][k];
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) q += st.S(lane, k) * w[k];
-    } else if (lane < NV) {
-      const int k = lane - NL;
-      const double* w = ar.W[kBox];
-      if (k < 3) q = w[3 + k];
-      else {
-        // column of S_box for the body-frame angular dof k - 3: [R e ; p x R e]
-        const double re[3] = {bR[k - 3], bR[3 + k - 3], bR[6 + k - 3]};
-        double c[3];
-        cross3(bp, re, c);
-        q = re[0] * w[0] + re[1] * w[1] + re[2] * w[2] + c[0] * w[3] + c[1] * w[4] + c[2] * w[5];
-      }
-    }
-    return q;
-  };
 
-  // ================================================================= Newton on the primal cost
+  TEAM_MARK(27)
   // start: the cheaper of the warm start and qacc_smooth
-  double cost_x;
   {
     if (lane < NL) ar.P[lane] = st.xs(lane);
     else if (lane < NV) ar.P[lane] = bs[kBoxW + lane - NL];
@@ -914,26 +976,21 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
     body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
     __syncthreads();
-    double g;
-    double ja[3], fa[3], Ha[6];
+    double g, ja[3], fa[3], Ha[6];
     const double c_smooth = wave_sum(eval_rows(ar.U, ja, fa, Ha) + robot_terms(ar.X, &g));
     const double c_warm = wave_sum(eval_rows(ar.Up, ja, fa, Ha) + robot_terms(ar.P, &g));
     __syncthreads();
-    if (c_warm < c_smooth) {
-      if (lane < NV) ar.X[lane] = ar.P[lane];
-      cost_x = c_warm;
-    } else cost_x = c_smooth;
+    if (c_warm < c_smooth && lane < NV) ar.X[lane] = ar.P[lane];
     __syncthreads();
   }
-  (void)cost_x;
-  int newton_it = 0;
-  for (; newton_it < 100; ++newton_it) {
+  for (int newton_it = 0; newton_it < 100; ++newton_it) {
+    TEAM_COUNT(29)
     body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
     __syncthreads();
     eval_rows(ar.U, jar, f, Hc);
     double gl;
     robot_terms(ar.X, &gl);
-    const double qf = contact_qfrc(f);
+    const double qf = contact_qfrc<T>(ar, st, c, f, ncon, bR, bp, lane);
     if (lane < NV) { gl -= qf; ar.Gd[lane] = gl; }
     const double g2 = wave_sum(lane < NV ? gl * gl : 0.0);
     if (b.scale * sqrt(g2) < 1e-12) break;
@@ -941,27 +998,26 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     // batches of seven entries: accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
     {
       double Kc[21];
-      if (on) {
+      if (c.on) {
         double Tm[3][6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          Tm[0][c] = Hc[0] * G[0][c] + Hc[1] * G[1][c] + Hc[3] * G[2][c];
-          Tm[1][c] = Hc[1] * G[0][c] + Hc[2] * G[1][c] + Hc[4] * G[2][c];
-          Tm[2][c] = Hc[3] * G[0][c] + Hc[4] * G[1][c] + Hc[5] * G[2][c];
+        for (int k = 0; k < 6; ++k) {
+          Tm[0][k] = Hc[0] * c.G[0][k] + Hc[1] * c.G[1][k] + Hc[3] * c.G[2][k];
+          Tm[1][k] = Hc[1] * c.G[0][k] + Hc[2] * c.G[1][k] + Hc[4] * c.G[2][k];
+          Tm[2][k] = Hc[3] * c.G[0][k] + Hc[4] * c.G[1][k] + Hc[5] * c.G[2][k];
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-          for (int c = 0; c <= r; ++c) Kc[tri(r, c)] = G[0][r] * Tm[0][c] + G[1][r] * Tm[1][c] + G[2][r] * Tm[2][c];
+          for (int k = 0; k <= r; ++k) Kc[tri(r, k)] = c.G[0][r] * Tm[0][k] + c.G[1][r] * Tm[1][k] + c.G[2][r] * Tm[2][k];
       } else {
 #pragma unroll
         for (int e = 0; e < 21; ++e) Kc[e] = 0.0;
       }
-      // which accumulator does contact c feed?  (slot index, or -1)
       int slot = -1;
-      if (on) {
-        const int lk = cA < NL ? cA : (cB < NL ? cB : -1);
-        const bool with_box = cA == kBox || cB == kBox;
+      if (c.on) {
+        const int lk = c.A < NL ? c.A : (c.B < NL ? c.B : -1);
+        const bool with_box = c.A == kBox || c.B == kBox;
         if (lk < 0) slot = 2 * kMaxActive;
         else {
           int a = -1;
@@ -983,8 +1039,8 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
           const int a = lane / 7, e = lane % 7;
           if (a < 2 * kMaxActive + 1) {
             double s = 0;
-            for (int c = 0; c < ncon; ++c)
-              if ((int)ar.stage[c][7] == a) s += ar.stage[c][e];
+            for (int cc = 0; cc < ncon; ++cc)
+              if ((int)ar.stage[cc][7] == a) s += ar.stage[cc][e];
             ar.KA[a][7 * batch + e] = s;
           }
         }
@@ -1009,10 +1065,10 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
       for (int r = 0; r < 6; ++r) {
         double sy = 0, sz = 0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const int e = r >= c ? tri(r, c) : tri(c, r);
-          sy += KD[e] * Sl[c];
-          sz += KX[e] * Sl[c];
+        for (int k = 0; k < 6; ++k) {
+          const int e = r >= k ? tri(r, k) : tri(k, r);
+          sy += KD[e] * Sl[k];
+          sz += KX[e] * Sl[k];
         }
         y[r] = sy; z[r] = sz;
       }
@@ -1036,15 +1092,9 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
       // box rows' robot columns: H[NL + k][lane] = -S_box[:, k] . z
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        double v;
-        if (k < 3) v = z[3 + k];
-        else {
-          const double re[3] = {bR[k - 3], bR[3 + k - 3], bR[6 + k - 3]};
-          double c[3];
-          cross3(bp, re, c);
-          v = re[0] * z[0] + re[1] * z[1] + re[2] * z[2] + c[0] * z[3] + c[1] * z[4] + c[2] * z[5];
-        }
-        ar.H[tri(NL + k, lane)] = -v;
+        double col[6];
+        box_column(bR, bp, k, col);
+        ar.H[tri(NL + k, lane)] = -dot6(col, z);
       }
     } else if (lane < NV) {
       const int k = lane - NL;
@@ -1054,60 +1104,68 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
       for (int a = 0; a < nact; ++a)
 #pragma unroll
         for (int e = 0; e < 21; ++e) Kb[e] += ar.KA[a][e];
-      auto sbox = [&](int kk, double* col) {
-        if (kk < 3) { col[0] = col[1] = col[2] = 0; col[3] = kk == 0; col[4] = kk == 1; col[5] = kk == 2; }
-        else {
-          const double re[3] = {bR[kk - 3], bR[3 + kk - 3], bR[6 + kk - 3]};
-          col[0] = re[0]; col[1] = re[1]; col[2] = re[2];
-          cross3(bp, re, col + 3);
-        }
-      };
       double ck[6], y[6];
-      sbox(k, ck);
+      box_column(bR, bp, k, ck);
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         double s = 0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) s += Kb[r >= c ? tri(r, c) : tri(c, r)] * ck[c];
+        for (int q = 0; q < 6; ++q) s += Kb[r >= q ? tri(r, q) : tri(q, r)] * ck[q];
         y[r] = s;
       }
       for (int l = 0; l <= k; ++l) {
         double cl[6];
-        sbox(l, cl);
+        box_column(bR, bp, l, cl);
         ar.H[tri(NL + k, NL + l)] = dot6(cl, y) + (l == k ? Mb[k] : 0.0);
       }
     }
     __syncthreads();
-    // ---- every lane: factor H, Newton direction
-    double p[NV];
-    {
-      double Hf[NV * (NV + 1) / 2];
-#pragma unroll
-      for (int e = 0; e < NV * (NV + 1) / 2; ++e) Hf[e] = ar.H[e];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) p[i] = -ar.Gd[i];
-      ldl_factor<NV>(Hf);
-      ldl_solve<NV>(Hf, p);
+    // ---- Newton direction p = -H^-1 grad.  LDL' of the 15 x 15 Hessian in place in LDS, lane i owning row i (right-looking:
+    // step j scales nothing, it only subtracts column j's outer product from the rows below -- column j itself stays
+    // unscaled, L_ij = H_ij / d_j); then every lane runs the two triangular solves for itself, streaming L out of LDS.
+    for (int j = 0; j < NV - 1; ++j) {
+      if (lane > j && lane < NV) {
+        const double lij = ar.H[tri(lane, j)] / ar.H[tri(j, j)];
+        for (int k = j + 1; k <= lane; ++k) ar.H[tri(lane, k)] -= lij * ar.H[tri(k, j)];
+      }
+      __syncthreads();
     }
     double dphi0 = 0;
+    {
+      double p[NV], dinv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) dphi0 += ar.Gd[i] * p[i];
-    if (!(dphi0 < 0)) break;
-    if (lane == 0) {
+      for (int i = 0; i < NV; ++i) { p[i] = -ar.Gd[i]; dinv[i] = 1.0 / ar.H[tri(i, i)]; }
 #pragma unroll
-      for (int i = 0; i < NV; ++i) ar.P[i] = p[i];
+      for (int i = 1; i < NV; ++i) {
+#pragma unroll
+        for (int k = 0; k < i; ++k) p[i] -= ar.H[tri(i, k)] * dinv[k] * p[k];
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) p[i] *= dinv[i];
+#pragma unroll
+      for (int i = NV - 2; i >= 0; --i) {
+#pragma unroll
+        for (int k = i + 1; k < NV; ++k) p[i] -= ar.H[tri(k, i)] * dinv[i] * p[k];
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) dphi0 += ar.Gd[i] * p[i];
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) ar.P[i] = p[i];
+      }
     }
+    if (!(dphi0 < 0)) break;
     __syncthreads();
     body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
     __syncthreads();
     // ---- line search: root of phi'(a) by safeguarded 1-D Newton (a = 1 is exact while no row changes zone)
     double jd[3] = {0, 0, 0};
-    if (on) {
+    if (c.on) {
       double rel[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) rel[k] = ar.Up[cB][k] - ar.Up[cA][k];
+      for (int k = 0; k < 6; ++k) rel[k] = ar.Up[c.B][k] - ar.Up[c.A][k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) jd[k] = dot6(G[k], rel);
+      for (int k = 0; k < 3; ++k) jd[k] = dot6(c.G[k], rel);
     }
     // Gauss term along the line: phi_M'(a) = gM0 + a pMp
     double gM0l = 0, pMpl = 0;
@@ -1116,7 +1174,7 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
       for (int j = 0; j < NL; ++j) {
         const double mij = lane >= j ? st.M(lane, j) : st.M(j, lane);
         mx += mij * (ar.X[j] - ar.A0[j]);
-        mp += mij * p[j];
+        mp += mij * ar.P[j];
       }
       gM0l = mx * ar.P[lane]; pMpl = mp * ar.P[lane];
     } else if (lane < NV) {
@@ -1127,12 +1185,13 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     const double gM0 = wave_sum(gM0l), pMp = wave_sum(pMpl);
     double lo = 0, hi = -1, a = 1, best = 1;
     for (int ls = 0; ls < 30; ++ls) {
+      TEAM_COUNT(35)
       double dl = 0, ddl = 0;
-      if (on) {
+      if (c.on) {
         double ja[3], fa[3], Ha[6];
 #pragma unroll
         for (int k = 0; k < 3; ++k) ja[k] = jar[k] + a * jd[k];
-        cone_eval(D, mu, fr, ja, fa, Ha);
+        cone_eval(c.D, c.mu, c.fr, ja, fa, Ha);
         dl = -(jd[0] * fa[0] + jd[1] * fa[1] + jd[2] * fa[2]);
         ddl = jd[0] * (Ha[0] * jd[0] + Ha[1] * jd[1] + Ha[3] * jd[2]) + jd[1] * (Ha[1] * jd[0] + Ha[2] * jd[1] + Ha[4] * jd[2]) +
               jd[2] * (Ha[3] * jd[0] + Ha[4] * jd[1] + Ha[5] * jd[2]);
@@ -1164,114 +1223,117 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     if (lane < NV) ar.X[lane] += best * ar.P[lane];
     __syncthreads();
   }
-  // forces at the solution
+  // forces at the solution -> records
   body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
   __syncthreads();
   eval_rows(ar.U, jar, f, Hc);
+  if (c.on) {
+    double* r = ar.rec[lane];
+    r[11] = f[0]; r[12] = f[1]; r[13] = f[2];
+  }
+  __syncthreads();
+  TEAM_MARK(28)
+}
 
-  // ================================================================= noslip (mj_solNoSlip over the contacts' friction rows)
+// ================================================================= phase 3: noslip + results
+// mj_solNoSlip over the contacts' friction rows (Gauss-Seidel in contact order, no regulariser), then the robot's
+// qfrc_constraint -> st.fcon and the box's acceleration -> bs[kBoxA..].  In: the bodies' accelerations ar.U at the Newton
+// solution ar.X, the records.
+template <class T>
+RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_) {
+  const BoxCfg& b = *in_lds(&b_);
+  const StageTeam<T> st{in_lds(st_.base)};
+  double* bs = in_lds(bs_);
+  ContactArena<T>& ar = *in_lds(&ar_);
+  constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6, NB = NL + 2;
+  constexpr int kBox = NL, kWorld = NL + 1;
+  const int lane = wave_lane();
+  const int ncon = ar.ncon, nact = ar.nact;
+  double bp[3], bR[9], bv[6];
+  box_frame(bs, bp, bR, bv);
+  const double Mbi[6] = {b.inv_mass, b.inv_mass, b.inv_mass, b.inv_inertia[0], b.inv_inertia[1], b.inv_inertia[2]};
+  ConLane c;
+  con_load(ar, b, lane, ncon, kWorld, c);
+  const bool has_eq = T::GRIP && st.eq(0) != 0.0;
+  const double eqD = T::GRIP ? st.eq(0) : 0.0, eqAref = T::GRIP ? st.eq(1) : 0.0, eqJ1 = T::GRIP ? st.eq(2) : 0.0;
   if (b.noslip_iterations > 0) {
     // Y_a = M^-1 S_a' for the links in contact (robot dofs x 6), [a][dof][k] in the stage area: lane (a, k) solves one column
     double (*Y)[NL][6] = reinterpret_cast<double (*)[NL][6]>(&ar.stage[0][0]);
-    __syncthreads();
-    if (lane < 6 * nact) {
-      const int a = lane / 6, k = lane % 6, lk = ar.act[a];
-      double col[NL];
+    static_assert(kMaxActive * NL * 6 <= 64 * 8, "Y fits the stage area");
+    {
+      double LM[T::NTRI];
 #pragma unroll
-      for (int j = 0; j < NL; ++j) col[j] = is_anc<T>(j, lk) ? st.S(j, k) : 0.0;
-      ldl_solve<NL>(LM, col);
+      for (int i = 0; i < NL; ++i)
 #pragma unroll
-      for (int j = 0; j < NL; ++j) Y[a][j][k] = col[j];
+        for (int j = 0; j <= i; ++j) LM[tri(i, j)] = st.M(i, j);
+      ldl_factor<NL>(LM);
+      if (lane < 6 * nact) {
+        const int a = lane / 6, k = lane % 6, lk = ar.act[a];
+        double col[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) col[j] = is_anc<T>(j, lk) ? st.S(j, k) : 0.0;
+        ldl_solve<NL>(LM, col);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) Y[a][j][k] = col[j];
+      }
     }
     __syncthreads();
-    // change of every body's spatial acceleration per unit wrench on body `src` (a link in contact, or the box):
-    // dU_b = S_b M^-1 S_src' w.  apply_wrench adds it to ar.U for wrench w (LDS, 6 doubles), sign +1 on B, -1 on A.
-    double* dw = ar.Gd;  // 6 doubles: the wrench change being broadcast; [8..] bodies
-    auto push = [&](int A_, int B_) {
-      // robot part: dx = Y_B dw - Y_A dw (lane j < NL), then links add sum_j S_j dx_j; box part: closed form
-      if (lane < NL) {
-        double dx = 0;
-        for (int a = 0; a < nact; ++a) {
-          const int lk = ar.act[a];
-          const double sgn = lk == B_ ? 1.0 : (lk == A_ ? -1.0 : 0.0);
-          if (sgn == 0.0) continue;
-          double s = 0;
+    // response of the bodies' accelerations to a wrench w on body B and -w on body A, as seen by the pair itself:
+    // rel = dU_B - dU_A (every lane for its own contact, no exchange)
+    int aA = -1, aB = -1;
+    for (int a = 0; a < nact; ++a) {
+      if (ar.act[a] == c.A) aA = a;
+      if (ar.act[a] == c.B) aB = a;
+    }
+    const bool boxed = c.A == kBox || c.B == kBox;
+    auto pair_response = [&](const double* w, double* rel) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) s += Y[a][lane][k] * dw[k];
-          dx += sgn * s;
-        }
-        ar.P[lane] = dx;
-      } else if (lane < NV) {
-        // box dofs: dx = M_box^-1 S_box' (+-dw)
-        const int k = lane - NL;
-        const double sgn = B_ == kBox ? 1.0 : (A_ == kBox ? -1.0 : 0.0);
-        double q;
-        if (k < 3) q = dw[3 + k];
-        else {
-          const double re[3] = {bR[k - 3], bR[3 + k - 3], bR[6 + k - 3]};
-          double c[3];
-          cross3(bp, re, c);
-          q = re[0] * dw[0] + re[1] * dw[1] + re[2] * dw[2] + c[0] * dw[3] + c[1] * dw[4] + c[2] * dw[5];
-        }
-        ar.P[lane] = sgn * Mbi[k] * q;
-      }
-      __syncthreads();
-      body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
-      __syncthreads();
-      if (lane < NB - 1) {
+      for (int k = 0; k < 6; ++k) rel[k] = 0.0;
+      if (aA >= 0 || aB >= 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ar.U[lane][k] += ar.Up[lane][k];
+        for (int j = 0; j < NL; ++j) {
+          const double sg = (c.B < NL && is_anc<T>(j, c.B) ? 1.0 : 0.0) - (c.A < NL && is_anc<T>(j, c.A) ? 1.0 : 0.0);
+          if (sg == 0.0) continue;
+          double dx = 0;
+          if (aB >= 0) dx += dot6(Y[aB][j], w);
+          if (aA >= 0) dx -= dot6(Y[aA][j], w);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) rel[k] += sg * st.S(j, k) * dx;
+        }
       }
-      __syncthreads();
+      if (boxed) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          double col[6];
+          box_column(bR, bp, k, col);
+          const double q = Mbi[k] * dot6(col, w);
+#pragma unroll
+          for (int m = 0; m < 6; ++m) rel[m] += col[m] * q;
+        }
+      }
     };
-    // the 2 x 2 friction block of A = J M^-1 J' (no regulariser) of every contact: response of the own rows to unit
-    // forces along the two tangents -- computed contact by contact with the same machinery (ncon pushes of a probe wrench)
+    // the 3 x 3 block of A = J M^-1 J' (no regulariser) of the lane's own contact
     double Ac[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Ac[r][c] = 0.0;
-    {
-      // save U (the accelerations at the Newton solution) in V: velocities are no longer needed
-      if (lane < NB) {
+      for (int k = 0; k < 3; ++k) Ac[r][k] = 0.0;
+    if (c.on) {
+      for (int kk = 0; kk < 3; ++kk) {
+        double rel[6];
+        pair_response(c.G[kk], rel);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ar.V[lane][k] = ar.U[lane][k];
+        for (int r = 0; r < 3; ++r) Ac[r][kk] = dot6(c.G[r], rel);
       }
-      __syncthreads();
-      for (int c = 0; c < ncon; ++c) {
-        const int cc = ar.cb[c], A_ = cc & 0xff, B_ = (cc >> 8) & 0xff;
-        for (int kk = 0; kk < 3; ++kk) {
-          if (lane < NB) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ar.U[lane][k] = 0.0;
-          }
-          if (lane == c) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dw[k] = G[kk][k];
-          }
-          __syncthreads();
-          push(A_, B_);
-          if (lane == c) {
-            double rel[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) rel[k] = ar.U[cB][k] - ar.U[cA][k];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) Ac[r][kk] = dot6(G[r], rel);
-          }
-          __syncthreads();
-        }
-      }
-      if (lane < NB) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ar.U[lane][k] = ar.V[lane][k];
-      }
-      __syncthreads();
     }
+    TEAM_MARK(30)
+    double* dw = ar.Gd;  // the wrench change of the contact being updated, broadcast through LDS
     int iter = 0;
     while (iter < b.noslip_iterations) {
+      TEAM_COUNT(36)
       double improvement = 0;
       if (iter == 0) {
-        double s = on ? 0.5 * (f[0] * f[0] * Rr[0] + f[1] * f[1] * Rr[1] + f[2] * f[2] * Rr[2]) : 0.0;
+        double s = c.on ? 0.5 * (c.f[0] * c.f[0] * c.Rr[0] + c.f[1] * c.f[1] * c.Rr[1] + c.f[2] * c.f[2] * c.Rr[2]) : 0.0;
         if (lane < NL) {
           const double sgn = st.limS(lane);
           if (sgn != 0.0) {
@@ -1281,23 +1343,23 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
         }
         improvement = wave_sum(s);
       }
-      for (int c = 0; c < ncon; ++c) {
-        const int cc = ar.cb[c], A_ = cc & 0xff, B_ = (cc >> 8) & 0xff;
+      for (int cc = 0; cc < ncon; ++cc) {
+        const int code = ar.cb[cc], A_ = code & 0xff, B_ = (code >> 8) & 0xff;
         double change = 0;
-        if (lane == c) {
-          double rel[6], res[3], old[3] = {f[0], f[1], f[2]};
+        if (lane == cc) {
+          double rel[6], res[3], old[3] = {c.f[0], c.f[1], c.f[2]};
 #pragma unroll
-          for (int k = 0; k < 6; ++k) rel[k] = ar.U[cB][k] - ar.U[cA][k];
+          for (int k = 0; k < 6; ++k) rel[k] = ar.U[c.B][k] - ar.U[c.A][k];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) res[k] = dot6(G[k], rel) - aref[k];
+          for (int k = 0; k < 3; ++k) res[k] = dot6(c.G[k], rel) - c.aref[k];
           double nf[3] = {old[0], old[1], old[2]};
           if (old[0] < kMinVal) {
             nf[0] = nf[1] = nf[2] = 0;
           } else {
             const double b1 = res[1] - Ac[1][1] * old[1] - Ac[1][2] * old[2], b2 = res[2] - Ac[2][1] * old[1] - Ac[2][2] * old[2];
             double vv[2];
-            if (qcqp2_dev(vv, Ac[1][1], Ac[1][2], Ac[2][2], b1, b2, fr, fr, old[0])) {
-              double s = vv[0] * vv[0] / (fr * fr) + vv[1] * vv[1] / (fr * fr);
+            if (qcqp2_dev(vv, Ac[1][1], Ac[1][2], Ac[2][2], b1, b2, c.fr, c.fr, old[0])) {
+              double s = vv[0] * vv[0] / (c.fr * c.fr) + vv[1] * vv[1] / (c.fr * c.fr);
               s = sqrt(old[0] * old[0] / (s > kMinVal ? s : kMinVal));
               vv[0] *= s; vv[1] *= s;
             }
@@ -1312,12 +1374,36 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
           }
           if (change > 1e-10) { nf[0] = old[0]; nf[1] = old[1]; nf[2] = old[2]; change = 0; }
 #pragma unroll
-          for (int k = 0; k < 6; ++k) dw[k] = G[0][k] * (nf[0] - old[0]) + G[1][k] * (nf[1] - old[1]) + G[2][k] * (nf[2] - old[2]);
-          f[0] = nf[0]; f[1] = nf[1]; f[2] = nf[2];
+          for (int k = 0; k < 6; ++k) dw[k] = c.G[0][k] * (nf[0] - old[0]) + c.G[1][k] * (nf[1] - old[1]) + c.G[2][k] * (nf[2] - old[2]);
+          c.f[0] = nf[0]; c.f[1] = nf[1]; c.f[2] = nf[2];
         }
         __syncthreads();
-        push(A_, B_);
-        improvement -= lane_get(change, c);
+        // push the wrench change into the accelerations: dx = (Y_B - Y_A) dw on the robot's dofs (lane j), M_box^-1 S_box' dw on the box's
+        if (lane < NL) {
+          double dx = 0;
+          for (int a = 0; a < nact; ++a) {
+            const int lk = ar.act[a];
+            const double sgn = lk == B_ ? 1.0 : (lk == A_ ? -1.0 : 0.0);
+            if (sgn == 0.0) continue;
+            dx += sgn * dot6(Y[a][lane], dw);
+          }
+          ar.P[lane] = dx;
+        } else if (lane < NV) {
+          const int k = lane - NL;
+          const double sgn = B_ == kBox ? 1.0 : (A_ == kBox ? -1.0 : 0.0);
+          double col[6];
+          box_column(bR, bp, k, col);
+          ar.P[lane] = sgn * Mbi[k] * dot6(col, dw);
+        }
+        __syncthreads();
+        body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
+        __syncthreads();
+        if (lane < NB - 1) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ar.U[lane][k] += ar.Up[lane][k];
+        }
+        __syncthreads();
+        improvement -= lane_get(change, cc);
       }
       improvement *= b.scale;
       ++iter;
@@ -1325,10 +1411,10 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     }
     __syncthreads();
   }
-
-  // ================================================================= results: qfrc_constraint of the robot, qacc of the box
+  TEAM_MARK(31)
+  // ---- results: qfrc_constraint of the robot, qacc of the box
   {
-    const double qf = contact_qfrc(f);
+    const double qf = contact_qfrc<T>(ar, st, c, c.f, ncon, bR, bp, lane);
     if (lane < NL) {
       double fc = qf;
       const double sgn = st.limS(lane);
@@ -1348,7 +1434,21 @@ __device__ __noinline__ uint32_t contact_phase(const ContactTable& tab, const Bo
     }
   }
   __syncthreads();
-  return 1u | (hit << 8);
+  TEAM_MARK(32)
+}
+
+// The contact phase of one environment, executed by the whole wavefront.  `st` / `bs`: the environment's LDS blocks
+// (robot: pre-step q, qd, motion axes S, mass matrix, qfrc_smooth, limit / equality rows of this substep; box: state).
+// Returns bit 0: coupled (a robot geom is in contact: st.fcon holds the robot's constraint force, bs[kBoxA..] the box's
+// acceleration); bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
+template <class T>
+RCSH_D uint32_t contact_phase(const ContactTable& tab, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
+                              ContactArena<T>& ar, const double* gravity) {
+  const uint32_t r = contact_collide<T>(tab, b, links, st, bs, ar);
+  if (!(r & 1u) || !b.resolve) return r & ~1u;
+  contact_newton<T>(b, st, bs, ar, gravity);
+  contact_noslip<T>(b, st, bs, ar);
+  return r;
 }
 
 #endif  // __HIP__

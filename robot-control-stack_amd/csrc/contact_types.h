@@ -16,7 +16,7 @@ struct ContactGeom {
   int32_t vert_adr, vert_num;
   int32_t geom_id;       // mjModel geom id
   int32_t plane_ok;      // the (floor, geom) pair passes MuJoCo's filters
-  int32_t pad;
+  int32_t box_slot;      // box geoms: index among the box geoms (LDS slot of the collider's clipping polygons)
   double pos[3], rot[9]; // geom frame in the link frame
   double size[3];
   double center[3];      // hull: an interior point (vertex mean), geom frame

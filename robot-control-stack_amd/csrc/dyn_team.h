@@ -83,8 +83,8 @@ struct StageTeam {
 #ifdef RCSH_PHASE_TIMING
 // Development instrumentation (tools/team_timing.py): cycle counter deltas between marks, accumulated in LDS by lane
 // 0 of workgroup 0 (an LDS round trip per mark, ~100 cycles) and flushed to global memory once per launch.
-__device__ unsigned long long g_team_cycles[24];
-__shared__ unsigned long long s_team_cycles[24];
+__device__ unsigned long long g_team_cycles[48];
+__shared__ unsigned long long s_team_cycles[48];
 __shared__ unsigned long long s_team_mark;
 #define TEAM_MARK(idx)                                            \
   if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
@@ -96,12 +96,12 @@ __shared__ unsigned long long s_team_mark;
   if (blockIdx.x == 0 && threadIdx.x == 0) s_team_cycles[idx] += 1;
 #define TEAM_CLOCK_START()                                        \
   if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
-    for (int k_ = 0; k_ < 24; ++k_) s_team_cycles[k_] = 0;        \
+    for (int k_ = 0; k_ < 48; ++k_) s_team_cycles[k_] = 0;        \
     s_team_mark = __builtin_readcyclecounter();                   \
   }
 #define TEAM_CLOCK_FLUSH()                                        \
   if (blockIdx.x == 0 && threadIdx.x == 0)                        \
-    for (int k_ = 0; k_ < 24; ++k_) g_team_cycles[k_] += s_team_cycles[k_];
+    for (int k_ = 0; k_ < 48; ++k_) g_team_cycles[k_] += s_team_cycles[k_];
 #else
 #define TEAM_MARK(idx)
 #define TEAM_COUNT(idx)
@@ -454,7 +454,7 @@ RCSH_D bool team_gc_is_mass(const LinkRec* links, int t) {
 struct SubstepK {
   double h, gravity[3], grp_c0, grp_c1;
   int32_t site_link, eq_active;
-  RCSH_D void load(const DevModel& m) {
+  RCSH_D void load(const DevModelHead& m) {
     h = m.timestep;
     gravity[0] = m.gravity[0]; gravity[1] = m.gravity[1]; gravity[2] = m.gravity[2];
     grp_c0 = m.grp_coef[0]; grp_c1 = m.grp_coef[1];
@@ -475,7 +475,7 @@ struct SubstepK {
 // whole team) when the contact phase solved the step's constraints itself (contact_team.h: st.fcon then holds
 // qfrc_constraint), which leaves only the implicit solve and the integration to this function.
 template <class T, bool FRIC, class FrameFn, class PreSolveFn>
-RCSH_D void team_substep(const DevModel& m, const SubstepK& sk, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping,
+RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping,
                          bool gc_is_mass, FrameFn&& on_frame, PreSolveFn&& pre_solve) {
   static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");

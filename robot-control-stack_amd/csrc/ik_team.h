@@ -22,7 +22,7 @@ struct IkTeamBlock {
 };
 
 // desired site placement in world coordinates for a TCP target in robot coordinates: base * (target * tcp^-1)
-RCSH_D void clik_desired(const DevModel& m, const Pose& target, const Pose& tcp, double* Rd, double* td) {
+RCSH_D void clik_desired(const DevModelHead& m, const Pose& target, const Pose& tcp, double* Rd, double* td) {
   Pose tinv, des_r, base, des;
   pose_inverse(tcp, tinv);
   pose_mul(target, tinv, des_r);
@@ -122,7 +122,7 @@ RCSH_D void se3_log_and_jlog_inverse(const double* R, const double* p, double* e
 // world placement of the site (same values on all lanes of the team); q: lane t's joint angle, in / out.
 // Returns success (uniform within the team); *iterations as Pin::inverse counts them.
 template <class T>
-RCSH_D bool clik_team(const DevModel& m, const LinkRec* links, IkTeamBlock<T>& blk, int t, bool run, const double* Rd,
+RCSH_D bool clik_team(const DevModelHead& m, const LinkRec* links, IkTeamBlock<T>& blk, int t, bool run, const double* Rd,
                       const double* td, double& q, int* iterations) {
   constexpr int NA = T::NARM;
   const bool joint = t < NA;

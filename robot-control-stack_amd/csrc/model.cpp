@@ -542,6 +542,12 @@ std::string build_contact_table(const HostModel& h, const DevModel& m, int plane
     cg.link = owner[b];
     cg.type = type;
     cg.geom_id = g;
+    if (type == 6) {
+      int nbox = 0;
+      for (const auto& o : geoms) nbox += o.type == 6;
+      if (nbox >= 10) return "too many box geoms for the contact phase";
+      cg.box_slot = nbox;
+    }
     cg.vert_adr = h.geom_vertadr[g];
     cg.vert_num = type == 7 ? h.geom_vertnum[g] : 0;
     const Xf t = xf_mul(rel[b], xf_from(&h.geom_pos[3 * g], &h.geom_quat[4 * g]));

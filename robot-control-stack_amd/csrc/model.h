@@ -30,20 +30,52 @@ struct Imp {
 
 // All members are wave-uniform in the kernels.  Fixed maximum sizes keep the struct a POD that is
 // copied to HBM once per GPU (a few KB); kernels template on the real sizes.
-struct DevModel {
+//
+// DevModelHead: everything that is NOT per link (options, qpos0, the gripper's tendon actuator and coupling equality, the
+// frames SimRobot reads).  The team kernels keep only this part in LDS -- their per-link constants are the LinkRec records
+// below -- which leaves the rest of a workgroup's 40 KB share of the CU's LDS to the contact phase (contact_team.h).
+struct DevModelHead {
   int32_t nl;    // links == dofs
   int32_t narm;  // arm dofs; a gripper (if any) occupies dofs narm, narm+1
   int32_t has_gripper;
   int32_t pad0;
   double timestep;
   double gravity[3];
+  double qpos0[kMaxLinks];
+  // ---- gripper: tendon actuator (ctrl slot narm) over the two finger dofs + coupling equality
+  int32_t grp_has_act;
+  int32_t grp_biasaffine;
+  int32_t grp_ctrllimited;
+  int32_t grp_forcelimited;
+  double grp_coef[2];  // moment of the actuator on finger dofs (gear * tendon coefficients)
+  double grp_gain;
+  double grp_bias[3];
+  double grp_ctrlrange[2];
+  double grp_forcerange[2];
+  int32_t eq_active;
+  int32_t pad1;
+  double eq_polycoef[5];
+  Imp eq_imp;
+  double eq_K, eq_B;
+  // ---- frames read by SimRobot
+  int32_t site_link;  // link carrying the attachment site (-1: static)
+  int32_t pad2;
+  double site_pos[3];
+  double site_rot[9];
+  double base_pos[3];   // world pose of the robot base body (static)
+  double base_quat[4];  // wxyz
+  int32_t has_friction;  // any fl_floss > 0
+  int32_t pad3;
+};
+static_assert(sizeof(DevModelHead) % 8 == 0, "staged into LDS in 8-byte words");
+
+struct DevModel : DevModelHead {
   // ---- link tree (link i's parent is i-1 for the arm; both fingers hang off link narm-1)
   double pos0[kMaxLinks][3];   // origin of link frame in parent link frame at q = qpos0
   double rot0[kMaxLinks][9];   // parent-link <- link rotation at q = qpos0 (row-major)
   double axis[kMaxLinks][3];   // joint axis, link frame
   double jpos[kMaxLinks][3];   // joint anchor, link frame
   int32_t jtype[kMaxLinks];
-  double qpos0[kMaxLinks];
   // composite inertial of the link with everything welded to it, link frame
   double mass[kMaxLinks];
   double com[kMaxLinks][3];
@@ -74,40 +106,17 @@ struct DevModel {
   double arm_ctrlrange[kMaxArm][2];
   int32_t arm_forcelimited[kMaxArm];
   double arm_forcerange[kMaxArm][2];
-  // ---- gripper: tendon actuator (ctrl slot narm) over the two finger dofs + coupling equality
-  int32_t grp_has_act;
-  int32_t grp_biasaffine;
-  int32_t grp_ctrllimited;
-  int32_t grp_forcelimited;
-  double grp_coef[2];  // moment of the actuator on finger dofs (gear * tendon coefficients)
-  double grp_gain;
-  double grp_bias[3];
-  double grp_ctrlrange[2];
-  double grp_forcerange[2];
-  int32_t eq_active;
-  int32_t pad1;
-  double eq_polycoef[5];
-  Imp eq_imp;
-  double eq_K, eq_B;
   int32_t axis_z[kMaxLinks];    // joint axis is +z and the anchor is the link origin (every FR3 / xArm7 hinge)
   int32_t gc_same_com[kMaxLinks];  // gccom == com (uniform gravcomp over the welded bodies)
-  // ---- frames read by SimRobot
-  int32_t site_link;  // link carrying the attachment site (-1: static)
-  int32_t pad2;
-  double site_pos[3];
-  double site_rot[9];
-  double base_pos[3];   // world pose of the robot base body (static)
-  double base_quat[4];  // wxyz
   // ---- dry joint friction (dof_frictionloss): one soft row per joint with a Huber cost.  The row's position is 0,
   // so its regulariser is a model constant: D = 1/R, R = (1 - imp(0)) / imp(0) * invweight0; aref = -B * qvel
-  int32_t has_friction;  // any fl_floss > 0
-  int32_t pad3;
   double fl_floss[kMaxLinks];
   double fl_D[kMaxLinks];
   double fl_B[kMaxLinks];
   double fl_R[kMaxLinks];  // half-width of the quadratic zone: frictionloss / D
   double inertia_diag_sum;  // trace of M(qpos0) (host side: mjModel.stat.meaninertia of scenes with free bodies)
 };
+static_assert(sizeof(DevModel) % 8 == 0, "copied in 8-byte words");
 
 // Per-link constants of the team kernels (dyn_team.h, ik_team.h) as an array of structures: lane t reads link t's
 // record through ONE base address with immediate offsets, and neighbouring fields merge into 16-byte LDS reads -- with

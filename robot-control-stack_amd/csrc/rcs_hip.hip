@@ -1245,6 +1245,10 @@ extern "C" int rcsh_debug_team_cycles(unsigned long long* out16 /* 24 slots */) 
   hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : 1;
 }
+extern "C" int rcsh_debug_team_cycles48(unsigned long long* out48) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : 1;
+}
 #endif
 
 int rcsh_debug_dump_model(rcsh_sim* s, void* buf, size_t cap, size_t* size) {

@@ -296,7 +296,7 @@ __device__ __noinline__ uint32_t plane_contacts(const DevModel& m, const Params&
 // Contacts: plane (floor) against the collision geoms only; geom-geom pairs are not detected in this revision.
 // `contacts()` returns the plane-contact classes of the last position stage (bit 0 arm geoms, bit 1 gripper geoms).
 template <class T, class ST, class HitFn>
-__device__ __forceinline__ bool condition_callbacks(const DevModel& m, const Params& P, EnvRegs<T, ST>& r, HitFn&& contacts) {
+__device__ __forceinline__ bool condition_callbacks(const DevModelHead& m, const Params& P, EnvRegs<T, ST>& r, HitFn&& contacts) {
   const bool has_g = T::GRIP && P.grip.present;
   const bool fire_r = P.robot.present && r.time - r.cb(2) > P.robot.period;
   const bool fire_g = has_g && r.time - r.cb(3) > P.grip.period;
@@ -354,7 +354,7 @@ __device__ __forceinline__ void gripper_set_width(const Params& P, EnvRegs<T, ST
 }
 
 // SimRobot::get_cartesian_position, reference src/sim/SimRobot.cpp:114-121 + src/rcs/Robot.cpp:5-9
-__device__ __forceinline__ void cartesian_position(const DevModel& m, const RobotCfg& rc, const double* linkR,
+__device__ __forceinline__ void cartesian_position(const DevModelHead& m, const RobotCfg& rc, const double* linkR,
                                                    const double* linkP, Pose& out) {
   double sp[3], sR[9];
   mulmv(linkR, m.site_pos, sp);
@@ -409,7 +409,7 @@ struct StepInStaged {
 // Wrappers' reset() / action() side effects on one environment: everything env.reset() / env.step() do before
 // the simulator is stepped (reference python/rcs/envs/base.py, envs/sim.py; see the inline citations).
 template <class T, class ST, class In>
-__device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, const DevModel& m, int e, EnvRegs<T, ST>& r, const In& in) {
+__device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, const DevModelHead& m, int e, EnvRegs<T, ST>& r, const In& in) {
   using L = Lay<T>;
   const int n = P.n;
   if (op.do_reset) {
@@ -487,7 +487,7 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
 // After stepping: park the site frame, refresh the relative-action origin on reset, write the state back and
 // produce observation + info (RobotEnv.get_obs, GripperWrapper.observation, RobotSimWrapper.step, GripperWrapperSim).
 template <class T, class ST, bool kStoreStaged = true>
-__device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, const DevModel& m, int e, EnvRegs<T, ST>& r,
+__device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, const DevModelHead& m, int e, EnvRegs<T, ST>& r,
                                              const ST& st, bool have_frames, int nsteps) {
   using L = Lay<T>;
   const int n = P.n;
@@ -627,25 +627,15 @@ __global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
   env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
 }
 
-// Stages the model into a workgroup's LDS for the team kernels (64 threads).  Of the DevModel only what is not per link
-// is read there: options, gripper + coupling constants, site / base frames -- and qpos0 (Sim::reset); the per-link
-// tables are superseded by the LinkRec records stored right behind it.  Four ranges, 67 of its 802 words: every
-// workgroup of the launch fetches these same lines from L2 at the same moment.
+// Stages the model into a workgroup's LDS for the team kernels (64 threads): the DevModelHead (what is not per link) and the
+// per-link LinkRec records stored right behind the DevModel.  Every workgroup of the launch fetches these same lines from
+// L2 at the same moment.
 template <int NREC>
-__device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModel& lm, LinkRec* llinks) {
-  constexpr int kWords = sizeof(DevModel) / 8;
+__device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModelHead& lm, LinkRec* llinks) {
+  constexpr int kWords = sizeof(DevModel) / 8, kHeadWords = sizeof(DevModelHead) / 8;
   const double* src = reinterpret_cast<const double*>(gm);
   double* dst = reinterpret_cast<double*>(&lm);
-  constexpr int kRange[4][2] = {{0, (int)offsetof(DevModel, pos0) / 8},
-                                {(int)offsetof(DevModel, qpos0) / 8, (int)offsetof(DevModel, mass) / 8},
-                                {(int)offsetof(DevModel, grp_has_act) / 8, (int)offsetof(DevModel, axis_z) / 8},
-                                {(int)offsetof(DevModel, site_link) / 8, (int)offsetof(DevModel, fl_floss) / 8}};
-  static_assert(offsetof(DevModel, pos0) % 8 == 0 && offsetof(DevModel, qpos0) % 8 == 0 && offsetof(DevModel, mass) % 8 == 0 &&
-                offsetof(DevModel, grp_has_act) % 8 == 0 && offsetof(DevModel, axis_z) % 8 == 0 &&
-                offsetof(DevModel, site_link) % 8 == 0 && offsetof(DevModel, fl_floss) % 8 == 0, "ranges copied in 8-byte words");
-#pragma unroll
-  for (int rg = 0; rg < 4; ++rg)
-    for (int k = kRange[rg][0] + threadIdx.x; k < kRange[rg][1]; k += 64) dst[k] = src[k];
+  for (int k = threadIdx.x; k < kHeadWords; k += 64) dst[k] = src[k];
   constexpr int kRecWords = sizeof(LinkRec) * NREC / 8;
   double* rdst = reinterpret_cast<double*>(llinks);
 #pragma unroll
@@ -662,7 +652,7 @@ template <class T, bool FRIC, bool BOX = false>
 __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
-  __shared__ DevModel lm;
+  __shared__ DevModelHead lm;
   // The kernel arguments move to LDS too.  As arguments they sit in ~100 SGPRs that the leader-only code (wrappers,
   // callbacks, observation) keeps alive across the whole substep loop, and the loop then spills and reloads them
   // around its own scalar needs every iteration; from LDS they are read where that rare code runs.  (The
@@ -738,7 +728,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     __syncthreads();
   }
   TEAM_MARK(12)
-  const DevModel& m = lm;
+  const DevModelHead& m = lm;
   const ST st{lds + team * ST::COUNT};
   EnvRegs<T, ST> r;  // meaningful on the leader only
   r.st = st;
@@ -863,7 +853,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
         if (nearw) {
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
-            const uint32_t r = contact_phase<T>(lp.ctab, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity, timestep);
+            const uint32_t r = contact_phase<T>(lp.ctab, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity);
             if (team == k) {
               coupled = r & 1u;
               hit |= (r >> 8) & 3u;
@@ -1019,7 +1009,7 @@ __device__ __forceinline__ void store_pose7(double* S, int n, int e, int field0,
 // whether a new target is commanded and, if so, the TCP target in robot coordinates.  env_layer 0: the bare
 // SimRobot::set_cartesian_position target.
 template <class T>
-__device__ __forceinline__ bool cart_prepare(const Params& P, const CartOp& op, const DevModel& m, int e, uint32_t& flags, Pose& target) {
+__device__ __forceinline__ bool cart_prepare(const Params& P, const CartOp& op, const DevModelHead& m, int e, uint32_t& flags, Pose& target) {
   using L = Lay<T>;
   const int n = P.n;
   double* S = P.S;
@@ -1145,7 +1135,7 @@ template <class T>
 __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
   using L = Lay<T>;
   constexpr int kTeams = 64 / kTeamLanes;
-  __shared__ DevModel lm;
+  __shared__ DevModelHead lm;
   __shared__ LinkRec llinks[T::NARM];
   __shared__ IkTeamBlock<T> blocks[kTeams];
   __shared__ double desired[kTeams][12];
@@ -1153,7 +1143,7 @@ __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
     stage_team_model<T::NARM>(P.model, lm, llinks);
     __syncthreads();
   }
-  const DevModel& m = lm;
+  const DevModelHead& m = lm;
   const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
   const int per_xcd = gridDim.x / 8;  // XCD-contiguous environment ranges, as in k_run_team
   const int e = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * kTeams + team;
