@@ -227,9 +227,24 @@ def main() -> None:
     info = torch.zeros((n, 8), device="cuda", dtype=torch.uint8)
     gw = torch.zeros((n,), device="cuda", dtype=torch.float64)
     sub = torch.zeros((n,), device="cuda", dtype=torch.int32)
-    from rcs_amd.envs.sharding import ObservationExchange
+    # the one exchange of the sharded rollout: all-gather of the observation tensor.  Measured configuration: RCCL behind the
+    # C-ABI (no host framework on the data path); --dist-backend gloo: the same protocol over torch.distributed, to exercise
+    # the N > 1 code path on a box with fewer GPUs than ranks.  (torch.distributed stays for rendezvous, barrier and the
+    # max-over-ranks of the timing -- plumbing.)
+    exchange = None
+    if world > 1 and args.dist_backend == "nccl":
+        from rcs_amd.envs.sharding import RcclObservationExchange, comm_unique_id
 
-    exchange = ObservationExchange(n, ow, torch.float64, "cuda") if world > 1 else None
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        exchange = RcclObservationExchange(env.sim, bytes(uid.cpu().numpy().tobytes()), rank, world)
+    elif world > 1:
+        from rcs_amd.envs.sharding import ObservationExchange
+
+        exchange = ObservationExchange(n, ow, torch.float64, "cuda")
+    rccl_exchange = exchange is not None and args.dist_backend == "nccl"
 
     episode = args.episode_length if args.episode_length is not None else (10 if args.control == "cartesian" else 0)
 
@@ -264,11 +279,11 @@ def main() -> None:
     def one_step(t: int) -> None:
         if episode and t % episode == 0:
             do_reset(t)
-        o = exchange.local(t) if exchange else obs
+        optr = (exchange.local_ptr(t) if rccl_exchange else exchange.local(t).data_ptr()) if exchange else obs.data_ptr()
         if task_out is not None:
-            env.step_task_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr(), task_out.data_ptr())
+            env.step_task_dev(joints[t].data_ptr(), grip[t].data_ptr(), optr, info.data_ptr(), gw.data_ptr(), sub.data_ptr(), task_out.data_ptr())
         else:
-            env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), o.data_ptr(), info.data_ptr(), gw.data_ptr(), sub.data_ptr())
+            env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), optr, info.data_ptr(), gw.data_ptr(), sub.data_ptr())
         for c, buf in cam_out.items():
             cam_set.render_depth_mm_dev(c, buf.data_ptr())
         if exchange:
@@ -293,11 +308,13 @@ def main() -> None:
             substeps_total += 0  # per-step counts stay on the device; read once after the timed region
     if exchange:
         exchange.drain()
-        obs = exchange.gathered(T - 1)[rank * n:(rank + 1) * n]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if exchange:  # (after the clock stopped) this rank's rows of the last gathered tensor: finiteness check below
+        g = exchange.gathered(T - 1)
+        obs = (torch.from_numpy(g).cuda() if rccl_exchange else g)[rank * n:(rank + 1) * n]
     if world > 1:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -355,7 +372,8 @@ def main() -> None:
                 "episode_length": episode or None,
                 "depth_frames": (f"{args.cameras} at {args.resolution}, one ray-cast uint16 frame per camera per env-step "
                                  f"({len(cam_out) * n * int(args.resolution.split('x')[0]) * int(args.resolution.split('x')[1]) / (elapsed / args.steps) / 1e9:.2f} G rays/s incl. the physics)") if cam_out else None,
-                "exchange": (("RCCL" if args.dist_backend == "nccl" else args.dist_backend) + f" all-gather of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
+                "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if args.dist_backend == "nccl" else f"torch.distributed {args.dist_backend} all_gather")
+                             + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
             },
             "roofline": {

@@ -360,6 +360,24 @@ int rcsh_sim_add_camera(rcsh_sim* sim, const rcsh_camera_desc* cam, int32_t* cam
 int rcsh_camera_render(rcsh_sim* sim, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose);
 int rcsh_camera_render_dev(rcsh_sim* sim, int32_t cam_id, float* depth_gl_dev, uint16_t* depth_mm_dev, double* cam_pose_dev);
 
+/* ---- multi-GPU: one process (one handle) per GPU, contiguous ranges of environments per rank, no data-path collective
+ * except ONE exchange step: the all-gather of the observation tensor [n][obs_width] f64 of every rank into
+ * [world * n][obs_width] on every GPU (the reference holds one model / data pair per Sim, src/sim/sim.h:75-77,
+ * and has nothing to exchange).  RCCL (librccl.so, loaded on first use) over xGMI; no host framework involved:
+ *   rank 0: rcsh_comm_get_unique_id -> ship the 128 bytes to the other ranks by any side channel -> every rank:
+ *   rcsh_comm_init(sim, id, rank, world).
+ * rcsh_env_allgather_obs_dev is ordered after the work already enqueued on the handle's stream (an event) but runs on
+ * the communicator's OWN stream, so the next env-step overlaps it; the caller alternates two send / receive buffer pairs
+ * (`slot` 0 / 1) and calls rcsh_comm_wait(slot) before it reads that slot's gathered tensor or overwrites its send buffer. */
+#define RCSH_COMM_ID_BYTES 128
+int rcsh_comm_get_unique_id(uint8_t id[RCSH_COMM_ID_BYTES]);
+int rcsh_comm_init(rcsh_sim* sim, const uint8_t id[RCSH_COMM_ID_BYTES], int32_t rank, int32_t world);
+int rcsh_comm_rank(const rcsh_sim* sim, int32_t* rank, int32_t* world);
+int rcsh_env_allgather_obs_dev(rcsh_sim* sim, int32_t slot, const double* local_obs_dev, double* all_obs_dev);
+int rcsh_comm_allgather_dev(rcsh_sim* sim, int32_t slot, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+int rcsh_comm_wait(rcsh_sim* sim, int32_t slot, int32_t block_host); /* 0: the handle's stream waits for the slot's gather; 1: the host does */
+int rcsh_comm_destroy(rcsh_sim* sim);
+
 /* device allocation helpers so a host language without a HIP binding can keep rollouts resident */
 int rcsh_dev_alloc(rcsh_sim* sim, size_t bytes, void** ptr);
 int rcsh_dev_free(rcsh_sim* sim, void* ptr);

@@ -1,6 +1,8 @@
 // rcs_hip.hip -- C-ABI (include/rcs_hip.h) over the batched kernels.  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -89,6 +91,12 @@ struct rcsh_sim {
   uint8_t* d_mask = nullptr;   // n bytes
   int32_t* d_ints = nullptr;   // n ints
   float* d_floats = nullptr;   // n floats
+  // multi-GPU exchange (RCCL, loaded on first use)
+  void* comm = nullptr;            // ncclComm_t
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ready = nullptr, comm_done[2] = {nullptr, nullptr};
+  bool comm_pending[2] = {false, false};
+  int comm_rank = 0, comm_world = 1;
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev_start, ev_stop;
@@ -436,6 +444,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
+  if (s->comm) rcsh_comm_destroy(s);
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
@@ -1212,6 +1221,116 @@ int rcsh_camera_render(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* d
   if (depth_mm) HIP_TRY(hipMemcpyAsync(depth_mm, dmm, px * sizeof(uint16_t), hipMemcpyDeviceToHost, s->stream));
   if (cam_pose) HIP_TRY(hipMemcpyAsync(cam_pose, dpose, sizeof(double) * 12 * s->n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return RCSH_OK;
+}
+
+// ---- RCCL behind the C-ABI.  The library is dlopen'ed so that single-GPU users neither link nor load it.
+namespace {
+struct Rccl {
+  typedef struct { char internal[RCSH_COMM_ID_BYTES]; } UniqueId;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* lib = nullptr;
+  std::string why;
+};
+Rccl& rccl() {
+  static Rccl r;
+  if (r.lib || !r.why.empty()) return r;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.lib) break;
+  }
+  if (!r.lib) { r.why = std::string("librccl.so not loadable: ") + dlerror(); return r; }
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) r.why = "librccl.so lacks the collective entry points";
+  return r;
+}
+#define RCCL_TRY(expr)                                                                                             \
+  do {                                                                                                             \
+    const int _e = (expr);                                                                                         \
+    if (_e != 0) return fail(RCSH_ERR_DEVICE, std::string(#expr) + ": " + rccl().GetErrorString(_e));             \
+  } while (0)
+}  // namespace
+
+int rcsh_comm_get_unique_id(uint8_t id[RCSH_COMM_ID_BYTES]) {
+  if (!id) return fail(RCSH_ERR_ARG, "null id");
+  Rccl& r = rccl();
+  if (!r.why.empty()) return fail(RCSH_ERR_DEVICE, r.why);
+  Rccl::UniqueId u;
+  RCCL_TRY(r.GetUniqueId(&u));
+  std::memcpy(id, u.internal, RCSH_COMM_ID_BYTES);
+  return RCSH_OK;
+}
+
+int rcsh_comm_init(rcsh_sim* s, const uint8_t id[RCSH_COMM_ID_BYTES], int32_t rank, int32_t world) {
+  REQUIRE_SIM(s);
+  if (!id || world < 1 || rank < 0 || rank >= world) return fail(RCSH_ERR_ARG, "communicator: need an id and 0 <= rank < world");
+  if (s->comm) return fail(RCSH_ERR_STATE, "a communicator is already attached to this sim");
+  Rccl& r = rccl();
+  if (!r.why.empty()) return fail(RCSH_ERR_DEVICE, r.why);
+  Rccl::UniqueId u;
+  std::memcpy(u.internal, id, RCSH_COMM_ID_BYTES);
+  RCCL_TRY(r.CommInitRank(&s->comm, world, u, rank));
+  HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&s->comm_ready, hipEventDisableTiming));
+  for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&s->comm_done[k], hipEventDisableTiming));
+  s->comm_rank = rank;
+  s->comm_world = world;
+  return RCSH_OK;
+}
+
+int rcsh_comm_rank(const rcsh_sim* s, int32_t* rank, int32_t* world) {
+  if (!s) return fail(RCSH_ERR_ARG, "null sim handle");
+  if (rank) *rank = s->comm_rank;
+  if (world) *world = s->comm_world;
+  return RCSH_OK;
+}
+
+int rcsh_comm_allgather_dev(rcsh_sim* s, int32_t slot, const void* send_dev, void* recv_dev, size_t bytes_per_rank) {
+  REQUIRE_SIM(s);
+  if (!s->comm) return fail(RCSH_ERR_STATE, "no communicator: call rcsh_comm_init first");
+  if (!send_dev || !recv_dev) return fail(RCSH_ERR_ARG, "null buffer");
+  if (slot < 0 || slot > 1) return fail(RCSH_ERR_ARG, "exchange slot is 0 or 1");
+  // after what the handle's stream holds so far (the env-step that wrote the observations), on the communicator's stream
+  HIP_TRY(hipEventRecord(s->comm_ready, s->stream));
+  HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->comm_ready, 0));
+  RCCL_TRY(rccl().AllGather(send_dev, recv_dev, bytes_per_rank, /* ncclInt8 */ 0, s->comm, s->comm_stream));
+  HIP_TRY(hipEventRecord(s->comm_done[slot], s->comm_stream));
+  s->comm_pending[slot] = true;
+  return RCSH_OK;
+}
+
+int rcsh_env_allgather_obs_dev(rcsh_sim* s, int32_t slot, const double* local_obs_dev, double* all_obs_dev) {
+  REQUIRE_SIM(s);
+  return rcsh_comm_allgather_dev(s, slot, local_obs_dev, all_obs_dev, sizeof(double) * (size_t)s->n * (14 + s->narm));
+}
+
+int rcsh_comm_wait(rcsh_sim* s, int32_t slot, int32_t block_host) {
+  REQUIRE_SIM(s);
+  if (!s->comm) return fail(RCSH_ERR_STATE, "no communicator: call rcsh_comm_init first");
+  if (slot < 0 || slot > 1) return fail(RCSH_ERR_ARG, "exchange slot is 0 or 1");
+  if (!s->comm_pending[slot]) return RCSH_OK;
+  if (block_host) HIP_TRY(hipEventSynchronize(s->comm_done[slot]));
+  else HIP_TRY(hipStreamWaitEvent(s->stream, s->comm_done[slot], 0));
+  return RCSH_OK;
+}
+
+int rcsh_comm_destroy(rcsh_sim* s) {
+  REQUIRE_SIM(s);
+  if (!s->comm) return RCSH_OK;
+  hipStreamSynchronize(s->comm_stream);
+  rccl().CommDestroy(s->comm);
+  hipEventDestroy(s->comm_ready); hipEventDestroy(s->comm_done[0]); hipEventDestroy(s->comm_done[1]);
+  hipStreamDestroy(s->comm_stream);
+  s->comm = nullptr; s->comm_stream = nullptr; s->comm_ready = s->comm_done[0] = s->comm_done[1] = nullptr; s->comm_pending[0] = s->comm_pending[1] = false;
+  s->comm_rank = 0; s->comm_world = 1;
   return RCSH_OK;
 }
 

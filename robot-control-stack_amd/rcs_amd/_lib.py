@@ -151,6 +151,8 @@ EXPORTS = (
     "rcsh_env_configure_pick_task", "rcsh_env_reset_task", "rcsh_env_step_task", "rcsh_env_reset_task_dev", "rcsh_env_step_task_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
+    "rcsh_comm_get_unique_id", "rcsh_comm_init", "rcsh_comm_rank", "rcsh_env_allgather_obs_dev", "rcsh_comm_allgather_dev", "rcsh_comm_wait",
+    "rcsh_comm_destroy",
 )
 
 _lib = None
@@ -174,6 +176,12 @@ def load() -> C.CDLL:
     L.rcsh_sim_stream.restype = C.c_void_p
     L.rcsh_sim_stream.argtypes = [C.c_void_p]
     L.rcsh_sim_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rcsh_comm_get_unique_id.argtypes = [C.c_char_p]
+    L.rcsh_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
+    L.rcsh_env_allgather_obs_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.rcsh_comm_allgather_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rcsh_comm_wait.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.rcsh_comm_destroy.argtypes = [C.c_void_p]
     L.rcsh_sim_set_kernel.argtypes = [C.c_void_p, C.c_int32]
     L.rcsh_sim_state_bytes.restype = C.c_size_t
     L.rcsh_sim_state_bytes.argtypes = [C.c_void_p]

@@ -2,8 +2,13 @@
 
 Environments are independent (the reference holds exactly one mjModel/mjData pair per Sim, reference
 src/sim/sim.h:75-77), so the batch is split into contiguous env-id ranges, one range per rank, and nothing is
-exchanged on the data path except the observation tensor: one all-gather per env-step (RCCL over xGMI on GPUs,
-gloo in the CPU tests).
+exchanged on the data path except the observation tensor: one all-gather per env-step.
+
+Two carriers of that one exchange:
+  * :class:`RcclObservationExchange` -- RCCL over xGMI through the C-ABI (``rcsh_comm_*``): no host framework on the data
+    path, what a reference-side user of ``librcs_hip.so`` gets; the measured configuration of ``bench.py``;
+  * :class:`ObservationExchange` / :func:`gather_observations` -- the same double-buffered protocol over a
+    ``torch.distributed`` process group (gloo in the CPU tests, where there is no GPU to run RCCL on).
 """
 
 from __future__ import annotations
@@ -78,3 +83,73 @@ class ObservationExchange:
             if self._work[b] is not None:
                 self._work[b].wait()
                 self._work[b] = None
+
+
+def comm_unique_id() -> bytes:
+    """``rcsh_comm_get_unique_id``: 128 bytes rank 0 creates and ships to the other ranks over any side channel."""
+    import ctypes as C
+
+    from .. import _lib
+
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().rcsh_comm_get_unique_id(buf))
+    return buf.raw
+
+
+class RcclObservationExchange:
+    """The observation all-gather over RCCL behind the C-ABI, double-buffered and overlapped with the next env-step.
+
+    Same protocol as :class:`ObservationExchange`: step t writes into ``local_ptr(t)`` (slot t & 1), ``post(t)`` enqueues
+    the gather of that slot on the communicator's own stream (ordered after the env-step already on the sim's stream), the
+    env-step of t + 1 writes the other slot meanwhile; ``local_ptr(t + 2)`` makes the sim's stream wait for slot t's gather.
+    Buffers are device memory owned by this object (``rcsh_dev_alloc``); ``gathered(t)`` downloads to numpy for inspection,
+    ``gathered_ptr(t)`` is what a resident consumer reads.
+    """
+
+    def __init__(self, sim, unique_id: bytes, rank: int, world: int):
+        import ctypes as C
+
+        from .. import _lib
+
+        self._C, self._lib, self._L, self._h = C, _lib, _lib.load(), sim._h
+        self.rank, self.world = rank, world
+        self.n, self.width = sim.n_envs, int(self._L.rcsh_env_obs_width(sim._h))
+        _lib.check(self._L.rcsh_comm_init(self._h, unique_id, rank, world))
+        self._bytes = 8 * self.n * self.width
+        self._local, self._all = [], []
+        for _ in range(2):
+            for lst, size in ((self._local, self._bytes), (self._all, self._bytes * world)):
+                p = C.c_void_p()
+                _lib.check(self._L.rcsh_dev_alloc(self._h, size, C.byref(p)))
+                lst.append(p)
+
+    def local_ptr(self, t: int) -> int:
+        self._lib.check(self._L.rcsh_comm_wait(self._h, t & 1, 0))
+        return self._local[t & 1].value
+
+    def post(self, t: int) -> None:
+        self._lib.check(self._L.rcsh_env_allgather_obs_dev(self._h, t & 1, self._local[t & 1], self._all[t & 1]))
+
+    def gathered_ptr(self, t: int) -> int:
+        self._lib.check(self._L.rcsh_comm_wait(self._h, t & 1, 0))
+        return self._all[t & 1].value
+
+    def gathered(self, t: int):
+        import numpy as np
+
+        self._lib.check(self._L.rcsh_comm_wait(self._h, t & 1, 1))
+        out = np.zeros((self.world * self.n, self.width))
+        self._lib.check(self._L.rcsh_dev_download(self._h, out.ctypes.data_as(self._C.c_void_p), self._all[t & 1], self._bytes * self.world))
+        return out
+
+    def drain(self) -> None:
+        for b in (0, 1):
+            self._lib.check(self._L.rcsh_comm_wait(self._h, b, 1))
+
+    def close(self) -> None:
+        if self._h is not None:
+            self.drain()
+            for p in self._local + self._all:
+                self._L.rcsh_dev_free(self._h, p)
+            self._L.rcsh_comm_destroy(self._h)
+            self._h = None
