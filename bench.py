@@ -239,7 +239,20 @@ def main() -> None:
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
-        exchange = RcclObservationExchange(env.sim, bytes(uid.cpu().numpy().tobytes()), rank, world)
+        comm_error = ""
+        try:
+            exchange = RcclObservationExchange(env.sim, bytes(uid.cpu().numpy().tobytes()), rank, world)
+        except RuntimeError as exc:  # e.g. a communicator RCCL refuses on this topology
+            comm_error = str(exc)
+        okflag = torch.tensor([0 if comm_error else 1], device="cuda")
+        dist.all_reduce(okflag, op=dist.ReduceOp.MIN)  # every rank takes the same carrier
+        if int(okflag.item()) == 0:
+            if exchange is not None:
+                exchange.close()
+            from rcs_amd.envs.sharding import ObservationExchange
+
+            exchange = ObservationExchange(n, ow, torch.float64, "cuda")
+            args.dist_backend = "nccl (torch.distributed process group; the C-ABI communicator could not be created: " + (comm_error or "on another rank") + ")"
     elif world > 1:
         from rcs_amd.envs.sharding import ObservationExchange
 
