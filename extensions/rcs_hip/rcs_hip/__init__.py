@@ -1,0 +1,39 @@
+"""``rcs_hip``: the reference-side extension package of the MI355X batched simulation backend.
+
+Laid out like the reference's hardware extensions (reference extensions/rcs_fr3: a Python package around a compiled pybind11
+``_core``).  ``rcs_hip._core.sim`` exposes ``Sim`` / ``SimConfig`` / ``SimRobot`` / ``SimRobotConfig`` / ``SimRobotState`` /
+``SimGripper`` / ``SimGripperConfig`` / ``SimGripperState`` with the reference's method names (python/rcs/_core/sim.pyi) and a
+leading environment axis on every array.  Build: ``python __graft_entry__.py`` (g++ + pybind11, links ``librcs_hip.so``).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def model_tables(cm) -> dict:
+    """The ``model`` argument of ``rcs_hip._core.sim.Sim``: mjModel-named tables of a compiled scene (``rcs_amd.mjcf.Model``;
+    with MuJoCo present the same names can be read off an ``mjModel``)."""
+    d = {k: np.ascontiguousarray(v) for k, v in cm.arrays.items()}
+    for k in ("nbody", "njnt", "nu", "ntendon", "nwrap", "neq", "nsite", "ngeom"):
+        d[k] = int(getattr(cm, k))
+    d["nmeshvert"] = int(cm.arrays["mesh_vert"].shape[0])
+    d["timestep"] = float(cm.timestep)
+    d["gravity"] = np.asarray(cm.gravity, dtype=np.float64)
+    d["names"] = {"joint": list(cm.jnt_names), "actuator": list(cm.actuator_names), "body": list(cm.body_names), "site": list(cm.site_names),
+                  "geom": list(cm.geom_names)}
+    return d
+
+
+def free_box_tables(cm, resolve_robot_contacts: bool = True) -> dict | None:
+    """The ``free_box`` argument: constants of the scene's free body (``None`` if it has none)."""
+    free = getattr(cm, "free_bodies", [])
+    if not free:
+        return None
+    fb = free[0]
+    d = {k: np.asarray(fb[k], dtype=np.float64) for k in ("qpos0", "inertia", "size", "friction", "solref", "solimp")}
+    d["geom_friction"] = np.asarray(fb.get("geom_friction", fb["friction"]), dtype=np.float64)
+    d["floor_friction"] = np.asarray(fb.get("floor_friction", (1.0, 0.005, 0.0001)), dtype=np.float64)
+    d.update(mass=float(fb["mass"]), plane_z=float(fb["plane_z"]), impratio=float(cm.impratio), noslip_tolerance=1e-6,
+             noslip_iterations=int(cm.noslip_iterations), cone_elliptic=int(cm.cone == "elliptic"), resolve_robot_contacts=int(resolve_robot_contacts))
+    return d

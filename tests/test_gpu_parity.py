@@ -811,3 +811,66 @@ def test_pick_task_reaches_success(kernel):
     assert rep["flag_mismatches"] == 0 and rep["truncated"] == 0, rep
     assert rep["success_steps"] >= 3 * 10 and rep["grasped_steps"] > 100 and rep["max_box_z"] > 1.002, rep
     assert rep["max_abs_obs"] < 1e-8 and rep["max_abs_box"] < 1e-7 and rep["max_abs_reward"] < 1e-8, rep
+
+
+def test_pybind_module_equals_ctypes_host_layer(kernel):
+    """The compiled pybind11 binding (extensions/rcs_hip: rcs_hip._core.sim, the reference-side plugin) drives the C-ABI
+    exactly like the ctypes host layer: same calls, same numbers bit for bit; exception types as the reference raises them."""
+    import os
+    import sys
+
+    import parity_util as pu
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_env_oracle import FR3_Q_HOME
+
+    sys.path.insert(0, os.path.join(pu.ROOT, "extensions", "rcs_hip"))
+    import rcs_hip
+    from rcs_hip import _core
+
+    n = 8
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    a = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+    a.set_kernel(kernel)
+    ra, ga = S.SimRobot(a, None, cfg), S.SimGripper(a, default_sim_gripper_cfg())
+    os.environ["RCSH_KERNEL"] = kernel
+    try:
+        b = _core.sim.Sim(rcs_hip.model_tables(a.model), n)
+    finally:
+        os.environ.pop("RCSH_KERNEL")
+    rc = _core.sim.SimRobotConfig()
+    rc.add_id("0")
+    rc.q_home = np.asarray(FR3_Q_HOME)
+    rb = _core.sim.SimRobot(b, None, rc)
+    gc = _core.sim.SimGripperConfig()
+    gc.add_id("0")
+    gb = _core.sim.SimGripper(b, gc)
+    rng = np.random.default_rng(5)
+    for simu, rob, grp in ((a, ra, ga), (b, rb, gb)):
+        simu.reset(); rob.reset(); grp.reset()
+        simu.step(1)
+    odd = np.arange(n) % 2 == 1
+    tgt = np.tile(FR3_Q_HOME, (n, 1)) + rng.uniform(-0.1, 0.1, (n, 7))
+    ra.set_joint_position(tgt, mask=odd); rb.set_joint_position(tgt, mask=odd)
+    ga.shut(mask=~odd); gb.shut(mask=~odd)
+    a.step(34); b.step(34)
+    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel)
+    a.step_until_convergence(); b.step_until_convergence()
+    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.is_converged(), b.is_converged()) and np.array_equal(a.convergence_steps(), b.convergence_steps())
+    sa, sb = ra.get_state(), rb.get_state()
+    assert np.array_equal(sa.target_angles, sb.target_angles) and np.array_equal(sa.is_arrived, sb.is_arrived) and np.array_equal(sa.is_moving, sb.is_moving)
+    assert np.array_equal(ra.get_cartesian_position(), rb.get_cartesian_position())
+    assert np.array_equal(ga.get_normalized_width(), gb.get_normalized_width()) and np.array_equal(ga.is_grasped(), gb.is_grasped())
+    pose = ra.get_cartesian_position()
+    pose[:, 0] += 0.05
+    ra.set_cartesian_position(pose); rb.set_cartesian_position(pose)
+    a.step(17); b.step(17)
+    assert np.array_equal(a.qpos, b.qpos)
+    assert np.allclose(rb.to_pose_in_world_coordinates(rb.to_pose_in_robot_coordinates(pose)), pose, atol=1e-15)
+    with pytest.raises(ValueError):
+        gb.set_normalized_width(1.5)  # std::invalid_argument in the reference (SimGripper.cpp:80-83)
+    bad = _core.sim.SimRobotConfig()
+    with pytest.raises(RuntimeError, match="No joint named"):
+        _core.sim.SimRobot(b, None, bad)  # names without the "_0" suffix: the reference's runtime_error
+    a.close()
+    del rb, gb, b
