@@ -870,7 +870,7 @@ def test_pybind_module_equals_ctypes_host_layer(kernel):
     with pytest.raises(ValueError):
         gb.set_normalized_width(1.5)  # std::invalid_argument in the reference (SimGripper.cpp:80-83)
     bad = _core.sim.SimRobotConfig()
-    with pytest.raises(RuntimeError, match="No joint named"):
+    with pytest.raises(RuntimeError, match="No geom named fr3_link0_collision"):
         _core.sim.SimRobot(b, None, bad)  # names without the "_0" suffix: the reference's runtime_error
     a.close()
     del rb, gb, b
