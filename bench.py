@@ -397,7 +397,7 @@ def main() -> None:
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 FETCH_SIZE + WRITE_SIZE, separate PMC passes (profiles/r1_traffic.json)" if traffic else None,
-                "kernel": ("k_run" if os.environ.get("RCSH_KERNEL") == "lane" else "k_run_team") + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
+                "kernel": "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
                           + (" + free box" if args.task != "none" or args.robot == "xarm7_box" else ""),
                 "kernel_ms_avg": kernel_ms,
                 "launches_timed": int(launches.value),

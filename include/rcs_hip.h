@@ -175,9 +175,9 @@ int rcsh_sim_synchronize(rcsh_sim* sim);
  * stream (e.g. the host framework's current stream, so its collectives order after the env-step kernel) */
 void* rcsh_sim_stream(rcsh_sim* sim);
 int rcsh_sim_set_stream(rcsh_sim* sim, void* hip_stream);
-/* Which kernel computes step / step_until_convergence / env step (no reference counterpart: the reference has
- * one CPU code path).  RCSH_KERNEL_AUTO is the team kernel (16 lanes per environment; the faster one at every batch
- * size measured); RCSH_KERNEL_LANE pins the one-lane-per-environment kernel (parity tests run both).  The environment variable RCSH_KERNEL=team|lane sets the default of new handles. */
+/* Kernel selection (no reference counterpart).  Every scene runs on the team kernel (16 lanes per environment);
+ * RCSH_KERNEL_AUTO and RCSH_KERNEL_TEAM both name it.  RCSH_KERNEL_LANE, the one-lane-per-environment kernel of ABI 1, was
+ * removed (it lost at every batch size and stepped neither dry friction nor free bodies): selecting it is RCSH_ERR_ARG. */
 enum { RCSH_KERNEL_AUTO = 0, RCSH_KERNEL_TEAM = 1, RCSH_KERNEL_LANE = 2 };
 int rcsh_sim_set_kernel(rcsh_sim* sim, int32_t variant);
 

@@ -1,27 +1,13 @@
-// dyn.h -- per-environment rigid-body dynamics of one robot archetype, written for
-// one GPU thread per environment with every per-link quantity in registers.
+// dyn.h -- shared math of the kernels (3-vectors, spatial inertia, packed LDL', fast reciprocal / sincos, the impedance
+// sigmoid, the robot archetypes) and the SERIAL formulation of the smooth dynamics of one environment
+// (smooth_dynamics: kinematics, composite-inertia mass matrix, bias forces, gravity compensation -- what mj_step1
+// computes for the RCS scenes, reference call sites src/sim/sim.cpp:110,112), all spatial quantities as Pluecker vectors
+// about the WORLD ORIGIN so that the composite-inertia and force recursions are plain sums.
 //
-// What it computes is what mj_step1 / mj_step2 compute for the RCS scenes
-// (reference call sites src/sim/sim.cpp:110,112): kinematics, mass matrix, bias
-// forces, gravity compensation, affine actuators with force clamps, the
-// soft-constraint solve (finger coupling equality + joint limits) and the
-// implicitfast integrator.  How it computes it is chosen for CDNA4:
-//
-//  * welded bodies are folded into links on the host (model.cpp), so the loops run
-//    over NL = 9 links instead of 14 bodies;
-//  * all spatial quantities are Pluecker vectors about the WORLD ORIGIN.  With one
-//    common reference point the composite-inertia and force recursions are plain
-//    sums -- no frame transforms on the backward pass;
-//  * the archetype (chain length, gripper or not) is a template parameter, so every
-//    loop unrolls and every array index is a compile-time constant: the arrays
-//    live in VGPR/AGPR, model constants arrive through scalar loads;
-//  * the constraint Hessian differs from M only on the diagonal (limit rows are
-//    +-e_i) and in the 2x2 finger block (coupling row), so the Newton solve is a
-//    packed 9x9 LDL^T with a handful of diagonal updates.
-//
-// The same templates are instantiated on the host by model.cpp for one purpose only:
-// dof_invweight0 = diag(M(qpos0)^-1) at model-finalise time (MuJoCo computes the same
-// constant when it compiles a model).  No stepping entry point runs on the CPU.
+// The serial formulation is instantiated on the HOST only (model.cpp): dof_invweight0 = diag(M(qpos0)^-1) and
+// body_invweight0 at model-finalise time, the constants MuJoCo derives when it compiles a model; and by the per-lane CLIK
+// utilities (ik.h).  Through round 1 it was also a second GPU kernel, one lane per environment; that kernel lost at every
+// batch size, stepped neither dry friction nor free bodies, and was removed.  No stepping entry point runs on the CPU.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -478,261 +464,6 @@ RCSH_HD double impedance(const Imp& p, double pos, double margin) {
 RCSH_HD double row_D(double imp, double invweight) {
   const double num = (1 - imp) * invweight;
   return num < kMinVal * imp ? 1.0 / kMinVal : imp * fast_rcp(num);
-}
-
-// One physics substep on the environment parked in `st`: reads qpos / qvel / ctrl from the staging
-// column, advances them by one timestep and writes them back, together with the world frame of the
-// attachment-site link computed from the PRE-step qpos (the reference reads site_xpos / site_xmat of
-// the last mj_step1).  Everything that is not needed between two phases is parked in
-// the column, so the register allocator only ever sees one phase's working set.
-template <class T, int STRIDE>
-RCSH_HD void substep(const DevModel& m, const Stage<T, STRIDE>& st) {
-  constexpr int NL = T::NL;
-  constexpr int NA = T::NARM;
-  const double h = m.timestep;
-  double smooth[NL];        // qfrc_smooth
-  uint32_t clampmask = 0;   // bit i: arm actuator i saturated its forcerange (no velocity derivative)
-  double gblock = 0.0;      // -bias_vel of the gripper actuator (2x2 block coef_a * coef_b * gblock)
-  double eqD = 0, eqAref = 0, eqJ1 = 0;  // coupling row = e_f1 + eqJ1 * e_f2
-  uint32_t limrows = 0;     // bit i: joint i has a limit row this substep
-  {
-    double q[NL], qd[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) { q[i] = st.q(i); qd[i] = st.v(i); st.qpre(i) = q[i]; }
-    Smooth<T> sm;
-    smooth_dynamics<T, STRIDE>(m, q, qd, st, sm);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) st.link(k) = sm.linkR[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st.link(9 + k) = sm.linkP[k];
-
-    // ---- actuation: affine actuators, force limits, actuator-side gravity compensation, joint clamp
-    double tau[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) tau[i] = 0;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      if (!m.arm_has_act[i]) continue;
-      double c = st.c(i);
-      if (m.arm_ctrllimited[i]) c = clampd(c, m.arm_ctrlrange[i][0], m.arm_ctrlrange[i][1]);
-      const double gear = m.arm_gear[i];
-      double force = m.arm_gain[i] * c;
-      if (m.arm_biasaffine[i]) force += m.arm_bias[i][0] + m.arm_bias[i][1] * (gear * q[i]) + m.arm_bias[i][2] * (gear * qd[i]);
-      if (m.arm_forcelimited[i]) {
-        if (force <= m.arm_forcerange[i][0] || force >= m.arm_forcerange[i][1]) clampmask |= 1u << i;
-        force = clampd(force, m.arm_forcerange[i][0], m.arm_forcerange[i][1]);
-      }
-      tau[i] = gear * force;
-    }
-    if (T::GRIP && m.grp_has_act) {
-      double c = st.c(NA);
-      if (m.grp_ctrllimited) c = clampd(c, m.grp_ctrlrange[0], m.grp_ctrlrange[1]);
-      const double len = m.grp_coef[0] * q[NA] + m.grp_coef[1] * q[NA + 1];
-      const double vel = m.grp_coef[0] * qd[NA] + m.grp_coef[1] * qd[NA + 1];
-      double force = m.grp_gain * c;
-      if (m.grp_biasaffine) force += m.grp_bias[0] + m.grp_bias[1] * len + m.grp_bias[2] * vel;
-      bool clamped = false;
-      if (m.grp_forcelimited) {
-        clamped = force <= m.grp_forcerange[0] || force >= m.grp_forcerange[1];
-        force = clampd(force, m.grp_forcerange[0], m.grp_forcerange[1]);
-      }
-      tau[NA] += m.grp_coef[0] * force;
-      tau[NA + 1] += m.grp_coef[1] * force;
-      if (m.grp_biasaffine && !clamped) gblock = -m.grp_bias[2];
-    }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      double passive = -m.damping[i] * qd[i];
-      if (m.actgravcomp[i]) tau[i] += sm.gc[i]; else passive += sm.gc[i];
-      if (m.actfrclimited[i]) tau[i] = clampd(tau[i], m.actfrcrange[i][0], m.actfrcrange[i][1]);
-      smooth[i] = passive - sm.bias[i] + tau[i];
-    }
-
-    // ---- constraint rows: finger coupling (equality, always active) and joint limits (one-sided)
-    if (T::GRIP && m.eq_active) {
-      const double* pc = m.eq_polycoef;
-      const double dif = q[NA + 1] - m.qpos0[NA + 1];
-      const double poly = pc[0] + dif * (pc[1] + dif * (pc[2] + dif * (pc[3] + dif * pc[4])));
-      const double deriv = pc[1] + dif * (2 * pc[2] + dif * (3 * pc[3] + dif * 4 * pc[4]));
-      const double pos = q[NA] - m.qpos0[NA] - poly;
-      eqJ1 = -deriv;
-      const double imp = impedance(m.eq_imp, pos, 0.0);
-      eqD = row_D(imp, m.invweight0[NA] + m.invweight0[NA + 1]);
-      eqAref = -m.eq_K * imp * pos - m.eq_B * (qd[NA] + eqJ1 * qd[NA + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      if (!m.limited[i]) continue;
-      const double dlo = q[i] - m.range[i][0], dhi = m.range[i][1] - q[i];
-      double dist = 0, sgn = 0;
-      if (dlo < m.margin[i]) { dist = dlo; sgn = 1; }
-      else if (dhi < m.margin[i]) { dist = dhi; sgn = -1; }
-      if (sgn != 0) {
-        const double imp = impedance(m.lim_imp[i], dist, m.margin[i]);
-        st.lim(i, 0) = row_D(imp, m.invweight0[i]);
-        st.lim(i, 1) = -m.lim_K[i] * imp * (dist - m.margin[i]) - m.lim_B[i] * (sgn * qd[i]);
-        st.lim(i, 2) = sgn;
-        limrows |= 1u << i;
-      }
-    }
-  }
-  stage_fence();
-
-  // ---- qacc = argmin 1/2 |qacc - M^-1 smooth|_M^2 + sum s_i(J_i qacc - aref_i), s_i quadratic (coupling
-  // row) or one-sided quadratic (limit rows).  Newton on the piecewise-quadratic cost: the minimiser under a
-  // guessed active set is the answer if the set it lands in equals the guess; otherwise an exact line search
-  // along the Newton direction is taken from the current iterate and the step repeated (finite convergence).
-  double fc[NL];  // qfrc_constraint
-#pragma unroll
-  for (int i = 0; i < NL; ++i) fc[i] = 0;
-  if ((T::GRIP && m.eq_active) || limrows) {
-    const bool has_eq = T::GRIP && m.eq_active;
-    double x[NL];
-    uint32_t act = limrows;  // first guess: every limit row that exists is active
-    bool have_x = false;
-    for (int iter = 0; iter < 16; ++iter) {
-      double xn[NL];
-      {
-        double H[T::NTRI];
-#pragma unroll
-        for (int k = 0; k < T::NTRI; ++k) H[k] = st.M(k);
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-          xn[i] = smooth[i];
-          if (act & (1u << i)) {
-            const double D = st.lim(i, 0);
-            H[tri(i, i)] += D;
-            xn[i] += st.lim(i, 2) * D * st.lim(i, 1);
-          }
-        }
-        if (has_eq) {
-          H[tri(NA, NA)] += eqD;
-          H[tri(NA + 1, NA)] += eqD * eqJ1;
-          H[tri(NA + 1, NA + 1)] += eqD * eqJ1 * eqJ1;
-          xn[NA] += eqD * eqAref;
-          xn[NA + 1] += eqD * eqAref * eqJ1;
-        }
-        ldl_factor<NL>(H);
-        ldl_solve<NL>(H, xn);
-      }
-      uint32_t now = 0;
-#pragma unroll
-      for (int i = 0; i < NL; ++i)
-        if ((limrows & (1u << i)) && st.lim(i, 2) * xn[i] - st.lim(i, 1) < 0) now |= 1u << i;
-      if (now == act || !have_x) {
-        // either the exact minimiser, or the starting point of the line-search iteration
-#pragma unroll
-        for (int i = 0; i < NL; ++i) x[i] = xn[i];
-        have_x = true;
-        if (now == act) break;
-        act = now;
-        continue;
-      }
-      // exact line search from x along d = xn - x:
-      // phi'(a) = p0 + a p1 + sum_{rows active at a} D_i jd_i (jar_i + a jd_i)
-      double d[NL], jar[NL], jd[NL];
-      double p0 = 0, p1 = 0;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) d[i] = xn[i] - x[i];
-#pragma unroll
-      for (int r = 0; r < NL; ++r) {
-        double mx = -smooth[r], md = 0;
-#pragma unroll
-        for (int c = 0; c < NL; ++c) {
-          const double mrc = st.M(r >= c ? tri(r, c) : tri(c, r));
-          mx += mrc * x[c];
-          md += mrc * d[c];
-        }
-        p0 += mx * d[r];
-        p1 += md * d[r];
-      }
-      if (has_eq) {
-        const double je = x[NA] + eqJ1 * x[NA + 1] - eqAref, jde = d[NA] + eqJ1 * d[NA + 1];
-        p0 += eqD * je * jde;
-        p1 += eqD * jde * jde;
-      }
-      uint32_t on = 0;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        jar[i] = 0; jd[i] = 0;
-        if (limrows & (1u << i)) {
-          const double sgn = st.lim(i, 2);
-          jar[i] = sgn * x[i] - st.lim(i, 1);
-          jd[i] = sgn * d[i];
-          if (jar[i] < 0 || (jar[i] == 0 && jd[i] < 0)) on |= 1u << i;
-        }
-      }
-      double alpha = 0;
-      for (int guard = 0; guard < NL + 2; ++guard) {
-        double c0 = p0, c1 = p1, a_next = INFINITY;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-          if (!(limrows & (1u << i))) continue;
-          const double D = st.lim(i, 0);
-          if (on & (1u << i)) { c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
-          if (jd[i] != 0) {
-            const double ab = -jar[i] / jd[i];
-            if (ab > alpha && ab < a_next) a_next = ab;
-          }
-        }
-        const double a_star = -c0 / c1;
-        if (a_star <= a_next) { if (a_star > alpha) alpha = a_star; break; }
-        alpha = a_next;
-#pragma unroll
-        for (int i = 0; i < NL; ++i)
-          if ((limrows & (1u << i)) && jd[i] != 0 && -jar[i] / jd[i] == a_next) on ^= 1u << i;
-      }
-      act = 0;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        x[i] += alpha * d[i];
-        if ((limrows & (1u << i)) && st.lim(i, 2) * x[i] - st.lim(i, 1) < 0) act |= 1u << i;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NL; ++i)
-      if ((limrows & (1u << i))) {
-        const double sgn = st.lim(i, 2);
-        const double r = sgn * x[i] - st.lim(i, 1);
-        if (r < 0) fc[i] = -sgn * st.lim(i, 0) * r;
-      }
-    if (has_eq) {
-      const double fe = -eqD * (x[NA] + eqJ1 * x[NA + 1] - eqAref);
-      fc[NA] += fe;
-      fc[NA + 1] += fe * eqJ1;
-    }
-  }
-  stage_fence();
-
-  // ---- implicitfast: (M - h dF/dqd) qacc = smooth + constraint, then semi-implicit Euler
-  {
-    double A[T::NTRI];
-#pragma unroll
-    for (int k = 0; k < T::NTRI; ++k) A[k] = st.M(k);
-    double rhs[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      double d = m.damping[i];
-      if (i < NA && m.arm_has_act[i] && m.arm_biasaffine[i] && !(clampmask & (1u << i)))
-        d -= m.arm_gear[i] * m.arm_gear[i] * m.arm_bias[i][2];
-      A[tri(i, i)] += h * d;
-      rhs[i] = smooth[i] + fc[i];
-    }
-    if (T::GRIP) {
-      A[tri(NA, NA)] += h * gblock * m.grp_coef[0] * m.grp_coef[0];
-      A[tri(NA + 1, NA)] += h * gblock * m.grp_coef[0] * m.grp_coef[1];
-      A[tri(NA + 1, NA + 1)] += h * gblock * m.grp_coef[1] * m.grp_coef[1];
-    }
-    ldl_factor<NL>(A);
-    ldl_solve<NL>(A, rhs);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const double v = st.v(i) + h * rhs[i];
-      st.v(i) = v;
-      st.q(i) += h * v;
-    }
-  }
-  stage_fence();
 }
 
 }  // namespace rcsh

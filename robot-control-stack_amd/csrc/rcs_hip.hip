@@ -34,7 +34,6 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int kBlock = 64;     // accessor kernels
-constexpr int kRunLanes = 16;                // environments per workgroup of k_run
 constexpr int kProfRing = 4096;
 
 }  // namespace
@@ -204,14 +203,10 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
     }
     HIP_TRY(hipEventRecord(s->ev_start[s->prof_pending], s->stream));
   }
-  // Two kernels compute the same launch (sim_kernels.h):
-  //  * k_run_team (the default): 16 lanes per environment, 4 environments per wavefront.  4096 environments are 1024
-  //    wavefronts = one per SIMD of the chip; measured 29 M env-steps/s at 4096 environments, 33 M from 65536 up.
-  //  * k_run: one lane per environment, 16 environments per workgroup (the 52 KB LDS staging block per workgroup
-  //    caps it at three workgroups per CU): 9.5 M at 4096 environments, 30 M at 524288.  It no longer wins at any
-  //    batch size (tools/sweep_envs.sh); it stays as an independent second formulation that the parity tests run
-  //    against the same oracle (rcsh_sim_set_kernel / RCSH_KERNEL=lane).  It has no dry-friction rows.
-  const bool team = s->dm.has_friction || s->box.present || s->kernel != RCSH_KERNEL_LANE;
+  // k_run_team: 16 lanes per environment, 4 environments per wavefront.  4096 environments are 1024 wavefronts = one per
+  // SIMD of the chip.  (A one-lane-per-environment kernel existed through round 1; it lost at every batch size and could
+  // step neither dry friction nor free bodies, and was removed: csrc/dyn.h keeps its formulas for the host-side model
+  // finalisation and the shared math.)
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
     if (s->box.present) {
@@ -220,12 +215,10 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
         hipLaunchKernelGGL((k_run_team<T, false, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
       else if constexpr (T::NARM == 7)
         hipLaunchKernelGGL((k_run_team<T, true, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
-    } else if (team && s->dm.has_friction)
+    } else if (s->dm.has_friction)
       hipLaunchKernelGGL((k_run_team<T, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
-    else if (team)
-      hipLaunchKernelGGL((k_run_team<T, false>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     else
-      hipLaunchKernelGGL((k_run<T, kRunLanes>), dim3((s->n + kRunLanes - 1) / kRunLanes), dim3(kRunLanes), 0, s->stream, P, op);
+      hipLaunchKernelGGL((k_run_team<T, false>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     err = hipGetLastError();
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
@@ -377,8 +370,6 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   }
   s->device = device;
   s->n = n_envs;
-  if (const char* v = getenv("RCSH_KERNEL"))
-    s->kernel = std::strcmp(v, "team") == 0 ? RCSH_KERNEL_TEAM : (std::strcmp(v, "lane") == 0 ? RCSH_KERNEL_LANE : RCSH_KERNEL_AUTO);
   s->narm = s->dm.narm; s->nl = s->dm.nl; s->grip = s->dm.has_gripper != 0;
   s->nu = s->narm + (s->grip ? 1 : 0);
   s->nfields = with_layout(s, [&](auto topo) { return (int)Lay<decltype(topo)>::COUNT; });
@@ -469,11 +460,8 @@ int rcsh_sim_set_stream(rcsh_sim* s, void* hip_stream) {
 
 int rcsh_sim_set_kernel(rcsh_sim* s, int32_t variant) {
   REQUIRE_SIM(s);
-  if (variant < RCSH_KERNEL_AUTO || variant > RCSH_KERNEL_LANE) return fail(RCSH_ERR_ARG, "unknown kernel variant");
-  if (variant == RCSH_KERNEL_LANE && s->dm.has_friction)
-    return fail(RCSH_ERR_MODEL, "the lane kernel has no dry-friction (frictionloss) rows; this model needs the team kernel");
-  if (variant == RCSH_KERNEL_LANE && s->box.present)
-    return fail(RCSH_ERR_MODEL, "the lane kernel does not step free bodies; this scene needs the team kernel");
+  if (variant == RCSH_KERNEL_LANE) return fail(RCSH_ERR_ARG, "the one-lane-per-environment kernel was removed (ABI 2): every scene runs on the team kernel");
+  if (variant != RCSH_KERNEL_AUTO && variant != RCSH_KERNEL_TEAM) return fail(RCSH_ERR_ARG, "unknown kernel variant");
   s->kernel = variant;
   return RCSH_OK;
 }
@@ -657,10 +645,7 @@ int launch_cartesian(rcsh_sim* s, const CartOp& op) {
   hipError_t err = hipSuccess;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    if (s->kernel != RCSH_KERNEL_LANE)
-      hipLaunchKernelGGL(k_cartesian_team<T>, dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
-    else
-      hipLaunchKernelGGL(k_cartesian<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, op);
+    hipLaunchKernelGGL(k_cartesian_team<T>, dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
     err = hipGetLastError();
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
@@ -868,7 +853,6 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
                                 "7-dof arm without gripper with it (xArm7)");
   if (s->dm.has_friction && d->noslip_iterations > 0)
     return fail(RCSH_ERR_MODEL, "the noslip pass over dry joint friction rows is not built: scenes with frictionloss need noslip_iterations = 0");
-  if (s->kernel == RCSH_KERNEL_LANE) return fail(RCSH_ERR_MODEL, "the lane kernel does not step free bodies");
   if (!d->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
   if (!(d->mass > 0) || !(d->inertia[0] > 0) || !(d->inertia[1] > 0) || !(d->inertia[2] > 0) || !(d->impratio > 0))
     return fail(RCSH_ERR_ARG, "free box: mass, inertia and impratio must be positive");

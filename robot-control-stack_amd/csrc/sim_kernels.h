@@ -1,7 +1,7 @@
 // sim_kernels.h -- the batched Sim / SimRobot / SimGripper / Gymnasium-loop kernels.
 //
-// One launch is one call of the reference's API for every environment: a team of 16 lanes (k_run_team, the default)
-// or one lane (k_run) owns an environment for the whole launch, loads its state from the SoA arrays ([field][env]),
+// One launch is one call of the reference's API for every environment: a team of 16 lanes (k_run_team) owns an
+// environment for the whole launch, loads its state from the SoA arrays ([field][env]),
 // keeps it in LDS / registers across all physics substeps of the call, and writes it back once.  The reference's
 // per-substep callback scheduler (reference src/sim/sim.cpp:14-61) is evaluated by the environment's leader lane with
 // the same double-precision timestamps and strict '>' compares, so callback cadence -- and with it every flag and
@@ -249,45 +249,6 @@ __device__ __forceinline__ void plain_callbacks(const Params& P, EnvRegs<T, ST>&
     set_flag(r.flags, kIsMoving, mx > 0.0001);
     r.cb(1) = r.time;
   }
-}
-
-// d->contact of the last mj_step1, reduced to what the two collision callbacks ask of it: which geom classes touch
-// the plane.  MuJoCo reports a plane-convex contact when the deepest hull point is below the plane (margin 0).
-// Frames are those of the qpos the last mj_step1 saw (Stage::qpre).
-template <class T, class ST>
-__device__ __noinline__ uint32_t plane_contacts(const DevModel& m, const Params& P, const ST& st) {
-  uint32_t hit = 0;
-  if (!P.coll.has_plane) return hit;
-  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
-  double Rt[9], pt[3];
-  const double* n = P.coll.plane_n;
-  for (int i = 0; i < T::NL; ++i) {
-    if (T::GRIP && i == T::NARM) {
-      for (int k = 0; k < 9; ++k) Rt[k] = R[k];
-      for (int k = 0; k < 3; ++k) pt[k] = p[k];
-    }
-    if (T::GRIP && i > T::NARM) {
-      for (int k = 0; k < 9; ++k) R[k] = Rt[k];
-      for (int k = 0; k < 3; ++k) p[k] = pt[k];
-    }
-    advance_link_frame(m, i, st.qpre(i), R, p);
-    // signed distance of a link-frame point v with radius r: n.(p + R v) - d - r = b + a.v - r
-    const double a[3] = {R[0] * n[0] + R[3] * n[1] + R[6] * n[2], R[1] * n[0] + R[4] * n[1] + R[7] * n[2],
-                         R[2] * n[0] + R[5] * n[1] + R[8] * n[2]};
-    const double b = dot3(n, p) - P.coll.plane_d;
-    // broad phase (per lane): the link's bounding sphere clears the plane -> none of its points can touch it
-    const double* sph = P.coll.link_sphere[i];
-    const bool near = b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < 0;
-    if (!__any(near)) continue;
-    // narrow phase: the table is read through the constant address space (wave-uniform index -> scalar loads)
-    typedef const __attribute__((address_space(4))) double* cptr;
-    const cptr tab = (cptr)(uintptr_t)P.coll.xyzr;
-    for (int k = P.coll.link_adr[i]; k < P.coll.link_adr[i + 1]; ++k) {
-      const double vx = tab[4 * (size_t)k], vy = tab[4 * (size_t)k + 1], vz = tab[4 * (size_t)k + 2], vr = tab[4 * (size_t)k + 3];
-      if (near && b + a[0] * vx + a[1] * vy + a[2] * vz - vr < 0) hit |= P.coll.cls[k];
-    }
-  }
-  return hit;
 }
 
 // Sim::invoke_condition_callbacks, reference src/sim/sim.cpp:14-23,49-61.  Callback bodies:
@@ -564,69 +525,6 @@ __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, c
   }
 }
 
-// The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step.
-template <class T, int kLanes>
-__global__ void __launch_bounds__(kLanes) k_run(Params P, RunOp op) {
-  using L = Lay<T>;
-  // Model tables: staged into LDS once per launch and read back with broadcast ds_reads.  (Scalar
-  // loads from constant memory were measured 2.2x slower here: ~800 doubles of tables cannot stay in
-  // ~100 SGPRs, and SMEM returns share -- and serialise -- the LDS wait counter.)
-  __shared__ DevModel lm;
-  {
-    constexpr int kWords = sizeof(DevModel) / 8;
-    const double* src = reinterpret_cast<const double*>(P.model);
-    double* dst = reinterpret_cast<double*>(&lm);
-#pragma unroll
-    for (int it = 0; it < (kWords + kLanes - 1) / kLanes; ++it) {
-      const int k = it * kLanes + threadIdx.x;
-      if (k < kWords) dst[k] = src[k];
-    }
-    __syncthreads();
-  }
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= P.n) return;
-  if (op.mask && !op.mask[e]) return;
-  const DevModel& m = lm;
-  const int n = P.n;
-  // LDS staging column of this lane (dyn.h: Stage), [slot][lane]
-  __shared__ double lds[Stage<T, kLanes>::COUNT * kLanes];
-  using ST = Stage<T, kLanes>;
-  const ST st{lds + threadIdx.x};
-  EnvRegs<T, ST> r;
-  r.st = st;
-  load_env<T, ST>(P, e, r);
-  bool have_frames = false;
-
-  env_prologue<T, ST>(P, op, m, e, r, StepInGlobal<T>{P, op, e});
-
-  // ---- Sim::step(k) / Sim::step_until_convergence (src/sim/sim.cpp:84-115).  One loop serves both so the
-  // (large, fully unrolled) substep body exists once in the instruction stream.
-  int nsteps = op.nsteps;
-  if (op.do_reset) nsteps = 1;
-  const bool until_conv = nsteps < 0;
-  int budget = nsteps;
-  if (until_conv) {
-    r.conv_steps = 0;
-    r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
-    const int cap = P.sim.max_convergence_steps;
-    budget = cap == -1 ? 0x7fffffff : cap;
-  }
-  bool converged = false;
-  while (budget > 0 && !converged) {
-    plain_callbacks<T, ST>(P, r);
-    substep<T, kLanes>(m, st);
-    r.time += m.timestep;
-    have_frames = true;
-    --budget;
-    if (until_conv) {
-      r.conv_steps++;
-      converged = condition_callbacks<T, ST>(m, P, r, [&] { return plane_contacts<T, ST>(m, P, r.st); });
-    }
-  }
-  if (until_conv) set_flag(r.flags, kConverged, converged);
-  env_epilogue<T, ST>(P, op, m, e, r, st, have_frames, nsteps);
-}
-
 // Stages the model into a workgroup's LDS for the team kernels (64 threads): the DevModelHead (what is not per link) and the
 // per-link LinkRec records stored right behind the DevModel.  Every workgroup of the launch fetches these same lines from
 // L2 at the same moment.
@@ -645,9 +543,9 @@ __device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModelHea
   }
 }
 
-// The same entry point with one TEAM of 16 lanes per environment (dyn_team.h): four environments per wavefront,
-// one wavefront per workgroup.  Lane 0 of a team (the leader) owns the RCS bookkeeping -- wrappers, callback
-// scheduler, observation -- through the same helpers as k_run; all 16 lanes run the physics.
+// The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step: one TEAM of 16 lanes per
+// environment (dyn_team.h), four environments per wavefront, one wavefront per workgroup.  Lane 0 of a team (the leader)
+// owns the RCS bookkeeping -- wrappers, callback scheduler, observation; all 16 lanes run the physics.
 template <class T, bool FRIC, bool BOX = false>
 __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   using ST = StageTeam<T>;
@@ -1091,46 +989,8 @@ __device__ __forceinline__ bool cart_prepare(const Params& P, const CartOp& op, 
   return command;
 }
 
-template <class T>
-__global__ void __launch_bounds__(64) k_cartesian(Params P, CartOp op) {
-  using L = Lay<T>;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= P.n) return;
-  if (op.mask && !op.mask[e]) return;
-  const DevModel& m = *P.model;
-  const int n = P.n;
-  double* S = P.S;
-  uint32_t flags = P.flags[e];
-  Pose tcp;
-  tcp.t[0] = P.robot.tcp[0]; tcp.t[1] = P.robot.tcp[1]; tcp.t[2] = P.robot.tcp[2];
-  tcp.q[0] = P.robot.tcp[3]; tcp.q[1] = P.robot.tcp[4]; tcp.q[2] = P.robot.tcp[5]; tcp.q[3] = P.robot.tcp[6];
-  Pose target;
-  const bool command = cart_prepare<T>(P, op, m, e, flags, target);
-  if (command) {
-    // SimRobot::set_cartesian_position (SimRobot.cpp:145-155)
-    double q[T::NARM];
-#pragma unroll
-    for (int i = 0; i < T::NARM; ++i) q[i] = S[(L::QPOS + i) * n + e];
-    int iters = 0;
-    const bool ok = clik<T>(m, target, tcp, q, &iters);
-    if (ok) {
-      flags |= kIkSuccess;
-#pragma unroll
-      for (int i = 0; i < T::NARM; ++i) {  // set_joint_position(joint_vals)
-        S[(L::TARGET + i) * n + e] = q[i];
-        S[(L::PREVQ + i) * n + e] = S[(L::QPOS + i) * n + e];
-        S[(L::CTRL + i) * n + e] = q[i];
-      }
-      flags = (flags | kIsMoving) & ~kIsArrived;
-    } else {
-      flags &= ~kIkSuccess;
-    }
-  }
-  P.flags[e] = flags;
-}
-
-// The same launch with a team of 16 lanes per environment (ik_team.h): the leader lane runs the wrapper logic, the
-// team the CLIK, lane t commits joint t.
+// The Cartesian launch, a team of 16 lanes per environment (ik_team.h): the leader lane runs the wrapper logic, the team
+// the CLIK, lane t commits joint t.
 template <class T>
 __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
   using L = Lay<T>;

@@ -109,7 +109,7 @@ class Sim:
         _lib.check(self._L.rcsh_sim_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def set_kernel(self, variant: str) -> None:
-        """Pin the kernel variant: "auto" / "team" (16 lanes per environment, the default) or "lane" (one lane)."""
+        """Pin the kernel variant: "auto" / "team" (16 lanes per environment).  "lane", the one-lane kernel of ABI 1, was removed: ValueError."""
         _lib.check(self._L.rcsh_sim_set_kernel(self._h, {"auto": 0, "team": 1, "lane": 2}[variant]))
 
     def get_state(self) -> np.ndarray:

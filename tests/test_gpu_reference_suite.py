@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 N = 3
 
 
-@pytest.fixture(autouse=True, params=["team", "lane"])
+@pytest.fixture(autouse=True, params=["team"])
 def kernel(request):
     import parity_util
 
