@@ -676,7 +676,9 @@ def test_joint_friction_on_the_other_archetypes(robot, kernel):
     equality, their limit rows and the tendon actuator -- `newton_rows<Topo<7,true>, FRIC>`) and the 6-dof arm."""
     for async_control in (True, False):
         rep = run_joint_rollout_parity(n_envs=32, n_steps=5 if async_control else 2, async_control=async_control, seed=23, robot=robot)
-        assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < VTOL and rep["max_abs_obs"] < TOL and rep["max_abs_finger"] < FINGER_TOL, rep
+        # (stiction: a 15 g finger under 0.5 N of dry friction sticks wherever it stops -- the quadratic zone of its Huber row is
+        # 1e-6 m/s^2 wide, so round-off decides the zone and the resting place to ~2e-6 m; nothing else in the suite is this loose)
+        assert rep["max_abs_qpos"] < 1e-8 and rep["max_abs_qvel"] < 1e-6 and rep["max_abs_obs"] < 1e-8 and rep["max_abs_finger"] < 1e-5, rep
         assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
 
 
