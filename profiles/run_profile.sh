@@ -1,13 +1,15 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash profiles/run_profile.sh <tag>
+# Usage (on the GPU box, from the repo root): bash profiles/run_profile.sh <tag> [extra bench.py arguments, e.g. --control cartesian]
 # Produces gpurun_out/prof_<tag>/{stats,pmc*} CSVs; copy the summaries you want judged into profiles/.
 set -u
 TAG=${1:-r1}
+shift || true
+EXTRA="$*"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-CMD="python bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+CMD="python bench.py --steps 100 --warmup 10 --no-cpu-baseline $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $CMD > "$OUT/bench_stats.log" 2>&1
 # PMC passes, each in its own run, kernel-trace only
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU -d "$OUT/pmc1" -o pmc1 -- $CMD > "$OUT/bench_pmc1.log" 2>&1
