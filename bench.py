@@ -350,7 +350,7 @@ def main() -> None:
         achieved_gbs = algo_bytes / (kernel_ms * 1e-3) / 1e9
         substeps_per_launch = mean_sub * n
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
         headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
         if os.path.exists(tpath) and headline:  # the PMC passes profiled exactly this workload (profiles/run_profile.sh)
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
@@ -396,7 +396,7 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "rocprofv3 FETCH_SIZE + WRITE_SIZE, separate PMC passes (profiles/r1_traffic.json)" if traffic else None,
+                "traffic_source": "rocprofv3 FETCH_SIZE + WRITE_SIZE, separate PMC passes (profiles/r2_traffic.json)" if traffic else None,
                 "kernel": "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
                           + (" + free box" if args.task != "none" or args.robot == "xarm7_box" else ""),
                 "kernel_ms_avg": kernel_ms,

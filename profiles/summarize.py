@@ -25,7 +25,7 @@ for f in find("*counter_collection.csv"):
     cnt = defaultdict(int)
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        if "k_run" not in name:
+        if "rcsh::k_run" not in name and "rcsh::k_cartesian" not in name and "rcsh::k_render" not in name:
             continue
         acc[name][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[(name, row["Counter_Name"])] += 1
