@@ -272,6 +272,17 @@ typedef struct rcsh_free_box_desc {
   int32_t reserved;
 } rcsh_free_box_desc;
 int rcsh_sim_add_free_box(rcsh_sim* sim, const rcsh_free_box_desc* box);
+/* Scenes WITHOUT a free body: the solver options mjModel.opt carries (reference assets/fr3/mjcf/fr3_common.xml:3) and the
+ * default contact parameters, so that contacts of the robot's collision geoms with the floor are resolved (the arm stops
+ * on the floor instead of only raising SimRobot's collision flag).  FR3 + hand archetype; elsewhere and with
+ * resolve_robot_contacts = 0 robot contacts are detected only. */
+typedef struct rcsh_contact_options {
+  double impratio, noslip_tolerance;
+  int32_t noslip_iterations, cone_elliptic;
+  double solref[2], solimp[5];
+  int32_t resolve_robot_contacts, reserved;
+} rcsh_contact_options;
+int rcsh_sim_set_contact_options(rcsh_sim* sim, const rcsh_contact_options* options);
 int rcsh_sim_reset_free_box(rcsh_sim* sim);
 int rcsh_sim_get_free_qpos(rcsh_sim* sim, double* qpos);  /* [N][7] */
 int rcsh_sim_get_free_qvel(rcsh_sim* sim, double* qvel);  /* [N][6] */

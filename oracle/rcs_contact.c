@@ -445,8 +445,11 @@ static double geom_rbound(const orc_model* m, int g) {
   if (m->geom_type[g] == 3) return sz[0] + sz[1];
   return sz[0];
 }
+/* contacts beyond the capacity are dropped in detection order; where contacts are resolved the capacity is the HIP
+   backend's (contact_types.h: kMaxCon), so that an overflowing scene overflows alike on both sides */
+static int g_contact_cap = ORC_MAXCON;
 static orc_contact* add_contact(orc_data* d, int g1, int g2, int b1, int b2, const double* pos, const double* n, double dist, double mu) {
-  if (d->ncon >= ORC_MAXCON) return 0;
+  if (d->ncon >= g_contact_cap) return 0;
   orc_contact* c = &d->contact[d->ncon];
   c->geom[0] = g1; c->geom[1] = g2; c->body[0] = b1; c->body[1] = b2;
   copy3(c->pos, pos);
@@ -469,6 +472,7 @@ static orc_contact* add_contact(orc_data* d, int g1, int g2, int b1, int b2, con
 void orc_collide(const orc_model* m, orc_data* d) {
   d->ncon = 0;
   d->coupled = 0;
+  g_contact_cap = m->resolve_contacts ? 48 : ORC_MAXCON;
   const int gbox = m->ngeom;
   int robot_contacts = 0;
   /* ---- floor plane against the robot's geoms */

@@ -345,14 +345,22 @@ def franka_hand_tcp_offset() -> Pose:
     return Pose(_raw=out)
 
 
-# Contacts of the robot's geoms enter the constraint solve (False: they only raise the collision flags).  None = where the
-# HIP backend resolves them: scenes with a free body and without dry joint friction (rcsh_sim_add_free_box); elsewhere
-# robot contacts are DETECTED only, in the kernels and therefore here.
+# Contacts of the robot's geoms enter the constraint solve (False: they only raise the collision flags).  None = the HIP
+# backend's default (resolves_contacts below); an explicit bool mirrors rcs_amd.sim.Sim(resolve_robot_contacts=...).
 DEFAULT_RESOLVE_CONTACTS = None
 
 
+def can_resolve_contacts(cm) -> bool:
+    """What the HIP backend can resolve: the FR3 + hand archetype, elliptic cones, no dry joint friction."""
+    if np.any(np.asarray(cm.arrays["dof_frictionloss"]) > 0) or cm.cone != "elliptic":
+        return False
+    return bool(cm.njnt == 9 and cm.nu == 8 and cm.ngeom > 1)
+
+
 def resolves_contacts(cm) -> bool:
-    return bool(getattr(cm, "free_bodies", [])) and not np.any(np.asarray(cm.arrays["dof_frictionloss"]) > 0)
+    """The backend's DEFAULT: resolved in scenes with a free body (the pick-up task), detected only elsewhere (opt-in there:
+    rcs_amd.sim.Sim(..., resolve_robot_contacts=True))."""
+    return can_resolve_contacts(cm) and bool(getattr(cm, "free_bodies", []))
 
 
 class Sim:

@@ -588,6 +588,39 @@ RCSH_D double contact_qfrc(AR& ar, const StageTeam<T>& st, const ConLane& c, con
   return q;
 }
 
+// Second level of the broad phase, run by the lane of a link whose bounding box reached the floor or the cube: the same
+// tests on the bounding boxes of the link's GEOMS (boxes: the geom itself; hulls: the box of its vertices; capsule: its box).
+// Only then does the wavefront gang up on the environment.  R, p: world frame of the link.
+RCSH_CONTACT_FN bool geom_level_near(const ContactGeom* geoms, int g0, int g1, const double* R, const double* p, const double* pln, double pld,
+                                     bool has_plane, const double* boxc, double box_r2, bool has_box) {
+  for (int g = g0; g < g1; ++g) {
+    const ContactGeom& cg = geoms[g];
+    double gR[9], c[3], h[3], lc[3];
+    mulmm(R, cg.rot, gR);
+    if (cg.type == 7) { for (int k = 0; k < 3; ++k) { lc[k] = cg.aabb_c[k]; h[k] = cg.aabb_h[k]; } }
+    else if (cg.type == 6) { for (int k = 0; k < 3; ++k) { lc[k] = 0; h[k] = cg.size[k]; } }
+    else { lc[0] = lc[1] = lc[2] = 0; h[0] = h[1] = cg.size[0]; h[2] = cg.size[0] + cg.size[1]; }
+    double off[3], w[3];
+    mulmv(cg.rot, lc, off);
+    for (int k = 0; k < 3; ++k) off[k] += cg.pos[k];
+    mulmv(R, off, w);
+    for (int k = 0; k < 3; ++k) c[k] = w[k] + p[k];
+    if (has_plane && cg.plane_ok) {
+      double nl[3];
+      mulTv(gR, pln, nl);
+      if (dot3(pln, c) - pld - (fabs(nl[0]) * h[0] + fabs(nl[1]) * h[1] + fabs(nl[2]) * h[2]) <= 0) return true;
+    }
+    if (has_box && !(cg.type == 7 && cg.vert_num == 0)) {
+      const double d[3] = {boxc[0] - c[0], boxc[1] - c[1], boxc[2] - c[2]};
+      double v[3];
+      mulTv(gR, d, v);
+      const double ex = fmax(fabs(v[0]) - h[0], 0.0), ey = fmax(fabs(v[1]) - h[1], 0.0), ez = fmax(fabs(v[2]) - h[2], 0.0);
+      if (ex * ex + ey * ey + ez * ez <= box_r2) return true;
+    }
+  }
+  return false;
+}
+
 // ================================================================= phase 1: collision
 // Lane g tests collision geom g against the floor and the box; the contacts are compacted into MuJoCo's order -- (floor,
 // robot geoms) by geom, (floor, box), (robot geoms, box) by geom -- and left as records in ar.rec / ar.cb.
@@ -658,7 +691,9 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
             double dir[3];
             if (q == 0) { dir[0] = -n[0]; dir[1] = -n[1]; dir[2] = -n[2]; }
             else {
-              const double ang = 2 * M_PI * (q - 1) / 3, cs = 1e-3 * cos(ang), sn = 1e-3 * sin(ang);
+              // cos / sin of 2 pi (q - 1) / 3 as the C library rounds them (the oracle calls it)
+              const double kc[3] = {1.0, -0.4999999999999998, -0.5000000000000004}, ks[3] = {0.0, 0.8660254037844387, -0.8660254037844384};
+              const double cs = 1e-3 * kc[q - 1], sn = 1e-3 * ks[q - 1];
               for (int k = 0; k < 3; ++k) dir[k] = -n[k] + cs * t1[k] + sn * t2[k];
             }
             double dl[3], bestv = -INFINITY;
@@ -759,6 +794,10 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       bppos[nBP][0] = corner[0] + bp[0]; bppos[nBP][1] = corner[1] + bp[1]; bppos[nBP][2] = corner[2] + bp[2] - 0.5 * (dist + ld);
       ++nBP;
     }
+  }
+  if (__ballot(nP > 0 || nB > 0) == 0) {  // nothing of the robot touches anything: the fast path keeps the step
+    TEAM_MARK(25)
+    return 0u;
   }
   ar.cnt[lane][0] = nP;
   ar.cnt[lane][1] = nB;

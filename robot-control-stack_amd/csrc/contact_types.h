@@ -30,6 +30,8 @@ struct ContactTable {
   const ContactGeom* geoms;
   const double* verts;   // [nvert][3] hull vertices, geom frame
   int32_t ngeom, has_plane;
+  int32_t link_geom_adr[13];  // geoms of link i are [link_geom_adr[i], link_geom_adr[i + 1]) (kMaxLinks + 1 entries)
+  int32_t pad;
   double plane_n[3], plane_d, plane_mu;
 };
 

@@ -436,6 +436,7 @@ std::string build_collision_points(const HostModel& h, CollisionPoints& out) {
   }
   out.link_adr.assign(nl + 1, 0);
   out.link_sphere.assign(4 * (size_t)nl, 0.0);
+  out.link_aabb.assign(6 * (size_t)nl, 0.0);
   for (int i = 0; i < nl; ++i) {
     // broad phase: sphere around the centroid of the link's sample points
     const size_t np = ids[i].size();
@@ -448,6 +449,12 @@ std::string build_collision_points(const HostModel& h, CollisionPoints& out) {
       }
       for (int a = 0; a < 3; ++a) out.link_sphere[4 * i + a] = c[a];
       out.link_sphere[4 * i + 3] = rad;
+      for (int a = 0; a < 3; ++a) {
+        double lo = HUGE_VAL, hi = -HUGE_VAL;
+        for (size_t k = 0; k < np; ++k) { lo = std::fmin(lo, pts[i][4 * k + a] - pts[i][4 * k + 3]); hi = std::fmax(hi, pts[i][4 * k + a] + pts[i][4 * k + 3]); }
+        out.link_aabb[6 * i + a] = 0.5 * (lo + hi);
+        out.link_aabb[6 * i + 3 + a] = 0.5 * (hi - lo);
+      }
     }
     out.link_adr[i + 1] = out.link_adr[i] + (int)ids[i].size();
     out.xyzr.insert(out.xyzr.end(), pts[i].begin(), pts[i].end());

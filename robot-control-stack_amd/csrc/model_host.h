@@ -41,6 +41,7 @@ struct CollisionPoints {
   std::vector<int32_t> geom;      // [npts] geom id the point belongs to
   std::vector<int32_t> link_adr;  // [nl + 1] points of link i are [link_adr[i], link_adr[i+1])
   std::vector<double> link_sphere;  // [nl][4] bounding sphere (centre, radius) of link i's points, link frame
+  std::vector<double> link_aabb;    // [nl][6] bounding box of link i's points (radii included), link frame: centre, half extents
   bool has_plane = false;
   int plane_geom = -1;
   double plane_n[3] = {0, 0, 1};

@@ -118,6 +118,8 @@ Params make_params(rcsh_sim* s) {
   for (int i = 0; i <= kMaxLinks; ++i) P.coll.link_adr[i] = i < (int)s->cp.link_adr.size() ? s->cp.link_adr[i] : (s->cp.link_adr.empty() ? 0 : s->cp.link_adr.back());
   for (int i = 0; i < kMaxLinks; ++i)
     for (int a = 0; a < 4; ++a) P.coll.link_sphere[i][a] = (size_t)(4 * i + a) < s->cp.link_sphere.size() ? s->cp.link_sphere[4 * i + a] : 0.0;
+  for (int i = 0; i < kMaxLinks; ++i)
+    for (int a = 0; a < 6; ++a) P.coll.link_aabb[i][a] = (size_t)(6 * i + a) < s->cp.link_aabb.size() ? s->cp.link_aabb[6 * i + a] : 0.0;
   P.coll.has_plane = s->cp.has_plane && !s->cp.geom.empty();
   for (int k = 0; k < 3; ++k) P.coll.plane_n[k] = s->cp.plane_n[k];
   P.coll.plane_d = s->cp.plane_d;
@@ -133,8 +135,21 @@ Params make_params(rcsh_sim* s) {
   P.boxtask = s->d_boxtask;
   P.ctab.geoms = s->d_cgeoms;
   P.ctab.verts = s->d_cverts;
-  P.ctab.ngeom = s->box.present && s->box.resolve ? (int)s->cgeoms.size() : 0;
+  P.ctab.ngeom = s->box.resolve ? (int)s->cgeoms.size() : 0;
   P.ctab.has_plane = s->cp.has_plane;
+  {
+    // geoms of a link are contiguous in the table (geom order = body order); geoms welded to the world sit in front
+    static_assert(kMaxLinks + 1 == 13, "ContactTable::link_geom_adr");
+    for (int i = 0; i <= kMaxLinks; ++i) P.ctab.link_geom_adr[i] = 0;
+    int idx = 0;
+    const int ng = (int)s->cgeoms.size();
+    while (idx < ng && s->cgeoms[idx].link < 0) ++idx;
+    for (int i = 0; i < kMaxLinks; ++i) {
+      P.ctab.link_geom_adr[i] = idx;
+      while (idx < ng && s->cgeoms[idx].link == i) ++idx;
+    }
+    P.ctab.link_geom_adr[kMaxLinks] = idx;
+  }
   for (int k = 0; k < 3; ++k) P.ctab.plane_n[k] = s->cp.plane_n[k];
   P.ctab.plane_d = s->cp.plane_d;
   P.ctab.plane_mu = s->plane_mu;
@@ -209,16 +224,23 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   // finalisation and the shared math.)
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    if (s->box.present) {
-      // scenes with a free box: FR3 + hand, and the 7-dof arm with dry joint friction (rcsh_sim_add_free_box checks)
+    const dim3 grid(((s->n + 31) / 32) * 8), block(64);
+    if (s->box.present && s->box.resolve) {
+      // free box + contacts of the robot's geoms (FR3 + hand): rcsh_sim_add_free_box checked the archetype
+      if constexpr (T::NARM == 7 && T::GRIP) hipLaunchKernelGGL((k_run_team<T, false, true, true>), grid, block, 0, s->stream, P, op);
+    } else if (s->box.present) {
+      // scenes with a free box that only touches the floor: FR3 + hand, and the 7-dof arm with dry joint friction
       if constexpr (T::NARM == 7 && T::GRIP)
-        hipLaunchKernelGGL((k_run_team<T, false, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+        hipLaunchKernelGGL((k_run_team<T, false, true>), grid, block, 0, s->stream, P, op);
       else if constexpr (T::NARM == 7)
-        hipLaunchKernelGGL((k_run_team<T, true, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+        hipLaunchKernelGGL((k_run_team<T, true, true>), grid, block, 0, s->stream, P, op);
+    } else if (s->box.resolve) {
+      // no free body, contacts of the robot with the floor resolved (rcsh_sim_set_contact_options; FR3 + hand)
+      if constexpr (T::NARM == 7 && T::GRIP) hipLaunchKernelGGL((k_run_team<T, false, false, true>), grid, block, 0, s->stream, P, op);
     } else if (s->dm.has_friction)
-      hipLaunchKernelGGL((k_run_team<T, true>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+      hipLaunchKernelGGL((k_run_team<T, true>), grid, block, 0, s->stream, P, op);
     else
-      hipLaunchKernelGGL((k_run_team<T, false>), dim3(((s->n + 31) / 32) * 8), dim3(64), 0, s->stream, P, op);
+      hipLaunchKernelGGL((k_run_team<T, false>), grid, block, 0, s->stream, P, op);
     err = hipGetLastError();
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
@@ -880,6 +902,34 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   if (int rc = upload_boxtask(s)) return rc;
   if (int rc = upload_contact_table(s)) return rc;
   return rcsh_sim_reset_free_box(s);
+}
+int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
+  REQUIRE_SIM(s);
+  if (!o) return fail(RCSH_ERR_ARG, "null contact options");
+  if (s->box.present) return fail(RCSH_ERR_STATE, "this scene has a free box: its description (rcsh_sim_add_free_box) carries the contact options");
+  if (!o->resolve_robot_contacts) { s->box = BoxCfg{}; return RCSH_OK; }
+  if (!(s->narm == 7 && s->grip && !s->dm.has_friction)) return fail(RCSH_ERR_MODEL, "contacts of the robot's geoms are resolved for the FR3 + hand archetype (no dry joint friction)");
+  if (!o->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
+  if (!(o->impratio > 0)) return fail(RCSH_ERR_ARG, "impratio must be positive");
+  if (s->cgeoms.empty() || !s->cp.has_plane) return RCSH_OK;  // nothing the robot could touch
+  // the phantom box of the contact phase: unit inertia, zero size, parked 1 km above the scene
+  BoxCfg b{};
+  b.present = 0;
+  b.resolve = 1;
+  b.noslip_iterations = o->noslip_iterations;
+  b.qpos0[2] = 1000.0; b.qpos0[3] = 1.0;
+  b.mass = b.inv_mass = 1.0;
+  for (int k = 0; k < 3; ++k) { b.inertia[k] = b.inv_inertia[k] = 1.0; b.size[k] = 0.0; }
+  b.fr = b.geom_mu = 1.0;
+  make_kb(o->solref, o->solimp, s->dm.timestep, b.K, b.B);
+  b.imp = make_imp(o->solimp);
+  b.inv_impratio = 1.0 / o->impratio;
+  b.plane_z = s->cp.plane_d;
+  b.scale = 1.0 / (s->dm.inertia_diag_sum / s->nl * s->nl);  // 1 / (meaninertia * nv)
+  b.noslip_tolerance = o->noslip_tolerance;
+  s->box = b;
+  if (int rc = upload_boxtask(s)) return rc;
+  return upload_contact_table(s);
 }
 int rcsh_sim_reset_free_box(rcsh_sim* s) {
   REQUIRE_SIM(s);

@@ -108,6 +108,7 @@ struct CollTable {
   const uint8_t* cls;      // [npts] bit 0: geom is one of SimRobot's arm collision geoms; bit 1: SimGripper's
   int32_t link_adr[kMaxLinks + 1];
   double link_sphere[kMaxLinks][4];  // broad phase: bounding sphere of the link's points (link frame)
+  double link_aabb[kMaxLinks][6];    // broad phase of the contact phase: bounding box of the link's points (centre, half extents)
   int32_t has_plane;
   double plane_n[3], plane_d;
 };
@@ -546,7 +547,10 @@ __device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModelHea
 // The N-environment form of Sim.step / Sim.step_until_convergence / env.reset / env.step: one TEAM of 16 lanes per
 // environment (dyn_team.h), four environments per wavefront, one wavefront per workgroup.  Lane 0 of a team (the leader)
 // owns the RCS bookkeeping -- wrappers, callback scheduler, observation; all 16 lanes run the physics.
-template <class T, bool FRIC, bool BOX = false>
+// BOX: the scene has a free box (box_team.h).  CON: contacts of the robot's collision geoms are resolved (contact_team.h);
+// without a box the contact phase sees a phantom one parked far above the scene (zero size: it touches nothing, its six
+// dofs stay decoupled), so that one formulation serves the pick-up scene and the robot-on-the-floor case alike.
+template <class T, bool FRIC, bool BOX = false, bool CON = false>
 __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
@@ -614,9 +618,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     }
   }
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
-  __shared__ std::conditional_t<BOX, BoxTaskCfg, char> lbt[1];
+  __shared__ std::conditional_t<(BOX || CON), BoxTaskCfg, char> lbt[1];
   {
-    if constexpr (BOX) {
+    if constexpr (BOX || CON) {
       static_assert(sizeof(BoxTaskCfg) % 8 == 0, "copied in 8-byte words");
       for (int k = threadIdx.x; k < (int)(sizeof(BoxTaskCfg) / 8); k += 64)
         reinterpret_cast<double*>(&lbt[0])[k] = reinterpret_cast<const double*>(Pk.boxtask)[k];
@@ -672,9 +676,13 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // two plain callbacks fire every `period` of simulated time, so the leader only looks at them when the earlier
   // of their two timestamps is due.
   // the free box of the scene: its state sits in the team's LDS block between substeps (box_team.h)
-  __shared__ double lbox[BOX ? kBoxLds * kTeams : 1];
-  __shared__ std::conditional_t<(BOX && !FRIC), ContactArena<T>, char> larena[1];  // the contact phase's workspace: one per wavefront
-  double* const bs = lbox + (BOX ? team * kBoxLds : 0);
+  __shared__ double lbox[(BOX || CON) ? kBoxLds * kTeams : 1];
+  __shared__ std::conditional_t<CON, ContactArena<T>, char> larena[1];  // the contact phase's workspace: one per wavefront
+  double* const bs = lbox + ((BOX || CON) ? team * kBoxLds : 0);
+  if constexpr (CON && !BOX) {
+    // the phantom box: at rest where the host parked it
+    for (int k = t; k < kBoxState; k += kTeamLanes) bs[k] = k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre ? lbt[0].box.qpos0[k - kBoxPre] : 0.0);
+  }
   if constexpr (BOX) {
     if (live) {
       using L = Lay<T>;
@@ -694,6 +702,18 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   const bool gc_is_mass = team_gc_is_mass<T>(llinks, t);
   SubstepK sk;
   sk.load(m);
+  // broad phase of the contact phase, per lane: the link's bounding box, the floor plane, the box's bounding sphere
+  double bbc[3] = {0, 0, 0}, bbh[3] = {0, 0, 0}, pln[3] = {0, 0, 1}, pld = 0, box_r2 = 0;
+  bool con_lane = false;
+  if constexpr (CON) {
+    con_lane = t < T::NL && lp.ctab.ngeom > 0;
+    const int tl = t < T::NL ? t : 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { bbc[k] = lc.link_aabb[tl][k]; bbh[k] = lc.link_aabb[tl][3 + k]; pln[k] = lc.plane_n[k]; }
+    pld = lc.plane_d;
+    const BoxCfg& bc = lbt[0].box;
+    box_r2 = bc.size[0] * bc.size[0] + bc.size[1] * bc.size[1] + bc.size[2] * bc.size[2];
+  }
   TEAM_MARK(11)
   while (going) {
     const bool stepping = (going >> (threadIdx.x & 48)) & 1u;
@@ -715,17 +735,28 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     bool near = false;  // broad phase of the contact phase: the lane's link may touch the floor or the box
     bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
     team_substep<T, FRIC>(m, sk, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
-      if constexpr (BOX && !FRIC) {
-        if (stepping && t < T::NL && lp.ctab.ngeom > 0) {
-          const double* sph = lc.link_sphere[t];
+      if constexpr (CON) {
+        if (stepping && con_lane) {
+          // the link's bounding box (link frame) against the floor -- its support along the plane normal -- and against
+          // the box's bounding sphere: tight enough that an arm in its workspace does not wake the contact phase
           double c[3];
-          mulmv(R, sph, c);
+          mulmv(R, bbc, c);
           c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
-          const BoxCfg& bc = lbt[0].box;
-          const double dx = c[0] - bs[kBoxQ], dy = c[1] - bs[kBoxQ + 1], dz = c[2] - bs[kBoxQ + 2];
-          const double rs = sph[3] + sqrt(bc.size[0] * bc.size[0] + bc.size[1] * bc.size[1] + bc.size[2] * bc.size[2]);
-          near = dx * dx + dy * dy + dz * dz <= rs * rs;
-          if (lc.has_plane) near = near || dot3(lc.plane_n, c) - lc.plane_d - sph[3] <= 0;
+          if constexpr (BOX) {
+            const double d[3] = {bs[kBoxQ] - c[0], bs[kBoxQ + 1] - c[1], bs[kBoxQ + 2] - c[2]};
+            double v[3];
+            mulTv(R, d, v);
+            const double ex = fmax(fabs(v[0]) - bbh[0], 0.0), ey = fmax(fabs(v[1]) - bbh[1], 0.0), ez = fmax(fabs(v[2]) - bbh[2], 0.0);
+            near = ex * ex + ey * ey + ez * ez <= box_r2;
+          }
+          if (has_plane) {
+            double nl[3];
+            mulTv(R, pln, nl);
+            near = near || dot3(pln, c) - pld - (fabs(nl[0]) * bbh[0] + fabs(nl[1]) * bbh[1] + fabs(nl[2]) * bbh[2]) <= 0;
+          }
+          // second level: the same tests on the boxes of the link's geoms
+          if (near)
+            near = geom_level_near(lp.ctab.geoms, lp.ctab.link_geom_adr[t], lp.ctab.link_geom_adr[t + 1], R, p, pln, pld, has_plane, bs + kBoxQ, box_r2, BOX);
         }
       }
       if (!want_contacts) return;
@@ -745,9 +776,15 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
     }, [&]() -> bool {
       bool coupled = false;
-      if constexpr (BOX && !FRIC) {
+      if constexpr (CON) {
         // teams whose broad phase fired take turns: the whole wavefront works on one environment's contacts (contact_team.h)
         const uint64_t nearw = __ballot(near);
+#ifdef RCSH_PHASE_TIMING
+        if (threadIdx.x == 0) {  // (all workgroups) substeps of wavefronts / with a woken contact phase / teams woken
+          atomicAdd(&g_team_cycles[41], 1ull);
+          if (nearw) { atomicAdd(&g_team_cycles[40], 1ull); atomicAdd(&g_team_cycles[42], (unsigned long long)__popcll(nearw & 0x0001000100010001ull | (nearw >> 1 & 0) )); }
+        }
+#endif
         if (nearw) {
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;

@@ -67,6 +67,24 @@ class FreeBoxDesc(C.Structure):
     ]
 
 
+class ContactOptions(C.Structure):
+    _fields_ = [
+        ("impratio", C.c_double), ("noslip_tolerance", C.c_double), ("noslip_iterations", C.c_int32), ("cone_elliptic", C.c_int32),
+        ("solref", C.c_double * 2), ("solimp", C.c_double * 5), ("resolve_robot_contacts", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+def make_contact_options(cm, resolve_robot_contacts: bool = True) -> ContactOptions:
+    """rcsh_contact_options of a compiled scene: mjModel.opt's solver options + the default contact solref / solimp."""
+    o = ContactOptions()
+    o.impratio, o.noslip_tolerance, o.noslip_iterations = float(cm.impratio), 1e-6, int(cm.noslip_iterations)
+    o.cone_elliptic = int(cm.cone == "elliptic")
+    o.solref[:] = [0.02, 1.0]
+    o.solimp[:] = [0.9, 0.95, 0.001, 0.5, 2.0]
+    o.resolve_robot_contacts = int(resolve_robot_contacts)
+    return o
+
+
 def make_free_box_desc(cm, resolve_robot_contacts: bool = True) -> FreeBoxDesc | None:
     """rcsh_free_box_desc of a compiled scene's free body (None: the scene has none)."""
     free = getattr(cm, "free_bodies", [])
@@ -144,7 +162,7 @@ EXPORTS = (
     "rcsh_ik_inverse", "rcsh_ik_forward", "rcsh_sim_add_gripper", "rcsh_gripper_set_normalized_width",
     "rcsh_gripper_get_normalized_width", "rcsh_gripper_is_grasped", "rcsh_gripper_reset", "rcsh_gripper_get_state",
     "rcsh_sim_get_qpos", "rcsh_sim_get_qvel", "rcsh_sim_get_ctrl", "rcsh_sim_get_time", "rcsh_sim_set_qpos",
-    "rcsh_sim_set_qvel", "rcsh_sim_add_free_box", "rcsh_sim_reset_free_box", "rcsh_sim_get_free_qpos", "rcsh_sim_get_free_qvel",
+    "rcsh_sim_set_qvel", "rcsh_sim_add_free_box", "rcsh_sim_set_contact_options", "rcsh_sim_reset_free_box", "rcsh_sim_get_free_qpos", "rcsh_sim_get_free_qvel",
     "rcsh_sim_set_free_qpos", "rcsh_sim_set_free_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
     "rcsh_sim_set_render_scene", "rcsh_sim_add_camera", "rcsh_camera_render", "rcsh_camera_render_dev",
@@ -189,6 +207,7 @@ def load() -> C.CDLL:
     L.rcsh_sim_set_state.argtypes = [C.c_void_p, C.c_void_p]
     L.rcsh_sim_create.argtypes = [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.rcsh_sim_add_free_box.argtypes = [C.c_void_p, C.POINTER(FreeBoxDesc)]
+    L.rcsh_sim_set_contact_options.argtypes = [C.c_void_p, C.POINTER(ContactOptions)]
     L.rcsh_sim_reset_free_box.argtypes = [C.c_void_p]
     for fn in (L.rcsh_sim_get_free_qpos, L.rcsh_sim_get_free_qvel):
         fn.argtypes = [C.c_void_p, C.c_void_p]

@@ -44,7 +44,7 @@ class Sim:
     """
 
     def __init__(self, mjmdl: str | PathLike, cfg: SimConfig | None = None, n_envs: int = 1, device: int = 0,
-                 resolve_robot_contacts: bool = True):
+                 resolve_robot_contacts: bool | None = None):
         path = Path(mjmdl)
         if path.suffix == ".mjb":
             path = path.with_suffix(".xml")  # scenes are registered by their .mjb name in the reference
@@ -58,13 +58,31 @@ class Sim:
         desc, self._keep = _lib.make_model_desc(self.model)
         self._h = C.c_void_p()
         _lib.check(self._L.rcsh_sim_create(C.byref(desc), self.n_envs, self.device, C.byref(self._h)))
-        # scenes with a free body: the robot's collision geoms push against it and the floor (False: detection only)
-        box = _lib.make_free_box_desc(self.model, resolve_robot_contacts)
+        # Contacts of the robot's collision geoms (with the floor, with a free body): RESOLVED by default where there is
+        # something to manipulate (scenes with a free body: the pick-up task), DETECTED only (collision flags, as the
+        # callbacks need them) in scenes without -- there the contact-capable kernel costs the no-contact rollout ~15 %, so it
+        # is opt-in: Sim(..., resolve_robot_contacts=True) makes the arm stop on the floor instead of passing through it.
+        has_free = bool(getattr(self.model, "free_bodies", []))
+        resolve = has_free if resolve_robot_contacts is None else bool(resolve_robot_contacts)
+        self.resolve_robot_contacts = resolve and self.resolves_robot_contacts(self.model)
+        box = _lib.make_free_box_desc(self.model, self.resolve_robot_contacts)
         if box is not None:
             _lib.check(self._L.rcsh_sim_add_free_box(self._h, C.byref(box)))
+        elif self.resolve_robot_contacts:
+            opts = _lib.make_contact_options(self.model, True)
+            _lib.check(self._L.rcsh_sim_set_contact_options(self._h, C.byref(opts)))
         self._cfg = SimConfig()
         if cfg is not None:
             self.set_config(cfg)
+
+    @staticmethod
+    def resolves_robot_contacts(model: Model) -> bool:
+        """Scenes whose robot-geom contacts CAN enter the constraint solve: the FR3 + hand archetype (7 arm joints + two fingers,
+        no dry joint friction) with elliptic cones and collision geoms; elsewhere contacts only raise the collision flags."""
+        import numpy as np
+
+        return bool(model.njnt == 9 and model.nu == 8 and model.cone == "elliptic" and not np.any(np.asarray(model.arrays["dof_frictionloss"]) > 0)
+                    and model.ngeom > 1)
 
     def __del__(self):
         h = getattr(self, "_h", None)

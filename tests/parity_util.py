@@ -734,3 +734,55 @@ def run_pick_success_parity(n_envs=3, seed=0):
             rep["steps"] += 1
     venv.close()
     return rep
+
+
+def run_floor_contact_parity(n_envs=8, seed=0):
+    """fr3_empty_world with robot contacts RESOLVED (opt-in: Sim(resolve_robot_contacts=True)): every environment drives its arm
+    into the floor (hand and forearm come down on it), kernel vs oracle; the arm must stop ON the floor instead of sinking
+    through it, the collision flags must fire in both."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs, resolve_robot_contacts=True)
+    assert simu.resolve_robot_contacts
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0", resolve_contacts=True) for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    simu.reset(); robot.reset(); grip.reset()
+    for o in osims:
+        o.reset(); o.robot_reset(); o.gripper_reset()
+    # the reference's own collision configuration (python/tests/test_sim_envs.py:347-360) and variations of it
+    tgt = np.tile([0, 1.78, 0, -1.45, 0, 0, 0], (n_envs, 1)) + rng.uniform(-0.15, 0.15, (n_envs, 7)) * (np.arange(n_envs) > 0)[:, None]
+    tgt = np.clip(tgt, [-2.7, -1.78, -2.9, -3.04, -2.8, 0.55, -3.0], [2.7, 1.78, 2.9, -0.16, 2.8, 4.5, 3.0])
+    robot.set_joint_position(tgt)
+    for e, o in enumerate(osims):
+        o.set_joint_position(tgt[e])
+    rep = {"max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "flag_mismatches": 0, "coupled_substeps": 0, "max_ncon": 0, "collisions": 0, "min_z": 9.0}
+    for call in range(8):
+        simu.step(100)
+        q, v = simu.qpos, simu.qvel
+        for e, o in enumerate(osims):
+            for _ in range(100):
+                o.step(1)
+                rep["coupled_substeps"] += int(o.s.d.coupled)
+                rep["max_ncon"] = max(rep["max_ncon"], int(o.s.d.ncon))
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - np.asarray(o.qpos)).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - np.asarray(o.qvel)).max()))
+    simu.step_until_convergence()
+    st, gs = robot.get_state(), grip.get_state()
+    for e, o in enumerate(osims):
+        o.step_until_convergence()
+        rep["flag_mismatches"] += int(bool(st.collision[e]) != bool(o.s.robot_collision)) + int(bool(gs.collision[e]) != bool(o.s.grp_collision))
+        rep["flag_mismatches"] += int(int(simu.convergence_steps()[e]) != int(o.s.convergence_steps))
+        rep["collisions"] += int(bool(o.s.robot_collision) or bool(o.s.grp_collision))
+        rep["min_z"] = min(rep["min_z"], float(o.get_cartesian_position().translation()[2]))
+    rep["tracking_error"] = float(np.abs(simu.qpos[:, :7] - tgt).max())
+    simu.close()
+    return rep

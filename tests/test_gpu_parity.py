@@ -841,3 +841,14 @@ def test_pybind_module_equals_ctypes_host_layer(kernel):
         _core.sim.SimRobot(b, None, bad)  # names without the "_0" suffix: the reference's runtime_error
     a.close()
     del rb, gb, b
+
+
+def test_robot_on_the_floor_resolved_contacts(kernel):
+    """Robot <-> floor contacts as FORCES (opt-in in scenes without a free body): the reference's folded-arm collision case
+    and variations; hull / pad / capsule contacts with the plane, the coupled solve without a box (phantom box), noslip."""
+    from parity_util import run_floor_contact_parity
+
+    rep = run_floor_contact_parity(n_envs=8, seed=2)
+    assert rep["coupled_substeps"] > 500 and rep["max_ncon"] >= 2 and rep["collisions"] == 8, rep
+    assert rep["max_abs_qpos"] < 1e-7 and rep["max_abs_qvel"] < 1e-5 and rep["flag_mismatches"] == 0, rep
+    assert rep["tracking_error"] > 0.05, rep  # the floor keeps the arm from reaching its target
