@@ -9,9 +9,9 @@
  * PARITY UNPINNED: everything here restates MuJoCo 3.2.6 (absent from /root/reference and from this image) from its
  * published description -- free-joint kinematics and integration, the plane-box collider, contact parameter mixing,
  * the constraint impedance / reference acceleration, the elliptic-cone primal cost with its three zones, and the
- * noslip post-pass (dual PGS on the friction dimensions without regularisation).  The box shares no constraint row
- * with the robot in this revision (robot-box contacts are not built), so its block of the constrained problem
- * separates exactly and is solved on its own; the solver iterates the same strictly convex cost MuJoCo's Newton
+ * noslip post-pass (dual PGS on the friction dimensions without regularisation).  While no robot geom touches the box it shares no
+ * constraint row with the robot, so its block of the constrained problem separates exactly and is solved on its own
+ * (orc_box_step2; with robot-box contacts the coupled problem of rcs_contact.c takes over: orc_box_smooth / orc_box_integrate); the solver iterates the same strictly convex cost MuJoCo's Newton
  * does, to a tighter tolerance.  The noslip pass is NOT iterated to convergence in MuJoCo (5 sweeps), so it is
  * restated sweep by sweep, including the early exit on the scaled cost improvement.
  */

@@ -4,8 +4,8 @@
 // friction cones, impratio 20, 5 noslip iterations), which RandomCubePos places and PickCubeSuccessWrapper reads
 // (python/rcs/envs/sim.py:358-431).
 //
-// The box shares no constraint row with the robot (robot-box contacts are not built), so its 6 degrees of freedom
-// are a separate block of the constrained forward dynamics: free-joint kinematics, plane-box collision (at most four
+// While no robot geom touches the box (contact_team.h otherwise: `coupled`) it shares no constraint row with the robot, so its
+// 6 degrees of freedom are a separate block of the constrained forward dynamics: free-joint kinematics, plane-box collision (at most four
 // corner contacts), one elliptic-cone contact of three rows per corner, Newton on the primal cost with an exact line
 // search, the noslip post-pass (Gauss-Seidel over the contacts' friction rows without regularisation; deliberately
 // only a few sweeps, as in MuJoCo), semi-implicit Euler with quaternion integration.

@@ -334,8 +334,8 @@ __device__ __forceinline__ void cartesian_position(const DevModelHead& m, const 
 }
 
 // What env.step() reads per environment before the simulator is stepped: the action, the gripper command and the
-// wrappers' remembered vectors.  StepInGlobal fetches from HBM where the value is used (lane kernel); the team kernel
-// has its 16 lanes fetch all of it ahead of time into LDS (StepInStaged; entry k of the list is `fetch(k)`).
+// wrappers' remembered vectors.  StepInGlobal names where each value lives in HBM; the team kernel has its 16 lanes fetch all of
+// it ahead of time into LDS (StepInStaged; entry k of the list is `fetch(k)`).
 template <class T>
 struct StepInGlobal {
   using L = Lay<T>;
