@@ -135,10 +135,12 @@ def main() -> None:
                     help="env.reset() every this many steps (inside the timed region; resets are not counted as env-steps). "
                          "Default: none for joints; 10 for cartesian, as the reference's examples loop (reset + 10 steps) -- a longer "
                          "random walk of Cartesian targets leaves the workspace and the CLIK then runs to its 1000-iteration cap")
-    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box", "arm6", "mixed"], default="fr3",
+    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box", "arm6", "ur5e", "so101", "mixed"], default="fr3",
                     help="xarm7: 7-dof arm with dry joint friction, no gripper; xarm7_box: the same next to a free cube with floor contacts "
-                         "(builder-authored scene xarm7_box_world, camera side_cam); arm6: builder-authored 6-dof arm (Topo<6,false>); mixed: even ranks FR3, odd ranks xArm7 -- sharding by robot type, "
-                         "one specialised kernel per GPU, as BASELINE configs[4] asks (not the headline)")
+                         "(builder-authored scene xarm7_box_world, camera side_cam); arm6 / ur5e: builder-authored 6-dof arms (Topo<6,false>); "
+                         "so101: builder-authored 5-dof arm + two-finger gripper (Topo<5,true>); mixed: FR3 / xArm7 / UR5e / SO101 sharded by robot "
+                         "type -- rank r runs type r mod 4 with one specialised kernel per GPU, as BASELINE configs[4] asks; with fewer than 4 "
+                         "ranks a rank hosts several types as sub-batches on streams of their own (throughput only, not the headline)")
     ap.add_argument("--task", choices=["none", "pick_up"], default="none",
                     help="pick_up = the registered gym task rcs/FR3SimplePickUpSim-v0 (fr3_simple_pick_up scene: free cube on the floor with "
                          "elliptic-cone contacts + noslip, RandomCubePos on reset, PickCubeSuccessWrapper reward; relative TRPY control, 30 Hz); "
@@ -196,8 +198,15 @@ def main() -> None:
     n = args.envs
     T = args.steps + args.warmup
     mixed = args.robot == "mixed"
+    MIXED_TYPES = ("fr3", "xarm7", "ur5e", "so101")
+    hosted = [args.robot]
     if mixed:
-        args.robot = "fr3" if rank % 2 == 0 else "xarm7"  # same observation width (21), so one all-gather serves both
+        if args.task != "none" or args.control != "joints" or args.cameras:
+            raise SystemExit("bench.py: --robot mixed is a JOINTS-mode throughput configuration (no task, no cameras)")
+        hosted = [MIXED_TYPES[rank % 4]] if world >= 4 else [MIXED_TYPES[i] for i in range(4) if i % world == rank]
+        if n % len(hosted):
+            raise SystemExit(f"bench.py: --envs {n} does not split over the {len(hosted)} robot types this rank hosts")
+        args.robot = hosted[0]
     if args.task == "pick_up":
         from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
 
@@ -209,8 +218,14 @@ def main() -> None:
         env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank,
                            control_mode=ControlMode.CARTESIAN_TRPY, max_relative_movement=(0.2, float(np.deg2rad(45))), robot=args.robot)
     else:
-        env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=args.robot)
-    env.sim.set_stream(torch.cuda.current_stream().cuda_stream)
+        env = make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=args.robot)
+    # a rank that hosts several robot types (mixed, fewer than 4 ranks): one sub-batch per type, each on a stream of its own so
+    # that the sub-batches' launches (each too small to fill the chip) run side by side
+    envs = [env] + [make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=r)
+                    for r in hosted[1:]]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in envs[1:]]
+    for e_, st_ in zip(envs, streams):
+        e_.sim.set_stream(st_.cuda_stream)
     L, h = env._L, env.sim._h
 
     # synthetic actions, resident in HBM (joints ~ U(+-5 deg)^7 f64, gripper ~ U(0,1) f32)
@@ -220,9 +235,11 @@ def main() -> None:
         scale = torch.tensor([0.05, 0.05, 0.05, 0.1, 0.1, 0.1], device="cuda", dtype=torch.float64)
         joints = (torch.rand((T, n, 6), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * scale
     else:
-        joints = (torch.rand((T, n, env.dof), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV
+        joints = (torch.rand((T, env.n_envs, env.dof), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV
     grip = torch.rand((T, n), generator=gen, device="cuda", dtype=torch.float32)
-    ow = env.obs_width
+    # (sub-batches of other robot types: their own action tensors; info / width / substep outputs are sliced from the rank's)
+    sub_joints = [joints] + [(torch.rand((T, e_.n_envs, e_.dof), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV for e_ in envs[1:]]
+    ow = max(e_.obs_width for e_ in envs) if not mixed else 21  # mixed: every rank's block is n x 21 doubles, narrower rows packed at its start
     obs = torch.zeros((n, ow), device="cuda", dtype=torch.float64)
     info = torch.zeros((n, 8), device="cuda", dtype=torch.uint8)
     gw = torch.zeros((n,), device="cuda", dtype=torch.float64)
@@ -241,7 +258,7 @@ def main() -> None:
         dist.broadcast(uid, 0)
         comm_error = ""
         try:
-            exchange = RcclObservationExchange(env.sim, bytes(uid.cpu().numpy().tobytes()), rank, world)
+            exchange = RcclObservationExchange(env.sim, bytes(uid.cpu().numpy().tobytes()), rank, world, n_rows=n, width=ow)
         except RuntimeError as exc:  # e.g. a communicator RCCL refuses on this topology
             comm_error = str(exc)
         okflag = torch.tensor([0 if comm_error else 1], device="cuda")
@@ -287,7 +304,11 @@ def main() -> None:
         if box_pose is not None:
             env.reset_task_dev(box_pose[t // max(episode, 1)].data_ptr(), obs.data_ptr(), info.data_ptr(), gw.data_ptr())
         else:
-            env.reset_dev(obs.data_ptr(), info.data_ptr(), gw.data_ptr())
+            row = 0
+            for e_ in envs:
+                e_.reset_dev(obs.data_ptr() + 8 * row * ow, info[row:].data_ptr(), gw[row:].data_ptr())
+                row += e_.n_envs
+            torch.cuda.synchronize()
 
     def one_step(t: int) -> None:
         if episode and t % episode == 0:
@@ -297,6 +318,13 @@ def main() -> None:
             env.step_task_dev(joints[t].data_ptr(), grip[t].data_ptr(), optr, info.data_ptr(), gw.data_ptr(), sub.data_ptr(), task_out.data_ptr())
         else:
             env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), optr, info.data_ptr(), gw.data_ptr(), sub.data_ptr())
+        row = env.n_envs
+        for e_, st_, j_ in zip(envs[1:], streams[1:], sub_joints[1:]):
+            st_.wait_stream(streams[0])  # (the slot of the exchange this step writes was released on the first stream)
+            e_.step_dev(j_[t].data_ptr(), grip[t, row:].data_ptr(), optr + 8 * row * ow, info[row:].data_ptr(), gw[row:].data_ptr(), sub[row:].data_ptr())
+            row += e_.n_envs
+        for st_ in streams[1:]:
+            streams[0].wait_stream(st_)  # the gather (and the clock) see all sub-batches
         for c, buf in cam_out.items():
             cam_set.render_depth_mm_dev(c, buf.data_ptr())
         if exchange:
@@ -343,12 +371,18 @@ def main() -> None:
     if task_out is not None:
         finite = finite and bool(torch.isfinite(task_out).all().item())
 
+    SCENE_OF = {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world", "arm6": "arm6_empty_world",
+                "ur5e": "ur5e_empty_world", "so101": "so101_empty_world"}
+    SCENE_LABEL = {**SCENE_OF, "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)", "arm6": "arm6_empty_world (builder-authored 6-dof arm)",
+                   "ur5e": "ur5e_empty_world (builder-authored, UR5e proportions)", "so101": "so101_empty_world (builder-authored 5-dof arm + two-finger gripper)"}
+    mixed_label = ("fr3 / xarm7 / ur5e (builder-authored) / so101 (builder-authored) _empty_world, robot type = rank mod 4" if world >= 4 else
+                   f"fr3 / xarm7 / ur5e (builder-authored) / so101 (builder-authored) _empty_world, {len(hosted)} types per rank as sub-batches of {n // len(hosted)} on streams of their own")
     if rank == 0:
         total_env_steps = world * n * args.steps
         value = total_env_steps / elapsed
-        algo_bytes = ALGO_BYTES_PER_ENV_STEP * n
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP * env.n_envs  # (the timed kernel is the first sub-batch's when a rank hosts several)
         achieved_gbs = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        substeps_per_launch = mean_sub * n
+        substeps_per_launch = mean_sub * env.n_envs
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
         headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
@@ -358,7 +392,7 @@ def main() -> None:
         out = {
             "metric": "env-steps/sec (whole node), " + (
                 "fr3_simple_pick_up task (CARTESIAN_TRPY)" if args.task != "none" else
-                ("fr3_empty_world + xarm7_empty_world by rank" if mixed else {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world", "arm6": "arm6_empty_world"}[args.robot])
+                ("fr3 / xarm7 / ur5e / so101 _empty_world by rank" if mixed else SCENE_OF[args.robot])
                 + (" JOINTS mode" if args.control == "joints" else " CARTESIAN_TRPY mode"))
                 + (", step_until_convergence" if args.mode == "convergence" else "") + f", {n} envs per GPU",
             "value": value,
@@ -376,7 +410,7 @@ def main() -> None:
                 "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off"
                              if args.control == "joints" else
                              f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
-                             ).replace("fr3_empty_world", ("fr3_empty_world on even ranks / xarm7_empty_world on odd ranks" if mixed else {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)", "arm6": "arm6_empty_world (builder-authored 6-dof arm)"}[args.robot]) if args.task == "none" else
+                             ).replace("fr3_empty_world", (mixed_label if mixed else SCENE_LABEL[args.robot]) if args.task == "none" else
                                        "fr3_simple_pick_up (free cube: plane-box contacts, elliptic cones, noslip; RandomCubePos + PickCubeSuccessWrapper)"),
                 "mode": "async_control 30Hz (17 substeps/env-step)" if args.mode == "async" else "step_until_convergence (cap 500)",
                 "envs_per_gpu": n,

@@ -44,6 +44,20 @@ ARM6 = dict(  # scenes/arm6_empty_world (builder-authored 6-dof arm); home pose 
     low=np.array([-2 * np.pi, -2 * np.pi, -np.pi, -2 * np.pi, -2 * np.pi, -2 * np.pi]),
     high=np.array([2 * np.pi, 2 * np.pi, np.pi, 2 * np.pi, 2 * np.pi, 2 * np.pi]),
     gripper_joint=None, gripper_actuator=None, arm_collision_geoms=[])
+UR5E = dict(  # scenes/ur5e_empty_world (builder-authored, public DH lengths); home pose and limits: Robot.h's UR5e entry
+    joints=[f"{a}_joint" for a in ("shoulder_pan", "shoulder_lift", "elbow", "wrist_1", "wrist_2", "wrist_3")],
+    actuators=["shoulder_pan", "shoulder_lift", "elbow", "wrist_1", "wrist_2", "wrist_3"], site="attachment_site", base="base",
+    q_home=ARM6["q_home"], low=ARM6["low"], high=ARM6["high"], gripper_joint=None, gripper_actuator=None, arm_collision_geoms=[])
+# scenes/so101_empty_world (builder-authored 5-dof arm + two-finger gripper).  Robot.h's SO101 entry is in the servo bus's
+# normalised units (-100 .. 100); a simulation reads it mapped linearly onto the joints' ranges (rcs_amd.common.sim_robots_meta_config)
+_SO101_LO = np.array([-1.91986, -1.74533, -1.69, -1.65806, -2.74385])
+_SO101_HI = np.array([1.91986, 1.74533, 1.69, 1.65806, 2.84121])
+_SO101_HOME_NORM = np.array([-9.40612320177057, -99.66130397967824, 99.9124726477024, 69.96996996996998, -9.095744680851055])  # Robot.h:82-84
+SO101 = dict(
+    joints=["shoulder_pan", "shoulder_lift", "elbow_flex", "wrist_flex", "wrist_roll"], actuators=[f"act{i}" for i in range(1, 6)],
+    site="attachment_site", base="base", q_home=_SO101_LO + (_SO101_HOME_NORM + 100.0) / 200.0 * (_SO101_HI - _SO101_LO),
+    low=_SO101_LO.copy(), high=_SO101_HI.copy(), gripper_joint="finger_joint1", gripper_actuator="gripper_act", arm_collision_geoms=[],
+    gripper_cfg=dict(max_joint_width=0.03, collision_geoms=[], collision_geoms_fingers=[]))
 TRPY_LOW = np.array([-0.855, -0.855, 0.0])  # base.py:31-38
 TRPY_HIGH = np.array([0.855, 0.855, 1.188])
 
@@ -59,7 +73,7 @@ class OracleEnv:
             cm, robot["joints"], robot["actuators"], robot["site"], robot["base"], robot["q_home"], tcp_offset,
             gripper_joint=robot["gripper_joint"] if gripper else None,
             gripper_actuator=robot["gripper_actuator"] if gripper else None,
-            arm_collision_geoms=robot.get("arm_collision_geoms"),
+            arm_collision_geoms=robot.get("arm_collision_geoms"), gripper_cfg=robot.get("gripper_cfg"),
         )
         self.sim.set_config(async_control=async_control, frequency=frequency, max_convergence_steps=max_convergence_steps)
         self.timestep = cm.timestep

@@ -369,7 +369,9 @@ class Sim:
     def __init__(self, cm, robot_joints, robot_actuators, attachment_site, base, q_home, tcp_offset: Pose | None = None,
                  gripper_joint: str | None = None, gripper_actuator: str | None = None,
                  register_convergence_callback: bool = True, idx: str = "0", arm_collision_geoms: list[str] | None = None,
-                 resolve_contacts: bool | None = None):
+                 resolve_contacts: bool | None = None, gripper_cfg: dict | None = None):
+        """`gripper_cfg`: SimGripperConfig fields that differ from the reference's defaults (SimGripper.h:15-45):
+        `max_joint_width`, `collision_geoms`, `collision_geoms_fingers` (full geom names)."""
         L = lib()
         self.cm = cm
         if resolve_contacts is None:
@@ -388,6 +390,9 @@ class Sim:
         if gripper_joint is not None:
             L.orc_sim_add_gripper(C.byref(self.s), self._id("jnt", gripper_joint, "joint"),
                                   self._id("actuator", gripper_actuator, "actuator"))
+            if gripper_cfg and "max_joint_width" in gripper_cfg:
+                self.s.max_joint_width = float(gripper_cfg["max_joint_width"])
+                L.orc_gripper_reset(C.byref(self.s))
         self.n = n
         # SimRobotConfig.arm_collision_geoms / SimGripperConfig collision geom lists (SimRobot.h:19-22, SimGripper.h:24-29)
         if arm_collision_geoms is None:
@@ -395,9 +400,11 @@ class Sim:
         arm_g = [self._id("geom", g, "geom") for g in arm_collision_geoms]
         L.orc_sim_set_robot_cgeoms(C.byref(self.s), len(arm_g), (I * max(len(arm_g), 1))(*arm_g))
         if gripper_joint is not None:
-            cg = [self._id("geom", f"{g}_{idx}", "geom") for g in ("hand_c", "d435i_collision", "finger_0_left", "finger_0_right")]
-            cf = [self._id("geom", f"{g}_{idx}", "geom") for g in ("finger_0_left", "finger_0_right")]
-            L.orc_sim_set_gripper_cgeoms(C.byref(self.s), len(cg), (I * len(cg))(*cg), len(cf), (I * len(cf))(*cf), 0, (I * 1)(0))
+            names = (gripper_cfg or {}).get("collision_geoms", [f"{g}_{idx}" for g in ("hand_c", "d435i_collision", "finger_0_left", "finger_0_right")])
+            fnames = (gripper_cfg or {}).get("collision_geoms_fingers", [f"{g}_{idx}" for g in ("finger_0_left", "finger_0_right")])
+            cg = [self._id("geom", g, "geom") for g in names]
+            cf = [self._id("geom", g, "geom") for g in fnames]
+            L.orc_sim_set_gripper_cgeoms(C.byref(self.s), len(cg), (I * max(len(cg), 1))(*cg), len(cf), (I * max(len(cf), 1))(*cf), 0, (I * 1)(0))
 
     def _id(self, kind, name, label):
         i = self.cm.name2id(kind, name)

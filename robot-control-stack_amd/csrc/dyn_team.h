@@ -112,12 +112,12 @@ __shared__ unsigned long long s_team_mark;
 // LDS traffic of one wave is ordered; the barrier is there for the compiler (and costs nothing with one wave)
 RCSH_D void team_sync() { __syncthreads(); }
 
-// ---- scans over the link tree.  BANKS_CHAIN / the extra round implement "both fingers hang off the last arm
-// link": lanes 0..7 scan as a chain, lane 8 (second finger) is kept out of the chain rounds and receives its
-// parent (two lanes up) in a round of its own.
+// ---- scans over the link tree.  "Both fingers hang off the last arm link": lanes 0..NARM (the arm and the first finger)
+// scan as a chain, lane NARM + 1 (second finger) is kept out of the chain rounds and receives its parent (two lanes
+// up) in a round of its own.
 
-// inclusive sum over a link's ancestors and itself.  `chain` is 1.0 on lanes 0..7 and `second` 1.0 on lane 8 (else
-// 0.0): the shifts run unmasked with zero fill (no destination to initialise) and the masks ride in the FMA.
+// inclusive sum over a link's ancestors and itself.  `chain` is 1.0 on lanes 0..NARM and `second` 1.0 on lane NARM + 1
+// (else 0.0): the shifts run unmasked with zero fill (no destination to initialise) and the masks ride in the FMA.
 template <class T>
 RCSH_D double scan_from_root(double x, double chain, double second) {
   if (T::GRIP) {
@@ -159,13 +159,41 @@ RCSH_D void compose_round(double* R, double* p) {
   p[0] = pn[0] + pq[0]; p[1] = pn[1] + pq[1]; p[2] = pn[2] + pq[2];
   mulmm(Rq, R, R);
 }
+// the same with the receiving lanes chosen by a predicate instead of by DPP bank (2 x 12 selects more per round)
+template <int N>
+RCSH_D void compose_round_if(double* R, double* p, bool take) {
+  double Rq[9], pq[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const double id = (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0;
+    const double up = row_up_or<N>(id, R[k]);
+    Rq[k] = take ? up : id;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double up = row_up<N>(p[k]);
+    pq[k] = take ? up : 0.0;
+  }
+  double pn[3];
+  mulmv(Rq, p, pn);
+  p[0] = pn[0] + pq[0]; p[1] = pn[1] + pq[1]; p[2] = pn[2] + pq[2];
+  mulmm(Rq, R, R);
+}
 template <class T>
 RCSH_D void scan_frames(double* R, double* p) {
-  if (T::GRIP) {
+  if (T::GRIP && T::NARM == 7) {
+    // fingers on lanes 7 and 8: the chain is banks 0-1, the second finger alone in bank 2 -- the DPP bank mask selects
     compose_round<1, 0x3>(R, p);
     compose_round<2, 0x3>(R, p);
     compose_round<4, 0x3>(R, p);
     compose_round<2, 0x4>(R, p);
+  } else if (T::GRIP) {
+    const int t = threadIdx.x & (kTeamLanes - 1);
+    const bool chain = t <= T::NARM, second = t == T::NARM + 1;
+    compose_round_if<1>(R, p, chain);
+    compose_round_if<2>(R, p, chain);
+    if (T::NARM + 1 > 4) compose_round_if<4>(R, p, chain);
+    compose_round_if<2>(R, p, second);
   } else {
     compose_round<1, 0xf>(R, p);
     compose_round<2, 0xf>(R, p);
@@ -477,7 +505,7 @@ struct SubstepK {
 template <class T, bool FRIC, class FrameFn, class PreSolveFn>
 RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRec* links, const StageTeam<T>& st, int t, bool stepping,
                          bool gc_is_mass, FrameFn&& on_frame, PreSolveFn&& pre_solve) {
-  static_assert(!T::GRIP || T::NARM == 7, "finger lanes are assumed to be 7 and 8 (bank masks in the scans)");
+  static_assert(!T::GRIP || T::NARM + 1 < 8 || T::NARM == 7, "the chain rounds of the scans reach 8 lanes; NARM = 7 uses the bank masks");
   static_assert(T::NL <= kTeamLanes - 1, "lane 15 is the implicit-integrator lane");
   constexpr int NL = T::NL, NA = T::NARM;
   const bool valid = t < NL;
@@ -530,7 +558,7 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     for (int k = 0; k < 6; ++k) st.S(tl, k) = S[k];
   }
   double vel[6], acc[6];
-  const double chain = t < 8 ? 1.0 : 0.0, second = t == 8 ? 1.0 : 0.0;
+  const double chain = t <= NA ? 1.0 : 0.0, second = t == NA + 1 ? 1.0 : 0.0;  // (only read by archetypes with a gripper)
 #pragma unroll
   for (int k = 0; k < 6; ++k) vel[k] = scan_from_root<T>(S[k] * qd, chain, second);
   {

@@ -59,6 +59,7 @@ bool dispatch_topology(int narm, bool grip, F&& fn) {
   if (narm == 7 && grip) { fn(Topo<7, true>{}); return true; }
   if (narm == 7 && !grip) { fn(Topo<7, false>{}); return true; }
   if (narm == 6 && !grip) { fn(Topo<6, false>{}); return true; }
+  if (narm == 5 && grip) { fn(Topo<5, true>{}); return true; }
   return false;
 }
 

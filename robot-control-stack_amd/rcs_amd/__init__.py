@@ -40,6 +40,8 @@ scenes: dict[str, Scene] = {
     "xarm7_empty_world": _scene("xarm7_empty_world", common.RobotType.XArm7),
     "xarm7_box_world": _scene("xarm7_box_world", common.RobotType.XArm7),
     "arm6_empty_world": _scene("arm6_empty_world", common.RobotType.UR5e),
+    "ur5e_empty_world": _scene("ur5e_empty_world", common.RobotType.UR5e),
+    "so101_empty_world": _scene("so101_empty_world", common.RobotType.SO101),
 }
 
 __all__ = ["__version__", "common", "sim", "envs", "scenes", "mjcf", "camera", "render"]

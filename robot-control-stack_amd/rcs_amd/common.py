@@ -66,6 +66,24 @@ def robots_meta_config(robot_type: RobotType) -> RobotMetaConfig:
     return _META[RobotType(robot_type)]
 
 
+# Joint ranges [rad] of the simulated SO101 stand-in (scenes/so101_empty_world).  The reference's SO101 entry is in the
+# units of the real arm's servo bus, normalised to -100 .. 100 per joint (extensions/rcs_so101 drives hardware only; the
+# reference has no simulated SO101), which a simulation in radians cannot use as is.
+SO101_SIM_JOINT_RANGES = np.array([[-1.91986, -1.74533, -1.69, -1.65806, -2.74385],
+                                   [1.91986, 1.74533, 1.69, 1.65806, 2.84121]])
+
+
+def sim_robots_meta_config(robot_type: RobotType) -> RobotMetaConfig:
+    """`robots_meta_config` as a simulation reads it: identical for every robot whose entry is in radians; the SO101's
+    normalised home pose and limits are mapped linearly onto the simulated joints' ranges (-100 -> lower, 100 -> upper)."""
+    meta = robots_meta_config(robot_type)
+    if RobotType(robot_type) != RobotType.SO101:
+        return meta
+    lo, hi = SO101_SIM_JOINT_RANGES
+    to_rad = lambda x: lo + (np.asarray(x) + 100.0) / 200.0 * (hi - lo)  # noqa: E731
+    return RobotMetaConfig(to_rad(meta.q_home), meta.dof, np.stack([to_rad(meta.joint_limits[0]), to_rad(meta.joint_limits[1])]))
+
+
 def IdentityTranslation() -> np.ndarray:
     return np.zeros(3)
 

@@ -45,7 +45,7 @@ class VecSimEnv:
         self.n_envs = simulation.n_envs
         self.dof = robot.dof
         self._L = simulation._L
-        meta = common.robots_meta_config(robot.get_config().robot_type)
+        meta = common.sim_robots_meta_config(robot.get_config().robot_type)
         self._low = np.ascontiguousarray(meta.joint_limits[0][: self.dof], dtype=np.float64)
         self._high = np.ascontiguousarray(meta.joint_limits[1][: self.dof], dtype=np.float64)
         rel = 0

@@ -12,12 +12,13 @@ import numpy as np
 from .. import sim
 from .base import ControlMode, RelativeTo
 from .creators import SimEnvCreator
-from .utils import arm6_sim_robot_cfg, default_sim_gripper_cfg, default_sim_robot_cfg, xarm7_sim_robot_cfg
+from .utils import (arm6_sim_robot_cfg, default_sim_gripper_cfg, default_sim_robot_cfg, so101_sim_gripper_cfg, so101_sim_robot_cfg,
+                    ur5e_sim_robot_cfg, xarm7_sim_robot_cfg)
 
 # max_relative_movement of the reference's joint-control example (examples/fr3/fr3_env_joint_control.py:38)
 MAX_JOINT_MOV = float(np.deg2rad(5))
 
-ROBOTS = ("fr3", "xarm7", "xarm7_box", "arm6")
+ROBOTS = ("fr3", "xarm7", "xarm7_box", "arm6", "ur5e", "so101")
 
 
 def robot_cfg_for(robot: str) -> sim.SimRobotConfig:
@@ -29,6 +30,10 @@ def robot_cfg_for(robot: str) -> sim.SimRobotConfig:
         return xarm7_sim_robot_cfg("xarm7_box_world")
     if robot == "arm6":
         return arm6_sim_robot_cfg()
+    if robot == "ur5e":
+        return ur5e_sim_robot_cfg()
+    if robot == "so101":
+        return so101_sim_robot_cfg()
     raise ValueError(f"unknown robot {robot!r}: one of {ROBOTS}")
 
 
@@ -36,16 +41,17 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500, robot_cfg: sim.SimRobotConfig | None = None):
     """`n_envs` environments of one robot type on GPU `device`.  `robot_cfg` overrides the robot's default configuration
-    (its scene decides the kernel archetype); only FR3 scenes carry a gripper."""
+    (its scene decides the kernel archetype); only the FR3 and SO101 scenes carry a gripper."""
     cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=frequency, max_convergence_steps=max_convergence_steps)
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    if not robot.startswith("fr3"):
+    if not (robot.startswith("fr3") or robot == "so101"):
         gripper = False
+    gripper_cfg = (so101_sim_gripper_cfg() if robot == "so101" else default_sim_gripper_cfg()) if gripper else None
     return SimEnvCreator()(
         mode, robot_cfg if robot_cfg is not None else robot_cfg_for(robot),
-        gripper_cfg=default_sim_gripper_cfg() if gripper else None,
+        gripper_cfg=gripper_cfg,
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None,
         relative_to=RelativeTo.LAST_STEP if relative_to == "last_step" else RelativeTo.CONFIGURED_ORIGIN,
         n_envs=n_envs, device=device,

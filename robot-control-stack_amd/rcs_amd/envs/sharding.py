@@ -106,14 +106,19 @@ class RcclObservationExchange:
     ``gathered_ptr(t)`` is what a resident consumer reads.
     """
 
-    def __init__(self, sim, unique_id: bytes, rank: int, world: int):
+    def __init__(self, sim, unique_id: bytes, rank: int, world: int, n_rows: int | None = None, width: int | None = None):
+        """`n_rows` x `width` (default: the sim's batch x its observation width) is the block every rank contributes.  Ranks
+        that run different robot types (observation widths 19 .. 21) agree on one block size and pack their rows at its
+        start; a rank hosting several sub-batches lets each write its part of the block (`local_ptr(t)` + offset)."""
         import ctypes as C
 
         from .. import _lib
 
         self._C, self._lib, self._L, self._h = C, _lib, _lib.load(), sim._h
         self.rank, self.world = rank, world
-        self.n, self.width = sim.n_envs, int(self._L.rcsh_env_obs_width(sim._h))
+        own = (sim.n_envs, int(self._L.rcsh_env_obs_width(sim._h)))
+        self.n, self.width = (n_rows or own[0]), (width or own[1])
+        self._plain = (self.n, self.width) == own  # the block IS the sim's observation tensor: rcsh_env_allgather_obs_dev
         _lib.check(self._L.rcsh_comm_init(self._h, unique_id, rank, world))
         self._bytes = 8 * self.n * self.width
         self._local, self._all = [], []
@@ -128,7 +133,10 @@ class RcclObservationExchange:
         return self._local[t & 1].value
 
     def post(self, t: int) -> None:
-        self._lib.check(self._L.rcsh_env_allgather_obs_dev(self._h, t & 1, self._local[t & 1], self._all[t & 1]))
+        if self._plain:
+            self._lib.check(self._L.rcsh_env_allgather_obs_dev(self._h, t & 1, self._local[t & 1], self._all[t & 1]))
+        else:
+            self._lib.check(self._L.rcsh_comm_allgather_dev(self._h, t & 1, self._local[t & 1], self._all[t & 1], self._bytes))
 
     def gathered_ptr(self, t: int) -> int:
         self._lib.check(self._L.rcsh_comm_wait(self._h, t & 1, 0))

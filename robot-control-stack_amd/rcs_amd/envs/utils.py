@@ -50,6 +50,52 @@ def arm6_sim_robot_cfg() -> sim.SimRobotConfig:
     return cfg
 
 
+def ur5e_sim_robot_cfg() -> sim.SimRobotConfig:
+    """The builder-authored UR5e-proportioned arm (scenes/ur5e_empty_world: public DH lengths and link masses, NOT a vendor
+    file); joint limits and home pose are robots_meta_config's UR5e entry."""
+    import rcs_amd
+
+    cfg = sim.SimRobotConfig()
+    cfg.actuators = ["shoulder_pan", "shoulder_lift", "elbow", "wrist_1", "wrist_2", "wrist_3"]
+    cfg.joints = [f"{a}_joint" for a in cfg.actuators]
+    cfg.base = "base"
+    cfg.robot_type = rcs_amd.common.RobotType.UR5e
+    cfg.attachment_site = "attachment_site"
+    cfg.arm_collision_geoms = []
+    cfg.mjcf_scene_path = rcs_amd.scenes["ur5e_empty_world"].mjb
+    cfg.kinematic_model_path = rcs_amd.scenes["ur5e_empty_world"].mjcf_robot
+    return cfg
+
+
+def so101_sim_robot_cfg() -> sim.SimRobotConfig:
+    """The builder-authored SO-101-proportioned 5-dof arm (scenes/so101_empty_world); home pose and limits are
+    robots_meta_config's SO101 entry mapped from the servo bus's normalised units to radians
+    (common.sim_robots_meta_config).  Its gripper: `so101_sim_gripper_cfg`."""
+    import rcs_amd
+
+    cfg = sim.SimRobotConfig()
+    cfg.actuators = [f"act{i}" for i in range(1, 6)]
+    cfg.joints = ["shoulder_pan", "shoulder_lift", "elbow_flex", "wrist_flex", "wrist_roll"]
+    cfg.base = "base"
+    cfg.robot_type = rcs_amd.common.RobotType.SO101
+    cfg.attachment_site = "attachment_site"
+    cfg.arm_collision_geoms = []
+    cfg.mjcf_scene_path = rcs_amd.scenes["so101_empty_world"].mjb
+    cfg.kinematic_model_path = rcs_amd.scenes["so101_empty_world"].mjcf_robot
+    return cfg
+
+
+def so101_sim_gripper_cfg() -> sim.SimGripperConfig:
+    """Two sliding fingers of 30 mm stroke each behind one tendon actuator (ctrl 0 .. 255), no collision geoms."""
+    cfg = sim.SimGripperConfig()
+    cfg.max_joint_width = 0.03
+    cfg.collision_geoms = []
+    cfg.collision_geoms_fingers = []
+    cfg.joint = "finger_joint1"
+    cfg.actuator = "gripper_act"
+    return cfg
+
+
 def default_sim_gripper_cfg(idx: str = "0") -> sim.SimGripperConfig:
     cfg = sim.SimGripperConfig()
     cfg.add_id(idx)

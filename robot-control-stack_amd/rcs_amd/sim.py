@@ -291,7 +291,7 @@ class SimRobot:
         base = _lookup(m, "body", cfg.base, "body")
         joints = np.array([_lookup(m, "jnt", j, "joint") for j in cfg.joints], dtype=np.int32)
         acts = np.array([_lookup(m, "actuator", a, "actuator") for a in cfg.actuators], dtype=np.int32)
-        meta = common.robots_meta_config(cfg.robot_type)
+        meta = common.sim_robots_meta_config(cfg.robot_type)
         self.dof = len(joints)
         q_home = np.ascontiguousarray(meta.q_home[: self.dof], dtype=np.float64)
         d = _lib.RobotDesc()

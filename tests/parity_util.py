@@ -48,6 +48,13 @@ KERNEL = "auto"
 
 XARM7_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "xarm7_empty_world", "scene.xml")
 ARM6_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "arm6_empty_world", "scene.xml")
+UR5E_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "ur5e_empty_world", "scene.xml")
+SO101_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "so101_empty_world", "scene.xml")
+GRIPPER_ROBOTS = ("fr3", "fr3_fric", "so101")
+
+
+def robot_dof(robot: str) -> int:
+    return 5 if robot == "so101" else 6 if robot.startswith(("arm6", "ur5e")) else 7
 
 
 PICKUP_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "fr3_simple_pick_up", "scene.xml")
@@ -344,14 +351,14 @@ def make_oracle_envs(n_envs: int, async_control: bool, gripper: bool = True, rel
                      max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                      max_convergence_steps: int = 500):
     from rcs_amd.mjcf import compile_mjcf
-    from rcs_env_oracle import ARM6, XARM7, OracleEnv
+    from rcs_env_oracle import ARM6, SO101, UR5E, XARM7, OracleEnv
 
     cm = compile_mjcf(xarm7_frictionless_scene() if robot == "xarm7_nofric" else scene_with_joint_friction(robot) if robot.endswith("_fric")
-                      else {"xarm7": XARM7_SCENE, "arm6": ARM6_SCENE}.get(robot, SCENE))
+                      else {"xarm7": XARM7_SCENE, "arm6": ARM6_SCENE, "ur5e": UR5E_SCENE, "so101": SO101_SCENE}.get(robot, SCENE))
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot in ("fr3", "fr3_fric"), max_relative_movement=max_relative_movement if relative else None,
-                      async_control=async_control, robot={"xarm7": XARM7, "xarm7_nofric": XARM7, "arm6": ARM6, "arm6_fric": ARM6}.get(robot), relative_to=relative_to,
+    return [OracleEnv(cm, control_mode=mode, gripper=gripper and robot in GRIPPER_ROBOTS, max_relative_movement=max_relative_movement if relative else None,
+                      async_control=async_control, robot={"xarm7": XARM7, "xarm7_nofric": XARM7, "arm6": ARM6, "arm6_fric": ARM6, "ur5e": UR5E, "so101": SO101}.get(robot), relative_to=relative_to,
                       frequency=frequency, max_convergence_steps=max_convergence_steps) for _ in range(n_envs)]
 
 
@@ -359,12 +366,12 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
                              episodes: int = 1, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                              max_convergence_steps: int = 500):
     """Fused HIP env-step vs the oracle on the same seeded actions; returns max abs differences + flag mismatches."""
-    gripper = gripper and robot in ("fr3", "fr3_fric")
+    gripper = gripper and robot in GRIPPER_ROBOTS
     venv = make_vec_env(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to, frequency=frequency,
                         max_convergence_steps=max_convergence_steps)
     oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, robot=robot, relative_to=relative_to, frequency=frequency,
                              max_convergence_steps=max_convergence_steps)
-    dof = 6 if robot.startswith("arm6") else 7
+    dof = robot_dof(robot)
     joints, grip = synthetic_actions(n_envs, n_steps * episodes, seed, dof=dof)
     rep = {"max_abs_obs": 0.0, "max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_finger": 0.0, "max_abs_gripper_width": 0.0,
            "flag_mismatches": 0, "substep_mismatches": 0, "steps": 0}
@@ -390,8 +397,8 @@ def run_joint_rollout_parity(n_envs: int = 64, n_steps: int = 3, async_control: 
             # whether a limit row exists in a substep, so their trajectories are only reproducible to ~1e-5 m
             rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e][:dof] - oe.sim.qpos[:dof]).max()))
             rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e][:dof] - oe.sim.qvel[:dof]).max()))
-            if q.shape[1] > 7:
-                rep["max_abs_finger"] = max(rep["max_abs_finger"], float(np.abs(q[e][7:] - oe.sim.qpos[7:]).max()))
+            if q.shape[1] > dof:
+                rep["max_abs_finger"] = max(rep["max_abs_finger"], float(np.abs(q[e][dof:] - oe.sim.qpos[dof : q.shape[1]]).max()))
             if substeps is not None and not async_control:
                 rep["substep_mismatches"] += int(int(substeps[e]) != int(oe.sim.s.convergence_steps))
 
@@ -438,7 +445,7 @@ def run_cartesian_rollout_parity(n_envs=32, n_steps=4, async_control=True, seed=
 
     cm = ControlMode.CARTESIAN_TRPY if mode == "xyzrpy" else ControlMode.CARTESIAN_TQuat
     mm = (0.2, float(np.deg2rad(45)))
-    gripper = gripper and robot == "fr3"
+    gripper = gripper and robot in ("fr3", "so101")
     venv = make_vec_env(n_envs, async_control, gripper=gripper, relative=relative, control_mode=cm, max_relative_movement=mm,
                         relative_to=relative_to, robot=robot)
     oenvs = make_oracle_envs(n_envs, async_control, gripper=gripper, relative=relative, mode=mode, max_relative_movement=mm,

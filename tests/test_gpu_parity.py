@@ -662,6 +662,41 @@ def test_arm6_cartesian_relative_clik(kernel):
 
 
 @pytest.mark.parametrize("async_control", [True, False])
+def test_ur5e_joints(async_control, kernel):
+    """The UR5e-proportioned 6-dof arm (scenes/ur5e_empty_world: public DH lengths and link masses, robots_meta_config's UR5e
+    home pose and limits; the reference ships no UR5e model): `Topo<6, false>` on a second chain, actuators holding the arm
+    against gravity (no gravity compensation)."""
+    rep = run_joint_rollout_parity(n_envs=40, n_steps=6 if async_control else 3, async_control=async_control, seed=27, robot="ur5e")
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < VTOL and rep["max_abs_obs"] < TOL, rep
+    assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
+
+
+def test_ur5e_cartesian_relative_clik(kernel):
+    rep = run_cartesian_rollout_parity(n_envs=24, n_steps=5, async_control=True, seed=29, mode="xyzrpy", robot="ur5e")
+    assert rep["max_abs_target"] < TOL and rep["max_abs_qpos"] < TOL and rep["max_abs_tquat"] < TOL, rep
+    assert rep["flag_mismatches"] == 0, rep
+
+
+@pytest.mark.parametrize("async_control", [True, False])
+def test_so101_joints_and_gripper(async_control, kernel):
+    """Fourth archetype, `Topo<5, true>`: the SO-101-proportioned 5-dof arm with the two-finger gripper
+    (scenes/so101_empty_world; fingers on lanes 5 and 6, so the frame scan selects its receiving lanes by predicate instead
+    of by DPP bank).  Its home pose -- robots_meta_config's SO101 entry -- sits 0.3 % of the range inside two joint limits and
+    the arm is not gravity-compensated, so limit rows come and go in almost every substep."""
+    rep = run_joint_rollout_parity(n_envs=40, n_steps=6 if async_control else 3, async_control=async_control, seed=31, robot="so101")
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < VTOL and rep["max_abs_obs"] < TOL and rep["max_abs_finger"] < FINGER_TOL, rep
+    assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0 and rep["max_abs_gripper_width"] < 1e-7, rep
+
+
+def test_so101_cartesian_relative_clik(kernel):
+    """The CLIK on 5 joints: 6 x 5 Jacobian, damped 6 x 6 normal equations; most 6-dof targets are unreachable, so the iteration
+    runs to its cap and `ik_success` is false -- in the oracle and in the kernel alike (flags compared bit for bit)."""
+    rep = run_cartesian_rollout_parity(n_envs=16, n_steps=4, async_control=True, seed=33, mode="xyzrpy", robot="so101")
+    assert rep["flag_mismatches"] == 0, rep
+    assert rep["max_abs_qpos"] < 1e-7 and rep["max_abs_tquat"] < 1e-7, rep  # (a thousand CLIK iterations amplify round-off)
+
+
+@pytest.mark.parametrize("async_control", [True, False])
 def test_seven_dof_arm_without_gripper_or_friction(async_control, kernel):
     """`Topo<7, false>` without the friction variant (team kernel) and on the lane kernel: the xArm7 chain with
     frictionloss = 0 -- a combination no shipped scene selects (the xArm7 has friction, the FR3 scene has fingers)."""

@@ -170,6 +170,41 @@ def test_robots_meta_config_values():
     assert common.robots_meta_config(common.RobotType.UR5e).dof == 6 and common.robots_meta_config(common.RobotType.SO101).dof == 5
 
 
+def test_authored_ur5e_and_so101_scenes():
+    """The two builder-authored stand-ins for robots the reference names but ships no model of: tree sizes, the archetype the
+    host derives (6 hinges / 5 hinges + 2 coupled slides), ranges = robots_meta_config's, and the SO101 entry read in radians."""
+    import parity_util as pu
+    from rcs_env_oracle import SO101, UR5E
+
+    ur = compile_mjcf(pu.UR5E_SCENE)
+    assert (ur.nq, ur.nv, ur.nu, ur.neq, ur.ntendon) == (6, 6, 6, 0, 0)
+    meta = common.sim_robots_meta_config(common.RobotType.UR5e)
+    assert meta is common.robots_meta_config(common.RobotType.UR5e)
+    rng = np.array([ur.arrays["jnt_range"][ur.name2id("jnt", j)] for j in UR5E["joints"]])
+    assert np.allclose(rng.T, meta.joint_limits, atol=1e-12)
+    # DH data sheet: shoulder height 0.163, upper arm 0.425, forearm 0.392, wrist offsets 0.127 / 0.1 / 0.1
+    so = compile_mjcf(pu.SO101_SCENE)
+    assert (so.nq, so.nv, so.nu, so.neq, so.ntendon) == (7, 7, 6, 1, 1)
+    sm = common.sim_robots_meta_config(common.RobotType.SO101)
+    rng = np.array([so.arrays["jnt_range"][so.name2id("jnt", j)] for j in SO101["joints"]])
+    assert np.allclose(rng.T, sm.joint_limits, atol=1e-12) and np.allclose(sm.joint_limits, common.SO101_SIM_JOINT_RANGES)
+    assert np.allclose(sm.q_home, SO101["q_home"], atol=1e-15) and np.all(sm.q_home > sm.joint_limits[0]) and np.all(sm.q_home < sm.joint_limits[1])
+    # -99.66 / +99.91 of the normalised range: 0.17 % / 0.04 % of the span inside the limit
+    assert 0 < sm.q_home[1] - sm.joint_limits[0][1] < 0.01 and 0 < sm.joint_limits[1][2] - sm.q_home[2] < 0.01
+    # the oracle steps both (arm held against gravity by its servos, gripper follows its command)
+    for robot in ("ur5e", "so101"):
+        oe = pu.make_oracle_envs(1, True, robot=robot)[0]
+        obs, _ = oe.reset()
+        for _ in range(10):
+            a = {"joints": np.zeros(pu.robot_dof(robot))}
+            if oe.has_gripper:
+                a["gripper"] = 1.0
+            obs, _, _, trunc, info = oe.step(a)
+        assert np.abs(obs["joints"] - oe.robot["q_home"]).max() < 0.02 and not trunc, (robot, obs["joints"])
+        if oe.has_gripper:
+            assert info["gripper_width"] > 0.5
+
+
 def test_library_loads_and_exports_every_declared_symbol():
     """Every function include/rcs_hip.h declares is exported by librcs_hip.so (built by __graft_entry__.build())."""
     header = open(os.path.join(ROOT, "include", "rcs_hip.h")).read()
