@@ -467,11 +467,55 @@ static orc_contact* add_contact(orc_data* d, int g1, int g2, int b1, int b2, con
 
 /* mj_collision for the RCS scenes: (floor, robot geom) pairs, (floor, free box), (robot geom, free box), in MuJoCo's
    order of body pairs.  Pair filters as MuJoCo applies them: bodies welded together never collide, contype / conaffinity
-   masks must match, parent-child pairs are skipped unless the parent is the world.  (Pairs of two robot geoms -- self
-   collision -- are not generated in this revision.) */
+   masks must match, parent-child pairs are skipped unless the parent is the world.  Pairs of two robot geoms -- self
+   collision, the robot against geoms welded to the world -- are detected (orc_data.self_geom) but carry no rows. */
+static int shape_of(const orc_model* m, int g, const double* gp, const double* gR, shape* S) {
+  const int t = m->geom_type[g];
+  if (t != 7 && t != 6 && t != 3) return 0;
+  if (t == 7 && m->geom_vertnum[g] == 0) return 0; /* mesh blob missing from the checkout */
+  S->type = t == 7 ? SH_HULL : t == 6 ? SH_BOX : SH_CAPSULE;
+  S->p = gp; S->R = gR; S->size = m->geom_size[g];
+  S->verts = m->mesh_vert + 3 * m->geom_vertadr[g];
+  S->nvert = m->geom_vertnum[g];
+  copy3(S->center, gp);
+  if (t == 7) hull_center(S->verts, S->nvert, gp, gR, S->center);
+  return 1;
+}
+/* geom-geom pairs of the robot (every convex pair through mjc_Convex's MPR: only "do they overlap" is read from it) */
+static void self_collide(const orc_model* m, orc_data* d) {
+  d->nself = 0;
+  for (int g1 = 0; g1 < m->ngeom; g1++) {
+    if (m->geom_type[g1] == 0) continue;
+    for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
+      if (m->geom_type[g2] == 0) continue;
+      const int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+      const int w1 = m->body_weldid[b1], w2 = m->body_weldid[b2];
+      if (w1 == w2) continue;
+      if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
+      const int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
+      if (w1 && w2 && (w1 == pw2 || w2 == pw1)) continue;
+      double R1[9], p1[3], R2[9], p2[3], x[3];
+      geom_frame(m, d, g1, R1, p1);
+      geom_frame(m, d, g2, R2, p2);
+      sub3(p1, p2, x);
+      const double rs = geom_rbound(m, g1) + geom_rbound(m, g2);
+      if (dot3(x, x) > rs * rs) continue;
+      /* MuJoCo orders a pair by geom type, then by id */
+      const int swap = m->geom_type[g1] > m->geom_type[g2];
+      const int ga = swap ? g2 : g1, gb = swap ? g1 : g2;
+      shape A, B;
+      if (!shape_of(m, ga, swap ? p2 : p1, swap ? R2 : R1, &A) || !shape_of(m, gb, swap ? p1 : p2, swap ? R1 : R2, &B)) continue;
+      double depth, dir[3], pos[3];
+      if (!mpr_penetration(&A, &B, &depth, dir, pos)) continue;
+      if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->nself++; }
+    }
+  }
+}
+
 void orc_collide(const orc_model* m, orc_data* d) {
   d->ncon = 0;
   d->coupled = 0;
+  self_collide(m, d);
   g_contact_cap = m->resolve_contacts ? 48 : ORC_MAXCON;
   const int gbox = m->ngeom;
   int robot_contacts = 0;

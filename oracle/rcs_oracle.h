@@ -44,6 +44,7 @@ enum { ORC_TRN_JOINT = 0, ORC_TRN_TENDON = 3 };
 enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1, ORC_EFC_FRICTION = 2, ORC_EFC_CONTACT = 3, ORC_EFC_CONTACT_T = 4 };
 /* body / geom id of the free box in contact records (the box is kept outside the robot's body and geom tables) */
 #define ORC_BODY_BOX (-2)
+#define ORC_MAXSELF 256
 
 /* ---- one free rigid box on the floor plane (rcs_object.c) */
 typedef struct orc_box {
@@ -200,6 +201,10 @@ typedef struct orc_data {
   int contact_geom[ORC_MAXCON][2];  /* d->contact[i].geom, i < ncon */
   orc_contact contact[ORC_MAXCON];
   int coupled; /* the last step solved robot and box in one problem (a contact involved a robot geom) */
+  /* contacts between two geoms of the robot (self collision): detected for the collision callbacks, which scan them after
+     contact[]; they carry no constraint rows in this revision */
+  int nself;
+  int self_geom[ORC_MAXSELF][2];
   orc_box_data box;
 } orc_data;
 

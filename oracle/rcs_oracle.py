@@ -81,6 +81,9 @@ class OrcModel(C.Structure):
     ]
 
 
+MAXSELF = 256
+
+
 class OrcContact(C.Structure):
     _fields_ = [("geom", I * 2), ("body", I * 2), ("pos", D * 3), ("frame", D * 9), ("dist", D), ("mu", D), ("efc_address", I), ("zone", I)]
 
@@ -103,7 +106,7 @@ class OrcData(C.Structure):
         ("efc_K", D * MAXEFC), ("efc_B", D * MAXEFC), ("efc_I", D * MAXEFC), ("efc_frictionloss", D * MAXEFC),
         ("efc_R", D * MAXEFC), ("efc_mu", D * MAXEFC),
         ("qfrc_constraint", D * NVT), ("solver_niter", I), ("noslip_niter", I), ("contact_geom", I * 2 * MAXCON),
-        ("contact", OrcContact * MAXCON), ("coupled", I),
+        ("contact", OrcContact * MAXCON), ("coupled", I), ("nself", I), ("self_geom", I * 2 * MAXSELF),
         ("box", OrcBoxData),
     ]
 

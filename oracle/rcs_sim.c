@@ -75,10 +75,13 @@ static int in_set(const int* set, int n, int g) {
   for (int i = 0; i < n; i++) if (set[i] == g) return 1;
   return 0;
 }
+/* geoms of contact i of the position stage: contact[] first, then the robot's geom-geom contacts (orc_data.self_geom) */
+static const int* contact_pair(const orc_sim* s, int i) { return i < s->d.ncon ? s->d.contact_geom[i] : s->d.self_geom[i - s->d.ncon]; }
 static int robot_collision_cb(orc_sim* s) { /* SimRobot.cpp:172-182: scan of d->contact[0..ncon) */
   s->robot_collision = 0;
-  for (int i = 0; i < s->d.ncon; i++) {
-    if (in_set(s->arm_cgeom, s->arm_ncgeom, s->d.contact_geom[i][0]) || in_set(s->arm_cgeom, s->arm_ncgeom, s->d.contact_geom[i][1])) {
+  for (int i = 0; i < s->d.ncon + s->d.nself; i++) {
+    const int* pr = contact_pair(s, i);
+    if (in_set(s->arm_cgeom, s->arm_ncgeom, pr[0]) || in_set(s->arm_cgeom, s->arm_ncgeom, pr[1])) {
       s->robot_collision = 1;
       break;
     }
@@ -98,8 +101,8 @@ static int gripper_convergence_cb(orc_sim* s) { /* SimGripper.cpp:143-151 */
 }
 static int gripper_collision_cb(orc_sim* s) { /* SimGripper.cpp:108-130 */
   s->grp_collision = 0;
-  for (int i = 0; i < s->d.ncon; i++) {
-    int g0 = s->d.contact_geom[i][0], g1 = s->d.contact_geom[i][1];
+  for (int i = 0; i < s->d.ncon + s->d.nself; i++) {
+    int g0 = contact_pair(s, i)[0], g1 = contact_pair(s, i)[1];
     if (in_set(s->grp_cfgeom, s->grp_ncfgeom, g0) && in_set(s->grp_cfgeom, s->grp_ncfgeom, g1)) continue; /* finger-finger */
     if ((in_set(s->grp_cgeom, s->grp_ncgeom, g0) || in_set(s->grp_cgeom, s->grp_ncgeom, g1)) &&
         !(in_set(s->grp_ignored, s->grp_nignored, g1) || in_set(s->grp_ignored, s->grp_nignored, g1))) { /* geom[1] twice: Q6 */

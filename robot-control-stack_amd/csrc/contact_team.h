@@ -389,6 +389,52 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
   }
 }
 
+// ---- self collision, flags only.  Lane t of a team takes pairs t, t + 16, ... of the table: bounding spheres first, then the
+// portal refinement of dev_mpr (mjc_Convex for every convex pair: only "do they overlap" is read from it).  F: world frames
+// of the team's links, [NL][12] in LDS (R row-major, p); geoms welded to the world carry their world frame in the table.
+// Returns the class bits of the overlapping pairs this lane found.
+RCSH_D void self_geom_world(const ContactGeom& g, const double* F, double* R, double* p) {
+  if (g.link < 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = g.rot[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = g.pos[k];
+    return;
+  }
+  const double* L = F + 12 * g.link;
+  double LR[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) LR[k] = L[k];
+  mulmm(LR, g.rot, R);
+  mulmv(LR, g.pos, p);
+  p[0] += L[9]; p[1] += L[10]; p[2] += L[11];
+}
+RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const double* verts, const SelfPair* pairs, int npair, const double* F_, int t) {
+  const double* F = in_lds(F_);
+  uint32_t mine = 0;
+  for (int i = t; i < npair; i += kTeamLanes) {
+    const SelfPair pr = pairs[i];
+    const ContactGeom& a = geoms[pr.g0];
+    const ContactGeom& b = geoms[pr.g1];
+    double Ra[9], pa[3], Rb[9], pb[3];
+    self_geom_world(a, F, Ra, pa);
+    self_geom_world(b, F, Rb, pb);
+    const double d[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    const double rs = a.rbound + b.rbound;
+    if (dot3(d, d) > rs * rs) continue;
+    Shape A, B;
+    A.type = a.type == 7 ? 0 : a.type == 6 ? 1 : 2; A.p = pa; A.R = Ra; A.size = a.size; A.verts = verts + 3 * (size_t)a.vert_adr; A.nvert = a.vert_num;
+    B.type = b.type == 7 ? 0 : b.type == 6 ? 1 : 2; B.p = pb; B.R = Rb; B.size = b.size; B.verts = verts + 3 * (size_t)b.vert_adr; B.nvert = b.vert_num;
+    if (a.type == 7) { mulmv(Ra, a.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
+    else { A.center[0] = pa[0]; A.center[1] = pa[1]; A.center[2] = pa[2]; }
+    if (b.type == 7) { mulmv(Rb, b.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
+    else { B.center[0] = pb[0]; B.center[1] = pb[1]; B.center[2] = pb[2]; }
+    double depth, dir[3], pos[3];
+    if (dev_mpr(A, B, &depth, dir, pos)) mine |= (uint32_t)pr.cls;
+  }
+  return mine;
+}
+
 // elliptic cone of one contact at jar (mj_constraintUpdate): force f = -dcost/djar, Hessian (00 10 11 20 21 22), cost
 RCSH_D double cone_eval(const double* D, double mu, double fr, const double* jar, double* f, double* Hc) {
   const double U0 = jar[0] * mu, U1 = jar[1] * fr, U2 = jar[2] * fr;

@@ -12,7 +12,8 @@ constexpr int kMaxActive = 4;    // links in contact at once that the noslip pas
 struct ContactGeom {
   int32_t link;          // link carrying the geom (-1: welded to the world)
   int32_t type;          // mjtGeom: 3 capsule, 6 box, 7 mesh (convex hull)
-  int32_t cls;           // bit 0: SimRobot arm collision geom, bit 1: SimGripper collision geom, bit 2: finger geom
+  int32_t cls;           // bit 0: SimRobot arm collision geom, bit 1: SimGripper collision geom (not ignored), bit 2: finger geom,
+                         // bit 3: in SimGripper's ignore list, bit 4: SimGripper collision geom (ignored or not)
   int32_t vert_adr, vert_num;
   int32_t geom_id;       // mjModel geom id
   int32_t plane_ok;      // the (floor, geom) pair passes MuJoCo's filters
@@ -26,12 +27,21 @@ struct ContactGeom {
   double invweight;      // body_invweight0 (translational) of the geom's body
 };
 
+// A pair of the robot's collision geoms that MuJoCo's filters let collide (different weld bodies, no parent-child pair
+// unless one is welded to the world) and whose contact one of the collision callbacks would react to.  g0 / g1 index
+// ContactTable::geoms, in MuJoCo's order within a contact (by geom type, then by id).
+struct SelfPair {
+  int16_t g0, g1;
+  int32_t cls;  // bit 0: SimRobot::collision_callback counts the contact, bit 1: SimGripper::collision_callback does
+};
+
 struct ContactTable {
   const ContactGeom* geoms;
   const double* verts;   // [nvert][3] hull vertices, geom frame
+  const SelfPair* pairs; // self collision (flags only): see self_collision_pairs, contact_team.h
   int32_t ngeom, has_plane;
   int32_t link_geom_adr[13];  // geoms of link i are [link_geom_adr[i], link_geom_adr[i + 1]) (kMaxLinks + 1 entries)
-  int32_t pad;
+  int32_t npair;
   double plane_n[3], plane_d, plane_mu;
 };
 

@@ -56,6 +56,8 @@ struct rcsh_sim {
   std::vector<ContactGeom> cgeoms;
   std::vector<double> cverts;
   ContactGeom* d_cgeoms = nullptr;
+  SelfPair* d_pairs = nullptr;       // self-collision pairs a collision callback reacts to (rebuilt when the class bits change)
+  std::vector<SelfPair> pairs;
   double* d_cverts = nullptr;
   double plane_mu = 1.0;
   std::vector<int> act_slot;
@@ -135,6 +137,8 @@ Params make_params(rcsh_sim* s) {
   P.boxtask = s->d_boxtask;
   P.ctab.geoms = s->d_cgeoms;
   P.ctab.verts = s->d_cverts;
+  P.ctab.pairs = s->d_pairs;
+  P.ctab.npair = (int)s->pairs.size();
   P.ctab.ngeom = s->box.resolve ? (int)s->cgeoms.size() : 0;
   P.ctab.has_plane = s->cp.has_plane;
   {
@@ -183,8 +187,38 @@ int upload_coll_classes(rcsh_sim* s) {
   return RCSH_OK;
 }
 
+// MuJoCo's pair filters on two collision geoms of the robot (mj_collision: different weld bodies -- here: links; no
+// parent-child pair unless one of the two is welded to the world), then what the callbacks make of a contact of the pair
+// (SimRobot.cpp:172-182: either geom is an arm collision geom; SimGripper.cpp:108-130: not finger-finger, either geom is a
+// gripper collision geom, geom[1] is not in the ignore list -- quirk Q6).  Pairs nobody reacts to are dropped.
+void build_self_pairs(rcsh_sim* s) {
+  s->pairs.clear();
+  const int ng = (int)s->cgeoms.size();
+  auto parent = [&](int link) { return link < s->narm ? link - 1 : s->narm - 1; };
+  for (int i = 0; i < ng; ++i)
+    for (int j = i + 1; j < ng; ++j) {
+      const ContactGeom &a = s->cgeoms[i], &b = s->cgeoms[j];
+      if (a.link == b.link) continue;
+      if (a.link >= 0 && b.link >= 0 && (parent(a.link) == b.link || parent(b.link) == a.link)) continue;
+      if ((a.type == 7 && a.vert_num == 0) || (b.type == 7 && b.vert_num == 0)) continue;  // mesh blob missing from the checkout
+      const bool swap = a.type > b.type;  // geom[0] / geom[1] of the contact: by type, then by id (the table is in id order)
+      const ContactGeom &g0 = swap ? b : a, &g1 = swap ? a : b;
+      int cls = 0;
+      if ((g0.cls | g1.cls) & 1) cls |= 1;
+      if (!((g0.cls & 4) && (g1.cls & 4)) && ((g0.cls | g1.cls) & 16) && !(g1.cls & 8)) cls |= 2;
+      if (!cls) continue;
+      s->pairs.push_back(SelfPair{(int16_t)(swap ? j : i), (int16_t)(swap ? i : j), cls});
+    }
+}
+
 int upload_contact_table(rcsh_sim* s) {
   if (s->cgeoms.empty()) return RCSH_OK;
+  build_self_pairs(s);
+  if (s->d_pairs) { HIP_TRY(hipStreamSynchronize(s->stream)); HIP_TRY(hipFree(s->d_pairs)); s->d_pairs = nullptr; }
+  if (!s->pairs.empty()) {
+    HIP_TRY(hipMalloc(&s->d_pairs, sizeof(SelfPair) * s->pairs.size()));
+    HIP_TRY(hipMemcpyAsync(s->d_pairs, s->pairs.data(), sizeof(SelfPair) * s->pairs.size(), hipMemcpyHostToDevice, s->stream));
+  }
   if (!s->d_cgeoms) HIP_TRY(hipMalloc(&s->d_cgeoms, sizeof(ContactGeom) * s->cgeoms.size()));
   HIP_TRY(hipMemcpyAsync(s->d_cgeoms, s->cgeoms.data(), sizeof(ContactGeom) * s->cgeoms.size(), hipMemcpyHostToDevice, s->stream));
   if (!s->d_cverts && !s->cverts.empty()) {
@@ -222,28 +256,38 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   // SIMD of the chip.  (A one-lane-per-environment kernel existed through round 1; it lost at every batch size and could
   // step neither dry friction nor free bodies, and was removed: csrc/dyn.h keeps its formulas for the host-side model
   // finalisation and the shared math.)
+  // DET: launches that run the collision callbacks (step_until_convergence) of a model with collision geoms carry the
+  // contact detection of the position stage; Sim::step(k) never looks at the flags (sim.cpp:108-115)
+  const bool det = op.nsteps < 0 && (P.coll.has_plane || !s->pairs.empty());
+  bool launched = false;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
     const dim3 grid(((s->n + 31) / 32) * 8), block(64);
+    auto go = [&](auto fric, auto box, auto con) {
+      constexpr bool F = decltype(fric)::value, B = decltype(box)::value, C = decltype(con)::value;
+      if (det) hipLaunchKernelGGL((k_run_team<T, F, B, C, true>), grid, block, 0, s->stream, P, op);
+      else hipLaunchKernelGGL((k_run_team<T, F, B, C, false>), grid, block, 0, s->stream, P, op);
+      launched = true;
+    };
+    using Y = std::true_type;
+    using N = std::false_type;
     if (s->box.present && s->box.resolve) {
       // free box + contacts of the robot's geoms (FR3 + hand): rcsh_sim_add_free_box checked the archetype
-      if constexpr (T::NARM == 7 && T::GRIP) hipLaunchKernelGGL((k_run_team<T, false, true, true>), grid, block, 0, s->stream, P, op);
+      if constexpr (T::NARM == 7 && T::GRIP) go(N{}, Y{}, Y{});
     } else if (s->box.present) {
       // scenes with a free box that only touches the floor: FR3 + hand, and the 7-dof arm with dry joint friction
-      if constexpr (T::NARM == 7 && T::GRIP)
-        hipLaunchKernelGGL((k_run_team<T, false, true>), grid, block, 0, s->stream, P, op);
-      else if constexpr (T::NARM == 7)
-        hipLaunchKernelGGL((k_run_team<T, true, true>), grid, block, 0, s->stream, P, op);
+      if constexpr (T::NARM == 7 && T::GRIP) go(N{}, Y{}, N{});
+      else if constexpr (T::NARM == 7) go(Y{}, Y{}, N{});
     } else if (s->box.resolve) {
       // no free body, contacts of the robot with the floor resolved (rcsh_sim_set_contact_options; FR3 + hand)
-      if constexpr (T::NARM == 7 && T::GRIP) hipLaunchKernelGGL((k_run_team<T, false, false, true>), grid, block, 0, s->stream, P, op);
+      if constexpr (T::NARM == 7 && T::GRIP) go(N{}, N{}, Y{});
     } else if (s->dm.has_friction)
-      hipLaunchKernelGGL((k_run_team<T, true>), grid, block, 0, s->stream, P, op);
+      go(Y{}, N{}, N{});
     else
-      hipLaunchKernelGGL((k_run_team<T, false>), grid, block, 0, s->stream, P, op);
+      go(N{}, N{}, N{});
     err = hipGetLastError();
   });
-  if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
+  if (!ok || !launched) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_run launch: ") + hipGetErrorString(err));
   if (sample) {
     HIP_TRY(hipEventRecord(s->ev_stop[s->prof_pending], s->stream));
@@ -461,7 +505,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_start) hipEventDestroy(e);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
-  hipFree(s->d_cgeoms); hipFree(s->d_cverts);
+  hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
@@ -767,6 +811,8 @@ int rcsh_sim_add_gripper(rcsh_sim* s, const rcsh_gripper_desc* g) {
   for (int c = 0; c < g->n_collision_geoms; ++c) {
     const int gid = g->collision_geom_ids[c];
     if (gid < 0 || gid >= s->hm.ngeom) return fail(RCSH_ERR_NAME, "gripper collision geom id out of range");
+    for (auto& cg : s->cgeoms)
+      if (cg.geom_id == gid) cg.cls |= 16;
     bool ignored = false;
     for (int q = 0; q < g->n_ignored_geoms; ++q) ignored = ignored || g->ignored_geom_ids[q] == gid;
     if (ignored) continue;
@@ -778,6 +824,9 @@ int rcsh_sim_add_gripper(rcsh_sim* s, const rcsh_gripper_desc* g) {
   for (int c = 0; c < g->n_finger_geoms; ++c)
     for (auto& cg : s->cgeoms)
       if (cg.geom_id == g->finger_geom_ids[c]) cg.cls |= 4;
+  for (int q = 0; q < g->n_ignored_geoms; ++q)
+    for (auto& cg : s->cgeoms)
+      if (cg.geom_id == g->ignored_geom_ids[q]) cg.cls |= 8;
   {
     int rc = upload_coll_classes(s);
     if (!rc) rc = upload_contact_table(s);
@@ -1270,7 +1319,7 @@ struct Rccl {
   void* lib = nullptr;
   std::string why;
 };
-Rccl& rccl() {
+static Rccl& rccl() {
   static Rccl r;
   if (r.lib || !r.why.empty()) return r;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {

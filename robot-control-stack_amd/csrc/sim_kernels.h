@@ -550,7 +550,11 @@ __device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModelHea
 // BOX: the scene has a free box (box_team.h).  CON: contacts of the robot's collision geoms are resolved (contact_team.h);
 // without a box the contact phase sees a phantom one parked far above the scene (zero size: it touches nothing, its six
 // dofs stay decoupled), so that one formulation serves the pick-up scene and the robot-on-the-floor case alike.
-template <class T, bool FRIC, bool BOX = false, bool CON = false>
+// DET: this launch runs the collision callbacks (step_until_convergence) of a model with collision geoms: in the substeps
+// after which one of them is due the position stage also detects contacts -- the floor against the sample points of the
+// collision geoms, and the robot's geoms against each other.  Launches that never look at the flags (Sim::step(k)) and
+// models without collision geoms run the instantiation without that code.
+template <class T, bool FRIC, bool BOX = false, bool CON = false, bool DET = false>
 __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
@@ -678,6 +682,14 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // the free box of the scene: its state sits in the team's LDS block between substeps (box_team.h)
   __shared__ double lbox[(BOX || CON) ? kBoxLds * kTeams : 1];
   __shared__ std::conditional_t<CON, ContactArena<T>, char> larena[1];  // the contact phase's workspace: one per wavefront
+  // self collision (DET): the world frames of every team's links for the pair tests.  The contact phase's workspace is idle
+  // while the position stage runs (it is rebuilt from scratch whenever the contact phase starts), so with CON the frames
+  // borrow it: that instantiation has no LDS to spare (38.7 of the 40 KB that let four workgroups share a CU).
+  constexpr int kSelfF = 12 * T::NL;
+  __shared__ double lselfF[(DET && !CON) ? kSelfF * kTeams : 1];
+  static_assert(!CON || sizeof(ContactArena<T>) >= sizeof(double) * kSelfF * kTeams, "the link frames of four teams fit into the contact arena");
+  double* const selfF = (DET ? (CON ? reinterpret_cast<double*>(&larena[0]) : lselfF) : lselfF) + (DET ? team * kSelfF : 0);
+  const int npair = DET ? lp.ctab.npair : 0;
   double* const bs = lbox + ((BOX || CON) ? team * kBoxLds : 0);
   if constexpr (CON && !BOX) {
     // the phantom box: at rest where the host parked it
@@ -726,11 +738,13 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     // plane contacts of the position stage: every lane tests its own link with the frame the substep just built,
     // in the substeps after which a collision callback is due (condition_callbacks, same comparisons)
     bool due = false;
-    if (leader && stepping && until_conv && has_plane) {
-      const double t_next = r.time + timestep;
-      due = (robot_present && t_next - r.cb(2) > robot_period) || (grip_present && t_next - r.cb(3) > grip_period);
+    if constexpr (DET) {
+      if (leader && stepping && until_conv && (has_plane || npair > 0)) {
+        const double t_next = r.time + timestep;
+        due = (robot_present && t_next - r.cb(2) > robot_period) || (grip_present && t_next - r.cb(3) > grip_period);
+      }
     }
-    const bool want_contacts = team_ballot(due) != 0;
+    const bool want_contacts = DET && team_ballot(due) != 0;
     uint32_t hit = 0;
     bool near = false;  // broad phase of the contact phase: the lane's link may touch the floor or the box
     bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
@@ -759,21 +773,39 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
             near = geom_level_near(lp.ctab.geoms, lp.ctab.link_geom_adr[t], lp.ctab.link_geom_adr[t + 1], R, p, pln, pld, has_plane, bs + kBoxQ, box_r2, BOX);
         }
       }
-      if (!want_contacts) return;
-      const double* nrm = lc.plane_n;
-      const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
-                           R[2] * nrm[0] + R[5] * nrm[1] + R[8] * nrm[2]};
-      const double b = dot3(nrm, p) - lc.plane_d;
-      const int tl = t < T::NL ? t : T::NL - 1;
-      const double* sph = lc.link_sphere[tl];
-      uint32_t mine = 0;
-      if (t < T::NL && b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < 0) {
-        for (int k = lc.link_adr[tl]; k < lc.link_adr[tl + 1]; ++k) {
-          const double* v = lc.xyzr + 4 * (size_t)k;
-          if (b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3] < 0) mine |= lc.cls[k];
+      if constexpr (DET) {
+        if (!want_contacts) return;
+        uint32_t mine = 0;
+        if (has_plane) {
+          const double* nrm = lc.plane_n;
+          const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
+                               R[2] * nrm[0] + R[5] * nrm[1] + R[8] * nrm[2]};
+          const double b = dot3(nrm, p) - lc.plane_d;
+          const int tl = t < T::NL ? t : T::NL - 1;
+          const double* sph = lc.link_sphere[tl];
+          if (t < T::NL && b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < 0) {
+            for (int k = lc.link_adr[tl]; k < lc.link_adr[tl + 1]; ++k) {
+              const double* v = lc.xyzr + 4 * (size_t)k;
+              if (b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3] < 0) mine |= lc.cls[k];
+            }
+          }
         }
+        if (npair > 0) {
+          // the robot's geoms against each other: every lane publishes its link's frame, then takes its share of the pairs
+          if (t < T::NL) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) selfF[12 * t + k] = R[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) selfF[12 * t + 9 + k] = p[k];
+          }
+          // (teams whose callbacks are not due are not in here: no barrier -- LDS traffic of one wavefront is ordered, the
+          // fence is for the compiler)
+          stage_fence();
+          mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfF, t);
+          stage_fence();  // (CON: the frames sit in the contact arena, which the contact phase may enter next)
+        }
+        hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
       }
-      hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
     }, [&]() -> bool {
       bool coupled = false;
       if constexpr (CON) {

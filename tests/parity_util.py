@@ -793,3 +793,52 @@ def run_floor_contact_parity(n_envs=8, seed=0):
     rep["tracking_error"] = float(np.abs(simu.qpos[:, :7] - tgt).max())
     simu.close()
     return rep
+
+
+def run_self_collision_parity(n_envs=40, seed=1, scene="fr3_empty_world", resolve=None):
+    """step_until_convergence towards folded-arm targets inside the MODEL's joint ranges but outside the RobotEnv's limits
+    (fine-grained API: SimRobot.set_joint_position does not clip): in about a third of them the fingers / the hand run into
+    links 1 and 2 with nothing touching the floor.  Compared with the oracle per environment: both collision flags, the
+    substep count at which the loop ended, the joint positions there."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = default_sim_robot_cfg(scene)
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs, resolve_robot_contacts=resolve)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(cfg.mjcf_scene_path)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0",
+                   resolve_contacts=simu.resolve_robot_contacts) for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    q = np.tile(FR3_Q_HOME, (n_envs, 1))
+    q[:, 0] = rng.uniform(-1, 1, n_envs)
+    q[:, 1] = rng.uniform(-1.78, 0.2, n_envs)
+    q[:, 3] = rng.uniform(-3.04, -2.6, n_envs)
+    q[:, 4] = rng.uniform(-0.5, 0.5, n_envs)
+    q[:, 5] = rng.uniform(0.55, 1.6, n_envs)
+    simu.step(1)
+    robot.set_joint_position(q)
+    simu.step_until_convergence()
+    st, gs = robot.get_state(), grip.get_state()
+    steps = simu.convergence_steps()
+    qk = simu.qpos
+    rep = {"flag_mismatches": 0, "substep_mismatches": 0, "max_abs_qpos": 0.0, "robot_hits": 0, "gripper_hits": 0, "self_only": 0, "floor": 0}
+    for e, o in enumerate(osims):
+        o.reset(); o.robot_reset(); o.gripper_reset(); o.step(1)
+        o.set_joint_position(q[e])
+        o.step_until_convergence()
+        rep["flag_mismatches"] += int(bool(st.collision[e]) != bool(o.s.robot_collision)) + int(bool(gs.collision[e]) != bool(o.s.grp_collision))
+        rep["substep_mismatches"] += int(int(steps[e]) != int(o.s.convergence_steps))
+        rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(qk[e] - o.qpos[: qk.shape[1]]).max()))
+        rep["robot_hits"] += int(o.s.robot_collision)
+        rep["gripper_hits"] += int(o.s.grp_collision)
+        robot_other = sum(1 for c in range(o.s.d.ncon) if o.s.d.contact[c].body[0] > 0 or o.s.d.contact[c].body[1] > 0)  # (contacts of a robot body with floor / cube)
+        rep["self_only"] += int((o.s.robot_collision or o.s.grp_collision) and robot_other == 0 and o.s.d.nself > 0)
+        rep["floor"] += int(o.s.d.ncon > 0)
+    simu.close()
+    return rep

@@ -887,3 +887,15 @@ def test_robot_on_the_floor_resolved_contacts(kernel):
     assert rep["coupled_substeps"] > 500 and rep["max_ncon"] >= 2 and rep["collisions"] == 8, rep
     assert rep["max_abs_qpos"] < 1e-7 and rep["max_abs_qvel"] < 1e-5 and rep["flag_mismatches"] == 0, rep
     assert rep["tracking_error"] > 0.05, rep  # the floor keeps the arm from reaching its target
+
+
+@pytest.mark.parametrize("scene,resolve", [("fr3_empty_world", None), ("fr3_empty_world", True), ("fr3_simple_pick_up", None)])
+def test_self_collision_flags_match_oracle(scene, resolve, kernel):
+    """SimRobot / SimGripper collision callbacks see contacts between two geoms of the robot (fingers, pads
+    and hand against links 1 and 2 when the arm folds onto itself).  All three instantiations that carry the detection: the
+    lean kernel, the contact-resolving one without a free body, and the pick-up scene's."""
+    from parity_util import run_self_collision_parity
+
+    rep = run_self_collision_parity(n_envs=48, seed=1, scene=scene, resolve=resolve)
+    assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0 and rep["max_abs_qpos"] < TOL, rep
+    assert rep["self_only"] >= 8 and rep["robot_hits"] >= 4 and rep["gripper_hits"] >= 4, rep
