@@ -481,6 +481,34 @@ static int shape_of(const orc_model* m, int g, const double* gp, const double* g
   if (t == 7) hull_center(S->verts, S->nvert, gp, gR, S->center);
   return 1;
 }
+/* oriented bounding boxes (centre, axes = columns of R, half extents): 1 if one of the 15 candidate axes separates them
+   (broad phase, as mj_collision's bounding-volume test: conservative) */
+static int obb_disjoint(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb) {
+  double C[3][3], A[3][3], d[3], tv[3];
+  sub3(cb, ca, d);
+  matT_vec(Ra, d, tv);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      C[i][j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+      A[i][j] = fabs(C[i][j]) + 1e-9;
+    }
+  for (int i = 0; i < 3; i++)
+    if (fabs(tv[i]) > ha[i] + hb[0] * A[i][0] + hb[1] * A[i][1] + hb[2] * A[i][2]) return 1;
+  for (int j = 0; j < 3; j++) {
+    const double tw = tv[0] * C[0][j] + tv[1] * C[1][j] + tv[2] * C[2][j];
+    if (fabs(tw) > hb[j] + ha[0] * A[0][j] + ha[1] * A[1][j] + ha[2] * A[2][j]) return 1;
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double ra = ha[i1] * A[i2][j] + ha[i2] * A[i1][j], rb = hb[j1] * A[i][j2] + hb[j2] * A[i][j1];
+      if (fabs(tv[i2] * C[i1][j] - tv[i1] * C[i2][j]) > ra + rb) return 1;
+    }
+  return 0;
+}
+int orc_dbg_mpr_calls = 0;
+int orc_dbg_sphere_pass = 0, orc_dbg_pairs = 0;
+int orc_dbg_mpr_pairs[512];
 /* geom-geom pairs of the robot (every convex pair through mjc_Convex's MPR: only "do they overlap" is read from it) */
 static void self_collide(const orc_model* m, orc_data* d) {
   d->nself = 0;
@@ -494,18 +522,27 @@ static void self_collide(const orc_model* m, orc_data* d) {
       if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
       const int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
       if (w1 && w2 && (w1 == pw2 || w2 == pw1)) continue;
-      double R1[9], p1[3], R2[9], p2[3], x[3];
+      double R1[9], p1[3], R2[9], p2[3], x[3], c1[3], c2[3];
       geom_frame(m, d, g1, R1, p1);
       geom_frame(m, d, g2, R2, p2);
-      sub3(p1, p2, x);
-      const double rs = geom_rbound(m, g1) + geom_rbound(m, g2);
+      const double *bb1 = m->geom_aabb[g1], *bb2 = m->geom_aabb[g2];
+      mat_vec(R1, bb1, c1);
+      mat_vec(R2, bb2, c2);
+      for (int k = 0; k < 3; k++) { c1[k] += p1[k]; c2[k] += p2[k]; }
+      sub3(c1, c2, x);
+      const double rs = norm3(bb1 + 3) + norm3(bb2 + 3);
+      orc_dbg_pairs++;
       if (dot3(x, x) > rs * rs) continue;
+      orc_dbg_sphere_pass++;
+      if (obb_disjoint(R1, c1, bb1 + 3, R2, c2, bb2 + 3)) continue;
       /* MuJoCo orders a pair by geom type, then by id */
       const int swap = m->geom_type[g1] > m->geom_type[g2];
       const int ga = swap ? g2 : g1, gb = swap ? g1 : g2;
       shape A, B;
       if (!shape_of(m, ga, swap ? p2 : p1, swap ? R2 : R1, &A) || !shape_of(m, gb, swap ? p1 : p2, swap ? R1 : R2, &B)) continue;
       double depth, dir[3], pos[3];
+      if (orc_dbg_mpr_calls < 256) { orc_dbg_mpr_pairs[2 * orc_dbg_mpr_calls] = ga; orc_dbg_mpr_pairs[2 * orc_dbg_mpr_calls + 1] = gb; }
+      orc_dbg_mpr_calls++;
       if (!mpr_penetration(&A, &B, &depth, dir, pos)) continue;
       if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->nself++; }
     }

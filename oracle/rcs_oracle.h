@@ -150,6 +150,7 @@ typedef struct orc_model {
   /* derived by orc_set0 */
   double dof_invweight0[ORC_MAXV];
   double body_invweight0[ORC_MAXBODY]; /* translational component (mjModel.body_invweight0[.][0]) */
+  double geom_aabb[ORC_MAXGEOM][6];    /* bounding box in the geom frame: centre, half extents (mjModel.geom_aabb) */
   /* dry joint friction (mjModel dof_frictionloss, dof_solref, dof_solimp) */
   double dof_frictionloss[ORC_MAXV];
   double dof_solref[ORC_MAXV][2];

@@ -75,7 +75,7 @@ class OrcModel(C.Structure):
         ("geom_pos", D * 3 * MAXGEOM), ("geom_quat", D * 4 * MAXGEOM), ("geom_size", D * 3 * MAXGEOM),
         ("geom_friction", D * 3 * MAXGEOM),
         ("mesh_vert", C.POINTER(D)), ("body_weldid", I * MAXBODY), ("resolve_contacts", I),
-        ("dof_invweight0", D * MAXV), ("body_invweight0", D * MAXBODY),
+        ("dof_invweight0", D * MAXV), ("body_invweight0", D * MAXBODY), ("geom_aabb", D * 6 * MAXGEOM),
         ("dof_frictionloss", D * MAXV), ("dof_solref", D * 2 * MAXV), ("dof_solimp", D * 5 * MAXV),
         ("box", OrcBox),
     ]

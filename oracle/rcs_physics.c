@@ -767,6 +767,24 @@ void orc_set0(orc_model* m) {
     chol_solve(L, m->njnt, e);
     m->dof_invweight0[j] = e[j];
   }
+  /* geom_aabb: bounding box in the geom frame (mesh: of its vertices) */
+  for (int g = 0; g < m->ngeom; g++) {
+    double* bb = m->geom_aabb[g];
+    const double* sz = m->geom_size[g];
+    memset(bb, 0, 6 * sizeof(double));
+    if (m->geom_type[g] == 7 && m->geom_vertnum[g] > 0) {
+      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (int v = 0; v < m->geom_vertnum[g]; v++)
+        for (int k = 0; k < 3; k++) {
+          const double w = m->mesh_vert[3 * (m->geom_vertadr[g] + v) + k];
+          if (w < lo[k]) lo[k] = w;
+          if (w > hi[k]) hi[k] = w;
+        }
+      for (int k = 0; k < 3; k++) { bb[k] = 0.5 * (lo[k] + hi[k]); bb[3 + k] = 0.5 * (hi[k] - lo[k]); }
+    } else if (m->geom_type[g] == 6) { bb[3] = sz[0]; bb[4] = sz[1]; bb[5] = sz[2]; }
+    else if (m->geom_type[g] == 3) { bb[3] = bb[4] = sz[0]; bb[5] = sz[0] + sz[1]; }
+    else if (m->geom_type[g] == 2) { bb[3] = bb[4] = bb[5] = sz[0]; }
+  }
   /* body_invweight0 (translational): mean diagonal of J M^-1 J' for the body's centre-of-mass Jacobian at qpos0 */
   for (int b = 0; b < m->nbody; b++) {
     m->body_invweight0[b] = 0;

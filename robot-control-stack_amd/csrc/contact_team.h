@@ -236,17 +236,60 @@ struct Shape {
   int nvert;
   double center[3];
 };
+// Hull support: the FIRST vertex of largest projection (what a serial scan with a strict comparison finds).
+// TEAM = false: the calling lane scans all vertices (global memory).  TEAM = true: the 16 lanes of a team compute the same
+// query on vertices staged in LDS, scan every 16th vertex each and agree on the winner (value, then lower index) with four
+// row rotations -- a lane scanning global memory alone pays a full round trip per vertex, its wavefront having nothing else
+// to run.
+template <bool TEAM>
+RCSH_D int hull_support_index(const double* verts_, int nvert, const double* l) {
+  double bestv = -INFINITY;
+  int bi = 0;
+  if (!TEAM) {
+    const double* verts = verts_;
+    for (int i = 0; i < nvert; ++i) {
+      const double v = verts[3 * i] * l[0] + verts[3 * i + 1] * l[1] + verts[3 * i + 2] * l[2];
+      if (v > bestv) { bestv = v; bi = i; }
+    }
+    return bi;
+  }
+  const double* verts = in_lds(verts_);
+  const int t = threadIdx.x & (kTeamLanes - 1);
+  bi = 0x7fffffff;  // (a lane without vertices: -inf and the largest index, never wins)
+  for (int i0 = t; i0 < nvert; i0 += 4 * kTeamLanes) {
+    // four vertices per trip: their reads go out together
+    double x[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kTeamLanes < nvert ? i0 + u * kTeamLanes : i0;
+      x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
+    }
+    sched_fence();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kTeamLanes;
+      const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];
+      if (i < nvert && v > bestv) { bestv = v; bi = i; }
+    }
+  }
+#define RCSH_ROT_MAX(N)                                                            \
+  {                                                                                \
+    const double ov = row_rotate<N>(bestv);                                        \
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, 0x120 + N, 0xf, 0xf, true);  \
+    if (ov > bestv || (ov == bestv && oi < bi)) { bestv = ov; bi = oi; }           \
+  }
+  RCSH_ROT_MAX(8) RCSH_ROT_MAX(4) RCSH_ROT_MAX(2) RCSH_ROT_MAX(1)
+#undef RCSH_ROT_MAX
+  return bi;
+}
+template <bool TEAM = false>
 RCSH_D void shape_support(const Shape& s, const double* dir, double* out) {
   double l[3], w[3] = {0, 0, 0};
   mulTv(s.R, dir, l);
   if (s.type == 0) {
-    double bestv = -INFINITY;
-    int bi = 0;
-    for (int i = 0; i < s.nvert; ++i) {
-      const double v = s.verts[3 * i] * l[0] + s.verts[3 * i + 1] * l[1] + s.verts[3 * i + 2] * l[2];
-      if (v > bestv) { bestv = v; bi = i; }
-    }
-    w[0] = s.verts[3 * bi]; w[1] = s.verts[3 * bi + 1]; w[2] = s.verts[3 * bi + 2];
+    const int bi = hull_support_index<TEAM>(s.verts, s.nvert, l);
+    const double* vv = TEAM ? in_lds(s.verts) : s.verts;
+    w[0] = vv[3 * bi]; w[1] = vv[3 * bi + 1]; w[2] = vv[3 * bi + 2];
   } else if (s.type == 1) {
     for (int k = 0; k < 3; ++k) w[k] = l[k] >= 0 ? s.size[k] : -s.size[k];
   } else {
@@ -258,10 +301,11 @@ RCSH_D void shape_support(const Shape& s, const double* dir, double* out) {
   out[0] += s.p[0]; out[1] += s.p[1]; out[2] += s.p[2];
 }
 struct MprPt { double v[3], v1[3], v2[3]; };
+template <bool TEAM = false>
 RCSH_D void mpr_support(const Shape& a, const Shape& b, const double* dir, MprPt& o) {
   const double nd[3] = {-dir[0], -dir[1], -dir[2]};
-  shape_support(a, dir, o.v1);
-  shape_support(b, nd, o.v2);
+  shape_support<TEAM>(a, dir, o.v1);
+  shape_support<TEAM>(b, nd, o.v2);
   for (int k = 0; k < 3; ++k) o.v[k] = o.v1[k] - o.v2[k];
 }
 RCSH_D void portal_dir(const MprPt& p1, const MprPt& p2, const MprPt& p3, double* dir) {
@@ -298,7 +342,10 @@ RCSH_D double origin_tri_dist2(const double* a, const double* b, const double* c
   for (int k = 0; k < 3; ++k) witness[k] = a[k] + s * ab[k] + t * ac[k];
   return dot3(witness, witness);
 }
-RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
+// Returns 0 when the shapes do not overlap; dir_out is then a direction along which the support of A - B is not positive
+// (a separating direction), or the zero vector where the refinement gave up without one.
+template <bool TEAM>
+RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
   constexpr double kTol = 1e-6;
   constexpr int kIter = 50;
   MprPt p0, p1, p2, p3, p4;
@@ -307,8 +354,8 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
   if (fabs(p0.v[0]) < kMinVal && fabs(p0.v[1]) < kMinVal && fabs(p0.v[2]) < kMinVal) p0.v[0] = 1e-5;
   double l = sqrt(dot3(p0.v, p0.v));
   for (int k = 0; k < 3; ++k) dir[k] = -p0.v[k] / l;
-  mpr_support(A, B, dir, p1);
-  if (dot3(p1.v, dir) <= 0) return 0;
+  mpr_support<TEAM>(A, B, dir, p1);
+  if (dot3(p1.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; return 0; }
   cross3(p0.v, p1.v, dir);
   l = sqrt(dot3(dir, dir));
   if (l < 1e-12) {
@@ -318,8 +365,8 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
     return 1;
   }
   for (int k = 0; k < 3; ++k) dir[k] /= l;
-  mpr_support(A, B, dir, p2);
-  if (dot3(p2.v, dir) <= 0) return 0;
+  mpr_support<TEAM>(A, B, dir, p2);
+  if (dot3(p2.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; return 0; }
   for (int k = 0; k < 3; ++k) { va[k] = p1.v[k] - p0.v[k]; vb[k] = p2.v[k] - p0.v[k]; }
   cross3(va, vb, dir);
   l = sqrt(dot3(dir, dir));
@@ -329,9 +376,9 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
     for (int k = 0; k < 3; ++k) dir[k] = -dir[k];
   }
   for (int guard = 0;; ++guard) {
-    if (guard > 100) return 0;
-    mpr_support(A, B, dir, p3);
-    if (dot3(p3.v, dir) <= 0) return 0;
+    if (guard > 100) { dir_out[0] = dir_out[1] = dir_out[2] = 0.0; return 0; }
+    mpr_support<TEAM>(A, B, dir, p3);
+    if (dot3(p3.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; return 0; }
     bool cont = false;
     cross3(p1.v, p3.v, va);
     if (dot3(va, p0.v) < -kMinVal) { p2 = p3; cont = true; }
@@ -348,15 +395,19 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
   for (int it = 0;; ++it) {
     portal_dir(p1, p2, p3, dir);
     if (dot3(dir, p1.v) >= 0) break;
-    mpr_support(A, B, dir, p4);
+    mpr_support<TEAM>(A, B, dir, p4);
     const double dv4 = dot3(p4.v, dir);
     const double dmax = fmax(dot3(p1.v, dir), fmax(dot3(p2.v, dir), dot3(p3.v, dir)));
-    if (dv4 < 0 || dv4 - dmax <= kTol || it > kIter) return 0;
+    if (dv4 < 0 || dv4 - dmax <= kTol || it > kIter) {
+      const double keep = dv4 < 0 ? 1.0 : 0.0;
+      dir_out[0] = keep * dir[0]; dir_out[1] = keep * dir[1]; dir_out[2] = keep * dir[2];
+      return 0;
+    }
     expand_portal(p0, p1, p2, p3, p4);
   }
   for (int it = 0;; ++it) {
     portal_dir(p1, p2, p3, dir);
-    mpr_support(A, B, dir, p4);
+    mpr_support<TEAM>(A, B, dir, p4);
     const double dv4 = dot3(p4.v, dir);
     const double dmax = fmax(dot3(p1.v, dir), fmax(dot3(p2.v, dir), dot3(p3.v, dir)));
     if (dv4 - dmax <= kTol || it > kIter) {
@@ -389,10 +440,26 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
   }
 }
 
-// ---- self collision, flags only.  Lane t of a team takes pairs t, t + 16, ... of the table: bounding spheres first, then the
-// portal refinement of dev_mpr (mjc_Convex for every convex pair: only "do they overlap" is read from it).  F: world frames
-// of the team's links, [NL][12] in LDS (R row-major, p); geoms welded to the world carry their world frame in the table.
-// Returns the class bits of the overlapping pairs this lane found.
+RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
+  return mpr_penetration<false>(A, B, depth, dir_out, pos);
+}
+
+// ---- self collision, flags only (DET instantiations of k_run_team).  Every lane of the wavefront calls this.
+// Broad phase: lane t of a team whose collision callback is due takes pairs t, t + 16, ... of the table, three at a time so
+// that their records travel together -- bounding spheres, then the geoms' oriented boxes, all from the pair record.
+// Narrow phase: a surviving pair (typically one per environment: links 5 and 7 wrap around the same wrist) has its two
+// hulls staged in LDS by the whole wavefront, once for all the teams it survived in; each of those teams then runs the
+// portal refinement (mjc_Convex for every convex pair: only "do they overlap" is read from it) identically on its 16 lanes,
+// which share the vertex scans of the support queries.
+// Fall: world frames of the links of the wavefront's four teams, [4][NL][12] in LDS (R row-major, p); geoms welded to the
+// world carry their world frame in the table.  stage: LDS room for kSelfStage doubles.
+// Returns the class bits of the overlapping pairs of the calling lane's team.
+constexpr int kSelfStageVerts = 400;  // both hulls of a pair (host: build_self_pairs checks)
+constexpr int kSelfStage = 3 * kSelfStageVerts;
+constexpr int kSelfCache = 4 * 8;      // per team two remembered separating directions (pair index, direction)
+constexpr int kSelfTag = 2;            // which pair the stage holds
+constexpr int kMaxSelfPairs = 160;     // pairs whose bounding spheres the lean DET kernels keep in LDS (host: build_self_pairs)
+constexpr int kSelfSphereWords = 9;    // per pair: c0, r0 + r1 (inflated by the rounding), c1 as float, the two links
 RCSH_D void self_geom_world(const ContactGeom& g, const double* F, double* R, double* p) {
   if (g.link < 0) {
 #pragma unroll
@@ -409,28 +476,217 @@ RCSH_D void self_geom_world(const ContactGeom& g, const double* F, double* R, do
   mulmv(LR, g.pos, p);
   p[0] += L[9]; p[1] += L[10]; p[2] += L[11];
 }
-RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const double* verts, const SelfPair* pairs, int npair, const double* F_, int t) {
-  const double* F = in_lds(F_);
+// oriented boxes (centre c, axes = columns of R, half extents h): true if a separating axis exists among the 15 candidates
+RCSH_D bool obb_disjoint(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb) {
+  double C[9], A[9], tw[3], tv[3];
+  const double d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+  mulTv(Ra, d, tv);  // centre offset in A's frame
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      C[3 * i + j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];  // A_i . B_j
+      A[3 * i + j] = fabs(C[3 * i + j]) + 1e-9;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (fabs(tv[i]) > ha[i] + hb[0] * A[3 * i] + hb[1] * A[3 * i + 1] + hb[2] * A[3 * i + 2]) return true;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    tw[j] = tv[0] * C[j] + tv[1] * C[3 + j] + tv[2] * C[6 + j];
+    if (fabs(tw[j]) > hb[j] + ha[0] * A[j] + ha[1] * A[3 + j] + ha[2] * A[6 + j]) return true;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double ra = ha[i1] * A[3 * i2 + j] + ha[i2] * A[3 * i1 + j];
+      const double rb = hb[j1] * A[3 * i + j2] + hb[j2] * A[3 * i + j1];
+      if (fabs(tv[i2] * C[3 * i1 + j] - tv[i1] * C[3 * i2 + j]) > ra + rb) return true;
+    }
+  return false;
+}
+// bounding box of a collision geom in its own frame: centre, half extents
+RCSH_D void geom_obb(const ContactGeom& g, double* c, double* h) {
+  if (g.type == 7) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c[k] = g.aabb_c[k]; h[k] = g.aabb_h[k]; }
+  } else {
+    c[0] = c[1] = c[2] = 0.0;
+    if (g.type == 6) { h[0] = g.size[0]; h[1] = g.size[1]; h[2] = g.size[2]; }
+    else { h[0] = h[1] = g.size[0]; h[2] = g.size[0] + g.size[1]; }
+  }
+}
+RCSH_D void self_box_world(const double* F, int link, const double* c, const double* rot, double* cw, double* Rw) {
+  if (link < 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cw[k] = c[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rw[k] = rot[k];
+    return;
+  }
+  const double* L = F + 12 * link;
+  double LR[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) LR[k] = L[k];
+  mulmv(LR, c, cw);
+  cw[0] += L[9]; cw[1] += L[10]; cw[2] += L[11];
+  mulmm(LR, rot, Rw);
+}
+// Fills the LDS copy of the pairs' bounding spheres (single precision, the sum of the radii rounded up: conservative).
+RCSH_D void self_sphere_table_fill(const SelfPair* pairs, int npair, float* tab) {
+  for (int i = threadIdx.x; i < npair; i += 64) {
+    const SelfPair& pr = pairs[i];
+    float* w = tab + kSelfSphereWords * i;
+    w[0] = (float)pr.c0[0]; w[1] = (float)pr.c0[1]; w[2] = (float)pr.c0[2];
+    w[3] = (float)pr.c1[0]; w[4] = (float)pr.c1[1]; w[5] = (float)pr.c1[2];
+    w[6] = (float)(pr.r0 + pr.r1) * 1.000001f + 1e-6f;
+    reinterpret_cast<int*>(w)[7] = pr.l0;
+    reinterpret_cast<int*>(w)[8] = pr.l1;
+  }
+}
+RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const double* verts, const SelfPair* pairs, int npair, const double* Fall_,
+                                              double* stage_, int nl, bool team_due, bool keep_stage, const float* sph_) {
+  const double* Fall = in_lds(Fall_);
+  double* stage = in_lds(stage_);
+  const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
+  const double* F = Fall + 12 * nl * team;
+  uint32_t cmask = 0, smask = 0;  // survivors of the broad phase (of its bounding spheres): bit j = pair t + 16 j
+  TEAM_MARK(42)
+  if (team_due && sph_) {
+    // the pairs' bounding spheres from their LDS table
+    const float* sph = in_lds(sph_);
+    for (int j = 0, i = t; i < npair; ++j, i += kTeamLanes) {
+      const float* w = sph + kSelfSphereWords * i;
+      const double c0[3] = {w[0], w[1], w[2]}, c1[3] = {w[3], w[4], w[5]}, rs = w[6];
+      const int l0 = reinterpret_cast<const int*>(w)[7], l1 = reinterpret_cast<const int*>(w)[8];
+      double s0[3], s1[3];
+      if (l0 >= 0) { const double* L = F + 12 * l0; mulmv(L, c0, s0); s0[0] += L[9]; s0[1] += L[10]; s0[2] += L[11]; }
+      else { s0[0] = c0[0]; s0[1] = c0[1]; s0[2] = c0[2]; }
+      if (l1 >= 0) { const double* L = F + 12 * l1; mulmv(L, c1, s1); s1[0] += L[9]; s1[1] += L[10]; s1[2] += L[11]; }
+      else { s1[0] = c1[0]; s1[1] = c1[1]; s1[2] = c1[2]; }
+      const double d[3] = {s0[0] - s1[0], s0[1] - s1[1], s0[2] - s1[2]};
+      if (dot3(d, d) <= rs * rs) smask |= 1u << j;
+    }
+  } else if (team_due) {
+    constexpr int kBatch = 3;
+    for (int j0 = 0; t + kTeamLanes * j0 < npair; j0 += kBatch) {
+      // the spheres of up to three pairs: one round trip
+      double c0[kBatch][3], c1[kBatch][3], rs[kBatch];
+      int l0[kBatch], l1[kBatch];
+      bool have[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int i = t + kTeamLanes * (j0 + u);
+        have[u] = i < npair;
+        const SelfPair& pr = pairs[have[u] ? i : t];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { c0[u][k] = pr.c0[k]; c1[u][k] = pr.c1[k]; }
+        rs[u] = pr.r0 + pr.r1;
+        l0[u] = pr.l0; l1[u] = pr.l1;
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        if (!have[u]) continue;
+        double s0[3], s1[3];
+        if (l0[u] >= 0) { const double* L = F + 12 * l0[u]; mulmv(L, c0[u], s0); s0[0] += L[9]; s0[1] += L[10]; s0[2] += L[11]; }
+        else { s0[0] = c0[u][0]; s0[1] = c0[u][1]; s0[2] = c0[u][2]; }
+        if (l1[u] >= 0) { const double* L = F + 12 * l1[u]; mulmv(L, c1[u], s1); s1[0] += L[9]; s1[1] += L[10]; s1[2] += L[11]; }
+        else { s1[0] = c1[u][0]; s1[1] = c1[u][1]; s1[2] = c1[u][2]; }
+        const double d[3] = {s0[0] - s1[0], s0[1] - s1[1], s0[2] - s1[2]};
+        if (dot3(d, d) <= rs[u] * rs[u]) smask |= 1u << (j0 + u);
+      }
+    }
+  }
+  // the oriented boxes of the spheres' survivors (a handful per environment): one per lane and round, so that the wavefront
+  // runs the box test once or twice instead of in every iteration of the loop above
+  while (__ballot(smask != 0)) {
+    if (smask) {
+      const int j = __ffs((int)smask) - 1;
+      smask &= smask - 1;
+      const SelfPair& pr = pairs[t + kTeamLanes * j];
+      double Ra[9], Rb[9], ca[3], cb[3];
+      self_box_world(F, pr.l0, pr.c0, pr.rot0, ca, Ra);
+      self_box_world(F, pr.l1, pr.c1, pr.rot1, cb, Rb);
+      if (!obb_disjoint(Ra, ca, pr.h0, Rb, cb, pr.h1)) cmask |= 1u << j;
+    }
+  }
   uint32_t mine = 0;
-  for (int i = t; i < npair; i += kTeamLanes) {
-    const SelfPair pr = pairs[i];
+  TEAM_MARK(43)
+  TEAM_COUNT(47)
+  for (uint64_t pending = __ballot(cmask != 0); pending; pending = __ballot(cmask != 0)) {
+    TEAM_COUNT(46)
+    const int src = __ffsll((long long)pending) - 1;  // wave-uniform
+    const uint32_t smask = (uint32_t)__builtin_amdgcn_readlane((int)cmask, src);
+    const int j = __ffs((int)smask) - 1, t0 = src & (kTeamLanes - 1);
+    // the teams this pair survived in (their lane t0 holds bit j) take it together
+    const bool holder = t == t0 && ((cmask >> j) & 1u);
+    const uint32_t take = team_ballot(holder);  // 0 or 1 << t0 for the caller's team
+    if (holder) cmask &= ~(1u << j);
+    const SelfPair& pr = pairs[t0 + kTeamLanes * j];
     const ContactGeom& a = geoms[pr.g0];
     const ContactGeom& b = geoms[pr.g1];
-    double Ra[9], pa[3], Rb[9], pb[3];
-    self_geom_world(a, F, Ra, pa);
-    self_geom_world(b, F, Rb, pb);
-    const double d[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-    const double rs = a.rbound + b.rbound;
-    if (dot3(d, d) > rs * rs) continue;
-    Shape A, B;
-    A.type = a.type == 7 ? 0 : a.type == 6 ? 1 : 2; A.p = pa; A.R = Ra; A.size = a.size; A.verts = verts + 3 * (size_t)a.vert_adr; A.nvert = a.vert_num;
-    B.type = b.type == 7 ? 0 : b.type == 6 ? 1 : 2; B.p = pb; B.R = Rb; B.size = b.size; B.verts = verts + 3 * (size_t)b.vert_adr; B.nvert = b.vert_num;
-    if (a.type == 7) { mulmv(Ra, a.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
-    else { A.center[0] = pa[0]; A.center[1] = pa[1]; A.center[2] = pa[2]; }
-    if (b.type == 7) { mulmv(Rb, b.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
-    else { B.center[0] = pb[0]; B.center[1] = pb[1]; B.center[2] = pb[2]; }
-    double depth, dir[3], pos[3];
-    if (dev_mpr(A, B, &depth, dir, pos)) mine |= (uint32_t)pr.cls;
+    // both hulls' vertices -> LDS: independent loads, one memory round trip for the wavefront.  The pair staged last stays
+    // (the same pair keeps coming back substep after substep); the tag is only trusted where this function owns the
+    // memory for the whole launch (`keep_stage`: not inside the contact arena).
+    const int na = 3 * a.vert_num, nb = 3 * b.vert_num;
+    const int pidx = t0 + kTeamLanes * j;
+    double* tag = stage + kSelfStage + kSelfCache;
+    if (!(keep_stage && tag[0] == (double)(pidx + 1))) {
+      const double* va = verts + 3 * (size_t)a.vert_adr;
+      const double* vb = verts + 3 * (size_t)b.vert_adr;
+      for (int k = lane; k < na; k += 64) stage[k] = va[k];
+      for (int k = lane; k < nb; k += 64) stage[na + k] = vb[k];
+      if (lane == 0) tag[0] = (double)(pidx + 1);
+      stage_fence();  // (LDS traffic of one wavefront is ordered)
+    }
+    TEAM_MARK(44)
+    if (take) {
+      double Ra[9], pa[3], Rb[9], pb[3];
+      self_geom_world(a, F, Ra, pa);
+      self_geom_world(b, F, Rb, pb);
+      Shape A, B;
+      A.type = a.type == 7 ? 0 : a.type == 6 ? 1 : 2; A.p = pa; A.R = Ra; A.size = a.size; A.verts = stage; A.nvert = a.vert_num;
+      B.type = b.type == 7 ? 0 : b.type == 6 ? 1 : 2; B.p = pb; B.R = Rb; B.size = b.size; B.verts = stage + na; B.nvert = b.vert_num;
+      if (a.type == 7) { mulmv(Ra, a.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
+      else { A.center[0] = pa[0]; A.center[1] = pa[1]; A.center[2] = pa[2]; }
+      if (b.type == 7) { mulmv(Rb, b.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
+      else { B.center[0] = pb[0]; B.center[1] = pb[1]; B.center[2] = pb[2]; }
+      // A pair that keeps surviving the broad phase (links 5 and 7) is separated by nearly the same plane substep after
+      // substep: the direction the last refinement ended on is remembered in the frame of geom 0's link, and one support
+      // query along it settles the pair while it still separates.  (Whatever the slot holds, a direction with negative
+      // support proves the hulls apart; anything else falls through to the full refinement.)
+      TEAM_MARK(37)
+      double* slot = stage + kSelfStage + 8 * team + 4 * (pidx & 1);
+      bool apart = false;
+      double LR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      if (pr.l0 >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) LR[k] = F[12 * pr.l0 + k];
+      }
+      if (slot[0] == (double)pidx) {
+        const double dl[3] = {slot[1], slot[2], slot[3]};
+        double dw[3];
+        mulmv(LR, dl, dw);
+        MprPt q;
+        mpr_support<true>(A, B, dw, q);
+        apart = dot3(q.v, dw) < 0;
+      }
+      TEAM_MARK(38)
+      if (apart) { TEAM_COUNT(39) }
+      if (!apart) {
+        double depth, dir[3], pos[3];
+        if (mpr_penetration<true>(A, B, &depth, dir, pos)) mine |= (uint32_t)pr.cls;
+        else {
+          double dl[3];
+          mulTv(LR, dir, dl);
+          slot[0] = (double)pidx; slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
+        }
+      }
+    }
+    stage_fence();
+    TEAM_MARK(45)
   }
   return mine;
 }

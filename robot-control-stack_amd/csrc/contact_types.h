@@ -32,7 +32,13 @@ struct ContactGeom {
 // ContactTable::geoms, in MuJoCo's order within a contact (by geom type, then by id).
 struct SelfPair {
   int16_t g0, g1;
-  int32_t cls;  // bit 0: SimRobot::collision_callback counts the contact, bit 1: SimGripper::collision_callback does
+  int16_t l0, l1;  // their links (-1: welded to the world)
+  int32_t cls;     // bit 0: SimRobot::collision_callback counts the contact, bit 1: SimGripper::collision_callback does
+  int32_t pad;
+  // broad phase, in the frames of the two links: centre of the geom's bounding box and its half diagonal (bounding sphere);
+  // then the box itself -- axes (columns of rot: geom frame in the link frame) and half extents
+  double c0[3], r0, c1[3], r1;
+  double rot0[9], h0[3], rot1[9], h1[3];
 };
 
 struct ContactTable {

@@ -191,8 +191,10 @@ int upload_coll_classes(rcsh_sim* s) {
 // parent-child pair unless one of the two is welded to the world), then what the callbacks make of a contact of the pair
 // (SimRobot.cpp:172-182: either geom is an arm collision geom; SimGripper.cpp:108-130: not finger-finger, either geom is a
 // gripper collision geom, geom[1] is not in the ignore list -- quirk Q6).  Pairs nobody reacts to are dropped.
+constexpr int kSelfStageVertsHost = 400;  // contact_team.h: kSelfStageVerts
 void build_self_pairs(rcsh_sim* s) {
   s->pairs.clear();
+  if (std::getenv("RCSH_DEBUG_NO_SELF_PAIRS")) return;  // development switch: what the pair tests cost
   const int ng = (int)s->cgeoms.size();
   auto parent = [&](int link) { return link < s->narm ? link - 1 : s->narm - 1; };
   for (int i = 0; i < ng; ++i)
@@ -201,13 +203,30 @@ void build_self_pairs(rcsh_sim* s) {
       if (a.link == b.link) continue;
       if (a.link >= 0 && b.link >= 0 && (parent(a.link) == b.link || parent(b.link) == a.link)) continue;
       if ((a.type == 7 && a.vert_num == 0) || (b.type == 7 && b.vert_num == 0)) continue;  // mesh blob missing from the checkout
+      if (a.vert_num + b.vert_num > kSelfStageVertsHost) continue;  // (checked at rcsh_sim_create: hulls of at most 200 vertices)
       const bool swap = a.type > b.type;  // geom[0] / geom[1] of the contact: by type, then by id (the table is in id order)
       const ContactGeom &g0 = swap ? b : a, &g1 = swap ? a : b;
       int cls = 0;
       if ((g0.cls | g1.cls) & 1) cls |= 1;
       if (!((g0.cls & 4) && (g1.cls & 4)) && ((g0.cls | g1.cls) & 16) && !(g1.cls & 8)) cls |= 2;
       if (!cls) continue;
-      s->pairs.push_back(SelfPair{(int16_t)(swap ? j : i), (int16_t)(swap ? i : j), cls});
+      SelfPair pr{};
+      pr.g0 = (int16_t)(swap ? j : i); pr.g1 = (int16_t)(swap ? i : j);
+      pr.l0 = (int16_t)g0.link; pr.l1 = (int16_t)g1.link;
+      pr.cls = cls;
+      auto bounds = [](const ContactGeom& g, double* c, double& r, double* rot, double* h) {
+        // bounding box of the geom (geom frame: centre lc, half extents h), carried into the link frame
+        double lc[3] = {0, 0, 0};
+        if (g.type == 7) { for (int k = 0; k < 3; ++k) { lc[k] = g.aabb_c[k]; h[k] = g.aabb_h[k]; } }
+        else if (g.type == 6) { for (int k = 0; k < 3; ++k) h[k] = g.size[k]; }
+        else { h[0] = h[1] = g.size[0]; h[2] = g.size[0] + g.size[1]; }
+        for (int k = 0; k < 3; ++k) c[k] = g.rot[3 * k] * lc[0] + g.rot[3 * k + 1] * lc[1] + g.rot[3 * k + 2] * lc[2] + g.pos[k];
+        for (int k = 0; k < 9; ++k) rot[k] = g.rot[k];
+        r = std::sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+      };
+      bounds(g0, pr.c0, pr.r0, pr.rot0, pr.h0);
+      bounds(g1, pr.c1, pr.r1, pr.rot1, pr.h1);
+      s->pairs.push_back(pr);
     }
 }
 

@@ -686,10 +686,19 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // while the position stage runs (it is rebuilt from scratch whenever the contact phase starts), so with CON the frames
   // borrow it: that instantiation has no LDS to spare (38.7 of the 40 KB that let four workgroups share a CU).
   constexpr int kSelfF = 12 * T::NL;
-  __shared__ double lselfF[(DET && !CON) ? kSelfF * kTeams : 1];
-  static_assert(!CON || sizeof(ContactArena<T>) >= sizeof(double) * kSelfF * kTeams, "the link frames of four teams fit into the contact arena");
-  double* const selfF = (DET ? (CON ? reinterpret_cast<double*>(&larena[0]) : lselfF) : lselfF) + (DET ? team * kSelfF : 0);
+  __shared__ double lself[(DET && !CON) ? kSelfF * kTeams + kSelfStage + kSelfCache + kSelfTag : 1];
+  static_assert(!CON || sizeof(ContactArena<T>) >= sizeof(double) * (kSelfF * kTeams + kSelfStage + kSelfCache + kSelfTag), "link frames and hull stage fit into the contact arena");
+  double* const selfAll = (DET && CON) ? reinterpret_cast<double*>(&larena[0]) : lself;
+  double* const selfF = selfAll + (DET ? team * kSelfF : 0);
   const int npair = DET ? lp.ctab.npair : 0;
+  __shared__ float lsph[(DET && !CON) ? kMaxSelfPairs * kSelfSphereWords : 1];
+  const float* const sph = (DET && !CON && npair <= kMaxSelfPairs) ? lsph : nullptr;
+  if constexpr (DET && !CON) {
+    if (sph) self_sphere_table_fill(lp.ctab.pairs, npair, lsph);
+  }
+  if constexpr (DET && !CON) {
+    if (threadIdx.x == 0) lself[kSelfF * kTeams + kSelfStage + kSelfCache] = 0.0;  // nothing staged yet
+  }
   double* const bs = lbox + ((BOX || CON) ? team * kBoxLds : 0);
   if constexpr (CON && !BOX) {
     // the phantom box: at rest where the host parked it
@@ -744,7 +753,8 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
         due = (robot_present && t_next - r.cb(2) > robot_period) || (grip_present && t_next - r.cb(3) > grip_period);
       }
     }
-    const bool want_contacts = DET && team_ballot(due) != 0;
+    const bool team_due = DET && team_ballot(due) != 0;
+    const bool want_contacts = DET && __ballot(due) != 0;  // (the wavefront detects together: self_collision_pairs)
     uint32_t hit = 0;
     bool near = false;  // broad phase of the contact phase: the lane's link may touch the floor or the box
     bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
@@ -791,18 +801,17 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
           }
         }
         if (npair > 0) {
-          // the robot's geoms against each other: every lane publishes its link's frame, then takes its share of the pairs
+          // the robot's geoms against each other: every lane publishes its link's frame, the due teams' lanes take their
+          // share of the pairs, the wavefront settles the survivors together
           if (t < T::NL) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) selfF[12 * t + k] = R[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) selfF[12 * t + 9 + k] = p[k];
           }
-          // (teams whose callbacks are not due are not in here: no barrier -- LDS traffic of one wavefront is ordered, the
-          // fence is for the compiler)
-          stage_fence();
-          mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfF, t);
-          stage_fence();  // (CON: the frames sit in the contact arena, which the contact phase may enter next)
+          stage_fence();  // (LDS traffic of one wavefront is ordered; the fence is for the compiler)
+          mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, !CON, sph);
+          stage_fence();  // (CON: frames and stage sit in the contact arena, which the contact phase may enter next)
         }
         hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
       }

@@ -182,3 +182,27 @@ def test_pick_task_success_is_reachable_in_the_oracle():
     assert not any(s[2] for s in seen)                      # never truncated: no collision geom of arm / gripper touches anything
     assert seen[-1][1] and seen[-1][3] and seen[-1][0] == 1.0 and oe.sim.box_qpos[2] > 1.002
     assert not seen[40][1] and seen[45][4]                  # grasped long before it counts as a success
+
+
+def test_self_collision_is_detected_between_robot_geoms():
+    """SimRobot / SimGripper collision callbacks scan every contact (SimRobot.cpp:172-182, SimGripper.cpp:108-130): at the home
+    pose no two geoms of the robot touch (link 0 and link 1, which MuJoCo's parent filter lets collide because link 0 is
+    welded to the world, keep their gap); folded onto itself the arm's fingers run into link 1, the loop ends on the flag."""
+    from rcs_amd.mjcf import compile_mjcf
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cm = compile_mjcf(os.path.join(os.path.dirname(PICKUP), "..", "fr3_empty_world", "scene.xml"))
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    o = O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0")
+    o.reset(); o.robot_reset(); o.gripper_reset(); o.step(1)
+    assert o.s.d.nself == 0 and o.s.d.ncon == 0
+    o.step_until_convergence()
+    assert not o.s.robot_collision and not o.s.grp_collision
+    o.set_joint_position(np.array([-0.48, -0.88, 0.0, -2.98, -0.3, 0.97, 0.79]))
+    o.step_until_convergence()
+    d = o.s.d
+    pairs = {(cm.geom_names[d.self_geom[i][0]], cm.geom_names[d.self_geom[i][1]]) for i in range(d.nself)}
+    assert d.ncon == 0 and ("fr3_link1_collision_0", "finger_0_right_0") in pairs, pairs
+    assert (o.s.robot_collision or o.s.grp_collision) and o.s.convergence_steps < 500  # (whichever callback was due first saw it)
+    # geom[0] / geom[1] in MuJoCo's order: by type (box 6 before mesh 7), then by id
+    assert all(cm.arrays["geom_type"][d.self_geom[i][0]] <= cm.arrays["geom_type"][d.self_geom[i][1]] for i in range(d.nself))
