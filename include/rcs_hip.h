@@ -342,7 +342,7 @@ int rcsh_env_step_task_dev(rcsh_sim* sim, const double* action_dev, const float*
  * mjr_render, mjr_readPixels; python/rcs/camera/sim.py:45-115 for the row flip, the conversion to metres and the
  * uint16 millimetre image, the intrinsics and the extrinsics).  The reference rasterises MuJoCo's visual geoms with
  * OpenGL; this backend casts one ray per pixel against the shapes given here (floor plane, boxes, convex hulls of the
- * collision meshes), expressed in the frame of the link they ride on (-1: world, -2: the free box).  No colour image.
+ * collision meshes), expressed in the frame of the link they ride on (-1: world, -2: the free box).  Colour: rcsh_sim_set_render_colours.
  * Frames are those of the last position stage, as mjData.geom_xpos / cam_xpos are. */
 typedef struct rcsh_render_scene_desc {
   int32_t nshape, nplanes;
@@ -370,6 +370,36 @@ int rcsh_sim_add_camera(rcsh_sim* sim, const rcsh_camera_desc* cam, int32_t* cam
  * handle's stream. */
 int rcsh_camera_render(rcsh_sim* sim, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose);
 int rcsh_camera_render_dev(rcsh_sim* sim, int32_t cam_id, float* depth_gl_dev, uint16_t* depth_mm_dev, double* cam_pose_dev);
+/* Colour frames (the ColorFrame of FrameSet, src/sim/camera.cpp:103-118: mjr_readPixels' rgb buffer).  The image is
+ * ray-cast like the depth: the colour of the shape a ray enters first (mjModel.geom_rgba / mat_rgba; a material with the
+ * builtin checker texture alternates its two colours in squares), flat-shaded on the entry face's normal by the headlight
+ * (mjModel.vis.headlight ambient / diffuse) and one directional light of the scene; rays that leave the scene see the
+ * skybox gradient.  No textures beyond the checker, no shadows, no specular term, no transparency: not OpenGL's pixels.
+ * colour: [nshape][8] = rgb (3), second checker colour (3), edge of a checker square [m], checker flag (0 / 1). */
+typedef struct rcsh_render_colours {
+  const double* colour;
+  double headlight_ambient[3], headlight_diffuse[3];
+  double light_dir[3], light_diffuse[3]; /* directional light (world frame, pointing away from the light); diffuse 0: none */
+  double sky_rgb1[3], sky_rgb2[3];       /* zenith / nadir colour of the background */
+} rcsh_render_colours;
+int rcsh_sim_set_render_colours(rcsh_sim* sim, const rcsh_render_colours* colours);
+/* rgb: [N][H][W][3] u8, rows bottom-up (as mjr_readPixels returns them); the depth outputs as above; each may be NULL. */
+int rcsh_camera_render_rgb(rcsh_sim* sim, int32_t cam_id, uint8_t* rgb, float* depth_gl, uint16_t* depth_mm, double* cam_pose);
+int rcsh_camera_render_rgb_dev(rcsh_sim* sim, int32_t cam_id, uint8_t* rgb_dev, float* depth_gl_dev, uint16_t* depth_mm_dev, double* cam_pose_dev);
+/* Rendering callbacks: SimCameraSet(render_on_demand = false) (src/sim/camera.cpp:23-47,97-102; Sim::register_rendering_callback,
+ * invoke_rendering_callbacks, reset_callbacks: src/sim/sim.cpp:63-81,108-115,131-137,160-173).  A camera with a frame rate is due
+ * after a substep when more than seconds_between_calls (= 1 / frame_rate) of simulated time passed since its last frame; the
+ * clocks start at -seconds_between_calls, and again after Sim::reset, so the first substep renders.  A kernel cannot call the
+ * renderer: the substep loop RECORDS per environment what the renderer would have seen at that moment (the kinematic state
+ * of the substep's position stage, the new time, which cameras are due), at most `capacity` records per environment and
+ * launch, and the host renders them afterwards:
+ *   launch (any stepping / env entry point) -> rcsh_render_pending(count[N]) -> for slot < max(count):
+ *   rcsh_camera_render_snapshot(cam, slot, ..., timestamp[N], due[N]) for each scheduled camera.
+ * Images of environments whose `due` is 0 for that slot and camera are meaningless.  ncam = 0 removes the schedule. */
+int rcsh_sim_set_render_schedule(rcsh_sim* sim, const int32_t* cam_ids, const double* seconds_between_calls, int32_t ncam, int32_t capacity);
+int rcsh_render_pending(rcsh_sim* sim, int32_t* count);
+int rcsh_camera_render_snapshot(rcsh_sim* sim, int32_t cam_id, int32_t slot, uint8_t* rgb, float* depth_gl, uint16_t* depth_mm, double* cam_pose,
+                                double* timestamp, uint8_t* due);
 
 /* ---- multi-GPU: one process (one handle) per GPU, contiguous ranges of environments per rank, no data-path collective
  * except ONE exchange step: the all-gather of the observation tensor [n][obs_width] f64 of every rank into

@@ -32,9 +32,10 @@ def oracle_frames(osim, cm) -> dict:
     return frames
 
 
-def render_depth(rs, cam, frames):
+def render_depth(rs, cam, frames, colour=False):
     """rs: rcs_amd.render.RenderScene; cam: (link, pos, rot9, fovy_deg, W, H).  Returns (depth_gl [H,W] float32 rows
-    bottom-up, depth_mm [H,W] uint16 rows top-down, cam_R, cam_p)."""
+    bottom-up, depth_mm [H,W] uint16 rows top-down, cam_R, cam_p) and, with `colour`, rgb [H,W,3] uint8 rows bottom-up:
+    the colour of the shape entered first, flat-shaded on the entry face (csrc/render.h, COLOR)."""
     link, cpos, crot, fovy, W, H = cam
     Rl, pl = frames[link]
     cR, cp = Rl @ np.asarray(crot).reshape(3, 3), Rl @ np.asarray(cpos) + pl
@@ -46,6 +47,8 @@ def render_depth(rs, cam, frames):
     dd = (d * d).sum(-1)
     best = np.full((H, W), rs.zfar)
     hit = np.zeros((H, W), dtype=bool)
+    hit_g = np.full((H, W), -1)
+    hit_n = np.zeros((H, W, 3))  # entry face normal, shape frame
     for g in range(len(rs.shape)):
         Rg, pg = frames[int(rs.link[g])]
         R, p = Rg @ rs.rot[g].reshape(3, 3), Rg @ rs.pos[g] + pg
@@ -65,8 +68,11 @@ def render_depth(rs, cam, frames):
             ok &= (t >= t0) & (t < t1)
             best = np.where(ok, t, best)
             hit |= ok
+            hit_g = np.where(ok, g, hit_g)
+            hit_n = np.where(ok[..., None], np.array([0.0, 0.0, 1.0]), hit_n)
             continue
         ok = live.copy()
+        face_n = np.zeros((H, W, 3))
         with np.errstate(divide="ignore", invalid="ignore"):
             if rs.shape[g] == SHAPE_BOX:
                 for k in range(3):
@@ -75,6 +81,9 @@ def render_depth(rs, cam, frames):
                     ta, tb = (-rs.size[g][k] - lo[k]) * inv, (rs.size[g][k] - lo[k]) * inv
                     ta, tb = np.minimum(ta, tb), np.maximum(ta, tb)
                     t0n, t1n = np.maximum(t0, ta), np.minimum(t1, tb)
+                    axis = np.zeros(3)
+                    axis[k] = 1.0
+                    face_n = np.where((~(zero | ~ok) & (ta > t0))[..., None], np.where(ld[..., k] > 0, -1.0, 1.0)[..., None] * axis, face_n)
                     t0, t1 = np.where(zero | ~ok, t0, t0n), np.where(zero | ~ok, t1, t1n)
                     ok &= np.where(zero, abs(lo[k]) <= rs.size[g][k], t0 <= t1)
             else:
@@ -85,15 +94,42 @@ def render_depth(rs, cam, frames):
                     t = no / nd
                     t0n = np.where(nd < 0, np.maximum(t0, t), t0)
                     t1n = np.where(nd > 0, np.minimum(t1, t), t1)
+                    face_n = np.where((~(zero | ~ok) & (nd < 0) & (t > t0))[..., None], pl4[:3], face_n)
                     t0, t1 = np.where(zero | ~ok, t0, t0n), np.where(zero | ~ok, t1, t1n)
                     ok &= np.where(zero, no >= 0, t0 <= t1)
         ok &= (t0 > rs.znear) & (t0 < best)
         best = np.where(ok, t0, best)
         hit |= ok
+        hit_g = np.where(ok, g, hit_g)
+        hit_n = np.where(ok[..., None], face_n, hit_n)
     inv_near, inv_far = 1.0 / rs.znear, 1.0 / rs.zfar
     dgl = np.where(hit, (inv_near - 1.0 / best) / (inv_near - inv_far), 1.0).astype(np.float32)
     # python/rcs/camera/sim.py:57-86 on the buffer mjr_readPixels returned
     frame = dgl[::-1]
     z = np.float32(rs.znear) / (np.float32(1) - frame * np.float32(1 - rs.znear / rs.zfar))
     mm = (z * np.float32(1000)).astype(np.uint16)
-    return dgl, mm, cR, cp
+    if not colour:
+        return dgl, mm, cR, cp
+    inv_len = 1.0 / np.sqrt(dd)
+    f = 0.5 * (d[..., 2] * inv_len + 1.0)
+    out = rs.sky_rgb2 + f[..., None] * (rs.sky_rgb1 - rs.sky_rgb2)
+    ldir = rs.light_dir / np.linalg.norm(rs.light_dir)
+    for g in range(len(rs.shape)):
+        m = hit & (hit_g == g)
+        if not m.any():
+            continue
+        Rg, pg = frames[int(rs.link[g])]
+        R, p = Rg @ rs.rot[g].reshape(3, 3), Rg @ rs.pos[g] + pg
+        nw = hit_n @ R.T
+        nn = 1.0 / np.sqrt((nw * nw).sum(-1))
+        kv = np.maximum(-(nw * d).sum(-1) * nn * inv_len, 0.0)
+        kl = np.maximum(-(nw @ ldir) * nn, 0.0)
+        base = np.broadcast_to(rs.colour[g][:3], (H, W, 3))
+        if rs.colour[g][7] != 0:
+            hp = (cp + best[..., None] * d - p) @ R
+            second = ((np.floor(hp[..., 0] / rs.colour[g][6]).astype(np.int64) + np.floor(hp[..., 1] / rs.colour[g][6]).astype(np.int64)) & 1) != 0
+            base = np.where(second[..., None], rs.colour[g][3:6], rs.colour[g][:3])
+        shaded = base * (rs.headlight_ambient + rs.headlight_diffuse * kv[..., None] + rs.light_diffuse * kl[..., None])
+        out = np.where(m[..., None], shaded, out)
+    rgb = (np.clip(out, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+    return dgl, mm, cR, cp, rgb

@@ -79,6 +79,11 @@ struct rcsh_sim {
   RenderScene rscene{};
   RenderShape* d_rshapes = nullptr;
   double* d_rplanes = nullptr;
+  RenderColour* d_rcolours = nullptr;
+  RendCfg rend{};                    // rate-driven cameras (rcsh_sim_set_render_schedule)
+  int rend_cam_id[kMaxRateCams] = {0, 0, 0, 0};
+  const double* frames_src = nullptr; // set while a record of the render schedule is being rendered
+  const double* frames_src_base(int slot) const { return rend.snap + (size_t)slot * (size_t)(nl + 9) * (size_t)n; }
   double* d_frames = nullptr;
   double* d_wframes = nullptr;  // world frames of the shapes + camera per environment (k_shape_frames)
   std::vector<RenderCam> cams;
@@ -137,6 +142,7 @@ Params make_params(rcsh_sim* s) {
   P.boxtask = s->d_boxtask;
   P.ctab.geoms = s->d_cgeoms;
   P.ctab.verts = s->d_cverts;
+  P.rend = s->rend;
   P.ctab.pairs = s->d_pairs;
   P.ctab.npair = (int)s->pairs.size();
   P.ctab.ngeom = s->box.resolve ? (int)s->cgeoms.size() : 0;
@@ -525,7 +531,8 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs);
-  hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
+  hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
+  hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_rcolours); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
@@ -622,6 +629,18 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
     for (int e = 0; e < s->n; ++e)
       for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = b0[(size_t)e * kBoxState + kBoxPre + k] = s->box.qpos0[k];
     rc = scatter_host(s, field_of(s, "box"), kBoxState, b0.data(), mask);
+  }
+  if (!rc && s->rend.ncam > 0) {
+    // reset_callbacks (sim.cpp:131-137): the cameras' clocks go back to -seconds_between_calls
+    const size_t n = (size_t)s->n;
+    std::vector<double> last(kMaxRateCams * n);
+    HIP_TRY(hipMemcpyAsync(last.data(), s->rend.last, sizeof(double) * last.size(), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int c = 0; c < s->rend.ncam; ++c)
+      for (size_t e = 0; e < n; ++e)
+        if (!mask || mask[e]) last[c * n + e] = -s->rend.period[c];
+    HIP_TRY(hipMemcpyAsync(s->rend.last, last.data(), sizeof(double) * last.size(), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
   }
   return rc;
 }
@@ -1237,8 +1256,9 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
     for (int k = 0; k < 4; ++k) r.sphere[k] = d->sphere[4 * i + k];
   }
   HIP_TRY(hipSetDevice(s->device));
-  hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes);
-  s->d_rshapes = nullptr; s->d_rplanes = nullptr; s->d_frames = nullptr; s->d_wframes = nullptr;
+  hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_rcolours);
+  s->d_rshapes = nullptr; s->d_rplanes = nullptr; s->d_frames = nullptr; s->d_wframes = nullptr; s->d_rcolours = nullptr;
+  s->rscene.colours = nullptr;
   const int np = d->nplanes > 0 ? d->nplanes : 1;
   HIP_TRY(hipMalloc(&s->d_rshapes, sizeof(RenderShape) * d->nshape));
   HIP_TRY(hipMalloc(&s->d_rplanes, sizeof(double) * 4 * np));
@@ -1268,17 +1288,125 @@ int rcsh_sim_add_camera(rcsh_sim* s, const rcsh_camera_desc* c, int32_t* cam_id)
   return RCSH_OK;
 }
 
-int rcsh_camera_render_dev(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
+int rcsh_sim_set_render_colours(rcsh_sim* s, const rcsh_render_colours* c) {
   REQUIRE_SIM(s);
   if (!s->d_frames) return fail(RCSH_ERR_STATE, "no render scene: call rcsh_sim_set_render_scene first");
+  if (!c || !c->colour) return fail(RCSH_ERR_ARG, "null colour table");
+  const int ns = s->rscene.nshape;
+  std::vector<RenderColour> col(ns);
+  for (int i = 0; i < ns; ++i) {
+    const double* w = c->colour + 8 * (size_t)i;
+    for (int k = 0; k < 3; ++k) { col[i].rgb[k] = w[k]; col[i].rgb2[k] = w[3 + k]; }
+    col[i].square = w[6]; col[i].checker = w[7];
+    if (col[i].checker != 0.0 && !(col[i].square > 0)) return fail(RCSH_ERR_ARG, "render colours: checker squares need a positive edge length");
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  if (!s->d_rcolours) HIP_TRY(hipMalloc(&s->d_rcolours, sizeof(RenderColour) * ns));
+  HIP_TRY(hipMemcpyAsync(s->d_rcolours, col.data(), sizeof(RenderColour) * ns, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->rscene.colours = s->d_rcolours;
+  RenderShade& L = s->rscene.shade;
+  for (int k = 0; k < 3; ++k) {
+    L.ambient[k] = c->headlight_ambient[k]; L.head_diffuse[k] = c->headlight_diffuse[k];
+    L.light_dir[k] = c->light_dir[k]; L.light_diffuse[k] = c->light_diffuse[k];
+    L.sky1[k] = c->sky_rgb1[k]; L.sky2[k] = c->sky_rgb2[k];
+  }
+  const double dn = std::sqrt(L.light_dir[0] * L.light_dir[0] + L.light_dir[1] * L.light_dir[1] + L.light_dir[2] * L.light_dir[2]);
+  if (dn > 0) for (int k = 0; k < 3; ++k) L.light_dir[k] /= dn;
+  return RCSH_OK;
+}
+
+int rcsh_sim_set_render_schedule(rcsh_sim* s, const int32_t* cam_ids, const double* seconds_between_calls, int32_t ncam, int32_t capacity) {
+  REQUIRE_SIM(s);
+  if (!s->d_frames) return fail(RCSH_ERR_STATE, "no render scene: call rcsh_sim_set_render_scene first");
+  if (ncam < 0 || ncam > kMaxRateCams) return fail(RCSH_ERR_ARG, "render schedule: at most 4 cameras with a frame rate");
+  if (ncam > 0 && (!cam_ids || !seconds_between_calls || capacity < 1 || capacity > 256)) return fail(RCSH_ERR_ARG, "render schedule: bad arguments");
+  for (int c = 0; c < ncam; ++c) {
+    if (cam_ids[c] < 0 || cam_ids[c] >= (int)s->cams.size()) return fail(RCSH_ERR_ARG, "render schedule: unknown camera id");
+    if (!(seconds_between_calls[c] > 0)) return fail(RCSH_ERR_ARG, "render schedule: the period must be positive");
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
+  s->rend = RendCfg{};
+  if (ncam == 0) return RCSH_OK;
+  const size_t n = (size_t)s->n, nf = (size_t)s->nl + 9;
+  HIP_TRY(hipMalloc(&s->rend.last, sizeof(double) * kMaxRateCams * n));
+  HIP_TRY(hipMalloc(&s->rend.snap, sizeof(double) * (size_t)capacity * nf * n));
+  HIP_TRY(hipMalloc(&s->rend.count, sizeof(int32_t) * n));
+  HIP_TRY(hipMemsetAsync(s->rend.count, 0, sizeof(int32_t) * n, s->stream));
+  // register_rendering_callback (sim.cpp:160-173): last_call_timestamp = -1 / frame_rate, "so that we will directly render"
+  std::vector<double> last(kMaxRateCams * n, 0.0);
+  for (int c = 0; c < ncam; ++c) {
+    s->rend.period[c] = seconds_between_calls[c];
+    s->rend_cam_id[c] = cam_ids[c];
+    for (size_t e = 0; e < n; ++e) last[c * n + e] = -seconds_between_calls[c];
+  }
+  HIP_TRY(hipMemcpyAsync(s->rend.last, last.data(), sizeof(double) * last.size(), hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->rend.ncam = ncam;
+  s->rend.capacity = capacity;
+  return RCSH_OK;
+}
+
+int rcsh_render_pending(rcsh_sim* s, int32_t* count) {
+  REQUIRE_SIM(s);
+  if (!count) return fail(RCSH_ERR_ARG, "null output");
+  if (s->rend.ncam == 0) return fail(RCSH_ERR_STATE, "no render schedule: call rcsh_sim_set_render_schedule first");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemcpyAsync(count, s->rend.count, sizeof(int32_t) * s->n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  for (int e = 0; e < s->n; ++e)
+    if (count[e] > s->rend.capacity)
+      return fail(RCSH_ERR_STATE, "more frames became due in one launch than the render schedule's capacity holds");
+  return RCSH_OK;
+}
+
+int rcsh_camera_render_snapshot(rcsh_sim* s, int32_t cam_id, int32_t slot, uint8_t* rgb, float* depth_gl, uint16_t* depth_mm, double* cam_pose,
+                                double* timestamp, uint8_t* due) {
+  REQUIRE_SIM(s);
+  if (s->rend.ncam == 0) return fail(RCSH_ERR_STATE, "no render schedule: call rcsh_sim_set_render_schedule first");
+  if (slot < 0 || slot >= s->rend.capacity) return fail(RCSH_ERR_ARG, "snapshot slot out of range");
+  int which = -1;
+  for (int c = 0; c < s->rend.ncam; ++c) which = s->rend_cam_id[c] == cam_id ? c : which;
+  if (which < 0) return fail(RCSH_ERR_ARG, "camera is not part of the render schedule");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t n = (size_t)s->n, nf = (size_t)s->nl + 9;
+  // the frames kernel reads "the qpos the last position stage saw" and the box's pre-step pose through field offsets: point
+  // it at the record instead of the state
+  s->frames_src = s->rend.snap + (size_t)slot * nf * n;
+  int rc = rcsh_camera_render_rgb(s, cam_id, rgb, depth_gl, depth_mm, cam_pose);
+  s->frames_src = nullptr;
+  if (rc) return rc;
+  std::vector<double> tm(2 * n);
+  HIP_TRY(hipMemcpyAsync(tm.data(), s->frames_src_base(slot) + (size_t)(s->nl + 7) * n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  std::vector<int32_t> cnt(n);
+  HIP_TRY(hipMemcpy(cnt.data(), s->rend.count, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < n; ++e) {
+    const bool have = slot < cnt[e] && (((uint32_t)tm[n + e] >> which) & 1u);
+    if (timestamp) timestamp[e] = tm[e];
+    if (due) due[e] = have ? 1 : 0;
+  }
+  return RCSH_OK;
+}
+
+int rcsh_camera_render_rgb_dev(rcsh_sim* s, int32_t cam_id, uint8_t* rgb, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
+  REQUIRE_SIM(s);
+  if (!s->d_frames) return fail(RCSH_ERR_STATE, "no render scene: call rcsh_sim_set_render_scene first");
+  if (rgb && !s->rscene.colours) return fail(RCSH_ERR_STATE, "no colours: call rcsh_sim_set_render_colours first");
   if (cam_id < 0 || cam_id >= (int)s->cams.size()) return fail(RCSH_ERR_ARG, "unknown camera id");
   HIP_TRY(hipSetDevice(s->device));
   const RenderCam& cam = s->cams[cam_id];
   hipError_t err = hipSuccess;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    hipLaunchKernelGGL((k_link_frames<T>), dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, s->d_model, s->S, s->n,
-                       (int)Lay<T>::QPRE, (int)Lay<T>::BOX, (int)s->box.present, s->d_frames);
+    if (s->frames_src)  // a record of the render schedule: qpre at field 0, the box's pre-step pose behind it
+      hipLaunchKernelGGL((k_link_frames<T>), dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, s->d_model, s->frames_src, s->n, 0,
+                         T::NL - kBoxPre, (int)s->box.present, s->d_frames);
+    else
+      hipLaunchKernelGGL((k_link_frames<T>), dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, s->d_model, s->S, s->n,
+                         (int)Lay<T>::QPRE, (int)Lay<T>::BOX, (int)s->box.present, s->d_frames);
     err = hipGetLastError();
   });
   if (!ok) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
@@ -1286,44 +1414,52 @@ int rcsh_camera_render_dev(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_
   hipLaunchKernelGGL(k_shape_frames, dim3(grid_for(s->n * (s->rscene.nshape + 1))), dim3(kBlock), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
                      s->d_wframes);
   const int blocks_per_env = ((cam.width + 15) / 16) * ((cam.height + 15) / 16);
-  hipLaunchKernelGGL(k_render_depth, dim3((unsigned)blocks_per_env * (unsigned)s->n), dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n,
-                     depth_gl, depth_mm, cam_pose);
+  const dim3 grid((unsigned)blocks_per_env * (unsigned)s->n);
+  if (rgb)
+    hipLaunchKernelGGL(k_render_depth<true>, grid, dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n, depth_gl, depth_mm, cam_pose, rgb);
+  else
+    hipLaunchKernelGGL(k_render_depth<false>, grid, dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n, depth_gl, depth_mm, cam_pose,
+                       (uint8_t*)nullptr);
   err = hipGetLastError();
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_render_depth launch: ") + hipGetErrorString(err));
   return RCSH_OK;
 }
 
-int rcsh_camera_render(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
+int rcsh_camera_render_dev(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
+  return rcsh_camera_render_rgb_dev(s, cam_id, nullptr, depth_gl, depth_mm, cam_pose);
+}
+
+int rcsh_camera_render_rgb(rcsh_sim* s, int32_t cam_id, uint8_t* rgb, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
   REQUIRE_SIM(s);
   if (cam_id < 0 || cam_id >= (int)s->cams.size()) return fail(RCSH_ERR_ARG, "unknown camera id");
   HIP_TRY(hipSetDevice(s->device));
   const size_t px = (size_t)s->n * s->cams[cam_id].width * s->cams[cam_id].height;
-  const size_t need = px * (sizeof(float) + sizeof(uint16_t)) + sizeof(double) * 12 * s->n;
+  // device staging: f32 depth, u16 depth, camera poses (8-byte aligned), rgb
+  const size_t off_mm = px * sizeof(float), off_pose = ((off_mm + px * sizeof(uint16_t) + 7) / 8) * 8, off_rgb = off_pose + sizeof(double) * 12 * s->n;
+  const size_t need = off_rgb + 3 * px;
   if (need > s->image_cap) {
     hipFree(s->d_image);
     s->d_image = nullptr; s->image_cap = 0;
     HIP_TRY(hipMalloc(&s->d_image, need));
     s->image_cap = need;
   }
-  float* dgl = static_cast<float*>(s->d_image);
-  uint16_t* dmm = reinterpret_cast<uint16_t*>(dgl + px);
-  double* dpose = reinterpret_cast<double*>(static_cast<char*>(s->d_image) + ((px * (sizeof(float) + sizeof(uint16_t)) + 7) / 8) * 8);
-  if (need + 8 > s->image_cap) {  // room for the alignment of the pose block
-    hipFree(s->d_image);
-    s->d_image = nullptr; s->image_cap = 0;
-    HIP_TRY(hipMalloc(&s->d_image, need + 8));
-    s->image_cap = need + 8;
-    dgl = static_cast<float*>(s->d_image);
-    dmm = reinterpret_cast<uint16_t*>(dgl + px);
-    dpose = reinterpret_cast<double*>(static_cast<char*>(s->d_image) + ((px * (sizeof(float) + sizeof(uint16_t)) + 7) / 8) * 8);
-  }
-  int rc = rcsh_camera_render_dev(s, cam_id, depth_gl ? dgl : nullptr, depth_mm ? dmm : nullptr, cam_pose ? dpose : nullptr);
+  char* base = static_cast<char*>(s->d_image);
+  float* dgl = reinterpret_cast<float*>(base);
+  uint16_t* dmm = reinterpret_cast<uint16_t*>(base + off_mm);
+  double* dpose = reinterpret_cast<double*>(base + off_pose);
+  uint8_t* drgb = reinterpret_cast<uint8_t*>(base + off_rgb);
+  int rc = rcsh_camera_render_rgb_dev(s, cam_id, rgb ? drgb : nullptr, depth_gl ? dgl : nullptr, depth_mm ? dmm : nullptr, cam_pose ? dpose : nullptr);
   if (rc) return rc;
+  if (rgb) HIP_TRY(hipMemcpyAsync(rgb, drgb, 3 * px, hipMemcpyDeviceToHost, s->stream));
   if (depth_gl) HIP_TRY(hipMemcpyAsync(depth_gl, dgl, px * sizeof(float), hipMemcpyDeviceToHost, s->stream));
   if (depth_mm) HIP_TRY(hipMemcpyAsync(depth_mm, dmm, px * sizeof(uint16_t), hipMemcpyDeviceToHost, s->stream));
   if (cam_pose) HIP_TRY(hipMemcpyAsync(cam_pose, dpose, sizeof(double) * 12 * s->n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
+}
+
+int rcsh_camera_render(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* depth_mm, double* cam_pose) {
+  return rcsh_camera_render_rgb(s, cam_id, nullptr, depth_gl, depth_mm, cam_pose);
 }
 
 // ---- RCCL behind the C-ABI.  The library is dlopen'ed so that single-GPU users neither link nor load it.

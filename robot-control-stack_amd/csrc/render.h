@@ -41,11 +41,22 @@ struct RenderCam {
   double pos[3], rot[9];  // camera frame in its link's frame
   double tan_half_fovy;
 };
+// colour of a shape: rgb; a checkered plane alternates rgb / rgb2 in squares of edge `square` (shape frame x, y)
+struct RenderColour {
+  double rgb[3], rgb2[3], square, checker;
+};
+// lighting of the colour image (fixed-function style, no shadows, no specular): the headlight at the camera and one
+// directional light of the scene; rays that leave the scene see the sky gradient (zenith sky1, nadir sky2)
+struct RenderShade {
+  double ambient[3], head_diffuse[3], light_dir[3], light_diffuse[3], sky1[3], sky2[3];
+};
 struct RenderScene {
   int32_t nshape, nframes;  // nframes = links + 1 (the last entry is the free box, identity if the scene has none)
   double znear, zfar;
   const RenderShape* shapes;
   const double* planes;  // [.][4] n . x <= d
+  const RenderColour* colours;  // [nshape], null until rcsh_sim_set_render_colours
+  RenderShade shade;
 };
 
 #if defined(__HIP__)
@@ -146,8 +157,11 @@ __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* fram
 // depth_gl: [n][H][W] float32 in [0, 1], rows bottom-up (mjr_readPixels); depth_mm: [n][H][W] uint16, rows top-down,
 // millimetres (SimCameraSet with physical_units); cam_pose: [n][12] world rotation (9) and position (3) of the camera
 // (mjData.cam_xmat / cam_xpos).  Any of the three may be null.
+// COLOR: also rgb [n][H][W][3] uint8, rows bottom-up like the depth buffer: the colour of the shape the ray enters first,
+// lit by the headlight and the scene's directional light on the entry face's normal (flat shading; sc.colours).
+template <bool COLOR>
 __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam cam, const double* wf, int n, float* depth_gl,
-                                                      uint16_t* depth_mm, double* cam_pose) {
+                                                      uint16_t* depth_mm, double* cam_pose, uint8_t* rgb) {
   __shared__ double lw[(kMaxShapes + 1) * kShapeFrameDoubles];  // this environment's rows of wf (k_shape_frames)
   __shared__ uint32_t tile_shapes;  // bit g: shape g can be seen from this tile
   const int W = cam.width, H = cam.height;
@@ -205,6 +219,8 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   double best = sc.zfar;
   bool hit = false;
+  // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
+  int hit_g = -1, hit_face = 0;
   for (uint32_t todo = tile_shapes; todo; todo &= todo - 1) {
     const int g = __ffs(todo) - 1;
     const RenderShape& sh = sc.shapes[g];
@@ -226,13 +242,14 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
       if (!(ld[2] < 0 && lo[2] > 0)) continue;
       const double t = -lo[2] / ld[2];
-      if (t >= t0 && t < t1) { best = t; hit = true; }
+      if (t >= t0 && t < t1) { best = t; hit = true; if (COLOR) { hit_g = g; hit_face = 0; } }
       continue;
     }
     bool ok = true;
     // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
     // `size`): most rays that pass the sphere of an elongated link miss the link
     const double cen[3] = {sh.shape == kShapeHull ? sh.sphere[0] : 0.0, sh.shape == kShapeHull ? sh.sphere[1] : 0.0, sh.shape == kShapeHull ? sh.sphere[2] : 0.0};
+    int face = 0;
     {
       double b0 = t0, b1 = t1;
       for (int k = 0; k < 3 && ok; ++k) {
@@ -241,6 +258,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
         const double inv = fast_rcp(ld[k]);
         double ta = (-sh.size[k] - lk) * inv, tb = (sh.size[k] - lk) * inv;
         if (ta > tb) { const double x = ta; ta = tb; tb = x; }
+        if (COLOR && ta > b0) face = ld[k] > 0 ? 2 * k : 2 * k + 1;  // entered through the -k (even) or the +k (odd) face
         b0 = ta > b0 ? ta : b0;
         b1 = tb < b1 ? tb : b1;
         ok = b0 <= b1;
@@ -264,13 +282,14 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
           const double no = q4[j][3] - (q4[j][0] * lo[0] + q4[j][1] * lo[1] + q4[j][2] * lo[2]);  // >= 0: origin inside this half space
           if (nd == 0) { ok = ok && no >= 0; continue; }
           const double t = no * fast_rcp(nd);
+          if (COLOR && nd < 0 && t > t0) face = k + j < sh.plane_num ? k + j : sh.plane_num - 1;
           if (nd < 0) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
         }
         ok = ok && t0 <= t1;
       }
     }
     // a camera inside a shape sees its inside faces culled (back faces): only entry points count
-    if (ok && t0 > sc.znear && t0 < best) { best = t0; hit = true; }
+    if (ok && t0 > sc.znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; } }
   }
   const double inv_near = 1.0 / sc.znear, inv_far = 1.0 / sc.zfar;
   const float dgl = hit ? (float)((inv_near - 1.0 / best) / (inv_near - inv_far)) : 1.0f;
@@ -285,6 +304,54 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     const float z = nearf / (1.0f - prod);
     const float mm = z * 1000.0f;
     depth_mm[img + (size_t)(H - 1 - row) * W + col] = (uint16_t)mm;
+  }
+  if constexpr (COLOR) {
+    if (!rgb) return;
+    const RenderShade& L = sc.shade;
+    const double inv_len = 1.0 / sqrt(dd);
+    double out[3];
+    if (!hit) {
+      const double f = 0.5 * (d[2] * inv_len + 1.0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[c] = L.sky2[c] + f * (L.sky1[c] - L.sky2[c]);
+    } else {
+      const RenderShape& sh = sc.shapes[hit_g];
+      const RenderColour& col_g = sc.colours[hit_g];
+      const double* R = lw + hit_g * kShapeFrameDoubles;
+      double nl[3] = {0, 0, 1};
+      if (sh.shape == kShapeBox) {
+        nl[2] = 0;
+        nl[hit_face >> 1] = (hit_face & 1) ? 1.0 : -1.0;
+      } else if (sh.shape == kShapeHull) {
+        const double* q = sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
+        nl[0] = q[0]; nl[1] = q[1]; nl[2] = q[2];
+      }
+      double nw[3];
+      mulmv(R, nl, nw);
+      const double nn = 1.0 / sqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+      const double ndv = -(nw[0] * d[0] + nw[1] * d[1] + nw[2] * d[2]) * nn * inv_len;       // towards the camera
+      const double ndl = -(nw[0] * L.light_dir[0] + nw[1] * L.light_dir[1] + nw[2] * L.light_dir[2]) * nn;  // towards the light
+      const double kv = ndv > 0 ? ndv : 0.0, kl = ndl > 0 ? ndl : 0.0;
+      bool second = false;
+      if (col_g.checker != 0.0) {
+        // hit point in the shape frame
+        const double om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
+        const double hx = R[0] * om[0] + R[3] * om[1] + R[6] * om[2], hy = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
+        const long long ix = (long long)floor(hx / col_g.square), iy = (long long)floor(hy / col_g.square);
+        second = ((ix + iy) & 1) != 0;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double base = second ? col_g.rgb2[c] : col_g.rgb[c];
+        out[c] = base * (L.ambient[c] + L.head_diffuse[c] * kv + L.light_diffuse[c] * kl);
+      }
+    }
+    uint8_t* px = rgb + 3 * (img + (size_t)row * W + col);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double v = out[c] < 0 ? 0.0 : (out[c] > 1 ? 1.0 : out[c]);
+      px[c] = (uint8_t)(v * 255.0 + 0.5);
+    }
   }
 }
 

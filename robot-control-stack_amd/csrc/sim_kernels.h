@@ -113,6 +113,20 @@ struct CollTable {
   double plane_n[3], plane_d;
 };
 
+// Rendering callbacks (reference Sim::invoke_rendering_callbacks, src/sim/sim.cpp:63-81,108-115): cameras with a frame rate are
+// due after a substep when more than 1 / frame_rate of simulated time has passed since their last frame.  A kernel cannot
+// call the renderer, so the substep loop RECORDS what the renderer would have seen -- the qpos of that substep's position
+// stage, the free box's pre-step pose, the new time, which cameras are due -- and the host renders the records after the
+// launch (rcsh_camera_render_snapshot): same frames, same timestamps, no change to the stepping.
+constexpr int kMaxRateCams = 4;
+struct RendCfg {
+  int32_t ncam, capacity;          // capacity: records per environment and launch
+  double period[kMaxRateCams];     // seconds_between_calls
+  double* last;                    // [kMaxRateCams][n] last_call_timestamp
+  double* snap;                    // [capacity][nfields][n]; fields: qpre (NL), box pre-step pose (7), time, camera mask
+  int32_t* count;                  // [n] records written by the last launch (more than capacity: the rest were dropped)
+};
+
 struct Params {
   const DevModel* model;  // HBM copy; each workgroup stages it into LDS once per launch
   CollTable coll;
@@ -127,6 +141,7 @@ struct Params {
   EnvCfg env;
   const struct BoxTaskCfg* boxtask;  // scenes with a free box: its constants and the task layer's (HBM; staged by k_run_team<.., BOX>)
   ContactTable ctab;                 // the robot's collision geoms for the contact phase (contact_team.h; scenes with a free box)
+  RendCfg rend;                      // rate-driven cameras (ncam = 0: none)
 };
 struct BoxTaskCfg {
   BoxCfg box;
@@ -712,6 +727,16 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
                             : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
     }
   }
+  // rate-driven cameras: the teams' camera clocks and record counters (RendCfg)
+  __shared__ double lrend[kTeams][kMaxRateCams + 2];
+  const int rend_ncam = lp.rend.ncam;
+  const bool rend_on = rend_ncam > 0;  // (wave-uniform)
+  if (rend_on && leader) {
+    // Sim::reset -> reset_callbacks (sim.cpp:131-137): "negative so that we will directly render the cameras in the first step"
+    for (int c = 0; c < rend_ncam; ++c) lrend[team][c] = op.do_reset ? -lp.rend.period[c] : lp.rend.last[(size_t)c * P.n + e];
+    lrend[team][kMaxRateCams + 1] = 0.0;
+  }
+  if (rend_on && t == 0 && e < P.n && !live) lp.rend.count[e] = 0;  // (masked out of this launch: nothing recorded)
   bool box_placed = false;  // env.reset() with RandomCubePos: the box got its pose after the first of the two substeps
   bool more = leader && budget > 0;
   double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
@@ -870,8 +895,39 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       }
       more = budget > 0 && !converged;
     }
+    if (rend_on) {
+      // rendering callbacks after mj_step2 (sim.cpp:108-115): the leader looks at the cameras' clocks, the team records
+      uint32_t due_cams = 0;
+      if (leader && stepping) {
+        for (int c = 0; c < rend_ncam; ++c)
+          if (r.time - lrend[team][c] > lp.rend.period[c]) { due_cams |= 1u << c; lrend[team][c] = r.time; }
+        if (due_cams) lrend[team][kMaxRateCams] = r.time;
+      }
+      due_cams = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48) << 2, (int)due_cams);
+      if (due_cams && live) {
+        stage_fence();
+        const int slot = (int)lrend[team][kMaxRateCams + 1];
+        if (slot < lp.rend.capacity) {
+          constexpr int NF = T::NL + 9;
+          double* dst = lp.rend.snap + (size_t)slot * NF * P.n + e;
+          for (int k = t; k < NF; k += kTeamLanes) {
+            double v;
+            if (k < T::NL) v = st.qpre(k);
+            else if (k < T::NL + 7) v = (BOX || CON) ? bs[kBoxPre + (k - T::NL)] : (k == T::NL + 3 ? 1.0 : 0.0);
+            else v = k == T::NL + 7 ? lrend[team][kMaxRateCams] : (double)due_cams;
+            dst[(size_t)k * P.n] = v;
+          }
+        }
+        stage_fence();
+        if (t == 0) lrend[team][kMaxRateCams + 1] += 1.0;
+      }
+    }
     going = __ballot(more);
     TEAM_MARK(9)
+  }
+  if (rend_on && leader) {
+    for (int c = 0; c < rend_ncam; ++c) lp.rend.last[(size_t)c * P.n + e] = lrend[team][c];
+    lp.rend.count[e] = (int32_t)lrend[team][kMaxRateCams + 1];
   }
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);

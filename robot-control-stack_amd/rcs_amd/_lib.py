@@ -114,6 +114,11 @@ class RenderSceneDesc(C.Structure):
     ]
 
 
+class RenderColours(C.Structure):
+    _fields_ = [("colour", _F64P), ("headlight_ambient", C.c_double * 3), ("headlight_diffuse", C.c_double * 3),
+                ("light_dir", C.c_double * 3), ("light_diffuse", C.c_double * 3), ("sky_rgb1", C.c_double * 3), ("sky_rgb2", C.c_double * 3)]
+
+
 class CameraDesc(C.Structure):
     _fields_ = [("link", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("pos", C.c_double * 3), ("rot", C.c_double * 9),
                 ("fovy_deg", C.c_double)]
@@ -166,6 +171,8 @@ EXPORTS = (
     "rcsh_sim_set_free_qpos", "rcsh_sim_set_free_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
     "rcsh_sim_set_render_scene", "rcsh_sim_add_camera", "rcsh_camera_render", "rcsh_camera_render_dev",
+    "rcsh_sim_set_render_colours", "rcsh_camera_render_rgb", "rcsh_camera_render_rgb_dev",
+    "rcsh_sim_set_render_schedule", "rcsh_render_pending", "rcsh_camera_render_snapshot",
     "rcsh_env_configure_pick_task", "rcsh_env_reset_task", "rcsh_env_step_task", "rcsh_env_reset_task_dev", "rcsh_env_step_task_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
@@ -217,6 +224,12 @@ def load() -> C.CDLL:
     L.rcsh_sim_add_camera.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(C.c_int32)]
     L.rcsh_camera_render.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_camera_render_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rcsh_sim_set_render_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    L.rcsh_render_pending.argtypes = [C.c_void_p, C.c_void_p]
+    L.rcsh_camera_render_snapshot.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rcsh_sim_set_render_colours.argtypes = [C.c_void_p, C.POINTER(RenderColours)]
+    L.rcsh_camera_render_rgb.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rcsh_camera_render_rgb_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_env_configure_pick_task.argtypes = [C.c_void_p, C.POINTER(PickTaskDesc)]
     L.rcsh_env_reset_task.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.rcsh_env_step_task.argtypes = [C.c_void_p] + [C.c_void_p] * 7

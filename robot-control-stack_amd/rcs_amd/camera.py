@@ -3,11 +3,13 @@ python/rcs/camera/sim.py, python/rcs/camera/interface.py).
 
 Kept from the reference: the configuration type, the frame-set buffer with its timestamp rule (frames rendered at the
 same simulation time share one frame set; ``clear_buffer`` forgets the last timestamp), render-on-demand,
-the conversion of the depth buffer (row flip, metres with ``physical_units``, ``DEPTH_SCALE``, uint16), intrinsics and
-extrinsics.  Different: the pixels are ray-cast against analytic shapes (``rcs_amd/render.py``), there is no colour image
-(``DataFrame.data`` of ``color`` is ``None``), ``render_on_demand=False`` (rendering from inside ``Sim.step`` at the
-cameras' frame rate) is not built, and the buffer keeps the last ``max_framesets`` frame sets instead of growing until
-the next reset (one frame set of 4096 environments at 256 x 256 is 0.5 GB).
+the conversion of the depth buffer (row flip, metres with ``physical_units``, ``DEPTH_SCALE``, uint16), the colour
+frame's layout ([H, W, 3] uint8, rows flipped like the depth), intrinsics and extrinsics, the four camera types
+(``fixed``, ``default_free``, ``free`` -- an untouched mjvCamera: it looks at the origin from 2 m -- and ``tracking``, which
+fails as it does in the reference: SimCameraSet never sets a body to track).  Different: the pixels are ray-cast against
+analytic shapes (``rcs_amd/render.py``) -- flat-shaded colours of the collision shapes, no textures but the floor's
+checker, no shadows: not OpenGL's pixels -- and the buffer keeps the last ``max_framesets`` frame sets instead of growing
+until the next reset (one frame set of 4096 environments at 256 x 256 is 0.5 GB).
 """
 
 from __future__ import annotations
@@ -74,8 +76,6 @@ class SimCameraSet:
 
     def __init__(self, simulation: _sim.Sim, cameras: dict[str, SimCameraConfig], physical_units: bool = False,
                  render_on_demand: bool = True, max_framesets: int = 2):
-        if not render_on_demand:
-            raise NotImplementedError("rendering from inside Sim.step at the cameras' frame rate is not built: use render_on_demand=True")
         self._sim = simulation
         self.cameras = cameras
         self.physical_units = physical_units
@@ -93,6 +93,13 @@ class SimCameraSet:
             self._keep.append(a)
             setattr(d, name, a.ctypes.data_as(_lib._I32P if a.dtype == np.int32 else _lib._F64P))
         _lib.check(self._L.rcsh_sim_set_render_scene(simulation._h, C.byref(d)))
+        rc = _lib.RenderColours()
+        col = np.ascontiguousarray(rs.colour, dtype=np.float64).reshape(-1)
+        self._keep.append(col)
+        rc.colour = col.ctypes.data_as(_lib._F64P)
+        for name in ("headlight_ambient", "headlight_diffuse", "light_dir", "light_diffuse", "sky_rgb1", "sky_rgb2"):
+            getattr(rc, name)[:] = [float(x) for x in getattr(rs, name)]
+        _lib.check(self._L.rcsh_sim_set_render_colours(simulation._h, C.byref(rc)))
         self._ids: dict[str, int] = {}
         self._fovy: dict[str, float] = {}
         for name, cfg in cameras.items():
@@ -100,8 +107,11 @@ class SimCameraSet:
                 link, pos, rot, fovy = render.default_free_camera(cm)
             elif cfg.type == CameraType.fixed:
                 link, pos, rot, fovy = render.camera_in_link(cm, cfg.identifier)
+            elif cfg.type == CameraType.free:  # camera.cpp:36-47: a default mjvCamera with type = mjCAMERA_FREE
+                link, pos, rot, fovy = render.free_camera(cm)
             else:
-                raise NotImplementedError("free / tracking cameras driven by an mjvCamera are not built (fixed and default_free are)")
+                # camera.cpp:44-46 sets type and fixedcamid only; trackbodyid stays -1 and mjv_updateCamera refuses it
+                raise RuntimeError("track body id is outside valid range")
             c = _lib.CameraDesc()
             c.link, c.width, c.height, c.fovy_deg = link, cfg.resolution_width, cfg.resolution_height, fovy
             c.pos[:] = [float(x) for x in pos]
@@ -112,6 +122,28 @@ class SimCameraSet:
             self._fovy[name] = fovy
         self._buffer: list[dict] = []
         self._last_ts = None
+        # Rendering callbacks (camera.cpp:23-47 -> Sim::register_rendering_callback): cameras with a frame rate are rendered
+        # from inside the stepping at that rate when render_on_demand is off.  The kernels record what the renderer would
+        # have seen at the moments a frame became due; `collect()` (called by Sim / the environments after every launch)
+        # renders the records.  Every environment has its own clock, so a frame set of the batch is "the environments whose
+        # cameras were due in that record", with a timestamp per environment; `_latest` keeps, per camera and environment,
+        # the newest frame.
+        self._rated = [name for name, cfg in cameras.items() if cfg.frame_rate != 0]
+        self._latest: dict | None = None
+        if not render_on_demand and self._rated:
+            if len(self._rated) > 4:
+                raise ValueError("at most 4 cameras with a frame rate")
+            ids = np.array([self._ids[nm] for nm in self._rated], dtype=np.int32)
+            periods = np.array([1.0 / cameras[nm].frame_rate for nm in self._rated], dtype=np.float64)
+            # records per launch: the longest launch is step_until_convergence's cap (Sim.step(k) beyond that: ValueError at collect)
+            cap = simulation.get_config().max_convergence_steps
+            horizon = (cap if cap > 0 else 2000) * cm.timestep
+            capacity = int(min(256, np.ceil(horizon / periods).sum() + 2))  # (records of different cameras need not coincide)
+            self._keep += [ids, periods]
+            _lib.check(self._L.rcsh_sim_set_render_schedule(simulation._h, _lib.ptr(ids), _lib.ptr(periods), len(ids), capacity))
+            if not hasattr(simulation, "_rate_camera_sets"):
+                simulation._rate_camera_sets = []
+            simulation._rate_camera_sets.append(self)
 
     # ---- SimCameraSet (src/sim/camera.cpp:54-83)
     def buffer_size(self) -> int:
@@ -120,6 +152,7 @@ class SimCameraSet:
     def clear_buffer(self) -> None:
         self._last_ts = None  # "when we clear the buffer, there is no last image timestep"
         self._buffer.clear()
+        self._latest = None
 
     def render_raw(self, name: str):
         """(depth buffer [N,H,W] f32 rows bottom-up as mjr_readPixels returns it, cam_xmat [N,3,3], cam_xpos [N,3])."""
@@ -129,6 +162,20 @@ class SimCameraSet:
         pose = np.zeros((n, 12))
         _lib.check(self._L.rcsh_camera_render(self._sim._h, self._ids[name], _lib.ptr(depth), None, _lib.ptr(pose)))
         return depth, pose[:, :9].reshape(n, 3, 3), pose[:, 9:]
+
+    def render_raw_rgbd(self, name: str):
+        """(rgb [N,H,W,3] uint8 and depth [N,H,W] f32, both rows bottom-up as mjr_readPixels returns them, cam_xmat, cam_xpos)."""
+        cfg = self.cameras[name]
+        n = self._sim.n_envs
+        rgb = np.zeros((n, cfg.resolution_height, cfg.resolution_width, 3), dtype=np.uint8)
+        depth = np.zeros((n, cfg.resolution_height, cfg.resolution_width), dtype=np.float32)
+        pose = np.zeros((n, 12))
+        _lib.check(self._L.rcsh_camera_render_rgb(self._sim._h, self._ids[name], _lib.ptr(rgb), _lib.ptr(depth), None, _lib.ptr(pose)))
+        return rgb, depth, pose[:, :9].reshape(n, 3, 3), pose[:, 9:]
+
+    def render_rgb_dev(self, name: str, out_ptr: int) -> None:
+        """The colour frame alone into device memory ([N,H,W,3] uint8, rows bottom-up)."""
+        _lib.check(self._L.rcsh_camera_render_rgb_dev(self._sim._h, self._ids[name], C.c_void_p(out_ptr), None, None, None))
 
     def render_depth_mm(self, name: str) -> np.ndarray:
         """The fused device path: [N,H,W] uint16 millimetres, rows top-down (physical units)."""
@@ -144,21 +191,76 @@ class SimCameraSet:
         ts = self._sim.time
         same = self._last_ts is not None and np.array_equal(ts, self._last_ts)
         if not same:
-            self._buffer.append({"timestamp": ts, "depth": {}, "pose": {}})
+            self._buffer.append({"timestamp": ts, "depth": {}, "color": {}, "pose": {}})
             del self._buffer[: max(0, len(self._buffer) - self.max_framesets)]
             self._last_ts = ts
         fs = self._buffer[-1]
         for name in self.cameras:
-            depth, xmat, xpos = self.render_raw(name)
+            rgb, depth, xmat, xpos = self.render_raw_rgbd(name)
             fs["depth"][name] = depth
+            fs["color"][name] = rgb
             fs["pose"][name] = (xmat, xpos)
+
+    def collect(self) -> None:
+        """Render the records of the launch that just ran (render_single for every due camera, camera.cpp:103-140)."""
+        if self.render_on_demand or not self._rated:
+            return
+        n = self._sim.n_envs
+        count = np.zeros(n, dtype=np.int32)
+        _lib.check(self._L.rcsh_render_pending(self._sim._h, _lib.ptr(count)))
+        for slot in range(int(count.max(initial=0))):
+            event = {"timestamp": np.full(n, np.nan), "depth": {}, "color": {}, "pose": {}, "have": {}}
+            for name in self._rated:
+                cfg = self.cameras[name]
+                rgb = np.zeros((n, cfg.resolution_height, cfg.resolution_width, 3), dtype=np.uint8)
+                depth = np.zeros((n, cfg.resolution_height, cfg.resolution_width), dtype=np.float32)
+                pose = np.zeros((n, 12))
+                ts = np.zeros(n)
+                due = np.zeros(n, dtype=np.uint8)
+                _lib.check(self._L.rcsh_camera_render_snapshot(self._sim._h, self._ids[name], slot, _lib.ptr(rgb), _lib.ptr(depth), None, _lib.ptr(pose),
+                                                               _lib.ptr(ts), _lib.ptr(due)))
+                have = due.astype(bool)
+                if not have.any():
+                    continue
+                event["timestamp"][have] = ts[have]
+                event["depth"][name], event["color"][name] = depth, rgb
+                event["pose"][name] = (pose[:, :9].reshape(n, 3, 3), pose[:, 9:])
+                event["have"][name] = have
+            if not event["have"]:
+                continue
+            self._buffer.append(event)
+            del self._buffer[: max(0, len(self._buffer) - self.max_framesets)]
+            self._merge_latest(event)
+
+    def _merge_latest(self, event: dict) -> None:
+        n = self._sim.n_envs
+        if self._latest is None:
+            self._latest = {"timestamp": np.full(n, np.nan), "depth": {}, "color": {}, "pose": {}, "cam_timestamp": {}}
+        lt = self._latest
+        for name, have in event["have"].items():
+            if name not in lt["depth"]:
+                lt["depth"][name] = np.ones_like(event["depth"][name])
+                lt["color"][name] = np.zeros_like(event["color"][name])
+                lt["pose"][name] = (np.tile(np.eye(3), (n, 1, 1)), np.zeros((n, 3)))
+                lt["cam_timestamp"][name] = np.full(n, np.nan)
+            lt["depth"][name][have] = event["depth"][name][have]
+            lt["color"][name][have] = event["color"][name][have]
+            lt["pose"][name][0][have] = event["pose"][name][0][have]
+            lt["pose"][name][1][have] = event["pose"][name][1][have]
+            lt["cam_timestamp"][name][have] = event["timestamp"][have]
+            lt["timestamp"][have] = event["timestamp"][have]
 
     def get_latest_frames(self) -> FrameSet | None:
         if self.render_on_demand:
             self._render_all()
-        if not self._buffer:
+            if not self._buffer:
+                return None
+            return self._to_frames(self._buffer[-1])
+        # rate-driven: the newest frame of every camera and environment (an environment's entry of `avg_timestamp` is NaN
+        # until its first frame; DataFrame.timestamp is the camera's own)
+        if self._latest is None:
             return None
-        return self._to_frames(self._buffer[-1])
+        return self._to_frames(self._latest)
 
     def get_timestamp_frames(self, ts) -> FrameSet | None:
         for fs in reversed(self._buffer):
@@ -175,10 +277,12 @@ class SimCameraSet:
                 near, far = self._scene.znear, self._scene.zfar
                 depth = near / (1 - depth * (1 - near / far))
             xmat, xpos = fs["pose"][name]
+            cam_ts = fs.get("cam_timestamp", {}).get(name, fs["timestamp"])
             frames[name] = Frame(
                 camera=CameraFrame(
-                    color=DataFrame(data=None, timestamp=fs["timestamp"], intrinsics=self._intrinsics(name), extrinsics=self._extrinsics(xmat, xpos)),
-                    depth=DataFrame(data=(depth * self.DEPTH_SCALE).astype(np.uint16), timestamp=fs["timestamp"],
+                    color=DataFrame(data=fs["color"][name][:, ::-1], timestamp=cam_ts, intrinsics=self._intrinsics(name),
+                                    extrinsics=self._extrinsics(xmat, xpos)),
+                    depth=DataFrame(data=(depth * self.DEPTH_SCALE).astype(np.uint16), timestamp=cam_ts,
                                     intrinsics=self._intrinsics(name), extrinsics=self._extrinsics(xmat, xpos)),
                 ),
                 avg_timestamp=fs["timestamp"],

@@ -81,13 +81,15 @@ class VecSimEnv:
         if self.gripper is not None:
             o["gripper"] = obs[:, 13 + d].copy()
         if self.camera_set is not None:
-            # CameraSetWrapper.observation (base.py:633-674): depth only -- this backend renders no colour image
+            # CameraSetWrapper.observation (base.py:633-674), include_depth=True: "rgb" always, "depth" next to it
             frameset = self.camera_set.get_latest_frames()
             if frameset is None:
                 o["frames"] = {}
                 i["camera_available"] = False
             else:
-                o["frames"] = {name: {"depth": {"data": f.camera.depth.data, "intrinsics": f.camera.depth.intrinsics,
+                o["frames"] = {name: {"rgb": {"data": f.camera.color.data, "intrinsics": f.camera.color.intrinsics,
+                                              "extrinsics": f.camera.color.extrinsics},
+                                      "depth": {"data": f.camera.depth.data, "intrinsics": f.camera.depth.intrinsics,
                                                 "extrinsics": f.camera.depth.extrinsics}} for name, f in frameset.frames.items()}
                 i["camera_available"] = True
                 if frameset.avg_timestamp is not None:
@@ -103,6 +105,7 @@ class VecSimEnv:
         if self.camera_set is not None:
             self.camera_set.clear_buffer()  # CameraSetWrapper.reset
         _lib.check(self._L.rcsh_env_reset(self.sim._h, _lib.ptr(m), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw)))
+        self.sim._collect_frames()
         o, i = self._unpack(obs, info, gw)
         if self.gripper is not None:  # GripperWrapperSim.observation runs on reset too (envs/sim.py:125-131)
             i["collision"] = info[:, 5].astype(bool)
@@ -122,6 +125,7 @@ class VecSimEnv:
         gw = np.zeros(n)
         sub = np.zeros(n, dtype=np.int32)
         _lib.check(self._L.rcsh_env_step(self.sim._h, _lib.ptr(a), _lib.ptr(g), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw), _lib.ptr(sub)))
+        self.sim._collect_frames()
         o, i = self._unpack(obs, info, gw)
         i["collision"] = info[:, 0].astype(bool)
         i["ik_success"] = info[:, 1].astype(bool)
@@ -204,6 +208,7 @@ class VecPickCubeEnv(VecSimEnv):
         if self.camera_set is not None:
             self.camera_set.clear_buffer()
         _lib.check(self._L.rcsh_env_reset_task(self.sim._h, _lib.ptr(m), _lib.ptr(box), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw)))
+        self.sim._collect_frames()
         o, i = self._unpack(obs, info, gw)
         i["collision"] = info[:, 5].astype(bool)
         i["gripper_width"] = gw
@@ -222,6 +227,7 @@ class VecPickCubeEnv(VecSimEnv):
         task = np.zeros((n, self.task_width))
         _lib.check(self._L.rcsh_env_step_task(self.sim._h, _lib.ptr(a), _lib.ptr(g), _lib.ptr(obs), _lib.ptr(info), _lib.ptr(gw),
                                               _lib.ptr(sub), _lib.ptr(task)))
+        self.sim._collect_frames()
         o, i = self._unpack(obs, info, gw)
         i["collision"] = info[:, 0].astype(bool)
         i["ik_success"] = info[:, 1].astype(bool)

@@ -203,6 +203,12 @@ class Model:
     vis_azimuth: float = 90.0
     vis_elevation: float = -45.0
     vis_fovy: float = 45.0
+    # colour rendering: mjModel.vis.headlight, the scene's directional lights (direction, diffuse), the skybox gradient
+    # (rgb1 at the zenith, rgb2 at the nadir; None: no skybox, the background is black) -- rcs_amd/render.py
+    vis_headlight_ambient: np.ndarray = field(default_factory=lambda: np.array([0.1, 0.1, 0.1]))
+    vis_headlight_diffuse: np.ndarray = field(default_factory=lambda: np.array([0.4, 0.4, 0.4]))
+    lights: list = field(default_factory=list)
+    skybox: tuple | None = None
     # sizes
     nbody: int = 0
     njnt: int = 0
@@ -348,6 +354,32 @@ class _Compiler:
         out.update(given)
         return out
 
+    def _geom_colour(self, ga: dict) -> dict:
+        """rgba of a geom (its own, else its material's, else MuJoCo's grey) and, for a material with a builtin checker
+        texture, the two colours and the edge length of the squares (texuniform: `texrepeat` tiles of 2 x 2 squares per unit)."""
+        rgba = _floats(ga.get("rgba"), 4, (0.5, 0.5, 0.5, 1.0))
+        checker = None
+        mat = self._materials.get(ga.get("material", ""))
+        if ga.get("material") and mat is None:
+            raise MjcfError(f"unknown material {ga.get('material')!r}")
+        if mat is not None:
+            if "rgba" not in ga:
+                rgba = _floats(mat.get("rgba"), 4, (1.0, 1.0, 1.0, 1.0))
+            tex = self._textures.get(mat.get("texture", ""))
+            if tex is not None and tex.get("builtin") == "checker":
+                rep = _floats(mat.get("texrepeat"), 2, (1.0, 1.0))
+                checker = (_floats(tex.get("rgb1"), 3, (0.8, 0.8, 0.8)), _floats(tex.get("rgb2"), 3, (0.5, 0.5, 0.5)), 0.5 / float(rep[0]))
+        return dict(rgba=rgba, checker=checker)
+
+    def _parse_assets(self):
+        self._materials: dict[str, dict] = {}
+        self._textures: dict[str, dict] = {}
+        for asset in self.root.findall("asset"):
+            for t in asset.findall("texture"):
+                self._textures[t.attrib.get("name", "__" + t.attrib.get("type", "2d"))] = dict(t.attrib)
+            for mt in asset.findall("material"):
+                self._materials[mt.attrib["name"]] = dict(mt.attrib)
+
     # ---- sections
     def _parse_compiler(self):
         for c in self.root.findall("compiler"):
@@ -491,6 +523,7 @@ class _Compiler:
                     mesh=ga.get("mesh", ""),
                     mass=float(ga["mass"]) if "mass" in ga else None,
                     density=float(ga.get("density", 1000)),
+                    **self._geom_colour(ga),
                 )
                 body["geoms"].append(len(self.geoms))
                 self.geoms.append(geom)
@@ -662,6 +695,7 @@ class _Compiler:
     # ---- assemble
     def compile(self) -> Model:
         self._parse_compiler()
+        self._parse_assets()
         for top in self.root.findall("default"):
             self._walk_defaults(top, self.defaults["main"])
         worlds = self.root.findall("worldbody")
@@ -732,7 +766,7 @@ class _Compiler:
                 qpos0=np.concatenate([b["pos"], quat_normalize(b["quat"])]),
                 mass=float(mass), inertia=np.asarray(diag, dtype=np.float64), size=g["size"].copy(),
                 # mj_contactParam, equal priority: friction element-wise max, solref / solimp mixed 50:50 (solmix 1:1)
-                friction=np.maximum(pl["friction"], g["friction"]), geom_friction=g["friction"].copy(), floor_friction=pl["friction"].copy(),
+                friction=np.maximum(pl["friction"], g["friction"]), geom_friction=g["friction"].copy(), floor_friction=pl["friction"].copy(), rgba=g["rgba"].copy(),
                 solref=0.5 * (pl["solref"] + g["solref"]), solimp=0.5 * (pl["solimp"] + g["solimp"]),
                 plane_z=float(pl["pos"][2]),
             ))
@@ -769,6 +803,17 @@ class _Compiler:
             for mp in vis.findall("map"):
                 m.vis_znear = float(mp.attrib.get("znear", m.vis_znear))
                 m.vis_zfar = float(mp.attrib.get("zfar", m.vis_zfar))
+            for hl in vis.findall("headlight"):
+                m.vis_headlight_ambient = _floats(hl.attrib.get("ambient"), 3, m.vis_headlight_ambient)
+                m.vis_headlight_diffuse = _floats(hl.attrib.get("diffuse"), 3, m.vis_headlight_diffuse)
+        for wb in self.root.findall("worldbody"):
+            for li in wb.findall("light"):  # lights fixed in the world (what the RCS scenes have)
+                if li.attrib.get("directional", "false") == "true":
+                    d = _floats(li.attrib.get("dir"), 3, (0, 0, -1))
+                    m.lights.append((d / np.linalg.norm(d), _floats(li.attrib.get("diffuse"), 3, (0.7, 0.7, 0.7))))
+        for tex in self._textures.values():
+            if tex.get("type") == "skybox" and tex.get("builtin") == "gradient":
+                m.skybox = (_floats(tex.get("rgb1"), 3, (0.8, 0.8, 0.8)), _floats(tex.get("rgb2"), 3, (0.5, 0.5, 0.5)))
 
         nb = len(self.bodies)
         A: dict[str, np.ndarray] = {}
@@ -875,6 +920,8 @@ class _Compiler:
         A["geom_group"] = np.array([g["group"] for g in self.geoms], dtype=np.int32)
         m.arrays = A
         m.geom_mesh = [g["mesh"] for g in self.geoms]  # type: ignore[attr-defined]
+        A["geom_rgba"] = np.array([g["rgba"] for g in self.geoms], dtype=np.float64).reshape(ng, 4)
+        m.geom_checker = [g["checker"] for g in self.geoms]  # type: ignore[attr-defined]
         # collision vertex sets of mesh geoms (hull vertices, numbers only; tools/make_collision_vertices.py)
         vadr, vnum, verts = [], [], []
         vfile = find_data_file(self.data_dirs, "collision_vertices.npz")

@@ -59,16 +59,30 @@ class RenderScene:
     names: list[str] = field(default_factory=list)
     znear: float = 0.01
     zfar: float = 50.0
+    # colour frames: per shape rgb (3), second checker colour (3), edge of a checker square, checker flag; the lighting
+    colour: np.ndarray = field(default_factory=lambda: np.zeros((0, 8)))
+    headlight_ambient: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    headlight_diffuse: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    light_dir: np.ndarray = field(default_factory=lambda: np.array([0.0, 0.0, -1.0]))
+    light_diffuse: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    sky_rgb1: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    sky_rgb2: np.ndarray = field(default_factory=lambda: np.zeros(3))
 
 
 def build_render_scene(cm: Model, scene_dir: str) -> RenderScene:
     A = cm.arrays
     hull_file = find_data_file([scene_dir, *getattr(cm, "data_dirs", [])], "render_hulls.npz")
     hulls = dict(np.load(hull_file)) if hull_file else {}
-    rows, planes, names = [], [], []
+    rows, planes, names, colours = [], [], [], []
 
-    def add(shape, link, p, q, size=(0, 0, 0), pl=None, sphere=(0, 0, 0, -1.0), name=""):
+    def colour_of(rgba, checker=None):
+        if checker is not None:
+            return [*checker[0], *checker[1], float(checker[2]), 1.0]
+        return [*np.asarray(rgba, dtype=np.float64)[:3], 0.0, 0.0, 0.0, 1.0, 0.0]
+
+    def add(shape, link, p, q, size=(0, 0, 0), pl=None, sphere=(0, 0, 0, -1.0), name="", colour=None):
         adr = sum(len(x) for x in planes)
+        colours.append(colour if colour is not None else colour_of((0.5, 0.5, 0.5, 1.0)))
         if pl is not None:
             planes.append(pl)
         rows.append((shape, link, p, quat_to_mat(q).reshape(9), np.asarray(size, dtype=np.float64), adr, 0 if pl is None else len(pl),
@@ -78,29 +92,37 @@ def build_render_scene(cm: Model, scene_dir: str) -> RenderScene:
     for g in range(cm.ngeom):
         t = int(A["geom_type"][g])
         link, p, q = _pose_in_link(cm, int(A["geom_bodyid"][g]), A["geom_pos"][g], A["geom_quat"][g])
+        gcol = colour_of(A["geom_rgba"][g], cm.geom_checker[g] if t == GEOM_PLANE else None)
         if t == GEOM_PLANE:
-            add(SHAPE_PLANE, link, p, q, name=cm.geom_names[g])
+            add(SHAPE_PLANE, link, p, q, name=cm.geom_names[g], colour=gcol)
         elif t == GEOM_BOX:
             s = A["geom_size"][g]
-            add(SHAPE_BOX, link, p, q, size=s, sphere=(0, 0, 0, float(np.linalg.norm(s))), name=cm.geom_names[g])
+            add(SHAPE_BOX, link, p, q, size=s, sphere=(0, 0, 0, float(np.linalg.norm(s))), name=cm.geom_names[g], colour=gcol)
         elif t == GEOM_MESH and cm.geom_mesh[g] in hulls:
             pl = hulls[cm.geom_mesh[g]]
             v = A["mesh_vert"][A["geom_vertadr"][g]: A["geom_vertadr"][g] + A["geom_vertnum"][g]]
             c = 0.5 * (v.min(axis=0) + v.max(axis=0))
             # bounding sphere about the centre of the hull's bounding box; `size` = half extents of that box
             add(SHAPE_HULL, link, p, q, size=0.5 * (v.max(axis=0) - v.min(axis=0)), pl=pl, sphere=(*c, float(np.linalg.norm(v - c, axis=1).max())),
-                name=cm.geom_names[g])
+                name=cm.geom_names[g], colour=gcol)
         # other geom types (and meshes without hull data) are not drawn
     for fb in getattr(cm, "free_bodies", []):
         s = fb["size"]
-        add(SHAPE_BOX, LINK_FREE_BODY, np.zeros(3), np.array([1.0, 0, 0, 0]), size=s, sphere=(0, 0, 0, float(np.linalg.norm(s))), name=fb["geom_name"])
+        add(SHAPE_BOX, LINK_FREE_BODY, np.zeros(3), np.array([1.0, 0, 0, 0]), size=s, sphere=(0, 0, 0, float(np.linalg.norm(s))), name=fb["geom_name"],
+            colour=colour_of(fb["rgba"]))
     if cm.stat_extent is None:
         raise RuntimeError("rendering needs <statistic extent=...> in the scene (near / far clip planes are fractions of it)")
     col = lambda i, dt: np.ascontiguousarray(np.array([r[i] for r in rows], dtype=dt))  # noqa: E731
     return RenderScene(shape=col(0, np.int32), link=col(1, np.int32), pos=col(2, np.float64), rot=col(3, np.float64), size=col(4, np.float64),
                        plane_adr=col(5, np.int32), plane_num=col(6, np.int32), sphere=col(7, np.float64),
                        planes=np.ascontiguousarray(np.concatenate(planes) if planes else np.zeros((1, 4))), names=names,
-                       znear=cm.vis_znear * cm.stat_extent, zfar=cm.vis_zfar * cm.stat_extent)
+                       znear=cm.vis_znear * cm.stat_extent, zfar=cm.vis_zfar * cm.stat_extent,
+                       colour=np.ascontiguousarray(np.array(colours, dtype=np.float64).reshape(-1, 8)),
+                       headlight_ambient=np.asarray(cm.vis_headlight_ambient, dtype=np.float64), headlight_diffuse=np.asarray(cm.vis_headlight_diffuse, dtype=np.float64),
+                       light_dir=np.asarray(cm.lights[0][0] if cm.lights else (0.0, 0.0, -1.0), dtype=np.float64),
+                       light_diffuse=np.asarray(cm.lights[0][1] if cm.lights else (0.0, 0.0, 0.0), dtype=np.float64),
+                       sky_rgb1=np.asarray(cm.skybox[0] if cm.skybox else (0.0, 0.0, 0.0), dtype=np.float64),
+                       sky_rgb2=np.asarray(cm.skybox[1] if cm.skybox else (0.0, 0.0, 0.0), dtype=np.float64))
 
 
 def camera_in_link(cm: Model, name: str):
@@ -111,6 +133,18 @@ def camera_in_link(cm: Model, name: str):
     A = cm.arrays
     link, p, q = _pose_in_link(cm, int(A["cam_bodyid"][cid]), A["cam_pos"][cid], A["cam_quat"][cid])
     return link, p, quat_to_mat(q).reshape(9), float(A["cam_fovy"][cid])
+
+
+def free_camera(cm: Model):
+    """(link, pos, rot[9], fovy_deg) of an untouched mjvCamera of type mjCAMERA_FREE (what SimCameraSet builds for
+    CameraType.free, camera.cpp:36-47: mjv_defaultCamera, then only `type` and `fixedcamid` are set): it looks at the world
+    origin from 2 m away, azimuth 90, elevation -45 degrees."""
+    az, el = np.deg2rad(90.0), np.deg2rad(-45.0)
+    forward = np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    up = np.array([-np.sin(el) * np.cos(az), -np.sin(el) * np.sin(az), np.cos(el)])
+    right = np.cross(forward, up)
+    rot = np.stack([right, up, -forward], axis=1)
+    return LINK_WORLD, -2.0 * forward, rot.reshape(9), float(cm.vis_fovy)
 
 
 def default_free_camera(cm: Model):

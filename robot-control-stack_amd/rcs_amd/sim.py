@@ -104,9 +104,18 @@ class Sim:
 
     def step(self, k: int) -> None:
         _lib.check(self._L.rcsh_sim_step(self._h, int(k)))
+        self._collect_frames()
 
     def step_until_convergence(self) -> None:
         _lib.check(self._L.rcsh_sim_step_until_convergence(self._h))
+        self._collect_frames()
+
+    def _collect_frames(self) -> None:
+        """Rendering callbacks (Sim::invoke_rendering_callbacks, sim.cpp:63-81): camera sets with render_on_demand=False render
+        the frames that became due inside the launch that just ran (rcs_amd/camera.py).  Called by every host-array stepping
+        entry point of Sim and of the environments; users of the `*_dev` entry points call `camera_set.collect()` themselves."""
+        for cs in getattr(self, "_rate_camera_sets", ()):
+            cs.collect()
 
     def is_converged(self) -> np.ndarray:
         out = np.zeros(self.n_envs, dtype=np.uint8)

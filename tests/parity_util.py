@@ -202,7 +202,8 @@ def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wri
     for e, o in enumerate(osims):
         o.box_qpos = qb[e]
     rep = {"pixels": 0, "mismatched_mm": 0, "max_mm_diff": 0, "max_abs_depth_gl": 0.0, "max_abs_extrinsics": 0.0, "robot_pixels": 0,
-           "cube_pixels": 0, "floor_pixels": 0, "background_pixels": 0, "fused_mismatch": 0}
+           "cube_pixels": 0, "floor_pixels": 0, "background_pixels": 0, "fused_mismatch": 0, "rgb_mismatched_pixels": 0, "rgb_max_level_diff": 0,
+           "rgb_off_by_more_than_one": 0, "green_pixels": 0, "white_pixels": 0, "colours_seen": set()}
     for _ in range(n_calls):
         tgt = FR3_Q_HOME + rng.uniform(-0.4, 0.4, (n_envs, 7))
         robot.set_joint_position(tgt)
@@ -218,7 +219,15 @@ def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wri
             rep["fused_mismatch"] += int((fused != data[..., 0]).sum())
             link, pos, rot, fovy = render.camera_in_link(cm, name)
             for e, o in enumerate(osims):
-                dgl, mm, cR, cp = RO.render_depth(cs._scene, (link, pos, rot, fovy, width, height), RO.oracle_frames(o, cm))
+                dgl, mm, cR, cp, orgb = RO.render_depth(cs._scene, (link, pos, rot, fovy, width, height), RO.oracle_frames(o, cm), colour=True)
+                krgb = frames.frames[name].camera.color.data[e]  # [H, W, 3] uint8, rows top-down
+                cd = np.abs(krgb.astype(np.int64) - orgb[::-1].astype(np.int64)).max(axis=-1)
+                same_surface = data[e, ..., 0] == mm  # (a silhouette pixel that fell on the other side shows another shape)
+                rep["rgb_mismatched_pixels"] += int((cd != 0).sum())
+                rep["rgb_off_by_more_than_one"] += int(((cd > 1) & same_surface).sum())
+                rep["rgb_max_level_diff"] = max(rep["rgb_max_level_diff"], int(cd[same_surface].max()))
+                rep["green_pixels"] += int(((krgb[..., 1] > 150) & (krgb[..., 0] < 60)).sum())   # the cube (rgba 0 0.984 0.373)
+                rep["white_pixels"] += int((krgb.min(axis=-1) > 150).sum())                       # the robot's hulls
                 diff = np.abs(data[e, ..., 0].astype(np.int64) - mm.astype(np.int64))
                 rep["pixels"] += diff.size
                 rep["mismatched_mm"] += int((diff != 0).sum())
@@ -840,5 +849,108 @@ def run_self_collision_parity(n_envs=40, seed=1, scene="fr3_empty_world", resolv
         robot_other = sum(1 for c in range(o.s.d.ncon) if o.s.d.contact[c].body[0] > 0 or o.s.d.contact[c].body[1] > 0)  # (contacts of a robot body with floor / cube)
         rep["self_only"] += int((o.s.robot_collision or o.s.grp_collision) and robot_other == 0 and o.s.d.nself > 0)
         rep["floor"] += int(o.s.d.ncon > 0)
+    simu.close()
+    return rep
+
+
+def run_rate_driven_camera_parity(n_envs=4, width=32, height=24, seed=3):
+    """SimCameraSet(render_on_demand=False): frames at the cameras' frame rates from inside Sim.step / step_until_convergence
+    (Sim::invoke_rendering_callbacks, sim.cpp:63-81,108-115).  The kernel records, the host renders after the launch; the
+    restatement steps the oracle one substep at a time, applies the reference's rule (due when time - last > 1 / rate, clocks
+    at -1 / rate after construction and after Sim::reset) and renders with the numpy ray-caster.  Compared per environment:
+    the sequence of (timestamp, cameras) -- exactly -- and the pixels."""
+    from rcs_amd import render
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    import rcs_render_oracle as RO
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = default_sim_robot_cfg("fr3_simple_pick_up")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    robot = S.SimRobot(simu, None, cfg)
+    S.SimGripper(simu, default_sim_gripper_cfg())
+    rates = {"wrist_0": 30, "bird_eye_cam": 10}
+    cams = {c: SimCameraConfig(identifier=c, frame_rate=r, resolution_width=width, resolution_height=height) for c, r in rates.items()}
+    cs = SimCameraSet(simu, cams, physical_units=True, render_on_demand=False, max_framesets=10000)
+    cm = compile_mjcf(PICKUP_SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
+    campose = {c: render.camera_in_link(cm, c) for c in rates}
+    last = [{c: -1.0 / r for c, r in rates.items()} for _ in range(n_envs)]
+    expect = [[] for _ in range(n_envs)]  # per environment: (timestamp, {camera: (mm, rgb)})
+
+    def oracle_substep(e, o):
+        o.step(1)
+        t = float(o.s.d.time)
+        due = [c for c, r in rates.items() if t - last[e][c] > 1.0 / r]
+        if due:
+            fr = RO.oracle_frames(o, cm)
+            imgs = {}
+            for c in due:
+                last[e][c] = t
+                link, pos, rot, fovy = campose[c]
+                _, mm, _, _, rgb = RO.render_depth(cs._scene, (link, pos, rot, fovy, width, height), fr, colour=True)
+                imgs[c] = (mm, rgb[::-1])
+            expect[e].append((t, imgs))
+
+    rng = np.random.default_rng(seed)
+    # 1. a plain Sim.step: the first substep renders both cameras, then each at its own rate
+    tgt = FR3_Q_HOME + rng.uniform(-0.3, 0.3, (n_envs, 7))
+    robot.set_joint_position(tgt)
+    simu.step(60)
+    for e, o in enumerate(osims):
+        o.set_joint_position(tgt[e])
+        for _ in range(60):
+            oracle_substep(e, o)
+    # 2. Sim.reset of half the batch: their camera clocks restart, the others' go on -- the batch is out of step from here
+    mask = np.arange(n_envs) % 2 == 0
+    simu.reset(mask)
+    for e, o in enumerate(osims):
+        if mask[e]:
+            o.reset()
+            last[e] = {c: -1.0 / r for c, r in rates.items()}
+    # 3. step_until_convergence: hundreds of substeps, ~15 frames of the wrist camera per environment in one launch
+    tgt = FR3_Q_HOME + rng.uniform(-0.2, 0.2, (n_envs, 7))
+    robot.set_joint_position(tgt)
+    simu.step_until_convergence()
+    steps = simu.convergence_steps()
+    for e, o in enumerate(osims):
+        o.set_joint_position(tgt[e])
+        o.s.convergence_steps = 0
+        # (Sim::step_until_convergence = step(1) in a loop: the same substeps, the rendering callback after each)
+        for _ in range(int(steps[e])):
+            oracle_substep(e, o)
+    rep = {"events": 0, "timestamp_mismatches": 0, "camera_set_mismatches": 0, "pixels": 0, "mismatched_mm": 0, "rgb_off_by_more_than_one": 0,
+           "max_abs_qpos": 0.0, "events_per_env": []}
+    qk = simu.qpos
+    for e, o in enumerate(osims):
+        rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(qk[e] - o.qpos[: qk.shape[1]]).max()))
+        got = [(float(ev["timestamp"][e]), {c: ev for c, have in ev["have"].items() if have[e]}) for ev in cs._buffer if not np.isnan(ev["timestamp"][e])]
+        rep["events_per_env"].append((len(got), len(expect[e])))
+        if len(got) != len(expect[e]):
+            rep.setdefault("debug", []).append(([g[0] for g in got], [x[0] for x in expect[e]], int(steps[e])))
+        rep["events"] += len(expect[e])
+        if len(got) != len(expect[e]):
+            rep["timestamp_mismatches"] += abs(len(got) - len(expect[e]))
+            continue
+        for (tg, cg), (to, co) in zip(got, expect[e]):
+            rep["timestamp_mismatches"] += int(tg != to)
+            rep["camera_set_mismatches"] += int(set(cg) != set(co))
+            for c in set(cg) & set(co):
+                ev = cg[c]
+                near, far = cs._scene.znear, cs._scene.zfar
+                z = near / (1 - ev["depth"][c][e][::-1] * (1 - near / far))
+                mm = (z * 1000).astype(np.uint16)
+                diff = mm.astype(np.int64) != co[c][0].astype(np.int64)
+                rep["pixels"] += diff.size
+                rep["mismatched_mm"] += int(diff.sum())
+                cd = np.abs(ev["color"][c][e][::-1].astype(np.int64) - co[c][1].astype(np.int64)).max(axis=-1)
+                rep["rgb_off_by_more_than_one"] += int(((cd > 1) & ~diff).sum())
+    latest = cs.get_latest_frames()
+    rep["latest_timestamp_ok"] = bool(all(float(latest.avg_timestamp[e]) == expect[e][-1][0] for e in range(n_envs)))
+    rep["obs_keys"] = sorted(latest.frames)
     simu.close()
     return rep

@@ -475,6 +475,34 @@ def test_depth_render_matches_oracle(kernel):
     assert rep["mismatched_mm"] <= 2e-4 * rep["pixels"], rep
     assert rep["max_abs_extrinsics"] < 1e-12, rep
     assert rep["robot_pixels"] > 100 and rep["wrist_min_mm"] < 700, rep  # robot and cube from above; the floor under the hand in the wrist view
+    # colour frames of the same rays: flat-shaded shape colours, identical to the restatement up to the rounding of a level
+    # (pixels whose ray fell on the other side of a silhouette edge aside)
+    assert rep["rgb_off_by_more_than_one"] == 0 and rep["rgb_mismatched_pixels"] <= 3e-3 * rep["pixels"], rep
+    assert rep["green_pixels"] > 20 and rep["white_pixels"] > 100, rep  # the cube and the robot are in the pictures
+
+
+def test_free_and_tracking_camera_types():
+    """CameraType.free is an untouched mjvCamera (camera.cpp:36-47): it looks at the world origin from 2 m away, azimuth 90,
+    elevation -45 degrees; CameraType.tracking fails as it does in the reference (no body to track is ever set)."""
+    from rcs_amd import sim as S
+    from rcs_amd.camera import CameraType, SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_robot_cfg
+
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=2)
+    S.SimRobot(simu, None, cfg)
+    simu.step(1)
+    cs = SimCameraSet(simu, {"free": SimCameraConfig(identifier="", type=CameraType.free, resolution_width=32, resolution_height=24)}, physical_units=True)
+    f = cs.get_latest_frames().frames["free"].camera
+    ext = f.depth.extrinsics[0]  # world -> camera (z in front)
+    cam_pos = -ext[:3, :3].T @ ext[:3, 3]
+    assert np.allclose(cam_pos, [0.0, -np.sqrt(2.0), np.sqrt(2.0)], atol=1e-12)  # 2 m from the origin, 45 degrees up, on -y
+    assert np.allclose(ext[:3, :3] @ (np.zeros(3) - cam_pos), [0, 0, 2.0], atol=1e-12)  # the origin is straight ahead
+    centre = f.depth.data[0, 12, 16, 0]
+    assert f.color.data.shape == (2, 24, 32, 3) and f.color.data.dtype == np.uint8 and 500 < centre < 2100  # the robot's base, or the floor behind it
+    with pytest.raises(RuntimeError, match="track body id"):
+        SimCameraSet(simu, {"t": SimCameraConfig(identifier="wrist_0", type=CameraType.tracking)})
+    simu.close()
 
 
 def test_camera_set_semantics():
@@ -501,7 +529,8 @@ def test_camera_set_semantics():
     cs.clear_buffer()
     assert cs.buffer_size() == 0
     d = f1.frames["top"].camera.depth
-    assert d.data.shape == (3, H, W, 1) and d.data.dtype == np.uint16 and f1.frames["top"].camera.color.data is None
+    c = f1.frames["top"].camera.color
+    assert d.data.shape == (3, H, W, 1) and d.data.dtype == np.uint16 and c.data.shape == (3, H, W, 3) and c.data.dtype == np.uint8
     assert np.array_equal(d.data, f2.frames["top"].camera.depth.data)
     K = d.intrinsics
     assert np.isclose(K[0, 0], 0.5 * H / np.tan(np.deg2rad(45) / 2)) and K[0, 0] == K[1, 1] and K[0, 2] == (W - 1) / 2 and K[1, 2] == (H - 1) / 2
@@ -555,10 +584,8 @@ def test_error_behaviour_of_free_body_task_and_camera_calls():
     assert L.rcsh_camera_render(empty._h, 0, None, None, None) == _lib.RCSH_ERR_ARG      # no such camera
     with pytest.raises(RuntimeError, match="No camera named nope"):
         SimCameraSet(empty, {"x": SimCameraConfig(identifier="nope")})
-    with pytest.raises(NotImplementedError):
-        SimCameraSet(empty, {"x": SimCameraConfig(identifier="bird_eye_cam")}, render_on_demand=False)
-    with pytest.raises(NotImplementedError):
-        SimCameraSet(empty, {"x": SimCameraConfig(identifier="bird_eye_cam", type=CameraType.free)})
+    with pytest.raises(RuntimeError, match="track body id"):  # what mjv_updateCamera says to the reference's tracking camera
+        SimCameraSet(empty, {"x": SimCameraConfig(identifier="bird_eye_cam", type=CameraType.tracking)})
     empty.step(1)
     empty.close()
 
@@ -899,3 +926,15 @@ def test_self_collision_flags_match_oracle(scene, resolve, kernel):
     rep = run_self_collision_parity(n_envs=48, seed=1, scene=scene, resolve=resolve)
     assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0 and rep["max_abs_qpos"] < TOL, rep
     assert rep["self_only"] >= 8 and rep["robot_hits"] >= 4 and rep["gripper_hits"] >= 4, rep
+
+
+def test_rate_driven_cameras_match_oracle(kernel):
+    """SURVEY 8 row f4, the rendering leg of Sim::step: SimCameraSet(render_on_demand=False) delivers frames at the cameras'
+    frame rates from inside Sim.step and step_until_convergence, first frame in the first substep after construction / reset;
+    timestamps per environment equal the restated callback rule exactly, pixels equal the numpy ray-caster's."""
+    from parity_util import run_rate_driven_camera_parity
+
+    rep = run_rate_driven_camera_parity(n_envs=4, seed=3)
+    assert rep["timestamp_mismatches"] == 0 and rep["camera_set_mismatches"] == 0 and rep["max_abs_qpos"] < TOL, rep
+    assert rep["events"] >= 4 * 12 and rep["latest_timestamp_ok"] and rep["obs_keys"] == ["bird_eye_cam", "wrist_0"], rep
+    assert rep["mismatched_mm"] <= 5e-4 * rep["pixels"] and rep["rgb_off_by_more_than_one"] == 0, rep
