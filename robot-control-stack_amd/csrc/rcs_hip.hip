@@ -1256,6 +1256,7 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
     for (int k = 0; k < 4; ++k) r.sphere[k] = d->sphere[4 * i + k];
   }
   HIP_TRY(hipSetDevice(s->device));
+  const bool first_scene = s->d_frames == nullptr;
   hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_rcolours);
   s->d_rshapes = nullptr; s->d_rplanes = nullptr; s->d_frames = nullptr; s->d_wframes = nullptr; s->d_rcolours = nullptr;
   s->rscene.colours = nullptr;
@@ -1266,6 +1267,18 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
   HIP_TRY(hipMalloc(&s->d_wframes, sizeof(double) * kShapeFrameDoubles * (size_t)(d->nshape + 1) * s->n));
   HIP_TRY(hipMemcpyAsync(s->d_rshapes, sh.data(), sizeof(RenderShape) * d->nshape, hipMemcpyHostToDevice, s->stream));
   if (d->nplanes > 0) HIP_TRY(hipMemcpyAsync(s->d_rplanes, d->planes, sizeof(double) * 4 * d->nplanes, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  // The kernels keep "the qpos the last position stage saw" (what mjData.xpos / geom_xpos derive from) only while a render
+  // scene is attached.  A scene attached after some stepping starts from the current qpos instead of whatever the field held:
+  // one substep's motion off for the first frame, never a stale pose.
+  if (first_scene) with_layout(s, [&](auto topo) {
+    using L = Lay<decltype(topo)>;
+    const size_t n = (size_t)s->n;
+    (void)hipMemcpyAsync(s->S + (size_t)L::QPRE * n, s->S + (size_t)L::QPOS * n, sizeof(double) * n * s->nl, hipMemcpyDeviceToDevice, s->stream);
+    if (s->box.present)
+      (void)hipMemcpyAsync(s->S + (size_t)(L::BOX + kBoxPre) * n, s->S + (size_t)(L::BOX + kBoxQ) * n, sizeof(double) * n * 7, hipMemcpyDeviceToDevice, s->stream);
+    return 0;
+  });
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->rscene.nshape = d->nshape; s->rscene.nframes = s->nl + 1;
   s->rscene.znear = d->znear; s->rscene.zfar = d->zfar;
