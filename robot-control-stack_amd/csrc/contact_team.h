@@ -454,12 +454,12 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
 // Fall: world frames of the links of the wavefront's four teams, [4][NL][12] in LDS (R row-major, p); geoms welded to the
 // world carry their world frame in the table.  stage: LDS room for kSelfStage doubles.
 // Returns the class bits of the overlapping pairs of the calling lane's team.
-constexpr int kSelfStageVerts = 400;  // both hulls of a pair (host: build_self_pairs checks)
+constexpr int kSelfStageVerts = 304;  // both hulls of a pair (host: build_self_pairs checks)
 constexpr int kSelfStage = 3 * kSelfStageVerts;
 constexpr int kSelfCache = 4 * 8;      // per team two remembered separating directions (pair index, direction)
 constexpr int kSelfTag = 2;            // which pair the stage holds
 constexpr int kMaxSelfPairs = 160;     // pairs whose bounding spheres the lean DET kernels keep in LDS (host: build_self_pairs)
-constexpr int kSelfSphereWords = 9;    // per pair: c0, r0 + r1 (inflated by the rounding), c1 as float, the two links
+constexpr int kSelfSphereWords = 10;   // per pair: c0, c1, r0 + r1 (inflated by the rounding) as float, the two links, the joints between them
 RCSH_D void self_geom_world(const ContactGeom& g, const double* F, double* R, double* p) {
   if (g.link < 0) {
 #pragma unroll
@@ -477,8 +477,10 @@ RCSH_D void self_geom_world(const ContactGeom& g, const double* F, double* R, do
   p[0] += L[9]; p[1] += L[10]; p[2] += L[11];
 }
 // oriented boxes (centre c, axes = columns of R, half extents h): true if a separating axis exists among the 15 candidates
-RCSH_D bool obb_disjoint(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb) {
+// `gap` (optional): a lower bound of the boxes' distance where one of the six face axes separates them, else 0
+RCSH_D bool obb_disjoint(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb, double* gap = nullptr) {
   double C[9], A[9], tw[3], tv[3];
+  double sep = 0.0;
   const double d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
   mulTv(Ra, d, tv);  // centre offset in A's frame
 #pragma unroll
@@ -489,13 +491,18 @@ RCSH_D bool obb_disjoint(const double* Ra, const double* ca, const double* ha, c
       A[3 * i + j] = fabs(C[3 * i + j]) + 1e-9;
     }
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-    if (fabs(tv[i]) > ha[i] + hb[0] * A[3 * i] + hb[1] * A[3 * i + 1] + hb[2] * A[3 * i + 2]) return true;
+  for (int i = 0; i < 3; ++i) {
+    const double g = fabs(tv[i]) - (ha[i] + hb[0] * A[3 * i] + hb[1] * A[3 * i + 1] + hb[2] * A[3 * i + 2]);
+    sep = g > sep ? g : sep;
+  }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     tw[j] = tv[0] * C[j] + tv[1] * C[3 + j] + tv[2] * C[6 + j];
-    if (fabs(tw[j]) > hb[j] + ha[0] * A[j] + ha[1] * A[3 + j] + ha[2] * A[6 + j]) return true;
+    const double g = fabs(tw[j]) - (hb[j] + ha[0] * A[j] + ha[1] * A[3 + j] + ha[2] * A[6 + j]);
+    sep = g > sep ? g : sep;
   }
+  if (gap) *gap = sep;
+  if (sep > 0) return true;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -503,7 +510,15 @@ RCSH_D bool obb_disjoint(const double* Ra, const double* ca, const double* ha, c
       const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       const double ra = ha[i1] * A[3 * i2 + j] + ha[i2] * A[3 * i1 + j];
       const double rb = hb[j1] * A[3 * i + j2] + hb[j2] * A[3 * i + j1];
-      if (fabs(tv[i2] * C[3 * i1 + j] - tv[i1] * C[3 * i2 + j]) > ra + rb) return true;
+      const double over = fabs(tv[i2] * C[3 * i1 + j] - tv[i1] * C[3 * i2 + j]) - (ra + rb);
+      if (over > 0) {
+        if (gap) {
+          // the axis A_i x B_j is not a unit vector: |A_i x B_j|^2 = 1 - (A_i . B_j)^2
+          const double l2 = 1.0 - C[3 * i + j] * C[3 * i + j];
+          if (l2 > 1e-6) *gap = over / sqrt(l2);
+        }
+        return true;
+      }
     }
   return false;
 }
@@ -535,7 +550,7 @@ RCSH_D void self_box_world(const double* F, int link, const double* c, const dou
   mulmm(LR, rot, Rw);
 }
 // Fills the LDS copy of the pairs' bounding spheres (single precision, the sum of the radii rounded up: conservative).
-RCSH_D void self_sphere_table_fill(const SelfPair* pairs, int npair, float* tab) {
+RCSH_D void self_sphere_table_fill(const SelfPair* pairs, int npair, float* tab, int narm) {
   for (int i = threadIdx.x; i < npair; i += 64) {
     const SelfPair& pr = pairs[i];
     float* w = tab + kSelfSphereWords * i;
@@ -544,20 +559,103 @@ RCSH_D void self_sphere_table_fill(const SelfPair* pairs, int npair, float* tab)
     w[6] = (float)(pr.r0 + pr.r1) * 1.000001f + 1e-6f;
     reinterpret_cast<int*>(w)[7] = pr.l0;
     reinterpret_cast<int*>(w)[8] = pr.l1;
+    // the joints between the two links, for the slack test: arm joints [a0, a1) as a range of the prefix sums, plus the
+    // slides of the fingers among the two links (joint index + 1, 0: none)
+    int a0 = 0, a1 = 0, f0 = 0, f1 = 0;
+    {
+      const int arm = pr.joints & ((1 << narm) - 1);
+      if (arm) { a0 = __ffs(arm) - 1; a1 = 32 - __clz(arm); }
+      const int fing = pr.joints >> narm;
+      if (fing & 1) f0 = narm + 1;
+      if (fing & 2) f1 = narm + 2;
+    }
+    reinterpret_cast<int*>(w)[9] = a0 | (a1 << 8) | (f0 << 16) | (f1 << 24);
   }
 }
+// What the self-collision test remembers per team for the length of a launch (lean DET kernels only; LDS).  A pair found
+// apart by a gap g cannot touch before the joints between its two links have moved the geoms by g: path[j] integrates
+// lever[j] * |dq_j| over the calls (prefix[] its running sums along the arm), and due[i] is the value the pair's sum of
+// path[] must reach before the pair is looked at again: the sum when its gap was measured, plus the gap.  In a settled or
+// slowly moving arm every pair is skipped, every call.
+struct SelfSlack {
+  double qprev[4][12], path[4][12], prefix[4][12];
+  float due[4][kMaxSelfPairs];
+};
+RCSH_D void self_slack_clear(SelfSlack& ss) {
+  for (int k = threadIdx.x; k < 4 * 12; k += 64) { (&ss.qprev[0][0])[k] = 0.0; (&ss.path[0][0])[k] = 0.0; (&ss.prefix[0][0])[k] = 0.0; }
+  for (int k = threadIdx.x; k < 4 * kMaxSelfPairs; k += 64) (&ss.due[0][0])[k] = 0.0f;
+}
 RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const double* verts, const SelfPair* pairs, int npair, const double* Fall_,
-                                              double* stage_, int nl, bool team_due, bool keep_stage, const float* sph_) {
+                                              double* stage_, int nl, bool team_due, bool keep_stage, const float* sph_, SelfSlack* ss_,
+                                              const double* lever_, double q_lane) {
   const double* Fall = in_lds(Fall_);
   double* stage = in_lds(stage_);
+  SelfSlack* ss = ss_ ? in_lds(ss_) : nullptr;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const double* F = Fall + 12 * nl * team;
   uint32_t cmask = 0, smask = 0;  // survivors of the broad phase (of its bounding spheres): bit j = pair t + 16 j
   TEAM_MARK(42)
+  if (team_due && sph_ && ss) {
+    // how far the joints have come since the last call
+    double mine_path = 0.0;
+    if (t < nl) {
+      const double lever = in_lds(lever_)[t];
+      mine_path = ss->path[team][t] + lever * fabs(q_lane - ss->qprev[team][t]);
+      ss->path[team][t] = mine_path;
+      ss->qprev[team][t] = q_lane;
+    }
+    // running sums along the lanes (arm joints are lanes 0 .. narm - 1): prefix[k] = path[0] + .. + path[k - 1]
+    double incl = mine_path;
+    incl += row_up<1>(incl);
+    incl += row_up<2>(incl);
+    incl += row_up<4>(incl);
+    if (t < 11) ss->prefix[team][t + 1] = incl;
+    stage_fence();
+  }
   if (team_due && sph_) {
-    // the pairs' bounding spheres from their LDS table
+    // the pairs' bounding spheres from their LDS table -- of the pairs whose slack is used up (with a slack cache; all without)
     const float* sph = in_lds(sph_);
-    for (int j = 0, i = t; i < npair; ++j, i += kTeamLanes) {
+    uint32_t amask = 0;
+    if (ss) {
+      // the pairs' slack: the gap measured last against what the joints between the two links have moved since.  The reads
+      // of all the lane's pairs go out together (a dependent chain per pair would cost an LDS round trip each, three deep).
+      constexpr int kMaxPer = (kMaxSelfPairs + kTeamLanes - 1) / kTeamLanes;
+      int jw[kMaxPer];
+#pragma unroll
+      for (int j = 0; j < kMaxPer; ++j) {
+        const int i = t + kTeamLanes * j;
+        jw[j] = reinterpret_cast<const int*>(sph + kSelfSphereWords * (i < npair ? i : t))[9];
+      }
+      sched_fence();
+      double hi[kMaxPer], lo[kMaxPer], p0[kMaxPer], p1[kMaxPer];
+      float due[kMaxPer];
+#pragma unroll
+      for (int j = 0; j < kMaxPer; ++j) {
+        const int i = t + kTeamLanes * j, f0 = (jw[j] >> 16) & 0xff, f1 = (jw[j] >> 24) & 0xff;
+        hi[j] = ss->prefix[team][(jw[j] >> 8) & 0xff];
+        lo[j] = ss->prefix[team][jw[j] & 0xff];
+        p0[j] = f0 ? ss->path[team][f0 - 1] : 0.0;
+        p1[j] = f1 ? ss->path[team][f1 - 1] : 0.0;
+        due[j] = ss->due[team][i < npair ? i : t];
+      }
+      sched_fence();
+#pragma unroll
+      for (int j = 0; j < kMaxPer; ++j) {
+        const int i = t + kTeamLanes * j;
+        const float moved = (float)((hi[j] - lo[j]) + p0[j] + p1[j]) * 1.000001f + 1e-6f;  // (rounded up)
+        if (i < npair && !(moved < due[j])) {
+          ss->due[team][i] = moved;  // (gap 0) until one of the stages below measures a new one
+          amask |= 1u << j;
+        }
+      }
+    } else {
+      for (int j = 0, i = t; i < npair; ++j, i += kTeamLanes) amask |= 1u << j;
+    }
+    // one pair per lane and round: the wavefront runs the sphere test as often as its busiest lane has pairs to look at
+    while (__ballot(amask != 0)) {
+      if (!amask) continue;
+      const int j = __ffs((int)amask) - 1, i = t + kTeamLanes * j;
+      amask &= amask - 1;
       const float* w = sph + kSelfSphereWords * i;
       const double c0[3] = {w[0], w[1], w[2]}, c1[3] = {w[3], w[4], w[5]}, rs = w[6];
       const int l0 = reinterpret_cast<const int*>(w)[7], l1 = reinterpret_cast<const int*>(w)[8];
@@ -567,7 +665,9 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
       if (l1 >= 0) { const double* L = F + 12 * l1; mulmv(L, c1, s1); s1[0] += L[9]; s1[1] += L[10]; s1[2] += L[11]; }
       else { s1[0] = c1[0]; s1[1] = c1[1]; s1[2] = c1[2]; }
       const double d[3] = {s0[0] - s1[0], s0[1] - s1[1], s0[2] - s1[2]};
-      if (dot3(d, d) <= rs * rs) smask |= 1u << j;
+      const double d2 = dot3(d, d);
+      if (d2 <= rs * rs) smask |= 1u << j;
+      else if (ss) ss->due[team][i] += (float)(sqrt(d2) - rs) * 0.999999f - 2e-5f;  // (single-precision centres: rounded down)
     }
   } else if (team_due) {
     constexpr int kBatch = 3;
@@ -599,6 +699,8 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
       }
     }
   }
+  TEAM_MARK(40)
+  if (__ballot(smask != 0)) { TEAM_COUNT(41) }
   // the oriented boxes of the spheres' survivors (a handful per environment): one per lane and round, so that the wavefront
   // runs the box test once or twice instead of in every iteration of the loop above
   while (__ballot(smask != 0)) {
@@ -609,7 +711,9 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
       double Ra[9], Rb[9], ca[3], cb[3];
       self_box_world(F, pr.l0, pr.c0, pr.rot0, ca, Ra);
       self_box_world(F, pr.l1, pr.c1, pr.rot1, cb, Rb);
-      if (!obb_disjoint(Ra, ca, pr.h0, Rb, cb, pr.h1)) cmask |= 1u << j;
+      double sep = 0.0;
+      if (!obb_disjoint(Ra, ca, pr.h0, Rb, cb, pr.h1, &sep)) cmask |= 1u << j;
+      else if (ss) ss->due[team][t + kTeamLanes * j] += (float)sep * 0.999999f - 2e-5f;
     }
   }
   uint32_t mine = 0;
@@ -671,7 +775,9 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
         mulmv(LR, dl, dw);
         MprPt q;
         mpr_support<true>(A, B, dw, q);
-        apart = dot3(q.v, dw) < 0;
+        const double along = dot3(q.v, dw);  // support of A - B along the (unit) direction: minus a lower bound of the distance
+        apart = along < 0;
+        if (apart && ss && t == t0) ss->due[team][pidx] += (float)(-along) * 0.999999f - 2e-5f;
       }
       TEAM_MARK(38)
       if (apart) { TEAM_COUNT(39) }

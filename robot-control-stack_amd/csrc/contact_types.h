@@ -34,7 +34,7 @@ struct SelfPair {
   int16_t g0, g1;
   int16_t l0, l1;  // their links (-1: welded to the world)
   int32_t cls;     // bit 0: SimRobot::collision_callback counts the contact, bit 1: SimGripper::collision_callback does
-  int32_t pad;
+  int32_t joints;  // bit j: joint j lies on the tree path between the two links (only those joints move the geoms relative to each other)
   // broad phase, in the frames of the two links: centre of the geom's bounding box and its half diagonal (bounding sphere);
   // then the box itself -- axes (columns of rot: geom frame in the link frame) and half extents
   double c0[3], r0, c1[3], r1;
@@ -48,6 +48,9 @@ struct ContactTable {
   int32_t ngeom, has_plane;
   int32_t link_geom_adr[13];  // geoms of link i are [link_geom_adr[i], link_geom_adr[i + 1]) (kMaxLinks + 1 entries)
   int32_t npair;
+  // self collision: lever[j] bounds how far one radian (hinge) / one metre (slide) of joint j can move any point of a collision
+  // geom downstream of it (host: build_self_pairs) -- what turns joint motion into a bound on how much a pair's gap can close
+  double self_lever[12];
   double plane_n[3], plane_d, plane_mu;
 };
 

@@ -58,6 +58,7 @@ struct rcsh_sim {
   ContactGeom* d_cgeoms = nullptr;
   SelfPair* d_pairs = nullptr;       // self-collision pairs a collision callback reacts to (rebuilt when the class bits change)
   std::vector<SelfPair> pairs;
+  double self_lever[12] = {0};       // contact_types.h: ContactTable::self_lever
   double* d_cverts = nullptr;
   double plane_mu = 1.0;
   std::vector<int> act_slot;
@@ -144,6 +145,7 @@ Params make_params(rcsh_sim* s) {
   P.ctab.verts = s->d_cverts;
   P.rend = s->rend;
   P.ctab.pairs = s->d_pairs;
+  for (int k = 0; k < 12; ++k) P.ctab.self_lever[k] = s->self_lever[k];
   P.ctab.npair = (int)s->pairs.size();
   P.ctab.ngeom = s->box.resolve ? (int)s->cgeoms.size() : 0;
   P.ctab.has_plane = s->cp.has_plane;
@@ -197,7 +199,7 @@ int upload_coll_classes(rcsh_sim* s) {
 // parent-child pair unless one of the two is welded to the world), then what the callbacks make of a contact of the pair
 // (SimRobot.cpp:172-182: either geom is an arm collision geom; SimGripper.cpp:108-130: not finger-finger, either geom is a
 // gripper collision geom, geom[1] is not in the ignore list -- quirk Q6).  Pairs nobody reacts to are dropped.
-constexpr int kSelfStageVertsHost = 400;  // contact_team.h: kSelfStageVerts
+constexpr int kSelfStageVertsHost = 304;  // contact_team.h: kSelfStageVerts
 void build_self_pairs(rcsh_sim* s) {
   s->pairs.clear();
   if (std::getenv("RCSH_DEBUG_NO_SELF_PAIRS")) return;  // development switch: what the pair tests cost
@@ -220,6 +222,16 @@ void build_self_pairs(rcsh_sim* s) {
       pr.g0 = (int16_t)(swap ? j : i); pr.g1 = (int16_t)(swap ? i : j);
       pr.l0 = (int16_t)g0.link; pr.l1 = (int16_t)g1.link;
       pr.cls = cls;
+      {
+        // joints on the tree path between the two links: root paths' symmetric difference (arm link i: joints 0..i; a finger:
+        // the whole arm and its own slide; welded to the world: none)
+        auto root_path = [&](int link) -> int {
+          if (link < 0) return 0;
+          if (link < s->narm) return (1 << (link + 1)) - 1;
+          return ((1 << s->narm) - 1) | (1 << link);
+        };
+        pr.joints = root_path(g0.link) ^ root_path(g1.link);
+      }
       auto bounds = [](const ContactGeom& g, double* c, double& r, double* rot, double* h) {
         // bounding box of the geom (geom frame: centre lc, half extents h), carried into the link frame
         double lc[3] = {0, 0, 0};
@@ -236,9 +248,46 @@ void build_self_pairs(rcsh_sim* s) {
     }
 }
 
+// lever[j]: how far one radian of hinge j (one metre of a slide) can move a point of any collision geom downstream of it.
+// Distances between consecutive joint anchors are constants of the links; a finger's anchor slides, so its stroke is added.
+void build_self_levers(rcsh_sim* s) {
+  const DevModel& m = s->dm;
+  const int na = s->narm, nl = s->nl;
+  auto parent = [&](int link) { return link < na ? link - 1 : na - 1; };
+  // reach[L]: from link L's joint anchor to the farthest point of a collision geom ON link L (link frame)
+  std::vector<double> reach(nl, 0.0), hop(nl, 0.0), stroke(nl, 0.0);
+  for (const auto& g : s->cgeoms) {
+    if (g.link < 0) continue;
+    double c[3], h[3] = {g.size[0], g.size[1], g.size[2]}, lc[3] = {0, 0, 0};
+    if (g.type == 7) for (int k = 0; k < 3; ++k) { lc[k] = g.aabb_c[k]; h[k] = g.aabb_h[k]; }
+    else if (g.type == 3) { h[0] = h[1] = g.size[0]; h[2] = g.size[0] + g.size[1]; }
+    for (int k = 0; k < 3; ++k) c[k] = g.rot[3 * k] * lc[0] + g.rot[3 * k + 1] * lc[1] + g.rot[3 * k + 2] * lc[2] + g.pos[k] - m.jpos[g.link][k];
+    const double r = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + std::sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+    reach[g.link] = std::max(reach[g.link], r);
+  }
+  for (int L = 0; L < nl; ++L) {
+    // hop[L]: from the parent link's anchor to link L's anchor (parent link frame, at qpos0; a hinge's anchor does not move)
+    const int p = parent(L);
+    double a[3];
+    for (int k = 0; k < 3; ++k) a[k] = m.pos0[L][k] + m.rot0[L][3 * k] * m.jpos[L][0] + m.rot0[L][3 * k + 1] * m.jpos[L][1] + m.rot0[L][3 * k + 2] * m.jpos[L][2] - (p >= 0 ? m.jpos[p][k] : 0.0);
+    hop[L] = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (m.jtype[L] == kSlide) stroke[L] = std::max(std::fabs(m.range[L][0] - m.qpos0[L]), std::fabs(m.range[L][1] - m.qpos0[L]));
+  }
+  // far[L]: from link L's anchor to the farthest geom point on L or downstream of it
+  std::vector<double> far(nl, 0.0);
+  for (int L = nl - 1; L >= 0; --L) {
+    far[L] = std::max(far[L], reach[L] + stroke[L]);
+    const int p = parent(L);
+    if (p >= 0) far[p] = std::max(far[p], hop[L] + stroke[L] + far[L]);
+  }
+  for (int j = 0; j < 12; ++j) s->self_lever[j] = 0.0;
+  for (int j = 0; j < nl; ++j) s->self_lever[j] = m.jtype[j] == kSlide ? 1.0 : 1.01 * far[j] + 1e-3;
+}
+
 int upload_contact_table(rcsh_sim* s) {
   if (s->cgeoms.empty()) return RCSH_OK;
   build_self_pairs(s);
+  build_self_levers(s);
   if (s->d_pairs) { HIP_TRY(hipStreamSynchronize(s->stream)); HIP_TRY(hipFree(s->d_pairs)); s->d_pairs = nullptr; }
   if (!s->pairs.empty()) {
     HIP_TRY(hipMalloc(&s->d_pairs, sizeof(SelfPair) * s->pairs.size()));

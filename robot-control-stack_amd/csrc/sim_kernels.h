@@ -706,10 +706,18 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   double* const selfAll = (DET && CON) ? reinterpret_cast<double*>(&larena[0]) : lself;
   double* const selfF = selfAll + (DET ? team * kSelfF : 0);
   const int npair = DET ? lp.ctab.npair : 0;
-  __shared__ float lsph[(DET && !CON) ? kMaxSelfPairs * kSelfSphereWords : 1];
-  const float* const sph = (DET && !CON && npair <= kMaxSelfPairs) ? lsph : nullptr;
-  if constexpr (DET && !CON) {
-    if (sph) self_sphere_table_fill(lp.ctab.pairs, npair, lsph);
+  // (lean kernels without a free box only: the others have no LDS to spare and read the pair records from memory)
+  constexpr bool kSelfLds = DET && !CON && !BOX;
+  __shared__ float lsph[kSelfLds ? kMaxSelfPairs * kSelfSphereWords : 1];
+  const float* const sph = (kSelfLds && npair <= kMaxSelfPairs) ? lsph : nullptr;
+  __shared__ std::conditional_t<kSelfLds, SelfSlack, char> lslack[1];
+  SelfSlack* slack = nullptr;
+  if constexpr (kSelfLds) {
+    if (sph) {
+      self_sphere_table_fill(lp.ctab.pairs, npair, lsph, T::NARM);
+      self_slack_clear(lslack[0]);
+      slack = &lslack[0];
+    }
   }
   if constexpr (DET && !CON) {
     if (threadIdx.x == 0) lself[kSelfF * kTeams + kSelfStage + kSelfCache] = 0.0;  // nothing staged yet
@@ -835,7 +843,8 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
             for (int k = 0; k < 3; ++k) selfF[12 * t + 9 + k] = p[k];
           }
           stage_fence();  // (LDS traffic of one wavefront is ordered; the fence is for the compiler)
-          mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, !CON, sph);
+          mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, !CON, sph, slack,
+                                       lp.ctab.self_lever, st.q(t < T::NL ? t : T::NL - 1));
           stage_fence();  // (CON: frames and stage sit in the contact arena, which the contact phase may enter next)
         }
         hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);

@@ -25,10 +25,11 @@ simu._L.rcsh_debug_team_cycles48(out); a = np.array(out[:], dtype=np.float64) - 
 calls = max(a[47], 1)
 print(f"substeps {simu.convergence_steps()[:4]}, calls of the pair test (workgroup 0): {a[47]:.0f}, narrow-phase candidates {a[46]:.0f}")
 print(f"  before (since last mark)      {a[42] / calls:10.0f}")
-print(f"  broad phase                   {a[43] / calls:10.0f}")
+print(f"  slack test + spheres          {a[40] / calls:10.0f}")
+print(f"  oriented boxes                {a[43] / calls:10.0f}   (ran in {a[41]:.0f} of {a[47]:.0f} calls)")
 print(f"  staging  (per candidate)      {a[44] / max(a[46], 1):10.0f}")
 print(f"  frames + shapes (per cand.)   {a[37] / max(a[46], 1):10.0f}")
 print(f"  remembered direction          {a[38] / max(a[46], 1):10.0f}   (settled {a[39]:.0f} of {a[46]:.0f})")
 print(f"  portal refinement (per cand.) {a[45] / max(a[46], 1):10.0f}")
 if len(sys.argv) > 2:
-    print("all slots (cycles, workgroup 0):", {i: int(a[i]) for i in range(48) if a[i]}, "sum of marks", int(sum(a[i] for i in range(48) if i not in (29, 33, 34, 35, 36, 39, 40, 41, 46, 47))))
+    print("all slots (cycles, workgroup 0):", {i: int(a[i]) for i in range(48) if a[i]}, "sum of marks", int(sum(a[i] for i in range(48) if i not in (29, 33, 34, 35, 36, 39, 41, 46, 47))))
