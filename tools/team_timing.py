@@ -8,8 +8,8 @@ lib.LIB_PATH = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "librcs_
 import numpy as np
 from parity_util import make_vec_env, synthetic_actions
 n, T = 4096, 20
-env = make_vec_env(n, True)
-j, g = synthetic_actions(64, T, 0)
+env = make_vec_env(n, True, robot=(sys.argv[1] if len(sys.argv) > 1 else "fr3"))
+j, g = synthetic_actions(64, T, 0, dof=env.dof)
 j = np.tile(j, (1, n // 64, 1)); g = np.tile(g, (1, n // 64))
 env.reset()
 out = (C.c_ulonglong * 24)()
