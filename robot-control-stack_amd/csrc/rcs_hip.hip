@@ -128,6 +128,27 @@ Params make_params(rcsh_sim* s) {
     for (int a = 0; a < 4; ++a) P.coll.link_sphere[i][a] = (size_t)(4 * i + a) < s->cp.link_sphere.size() ? s->cp.link_sphere[4 * i + a] : 0.0;
   for (int i = 0; i < kMaxLinks; ++i)
     for (int a = 0; a < 6; ++a) P.coll.link_aabb[i][a] = (size_t)(6 * i + a) < s->cp.link_aabb.size() ? s->cp.link_aabb[6 * i + a] : 0.0;
+  {
+    // entry nl: the box (world frame) around the robot's collision geoms that are welded to the world (link 0's hull): the
+    // broad phase of the contact phase tests the free body against it on the first lane that carries no link
+    double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    bool any = false;
+    for (const auto& g : s->cgeoms) {
+      if (g.link >= 0 || (g.type == 7 && g.vert_num == 0)) continue;
+      double lc[3] = {0, 0, 0}, h[3] = {g.size[0], g.size[1], g.size[2]};
+      if (g.type == 7) for (int k = 0; k < 3; ++k) { lc[k] = g.aabb_c[k]; h[k] = g.aabb_h[k]; }
+      else if (g.type == 3) { h[0] = h[1] = g.size[0]; h[2] = g.size[0] + g.size[1]; }
+      for (int a = 0; a < 3; ++a) {
+        const double c = g.rot[3 * a] * lc[0] + g.rot[3 * a + 1] * lc[1] + g.rot[3 * a + 2] * lc[2] + g.pos[a];
+        const double e = std::fabs(g.rot[3 * a]) * h[0] + std::fabs(g.rot[3 * a + 1]) * h[1] + std::fabs(g.rot[3 * a + 2]) * h[2];
+        lo[a] = std::fmin(lo[a], c - e); hi[a] = std::fmax(hi[a], c + e);
+      }
+      any = true;
+    }
+    if (any && s->nl < kMaxLinks)
+      for (int a = 0; a < 3; ++a) { P.coll.link_aabb[s->nl][a] = 0.5 * (lo[a] + hi[a]); P.coll.link_aabb[s->nl][3 + a] = 0.5 * (hi[a] - lo[a]); }
+    P.coll.has_static = any ? 1 : 0;
+  }
   P.coll.has_plane = s->cp.has_plane && !s->cp.geom.empty();
   for (int k = 0; k < 3; ++k) P.coll.plane_n[k] = s->cp.plane_n[k];
   P.coll.plane_d = s->cp.plane_d;

@@ -109,7 +109,7 @@ struct CollTable {
   int32_t link_adr[kMaxLinks + 1];
   double link_sphere[kMaxLinks][4];  // broad phase: bounding sphere of the link's points (link frame)
   double link_aabb[kMaxLinks][6];    // broad phase of the contact phase: bounding box of the link's points (centre, half extents)
-  int32_t has_plane;
+  int32_t has_plane, has_static;     // has_static: link_aabb[NL] bounds collision geoms welded to the world (world frame)
   double plane_n[3], plane_d;
 };
 
@@ -760,8 +760,10 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   double bbc[3] = {0, 0, 0}, bbh[3] = {0, 0, 0}, pln[3] = {0, 0, 1}, pld = 0, box_r2 = 0;
   bool con_lane = false;
   if constexpr (CON) {
-    con_lane = t < T::NL && lp.ctab.ngeom > 0;
-    const int tl = t < T::NL ? t : 0;
+    // (lane NL: the geoms welded to the world -- link 0's hull -- against the free body; their frame is the world's)
+    const bool static_lane = BOX && t == T::NL && lc.has_static;
+    con_lane = (t < T::NL || static_lane) && lp.ctab.ngeom > 0;
+    const int tl = t <= T::NL ? t : 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { bbc[k] = lc.link_aabb[tl][k]; bbh[k] = lc.link_aabb[tl][3 + k]; pln[k] = lc.plane_n[k]; }
     pld = lc.plane_d;
@@ -793,7 +795,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
     bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
     team_substep<T, FRIC>(m, sk, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
       if constexpr (CON) {
-        if (stepping && con_lane) {
+        if (stepping && con_lane && t < T::NL) {
           // the link's bounding box (link frame) against the floor -- its support along the plane normal -- and against
           // the box's bounding sphere: tight enough that an arm in its workspace does not wake the contact phase
           double c[3];
@@ -814,6 +816,18 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
           // second level: the same tests on the boxes of the link's geoms
           if (near)
             near = geom_level_near(lp.ctab.geoms, lp.ctab.link_geom_adr[t], lp.ctab.link_geom_adr[t + 1], R, p, pln, pld, has_plane, bs + kBoxQ, box_r2, BOX);
+        }
+        if constexpr (BOX) {
+          if (stepping && con_lane && t == T::NL) {
+            // the lane of the world-welded geoms (link 0's hull): their box is in the world frame; no floor test (MuJoCo
+            // filters that pair)
+            const double ex = fmax(fabs(bs[kBoxQ] - bbc[0]) - bbh[0], 0.0), ey = fmax(fabs(bs[kBoxQ + 1] - bbc[1]) - bbh[1], 0.0),
+                         ez = fmax(fabs(bs[kBoxQ + 2] - bbc[2]) - bbh[2], 0.0);
+            if (ex * ex + ey * ey + ez * ez <= box_r2) {
+              const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+              near = geom_level_near(lp.ctab.geoms, 0, lp.ctab.link_geom_adr[0], I9, z3, pln, pld, false, bs + kBoxQ, box_r2, true);
+            }
+          }
         }
       }
       if constexpr (DET) {

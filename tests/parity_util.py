@@ -954,3 +954,59 @@ def run_rate_driven_camera_parity(n_envs=4, width=32, height=24, seed=3):
     rep["obs_keys"] = sorted(latest.frames)
     simu.close()
     return rep
+
+
+def run_cube_against_base_parity(n_envs=12, n_calls=6, k=25, seed=5):
+    """The free cube thrown at / dropped onto the robot's base: link 0's collision hull is welded to the world, so MuJoCo
+    filters it against the floor but not against the cube (mjc_Convex, box first).  Kernel vs oracle: cube pose, how many
+    environments saw a (link 0, cube) contact."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cfg = default_sim_robot_cfg("fr3_simple_pick_up")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    robot = S.SimRobot(simu, None, cfg)
+    S.SimGripper(simu, default_sim_gripper_cfg())
+    cm = compile_mjcf(PICKUP_SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
+    g0 = cm.name2id("geom", "fr3_link0_collision_0")
+    rng = np.random.default_rng(seed)
+    ang = rng.uniform(-np.pi, np.pi, n_envs)
+    rad = rng.uniform(0.16, 0.22, n_envs)
+    qb = np.zeros((n_envs, 7))
+    qb[:, 0], qb[:, 1], qb[:, 2] = rad * np.cos(ang), rad * np.sin(ang), rng.uniform(0.03, 0.12, n_envs)
+    qb[:, 3:] = rng.normal(size=(n_envs, 4))
+    vb = np.zeros((n_envs, 6))
+    vb[:, 0], vb[:, 1] = -1.2 * np.cos(ang), -1.2 * np.sin(ang)  # towards the base
+    vb[:, 3:] = rng.uniform(-2, 2, (n_envs, 3))
+    simu.set_free_joint_qpos("box_joint", qb)
+    simu.set_free_joint_qvel("box_joint", vb)
+    for e, o in enumerate(osims):
+        o.box_qpos, o.box_qvel = qb[e], vb[e]
+    rep = {"max_abs_pos": 0.0, "max_abs_quat": 0.0, "max_abs_robot_qpos": 0.0, "base_contact_envs": set(), "max_ncon": 0,
+           "env_pos_err": np.zeros(n_envs)}
+    home = np.tile(FR3_Q_HOME, (n_envs, 1))
+    for _ in range(n_calls):
+        robot.set_joint_position(home)
+        simu.step(k)
+        qk, qr = simu.free_joint_qpos("box_joint"), simu.qpos
+        for e, o in enumerate(osims):
+            o.set_joint_position(home[e])
+            for _ in range(k):
+                o.step(1)
+                d = o.s.d
+                rep["max_ncon"] = max(rep["max_ncon"], int(d.ncon))
+                if any(g0 in (d.contact[c].geom[0], d.contact[c].geom[1]) for c in range(d.ncon)):
+                    rep["base_contact_envs"].add(e)
+            rep["env_pos_err"][e] = max(rep["env_pos_err"][e], float(np.abs(qk[e, :3] - o.box_qpos[:3]).max()))
+            rep["max_abs_pos"] = max(rep["max_abs_pos"], float(np.abs(qk[e, :3] - o.box_qpos[:3]).max()))
+            rep["max_abs_quat"] = max(rep["max_abs_quat"], float(np.abs(qk[e, 3:] - o.box_qpos[3:]).max()))
+            rep["max_abs_robot_qpos"] = max(rep["max_abs_robot_qpos"], float(np.abs(qr[e] - o.qpos).max()))
+    rep["base_contact_envs"] = len(rep["base_contact_envs"])
+    rep["final_radius"] = np.hypot(qk[:, 0], qk[:, 1])
+    simu.close()
+    return rep

@@ -938,3 +938,19 @@ def test_rate_driven_cameras_match_oracle(kernel):
     assert rep["timestamp_mismatches"] == 0 and rep["camera_set_mismatches"] == 0 and rep["max_abs_qpos"] < TOL, rep
     assert rep["events"] >= 4 * 12 and rep["latest_timestamp_ok"] and rep["obs_keys"] == ["bird_eye_cam", "wrist_0"], rep
     assert rep["mismatched_mm"] <= 5e-4 * rep["pixels"] and rep["rgb_off_by_more_than_one"] == 0, rep
+
+
+def test_cube_against_the_robot_base(kernel):
+    """Collision geoms welded to the world (link 0's hull) against the free cube: contacts between the world body and the cube
+    that are NOT the floor's.  The cube is thrown at the base from all around, spinning; it bounces off in the kernel as in the
+    oracle.  Most environments agree to round-off over the 150 substeps.  Not all can be held to that: the portal refinement of
+    a box face lying 15 mm deep in a hull facet has several portals of nearly equal depth to end on, and which one it picks --
+    a jump of the contact normal by a few degrees -- is decided by the last bit of its inputs (the kernel contracts
+    multiply-adds, the oracle does not); MuJoCo's own libccd is no more deterministic across compilers.  Those environments
+    must still keep the cube outside the base and within millimetres of the oracle's."""
+    from parity_util import run_cube_against_base_parity
+
+    rep = run_cube_against_base_parity()
+    assert rep["base_contact_envs"] >= 6 and rep["max_abs_robot_qpos"] < TOL, rep
+    assert (rep["env_pos_err"] < 1e-7).sum() >= 9 and rep["max_abs_pos"] < 0.02, rep
+    assert (rep["final_radius"] > 0.08).all(), rep  # nowhere did the cube pass through the base
