@@ -639,6 +639,46 @@ def test_xarm7_with_free_box_and_camera(kernel):
     assert rep["depth_mismatch"] <= 3 and rep["cube_pixels"] > 16, rep
 
 
+def test_xarm7_box_batch_of_baseline_config_3(kernel):
+    """BASELINE configs[3] at its per-GPU size -- 8192 environments split over 2 GPUs = 4096 each -- on the scene that stands in for
+    "xarm7 pick-place with object contacts + SimCameraSet depth render" (the reference ships no such scene): xArm7 with dry joint
+    friction next to the free cube, one depth AND colour frame of the fixed camera per step.  16 distinct (cube state, target
+    stream) pairs tiled 256x: every copy equals the first bit for bit wherever it sits (the same scene against the oracle:
+    test_xarm7_with_free_box_and_camera)."""
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import xarm7_sim_robot_cfg
+
+    n, base = 4096, 16
+    cfg = xarm7_sim_robot_cfg("xarm7_box_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+    robot = S.SimRobot(simu, None, cfg)
+    cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", resolution_width=24, resolution_height=16)}, physical_units=True)
+    rng = np.random.default_rng(6)
+    qb = np.zeros((base, 7))
+    qb[:, 0], qb[:, 1], qb[:, 2] = 0.45 + rng.uniform(-0.1, 0.1, base), rng.uniform(-0.1, 0.1, base), rng.uniform(0.02, 0.08, base)
+    qb[:, 3:] = rng.normal(size=(base, 4))
+    vb = np.concatenate([rng.uniform(-0.4, 0.4, (base, 3)), rng.uniform(-3, 3, (base, 3))], axis=1)
+    simu.set_free_joint_qpos("box_joint", np.tile(qb, (n // base, 1)))
+    simu.set_free_joint_qvel("box_joint", np.tile(vb, (n // base, 1)))
+
+    def tiled(arr):
+        a = np.asarray(arr).reshape(n // base, base, -1)
+        return np.array_equal(a, np.broadcast_to(a[0], a.shape))
+
+    from rcs_env_oracle import XARM7
+
+    for _ in range(4):
+        tgt = np.asarray(XARM7["q_home"]) + rng.uniform(-0.2, 0.2, (base, 7))
+        robot.set_joint_position(np.tile(tgt, (n // base, 1)))
+        simu.step(17)
+        f = cs.get_latest_frames().frames["side"].camera
+        for arr in (simu.qpos, simu.qvel, simu.free_joint_qpos("box_joint"), simu.free_joint_qvel("box_joint"), f.depth.data, f.color.data):
+            assert tiled(arr), "replicas diverged"
+    assert (f.depth.data[:base] < 1500).any() and np.isfinite(simu.qpos).all()
+    simu.close()
+
+
 def test_pick_task_batch_is_position_independent(kernel):
     """The pick-up task at BASELINE's batch size (4096 environments): 32 distinct (cube placement, action stream) pairs tiled
     128x over the batch; every copy equals the first BIT FOR BIT wherever it sits (lane, team, wavefront, XCD) -- robot,
