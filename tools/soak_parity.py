@@ -12,7 +12,7 @@ for seed in range(3):
 rep = pu.run_depth_render_parity(n_envs=8, width=96, height=64, seed=5, n_calls=4)
 print("depth", {k: v for k, v in rep.items() if k != "sample"})
 import time
-for kernel in ("team", "lane"):
+for kernel in ("team",):
     pu.KERNEL = kernel
     t0 = time.time()
     rep = pu.run_joint_rollout_parity(n_envs=192, n_steps=40, async_control=True, seed=100)
@@ -26,3 +26,16 @@ rep = pu.run_joint_rollout_parity(n_envs=96, n_steps=20, async_control=True, see
 print("xarm7 async", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
 rep = pu.run_joint_rollout_parity(n_envs=96, n_steps=20, async_control=True, seed=104, robot="arm6")
 print("arm6 async", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
+for robot in ("ur5e", "so101"):
+    rep = pu.run_joint_rollout_parity(n_envs=96, n_steps=20, async_control=True, seed=105, robot=robot)
+    print(robot, "async", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
+    rep = pu.run_joint_rollout_parity(n_envs=48, n_steps=5, async_control=False, seed=106, robot=robot)
+    print(robot, "conv ", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items()})
+for seed in (2, 3):
+    rep = pu.run_self_collision_parity(n_envs=96, seed=seed)
+    print("self collision", seed, rep)
+for seed in (1, 2):
+    rep = pu.run_grasp_parity(n_envs=8, seed=seed) if "seed" in pu.run_grasp_parity.__code__.co_varnames else pu.run_grasp_parity(n_envs=8)
+    print("grasp", seed, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items() if not hasattr(v, "shape")})
+rep = pu.run_rate_driven_camera_parity(n_envs=8, seed=9)
+print("rate-driven cameras", {k: v for k, v in rep.items() if k != "debug"})
