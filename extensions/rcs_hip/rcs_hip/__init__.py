@@ -2,7 +2,7 @@
 
 Laid out like the reference's hardware extensions (reference extensions/rcs_fr3: a Python package around a compiled pybind11
 ``_core``).  ``rcs_hip._core.sim`` exposes ``Sim`` / ``SimConfig`` / ``SimRobot`` / ``SimRobotConfig`` / ``SimRobotState`` /
-``SimGripper`` / ``SimGripperConfig`` / ``SimGripperState`` with the reference's method names (python/rcs/_core/sim.pyi) and a
+``SimGripper`` / ``SimGripperConfig`` / ``SimGripperState`` / ``SimCameraSet`` / ``SimCameraConfig`` / ``FrameSet`` / ``CameraType`` with the reference's method names (python/rcs/_core/sim.pyi) and a
 leading environment axis on every array.  Build: ``python __graft_entry__.py`` (g++ + pybind11, links ``librcs_hip.so``).
 """
 
@@ -36,4 +36,22 @@ def free_box_tables(cm, resolve_robot_contacts: bool = True) -> dict | None:
     d["floor_friction"] = np.asarray(fb.get("floor_friction", (1.0, 0.005, 0.0001)), dtype=np.float64)
     d.update(mass=float(fb["mass"]), plane_z=float(fb["plane_z"]), impratio=float(cm.impratio), noslip_tolerance=1e-6,
              noslip_iterations=int(cm.noslip_iterations), cone_elliptic=int(cm.cone == "elliptic"), resolve_robot_contacts=int(resolve_robot_contacts))
+    return d
+
+
+def render_tables(cm, scene_dir: str) -> dict:
+    """The argument of ``Sim.set_render_scene``: the shapes the ray-caster draws, their colours and lights, and the pose of every
+    camera a ``SimCameraConfig`` can name -- the scene's MJCF cameras by name, ``""`` for ``CameraType.default_free`` and
+    ``"<free>"`` for ``CameraType.free`` (``rcs_amd.render``)."""
+    from rcs_amd import render
+
+    rs = render.build_render_scene(cm, scene_dir)
+    d = {k: np.ascontiguousarray(getattr(rs, k)) for k in ("shape", "link", "pos", "rot", "size", "plane_adr", "plane_num", "sphere", "planes", "colour",
+                                                           "headlight_ambient", "headlight_diffuse", "light_dir", "light_diffuse", "sky_rgb1", "sky_rgb2")}
+    d.update(nshape=len(rs.shape), nplanes=len(rs.planes), znear=float(rs.znear), zfar=float(rs.zfar))
+    cams = {name: render.camera_in_link(cm, name) for name in cm.cam_names}
+    cams["<free>"] = render.free_camera(cm)
+    if cm.stat_extent is not None and cm.stat_center is not None:
+        cams[""] = render.default_free_camera(cm)
+    d["cameras"] = {k: (int(v[0]), np.asarray(v[1], dtype=np.float64), np.asarray(v[2], dtype=np.float64), float(v[3])) for k, v in cams.items()}
     return d

@@ -19,6 +19,8 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <algorithm>
+#include <cmath>
 #include <map>
 #include <memory>
 #include <optional>
@@ -61,9 +63,17 @@ struct SimConfig {  // reference src/sim/sim.h:29-34
   int frequency = 30, max_convergence_steps = 500;
 };
 
+struct SimCameraSet;
+struct CamPose { int link; double pos[3], rot[9], fovy; };
 struct Sim {
   rcsh_sim* h = nullptr;
   int n = 0;
+  // cameras (set_render_scene): poses of the MJCF cameras by name, plus "" = the default free camera and "<free>" = an
+  // untouched mjvCamera; the camera sets that render from inside the stepping (render_on_demand = false)
+  std::map<std::string, CamPose> cam_poses;
+  double znear = 0, zfar = 0, timestep = 0.002;
+  std::vector<SimCameraSet*> rate_sets;
+  void collect_frames();
   std::map<std::string, std::vector<std::string>> names;  // mj_name2id tables: "joint", "actuator", "body", "site", "geom"
   std::vector<py::array> keep;
 
@@ -73,6 +83,7 @@ struct Sim {
     d.nbody = geti("nbody"); d.njnt = geti("njnt"); d.nu = geti("nu"); d.ntendon = geti("ntendon"); d.nwrap = geti("nwrap");
     d.neq = geti("neq"); d.nsite = geti("nsite"); d.ngeom = geti("ngeom"); d.nmeshvert = geti("nmeshvert");
     d.timestep = model["timestep"].cast<double>();
+    timestep = d.timestep;
     {
       darr g = model["gravity"].cast<darr>();
       for (int k = 0; k < 3; ++k) d.gravity[k] = g.data()[k];
@@ -277,6 +288,139 @@ struct SimGripper {
   }
 };
 
+// ---- cameras: reference src/sim/camera.h / camera.cpp, bound at src/pybind/rcs.cpp:560-597
+enum class CameraType : int { free = 0, tracking = 1, fixed = 2, default_free = 3 };
+struct SimCameraConfig {  // camera.h:26-34 (common::BaseCameraConfig + type)
+  std::string identifier;
+  int frame_rate = 0, resolution_width = 256, resolution_height = 256;
+  CameraType type = CameraType::fixed;
+};
+// FrameSet (camera.h:36-40) of the batch: per camera [N, 3 W H] uint8 / [N, W H] float32 as mjr_readPixels returns them (rows
+// bottom-up), one timestamp per environment
+struct FrameSet {
+  std::map<std::string, py::array_t<uint8_t>> color_frames;
+  std::map<std::string, py::array_t<float>> depth_frames;
+  darr timestamp;
+  std::map<std::string, barr> rendered;  // rate-driven sets: which environments' frames of that camera belong to this set
+};
+struct SimCameraSet {
+  std::shared_ptr<Sim> sim;
+  std::map<std::string, SimCameraConfig> cfg;
+  std::map<std::string, int32_t> ids;
+  bool on_demand;
+  std::vector<FrameSet> buffer;
+  std::vector<double> last_ts;
+  bool have_last = false;
+  size_t max_framesets = 64;
+  SimCameraSet(std::shared_ptr<Sim> s, std::map<std::string, SimCameraConfig> cams, bool render_on_demand)
+      : sim(std::move(s)), cfg(std::move(cams)), on_demand(render_on_demand) {
+    if (sim->cam_poses.empty()) throw std::runtime_error("no render scene: call Sim.set_render_scene(rcs_hip.render_tables(model)) first");
+    std::vector<int32_t> rated;
+    std::vector<double> periods;
+    for (auto& [name, c] : cfg) {
+      std::string key = c.identifier;
+      if (c.type == CameraType::default_free) key = "";
+      else if (c.type == CameraType::free) key = "<free>";
+      else if (c.type == CameraType::tracking) throw std::runtime_error("track body id is outside valid range");  // camera.cpp:44-46 never sets one
+      auto it = sim->cam_poses.find(key);
+      if (it == sim->cam_poses.end()) throw std::runtime_error("No camera named " + c.identifier);
+      rcsh_camera_desc d{};
+      d.link = it->second.link; d.width = c.resolution_width; d.height = c.resolution_height; d.fovy_deg = it->second.fovy;
+      for (int k = 0; k < 3; ++k) d.pos[k] = it->second.pos[k];
+      for (int k = 0; k < 9; ++k) d.rot[k] = it->second.rot[k];
+      int32_t id = -1;
+      check(rcsh_sim_add_camera(sim->h, &d, &id));
+      ids[name] = id;
+      if (c.frame_rate != 0) { rated.push_back(id); periods.push_back(1.0 / c.frame_rate); }
+    }
+    if (!on_demand && !rated.empty()) {
+      SimConfig sc; int32_t a, r, f, k;
+      check(rcsh_sim_get_config(sim->h, &a, &r, &f, &k));
+      double cap = 2;
+      for (double pd : periods) cap += std::ceil((k > 0 ? k : 2000) * sim->timestep / pd);
+      check(rcsh_sim_set_render_schedule(sim->h, rated.data(), periods.data(), (int)rated.size(), (int)std::min(256.0, cap)));
+      sim->rate_sets.push_back(this);
+    }
+  }
+  ~SimCameraSet() {
+    auto& v = sim->rate_sets;
+    v.erase(std::remove(v.begin(), v.end(), this), v.end());
+  }
+  int buffer_size() const { return (int)buffer.size(); }
+  void clear_buffer() { buffer.clear(); have_last = false; }
+  void push(FrameSet&& fs) {
+    buffer.push_back(std::move(fs));
+    if (buffer.size() > max_framesets) buffer.erase(buffer.begin());
+  }
+  void render_all() {  // camera.cpp:86-140
+    darr ts(sim->n);
+    check(rcsh_sim_get_time(sim->h, ts.mutable_data()));
+    bool same = have_last;
+    for (int e = 0; e < sim->n && same; ++e) same = ts.data()[e] == last_ts[e];
+    if (!same) {
+      FrameSet fs;
+      fs.timestamp = ts;
+      push(std::move(fs));
+      last_ts.assign(ts.data(), ts.data() + sim->n);
+      have_last = true;
+    }
+    FrameSet& fs = buffer.back();
+    for (auto& [name, c] : cfg) {
+      const py::ssize_t px = (py::ssize_t)c.resolution_width * c.resolution_height;
+      py::array_t<uint8_t> rgb({(py::ssize_t)sim->n, 3 * px});
+      py::array_t<float> depth({(py::ssize_t)sim->n, px});
+      check(rcsh_camera_render_rgb(sim->h, ids[name], rgb.mutable_data(), depth.mutable_data(), nullptr, nullptr));
+      fs.color_frames[name] = rgb;
+      fs.depth_frames[name] = depth;
+    }
+  }
+  void collect() {  // the frames that became due inside the launch that just ran
+    std::vector<int32_t> count(sim->n);
+    check(rcsh_render_pending(sim->h, count.data()));
+    int slots = 0;
+    for (int c : count) slots = std::max(slots, c);
+    for (int slot = 0; slot < slots; ++slot) {
+      FrameSet fs;
+      fs.timestamp = darr(sim->n);
+      for (int e = 0; e < sim->n; ++e) fs.timestamp.mutable_data()[e] = std::nan("");
+      for (auto& [name, c] : cfg) {
+        if (c.frame_rate == 0) continue;
+        const py::ssize_t px = (py::ssize_t)c.resolution_width * c.resolution_height;
+        py::array_t<uint8_t> rgb({(py::ssize_t)sim->n, 3 * px});
+        py::array_t<float> depth({(py::ssize_t)sim->n, px});
+        darr ts(sim->n);
+        barr due(sim->n);
+        check(rcsh_camera_render_snapshot(sim->h, ids[name], slot, rgb.mutable_data(), depth.mutable_data(), nullptr, nullptr, ts.mutable_data(),
+                                          due.mutable_data()));
+        bool any = false;
+        for (int e = 0; e < sim->n; ++e)
+          if (due.data()[e]) { fs.timestamp.mutable_data()[e] = ts.data()[e]; any = true; }
+        if (!any) continue;
+        fs.color_frames[name] = rgb;
+        fs.depth_frames[name] = depth;
+        fs.rendered[name] = due;
+      }
+      if (!fs.color_frames.empty()) push(std::move(fs));
+    }
+  }
+  std::optional<FrameSet> get_latest_frameset() {  // camera.cpp:64-73
+    if (on_demand) render_all();
+    if (buffer.empty()) return std::nullopt;
+    return buffer.back();
+  }
+  std::optional<FrameSet> get_timestamp_frameset(const darr& ts) {  // camera.cpp:74-83, one timestamp per environment
+    for (auto it = buffer.rbegin(); it != buffer.rend(); ++it) {
+      bool eq = ts.size() == it->timestamp.size();
+      for (py::ssize_t e = 0; e < ts.size() && eq; ++e) eq = ts.data()[e] == it->timestamp.data()[e];
+      if (eq) return *it;
+    }
+    return std::nullopt;
+  }
+};
+void Sim::collect_frames() {
+  for (auto* cs : rate_sets) cs->collect();
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_core, m) {
@@ -297,13 +441,45 @@ PYBIND11_MODULE(_core, m) {
       .def(py::init<const py::dict&, int, int, const py::object&>(), py::arg("model"), py::arg("n_envs") = 1, py::arg("device") = 0,
            py::arg("free_box") = py::none())
       // GIL policy of the reference: released for step_until_convergence (rcs.cpp:498-499), held for step (rcs.cpp:503)
-      .def("step_until_convergence", [](Sim& s) { check(rcsh_sim_step_until_convergence(s.h)); }, py::call_guard<py::gil_scoped_release>())
+      .def("step_until_convergence", [](Sim& s) {
+        { py::gil_scoped_release nogil; check(rcsh_sim_step_until_convergence(s.h)); }
+        s.collect_frames(); })
       .def("is_converged", [](Sim& s) { barr c(s.n); check(rcsh_sim_is_converged(s.h, c.mutable_data(), nullptr)); return to_bool(c); })
       .def("convergence_steps", [](Sim& s) { barr c(s.n); iarr k(s.n); check(rcsh_sim_is_converged(s.h, c.mutable_data(), k.mutable_data())); return k; })
       .def("set_config", [](Sim& s, const SimConfig& c) { check(rcsh_sim_set_config(s.h, c.async_control, c.realtime, c.frequency, c.max_convergence_steps)); return true; },
            py::arg("cfg"))
       .def("get_config", [](Sim& s) { SimConfig c; int32_t a, r, f, k; check(rcsh_sim_get_config(s.h, &a, &r, &f, &k)); c.async_control = a; c.realtime = r; c.frequency = f; c.max_convergence_steps = k; return c; })
-      .def("step", [](Sim& s, size_t k) { check(rcsh_sim_step(s.h, (int64_t)k)); }, py::arg("k"))
+      .def("step", [](Sim& s, size_t k) { check(rcsh_sim_step(s.h, (int64_t)k)); s.collect_frames(); }, py::arg("k"))
+      // cameras: the drawn shapes, their colours and the camera poses (rcs_hip.render_tables(model, scene_dir)); before SimCameraSet
+      .def("set_render_scene", [](Sim& s, const py::dict& r) {
+        rcsh_render_scene_desc d{};
+        std::vector<py::array> hold;
+        auto f64 = [&](const char* k) { darr a = r[k].cast<darr>(); hold.push_back(a); return a.data(); };
+        auto i32 = [&](const char* k) { iarr a = r[k].cast<iarr>(); hold.push_back(a); return a.data(); };
+        d.nshape = r["nshape"].cast<int>(); d.nplanes = r["nplanes"].cast<int>();
+        d.shape = i32("shape"); d.link = i32("link"); d.pos = f64("pos"); d.rot = f64("rot"); d.size = f64("size");
+        d.plane_adr = i32("plane_adr"); d.plane_num = i32("plane_num"); d.sphere = f64("sphere"); d.planes = f64("planes");
+        d.znear = r["znear"].cast<double>(); d.zfar = r["zfar"].cast<double>();
+        check(rcsh_sim_set_render_scene(s.h, &d));
+        rcsh_render_colours c{};
+        c.colour = f64("colour");
+        auto v3 = [&](const char* k, double* dst) { darr a = r[k].cast<darr>(); for (int i = 0; i < 3; ++i) dst[i] = a.data()[i]; };
+        v3("headlight_ambient", c.headlight_ambient); v3("headlight_diffuse", c.headlight_diffuse); v3("light_dir", c.light_dir);
+        v3("light_diffuse", c.light_diffuse); v3("sky_rgb1", c.sky_rgb1); v3("sky_rgb2", c.sky_rgb2);
+        check(rcsh_sim_set_render_colours(s.h, &c));
+        s.znear = d.znear; s.zfar = d.zfar;
+        s.cam_poses.clear();
+        for (auto item : r["cameras"].cast<py::dict>()) {
+          const py::tuple t = item.second.cast<py::tuple>();
+          CamPose cp{};
+          cp.link = t[0].cast<int>();
+          darr pos = t[1].cast<darr>(), rot = t[2].cast<darr>();
+          for (int i = 0; i < 3; ++i) cp.pos[i] = pos.data()[i];
+          for (int i = 0; i < 9; ++i) cp.rot[i] = rot.data()[i];
+          cp.fovy = t[3].cast<double>();
+          s.cam_poses[item.first.cast<std::string>()] = cp;
+        } }, py::arg("render"))
+      .def_property_readonly("time", [](Sim& s) { darr t(s.n); check(rcsh_sim_get_time(s.h, t.mutable_data())); return t; })
       .def("reset", [](Sim& s, const mask_t& mask) { Mask mk(mask, s.n); check(rcsh_sim_reset(s.h, mk.p)); }, py::arg("mask") = py::none())
       .def("_start_gui_server", [](Sim&, const std::string&) { throw std::runtime_error("the batched backend has no GUI server"); }, py::arg("id"))
       .def("_stop_gui_server", [](Sim&) {})
@@ -462,4 +638,30 @@ PYBIND11_MODULE(_core, m) {
     { py::gil_scoped_release nogil;
       check(rcsh_env_step(s.h, action.data(), gripper ? gripper->data() : nullptr, obs.mutable_data(), info.mutable_data(), gw.mutable_data(), sub.mutable_data())); }
     return py::make_tuple(obs, info, gw, sub); }, py::arg("sim"), py::arg("action"), py::arg("gripper") = py::none());
+  py::enum_<CameraType>(sim, "CameraType")  // rcs.cpp:560-566
+      .value("free", CameraType::free).value("tracking", CameraType::tracking).value("fixed", CameraType::fixed)
+      .value("default_free", CameraType::default_free).export_values();
+  py::class_<SimCameraConfig>(sim, "SimCameraConfig")  // rcs.cpp:567-574
+      .def(py::init([](const std::string& identifier, int frame_rate, int w, int h, CameraType type) {
+             SimCameraConfig c; c.identifier = identifier; c.frame_rate = frame_rate; c.resolution_width = w; c.resolution_height = h; c.type = type; return c; }),
+           py::arg("identifier"), py::arg("frame_rate"), py::arg("resolution_width"), py::arg("resolution_height"), py::arg("type") = CameraType::fixed)
+      .def_readwrite("identifier", &SimCameraConfig::identifier)
+      .def_readwrite("frame_rate", &SimCameraConfig::frame_rate)
+      .def_readwrite("resolution_width", &SimCameraConfig::resolution_width)
+      .def_readwrite("resolution_height", &SimCameraConfig::resolution_height)
+      .def_readwrite("type", &SimCameraConfig::type);
+  py::class_<FrameSet>(sim, "FrameSet")  // rcs.cpp:575-580
+      .def(py::init<>())
+      .def_readonly("color_frames", &FrameSet::color_frames)
+      .def_readonly("depth_frames", &FrameSet::depth_frames)
+      .def_readonly("timestamp", &FrameSet::timestamp)
+      .def_readonly("rendered", &FrameSet::rendered);
+  py::class_<SimCameraSet, std::shared_ptr<SimCameraSet>>(sim, "SimCameraSet")  // rcs.cpp:586-597
+      .def(py::init<std::shared_ptr<Sim>, std::map<std::string, SimCameraConfig>, bool>(), py::arg("sim"), py::arg("cameras"),
+           py::arg("render_on_demand") = true)
+      .def("buffer_size", &SimCameraSet::buffer_size)
+      .def("clear_buffer", &SimCameraSet::clear_buffer)
+      .def("get_latest_frameset", &SimCameraSet::get_latest_frameset)
+      .def("get_timestamp_frameset", &SimCameraSet::get_timestamp_frameset, py::arg("ts"))
+      .def_property_readonly("_sim", [](SimCameraSet& c) { return c.sim; });
 }

@@ -994,3 +994,83 @@ def test_cube_against_the_robot_base(kernel):
     assert rep["base_contact_envs"] >= 6 and rep["max_abs_robot_qpos"] < TOL, rep
     assert (rep["env_pos_err"] < 1e-7).sum() >= 9 and rep["max_abs_pos"] < 0.02, rep
     assert (rep["final_radius"] > 0.08).all(), rep  # nowhere did the cube pass through the base
+
+
+def test_pybind_camera_set_equals_ctypes_host_layer(kernel):
+    """The compiled module's SimCameraSet (rcs_hip._core.sim: the reference's class and method names) against the ctypes
+    host's: the same rgb / depth buffers bit for bit on demand, the same frame-set rule (one set per simulation time), and
+    -- render_on_demand=False -- the same frames with the same timestamps from inside Sim.step."""
+    import os
+    import sys
+
+    import parity_util as pu
+
+    sys.path.insert(0, os.path.join(pu.ROOT, "extensions", "rcs_hip"))
+    import rcs_hip
+    from rcs_hip import _core
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    from rcs_env_oracle import FR3_Q_HOME
+
+    n, W, H = 3, 32, 24
+    cfg = default_sim_robot_cfg("fr3_simple_pick_up")
+    cm = compile_mjcf(cfg.mjcf_scene_path)
+    tgt = np.tile(np.array([0.1, -0.6, 0.1, -2.2, 0.1, 1.7, 0.9]), (n, 1)) + 0.05 * np.arange(n)[:, None]
+
+    def host(on_demand):
+        simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+        robot = S.SimRobot(simu, None, cfg)
+        cams = {"w": SimCameraConfig(identifier="wrist_0", frame_rate=30, resolution_width=W, resolution_height=H),
+                "b": SimCameraConfig(identifier="bird_eye_cam", frame_rate=10, resolution_width=W, resolution_height=H)}
+        cs = SimCameraSet(simu, cams, physical_units=True, render_on_demand=on_demand, max_framesets=100)
+        robot.set_joint_position(tgt)
+        simu.step(40)
+        if on_demand:
+            raw = {k: cs.render_raw_rgbd(k) for k in cams}
+            out = {k: (raw[k][0].reshape(n, -1), raw[k][1].reshape(n, -1)) for k in cams}, simu.time
+        else:
+            out = [(ev["timestamp"], {k: (ev["color"][k].reshape(n, -1), ev["depth"][k].reshape(n, -1), ev["have"][k]) for k in ev["have"]}) for ev in cs._buffer], None
+        simu.close()
+        return out
+
+    def bound(on_demand):
+        simu = _core.sim.Sim(rcs_hip.model_tables(cm), n, 0, rcs_hip.free_box_tables(cm))
+        simu.set_render_scene(rcs_hip.render_tables(cm, os.path.dirname(cfg.mjcf_scene_path)))
+        rc = _core.sim.SimRobotConfig()
+        rc.add_id("0")
+        rc.q_home = np.asarray(FR3_Q_HOME)
+        robot = _core.sim.SimRobot(simu, None, rc)
+        cams = {"w": _core.sim.SimCameraConfig("wrist_0", 30, W, H), "b": _core.sim.SimCameraConfig("bird_eye_cam", 10, W, H)}
+        cs = _core.sim.SimCameraSet(simu, cams, render_on_demand=on_demand)
+        robot.set_joint_position(tgt)
+        simu.step(40)
+        return simu, cs
+
+    (want, t_want) = host(True)
+    simu, cs = bound(True)
+    assert cs.buffer_size() == 0
+    fs = cs.get_latest_frameset()
+    fs2 = cs.get_latest_frameset()
+    assert cs.buffer_size() == 1 and np.array_equal(fs.timestamp, t_want) and np.array_equal(fs2.timestamp, t_want)
+    for k in ("w", "b"):
+        assert np.array_equal(fs.color_frames[k], want[k][0]) and np.array_equal(fs.depth_frames[k], want[k][1])
+    assert cs.get_timestamp_frameset(fs.timestamp) is not None and cs.get_timestamp_frameset(fs.timestamp + 1) is None
+    cs.clear_buffer()
+    assert cs.buffer_size() == 0 and cs._sim is simu
+    del cs, simu
+
+    events, _ = host(False)
+    simu, cs = bound(False)
+    assert cs.buffer_size() == len(events) >= 3
+    for i, (ts, cams) in enumerate(events):
+        fs = cs.get_timestamp_frameset(ts) if not np.isnan(ts).any() else None
+        assert fs is not None and sorted(fs.color_frames) == sorted(cams)
+        for k, (rgb, depth, have) in cams.items():
+            assert np.array_equal(fs.rendered[k].astype(bool), have)
+            assert np.array_equal(fs.color_frames[k][have], rgb[have]) and np.array_equal(fs.depth_frames[k][have], depth[have])
+    with pytest.raises(RuntimeError, match="No camera named"):
+        _core.sim.SimCameraSet(simu, {"x": _core.sim.SimCameraConfig("nope", 0, 8, 8)})
+    with pytest.raises(RuntimeError, match="track body id"):
+        _core.sim.SimCameraSet(simu, {"x": _core.sim.SimCameraConfig("wrist_0", 0, 8, 8, _core.sim.CameraType.tracking)})

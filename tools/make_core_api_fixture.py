@@ -9,8 +9,9 @@ import os
 
 REF = "/root/reference/python/rcs/_core"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "core_sim_api.json")
-WANT = {"sim.pyi": ["Sim", "SimConfig", "SimRobot", "SimRobotConfig", "SimRobotState", "SimGripper", "SimGripperConfig", "SimGripperState"],
-        "common.pyi": ["Robot", "Gripper"]}
+WANT = {"sim.pyi": ["Sim", "SimConfig", "SimRobot", "SimRobotConfig", "SimRobotState", "SimGripper", "SimGripperConfig", "SimGripperState",
+                    "SimCameraSet", "SimCameraConfig", "FrameSet", "CameraType"],
+        "common.pyi": ["Robot", "Gripper", "BaseCameraConfig"]}
 
 
 def main():
