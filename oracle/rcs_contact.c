@@ -314,7 +314,7 @@ static int mpr_penetration(const shape* A, const shape* B, double* depth, double
   double l = norm3(p0.v);
   for (int k = 0; k < 3; k++) dir[k] = -p0.v[k] / l;
   mpr_support(A, B, dir, &p1);
-  if (dot3(p1.v, dir) <= 0) return 0;
+  if (dot3(p1.v, dir) <= 0) { copy3(dir_out, dir); return 0; }
   cross3(p0.v, p1.v, dir);
   l = norm3(dir);
   if (l < 1e-12) {
@@ -326,7 +326,7 @@ static int mpr_penetration(const shape* A, const shape* B, double* depth, double
   }
   for (int k = 0; k < 3; k++) dir[k] /= l;
   mpr_support(A, B, dir, &p2);
-  if (dot3(p2.v, dir) <= 0) return 0;
+  if (dot3(p2.v, dir) <= 0) { copy3(dir_out, dir); return 0; }
   sub3(p1.v, p0.v, va);
   sub3(p2.v, p0.v, vb);
   cross3(va, vb, dir);
@@ -337,9 +337,9 @@ static int mpr_penetration(const shape* A, const shape* B, double* depth, double
     for (int k = 0; k < 3; k++) dir[k] = -dir[k];
   }
   for (int guard = 0;; guard++) {
-    if (guard > 100) return 0;
+    if (guard > 100) { dir_out[0] = dir_out[1] = dir_out[2] = 0; return 0; }
     mpr_support(A, B, dir, &p3);
-    if (dot3(p3.v, dir) <= 0) return 0;
+    if (dot3(p3.v, dir) <= 0) { copy3(dir_out, dir); return 0; }
     int cont = 0;
     cross3(p1.v, p3.v, va);
     if (dot3(va, p0.v) < -MINVAL) { p2 = p3; cont = 1; }
@@ -361,7 +361,7 @@ static int mpr_penetration(const shape* A, const shape* B, double* depth, double
     mpr_support(A, B, dir, &p4);
     double dv4 = dot3(p4.v, dir);
     double dmax = fmax(dot3(p1.v, dir), fmax(dot3(p2.v, dir), dot3(p3.v, dir)));
-    if (dv4 < 0 || dv4 - dmax <= MPR_TOL || it > MPR_ITER) return 0;
+    if (dv4 < 0 || dv4 - dmax <= MPR_TOL || it > MPR_ITER) { const double keep = dv4 < 0 ? 1.0 : 0.0; for (int k = 0; k < 3; k++) dir_out[k] = keep * dir[k]; return 0; }
     expand_portal(&p0, &p1, &p2, &p3, &p4);
   }
   /* penetration: refine the portal towards the surface of the difference */
@@ -421,8 +421,16 @@ int orc_mpr_hull_box(const double* verts, int nvert, const double* ph, const dou
 }
 
 /* ------------------------------------------------------------------ collision driver */
-
+static void geom_frame_compute(const orc_model* m, const orc_data* d, int g, double* R, double* p);
+/* world frames of the geoms of the position stage being collided (orc_collide fills them once; its helpers read them) */
+typedef struct { double R[ORC_MAXGEOM][9], p[ORC_MAXGEOM][3]; } geom_frames;
+static const geom_frames* g_frames = 0;
 static void geom_frame(const orc_model* m, const orc_data* d, int g, double* R, double* p) {
+  if (g_frames) { memcpy(R, g_frames->R[g], 9 * sizeof(double)); memcpy(p, g_frames->p[g], 3 * sizeof(double)); return; }
+  geom_frame_compute(m, d, g, R, p);
+}
+
+static void geom_frame_compute(const orc_model* m, const orc_data* d, int g, double* R, double* p) {
   int b = m->geom_bodyid[g];
   double q[4], v[3];
   quat_mul(d->xquat[b], m->geom_quat[g], q);
@@ -430,21 +438,7 @@ static void geom_frame(const orc_model* m, const orc_data* d, int g, double* R, 
   mat_vec(d->xmat[b], m->geom_pos[g], v);
   p[0] = v[0] + d->xpos[b][0]; p[1] = v[1] + d->xpos[b][1]; p[2] = v[2] + d->xpos[b][2];
 }
-static double geom_rbound(const orc_model* m, int g) {
-  const double* sz = m->geom_size[g];
-  if (m->geom_type[g] == 7) {
-    double rb = 0;
-    for (int v = 0; v < m->geom_vertnum[g]; v++) {
-      const double* w = m->mesh_vert + 3 * (m->geom_vertadr[g] + v);
-      double r2 = dot3(w, w);
-      if (r2 > rb) rb = r2;
-    }
-    return sqrt(rb);
-  }
-  if (m->geom_type[g] == 6) return sqrt(dot3(sz, sz));
-  if (m->geom_type[g] == 3) return sz[0] + sz[1];
-  return sz[0];
-}
+static double geom_rbound(const orc_model* m, int g) { return m->geom_rbound[g]; }
 /* contacts beyond the capacity are dropped in detection order; where contacts are resolved the capacity is the HIP
    backend's (contact_types.h: kMaxCon), so that an overflowing scene overflows alike on both sides */
 static int g_contact_cap = ORC_MAXCON;
@@ -478,7 +472,7 @@ static int shape_of(const orc_model* m, int g, const double* gp, const double* g
   S->verts = m->mesh_vert + 3 * m->geom_vertadr[g];
   S->nvert = m->geom_vertnum[g];
   copy3(S->center, gp);
-  if (t == 7) hull_center(S->verts, S->nvert, gp, gR, S->center);
+  if (t == 7) { mat_vec(gR, m->geom_center[g], S->center); for (int k = 0; k < 3; k++) S->center[k] += gp[k]; }
   return 1;
 }
 /* oriented bounding boxes (centre, axes = columns of R, half extents): 1 if one of the 15 candidate axes separates them
@@ -507,11 +501,23 @@ static int obb_disjoint(const double* Ra, const double* ca, const double* ha, co
   return 0;
 }
 int orc_dbg_mpr_calls = 0;
-int orc_dbg_sphere_pass = 0, orc_dbg_pairs = 0;
+int orc_dbg_sphere_pass = 0, orc_dbg_pairs = 0, orc_dbg_skip_self = 0;
 int orc_dbg_mpr_pairs[512];
 /* geom-geom pairs of the robot (every convex pair through mjc_Convex's MPR: only "do they overlap" is read from it) */
-static void self_collide(const orc_model* m, orc_data* d) {
-  d->nself = 0;
+/* The geom pairs MuJoCo's filters let collide are a property of the model: listed once per model (a process steps one
+   model, or a few in turn; the key is the model's address plus a checksum of what the filters read). */
+static const orc_model* g_pairs_model = 0;
+static long g_pairs_sum = 0;
+static int g_npairs = 0;
+static short g_pairs[ORC_MAXGEOM * ORC_MAXGEOM / 2][2];
+static long pair_checksum(const orc_model* m) {
+  long s = m->ngeom * 131 + m->nbody;
+  for (int g = 0; g < m->ngeom; g++) s = s * 31 + m->geom_bodyid[g] * 7 + m->geom_type[g] * 3 + m->geom_contype[g] + 2 * m->geom_conaffinity[g] + m->geom_vertnum[g];
+  for (int b = 0; b < m->nbody; b++) s = s * 17 + m->body_weldid[b] + 5 * m->body_parentid[b];
+  return s;
+}
+static void list_pairs(const orc_model* m) {
+  g_npairs = 0;
   for (int g1 = 0; g1 < m->ngeom; g1++) {
     if (m->geom_type[g1] == 0) continue;
     for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
@@ -522,28 +528,61 @@ static void self_collide(const orc_model* m, orc_data* d) {
       if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
       const int pw1 = m->body_weldid[m->body_parentid[w1]], pw2 = m->body_weldid[m->body_parentid[w2]];
       if (w1 && w2 && (w1 == pw2 || w2 == pw1)) continue;
-      double R1[9], p1[3], R2[9], p2[3], x[3], c1[3], c2[3];
-      geom_frame(m, d, g1, R1, p1);
-      geom_frame(m, d, g2, R2, p2);
-      const double *bb1 = m->geom_aabb[g1], *bb2 = m->geom_aabb[g2];
-      mat_vec(R1, bb1, c1);
-      mat_vec(R2, bb2, c2);
-      for (int k = 0; k < 3; k++) { c1[k] += p1[k]; c2[k] += p2[k]; }
-      sub3(c1, c2, x);
-      const double rs = norm3(bb1 + 3) + norm3(bb2 + 3);
+      g_pairs[g_npairs][0] = (short)g1; g_pairs[g_npairs][1] = (short)g2;
+      g_npairs++;
+    }
+  }
+  g_pairs_model = m;
+  g_pairs_sum = pair_checksum(m);
+}
+static void self_collide(const orc_model* m, orc_data* d) {
+  d->nself = 0;
+  if (orc_dbg_skip_self) return;
+  if (g_pairs_model != m || g_pairs_sum != pair_checksum(m)) list_pairs(m);
+  /* world frames and bounding-box centres of the geoms, once per position stage */
+  double R[ORC_MAXGEOM][9], p[ORC_MAXGEOM][3], c[ORC_MAXGEOM][3], rad[ORC_MAXGEOM];
+  for (int g = 0; g < m->ngeom; g++) {
+    if (m->geom_type[g] == 0) continue;
+    geom_frame(m, d, g, R[g], p[g]);
+    mat_vec(R[g], m->geom_aabb[g], c[g]);
+    for (int k = 0; k < 3; k++) c[g][k] += p[g][k];
+    rad[g] = norm3(m->geom_aabb[g] + 3);
+  }
+  for (int i = 0; i < g_npairs; i++) {
+    const int g1 = g_pairs[i][0], g2 = g_pairs[i][1];
+    {
+      double x[3];
+      sub3(c[g1], c[g2], x);
+      const double rs = rad[g1] + rad[g2];
       orc_dbg_pairs++;
       if (dot3(x, x) > rs * rs) continue;
       orc_dbg_sphere_pass++;
-      if (obb_disjoint(R1, c1, bb1 + 3, R2, c2, bb2 + 3)) continue;
+      if (obb_disjoint(R[g1], c[g1], m->geom_aabb[g1] + 3, R[g2], c[g2], m->geom_aabb[g2] + 3)) continue;
       /* MuJoCo orders a pair by geom type, then by id */
       const int swap = m->geom_type[g1] > m->geom_type[g2];
       const int ga = swap ? g2 : g1, gb = swap ? g1 : g2;
       shape A, B;
-      if (!shape_of(m, ga, swap ? p2 : p1, swap ? R2 : R1, &A) || !shape_of(m, gb, swap ? p1 : p2, swap ? R1 : R2, &B)) continue;
+      if (!shape_of(m, ga, p[ga], R[ga], &A) || !shape_of(m, gb, p[gb], R[gb], &B)) continue;
       double depth, dir[3], pos[3];
+      /* the remembered separating direction of this pair, if any: support of A - B along it still negative -> apart */
+      int slot = -1;
+      for (int k = 0; k < d->sep_n; k++) if (d->sep_pair[k][0] == ga && d->sep_pair[k][1] == gb) slot = k;
+      if (slot >= 0) {
+        double dw[3];
+        mpr_pt q;
+        mat_vec(R[ga], d->sep_dir[slot], dw);
+        mpr_support(&A, &B, dw, &q);
+        if (dot3(q.v, dw) < 0) continue;
+      }
       if (orc_dbg_mpr_calls < 256) { orc_dbg_mpr_pairs[2 * orc_dbg_mpr_calls] = ga; orc_dbg_mpr_pairs[2 * orc_dbg_mpr_calls + 1] = gb; }
       orc_dbg_mpr_calls++;
-      if (!mpr_penetration(&A, &B, &depth, dir, pos)) continue;
+      if (!mpr_penetration(&A, &B, &depth, dir, pos)) {
+        if (dot3(dir, dir) > 0.5) { /* a unit separating direction came back */
+          if (slot < 0) { slot = d->sep_n < ORC_MAXSEP ? d->sep_n++ : (ga + gb) % ORC_MAXSEP; d->sep_pair[slot][0] = ga; d->sep_pair[slot][1] = gb; }
+          matT_vec(R[ga], dir, d->sep_dir[slot]);
+        }
+        continue;
+      }
       if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->nself++; }
     }
   }
@@ -552,6 +591,9 @@ static void self_collide(const orc_model* m, orc_data* d) {
 void orc_collide(const orc_model* m, orc_data* d) {
   d->ncon = 0;
   d->coupled = 0;
+  geom_frames fr;
+  for (int g = 0; g < m->ngeom; g++) geom_frame_compute(m, d, g, fr.R[g], fr.p[g]);
+  g_frames = &fr;
   self_collide(m, d);
   g_contact_cap = m->resolve_contacts ? 48 : ORC_MAXCON;
   const int gbox = m->ngeom;
@@ -679,7 +721,7 @@ void orc_collide(const orc_model* m, orc_data* d) {
         shape S = {m->geom_type[g] == 7 ? SH_HULL : SH_CAPSULE, gp, gR, m->geom_size[g], m->mesh_vert + 3 * m->geom_vertadr[g],
                    m->geom_vertnum[g], {gp[0], gp[1], gp[2]}};
         shape Bx = {SH_BOX, bp, bR, bs, 0, 0, {bp[0], bp[1], bp[2]}};
-        if (S.type == SH_HULL) hull_center(S.verts, S.nvert, gp, gR, S.center);
+        if (S.type == SH_HULL) { mat_vec(gR, m->geom_center[g], S.center); for (int k = 0; k < 3; k++) S.center[k] += gp[k]; }
         double depth, dir[3], pos[3];
         if (m->geom_type[g] == 7) {
           /* MuJoCo orders a pair by geom type: box (6) before mesh (7) -> the free box is geom 1 */
@@ -692,6 +734,7 @@ void orc_collide(const orc_model* m, orc_data* d) {
     }
   }
   d->coupled = m->resolve_contacts && robot_contacts > 0;
+  g_frames = 0;
 }
 
 /* ------------------------------------------------------------------ rows of the coupled problem */

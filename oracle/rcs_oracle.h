@@ -45,6 +45,7 @@ enum { ORC_EFC_EQUALITY = 0, ORC_EFC_LIMIT = 1, ORC_EFC_FRICTION = 2, ORC_EFC_CO
 /* body / geom id of the free box in contact records (the box is kept outside the robot's body and geom tables) */
 #define ORC_BODY_BOX (-2)
 #define ORC_MAXSELF 256
+#define ORC_MAXSEP 8
 
 /* ---- one free rigid box on the floor plane (rcs_object.c) */
 typedef struct orc_box {
@@ -151,6 +152,8 @@ typedef struct orc_model {
   double dof_invweight0[ORC_MAXV];
   double body_invweight0[ORC_MAXBODY]; /* translational component (mjModel.body_invweight0[.][0]) */
   double geom_aabb[ORC_MAXGEOM][6];    /* bounding box in the geom frame: centre, half extents (mjModel.geom_aabb) */
+  double geom_rbound[ORC_MAXGEOM];     /* radius of the bounding sphere about the geom's origin (mjModel.geom_rbound) */
+  double geom_center[ORC_MAXGEOM][3];  /* mesh geoms: mean of the hull's vertices, geom frame (the interior point MPR starts from) */
   /* dry joint friction (mjModel dof_frictionloss, dof_solref, dof_solimp) */
   double dof_frictionloss[ORC_MAXV];
   double dof_solref[ORC_MAXV][2];
@@ -206,6 +209,11 @@ typedef struct orc_data {
      contact[]; they carry no constraint rows in this revision */
   int nself;
   int self_geom[ORC_MAXSELF][2];
+  /* warm start of the self-collision narrow phase (as a collision library keeps per-pair caches): the direction that
+     separated a pair last, in the frame of its first geom; one support query along it settles the pair while it still does */
+  int sep_n;
+  int sep_pair[ORC_MAXSEP][2];
+  double sep_dir[ORC_MAXSEP][3];
   orc_box_data box;
 } orc_data;
 

@@ -75,7 +75,7 @@ class OrcModel(C.Structure):
         ("geom_pos", D * 3 * MAXGEOM), ("geom_quat", D * 4 * MAXGEOM), ("geom_size", D * 3 * MAXGEOM),
         ("geom_friction", D * 3 * MAXGEOM),
         ("mesh_vert", C.POINTER(D)), ("body_weldid", I * MAXBODY), ("resolve_contacts", I),
-        ("dof_invweight0", D * MAXV), ("body_invweight0", D * MAXBODY), ("geom_aabb", D * 6 * MAXGEOM),
+        ("dof_invweight0", D * MAXV), ("body_invweight0", D * MAXBODY), ("geom_aabb", D * 6 * MAXGEOM), ("geom_rbound", D * MAXGEOM), ("geom_center", D * 3 * MAXGEOM),
         ("dof_frictionloss", D * MAXV), ("dof_solref", D * 2 * MAXV), ("dof_solimp", D * 5 * MAXV),
         ("box", OrcBox),
     ]
@@ -107,6 +107,7 @@ class OrcData(C.Structure):
         ("efc_R", D * MAXEFC), ("efc_mu", D * MAXEFC),
         ("qfrc_constraint", D * NVT), ("solver_niter", I), ("noslip_niter", I), ("contact_geom", I * 2 * MAXCON),
         ("contact", OrcContact * MAXCON), ("coupled", I), ("nself", I), ("self_geom", I * 2 * MAXSELF),
+        ("sep_n", I), ("sep_pair", I * 2 * 8), ("sep_dir", D * 3 * 8),
         ("box", OrcBoxData),
     ]
 

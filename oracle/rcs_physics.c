@@ -784,6 +784,26 @@ void orc_set0(orc_model* m) {
     } else if (m->geom_type[g] == 6) { bb[3] = sz[0]; bb[4] = sz[1]; bb[5] = sz[2]; }
     else if (m->geom_type[g] == 3) { bb[3] = bb[4] = sz[0]; bb[5] = sz[0] + sz[1]; }
     else if (m->geom_type[g] == 2) { bb[3] = bb[4] = bb[5] = sz[0]; }
+    /* geom_rbound: about the geom's own origin (mesh: farthest vertex) */
+    double rb = sz[0];
+    if (m->geom_type[g] == 7) {
+      rb = 0;
+      for (int v = 0; v < m->geom_vertnum[g]; v++) {
+        const double* w = m->mesh_vert + 3 * (m->geom_vertadr[g] + v);
+        const double r2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+        if (r2 > rb) rb = r2;
+      }
+      rb = sqrt(rb);
+    } else if (m->geom_type[g] == 6) rb = sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+    else if (m->geom_type[g] == 3) rb = sz[0] + sz[1];
+    m->geom_rbound[g] = rb;
+    m->geom_center[g][0] = m->geom_center[g][1] = m->geom_center[g][2] = 0;
+    if (m->geom_type[g] == 7 && m->geom_vertnum[g] > 0) {
+      double c[3] = {0, 0, 0};
+      for (int v = 0; v < m->geom_vertnum[g]; v++)
+        for (int k = 0; k < 3; k++) c[k] += m->mesh_vert[3 * (m->geom_vertadr[g] + v) + k];
+      for (int k = 0; k < 3; k++) m->geom_center[g][k] = c[k] / m->geom_vertnum[g];
+    }
   }
   /* body_invweight0 (translational): mean diagonal of J M^-1 J' for the body's centre-of-mass Jacobian at qpos0 */
   for (int b = 0; b < m->nbody; b++) {
