@@ -388,7 +388,8 @@ def main() -> None:
         headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
         if os.path.exists(tpath) and headline:  # the PMC passes profiled exactly this workload (profiles/run_profile.sh)
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
-            traffic = (tj["fetch_size_kb_per_dispatch"] + tj["write_size_kb_per_dispatch"]) * 1024
+            # (counter units are KiB; corrected as calibrated on this access pattern: profiles/r2_hbm_calib, tools/hbm_calib.hip)
+            traffic = (tj["fetch_size_kb_per_dispatch"] * tj.get("fetch_correction", 1.0) + tj["write_size_kb_per_dispatch"] * tj.get("write_correction", 1.0)) * 1024
         out = {
             "metric": "env-steps/sec (whole node), " + (
                 "fr3_simple_pick_up task (CARTESIAN_TRPY)" if args.task != "none" else
@@ -430,7 +431,7 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "rocprofv3 FETCH_SIZE + WRITE_SIZE, separate PMC passes (profiles/r2_traffic.json)" if traffic else None,
+                "traffic_source": "rocprofv3 FETCH_SIZE x 2 (gfx950: counts half the bytes of this access pattern, calibrated in profiles/r2_hbm_calib) + WRITE_SIZE, separate PMC passes (profiles/r2_traffic.json)" if traffic else None,
                 "kernel": "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
                           + (" + free box" if args.task != "none" or args.robot == "xarm7_box" else ""),
                 "kernel_ms_avg": kernel_ms,
