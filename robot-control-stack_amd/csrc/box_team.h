@@ -355,9 +355,11 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
     if (b.noslip_iterations > 0) {
       // ---- mj_solNoSlip on the friction rows.  The lane's rows of A = J M^-1 J' (no regulariser) and of
       // b = J qacc_smooth - aref; all 12 forces on every lane.
+      // (only the two friction rows are updated, the normal forces stay: row 0 of A and the normal forces' part of the
+      // residual are constants of the pass)
       double A[3][12], bb[3], force[12];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 1; k < 3; ++k) {
         double jm[6], s = 0;
 #pragma unroll
         for (int j = 0; j < 6; ++j) { jm[j] = c.J[k][j] * Mi[j]; s += c.J[k][j] * xs[j]; }
@@ -376,6 +378,8 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
         force[k] = quad_bcast<0>(f[k]); force[3 + k] = quad_bcast<1>(f[k]);
         force[6 + k] = quad_bcast<2>(f[k]); force[9 + k] = quad_bcast<3>(f[k]);
       }
+#pragma unroll
+      for (int k = 1; k < 3; ++k) bb[k] += A[k][0] * force[0] + A[k][3] * force[3] + A[k][6] * force[6] + A[k][9] * force[9];
       int iter = 0;
       while (iter < b.noslip_iterations) {
         double improvement = 0;
@@ -385,13 +389,13 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
           constexpr int C = decltype(slot_c)::value;
           if (C >= ncon) return;
           // the owner of contact C (lane C of every quad) runs the update on its rows; the others wait
-          double res[3], old[3], nf[3] = {0, 0, 0}, change = 0;
+          double res[3] = {0, 0, 0}, old[3], nf[3] = {0, 0, 0}, change = 0;
           if ((t & 3) == C) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
+          for (int k = 1; k < 3; ++k) {
             double s = bb[k];
 #pragma unroll
-            for (int j = 0; j < 12; ++j) s += A[k][j] * force[j];
+            for (int j = 0; j < 4; ++j) s += A[k][3 * j + 1] * force[3 * j + 1] + A[k][3 * j + 2] * force[3 * j + 2];
             res[k] = s;
           }
           old[0] = nf[0] = force[3 * C]; old[1] = force[3 * C + 1]; old[2] = force[3 * C + 2];
@@ -409,11 +413,11 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
             nf[1] = vv[0]; nf[2] = vv[1];
           }
           // costChange(): a step that raises the dual cost is undone
-          const double dl[3] = {nf[0] - old[0], nf[1] - old[1], nf[2] - old[2]};
+          const double dl[3] = {0.0, nf[1] - old[1], nf[2] - old[2]};  // (the normal force is not touched)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
+          for (int k = 1; k < 3; ++k) {
 #pragma unroll
-            for (int l = 0; l < 3; ++l) change += 0.5 * dl[k] * A[k][3 * C + l] * dl[l];
+            for (int l = 1; l < 3; ++l) change += 0.5 * dl[k] * A[k][3 * C + l] * dl[l];
             change += dl[k] * res[k];
           }
           if (change > 1e-10) { nf[0] = old[0]; nf[1] = old[1]; nf[2] = old[2]; change = 0; }
