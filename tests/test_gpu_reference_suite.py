@@ -78,6 +78,9 @@ class TestSimEnvsTRPY(SimEnvsBase):
         env.reset()
         obs, info = env.reset()  # double reset: "a lot can go wrong when resetting"
         assert info["camera_available"] and set(obs["frames"]) == {"wrist", "default_free"}
+        for cam in obs["frames"].values():  # CameraSetWrapper(include_depth=True): rgb always, depth next to it (base.py:585-674)
+            assert cam["rgb"]["data"].shape[1:] == (32, 32, 3) and cam["rgb"]["data"].dtype == np.uint8
+            assert cam["depth"]["data"].shape[1:] == (32, 32, 1) and cam["depth"]["data"].dtype == np.uint16
 
     def test_zero_action_trpy(self, cfg, kernel):
         from rcs_amd.envs import ControlMode
