@@ -384,10 +384,12 @@ def main() -> None:
         achieved_gbs = algo_bytes / (kernel_ms * 1e-3) / 1e9
         substeps_per_launch = mean_sub * env.n_envs
         traffic = None
+        tj_extra = {}
         tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
         headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
         if os.path.exists(tpath) and headline:  # the PMC passes profiled exactly this workload (profiles/run_profile.sh)
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
+            tj_extra = tj
             # (counter units are KiB; corrected as calibrated on this access pattern: profiles/r2_hbm_calib, tools/hbm_calib.hip)
             traffic = (tj["fetch_size_kb_per_dispatch"] * tj.get("fetch_correction", 1.0) + tj["write_size_kb_per_dispatch"] * tj.get("write_correction", 1.0)) * 1024
         out = {
@@ -439,6 +441,8 @@ def main() -> None:
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "fp64_algorithmic_tflops": substeps_per_launch * ALGO_FLOP_PER_SUBSTEP / (kernel_ms * 1e-3) / 1e12,
                 "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                "valu_busy_frac": tj_extra.get("valu_busy_frac"),
+                "wait_any_frac": tj_extra.get("wait_any_frac"),
                 "note": "path is FP64 VALU-issue bound, not HBM bound (SURVEY F7; profiles/README.md: every SIMD holds one wavefront that issues ~1 VALU instruction per 5 cycles): the HBM fraction is reported as the contract asks",
             },
         }
