@@ -1068,8 +1068,10 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
   double bp[3], bR[9], bv[6];
   box_frame(bs, bp, bR, bv);
   __syncthreads();
+  TEAM_MARK(37)  // (slots 37-39 here: the contact timing tool; the self-collision marks of the same slots are in kernels it does not launch)
   double ppos[4][3], pdist[4], cpos[8][3], cdist[8], cn[3] = {0, 0, 0};
   int nP = 0, nB = 0, boxfirst = 0;
+  bool want_plane = false, want_box = false;  // hull geoms: vertex work left for the cooperative stage
   ContactGeom cg;
   const bool has_geom = lane < tab.ngeom;
   if (has_geom) {
@@ -1092,40 +1094,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       const double cdst = dot3(n, gp) - tab.plane_d;
       if (cdst - cg.rbound <= 0) {
         if (cg.type == 7) {
-          double t1[3], t2[3];
-          make_frame(n, t1, t2);
-          int chosen[4];
-          for (int q = 0; q < 4; ++q) {
-            double dir[3];
-            if (q == 0) { dir[0] = -n[0]; dir[1] = -n[1]; dir[2] = -n[2]; }
-            else {
-              // cos / sin of 2 pi (q - 1) / 3 as the C library rounds them (the oracle calls it)
-              const double kc[3] = {1.0, -0.4999999999999998, -0.5000000000000004}, ks[3] = {0.0, 0.8660254037844387, -0.8660254037844384};
-              const double cs = 1e-3 * kc[q - 1], sn = 1e-3 * ks[q - 1];
-              for (int k = 0; k < 3; ++k) dir[k] = -n[k] + cs * t1[k] + sn * t2[k];
-            }
-            double dl[3], bestv = -INFINITY;
-            mulTv(gR, dir, dl);
-            int bi = -1;
-            for (int v = 0; v < cg.vert_num; ++v) {
-              const double s = V[3 * v] * dl[0] + V[3 * v + 1] * dl[1] + V[3 * v + 2] * dl[2];
-              if (s > bestv) { bestv = s; bi = v; }
-            }
-            if (bi < 0) break;
-            bool dup = false;
-            for (int k = 0; k < nP; ++k) dup = dup || chosen[k] == bi;
-            if (dup) continue;
-            const double vl[3] = {V[3 * bi], V[3 * bi + 1], V[3 * bi + 2]};
-            double w[3];
-            mulmv(gR, vl, w);
-            const double xw[3] = {w[0] + gp[0], w[1] + gp[1], w[2] + gp[2]};
-            const double dist = dot3(n, xw) - tab.plane_d;
-            if (dist >= 0) { if (q == 0) break; else continue; }
-            chosen[nP] = bi;
-            for (int k = 0; k < 3; ++k) ppos[nP][k] = xw[k] - n[k] * dist * 0.5;
-            pdist[nP] = dist;
-            ++nP;
-          }
+          want_plane = true;  // (a hull's support vertices: with the whole wavefront, below)
         } else if (cg.type == 6) {
           for (int c = 0; c < 8 && nP < 4; ++c) {
             const double loc[3] = {(c & 1 ? cg.size[0] : -cg.size[0]), (c & 2 ? cg.size[1] : -cg.size[1]), (c & 4 ? cg.size[2] : -cg.size[2])};
@@ -1179,13 +1148,105 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
           }
           double depth = 0;
           if (may) {
-            if (cg.type == 7) { nB = dev_mpr(Bx, S, &depth, cn, cpos[0]); boxfirst = 1; }  // box (type 6) before mesh (type 7)
+            if (cg.type == 7) want_box = true;  // (the hull's portal refinement: with the whole wavefront, below)
             else nB = dev_mpr(S, Bx, &depth, cn, cpos[0]);
           }
           cdist[0] = -depth;
         }
       }
     }
+  }
+  // ---- the hulls' vertex work, one hull at a time with the whole wavefront: a lane scanning its hull's vertices in global
+  // memory alone pays a memory round trip per vertex (its wavefront has nothing else to run); staged into LDS once, the
+  // lanes of every 16-lane team scan every 16th vertex and agree on the winner -- the same vertex the serial scan finds.
+  {
+    __syncthreads();  // (the pads' clipping polygons in ar.stage are done with)
+    TEAM_MARK(38)
+    double* hv = &ar.stage[0][0];
+    static_assert(sizeof(ar.stage) >= sizeof(double) * 3 * 160, "a hull's vertices fit into the stage");
+    for (uint64_t todo = __ballot(has_geom && (want_plane || want_box)); todo; todo &= todo - 1) {
+      const int h = __ffsll((long long)todo) - 1;
+      const ContactGeom& hg = tab.geoms[h];
+      const bool do_plane = (__ballot(want_plane) >> h) & 1, do_box = (__ballot(want_box) >> h) & 1;
+      const int nv = hg.vert_num;
+      {
+        const double* Vh = tab.verts + 3 * (size_t)hg.vert_adr;
+        for (int k = lane; k < 3 * nv; k += 64) hv[k] = Vh[k];
+        __syncthreads();
+      }
+      double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0};
+      if (hg.link >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rl[k] = ar.F[hg.link][k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl[k] = ar.F[hg.link][9 + k];
+      }
+      double gR[9], gp[3];
+      mulmm(Rl, hg.rot, gR);
+      mulmv(Rl, hg.pos, gp);
+      gp[0] += pl[0]; gp[1] += pl[1]; gp[2] += pl[2];
+      // every lane computes the same; lane h keeps it
+      int hP = 0;
+      double hpos[4][3], hdist[4];
+      if (do_plane) {
+        const double n[3] = {tab.plane_n[0], tab.plane_n[1], tab.plane_n[2]};
+        double t1[3], t2[3];
+        make_frame(n, t1, t2);
+        int chosen[4];
+        for (int q = 0; q < 4; ++q) {
+          double dir[3];
+          if (q == 0) { dir[0] = -n[0]; dir[1] = -n[1]; dir[2] = -n[2]; }
+          else {
+            // cos / sin of 2 pi (q - 1) / 3 as the C library rounds them (the oracle calls it)
+            const double kc[3] = {1.0, -0.4999999999999998, -0.5000000000000004}, ks[3] = {0.0, 0.8660254037844387, -0.8660254037844384};
+            const double cs = 1e-3 * kc[q - 1], sn = 1e-3 * ks[q - 1];
+            for (int k = 0; k < 3; ++k) dir[k] = -n[k] + cs * t1[k] + sn * t2[k];
+          }
+          double dl[3];
+          mulTv(gR, dir, dl);
+          if (nv <= 0) break;
+          const int bi = hull_support_index<true>(hv, nv, dl);
+          bool dup = false;
+          for (int k = 0; k < hP; ++k) dup = dup || chosen[k] == bi;
+          if (dup) continue;
+          const double* hvl = in_lds(hv);
+          const double vl[3] = {hvl[3 * bi], hvl[3 * bi + 1], hvl[3 * bi + 2]};
+          double w[3];
+          mulmv(gR, vl, w);
+          const double xw[3] = {w[0] + gp[0], w[1] + gp[1], w[2] + gp[2]};
+          const double dist = dot3(n, xw) - tab.plane_d;
+          if (dist >= 0) { if (q == 0) break; else continue; }
+          chosen[hP] = bi;
+          for (int k = 0; k < 3; ++k) hpos[hP][k] = xw[k] - n[k] * dist * 0.5;
+          hdist[hP] = dist;
+          ++hP;
+        }
+      }
+      int hB = 0;
+      double hdepth = 0, hn[3] = {0, 0, 0}, hc[3] = {0, 0, 0};
+      if (do_box) {
+        const double bsz[3] = {b.size[0], b.size[1], b.size[2]};
+        Shape S{0, gp, gR, hg.size, hv, nv, {gp[0], gp[1], gp[2]}};
+        Shape Bx{1, bp, bR, bsz, nullptr, 0, {bp[0], bp[1], bp[2]}};
+        double c[3];
+        mulmv(gR, hg.center, c);
+        for (int k = 0; k < 3; ++k) S.center[k] = c[k] + gp[k];
+        hB = mpr_penetration<true>(Bx, S, &hdepth, hn, hc);  // box (type 6) before mesh (type 7)
+      }
+      if (lane == h) {
+        if (do_plane) {
+          nP = hP;
+          for (int k = 0; k < 4; ++k) { pdist[k] = hdist[k]; ppos[k][0] = hpos[k][0]; ppos[k][1] = hpos[k][1]; ppos[k][2] = hpos[k][2]; }
+        }
+        if (do_box) {
+          nB = hB; boxfirst = 1;
+          cdist[0] = -hdepth;
+          for (int k = 0; k < 3; ++k) { cn[k] = hn[k]; cpos[0][k] = hc[k]; }
+        }
+      }
+      __syncthreads();
+    }
+    TEAM_MARK(39)
   }
   // the box against the floor (mjc_PlaneBox: corners in order, at most four)
   int nBP = 0;
@@ -1773,8 +1834,53 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
         for (int r = 0; r < 3; ++r) Ac[r][kk] = dot6(c.G[r], rel);
       }
     }
+    // The sweeps move wrenches on few bodies -- the links in contact (slots 0..nact-1) and the cube (slot kMaxActive) -- and
+    // read only those bodies' accelerations.  Lane 6 s + k keeps component k of the CHANGE of slot s's acceleration in a
+    // register; K[s][t] = S_s M^-1 S_t' (6 x 6, from Y) says what a wrench on slot t does to slot s, the cube answers with
+    // its own inverse inertia only.  An update is then: the owner reads the two bodies' changes across the lanes, solves
+    // its friction rows, hands the wrench change back across the lanes, and the slot lanes add their row of K times it:
+    // no barrier and no pass over the kinematic tree per contact.
+    double (*Kl)[kMaxActive][6][6] = reinterpret_cast<double (*)[kMaxActive][6][6]>(&ar.rec[0][0]);  // (the records are in the lanes by now)
+    static_assert(sizeof(ar.rec) >= sizeof(double) * kMaxActive * kMaxActive * 36, "K fits the records' area");
+    double kb[6] = {0, 0, 0, 0, 0, 0};  // slot lanes of the cube: their row of S_box M_box^-1 S_box'
+    if (lane < 6 * nact) {
+      const int sl = lane / 6, k = lane % 6, lk = ar.act[sl];
+      for (int t = 0; t < nact; ++t) {
+        double row[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+          if (!is_anc<T>(j, lk)) continue;
+          const double sjk = st.S(j, k);
+#pragma unroll
+          for (int m = 0; m < 6; ++m) row[m] += sjk * Y[t][j][m];
+        }
+#pragma unroll
+        for (int m = 0; m < 6; ++m) Kl[sl][t][k][m] = row[m];
+      }
+    } else if (lane >= 6 * kMaxActive && lane < 6 * kMaxActive + 6) {
+      const int k = lane - 6 * kMaxActive;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double col[6];
+        box_column(bR, bp, i, col);
+        const double q = Mbi[i] * col[k];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) kb[m] += q * col[m];
+      }
+    }
+    auto slot_of = [&](int body) {
+      if (body == kBox) return kMaxActive;
+      int sl = -1;
+      for (int a = 0; a < nact; ++a) if (ar.act[a] == body) sl = a;
+      return sl;
+    };
+    const int my_slots = (slot_of(c.A) & 0xff) | (slot_of(c.B) & 0xff) << 8;  // (0xff: the world, or a link beyond the kept ones)
+    double rel0[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rel0[k] = ar.U[c.B][k] - ar.U[c.A][k];
+    double du = 0;
+    __syncthreads();
     TEAM_MARK(30)
-    double* dw = ar.Gd;  // the wrench change of the contact being updated, broadcast through LDS
     int iter = 0;
     while (iter < b.noslip_iterations) {
       TEAM_COUNT(36)
@@ -1791,12 +1897,20 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
         improvement = wave_sum(s);
       }
       for (int cc = 0; cc < ncon; ++cc) {
-        const int code = ar.cb[cc], A_ = code & 0xff, B_ = (code >> 8) & 0xff;
-        double change = 0;
-        if (lane == cc) {
-          double rel[6], res[3], old[3] = {c.f[0], c.f[1], c.f[2]};
+        TEAM_MARK(40)
+        const int slots = wave_read(my_slots, cc), sA = slots & 0xff, sB = slots >> 8;
+        double rel[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) rel[k] = ar.U[c.B][k] - ar.U[c.A][k];
+        for (int k = 0; k < 6; ++k) {
+          double r = rel0[k];
+          if (sB != 0xff) r += wave_read(du, 6 * sB + k);
+          if (sA != 0xff) r -= wave_read(du, 6 * sA + k);
+          rel[k] = r;
+        }
+        double change = 0, dw[6] = {0, 0, 0, 0, 0, 0};
+        int moved = 0;
+        if (lane == cc) {
+          double res[3], old[3] = {c.f[0], c.f[1], c.f[2]};
 #pragma unroll
           for (int k = 0; k < 3; ++k) res[k] = dot6(c.G[k], rel) - c.aref[k];
           double nf[3] = {old[0], old[1], old[2]};
@@ -1822,35 +1936,27 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
           if (change > 1e-10) { nf[0] = old[0]; nf[1] = old[1]; nf[2] = old[2]; change = 0; }
 #pragma unroll
           for (int k = 0; k < 6; ++k) dw[k] = c.G[0][k] * (nf[0] - old[0]) + c.G[1][k] * (nf[1] - old[1]) + c.G[2][k] * (nf[2] - old[2]);
+          moved = nf[0] != old[0] || nf[1] != old[1] || nf[2] != old[2];
           c.f[0] = nf[0]; c.f[1] = nf[1]; c.f[2] = nf[2];
         }
-        __syncthreads();
-        // push the wrench change into the accelerations: dx = (Y_B - Y_A) dw on the robot's dofs (lane j), M_box^-1 S_box' dw on the box's
-        if (lane < NL) {
-          double dx = 0;
-          for (int a = 0; a < nact; ++a) {
-            const int lk = ar.act[a];
-            const double sgn = lk == B_ ? 1.0 : (lk == A_ ? -1.0 : 0.0);
-            if (sgn == 0.0) continue;
-            dx += sgn * dot6(Y[a][lane], dw);
-          }
-          ar.P[lane] = dx;
-        } else if (lane < NV) {
-          const int k = lane - NL;
-          const double sgn = B_ == kBox ? 1.0 : (A_ == kBox ? -1.0 : 0.0);
-          double col[6];
-          box_column(bR, bp, k, col);
-          ar.P[lane] = sgn * Mbi[k] * dot6(col, dw);
-        }
-        __syncthreads();
-        body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
-        __syncthreads();
-        if (lane < NB - 1) {
+        TEAM_MARK(41)
+        if (wave_read(moved, cc)) {
+          // the wrench change dw on body B, -dw on body A: what it does to the kept bodies' accelerations
+          double w[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) ar.U[lane][k] += ar.Up[lane][k];
+          for (int k = 0; k < 6; ++k) w[k] = wave_read(dw[k], cc);
+          if (lane < 6 * nact) {
+            const int sl = lane / 6, k = lane % 6;
+            if (sB < kMaxActive) du += dot6(Kl[sl][sB][k], w);
+            if (sA < kMaxActive) du -= dot6(Kl[sl][sA][k], w);
+          } else if (lane >= 6 * kMaxActive && lane < 6 * kMaxActive + 6) {
+            const double sg = (sB == kMaxActive ? 1.0 : 0.0) - (sA == kMaxActive ? 1.0 : 0.0);
+            du += sg * dot6(kb, w);
+          }
         }
-        __syncthreads();
-        improvement -= lane_get(change, cc);
+        TEAM_MARK(44)
+        TEAM_COUNT(45)
+        improvement -= wave_read(change, cc);
       }
       improvement *= b.scale;
       ++iter;

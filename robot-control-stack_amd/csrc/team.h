@@ -73,6 +73,12 @@ RCSH_D double lane_get(double x, int src) {
   const int hi = __builtin_amdgcn_ds_bpermute(src << 2, hi32(x));
   return mk64(hi, lo);
 }
+// the same for a source lane that is the same in every lane of the wave: into scalar registers (v_readlane), no LDS crossbar
+RCSH_D int wave_read(int x, int src) { return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(src)); }
+RCSH_D double wave_read(double x, int src) {
+  const int s = __builtin_amdgcn_readfirstlane(src);
+  return mk64(__builtin_amdgcn_readlane(hi32(x), s), __builtin_amdgcn_readlane(lo32(x), s));
+}
 // 16-bit mask of the team's lanes for which `pred` holds
 RCSH_D uint32_t team_ballot(bool pred) {
   const uint64_t b = __ballot(pred);

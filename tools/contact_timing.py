@@ -18,7 +18,7 @@ simu.reset(); robot.reset(); grip.reset(); simu.step(1)
 home = robot.get_cartesian_position()
 q = np.asarray(home)[0, 3:]
 out = (C.c_ulonglong * 48)()
-names = {24: "before (since last mark)", 25: "frames + narrow phase", 26: "compaction", 27: "rows, qacc_smooth, M factor", 28: "Newton", 30: "forces, Y, A blocks",
+names = {24: "before (since last mark)", 37: "  link frames", 38: "  lane per geom", 39: "  hulls, cooperative", 25: "frames + narrow phase (rest)", 26: "compaction", 27: "rows, qacc_smooth, M factor", 28: "Newton", 30: "forces, Y, A blocks",
          31: "noslip sweeps", 32: "results"}
 def stage(tag, k, mv=None, g=None):
     if mv is not None:
@@ -32,7 +32,9 @@ def stage(tag, k, mv=None, g=None):
     print(f"{tag}: {k} substeps, contact phases {a[33]:.0f} (coupled {a[34]:.0f}); box z {simu.free_joint_qpos('box_joint')[0, 2]:.3f}")
     if a[33] > 0:
         for i, nm in names.items():
-            print(f"    {nm:30s} {a[i] / (coupled if i > 26 else calls):10.0f} cycles per {'coupled ' if i > 26 else ''}phase")
+            print(f"    {nm:30s} {a[i] / (coupled if 26 < i < 37 else calls):10.0f} cycles per {'coupled ' if 26 < i < 37 else ''}phase")
+        nc = max(a[45], 1)
+        print(f"    noslip per contact update ({a[45] / max(a[36], 1):.1f} contacts per sweep): loop head {a[40] / nc:.0f}, owner {a[41] / nc:.0f}, dx {a[42] / nc:.0f}, body_spatial {a[43] / nc:.0f}, accumulate {a[44] / nc:.0f} cycles")
         print(f"    Newton iterations {a[29] / coupled:.2f}, line-search evaluations {a[35] / coupled:.2f}, noslip sweeps {a[36] / coupled:.2f} per coupled phase")
 stage("above", 400, mv=[0.44, 0.1, 0.2])
 stage("down", 600, mv=[0.44, 0.1, 0.035])
