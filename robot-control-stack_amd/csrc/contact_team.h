@@ -49,7 +49,7 @@ RCSH_D double wave_sum(double x) {
   x = quad_sum(x);
   x += row_rotate<4>(x);
   x += row_rotate<8>(x);
-  return (lane_get(x, 0) + lane_get(x, 16)) + (lane_get(x, 32) + lane_get(x, 48));
+  return (wave_read(x, 0) + wave_read(x, 16)) + (wave_read(x, 32) + wave_read(x, 48));
 }
 RCSH_D int wave_lane() { return threadIdx.x & 63; }
 
@@ -955,8 +955,21 @@ RCSH_D void con_load(const AR& ar, const BoxCfg& b, int lane, int ncon, int worl
 
 // Wrench of every body from the contact forces `fc` of the owner lanes -> ar.W; returns the generalised force J' f of dof
 // `lane` (lanes < NV).  Contains barriers: every lane calls it.
+// contacts of body lane / 6, as 64-bit lane masks (the same for every call of a phase)
+struct BodyMasks { uint64_t asB, asA; };
+template <int NBODY>
+RCSH_D BodyMasks body_masks(const ConLane& c, int lane) {
+  BodyMasks bm{0, 0};
+  const int bdy = lane / 6;
+#pragma unroll
+  for (int bb = 0; bb < NBODY; ++bb) {
+    const uint64_t mb = __ballot(c.on && c.B == bb), ma = __ballot(c.on && c.A == bb);
+    if (bdy == bb) { bm.asB = mb; bm.asA = ma; }
+  }
+  return bm;
+}
 template <class T, class AR>
-RCSH_D double contact_qfrc(AR& ar, const StageTeam<T>& st, const ConLane& c, const double* fc, int ncon, const double* bR, const double* bp, int lane) {
+RCSH_D double contact_qfrc(AR& ar, const StageTeam<T>& st, const ConLane& c, const double* fc, const BodyMasks& bm, const double* bR, const double* bp, int lane) {
   constexpr int NL = T::NL, NV = NL + 6, NB = NL + 2, kBox = NL;
   if (lane < kMaxCon) {
     double* wr = ar.stage[lane];
@@ -965,14 +978,15 @@ RCSH_D double contact_qfrc(AR& ar, const StageTeam<T>& st, const ConLane& c, con
   }
   __syncthreads();
   {
-    // lane (body, component): sum over the contacts in order
+    // lane (body, component): sum over the body's contacts in order (bm: the contacts with the body as B / as A)
     const int bdy = lane / 6, k = lane % 6;
     if (bdy < NB - 1) {  // (the world takes no force)
       double s = 0;
-      for (int cc = 0; cc < ncon; ++cc) {
-        const int code = ar.cb[cc];
-        if (((code >> 8) & 0xff) == bdy) s += ar.stage[cc][k];
-        if ((code & 0xff) == bdy) s -= ar.stage[cc][k];
+      for (uint64_t m = bm.asB | bm.asA; m; m &= m - 1) {
+        const int cc = __ffsll((long long)m) - 1;
+        const double v = ar.stage[cc][k];
+        if (bm.asB >> cc & 1) s += v;
+        if (bm.asA >> cc & 1) s -= v;
       }
       ar.W[bdy][k] = s;
     }
@@ -1491,17 +1505,41 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
     if (c_warm < c_smooth && lane < NV) ar.X[lane] = ar.P[lane];
     __syncthreads();
   }
+  // what does not change over the iterations: the contacts of every body (the generalised force) and of every stiffness
+  // accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
+  const BodyMasks bmasks = body_masks<NL + 1>(c, lane);
+  uint64_t kmask = 0;
+  {
+    int slot = -1;
+    if (c.on) {
+      const int lk = c.A < NL ? c.A : (c.B < NL ? c.B : -1);
+      const bool with_box = c.A == kBox || c.B == kBox;
+      if (lk < 0) slot = 2 * kMaxActive;
+      else {
+        int a = -1;
+        for (int k = 0; k < nact; ++k) if (ar.act[k] == lk) a = k;
+        slot = a < 0 ? -1 : (with_box ? a : kMaxActive + a);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 2 * kMaxActive + 1; ++a) {
+      const uint64_t m = __ballot(slot == a);
+      if (lane / 7 == a) kmask = m;
+    }
+  }
   for (int newton_it = 0; newton_it < 100; ++newton_it) {
+    TEAM_MARK(55)
     TEAM_COUNT(29)
     body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
     __syncthreads();
     eval_rows(ar.U, jar, f, Hc);
     double gl;
     robot_terms(ar.X, &gl);
-    const double qf = contact_qfrc<T>(ar, st, c, f, ncon, bR, bp, lane);
+    const double qf = contact_qfrc<T>(ar, st, c, f, bmasks, bR, bp, lane);
     if (lane < NV) { gl -= qf; ar.Gd[lane] = gl; }
     const double g2 = wave_sum(lane < NV ? gl * gl : 0.0);
     if (b.scale * sqrt(g2) < 1e-12) break;
+    TEAM_MARK(48)
     // ---- contact stiffness K_c = G' Hc G (6 x 6 symmetric, 21 entries), summed per body pair through LDS in three
     // batches of seven entries: accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
     {
@@ -1522,17 +1560,6 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
 #pragma unroll
         for (int e = 0; e < 21; ++e) Kc[e] = 0.0;
       }
-      int slot = -1;
-      if (c.on) {
-        const int lk = c.A < NL ? c.A : (c.B < NL ? c.B : -1);
-        const bool with_box = c.A == kBox || c.B == kBox;
-        if (lk < 0) slot = 2 * kMaxActive;
-        else {
-          int a = -1;
-          for (int k = 0; k < nact; ++k) if (ar.act[k] == lk) a = k;
-          slot = a < 0 ? -1 : (with_box ? a : kMaxActive + a);
-        }
-      }
 #pragma unroll
       for (int batch = 0; batch < 3; ++batch) {
         __syncthreads();
@@ -1540,21 +1567,20 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
           double* wr = ar.stage[lane];
 #pragma unroll
           for (int e = 0; e < 7; ++e) wr[e] = Kc[7 * batch + e];
-          wr[7] = (double)slot;
         }
         __syncthreads();
         {
           const int a = lane / 7, e = lane % 7;
           if (a < 2 * kMaxActive + 1) {
             double s = 0;
-            for (int cc = 0; cc < ncon; ++cc)
-              if ((int)ar.stage[cc][7] == a) s += ar.stage[cc][e];
+            for (uint64_t m = kmask; m; m &= m - 1) s += ar.stage[__ffsll((long long)m) - 1][e];
             ar.KA[a][7 * batch + e] = s;
           }
         }
       }
       __syncthreads();
     }
+    TEAM_MARK(49)
     // ---- Hessian H = M + rows' curvature + S' K S (lower triangle, LDS): lane t < NV writes row t
     if (lane < NL) {
       // composite stiffness below link `lane`: KD over (link, box) and (world, link) pairs, KX over (link, box) pairs
@@ -1628,40 +1654,46 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
       }
     }
     __syncthreads();
-    // ---- Newton direction p = -H^-1 grad.  LDL' of the 15 x 15 Hessian in place in LDS, lane i owning row i (right-looking:
-    // step j scales nothing, it only subtracts column j's outer product from the rows below -- column j itself stays
-    // unscaled, L_ij = H_ij / d_j); then every lane runs the two triangular solves for itself, streaming L out of LDS.
-    for (int j = 0; j < NV - 1; ++j) {
-      if (lane > j && lane < NV) {
-        const double lij = ar.H[tri(lane, j)] / ar.H[tri(j, j)];
-        for (int k = j + 1; k <= lane; ++k) ar.H[tri(lane, k)] -= lij * ar.H[tri(k, j)];
-      }
-      __syncthreads();
-    }
+    TEAM_MARK(50)
+    // ---- Newton direction p = -H^-1 grad.  Lane i < NV takes row i of the (symmetric) Hessian into registers; LDL'
+    // right-looking: step j divides column j by the pivot (every lane its own entry) and subtracts the column's outer
+    // product from the rows below, the other rows' entries of column j read across the lanes into scalar registers.  A lane
+    // stops at its own step, so its entries right of the diagonal stay what column i was then (L_ki d_i): the backward
+    // substitution's coefficients.  Both substitutions are column sweeps with the finished entry read across the lanes.
     double dphi0 = 0;
     {
-      double p[NV], dinv[NV];
+      const int row = lane < NV ? lane : NV - 1;
+      double hr[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) { p[i] = -ar.Gd[i]; dinv[i] = 1.0 / ar.H[tri(i, i)]; }
+      for (int k = 0; k < NV; ++k) hr[k] = ar.H[row >= k ? tri(row, k) : tri(k, row)];
+      TEAM_MARK(51)
 #pragma unroll
-      for (int i = 1; i < NV; ++i) {
+      for (int j = 0; j < NV - 1; ++j) {
+        const double dj = wave_read(hr[j], j);
+        const double lij = lane > j ? hr[j] / dj : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) p[i] -= ar.H[tri(i, k)] * dinv[k] * p[k];
+        for (int k = j + 1; k < NV; ++k) hr[k] -= lij * wave_read(hr[j], k);
       }
+      double dg = 0;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) p[i] *= dinv[i];
+      for (int k = 0; k < NV; ++k) dg = row == k ? hr[k] : dg;
+      const double dinv = 1.0 / dg, gl_ = lane < NV ? ar.Gd[lane] : 0.0;
+      double acc = -gl_;
 #pragma unroll
-      for (int i = NV - 2; i >= 0; --i) {
-#pragma unroll
-        for (int k = i + 1; k < NV; ++k) p[i] -= ar.H[tri(k, i)] * dinv[i] * p[k];
+      for (int k = 0; k < NV - 1; ++k) {
+        const double yk = wave_read(acc, k) * wave_read(dinv, k);
+        if (lane > k) acc -= hr[k] * yk;
       }
+      acc *= dinv;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) dphi0 += ar.Gd[i] * p[i];
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) ar.P[i] = p[i];
+      for (int k = NV - 1; k >= 1; --k) {
+        const double xk = wave_read(acc, k);
+        if (lane < k) acc -= hr[k] * dinv * xk;
       }
+      dphi0 = wave_sum(lane < NV ? gl_ * acc : 0.0);
+      if (lane < NV) ar.P[lane] = acc;
     }
+    TEAM_MARK(52)
     if (!(dphi0 < 0)) break;
     __syncthreads();
     body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
@@ -1691,6 +1723,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
       pMpl = Mb[k] * ar.P[lane] * ar.P[lane];
     }
     const double gM0 = wave_sum(gM0l), pMp = wave_sum(pMpl);
+    TEAM_MARK(53)
     double lo = 0, hi = -1, a = 1, best = 1;
     for (int ls = 0; ls < 30; ++ls) {
       TEAM_COUNT(35)
@@ -1727,6 +1760,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
       if (fabs(an - a) <= 1e-3 * a) break;
       a = an;
     }
+    TEAM_MARK(54)
     __syncthreads();
     if (lane < NV) ar.X[lane] += best * ar.P[lane];
     __syncthreads();
@@ -1967,7 +2001,7 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
   TEAM_MARK(31)
   // ---- results: qfrc_constraint of the robot, qacc of the box
   {
-    const double qf = contact_qfrc<T>(ar, st, c, c.f, ncon, bR, bp, lane);
+    const double qf = contact_qfrc<T>(ar, st, c, c.f, body_masks<NB - 1>(c, lane), bR, bp, lane);
     if (lane < NL) {
       double fc = qf;
       const double sgn = st.limS(lane);

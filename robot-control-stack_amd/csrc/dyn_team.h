@@ -83,8 +83,8 @@ struct StageTeam {
 #ifdef RCSH_PHASE_TIMING
 // Development instrumentation (tools/team_timing.py): cycle counter deltas between marks, accumulated in LDS by lane
 // 0 of workgroup 0 (an LDS round trip per mark, ~100 cycles) and flushed to global memory once per launch.
-__device__ unsigned long long g_team_cycles[48];
-__shared__ unsigned long long s_team_cycles[48];
+__device__ unsigned long long g_team_cycles[64];
+__shared__ unsigned long long s_team_cycles[64];
 __shared__ unsigned long long s_team_mark;
 #define TEAM_MARK(idx)                                            \
   if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
@@ -96,12 +96,12 @@ __shared__ unsigned long long s_team_mark;
   if (blockIdx.x == 0 && threadIdx.x == 0) s_team_cycles[idx] += 1;
 #define TEAM_CLOCK_START()                                        \
   if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
-    for (int k_ = 0; k_ < 48; ++k_) s_team_cycles[k_] = 0;        \
+    for (int k_ = 0; k_ < 64; ++k_) s_team_cycles[k_] = 0;        \
     s_team_mark = __builtin_readcyclecounter();                   \
   }
 #define TEAM_CLOCK_FLUSH()                                        \
   if (blockIdx.x == 0 && threadIdx.x == 0)                        \
-    for (int k_ = 0; k_ < 48; ++k_) g_team_cycles[k_] += s_team_cycles[k_];
+    for (int k_ = 0; k_ < 64; ++k_) g_team_cycles[k_] += s_team_cycles[k_];
 #else
 #define TEAM_MARK(idx)
 #define TEAM_COUNT(idx)

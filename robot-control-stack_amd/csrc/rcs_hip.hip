@@ -1689,6 +1689,10 @@ extern "C" int rcsh_debug_team_cycles48(unsigned long long* out48) {
   hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : 1;
 }
+extern "C" int rcsh_debug_team_cycles64(unsigned long long* out64) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
 #endif
 
 int rcsh_debug_dump_model(rcsh_sim* s, void* buf, size_t cap, size_t* size) {

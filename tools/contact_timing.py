@@ -17,25 +17,37 @@ grip = S.SimGripper(simu, default_sim_gripper_cfg())
 simu.reset(); robot.reset(); grip.reset(); simu.step(1)
 home = robot.get_cartesian_position()
 q = np.asarray(home)[0, 3:]
-out = (C.c_ulonglong * 48)()
-names = {24: "before (since last mark)", 37: "  link frames", 38: "  lane per geom", 39: "  hulls, cooperative", 25: "frames + narrow phase (rest)", 26: "compaction", 27: "rows, qacc_smooth, M factor", 28: "Newton", 30: "forces, Y, A blocks",
-         31: "noslip sweeps", 32: "results"}
+out = (C.c_ulonglong * 64)()
+# TEAM_MARK(i) adds the cycles since the previous mark to slot i; TEAM_COUNT(i) counts
+COLLIDE = ((37, "link frames"), (38, "lane per geom"), (39, "hulls, whole wavefront"), (25, "floor corners, fast-path test"))
+NEWTON = ((55, "x update (+ start)"), (48, "rows + gradient"), (49, "stiffness sums"), (50, "Hessian"), (51, "row loads"), (52, "LDL + solves"),
+          (53, "before line search"), (54, "line search"))
+NOSLIP = ((40, "rel across lanes"), (41, "owner"), (44, "slot lanes"))
 def stage(tag, k, mv=None, g=None):
     if mv is not None:
         robot.set_cartesian_position(np.tile(np.concatenate([mv, q]), (n, 1)))
     if g is not None:
         (grip.shut if g == 0 else grip.open)()
-    simu._L.rcsh_debug_team_cycles48(out); base = np.array(out[:], dtype=np.float64)
+    simu._L.rcsh_debug_team_cycles64(out); base = np.array(out[:], dtype=np.float64)
     simu.step(k)
-    simu._L.rcsh_debug_team_cycles48(out); a = np.array(out[:], dtype=np.float64) - base
+    simu._L.rcsh_debug_team_cycles64(out); a = np.array(out[:], dtype=np.float64) - base
     calls, coupled = max(a[33], 1), max(a[34], 1)
     print(f"{tag}: {k} substeps, contact phases {a[33]:.0f} (coupled {a[34]:.0f}); box z {simu.free_joint_qpos('box_joint')[0, 2]:.3f}")
-    if a[33] > 0:
-        for i, nm in names.items():
-            print(f"    {nm:30s} {a[i] / (coupled if 26 < i < 37 else calls):10.0f} cycles per {'coupled ' if 26 < i < 37 else ''}phase")
-        nc = max(a[45], 1)
-        print(f"    noslip per contact update ({a[45] / max(a[36], 1):.1f} contacts per sweep): loop head {a[40] / nc:.0f}, owner {a[41] / nc:.0f}, dx {a[42] / nc:.0f}, body_spatial {a[43] / nc:.0f}, accumulate {a[44] / nc:.0f} cycles")
-        print(f"    Newton iterations {a[29] / coupled:.2f}, line-search evaluations {a[35] / coupled:.2f}, noslip sweeps {a[36] / coupled:.2f} per coupled phase")
+    if a[33] == 0:
+        return
+    print(f"    collision {sum(a[i] for i, _ in COLLIDE) / calls:8.0f} cycles per phase: " + ", ".join(f"{nm} {a[i] / calls:.0f}" for i, nm in COLLIDE))
+    if a[34] == 0:
+        return
+    newton = a[28] + sum(a[i] for i, _ in NEWTON)
+    noslip = a[31] + sum(a[i] for i, _ in NOSLIP)
+    total = a[26] + a[27] + newton + a[30] + noslip + a[32]
+    print(f"    coupled solve {total / coupled:8.0f} cycles per coupled phase: compaction {a[26] / coupled:.0f}, rows / qacc_smooth / M factor {a[27] / coupled:.0f}, "
+          f"Newton {newton / coupled:.0f}, forces / Y / K blocks {a[30] / coupled:.0f}, noslip {noslip / coupled:.0f}, results {a[32] / coupled:.0f}")
+    ni, nc = max(a[29], 1), max(a[45], 1)
+    print(f"    Newton: {a[29] / coupled:.2f} iterations, {a[35] / coupled:.2f} line-search evaluations per coupled phase; per iteration {sum(a[i] for i, _ in NEWTON) / ni:.0f} cycles: "
+          + ", ".join(f"{nm} {a[i] / ni:.0f}" for i, nm in NEWTON))
+    print(f"    noslip: {a[36] / coupled:.2f} sweeps of {a[45] / max(a[36], 1):.1f} contacts per coupled phase; per contact update {sum(a[i] for i, _ in NOSLIP) / nc:.0f} cycles: "
+          + ", ".join(f"{nm} {a[i] / nc:.0f}" for i, nm in NOSLIP))
 stage("above", 400, mv=[0.44, 0.1, 0.2])
 stage("down", 600, mv=[0.44, 0.1, 0.035])
 stage("closing", 100, g=0)
