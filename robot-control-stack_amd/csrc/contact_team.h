@@ -1527,12 +1527,15 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
       if (lane / 7 == a) kmask = m;
     }
   }
+  bool at_x = false;  // jar / f / Hc are those of ar.X
   for (int newton_it = 0; newton_it < 100; ++newton_it) {
     TEAM_MARK(55)
     TEAM_COUNT(29)
-    body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
+    // (the bodies' accelerations at x: by the tree pass at the start, along the search direction afterwards)
+    if (newton_it == 0) body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
     __syncthreads();
     eval_rows(ar.U, jar, f, Hc);
+    at_x = true;
     double gl;
     robot_terms(ar.X, &gl);
     const double qf = contact_qfrc<T>(ar, st, c, f, bmasks, bR, bp, lane);
@@ -1763,12 +1766,15 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
     TEAM_MARK(54)
     __syncthreads();
     if (lane < NV) ar.X[lane] += best * ar.P[lane];
+    if (lane < NL + 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ar.U[lane][k] += best * ar.Up[lane][k];
+    }
+    at_x = false;
     __syncthreads();
   }
-  // forces at the solution -> records
-  body_spatial<T>(st, ar.X, bR, bp, ar.U, lane);
-  __syncthreads();
-  eval_rows(ar.U, jar, f, Hc);
+  // forces at the solution -> records (the loop's last evaluation unless it ran into its cap)
+  if (!at_x) eval_rows(ar.U, jar, f, Hc);
   if (c.on) {
     double* r = ar.rec[lane];
     r[11] = f[0]; r[12] = f[1]; r[13] = f[2];
