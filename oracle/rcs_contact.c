@@ -1001,7 +1001,7 @@ void orc_solve_coupled(const orc_model* m, orc_data* d) {
     for (int j = 0; j < nv; j++) dphi0 += grad[j] * p[j];
     if (!(dphi0 < 0)) break;
     /* line search: root of phi'(a) by safeguarded 1-D Newton; a = 1 is exact while no row changes zone */
-    double lo = 0, hi = -1, a = 1, best = 1;
+    double lo = 0, hi = -1, a = 1, best = 1, dx = 1e300, dxold = 1e300;
     for (int ls = 0; ls < 30; ls++) {
       double xa[ORC_NVT];
       for (int j = 0; j < nv; j++) xa[j] = x[j] + a * p[j];
@@ -1015,9 +1015,13 @@ void orc_solve_coupled(const orc_model* m, orc_data* d) {
       if (fabs(dphi) <= 1e-3 * fabs(dphi0)) break;
       if (dphi < 0) lo = a; else hi = a;
       double an = a - dphi / ddphi;
-      if (hi > 0 && !(an > lo && an < hi)) an = 0.5 * (lo + hi);
+      /* Newton on phi' with the bracket as the safeguard (the rtsafe rule): bisect when the step leaves the bracket or does not
+         at least halve the step before last -- phi' is piecewise smooth, between two pieces Newton alone can cycle */
+      if (hi > 0 && (!(an > lo && an < hi) || fabs(2 * dphi) > fabs(dxold * ddphi))) an = 0.5 * (lo + hi);
       if (hi < 0 && !(an > lo)) an = 2 * a;
       if (fabs(an - a) <= 1e-3 * a) break;
+      dxold = dx;
+      dx = an - a;
       a = an;
     }
     for (int j = 0; j < nv; j++) x[j] += best * p[j];

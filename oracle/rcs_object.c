@@ -260,7 +260,7 @@ static void box_newton(const orc_box* b, orc_box_data* d) {
     chol6_solve(P.H, p);
     /* line search: root of phi'(a) = grad(x + a p) . p in a bracket [lo, hi], 1-D Newton steps with bisection as
        the fallback; a = 1 is the exact minimiser whenever no contact changes zone along the step */
-    double lo = 0, hi = -1, a = 1, dphi0 = 0;
+    double lo = 0, hi = -1, a = 1, dphi0 = 0, dx = 1e300, dxold = 1e300;
     for (int j = 0; j < 6; j++) dphi0 += P.grad[j] * p[j];
     if (!(dphi0 < 0)) break;
     double best = 1;
@@ -277,9 +277,13 @@ static void box_newton(const orc_box* b, orc_box_data* d) {
       if (fabs(dphi) <= 1e-3 * fabs(dphi0)) break;
       if (dphi < 0) lo = a; else hi = a;
       double an = a - dphi / ddphi;
-      if (hi > 0 && !(an > lo && an < hi)) an = 0.5 * (lo + hi);
+      /* Newton on phi' with the bracket as the safeguard (the rtsafe rule): bisect when the step leaves the bracket or does not
+         at least halve the step before last -- phi' is piecewise smooth, between two pieces Newton alone can cycle */
+      if (hi > 0 && (!(an > lo && an < hi) || fabs(2 * dphi) > fabs(dxold * ddphi))) an = 0.5 * (lo + hi);
       if (hi < 0 && !(an > lo)) an = 2 * a;
       if (fabs(an - a) <= 1e-3 * a) break;
+      dxold = dx;
+      dx = an - a;
       a = an;
     }
     for (int j = 0; j < 6; j++) x[j] += best * p[j];

@@ -42,8 +42,9 @@ struct BoxCfg {
 
 // per-team LDS block: qpos 7, qvel 6, qacc_warmstart 6, then the 12 x 6 contact Jacobian for the noslip pass
 // (and the pose the last position stage saw: what the renderer draws)
-// (kBoxA: the box's acceleration out of a coupled robot + box solve)
-constexpr int kBoxQ = 0, kBoxV = 7, kBoxW = 13, kBoxPre = 19, kBoxState = 26, kBoxJ = 26, kBoxA = kBoxJ + 72, kBoxLds = kBoxA + 6;
+// (kBoxA: the box's acceleration out of a coupled robot + box solve; kBoxX: the minimiser the last coupled Newton solve found
+// over the robot's and the box's dofs -- a third candidate for the next solve's starting point, contact_team.h)
+constexpr int kBoxQ = 0, kBoxV = 7, kBoxW = 13, kBoxPre = 19, kBoxX = 26, kBoxState = 41, kBoxJ = 41, kBoxA = kBoxJ + 72, kBoxLds = kBoxA + 6;
 
 #if defined(__HIP__)
 
@@ -320,7 +321,7 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
         for (int j = 0; j < 6; ++j) s += c.J[k][j] * d[j];
         jd[k] = s;
       }
-      double lo = 0, hi = -1, a = 1, best = 1;
+      double lo = 0, hi = -1, a = 1, best = 1, dx = 1e300, dxold = 1e300;
       for (int ls = 0; ls < 20; ++ls) {
         TEAM_COUNT(22)
         double ja[3], fa[3], Ha[6];
@@ -338,9 +339,13 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
         if (fabs(dphi) <= 1e-3 * fabs(dphi0)) break;
         if (dphi < 0) lo = a; else hi = a;
         double an = a - dphi * fast_rcp(ddphi);
-        if (hi > 0 && !(an > lo && an < hi)) an = 0.5 * (lo + hi);
+        // Newton on phi' with the bracket as the safeguard (the rtsafe rule): bisect when the step leaves the bracket or does
+        // not at least halve the step before last -- phi' is piecewise smooth, between two pieces Newton alone can cycle
+        if (hi > 0 && (!(an > lo && an < hi) || fabs(2 * dphi) > fabs(dxold * ddphi))) an = 0.5 * (lo + hi);
         if (hi < 0 && !(an > lo)) an = 2 * a;
         if (fabs(an - a) <= 1e-3 * a) break;
+        dxold = dx;
+        dx = an - a;
         a = an;
       }
 #pragma unroll

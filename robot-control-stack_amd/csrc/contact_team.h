@@ -1349,10 +1349,10 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
 // Lane c owns contact c.  Leaves the minimiser in ar.X, qacc_smooth in ar.A0, the rows' reference accelerations /
 // regularisers and the contact forces in the records.
 template <class T>
-RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, const double* bs_, ContactArena<T>& ar_, const double* gravity_) {
+RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_, const double* gravity_) {
   const BoxCfg& b = *in_lds(&b_);
   const StageTeam<T> st{in_lds(st_.base)};
-  const double* bs = in_lds(bs_);
+  double* bs = in_lds(bs_);
   ContactArena<T>& ar = *in_lds(&ar_);
   const double* gravity = in_lds(gravity_);
   constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6;
@@ -1501,8 +1501,20 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
     double g, ja[3], fa[3], Ha[6];
     const double c_smooth = wave_sum(eval_rows(ar.U, ja, fa, Ha) + robot_terms(ar.X, &g));
     const double c_warm = wave_sum(eval_rows(ar.Up, ja, fa, Ha) + robot_terms(ar.P, &g));
+    // a third candidate: where the previous coupled solve of this environment ended.  MuJoCo's warm start is the previous
+    // step's final qacc, i.e. AFTER the noslip pass, which moves the friction forces away from the soft problem's minimiser
+    // by about the same amount every step; a steadily held cube starts two to three iterations closer from here.  The cost
+    // is strictly convex and the iteration runs to its minimiser: the starting point decides the path, not the result.
+    static_assert(NV <= kBoxState - kBoxX, "the kept minimiser fits its slot of the box state");
+    if (lane < NV) ar.Gd[lane] = bs[kBoxX + lane];
     __syncthreads();
-    if (c_warm < c_smooth && lane < NV) ar.X[lane] = ar.P[lane];
+    body_spatial<T>(st, ar.Gd, bR, bp, ar.W, lane);
+    __syncthreads();
+    const double c_prev = wave_sum(eval_rows(ar.W, ja, fa, Ha) + robot_terms(ar.Gd, &g));
+    if (lane < NV) {
+      if (c_warm < c_smooth) ar.X[lane] = ar.P[lane];
+      if (c_prev < fmin(c_warm, c_smooth)) ar.X[lane] = ar.Gd[lane];
+    }
     __syncthreads();
   }
   // what does not change over the iterations: the contacts of every body (the generalised force) and of every stiffness
@@ -1727,7 +1739,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
     }
     const double gM0 = wave_sum(gM0l), pMp = wave_sum(pMpl);
     TEAM_MARK(53)
-    double lo = 0, hi = -1, a = 1, best = 1;
+    double lo = 0, hi = -1, a = 1, best = 1, dx = 1e300, dxold = 1e300;
     for (int ls = 0; ls < 30; ++ls) {
       TEAM_COUNT(35)
       double dl = 0, ddl = 0;
@@ -1758,9 +1770,13 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
       if (fabs(dphi) <= 1e-3 * fabs(dphi0)) break;
       if (dphi < 0) lo = a; else hi = a;
       double an = a - dphi / ddphi;
-      if (hi > 0 && !(an > lo && an < hi)) an = 0.5 * (lo + hi);
+      // Newton on phi' with the bracket as the safeguard (the rtsafe rule): bisect when the step leaves the bracket or does
+      // not at least halve the step before last -- phi' is piecewise smooth, between two pieces Newton alone can cycle
+      if (hi > 0 && (!(an > lo && an < hi) || fabs(2 * dphi) > fabs(dxold * ddphi))) an = 0.5 * (lo + hi);
       if (hi < 0 && !(an > lo)) an = 2 * a;
       if (fabs(an - a) <= 1e-3 * a) break;
+      dxold = dx;
+      dx = an - a;
       a = an;
     }
     TEAM_MARK(54)
@@ -1775,6 +1791,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, c
   }
   // forces at the solution -> records (the loop's last evaluation unless it ran into its cap)
   if (!at_x) eval_rows(ar.U, jar, f, Hc);
+  if (lane < NV) bs[kBoxX + lane] = ar.X[lane];
   if (c.on) {
     double* r = ar.rec[lane];
     r[11] = f[0]; r[12] = f[1]; r[13] = f[2];

@@ -92,7 +92,7 @@ struct rcsh_sim {
   size_t image_cap = 0;  // device copy of {box, task} (scenes with a free box)
   double* pending_task = nullptr;  // task output of the env-step being enqueued (rcsh_env_step_task*)
   // staging for the host-pointer entry points
-  double* d_stage = nullptr;   // n * 32 doubles
+  double* d_stage = nullptr;   // n * kStageWidth doubles
   double* d_stage2 = nullptr;  // n * 32 doubles
   uint8_t* d_bytes = nullptr;  // n * 16 bytes
   uint8_t* d_mask = nullptr;   // n bytes
@@ -429,7 +429,10 @@ int upload_mask(rcsh_sim* s, const uint8_t* mask, const uint8_t** dev) {
 }
 
 // host [n][width] -> state fields
+constexpr int kStageWidth = 48;  // doubles per environment of the staging buffer (the widest field group: the free body's state)
+static_assert(kBoxState <= kStageWidth, "the free body's state passes through the staging buffer in one piece");
 int scatter_host(rcsh_sim* s, int field0, int width, const double* src, const uint8_t* mask) {
+  if (width > kStageWidth) return fail(RCSH_ERR_ARG, "scatter_host: field group wider than the staging buffer");
   const uint8_t* dm = nullptr;
   int rc = upload_mask(s, mask, &dm);
   if (rc) return rc;
@@ -441,6 +444,7 @@ int scatter_host(rcsh_sim* s, int field0, int width, const double* src, const ui
 }
 
 int gather_host(rcsh_sim* s, int field0, int width, double* dst) {
+  if (width > kStageWidth) return fail(RCSH_ERR_ARG, "gather_host: field group wider than the staging buffer");
   hipLaunchKernelGGL(k_gather, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, (const double*)s->S, s->n, field0, width, s->d_stage);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(dst, s->d_stage, sizeof(double) * s->n * width, hipMemcpyDeviceToHost, s->stream));
@@ -565,7 +569,7 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   HIP_NEW(hipMalloc(&s->S, sizeof(double) * n * s->nfields));
   HIP_NEW(hipMalloc(&s->flags, sizeof(uint32_t) * n));
   HIP_NEW(hipMalloc(&s->conv, sizeof(int32_t) * n));
-  HIP_NEW(hipMalloc(&s->d_stage, sizeof(double) * n * 32));
+  HIP_NEW(hipMalloc(&s->d_stage, sizeof(double) * n * kStageWidth));
   HIP_NEW(hipMalloc(&s->d_stage2, sizeof(double) * n * 32));
   HIP_NEW(hipMalloc(&s->d_bytes, n * 16));
   HIP_NEW(hipMalloc(&s->d_mask, n));

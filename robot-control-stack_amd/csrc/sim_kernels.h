@@ -725,13 +725,13 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   double* const bs = lbox + ((BOX || CON) ? team * kBoxLds : 0);
   if constexpr (CON && !BOX) {
     // the phantom box: at rest where the host parked it
-    for (int k = t; k < kBoxState; k += kTeamLanes) bs[k] = k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre ? lbt[0].box.qpos0[k - kBoxPre] : 0.0);
+    for (int k = t; k < kBoxState; k += kTeamLanes) bs[k] = k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre && k < kBoxPre + 7 ? lbt[0].box.qpos0[k - kBoxPre] : 0.0);
   }
   if constexpr (BOX) {
     if (live) {
       using L = Lay<T>;
       for (int k = t; k < kBoxState; k += kTeamLanes)
-        bs[k] = op.do_reset ? (k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre ? lbt[0].box.qpos0[k - kBoxPre] : 0.0))
+        bs[k] = op.do_reset ? (k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre && k < kBoxPre + 7 ? lbt[0].box.qpos0[k - kBoxPre] : 0.0))
                             : P.S[(size_t)(L::BOX + k) * P.n + e];  // Sim::reset: mj_resetData
     }
   }

@@ -695,6 +695,72 @@ def run_grasp_parity(n_envs=4, seed=0, swing_up=True):
     return rep
 
 
+def run_hard_pinch_parity(chunks=(1, 20, 60)):
+    """The cube placement of tests/test_contacts_cpu.py::HARD_PINCH_PLACEMENT (found at batch scale: the coupled Newton solve
+    of its closing pads is the hardest of 4096 random placements) among ordinary ones, pinched with the closing stage cut into
+    launches of different lengths.  The robot's warm start inside a launch is not the one a fresh launch has (DESIGN design
+    point 12), so the iterates differ between the splits: the RESULT must not.  Every split against the oracle."""
+    import dataclasses
+
+    from rcs_amd import common
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import FR3_Q_HOME
+    from test_contacts_cpu import HARD_PINCH_PLACEMENT
+
+    n = 4
+    qb = _pinch_placements(n, 3)
+    qb[0] = HARD_PINCH_PLACEMENT
+    cfg = dataclasses.replace(default_sim_robot_cfg("fr3_simple_pick_up"), tcp_offset=common.Pose(common.FrankaHandTCPOffset()))
+    cm = compile_mjcf(PICKUP_SCENE)
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, O.franka_hand_tcp_offset(), "finger_joint1_0", "actuator8_0") for _ in range(n)]
+    for e, o in enumerate(osims):
+        o.reset(); o.robot_reset(); o.gripper_reset()
+        o.box_qpos = qb[e]
+        o.step(1)
+    home = osims[0].get_cartesian_position()
+    rep = {"max_newton": 0, "splits": {}}
+    for o in osims:
+        o.gripper_open()
+        for xyz, k in (([0.44, 0.1, 0.20], 400), ([0.44, 0.1, 0.035], 600)):
+            o.set_cartesian_position(O.Pose(translation=np.array(xyz), quaternion=home.rotation_q()))
+            o.step(k)
+        o.gripper_grasp()
+        for _ in range(120):
+            o.step(1)
+            if o.s.d.coupled:
+                rep["max_newton"] = max(rep["max_newton"], int(o.s.d.solver_niter))
+    for ch in chunks:
+        simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+        if KERNEL != "auto":
+            simu.set_kernel(KERNEL)
+        robot = S.SimRobot(simu, None, cfg)
+        grip = S.SimGripper(simu, default_sim_gripper_cfg())
+        simu.reset(); robot.reset(); grip.reset()
+        simu.set_free_joint_qpos("box_joint", qb)
+        simu.step(1)
+        grip.open()
+        for xyz, k in (([0.44, 0.1, 0.20], 400), ([0.44, 0.1, 0.035], 600)):
+            robot.set_cartesian_position(np.tile(np.concatenate([xyz, home.rotation_q()]), (n, 1)))
+            simu.step(k)
+        grip.shut()
+        for i in range(0, 120, ch):
+            simu.step(min(ch, 120 - i))
+        q, v, bq, bv = simu.qpos, simu.qvel, simu.free_joint_qpos("box_joint"), simu.free_joint_qvel("box_joint")
+        rep["splits"][ch] = {
+            "qpos": max(float(np.abs(q[e] - np.asarray(o.qpos)).max()) for e, o in enumerate(osims)),
+            "qvel": max(float(np.abs(v[e] - np.asarray(o.qvel)).max()) for e, o in enumerate(osims)),
+            "box": max(float(np.abs(bq[e] - o.box_qpos).max()) for e, o in enumerate(osims)),
+            "box_vel": max(float(np.abs(bv[e] - o.box_qvel).max()) for e, o in enumerate(osims)),
+            "box_z": bq[:, 2].copy(),
+        }
+        simu.close()
+    return rep
+
+
 def run_pick_success_parity(n_envs=3, seed=0):
     """The registered pick-up task driven to SUCCESS: SimTaskEnvCreator with absolute joint actions (30 Hz async control), a
     scripted pinch-lift-swing; reward, `success` / `terminated`, is_grasped and the cube pose against the oracle's wrapper

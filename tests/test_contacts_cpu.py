@@ -143,6 +143,36 @@ def test_pinch_statics_and_lift():
     assert o.box_qpos[2] < 0.03  # released: back on the floor
 
 
+# a cube placement (2.75 mm / -1.15 mm off the closing axis, yawed 2.9 degrees) whose closing pads make the coupled solve hard:
+# found in a 4096-environment pinch (tools/grasp_bench.py), where the environment with it lost its cube
+HARD_PINCH_PLACEMENT = (0.44275289, 0.09885114, 0.0288, 0.02511928, 0.0, 0.0, 0.99968446)
+
+
+def test_line_search_does_not_cycle_on_a_hard_pinch():
+    """The exact line search is Newton on phi'(a), which is only piecewise smooth: on this pinch the plain iteration cycled
+    between two pieces (a ~ 0 and a ~ 1) until its cap and left the step at zero -- 35 Newton iterations from MuJoCo's warm
+    start, the 100-iteration cap (an unconverged solve) from others.  With the bracket's safeguard (bisect when the step does
+    not halve the one before last) the solve takes a handful of iterations from anywhere."""
+    o = _pick_sim()
+    o.box_qpos = np.array(HARD_PINCH_PLACEMENT)
+    home = o.get_cartesian_position()
+    o.gripper_open()
+    for xyz, k in (([0.44, 0.1, 0.20], 400), ([0.44, 0.1, 0.035], 600)):
+        o.set_cartesian_position(O.Pose(translation=np.array(xyz), quaternion=home.rotation_q()))
+        o.step(k)
+    o.gripper_grasp()
+    worst = 0
+    for _ in range(200):
+        o.step(1)
+        if o.s.d.coupled:
+            worst = max(worst, int(o.s.d.solver_niter))
+    assert 2 <= worst <= 12, worst
+    assert abs(o.box_qpos[2] - 0.02831) < 2e-4, o.box_qpos  # pinched a little into the floor's soft contact, not squashed through it
+    o.set_cartesian_position(O.Pose(translation=np.array([0.44, 0.1, 0.30]), quaternion=home.rotation_q()))
+    o.step(500)
+    assert o.box_qpos[2] > 0.28, o.box_qpos
+
+
 def test_pinch_slips_when_the_cube_is_too_heavy():
     """... and does NOT follow when m g > 2 mu N: the same pinch on a cube 100 times as dense (0.59 kg, 5.8 N against at most
     4 x 0.8 N of friction) leaves it on the floor."""

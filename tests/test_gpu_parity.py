@@ -871,6 +871,19 @@ def test_grasp_lift_swing_matches_oracle(kernel):
     assert ((st["held"]["width"] > 0.3) & (st["held"]["width"] < 0.5)).all(), st                  # fingers stopped by the 32 mm cube
 
 
+def test_hard_pinch_is_independent_of_the_launch_split(kernel):
+    """A placement whose closing pads made the coupled solve's line search cycle (tests/test_contacts_cpu.py): inside a
+    launch of several substeps the solve started from the previous minimiser, stalled, and the cube was squashed through the
+    floor, while launches of one substep agreed with the oracle.  Any split must, now that the line search is safeguarded."""
+    from parity_util import run_hard_pinch_parity
+
+    rep = run_hard_pinch_parity()
+    assert 2 <= rep["max_newton"] <= 12, rep
+    for ch, r in rep["splits"].items():
+        assert r["qpos"] < 1e-9 and r["qvel"] < 1e-7 and r["box"] < 1e-8 and r["box_vel"] < 1e-6, (ch, rep)
+        assert (r["box_z"] > 0.0275).all(), (ch, rep)
+
+
 def test_pick_task_reaches_success(kernel):
     """rcs/FR3SimplePickUpSim-v0's wrapper stack (RandomCubePos, PickCubeSuccessWrapper) with absolute joint actions: the
     scripted pinch ends in `success` / `terminated` with reward 1, in the kernel and in the oracle alike."""
