@@ -1540,6 +1540,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     }
   }
   bool at_x = false;  // jar / f / Hc are those of ar.X
+  int newton_done = 100;  // iterations the loop took (100: ran into its cap)
   for (int newton_it = 0; newton_it < 100; ++newton_it) {
     TEAM_MARK(55)
     TEAM_COUNT(29)
@@ -1553,7 +1554,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     const double qf = contact_qfrc<T>(ar, st, c, f, bmasks, bR, bp, lane);
     if (lane < NV) { gl -= qf; ar.Gd[lane] = gl; }
     const double g2 = wave_sum(lane < NV ? gl * gl : 0.0);
-    if (b.scale * sqrt(g2) < 1e-12) break;
+    if (b.scale * sqrt(g2) < 1e-12) { newton_done = newton_it; break; }
     TEAM_MARK(48)
     // ---- contact stiffness K_c = G' Hc G (6 x 6 symmetric, 21 entries), summed per body pair through LDS in three
     // batches of seven entries: accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
@@ -1709,7 +1710,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
       if (lane < NV) ar.P[lane] = acc;
     }
     TEAM_MARK(52)
-    if (!(dphi0 < 0)) break;
+    if (!(dphi0 < 0)) { newton_done = 1000 + newton_it; break; }
     __syncthreads();
     body_spatial<T>(st, ar.P, bR, bp, ar.Up, lane);
     __syncthreads();
@@ -1789,6 +1790,16 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     at_x = false;
     __syncthreads();
   }
+#ifdef RCSH_PHASE_TIMING
+  if (lane == 0) {  // (every workgroup) worst iteration count, solves over 20 iterations, capped solves, solves that left on a non-descent direction
+    atomicMax(&g_team_cycles[56], (unsigned long long)(newton_done % 1000));
+    if (newton_done % 1000 > 20) atomicAdd(&g_team_cycles[57], 1ull);
+    if (newton_done == 100) atomicAdd(&g_team_cycles[58], 1ull);
+    if (newton_done >= 1000) atomicAdd(&g_team_cycles[59], 1ull);
+    atomicAdd(&g_team_cycles[60], 1ull);
+  }
+#endif
+  (void)newton_done;
   // forces at the solution -> records (the loop's last evaluation unless it ran into its cap)
   if (!at_x) eval_rows(ar.U, jar, f, Hc);
   if (lane < NV) bs[kBoxX + lane] = ar.X[lane];
