@@ -1076,3 +1076,58 @@ def run_cube_against_base_parity(n_envs=12, n_calls=6, k=25, seed=5):
     rep["final_radius"] = np.hypot(qk[:, 0], qk[:, 1])
     simu.close()
     return rep
+
+
+def batch_pinch(n, chunk, seed=0, spread=0.004, yaw=0.1):
+    """One scripted pinch / lift / release of `n` environments at once, stepping in launches of `chunk` substeps; the state
+    after each stage."""
+    import dataclasses
+
+    from rcs_amd import common
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+
+    cfg = dataclasses.replace(default_sim_robot_cfg("fr3_simple_pick_up"), tcp_offset=common.Pose(common.FrankaHandTCPOffset()))
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    rng = np.random.default_rng(seed)
+    qb = np.tile(np.array([0.44, 0.1, 0.0288, 0, 0, 0, 1.0]), (n, 1))
+    qb[1:, 0] += rng.uniform(-spread, spread, n - 1)
+    qb[1:, 1] += rng.uniform(-spread, spread, n - 1)
+    y = np.zeros(n); y[1:] = rng.uniform(-yaw, yaw, n - 1)
+    qb[:, 3], qb[:, 6] = np.cos((np.pi + y) / 2), np.sin((np.pi + y) / 2)
+    simu.reset(); robot.reset(); grip.reset()
+    simu.set_free_joint_qpos("box_joint", qb)
+    simu.step(1)
+    home = np.asarray(robot.get_cartesian_position())[0, 3:]
+
+    def run(k):
+        for i in range(0, k, chunk):
+            simu.step(min(chunk, k - i))
+
+    out = {}
+    robot.set_cartesian_position(np.tile(np.concatenate([[0.44, 0.1, 0.2], home]), (n, 1))); run(400)
+    robot.set_cartesian_position(np.tile(np.concatenate([[0.44, 0.1, 0.035], home]), (n, 1))); run(600)
+    grip.shut(); run(200)
+    out["closed"] = (simu.qpos.copy(), simu.free_joint_qpos("box_joint").copy())
+    robot.set_cartesian_position(np.tile(np.concatenate([[0.44, 0.1, 0.3], home]), (n, 1))); run(500)
+    out["lifted"] = (simu.qpos.copy(), simu.free_joint_qpos("box_joint").copy())
+    grip.open(); run(300)
+    out["released"] = (simu.qpos.copy(), simu.free_joint_qpos("box_joint").copy())
+    simu.close()
+    return out
+
+
+def run_split_consistency(n=4096, ca=17, cb=100, **kw):
+    """The same pinch at batch scale with the stepping cut into launches of different lengths, kernel against kernel.  The
+    coupled solve's starting point inside a launch differs from a fresh launch's, so equal results for every environment say
+    that every solve of every environment reached its minimiser (no stalled or capped Newton solve anywhere)."""
+    a, b = batch_pinch(n, ca, **kw), batch_pinch(n, cb, **kw)
+    rep = {}
+    for tag in a:
+        dq = np.abs(a[tag][0] - b[tag][0]).max(axis=1)
+        db = np.abs(a[tag][1] - b[tag][1]).max(axis=1)
+        rep[tag] = {"max_dq": float(dq.max()), "max_dbox": float(db.max()), "envs_over_1e-8": int(((dq > 1e-8) | (db > 1e-8)).sum()),
+                    "worst_env": int(np.argmax(np.maximum(dq, db))), "box_z": (float(a[tag][1][:, 2].min()), float(a[tag][1][:, 2].max()))}
+    return rep

@@ -884,6 +884,19 @@ def test_hard_pinch_is_independent_of_the_launch_split(kernel):
         assert (r["box_z"] > 0.0275).all(), (ch, rep)
 
 
+def test_batch_scale_pinch_is_launch_split_independent(kernel):
+    """BASELINE's batch size, every environment in contact at once: 4096 cubes at random offsets pinched, lifted and released
+    with the stepping cut into launches of 17 and of 100 substeps.  Inside a launch the coupled solve starts elsewhere than
+    after a fresh launch, so agreement of EVERY environment says that none of the ~2.7 million solves stalled or ran into its
+    cap -- a property the oracle cannot check at this size (the first run of this kind found the line search's cycle)."""
+    from parity_util import run_split_consistency
+
+    rep = run_split_consistency(4096, 17, 100)
+    for tag, r in rep.items():
+        assert r["envs_over_1e-8"] == 0 and r["max_dq"] < 1e-10 and r["max_dbox"] < 1e-9, (tag, rep)
+    assert rep["closed"]["box_z"][0] > 0.027 and rep["lifted"]["box_z"][0] > 0.28 and rep["released"]["box_z"][1] < 0.03, rep
+
+
 def test_pick_task_reaches_success(kernel):
     """rcs/FR3SimplePickUpSim-v0's wrapper stack (RandomCubePos, PickCubeSuccessWrapper) with absolute joint actions: the
     scripted pinch ends in `success` / `terminated` with reward 1, in the kernel and in the oracle alike."""
