@@ -8,6 +8,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "robot-control-stack_amd"), os.path.join(ROOT, "tests")]
+import rcs_amd._lib as _lib
+if os.environ.get("RCSH_LIB"): _lib.LIB_PATH = os.environ["RCSH_LIB"]
 from rcs_amd import common
 from rcs_amd import sim as S
 from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
