@@ -829,14 +829,18 @@ RCSH_D double cone_eval(const double* D, double mu, double fr, const double* jar
 }
 
 // mju_QCQP2 with separate friction coefficients (oracle: qcqp2)
-RCSH_D bool qcqp2_dev(double* res, double A00, double A01, double A11, double b0, double b1, double d0, double d1, double r) {
+// det0 / di0: the caller's S11 S22 - S12^2 (multiplier 0) and its reciprocal when it has them (the noslip sweeps, where A
+// and d stay the same update after update), NaN otherwise
+RCSH_D bool qcqp2_dev(double* res, double A00, double A01, double A11, double b0, double b1, double d0, double d1, double r,
+                      double det0 = __builtin_nan(""), double di0 = 0.0) {
   const double s1 = b0 * d0, s2 = b1 * d1;
   const double S11 = A00 * d0 * d0, S22 = A11 * d1 * d1, S12 = A01 * d0 * d1;
   double la = 0, v1 = 0, v2 = 0;
   for (int iter = 0; iter < 20; ++iter) {
-    const double det = (S11 + la) * (S22 + la) - S12 * S12;
+    const bool given = iter == 0 && det0 == det0;
+    const double det = given ? det0 : (S11 + la) * (S22 + la) - S12 * S12;
     if (det < 1e-10) { res[0] = res[1] = 0; return false; }
-    const double di = 1 / det, P11 = (S22 + la) * di, P22 = (S11 + la) * di, P12 = -S12 * di;
+    const double di = given ? di0 : 1 / det, P11 = (S22 + la) * di, P22 = (S11 + la) * di, P12 = -S12 * di;
     v1 = -P11 * s1 - P12 * s2;
     v2 = -P12 * s1 - P22 * s2;
     const double val = v1 * v1 + v2 * v2 - r * r;
@@ -1416,6 +1420,13 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
 #pragma unroll
       for (int j = 0; j <= i; ++j) LM[tri(i, j)] = st.M(i, j);
     ldl_factor<NL>(LM);
+    // (the factor stays for the noslip pass where the bodies' velocities were: the rows above are done with them)
+    static_assert(sizeof(ar.V) >= sizeof(double) * T::NTRI, "the factor of M fits the velocities' area");
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < T::NTRI; ++k) (&ar.V[0][0])[k] = LM[k];
+    }
 #pragma unroll
     for (int i = 0; i < NL; ++i) a0[i] = st.smooth(i);
     ldl_solve<NL>(LM, a0);
@@ -1837,15 +1848,11 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
     double (*Y)[NL][6] = reinterpret_cast<double (*)[NL][6]>(&ar.stage[0][0]);
     static_assert(kMaxActive * NL * 6 <= 64 * 8, "Y fits the stage area");
     {
-      double LM[T::NTRI];
-#pragma unroll
-      for (int i = 0; i < NL; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) LM[tri(i, j)] = st.M(i, j);
-      ldl_factor<NL>(LM);
       if (lane < 6 * nact) {
         const int a = lane / 6, k = lane % 6, lk = ar.act[a];
-        double col[NL];
+        double LM[T::NTRI], col[NL];  // (M's factor: left in ar.V by contact_newton)
+#pragma unroll
+        for (int e = 0; e < T::NTRI; ++e) LM[e] = (&ar.V[0][0])[e];
 #pragma unroll
         for (int j = 0; j < NL; ++j) col[j] = is_anc<T>(j, lk) ? st.S(j, k) : 0.0;
         ldl_solve<NL>(LM, col);
@@ -1854,54 +1861,6 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
       }
     }
     __syncthreads();
-    // response of the bodies' accelerations to a wrench w on body B and -w on body A, as seen by the pair itself:
-    // rel = dU_B - dU_A (every lane for its own contact, no exchange)
-    int aA = -1, aB = -1;
-    for (int a = 0; a < nact; ++a) {
-      if (ar.act[a] == c.A) aA = a;
-      if (ar.act[a] == c.B) aB = a;
-    }
-    const bool boxed = c.A == kBox || c.B == kBox;
-    auto pair_response = [&](const double* w, double* rel) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) rel[k] = 0.0;
-      if (aA >= 0 || aB >= 0) {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-          const double sg = (c.B < NL && is_anc<T>(j, c.B) ? 1.0 : 0.0) - (c.A < NL && is_anc<T>(j, c.A) ? 1.0 : 0.0);
-          if (sg == 0.0) continue;
-          double dx = 0;
-          if (aB >= 0) dx += dot6(Y[aB][j], w);
-          if (aA >= 0) dx -= dot6(Y[aA][j], w);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) rel[k] += sg * st.S(j, k) * dx;
-        }
-      }
-      if (boxed) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          double col[6];
-          box_column(bR, bp, k, col);
-          const double q = Mbi[k] * dot6(col, w);
-#pragma unroll
-          for (int m = 0; m < 6; ++m) rel[m] += col[m] * q;
-        }
-      }
-    };
-    // the 3 x 3 block of A = J M^-1 J' (no regulariser) of the lane's own contact
-    double Ac[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) Ac[r][k] = 0.0;
-    if (c.on) {
-      for (int kk = 0; kk < 3; ++kk) {
-        double rel[6];
-        pair_response(c.G[kk], rel);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Ac[r][kk] = dot6(c.G[r], rel);
-      }
-    }
     // The sweeps move wrenches on few bodies -- the links in contact (slots 0..nact-1) and the cube (slot kMaxActive) -- and
     // read only those bodies' accelerations.  Lane 6 s + k keeps component k of the CHANGE of slot s's acceleration in a
     // register; K[s][t] = S_s M^-1 S_t' (6 x 6, from Y) says what a wrench on slot t does to slot s, the cube answers with
@@ -1909,7 +1868,8 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
     // its friction rows, hands the wrench change back across the lanes, and the slot lanes add their row of K times it:
     // no barrier and no pass over the kinematic tree per contact.
     double (*Kl)[kMaxActive][6][6] = reinterpret_cast<double (*)[kMaxActive][6][6]>(&ar.rec[0][0]);  // (the records are in the lanes by now)
-    static_assert(sizeof(ar.rec) >= sizeof(double) * kMaxActive * kMaxActive * 36, "K fits the records' area");
+    double (*Kbox)[6] = reinterpret_cast<double (*)[6]>(&ar.rec[0][0] + kMaxActive * kMaxActive * 36);  // the cube's own block
+    static_assert(sizeof(ar.rec) >= sizeof(double) * (kMaxActive * kMaxActive + 1) * 36, "K fits the records' area");
     double kb[6] = {0, 0, 0, 0, 0, 0};  // slot lanes of the cube: their row of S_box M_box^-1 S_box'
     if (lane < 6 * nact) {
       const int sl = lane / 6, k = lane % 6, lk = ar.act[sl];
@@ -1943,6 +1903,36 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
       return sl;
     };
     const int my_slots = (slot_of(c.A) & 0xff) | (slot_of(c.B) & 0xff) << 8;  // (0xff: the world, or a link beyond the kept ones)
+    if (lane >= 6 * kMaxActive && lane < 6 * kMaxActive + 6) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) Kbox[lane - 6 * kMaxActive][m] = kb[m];
+    }
+    __syncthreads();
+    // the 3 x 3 block of A = J M^-1 J' (no regulariser) of the lane's own contact: a wrench w on body B and -w on body A moves
+    // the pair's relative acceleration by (K_BB + K_AA) w (a link and the cube, or the world, do not see each other in M^-1)
+    double Ac[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Ac[r][k] = 0.0;
+    if (c.on) {
+      for (int side = 0; side < 2; ++side) {
+        const int sl = (my_slots >> (8 * side)) & 0xff;
+        if (sl == 0xff) continue;
+        const double (*Km)[6] = sl == kMaxActive ? Kbox : Kl[sl][sl];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          double rel[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) rel[k] = dot6(Km[k], c.G[kk]);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) Ac[r][kk] += dot6(c.G[r], rel);
+        }
+      }
+    }
+    // the friction rows' unconstrained solve (the first pass of the QCQP: multiplier 0) needs the inverse of its scaled block only
+    const double qS11 = Ac[1][1] * c.fr * c.fr, qS22 = Ac[2][2] * c.fr * c.fr, qS12 = Ac[1][2] * c.fr * c.fr;
+    const double qdet = qS11 * qS22 - qS12 * qS12, qdi = 1 / qdet;
     double rel0[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) rel0[k] = ar.U[c.B][k] - ar.U[c.A][k];
@@ -1987,7 +1977,7 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
           } else {
             const double b1 = res[1] - Ac[1][1] * old[1] - Ac[1][2] * old[2], b2 = res[2] - Ac[2][1] * old[1] - Ac[2][2] * old[2];
             double vv[2];
-            if (qcqp2_dev(vv, Ac[1][1], Ac[1][2], Ac[2][2], b1, b2, c.fr, c.fr, old[0])) {
+            if (qcqp2_dev(vv, Ac[1][1], Ac[1][2], Ac[2][2], b1, b2, c.fr, c.fr, old[0], qdet, qdi)) {
               double s = vv[0] * vv[0] / (c.fr * c.fr) + vv[1] * vv[1] / (c.fr * c.fr);
               s = sqrt(old[0] * old[0] / (s > kMinVal ? s : kMinVal));
               vv[0] *= s; vv[1] *= s;
