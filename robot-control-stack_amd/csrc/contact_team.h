@@ -1017,8 +1017,14 @@ RCSH_D double contact_qfrc(AR& ar, const StageTeam<T>& st, const ConLane& c, con
 // Second level of the broad phase, run by the lane of a link whose bounding box reached the floor or the cube: the same
 // tests on the bounding boxes of the link's GEOMS (boxes: the geom itself; hulls: the box of its vertices; capsule: its box).
 // Only then does the wavefront gang up on the environment.  R, p: world frame of the link.
+// `boxs`: the cube's LDS block (its pose and velocity), `box_half`: its half sizes.  Against the cube the geom's box must come
+// within the cube's bounding sphere and then overlap the cube itself (separating axes of the two boxes): fingers that
+// straddle the cube without touching it leave the wavefront alone.
 RCSH_CONTACT_FN bool geom_level_near(const ContactGeom* geoms, int g0, int g1, const double* R, const double* p, const double* pln, double pld,
-                                     bool has_plane, const double* boxc, double box_r2, bool has_box) {
+                                     bool has_plane, const double* boxs, double box_r2, bool has_box, const double* box_half) {
+  const double* boxc = boxs + kBoxQ;
+  double bp[3], bR[9], bv[6];
+  bool have_frame = false;
   for (int g = g0; g < g1; ++g) {
     const ContactGeom& cg = geoms[g];
     double gR[9], c[3], h[3], lc[3];
@@ -1041,7 +1047,10 @@ RCSH_CONTACT_FN bool geom_level_near(const ContactGeom* geoms, int g0, int g1, c
       double v[3];
       mulTv(gR, d, v);
       const double ex = fmax(fabs(v[0]) - h[0], 0.0), ey = fmax(fabs(v[1]) - h[1], 0.0), ez = fmax(fabs(v[2]) - h[2], 0.0);
-      if (ex * ex + ey * ey + ez * ez <= box_r2) return true;
+      if (ex * ex + ey * ey + ez * ez <= box_r2) {
+        if (!have_frame) { box_frame(boxs, bp, bR, bv); have_frame = true; }
+        if (!obb_disjoint(gR, c, h, bR, bp, box_half)) return true;
+      }
     }
   }
   return false;
@@ -1066,14 +1075,29 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
   TEAM_MARK(24)
   TEAM_COUNT(33)
   // ---- link frames at the pre-step configuration: lane i < NL walks the chain to link i
+  // (every lane its own joint's local frame once, through the stage area; then the products down the chain)
+  double (*loc)[12] = reinterpret_cast<double (*)[12]>(&ar.stage[0][0]);
+  static_assert(sizeof(ar.stage) >= sizeof(double) * 12 * NL, "the links' local frames fit the stage area");
+  if (lane < NL) {
+    KinK kk;
+    kk.load(links[lane]);
+    double Rl[9], pl[3];
+    link_local_frame(kk, st.q(lane), Rl, pl);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) loc[lane][k] = Rl[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) loc[lane][9 + k] = pl[k];
+  }
+  __syncthreads();
   if (lane < NL) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
     for (int i = 0; i < NL; ++i) {
       if (!is_anc<T>(i, lane)) continue;
-      KinK kk;
-      kk.load(links[i]);
       double Rl[9], pl[3], pn[3];
-      link_local_frame(kk, st.q(i), Rl, pl);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rl[k] = loc[i][k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pl[k] = loc[i][9 + k];
       mulmv(R, pl, pn);
       p[0] += pn[0]; p[1] += pn[1]; p[2] += pn[2];
       mulmm(R, Rl, R);

@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
           }
           // second level: the same tests on the boxes of the link's geoms
           if (near)
-            near = geom_level_near(lp.ctab.geoms, lp.ctab.link_geom_adr[t], lp.ctab.link_geom_adr[t + 1], R, p, pln, pld, has_plane, bs + kBoxQ, box_r2, BOX);
+            near = geom_level_near(lp.ctab.geoms, lp.ctab.link_geom_adr[t], lp.ctab.link_geom_adr[t + 1], R, p, pln, pld, has_plane, bs, box_r2, BOX, lbt[0].box.size);
         }
         if constexpr (BOX) {
           if (stepping && con_lane && t == T::NL) {
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
                          ez = fmax(fabs(bs[kBoxQ + 2] - bbc[2]) - bbh[2], 0.0);
             if (ex * ex + ey * ey + ez * ez <= box_r2) {
               const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
-              near = geom_level_near(lp.ctab.geoms, 0, lp.ctab.link_geom_adr[0], I9, z3, pln, pld, false, bs + kBoxQ, box_r2, true);
+              near = geom_level_near(lp.ctab.geoms, 0, lp.ctab.link_geom_adr[0], I9, z3, pln, pld, false, bs, box_r2, true, lbt[0].box.size);
             }
           }
         }
