@@ -74,7 +74,7 @@ struct Lay {
   static constexpr int PREVA = SITE + 12;        // RobotEnv.prev_action (7 wide: joints or tquat)
   static constexpr int ORIGIN = PREVA + 7;       // RelativeActionSpace._origin
   static constexpr int LASTA = ORIGIN + 7;       // RelativeActionSpace._last_action
-  static constexpr int BOX = LASTA + 7;           // free box (box_team.h): qpos 7, qvel 6, qacc_warmstart 6, pose seen by the last position stage 7
+  static constexpr int BOX = LASTA + 7;           // free box (box_team.h): qpos 7, qvel 6, qacc_warmstart 6, pose seen by the last position stage 7, minimiser of the last coupled solve 15
   static constexpr int QPRE = BOX + kBoxState;    // qpos seen by the last mj_step1 (what mjData.xpos / geom_xpos / cam_xpos derive from: the renderer's frames)
   static constexpr int COUNT = QPRE + T::NL;
 };
