@@ -863,7 +863,8 @@ def test_grasp_lift_swing_matches_oracle(kernel):
 
     rep = run_grasp_parity(n_envs=4, seed=0)
     assert rep["max_ncon"] >= 36 and rep["coupled_substeps"] > 1000 and rep["max_noslip"] >= 1, rep
-    assert rep["max_abs_qpos"] < 1e-8 and rep["max_abs_qvel"] < 1e-6 and rep["max_abs_box"] < 1e-7 and rep["max_abs_box_vel"] < 1e-5, rep
+    # (measured 7e-13 / 2e-12 / 6e-10 / 2e-8 over three seeds of eight environments: profiles/r2_soak_parity.log)
+    assert rep["max_abs_qpos"] < 1e-10 and rep["max_abs_qvel"] < 1e-9 and rep["max_abs_box"] < 1e-8 and rep["max_abs_box_vel"] < 5e-7, rep
     assert rep["flag_mismatches"] == 0, rep
     st = rep["stages"]
     assert (st["closed"]["box_z"] < 0.03).all() and (st["lifted"]["box_z"] > 0.28).all(), st       # on the floor, then in the hand
