@@ -33,12 +33,6 @@ namespace rcsh {
 
 #if defined(__HIP__)
 
-// A pointer handed to a non-inlined function has lost its address space: the compiler would reach LDS through flat
-// instructions.  The round trip through an LDS-qualified pointer tells it (InferAddressSpaces) where the memory is.
-template <class P>
-RCSH_D P* in_lds(P* p) {
-  return (P*)(__attribute__((address_space(3))) P*)p;
-}
 
 // The contact phase is split into three non-inlined functions (collision, Newton, noslip) that hand their state over in
 // LDS: each gets a register allocation of its own instead of one that must hold everything at once.

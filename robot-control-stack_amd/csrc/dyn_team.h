@@ -238,7 +238,9 @@ RCSH_D void newton_rows(const LinkRec* links, const StageTeam<T>& st, uint32_t l
       else if (jf >= fR[i]) fpos |= 1u << i;
     }
   bool have_x = false;
+  int iters_done = 0;
   for (int iter = 0; iter < 32; ++iter) {
+    iters_done = iter + 1;
     double xn[NL];
     {
       double H[T::NTRI];
@@ -384,6 +386,16 @@ RCSH_D void newton_rows(const LinkRec* links, const StageTeam<T>& st, uint32_t l
       }
     }
   }
+#ifdef RCSH_PHASE_TIMING
+  if ((threadIdx.x & 15) == 0) {  // (every team) solves, their iterations, the worst, solves over 4 / at the cap
+    atomicAdd(&g_team_cycles[44], 1ull);
+    atomicAdd(&g_team_cycles[45], (unsigned long long)iters_done);
+    atomicMax(&g_team_cycles[46], (unsigned long long)iters_done);
+    if (iters_done > 4) atomicAdd(&g_team_cycles[47], 1ull);
+    if (iters_done >= 32) atomicAdd(&g_team_cycles[43], 1ull);
+  }
+#endif
+  (void)iters_done;
 }
 
 // ---- per-lane model constants, fetched from the LDS model tables in one batch per phase.  A batch is issued
@@ -776,6 +788,16 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
   const bool fast = nrows <= 3 && !FRIC;
   const bool solver_lane = fast && t < (1 << nrows);
   double H[T::NTRI], x[NL];
+  // (dry friction: the lane's candidate -- friction rows at +frictionloss / at -frictionloss, limit rows active -- and the rows' data)
+  uint32_t frows = 0, c_neg = 0, c_pos = 0, c_act = 0;
+  bool cand_lane = false;
+  double fFv[FRIC ? NL : 1], fDv[FRIC ? NL : 1], fRv[FRIC ? NL : 1], fAv[FRIC ? NL : 1];
+  // (dry friction: the slot runs up to kFricRounds times -- a round without a self-consistent candidate hands the zones lane 0's
+  // solution landed in to the next one as its base, which is what the serial iteration's next step would solve)
+  constexpr int kFricRounds = 4;
+  uint32_t b_neg = 0, b_pos = 0, b_act = 0, winners = 0;
+  double xprev[FRIC ? NL : 1];
+  for (int round = 0; round < (FRIC ? kFricRounds : 1); ++round) {
 #pragma unroll
   for (int i = 0; i < NL; ++i)
 #pragma unroll
@@ -792,7 +814,39 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     const int unit = FRIC ? -1 : (t == kTeamLanes - 3 ? idx0 : (t == kTeamLanes - 4 ? idx1 : (t == kTeamLanes - 5 ? idx2 : -1)));
     const bool eq_helper = !FRIC && T::GRIP && t == kTeamLanes - 2;
     const double wh = helper_lane ? 1.0 : 0.0, ws = (!helper_lane || t == kTeamLanes - 1) ? 1.0 : 0.0;
-    const uint32_t guess = helper_lane ? 0u : act;
+    if constexpr (FRIC) {
+      // Dry friction: three zones per row are too many to enumerate, but the zones rarely move by more than one row from one
+      // substep to the next.  Lane 0 takes the zones of the previous substep's solution (friction rows and limit rows alike),
+      // lanes 1..14 the same with ONE friction row moved to one of its two other zones (joint (t - 1) / 2, alternative
+      // (t - 1) % 2); a lane whose solution lands in the zones it assumed has the minimiser of the convex cost.  Nobody:
+      // newton_rows below, as before.
+      frows = 0; c_neg = 0; c_pos = 0; c_act = 0; cand_lane = false;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        fFv[i] = links[i].fl_floss; fDv[i] = links[i].fl_D; fRv[i] = links[i].fl_R; fAv[i] = st.fa(i);
+        const double xw = st.xs(i), jf = xw - fAv[i];
+        if (fFv[i] > 0) {
+          frows |= 1u << i;
+          if (jf <= -fRv[i]) c_neg |= 1u << i;
+          else if (jf >= fRv[i]) c_pos |= 1u << i;
+        }
+        if (((limrows >> i) & 1u) && lSv[i] * xw - lAv[i] < 0) c_act |= 1u << i;
+      }
+      if (round > 0) { c_neg = b_neg; c_pos = b_pos; c_act = b_act; }
+      if (t == 0) cand_lane = true;
+      else if (t < kTeamLanes - 1) {
+        const int j = (t - 1) >> 1, alt = (t - 1) & 1;
+        const uint32_t bit = j < NL ? 1u << j : 0u;
+        if (frows & bit) {
+          const int zone0 = (c_neg & bit) ? 0 : ((c_pos & bit) ? 2 : 1);                // 0: f = +frictionloss, 1: quadratic, 2: f = -frictionloss
+          const int zone1 = alt == 0 ? (zone0 == 0 ? 1 : 0) : (zone0 == 2 ? 1 : 2);
+          c_neg = (c_neg & ~bit) | (zone1 == 0 ? bit : 0u);
+          c_pos = (c_pos & ~bit) | (zone1 == 2 ? bit : 0u);
+          cand_lane = true;
+        }
+      }
+    }
+    const uint32_t guess = helper_lane ? 0u : (FRIC ? c_act : act);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const bool on = (guess >> i) & 1u;
@@ -801,6 +855,13 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
       double xi = fma(ws, sm[i], dsolve * (lSv[i] * lAv[i]));
       if (i == unit) xi = 1.0;
       if (T::GRIP && eq_helper && (i == NA || i == NA + 1)) xi = i == NA ? 1.0 : eqJ1;
+      if constexpr (FRIC) {
+        if (!helper_lane && ((frows >> i) & 1u)) {
+          if ((c_neg >> i) & 1u) xi += fFv[i];
+          else if ((c_pos >> i) & 1u) xi -= fFv[i];
+          else { H[tri(i, i)] += fDv[i]; xi += fDv[i] * fAv[i]; }
+        }
+      }
       x[i] = xi;
     }
   }
@@ -825,7 +886,50 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     for (int i = 0; i < NL; ++i)
       if (((limrows >> i) & 1u) && lSv[i] * x[i] - lAv[i] < 0) now |= 1u << i;
   }
-  const uint32_t winners = coupled ? 0u : team_ballot(solver_lane && now == act);
+  bool hit_guess = solver_lane && now == act;
+  if constexpr (FRIC) {
+    uint32_t nneg = 0, npos = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      if ((frows >> i) & 1u) {
+        const double jf = x[i] - fAv[i];
+        if (jf <= -fRv[i]) nneg |= 1u << i;
+        else if (jf >= fRv[i]) npos |= 1u << i;
+      }
+    hit_guess = cand_lane && now == c_act && nneg == c_neg && npos == c_pos;
+    // the next round's base: where lane 0's solution landed -- from the third round on, where the point half way between its
+    // last two solutions lies (two zone sets that send the solve to each other enclose the minimiser between their solutions)
+    uint32_t zn = nneg, zp = npos, za = now;
+    if (round > 0) {
+      zn = 0; zp = 0; za = 0;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const double xm = 0.5 * (x[i] + xprev[i]);
+        if ((frows >> i) & 1u) {
+          const double jf = xm - fAv[i];
+          if (jf <= -fRv[i]) zn |= 1u << i;
+          else if (jf >= fRv[i]) zp |= 1u << i;
+        }
+        if (((limrows >> i) & 1u) && st.limS(i) * xm - st.limA(i) < 0) za |= 1u << i;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) xprev[i] = x[i];
+    const int l0 = (int)(threadIdx.x & 48u) << 2;
+    b_neg = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)zn);
+    b_pos = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)zp);
+    b_act = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)za);
+  }
+  winners = coupled ? 0u : team_ballot(hit_guess);
+  if (winners || coupled) break;
+  }  // (rounds)
+#ifdef RCSH_PHASE_TIMING
+  if (t == 0) {  // (every team of every workgroup) team-substeps / with a self-consistent candidate / wavefront-substeps that ran newton_rows
+    atomicAdd(&g_team_cycles[61], 1ull);
+    if (winners) atomicAdd(&g_team_cycles[62], 1ull);
+    if ((threadIdx.x & 63) == 0 && __ballot(!coupled && winners == 0)) atomicAdd(&g_team_cycles[63], 1ull);
+  }
+#endif
   const bool superpose = !FRIC && winners != 0;  // uniform within the team
   if (coupled) {
     // the contact phase solved the coupled problem: nothing to do here
@@ -839,7 +943,10 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     }
   } else {
     double xs[NL];
+    TEAM_MARK(41)
+    TEAM_COUNT(42)
     newton_rows<T, FRIC>(links, st, limrows, has_eq, eqD, eqAref, eqJ1, xs);
+    TEAM_MARK(40)
     if (t == 0) {
 #pragma unroll
       for (int i = 0; i < NL; ++i) st.xs(i) = xs[i];

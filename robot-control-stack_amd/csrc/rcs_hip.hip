@@ -416,6 +416,7 @@ int field_of(rcsh_sim* s, const char* name) {
     if (f == "lasta") return (int)L::LASTA;
     if (f == "box") return (int)L::BOX;
     if (f == "qpre") return (int)L::QPRE;
+    if (f == "xs") return (int)L::XS;
     return -1;
   });
 }
@@ -698,6 +699,7 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   if (!rc) rc = scatter_host(s, field_of(s, "ctrl"), s->nu, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "time"), 1, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "cb"), 6, z.data(), mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "xs"), s->nl, z.data(), mask);  // (mj_resetData: qacc_warmstart := 0)
   if (!rc && s->box.present) {
     std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
     for (int e = 0; e < s->n; ++e)

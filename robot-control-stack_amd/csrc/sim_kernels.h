@@ -76,7 +76,9 @@ struct Lay {
   static constexpr int LASTA = ORIGIN + 7;       // RelativeActionSpace._last_action
   static constexpr int BOX = LASTA + 7;           // free box (box_team.h): qpos 7, qvel 6, qacc_warmstart 6, pose seen by the last position stage 7, minimiser of the last coupled solve 15
   static constexpr int QPRE = BOX + kBoxState;    // qpos seen by the last mj_step1 (what mjData.xpos / geom_xpos / cam_xpos derive from: the renderer's frames)
-  static constexpr int COUNT = QPRE + T::NL;
+  static constexpr int XS = QPRE + T::NL;         // models with dry friction: the constraint solve's last solution (MuJoCo: qacc_warmstart) -- the
+                                                  // zones it sits in are the first guess of the next solve, also across launches
+  static constexpr int COUNT = XS + T::NL;
 };
 
 // PickCubeSuccessWrapper (reference python/rcs/envs/sim.py:386-431)
@@ -611,6 +613,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   double pre_time = 0, pre_cmd = 0, pre_width = 0;
   uint32_t pre_flags = 0;
   int32_t pre_conv = 0;
+  double xs_in = 0.0;
   if (live) {
 #pragma unroll
     for (int rd = 0; rd < SF::kRounds; ++rd) {
@@ -618,6 +621,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       int field = 0, slot = 0;
       SF::locate(k < nstaged ? k : 0, field, slot);
       staged[rd] = Pk.S[(size_t)field * Pk.n + e];
+    }
+    if constexpr (FRIC) {
+      if (t < T::NL && !opk.do_reset) xs_in = Pk.S[(size_t)(Lay<T>::XS + t) * Pk.n + e];  // (Sim::reset: mj_resetData zeroes the warm start)
     }
     if (opk.apply_action) {
       const StepInGlobal<T> gin{Pk, opk, e};
@@ -670,6 +676,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       int field = 0, slot = 0;
       SF::locate(k < nstaged ? k : 0, field, slot);
       if (k < nstaged) st.at(slot) = staged[rd];
+    }
+    if constexpr (FRIC) {
+      if (t < T::NL) st.xs(t) = xs_in;
     }
 #pragma unroll
     for (int rd = 0; rd < kInRounds; ++rd) {
@@ -965,6 +974,9 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
       int field = 0, slot = 0;
       SF::locate(k < nstaged ? k : 0, field, slot);
       if (k < nstaged) P.S[(size_t)field * P.n + e] = st.at(slot);
+    }
+    if constexpr (FRIC) {
+      if (t < T::NL) P.S[(size_t)(Lay<T>::XS + t) * P.n + e] = st.xs(t);
     }
   }
   if constexpr (BOX) {

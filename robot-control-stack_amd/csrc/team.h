@@ -79,6 +79,12 @@ RCSH_D double wave_read(double x, int src) {
   const int s = __builtin_amdgcn_readfirstlane(src);
   return mk64(__builtin_amdgcn_readlane(hi32(x), s), __builtin_amdgcn_readlane(lo32(x), s));
 }
+// A pointer handed to a non-inlined function has lost its address space: the compiler would reach LDS through flat
+// instructions.  The round trip through an LDS-qualified pointer tells it (InferAddressSpaces) where the memory is.
+template <class P>
+RCSH_D P* in_lds(P* p) {
+  return (P*)(__attribute__((address_space(3))) P*)p;
+}
 // 16-bit mask of the team's lanes for which `pred` holds
 RCSH_D uint32_t team_ballot(bool pred) {
   const uint64_t b = __ballot(pred);

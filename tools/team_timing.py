@@ -9,8 +9,8 @@ import numpy as np
 from parity_util import make_vec_env, synthetic_actions
 n, T = 4096, 20
 env = make_vec_env(n, True, robot=(sys.argv[1] if len(sys.argv) > 1 else "fr3"))
-j, g = synthetic_actions(64, T, 0, dof=env.dof)
-j = np.tile(j, (1, n // 64, 1)); g = np.tile(g, (1, n // 64))
+j, g = synthetic_actions(64 if os.environ.get("TILED", "1") == "1" else n, T, 0, dof=env.dof)
+if j.shape[1] != n: j = np.tile(j, (1, n // 64, 1)); g = np.tile(g, (1, n // 64))
 env.reset()
 out = (C.c_ulonglong * 24)()
 env._L.rcsh_debug_team_cycles(out)
@@ -26,3 +26,11 @@ for i in range(10): print(f"  {names[i]:28s} {a[i] / sub:9.0f}")
 print(f"  {'substep total':28s} {a[:10].sum() / sub:9.0f}")
 print(f"  (of actuation+rows: through the gripper / coupling block {a[15] / sub:.0f})")
 print(f"per launch: tables -> LDS {a[12] / T:.0f}  load_env {a[13] / T:.0f}  env_prologue {a[14] / T:.0f}  rest of prologue {a[11] / T:.0f}  epilogue {a[10] / T:.0f}  substeps {a[:10].sum() / T:.0f}")
+out64 = (C.c_ulonglong * 64)()
+env._L.rcsh_debug_team_cycles64(out64)
+if out64[61]:
+    print(f"dry-friction candidates: {out64[62] / out64[61]:.3f} of the team-substeps found a self-consistent zone set in the slot; newton_rows ran in {out64[63] / (out64[61] / 4):.3f} of the wavefront-substeps")
+if out64[44]:
+    print(f"newton_rows: {out64[44]} team-calls, {out64[45] / out64[44]:.2f} iterations each, worst {out64[46]}, over 4 iterations {out64[47]}, at the cap {out64[43]}")
+if out64[42]:
+    print(f"block 0: newton_rows entered {out64[42]} times in {sub} substeps, {out64[40] / out64[42]:.0f} cycles per call")
