@@ -212,7 +212,7 @@ RCSH_D void scan_frames(double* R, double* p) {
 // FRIC = false compiles the friction rows out (frows is the constant 0), leaving dyn.h's loop.
 template <class T, bool FRIC>
 RCSH_D void newton_rows(const LinkRec* links, const StageTeam<T>& st, uint32_t limrows, bool has_eq, double eqD, double eqAref,
-                        double eqJ1, double* x) {
+                        double eqJ1, double* x, bool seeded = false) {
   constexpr int NL = T::NL, NA = T::NARM;
   // dry-friction rows: D, frictionloss, aref, half-width of the quadratic zone
   double fD[NL], fF[NL], fA[NL], fR[NL];
@@ -237,7 +237,20 @@ RCSH_D void newton_rows(const LinkRec* links, const StageTeam<T>& st, uint32_t l
       if (jf <= -fR[i]) fneg |= 1u << i;
       else if (jf >= fR[i]) fpos |= 1u << i;
     }
-  bool have_x = false;
+  // seeded: x already holds an iterate (the factorisation slot's last solution): start from it and from the zones it lies in
+  bool have_x = seeded;
+  if (seeded) {
+    act = 0; fneg = 0; fpos = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      if ((limrows & (1u << i)) && st.limS(i) * x[i] - st.limA(i) < 0) act |= 1u << i;
+      if (frows & (1u << i)) {
+        const double jf = x[i] - fA[i];
+        if (jf <= -fR[i]) fneg |= 1u << i;
+        else if (jf >= fR[i]) fpos |= 1u << i;
+      }
+    }
+  }
   int iters_done = 0;
   for (int iter = 0; iter < 32; ++iter) {
     iters_done = iter + 1;
@@ -329,47 +342,126 @@ RCSH_D void newton_rows(const LinkRec* links, const StageTeam<T>& st, uint32_t l
         else if (jf > fR[i] || (jf == fR[i] && d[i] >= 0)) wpos |= 1u << i;
       }
     }
+    // The minimum of phi along the step.  phi' is piecewise linear and nondecreasing; its pieces end where a row crosses a
+    // zone boundary: the limit row of joint i at aL, its friction row through -R at aN and through +R at aP.  All lanes of
+    // the team hold the same x and d, so lane t takes crossing t (+ 16 per pass), evaluates phi' there with the slopes of the
+    // pieces on either side, and the team picks the first crossing at which phi' has turned non-negative: the root lies on
+    // the piece that ends there.  (A serial walk from piece to piece costs an order of magnitude more.)
     double alpha = 0;
-    for (int guard = 0; guard < 3 * NL + 2; ++guard) {
-      double c0 = p0, c1 = p1, a_next = INFINITY;
+    if constexpr (FRIC) {
+      const int tlane = (int)(threadIdx.x & 15u);
+      double jfv[NL], rdv[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) { jfv[i] = x[i] - fA[i]; rdv[i] = d[i] != 0 ? 1.0 / d[i] : 0.0; }
+      // the first piece (zones just past alpha = 0): the root if nothing is crossed before it
+      double c0 = p0, c1 = p1;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        if (limrows & (1u << i)) {
-          const double D = st.limD(i);
-          if (on & (1u << i)) { c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
-          if (jd[i] != 0) {
-            const double ab = -jar[i] / jd[i];
-            if (ab > alpha && ab < a_next) a_next = ab;
-          }
-        }
+        if ((limrows & (1u << i)) && (on & (1u << i))) { const double D = st.limD(i); c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
         if (frows & (1u << i)) {
-          const double jf = x[i] - fA[i];
-          const bool ln = wneg & (1u << i), lp = wpos & (1u << i);
-          if (ln) c0 -= fF[i] * d[i];
-          else if (lp) c0 += fF[i] * d[i];
-          else { c0 += fD[i] * jf * d[i]; c1 += fD[i] * d[i] * d[i]; }
-          if (d[i] != 0 && !(d[i] > 0 ? lp : ln)) {
-            const double bound = d[i] > 0 ? (ln ? -fR[i] : fR[i]) : (lp ? fR[i] : -fR[i]);
-            const double ab = (bound - jf) / d[i];
-            if (ab > alpha && ab < a_next) a_next = ab;
-          }
+          if (wneg & (1u << i)) c0 -= fF[i] * d[i];
+          else if (wpos & (1u << i)) c0 += fF[i] * d[i];
+          else { c0 += fD[i] * jfv[i] * d[i]; c1 += fD[i] * d[i] * d[i]; }
         }
       }
-      const double a_star = -c0 / c1;
-      if (a_star <= a_next) { if (a_star > alpha) alpha = a_star; break; }
-      alpha = a_next;
+      double a_first = INFINITY, root_first = INFINITY;  // the first crossing with phi' >= 0, the root on the piece before it
+      double a_last = -INFINITY, root_last = INFINITY;   // the last crossing at all, the root on the piece after it
+      const int ncross = limrows ? 3 * NL : 2 * NL;
+      for (int k0 = 0; k0 < ncross; k0 += kTeamLanes) {
+        const int k = k0 + tlane;
+        // this lane's crossing: row, which boundary, where
+        int row = -1, kind = 0;  // kind 0: friction through -R, 1: friction through +R, 2: limit
+        double ak = INFINITY;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        if ((limrows & (1u << i)) && jd[i] != 0 && -jar[i] / jd[i] == a_next) on ^= 1u << i;
-        if ((frows & (1u << i)) && d[i] != 0) {
-          const double jf = x[i] - fA[i];
-          const bool ln = wneg & (1u << i), lp = wpos & (1u << i);
-          if (d[i] > 0) {
-            if (ln && (-fR[i] - jf) / d[i] == a_next) wneg &= ~(1u << i);
-            else if (!ln && !lp && (fR[i] - jf) / d[i] == a_next) wpos |= 1u << i;
-          } else {
-            if (lp && (fR[i] - jf) / d[i] == a_next) wpos &= ~(1u << i);
-            else if (!ln && !lp && (-fR[i] - jf) / d[i] == a_next) wneg |= 1u << i;
+        for (int i = 0; i < NL; ++i) {
+          const bool fr = (frows >> i) & 1u, lr = (limrows >> i) & 1u;
+          if (k == i && fr && d[i] != 0) { row = i; kind = 0; ak = (-fR[i] - jfv[i]) * rdv[i]; }
+          if (k == NL + i && fr && d[i] != 0) { row = i; kind = 1; ak = (fR[i] - jfv[i]) * rdv[i]; }
+          if (k == 2 * NL + i && lr && jd[i] != 0) { row = i; kind = 2; ak = -jar[i] / jd[i]; }
+        }
+        if (!(ak > 0)) ak = INFINITY;  // (behind the starting point: not on the way)
+        const bool have = ak < INFINITY;
+        const double at = have ? ak : 0.0;
+        double val = p0 + at * p1, s_before = p1, s_after = p1;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          if ((limrows >> i) & 1u) {
+            const double D = st.limD(i), ra = jar[i] + at * jd[i];
+            const bool own = kind == 2 && row == i;
+            bool on_b = ra < 0, on_a = ra < 0;
+            if (own) { on_b = jd[i] > 0; on_a = !on_b; }  // (rising through 0: active before, off after)
+            val += ra < 0 && !own ? D * ra * jd[i] : 0.0;   // (at its own crossing the row's residual is 0)
+            s_before += on_b ? D * jd[i] * jd[i] : 0.0;
+            s_after += on_a ? D * jd[i] * jd[i] : 0.0;
+          }
+          if ((frows >> i) & 1u) {
+            const double ja = jfv[i] + at * d[i];
+            int zb = ja <= -fR[i] ? 0 : (ja >= fR[i] ? 2 : 1), za = zb;  // 0: below -R, 1: quadratic, 2: above +R
+            if (kind != 2 && row == i) {
+              if (kind == 0) { zb = d[i] > 0 ? 0 : 1; za = d[i] > 0 ? 1 : 0; }
+              else { zb = d[i] > 0 ? 1 : 2; za = d[i] > 0 ? 2 : 1; }
+            }
+            // (phi' is continuous: at the row's own crossing both neighbouring pieces give the same value; the piece before is used)
+            val += zb == 0 ? -fF[i] * d[i] : (zb == 2 ? fF[i] * d[i] : fD[i] * ja * d[i]);
+            s_before += zb == 1 ? fD[i] * d[i] * d[i] : 0.0;
+            s_after += za == 1 ? fD[i] * d[i] * d[i] : 0.0;
+          }
+        }
+        if (have && val >= 0 && ak < a_first) { a_first = ak; root_first = ak - val / s_before; }
+        if (have && ak > a_last) { a_last = ak; root_last = ak - val / s_after; }
+      }
+      const double af = team_min(a_first);
+      if (af < INFINITY) {
+        alpha = team_min(a_first == af ? root_first : INFINITY);
+      } else {
+        const double al = -team_min(-a_last);
+        alpha = al > -INFINITY ? team_min(a_last == al ? root_last : INFINITY) : -c0 / c1;
+      }
+      if (!(alpha > 0)) alpha = -c0 / c1 > 0 ? -c0 / c1 : 0.0;  // (round-off at a crossing: fall back to the first piece)
+    } else {
+      // (models without dry friction reach this routine rarely -- more than three limit rows, or no self-consistent guess --
+      // and keep the serial walk from piece to piece: the headline kernel's code stays what it was)
+      for (int guard = 0; guard < 3 * NL + 2; ++guard) {
+        double c0 = p0, c1 = p1, a_next = INFINITY;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          if (limrows & (1u << i)) {
+            const double D = st.limD(i);
+            if (on & (1u << i)) { c0 += D * jar[i] * jd[i]; c1 += D * jd[i] * jd[i]; }
+            if (jd[i] != 0) {
+              const double ab = -jar[i] / jd[i];
+              if (ab > alpha && ab < a_next) a_next = ab;
+            }
+          }
+          if (frows & (1u << i)) {
+            const double jf = x[i] - fA[i];
+            const bool ln = wneg & (1u << i), lp = wpos & (1u << i);
+            if (ln) c0 -= fF[i] * d[i];
+            else if (lp) c0 += fF[i] * d[i];
+            else { c0 += fD[i] * jf * d[i]; c1 += fD[i] * d[i] * d[i]; }
+            if (d[i] != 0 && !(d[i] > 0 ? lp : ln)) {
+              const double bound = d[i] > 0 ? (ln ? -fR[i] : fR[i]) : (lp ? fR[i] : -fR[i]);
+              const double ab = (bound - jf) / d[i];
+              if (ab > alpha && ab < a_next) a_next = ab;
+            }
+          }
+        }
+        const double a_star = -c0 / c1;
+        if (a_star <= a_next) { if (a_star > alpha) alpha = a_star; break; }
+        alpha = a_next;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          if ((limrows & (1u << i)) && jd[i] != 0 && -jar[i] / jd[i] == a_next) on ^= 1u << i;
+          if ((frows & (1u << i)) && d[i] != 0) {
+            const double jf = x[i] - fA[i];
+            const bool ln = wneg & (1u << i), lp = wpos & (1u << i);
+            if (d[i] > 0) {
+              if (ln && (-fR[i] - jf) / d[i] == a_next) wneg &= ~(1u << i);
+              else if (!ln && !lp && (fR[i] - jf) / d[i] == a_next) wpos |= 1u << i;
+            } else {
+              if (lp && (fR[i] - jf) / d[i] == a_next) wpos &= ~(1u << i);
+              else if (!ln && !lp && (-fR[i] - jf) / d[i] == a_next) wneg |= 1u << i;
+            }
           }
         }
       }
@@ -794,7 +886,7 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
   double fFv[FRIC ? NL : 1], fDv[FRIC ? NL : 1], fRv[FRIC ? NL : 1], fAv[FRIC ? NL : 1];
   // (dry friction: the slot runs up to kFricRounds times -- a round without a self-consistent candidate hands the zones lane 0's
   // solution landed in to the next one as its base, which is what the serial iteration's next step would solve)
-  constexpr int kFricRounds = 4;
+  constexpr int kFricRounds = 3;
   uint32_t b_neg = 0, b_pos = 0, b_act = 0, winners = 0;
   double xprev[FRIC ? NL : 1];
   for (int round = 0; round < (FRIC ? kFricRounds : 1); ++round) {
@@ -945,7 +1037,13 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     double xs[NL];
     TEAM_MARK(41)
     TEAM_COUNT(42)
-    newton_rows<T, FRIC>(links, st, limrows, has_eq, eqD, eqAref, eqJ1, xs);
+    if constexpr (FRIC) {
+      // (the rounds' last solution of lane 0 is as good an iterate as any: the serial routine picks up there)
+      const int l0 = (int)(threadIdx.x & 48u);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) xs[i] = lane_get(x[i], l0);
+    }
+    newton_rows<T, FRIC>(links, st, limrows, has_eq, eqD, eqAref, eqJ1, xs, FRIC);
     TEAM_MARK(40)
     if (t == 0) {
 #pragma unroll

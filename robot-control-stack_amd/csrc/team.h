@@ -85,6 +85,14 @@ template <class P>
 RCSH_D P* in_lds(P* p) {
   return (P*)(__attribute__((address_space(3))) P*)p;
 }
+// minimum over the team's 16 lanes, in every lane (cyclic rotations within the DPP row)
+RCSH_D double team_min(double x) {
+  x = fmin(x, row_rotate<1>(x));
+  x = fmin(x, row_rotate<2>(x));
+  x = fmin(x, row_rotate<4>(x));
+  x = fmin(x, row_rotate<8>(x));
+  return x;
+}
 // 16-bit mask of the team's lanes for which `pred` holds
 RCSH_D uint32_t team_ballot(bool pred) {
   const uint64_t b = __ballot(pred);
