@@ -913,16 +913,17 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
       // (t - 1) % 2); a lane whose solution lands in the zones it assumed has the minimiser of the convex cost.  Nobody:
       // newton_rows below, as before.
       frows = 0; c_neg = 0; c_pos = 0; c_act = 0; cand_lane = false;
+      // (selects, not branches: the rows' data is the same in every lane, but the compiler cannot know, and a scalar branch
+      // per row and test costs this lonely wavefront more than the arithmetic it would skip)
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         fFv[i] = links[i].fl_floss; fDv[i] = links[i].fl_D; fRv[i] = links[i].fl_R; fAv[i] = st.fa(i);
         const double xw = st.xs(i), jf = xw - fAv[i];
-        if (fFv[i] > 0) {
-          frows |= 1u << i;
-          if (jf <= -fRv[i]) c_neg |= 1u << i;
-          else if (jf >= fRv[i]) c_pos |= 1u << i;
-        }
-        if (((limrows >> i) & 1u) && lSv[i] * xw - lAv[i] < 0) c_act |= 1u << i;
+        const bool fr = fFv[i] > 0, below = jf <= -fRv[i], above = jf >= fRv[i];
+        frows |= fr ? 1u << i : 0u;
+        c_neg |= fr && below ? 1u << i : 0u;
+        c_pos |= fr && !below && above ? 1u << i : 0u;
+        c_act |= ((limrows >> i) & 1u) && lSv[i] * xw - lAv[i] < 0 ? 1u << i : 0u;
       }
       if (round > 0) { c_neg = b_neg; c_pos = b_pos; c_act = b_act; }
       if (t == 0) cand_lane = true;
@@ -948,11 +949,12 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
       if (i == unit) xi = 1.0;
       if (T::GRIP && eq_helper && (i == NA || i == NA + 1)) xi = i == NA ? 1.0 : eqJ1;
       if constexpr (FRIC) {
-        if (!helper_lane && ((frows >> i) & 1u)) {
-          if ((c_neg >> i) & 1u) xi += fFv[i];
-          else if ((c_pos >> i) & 1u) xi -= fFv[i];
-          else { H[tri(i, i)] += fDv[i]; xi += fDv[i] * fAv[i]; }
-        }
+        const bool fr = !helper_lane && ((frows >> i) & 1u), ng = (c_neg >> i) & 1u, ps = (c_pos >> i) & 1u;
+        const double push = fr && ng ? fFv[i] : (fr && ps ? -fFv[i] : 0.0);  // the linear zones' constant force
+        const double dq = fr && !ng && !ps ? fDv[i] : 0.0;                    // the quadratic zone's stiffness
+        H[tri(i, i)] += dq;
+        xi += push;
+        xi += dq * fAv[i];
       }
       x[i] = xi;
     }
@@ -982,12 +984,12 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
   if constexpr (FRIC) {
     uint32_t nneg = 0, npos = 0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      if ((frows >> i) & 1u) {
-        const double jf = x[i] - fAv[i];
-        if (jf <= -fRv[i]) nneg |= 1u << i;
-        else if (jf >= fRv[i]) npos |= 1u << i;
-      }
+    for (int i = 0; i < NL; ++i) {
+      const double jf = x[i] - fAv[i];
+      const bool fr = (frows >> i) & 1u, below = jf <= -fRv[i], above = jf >= fRv[i];
+      nneg |= fr && below ? 1u << i : 0u;
+      npos |= fr && !below && above ? 1u << i : 0u;
+    }
     hit_guess = cand_lane && now == c_act && nneg == c_neg && npos == c_pos;
     // the next round's base: where lane 0's solution landed -- from the third round on, where the point half way between its
     // last two solutions lies (two zone sets that send the solve to each other enclose the minimiser between their solutions)
@@ -1086,16 +1088,15 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
         const double r = lSv[i] * xs[i] - lAv[i];
-        if (!coupled && ((limrows >> i) & 1u) && r < 0) rhs[i] -= lSv[i] * lDv[i] * r;
+        rhs[i] -= !coupled && ((limrows >> i) & 1u) && r < 0 ? lSv[i] * lDv[i] * r : 0.0;
       }
       if constexpr (FRIC) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-          const double fF = links[i].fl_floss, fD = links[i].fl_D;
-          if (fF > 0) {
-            const double jf = xs[i] - st.fa(i), fR = links[i].fl_R;
-            rhs[i] += jf <= -fR ? fF : (jf >= fR ? -fF : -fD * jf);
-          }
+          const double fF = links[i].fl_floss, fD = links[i].fl_D, fR = links[i].fl_R;
+          const double jf = xs[i] - st.fa(i);
+          const double f = jf <= -fR ? fF : (jf >= fR ? -fF : -fD * jf);
+          rhs[i] += fF > 0 ? f : 0.0;
         }
       }
       if constexpr (T::GRIP) if (has_eq && !coupled) {
