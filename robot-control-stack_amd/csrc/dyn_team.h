@@ -976,9 +976,10 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
 #pragma unroll
     for (int i = 0; i < NL; ++i) { lAv[i] = st.limA(i); lSv[i] = st.limS(i); }
     sched_fence();
+    // (every row's test, then the mask of the rows that exist: a test per row behind a scalar branch on its bit costs more)
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      if (((limrows >> i) & 1u) && lSv[i] * x[i] - lAv[i] < 0) now |= 1u << i;
+    for (int i = 0; i < NL; ++i) now |= lSv[i] * x[i] - lAv[i] < 0 ? 1u << i : 0u;
+    now &= limrows;
   }
   bool hit_guess = solver_lane && now == act;
   if constexpr (FRIC) {
