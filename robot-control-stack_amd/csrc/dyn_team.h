@@ -887,7 +887,8 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
   // (dry friction: the slot runs up to kFricRounds times -- a round without a self-consistent candidate hands the zones lane 0's
   // solution landed in to the next one as its base, which is what the serial iteration's next step would solve)
   constexpr int kFricRounds = 3;
-  uint32_t b_neg = 0, b_pos = 0, b_act = 0, winners = 0;
+  uint32_t b_neg = 0, b_pos = 0, b_act = 0, b_side = 0, winners = 0;
+  int b_m = 0;
   double xprev[FRIC ? NL : 1];
   for (int round = 0; round < (FRIC ? kFricRounds : 1); ++round) {
 #pragma unroll
@@ -925,16 +926,40 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
         c_pos |= fr && !below && above ? 1u << i : 0u;
         c_act |= ((limrows >> i) & 1u) && lSv[i] * xw - lAv[i] < 0 ? 1u << i : 0u;
       }
-      if (round > 0) { c_neg = b_neg; c_pos = b_pos; c_act = b_act; }
+      // which way each row would leave its zone (a quadratic row through the nearer boundary) and the row closest to doing so
+      uint32_t c_side = 0;
+      int c_m = 0;
+      {
+        double best = INFINITY;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const double jf = st.xs(i) - fAv[i], aj = fabs(jf);
+          const bool fr = (frows >> i) & 1u;
+          c_side |= jf > 0 ? 1u << i : 0u;
+          const double margin = fr ? fabs(aj - fRv[i]) : INFINITY;
+          c_m = margin < best ? i : c_m;
+          best = fmin(best, margin);
+        }
+      }
+      if (round > 0) { c_neg = b_neg; c_pos = b_pos; c_act = b_act; c_side = b_side; c_m = b_m; }
+      // lane 0: the base; lanes 1..7: row t - 1 moved to the zone next to its own; lanes 8..14: row t - 8 AND the row closest
+      // to its boundary both moved (that row alone, to its far side, on the lane where the two coincide)
+      auto move_row = [&](int j, bool far) {
+        const uint32_t bit = 1u << j;
+        const int zone0 = (c_neg & bit) ? 0 : ((c_pos & bit) ? 2 : 1);  // 0: f = +frictionloss, 1: quadratic, 2: f = -frictionloss
+        const bool up = (c_side >> j) & 1u;
+        const int near1 = zone0 == 1 ? (up ? 2 : 0) : 1, far1 = zone0 == 1 ? (up ? 0 : 2) : 2 - zone0;
+        const int zone1 = far ? far1 : near1;
+        c_neg = (c_neg & ~bit) | (zone1 == 0 ? bit : 0u);
+        c_pos = (c_pos & ~bit) | (zone1 == 2 ? bit : 0u);
+      };
       if (t == 0) cand_lane = true;
       else if (t < kTeamLanes - 1) {
-        const int j = (t - 1) >> 1, alt = (t - 1) & 1;
-        const uint32_t bit = j < NL ? 1u << j : 0u;
-        if (frows & bit) {
-          const int zone0 = (c_neg & bit) ? 0 : ((c_pos & bit) ? 2 : 1);                // 0: f = +frictionloss, 1: quadratic, 2: f = -frictionloss
-          const int zone1 = alt == 0 ? (zone0 == 0 ? 1 : 0) : (zone0 == 2 ? 1 : 2);
-          c_neg = (c_neg & ~bit) | (zone1 == 0 ? bit : 0u);
-          c_pos = (c_pos & ~bit) | (zone1 == 2 ? bit : 0u);
+        const int j = t < 8 ? t - 1 : t - 8;
+        if (j < NL && ((frows >> j) & 1u)) {
+          if (t < 8) move_row(j, false);
+          else if (j == c_m) move_row(j, true);
+          else { move_row(j, false); move_row(c_m, false); }
           cand_lane = true;
         }
       }
@@ -994,18 +1019,22 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     hit_guess = cand_lane && now == c_act && nneg == c_neg && npos == c_pos;
     // the next round's base: where lane 0's solution landed -- from the third round on, where the point half way between its
     // last two solutions lies (two zone sets that send the solve to each other enclose the minimiser between their solutions)
-    uint32_t zn = nneg, zp = npos, za = now;
-    if (round > 0) {
-      zn = 0; zp = 0; za = 0;
+    uint32_t zn = 0, zp = 0, za = 0, zs = 0;
+    int zm = 0;
+    {
+      double best = INFINITY;
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const double xm = 0.5 * (x[i] + xprev[i]);
-        if ((frows >> i) & 1u) {
-          const double jf = xm - fAv[i];
-          if (jf <= -fRv[i]) zn |= 1u << i;
-          else if (jf >= fRv[i]) zp |= 1u << i;
-        }
-        if (((limrows >> i) & 1u) && st.limS(i) * xm - st.limA(i) < 0) za |= 1u << i;
+        const double xm = round > 0 ? 0.5 * (x[i] + xprev[i]) : x[i];
+        const double jf = xm - fAv[i], aj = fabs(jf);
+        const bool fr = (frows >> i) & 1u, below = jf <= -fRv[i], above = jf >= fRv[i];
+        zn |= fr && below ? 1u << i : 0u;
+        zp |= fr && !below && above ? 1u << i : 0u;
+        zs |= jf > 0 ? 1u << i : 0u;
+        const double margin = fr ? fabs(aj - fRv[i]) : INFINITY;
+        zm = margin < best ? i : zm;
+        best = fmin(best, margin);
+        za |= ((limrows >> i) & 1u) && st.limS(i) * xm - st.limA(i) < 0 ? 1u << i : 0u;
       }
     }
 #pragma unroll
@@ -1014,6 +1043,8 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     b_neg = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)zn);
     b_pos = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)zp);
     b_act = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)za);
+    b_side = (uint32_t)__builtin_amdgcn_ds_bpermute(l0, (int)zs);
+    b_m = __builtin_amdgcn_ds_bpermute(l0, zm);
   }
   winners = coupled ? 0u : team_ballot(hit_guess);
   if (winners || coupled) break;
