@@ -888,6 +888,9 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
   // solution landed in to the next one as its base, which is what the serial iteration's next step would solve)
   constexpr int kFricRounds = 3;
   uint32_t b_neg = 0, b_pos = 0, b_act = 0, b_side = 0, winners = 0;
+  int rounds_used = 0;
+  uint32_t dbg_n0 = 0, dbg_p0 = 0;
+  (void)dbg_n0; (void)dbg_p0;
   int b_m = 0;
   double xprev[FRIC ? NL : 1];
   for (int round = 0; round < (FRIC ? kFricRounds : 1); ++round) {
@@ -942,8 +945,8 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
         }
       }
       if (round > 0) { c_neg = b_neg; c_pos = b_pos; c_act = b_act; c_side = b_side; c_m = b_m; }
-      // lane 0: the base; lanes 1..7: row t - 1 moved to the zone next to its own; lanes 8..14: row t - 8 AND the row closest
-      // to its boundary both moved (that row alone, to its far side, on the lane where the two coincide)
+      // lane 0: the base.  Later rounds: lanes 1..7: row t - 1 moved to the zone next to its own; lanes 8..14: row t - 8 AND the row
+      // closest to its boundary both moved (that row alone, to its far side, on the lane where the two coincide)
       auto move_row = [&](int j, bool far) {
         const uint32_t bit = 1u << j;
         const int zone0 = (c_neg & bit) ? 0 : ((c_pos & bit) ? 2 : 1);  // 0: f = +frictionloss, 1: quadratic, 2: f = -frictionloss
@@ -955,12 +958,18 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
       };
       if (t == 0) cand_lane = true;
       else if (t < kTeamLanes - 1) {
-        const int j = t < 8 ? t - 1 : t - 8;
-        if (j < NL && ((frows >> j) & 1u)) {
-          if (t < 8) move_row(j, false);
-          else if (j == c_m) move_row(j, true);
-          else { move_row(j, false); move_row(c_m, false); }
-          cand_lane = true;
+        if (round == 0) {
+          // (first round: every row to either of its two other zones -- one row moving is by far the commonest change)
+          const int j = (t - 1) >> 1;
+          if (j < NL && ((frows >> j) & 1u)) { move_row(j, (t - 1) & 1); cand_lane = true; }
+        } else {
+          const int j = t < 8 ? t - 1 : t - 8;
+          if (j < NL && ((frows >> j) & 1u)) {
+            if (t < 8) move_row(j, false);
+            else if (j == c_m) move_row(j, true);
+            else { move_row(j, false); move_row(c_m, false); }
+            cand_lane = true;
+          }
         }
       }
     }
@@ -1047,8 +1056,28 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
     b_m = __builtin_amdgcn_ds_bpermute(l0, zm);
   }
   winners = coupled ? 0u : team_ballot(hit_guess);
+  rounds_used = round + 1;
+#ifdef RCSH_PHASE_TIMING
+  if constexpr (FRIC) {
+    if (round == 0) { dbg_n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)c_neg); dbg_p0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)c_pos); }
+    if (winners && round > 0) {
+      const int wl = ((int)(threadIdx.x & 48u) + __ffs(winners) - 1) << 2;
+      const uint32_t wn = (uint32_t)__builtin_amdgcn_ds_bpermute(wl, (int)c_neg), wp = (uint32_t)__builtin_amdgcn_ds_bpermute(wl, (int)c_pos);
+      const int nd = __popc((wn ^ dbg_n0) | (wp ^ dbg_p0));
+      if (t == 0) atomicAdd(&g_team_cycles[55 + (nd > 3 ? 3 : nd)], 1ull);  // slots 55..58: rows whose zone differs between the first base and the winner: 0, 1, 2, 3+
+    }
+  }
+#endif
   if (winners || coupled) break;
   }  // (rounds)
+#ifdef RCSH_PHASE_TIMING
+  if constexpr (FRIC) {
+    const uint64_t r2 = __ballot(rounds_used >= 2), r3 = __ballot(rounds_used >= 3);
+    if (t == 0) atomicAdd(&g_team_cycles[48 + (rounds_used > 3 ? 3 : rounds_used)], 1ull);        // team-substeps by rounds used: slots 49..51
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_team_cycles[52 + (r3 ? 2 : (r2 ? 1 : 0))], 1ull);  // wavefront-substeps by passes: slots 52..54
+  }
+#endif
+  (void)rounds_used;
 #ifdef RCSH_PHASE_TIMING
   if (t == 0) {  // (every team of every workgroup) team-substeps / with a self-consistent candidate / wavefront-substeps that ran newton_rows
     atomicAdd(&g_team_cycles[61], 1ull);

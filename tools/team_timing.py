@@ -34,3 +34,8 @@ if out64[44]:
     print(f"newton_rows: {out64[44]} team-calls, {out64[45] / out64[44]:.2f} iterations each, worst {out64[46]}, over 4 iterations {out64[47]}, at the cap {out64[43]}")
 if out64[42]:
     print(f"block 0: newton_rows entered {out64[42]} times in {sub} substeps, {out64[40] / out64[42]:.0f} cycles per call")
+if out64[49] + out64[50] + out64[51]:
+    tt = out64[49] + out64[50] + out64[51]; ww = out64[52] + out64[53] + out64[54]
+    print(f"slot rounds used, team-substeps: 1: {out64[49] / tt:.3f}  2: {out64[50] / tt:.3f}  3: {out64[51] / tt:.3f};  passes run, wavefront-substeps: 1: {out64[52] / ww:.3f}  2: {out64[53] / ww:.3f}  3: {out64[54] / ww:.3f}")
+if out64[55] + out64[56] + out64[57] + out64[58]:
+    print(f"late winners: rows differing from the first base: 0: {out64[55]}  1: {out64[56]}  2: {out64[57]}  3+: {out64[58]}")
