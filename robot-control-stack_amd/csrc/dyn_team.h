@@ -915,7 +915,8 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
       // substep to the next.  Lane 0 takes the zones of the previous substep's solution (friction rows and limit rows alike),
       // lanes 1..14 the same with ONE friction row moved to one of its two other zones (joint (t - 1) / 2, alternative
       // (t - 1) % 2); a lane whose solution lands in the zones it assumed has the minimiser of the convex cost.  Nobody:
-      // newton_rows below, as before.
+      // another round from the zones lane 0's solution landed in (single moves to the neighbouring zone and pairs with the
+      // row closest to its boundary), then a third; only after that newton_rows below, seeded with lane 0's last solution.
       frows = 0; c_neg = 0; c_pos = 0; c_act = 0; cand_lane = false;
       // (selects, not branches: the rows' data is the same in every lane, but the compiler cannot know, and a scalar branch
       // per row and test costs this lonely wavefront more than the arithmetic it would skip)
