@@ -1416,18 +1416,31 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     r[6] = R0;
   }
   // links in contact (their composite contact stiffness enters the Hessian; the noslip pass keeps M^-1 S' for them)
-  if (lane == 0) {
+  // in the order of their first contact, at most kMaxActive: a ballot per link says where it first appears (a contact names
+  // at most one link: the other body is the cube or the world), then the earliest ones are picked -- scalar work for the
+  // wavefront instead of one lane walking the contact list
+  {
+    const int myA = lane < ncon ? ar.cb[lane] & 0xff : 0xff, myB = lane < ncon ? (ar.cb[lane] >> 8) & 0xff : 0xff;
+    uint64_t first_of[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) first_of[l] = __ballot(myA == l || myB == l);
+    uint64_t taken = 0;  // contacts whose link is listed already
     int na = 0;
-    for (int c = 0; c < ncon; ++c) {
-      const int bb[2] = {ar.cb[c] & 0xff, (ar.cb[c] >> 8) & 0xff};
-      for (int s = 0; s < 2; ++s) {
-        if (bb[s] >= NL) continue;
-        bool have = false;
-        for (int k = 0; k < na; ++k) have = have || ar.act[k] == bb[s];
-        if (!have && na < kMaxActive) ar.act[na++] = bb[s];
+    for (int k = 0; k < kMaxActive; ++k) {
+      int best_l = -1, best_c = 64;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        const uint64_t m = first_of[l] & ~taken;
+        const int c0 = first_of[l] && !(first_of[l] & taken) ? __ffsll((long long)m) - 1 : 64;
+        if (c0 < best_c) { best_c = c0; best_l = l; }
       }
+      if (best_l < 0) break;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) taken |= l == best_l ? first_of[l] : 0ull;
+      if (lane == 0) ar.act[na] = best_l;
+      ++na;
     }
-    ar.nact = na;
+    if (lane == 0) ar.nact = na;
   }
   // ---- qacc_smooth: the robot's by its own factorisation (every lane), the box's in closed form
   const double Mb[6] = {b.mass, b.mass, b.mass, b.inertia[0], b.inertia[1], b.inertia[2]};
