@@ -1999,14 +1999,28 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
         double change = 0, dw[6] = {0, 0, 0, 0, 0, 0};
         int moved = 0;
         if (lane == cc) {
-          double res[3], old[3] = {c.f[0], c.f[1], c.f[2]};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) res[k] = dot6(c.G[k], rel) - c.aref[k];
+          const double old[3] = {c.f[0], c.f[1], c.f[2]};
           double nf[3] = {old[0], old[1], old[2]};
           if (old[0] < kMinVal) {
+            // (a contact the Newton solution left without normal force: all three rows go to zero -- the general update)
+            double res[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) res[k] = dot6(c.G[k], rel) - c.aref[k];
             nf[0] = nf[1] = nf[2] = 0;
+            const double dl[3] = {-old[0], -old[1], -old[2]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+              for (int l = 0; l < 3; ++l) change += 0.5 * dl[k] * Ac[k][l] * dl[l];
+              change += dl[k] * res[k];
+            }
+            if (change > 1e-10) { nf[0] = old[0]; nf[1] = old[1]; nf[2] = old[2]; change = 0; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dw[k] = c.G[0][k] * (nf[0] - old[0]) + c.G[1][k] * (nf[1] - old[1]) + c.G[2][k] * (nf[2] - old[2]);
           } else {
-            const double b1 = res[1] - Ac[1][1] * old[1] - Ac[1][2] * old[2], b2 = res[2] - Ac[2][1] * old[1] - Ac[2][2] * old[2];
+            // the normal force stays: only the friction rows' residuals, their 2 x 2 block and their part of the wrench are needed
+            const double res1 = dot6(c.G[1], rel) - c.aref[1], res2 = dot6(c.G[2], rel) - c.aref[2];
+            const double b1 = res1 - Ac[1][1] * old[1] - Ac[1][2] * old[2], b2 = res2 - Ac[2][1] * old[1] - Ac[2][2] * old[2];
             double vv[2];
             if (qcqp2_dev(vv, Ac[1][1], Ac[1][2], Ac[2][2], b1, b2, c.fr, c.fr, old[0], qdet, qdi)) {
               double s = vv[0] * vv[0] / (c.fr * c.fr) + vv[1] * vv[1] / (c.fr * c.fr);
@@ -2014,17 +2028,12 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
               vv[0] *= s; vv[1] *= s;
             }
             nf[1] = vv[0]; nf[2] = vv[1];
+            const double d1 = nf[1] - old[1], d2 = nf[2] - old[2];
+            change = 0.5 * d1 * Ac[1][1] * d1 + 0.5 * d1 * Ac[1][2] * d2 + d1 * res1 + 0.5 * d2 * Ac[2][1] * d1 + 0.5 * d2 * Ac[2][2] * d2 + d2 * res2;
+            if (change > 1e-10) { nf[1] = old[1]; nf[2] = old[2]; change = 0; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dw[k] = c.G[1][k] * (nf[1] - old[1]) + c.G[2][k] * (nf[2] - old[2]);
           }
-          const double dl[3] = {nf[0] - old[0], nf[1] - old[1], nf[2] - old[2]};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-#pragma unroll
-            for (int l = 0; l < 3; ++l) change += 0.5 * dl[k] * Ac[k][l] * dl[l];
-            change += dl[k] * res[k];
-          }
-          if (change > 1e-10) { nf[0] = old[0]; nf[1] = old[1]; nf[2] = old[2]; change = 0; }
-#pragma unroll
-          for (int k = 0; k < 6; ++k) dw[k] = c.G[0][k] * (nf[0] - old[0]) + c.G[1][k] * (nf[1] - old[1]) + c.G[2][k] * (nf[2] - old[2]);
           moved = nf[0] != old[0] || nf[1] != old[1] || nf[2] != old[2];
           c.f[0] = nf[0]; c.f[1] = nf[1]; c.f[2] = nf[2];
         }
