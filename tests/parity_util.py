@@ -592,6 +592,52 @@ def run_physics_parity_at_joint_limits(n_envs=32, n_calls=8, k=17, seed=0, n_ove
     return rep
 
 
+def run_xarm7_at_joint_limits_parity(n_envs=48, n_calls=8, k=17, seed=0, n_over=3):
+    """xArm7 (a dry-friction row on every joint) with `n_over` of its bounded joints started BEYOND their range and commanded
+    to the range end, the others to random targets: limit rows and friction rows change zones in the same solves -- the
+    candidate rounds of the factorisation slot carry limit rows in their zone sets, and the serial routine's team-wide line
+    search takes the limit crossings in its second pass.  Kernel vs oracle through the fine-grained API."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import xarm7_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import XARM7
+
+    cfg = xarm7_sim_robot_cfg()
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    if KERNEL != "auto":
+        simu.set_kernel(KERNEL)
+    robot = S.SimRobot(simu, None, cfg)
+    cm = compile_mjcf(XARM7_SCENE)
+    osims = [O.Sim(cm, XARM7["joints"], XARM7["actuators"], XARM7["site"], XARM7["base"], XARM7["q_home"], None, arm_collision_geoms=[]) for _ in range(n_envs)]
+    rng = np.random.default_rng(seed)
+    hi = np.asarray(cm.jnt_range)[:7, 1]
+    bounded = [1, 3, 5][:n_over]  # (the xArm7's joints 2, 4, 6 have ranges narrower than a turn)
+    q0 = np.tile(np.asarray(XARM7["q_home"]), (n_envs, 1)) + rng.uniform(-0.1, 0.1, (n_envs, 7))
+    q0[:, bounded] = hi[bounded] + rng.uniform(0.002, 0.03, size=(n_envs, len(bounded)))
+    simu.reset(); robot.reset()
+    simu.set_qpos(q0)
+    for e, o in enumerate(osims):
+        o.reset(); o.robot_reset()
+        for i in range(7):
+            o.s.d.qpos[i] = q0[e, i]
+    rep = {"max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_rows": 0}
+    for _ in range(n_calls):
+        tgt = np.asarray(XARM7["q_home"]) + rng.uniform(-0.3, 0.3, (n_envs, 7))
+        tgt[:, bounded] = hi[bounded]
+        robot.set_joint_position(tgt)
+        simu.step(k)
+        q, v = simu.qpos, simu.qvel
+        for e, o in enumerate(osims):
+            rep["max_rows"] = max(rep["max_rows"], int((np.asarray(o.qpos)[:7] > hi - 1e-3).sum()))
+            o.set_joint_position(tgt[e])
+            o.step(k)
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - np.asarray(o.qpos)[:7]).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - np.asarray(o.qvel)[:7]).max()))
+    simu.close()
+    return rep
+
+
 def _pinch_placements(n_envs: int, seed: int):
     """Cube poses a few millimetres / degrees off the gripper's closing axis (the scene's own pose first)."""
     rng = np.random.default_rng(seed)

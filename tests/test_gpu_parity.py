@@ -389,6 +389,17 @@ def test_xarm7_joints_with_dry_friction(async_control, kernel):
     assert rep["flag_mismatches"] == 0 and rep["substep_mismatches"] == 0, rep
 
 
+@pytest.mark.parametrize("n_over", [1, 3])
+def test_xarm7_friction_rows_and_limit_rows_together(n_over, kernel):
+    """Dry-friction rows and penetrating joint-limit rows in the same constraint solves: the zone candidates of the
+    factorisation slot carry the limit rows' states, the serial routine's line search crosses both kinds of boundary."""
+    from parity_util import run_xarm7_at_joint_limits_parity
+
+    rep = run_xarm7_at_joint_limits_parity(n_envs=48, n_calls=8, k=17, seed=6, n_over=n_over)
+    assert rep["max_rows"] >= n_over, rep
+    assert rep["max_abs_qpos"] < 1e-9 and rep["max_abs_qvel"] < 1e-7, rep
+
+
 def test_xarm7_cartesian_relative_clik(kernel):
     """The CLIK on the xArm7 chain (7 joints, attachment site on link7) + its friction-row physics."""
     rep = run_cartesian_rollout_parity(n_envs=24, n_steps=5, async_control=True, seed=17, mode="xyzrpy", robot="xarm7")
