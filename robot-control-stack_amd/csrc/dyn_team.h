@@ -1060,7 +1060,7 @@ RCSH_D void team_substep(const DevModelHead& m, const SubstepK& sk, const LinkRe
   rounds_used = round + 1;
 #ifdef RCSH_PHASE_TIMING
   if constexpr (FRIC) {
-    if (round == 0 && winners && t == 0) { const int wl_ = __ffs(winners) - 1; atomicAdd(&g_team_cycles[wl_ == 0 ? 40 : (((wl_ - 1) & 1) ? 42 : 41)], 1ull); }  // first-round winners: base / near move / far move
+    if (round == 0 && winners && t == 0) { const int wl_ = __ffs(winners) - 1; atomicAdd(&g_team_cycles[wl_ == 0 ? 24 : (((wl_ - 1) & 1) ? 26 : 25)], 1ull); }  // first-round winners: base / near move / far move (slots 24-26: the contact phase's marks in the kernels that have one)
     if (round == 0) { dbg_n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)c_neg); dbg_p0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)c_pos); }
     if (winners && round > 0) {
       const int wl = ((int)(threadIdx.x & 48u) + __ffs(winners) - 1) << 2;

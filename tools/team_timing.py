@@ -39,4 +39,5 @@ if out64[49] + out64[50] + out64[51]:
     print(f"slot rounds used, team-substeps: 1: {out64[49] / tt:.3f}  2: {out64[50] / tt:.3f}  3: {out64[51] / tt:.3f};  passes run, wavefront-substeps: 1: {out64[52] / ww:.3f}  2: {out64[53] / ww:.3f}  3: {out64[54] / ww:.3f}")
 if out64[55] + out64[56] + out64[57] + out64[58]:
     print(f"late winners: rows differing from the first base: 0: {out64[55]}  1: {out64[56]}  2: {out64[57]}  3+: {out64[58]}")
-print(f"first-round winners: base {out64[40]}, a near move {out64[41]}, a far move {out64[42]}")
+if out64[61]:
+    print(f"first-round winners: base {out64[24]}, a near move {out64[25]}, a far move {out64[26]}")
