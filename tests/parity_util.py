@@ -313,6 +313,38 @@ def xarm7_frictionless_scene() -> str:
     return path
 
 
+def fr3_arm_only_scene() -> str:
+    """The FR3 scene without its hand (hand, camera body, fingers, gripper actuator, tendon and equality removed), written to a
+    temporary file: 7 dofs and NO constraint row away from the joint limits, so one substep is the smooth system alone --
+    what tests/golden/fr3_arm_dynamics.json (tools/derive_fr3_dynamics.py) predicts from first principles."""
+    import tempfile
+    import xml.etree.ElementTree as ET
+
+    path = os.path.join(tempfile.gettempdir(), "rcs_amd_fr3_arm_only", "scene.xml")
+    if not os.path.exists(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tree = ET.parse(SCENE)
+        root = tree.getroot()
+        for parent in root.iter("body"):
+            for child in list(parent):
+                if child.tag == "body" and child.get("name") == "hand_0":
+                    parent.remove(child)
+        for tag in ("tendon", "equality"):
+            for node in root.findall(tag):
+                root.remove(node)
+        for act in root.findall("actuator"):
+            for a in list(act):
+                if a.get("tendon") is not None:
+                    act.remove(a)
+        tree.write(path)
+        for extra in ("collision_vertices.npz", "render_hulls.npz"):
+            if os.path.exists(os.path.join(os.path.dirname(SCENE), extra)):
+                import shutil
+
+                shutil.copy(os.path.join(os.path.dirname(SCENE), extra), os.path.dirname(path))
+    return path
+
+
 def scene_with_joint_friction(robot: str) -> str:
     """The FR3 / arm6 scene with dry joint friction on every joint (frictionloss = 0.5), written to a temporary file: the
     friction-row kernels for the archetypes whose shipped scenes have none -- FR3 + hand (friction rows next to the coupling
