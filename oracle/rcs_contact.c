@@ -232,22 +232,37 @@ typedef struct {
   double center[3];      /* an interior point, world */
 } shape;
 
+/* Support ties.  The portal refinement keeps asking for the support of A - B along the normal of a triangle of three of its
+ * vertices; as soon as two of them share a vertex of one shape, that normal is perpendicular to an EDGE of the other shape by
+ * construction, and the two ends of that edge tie to the last bit.  libccd (and MuJoCo through it) breaks such ties by the sign
+ * of a number that is zero up to round-off -- the outcome, a contact normal that can differ by tens of degrees, then depends
+ * on the compiler and on 1e-16 of the inputs (two runs of THIS file on inputs 1e-14 apart disagreed in a quarter of the
+ * cube-against-base throws).  Here ties are broken by rule instead: vertices within 1e-10 m of the largest projection count
+ * as tied and the lowest index wins; a box or capsule axis whose direction component is above -1e-10 takes its positive end.
+ * Either outcome is one MuJoCo could have produced; the support value changes by at most 1e-10 m against MPR's 1e-6 tolerance. */
+#define SUPPORT_TIE 1e-10
+/* the FIRST vertex whose projection on l is within SUPPORT_TIE of the largest (-1: no vertices) */
+static int hull_support_index(const double* verts, int nvert, const double* l) {
+  double bestv = -INFINITY;
+  for (int i = 0; i < nvert; i++) {
+    double v = dot3(verts + 3 * i, l);
+    if (v > bestv) bestv = v;
+  }
+  for (int i = 0; i < nvert; i++)
+    if (dot3(verts + 3 * i, l) >= bestv - SUPPORT_TIE) return i;
+  return -1;
+}
 static void support(const shape* s, const double* dir, double* out) {
   double l[3], w[3] = {0, 0, 0};
   matT_vec(s->R, dir, l);
   if (s->type == SH_HULL) {
-    double bestv = -INFINITY;
-    int bi = 0;
-    for (int i = 0; i < s->nvert; i++) {
-      double v = dot3(s->verts + 3 * i, l);
-      if (v > bestv) { bestv = v; bi = i; }
-    }
-    copy3(w, s->verts + 3 * bi);
+    const int bi = hull_support_index(s->verts, s->nvert, l);
+    copy3(w, s->verts + 3 * (bi < 0 ? 0 : bi));
   } else if (s->type == SH_BOX) {
-    for (int k = 0; k < 3; k++) w[k] = l[k] >= 0 ? s->size[k] : -s->size[k];
+    for (int k = 0; k < 3; k++) w[k] = l[k] >= -SUPPORT_TIE ? s->size[k] : -s->size[k];
   } else {
     double nl = norm3(l);
-    w[2] = l[2] >= 0 ? s->size[1] : -s->size[1];
+    w[2] = l[2] >= -SUPPORT_TIE ? s->size[1] : -s->size[1];
     if (nl > MINVAL) for (int k = 0; k < 3; k++) w[k] += s->size[0] * l[k] / nl;
   }
   mat_vec(s->R, w, out);
@@ -636,13 +651,9 @@ void orc_collide(const orc_model* m, orc_data* d) {
             const double ang = 2 * M_PI * (q - 1) / 3, cs = 1e-3 * cos(ang), sn = 1e-3 * sin(ang);
             for (int k = 0; k < 3; k++) dir[k] = -n[k] + cs * fr[3 + k] + sn * fr[6 + k];
           }
-          double dl[3], bestv = -INFINITY;
+          double dl[3];
           matT_vec(gR, dir, dl);
-          int bi = -1;
-          for (int v = 0; v < nv; v++) {
-            double s = dot3(V + 3 * v, dl);
-            if (s > bestv) { bestv = s; bi = v; }
-          }
+          const int bi = hull_support_index(V, nv, dl);
           if (bi < 0) break;
           int dup = 0;
           for (int k = 0; k < nch; k++) dup = dup || chosen[k] == bi;

@@ -222,6 +222,28 @@ RCSH_CONTACT_FN int dev_box_box(const double* p1, const double* R1, const double
 }
 
 // ------------------------------------------------------------------ Minkowski portal refinement (oracle: mpr_penetration)
+// Everything between here and `dev_mpr` is compiled WITHOUT multiply-add contraction and with vector helpers of its own that
+// round every product, as the oracle does (gcc -ffp-contract=off) and as libccd built by any C compiler does: the refinement is
+// a chain of sign tests on cross / dot products of nearly coplanar support points, and which portal it ends on -- a jump of
+// the contact normal by degrees -- must not depend on whether a product was rounded before its sum.
+#pragma clang fp contract(off)
+RCSH_D double nofma_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+RCSH_D void nofma_cross3(const double* a, const double* b, double* r) {
+  const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+RCSH_D void nofma_mulmv(const double* A, const double* v, double* r) {
+  const double x = A[0] * v[0] + A[1] * v[1] + A[2] * v[2], y = A[3] * v[0] + A[4] * v[1] + A[5] * v[2], z = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+RCSH_D void nofma_mulTv(const double* R, const double* v, double* o) {
+  const double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2], z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+#define dot3 nofma_dot3
+#define cross3 nofma_cross3
+#define mulmv nofma_mulmv
+#define mulTv nofma_mulTv
 struct Shape {
   int type;              // 0 hull, 1 box, 2 capsule
   const double *p, *R;   // world frame
@@ -230,11 +252,15 @@ struct Shape {
   int nvert;
   double center[3];
 };
-// Hull support: the FIRST vertex of largest projection (what a serial scan with a strict comparison finds).
-// TEAM = false: the calling lane scans all vertices (global memory).  TEAM = true: the 16 lanes of a team compute the same
-// query on vertices staged in LDS, scan every 16th vertex each and agree on the winner (value, then lower index) with four
-// row rotations -- a lane scanning global memory alone pays a full round trip per vertex, its wavefront having nothing else
-// to run.
+// Support ties are broken by RULE, not by round-off (oracle: SUPPORT_TIE, where the reason is written down): vertices within
+// kSupportTie of the largest projection count as tied and the lowest index wins; a box / capsule axis whose direction
+// component is above -kSupportTie takes its positive end.
+constexpr double kSupportTie = 1e-10;
+// Hull support.  TEAM = false: the calling lane scans all vertices (global memory), twice -- the largest projection, then the
+// first vertex within the tie band of it.  TEAM = true: the 16 lanes of a team compute the same query on vertices staged in
+// LDS, scan every 16th vertex each, agree on the largest projection with four row rotations, then each lane looks for its
+// first vertex inside the band and the team takes the lowest index -- a lane scanning global memory alone pays a full round
+// trip per vertex, its wavefront having nothing else to run.
 template <bool TEAM>
 RCSH_D int hull_support_index(const double* verts_, int nvert, const double* l) {
   double bestv = -INFINITY;
@@ -243,13 +269,16 @@ RCSH_D int hull_support_index(const double* verts_, int nvert, const double* l) 
     const double* verts = verts_;
     for (int i = 0; i < nvert; ++i) {
       const double v = verts[3 * i] * l[0] + verts[3 * i + 1] * l[1] + verts[3 * i + 2] * l[2];
-      if (v > bestv) { bestv = v; bi = i; }
+      if (v > bestv) bestv = v;
+    }
+    for (int i = 0; i < nvert; ++i) {
+      const double v = verts[3 * i] * l[0] + verts[3 * i + 1] * l[1] + verts[3 * i + 2] * l[2];
+      if (v >= bestv - kSupportTie) { bi = i; break; }
     }
     return bi;
   }
   const double* verts = in_lds(verts_);
   const int t = threadIdx.x & (kTeamLanes - 1);
-  bi = 0x7fffffff;  // (a lane without vertices: -inf and the largest index, never wins)
   for (int i0 = t; i0 < nvert; i0 += 4 * kTeamLanes) {
     // four vertices per trip: their reads go out together
     double x[4][3];
@@ -261,19 +290,38 @@ RCSH_D int hull_support_index(const double* verts_, int nvert, const double* l) 
     sched_fence();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * kTeamLanes;
-      const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];
-      if (i < nvert && v > bestv) { bestv = v; bi = i; }
+      const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];  // (a clamped duplicate of vertex i0 changes no maximum)
+      if (v > bestv) bestv = v;
     }
   }
-#define RCSH_ROT_MAX(N)                                                            \
-  {                                                                                \
-    const double ov = row_rotate<N>(bestv);                                        \
-    const int oi = __builtin_amdgcn_update_dpp(0, bi, 0x120 + N, 0xf, 0xf, true);  \
-    if (ov > bestv || (ov == bestv && oi < bi)) { bestv = ov; bi = oi; }           \
+  bestv = fmax(bestv, row_rotate<8>(bestv));
+  bestv = fmax(bestv, row_rotate<4>(bestv));
+  bestv = fmax(bestv, row_rotate<2>(bestv));
+  bestv = fmax(bestv, row_rotate<1>(bestv));
+  const double band = bestv - kSupportTie;
+  bi = 0x7fffffff;  // (a lane without a vertex in the band: the largest index, never wins)
+  for (int i0 = t; i0 < nvert && bi == 0x7fffffff; i0 += 4 * kTeamLanes) {
+    double x[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kTeamLanes < nvert ? i0 + u * kTeamLanes : i0;
+      x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
+    }
+    sched_fence();
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      const int i = i0 + u * kTeamLanes;
+      const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];
+      if (i < nvert && v >= band) bi = i;  // descending u: the lowest index of the trip is kept
+    }
   }
-  RCSH_ROT_MAX(8) RCSH_ROT_MAX(4) RCSH_ROT_MAX(2) RCSH_ROT_MAX(1)
-#undef RCSH_ROT_MAX
+#define RCSH_ROT_MIN(N)                                                            \
+  {                                                                                \
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, 0x120 + N, 0xf, 0xf, true);  \
+    bi = oi < bi ? oi : bi;                                                        \
+  }
+  RCSH_ROT_MIN(8) RCSH_ROT_MIN(4) RCSH_ROT_MIN(2) RCSH_ROT_MIN(1)
+#undef RCSH_ROT_MIN
   return bi;
 }
 template <bool TEAM = false>
@@ -285,10 +333,10 @@ RCSH_D void shape_support(const Shape& s, const double* dir, double* out) {
     const double* vv = TEAM ? in_lds(s.verts) : s.verts;
     w[0] = vv[3 * bi]; w[1] = vv[3 * bi + 1]; w[2] = vv[3 * bi + 2];
   } else if (s.type == 1) {
-    for (int k = 0; k < 3; ++k) w[k] = l[k] >= 0 ? s.size[k] : -s.size[k];
+    for (int k = 0; k < 3; ++k) w[k] = l[k] >= -kSupportTie ? s.size[k] : -s.size[k];
   } else {
     const double nl = sqrt(dot3(l, l));
-    w[2] = l[2] >= 0 ? s.size[1] : -s.size[1];
+    w[2] = l[2] >= -kSupportTie ? s.size[1] : -s.size[1];
     if (nl > kMinVal) for (int k = 0; k < 3; ++k) w[k] += s.size[0] * l[k] / nl;
   }
   mulmv(s.R, w, out);
@@ -437,6 +485,11 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
 RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
   return mpr_penetration<false>(A, B, depth, dir_out, pos);
 }
+#undef dot3
+#undef cross3
+#undef mulmv
+#undef mulTv
+#pragma clang fp contract(fast)
 
 // ---- self collision, flags only (DET instantiations of k_run_team).  Every lane of the wavefront calls this.
 // Broad phase: lane t of a team whose collision callback is due takes pairs t, t + 16, ... of the table, three at a time so

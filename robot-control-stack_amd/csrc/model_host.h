@@ -51,7 +51,8 @@ std::string build_collision_points(const HostModel& h, CollisionPoints& out);
 
 // The robot's collision geoms for the contact phase (contact_team.h), in geom order; `verts` are the hull vertices they
 // index (geom frame).  Class bits are filled in later from the SimRobot / SimGripper configurations.
-std::string build_contact_table(const HostModel& h, const DevModel& m, int plane_geom, std::vector<ContactGeom>& geoms, std::vector<double>& verts);
+std::string build_contact_table(const HostModel& h, const DevModel& m, int plane_geom, std::vector<ContactGeom>& geoms, std::vector<double>& verts,
+                                std::string& overflow /* geoms left out of the table because of a capacity limit: why (empty: none) */);
 
 // Calls fn(Topo<NARM, GRIP>{}) for the compiled archetype matching (narm, grip); false if none does.
 template <class F>

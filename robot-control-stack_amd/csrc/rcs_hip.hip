@@ -54,6 +54,7 @@ struct rcsh_sim {
   uint8_t* d_coll_cls = nullptr;
   // contact phase (contact_team.h): the robot's collision geoms and their hull vertices
   std::vector<ContactGeom> cgeoms;
+  std::string contact_overflow;  // why collision geoms were left out of `cgeoms` (capacity); empty: none were
   std::vector<double> cverts;
   ContactGeom* d_cgeoms = nullptr;
   SelfPair* d_pairs = nullptr;       // self-collision pairs a collision callback reacts to (rebuilt when the class bits change)
@@ -232,7 +233,7 @@ void build_self_pairs(rcsh_sim* s) {
       if (a.link == b.link) continue;
       if (a.link >= 0 && b.link >= 0 && (parent(a.link) == b.link || parent(b.link) == a.link)) continue;
       if ((a.type == 7 && a.vert_num == 0) || (b.type == 7 && b.vert_num == 0)) continue;  // mesh blob missing from the checkout
-      if (a.vert_num + b.vert_num > kSelfStageVertsHost) continue;  // (checked at rcsh_sim_create: hulls of at most 200 vertices)
+      if (a.vert_num + b.vert_num > kSelfStageVertsHost) continue;  // (the contact table admits hulls of at most 152 vertices each: model.cpp build_contact_table)
       const bool swap = a.type > b.type;  // geom[0] / geom[1] of the contact: by type, then by id (the table is in id order)
       const ContactGeom &g0 = swap ? b : a, &g1 = swap ? a : b;
       int cls = 0;
@@ -489,6 +490,7 @@ int observe_unmasked(rcsh_sim* s, const uint8_t* mask) {
   RunOp op{};
   op.nsteps = 0;
   op.write_obs = 1;
+  op.observe_only = 1;  // the frames the reset launch just recorded for the masked environments stay pending (rend.count / last)
   op.mask = d_inv;
   op.obs = s->d_stage2; op.info = s->d_bytes; op.gripper_width = s->d_stage;
   return launch_run(s, op, false);
@@ -557,7 +559,7 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
     std::string cwhy = build_collision_points(s->hm, s->cp);
     if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);
     s->cp_class.assign(s->cp.geom.size(), 0);
-    cwhy = build_contact_table(s->hm, s->dm, s->cp.has_plane ? s->cp.plane_geom : -1, s->cgeoms, s->cverts);
+    cwhy = build_contact_table(s->hm, s->dm, s->cp.has_plane ? s->cp.plane_geom : -1, s->cgeoms, s->cverts, s->contact_overflow);
     if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);
     if (s->cp.has_plane) s->plane_mu = s->hm.geom_friction[3 * (size_t)s->cp.plane_geom];
     if (!s->cp.geom.empty()) {
@@ -798,6 +800,7 @@ int rcsh_robot_get_cartesian_position(rcsh_sim* s, double* pose) {
   RunOp op{};
   op.nsteps = 0;
   op.write_obs = 1;
+  op.observe_only = 1;
   op.obs = s->d_stage2;
   int rc = launch_run(s, op, false);
   if (rc) return rc;
@@ -1051,6 +1054,7 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   b.geom_mu = d->geom_friction[0] > 0 ? d->geom_friction[0] : d->friction[0];
   // contacts of the robot's geoms with the floor and the box: FR3 + hand archetype (the coupled solve has no dry-friction rows)
   b.resolve = d->resolve_robot_contacts && s->grip && !s->dm.has_friction && !s->cgeoms.empty();
+  if (b.resolve && !s->contact_overflow.empty()) return fail(RCSH_ERR_MODEL, "robot contacts cannot be resolved in this scene: " + s->contact_overflow);
   make_kb(d->solref, d->solimp, s->dm.timestep, b.K, b.B);
   b.imp = make_imp(d->solimp);
   b.inv_impratio = 1.0 / d->impratio;
@@ -1074,6 +1078,7 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
   if (!(s->narm == 7 && s->grip && !s->dm.has_friction)) return fail(RCSH_ERR_MODEL, "contacts of the robot's geoms are resolved for the FR3 + hand archetype (no dry joint friction)");
   if (!o->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
   if (!(o->impratio > 0)) return fail(RCSH_ERR_ARG, "impratio must be positive");
+  if (!s->contact_overflow.empty()) return fail(RCSH_ERR_MODEL, "robot contacts cannot be resolved in this scene: " + s->contact_overflow);
   if (s->cgeoms.empty() || !s->cp.has_plane) return RCSH_OK;  // nothing the robot could touch
   // the phantom box of the contact phase: unit inertia, zero size, parked 1 km above the scene
   BoxCfg b{};

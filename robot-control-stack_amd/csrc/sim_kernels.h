@@ -93,6 +93,7 @@ struct RunOp {
   int32_t apply_action;   // env.step(): wrappers' action() + RobotEnv.step
   int32_t nsteps;         // >= 0: Sim.step(nsteps); < 0: Sim.step_until_convergence()
   int32_t write_obs;
+  int32_t observe_only;   // an observation-only pass (nsteps = 0) that must leave the rendering records of the last stepping launch alone
   const uint8_t* mask;    // optional, device
   const double* action;   // [n][action_width], device
   const float* gripper;   // [n], device
@@ -747,7 +748,7 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   // rate-driven cameras: the teams' camera clocks and record counters (RendCfg)
   __shared__ double lrend[kTeams][kMaxRateCams + 2];
   const int rend_ncam = lp.rend.ncam;
-  const bool rend_on = rend_ncam > 0;  // (wave-uniform)
+  const bool rend_on = rend_ncam > 0 && !op.observe_only;  // (wave-uniform)
   if (rend_on && leader) {
     // Sim::reset -> reset_callbacks (sim.cpp:131-137): "negative so that we will directly render the cameras in the first step"
     for (int c = 0; c < rend_ncam; ++c) lrend[team][c] = op.do_reset ? -lp.rend.period[c] : lp.rend.last[(size_t)c * P.n + e];

@@ -261,11 +261,13 @@ def check(rc: int) -> None:
 
 
 def ptr(a: np.ndarray | None):
-    """void* of a C-contiguous numpy array (None -> NULL)."""
+    """void* of a C-contiguous numpy array (None -> NULL).  The returned object holds a reference to the array (numpy's
+    `data_as` contract), so `ptr(temporary)` as a call argument keeps the temporary alive until the call has returned -- a bare
+    `c_void_p(a.ctypes.data)` does not: the C side then reads freed memory (found by tests/test_dynamics_golden.py, round 3)."""
     if a is None:
         return None
     assert a.flags["C_CONTIGUOUS"]
-    return C.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def make_model_desc(cm) -> tuple[ModelDesc, list[np.ndarray]]:

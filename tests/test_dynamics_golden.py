@@ -100,8 +100,8 @@ def _hip_one_substep(tag, g):
     simu.set_qpos(np.array([s["qpos"] for s in g["samples"]]))
     simu.set_qvel(np.array([s["qvel"] for s in g["samples"]]))
     robot.set_joint_position(ctrl[:, :7])
-    assert np.abs(simu.ctrl - ctrl).max() < 1e-12
-    simu.step(1)
+    simu.step(1)  # the commanded targets reach mjData.ctrl inside this launch
+    assert np.abs(simu.ctrl - ctrl).max() < 1e-12, (simu.ctrl[:2], ctrl[:2])
     q, v = simu.qpos, simu.qvel
     simu.close()
     return q, v

@@ -11,6 +11,8 @@ async 17 substeps and until-convergence): joint positions 2e-15, joint VELOCITIE
 on a joint limit with zero actuator force, flipped a one-sided limit row on 1e-17 round-off.  That kernel is gone.)
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -1021,17 +1023,17 @@ def test_rate_driven_cameras_match_oracle(kernel):
 def test_cube_against_the_robot_base(kernel):
     """Collision geoms welded to the world (link 0's hull) against the free cube: contacts between the world body and the cube
     that are NOT the floor's.  The cube is thrown at the base from all around, spinning; it bounces off in the kernel as in the
-    oracle.  Most environments agree to round-off over the 150 substeps.  Not all can be held to that: the portal refinement of
-    a box face lying 15 mm deep in a hull facet has several portals of nearly equal depth to end on, and which one it picks --
-    a jump of the contact normal by a few degrees -- is decided by the last bit of its inputs (the kernel contracts
-    multiply-adds, the oracle does not); MuJoCo's own libccd is no more deterministic across compilers.  Those environments
-    must still keep the cube outside the base and within millimetres of the oracle's."""
+    oracle, in EVERY environment to round-off.  (Round 2 let 3 of 12 environments differ by centimetres: the portal refinement
+    broke exact support ties -- a portal normal is perpendicular to a box edge by construction -- by the sign of round-off;
+    ties are broken by rule now, in the oracle and in the kernel, and the refinement is compiled without multiply-add
+    contraction: oracle rcs_contact.c SUPPORT_TIE, kernel contact_team.h kSupportTie.)"""
     from parity_util import run_cube_against_base_parity
 
-    rep = run_cube_against_base_parity()
-    assert rep["base_contact_envs"] >= 6 and rep["max_abs_robot_qpos"] < TOL, rep
-    assert (rep["env_pos_err"] < 1e-7).sum() >= 9 and rep["max_abs_pos"] < 0.02, rep
-    assert (rep["final_radius"] > 0.08).all(), rep  # nowhere did the cube pass through the base
+    for seed in (5, 11, 15):
+        rep = run_cube_against_base_parity(seed=seed)
+        assert rep["base_contact_envs"] >= 6 and rep["max_abs_robot_qpos"] < TOL, rep
+        assert (rep["env_pos_err"] < 1e-9).all() and rep["max_abs_quat"] < 1e-8, rep
+        assert (rep["final_radius"] > 0.08).all(), rep  # nowhere did the cube pass through the base
 
 
 def test_pybind_camera_set_equals_ctypes_host_layer(kernel):
@@ -1166,3 +1168,71 @@ def test_c_host_equals_python_host(kernel, tmp_path):
             if t > 0:
                 assert int(tok[tok.index("substeps") + 1]) == int(info["substeps"][e]) == 17
     env.close()
+
+
+def test_masked_reset_keeps_the_reset_frames_of_rate_driven_cameras(kernel):
+    """env.reset(mask) with SimCameraSet(render_on_demand=False): the reference renders in the first substep after a reset
+    (clocks at -1 / rate, sim.cpp:131-137), so the reset environments must come back with a frame stamped with their new
+    time.  (Advisor, round 2: the observation-only pass over the UNmasked rows used to wipe those records.)"""
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import ControlMode, RelativeTo, default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_amd.envs.creators import VecSimEnv
+
+    n = 6
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(async_control=True, frequency=30), n_envs=n)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, default_sim_gripper_cfg())
+    cams = {"wrist_0": SimCameraConfig(identifier="wrist_0", frame_rate=30, resolution_width=16, resolution_height=12)}
+    cs = SimCameraSet(simu, cams, physical_units=True, render_on_demand=False)
+    env = VecSimEnv(simu, robot, grip, ControlMode.JOINTS, float(np.deg2rad(5)), RelativeTo.LAST_STEP, camera_set=cs)
+    obs, info = env.reset()
+    assert info["camera_available"] and np.allclose(info["frame_timestamp"], 0.002)
+    for _ in range(3):
+        obs, _, _, _, info = env.step({"joints": np.full((n, 7), 0.01), "gripper": np.ones(n)})
+    t_before = simu.time.copy()
+    mask = np.array([1, 0, 1, 0, 0, 1], dtype=bool)
+    obs, info = env.reset(mask=mask)
+    assert info["camera_available"], "the reset environments' first frames were dropped"
+    ts = info["frame_timestamp"]
+    assert np.allclose(ts[mask], 0.002) and np.all(np.isnan(ts[~mask])), ts  # (clear_buffer: the others wait for their next frame)
+    assert np.allclose(simu.time[mask], 0.002) and np.array_equal(simu.time[~mask], t_before[~mask])
+    obs, _, _, _, info = env.step({"joints": np.zeros((n, 7)), "gripper": np.ones(n)})
+    assert not np.isnan(info["frame_timestamp"]).any()
+    env.close()
+
+
+def test_contact_table_capacity_is_fatal_only_when_contacts_are_resolved(kernel, tmp_path):
+    """A scene with more box geoms than the contact phase holds (the two fingers' pads use all ten) still loads and steps --
+    the extra geom is merely invisible to geom-geom detection -- and asking for its robot contacts to be RESOLVED is the
+    model error.  (Advisor, round 2.)"""
+    import shutil
+
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_robot_cfg
+    from parity_util import SCENE
+
+    xml = open(SCENE).read()
+    marker = "<worldbody>"
+    assert marker in xml
+    xml = xml.replace(marker, marker + '\n    <geom name="table_block" type="box" size="0.1 0.1 0.02" pos="0.9 0 0.02"/>', 1)
+    scene = tmp_path / "scene.xml"
+    scene.write_text(xml)
+    for extra in ("collision_vertices.npz", "render_hulls.npz"):
+        shutil.copy(os.path.join(os.path.dirname(SCENE), extra), tmp_path)
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(str(scene), S.SimConfig(), n_envs=4)
+    robot = S.SimRobot(simu, None, cfg)
+    robot.set_joint_position(np.tile(cfg_home(robot), (4, 1)))
+    simu.step_until_convergence()
+    assert simu.is_converged().all()
+    simu.close()
+    with pytest.raises(RuntimeError, match="box geoms"):
+        S.Sim(str(scene), S.SimConfig(), n_envs=4, resolve_robot_contacts=True)
+
+
+def cfg_home(robot):
+    from rcs_amd import common
+
+    return np.asarray(common.sim_robots_meta_config(robot.get_config().robot_type).q_home)[: robot.dof]
