@@ -335,9 +335,11 @@ def main() -> None:
         one_step(t)
     from rcs_amd import _lib
 
-    # HIP events on the launch stream around every 8th env-step launch of the timed region: a pair of event records
-    # around every launch would put ~8 us of dispatch gap into each step of the run it is measuring
-    _lib.check(L.rcsh_prof_enable(h, 8))
+    # HIP events on the launch stream: ONE pair around the whole timed region (rcsh_prof_enable(h, -1)) -- the stream time of
+    # the region's stepping launches, dispatch gaps included, divided by their number.  (A pair around every launch puts ~8 us
+    # of dispatch gap into each step of the run it is measuring; pairs around every 8th launch, rounds 1-2, left 3 samples at
+    # the driver's --steps 20 and a per-launch figure above the step time it is part of.)
+    _lib.check(L.rcsh_prof_enable(h, -1))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -347,6 +349,11 @@ def main() -> None:
         one_step(t)
         if args.mode == "convergence":
             substeps_total += 0  # per-step counts stay on the device; read once after the timed region
+    # the region's closing event goes onto the launch stream right behind the last step (reading it waits for that stream)
+    import ctypes as C
+
+    ms, launches = C.c_double(0), C.c_int64(0)
+    _lib.check(L.rcsh_prof_read(h, C.byref(ms), C.byref(launches)))
     if exchange:
         exchange.drain()
     torch.cuda.synchronize()
@@ -361,10 +368,6 @@ def main() -> None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    import ctypes as C
-
-    ms, launches = C.c_double(0), C.c_int64(0)
-    _lib.check(L.rcsh_prof_read(h, C.byref(ms), C.byref(launches)))
     kernel_ms = ms.value / max(launches.value, 1)
     mean_sub = float(sub.to(torch.float64).mean().item())
     finite = bool(torch.isfinite(obs).all().item())

@@ -177,8 +177,11 @@ void* rcsh_sim_stream(rcsh_sim* sim);
 int rcsh_sim_set_stream(rcsh_sim* sim, void* hip_stream);
 /* Kernel selection (no reference counterpart).  Every scene runs on the team kernel (16 lanes per environment);
  * RCSH_KERNEL_AUTO and RCSH_KERNEL_TEAM both name it.  RCSH_KERNEL_LANE, the one-lane-per-environment kernel of ABI 1, was
- * removed (it lost at every batch size and stepped neither dry friction nor free bodies): selecting it is RCSH_ERR_ARG. */
-enum { RCSH_KERNEL_AUTO = 0, RCSH_KERNEL_TEAM = 1, RCSH_KERNEL_LANE = 2 };
+ * removed (it lost at every batch size and stepped neither dry friction nor free bodies): selecting it is RCSH_ERR_ARG.
+ * RCSH_KERNEL_TEAM_OCC2 is the same team kernel compiled for two resident wavefronts per SIMD (<= 256 registers); it exists
+ * for the launches without free box / resolved contacts / collision callbacks and falls back to TEAM elsewhere.  AUTO picks
+ * by batch size; the results of the two are bit-identical. */
+enum { RCSH_KERNEL_AUTO = 0, RCSH_KERNEL_TEAM = 1, RCSH_KERNEL_LANE = 2, RCSH_KERNEL_TEAM_OCC2 = 3 };
 int rcsh_sim_set_kernel(rcsh_sim* sim, int32_t variant);
 
 /* Sim.set_config / get_config -- rcs.cpp:501-502, sim.cpp:27-32; SimConfig sim.h:29-34 */
@@ -430,7 +433,10 @@ int rcsh_dev_download(rcsh_sim* sim, void* dst_host, const void* src_dev, size_t
 int rcsh_debug_dump_model(rcsh_sim* sim, void* buf, size_t cap, size_t* size);
 
 /* kernel timing hooks for bench.py: HIP events on the handle's stream around every `enable`-th fused env-step launch
- * (1: every launch; 0: off).  A pair of event records around EVERY launch costs ~8 us of dispatch gap per step. */
+ * (1: every launch; 0: off).  A pair of event records around EVERY launch costs ~8 us of dispatch gap per step.
+ * enable < 0: REGION mode -- one event before the first stepping launch after this call, one when rcsh_prof_read is called;
+ * read returns the stream time between them and the number of stepping launches it covers (the launches' durations plus the
+ * dispatch gaps between them: an upper bound of the kernel's average duration, no event traffic inside the region). */
 int rcsh_prof_enable(rcsh_sim* sim, int32_t enable);
 int rcsh_prof_read(rcsh_sim* sim, double* total_ms, int64_t* launches);
 

@@ -41,6 +41,7 @@ constexpr int kProfRing = 4096;
 struct rcsh_sim {
   int device = 0;
   int kernel = RCSH_KERNEL_AUTO;
+  int n_simd = 1024;  // SIMDs of the device (4 per compute unit)
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
   int n = 0;
@@ -107,6 +108,8 @@ struct rcsh_sim {
   int comm_rank = 0, comm_world = 1;
   // profiling
   bool prof = false;
+  bool prof_region = false;            // one event pair around the whole timed region instead of sampled launches
+  int64_t prof_region_launches = 0;
   std::vector<hipEvent_t> ev_start, ev_stop;
   int prof_pending = 0;
   int prof_every = 1;       // HIP events around every prof_every-th stepping launch
@@ -337,10 +340,40 @@ int prof_flush(rcsh_sim* s) {
   return RCSH_OK;
 }
 
+// Which compilation of the team kernel a launch without free box / contacts / detection takes.  Measured (profiles/r3_occ2):
+// a second resident wavefront per SIMD is worth 1.4-1.6x once the batch brings more than one wavefront per SIMD -- for a build
+// that fits 256 registers by itself (the 6-dof arms: 67.6 M env-steps/s at 8192 environments against 49.0 M at 4096) or spills
+// a few values (SO101: 200 bytes of scratch, 1.21-1.31x); a build squeezed into 256 registers at the price of hundreds of
+// scratch accesses per substep loses (FR3 + hand: 488 bytes, 0.70x; xArm7: 888 bytes, 0.9x).  Hence AUTO: the <= 256-register
+// build when the batch has more wavefronts than the device has SIMDs AND that build's private segment is at most 256 bytes.
+// RCSH_OCC2=0/1 in the environment overrides the rule (measurements).
+template <class T, bool F>
+bool occ2_build_pays() {
+  static const bool pays = [] {
+    hipFuncAttributes a{};
+    if (hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_run_team_occ2<T, F, false, false, false>)) != hipSuccess) return false;
+    return a.localSizeBytes <= 256;
+  }();
+  return pays;
+}
+template <class T, bool F>
+bool use_occ2(const rcsh_sim* s) {
+  if (s->kernel == RCSH_KERNEL_TEAM_OCC2) return true;
+  if (s->kernel == RCSH_KERNEL_TEAM) return false;
+  static const int forced = [] { const char* e = std::getenv("RCSH_OCC2"); return e ? std::atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  return (s->n + 3) / 4 > s->n_simd && occ2_build_pays<T, F>();
+}
+
 int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
   Params P = make_params(s);
   hipError_t err = hipSuccess;
-  const bool sample = timed && s->prof && (s->prof_seen++ % s->prof_every) == 0;
+  if (timed && s->prof_region) {
+    // region mode: one event before the first timed launch, one after the last (rcsh_prof_read): no event traffic in between
+    if (s->prof_region_launches == 0) HIP_TRY(hipEventRecord(s->ev_start[0], s->stream));
+    s->prof_region_launches++;
+  }
+  const bool sample = timed && s->prof && !s->prof_region && (s->prof_seen++ % s->prof_every) == 0;
   if (sample) {
     if (s->prof_pending == kProfRing) {
       int rc = prof_flush(s);
@@ -362,7 +395,10 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
     auto go = [&](auto fric, auto box, auto con) {
       constexpr bool F = decltype(fric)::value, B = decltype(box)::value, C = decltype(con)::value;
       if (det) hipLaunchKernelGGL((k_run_team<T, F, B, C, true>), grid, block, 0, s->stream, P, op);
-      else hipLaunchKernelGGL((k_run_team<T, F, B, C, false>), grid, block, 0, s->stream, P, op);
+      else if constexpr (!B && !C) {
+        if (use_occ2<T, F>(s)) hipLaunchKernelGGL((k_run_team_occ2<T, F, false, false, false>), grid, block, 0, s->stream, P, op);
+        else hipLaunchKernelGGL((k_run_team<T, F, false, false, false>), grid, block, 0, s->stream, P, op);
+      } else hipLaunchKernelGGL((k_run_team<T, F, B, C, false>), grid, block, 0, s->stream, P, op);
       launched = true;
     };
     using Y = std::true_type;
@@ -551,6 +587,10 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
     if (_e != hipSuccess) return cleanup(RCSH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
   HIP_NEW(hipSetDevice(device));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_simd = 4 * cus;
+  }
   HIP_NEW(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
   s->stream = s->own_stream;
   const size_t n = (size_t)n_envs;
@@ -630,7 +670,7 @@ int rcsh_sim_set_stream(rcsh_sim* s, void* hip_stream) {
 int rcsh_sim_set_kernel(rcsh_sim* s, int32_t variant) {
   REQUIRE_SIM(s);
   if (variant == RCSH_KERNEL_LANE) return fail(RCSH_ERR_ARG, "the one-lane-per-environment kernel was removed (ABI 2): every scene runs on the team kernel");
-  if (variant != RCSH_KERNEL_AUTO && variant != RCSH_KERNEL_TEAM) return fail(RCSH_ERR_ARG, "unknown kernel variant");
+  if (variant != RCSH_KERNEL_AUTO && variant != RCSH_KERNEL_TEAM && variant != RCSH_KERNEL_TEAM_OCC2) return fail(RCSH_ERR_ARG, "unknown kernel variant");
   s->kernel = variant;
   return RCSH_OK;
 }
@@ -1609,10 +1649,24 @@ int rcsh_comm_init(rcsh_sim* s, const uint8_t id[RCSH_COMM_ID_BYTES], int32_t ra
   if (!r.why.empty()) return fail(RCSH_ERR_DEVICE, r.why);
   Rccl::UniqueId u;
   std::memcpy(u.internal, id, RCSH_COMM_ID_BYTES);
-  RCCL_TRY(r.CommInitRank(&s->comm, world, u, rank));
-  HIP_TRY(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&s->comm_ready, hipEventDisableTiming));
-  for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&s->comm_done[k], hipEventDisableTiming));
+  // the communicator, its stream and its events belong to THIS handle's device: a host with one process per GPU that never
+  // called hipSetDevice itself (a plain C host has no reason to) must not end up with every rank on device 0
+  HIP_TRY(hipSetDevice(s->device));
+  // stream and events first: they cannot fail collectively, ncclCommInitRank can only be entered by all ranks or none
+  hipError_t he = hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipEventCreateWithFlags(&s->comm_ready, hipEventDisableTiming);
+  for (int k = 0; k < 2 && he == hipSuccess; ++k) he = hipEventCreateWithFlags(&s->comm_done[k], hipEventDisableTiming);
+  int nrc = 0;
+  if (he == hipSuccess) nrc = r.CommInitRank(&s->comm, world, u, rank);
+  if (he != hipSuccess || nrc != 0) {
+    if (s->comm_stream) hipStreamDestroy(s->comm_stream);
+    if (s->comm_ready) hipEventDestroy(s->comm_ready);
+    for (int k = 0; k < 2; ++k) if (s->comm_done[k]) hipEventDestroy(s->comm_done[k]);
+    s->comm = nullptr; s->comm_stream = nullptr; s->comm_ready = s->comm_done[0] = s->comm_done[1] = nullptr;
+    if (he != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("communicator stream / events: ") + hipGetErrorString(he));
+    return fail(RCSH_ERR_DEVICE, std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(nrc) : "error ") + " (" + std::to_string(nrc) + ")");
+  }
+  s->comm_pending[0] = s->comm_pending[1] = false;
   s->comm_rank = rank;
   s->comm_world = world;
   return RCSH_OK;
@@ -1649,8 +1703,10 @@ int rcsh_comm_wait(rcsh_sim* s, int32_t slot, int32_t block_host) {
   if (!s->comm) return fail(RCSH_ERR_STATE, "no communicator: call rcsh_comm_init first");
   if (slot < 0 || slot > 1) return fail(RCSH_ERR_ARG, "exchange slot is 0 or 1");
   if (!s->comm_pending[slot]) return RCSH_OK;
-  if (block_host) HIP_TRY(hipEventSynchronize(s->comm_done[slot]));
-  else HIP_TRY(hipStreamWaitEvent(s->stream, s->comm_done[slot], 0));
+  if (block_host) {
+    HIP_TRY(hipEventSynchronize(s->comm_done[slot]));
+    s->comm_pending[slot] = false;  // (a stream-side wait leaves it set: a later host-side wait must still see the event)
+  } else HIP_TRY(hipStreamWaitEvent(s->stream, s->comm_done[slot], 0));
   return RCSH_OK;
 }
 
@@ -1725,6 +1781,8 @@ int rcsh_prof_enable(rcsh_sim* s, int32_t enable) {
     }
   }
   s->prof = enable != 0;
+  s->prof_region = enable < 0;
+  s->prof_region_launches = 0;
   s->prof_every = enable > 1 ? enable : 1;
   s->prof_seen = 0;
   s->prof_pending = 0; s->prof_ms = 0; s->prof_launches = 0;
@@ -1732,6 +1790,18 @@ int rcsh_prof_enable(rcsh_sim* s, int32_t enable) {
 }
 int rcsh_prof_read(rcsh_sim* s, double* total_ms, int64_t* launches) {
   REQUIRE_SIM(s);
+  if (s->prof_region) {
+    float ms = 0.f;
+    if (s->prof_region_launches > 0) {
+      HIP_TRY(hipEventRecord(s->ev_stop[0], s->stream));
+      HIP_TRY(hipEventSynchronize(s->ev_stop[0]));
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev_start[0], s->ev_stop[0]));
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = s->prof_region_launches;
+    s->prof_region_launches = 0;
+    return RCSH_OK;
+  }
   int rc = prof_flush(s);
   if (rc) return rc;
   if (total_ms) *total_ms = s->prof_ms;

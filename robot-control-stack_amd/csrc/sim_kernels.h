@@ -572,8 +572,11 @@ __device__ __forceinline__ void stage_team_model(const DevModel* gm, DevModelHea
 // after which one of them is due the position stage also detects contacts -- the floor against the sample points of the
 // collision geoms, and the robot's geoms against each other.  Launches that never look at the flags (Sim::step(k)) and
 // models without collision geoms run the instantiation without that code.
-template <class T, bool FRIC, bool BOX = false, bool CON = false, bool DET = false>
-__global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
+// The body is a device function so that two kernels can share it: `k_run_team` (whatever registers it takes: one wavefront
+// per SIMD, the headline batch of 4096 environments IS one wavefront per SIMD) and `k_run_team_occ2`, compiled for two resident
+// wavefronts per SIMD (at most 256 VGPRs + AGPRs), for batches that bring more than one wavefront per SIMD.
+template <class T, bool FRIC, bool BOX, bool CON, bool DET>
+__device__ __attribute__((always_inline)) inline void run_team_body(const Params& Pk, const RunOp& opk) {
   using ST = StageTeam<T>;
   constexpr int kTeams = 64 / kTeamLanes;
   __shared__ DevModelHead lm;
@@ -1017,6 +1020,14 @@ __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
   }
   TEAM_MARK(10)
   TEAM_CLOCK_FLUSH()
+}
+template <class T, bool FRIC, bool BOX = false, bool CON = false, bool DET = false>
+__global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {
+  run_team_body<T, FRIC, BOX, CON, DET>(Pk, opk);
+}
+template <class T, bool FRIC, bool BOX = false, bool CON = false, bool DET = false>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_run_team_occ2(Params Pk, RunOp opk) {
+  run_team_body<T, FRIC, BOX, CON, DET>(Pk, opk);
 }
 
 // ---- small elementwise kernels behind the 1:1 SimRobot / SimGripper / mjData accessors

@@ -115,13 +115,14 @@ class RcclObservationExchange:
         from .. import _lib
 
         self._C, self._lib, self._L, self._h = C, _lib, _lib.load(), sim._h
+        self._sim = sim  # keeps the handle alive for as long as the buffers exist
+        self._local, self._all = [], []
         self.rank, self.world = rank, world
         own = (sim.n_envs, int(self._L.rcsh_env_obs_width(sim._h)))
         self.n, self.width = (n_rows or own[0]), (width or own[1])
         self._plain = (self.n, self.width) == own  # the block IS the sim's observation tensor: rcsh_env_allgather_obs_dev
         _lib.check(self._L.rcsh_comm_init(self._h, unique_id, rank, world))
         self._bytes = 8 * self.n * self.width
-        self._local, self._all = [], []
         for _ in range(2):
             for lst, size in ((self._local, self._bytes), (self._all, self._bytes * world)):
                 p = C.c_void_p()
@@ -161,3 +162,17 @@ class RcclObservationExchange:
                 self._L.rcsh_dev_free(self._h, p)
             self._L.rcsh_comm_destroy(self._h)
             self._h = None
+            self._sim = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    def __del__(self):
+        try:
+            if self._sim is not None and getattr(self._sim, "_h", None):  # (the sim's own close destroys the communicator)
+                self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass

@@ -137,7 +137,7 @@ class Sim:
 
     def set_kernel(self, variant: str) -> None:
         """Pin the kernel variant: "auto" / "team" (16 lanes per environment).  "lane", the one-lane kernel of ABI 1, was removed: ValueError."""
-        _lib.check(self._L.rcsh_sim_set_kernel(self._h, {"auto": 0, "team": 1, "lane": 2}[variant]))
+        _lib.check(self._L.rcsh_sim_set_kernel(self._h, {"auto": 0, "team": 1, "lane": 2, "team_occ2": 3}[variant]))
 
     def get_state(self) -> np.ndarray:
         """Opaque snapshot of everything that evolves (physics, callback scheduler, robot / gripper / wrapper state)."""
