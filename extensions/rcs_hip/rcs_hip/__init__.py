@@ -55,3 +55,38 @@ def render_tables(cm, scene_dir: str) -> dict:
         cams[""] = render.default_free_camera(cm)
     d["cameras"] = {k: (int(v[0]), np.asarray(v[1], dtype=np.float64), np.asarray(v[2], dtype=np.float64), float(v[3])) for k, v in cams.items()}
     return d
+
+
+def pin_tables(path: str, frame_id: str, device: int = 0) -> dict:
+    """What ``rcs_hip._core.common.Pin(path, frame_id, urdf=False)`` loads: the model tables of the MJCF at `path` plus the ids
+    of the serial chain that carries the site `frame_id` -- its hinge joints from the root outwards, their actuators, the site,
+    the root body the chain hangs on (the frame ``Pin`` works in; DESIGN.md section 5 on pinocchio's root-frame semantics)."""
+    from rcs_amd.mjcf import compile_mjcf
+
+    cm = compile_mjcf(path)
+    site = cm.name2id("site", frame_id)
+    if site < 0:
+        raise RuntimeError(f"No site named {frame_id}")
+    parent = np.asarray(cm.arrays["body_parentid"])
+    jnt_body = np.asarray(cm.arrays["jnt_bodyid"])
+    jnt_type = np.asarray(cm.arrays["jnt_type"])
+    chain, b = [], int(np.asarray(cm.arrays["site_bodyid"])[site])
+    base = b
+    while b > 0:
+        js = [int(j) for j in np.nonzero(jnt_body == b)[0] if jnt_type[j] == 3]
+        chain = js + chain
+        if js:
+            base = int(parent[b])
+        b = int(parent[b])
+    trn = np.asarray(cm.arrays["actuator_trnid"]).reshape(cm.nu, -1)[:, 0]
+    trntype = np.asarray(cm.arrays["actuator_trntype"])
+    acts = []
+    for j in chain:
+        a = [u for u in range(cm.nu) if trntype[u] == 0 and trn[u] == j]
+        if not a:
+            raise RuntimeError(f"joint {cm.jnt_names[j]} of the chain has no actuator: the backend's archetypes are actuated arms")
+        acts.append(a[0])
+    while base > 0 and len(np.nonzero(jnt_body == base)[0]) == 0 and parent[base] > 0:
+        base = int(parent[base])  # the robot's root body: the first static body under the world
+    return {"model": model_tables(cm), "joints": np.asarray(chain, dtype=np.int32), "actuators": np.asarray(acts, dtype=np.int32), "site": int(site),
+            "base": int(base), "device": int(device)}

@@ -423,11 +423,14 @@ void Sim::collect_frames() {
 
 }  // namespace
 
+void bind_common(py::module_& m);  // common.cpp: rcs_hip._core.common (Pose, RPY, Kinematics, Pin, robots_meta_config, ...)
+
 PYBIND11_MODULE(_core, m) {
   m.doc() = "MI355X batched simulation backend for RCS: the N-environment form of rcs._core.sim (librcs_hip.so)";
   m.attr("__version__") = "0.2";
   m.def("abi_version", &rcsh_abi_version);
   m.def("device_count", &rcsh_device_count);
+  bind_common(m);
   auto sim = m.def_submodule("sim", "sim module");
 
   py::class_<SimConfig>(sim, "SimConfig")

@@ -531,3 +531,90 @@ def test_pybind_module_matches_the_reference_api():
     g = _core.sim.SimGripperConfig()
     g.add_id("0")
     assert g.joint == "finger_joint1_0" and g.collision_geoms[0] == "hand_c_0" and g.max_actuator_width == 255
+
+
+def test_pybind_common_module_matches_the_reference_api():
+    """`rcs_hip._core.common` against the NAMES of the reference's `rcs._core.common` (tests/golden/core_common_api.json, from
+    the reference's common.pyi by tools/make_core_api_fixture.py): Pose, RPY, Kinematics, Pin, RobotType, RobotPlatform,
+    RobotMetaConfig, RobotConfig, BaseCameraConfig, GraspType -- every method, every overload's argument names, every field --
+    the module functions and the exported enum constants, with the reference's enum values (Robot.h:22-23)."""
+    import json
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "extensions", "rcs_hip"))
+    from rcs_hip import _core
+
+    c = _core.common
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "core_common_api.json")))
+    for cls, spec in api["classes"].items():
+        k = getattr(c, cls)
+        for name, args in spec["methods"].items():
+            assert hasattr(k, name), (cls, name)
+            if cls in ("RobotType", "RobotPlatform", "GraspType") and name.startswith("__"):
+                continue  # pybind11's enum machinery
+            doc = getattr(k, name).__doc__ or ""
+            for overload in spec["overloads"].get(name, [args]):
+                # some line of the docstring (one per overload) names all of this overload's arguments
+                assert any(all(re.search(rf"\b{a}: ", line) for a in overload) for line in doc.split("\n")), (cls, name, overload, doc)
+        for f in spec["fields"]:
+            assert hasattr(k, f), (cls, f)
+        for base in spec["bases"]:
+            assert issubclass(k, getattr(c, base)), (cls, base)
+    for fn, args in api["functions"].items():
+        sig = getattr(c, fn).__doc__.split("\n")[0]
+        assert [a for a in args if a not in re.findall(r"(\w+): ", sig)] == [], (fn, sig)
+    for name in api["constants"]:
+        assert hasattr(c, name), name
+    assert [int(c.RobotType.FR3), int(c.RobotType.UR5e), int(c.RobotType.SO101), int(c.RobotType.XArm7)] == [0, 1, 2, 3]
+    assert [int(c.RobotPlatform.SIMULATION), int(c.RobotPlatform.HARDWARE)] == [0, 1]
+    # values: the compiled tables equal the host mirror's (include/rcs/Robot.h:24-95), the helpers the reference's constants
+    from rcs_amd import common as H
+
+    for t in ("FR3", "UR5e", "SO101", "XArm7"):
+        a, b = c.robots_meta_config(getattr(c.RobotType, t)), H.robots_meta_config(getattr(H.RobotType, t))
+        assert a.dof == b.dof and np.array_equal(a.q_home, b.q_home) and np.array_equal(a.joint_limits, b.joint_limits), t
+    assert np.array_equal(c.FrankaHandTCPOffset(), H.FrankaHandTCPOffset()) and np.array_equal(c.IdentityRotQuatVec(), [0, 0, 0, 1])
+    cfg = c.RobotConfig()
+    assert (cfg.robot_type, cfg.robot_platform, cfg.attachment_site) == (c.RobotType.FR3, c.RobotPlatform.SIMULATION, "attachment_site")
+    assert cfg.tcp_offset.is_close(c.Pose())
+    with pytest.raises(RuntimeError, match="URDF"):
+        c.Pin("robot.urdf")
+
+
+def test_compiled_pose_equals_the_host_mirror():
+    """Every Pose / RPY operation of the compiled classes (csrc/pose.h on the host) against the Python mirror that the
+    reference's own known answers pin (tests/test_oracle_pins.py), on random inputs incl. improper matrices: round-off."""
+    import pickle
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "extensions", "rcs_hip"))
+    from rcs_hip import _core
+    from rcs_amd import common as H
+
+    c = _core.common
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(300):
+        q, t, m = rng.normal(size=4), rng.normal(size=3), rng.normal(size=(4, 4))
+        m[3] = [0, 0, 0, 1]
+        a, b = c.Pose(quaternion=q, translation=t), H.Pose(quaternion=q, translation=t)
+        a2, b2 = c.Pose(pose_matrix=m), H.Pose(pose_matrix=m)
+        worst = max(worst, np.abs(a.xyzrpy() - b.xyzrpy()).max(), np.abs((a * a2).pose_matrix() - (b * b2).pose_matrix()).max(),
+                    np.abs(a2.rotation_q() - b2.rotation_q()).max(), abs(a.total_angle() - b.total_angle()),
+                    np.abs(a.inverse().pose_matrix() - b.inverse().pose_matrix()).max(),
+                    np.abs(a.interpolate(a2, 0.3).pose_matrix() - b.interpolate(b2, 0.3).pose_matrix()).max(),
+                    np.abs(a.limit_rotation_angle(0.2).rotation_q() - b.limit_rotation_angle(0.2).rotation_q()).max(),
+                    np.abs(a.limit_translation_length(0.1).translation() - b.limit_translation_length(0.1).translation()).max(),
+                    np.abs(c.Pose(rpy_vector=t, translation=t).rotation_q() - H.Pose(rpy_vector=t, translation=t).rotation_q()).max(),
+                    np.abs(c.Pose(rpy=c.RPY(rpy=t)).rotation_q() - H.Pose(rpy=H.RPY(rpy=t)).rotation_q()).max(),
+                    np.abs(c.Pose(rotation=a.rotation_m()).rotation_q() - H.Pose(rotation=b.rotation_m()).rotation_q()).max(),
+                    np.abs(c.RPY(rpy=t).rotation_matrix() - H.RPY(rpy=t).rotation_matrix()).max(),
+                    np.abs(c.RPY(rpy=t).as_quaternion_vector() - H.RPY(rpy=t).as_quaternion_vector()).max(),
+                    np.abs(a.rotation_rpy().as_vector() - b.rotation_rpy().as_vector()).max())
+        assert a.is_close(a2, 0.3, 0.3) == b.is_close(b2, 0.3, 0.3)
+    assert worst < 1e-12, worst
+    p = c.Pose(quaternion=rng.normal(size=4), translation=rng.normal(size=3))
+    assert pickle.loads(pickle.dumps(p)).is_close(p, 1e-12, 1e-12) and c.Pose(pose=p).is_close(p)
+    r = pickle.loads(pickle.dumps(c.RPY(0.1, 0.2, 0.3)))
+    assert (r.roll, r.pitch, r.yaw) == (0.1, 0.2, 0.3) and (r + r).is_close(c.RPY(0.2, 0.4, 0.6)) and "roll" in str(p)

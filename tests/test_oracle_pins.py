@@ -27,12 +27,20 @@ def _pose(m, P=None):
     return (P or O.Pose)(pose_matrix=np.array(m, dtype=np.float64))
 
 
-@pytest.fixture(params=["oracle", "host"])
+@pytest.fixture(params=["oracle", "host", "compiled"])
 def P(request):
-    """The Pose class under test: the oracle's restatement, and the host-side mirror a user of rcs_amd works with
-    (rcs_amd.common.Pose) -- the reference's test_common.py cases hold for both."""
+    """The Pose class under test: the oracle's restatement, the host-side mirror a user of rcs_amd works with
+    (rcs_amd.common.Pose) and the COMPILED class of the binding (rcs_hip._core.common.Pose: csrc/pose.h, the kernels' own
+    functions, behind the reference's constructor overloads) -- the reference's test_common.py cases hold for all three."""
     if request.param == "oracle":
         return O.Pose
+    if request.param == "compiled":
+        import sys
+
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "extensions", "rcs_hip"))
+        from rcs_hip import _core
+
+        return _core.common.Pose
     from rcs_amd import common
 
     return common.Pose
