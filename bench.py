@@ -135,9 +135,11 @@ def main() -> None:
                     help="env.reset() every this many steps (inside the timed region; resets are not counted as env-steps). "
                          "Default: none for joints; 10 for cartesian, as the reference's examples loop (reset + 10 steps) -- a longer "
                          "random walk of Cartesian targets leaves the workspace and the CLIK then runs to its 1000-iteration cap")
-    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box", "arm6", "ur5e", "so101", "mixed"], default="fr3",
+    ap.add_argument("--robot", choices=["fr3", "xarm7", "xarm7_box", "xarm7_pick", "arm6", "ur5e", "so101", "mixed"], default="fr3",
                     help="xarm7: 7-dof arm with dry joint friction, no gripper; xarm7_box: the same next to a free cube with floor contacts "
-                         "(builder-authored scene xarm7_box_world, camera side_cam); arm6 / ur5e: builder-authored 6-dof arms (Topo<6,false>); "
+                         "(builder-authored scene xarm7_box_world, camera side_cam); xarm7_pick: BASELINE configs[3] as written -- the xArm7 with a two-finger "
+                         "gripper next to the cube, gripper / cube / floor contacts resolved together with the dry-friction rows (builder-authored "
+                         "scene xarm7_pick_world, camera side_cam); arm6 / ur5e: builder-authored 6-dof arms (Topo<6,false>); "
                          "so101: builder-authored 5-dof arm + two-finger gripper (Topo<5,true>); mixed: FR3 / xArm7 / UR5e / SO101 sharded by robot "
                          "type -- rank r runs type r mod 4 with one specialised kernel per GPU, as BASELINE configs[4] asks; with fewer than 4 "
                          "ranks a rank hosts several types as sub-batches on streams of their own (throughput only, not the headline)")
@@ -374,9 +376,10 @@ def main() -> None:
     if task_out is not None:
         finite = finite and bool(torch.isfinite(task_out).all().item())
 
-    SCENE_OF = {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world", "arm6": "arm6_empty_world",
+    SCENE_OF = {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world", "xarm7_pick": "xarm7_pick_world", "arm6": "arm6_empty_world",
                 "ur5e": "ur5e_empty_world", "so101": "so101_empty_world"}
-    SCENE_LABEL = {**SCENE_OF, "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)", "arm6": "arm6_empty_world (builder-authored 6-dof arm)",
+    SCENE_LABEL = {**SCENE_OF, "xarm7_box": "xarm7_box_world (free cube, elliptic-cone floor contacts)",
+                   "xarm7_pick": "xarm7_pick_world (xArm7 + two-finger gripper + free cube: gripper / cube / floor contacts resolved, dry-friction rows in the coupled solve)", "arm6": "arm6_empty_world (builder-authored 6-dof arm)",
                    "ur5e": "ur5e_empty_world (builder-authored, UR5e proportions)", "so101": "so101_empty_world (builder-authored 5-dof arm + two-finger gripper)"}
     mixed_label = ("fr3 / xarm7 / ur5e (builder-authored) / so101 (builder-authored) _empty_world, robot type = rank mod 4" if world >= 4 else
                    f"fr3 / xarm7 / ur5e (builder-authored) / so101 (builder-authored) _empty_world, {len(hosted)} types per rank as sub-batches of {n // len(hosted)} on streams of their own")
@@ -438,7 +441,7 @@ def main() -> None:
                 "traffic": traffic,
                 "traffic_source": "rocprofv3 FETCH_SIZE x 2 (gfx950: counts half the bytes of this access pattern, calibrated in profiles/r2_hbm_calib) + WRITE_SIZE, separate PMC passes (profiles/r2_traffic.json)" if traffic else None,
                 "kernel": "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
-                          + (" + free box" if args.task != "none" or args.robot == "xarm7_box" else ""),
+                          + (" + free box" if args.task != "none" or args.robot in ("xarm7_box", "xarm7_pick") else ""),
                 "kernel_ms_avg": kernel_ms,
                 "launches_timed": int(launches.value),
                 "algorithmic_bytes_per_launch": algo_bytes,

@@ -37,6 +37,9 @@ XARM7 = dict(  # examples/xarm7/xarm7_env_joint_control.py:41-64; include/rcs/Ro
     low=np.array([-2 * np.pi, -2.094395, -2 * np.pi, -3.92699, -2 * np.pi, -np.pi, -2 * np.pi]),
     high=np.array([2 * np.pi, 2.059488, 2 * np.pi, 0.191986, 2 * np.pi, 1.692969, 2 * np.pi]),
     gripper_joint=None, gripper_actuator=None, arm_collision_geoms=[])
+# scenes/xarm7_pick_world (builder-authored: the xArm7 with the Franka hand on its flange next to the pick-up cube, BASELINE configs[3])
+XARM7_PICK = dict(XARM7, gripper_joint="finger_joint1", gripper_actuator="actuator8",
+                  gripper_cfg=dict(collision_geoms=["hand_c", "finger_0_left", "finger_0_right"], collision_geoms_fingers=["finger_0_left", "finger_0_right"]))
 ARM6 = dict(  # scenes/arm6_empty_world (builder-authored 6-dof arm); home pose and limits: Robot.h's UR5e entry
     joints=["shoulder_pan", "shoulder_lift", "elbow", "wrist_1", "wrist_2", "wrist_3"], actuators=[f"act{i}" for i in range(1, 7)],
     site="attachment_site", base="base",

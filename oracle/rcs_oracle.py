@@ -355,8 +355,12 @@ DEFAULT_RESOLVE_CONTACTS = None
 
 
 def can_resolve_contacts(cm) -> bool:
-    """What the HIP backend can resolve: the FR3 + hand archetype, elliptic cones, no dry joint friction."""
-    if np.any(np.asarray(cm.arrays["dof_frictionloss"]) > 0) or cm.cone != "elliptic":
+    """What the HIP backend can resolve: the 7-dof arm + two-finger gripper archetype with elliptic cones -- FR3 + hand, and
+    (round 3) the same archetype with dry joint friction (xArm7 + gripper) where the scene asks for no noslip pass (the
+    friction-dof rows would take part in it)."""
+    if cm.cone != "elliptic":
+        return False
+    if np.any(np.asarray(cm.arrays["dof_frictionloss"]) > 0) and cm.noslip_iterations > 0:
         return False
     return bool(cm.njnt == 9 and cm.nu == 8 and cm.ngeom > 1)
 

@@ -1423,8 +1423,15 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
 // ================================================================= phase 2: rows + Newton on the primal cost
 // Lane c owns contact c.  Leaves the minimiser in ar.X, qacc_smooth in ar.A0, the rows' reference accelerations /
 // regularisers and the contact forces in the records.
-template <class T>
-RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_, const double* gravity_) {
+// FRIC: the model has dry joint friction (xArm7): its rows -- one per arm joint, Huber cost: quadratic while
+// |qacc_i - aref_i| < R frictionloss, linear with force -+frictionloss outside (oracle primal(): ORC_EFC_FRICTION) -- are rows of
+// the coupled problem like the limit rows: a term of the lane's cost / gradient entry, of its diagonal Hessian entry and of
+// phi', phi'' along the search line.
+template <class T, bool FRIC>
+RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_, const double* gravity_,
+                                    const LinkRec* links_) {
+  const LinkRec* links = in_lds(links_);
+  (void)links;
   const BoxCfg& b = *in_lds(&b_);
   const StageTeam<T> st{in_lds(st_.base)};
   double* bs = in_lds(bs_);
@@ -1572,6 +1579,15 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
         const double je = x[NA] + eqJ1 * x[NA + 1] - eqAref;
         if (lane == NA) { cost += 0.5 * eqD * je * je; g += eqD * je; }
         else g += eqD * je * eqJ1;
+      }
+      if constexpr (FRIC) {
+        const double fF = links[lane].fl_floss;
+        if (fF > 0) {
+          const double fD = links[lane].fl_D, fR = links[lane].fl_R, jf = x[lane] - st.fa(lane);
+          if (jf <= -fR) { cost += -0.5 * fR * fF - fF * jf; g -= fF; }
+          else if (jf >= fR) { cost += -0.5 * fR * fF + fF * jf; g += fF; }
+          else { cost += 0.5 * fD * jf * jf; g += fD * jf; }
+        }
       }
     } else if (lane < NV) {
       const int k = lane - NL;
@@ -1726,6 +1742,10 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
         if (j == lane) {
           const double sgn = st.limS(lane);
           if (sgn != 0.0 && sgn * ar.X[lane] - st.limA(lane) < 0) v += st.limD(lane);
+          if constexpr (FRIC) {
+            const double fF = links[lane].fl_floss, fR = links[lane].fl_R, jf = ar.X[lane] - st.fa(lane);
+            if (fF > 0 && jf > -fR && jf < fR) v += links[lane].fl_D;
+          }
         }
         if (T::GRIP && has_eq) {
           if (lane == NA && j == NA) v += eqD;
@@ -1858,6 +1878,15 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
           const double je = (ar.X[NA] + a * ar.P[NA]) + eqJ1 * (ar.X[NA + 1] + a * ar.P[NA + 1]) - eqAref;
           const double jde = ar.P[NA] + eqJ1 * ar.P[NA + 1];
           dl += eqD * je * jde; ddl += eqD * jde * jde;
+        }
+        if constexpr (FRIC) {
+          const double fF = links[lane].fl_floss;
+          if (fF > 0) {
+            const double fD = links[lane].fl_D, fR = links[lane].fl_R, pl = ar.P[lane], jf = ar.X[lane] + a * pl - st.fa(lane);
+            if (jf <= -fR) dl -= fF * pl;
+            else if (jf >= fR) dl += fF * pl;
+            else { dl += fD * jf * pl; ddl += fD * pl * pl; }
+          }
         }
       }
       const double dphi = wave_sum(dl) + gM0 + a * pMp;
@@ -2145,12 +2174,12 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
 // (robot: pre-step q, qd, motion axes S, mass matrix, qfrc_smooth, limit / equality rows of this substep; box: state).
 // Returns bit 0: coupled (a robot geom is in contact: st.fcon holds the robot's constraint force, bs[kBoxA..] the box's
 // acceleration); bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
-template <class T>
+template <class T, bool FRIC = false>
 RCSH_D uint32_t contact_phase(const ContactTable& tab, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
                               ContactArena<T>& ar, const double* gravity) {
   const uint32_t r = contact_collide<T>(tab, b, links, st, bs, ar);
   if (!(r & 1u) || !b.resolve) return r & ~1u;
-  contact_newton<T>(b, st, bs, ar, gravity);
+  contact_newton<T, FRIC>(b, st, bs, ar, gravity, links);
   contact_noslip<T>(b, st, bs, ar);
   return r;
 }

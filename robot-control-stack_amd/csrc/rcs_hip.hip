@@ -404,8 +404,12 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
     using Y = std::true_type;
     using N = std::false_type;
     if (s->box.present && s->box.resolve) {
-      // free box + contacts of the robot's geoms (FR3 + hand): rcsh_sim_add_free_box checked the archetype
-      if constexpr (T::NARM == 7 && T::GRIP) go(N{}, Y{}, Y{});
+      // free box + contacts of the robot's geoms (FR3 + hand; xArm7 + gripper: friction rows in the coupled solve):
+      // rcsh_sim_add_free_box checked the archetype
+      if constexpr (T::NARM == 7 && T::GRIP) {
+        if (s->dm.has_friction) go(Y{}, Y{}, Y{});
+        else go(N{}, Y{}, Y{});
+      }
     } else if (s->box.present) {
       // scenes with a free box that only touches the floor: FR3 + hand, and the 7-dof arm with dry joint friction
       if constexpr (T::NARM == 7 && T::GRIP) go(N{}, Y{}, N{});
@@ -1076,9 +1080,11 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   REQUIRE_SIM(s);
   if (!d) return fail(RCSH_ERR_ARG, "null free-box description");
   if (s->box.present) return fail(RCSH_ERR_STATE, "a free box is already attached to this sim");
-  if (!(s->narm == 7 && (s->grip ? !s->dm.has_friction : s->dm.has_friction != 0)))
-    return fail(RCSH_ERR_MODEL, "free bodies are compiled for two archetypes: 7-dof arm + two-finger gripper without dry joint friction (FR3), "
-                                "7-dof arm without gripper with it (xArm7)");
+  if (!(s->narm == 7 && (s->grip || s->dm.has_friction != 0)))
+    return fail(RCSH_ERR_MODEL, "free bodies are compiled for three archetypes: 7-dof arm + two-finger gripper without dry joint friction (FR3) "
+                                "and with it (xArm7 + gripper), 7-dof arm without gripper with it (xArm7)");
+  if (s->grip && s->dm.has_friction && !d->resolve_robot_contacts)
+    return fail(RCSH_ERR_MODEL, "7-dof arm + gripper with dry joint friction next to a free body: compiled with robot contacts resolved only");
   if (s->dm.has_friction && d->noslip_iterations > 0)
     return fail(RCSH_ERR_MODEL, "the noslip pass over dry joint friction rows is not built: scenes with frictionloss need noslip_iterations = 0");
   if (!d->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
@@ -1092,8 +1098,9 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   for (int k = 0; k < 3; ++k) { b.inertia[k] = d->inertia[k]; b.inv_inertia[k] = 1.0 / d->inertia[k]; b.size[k] = d->size[k]; }
   b.fr = d->friction[0];
   b.geom_mu = d->geom_friction[0] > 0 ? d->geom_friction[0] : d->friction[0];
-  // contacts of the robot's geoms with the floor and the box: FR3 + hand archetype (the coupled solve has no dry-friction rows)
-  b.resolve = d->resolve_robot_contacts && s->grip && !s->dm.has_friction && !s->cgeoms.empty();
+  // contacts of the robot's geoms with the floor and the box enter one constraint problem with the robot's own rows
+  // (limit / equality rows; dry-friction rows in the xArm7 + gripper archetype)
+  b.resolve = d->resolve_robot_contacts && s->grip && !s->cgeoms.empty();
   if (b.resolve && !s->contact_overflow.empty()) return fail(RCSH_ERR_MODEL, "robot contacts cannot be resolved in this scene: " + s->contact_overflow);
   make_kb(d->solref, d->solimp, s->dm.timestep, b.K, b.B);
   b.imp = make_imp(d->solimp);

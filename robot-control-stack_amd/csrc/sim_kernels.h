@@ -890,7 +890,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
         if (nearw) {
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
-            const uint32_t r = contact_phase<T>(lp.ctab, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity);
+            const uint32_t r = contact_phase<T, FRIC>(lp.ctab, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity);
             if (team == k) {
               coupled = r & 1u;
               hit |= (r >> 8) & 3u;

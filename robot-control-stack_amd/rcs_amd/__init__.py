@@ -39,6 +39,7 @@ scenes: dict[str, Scene] = {
     "fr3_simple_pick_up": _scene("fr3_simple_pick_up", common.RobotType.FR3),
     "xarm7_empty_world": _scene("xarm7_empty_world", common.RobotType.XArm7),
     "xarm7_box_world": _scene("xarm7_box_world", common.RobotType.XArm7),
+    "xarm7_pick_world": _scene("xarm7_pick_world", common.RobotType.XArm7),
     "arm6_empty_world": _scene("arm6_empty_world", common.RobotType.UR5e),
     "ur5e_empty_world": _scene("ur5e_empty_world", common.RobotType.UR5e),
     "so101_empty_world": _scene("so101_empty_world", common.RobotType.SO101),

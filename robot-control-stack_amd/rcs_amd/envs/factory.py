@@ -13,12 +13,12 @@ from .. import sim
 from .base import ControlMode, RelativeTo
 from .creators import SimEnvCreator
 from .utils import (arm6_sim_robot_cfg, default_sim_gripper_cfg, default_sim_robot_cfg, so101_sim_gripper_cfg, so101_sim_robot_cfg,
-                    ur5e_sim_robot_cfg, xarm7_sim_robot_cfg)
+                    ur5e_sim_robot_cfg, xarm7_pick_sim_gripper_cfg, xarm7_pick_sim_robot_cfg, xarm7_sim_robot_cfg)
 
 # max_relative_movement of the reference's joint-control example (examples/fr3/fr3_env_joint_control.py:38)
 MAX_JOINT_MOV = float(np.deg2rad(5))
 
-ROBOTS = ("fr3", "xarm7", "xarm7_box", "arm6", "ur5e", "so101")
+ROBOTS = ("fr3", "xarm7", "xarm7_box", "xarm7_pick", "arm6", "ur5e", "so101")
 
 
 def robot_cfg_for(robot: str) -> sim.SimRobotConfig:
@@ -28,6 +28,8 @@ def robot_cfg_for(robot: str) -> sim.SimRobotConfig:
         return xarm7_sim_robot_cfg("xarm7_empty_world")
     if robot == "xarm7_box":
         return xarm7_sim_robot_cfg("xarm7_box_world")
+    if robot == "xarm7_pick":
+        return xarm7_pick_sim_robot_cfg()
     if robot == "arm6":
         return arm6_sim_robot_cfg()
     if robot == "ur5e":
@@ -41,14 +43,15 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
                  max_convergence_steps: int = 500, robot_cfg: sim.SimRobotConfig | None = None):
     """`n_envs` environments of one robot type on GPU `device`.  `robot_cfg` overrides the robot's default configuration
-    (its scene decides the kernel archetype); only the FR3 and SO101 scenes carry a gripper."""
+    (its scene decides the kernel archetype); only the FR3, SO101 and xarm7_pick scenes carry a gripper."""
     cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=frequency, max_convergence_steps=max_convergence_steps)
     mode = control_mode or ControlMode.JOINTS
     if relative and max_relative_movement is None:
         max_relative_movement = MAX_JOINT_MOV
-    if not (robot.startswith("fr3") or robot == "so101"):
+    if not (robot.startswith("fr3") or robot in ("so101", "xarm7_pick")):
         gripper = False
-    gripper_cfg = (so101_sim_gripper_cfg() if robot == "so101" else default_sim_gripper_cfg()) if gripper else None
+    gripper_cfg = ((so101_sim_gripper_cfg() if robot == "so101" else xarm7_pick_sim_gripper_cfg() if robot == "xarm7_pick" else default_sim_gripper_cfg())
+                   if gripper else None)
     return SimEnvCreator()(
         mode, robot_cfg if robot_cfg is not None else robot_cfg_for(robot),
         gripper_cfg=gripper_cfg,

@@ -33,6 +33,26 @@ def xarm7_sim_robot_cfg(scene: str = "xarm7_empty_world") -> sim.SimRobotConfig:
     return cfg
 
 
+def xarm7_pick_sim_robot_cfg() -> sim.SimRobotConfig:
+    """The xArm7 of scenes/xarm7_pick_world (BASELINE configs[3]: the arm of the reference's xarm7.xml with the Franka hand on
+    its flange, next to the pick-up scene's cube): the xArm7 example's names, the TCP at the fingertips (0.1034 m along the
+    tool axis -- the translation of FrankaHandTCPOffset; the hand is mounted without the FR3's 45 degree turn)."""
+    import rcs_amd
+
+    cfg = xarm7_sim_robot_cfg("xarm7_pick_world")
+    cfg.tcp_offset = rcs_amd.common.Pose(translation=[0.0, 0.0, 0.1034])
+    return cfg
+
+
+def xarm7_pick_sim_gripper_cfg() -> sim.SimGripperConfig:
+    """The Franka hand of scenes/xarm7_pick_world: SimGripperConfig's defaults without the add_id suffix and without the camera
+    body the FR3's hand carries."""
+    cfg = sim.SimGripperConfig()
+    cfg.collision_geoms = ["hand_c", "finger_0_left", "finger_0_right"]
+    cfg.collision_geoms_fingers = ["finger_0_left", "finger_0_right"]
+    return cfg
+
+
 def arm6_sim_robot_cfg() -> sim.SimRobotConfig:
     """The builder-authored 6-dof arm (scenes/arm6_empty_world: UR5e-class proportions, NOT a vendor model), configured the
     way the reference's xArm7 example configures its robot; joint limits and home pose are robots_meta_config's UR5e entry."""

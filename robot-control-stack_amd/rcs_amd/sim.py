@@ -77,12 +77,16 @@ class Sim:
 
     @staticmethod
     def resolves_robot_contacts(model: Model) -> bool:
-        """Scenes whose robot-geom contacts CAN enter the constraint solve: the FR3 + hand archetype (7 arm joints + two fingers,
-        no dry joint friction) with elliptic cones and collision geoms; elsewhere contacts only raise the collision flags."""
+        """Scenes whose robot-geom contacts CAN enter the constraint solve: the 7-dof arm + two-finger gripper archetype with
+        elliptic cones and collision geoms -- FR3 + hand; with dry joint friction (xArm7 + gripper) only next to a free body and
+        without a noslip pass (the friction-dof rows would take part in it).  Elsewhere contacts only raise the collision flags."""
         import numpy as np
 
-        return bool(model.njnt == 9 and model.nu == 8 and model.cone == "elliptic" and not np.any(np.asarray(model.arrays["dof_frictionloss"]) > 0)
-                    and model.ngeom > 1)
+        if not (model.njnt == 9 and model.nu == 8 and model.cone == "elliptic" and model.ngeom > 1):
+            return False
+        if np.any(np.asarray(model.arrays["dof_frictionloss"]) > 0):
+            return bool(getattr(model, "free_bodies", [])) and model.noslip_iterations == 0
+        return True
 
     def __del__(self):
         h = getattr(self, "_h", None)

@@ -773,6 +773,91 @@ def run_grasp_parity(n_envs=4, seed=0, swing_up=True):
     return rep
 
 
+XARM7_PICK_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "xarm7_pick_world", "scene.xml")
+
+
+def run_xarm7_pick_parity(n_envs=4, seed=0, stages=("above", "down", "closed", "lifted", "held", "released")):
+    """BASELINE configs[3] as written: the xArm7 (dry joint friction on every arm joint) with a two-finger gripper picks the
+    cube up -- move over it, descend, close the fingers (pads against the cube: box-box contacts; the friction-dof rows are
+    rows of the same coupled problem), lift 20 cm, hold, release.  Kernel vs oracle through the 1:1 Sim / SimRobot / SimGripper
+    API, cube placements a few millimetres / degrees apart per environment."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import xarm7_pick_sim_gripper_cfg, xarm7_pick_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    from rcs_env_oracle import XARM7_PICK
+
+    cfg = xarm7_pick_sim_robot_cfg()
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    if KERNEL != "auto":
+        simu.set_kernel(KERNEL)
+    robot = S.SimRobot(simu, None, cfg)
+    grip = S.SimGripper(simu, xarm7_pick_sim_gripper_cfg())
+    cm = compile_mjcf(XARM7_PICK_SCENE)
+    R = XARM7_PICK
+    tcp = O.Pose(translation=np.array([0.0, 0.0, 0.1034]))
+    osims = [O.Sim(cm, R["joints"], R["actuators"], R["site"], R["base"], R["q_home"], tcp, R["gripper_joint"], R["gripper_actuator"],
+                   arm_collision_geoms=[], gripper_cfg=R["gripper_cfg"]) for _ in range(n_envs)]
+    assert osims[0].model.resolve_contacts == 1 and simu.resolve_robot_contacts
+    rng = np.random.default_rng(seed)
+    qb = np.tile(np.array([0.40, 0.0, 0.0288, 0, 0, 0, 1.0]), (n_envs, 1))
+    qb[1:, 0] += rng.uniform(-0.004, 0.004, n_envs - 1)
+    qb[1:, 1] += rng.uniform(-0.004, 0.004, n_envs - 1)
+    yaw = np.zeros(n_envs)
+    yaw[1:] = rng.uniform(-0.1, 0.1, n_envs - 1)
+    qb[:, 3], qb[:, 6] = np.cos((np.pi + yaw) / 2), np.sin((np.pi + yaw) / 2)
+    simu.reset(); robot.reset(); grip.reset()
+    for o in osims:
+        o.reset(); o.robot_reset(); o.gripper_reset()
+    simu.set_free_joint_qpos("box_joint", qb)
+    for e, o in enumerate(osims):
+        o.box_qpos = qb[e]
+    rep = {"max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_box": 0.0, "max_abs_box_vel": 0.0, "flag_mismatches": 0, "max_ncon": 0,
+           "coupled_substeps": 0, "max_newton": 0, "ik_failures": 0, "stages": {}}
+
+    def advance(tag, k):
+        simu.step(k)
+        q, v, bq, bv, st, gs = simu.qpos, simu.qvel, simu.free_joint_qpos("box_joint"), simu.free_joint_qvel("box_joint"), robot.get_state(), grip.get_state()
+        for e, o in enumerate(osims):
+            for _ in range(k):
+                o.step(1)
+                d = o.s.d
+                rep["max_ncon"] = max(rep["max_ncon"], int(d.ncon))
+                if d.coupled:
+                    rep["coupled_substeps"] += 1
+                    rep["max_newton"] = max(rep["max_newton"], int(d.solver_niter))
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - np.asarray(o.qpos)).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - np.asarray(o.qvel)).max()))
+            rep["max_abs_box"] = max(rep["max_abs_box"], float(np.abs(bq[e] - o.box_qpos).max()))
+            rep["max_abs_box_vel"] = max(rep["max_abs_box_vel"], float(np.abs(bv[e] - o.box_qvel).max()))
+            rep["flag_mismatches"] += int(bool(st.collision[e]) != bool(o.s.robot_collision)) + int(bool(gs.collision[e]) != bool(o.s.grp_collision))
+            rep["flag_mismatches"] += int(bool(grip.is_grasped()[e]) != o.gripper_is_grasped()) + int(bool(st.ik_success[e]) != bool(o.s.ik_success))
+            rep["ik_failures"] += int(not o.s.ik_success)
+        rep["stages"][tag] = {"box_z": bq[:, 2].copy(), "width": grip.get_normalized_width().copy()}
+
+    simu.step(1); [o.step(1) for o in osims]
+    down = O.Pose(rotation=np.diag([1.0, -1.0, -1.0])).rotation_q()  # tool axis pointing at the floor, fingers closing along y
+    base_z = 0.12  # the robot frame: the xArm7's base body sits 0.12 m above the floor
+
+    def move(xyz):
+        t = np.array([xyz[0], xyz[1], xyz[2] - base_z])
+        robot.set_cartesian_position(np.tile(np.concatenate([t, down]), (n_envs, 1)))
+        for o in osims:
+            o.set_cartesian_position(O.Pose(translation=t, quaternion=down))
+
+    script = {"above": (lambda: (grip.open(), [o.gripper_open() for o in osims], move([0.40, 0.0, 0.20])), 500),
+              "down": (lambda: move([0.40, 0.0, 0.035]), 700),
+              "closed": (lambda: (grip.shut(), [o.gripper_grasp() for o in osims]), 250),
+              "lifted": (lambda: move([0.40, 0.0, 0.30]), 600),
+              "held": (lambda: None, 300),
+              "released": (lambda: (grip.open(), [o.gripper_open() for o in osims]), 300)}
+    for tag in stages:
+        script[tag][0]()
+        advance(tag, script[tag][1])
+    simu.close()
+    return rep
+
+
 def run_hard_pinch_parity(chunks=(1, 20, 60)):
     """The cube placement of tests/test_contacts_cpu.py::HARD_PINCH_PLACEMENT (found at batch scale: the coupled Newton solve
     of its closing pads is the hardest of 4096 random placements) among ordinary ones, pinched with the closing stage cut into

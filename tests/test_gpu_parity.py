@@ -653,42 +653,60 @@ def test_xarm7_with_free_box_and_camera(kernel):
 
 
 def test_xarm7_box_batch_of_baseline_config_3(kernel):
-    """BASELINE configs[3] at its per-GPU size -- 8192 environments split over 2 GPUs = 4096 each -- on the scene that stands in for
-    "xarm7 pick-place with object contacts + SimCameraSet depth render" (the reference ships no such scene): xArm7 with dry joint
-    friction next to the free cube, one depth AND colour frame of the fixed camera per step.  16 distinct (cube state, target
-    stream) pairs tiled 256x: every copy equals the first bit for bit wherever it sits (the same scene against the oracle:
-    test_xarm7_with_free_box_and_camera)."""
+    """BASELINE configs[3] at its per-GPU size -- 8192 environments split over 2 GPUs = 4096 each -- AS WRITTEN: "xarm7 pick-place
+    scene with object contacts + SimCameraSet depth render" is scenes/xarm7_pick_world (the xArm7 with dry joint friction and a
+    two-finger gripper next to the pick-up cube; the reference ships no such scene).  All 4096 environments pinch their cube, lift
+    it and hold it, with a depth AND colour frame of the fixed camera per launch; 16 distinct cube placements tiled 256x: every
+    copy equals the first bit for bit wherever it sits, and every cube ends up in the air.  (The same script against the oracle:
+    test_xarm7_picks_the_cube_up_matches_oracle.)"""
     from rcs_amd import sim as S
     from rcs_amd.camera import SimCameraConfig, SimCameraSet
-    from rcs_amd.envs import xarm7_sim_robot_cfg
+    from rcs_amd.envs import xarm7_pick_sim_gripper_cfg, xarm7_pick_sim_robot_cfg
 
     n, base = 4096, 16
-    cfg = xarm7_sim_robot_cfg("xarm7_box_world")
+    cfg = xarm7_pick_sim_robot_cfg()
     simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+    assert simu.resolve_robot_contacts
     robot = S.SimRobot(simu, None, cfg)
-    cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", resolution_width=24, resolution_height=16)}, physical_units=True)
+    grip = S.SimGripper(simu, xarm7_pick_sim_gripper_cfg())
+    cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", resolution_width=32, resolution_height=24)}, physical_units=True)
     rng = np.random.default_rng(6)
-    qb = np.zeros((base, 7))
-    qb[:, 0], qb[:, 1], qb[:, 2] = 0.45 + rng.uniform(-0.1, 0.1, base), rng.uniform(-0.1, 0.1, base), rng.uniform(0.02, 0.08, base)
-    qb[:, 3:] = rng.normal(size=(base, 4))
-    vb = np.concatenate([rng.uniform(-0.4, 0.4, (base, 3)), rng.uniform(-3, 3, (base, 3))], axis=1)
+    qb = np.tile(np.array([0.40, 0.0, 0.0288, 0, 0, 0, 1.0]), (base, 1))
+    qb[:, 0] += rng.uniform(-0.004, 0.004, base)
+    qb[:, 1] += rng.uniform(-0.004, 0.004, base)
+    yaw = rng.uniform(-0.1, 0.1, base)
+    qb[:, 3], qb[:, 6] = np.cos((np.pi + yaw) / 2), np.sin((np.pi + yaw) / 2)
+    simu.reset(); robot.reset(); grip.reset()
     simu.set_free_joint_qpos("box_joint", np.tile(qb, (n // base, 1)))
-    simu.set_free_joint_qvel("box_joint", np.tile(vb, (n // base, 1)))
+    simu.step(1)
 
     def tiled(arr):
         a = np.asarray(arr).reshape(n // base, base, -1)
         return np.array_equal(a, np.broadcast_to(a[0], a.shape))
 
-    from rcs_env_oracle import XARM7
+    from rcs_amd import common
 
-    for _ in range(4):
-        tgt = np.asarray(XARM7["q_home"]) + rng.uniform(-0.2, 0.2, (base, 7))
-        robot.set_joint_position(np.tile(tgt, (n // base, 1)))
-        simu.step(17)
+    down = common.Pose(rotation=np.diag([1.0, -1.0, -1.0])).rotation_q()
+
+    def move(z):
+        robot.set_cartesian_position(np.tile(np.concatenate([[0.40, 0.0, z - 0.12], down]), (n, 1)))  # (robot frame: base 0.12 m up)
+
+    def run(k):
+        simu.step(k)
         f = cs.get_latest_frames().frames["side"].camera
         for arr in (simu.qpos, simu.qvel, simu.free_joint_qpos("box_joint"), simu.free_joint_qvel("box_joint"), f.depth.data, f.color.data):
             assert tiled(arr), "replicas diverged"
-    assert (f.depth.data[:base] < 1500).any() and np.isfinite(simu.qpos).all()
+        return f
+
+    grip.open(); move(0.20); run(500)
+    move(0.035); run(700)
+    grip.shut(); run(250)
+    assert (grip.get_normalized_width() > 0.3).all()  # the fingers stopped on the cube
+    move(0.30); run(600)
+    f = run(200)
+    z = simu.free_joint_qpos("box_joint")[:, 2]
+    assert (z > 0.25).all() and np.isfinite(simu.qpos).all(), (z.min(), z.max())  # every one of the 4096 cubes hangs in its gripper
+    assert (f.depth.data[:base] < 2500).any()
     simu.close()
 
 
@@ -1276,3 +1294,19 @@ def test_compiled_pin_kinematics_match_oracle(robot, kernel):
     assert solved >= 8
     far = c.Pose(translation=np.array([5.0, 0.0, 0.5]))  # out of reach: the CLIK hits its 1000-iteration cap
     assert pin.inverse(far, q_home) is None and pin.forward(q_home).is_close(pin.forward(q_home, c.Pose()))
+
+
+def test_xarm7_picks_the_cube_up_matches_oracle(kernel):
+    """BASELINE configs[3] as written -- "xarm7 pick-place scene with object contacts": the xArm7 of the reference's xarm7.xml
+    (dry joint friction on all seven arm joints) with the Franka hand on its flange pinches the pick-up scene's cube, lifts it
+    20 cm and holds it; kernel (`k_run_team<Topo<7,true>, FRIC, BOX, CON>`: friction-dof rows inside the coupled 15-dof solve)
+    vs oracle: every flag bit-equal, arm joints <= 1e-9, cube pose <= 1e-8 over ~1700 substeps in contact."""
+    from parity_util import run_xarm7_pick_parity
+
+    rep = run_xarm7_pick_parity(n_envs=4, seed=0)
+    assert rep["flag_mismatches"] == 0 and rep["ik_failures"] == 0, rep
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < VTOL and rep["max_abs_box"] < 1e-8, rep
+    assert rep["coupled_substeps"] >= 4 * 1000 and rep["max_ncon"] >= 20, rep
+    st = rep["stages"]
+    assert (st["down"]["box_z"] < 0.03).all() and (st["lifted"]["box_z"] > 0.25).all() and (st["held"]["box_z"] > 0.25).all(), st  # picked up and held
+    assert (st["released"]["box_z"] < 0.06).all() and (st["held"]["width"] > 0.3).all(), st  # dropped again; the fingers stopped on the cube
