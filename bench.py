@@ -416,7 +416,8 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, no contacts, IK off"
+                "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, "
+                             + ("robot contacts resolved, IK off" if args.robot == "xarm7_pick" else "no contacts, IK off")
                              if args.control == "joints" else
                              f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
                              ).replace("fr3_empty_world", (mixed_label if mixed else SCENE_LABEL[args.robot]) if args.task == "none" else
