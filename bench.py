@@ -10,7 +10,9 @@ mode the reference uses for rollouts (SimConfig async_control=True, 30 Hz => 17 
 reference python/rcs/envs/sim.py:52-53).  Inputs (the pre-generated action tensor) are resident in HBM before the
 timed region; each step is one fused kernel launch through the C-ABI (rcsh_env_step_dev).  With N > 1 every rank
 owns 4096 environments on its own GPU (weak scaling) and the observation tensor is all-gathered over RCCL once
-per step, inside the timed region.
+per step, inside the timed region.  No PyTorch on the data path: device buffers are rcsh_dev_alloc'ed, actions drawn with
+numpy, streams ordered by the library's own handles; with N > 1 torch.distributed (gloo, CPU tensors) is the launcher's
+rendezvous only -- RCCL id, barriers, max-over-ranks of the clock -- and the exchange is RCCL behind the C-ABI.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (algorithmic HBM bytes of the fused launch / measured
 kernel time, HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this host's cores on a
@@ -179,23 +181,30 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = run_cpu_baseline()  # before any GPU context exists in this process
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    import ctypes as C
 
-    if not torch.cuda.is_available():
+    import numpy as np
+
+    from rcs_amd import _lib
+    from rcs_amd.envs import MAX_JOINT_MOV, make_vec_env
+
+    # No PyTorch on this path (BASELINE north star): device memory comes from the C-ABI (rcsh_dev_alloc), the synthetic actions
+    # from numpy, streams and their ordering from the library's own handles.  With N > 1 ranks torch.distributed serves as the
+    # launcher's rendezvous only -- a gloo group on CPU tensors for the RCCL id, the barriers and the max-over-ranks of the
+    # clock -- and the one exchange of the data path, the all-gather of the observation block, is RCCL behind the C-ABI.
+    L0 = _lib.load()
+    n_dev = int(L0.rcsh_device_count())
+    if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the batched backend has no CPU execution path")
     if args.dist_backend != "nccl":
-        local_rank %= torch.cuda.device_count()  # functional check only: ranks may share a GPU
-    torch.cuda.set_device(local_rank)
+        local_rank %= n_dev  # functional check only: ranks may share a GPU
+    dist = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
+        import torch
+        import torch.distributed as dist
 
-    from rcs_amd.envs import MAX_JOINT_MOV, make_vec_env
+        dist.init_process_group("gloo")
 
     n = args.envs
     T = args.steps + args.warmup
@@ -221,62 +230,99 @@ def main() -> None:
                            control_mode=ControlMode.CARTESIAN_TRPY, max_relative_movement=(0.2, float(np.deg2rad(45))), robot=args.robot)
     else:
         env = make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=args.robot)
-    # a rank that hosts several robot types (mixed, fewer than 4 ranks): one sub-batch per type, each on a stream of its own so
-    # that the sub-batches' launches (each too small to fill the chip) run side by side
+    # a rank that hosts several robot types (mixed, fewer than 4 ranks): one sub-batch per type, each on its handle's own
+    # stream, so that the sub-batches' launches (each too small to fill the chip) run side by side
     envs = [env] + [make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=r)
                     for r in hosted[1:]]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in envs[1:]]
-    for e_, st_ in zip(envs, streams):
-        e_.sim.set_stream(st_.cuda_stream)
     L, h = env._L, env.sim._h
 
-    # synthetic actions, resident in HBM (joints ~ U(+-5 deg)^7 f64, gripper ~ U(0,1) f32)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
+    class DevBuf:
+        """[rows, ...] array in HBM (rcsh_dev_alloc), optionally filled from a host array; `at(t)` = address of row t."""
+
+        def __init__(self, shape, dtype, host=None):
+            self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+            self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+            self.row_bytes = self.nbytes // self.shape[0]
+            p = C.c_void_p()
+            _lib.check(L.rcsh_dev_alloc(h, max(self.nbytes, 8), C.byref(p)))
+            self.ptr = p.value
+            a = np.zeros(self.shape, dtype=self.dtype) if host is None else np.ascontiguousarray(host, dtype=self.dtype)
+            assert a.nbytes == self.nbytes
+            _lib.check(L.rcsh_dev_upload(h, C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p), self.nbytes))
+
+        def at(self, t: int, offset_rows_bytes: int = 0) -> int:
+            return self.ptr + t * self.row_bytes + offset_rows_bytes
+
+        def download(self) -> np.ndarray:
+            out = np.zeros(self.shape, dtype=self.dtype)
+            _lib.check(L.rcsh_dev_download(h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), self.nbytes))
+            return out
+
+    def device_sync() -> None:
+        for e_ in envs:
+            e_.sim.synchronize()
+
+    # synthetic actions, resident in HBM (SURVEY 8d: joints ~ U(+-5 deg)^7 f64, gripper ~ U(0,1) f32), drawn on the host
+    rng = np.random.default_rng(1234 + rank)
     if args.control == "cartesian":  # SURVEY 8d config 3: xyz ~ U(+-0.05 m)^3, rpy ~ U(+-0.1 rad)^3
-        scale = torch.tensor([0.05, 0.05, 0.05, 0.1, 0.1, 0.1], device="cuda", dtype=torch.float64)
-        joints = (torch.rand((T, n, 6), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * scale
+        scale = np.array([0.05, 0.05, 0.05, 0.1, 0.1, 0.1])
+        joints = DevBuf((T, n, 6), np.float64, (rng.random((T, n, 6)) * 2 - 1) * scale)
     else:
-        joints = (torch.rand((T, env.n_envs, env.dof), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV
-    grip = torch.rand((T, n), generator=gen, device="cuda", dtype=torch.float32)
-    # (sub-batches of other robot types: their own action tensors; info / width / substep outputs are sliced from the rank's)
-    sub_joints = [joints] + [(torch.rand((T, e_.n_envs, e_.dof), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1) * MAX_JOINT_MOV for e_ in envs[1:]]
+        joints = DevBuf((T, env.n_envs, env.dof), np.float64, (rng.random((T, env.n_envs, env.dof)) * 2 - 1) * MAX_JOINT_MOV)
+    grip = DevBuf((T, n), np.float32, rng.random((T, n), dtype=np.float32))
+    # (sub-batches of other robot types: their own action tensors; info / width / substep outputs are slices of the rank's)
+    sub_joints = [joints] + [DevBuf((T, e_.n_envs, e_.dof), np.float64, (rng.random((T, e_.n_envs, e_.dof)) * 2 - 1) * MAX_JOINT_MOV) for e_ in envs[1:]]
     ow = max(e_.obs_width for e_ in envs) if not mixed else 21  # mixed: every rank's block is n x 21 doubles, narrower rows packed at its start
-    obs = torch.zeros((n, ow), device="cuda", dtype=torch.float64)
-    info = torch.zeros((n, 8), device="cuda", dtype=torch.uint8)
-    gw = torch.zeros((n,), device="cuda", dtype=torch.float64)
-    sub = torch.zeros((n,), device="cuda", dtype=torch.int32)
-    # the one exchange of the sharded rollout: all-gather of the observation tensor.  Measured configuration: RCCL behind the
-    # C-ABI (no host framework on the data path); --dist-backend gloo: the same protocol over torch.distributed, to exercise
-    # the N > 1 code path on a box with fewer GPUs than ranks.  (torch.distributed stays for rendezvous, barrier and the
-    # max-over-ranks of the timing -- plumbing.)
+    obs = DevBuf((n, ow), np.float64)
+    info = DevBuf((n, 8), np.uint8)
+    gw = DevBuf((n,), np.float64)
+    sub = DevBuf((n,), np.int32)
+
+    class HostStagedExchange:
+        """The exchange protocol of RcclObservationExchange carried by the rendezvous group instead (gloo, through host memory,
+        not overlapped): `--dist-backend gloo` -- ranks sharing a GPU, where RCCL refuses to form a communicator -- and the
+        fallback when the C-ABI communicator cannot be created on some rank.  Functional, not the measured configuration."""
+
+        def __init__(self):
+            self._local = [DevBuf((n, ow), np.float64) for _ in range(2)]
+            self._all = [torch.zeros((world * n, ow), dtype=torch.float64) for _ in range(2)]
+
+        def local_ptr(self, t: int) -> int:
+            return self._local[t & 1].ptr
+
+        def post(self, t: int) -> None:
+            dist.all_gather_into_tensor(self._all[t & 1], torch.from_numpy(self._local[t & 1].download()))
+
+        def gathered(self, t: int) -> np.ndarray:
+            return self._all[t & 1].numpy()
+
+        def drain(self) -> None:
+            pass
+
+        def close(self) -> None:
+            pass
+
+    # the one exchange of the sharded rollout: all-gather of the observation block, RCCL behind the C-ABI
     exchange = None
     if world > 1 and args.dist_backend == "nccl":
         from rcs_amd.envs.sharding import RcclObservationExchange, comm_unique_id
 
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
+        box = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
         comm_error = ""
         try:
-            exchange = RcclObservationExchange(env.sim, bytes(uid.cpu().numpy().tobytes()), rank, world, n_rows=n, width=ow)
+            exchange = RcclObservationExchange(env.sim, bytes(box[0]), rank, world, n_rows=n, width=ow)
         except RuntimeError as exc:  # e.g. a communicator RCCL refuses on this topology
             comm_error = str(exc)
-        okflag = torch.tensor([0 if comm_error else 1], device="cuda")
+        okflag = torch.tensor([0 if comm_error else 1])
         dist.all_reduce(okflag, op=dist.ReduceOp.MIN)  # every rank takes the same carrier
         if int(okflag.item()) == 0:
             if exchange is not None:
                 exchange.close()
-            from rcs_amd.envs.sharding import ObservationExchange
-
-            exchange = ObservationExchange(n, ow, torch.float64, "cuda")
-            args.dist_backend = "nccl (torch.distributed process group; the C-ABI communicator could not be created: " + (comm_error or "on another rank") + ")"
+            exchange = HostStagedExchange()
+            args.dist_backend = "gloo through host memory (the C-ABI RCCL communicator could not be created: " + (comm_error or "on another rank") + ")"
     elif world > 1:
-        from rcs_amd.envs.sharding import ObservationExchange
-
-        exchange = ObservationExchange(n, ow, torch.float64, "cuda")
-    rccl_exchange = exchange is not None and args.dist_backend == "nccl"
+        exchange = HostStagedExchange()
 
     episode = args.episode_length if args.episode_length is not None else (10 if args.control == "cartesian" else 0)
 
@@ -284,14 +330,15 @@ def main() -> None:
     if args.task == "pick_up":
         # RandomCubePos placements of every reset, resident: x, y ~ iso_cube +- 0.1 m, z = 14.4 mm, quaternion (w ~ U(-1, 1), 0, 0, 1)
         n_resets = T // max(episode, 1) + 2
-        box_pose = torch.zeros((n_resets, n, 7), device="cuda", dtype=torch.float64)
-        u = torch.rand((n_resets, n, 3), generator=gen, device="cuda", dtype=torch.float64)
-        box_pose[..., 0] = 0.498 + u[..., 0] * 0.2 - 0.1
-        box_pose[..., 1] = u[..., 1] * 0.2 - 0.1
-        box_pose[..., 2] = 0.0288 / 2
-        box_pose[..., 3] = 2 * u[..., 2] - 1
-        box_pose[..., 6] = 1.0
-        task_out = torch.zeros((n, 9), device="cuda", dtype=torch.float64)
+        bp = np.zeros((n_resets, n, 7))
+        u = rng.random((n_resets, n, 3))
+        bp[..., 0] = 0.498 + u[..., 0] * 0.2 - 0.1
+        bp[..., 1] = u[..., 1] * 0.2 - 0.1
+        bp[..., 2] = 0.0288 / 2
+        bp[..., 3] = 2 * u[..., 2] - 1
+        bp[..., 6] = 1.0
+        box_pose = DevBuf((n_resets, n, 7), np.float64, bp)
+        task_out = DevBuf((n, 9), np.float64)
 
     cam_set, cam_out = None, {}
     if args.cameras:
@@ -300,81 +347,82 @@ def main() -> None:
         rw, rh = (int(x) for x in args.resolution.split("x"))
         cam_set = SimCameraSet(env.sim, {c: SimCameraConfig(identifier=c, resolution_width=rw, resolution_height=rh) for c in args.cameras.split(",")},
                                physical_units=True)
-        cam_out = {c: torch.zeros((n, rh, rw), device="cuda", dtype=torch.uint16) for c in cam_set.camera_names}
+        cam_out = {c: DevBuf((n, rh, rw), np.uint16) for c in cam_set.camera_names}
 
     def do_reset(t: int) -> None:
         if box_pose is not None:
-            env.reset_task_dev(box_pose[t // max(episode, 1)].data_ptr(), obs.data_ptr(), info.data_ptr(), gw.data_ptr())
+            env.reset_task_dev(box_pose.at(t // max(episode, 1)), obs.ptr, info.ptr, gw.ptr)
         else:
             row = 0
             for e_ in envs:
-                e_.reset_dev(obs.data_ptr() + 8 * row * ow, info[row:].data_ptr(), gw[row:].data_ptr())
+                e_.reset_dev(obs.ptr + 8 * row * ow, info.ptr + 8 * row, gw.ptr + 8 * row)
                 row += e_.n_envs
-            torch.cuda.synchronize()
+            device_sync()
 
     def one_step(t: int) -> None:
         if episode and t % episode == 0:
             do_reset(t)
-        optr = (exchange.local_ptr(t) if rccl_exchange else exchange.local(t).data_ptr()) if exchange else obs.data_ptr()
+        optr = exchange.local_ptr(t) if exchange else obs.ptr
+        for e_ in envs[1:]:
+            # (the slot of the exchange this step writes was released on the first handle's stream -- and the previous step's
+            # render / gather read the block from there: rcsh_sim_wait_for orders the sub-batches' streams behind that point,
+            # BEFORE the first sub-batch's own launch goes out, so that all sub-batches run side by side)
+            _lib.check(L.rcsh_sim_wait_for(e_.sim._h, h))
         if task_out is not None:
-            env.step_task_dev(joints[t].data_ptr(), grip[t].data_ptr(), optr, info.data_ptr(), gw.data_ptr(), sub.data_ptr(), task_out.data_ptr())
+            env.step_task_dev(joints.at(t), grip.at(t), optr, info.ptr, gw.ptr, sub.ptr, task_out.ptr)
         else:
-            env.step_dev(joints[t].data_ptr(), grip[t].data_ptr(), optr, info.data_ptr(), gw.data_ptr(), sub.data_ptr())
+            env.step_dev(joints.at(t), grip.at(t), optr, info.ptr, gw.ptr, sub.ptr)
         row = env.n_envs
-        for e_, st_, j_ in zip(envs[1:], streams[1:], sub_joints[1:]):
-            st_.wait_stream(streams[0])  # (the slot of the exchange this step writes was released on the first stream)
-            e_.step_dev(j_[t].data_ptr(), grip[t, row:].data_ptr(), optr + 8 * row * ow, info[row:].data_ptr(), gw[row:].data_ptr(), sub[row:].data_ptr())
+        for e_, j_ in zip(envs[1:], sub_joints[1:]):
+            e_.step_dev(j_.at(t), grip.at(t, 4 * row), optr + 8 * row * ow, info.ptr + 8 * row, gw.ptr + 8 * row, sub.ptr + 4 * row)
             row += e_.n_envs
-        for st_ in streams[1:]:
-            streams[0].wait_stream(st_)  # the gather (and the clock) see all sub-batches
+        for e_ in envs[1:]:
+            _lib.check(L.rcsh_sim_wait_for(h, e_.sim._h))  # the gather (and the clock) see all sub-batches
         for c, buf in cam_out.items():
-            cam_set.render_depth_mm_dev(c, buf.data_ptr())
+            cam_set.render_depth_mm_dev(c, buf.ptr)
         if exchange:
             exchange.post(t)  # overlaps with the next env-step
 
     do_reset(0)
     for t in range(args.warmup):
         one_step(t)
-    from rcs_amd import _lib
 
     # HIP events on the launch stream: ONE pair around the whole timed region (rcsh_prof_enable(h, -1)) -- the stream time of
     # the region's stepping launches, dispatch gaps included, divided by their number.  (A pair around every launch puts ~8 us
     # of dispatch gap into each step of the run it is measuring; pairs around every 8th launch, rounds 1-2, left 3 samples at
     # the driver's --steps 20 and a per-launch figure above the step time it is part of.)
     _lib.check(L.rcsh_prof_enable(h, -1))
+    if exchange:
+        exchange.drain()
+    device_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    substeps_total = 0
     for t in range(args.warmup, T):
         one_step(t)
-        if args.mode == "convergence":
-            substeps_total += 0  # per-step counts stay on the device; read once after the timed region
     # the region's closing event goes onto the launch stream right behind the last step (reading it waits for that stream)
-    import ctypes as C
-
     ms, launches = C.c_double(0), C.c_int64(0)
     _lib.check(L.rcsh_prof_read(h, C.byref(ms), C.byref(launches)))
     if exchange:
         exchange.drain()
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    obs_host = obs.download()
     if exchange:  # (after the clock stopped) this rank's rows of the last gathered tensor: finiteness check below
-        g = exchange.gathered(T - 1)
-        obs = (torch.from_numpy(g).cuda() if rccl_exchange else g)[rank * n:(rank + 1) * n]
+        obs_host = np.asarray(exchange.gathered(T - 1))[rank * n:(rank + 1) * n]
     if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     kernel_ms = ms.value / max(launches.value, 1)
-    mean_sub = float(sub.to(torch.float64).mean().item())
-    finite = bool(torch.isfinite(obs).all().item())
+    mean_sub = float(sub.download().astype(np.float64).mean())
+    finite = bool(np.isfinite(obs_host).all())
     if task_out is not None:
-        finite = finite and bool(torch.isfinite(task_out).all().item())
+        finite = finite and bool(np.isfinite(task_out.download()).all())
+    rccl_exchange = exchange is not None and args.dist_backend == "nccl"
 
     SCENE_OF = {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world", "xarm7_pick": "xarm7_pick_world", "arm6": "arm6_empty_world",
                 "ur5e": "ur5e_empty_world", "so101": "so101_empty_world"}
@@ -429,7 +477,7 @@ def main() -> None:
                 "episode_length": episode or None,
                 "depth_frames": (f"{args.cameras} at {args.resolution}, one ray-cast uint16 frame per camera per env-step "
                                  f"({len(cam_out) * n * int(args.resolution.split('x')[0]) * int(args.resolution.split('x')[1]) / (elapsed / args.steps) / 1e9:.2f} G rays/s incl. the physics)") if cam_out else None,
-                "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if args.dist_backend == "nccl" else f"torch.distributed {args.dist_backend} all_gather")
+                "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"torch.distributed {args.dist_backend} all_gather")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
             },
@@ -456,6 +504,8 @@ def main() -> None:
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
+    if exchange:
+        exchange.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -175,6 +175,11 @@ int rcsh_sim_synchronize(rcsh_sim* sim);
  * stream (e.g. the host framework's current stream, so its collectives order after the env-step kernel) */
 void* rcsh_sim_stream(rcsh_sim* sim);
 int rcsh_sim_set_stream(rcsh_sim* sim, void* hip_stream);
+/* Stream ordering between handles (no reference counterpart): everything enqueued on `sim`'s stream after this call runs after
+ * what `producer`'s stream holds now (an event on the producer's stream, a stream-side wait on the other: no host blocking).
+ * A host that runs several handles side by side -- sub-batches of different robot types on one GPU -- orders the places where
+ * they meet (a shared observation block, an exchange slot) with it, without a HIP binding of its own. */
+int rcsh_sim_wait_for(rcsh_sim* sim, rcsh_sim* producer);
 /* Kernel selection (no reference counterpart).  Every scene runs on the team kernel (16 lanes per environment);
  * RCSH_KERNEL_AUTO and RCSH_KERNEL_TEAM both name it.  RCSH_KERNEL_LANE, the one-lane-per-environment kernel of ABI 1, was
  * removed (it lost at every batch size and stepped neither dry friction nor free bodies): selecting it is RCSH_ERR_ARG.

@@ -107,6 +107,7 @@ struct rcsh_sim {
   bool comm_pending[2] = {false, false};
   int comm_rank = 0, comm_world = 1;
   // profiling
+  hipEvent_t order_ev = nullptr;       // rcsh_sim_wait_for: marks this handle's stream for another handle's stream to wait on
   bool prof = false;
   bool prof_region = false;            // one event pair around the whole timed region instead of sampled launches
   int64_t prof_region_launches = 0;
@@ -649,6 +650,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   if (s->stream) hipStreamSynchronize(s->stream);
   if (s->comm) rcsh_comm_destroy(s);
   for (auto e : s->ev_start) hipEventDestroy(e);
+  if (s->order_ev) hipEventDestroy(s->order_ev);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs);
@@ -668,6 +670,17 @@ int rcsh_sim_set_stream(rcsh_sim* s, void* hip_stream) {
   REQUIRE_SIM(s);
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  return RCSH_OK;
+}
+
+int rcsh_sim_wait_for(rcsh_sim* s, rcsh_sim* producer) {
+  REQUIRE_SIM(s);
+  if (!producer) return fail(RCSH_ERR_ARG, "null producer handle");
+  if (producer == s || producer->stream == s->stream) return RCSH_OK;  // same stream: already ordered
+  HIP_TRY(hipSetDevice(producer->device));
+  if (!producer->order_ev) HIP_TRY(hipEventCreateWithFlags(&producer->order_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(producer->order_ev, producer->stream));
+  HIP_TRY(hipStreamWaitEvent(s->stream, producer->order_ev, 0));
   return RCSH_OK;
 }
 

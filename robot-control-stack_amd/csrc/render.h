@@ -210,6 +210,36 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     }
   }
   __syncthreads();
+  // Second level, per wavefront: the 8 x 8 pixels of a wavefront see a much thinner pyramid than the tile, and the links of an
+  // arm are long and thin -- a bounding sphere of 0.2 m radius puts every link into every tile around the arm, its oriented box
+  // into few.  Lane g: is shape g's box (hulls: their bounding box; centre = the bounding sphere's) entirely outside one of
+  // the four side planes of this wavefront's pyramid?  All of a wavefront's rays skip the culled shapes: pure culling, the
+  // pixels are the same.
+  uint32_t wave_shapes = tile_shapes;
+  {
+    bool keep = true;
+    if (lane < sc.nshape && ((tile_shapes >> lane) & 1u)) {
+      const RenderShape& sh = sc.shapes[lane];
+      if (sh.shape != kShapePlane) {
+        const double* w = lw + lane * kShapeFrameDoubles;
+        const int c0 = (tile % tiles_x) * 16 + (wave % 2) * 8, r0 = (tile / tiles_x) * 16 + (wave / 2) * 8;
+        const double xl = (2.0 * c0 / W - 1.0) * tx, xr = (2.0 * (c0 + 8) / W - 1.0) * tx;
+        const double yb = (2.0 * r0 / H - 1.0) * ty, yt = (2.0 * (r0 + 8) / H - 1.0) * ty;
+        const double nc[4][3] = {{1.0, 0.0, xl}, {-1.0, 0.0, -xr}, {0.0, 1.0, yb}, {0.0, -1.0, -yt}};  // inward normals, camera frame
+        const double q[3] = {w[12] - cp[0], w[13] - cp[1], w[14] - cp[2]};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          double nw[3];
+          mulmv(cR, nc[f], nw);
+          double reach = nw[0] * q[0] + nw[1] * q[1] + nw[2] * q[2];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) reach += sh.size[k] * fabs(nw[0] * w[k] + nw[1] * w[3 + k] + nw[2] * w[6 + k]);
+          keep = keep && reach >= 0.0;
+        }
+      }
+    }
+    wave_shapes &= (uint32_t)__ballot(keep);
+  }
   if (col >= W || row >= H) return;
   // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
   const double dc[3] = {(2.0 * (col + 0.5) / W - 1.0) * tx, (2.0 * (row + 0.5) / H - 1.0) * ty, -1.0};
@@ -221,7 +251,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   bool hit = false;
   // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
   int hit_g = -1, hit_face = 0;
-  for (uint32_t todo = tile_shapes; todo; todo &= todo - 1) {
+  for (uint32_t todo = wave_shapes; todo; todo &= todo - 1) {
     const int g = __ffs(todo) - 1;
     const RenderShape& sh = sc.shapes[g];
     const double* w = lw + g * kShapeFrameDoubles;  // R (9) p (3) sphere centre (3) radius

@@ -159,7 +159,7 @@ class EnvDesc(C.Structure):
 # every symbol include/rcs_hip.h declares; load() fails if one is missing
 EXPORTS = (
     "rcsh_last_error", "rcsh_abi_version", "rcsh_device_count", "rcsh_sim_create", "rcsh_sim_destroy",
-    "rcsh_sim_num_envs", "rcsh_sim_synchronize", "rcsh_sim_stream", "rcsh_sim_set_stream", "rcsh_sim_set_kernel", "rcsh_sim_set_config", "rcsh_sim_get_config",
+    "rcsh_sim_num_envs", "rcsh_sim_synchronize", "rcsh_sim_stream", "rcsh_sim_set_stream", "rcsh_sim_wait_for", "rcsh_sim_set_kernel", "rcsh_sim_set_config", "rcsh_sim_get_config",
     "rcsh_sim_step", "rcsh_sim_step_until_convergence", "rcsh_sim_is_converged", "rcsh_sim_reset",
     "rcsh_sim_add_robot", "rcsh_robot_set_joint_position", "rcsh_robot_get_joint_position",
     "rcsh_robot_get_cartesian_position", "rcsh_robot_get_base_pose", "rcsh_robot_set_cartesian_position",
@@ -201,6 +201,7 @@ def load() -> C.CDLL:
     L.rcsh_sim_stream.restype = C.c_void_p
     L.rcsh_sim_stream.argtypes = [C.c_void_p]
     L.rcsh_sim_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.rcsh_sim_wait_for.argtypes = [C.c_void_p, C.c_void_p]
     L.rcsh_comm_get_unique_id.argtypes = [C.c_char_p]
     L.rcsh_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
     L.rcsh_env_allgather_obs_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
