@@ -210,36 +210,43 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     }
   }
   __syncthreads();
-  // Second level, per wavefront: the 8 x 8 pixels of a wavefront see a much thinner pyramid than the tile, and the links of an
-  // arm are long and thin -- a bounding sphere of 0.2 m radius puts every link into every tile around the arm, its oriented box
-  // into few.  Lane g: is shape g's box (hulls: their bounding box; centre = the bounding sphere's) entirely outside one of
-  // the four side planes of this wavefront's pyramid?  All of a wavefront's rays skip the culled shapes: pure culling, the
-  // pixels are the same.
-  uint32_t wave_shapes = tile_shapes;
+  const uint32_t wave_shapes = tile_shapes;
+  // Front to back.  A ray only needs the NEAREST entry point, and the slab test below starts from t1 = best: a shape whose box
+  // begins behind the nearest hit so far costs three slabs instead of its ~100 face planes.  Seen from above an arm is a stack
+  // of links, each ray's pyramid crossing most of their boxes -- visited base first (index order) every one of them was walked
+  // in full.  The wavefront's shapes are ranked by the view depth of their box's nearest point (lane g ranks shape g; planes
+  // first: one cheap test that bounds `best`), the order goes through LDS.  Which shape is hit does not depend on the order
+  // (ties between two shapes' entry depths aside), the depth never does.
+  __shared__ uint8_t visit[4][kMaxShapes];
+  int nvisit = __popc(wave_shapes);
   {
-    bool keep = true;
-    if (lane < sc.nshape && ((tile_shapes >> lane) & 1u)) {
+    double key = INFINITY;
+    const bool mine = lane < sc.nshape && ((wave_shapes >> lane) & 1u);
+    if (mine) {
       const RenderShape& sh = sc.shapes[lane];
-      if (sh.shape != kShapePlane) {
-        const double* w = lw + lane * kShapeFrameDoubles;
-        const int c0 = (tile % tiles_x) * 16 + (wave % 2) * 8, r0 = (tile / tiles_x) * 16 + (wave / 2) * 8;
-        const double xl = (2.0 * c0 / W - 1.0) * tx, xr = (2.0 * (c0 + 8) / W - 1.0) * tx;
-        const double yb = (2.0 * r0 / H - 1.0) * ty, yt = (2.0 * (r0 + 8) / H - 1.0) * ty;
-        const double nc[4][3] = {{1.0, 0.0, xl}, {-1.0, 0.0, -xr}, {0.0, 1.0, yb}, {0.0, -1.0, -yt}};  // inward normals, camera frame
-        const double q[3] = {w[12] - cp[0], w[13] - cp[1], w[14] - cp[2]};
+      const double* w = lw + lane * kShapeFrameDoubles;
+      if (sh.shape == kShapePlane) key = -INFINITY;
+      else {
+        // view depth = -(z of the camera frame); the camera's z axis in world coordinates is the third column of cR
+        const double az[3] = {cR[2], cR[5], cR[8]};
+        key = -(az[0] * (w[12] - cp[0]) + az[1] * (w[13] - cp[1]) + az[2] * (w[14] - cp[2]));
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          double nw[3];
-          mulmv(cR, nc[f], nw);
-          double reach = nw[0] * q[0] + nw[1] * q[1] + nw[2] * q[2];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) reach += sh.size[k] * fabs(nw[0] * w[k] + nw[1] * w[3 + k] + nw[2] * w[6 + k]);
-          keep = keep && reach >= 0.0;
-        }
+        for (int k = 0; k < 3; ++k) key -= sh.size[k] * fabs(az[0] * w[k] + az[1] * w[3 + k] + az[2] * w[6 + k]);
       }
     }
-    wave_shapes &= (uint32_t)__ballot(keep);
+    // (few shapes -- the wrist camera's usual view: floor, cube, finger pads -- are visited in index order: nothing to gain)
+    int rank = __popc(wave_shapes & ((1u << (lane & 31)) - 1u));
+    if (nvisit > 4) {
+      rank = 0;
+      for (uint32_t m = wave_shapes; m; m &= m - 1) {
+        const int g = __ffs(m) - 1;
+        const double kg = __shfl(key, g);
+        rank += (kg < key || (kg == key && g < lane)) ? 1 : 0;
+      }
+    }
+    if (mine) visit[wave][rank] = (uint8_t)lane;
   }
+  __syncthreads();
   if (col >= W || row >= H) return;
   // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
   const double dc[3] = {(2.0 * (col + 0.5) / W - 1.0) * tx, (2.0 * (row + 0.5) / H - 1.0) * ty, -1.0};
@@ -251,8 +258,9 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   bool hit = false;
   // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
   int hit_g = -1, hit_face = 0;
-  for (uint32_t todo = wave_shapes; todo; todo &= todo - 1) {
-    const int g = __ffs(todo) - 1;
+  for (int vi = 0; vi < nvisit; ++vi) {
+    // (the visit list is the wavefront's: saying so lets the shape's constants and its ~100 face planes come through scalar loads)
+    const int g = __builtin_amdgcn_readfirstlane((int)visit[wave][vi]);
     const RenderShape& sh = sc.shapes[g];
     const double* w = lw + g * kShapeFrameDoubles;  // R (9) p (3) sphere centre (3) radius
     if (w[15] >= 0) {

@@ -5,6 +5,8 @@ sys.path[:0] = [os.path.join(ROOT, "robot-control-stack_amd"), os.path.join(ROOT
 import ctypes as C
 import numpy as np
 from rcs_amd import _lib
+if os.environ.get("RCSH_LIB"): _lib.LIB_PATH = os.environ["RCSH_LIB"]  # (a development build of the library)
+np.random.seed(0)  # RandomCubePos draws from numpy's global generator: the same cubes every run
 from rcs_amd.camera import SimCameraConfig, SimCameraSet
 from rcs_amd.envs import FR3SimplePickUpSimEnvCreator
 
