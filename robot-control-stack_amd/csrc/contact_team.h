@@ -1370,6 +1370,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
   const int robot_contacts = totP + totB;
   offB += totP + nBP;
   int ncon = totP + nBP + totB;
+  const bool too_many_contacts = ncon > kMaxCon;  // (the tail of MuJoCo's contact order is dropped: flagged, kContactOverflow)
   if (ncon > kMaxCon) ncon = kMaxCon;
   if (has_geom) {
     const int lcode = cg.link >= 0 ? cg.link : kWorld;
@@ -1409,6 +1410,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       ar.cb[c] = kWorld | (kBox << 8);
     }
     ar.ncon = ncon;
+    ar.pad[0] = too_many_contacts ? 1 : 0;  // capacity overflow of this phase (contact_newton adds the links' share)
   }
   __syncthreads();
   // contact classes of this position stage (what the collision callbacks scan d->contact for).  SimGripper::collision_callback
@@ -1500,7 +1502,15 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
       if (lane == 0) ar.act[na] = best_l;
       ++na;
     }
-    if (lane == 0) ar.nact = na;
+    if (lane == 0) {
+      ar.nact = na;
+      // more links in contact than the stiffness fold / the noslip slots hold: the rest keep their contact forces but drop out
+      // of the Hessian and of the noslip update -- a different (slower, for noslip: incomplete) iteration than MuJoCo's: flagged
+      uint64_t left = 0;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) left |= first_of[l] & ~taken;
+      if (left) ar.pad[0] |= 2;
+    }
   }
   // ---- qacc_smooth: the robot's by its own factorisation (every lane), the box's in closed form
   const double Mb[6] = {b.mass, b.mass, b.mass, b.inertia[0], b.inertia[1], b.inertia[2]};
@@ -2173,7 +2183,8 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
 // The contact phase of one environment, executed by the whole wavefront.  `st` / `bs`: the environment's LDS blocks
 // (robot: pre-step q, qd, motion axes S, mass matrix, qfrc_smooth, limit / equality rows of this substep; box: state).
 // Returns bit 0: coupled (a robot geom is in contact: st.fcon holds the robot's constraint force, bs[kBoxA..] the box's
-// acceleration); bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
+// acceleration); bit 4: more than kMaxCon contacts or more than kMaxActive links in contact (results then differ from MuJoCo's);
+// bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
 template <class T, bool FRIC = false>
 RCSH_D uint32_t contact_phase(const ContactTable& tab, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
                               ContactArena<T>& ar, const double* gravity) {
@@ -2181,7 +2192,7 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const BoxCfg& b, const Li
   if (!(r & 1u) || !b.resolve) return r & ~1u;
   contact_newton<T, FRIC>(b, st, bs, ar, gravity, links);
   contact_noslip<T>(b, st, bs, ar);
-  return r;
+  return r | (in_lds(&ar)->pad[0] ? 16u : 0u);  // bit 4: a capacity of the contact phase overflowed in this substep
 }
 
 #endif  // __HIP__

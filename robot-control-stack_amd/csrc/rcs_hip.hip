@@ -759,6 +759,7 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   if (!rc) rc = scatter_host(s, field_of(s, "time"), 1, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "cb"), 6, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "xs"), s->nl, z.data(), mask);  // (mj_resetData: qacc_warmstart := 0)
+  if (!rc) rc = flags_update_host(s, 0, kContactOverflow, mask);
   if (!rc && s->box.present) {
     std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
     for (int e = 0; e < s->n; ++e)

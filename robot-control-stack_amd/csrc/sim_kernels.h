@@ -37,6 +37,7 @@ enum : uint32_t {
   kHasGripCmd = 1u << 12,
   kGripCmd = 1u << 13,
   kHasLastAction = 1u << 14,
+  kContactOverflow = 1u << 15,  // sticky until Sim::reset: a contact phase of this environment ran out of contact / link slots
 };
 
 struct SimCfg {
@@ -405,6 +406,7 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
 #pragma unroll
     for (int i = 0; i < T::NU; ++i) r.st.c(i) = 0;
     r.time = 0;
+    r.flags &= ~kContactOverflow;
 #pragma unroll
     for (int i = 0; i < 6; ++i) r.cb(i) = 0;
     // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
@@ -537,7 +539,8 @@ __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, c
       inf[3] = has_g && (w > 0.01 && w < 0.99);
       inf[4] = rc || !ik;
       inf[5] = gc;
-      inf[6] = 0; inf[7] = 0;
+      inf[6] = (r.flags & kContactOverflow) != 0;  // a contact phase ran out of contact / link slots since the last Sim.reset
+      inf[7] = 0;
     }
     if (op.gripper_width) op.gripper_width[e] = w;
     if (op.substeps) op.substeps[e] = nsteps >= 0 ? nsteps : r.conv_steps;
@@ -803,7 +806,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     }
     const bool team_due = DET && team_ballot(due) != 0;
     const bool want_contacts = DET && __ballot(due) != 0;  // (the wavefront detects together: self_collision_pairs)
-    uint32_t hit = 0;
+    uint32_t hit = 0, overflow = 0;
     bool near = false;  // broad phase of the contact phase: the lane's link may touch the floor or the box
     bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
     team_substep<T, FRIC>(m, sk, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
@@ -894,6 +897,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
             if (team == k) {
               coupled = r & 1u;
               hit |= (r >> 8) & 3u;
+              overflow |= (r >> 4) & 1u;
             }
           }
         }
@@ -922,6 +926,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       }
     }
     if (leader && stepping) {
+      if (CON && overflow) r.flags |= kContactOverflow;
       r.time += timestep;
       have_frames = true;
       --budget;

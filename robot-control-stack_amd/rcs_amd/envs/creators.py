@@ -134,6 +134,9 @@ class VecSimEnv:
             i["gripper_width"] = gw
             i["is_grasped"] = info[:, 3].astype(bool)
         i["substeps"] = sub
+        # (no reference counterpart) a contact phase of the environment ran out of contact / link slots since its last reset:
+        # its trajectory is no longer what MuJoCo would compute (csrc/contact_team.h: kMaxCon, kMaxActive)
+        i["contact_overflow"] = info[:, 6].astype(bool)
         truncated = info[:, 4].astype(bool)
         return o, np.zeros(n), np.zeros(n, dtype=bool), truncated, i
 
@@ -235,6 +238,7 @@ class VecPickCubeEnv(VecSimEnv):
         i["gripper_width"] = gw
         i["is_grasped"] = info[:, 3].astype(bool)
         i["substeps"] = sub
+        i["contact_overflow"] = info[:, 6].astype(bool)  # (see VecSimEnv.step)
         i["box_qpos"] = task[:, :7].copy()
         success = task[:, 8] != 0
         i["success"] = success

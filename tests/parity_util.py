@@ -976,6 +976,7 @@ def run_pick_success_parity(n_envs=3, seed=0):
                 rep["grasped_steps"] += int(bool(oi["is_grasped"]))
                 rep["truncated"] += int(bool(otrunc))
             rep["max_box_z"] = max(rep["max_box_z"], float(info["box_qpos"][:, 2].min()))
+            rep["contact_overflows"] = rep.get("contact_overflows", 0) + int(np.asarray(info["contact_overflow"]).sum())
             rep["steps"] += 1
     venv.close()
     return rep

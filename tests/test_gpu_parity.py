@@ -938,6 +938,7 @@ def test_pick_task_reaches_success(kernel):
     assert rep["flag_mismatches"] == 0 and rep["truncated"] == 0, rep
     assert rep["success_steps"] >= 3 * 10 and rep["grasped_steps"] > 100 and rep["max_box_z"] > 1.002, rep
     assert rep["max_abs_obs"] < 1e-8 and rep["max_abs_box"] < 1e-7 and rep["max_abs_reward"] < 1e-8, rep
+    assert rep["contact_overflows"] == 0, rep  # no contact phase ran out of contact (48) or link (4) slots: info["contact_overflow"]
 
 
 def test_pybind_module_equals_ctypes_host_layer(kernel):
