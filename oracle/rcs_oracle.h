@@ -7,12 +7,18 @@
  * leg may load this library; nothing under robot-control-stack_amd/ links,
  * imports or calls it.
  *
- * PARITY UNPINNED for the physics: the arithmetic of mj_step1/mj_step2 lives in
- * third-party MuJoCo 3.2.6 (reference pyproject.toml:23), absent from
- * /root/reference and from this image.  orc_step1/orc_step2 restate MuJoCo's
- * published forward-dynamics pipeline (kinematics, comPos, CRBA, RNE, passive,
- * actuation, soft constraints, implicitfast) for the RCS scenes and are pinned
- * only by the reference's own tests (tests/test_oracle_pins.py lists them).
+ * PARITY UNPINNED AGAINST MUJOCO for the physics: the arithmetic of
+ * mj_step1/mj_step2 lives in third-party MuJoCo 3.2.6 (reference
+ * pyproject.toml:23), absent from /root/reference and from this image.
+ * orc_step1/orc_step2 restate MuJoCo's published forward-dynamics pipeline
+ * (kinematics, comPos, CRBA, RNE, passive, actuation, soft constraints,
+ * implicitfast) for the RCS scenes.  What pins them instead: the reference's own
+ * tests (tests/test_oracle_pins.py lists them); since round 3 an independent
+ * first-principles derivation of the robots' dynamics from the reference's MJCF
+ * constants (tests/golden/{fr3,fr3_arm,xarm7}_dynamics.json,
+ * tools/derive_fr3_dynamics.py: mass matrix, bias, gravity compensation,
+ * actuation, one implicitfast step, held at 1e-10) and closed forms of the
+ * soft-constraint model (tests/test_closed_forms.py).
  * The RCS-side semantics (callback scheduler, SimRobot, SimGripper, Pose) are
  * restated line by line from sources that ARE under /root/reference; each
  * function cites the file:line it follows.
