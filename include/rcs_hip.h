@@ -406,6 +406,10 @@ int rcsh_camera_render_rgb_dev(rcsh_sim* sim, int32_t cam_id, uint8_t* rgb_dev, 
  * Images of environments whose `due` is 0 for that slot and camera are meaningless.  ncam = 0 removes the schedule. */
 int rcsh_sim_set_render_schedule(rcsh_sim* sim, const int32_t* cam_ids, const double* seconds_between_calls, int32_t ncam, int32_t capacity);
 int rcsh_render_pending(rcsh_sim* sim, int32_t* count);
+/* Calling rcsh_sim_set_render_schedule again with the SAME cameras and periods and a larger capacity grows the schedule in
+ * place: clocks and pending records stay.  Records beyond the capacity are not written; rcsh_render_pending clamps its counts
+ * to the capacity and adds what was lost to a counter that rcsh_render_dropped reads (reset with the schedule). */
+int rcsh_render_dropped(rcsh_sim* sim, int64_t* dropped);
 int rcsh_camera_render_snapshot(rcsh_sim* sim, int32_t cam_id, int32_t slot, uint8_t* rgb, float* depth_gl, uint16_t* depth_mm, double* cam_pose,
                                 double* timestamp, uint8_t* due);
 

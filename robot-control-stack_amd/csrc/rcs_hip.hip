@@ -85,6 +85,7 @@ struct rcsh_sim {
   RenderColour* d_rcolours = nullptr;
   RendCfg rend{};                    // rate-driven cameras (rcsh_sim_set_render_schedule)
   int rend_cam_id[kMaxRateCams] = {0, 0, 0, 0};
+  int64_t rend_dropped = 0;          // records that did not fit the schedule's capacity (rcsh_render_pending counts them)
   const double* frames_src = nullptr; // set while a record of the render schedule is being rendered
   const double* frames_src_base(int slot) const { return rend.snap + (size_t)slot * (size_t)(nl + 9) * (size_t)n; }
   double* d_frames = nullptr;
@@ -1482,10 +1483,26 @@ int rcsh_sim_set_render_schedule(rcsh_sim* s, const int32_t* cam_ids, const doub
   }
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  const size_t n = (size_t)s->n, nf = (size_t)s->nl + 9;
+  // The same cameras with the same periods and a larger capacity: the schedule GROWS -- the cameras' clocks and what the last
+  // launch recorded stay (a host that is about to run a longer launch than the schedule was sized for -- Sim.step(k) with a
+  // large k, a raised max_convergence_steps -- calls this first; re-registering must not make every camera due again).
+  bool same = ncam > 0 && ncam == s->rend.ncam && capacity >= s->rend.capacity;
+  for (int c = 0; same && c < ncam; ++c) same = s->rend_cam_id[c] == cam_ids[c] && s->rend.period[c] == seconds_between_calls[c];
+  if (same) {
+    if (capacity == s->rend.capacity) return RCSH_OK;
+    double* snap = nullptr;
+    HIP_TRY(hipMalloc(&snap, sizeof(double) * (size_t)capacity * nf * n));
+    HIP_TRY(hipMemcpy(snap, s->rend.snap, sizeof(double) * (size_t)s->rend.capacity * nf * n, hipMemcpyDeviceToDevice));
+    hipFree(s->rend.snap);
+    s->rend.snap = snap;
+    s->rend.capacity = capacity;
+    return RCSH_OK;
+  }
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
   s->rend = RendCfg{};
+  s->rend_dropped = 0;
   if (ncam == 0) return RCSH_OK;
-  const size_t n = (size_t)s->n, nf = (size_t)s->nl + 9;
   HIP_TRY(hipMalloc(&s->rend.last, sizeof(double) * kMaxRateCams * n));
   HIP_TRY(hipMalloc(&s->rend.snap, sizeof(double) * (size_t)capacity * nf * n));
   HIP_TRY(hipMalloc(&s->rend.count, sizeof(int32_t) * n));
@@ -1511,9 +1528,19 @@ int rcsh_render_pending(rcsh_sim* s, int32_t* count) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemcpyAsync(count, s->rend.count, sizeof(int32_t) * s->n, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  // more frames due in one launch than the schedule holds: the records beyond its capacity were not written (the newest are
+  // lost); the stepping itself is unaffected, so this is a count for the host to warn about, not an error after the fact
   for (int e = 0; e < s->n; ++e)
-    if (count[e] > s->rend.capacity)
-      return fail(RCSH_ERR_STATE, "more frames became due in one launch than the render schedule's capacity holds");
+    if (count[e] > s->rend.capacity) {
+      s->rend_dropped += count[e] - s->rend.capacity;
+      count[e] = s->rend.capacity;
+    }
+  return RCSH_OK;
+}
+
+int rcsh_render_dropped(rcsh_sim* s, int64_t* dropped) {
+  REQUIRE_SIM(s);
+  if (dropped) *dropped = s->rend_dropped;
   return RCSH_OK;
 }
 

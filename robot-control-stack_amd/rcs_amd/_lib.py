@@ -172,7 +172,7 @@ EXPORTS = (
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
     "rcsh_sim_set_render_scene", "rcsh_sim_add_camera", "rcsh_camera_render", "rcsh_camera_render_dev",
     "rcsh_sim_set_render_colours", "rcsh_camera_render_rgb", "rcsh_camera_render_rgb_dev",
-    "rcsh_sim_set_render_schedule", "rcsh_render_pending", "rcsh_camera_render_snapshot",
+    "rcsh_sim_set_render_schedule", "rcsh_render_pending", "rcsh_render_dropped", "rcsh_camera_render_snapshot",
     "rcsh_env_configure_pick_task", "rcsh_env_reset_task", "rcsh_env_step_task", "rcsh_env_reset_task_dev", "rcsh_env_step_task_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
@@ -227,6 +227,7 @@ def load() -> C.CDLL:
     L.rcsh_camera_render_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_sim_set_render_schedule.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.rcsh_render_pending.argtypes = [C.c_void_p, C.c_void_p]
+    L.rcsh_render_dropped.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.rcsh_camera_render_snapshot.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_sim_set_render_colours.argtypes = [C.c_void_p, C.POINTER(RenderColours)]
     L.rcsh_camera_render_rgb.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -133,17 +133,32 @@ class SimCameraSet:
         if not render_on_demand and self._rated:
             if len(self._rated) > 4:
                 raise ValueError("at most 4 cameras with a frame rate")
-            ids = np.array([self._ids[nm] for nm in self._rated], dtype=np.int32)
-            periods = np.array([1.0 / cameras[nm].frame_rate for nm in self._rated], dtype=np.float64)
-            # records per launch: the longest launch is step_until_convergence's cap (Sim.step(k) beyond that: ValueError at collect)
+            if getattr(simulation, "_rate_camera_sets", None):
+                # the kernels keep ONE render schedule per Sim; a second rate-driven set would silently replace the first one's
+                raise RuntimeError("this Sim already has a SimCameraSet with render_on_demand=False: put all rate-driven cameras into one set")
+            self._sched_ids = np.array([self._ids[nm] for nm in self._rated], dtype=np.int32)
+            self._sched_periods = np.array([1.0 / cameras[nm].frame_rate for nm in self._rated], dtype=np.float64)
+            self._timestep = float(cm.timestep)
+            self._capacity = 0
+            self._dropped = 0
+            # records per launch: sized for the longest launch the present SimConfig can produce (step_until_convergence's cap);
+            # Sim.step(k) / Sim.set_config call ensure_capacity again before a longer one
             cap = simulation.get_config().max_convergence_steps
-            horizon = (cap if cap > 0 else 2000) * cm.timestep
-            capacity = int(min(256, np.ceil(horizon / periods).sum() + 2))  # (records of different cameras need not coincide)
-            self._keep += [ids, periods]
-            _lib.check(self._L.rcsh_sim_set_render_schedule(simulation._h, _lib.ptr(ids), _lib.ptr(periods), len(ids), capacity))
-            if not hasattr(simulation, "_rate_camera_sets"):
-                simulation._rate_camera_sets = []
-            simulation._rate_camera_sets.append(self)
+            self.ensure_capacity(cap if cap > 0 else 2000)
+            simulation._rate_camera_sets = [self]
+
+    def ensure_capacity(self, substeps: int) -> None:
+        """Make the render schedule hold every record a launch of `substeps` substeps can produce (records of different cameras
+        need not coincide).  Growing keeps the cameras' clocks and pending records (rcsh_sim_set_render_schedule with the same
+        cameras); the device buffer is capped at 256 records per environment and launch -- beyond that the newest records of a
+        launch are lost, which `collect` reports with a warning."""
+        if self.render_on_demand or not self._rated:
+            return
+        want = int(min(256, np.ceil(substeps * self._timestep / self._sched_periods).sum() + 2))
+        if want > self._capacity:
+            _lib.check(self._L.rcsh_sim_set_render_schedule(self._sim._h, _lib.ptr(self._sched_ids), _lib.ptr(self._sched_periods),
+                                                            len(self._sched_ids), want))
+            self._capacity = want
 
     # ---- SimCameraSet (src/sim/camera.cpp:54-83)
     def buffer_size(self) -> int:
@@ -208,6 +223,14 @@ class SimCameraSet:
         n = self._sim.n_envs
         count = np.zeros(n, dtype=np.int32)
         _lib.check(self._L.rcsh_render_pending(self._sim._h, _lib.ptr(count)))
+        dropped = C.c_int64(0)
+        _lib.check(self._L.rcsh_render_dropped(self._sim._h, C.byref(dropped)))
+        if dropped.value > self._dropped:
+            import warnings
+
+            warnings.warn(f"SimCameraSet: {dropped.value - self._dropped} frames became due in one launch beyond the render schedule's "
+                          f"capacity ({self._capacity} records per environment) and were not rendered", RuntimeWarning, stacklevel=2)
+            self._dropped = dropped.value
         for slot in range(int(count.max(initial=0))):
             event = {"timestamp": np.full(n, np.nan), "depth": {}, "color": {}, "pose": {}, "have": {}}
             for name in self._rated:

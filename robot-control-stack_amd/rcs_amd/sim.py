@@ -98,6 +98,10 @@ class Sim:
 
     # -- reference Sim API (rcs.cpp:493-506)
     def set_config(self, cfg: SimConfig) -> bool:
+        for cs in getattr(self, "_rate_camera_sets", ()):
+            # the longest launch this configuration produces: step_until_convergence's cap, or one asynchronous env-step
+            conv = cfg.max_convergence_steps if cfg.max_convergence_steps > 0 else 2000
+            cs.ensure_capacity(max(conv, int(round(1.0 / (max(cfg.frequency, 1) * self.model.timestep)))))
         self._cfg = SimConfig(cfg.async_control, cfg.realtime, cfg.frequency, cfg.max_convergence_steps)
         _lib.check(self._L.rcsh_sim_set_config(self._h, int(cfg.async_control), int(cfg.realtime), int(cfg.frequency),
                                                int(cfg.max_convergence_steps)))
@@ -107,6 +111,8 @@ class Sim:
         return SimConfig(self._cfg.async_control, self._cfg.realtime, self._cfg.frequency, self._cfg.max_convergence_steps)
 
     def step(self, k: int) -> None:
+        for cs in getattr(self, "_rate_camera_sets", ()):
+            cs.ensure_capacity(int(k))  # (a launch longer than the render schedule was sized for)
         _lib.check(self._L.rcsh_sim_step(self._h, int(k)))
         self._collect_frames()
 

@@ -1311,3 +1311,38 @@ def test_xarm7_picks_the_cube_up_matches_oracle(kernel):
     st = rep["stages"]
     assert (st["down"]["box_z"] < 0.03).all() and (st["lifted"]["box_z"] > 0.25).all() and (st["held"]["box_z"] > 0.25).all(), st  # picked up and held
     assert (st["released"]["box_z"] < 0.06).all() and (st["held"]["width"] > 0.3).all(), st  # dropped again; the fingers stopped on the cube
+
+
+def test_render_schedule_grows_with_the_launch_and_rejects_a_second_set(kernel):
+    """Advisor, round 2: the render schedule's capacity was frozen at construction (from max_convergence_steps at that moment) and a
+    longer launch -- Sim.step(k) with a large k, a raised cap -- failed after the state had advanced; a second rate-driven
+    SimCameraSet silently replaced the first one's schedule.  Now the schedule grows before a longer launch, keeping the cameras'
+    clocks (no camera becomes due again by re-registration), and a second set is refused."""
+    import warnings
+
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+
+    n = 3
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(max_convergence_steps=40), n_envs=n)
+    S.SimRobot(simu, None, cfg)
+    S.SimGripper(simu, default_sim_gripper_cfg())
+    cams = {"wrist_0": SimCameraConfig(identifier="wrist_0", frame_rate=30, resolution_width=8, resolution_height=6)}
+    cs = SimCameraSet(simu, cams, physical_units=True, render_on_demand=False, max_framesets=10000)
+    small = cs._capacity
+    with pytest.raises(RuntimeError, match="already has a SimCameraSet"):
+        SimCameraSet(simu, cams, physical_units=True, render_on_demand=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a dropped frame would warn
+        simu.step(10)
+        first = cs.buffer_size()
+        simu.step(1500)  # 3 s of simulated time in one launch: 90 frames at 30 Hz, far beyond the initial capacity
+    assert cs._capacity > small and first == 1
+    ts = np.array([ev["timestamp"][0] for ev in cs._buffer])
+    # (a 30 Hz camera is due when MORE than 1/30 s has passed: every 17th substep of 2 ms, Sim::invoke_rendering_callbacks)
+    assert len(ts) == 1 + int((1510 - 1) // 17), len(ts)
+    gaps = np.diff(ts)
+    assert np.all(gaps > 1 / 30) and np.all(gaps < 1 / 30 + 2 * 0.002 + 1e-12), gaps  # every frame one period (plus <= a substep) after the last
+    simu.close()
