@@ -119,3 +119,102 @@ def test_hip_substep_matches_first_principles(tag):
     qacc = np.array([s["qacc_implicit"] for s in g["samples"]])
     assert np.abs(v - v1).max() < REL and np.abs(q - q1).max() < REL, (np.abs(v - v1).max(), np.abs(q - q1).max())
     assert np.abs((v - v0) / h - qacc).max() < 1e-7 * max(1.0, np.abs(qacc).max()), np.abs((v - v0) / h - qacc).max()
+
+
+# ---- the builder-authored scenes (no reference model: nothing else pins what the shared MJCF compiler makes of them)
+AUTHORED = {"ur5e": lambda: P.UR5E_SCENE, "arm6": lambda: P.ARM6_SCENE, "so101": lambda: P.SO101_SCENE, "xarm7_pick": lambda: P.XARM7_PICK_SCENE}
+
+
+def authored():
+    return json.load(open(os.path.join(HERE, "golden", "authored_scene_dynamics.json")))
+
+
+def xarm7_pick_frictionless_scene() -> str:
+    """scenes/xarm7_pick_world with frictionloss = 0 on the arm joints (temporary file): the substep is then the smooth system
+    plus the fingers' equality row, which the first-principles vectors predict."""
+    import shutil
+    import tempfile
+
+    path = os.path.join(tempfile.gettempdir(), "rcs_amd_xarm7_pick_frictionless", "scene.xml")
+    if not os.path.exists(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        xml = open(P.XARM7_PICK_SCENE).read()
+        assert 'frictionloss="1"' in xml
+        open(path, "w").write(xml.replace('frictionloss="1"', 'frictionloss="0"'))
+        for extra in ("collision_vertices.npz", "render_hulls.npz"):
+            shutil.copy(os.path.join(os.path.dirname(P.XARM7_PICK_SCENE), extra), os.path.dirname(path))
+    return path
+
+
+@pytest.mark.parametrize("tag", list(AUTHORED))
+def test_authored_scenes_oracle_intermediates_match_first_principles(tag):
+    """UR5e / arm6 / SO101 / xarm7_pick_world: the scenes this repository authored.  Same derivation, same bars as for the
+    reference's robots; arm6 brings joint axes that are not +z and anchors off the link origin (the kernels' general-axis path),
+    SO101 and xarm7_pick a gripper with its equality row.  xarm7_pick's arm joints carry dry friction: the smooth quantities are
+    compared on the scene itself, the step on its frictionless variant."""
+    import rcs_oracle as O
+    from rcs_amd.mjcf import compile_mjcf
+
+    g = authored()["models"][tag]
+    nv = g["nv"]
+    fric = any(f > 0 for f in g["frictionloss"])
+    models = {"own": O.make_model(compile_mjcf(AUTHORED[tag]()), False)}
+    if fric:
+        models["nofric"] = O.make_model(compile_mjcf(xarm7_pick_frictionless_scene()), False)
+    assert models["own"].njnt == nv
+    L = O.lib()
+    worst = {}
+    for s in g["samples"]:
+        for kind, m in models.items():
+            d = O.OrcData()
+            L.orc_reset_data(C.byref(m), C.byref(d))
+            for i in range(nv):
+                d.qpos[i], d.qvel[i] = s["qpos"][i], s["qvel"][i]
+            for i, u in enumerate(s["ctrl"]):
+                d.ctrl[i] = u
+            L.orc_step1(C.byref(m), C.byref(d))
+            L.orc_step2(C.byref(m), C.byref(d))
+            got = {}
+            if kind == "own":
+                got["qM"] = np.array(d.qM[:]).reshape(O.MAXV, O.MAXV)[:nv, :nv]
+                for k in ("qfrc_bias", "qfrc_gravcomp", "qfrc_passive", "qfrc_actuator", "qfrc_smooth", "qacc_smooth"):
+                    got[k] = getattr(d, k)[:nv]
+            if kind == "nofric" or not fric:
+                got.update(qvel_next=d.qvel[:nv], qpos_next=d.qpos[:nv])
+            for k, v in got.items():
+                worst[k] = max(worst.get(k, 0.0), rel_err(v, s[k]))
+    assert max(worst.values()) < REL and "qvel_next" in worst, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(AUTHORED))
+def test_authored_scenes_hip_substep_matches_first_principles(tag):
+    from rcs_amd import sim as S
+    from rcs_amd import envs as E
+
+    g = authored()["models"][tag]
+    n, nv = len(g["samples"]), g["nv"]
+    cfg = {"ur5e": E.ur5e_sim_robot_cfg, "arm6": E.arm6_sim_robot_cfg, "so101": E.so101_sim_robot_cfg, "xarm7_pick": E.xarm7_pick_sim_robot_cfg}[tag]()
+    if tag == "xarm7_pick":
+        cfg.mjcf_scene_path = cfg.kinematic_model_path = xarm7_pick_frictionless_scene()
+    # (xarm7_pick_world: random arm poses reach through the floor and the cube -- the vectors are contact-free mechanics, so the
+    # robot's contacts are only detected here, not resolved)
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n, resolve_robot_contacts=False if tag == "xarm7_pick" else None)
+    if P.KERNEL != "auto":
+        simu.set_kernel(P.KERNEL)
+    robot = S.SimRobot(simu, None, cfg)
+    ctrl = np.array([s["ctrl"] for s in g["samples"]])
+    dof = robot.dof
+    if nv > dof:
+        grip = S.SimGripper(simu, E.so101_sim_gripper_cfg() if tag == "so101" else E.xarm7_pick_sim_gripper_cfg())
+        grip.set_normalized_width(ctrl[:, dof] / 255.0)
+    simu.set_qpos(np.array([s["qpos"] for s in g["samples"]]))
+    simu.set_qvel(np.array([s["qvel"] for s in g["samples"]]))
+    robot.set_joint_position(ctrl[:, :dof])
+    simu.step(1)
+    assert np.abs(simu.ctrl - ctrl).max() < 1e-12
+    q, v = simu.qpos, simu.qvel
+    simu.close()
+    v1 = np.array([s["qvel_next"] for s in g["samples"]])
+    q1 = np.array([s["qpos_next"] for s in g["samples"]])
+    assert np.abs(v - v1).max() < REL and np.abs(q - q1).max() < REL, (np.abs(v - v1).max(), np.abs(q - q1).max())

@@ -77,7 +77,7 @@ class Chain:
         names = {}
         dropped = set()
         for b in robot["bodies"]:
-            if b["name"] in drop or b["parent"] in dropped:
+            if b["name"] in drop or b["parent"] in dropped or any(j["type"] == "free" for j in b["joints"]):
                 dropped.add(b["name"])
                 continue
             R0 = quat_R(b["quat"]) if b["quat"] else euler_R(b["euler"]) if b["euler"] else mp.eye(3)
@@ -107,7 +107,11 @@ class Chain:
                 j = self.dofs[b["dof"]]
                 ax = [mpf(v) for v in j["axis"]]
                 if j["type"] == "hinge":
-                    R = R * axis_R(ax, q[b["dof"]])  # joint anchor at the body origin (no joint declares pos)
+                    Q = axis_R(ax, q[b["dof"]])
+                    if j.get("pos"):  # anchor off the body origin (the builder-authored arm6 scene): rotate about the axis THROUGH it
+                        a0 = mp.matrix([mpf(v) for v in j["pos"]])
+                        p = p + R * (a0 - Q * a0)
+                    R = R * Q
                 else:
                     a = mp.matrix(ax)
                     p = p + R * (a / mp.norm(a)) * q[b["dof"]]
@@ -238,8 +242,8 @@ def sample(robot, chain, rng, with_equality, gentle=False):
     """`gentle`: small tracking errors and velocities, so that no actuator force reaches a clamp (the other half of the samples
     saturates `actuatorfrcrange` / `forcerange` on most joints)."""
     nv = chain.nv
-    lo = np.array([j["range"][0] for j in chain.dofs])
-    hi = np.array([j["range"][1] for j in chain.dofs])
+    lo = np.array([j["range"][0] if j["range"] else -3.0 for j in chain.dofs])
+    hi = np.array([j["range"][1] if j["range"] else 3.0 for j in chain.dofs])
     lo, hi = np.maximum(lo, -3.0), np.minimum(hi, 3.0)
     span = hi - lo
     qn = lo + span * rng.uniform(0.15, 0.85, nv)  # away from the joint limits: no limit row
@@ -247,10 +251,13 @@ def sample(robot, chain, rng, with_equality, gentle=False):
     names = [j["name"] for j in chain.dofs]
     slide = np.array([j["type"] == "slide" for j in chain.dofs])
     vn[slide] *= 0.05
-    nu = len([a for a in robot["actuators"] if a.get("joint") in names or a.get("tendon")]) if chain.nv > 7 else 7
-    ctrl = list(qn[:7] + rng.uniform(-0.15, 0.15, 7) * (0.01 if gentle else 1.0))
-    if nu == 8:
-        ctrl.append(float(rng.uniform(0, 255)))
+    tendons_ = {t["name"]: t["joints"] for t in robot["tendons"]}
+    ctrl = []
+    for a in robot["actuators"]:  # (the same selection and order as actuation() below)
+        if a.get("joint") in names:
+            ctrl.append(float(qn[names.index(a["joint"])] + rng.uniform(-0.15, 0.15) * (0.01 if gentle else 1.0)))
+        elif a.get("tendon") and all(j in names for j, _ in tendons_[a["tendon"]]):
+            ctrl.append(float(rng.uniform(0, 255)))
     q, v = [mpf(x) for x in qn], [mpf(x) for x in vn]
     M = chain.mass_matrix(q)
     bias, cor, grav = chain.bias(q, v)
@@ -329,6 +336,8 @@ def self_check(chain, rng):
                 Rj, pj = frames[dof["body"]]
                 a = mp.matrix([mpf(x) for x in dof["axis"]])
                 a = Rj * (a / mp.norm(a))
+                if dof.get("pos"):
+                    pj = pj + Rj * mp.matrix([mpf(x) for x in dof["pos"]])
                 if dof["type"] == "hinge":
                     d = base[b][1] - pj
                     col_v = mp.matrix([a[1] * d[2] - a[2] * d[1], a[2] * d[0] - a[0] * d[2], a[0] * d[1] - a[1] * d[0]])
@@ -358,5 +367,39 @@ def main(n_samples=32):
         print("wrote", path, "nv", chain.nv, "jacobian check", err)
 
 
+def main_authored(n_samples=16):
+    """The builder-authored scenes -- no reference model exists for them, so nothing pins what the shared MJCF compiler makes of
+    them.  The same derivation over THEIR files, read by the same independent reader
+    (tools/make_reference_model_fixture.read_robot): what oracle and kernels compute for these robots is then held to first
+    principles too -- general joint axes and off-origin anchors (arm6), the 5-dof arm with its gripper (so101), the UR5e
+    proportions, the xArm7 with the Franka hand (xarm7_pick_world; one-substep prediction for its variant without dry friction)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from make_reference_model_fixture import read_robot
+
+    scenes = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes")
+    out = {"source": "tools/derive_fr3_dynamics.py main_authored() over the repository's own scene files (independent reader)", "timestep": float(TIMESTEP),
+           "gravity": [0, 0, -9.81], "models": {}}
+    for tag, scene, eq in (("ur5e", "ur5e_empty_world", False), ("arm6", "arm6_empty_world", False), ("so101", "so101_empty_world", True),
+                           ("xarm7_pick", "xarm7_pick_world", True)):
+        robot = read_robot(os.path.join(scenes, scene, "scene.xml"))
+        chain = Chain(robot)
+        rng = np.random.default_rng(sum(map(ord, tag)))
+        err = self_check(chain, rng)
+        samples = [sample(robot, chain, rng, eq, gentle=bool(i % 2)) for i in range(n_samples)]
+        out["models"][tag] = {"scene": scene, "nv": chain.nv, "dof_names": [j["name"] for j in chain.dofs], "jacobian_self_check": err,
+                              "frictionloss": [float(j["frictionloss"]) for j in chain.dofs], "samples": samples}
+        print(tag, "nv", chain.nv, "jacobian check", err)
+    path = os.path.join(ROOT, "tests", "golden", "authored_scene_dynamics.json")
+    json.dump(out, open(path, "w"), indent=0)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+
+    if "--authored" in sys.argv:
+        main_authored()
+    else:
+        main()

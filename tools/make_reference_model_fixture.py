@@ -64,6 +64,7 @@ def read_robot(path):
         for j in elem.findall("joint"):
             a = d.resolve("joint", j, cc)
             b["joints"].append({"name": a.get("name"), "type": a.get("type", "hinge"), "axis": floats(a.get("axis")) or [0, 0, 1], "range": floats(a.get("range")),
+                                "pos": floats(a.get("pos")),
                                 "armature": float(a.get("armature", 0)), "damping": float(a.get("damping", 0)), "frictionloss": float(a.get("frictionloss", 0)),
                                 "actuatorfrcrange": floats(a.get("actuatorfrcrange")), "actuatorgravcomp": a.get("actuatorgravcomp", "false") == "true"})
         for g in elem.findall("geom"):
