@@ -201,6 +201,11 @@ def main() -> None:
     dist = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: RCCL's bootstrap (ncclGetUniqueId / ncclCommInitRank) and gloo over the loopback interface -- the
+            # container's hostname may not resolve, and the interface RCCL would pick by default may not be routable between ranks
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         import torch
         import torch.distributed as dist
 
