@@ -31,6 +31,7 @@ def _exchange_worker(rank, world, uid_q, out_q, n_steps):
     """One rank of the slot protocol: step, post slot t & 1, keep stepping into the other slot, read the gathered block two steps
     later (the overlap bench.py relies on).  Every rank's rows must be that rank's observations, in rank order."""
     try:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap over the loopback interface
         from rcs_amd.envs import make_vec_env
         from rcs_amd.envs.sharding import RcclObservationExchange, comm_unique_id
 
@@ -91,7 +92,7 @@ def test_rccl_exchange_slot_protocol_one_rank_per_gpu():
     ndev = int(_lib.load().rcsh_device_count())
     if ndev < 2:
         pytest.skip("one GPU: RCCL refuses two ranks on one device (covered over gloo in tests/test_distributed_cpu.py)")
-    _run_exchange(min(ndev, 8))
+    _run_exchange(2)  # (two ranks exercise everything the protocol has; the full node is the driver's scaling run)
 
 
 def test_mixed_robot_shards_of_baseline_config_4():
