@@ -39,3 +39,13 @@ for seed in (1, 2):
     print("grasp", seed, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items() if not hasattr(v, "shape")})
 rep = pu.run_rate_driven_camera_parity(n_envs=8, seed=9)
 print("rate-driven cameras", {k: v for k, v in rep.items() if k != "debug"})
+# ---- round 3: the cube thrown at the base over more seeds (support ties broken by rule), the xArm7 pick-up over more seeds,
+# the first-principles vectors through the kernel
+for seed in (5, 11, 12, 13, 14, 15, 21, 22):
+    rep = pu.run_cube_against_base_parity(seed=seed)
+    print("cube vs base seed", seed, {"worst_env_pos_err": f"{rep['env_pos_err'].max():.2e}", "max_abs_quat": f"{rep['max_abs_quat']:.2e}", "base_contact_envs": rep["base_contact_envs"], "max_ncon": rep["max_ncon"]})
+for seed in (0, 1, 2, 3):
+    rep = pu.run_xarm7_pick_parity(n_envs=6, seed=seed)
+    print("xarm7 pick seed", seed, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items() if k != "stages"},
+          "lifted z", [round(float(z), 4) for z in rep["stages"]["held"]["box_z"]])
+print("elapsed", time.time() - t0 if "t0" in dir() else "")
