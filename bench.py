@@ -444,7 +444,7 @@ def main() -> None:
         substeps_per_launch = mean_sub * env.n_envs
         traffic = None
         tj_extra = {}
-        tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
         headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
         if os.path.exists(tpath) and headline:  # the PMC passes profiled exactly this workload (profiles/run_profile.sh)
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
@@ -493,7 +493,7 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "rocprofv3 FETCH_SIZE x 2 (gfx950: counts half the bytes of this access pattern, calibrated in profiles/r2_hbm_calib) + WRITE_SIZE, separate PMC passes (profiles/r2_traffic.json)" if traffic else None,
+                "traffic_source": "rocprofv3 FETCH_SIZE x 2 (gfx950: counts half the bytes of this access pattern, calibrated in profiles/r2_hbm_calib) + WRITE_SIZE, separate PMC passes (profiles/r3_traffic.json, profiles/r3_v1)" if traffic else None,
                 "kernel": "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
                           + (" + free box" if args.task != "none" or args.robot in ("xarm7_box", "xarm7_pick") else ""),
                 "kernel_ms_avg": kernel_ms,
