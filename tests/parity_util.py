@@ -776,6 +776,84 @@ def run_grasp_parity(n_envs=4, seed=0, swing_up=True):
 XARM7_PICK_SCENE = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes", "xarm7_pick_world", "scene.xml")
 
 
+def run_xarm7_links_on_the_floor_parity(n_envs=3, seed=0, substeps=900, width=48, height=36):
+    """scenes/xarm7_pick_world: the arm's OWN link hulls (the reference's link<i>_convex collision meshes, xarm7.xml:103-156)
+    against the floor.  The shoulder joint is sent far enough forward that the forearm links come down on the floor plane
+    (hull-plane contacts on arm links, resolved in the coupled solve together with the arm's dry-friction rows), then the
+    fixed camera's frame is compared with the numpy ray caster on the oracle's frames -- the arm is in the picture."""
+    from rcs_amd import render
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import xarm7_pick_sim_gripper_cfg, xarm7_pick_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    import rcs_oracle as O
+    import rcs_render_oracle as RO
+    from rcs_env_oracle import XARM7_PICK
+
+    cfg = xarm7_pick_sim_robot_cfg()
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
+    if KERNEL != "auto":
+        simu.set_kernel(KERNEL)
+    robot = S.SimRobot(simu, None, cfg)
+    S.SimGripper(simu, xarm7_pick_sim_gripper_cfg())
+    cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", frame_rate=0, resolution_width=width, resolution_height=height)},
+                      physical_units=True, render_on_demand=True)
+    cm = compile_mjcf(XARM7_PICK_SCENE)
+    R = XARM7_PICK
+    osims = [O.Sim(cm, R["joints"], R["actuators"], R["site"], R["base"], R["q_home"], O.Pose(translation=np.array([0.0, 0.0, 0.1034])),
+                   R["gripper_joint"], R["gripper_actuator"], arm_collision_geoms=[], gripper_cfg=R["gripper_cfg"]) for _ in range(n_envs)]
+    assert osims[0].model.resolve_contacts == 1 and simu.resolve_robot_contacts
+    rng = np.random.default_rng(seed)
+    simu.reset(); robot.reset()
+    for o in osims:
+        o.reset(); o.robot_reset()
+    # shoulder forward and down (joint2 range: -2.059 .. 2.0944), elbow bent so that the forearm points at the floor, the wrist folded
+    # back so that the hand stays clear: links 5 and 6 are what comes down; turned away from the cube
+    tgt = np.tile(np.array([0.0, 2.05, 0.0, 1.2, 0.0, 3.0, 0.0]), (n_envs, 1))
+    tgt[:, 0] = rng.uniform(0.9, 1.3, n_envs)
+    tgt[:, 3] += rng.uniform(-0.1, 0.1, n_envs)
+    tgt[:, 5] += rng.uniform(-0.1, 0.1, n_envs)
+    robot.set_joint_position(tgt)
+    for e, o in enumerate(osims):
+        o.set_joint_position(tgt[e])
+    rep = {"max_abs_qpos": 0.0, "max_abs_qvel": 0.0, "max_abs_box": 0.0, "max_ncon": 0, "coupled_substeps": 0, "arm_link_contacts": 0,
+           "max_links_in_contact": 0, "pixels": 0, "mismatched_mm": 0, "arm_pixels": 0}
+    gb = np.asarray(cm.arrays["geom_bodyid"])
+    hand_body = cm.name2id("body", "hand")
+    done = 0
+    while done < substeps:
+        k = min(150, substeps - done)
+        simu.step(k)
+        done += k
+        q, v, bq = simu.qpos, simu.qvel, simu.free_joint_qpos("box_joint")
+        for e, o in enumerate(osims):
+            for _ in range(k):
+                o.step(1)
+                d = o.s.d
+                rep["max_ncon"] = max(rep["max_ncon"], int(d.ncon))
+                rep["coupled_substeps"] += int(bool(d.coupled))
+                # contacts whose robot geom rides on an arm link (a body before the hand in the tree)
+                bodies = {int(gb[g]) for c in range(int(d.ncon)) for g in d.contact_geom[c] if g < cm.ngeom} - {0}  # (ids past the model's: the free cube)
+                rep["arm_link_contacts"] += sum(1 for b in bodies if b < hand_body)
+                rep["max_links_in_contact"] = max(rep["max_links_in_contact"], len(bodies))
+            rep["max_abs_qpos"] = max(rep["max_abs_qpos"], float(np.abs(q[e] - np.asarray(o.qpos)).max()))
+            rep["max_abs_qvel"] = max(rep["max_abs_qvel"], float(np.abs(v[e] - np.asarray(o.qvel)).max()))
+            rep["max_abs_box"] = max(rep["max_abs_box"], float(np.abs(bq[e] - o.box_qpos).max()))
+    rep["qpos"] = simu.qpos[:, :7].copy()
+    rep["target"] = tgt
+    frames = cs.get_latest_frames()
+    data = frames.frames["side"].camera.depth.data
+    link, pos, rot, fovy = render.camera_in_link(cm, "side_cam")
+    for e, o in enumerate(osims):
+        dgl, mm, cR, cp, orgb = RO.render_depth(cs._scene, (link, pos, rot, fovy, width, height), RO.oracle_frames(o, cm), colour=True)
+        diff = np.abs(data[e, ..., 0].astype(np.int64) - mm.astype(np.int64))
+        rep["pixels"] += diff.size
+        rep["mismatched_mm"] += int((diff != 0).sum())
+        rep["arm_pixels"] += int((orgb.min(axis=-1) > 150).sum())  # the white hulls
+    simu.close()
+    return rep
+
+
 def run_xarm7_pick_parity(n_envs=4, seed=0, stages=("above", "down", "closed", "lifted", "held", "released")):
     """BASELINE configs[3] as written: the xArm7 (dry joint friction on every arm joint) with a two-finger gripper picks the
     cube up -- move over it, descend, close the fingers (pads against the cube: box-box contacts; the friction-dof rows are

@@ -1313,6 +1313,21 @@ def test_xarm7_picks_the_cube_up_matches_oracle(kernel):
     assert (st["released"]["box_z"] < 0.06).all() and (st["held"]["width"] > 0.3).all(), st  # dropped again; the fingers stopped on the cube
 
 
+def test_xarm7_arm_links_rest_on_the_floor_and_show_in_the_frame(kernel):
+    """scenes/xarm7_pick_world carries the reference's convex collision mesh on every arm link (xarm7.xml:103-156): with the
+    shoulder sent forward the forearm comes down on the floor -- hull-plane contacts on ARM links, resolved in the coupled solve
+    next to the arm's dry-friction rows -- kernel vs oracle <= 1e-9 on the joints; the arm comes to rest short of its target,
+    held up by the floor; and the fixed camera's depth frame, arm included, equals the numpy ray caster's on the oracle's frames
+    (silhouette pixels aside)."""
+    from parity_util import run_xarm7_links_on_the_floor_parity
+
+    rep = run_xarm7_links_on_the_floor_parity(n_envs=3, seed=0)
+    assert rep["max_abs_qpos"] < TOL and rep["max_abs_qvel"] < VTOL and rep["max_abs_box"] < 1e-8, rep
+    assert rep["coupled_substeps"] > 3 * 300 and rep["arm_link_contacts"] > 3 * 300 and rep["max_links_in_contact"] <= 4, rep
+    assert (np.abs(rep["qpos"] - rep["target"]).max(axis=1) > 0.05).all(), rep  # the floor is in the way
+    assert rep["mismatched_mm"] <= 2e-3 * rep["pixels"] and rep["arm_pixels"] > 3 * 40, rep
+
+
 def test_render_schedule_grows_with_the_launch_and_rejects_a_second_set(kernel):
     """Advisor, round 2: the render schedule's capacity was frozen at construction (from max_convergence_steps at that moment) and a
     longer launch -- Sim.step(k) with a large k, a raised cap -- failed after the state had advanced; a second rate-driven
