@@ -372,6 +372,13 @@ typedef struct rcsh_camera_desc {
 } rcsh_camera_desc;
 int rcsh_sim_set_render_scene(rcsh_sim* sim, const rcsh_render_scene_desc* scene);
 int rcsh_sim_add_camera(rcsh_sim* sim, const rcsh_camera_desc* cam, int32_t* cam_id);
+/* Host only (no device needed): the edges of the convex polytope { x : n_i . x <= d_i } that `planes` ([nplanes][4]) describe --
+ * what rcsh_sim_set_render_scene works out for every hull so that the ray caster can find the hull's outline as the camera
+ * sees it (a ray hits the hull exactly when it passes inside the outline; its entry depth comes from the planes facing the
+ * camera alone).  edge_planes: [capacity][2] the two planes meeting in the edge, edge_verts: [capacity][6] its end points (both may
+ * be NULL to ask for the count), centre: [3] a point inside.  *nedges = 0: the planes bound no polytope the routine vouches
+ * for (Euler's formula failed on what it found); such a hull is drawn by walking all its planes. */
+int rcsh_hull_edges(const double* planes, int32_t nplanes, int32_t capacity, int32_t* edge_planes, double* edge_verts, int32_t* nedges, double* centre);
 /* One image per environment.  depth_gl: [N][H][W] f32 in [0, 1], rows bottom-up, what mjr_readPixels returns;
  * depth_mm: [N][H][W] u16, rows top-down, millimetres: DataFrame.data of SimCameraSet(physical_units=True);
  * cam_pose: [N][12] mjData.cam_xmat (9) + cam_xpos (3).  Each may be NULL.  _dev: device pointers, enqueued on the

@@ -590,6 +590,88 @@ std::string build_contact_table(const HostModel& h, const DevModel& m, int plane
   return "";
 }
 
+bool build_hull_edges(const double* planes, int np, std::vector<HullEdge>& edges, double centre[3]) {
+  edges.clear();
+  centre[0] = centre[1] = centre[2] = 0;
+  if (np < 4) return false;
+  constexpr double kOn = 1e-8, kMerge = 1e-7;
+  // vertices: intersection points of three planes that violate no other plane
+  std::vector<double> V;
+  for (int i = 0; i < np; ++i)
+    for (int j = i + 1; j < np; ++j) {
+      const double* a = planes + 4 * i;
+      const double* b = planes + 4 * j;
+      const double ab[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+      if (ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2] < 1e-12) continue;  // parallel
+      for (int k = j + 1; k < np; ++k) {
+        const double* c = planes + 4 * k;
+        const double det = ab[0] * c[0] + ab[1] * c[1] + ab[2] * c[2];
+        if (std::fabs(det) < 1e-9) continue;
+        // x = (d_a (b x c) + d_b (c x a) + d_c (a x b)) / det
+        const double bc[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+        const double ca[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
+        double x[3];
+        for (int t = 0; t < 3; ++t) x[t] = (a[3] * bc[t] + b[3] * ca[t] + c[3] * ab[t]) / det;
+        bool inside = true;
+        for (int m = 0; m < np && inside; ++m) {
+          const double* q = planes + 4 * m;
+          inside = q[0] * x[0] + q[1] * x[1] + q[2] * x[2] - q[3] <= kOn;
+        }
+        if (!inside) continue;
+        bool seen = false;
+        for (size_t v = 0; v < V.size() && !seen; v += 3) {
+          const double d[3] = {V[v] - x[0], V[v + 1] - x[1], V[v + 2] - x[2]};
+          seen = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < kMerge * kMerge;
+        }
+        if (!seen) V.insert(V.end(), x, x + 3);
+      }
+    }
+  const int nv = (int)V.size() / 3;
+  if (nv < 4) return false;
+  // which vertices lie on which plane; a plane with fewer than three of them is no face
+  std::vector<std::vector<int>> on(np);
+  for (int i = 0; i < np; ++i) {
+    const double* q = planes + 4 * i;
+    for (int v = 0; v < nv; ++v)
+      if (std::fabs(q[0] * V[3 * v] + q[1] * V[3 * v + 1] + q[2] * V[3 * v + 2] - q[3]) < kOn) on[i].push_back(v);
+  }
+  int nf = 0;
+  for (int i = 0; i < np; ++i) nf += on[i].size() >= 3;
+  for (int i = 0; i < np; ++i) {
+    if (on[i].size() < 3) continue;
+    for (int j = i + 1; j < np; ++j) {
+      if (on[j].size() < 3) continue;
+      // the vertices both faces share (sorted lists): two or more -- an edge, from the first to the last of them along it
+      const double* a = planes + 4 * i;
+      const double* b = planes + 4 * j;
+      const double dir[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+      int lo = -1, hi = -1, cnt = 0;
+      double slo = 0, shi = 0;
+      size_t p = 0, q = 0;
+      while (p < on[i].size() && q < on[j].size()) {
+        if (on[i][p] < on[j][q]) ++p;
+        else if (on[i][p] > on[j][q]) ++q;
+        else {
+          const int v = on[i][p];
+          const double sv = dir[0] * V[3 * v] + dir[1] * V[3 * v + 1] + dir[2] * V[3 * v + 2];
+          if (cnt == 0 || sv < slo) { slo = sv; lo = v; }
+          if (cnt == 0 || sv > shi) { shi = sv; hi = v; }
+          ++cnt; ++p; ++q;
+        }
+      }
+      if (cnt < 2 || lo == hi) continue;
+      HullEdge e;
+      e.a = i; e.b = j;
+      for (int t = 0; t < 3; ++t) { e.v1[t] = V[3 * lo + t]; e.v2[t] = V[3 * hi + t]; }
+      edges.push_back(e);
+    }
+  }
+  if (nv - (int)edges.size() + nf != 2) { edges.clear(); return false; }
+  for (int v = 0; v < nv; ++v)
+    for (int t = 0; t < 3; ++t) centre[t] += V[3 * v + t] / nv;
+  return true;
+}
+
 std::string attach_robot_frames(const HostModel& h, DevModel& m, int site, int base_body) {
   std::vector<int> owner;
   std::vector<Xf> rel;

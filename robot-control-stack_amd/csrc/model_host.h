@@ -54,6 +54,17 @@ std::string build_collision_points(const HostModel& h, CollisionPoints& out);
 std::string build_contact_table(const HostModel& h, const DevModel& m, int plane_geom, std::vector<ContactGeom>& geoms, std::vector<double>& verts,
                                 std::string& overflow /* geoms left out of the table because of a capacity limit: why (empty: none) */);
 
+// Edges of the convex polytope { x : n_i . x <= d_i } a drawn hull is given as (render.h: the ray caster finds a hull's outline
+// as seen from the camera among them).  Each edge: the two planes that meet in it and its end points.  `centre`: a point
+// inside (the mean of the polytope's vertices).  false: the planes do not bound a polytope this routine can vouch for
+// (fewer than 4 faces, unbounded, or Euler's formula V - E + F = 2 fails on what it found) -- the caller draws the hull
+// without the outline then.
+struct HullEdge {
+  int32_t a, b;
+  double v1[3], v2[3];
+};
+bool build_hull_edges(const double* planes, int nplanes, std::vector<HullEdge>& edges, double centre[3]);
+
 // Calls fn(Topo<NARM, GRIP>{}) for the compiled archetype matching (narm, grip); false if none does.
 template <class F>
 bool dispatch_topology(int narm, bool grip, F&& fn) {

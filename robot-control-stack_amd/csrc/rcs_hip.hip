@@ -83,6 +83,9 @@ struct rcsh_sim {
   RenderShape* d_rshapes = nullptr;
   double* d_rplanes = nullptr;
   RenderColour* d_rcolours = nullptr;
+  int32_t* d_redge_planes = nullptr;  // the outline method of the ray caster (render.h: k_hull_views)
+  double* d_redge_verts = nullptr;
+  double* d_rviews = nullptr;
   RendCfg rend{};                    // rate-driven cameras (rcsh_sim_set_render_schedule)
   int rend_cam_id[kMaxRateCams] = {0, 0, 0, 0};
   int64_t rend_dropped = 0;          // records that did not fit the schedule's capacity (rcsh_render_pending counts them)
@@ -657,6 +660,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs);
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_rcolours); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
+  hipFree(s->d_redge_planes); hipFree(s->d_redge_verts); hipFree(s->d_rviews);
   hipFree(s->d_stage); hipFree(s->d_stage2); hipFree(s->d_bytes); hipFree(s->d_mask); hipFree(s->d_ints); hipFree(s->d_floats);
   if (s->own_stream) hipStreamDestroy(s->own_stream);
   delete s;
@@ -1398,16 +1402,51 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
     for (int k = 0; k < 9; ++k) r.rot[k] = d->rot[9 * i + k];
     for (int k = 0; k < 4; ++k) r.sphere[k] = d->sphere[4 * i + k];
   }
+  // The outline method (render.h: k_hull_views): each hull's polytope edges, worked out here from its planes, and room for one view
+  // record per environment and hull.  RCSH_RENDER_OUTLINE=0 keeps the plane-by-plane walk (measurements); a hull whose planes
+  // do not give a clean polytope is walked plane by plane as well.
+  std::vector<int32_t> edge_planes;
+  std::vector<double> edge_verts;
+  int64_t view_stride = 0;
+  {
+    const char* env = std::getenv("RCSH_RENDER_OUTLINE");
+    const bool outline = !(env && env[0] == '0');
+    for (int i = 0; i < d->nshape && outline; ++i) {
+      RenderShape& r = sh[i];
+      if (r.shape != kShapeHull) continue;
+      std::vector<HullEdge> edges;
+      if (!build_hull_edges(d->planes + 4 * (size_t)r.plane_adr, r.plane_num, edges, r.centre)) continue;
+      r.edge_adr = (int32_t)(edge_planes.size() / 2);
+      r.edge_num = (int32_t)edges.size();
+      r.view_adr = view_stride;
+      view_stride += kViewHeaderDoubles + 4 * (int64_t)(r.plane_num + kMaxOutline);
+      for (const HullEdge& e : edges) {
+        edge_planes.push_back(e.a); edge_planes.push_back(e.b);
+        edge_verts.insert(edge_verts.end(), e.v1, e.v1 + 3);
+        edge_verts.insert(edge_verts.end(), e.v2, e.v2 + 3);
+      }
+    }
+  }
   HIP_TRY(hipSetDevice(s->device));
   const bool first_scene = s->d_frames == nullptr;
   hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_rcolours);
+  hipFree(s->d_redge_planes); hipFree(s->d_redge_verts); hipFree(s->d_rviews);
   s->d_rshapes = nullptr; s->d_rplanes = nullptr; s->d_frames = nullptr; s->d_wframes = nullptr; s->d_rcolours = nullptr;
+  s->d_redge_planes = nullptr; s->d_redge_verts = nullptr; s->d_rviews = nullptr;
   s->rscene.colours = nullptr;
+  s->rscene.edge_planes = nullptr; s->rscene.edge_verts = nullptr; s->rscene.views = nullptr; s->rscene.view_stride = 0;
   const int np = d->nplanes > 0 ? d->nplanes : 1;
   HIP_TRY(hipMalloc(&s->d_rshapes, sizeof(RenderShape) * d->nshape));
   HIP_TRY(hipMalloc(&s->d_rplanes, sizeof(double) * 4 * np));
   HIP_TRY(hipMalloc(&s->d_frames, sizeof(double) * 12 * (size_t)(s->nl + 1) * s->n));
   HIP_TRY(hipMalloc(&s->d_wframes, sizeof(double) * kShapeFrameDoubles * (size_t)(d->nshape + 1) * s->n));
+  if (view_stride > 0) {
+    HIP_TRY(hipMalloc(&s->d_redge_planes, sizeof(int32_t) * edge_planes.size()));
+    HIP_TRY(hipMalloc(&s->d_redge_verts, sizeof(double) * edge_verts.size()));
+    HIP_TRY(hipMalloc(&s->d_rviews, sizeof(double) * (size_t)view_stride * s->n));
+    HIP_TRY(hipMemcpyAsync(s->d_redge_planes, edge_planes.data(), sizeof(int32_t) * edge_planes.size(), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_redge_verts, edge_verts.data(), sizeof(double) * edge_verts.size(), hipMemcpyHostToDevice, s->stream));
+  }
   HIP_TRY(hipMemcpyAsync(s->d_rshapes, sh.data(), sizeof(RenderShape) * d->nshape, hipMemcpyHostToDevice, s->stream));
   if (d->nplanes > 0) HIP_TRY(hipMemcpyAsync(s->d_rplanes, d->planes, sizeof(double) * 4 * d->nplanes, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1426,6 +1465,22 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
   s->rscene.nshape = d->nshape; s->rscene.nframes = s->nl + 1;
   s->rscene.znear = d->znear; s->rscene.zfar = d->zfar;
   s->rscene.shapes = s->d_rshapes; s->rscene.planes = s->d_rplanes;
+  s->rscene.edge_planes = s->d_redge_planes; s->rscene.edge_verts = s->d_redge_verts; s->rscene.views = s->d_rviews; s->rscene.view_stride = view_stride;
+  return RCSH_OK;
+}
+
+int rcsh_hull_edges(const double* planes, int32_t nplanes, int32_t capacity, int32_t* edge_planes, double* edge_verts, int32_t* nedges, double* centre) {
+  if (!planes || !nedges || !centre || nplanes < 0 || capacity < 0) return fail(RCSH_ERR_ARG, "hull edges: null argument");
+  std::vector<HullEdge> edges;
+  *nedges = 0;
+  if (!build_hull_edges(planes, nplanes, edges, centre)) return RCSH_OK;  // (no clean polytope: zero edges, the hull is walked plane by plane)
+  *nedges = (int32_t)edges.size();
+  if (!edge_planes || !edge_verts) return RCSH_OK;
+  if ((int32_t)edges.size() > capacity) return fail(RCSH_ERR_ARG, "hull edges: capacity too small");
+  for (size_t k = 0; k < edges.size(); ++k) {
+    edge_planes[2 * k] = edges[k].a; edge_planes[2 * k + 1] = edges[k].b;
+    for (int t = 0; t < 3; ++t) { edge_verts[6 * k + t] = edges[k].v1[t]; edge_verts[6 * k + 3 + t] = edges[k].v2[t]; }
+  }
   return RCSH_OK;
 }
 
@@ -1595,8 +1650,10 @@ int rcsh_camera_render_rgb_dev(rcsh_sim* s, int32_t cam_id, uint8_t* rgb, float*
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_link_frames launch: ") + hipGetErrorString(err));
   hipLaunchKernelGGL(k_shape_frames, dim3(grid_for(s->n * (s->rscene.nshape + 1))), dim3(kBlock), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
                      s->d_wframes);
+  if (s->rscene.views)
+    hipLaunchKernelGGL(k_hull_views, dim3((unsigned)s->n * (unsigned)s->rscene.nshape), dim3(64), 0, s->stream, s->rscene, s->d_wframes, s->n);
   const int blocks_per_env = ((cam.width + 15) / 16) * ((cam.height + 15) / 16);
-  const dim3 grid((unsigned)blocks_per_env * (unsigned)s->n);
+  const dim3 grid((unsigned)(((size_t)blocks_per_env * (size_t)s->n + 7) / 8 * 8));  // (a multiple of 8: k_render_depth numbers its workgroups per XCD)
   if (rgb)
     hipLaunchKernelGGL(k_render_depth<true>, grid, dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n, depth_gl, depth_mm, cam_pose, rgb);
   else

@@ -35,6 +35,11 @@ struct RenderShape {
   double pos[3], rot[9];  // shape frame in its link's frame
   double size[3];
   double sphere[4];       // bounding sphere: centre (shape frame), radius (< 0: unbounded)
+  // hulls, the outline method (k_hull_views): the polytope's edges [edge_adr, edge_adr + edge_num) of RenderScene::edge_*,
+  // a point inside it, and where this hull's view record starts within an environment's block of RenderScene::views
+  int32_t edge_adr, edge_num;
+  int64_t view_adr;       // in doubles
+  double centre[3];
 };
 struct RenderCam {
   int32_t link, width, height, pad;
@@ -57,7 +62,16 @@ struct RenderScene {
   const double* planes;  // [.][4] n . x <= d
   const RenderColour* colours;  // [nshape], null until rcsh_sim_set_render_colours
   RenderShade shade;
+  // the outline method (null / 0: every hull is walked plane by plane)
+  const int32_t* edge_planes;  // [.][2] the two planes (indices within the hull) that meet in the edge
+  const double* edge_verts;    // [.][6] its end points, shape frame
+  double* views;               // [n][view_stride] per environment and hull: what k_hull_views found for the camera being rendered
+  int64_t view_stride;         // in doubles
 };
+// A hull's view record: header (int32 nfront, int32 noutline (-1: not usable, walk the planes), 16 bytes unused), then room for
+// plane_num rows (nx, ny, nz, no) of the planes facing the camera, then kMaxOutline rows (mx, my, mz, 0) of the outline.
+constexpr int kMaxOutline = 64;
+constexpr int kViewHeaderDoubles = 4;
 
 #if defined(__HIP__)
 
@@ -154,6 +168,81 @@ __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* fram
   for (int k = 0; k < 3; ++k) out[9 + k] = p[k];
 }
 
+// The outline method.  All rays of a camera start at one point o.  Seen from o a convex polytope has FRONT faces (o outside
+// their plane: n . o > d) and back faces; a ray can only ENTER through a front face, and it hits the polytope at all exactly
+// when its direction lies inside the cone from o over the polytope's outline -- the closed chain of edges where a front face
+// meets a back face.  So per (environment, camera, hull), once: classify the ~110 face planes (keeping d - n . o, which every
+// ray needs and which is the same for all of them), find the ~40 outline edges among the polytope's ~330, and turn each into
+// the plane through o that contains it, normal pointing at the hull.  A ray then costs one dot product per outline edge (inside
+// all of them = hit) and one per FRONT plane (the entry depth is the largest no / nd) -- ~85 dot products instead of the two per
+// plane, ~220, of walking every face plane for both ends of the ray's interval.  What a ray sees is the same set of points;
+// rays that graze the outline may fall on the other side of it by round-off (as between any two ways of writing the test).
+// One wavefront per (environment, hull); lanes take planes, then edges; ballots compact the survivors into the view record.
+__device__ __forceinline__ double plane_no(const double* q, const double* lo) {
+  return fma(-q[2], lo[2], fma(-q[1], lo[1], fma(-q[0], lo[0], q[3])));  // d - n . o, one rounding order everywhere it is needed
+}
+__global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, const double* wf, int n) {
+  const int e = blockIdx.x / sc.nshape, g = blockIdx.x % sc.nshape;
+  if (e >= n) return;
+  const RenderShape& sh = sc.shapes[g];
+  if (sh.shape != kShapeHull || sh.edge_num <= 0) return;
+  const int lane = threadIdx.x;
+  const double* w = wf + ((size_t)e * (sc.nshape + 1) + g) * kShapeFrameDoubles;           // the hull's frame: R (9) p (3)
+  const double* cw = wf + ((size_t)e * (sc.nshape + 1) + sc.nshape) * kShapeFrameDoubles;  // the camera's
+  const double om[3] = {cw[9] - w[9], cw[10] - w[10], cw[11] - w[11]};
+  const double lo[3] = {w[0] * om[0] + w[3] * om[1] + w[6] * om[2], w[1] * om[0] + w[4] * om[1] + w[7] * om[2], w[2] * om[0] + w[5] * om[1] + w[8] * om[2]};
+  double* out = sc.views + (size_t)e * sc.view_stride + sh.view_adr;
+  const double* planes = sc.planes + 4 * (size_t)sh.plane_adr;
+  const uint64_t below = (1ull << lane) - 1ull;
+  int nfront = 0;
+  for (int base = 0; base < sh.plane_num; base += 64) {
+    const int i = base + lane;
+    bool front = false;
+    double q[4] = {0, 0, 0, 0}, no = 0;
+    if (i < sh.plane_num) {
+      for (int k = 0; k < 4; ++k) q[k] = planes[4 * i + k];
+      no = plane_no(q, lo);
+      front = no < 0;
+    }
+    const uint64_t m = __ballot(front);
+    if (front) {
+      double* r = out + kViewHeaderDoubles + 4 * (size_t)(nfront + __popcll(m & below));
+      r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = no;
+    }
+    nfront += __popcll(m);
+  }
+  double* outline = out + kViewHeaderDoubles + 4 * (size_t)sh.plane_num;
+  const double ci[3] = {sh.centre[0] - lo[0], sh.centre[1] - lo[1], sh.centre[2] - lo[2]};
+  int nout = 0;
+  for (int base = 0; base < sh.edge_num; base += 64) {
+    const int k = base + lane;
+    bool sil = false;
+    double mm[3] = {0, 0, 0};
+    if (k < sh.edge_num) {
+      const int32_t* ep = sc.edge_planes + 2 * (size_t)(sh.edge_adr + k);
+      sil = (plane_no(planes + 4 * ep[0], lo) < 0) != (plane_no(planes + 4 * ep[1], lo) < 0);
+      if (sil) {
+        const double* ev = sc.edge_verts + 6 * (size_t)(sh.edge_adr + k);
+        const double a[3] = {ev[0] - lo[0], ev[1] - lo[1], ev[2] - lo[2]}, b[3] = {ev[3] - lo[0], ev[4] - lo[1], ev[5] - lo[2]};
+        mm[0] = a[1] * b[2] - a[2] * b[1]; mm[1] = a[2] * b[0] - a[0] * b[2]; mm[2] = a[0] * b[1] - a[1] * b[0];
+        if (mm[0] * ci[0] + mm[1] * ci[1] + mm[2] * ci[2] < 0) { mm[0] = -mm[0]; mm[1] = -mm[1]; mm[2] = -mm[2]; }
+      }
+    }
+    const uint64_t m = __ballot(sil);
+    const int r = nout + __popcll(m & below);
+    if (sil && r < kMaxOutline) {
+      double* o = outline + 4 * (size_t)r;
+      o[0] = mm[0]; o[1] = mm[1]; o[2] = mm[2]; o[3] = 0;
+    }
+    nout += __popcll(m);
+  }
+  if (lane == 0) {
+    int32_t* hdr = (int32_t*)out;
+    hdr[0] = nfront;
+    hdr[1] = nout <= kMaxOutline ? nout : -1;
+  }
+}
+
 // depth_gl: [n][H][W] float32 in [0, 1], rows bottom-up (mjr_readPixels); depth_mm: [n][H][W] uint16, rows top-down,
 // millimetres (SimCameraSet with physical_units); cam_pose: [n][12] world rotation (9) and position (3) of the camera
 // (mjData.cam_xmat / cam_xpos).  Any of the three may be null.
@@ -169,8 +258,18 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   // together, so they mostly agree on which shapes they have to look at
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
   const int blocks_per_env = tiles_x * tiles_y;
-  const int e = blockIdx.x / blocks_per_env;
-  const int tile = blockIdx.x % blocks_per_env;
+  // Workgroups go to the chip's 8 XCDs round robin by their index.  The tiles of one environment read the same shape frames and
+  // hull views; numbered so that they follow each other on ONE XCD they find them in that XCD's L2, instead of all eight L2s
+  // fetching every environment's rows.  (The grid is rounded up to a multiple of 8.)
+  const int nblocks = n * blocks_per_env, per_xcd = (nblocks + 7) / 8;
+#ifdef RCSH_NO_XCD_REMAP
+  const int block = (int)blockIdx.x;
+#else
+  const int block = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
+#endif
+  if (block >= nblocks) return;
+  const int e = block / blocks_per_env;
+  const int tile = block % blocks_per_env;
   const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
   const int col = (tile % tiles_x) * 16 + (wave % 2) * 8 + lane % 8;
   const int row = (tile / tiles_x) * 16 + (wave / 2) * 8 + lane / 8;  // row 0 = bottom of the image (OpenGL window coordinates)
@@ -258,6 +357,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   bool hit = false;
   // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
   int hit_g = -1, hit_face = 0;
+  bool hit_outline = false;  // hit_face counts the hull's FRONT planes (its view record), not its planes
   for (int vi = 0; vi < nvisit; ++vi) {
     // (the visit list is the wavefront's: saying so lets the shape's constants and its ~100 face planes come through scalar loads)
     const int g = __builtin_amdgcn_readfirstlane((int)visit[wave][vi]);
@@ -303,12 +403,56 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       }
       if (sh.shape == kShapeBox) { t0 = b0; t1 = b1; }
     }
-    if (ok && sh.shape == kShapeHull) {
+    bool by_outline = false;
+    typedef const double __attribute__((address_space(4))) kdouble;
+    if (ok && sh.shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
+      // the outline method (k_hull_views): this environment's record of the hull as the camera sees it.  The address is the
+      // wavefront's (e is the workgroup's, g the wavefront's): header and rows come through scalar loads.
+      kdouble* vw = (kdouble*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr);
+      typedef const int32_t __attribute__((address_space(4))) kint;
+      const int nfront = __builtin_amdgcn_readfirstlane(((kint*)vw)[0]), nout = __builtin_amdgcn_readfirstlane(((kint*)vw)[1]);
+      if (nout >= 0) {
+        by_outline = true;
+        kdouble* ol = vw + kViewHeaderDoubles + 4 * (size_t)__builtin_amdgcn_readfirstlane(sh.plane_num);
+        // inside the cone over the outline?  (four rows per round, the tail round repeats the last row)
+        ok = ok && nfront > 0 && nout > 0;
+        for (int k = 0; k < nout && ok; k += 4) {
+          double q4[4][3];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            kdouble* src = ol + 4 * (size_t)(k + j < nout ? k + j : nout - 1);
+            q4[j][0] = src[0]; q4[j][1] = src[1]; q4[j][2] = src[2];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ok = ok && q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2] >= 0;
+        }
+        // entry depth: the largest no / nd over the front planes (nd < 0 on every one of them for a ray inside the cone)
+        kdouble* fr = vw + kViewHeaderDoubles;
+        for (int k = 0; k < nfront && ok; k += 4) {
+          double q4[4][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            kdouble* src = fr + 4 * (size_t)(k + j < nfront ? k + j : nfront - 1);
+            q4[j][0] = src[0]; q4[j][1] = src[1]; q4[j][2] = src[2]; q4[j][3] = src[3];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
+            if (nd < 0 && q4[j][3] < t0 * nd) {  // (the gate of the plane walk below: only a plane that moves t0 pays for the division)
+              const double t = q4[j][3] * fast_rcp(nd);
+              if (COLOR && t > t0) face = k + j < nfront ? k + j : nfront - 1;
+              t0 = t > t0 ? t : t0;
+            }
+          }
+        }
+        ok = ok && t0 <= t1;
+      }
+    }
+    if (ok && sh.shape == kShapeHull && !by_outline) {
       // four planes per round: their loads go out together (a plane a round would wait for L1 every time); the tail
       // round repeats the last plane, which changes nothing
       // (the planes are read through the constant address space: the address is the wavefront's -- g is -- so they arrive by
       // scalar loads, 32 bytes per plane per WAVEFRONT instead of per lane, and feed the multiply-adds from scalar registers)
-      typedef const double __attribute__((address_space(4))) kdouble;
       kdouble* pl = (kdouble*)(sc.planes + 4 * (size_t)sh.plane_adr);
       const int plane_num = __builtin_amdgcn_readfirstlane(sh.plane_num);
       for (int k = 0; k < plane_num && ok; k += 4) {
@@ -339,7 +483,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       }
     }
     // a camera inside a shape sees its inside faces culled (back faces): only entry points count
-    if (ok && t0 > sc.znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; } }
+    if (ok && t0 > sc.znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; hit_outline = by_outline; } }
   }
   const double inv_near = 1.0 / sc.znear, inv_far = 1.0 / sc.zfar;
   const float dgl = hit ? (float)((inv_near - 1.0 / best) / (inv_near - inv_far)) : 1.0f;
@@ -373,7 +517,8 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
         nl[2] = 0;
         nl[hit_face >> 1] = (hit_face & 1) ? 1.0 : -1.0;
       } else if (sh.shape == kShapeHull) {
-        const double* q = sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
+        const double* q = hit_outline ? sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles + 4 * (size_t)hit_face
+                                      : sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
         nl[0] = q[0]; nl[1] = q[1]; nl[2] = q[2];
       }
       double nw[3];

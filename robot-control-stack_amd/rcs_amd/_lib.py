@@ -170,7 +170,7 @@ EXPORTS = (
     "rcsh_sim_set_qvel", "rcsh_sim_add_free_box", "rcsh_sim_set_contact_options", "rcsh_sim_reset_free_box", "rcsh_sim_get_free_qpos", "rcsh_sim_get_free_qvel",
     "rcsh_sim_set_free_qpos", "rcsh_sim_set_free_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
-    "rcsh_sim_set_render_scene", "rcsh_sim_add_camera", "rcsh_camera_render", "rcsh_camera_render_dev",
+    "rcsh_sim_set_render_scene", "rcsh_sim_add_camera", "rcsh_hull_edges", "rcsh_camera_render", "rcsh_camera_render_dev",
     "rcsh_sim_set_render_colours", "rcsh_camera_render_rgb", "rcsh_camera_render_rgb_dev",
     "rcsh_sim_set_render_schedule", "rcsh_render_pending", "rcsh_render_dropped", "rcsh_camera_render_snapshot",
     "rcsh_env_configure_pick_task", "rcsh_env_reset_task", "rcsh_env_step_task", "rcsh_env_reset_task_dev", "rcsh_env_step_task_dev",
@@ -222,6 +222,7 @@ def load() -> C.CDLL:
     for fn in (L.rcsh_sim_set_free_qpos, L.rcsh_sim_set_free_qvel):
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_sim_set_render_scene.argtypes = [C.c_void_p, C.POINTER(RenderSceneDesc)]
+    L.rcsh_hull_edges.argtypes = [_F64P, C.c_int32, C.c_int32, _I32P, _F64P, C.POINTER(C.c_int32), _F64P]
     L.rcsh_sim_add_camera.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(C.c_int32)]
     L.rcsh_camera_render.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_camera_render_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

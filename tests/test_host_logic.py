@@ -618,3 +618,65 @@ def test_compiled_pose_equals_the_host_mirror():
     assert pickle.loads(pickle.dumps(p)).is_close(p, 1e-12, 1e-12) and c.Pose(pose=p).is_close(p)
     r = pickle.loads(pickle.dumps(c.RPY(0.1, 0.2, 0.3)))
     assert (r.roll, r.pitch, r.yaw) == (0.1, 0.2, 0.3) and (r + r).is_close(c.RPY(0.2, 0.4, 0.6)) and "roll" in str(p)
+
+
+def test_hull_edges_and_the_outline_method_against_the_plane_walk():
+    """The ray caster's outline method (csrc/render.h: k_hull_views) rests on the polytope edges the library works out from a
+    hull's face planes (csrc/model.cpp: build_hull_edges, exported host-only as rcsh_hull_edges).  For every drawn hull of the
+    scenes: Euler's formula holds on what it finds, every edge lies on both its planes, and -- restated in numpy -- "inside the
+    cone over the outline, entry depth from the front planes" sees exactly what walking all planes for both ends of the ray's
+    interval sees, for thousands of rays from random eye points."""
+    import ctypes as C
+
+    from rcs_amd import _lib
+
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    scenes = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "scenes")
+    n_hulls = rays = 0
+    for scene in ("fr3_empty_world", "xarm7_pick_world"):
+        hulls = np.load(os.path.join(scenes, scene, "render_hulls.npz"))
+        for name in hulls.files:
+            pl = np.ascontiguousarray(hulls[name], dtype=np.float64)
+            ne, centre = C.c_int32(0), np.zeros(3)
+            _lib.check(L.rcsh_hull_edges(pl.ctypes.data_as(_lib._F64P), len(pl), 0, None, None, C.byref(ne), centre.ctypes.data_as(_lib._F64P)))
+            assert ne.value > len(pl), (scene, name, ne.value)  # a polytope with f faces has at least 3 f / 2 edges
+            ep, ev = np.zeros((ne.value, 2), dtype=np.int32), np.zeros((ne.value, 6))
+            _lib.check(L.rcsh_hull_edges(pl.ctypes.data_as(_lib._F64P), len(pl), ne.value, ep.ctypes.data_as(_lib._I32P), ev.ctypes.data_as(_lib._F64P),
+                                         C.byref(ne), centre.ctypes.data_as(_lib._F64P)))
+            for side in (0, 1):  # both end points on both planes
+                v = ev[:, :3], ev[:, 3:]
+                for w in v:
+                    assert np.abs((pl[ep[:, side], :3] * w).sum(axis=1) - pl[ep[:, side], 3]).max() < 1e-7
+            assert (pl[:, :3] @ centre - pl[:, 3]).max() < -1e-4  # strictly inside
+            # Euler: vertices = distinct end points
+            verts = np.unique(np.round(np.concatenate([ev[:, :3], ev[:, 3:]]) / 1e-6).astype(np.int64), axis=0)
+            faces = len(np.unique(ep))
+            assert len(verts) - ne.value + faces == 2, (scene, name, len(verts), ne.value, faces)
+            r = np.linalg.norm(ev[:, :3] - centre, axis=1).max()
+            for _ in range(6):
+                u = rng.normal(size=3); u /= np.linalg.norm(u)
+                o = centre + u * rng.uniform(1.3 * r, 2.0)
+                D = centre + rng.normal(size=(1500, 3)) * 0.8 * r - o
+                D /= np.abs(D @ u)[:, None]
+                nd, no = D @ pl[:, :3].T, pl[:, 3] - pl[:, :3] @ o
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    t = no / nd
+                t0 = np.maximum(np.where(nd < 0, t, -np.inf).max(axis=1), 0.01)
+                t1 = np.minimum(np.where(nd > 0, t, np.inf).min(axis=1), 50.0)
+                hit_walk = (t0 <= t1) & (t0 > 0.01)
+                front = no < 0
+                sil = front[ep[:, 0]] != front[ep[:, 1]]
+                m = np.cross(ev[sil, :3] - o, ev[sil, 3:] - o)
+                m[m @ (centre - o) < 0] *= -1
+                inside = (D @ m.T >= 0).all(axis=1)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tf = np.where(nd[:, front] < 0, no[front] / nd[:, front], -np.inf)
+                t0o = np.maximum(tf.max(axis=1), 0.01)
+                hit_out = inside & (t0o > 0.01) & (t0o < 50.0)
+                assert 8 <= sil.sum() <= 64, sil.sum()
+                assert (hit_walk != hit_out).sum() <= 1 and np.abs(t0[hit_walk & hit_out] - t0o[hit_walk & hit_out]).max() < 1e-12
+                assert hit_walk.sum() > 100
+                rays += len(D)
+            n_hulls += 1
+    assert n_hulls == 19 and rays > 100000
