@@ -414,32 +414,34 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       if (nout >= 0) {
         by_outline = true;
         kdouble* ol = vw + kViewHeaderDoubles + 4 * (size_t)__builtin_amdgcn_readfirstlane(sh.plane_num);
-        // inside the cone over the outline?  (four rows per round, the tail round repeats the last row)
+        // inside the cone over the outline?  (kRows rows per round -- their scalar loads go out together and the L2's latency is
+        // paid once per round; the tail round repeats the last row, which changes nothing)
+        constexpr int kRows = 4;
         ok = ok && nfront > 0 && nout > 0;
-        for (int k = 0; k < nout && ok; k += 4) {
-          double q4[4][3];
+        for (int k = 0; k < nout && ok; k += kRows) {
+          double q[kRows][3];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < kRows; ++j) {
             kdouble* src = ol + 4 * (size_t)(k + j < nout ? k + j : nout - 1);
-            q4[j][0] = src[0]; q4[j][1] = src[1]; q4[j][2] = src[2];
+            q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2];
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ok = ok && q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2] >= 0;
+          for (int j = 0; j < kRows; ++j) ok = ok && q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2] >= 0;
         }
         // entry depth: the largest no / nd over the front planes (nd < 0 on every one of them for a ray inside the cone)
         kdouble* fr = vw + kViewHeaderDoubles;
-        for (int k = 0; k < nfront && ok; k += 4) {
-          double q4[4][4];
+        for (int k = 0; k < nfront && ok; k += kRows) {
+          double q[kRows][4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < kRows; ++j) {
             kdouble* src = fr + 4 * (size_t)(k + j < nfront ? k + j : nfront - 1);
-            q4[j][0] = src[0]; q4[j][1] = src[1]; q4[j][2] = src[2]; q4[j][3] = src[3];
+            q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2]; q[j][3] = src[3];
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const double nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
-            if (nd < 0 && q4[j][3] < t0 * nd) {  // (the gate of the plane walk below: only a plane that moves t0 pays for the division)
-              const double t = q4[j][3] * fast_rcp(nd);
+          for (int j = 0; j < kRows; ++j) {
+            const double nd = q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2];
+            if (nd < 0 && q[j][3] < t0 * nd) {  // (the gate of the plane walk below: only a plane that moves t0 pays for the division)
+              const double t = q[j][3] * fast_rcp(nd);
               if (COLOR && t > t0) face = k + j < nfront ? k + j : nfront - 1;
               t0 = t > t0 ? t : t0;
             }
