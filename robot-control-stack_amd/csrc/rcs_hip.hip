@@ -934,8 +934,12 @@ int run_ik(rcsh_sim* s, const double* pose, const double* q0, const double* tcp7
   hipError_t err = hipSuccess;
   dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
-    hipLaunchKernelGGL(k_ik<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, (const double*)d_pose, (const double*)d_q0,
-                       tcp7 ? (const double*)d_tcp : (const double*)nullptr, d_out, s->d_bytes, s->d_ints, forward);
+    if (forward)
+      hipLaunchKernelGGL(k_ik<T>, dim3((s->n + 63) / 64), dim3(64), 0, s->stream, P, (const double*)d_pose, (const double*)d_q0,
+                         tcp7 ? (const double*)d_tcp : (const double*)nullptr, d_out, s->d_bytes, s->d_ints, forward);
+    else
+      hipLaunchKernelGGL(k_ik_team<T>, dim3((s->n + 3) / 4), dim3(64), 0, s->stream, P, (const double*)d_pose, (const double*)d_q0,
+                         tcp7 ? (const double*)d_tcp : (const double*)nullptr, d_out, s->d_bytes, s->d_ints);
     err = hipGetLastError();
   });
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_ik launch: ") + hipGetErrorString(err));

@@ -1233,6 +1233,49 @@ __global__ void __launch_bounds__(64) k_cartesian_team(Params P, CartOp op) {
   }
 }
 
+// Kinematics.inverse on caller-supplied targets and start configurations (reference src/rcs/Kinematics.cpp:28-82), a team of 16
+// lanes per target like k_cartesian_team: the leader lane composes the desired site placement, the team runs the CLIK, lane t
+// writes joint t.  (Through round 2 a lane per target did this: 512 VGPRs and scratch for a 1300-instruction serial iteration.)
+template <class T>
+__global__ void __launch_bounds__(64) k_ik_team(Params P, const double* pose, const double* q0, const double* tcp7, double* q_out,
+                                                uint8_t* success, int32_t* iterations) {
+  constexpr int kTeams = 64 / kTeamLanes;
+  __shared__ DevModelHead lm;
+  __shared__ LinkRec llinks[T::NARM];
+  __shared__ IkTeamBlock<T> blocks[kTeams];
+  __shared__ double desired[kTeams][12];
+  stage_team_model<T::NARM>(P.model, lm, llinks);
+  __syncthreads();
+  const DevModelHead& m = lm;
+  const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
+  const int e = blockIdx.x * kTeams + team;
+  const bool live = e < P.n;
+  if (t == 0 && live) {
+    Pose tcp, target;
+    const double* tv = tcp7 ? tcp7 : P.robot.tcp;
+    tcp.t[0] = tv[0]; tcp.t[1] = tv[1]; tcp.t[2] = tv[2];
+    tcp.q[0] = tv[3]; tcp.q[1] = tv[4]; tcp.q[2] = tv[5]; tcp.q[3] = tv[6];
+    quat_normalize(tcp.q);
+    pose_from_quat(pose + (size_t)e * 7 + 3, pose + (size_t)e * 7, target);
+    clik_desired(m, target, tcp, desired[team], desired[team] + 9);
+  }
+  __syncthreads();
+  double Rd[9], td[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rd[k] = desired[team][k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) td[k] = desired[team][9 + k];
+  const bool joint = live && t < T::NARM;
+  double q = joint ? q0[(size_t)e * T::NARM + t] : 0.0;
+  int iters = 0;
+  const bool ok = clik_team<T>(m, llinks, blocks[team], t, live, Rd, td, q, &iters);
+  if (live && t < T::NL) q_out[(size_t)e * T::NL + t] = t < T::NARM ? q : 0.0;  // model.nq entries, fingers zero (quirk Q7)
+  if (live && t == 0) {
+    if (success) success[e] = ok;
+    if (iterations) iterations[e] = iters;
+  }
+}
+
 // Kinematics.inverse / forward on caller-supplied configurations (reference src/rcs/Kinematics.cpp:28-82)
 template <class T>
 __global__ void __launch_bounds__(64) k_ik(Params P, const double* pose, const double* q0, const double* tcp7, double* q_out,
@@ -1262,17 +1305,8 @@ __global__ void __launch_bounds__(64) k_ik(Params P, const double* pose, const d
     pose_mul(in_robot, tinv, out);
     double* o = q_out + (size_t)e * 7;
     o[0] = out.t[0]; o[1] = out.t[1]; o[2] = out.t[2]; o[3] = out.q[0]; o[4] = out.q[1]; o[5] = out.q[2]; o[6] = out.q[3];
-    return;
   }
-  Pose target;
-  pose_from_quat(pose + (size_t)e * 7 + 3, pose + (size_t)e * 7, target);
-  int iters = 0;
-  const bool ok = clik<T>(m, target, tcp, q, &iters);
-  double* o = q_out + (size_t)e * T::NL;
-#pragma unroll
-  for (int i = 0; i < T::NL; ++i) o[i] = i < T::NARM ? q[i] : 0.0;  // model.nq entries, fingers zero (quirk Q7)
-  if (success) success[e] = ok;
-  if (iterations) iterations[e] = iters;
+  // (the inverse: k_ik_team)
 }
 
 }  // namespace rcsh
