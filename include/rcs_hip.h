@@ -354,11 +354,11 @@ int rcsh_env_step_task_dev(rcsh_sim* sim, const double* action_dev, const float*
  * Frames are those of the last position stage, as mjData.geom_xpos / cam_xpos are. */
 typedef struct rcsh_render_scene_desc {
   int32_t nshape, nplanes;
-  const int32_t* shape;      /* [nshape] 0 plane (z = 0 of the shape frame, seen from +z), 1 box, 2 convex hull */
+  const int32_t* shape;      /* [nshape] 0 plane (z = 0 of the shape frame, seen from +z), 1 box, 2 convex hull, 3 capsule (axis z) */
   const int32_t* link;       /* [nshape] */
   const double* pos;         /* [nshape][3] shape frame in the link frame */
   const double* rot;         /* [nshape][9] row-major */
-  const double* size;        /* [nshape][3] box half extents; hulls: half extents of the bounding box centred at sphere[0..2] */
+  const double* size;        /* [nshape][3] box half extents; hulls: half extents of the bounding box centred at sphere[0..2]; capsules: (r, r, r + half length) */
   const int32_t* plane_adr;  /* [nshape] hulls: first row of `planes` */
   const int32_t* plane_num;  /* [nshape] */
   const double* sphere;      /* [nshape][4] bounding sphere, shape frame: centre, radius (< 0: unbounded) */

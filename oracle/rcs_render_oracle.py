@@ -11,7 +11,8 @@ from __future__ import annotations
 
 import numpy as np
 
-SHAPE_PLANE, SHAPE_BOX, SHAPE_HULL = 0, 1, 2
+SHAPE_PLANE, SHAPE_BOX, SHAPE_HULL, SHAPE_CAPSULE = 0, 1, 2, 3
+last_hit_shape = None
 
 
 def oracle_frames(osim, cm) -> dict:
@@ -73,6 +74,34 @@ def render_depth(rs, cam, frames, colour=False):
             continue
         ok = live.copy()
         face_n = np.zeros((H, W, 3))
+        if rs.shape[g] == SHAPE_CAPSULE:
+            # axis z of the shape frame, radius size[0], half length size[2] - size[0]: the first point of the ray on the wall
+            # between the caps or on the outer half of a cap sphere
+            r, hl = rs.size[g][0], rs.size[g][2] - rs.size[g][0]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                a = ld[..., 0] ** 2 + ld[..., 1] ** 2
+                bq = lo[0] * ld[..., 0] + lo[1] * ld[..., 1]
+                cq = lo[0] ** 2 + lo[1] ** 2 - r * r
+                disc = bq * bq - a * cq
+                t = (-bq - np.sqrt(disc)) / a
+                te = np.where((a > 0) & (disc >= 0) & (np.abs(lo[2] + t * ld[..., 2]) <= hl), t, np.inf)
+                A = a + ld[..., 2] ** 2
+                for zc in (-hl, hl):
+                    oz = lo[2] - zc
+                    B, Cq = bq + oz * ld[..., 2], cq + oz * oz
+                    ds = B * B - A * Cq
+                    t = (-B - np.sqrt(ds)) / A
+                    zr = oz + t * ld[..., 2]
+                    te = np.where((ds >= 0) & ((zr >= 0) if zc > 0 else (zr <= 0)) & (t < te), t, te)
+            ok &= np.isfinite(te) & (te > rs.znear) & (te < best)
+            hp = lo + np.where(ok, te, 0.0)[..., None] * ld
+            face_n = hp.copy()
+            face_n[..., 2] = hp[..., 2] - np.clip(hp[..., 2], -hl, hl)
+            best = np.where(ok, te, best)
+            hit |= ok
+            hit_g = np.where(ok, g, hit_g)
+            hit_n = np.where(ok[..., None], face_n, hit_n)
+            continue
         with np.errstate(divide="ignore", invalid="ignore"):
             if rs.shape[g] == SHAPE_BOX:
                 for k in range(3):
@@ -102,6 +131,8 @@ def render_depth(rs, cam, frames, colour=False):
         hit |= ok
         hit_g = np.where(ok, g, hit_g)
         hit_n = np.where(ok[..., None], face_n, hit_n)
+    global last_hit_shape
+    last_hit_shape = hit_g  # [H, W] index of the shape each ray enters first (-1: none), rows bottom-up: for the tests' bookkeeping
     inv_near, inv_far = 1.0 / rs.znear, 1.0 / rs.zfar
     dgl = np.where(hit, (inv_near - 1.0 / best) / (inv_near - inv_far), 1.0).astype(np.float32)
     # python/rcs/camera/sim.py:57-86 on the buffer mjr_readPixels returned

@@ -1397,7 +1397,7 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
   for (int i = 0; i < d->nshape; ++i) {
     RenderShape& r = sh[i];
     r.shape = d->shape[i]; r.link = d->link[i]; r.plane_adr = d->plane_adr[i]; r.plane_num = d->plane_num[i];
-    if (r.shape < kShapePlane || r.shape > kShapeHull) return fail(RCSH_ERR_ARG, "render scene: unknown shape type");
+    if (r.shape < kShapePlane || r.shape > kShapeCapsule) return fail(RCSH_ERR_ARG, "render scene: unknown shape type");
     if (r.link < kLinkFreeBody || r.link >= s->nl) return fail(RCSH_ERR_ARG, "render scene: link index out of range");
     if (r.link == kLinkFreeBody && !s->box.present) return fail(RCSH_ERR_STATE, "render scene: no free box attached");
     if (r.shape == kShapeHull && (r.plane_adr < 0 || r.plane_num < 4 || r.plane_adr + r.plane_num > d->nplanes))

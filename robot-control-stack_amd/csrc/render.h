@@ -27,13 +27,13 @@
 namespace rcsh {
 
 constexpr int kMaxShapes = 32;
-enum : int32_t { kShapePlane = 0, kShapeBox = 1, kShapeHull = 2 };
+enum : int32_t { kShapePlane = 0, kShapeBox = 1, kShapeHull = 2, kShapeCapsule = 3 };
 enum : int32_t { kLinkWorld = -1, kLinkFreeBody = -2 };
 
 struct RenderShape {
   int32_t shape, link, plane_adr, plane_num;
   double pos[3], rot[9];  // shape frame in its link's frame
-  double size[3];
+  double size[3];         // box: half extents; hull / capsule: half extents of the bounding box (capsule, axis z: radius = size[0], half length = size[2] - size[0])
   double sphere[4];       // bounding sphere: centre (shape frame), radius (< 0: unbounded)
   // hulls, the outline method (k_hull_views): the polytope's edges [edge_adr, edge_adr + edge_num) of RenderScene::edge_*,
   // a point inside it, and where this hull's view record starts within an environment's block of RenderScene::views
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     bool ok = true;
     // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
     // `size`): most rays that pass the sphere of an elongated link miss the link
-    const double cen[3] = {sh.shape == kShapeHull ? sh.sphere[0] : 0.0, sh.shape == kShapeHull ? sh.sphere[1] : 0.0, sh.shape == kShapeHull ? sh.sphere[2] : 0.0};
+    const double cen[3] = {sh.shape != kShapeBox ? sh.sphere[0] : 0.0, sh.shape != kShapeBox ? sh.sphere[1] : 0.0, sh.shape != kShapeBox ? sh.sphere[2] : 0.0};
     int face = 0;
     {
       double b0 = t0, b1 = t1;
@@ -402,6 +402,33 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
         ok = b0 <= b1;
       }
       if (sh.shape == kShapeBox) { t0 = b0; t1 = b1; }
+    }
+    if (ok && sh.shape == kShapeCapsule) {
+      // capsule about the shape frame's z axis: the ray's first point on the cylinder's wall between the caps, or on the outer
+      // half of a cap sphere -- the smallest of the (at most three) candidates, the surface being convex
+      const double r = sh.size[0], hl = sh.size[2] - sh.size[0];
+      double te = INFINITY;
+      const double a = ld[0] * ld[0] + ld[1] * ld[1], bq = lo[0] * ld[0] + lo[1] * ld[1], cq = lo[0] * lo[0] + lo[1] * lo[1] - r * r;
+      const double disc = bq * bq - a * cq;
+      if (a > 0 && disc >= 0) {
+        const double t = (-bq - sqrt(disc)) / a;
+        if (fabs(lo[2] + t * ld[2]) <= hl) te = t;
+      }
+      const double A = a + ld[2] * ld[2];
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const double zc = side ? hl : -hl, oz = lo[2] - zc;
+        const double B = bq + oz * ld[2], Cq = cq + oz * oz;
+        const double ds = B * B - A * Cq;
+        if (ds >= 0) {
+          const double t = (-B - sqrt(ds)) / A;
+          const double zr = oz + t * ld[2];  // of the point, from the cap's centre
+          if ((side ? zr >= 0 : zr <= 0) && t < te) te = t;
+        }
+      }
+      ok = te < INFINITY;
+      t0 = ok && te > t0 ? te : t0;
+      ok = ok && te >= sc.znear && t0 <= t1;
     }
     bool by_outline = false;
     typedef const double __attribute__((address_space(4))) kdouble;
@@ -518,6 +545,14 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       if (sh.shape == kShapeBox) {
         nl[2] = 0;
         nl[hit_face >> 1] = (hit_face & 1) ? 1.0 : -1.0;
+      } else if (sh.shape == kShapeCapsule) {
+        // the hit point from the nearest point of the axis segment
+        const double om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
+        const double hl = sh.size[2] - sh.size[0];
+        const double hz = R[2] * om[0] + R[5] * om[1] + R[8] * om[2];
+        nl[0] = R[0] * om[0] + R[3] * om[1] + R[6] * om[2];
+        nl[1] = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
+        nl[2] = hz - (hz > hl ? hl : (hz < -hl ? -hl : hz));
       } else if (sh.shape == kShapeHull) {
         const double* q = hit_outline ? sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles + 4 * (size_t)hit_face
                                       : sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);

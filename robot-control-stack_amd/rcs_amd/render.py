@@ -2,8 +2,8 @@
 
 The reference renders with MuJoCo's OpenGL rasteriser through ``SimCameraSet`` (src/sim/camera.cpp:86-140): every geom
 of the visible groups (0-2: the floor, free objects, the robot's *visual* meshes) ends up in the depth buffer.  This
-backend casts one ray per pixel against analytic shapes instead: the floor plane, boxes (the free cube, the camera
-body), and the convex hulls of the robot's *collision* meshes (``render_hulls.npz``; the visual OBJ meshes -- 59 files
+backend casts one ray per pixel against analytic shapes instead: the floor plane, boxes (the free cube), capsules (the
+wrist camera's body, drawn as its collision capsule), and the convex hulls of the robot's *collision* meshes (``render_hulls.npz``; the visual OBJ meshes -- 59 files
 for the FR3 -- are not used, so the robot's silhouette is that of its collision hulls, a few millimetres fatter).  The
 camera model, the depth encoding and everything above the pixels follow the reference.
 
@@ -18,10 +18,10 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .mjcf import GEOM_BOX, GEOM_MESH, GEOM_PLANE, Model, find_data_file, quat_mul, quat_to_mat
+from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_MESH, GEOM_PLANE, Model, find_data_file, quat_mul, quat_to_mat
 
 LINK_WORLD, LINK_FREE_BODY = -1, -2
-SHAPE_PLANE, SHAPE_BOX, SHAPE_HULL = 0, 1, 2
+SHAPE_PLANE, SHAPE_BOX, SHAPE_HULL, SHAPE_CAPSULE = 0, 1, 2, 3
 
 
 def _compose(pa, qa, pb, qb):
@@ -51,7 +51,7 @@ class RenderScene:
     link: np.ndarray       # [ng] link index, LINK_WORLD or LINK_FREE_BODY
     pos: np.ndarray        # [ng, 3] shape frame in its link's frame
     rot: np.ndarray        # [ng, 9] row-major
-    size: np.ndarray       # [ng, 3] box half extents; hulls: half extents of the bounding box centred at sphere[:3]
+    size: np.ndarray       # [ng, 3] box half extents; hulls: half extents of the bounding box centred at sphere[:3]; capsules (axis z): (r, r, r + half length)
     plane_adr: np.ndarray  # [ng] first row of `planes` (hulls)
     plane_num: np.ndarray  # [ng]
     sphere: np.ndarray     # [ng, 4] bounding sphere: centre (shape frame), radius; radius < 0: unbounded (plane)
@@ -98,6 +98,9 @@ def build_render_scene(cm: Model, scene_dir: str) -> RenderScene:
         elif t == GEOM_BOX:
             s = A["geom_size"][g]
             add(SHAPE_BOX, link, p, q, size=s, sphere=(0, 0, 0, float(np.linalg.norm(s))), name=cm.geom_names[g], colour=gcol)
+        elif t == GEOM_CAPSULE:
+            r, hl = float(A["geom_size"][g][0]), float(A["geom_size"][g][1])
+            add(SHAPE_CAPSULE, link, p, q, size=(r, r, r + hl), sphere=(0, 0, 0, r + hl), name=cm.geom_names[g], colour=gcol)
         elif t == GEOM_MESH and cm.geom_mesh[g] in hulls:
             pl = hulls[cm.geom_mesh[g]]
             v = A["mesh_vert"][A["geom_vertadr"][g]: A["geom_vertadr"][g] + A["geom_vertnum"][g]]

@@ -201,6 +201,7 @@ def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wri
     simu.set_free_joint_qpos("box_joint", qb)
     for e, o in enumerate(osims):
         o.box_qpos = qb[e]
+    capsule_shapes = [g for g in range(len(cs._scene.shape)) if cs._scene.shape[g] == render.SHAPE_CAPSULE]
     rep = {"pixels": 0, "mismatched_mm": 0, "max_mm_diff": 0, "max_abs_depth_gl": 0.0, "max_abs_extrinsics": 0.0, "robot_pixels": 0,
            "cube_pixels": 0, "floor_pixels": 0, "background_pixels": 0, "fused_mismatch": 0, "rgb_mismatched_pixels": 0, "rgb_max_level_diff": 0,
            "rgb_off_by_more_than_one": 0, "green_pixels": 0, "white_pixels": 0, "colours_seen": set()}
@@ -236,6 +237,8 @@ def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wri
                 ext = np.linalg.inv(np.block([[cR @ np.diag([1.0, -1.0, -1.0]), cp[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]]))
                 rep["max_abs_extrinsics"] = max(rep["max_abs_extrinsics"], float(np.abs(frames.frames[name].camera.depth.extrinsics[e] - ext).max()))
                 rep["background_pixels"] += int((dgl == 1.0).sum())
+                if capsule_shapes:  # pixels whose ray enters a capsule first (the wrist camera's body, drawn as its collision capsule)
+                    rep["capsule_pixels"] = rep.get("capsule_pixels", 0) + int(np.isin(RO.last_hit_shape, capsule_shapes).sum())
                 if name == "bird_eye_cam":
                     rep["robot_pixels"] += int((mm < 1900).sum())  # nearer than the floor: robot and cube seen from above
                 else:

@@ -492,6 +492,7 @@ def test_depth_render_matches_oracle(kernel):
     # (pixels whose ray fell on the other side of a silhouette edge aside)
     assert rep["rgb_off_by_more_than_one"] == 0 and rep["rgb_mismatched_pixels"] <= 3e-3 * rep["pixels"], rep
     assert rep["green_pixels"] > 20 and rep["white_pixels"] > 100, rep  # the cube and the robot are in the pictures
+    assert rep["capsule_pixels"] > 10, rep  # and so is the wrist camera's body (a capsule on the hand), seen from above
 
 
 def test_free_and_tracking_camera_types():
