@@ -368,3 +368,49 @@ def test_mpr_contacts_are_geometrically_what_they_claim_to_be():
         if mtd < 5e-4:
             ratios.append(depth / mtd)
     assert n_contacts > 800 and len(ratios) > 15 and np.median(ratios) < 1 + 1e-6, (n_contacts, len(ratios), np.median(ratios))
+
+
+def test_contact_forces_stay_in_their_friction_cones_and_balance_the_cube():
+    """Physical validity of the coupled solve's answer through a whole pinch-lift-hold, whatever the solver's internals: every
+    contact pushes (f_n >= 0), its friction stays inside Coulomb's cone (|f_t| <= mu f_n, mu the pair's coefficient -- after the
+    noslip pass as well), and while the cube hangs at rest in the hand the contact forces on it add up to its weight:
+    sum of f_n n + f_t1 t1 + f_t2 t2 over the contacts = m g upwards (Newton's second law on the cube alone)."""
+    o = _pick_sim()
+    d = o.s.d
+    checked = 0
+
+    def check():
+        nonlocal checked
+        if not d.coupled:  # (the cube alone on the floor is stepped by rcs_object.c: test_closed_forms covers its rows)
+            return
+        for c in d.contact[: d.ncon]:
+            f = [d.efc_force[c.efc_address + k] for k in range(3)]
+            assert f[0] >= -1e-10, f
+            assert np.hypot(f[1], f[2]) <= c.mu * f[0] * (1 + 1e-9) + 1e-9, (f, c.mu)
+            checked += 1
+
+    home = o.get_cartesian_position()
+
+    def mv(xyz, k):
+        o.set_cartesian_position(O.Pose(translation=np.array(xyz), quaternion=home.rotation_q()))
+        for _ in range(k):
+            o.step(1)
+            check()
+
+    o.gripper_open()
+    mv([0.44, 0.1, 0.20], 400)
+    mv([0.44, 0.1, 0.035], 600)
+    o.gripper_grasp()
+    mv([0.44, 0.1, 0.035], 250)
+    mv([0.44, 0.1, 0.30], 900)
+    assert o.box_qpos[2] > 0.28 and checked > 20000
+    # at rest in the hand: the forces on the cube (body ORC_BODY_BOX = -2; +f on body[1], -f on body[0]) carry its weight
+    total = np.zeros(3)
+    for c in d.contact[: d.ncon]:
+        fr = np.array(c.frame[:]).reshape(3, 3)
+        f = sum(d.efc_force[c.efc_address + k] * fr[k] for k in range(3))
+        assert -2 in (c.body[0], c.body[1])
+        total += f if c.body[1] == -2 else -f
+    weight = 9.81 * o.model.box.mass
+    assert np.abs(o.box_qvel[:3]).max() < 1e-3 and np.abs(o.box_qvel[3:]).max() < 1e-2
+    assert abs(total[2] - weight) < 2e-3 * weight and np.abs(total[:2]).max() < 2e-3 * weight, (total, weight)
