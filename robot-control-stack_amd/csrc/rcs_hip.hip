@@ -1468,6 +1468,7 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   s->rscene.nshape = d->nshape; s->rscene.nframes = s->nl + 1;
   s->rscene.znear = d->znear; s->rscene.zfar = d->zfar;
+  s->rscene.inv_near = 1.0 / d->znear; s->rscene.inv_span = 1.0 / (1.0 / d->znear - 1.0 / d->zfar);
   s->rscene.shapes = s->d_rshapes; s->rscene.planes = s->d_rplanes;
   s->rscene.edge_planes = s->d_redge_planes; s->rscene.edge_verts = s->d_redge_verts; s->rscene.views = s->d_rviews; s->rscene.view_stride = view_stride;
   return RCSH_OK;
@@ -1498,6 +1499,8 @@ int rcsh_sim_add_camera(rcsh_sim* s, const rcsh_camera_desc* c, int32_t* cam_id)
   for (int k = 0; k < 3; ++k) rc.pos[k] = c->pos[k];
   for (int k = 0; k < 9; ++k) rc.rot[k] = c->rot[k];
   rc.tan_half_fovy = std::tan(c->fovy_deg * 3.14159265358979323846 / 360.0);
+  rc.tx = rc.tan_half_fovy * (double)c->width / (double)c->height;
+  rc.two_over_w = 2.0 / c->width; rc.two_over_h = 2.0 / c->height;
   s->cams.push_back(rc);
   *cam_id = (int32_t)s->cams.size() - 1;
   return RCSH_OK;

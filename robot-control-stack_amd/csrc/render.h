@@ -45,6 +45,7 @@ struct RenderCam {
   int32_t link, width, height, pad;
   double pos[3], rot[9];  // camera frame in its link's frame
   double tan_half_fovy;
+  double tx, two_over_w, two_over_h;  // host-computed: tan_half_fovy * W / H, 2 / W, 2 / H (the kernels divide by nothing that is the same for every ray)
 };
 // colour of a shape: rgb; a checkered plane alternates rgb / rgb2 in squares of edge `square` (shape frame x, y)
 struct RenderColour {
@@ -58,6 +59,7 @@ struct RenderShade {
 struct RenderScene {
   int32_t nshape, nframes;  // nframes = links + 1 (the last entry is the free box, identity if the scene has none)
   double znear, zfar;
+  double inv_near, inv_span;  // host-computed: 1 / znear, 1 / (1 / znear - 1 / zfar)
   const RenderShape* shapes;
   const double* planes;  // [.][4] n . x <= d
   const RenderColour* colours;  // [nshape], null until rcsh_sim_set_render_colours
@@ -273,8 +275,10 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
   const int col = (tile % tiles_x) * 16 + (wave % 2) * 8 + lane % 8;
   const int row = (tile / tiles_x) * 16 + (wave / 2) * 8 + lane / 8;  // row 0 = bottom of the image (OpenGL window coordinates)
-  const double ty = cam.tan_half_fovy, tx = ty * (double)W / (double)H;
+  const double ty = cam.tan_half_fovy, tx = cam.tx;
   {
+    // (this environment's rows of wf, staged in LDS.  Reading them through scalar loads instead -- the row index is the
+    // wavefront's -- was tried and measured slower: 2.90 vs 2.72 ms wrist, 5.26 vs 4.93 ms bird's-eye at 256 x 256: the L2's latency)
     const int words = (sc.nshape + 1) * kShapeFrameDoubles;
     const double* src = wf + (size_t)e * words;
     for (int k = threadIdx.x; k < words; k += 256) lw[k] = src[k];
@@ -295,10 +299,14 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
         const double q[3] = {w[12] - cp[0], w[13] - cp[1], w[14] - cp[2]};
         const double x = cR[0] * q[0] + cR[3] * q[1] + cR[6] * q[2], y = cR[1] * q[0] + cR[4] * q[1] + cR[7] * q[2], z = cR[2] * q[0] + cR[5] * q[1] + cR[8] * q[2];
         const int c0 = (tile % tiles_x) * 16, r0 = (tile / tiles_x) * 16;
-        const double xl = (2.0 * c0 / W - 1.0) * tx, xr = (2.0 * (c0 + 16) / W - 1.0) * tx;
-        const double yb = (2.0 * r0 / H - 1.0) * ty, yt = (2.0 * (r0 + 16) / H - 1.0) * ty;
-        visible = -z + r >= sc.znear && x + xl * z >= -r * sqrt(1 + xl * xl) && -x - xr * z >= -r * sqrt(1 + xr * xr) &&
-                  y + yb * z >= -r * sqrt(1 + yb * yb) && -y - yt * z >= -r * sqrt(1 + yt * yt);
+        const double xl = (c0 * cam.two_over_w - 1.0) * tx, xr = ((c0 + 16) * cam.two_over_w - 1.0) * tx;
+        const double yb = (r0 * cam.two_over_h - 1.0) * ty, yt = ((r0 + 16) * cam.two_over_h - 1.0) * ty;
+        // signed distance of the centre to each side plane of the pyramid, times that plane's normal's length: on the inner side,
+        // or no further out than the radius (squares: no square root)
+        const double r2 = r * r;
+        const double sl = x + xl * z, sr = -x - xr * z, sb = y + yb * z, st = -y - yt * z;
+        visible = -z + r >= sc.znear && (sl >= 0 || sl * sl <= r2 * (1 + xl * xl)) && (sr >= 0 || sr * sr <= r2 * (1 + xr * xr)) &&
+                  (sb >= 0 || sb * sb <= r2 * (1 + yb * yb)) && (st >= 0 || st * st <= r2 * (1 + yt * yt));
       }
     }
     const uint64_t m = __ballot(visible);
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   __syncthreads();
   if (col >= W || row >= H) return;
   // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
-  const double dc[3] = {(2.0 * (col + 0.5) / W - 1.0) * tx, (2.0 * (row + 0.5) / H - 1.0) * ty, -1.0};
+  const double dc[3] = {((col + 0.5) * cam.two_over_w - 1.0) * tx, ((row + 0.5) * cam.two_over_h - 1.0) * ty, -1.0};
   double d[3];
   mulmv(cR, dc, d);
   const double o[3] = {cp[0], cp[1], cp[2]};
@@ -379,7 +387,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     if (sh.shape == kShapePlane) {
       // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
       if (!(ld[2] < 0 && lo[2] > 0)) continue;
-      const double t = -lo[2] / ld[2];
+      const double t = -lo[2] * fast_rcp(ld[2]);
       if (t >= t0 && t < t1) { best = t; hit = true; if (COLOR) { hit_g = g; hit_face = 0; } }
       continue;
     }
@@ -430,6 +438,12 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       t0 = ok && te > t0 ? te : t0;
       ok = ok && te >= sc.znear && t0 <= t1;
     }
+#ifdef RCSH_RENDER_NOWALK
+    if (sh.shape == kShapeHull) ok = false;  // (measurement: everything but the hulls' own tests)
+#endif
+#ifdef RCSH_RENDER_FLOORONLY
+    ok = false;  // (measurement: the floor and the bookkeeping)
+#endif
     bool by_outline = false;
     typedef const double __attribute__((address_space(4))) kdouble;
     if (ok && sh.shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
@@ -514,8 +528,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     // a camera inside a shape sees its inside faces culled (back faces): only entry points count
     if (ok && t0 > sc.znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; hit_outline = by_outline; } }
   }
-  const double inv_near = 1.0 / sc.znear, inv_far = 1.0 / sc.zfar;
-  const float dgl = hit ? (float)((inv_near - 1.0 / best) / (inv_near - inv_far)) : 1.0f;
+  const float dgl = hit ? (float)((sc.inv_near - fast_rcp(best)) * sc.inv_span) : 1.0f;  // (1/near - 1/z) / (1/near - 1/far)
   const size_t img = (size_t)e * W * H;
   if (depth_gl) depth_gl[img + (size_t)row * W + col] = dgl;
   if (depth_mm) {
