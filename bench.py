@@ -196,8 +196,10 @@ def main() -> None:
     n_dev = int(L0.rcsh_device_count())
     if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the batched backend has no CPU execution path")
-    if args.dist_backend != "nccl":
-        local_rank %= n_dev  # functional check only: ranks may share a GPU
+    # One rank per GPU: LOCAL_RANK names the device -- unless the launcher masked the devices so that every rank sees only its own
+    # (then that is device 0), or there are fewer GPUs than ranks (a functional check: ranks share a GPU, RCCL refuses two ranks on
+    # one device and the exchange falls back to the rendezvous group through host memory, see below).
+    local_rank %= n_dev
     dist = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
