@@ -1658,7 +1658,7 @@ int rcsh_camera_render_rgb_dev(rcsh_sim* s, int32_t cam_id, uint8_t* rgb, float*
   hipLaunchKernelGGL(k_shape_frames, dim3(grid_for(s->n * (s->rscene.nshape + 1))), dim3(kBlock), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
                      s->d_wframes);
   if (s->rscene.views)
-    hipLaunchKernelGGL(k_hull_views, dim3((unsigned)s->n * (unsigned)s->rscene.nshape), dim3(64), 0, s->stream, s->rscene, s->d_wframes, s->n);
+    hipLaunchKernelGGL(k_hull_views, dim3((unsigned)s->n * (unsigned)s->rscene.nshape), dim3(64), 0, s->stream, s->rscene, cam, s->d_wframes, s->n);
   const int blocks_per_env = ((cam.width + 15) / 16) * ((cam.height + 15) / 16);
   const dim3 grid((unsigned)(((size_t)blocks_per_env * (size_t)s->n + 7) / 8 * 8));  // (a multiple of 8: k_render_depth numbers its workgroups per XCD)
   if (rgb)

@@ -183,7 +183,7 @@ __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* fram
 __device__ __forceinline__ double plane_no(const double* q, const double* lo) {
   return fma(-q[2], lo[2], fma(-q[1], lo[1], fma(-q[0], lo[0], q[3])));  // d - n . o, one rounding order everywhere it is needed
 }
-__global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, const double* wf, int n) {
+__global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam, const double* wf, int n) {
   const int e = blockIdx.x / sc.nshape, g = blockIdx.x % sc.nshape;
   if (e >= n) return;
   const RenderShape& sh = sc.shapes[g];
@@ -191,6 +191,22 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, const double*
   const int lane = threadIdx.x;
   const double* w = wf + ((size_t)e * (sc.nshape + 1) + g) * kShapeFrameDoubles;           // the hull's frame: R (9) p (3)
   const double* cw = wf + ((size_t)e * (sc.nshape + 1) + sc.nshape) * kShapeFrameDoubles;  // the camera's
+  {
+    // a hull the camera cannot see (its bounding sphere outside the image's pyramid of rays or behind the near plane) is never
+    // visited by a ray -- k_render_depth culls it per tile with the same test -- so its view is not needed: the wrist camera
+    // sees the fingers and little else of the arm
+    const double q[3] = {w[12] - cw[9], w[13] - cw[10], w[14] - cw[11]}, r = w[15];
+    const double x = cw[0] * q[0] + cw[3] * q[1] + cw[6] * q[2], y = cw[1] * q[0] + cw[4] * q[1] + cw[7] * q[2], z = cw[2] * q[0] + cw[5] * q[1] + cw[8] * q[2];
+    const double tx = cam.tx, ty = cam.tan_half_fovy, r2 = r * r;
+    const double sl = x - tx * z, sr = -x - tx * z, sb = y - ty * z, st = -y - ty * z;  // (the image spans x in [-tx, tx] (-z), y in [-ty, ty] (-z))
+    const bool visible = -z + r >= sc.znear && (sl >= 0 || sl * sl <= r2 * (1 + tx * tx)) && (sr >= 0 || sr * sr <= r2 * (1 + tx * tx)) &&
+                         (sb >= 0 || sb * sb <= r2 * (1 + ty * ty)) && (st >= 0 || st * st <= r2 * (1 + ty * ty));
+    if (!visible) {
+      // (should a tile's own cull let it through after all -- the two tests are not the same inequality -- the rays walk its planes)
+      if (lane == 0) { int32_t* hdr = (int32_t*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr); hdr[0] = 0; hdr[1] = -1; }
+      return;
+    }
+  }
   const double om[3] = {cw[9] - w[9], cw[10] - w[10], cw[11] - w[11]};
   const double lo[3] = {w[0] * om[0] + w[3] * om[1] + w[6] * om[2], w[1] * om[0] + w[4] * om[1] + w[7] * om[2], w[2] * om[0] + w[5] * om[1] + w[8] * om[2]};
   double* out = sc.views + (size_t)e * sc.view_stride + sh.view_adr;

@@ -13,6 +13,11 @@ run --steps 200 --warmup 20 --robot xarm7_box
 run --steps 200 --warmup 20 --task pick_up
 run --steps 100 --warmup 10 --task pick_up --cameras wrist_0 --resolution 64x64
 run --steps 100 --warmup 10 --envs 65536
+run --steps 200 --warmup 20 --robot ur5e
+run --steps 200 --warmup 20 --robot so101
+run --steps 200 --warmup 20 --robot mixed --envs 4096
+run --steps 200 --warmup 20 --robot xarm7_pick
+run --steps 50 --warmup 5 --robot xarm7_pick --cameras side_cam --resolution 256x256
 python - <<'PY'
 import json
 for l in open("gpurun_out/bench_matrix.jsonl"):
