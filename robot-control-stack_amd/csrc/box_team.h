@@ -274,12 +274,14 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
       for (int j = 0; j < 6; ++j) x[j] = warm[j];
     }
     double f[3];
+    bool f_at_x = false;  // f holds the forces at the current x (the loop leaves through one of its two breaks: right after computing them)
     TEAM_MARK(17)
     for (int it = 0; it < 50; ++it) {
       TEAM_COUNT(21)
       double jar[3], Hc[6], grad[6], H[36];
       box_jar(c, x, jar);
       box_cone(c, b.fr, jar, f, Hc);
+      f_at_x = true;
       // gradient first: the Hessian is only assembled when another step follows
       double g2 = 0;
 #pragma unroll
@@ -350,8 +352,9 @@ RCSH_D void box_substep(const BoxCfg& b, double* bs, const double* gravity, doub
       }
 #pragma unroll
       for (int j = 0; j < 6; ++j) x[j] += best * d[j];
+      f_at_x = false;
     }
-    {
+    if (!f_at_x) {  // (only when the loop ran into its cap)
       double jar[3], Hc[6];
       box_jar(c, x, jar);
       box_cone(c, b.fr, jar, f, Hc);  // forces at the solution
