@@ -1362,3 +1362,54 @@ def test_render_schedule_grows_with_the_launch_and_rejects_a_second_set(kernel):
     gaps = np.diff(ts)
     assert np.all(gaps > 1 / 30) and np.all(gaps < 1 / 30 + 2 * 0.002 + 1e-12), gaps  # every frame one period (plus <= a substep) after the last
     simu.close()
+
+
+def test_depth_frames_at_the_size_of_baseline_config_3(kernel):
+    """The ray caster at BASELINE configs[3]'s per-GPU size: 4096 environments x one 256 x 256 depth frame of the fixed camera of
+    scenes/xarm7_pick_world -- 268 million rays, a million workgroups numbered per XCD, 230 MB of per-environment hull views.  32
+    distinct arm poses / cube placements tiled 128x over the batch: every copy of a frame equals the first bit for bit wherever
+    its environment sits, and the first two frames equal the numpy ray caster's on the oracle's kinematics (silhouette pixels aside)."""
+    import rcs_oracle as O
+    import rcs_render_oracle as RO
+    from parity_util import XARM7_PICK_SCENE
+    from rcs_amd import render
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import xarm7_pick_sim_gripper_cfg, xarm7_pick_sim_robot_cfg
+    from rcs_amd.mjcf import compile_mjcf
+    from rcs_env_oracle import XARM7_PICK as R
+
+    n, base, W = 4096, 32, 256
+    cfg = xarm7_pick_sim_robot_cfg()
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+    robot = S.SimRobot(simu, None, cfg)
+    S.SimGripper(simu, xarm7_pick_sim_gripper_cfg())
+    cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", frame_rate=0, resolution_width=W, resolution_height=W)},
+                      physical_units=True, render_on_demand=True)
+    rng = np.random.default_rng(3)
+    q = np.asarray(R["q_home"]) + rng.uniform(-0.5, 0.5, (base, 7))
+    qb = np.tile(np.array([0.40, 0.0, 0.0288, 1.0, 0, 0, 0]), (base, 1))
+    qb[:, :2] += rng.uniform(-0.1, 0.1, (base, 2))
+    simu.reset(); robot.reset()
+    simu.set_free_joint_qpos("box_joint", np.tile(qb, (n // base, 1)))
+    robot.set_joints_hard(np.tile(q, (n // base, 1)))
+    simu.step(2)
+    mm = cs.render_depth_mm("side")
+    assert mm.shape == (n, W, W)
+    tiles = mm.reshape(n // base, base, W, W)
+    assert all(np.array_equal(tiles[k], tiles[0]) for k in range(1, n // base)), "replicas of a frame differ"
+    assert len({int(f.astype(np.uint64).sum()) for f in tiles[0]}) == base  # 32 different pictures
+    cm = compile_mjcf(XARM7_PICK_SCENE)
+    link, pos, rot, fovy = render.camera_in_link(cm, "side_cam")
+    for e in range(2):
+        o = O.Sim(cm, R["joints"], R["actuators"], R["site"], R["base"], R["q_home"], O.Pose(translation=np.array([0.0, 0.0, 0.1034])),
+                  R["gripper_joint"], R["gripper_actuator"], arm_collision_geoms=[], gripper_cfg=R["gripper_cfg"])
+        o.reset(); o.robot_reset()
+        o.box_qpos = qb[e]
+        o.set_joints_hard(q[e])
+        o.step(2)
+        _, omm, _, _ = RO.render_depth(cs._scene, (link, pos, rot, fovy, W, W), RO.oracle_frames(o, cm))
+        diff = mm[e].astype(np.int64) != omm.astype(np.int64)
+        assert diff.sum() <= 2e-4 * W * W, int(diff.sum())
+        assert (omm < 1500).sum() > 2000  # the arm fills a good part of the picture
+    simu.close()
