@@ -153,6 +153,10 @@ def main() -> None:
                                                  "env-step, inside the timed region (SimCameraSet, render on demand); not the headline")
     ap.add_argument("--resolution", default="256x256", help="WxH of the depth frames (FR3SimplePickUpSimEnvCreator default 256x256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clock-warmup-ms", type=float, default=25.0,
+                    help="before the W warmup steps: this many milliseconds of the same env-step launches, then a reset -- the device needs "
+                         "~12 ms of work to reach its operating clocks (profiles/README.md: a launch takes 128 us at first, 112.5 us from "
+                         "there on), W = 5 steps are 0.6 ms.  0: off")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
     args = ap.parse_args()
@@ -391,6 +395,20 @@ def main() -> None:
             exchange.post(t)  # overlaps with the next env-step
 
     do_reset(0)
+    # Clocks first.  A device that sat idle through the set-up starts its first launches below its operating frequency and needs
+    # ~12 ms of work to get there: stepping launches (the measured ones, exchange off) for --clock-warmup-ms, then the environments
+    # are reset and the contract's W warmup steps and K timed steps run as specified -- at the clocks a rollout of any length sees.
+    clock_warmup_launches = 0
+    if args.clock_warmup_ms > 0:
+        saved_exchange, exchange = exchange, None
+        t_end = time.perf_counter() + args.clock_warmup_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for t in range(8):
+                one_step(clock_warmup_launches % T if not episode else 1 + clock_warmup_launches % max(min(episode, T) - 1, 1))
+                clock_warmup_launches += 1
+            device_sync()
+        exchange = saved_exchange
+        do_reset(0)
     for t in range(args.warmup):
         one_step(t)
 
@@ -487,6 +505,8 @@ def main() -> None:
                 "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"torch.distributed {args.dist_backend} all_gather")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
+                "clock_warmup": (f"{clock_warmup_launches} untimed launches over {args.clock_warmup_ms:g} ms before the W warmup steps, then a reset "
+                                 "(the device reaches its operating clocks after ~12 ms of work)") if clock_warmup_launches else None,
             },
             "roofline": {
                 "bound": "hbm",
