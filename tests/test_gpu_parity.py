@@ -1413,3 +1413,39 @@ def test_depth_frames_at_the_size_of_baseline_config_3(kernel):
         assert diff.sum() <= 2e-4 * W * W, int(diff.sum())
         assert (omm < 1500).sum() > 2000  # the arm fills a good part of the picture
     simu.close()
+
+
+def test_outline_method_and_plane_walk_draw_the_same_frames(kernel, monkeypatch):
+    """The ray caster's two ways through a hull -- the outline as the camera sees it plus the front planes (k_hull_views; the default)
+    and the walk over every face plane for both ends of the ray's interval (RCSH_RENDER_OUTLINE=0; also the fallback for hulls
+    without a clean edge table) -- on the same 24 poses of the pick-up scene, both cameras, depth and colour: the same pixels
+    (a ray that grazes an outline may fall on either side: at most one pixel in ten thousand)."""
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+    from rcs_env_oracle import FR3_Q_HOME
+
+    n, W, H = 24, 96, 64
+    rng = np.random.default_rng(12)
+    q = np.asarray(FR3_Q_HOME) + rng.uniform(-0.5, 0.5, (n, 7))
+    qb = np.tile(np.array([0.5, 0.0, 0.0288, 1, 0, 0, 0.0]), (n, 1))
+    qb[:, :2] += rng.uniform(-0.15, 0.15, (n, 2))
+    qb[:, 6] = rng.uniform(-1, 1, n)
+    frames = {}
+    for outline in ("1", "0"):
+        monkeypatch.setenv("RCSH_RENDER_OUTLINE", outline)
+        cfg = default_sim_robot_cfg("fr3_simple_pick_up")
+        simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n)
+        robot = S.SimRobot(simu, None, cfg)
+        S.SimGripper(simu, default_sim_gripper_cfg())
+        cs = SimCameraSet(simu, {c: SimCameraConfig(identifier=c, frame_rate=0, resolution_width=W, resolution_height=H) for c in ("wrist_0", "bird_eye_cam")},
+                          physical_units=True, render_on_demand=True)
+        simu.set_free_joint_qpos("box_joint", qb)
+        robot.set_joints_hard(q)
+        simu.step(2)
+        frames[outline] = {c: cs.render_raw_rgbd(c)[:2] for c in ("wrist_0", "bird_eye_cam")}
+        simu.close()
+    for c in ("wrist_0", "bird_eye_cam"):
+        (rgb1, d1), (rgb0, d0) = frames["1"][c], frames["0"][c]
+        assert (d1 != d0).sum() <= 1e-4 * d1.size and (rgb1 != rgb0).any(axis=-1).sum() <= 1e-4 * d1.size, ((d1 != d0).sum(), c)
+        assert (d1 < 1.0).mean() > 0.5  # something is in the pictures
