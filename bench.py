@@ -443,6 +443,22 @@ def main() -> None:
         elapsed = float(tt.item())
 
     kernel_ms = ms.value / max(launches.value, 1)
+    # N > 1: the same K steps once more WITHOUT the exchange (after the clock stopped; reported next to the measured value, never
+    # as it) -- what the all-gather costs a step on this node, i.e. how much of a scaling loss is the exchange's and how much the shards'
+    no_exchange_value = None
+    if world > 1 and exchange is not None and not episode:
+        saved_exchange, exchange = exchange, None
+        device_sync()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for t in range(args.warmup, T):
+            one_step(t)
+        device_sync()
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        no_exchange_value = world * n * args.steps / float(tt.item())
+        exchange = saved_exchange
     mean_sub = float(sub.download().astype(np.float64).mean())
     finite = bool(np.isfinite(obs_host).all())
     if task_out is not None:
@@ -505,6 +521,7 @@ def main() -> None:
                 "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"torch.distributed {args.dist_backend} all_gather")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "obs_finite": finite,
+                "value_without_exchange": no_exchange_value,
                 "clock_warmup": (f"{clock_warmup_launches} untimed launches over {args.clock_warmup_ms:g} ms before the W warmup steps, then a reset "
                                  "(the device reaches its operating clocks after ~12 ms of work)") if clock_warmup_launches else None,
             },
