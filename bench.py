@@ -196,6 +196,8 @@ def main() -> None:
     # from numpy, streams and their ordering from the library's own handles.  With N > 1 ranks torch.distributed serves as the
     # launcher's rendezvous only -- a gloo group on CPU tensors for the RCCL id, the barriers and the max-over-ranks of the
     # clock -- and the one exchange of the data path, the all-gather of the observation block, is RCCL behind the C-ABI.
+    if os.environ.get("RCSH_LIB"):
+        _lib.LIB_PATH = os.environ["RCSH_LIB"]  # (a development build of the library, for A/B measurements)
     L0 = _lib.load()
     n_dev = int(L0.rcsh_device_count())
     if n_dev < 1:
