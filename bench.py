@@ -320,15 +320,25 @@ def main() -> None:
     if world > 1 and args.dist_backend == "nccl":
         from rcs_amd.envs.sharding import RcclObservationExchange, comm_unique_id
 
-        box = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm_error = ""
+        # ncclCommInitRank is collective: a rank that cannot even load RCCL must not leave the others waiting inside it.  Every rank
+        # first asks the library for an id of its own (that loads librccl and resolves its entry points); only if all of them could
+        # does rank 0's id go round and the communicator get created.
+        comm_error, my_id = "", None
         try:
-            exchange = RcclObservationExchange(env.sim, bytes(box[0]), rank, world, n_rows=n, width=ow)
-        except RuntimeError as exc:  # e.g. a communicator RCCL refuses on this topology
+            my_id = comm_unique_id()
+        except RuntimeError as exc:
             comm_error = str(exc)
         okflag = torch.tensor([0 if comm_error else 1])
-        dist.all_reduce(okflag, op=dist.ReduceOp.MIN)  # every rank takes the same carrier
+        dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+        if int(okflag.item()) == 1:
+            box = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            try:
+                exchange = RcclObservationExchange(env.sim, bytes(box[0]), rank, world, n_rows=n, width=ow)
+            except RuntimeError as exc:  # e.g. a communicator RCCL refuses on this topology
+                comm_error = str(exc)
+            okflag = torch.tensor([0 if comm_error else 1])
+            dist.all_reduce(okflag, op=dist.ReduceOp.MIN)  # every rank takes the same carrier
         if int(okflag.item()) == 0:
             if exchange is not None:
                 exchange.close()
