@@ -740,8 +740,13 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   }
   double* const bs = lbox + ((BOX || CON) ? team * kBoxLds : 0);
   if constexpr (CON && !BOX) {
-    // the phantom box: at rest where the host parked it
-    for (int k = t; k < kBoxState; k += kTeamLanes) bs[k] = k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre && k < kBoxPre + 7 ? lbt[0].box.qpos0[k - kBoxPre] : 0.0);
+    // the phantom box: at rest where the host parked it; what it carries from launch to launch is the minimiser of the last coupled
+    // solve (kBoxX: the warm start of the next one -- mjData.qacc_warmstart outlives a Sim.step call, only Sim::reset zeroes it)
+    for (int k = t; k < kBoxState; k += kTeamLanes) {
+      double v = k < 7 ? lbt[0].box.qpos0[k] : (k >= kBoxPre && k < kBoxPre + 7 ? lbt[0].box.qpos0[k - kBoxPre] : 0.0);
+      if (k >= kBoxX && live && !op.do_reset) v = P.S[(size_t)(Lay<T>::BOX + k) * P.n + e];
+      bs[k] = v;
+    }
   }
   if constexpr (BOX) {
     if (live) {
@@ -987,6 +992,10 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     if constexpr (FRIC) {
       if (t < T::NL) P.S[(size_t)(Lay<T>::XS + t) * P.n + e] = st.xs(t);
     }
+  }
+  if constexpr (CON && !BOX) {
+    if (live)
+      for (int k = kBoxX + t; k < kBoxState; k += kTeamLanes) P.S[(size_t)(Lay<T>::BOX + k) * P.n + e] = bs[k];
   }
   if constexpr (BOX) {
     if (live) {
