@@ -28,6 +28,41 @@
 namespace py = pybind11;
 using darr = py::array_t<double, py::array::c_style | py::array::forcecast>;
 
+// Fixed-shape arguments of the Pose / RPY constructors.  The reference's overloads are told apart by Eigen's fixed-size types
+// (Vector3d, Vector4d, Matrix3d, Matrix4d: src/pybind/rcs.cpp:248-262), whose casters REFUSE an array of another shape, so that
+// pybind moves on to the next overload; a plain array_t accepts anything and a size check inside the constructor body throws
+// instead of falling through (positional `Pose(np.zeros(3))` then died in the pose_matrix overload).  Shaped<R, C> restores the
+// Eigen behaviour: C == 1 takes a 1-D array of R numbers (or R x 1 / 1 x R, as Eigen's vector caster does), otherwise exactly R x C.
+template <int R, int C>
+struct Shaped {
+  darr a;
+  const double* data() const { return a.data(); }
+};
+namespace pybind11 { namespace detail {
+template <int R, int C>
+struct type_caster<Shaped<R, C>> {
+  using ShapedT = Shaped<R, C>;
+  PYBIND11_TYPE_CASTER(ShapedT, const_name("numpy.ndarray[numpy.float64[") + const_name<R>() + const_name(", ") + const_name<C>() + const_name("]]"));
+  bool load(handle src, bool convert) {
+    if (!convert && !darr::check_(src)) return false;
+    darr arr = darr::ensure(src);
+    if (!arr) { PyErr_Clear(); return false; }
+    const auto nd = arr.ndim();
+    bool ok;
+    if (C == 1) ok = (nd == 1 && arr.shape(0) == R) || (nd == 2 && ((arr.shape(0) == R && arr.shape(1) == 1) || (arr.shape(0) == 1 && arr.shape(1) == R)));
+    else ok = nd == 2 && arr.shape(0) == R && arr.shape(1) == C;
+    if (!ok) return false;
+    value.a = std::move(arr);
+    return true;
+  }
+  static handle cast(const Shaped<R, C>& s, return_value_policy, handle) { return darr(s.a).release(); }
+};
+}}  // namespace pybind11::detail
+using Vec3 = Shaped<3, 1>;
+using Vec4 = Shaped<4, 1>;
+using Mat3 = Shaped<3, 3>;
+using Mat4 = Shaped<4, 4>;
+
 namespace {
 
 constexpr double kPi = 3.141592653589793238462643383279502884;
@@ -350,7 +385,7 @@ void bind_common(py::module_& m) {
 
   py::class_<RPY>(common, "RPY")
       .def(py::init([](double roll, double pitch, double yaw) { return RPY{roll, pitch, yaw}; }), py::arg("roll") = 0.0, py::arg("pitch") = 0.0, py::arg("yaw") = 0.0)
-      .def(py::init([](const darr& rpy) { const double* v = need(rpy, 3, "rpy"); return RPY{v[0], v[1], v[2]}; }), py::arg("rpy"))
+      .def(py::init([](const Vec3& rpy) { const double* v = rpy.data(); return RPY{v[0], v[1], v[2]}; }), py::arg("rpy"))
       .def_readwrite("roll", &RPY::roll)
       .def_readwrite("pitch", &RPY::pitch)
       .def_readwrite("yaw", &RPY::yaw)
@@ -366,16 +401,16 @@ void bind_common(py::module_& m) {
 
   py::class_<Pose>(common, "Pose")
       .def(py::init<>())
-      .def(py::init([](const darr& m) { return Pose::from_matrix(m); }), py::arg("pose_matrix"))
-      .def(py::init([](const darr& r, const darr& t) { return Pose::from_rotation(r, &t); }), py::arg("rotation"), py::arg("translation"))
-      .def(py::init([](const darr& q, const darr& t) { return Pose::from_quaternion(q, &t); }), py::arg("quaternion"), py::arg("translation"))
-      .def(py::init([](const RPY& r, const darr& t) { return Pose::from_rpy(r, &t); }), py::arg("rpy"), py::arg("translation"))
-      .def(py::init([](const darr& v, const darr& t) { const double* x = need(v, 3, "rpy_vector"); return Pose::from_rpy(RPY{x[0], x[1], x[2]}, &t); }),
+      .def(py::init([](const Mat4& m) { return Pose::from_matrix(m.a); }), py::arg("pose_matrix"))
+      .def(py::init([](const Mat3& r, const Vec3& t) { return Pose::from_rotation(r.a, &t.a); }), py::arg("rotation"), py::arg("translation"))
+      .def(py::init([](const Vec4& q, const Vec3& t) { return Pose::from_quaternion(q.a, &t.a); }), py::arg("quaternion"), py::arg("translation"))
+      .def(py::init([](const RPY& r, const Vec3& t) { return Pose::from_rpy(r, &t.a); }), py::arg("rpy"), py::arg("translation"))
+      .def(py::init([](const Vec3& v, const Vec3& t) { const double* x = v.data(); return Pose::from_rpy(RPY{x[0], x[1], x[2]}, &t.a); }),
            py::arg("rpy_vector"), py::arg("translation"))
-      .def(py::init([](const darr& t) { return Pose::from_translation(t); }), py::arg("translation"))
-      .def(py::init([](const darr& q) { return Pose::from_quaternion(q, nullptr); }), py::arg("quaternion"))
+      .def(py::init([](const Vec3& t) { return Pose::from_translation(t.a); }), py::arg("translation"))
+      .def(py::init([](const Vec4& q) { return Pose::from_quaternion(q.a, nullptr); }), py::arg("quaternion"))
       .def(py::init([](const RPY& r) { return Pose::from_rpy(r, nullptr); }), py::arg("rpy"))
-      .def(py::init([](const darr& r) { return Pose::from_rotation(r, nullptr); }), py::arg("rotation"))
+      .def(py::init([](const Mat3& r) { return Pose::from_rotation(r.a, nullptr); }), py::arg("rotation"))
       .def(py::init([](const Pose& p) { return Pose(p); }), py::arg("pose"))
       .def("translation", [](const Pose& p) { return vec(p.p.t, 3); })
       .def("rotation_m", &Pose::rotation_m)

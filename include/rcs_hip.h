@@ -291,6 +291,12 @@ typedef struct rcsh_contact_options {
   int32_t resolve_robot_contacts, reserved;
 } rcsh_contact_options;
 int rcsh_sim_set_contact_options(rcsh_sim* sim, const rcsh_contact_options* options);
+/* Collision geoms of the scene that exceed the contact table's capacity (32 geoms, 10 boxes, 152 hull vertices) are left out of
+ * GEOM-GEOM detection (the floor test still sees them): their mjModel ids (up to `capacity`), how many there are, and why.
+ * rcsh_sim_add_robot / rcsh_sim_add_gripper refuse a collision geom that is on this list; the Python host warns about the
+ * rest (a world-welded obstacle no callback list names would still count for SimRobot::collision_callback,
+ * reference src/sim/SimRobot.cpp:172-182).  No reference counterpart: MuJoCo has no such capacity. */
+int rcsh_sim_contact_table_dropped(rcsh_sim* sim, int32_t* geom_ids, int32_t capacity, int32_t* count, char* reason, size_t reason_capacity);
 int rcsh_sim_reset_free_box(rcsh_sim* sim);
 int rcsh_sim_get_free_qpos(rcsh_sim* sim, double* qpos);  /* [N][7] */
 int rcsh_sim_get_free_qvel(rcsh_sim* sim, double* qvel);  /* [N][6] */

@@ -25,7 +25,7 @@ I = C.c_int
 
 def build(force: bool = False) -> str:
     """Compile oracle/*.c into oracle/_build/librcs_oracle.so (gcc, seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rcs_physics.c", "rcs_pose_ik.c", "rcs_sim.c", "rcs_object.c", "rcs_contact.c", "rcs_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("rcs_physics.c", "rcs_pose_ik.c", "rcs_sim.c", "rcs_object.c", "rcs_contact.c", "rcs_oracle.h", "Makefile")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
     return _SO

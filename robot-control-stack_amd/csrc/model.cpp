@@ -529,8 +529,13 @@ void body_invweight0(const HostModel& h, const DevModel& m, const std::vector<in
 }  // namespace
 
 std::string build_contact_table(const HostModel& h, const DevModel& m, int plane_geom, std::vector<ContactGeom>& geoms, std::vector<double>& verts,
-                                std::string& overflow) {
+                                std::string& overflow, std::vector<int>* dropped) {
   overflow.clear();
+  if (dropped) dropped->clear();
+  auto drop = [&](int g, const std::string& why) {
+    if (overflow.empty()) overflow = why;
+    if (dropped) dropped->push_back(g);
+  };
   std::vector<int> owner;
   std::vector<Xf> rel;
   body_owner_frames(h, owner, rel);
@@ -546,7 +551,7 @@ std::string build_contact_table(const HostModel& h, const DevModel& m, int plane
     if (h.geom_contype[g] == 0 && h.geom_conaffinity[g] == 0) continue;
     // Capacity limits: a geom beyond them stays OUT of the table (geom-geom detection does not see it; the floor test by
     // sample points still does) and the reason is kept -- fatal only once contacts are to be RESOLVED for this scene.
-    if ((int)geoms.size() >= kMaxCGeom) { if (overflow.empty()) overflow = "too many collision geoms for the contact phase (" + std::to_string(kMaxCGeom) + ")"; continue; }
+    if ((int)geoms.size() >= kMaxCGeom) { drop(g, "too many collision geoms for the contact phase (" + std::to_string(kMaxCGeom) + ")"); continue; }
     ContactGeom cg;
     std::memset(&cg, 0, sizeof(cg));
     const int b = h.geom_bodyid[g];
@@ -556,12 +561,12 @@ std::string build_contact_table(const HostModel& h, const DevModel& m, int plane
     if (type == 6) {
       int nbox = 0;
       for (const auto& o : geoms) nbox += o.type == 6;
-      if (nbox >= 10) { if (overflow.empty()) overflow = "too many box geoms for the contact phase (10)"; continue; }
+      if (nbox >= 10) { drop(g, "too many box geoms for the contact phase (10)"); continue; }
       cg.box_slot = nbox;
     }
     cg.vert_adr = h.geom_vertadr[g];
     cg.vert_num = type == 7 ? h.geom_vertnum[g] : 0;
-    if (cg.vert_num > 152) { if (overflow.empty()) overflow = "collision hull with more than 152 vertices (the self-collision test stages two hulls in LDS)"; continue; }
+    if (cg.vert_num > 152) { drop(g, "collision hull with more than 152 vertices (the self-collision test stages two hulls in LDS)"); continue; }
     const Xf t = xf_mul(rel[b], xf_from(&h.geom_pos[3 * g], &h.geom_quat[4 * g]));
     for (int k = 0; k < 3; ++k) { cg.pos[k] = t.p[k]; cg.size[k] = h.geom_size[3 * g + k]; }
     for (int k = 0; k < 9; ++k) cg.rot[k] = t.R[k];

@@ -52,7 +52,8 @@ std::string build_collision_points(const HostModel& h, CollisionPoints& out);
 // The robot's collision geoms for the contact phase (contact_team.h), in geom order; `verts` are the hull vertices they
 // index (geom frame).  Class bits are filled in later from the SimRobot / SimGripper configurations.
 std::string build_contact_table(const HostModel& h, const DevModel& m, int plane_geom, std::vector<ContactGeom>& geoms, std::vector<double>& verts,
-                                std::string& overflow /* geoms left out of the table because of a capacity limit: why (empty: none) */);
+                                std::string& overflow /* geoms left out of the table because of a capacity limit: why (empty: none) */,
+                                std::vector<int>* dropped = nullptr /* their mjModel geom ids */);
 
 // Edges of the convex polytope { x : n_i . x <= d_i } a drawn hull is given as (render.h: the ray caster finds a hull's outline
 // as seen from the camera among them).  Each edge: the two planes that meet in it and its end points.  `centre`: a point

@@ -56,6 +56,7 @@ struct rcsh_sim {
   // contact phase (contact_team.h): the robot's collision geoms and their hull vertices
   std::vector<ContactGeom> cgeoms;
   std::string contact_overflow;  // why collision geoms were left out of `cgeoms` (capacity); empty: none were
+  std::vector<int> cgeoms_dropped;  // mjModel ids of those geoms: invisible to geom-geom detection (the floor test by sample points still sees them)
   std::vector<double> cverts;
   ContactGeom* d_cgeoms = nullptr;
   SelfPair* d_pairs = nullptr;       // self-collision pairs a collision callback reacts to (rebuilt when the class bits change)
@@ -608,7 +609,7 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
     std::string cwhy = build_collision_points(s->hm, s->cp);
     if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);
     s->cp_class.assign(s->cp.geom.size(), 0);
-    cwhy = build_contact_table(s->hm, s->dm, s->cp.has_plane ? s->cp.plane_geom : -1, s->cgeoms, s->cverts, s->contact_overflow);
+    cwhy = build_contact_table(s->hm, s->dm, s->cp.has_plane ? s->cp.plane_geom : -1, s->cgeoms, s->cverts, s->contact_overflow, &s->cgeoms_dropped);
     if (!cwhy.empty()) return cleanup(RCSH_ERR_MODEL, cwhy);
     if (s->cp.has_plane) s->plane_mu = s->hm.geom_friction[3 * (size_t)s->cp.plane_geom];
     if (!s->cp.geom.empty()) {
@@ -756,6 +757,7 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   REQUIRE_SIM(s);
   // mj_resetData: qpos := qpos0, qvel := 0, ctrl := 0, time := 0; reset_callbacks: timestamps := 0
   std::vector<double> z((size_t)s->n * 32, 0.0);
+  static_assert(kBoxState - kBoxX <= 32, "the zero block covers the coupled solve's warm start");
   std::vector<double> q0 = tile(s->dm.qpos0, s->nl, s->n);
   int rc = scatter_host(s, field_of(s, "qpos"), s->nl, q0.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "qpre"), s->nl, q0.data(), mask);
@@ -770,6 +772,10 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
     for (int e = 0; e < s->n; ++e)
       for (int k = 0; k < 7; ++k) b0[(size_t)e * kBoxState + k] = b0[(size_t)e * kBoxState + kBoxPre + k] = s->box.qpos0[k];
     rc = scatter_host(s, field_of(s, "box"), kBoxState, b0.data(), mask);
+  } else if (!rc && s->box.resolve) {
+    // contacts resolved without a free body: the phantom box's slot carries the coupled solve's warm start from launch to launch
+    // (mjData.qacc_warmstart); mj_resetData zeroes it, so that a reset sim reproduces a fresh one bit for bit (advisor, round 3)
+    rc = scatter_host(s, field_of(s, "box") + kBoxX, kBoxState - kBoxX, z.data(), mask);
   }
   if (!rc && s->rend.ncam > 0) {
     // reset_callbacks (sim.cpp:131-137): the cameras' clocks go back to -seconds_between_calls
@@ -810,6 +816,10 @@ int rcsh_sim_add_robot(rcsh_sim* s, const rcsh_robot_desc* r) {
   for (int c = 0; c < r->n_collision_geoms; ++c) {
     const int g = r->collision_geom_ids[c];
     if (g < 0 || g >= s->hm.ngeom) return fail(RCSH_ERR_NAME, "arm collision geom id out of range");
+    // a collision callback must not be registered on a geom the geom-geom detection cannot see (advisor, round 3): its contacts
+    // with other geoms would silently never raise the flag
+    for (int d : s->cgeoms_dropped)
+      if (d == g) return fail(RCSH_ERR_MODEL, "arm collision geom " + std::to_string(g) + " is not in the contact table (" + s->contact_overflow + "): its geom-geom collisions would go undetected");
     for (size_t k = 0; k < s->cp.geom.size(); ++k)
       if (s->cp.geom[k] == g) s->cp_class[k] |= 1u;
     for (auto& cg : s->cgeoms)
@@ -995,6 +1005,8 @@ int rcsh_sim_add_gripper(rcsh_sim* s, const rcsh_gripper_desc* g) {
   for (int c = 0; c < g->n_collision_geoms; ++c) {
     const int gid = g->collision_geom_ids[c];
     if (gid < 0 || gid >= s->hm.ngeom) return fail(RCSH_ERR_NAME, "gripper collision geom id out of range");
+    for (int d : s->cgeoms_dropped)
+      if (d == gid) return fail(RCSH_ERR_MODEL, "gripper collision geom " + std::to_string(gid) + " is not in the contact table (" + s->contact_overflow + "): its geom-geom collisions would go undetected");
     for (auto& cg : s->cgeoms)
       if (cg.geom_id == gid) cg.cls |= 16;
     bool ignored = false;
@@ -1169,6 +1181,17 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
   if (int rc = upload_boxtask(s)) return rc;
   return upload_contact_table(s);
 }
+int rcsh_sim_contact_table_dropped(rcsh_sim* s, int32_t* geom_ids, int32_t capacity, int32_t* count, char* reason, size_t reason_capacity) {
+  REQUIRE_SIM(s);
+  if (count) *count = (int32_t)s->cgeoms_dropped.size();
+  for (int i = 0; geom_ids && i < capacity && i < (int)s->cgeoms_dropped.size(); ++i) geom_ids[i] = s->cgeoms_dropped[i];
+  if (reason && reason_capacity > 0) {
+    std::strncpy(reason, s->contact_overflow.c_str(), reason_capacity - 1);
+    reason[reason_capacity - 1] = 0;
+  }
+  return RCSH_OK;
+}
+
 int rcsh_sim_reset_free_box(rcsh_sim* s) {
   REQUIRE_SIM(s);
   if (!s->box.present) return fail(RCSH_ERR_STATE, "no free box attached: call rcsh_sim_add_free_box first");
@@ -1592,11 +1615,19 @@ int rcsh_render_pending(rcsh_sim* s, int32_t* count) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   // more frames due in one launch than the schedule holds: the records beyond its capacity were not written (the newest are
   // lost); the stepping itself is unaffected, so this is a count for the host to warn about, not an error after the fact
+  bool clamped = false;
   for (int e = 0; e < s->n; ++e)
     if (count[e] > s->rend.capacity) {
       s->rend_dropped += count[e] - s->rend.capacity;
       count[e] = s->rend.capacity;
+      clamped = true;
     }
+  if (clamped) {
+    // the device-side counters outlive this call (observation-only launches keep them, and so does a second pending / collect
+    // without a stepping launch in between): write the clamped counts back, so that an overflow is counted ONCE (advisor, round 3)
+    HIP_TRY(hipMemcpyAsync(s->rend.count, count, sizeof(int32_t) * s->n, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   return RCSH_OK;
 }
 

@@ -58,6 +58,16 @@ class Sim:
         desc, self._keep = _lib.make_model_desc(self.model)
         self._h = C.c_void_p()
         _lib.check(self._L.rcsh_sim_create(C.byref(desc), self.n_envs, self.device, C.byref(self._h)))
+        # collision geoms beyond the contact table's capacity are invisible to geom-geom detection: say so (an obstacle no callback
+        # list names would still count for SimRobot::collision_callback in the reference); listing one of them as a collision
+        # geom of SimRobot / SimGripper is refused by the library
+        self.undetected_collision_geoms = self._contact_table_dropped()
+        if self.undetected_collision_geoms:
+            import warnings
+
+            names = [self.model.geom_names[g] or f"#{g}" for g in self.undetected_collision_geoms]
+            warnings.warn(f"collision geoms {names} exceed the contact table's capacity ({self._contact_table_reason}): their collisions "
+                          "with other geoms are NOT detected (the floor test still sees them)", RuntimeWarning, stacklevel=2)
         # Contacts of the robot's collision geoms (with the floor, with a free body): RESOLVED by default where there is
         # something to manipulate (scenes with a free body: the pick-up task), DETECTED only (collision flags, as the
         # callbacks need them) in scenes without -- there the contact-capable kernel costs the no-contact rollout ~15 %, so it
@@ -74,6 +84,16 @@ class Sim:
         self._cfg = SimConfig()
         if cfg is not None:
             self.set_config(cfg)
+
+    def _contact_table_dropped(self) -> list[int]:
+        import numpy as np
+
+        count = C.c_int32(0)
+        ids = np.zeros(64, dtype=np.int32)
+        reason = C.create_string_buffer(256)
+        _lib.check(self._L.rcsh_sim_contact_table_dropped(self._h, ids.ctypes.data_as(C.POINTER(C.c_int32)), 64, C.byref(count), reason, 256))
+        self._contact_table_reason = reason.value.decode()
+        return [int(g) for g in ids[: min(count.value, 64)]]
 
     @staticmethod
     def resolves_robot_contacts(model: Model) -> bool:

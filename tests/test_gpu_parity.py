@@ -1242,14 +1242,27 @@ def test_contact_table_capacity_is_fatal_only_when_contacts_are_resolved(kernel,
     for extra in ("collision_vertices.npz", "render_hulls.npz"):
         shutil.copy(os.path.join(os.path.dirname(SCENE), extra), tmp_path)
     cfg = default_sim_robot_cfg("fr3_empty_world")
-    simu = S.Sim(str(scene), S.SimConfig(), n_envs=4)
+    # (advisor, round 3) the overflow is not silent for DETECTION either: the host is told which geoms geom-geom detection
+    # cannot see and warns, and a collision callback cannot be registered on one of them
+    with pytest.warns(RuntimeWarning, match="table_block"):
+        simu = S.Sim(str(scene), S.SimConfig(), n_envs=4)
+    assert [simu.model.geom_names[g] for g in simu.undetected_collision_geoms] == ["table_block"]
     robot = S.SimRobot(simu, None, cfg)
     robot.set_joint_position(np.tile(cfg_home(robot), (4, 1)))
     simu.step_until_convergence()
     assert simu.is_converged().all()
     simu.close()
-    with pytest.raises(RuntimeError, match="box geoms"):
+    with pytest.warns(RuntimeWarning), pytest.raises(RuntimeError, match="box geoms"):
         S.Sim(str(scene), S.SimConfig(), n_envs=4, resolve_robot_contacts=True)
+    import copy
+
+    bad = copy.deepcopy(cfg)
+    bad.arm_collision_geoms = list(bad.arm_collision_geoms) + ["table_block"]
+    with pytest.warns(RuntimeWarning):
+        simu = S.Sim(str(scene), S.SimConfig(), n_envs=4)
+    with pytest.raises(RuntimeError, match="not in the contact table"):
+        S.SimRobot(simu, None, bad)
+    simu.close()
 
 
 def cfg_home(robot):

@@ -1,0 +1,83 @@
+"""GPU tests added in round 4 (through the C-ABI; the oracle is the checker)."""
+
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _floor_targets(n, seed):
+    rng = np.random.default_rng(seed)
+    tgt = np.tile([0, 1.78, 0, -1.45, 0, 0, 0], (n, 1)) + rng.uniform(-0.15, 0.15, (n, 7)) * (np.arange(n) > 0)[:, None]
+    return np.clip(tgt, [-2.7, -1.78, -2.9, -3.04, -2.8, 0.55, -3.0], [2.7, 1.78, 2.9, -0.16, 2.8, 4.5, 3.0])
+
+
+def test_sim_reset_reproduces_a_fresh_sim_with_resolved_contacts_and_no_free_body():
+    """Advisor (round 3, low): with robot contacts resolved in a scene WITHOUT a free body the coupled solve's warm start lives in
+    the phantom box's slot of the state and outlives a launch (mjData.qacc_warmstart); Sim.reset must zero it (mj_resetData),
+    so that an episode after Sim.reset is bit-identical to the same episode on a fresh sim."""
+    from rcs_amd import sim as S
+    from rcs_amd.envs import default_sim_gripper_cfg, default_sim_robot_cfg
+
+    n = 6
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+
+    def episode(simu, robot, grip):
+        simu.reset(); robot.reset(); grip.reset()
+        robot.set_joint_position(_floor_targets(n, 3))
+        out = []
+        for _ in range(5):
+            simu.step(120)
+            out.append((simu.qpos.copy(), simu.qvel.copy()))
+        return out
+
+    def make():
+        simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n, resolve_robot_contacts=True)
+        return simu, S.SimRobot(simu, None, cfg), S.SimGripper(simu, default_sim_gripper_cfg())
+
+    a = make()
+    first = episode(*a)
+    assert np.abs(first[-1][0][:, :7] - _floor_targets(n, 3)).max() > 0.05  # the floor holds the arm: the coupled solve ran
+    again = episode(*a)  # the same episode after Sim.reset on a sim that has been in contact
+    a[0].close()
+    b = make()
+    fresh = episode(*b)
+    b[0].close()
+    for (q0, v0), (q1, v1), (q2, v2) in zip(first, again, fresh):
+        assert np.array_equal(q0, q2) and np.array_equal(v0, v2)
+        assert np.array_equal(q1, q2) and np.array_equal(v1, v2), "Sim.reset left state of the previous episode behind"
+
+
+def test_dropped_render_records_are_counted_once():
+    """Advisor (round 3, low): rcsh_render_pending accounts the records of a launch that did not fit the schedule's capacity;
+    asking again without a stepping launch in between (collect after an observation pass) must not count them a second time."""
+    from rcs_amd import _lib
+    from rcs_amd import sim as S
+    from rcs_amd.camera import SimCameraConfig, SimCameraSet
+    from rcs_amd.envs import default_sim_robot_cfg
+
+    n = 3
+    cfg = default_sim_robot_cfg("fr3_empty_world")
+    simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(async_control=True), n_envs=n)
+    S.SimRobot(simu, None, cfg)
+    cs = SimCameraSet(simu, {"wrist": SimCameraConfig(identifier="wrist_0", frame_rate=250, resolution_width=8, resolution_height=8)},
+                      physical_units=True, render_on_demand=False)
+    L, h = simu._L, simu._h
+    ids = np.array([cs._ids["wrist"]], dtype=np.int32)
+    per = np.array([1.0 / 250], dtype=np.float64)
+    _lib.check(L.rcsh_sim_set_render_schedule(h, _lib.ptr(ids), _lib.ptr(per), 1, 2))  # room for two records per launch
+    _lib.check(L.rcsh_sim_step(h, 40))  # a frame every other substep: ~20 due, 2 kept
+    count = np.zeros(n, dtype=np.int32)
+    dropped = C.c_int64(0)
+    _lib.check(L.rcsh_render_pending(h, _lib.ptr(count)))
+    _lib.check(L.rcsh_render_dropped(h, C.byref(dropped)))
+    first = dropped.value
+    assert (count == 2).all() and first >= n * 10, (count, first)
+    simu.qpos  # (an accessor launch in between)
+    _lib.check(L.rcsh_render_pending(h, _lib.ptr(count)))
+    _lib.check(L.rcsh_render_dropped(h, C.byref(dropped)))
+    assert (count == 2).all() and dropped.value == first, (count, first, dropped.value)
+    simu.close()

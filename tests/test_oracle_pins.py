@@ -72,6 +72,35 @@ def test_interpolate_full_progress(P):
     assert np.array_equal(r.rotation_m(), np.eye(3)) and np.array_equal(r.translation(), [1.0, 1.0, 1.0])
 
 
+def test_compiled_pose_constructors_dispatch_by_shape_positionally():
+    """The reference tells its Pose / RPY overloads apart by Eigen's fixed-size argument types (src/pybind/rcs.cpp:248-262): a 3-vector
+    is a translation, a 4-vector a quaternion, 3 x 3 a rotation, 4 x 4 a pose matrix -- also when passed POSITIONALLY.  The compiled
+    binding's casters must refuse a wrong shape so that pybind moves on to the next overload (advisor, round 3)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "extensions", "rcs_hip"))
+    from rcs_hip._core import common as c
+
+    Pc = c.Pose
+    q = np.array([0.0, 0.0, np.sin(0.3), np.cos(0.3)])
+    t = np.array([1.0, 2.0, 3.0])
+    rot = Pc(quaternion=q).rotation_m()
+    assert np.array_equal(Pc(t).translation(), t) and np.array_equal(Pc(t).rotation_q(), [0, 0, 0, 1])
+    assert np.allclose(Pc(q).rotation_q(), q) and np.array_equal(Pc(q).translation(), [0, 0, 0])
+    assert Pc(rot).is_close(Pc(quaternion=q)) and Pc(np.eye(4)).is_close(Pc())
+    assert Pc(q, t).is_close(Pc(quaternion=q, translation=t)) and Pc(rot, t).is_close(Pc(quaternion=q, translation=t))
+    rpy = np.array([0.1, -0.2, 0.3])
+    assert Pc(rpy, t).is_close(Pc(rpy_vector=rpy, translation=t)) and Pc(c.RPY(*rpy), t).is_close(Pc(rpy_vector=rpy, translation=t))
+    assert Pc(c.RPY(*rpy)).is_close(Pc(rpy_vector=rpy, translation=np.zeros(3)))
+    assert Pc([1.0, 2.0, 3.0]).is_close(Pc(t)) and Pc(t.reshape(3, 1)).is_close(Pc(t))  # sequences / column vectors, as Eigen's caster takes them
+    assert c.RPY(rpy).yaw == 0.3 and c.RPY([0.1, -0.2, 0.3]).pitch == -0.2
+    for bad in (np.zeros(5), np.zeros((3, 4)), np.zeros((2, 2))):
+        with pytest.raises(TypeError):
+            Pc(bad)
+    with pytest.raises(TypeError):
+        Pc(np.zeros(4), np.zeros(4))
+
+
 # ---- (iv) home_m: xyzrpy round trip (test_common.py:198-218)
 def test_home_m_rpy_round_trip(P):
     home_m = np.array(PINS["home_m"])
