@@ -472,6 +472,16 @@ def main() -> None:
         no_exchange_value = world * n * args.steps / float(tt.item())
         exchange = saved_exchange
     mean_sub = float(sub.download().astype(np.float64).mean())
+    # Environments found in a contact the running configuration does not resolve, by the end of the timed region (the sticky flag
+    # of the end-of-launch check, csrc/check_team.h; cleared by the reset before the W warmup steps).  The words "no contacts" in
+    # config.workload are DERIVED from this count being zero on every rank.
+    contacts_seen = 0
+    for e_ in envs:
+        contacts_seen += int(e_.sim.contact_unresolved().sum())
+    if world > 1:
+        tc = torch.tensor([contacts_seen], dtype=torch.int64)
+        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        contacts_seen = int(tc.item())
     finite = bool(np.isfinite(obs_host).all())
     if task_out is not None:
         finite = finite and bool(np.isfinite(task_out.download()).all())
@@ -492,7 +502,9 @@ def main() -> None:
         substeps_per_launch = mean_sub * env.n_envs
         traffic = None
         tj_extra = {}
-        tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r4_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
         headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
         if os.path.exists(tpath) and headline:  # the PMC passes profiled exactly this workload (profiles/run_profile.sh)
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch
@@ -518,7 +530,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, "
-                             + ("robot contacts resolved, IK off" if args.robot == "xarm7_pick" else "no contacts, IK off")
+                             + ("robot contacts resolved, IK off" if args.robot == "xarm7_pick" else
+                                ("no contacts (checked: 0 environments touched the floor or themselves), IK off" if contacts_seen == 0 else
+                                 f"{contacts_seen} environments ran into a contact the lean kernels do not resolve (flagged: info.contact_unresolved), IK off"))
                              if args.control == "joints" else
                              f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
                              ).replace("fr3_empty_world", (mixed_label if mixed else SCENE_LABEL[args.robot]) if args.task == "none" else
@@ -532,6 +546,7 @@ def main() -> None:
                                  f"({len(cam_out) * n * int(args.resolution.split('x')[0]) * int(args.resolution.split('x')[1]) / (elapsed / args.steps) / 1e9:.2f} G rays/s incl. the physics)") if cam_out else None,
                 "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"torch.distributed {args.dist_backend} all_gather")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
+                "contacts_seen": contacts_seen,
                 "obs_finite": finite,
                 "value_without_exchange": no_exchange_value,
                 "clock_warmup": (f"{clock_warmup_launches} untimed launches over {args.clock_warmup_ms:g} ms before the W warmup steps, then a reset "
@@ -544,9 +559,13 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": "rocprofv3 FETCH_SIZE x 2 (gfx950: counts half the bytes of this access pattern, calibrated in profiles/r2_hbm_calib) + WRITE_SIZE, separate PMC passes (profiles/r3_traffic.json, profiles/r3_v1)" if traffic else None,
+                "traffic_source": (f"rocprofv3 FETCH_SIZE x 2 (gfx950: counts half the bytes of this access pattern, calibrated in profiles/r2_hbm_calib) + WRITE_SIZE, "
+                                   f"separate PMC passes (profiles/{os.path.basename(tpath)}: {tj_extra.get('source', 'profiles/run_profile.sh')})") if traffic else None,
                 "kernel": "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
                           + (" + free box" if args.task != "none" or args.robot in ("xarm7_box", "xarm7_pick") else ""),
+                # what the region's event pair brackets: every launch of a step on the handle's stream, not the stepping kernel alone
+                "timed_region": "k_run_team" + (" + k_cartesian_team" if args.control == "cartesian" else "") + (" + the depth frames' kernels (k_link_frames, k_shape_frames, k_hull_views, k_render_depth)" if cam_out else "")
+                                + (" + the reset launches" if episode else "") + ", dispatch gaps included",
                 "kernel_ms_avg": kernel_ms,
                 "launches_timed": int(launches.value),
                 "algorithmic_bytes_per_launch": algo_bytes,

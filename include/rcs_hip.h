@@ -291,6 +291,12 @@ typedef struct rcsh_contact_options {
   int32_t resolve_robot_contacts, reserved;
 } rcsh_contact_options;
 int rcsh_sim_set_contact_options(rcsh_sim* sim, const rcsh_contact_options* options);
+/* [N] flags: the environment's geoms were found in a contact this configuration does not resolve -- robot <-> floor in scenes
+ * that only detect contacts (the default without a free body), robot <-> robot everywhere -- at the end of a stepping launch,
+ * since its last rcsh_sim_reset.  MuJoCo resolves every contact of d->contact in every mj_step2 (reference src/sim/sim.cpp:
+ * 108-115), so from that launch on the environment's trajectory is not the reference's; the same bit is byte 7 of an
+ * env-step's info row.  Checked once per launch on the position the next position stage will see (csrc/check_team.h). */
+int rcsh_sim_contact_unresolved(rcsh_sim* sim, uint8_t* unresolved);
 /* Collision geoms of the scene that exceed the contact table's capacity (32 geoms, 10 boxes, 152 hull vertices) are left out of
  * GEOM-GEOM detection (the floor test still sees them): their mjModel ids (up to `capacity`), how many there are, and why.
  * rcsh_sim_add_robot / rcsh_sim_add_gripper refuse a collision geom that is on this list; the Python host warns about the
@@ -316,7 +322,9 @@ int rcsh_sim_set_state(rcsh_sim* sim, const void* blob);
  * Wrapper stack restated in the kernel (reference python/rcs/envs/base.py:246-304,469-565,680-735;
  * envs/sim.py:49-76,119-131).  Observation row: tquat[7] joints[dof] xyzrpy[6] gripper[1]
  * (obs_width = 14 + dof); info row (uint8[8]): collision, ik_success, is_sim_converged, is_grasped,
- * truncated, gripper_collision, 0, 0; gripper_width[N] (double). */
+ * truncated, gripper_collision, contact_overflow, contact_unresolved (the last two: no reference counterpart -- a contact
+ * phase ran out of slots / the environment was found in a contact this configuration does not resolve, sticky until reset,
+ * see rcsh_sim_contact_unresolved); gripper_width[N] (double). */
 int rcsh_env_configure(rcsh_sim* sim, const rcsh_env_desc* env);
 int rcsh_env_obs_width(const rcsh_sim* sim);
 int rcsh_env_action_width(const rcsh_sim* sim);

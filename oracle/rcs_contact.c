@@ -598,7 +598,7 @@ static void self_collide(const orc_model* m, orc_data* d) {
         }
         continue;
       }
-      if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->nself++; }
+      if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->self_depth[d->nself] = depth; d->nself++; }
     }
   }
 }

@@ -220,6 +220,7 @@ typedef struct orc_data {
   int sep_n;
   int sep_pair[ORC_MAXSEP][2];
   double sep_dir[ORC_MAXSEP][3];
+  double self_depth[ORC_MAXSELF]; /* penetration depth of self contact i (MPR) */
   orc_box_data box;
 } orc_data;
 

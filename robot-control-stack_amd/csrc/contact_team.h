@@ -244,14 +244,27 @@ RCSH_D void nofma_mulTv(const double* R, const double* v, double* o) {
 #define cross3 nofma_cross3
 #define mulmv nofma_mulmv
 #define mulTv nofma_mulTv
+// (frame and size by VALUE: as pointers to the caller's local arrays they pinned those arrays -- 24 doubles per pair -- in private
+// memory, the only scratch the flag-only kernels had)
 struct Shape {
   int type;              // 0 hull, 1 box, 2 capsule
-  const double *p, *R;   // world frame
-  const double* size;
+  double p[3], R[9];     // world frame
+  double size[3];
   const double* verts;
   int nvert;
   double center[3];
 };
+RCSH_D Shape make_shape(int type, const double* p, const double* R, const double* size, const double* verts, int nvert) {
+  Shape s;
+  s.type = type;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { s.p[k] = p[k]; s.size[k] = size[k]; s.center[k] = p[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s.R[k] = R[k];
+  s.verts = verts;
+  s.nvert = nvert;
+  return s;
+}
 // Support ties are broken by RULE, not by round-off (oracle: SUPPORT_TIE, where the reason is written down): vertices within
 // kSupportTie of the largest projection count as tied and the lowest index wins; a box / capsule axis whose direction
 // component is above -kSupportTie takes its positive end.
@@ -356,13 +369,18 @@ RCSH_D void portal_dir(const MprPt& p1, const MprPt& p2, const MprPt& p3, double
   const double l = sqrt(dot3(dir, dir));
   if (l > kMinVal) { dir[0] /= l; dir[1] /= l; dir[2] /= l; }
 }
+// (which of the portal's three points the new one replaces is decided at run time: written as selects per component -- assigning
+// whole structs behind the branches made the compiler address p1 / p2 / p3 through a pointer and keep all of them in scratch)
 RCSH_D void expand_portal(const MprPt& p0, MprPt& p1, MprPt& p2, MprPt& p3, const MprPt& p4) {
   double c[3];
   cross3(p4.v, p0.v, c);
-  if (dot3(p1.v, c) > 0) {
-    if (dot3(p2.v, c) > 0) p1 = p4; else p3 = p4;
-  } else {
-    if (dot3(p3.v, c) > 0) p2 = p4; else p1 = p4;
+  const bool a1 = dot3(p1.v, c) > 0, a2 = dot3(p2.v, c) > 0, a3 = dot3(p3.v, c) > 0;
+  const bool r1 = a1 ? a2 : !a3, r3 = a1 && !a2, r2 = !a1 && a3;  // replace p1 / p3 / p2 (exactly one holds)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    p1.v[k] = r1 ? p4.v[k] : p1.v[k]; p1.v1[k] = r1 ? p4.v1[k] : p1.v1[k]; p1.v2[k] = r1 ? p4.v2[k] : p1.v2[k];
+    p2.v[k] = r2 ? p4.v[k] : p2.v[k]; p2.v1[k] = r2 ? p4.v1[k] : p2.v1[k]; p2.v2[k] = r2 ? p4.v2[k] : p2.v2[k];
+    p3.v[k] = r3 ? p4.v[k] : p3.v[k]; p3.v1[k] = r3 ? p4.v1[k] : p3.v1[k]; p3.v2[k] = r3 ? p4.v2[k] : p3.v2[k];
   }
 }
 RCSH_D double origin_tri_dist2(const double* a, const double* b, const double* c, double* witness) {
@@ -386,8 +404,13 @@ RCSH_D double origin_tri_dist2(const double* a, const double* b, const double* c
 }
 // Returns 0 when the shapes do not overlap; dir_out is then a direction along which the support of A - B is not positive
 // (a separating direction), or the zero vector where the refinement gave up without one.
-template <bool TEAM>
+// WANT: what the caller reads.  kMprFull: depth, direction, position.  kMprOverlap: nothing but "do they overlap" (the flag-only
+// detection): depth and position are not computed -- the third phase of the refinement, which only sharpens them, is skipped --
+// and may be null.  kMprDepth: the depth too, not the position (the unresolved-contact check: pos may be null).
+constexpr int kMprFull = 0, kMprOverlap = 1, kMprDepth = 2;
+template <bool TEAM, int WANT = kMprFull>
 RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
+  constexpr bool OVERLAP_ONLY = WANT == kMprOverlap;
   constexpr double kTol = 1e-6;
   constexpr int kIter = 50;
   MprPt p0, p1, p2, p3, p4;
@@ -401,7 +424,9 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   cross3(p0.v, p1.v, dir);
   l = sqrt(dot3(dir, dir));
   if (l < 1e-12) {
+    if (OVERLAP_ONLY) return 1;
     *depth = sqrt(dot3(p1.v, p1.v));
+    if (WANT == kMprDepth) return 1;
     const double l0 = sqrt(dot3(p0.v, p0.v));
     for (int k = 0; k < 3; ++k) { dir_out[k] = *depth > kMinVal ? p1.v[k] / *depth : -p0.v[k] / l0; pos[k] = 0.5 * (p1.v1[k] + p1.v2[k]); }
     return 1;
@@ -447,6 +472,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
     }
     expand_portal(p0, p1, p2, p3, p4);
   }
+  if (OVERLAP_ONLY) return 1;  // (the origin is inside the portal: every exit of the loop below reports a penetration)
   for (int it = 0;; ++it) {
     portal_dir(p1, p2, p3, dir);
     mpr_support<TEAM>(A, B, dir, p4);
@@ -456,6 +482,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
       double w[3];
       const double d2 = origin_tri_dist2(p1.v, p2.v, p3.v, w);
       *depth = sqrt(d2);
+      if (WANT == kMprDepth) return 1;
       if (*depth > kMinVal) for (int k = 0; k < 3; ++k) dir_out[k] = w[k] / *depth;
       else for (int k = 0; k < 3; ++k) dir_out[k] = dir[k];
       double bw[4], c[3];
@@ -797,9 +824,8 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
       double Ra[9], pa[3], Rb[9], pb[3];
       self_geom_world(a, F, Ra, pa);
       self_geom_world(b, F, Rb, pb);
-      Shape A, B;
-      A.type = a.type == 7 ? 0 : a.type == 6 ? 1 : 2; A.p = pa; A.R = Ra; A.size = a.size; A.verts = stage; A.nvert = a.vert_num;
-      B.type = b.type == 7 ? 0 : b.type == 6 ? 1 : 2; B.p = pb; B.R = Rb; B.size = b.size; B.verts = stage + na; B.nvert = b.vert_num;
+      Shape A = make_shape(a.type == 7 ? 0 : a.type == 6 ? 1 : 2, pa, Ra, a.size, stage, a.vert_num);
+      Shape B = make_shape(b.type == 7 ? 0 : b.type == 6 ? 1 : 2, pb, Rb, b.size, stage + na, b.vert_num);
       if (a.type == 7) { mulmv(Ra, a.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
       else { A.center[0] = pa[0]; A.center[1] = pa[1]; A.center[2] = pa[2]; }
       if (b.type == 7) { mulmv(Rb, b.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
@@ -829,8 +855,8 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
       TEAM_MARK(38)
       if (apart) { TEAM_COUNT(39) }
       if (!apart) {
-        double depth, dir[3], pos[3];
-        if (mpr_penetration<true>(A, B, &depth, dir, pos)) mine |= (uint32_t)pr.cls;
+        double dir[3];
+        if (mpr_penetration<true, kMprOverlap>(A, B, nullptr, dir, nullptr)) mine |= (uint32_t)pr.cls;
         else {
           double dl[3];
           mulTv(LR, dir, dl);
@@ -1220,8 +1246,8 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
         if (cg.type == 6) {
           nB = dev_box_box(gp, gR, cg.size, bp, bR, bsz, &cpos[0][0], cn, cdist, &ar.stage[0][0] + 48 * cg.box_slot);
         } else {
-          Shape S{cg.type == 7 ? 0 : 2, gp, gR, cg.size, V, cg.vert_num, {gp[0], gp[1], gp[2]}};
-          Shape Bx{1, bp, bR, bsz, nullptr, 0, {bp[0], bp[1], bp[2]}};
+          Shape S = make_shape(cg.type == 7 ? 0 : 2, gp, gR, cg.size, V, cg.vert_num);
+          Shape Bx = make_shape(1, bp, bR, bsz, nullptr, 0);
           if (cg.type == 7) {
             double c[3];
             mulmv(gR, cg.center, c);
@@ -1315,8 +1341,8 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       double hdepth = 0, hn[3] = {0, 0, 0}, hc[3] = {0, 0, 0};
       if (do_box) {
         const double bsz[3] = {b.size[0], b.size[1], b.size[2]};
-        Shape S{0, gp, gR, hg.size, hv, nv, {gp[0], gp[1], gp[2]}};
-        Shape Bx{1, bp, bR, bsz, nullptr, 0, {bp[0], bp[1], bp[2]}};
+        Shape S = make_shape(0, gp, gR, hg.size, hv, nv);
+        Shape Bx = make_shape(1, bp, bR, bsz, nullptr, 0);
         double c[3];
         mulmv(gR, hg.center, c);
         for (int k = 0; k < 3; ++k) S.center[k] = c[k] + gp[k];

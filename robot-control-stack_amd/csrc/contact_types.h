@@ -41,6 +41,23 @@ struct SelfPair {
   double rot0[9], h0[3], rot1[9], h1[3];
 };
 
+// The once-per-launch check for contacts nobody resolves (check_team.h): EVERY geom pair MuJoCo's filters let collide -- whether a
+// collision callback reacts to it or not -- grouped by the pair of bodies the geoms ride on, so that one bounding-sphere test per
+// body pair rules out all its geom pairs while the two links are far apart.  Body index: link + 1 (0: welded to the world).
+struct CheckBodyPair {
+  int16_t ba, bb;    // the two bodies
+  int16_t adr, num;  // their geom pairs: CheckTable::pairs[adr .. adr + num)
+};
+constexpr int kMaxCheckBodies = 13;  // kMaxLinks + 1
+struct CheckTable {
+  const SelfPair* pairs;
+  const CheckBodyPair* bpairs;
+  int32_t npair, nbpair;
+  int32_t plane_points;  // the scene has a floor plane and collision geoms with sample points to test against it
+  int32_t pad;
+  double bsphere[kMaxCheckBodies][4];  // bounding sphere of a body's collision geoms, body frame (world frame for body 0)
+};
+
 struct ContactTable {
   const ContactGeom* geoms;
   const double* verts;   // [nvert][3] hull vertices, geom frame

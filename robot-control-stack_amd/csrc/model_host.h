@@ -70,9 +70,11 @@ bool build_hull_edges(const double* planes, int nplanes, std::vector<HullEdge>& 
 template <class F>
 bool dispatch_topology(int narm, bool grip, F&& fn) {
   if (narm == 7 && grip) { fn(Topo<7, true>{}); return true; }
+#ifndef RCSH_DEV_ONLY_FR3  // (development builds define it: the FR3 + hand archetype alone, minutes -> seconds)
   if (narm == 7 && !grip) { fn(Topo<7, false>{}); return true; }
   if (narm == 6 && !grip) { fn(Topo<6, false>{}); return true; }
   if (narm == 5 && grip) { fn(Topo<5, true>{}); return true; }
+#endif
   return false;
 }
 

@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +64,13 @@ struct rcsh_sim {
   std::vector<SelfPair> pairs;
   double self_lever[12] = {0};       // contact_types.h: ContactTable::self_lever
   double* d_cverts = nullptr;
+  // the once-per-launch check for contacts nobody resolves (check_team.h): every geom pair MuJoCo's filters let collide, by body pair
+  std::vector<SelfPair> chk_pairs;
+  std::vector<CheckBodyPair> chk_bpairs;
+  double chk_bsphere[kMaxCheckBodies][4] = {{0}};
+  SelfPair* d_chk_pairs = nullptr;
+  CheckBodyPair* d_chk_bpairs = nullptr;
+  bool contact_check = true;  // RCSH_CONTACT_CHECK=0 switches the check off (measurements of its cost)
   double plane_mu = 1.0;
   std::vector<int> act_slot;
   int narm = 0, nl = 0, nu = 0;
@@ -196,6 +204,13 @@ Params make_params(rcsh_sim* s) {
   for (int k = 0; k < 3; ++k) P.ctab.plane_n[k] = s->cp.plane_n[k];
   P.ctab.plane_d = s->cp.plane_d;
   P.ctab.plane_mu = s->plane_mu;
+  P.chk.pairs = s->d_chk_pairs;
+  P.chk.bpairs = s->d_chk_bpairs;
+  P.chk.npair = s->contact_check ? (int)s->chk_pairs.size() : 0;
+  P.chk.nbpair = s->contact_check ? (int)s->chk_bpairs.size() : 0;
+  P.chk.plane_points = s->contact_check && P.coll.has_plane ? 1 : 0;
+  P.chk.pad = 0;
+  std::memcpy(P.chk.bsphere, s->chk_bsphere, sizeof(P.chk.bsphere));
   return P;
 }
 
@@ -231,9 +246,9 @@ int upload_coll_classes(rcsh_sim* s) {
 // (SimRobot.cpp:172-182: either geom is an arm collision geom; SimGripper.cpp:108-130: not finger-finger, either geom is a
 // gripper collision geom, geom[1] is not in the ignore list -- quirk Q6).  Pairs nobody reacts to are dropped.
 constexpr int kSelfStageVertsHost = 304;  // contact_team.h: kSelfStageVerts
-void build_self_pairs(rcsh_sim* s) {
-  s->pairs.clear();
-  if (std::getenv("RCSH_DEBUG_NO_SELF_PAIRS")) return;  // development switch: what the pair tests cost
+// all pairs MuJoCo's filters admit; `reacting_only`: drop those no collision callback reacts to (cls == 0)
+std::vector<SelfPair> list_geom_pairs(const rcsh_sim* s, bool reacting_only) {
+  std::vector<SelfPair> out;
   const int ng = (int)s->cgeoms.size();
   auto parent = [&](int link) { return link < s->narm ? link - 1 : s->narm - 1; };
   for (int i = 0; i < ng; ++i)
@@ -248,7 +263,7 @@ void build_self_pairs(rcsh_sim* s) {
       int cls = 0;
       if ((g0.cls | g1.cls) & 1) cls |= 1;
       if (!((g0.cls & 4) && (g1.cls & 4)) && ((g0.cls | g1.cls) & 16) && !(g1.cls & 8)) cls |= 2;
-      if (!cls) continue;
+      if (!cls && reacting_only) continue;
       SelfPair pr{};
       pr.g0 = (int16_t)(swap ? j : i); pr.g1 = (int16_t)(swap ? i : j);
       pr.l0 = (int16_t)g0.link; pr.l1 = (int16_t)g1.link;
@@ -275,8 +290,56 @@ void build_self_pairs(rcsh_sim* s) {
       };
       bounds(g0, pr.c0, pr.r0, pr.rot0, pr.h0);
       bounds(g1, pr.c1, pr.r1, pr.rot1, pr.h1);
-      s->pairs.push_back(pr);
+      out.push_back(pr);
     }
+  return out;
+}
+void build_self_pairs(rcsh_sim* s) {
+  s->pairs.clear();
+  if (std::getenv("RCSH_DEBUG_NO_SELF_PAIRS")) return;  // development switch: what the pair tests cost
+  s->pairs = list_geom_pairs(s, true);
+}
+
+// The tables of the end-of-launch check for contacts nobody resolves (check_team.h): ALL admitted geom pairs, grouped by the pair
+// of bodies (link + 1; 0: welded to the world) they belong to, and a bounding sphere per body over its geoms' bounding spheres.
+void build_check_table(rcsh_sim* s) {
+  s->chk_pairs.clear();
+  s->chk_bpairs.clear();
+  std::memset(s->chk_bsphere, 0, sizeof(s->chk_bsphere));
+  std::vector<SelfPair> all = list_geom_pairs(s, false);
+  auto key = [](const SelfPair& p) { const int a = std::min(p.l0, p.l1) + 1, b = std::max(p.l0, p.l1) + 1; return a * 64 + b; };
+  std::stable_sort(all.begin(), all.end(), [&](const SelfPair& x, const SelfPair& y) { return key(x) < key(y); });
+  for (size_t i = 0; i < all.size();) {
+    size_t j = i;
+    while (j < all.size() && key(all[j]) == key(all[i])) ++j;
+    CheckBodyPair bp{};
+    bp.ba = (int16_t)(key(all[i]) / 64); bp.bb = (int16_t)(key(all[i]) % 64);
+    bp.adr = (int16_t)i; bp.num = (int16_t)(j - i);
+    s->chk_bpairs.push_back(bp);
+    i = j;
+  }
+  s->chk_pairs = all;
+  // per body: centre = mean of its geoms' box centres, radius = the farthest reach of a geom's bounding sphere from there
+  for (int b = 0; b < kMaxCheckBodies; ++b) {
+    double c[3] = {0, 0, 0};
+    int cnt = 0;
+    auto each = [&](auto&& fn) {
+      for (const auto& p : all) {
+        if (p.l0 + 1 == b) fn(p.c0, p.r0);
+        if (p.l1 + 1 == b) fn(p.c1, p.r1);
+      }
+    };
+    each([&](const double* gc, double) { for (int k = 0; k < 3; ++k) c[k] += gc[k]; ++cnt; });
+    if (!cnt) continue;
+    for (int k = 0; k < 3; ++k) c[k] /= cnt;
+    double rad = 0;
+    each([&](const double* gc, double gr) {
+      const double d[3] = {gc[0] - c[0], gc[1] - c[1], gc[2] - c[2]};
+      rad = std::max(rad, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + gr);
+    });
+    for (int k = 0; k < 3; ++k) s->chk_bsphere[b][k] = c[k];
+    s->chk_bsphere[b][3] = rad * (1 + 1e-12) + 1e-12;
+  }
 }
 
 // lever[j]: how far one radian of hinge j (one metre of a slide) can move a point of any collision geom downstream of it.
@@ -323,6 +386,15 @@ int upload_contact_table(rcsh_sim* s) {
   if (!s->pairs.empty()) {
     HIP_TRY(hipMalloc(&s->d_pairs, sizeof(SelfPair) * s->pairs.size()));
     HIP_TRY(hipMemcpyAsync(s->d_pairs, s->pairs.data(), sizeof(SelfPair) * s->pairs.size(), hipMemcpyHostToDevice, s->stream));
+  }
+  build_check_table(s);
+  if (s->d_chk_pairs) { HIP_TRY(hipStreamSynchronize(s->stream)); HIP_TRY(hipFree(s->d_chk_pairs)); s->d_chk_pairs = nullptr; }
+  if (s->d_chk_bpairs) { HIP_TRY(hipFree(s->d_chk_bpairs)); s->d_chk_bpairs = nullptr; }
+  if (!s->chk_pairs.empty()) {
+    HIP_TRY(hipMalloc(&s->d_chk_pairs, sizeof(SelfPair) * s->chk_pairs.size()));
+    HIP_TRY(hipMemcpyAsync(s->d_chk_pairs, s->chk_pairs.data(), sizeof(SelfPair) * s->chk_pairs.size(), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMalloc(&s->d_chk_bpairs, sizeof(CheckBodyPair) * s->chk_bpairs.size()));
+    HIP_TRY(hipMemcpyAsync(s->d_chk_bpairs, s->chk_bpairs.data(), sizeof(CheckBodyPair) * s->chk_bpairs.size(), hipMemcpyHostToDevice, s->stream));
   }
   if (!s->d_cgeoms) HIP_TRY(hipMalloc(&s->d_cgeoms, sizeof(ContactGeom) * s->cgeoms.size()));
   HIP_TRY(hipMemcpyAsync(s->d_cgeoms, s->cgeoms.data(), sizeof(ContactGeom) * s->cgeoms.size(), hipMemcpyHostToDevice, s->stream));
@@ -409,6 +481,10 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
     };
     using Y = std::true_type;
     using N = std::false_type;
+#ifdef RCSH_DEV_NO_CONTACT_KERNELS  // development builds: the lean instantiations alone
+    if (s->dm.has_friction) go(Y{}, N{}, N{});
+    else go(N{}, N{}, N{});
+#else
     if (s->box.present && s->box.resolve) {
       // free box + contacts of the robot's geoms (FR3 + hand; xArm7 + gripper: friction rows in the coupled solve):
       // rcsh_sim_add_free_box checked the archetype
@@ -427,6 +503,7 @@ int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
       go(Y{}, N{}, N{});
     else
       go(N{}, N{}, N{});
+#endif
     err = hipGetLastError();
   });
   if (!ok || !launched) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
@@ -464,6 +541,7 @@ int field_of(rcsh_sim* s, const char* name) {
     if (f == "box") return (int)L::BOX;
     if (f == "qpre") return (int)L::QPRE;
     if (f == "xs") return (int)L::XS;
+    if (f == "sep") return (int)L::SEP;
     return -1;
   });
 }
@@ -644,6 +722,8 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
     if (rc) return cleanup(rc, g_err);
   }
   if (upload_model(s)) return cleanup(RCSH_ERR_DEVICE, g_err);
+  if (const char* cc = std::getenv("RCSH_CONTACT_CHECK")) s->contact_check = std::atoi(cc) != 0;
+  if (upload_contact_table(s)) return cleanup(RCSH_ERR_DEVICE, g_err);  // (the contact check's pair tables exist before any robot is attached)
 #undef HIP_NEW
   *out = s;
   return RCSH_OK;
@@ -658,7 +738,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   if (s->order_ev) hipEventDestroy(s->order_ev);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
-  hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs);
+  hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_pairs); hipFree(s->d_chk_bpairs);
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_rcolours); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
   hipFree(s->d_redge_planes); hipFree(s->d_redge_verts); hipFree(s->d_rviews);
@@ -766,7 +846,8 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   if (!rc) rc = scatter_host(s, field_of(s, "time"), 1, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "cb"), 6, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "xs"), s->nl, z.data(), mask);  // (mj_resetData: qacc_warmstart := 0)
-  if (!rc) rc = flags_update_host(s, 0, kContactOverflow, mask);
+  if (!rc) rc = flags_update_host(s, 0, kContactOverflow | kContactUnresolved, mask);
+  if (!rc) rc = scatter_host(s, field_of(s, "sep"), kCheckSep, z.data(), mask);
   if (!rc && s->box.present) {
     std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
     for (int e = 0; e < s->n; ++e)
@@ -1180,6 +1261,10 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
   s->box = b;
   if (int rc = upload_boxtask(s)) return rc;
   return upload_contact_table(s);
+}
+int rcsh_sim_contact_unresolved(rcsh_sim* s, uint8_t* unresolved) {
+  REQUIRE_SIM(s);
+  return flag_host(s, kContactUnresolved, unresolved);
 }
 int rcsh_sim_contact_table_dropped(rcsh_sim* s, int32_t* geom_ids, int32_t capacity, int32_t* count, char* reason, size_t reason_capacity) {
   REQUIRE_SIM(s);
@@ -1890,6 +1975,18 @@ int rcsh_dev_download(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
   return RCSH_OK;
 }
 
+#ifdef RCSH_CHECK_DEBUG
+extern "C" int rcsh_debug_check(int* out64, int clear) {
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(rcsh::g_chk_dbg), sizeof(int) * 64) != hipSuccess) return 1;
+  if (clear) { int z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rcsh::g_chk_dbg), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+extern "C" int rcsh_debug_check_pairs(rcsh_sim* s, int32_t* g0g1 /* [cap][2] */, int32_t cap, int32_t* n, int32_t* nb) {
+  *n = (int)s->chk_pairs.size(); *nb = (int)s->chk_bpairs.size();
+  for (int i = 0; i < *n && i < cap; ++i) { g0g1[2 * i] = s->cgeoms[s->chk_pairs[i].g0].geom_id; g0g1[2 * i + 1] = s->cgeoms[s->chk_pairs[i].g1].geom_id; }
+  return 0;
+}
+#endif
 #ifdef RCSH_PHASE_TIMING
 extern "C" int rcsh_debug_team_cycles(unsigned long long* out16 /* 24 slots */) {
   hipDeviceSynchronize();

@@ -14,6 +14,7 @@
 
 #include "box_team.h"
 #include "contact_team.h"
+#include "check_team.h"
 #include "dyn.h"
 #include "dyn_team.h"
 #include "pose.h"
@@ -38,6 +39,8 @@ enum : uint32_t {
   kGripCmd = 1u << 13,
   kHasLastAction = 1u << 14,
   kContactOverflow = 1u << 15,  // sticky until Sim::reset: a contact phase of this environment ran out of contact / link slots
+  kContactUnresolved = 1u << 16,  // sticky until Sim::reset: the environment's geoms were found in a contact this configuration does
+                                  // not resolve (check_team.h): from then on its trajectory is not what MuJoCo's would be
 };
 
 struct SimCfg {
@@ -79,7 +82,8 @@ struct Lay {
   static constexpr int QPRE = BOX + kBoxState;    // qpos seen by the last mj_step1 (what mjData.xpos / geom_xpos / cam_xpos derive from: the renderer's frames)
   static constexpr int XS = QPRE + T::NL;         // models with dry friction: the constraint solve's last solution (MuJoCo: qacc_warmstart) -- the
                                                   // zones it sits in are the first guess of the next solve, also across launches
-  static constexpr int COUNT = XS + T::NL;
+  static constexpr int SEP = XS + T::NL;          // the unresolved-contact check's remembered separating directions (check_team.h)
+  static constexpr int COUNT = SEP + kCheckSep;
 };
 
 // PickCubeSuccessWrapper (reference python/rcs/envs/sim.py:386-431)
@@ -146,6 +150,7 @@ struct Params {
   const struct BoxTaskCfg* boxtask;  // scenes with a free box: its constants and the task layer's (HBM; staged by k_run_team<.., BOX>)
   ContactTable ctab;                 // the robot's collision geoms for the contact phase (contact_team.h; scenes with a free box)
   RendCfg rend;                      // rate-driven cameras (ncam = 0: none)
+  CheckTable chk;                    // the once-per-launch check for contacts nobody resolves (check_team.h)
 };
 struct BoxTaskCfg {
   BoxCfg box;
@@ -406,7 +411,7 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
 #pragma unroll
     for (int i = 0; i < T::NU; ++i) r.st.c(i) = 0;
     r.time = 0;
-    r.flags &= ~kContactOverflow;
+    r.flags &= ~(kContactOverflow | kContactUnresolved);
 #pragma unroll
     for (int i = 0; i < 6; ++i) r.cb(i) = 0;
     // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
@@ -540,7 +545,7 @@ __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, c
       inf[4] = rc || !ik;
       inf[5] = gc;
       inf[6] = (r.flags & kContactOverflow) != 0;  // a contact phase ran out of contact / link slots since the last Sim.reset
-      inf[7] = 0;
+      inf[7] = (r.flags & kContactUnresolved) != 0;  // found in a contact this configuration does not resolve, since the last Sim.reset
     }
     if (op.gripper_width) op.gripper_width[e] = w;
     if (op.substeps) op.substeps[e] = nsteps >= 0 ? nsteps : r.conv_steps;
@@ -589,7 +594,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   // collision table inside is also indexed per lane, which a kernel argument cannot be.)
   __shared__ Params lp;
   __shared__ RunOp lop;
-  __shared__ __attribute__((aligned(16))) double lds[ST::COUNT * kTeams];
+  // (sized for the end-of-launch contact check too, which takes the block over once the state has been written back)
+  constexpr int kLdsDoubles = ST::COUNT * kTeams > check_work_doubles(T::NL) ? ST::COUNT * kTeams : check_work_doubles(T::NL);
+  __shared__ __attribute__((aligned(16))) double lds[kLdsDoubles];
   {
     static_assert(sizeof(Params) % 8 == 0 && sizeof(RunOp) % 8 == 0, "copied in 8-byte words");
     for (int k = threadIdx.x; k < (int)(sizeof(Params) / 8); k += 64)
@@ -1030,6 +1037,22 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       for (int k = 0; k < 7; ++k) o[k] = bs[kBoxQ + k];
       o[7] = reward / 5;
       o[8] = success ? 1.0 : 0.0;
+    }
+  }
+  // ---- contacts nobody resolves (check_team.h): once per stepping launch, on the position the next position stage will see.
+  // Everything of the launch is in HBM by now; the LDS block and the link records' memory are the check's workspace.
+  if ((op.nsteps != 0 || op.do_reset) && (lp.chk.nbpair > 0 || (!CON && lp.chk.plane_points))) {  // (wave-uniform)
+    static_assert(sizeof(LinkRec) * T::NL >= sizeof(double) * 12 * T::NL * kTeams, "the links' world frames fit where their records were");
+    const double q_final = live && t < T::NL ? st.q(t) : 0.0;
+    __syncthreads();
+    double* const sep = P.S + (size_t)Lay<T>::SEP * P.n + (live ? e : 0);
+    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), lds, q_final, live, !CON, sep, P.n);
+#ifdef RCSH_CHECK_DEBUG
+    if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[35], (int)((r.flags >> 16) & 1u)); atomicAdd(&g_chk_dbg[36], (int)((pre_flags >> 16) & 1u)); atomicAdd(&g_chk_dbg[37], 1); }
+#endif
+    if (leader && hit && !(r.flags & kContactUnresolved)) {
+      P.flags[e] = r.flags | kContactUnresolved;
+      if (op.write_obs && op.info) op.info[(size_t)e * 8 + 7] = 1;
     }
   }
   TEAM_MARK(10)

@@ -179,6 +179,7 @@ EXPORTS = (
     "rcsh_comm_get_unique_id", "rcsh_comm_init", "rcsh_comm_rank", "rcsh_env_allgather_obs_dev", "rcsh_comm_allgather_dev", "rcsh_comm_wait",
     "rcsh_comm_destroy",
     "rcsh_sim_contact_table_dropped",
+    "rcsh_sim_contact_unresolved",
 )
 
 _lib = None

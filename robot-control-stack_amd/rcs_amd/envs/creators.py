@@ -72,6 +72,19 @@ class VecSimEnv:
         self.obs_width = self._L.rcsh_env_obs_width(simulation._h)
         self.action_width = self._L.rcsh_env_action_width(simulation._h)
         self.action_key = _ACTION_KEY[control_mode]
+        # What an environment gets whose geoms are found in a contact this configuration does not resolve (info["contact_unresolved"],
+        # sticky until reset; csrc/check_team.h).  The reference resolves every contact in every mode (mj_step2, sim.cpp:112); the
+        # lean kernels of scenes without a free body do not, because the capability costs the contact-free rollout ~15 %.
+        #   "flag":    report only -- the environment steps on unresolved (the arm passes through the floor / itself) and the caller
+        #              decides (mask it, reset it, discard the episode);
+        #   "resolve": as soon as a step reports one, the whole batch switches to the contact-resolving kernels for all later steps
+        #              (robot <-> floor resolved from then on; robot <-> robot contacts stay flagged).  Host-array interface only:
+        #              the `*_dev` entry points never read the flags back.
+        self.on_unresolved_contact = "flag"
+
+    def _after_step(self, info) -> None:
+        if self.on_unresolved_contact == "resolve" and not self.sim.resolve_robot_contacts and info[:, 7].any():
+            self.sim.enable_contact_resolution()
 
     # ---- host-array interface (Gymnasium-shaped)
     def _unpack(self, obs, info, gw) -> tuple[dict[str, Any], dict[str, Any]]:
@@ -137,6 +150,10 @@ class VecSimEnv:
         # (no reference counterpart) a contact phase of the environment ran out of contact / link slots since its last reset:
         # its trajectory is no longer what MuJoCo would compute (csrc/contact_team.h: kMaxCon, kMaxActive)
         i["contact_overflow"] = info[:, 6].astype(bool)
+        # (no reference counterpart) the environment's geoms were found in a contact this configuration does not resolve, since its
+        # last reset (csrc/check_team.h): MuJoCo would have resolved it, so from that step on the trajectory is not MuJoCo's
+        i["contact_unresolved"] = info[:, 7].astype(bool)
+        self._after_step(info)
         truncated = info[:, 4].astype(bool)
         return o, np.zeros(n), np.zeros(n, dtype=bool), truncated, i
 
@@ -239,6 +256,7 @@ class VecPickCubeEnv(VecSimEnv):
         i["is_grasped"] = info[:, 3].astype(bool)
         i["substeps"] = sub
         i["contact_overflow"] = info[:, 6].astype(bool)  # (see VecSimEnv.step)
+        i["contact_unresolved"] = info[:, 7].astype(bool)
         i["box_qpos"] = task[:, :7].copy()
         success = task[:, 8] != 0
         i["success"] = success

@@ -95,6 +95,27 @@ class Sim:
         self._contact_table_reason = reason.value.decode()
         return [int(g) for g in ids[: min(count.value, 64)]]
 
+    def enable_contact_resolution(self) -> bool:
+        """Switch a scene WITHOUT a free body to the contact-resolving kernels from the next launch on (robot <-> floor contacts
+        enter the constraint solve; rcsh_sim_set_contact_options).  False where the archetype cannot (see resolves_robot_contacts)."""
+        if self.resolve_robot_contacts:
+            return True
+        if getattr(self.model, "free_bodies", []) or not self.resolves_robot_contacts(self.model):
+            return False
+        opts = _lib.make_contact_options(self.model, True)
+        _lib.check(self._L.rcsh_sim_set_contact_options(self._h, C.byref(opts)))
+        self.resolve_robot_contacts = True
+        return True
+
+    def contact_unresolved(self) -> np.ndarray:
+        """[N] bool: the environment's geoms were found in a contact this configuration does not resolve, since its last
+        Sim.reset (the sticky flag the end-of-launch check sets, csrc/check_team.h; also info["contact_unresolved"])."""
+        import numpy as np
+
+        out = np.zeros(self.n_envs, dtype=np.uint8)
+        _lib.check(self._L.rcsh_sim_contact_unresolved(self._h, _lib.ptr(out)))
+        return out.astype(bool)
+
     @staticmethod
     def resolves_robot_contacts(model: Model) -> bool:
         """Scenes whose robot-geom contacts CAN enter the constraint solve: the 7-dof arm + two-finger gripper archetype with

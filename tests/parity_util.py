@@ -1376,3 +1376,71 @@ def run_split_consistency(n=4096, ca=17, cb=100, **kw):
         rep[tag] = {"max_dq": float(dq.max()), "max_dbox": float(db.max()), "envs_over_1e-8": int(((dq > 1e-8) | (db > 1e-8)).sum()),
                     "worst_env": int(np.argmax(np.maximum(dq, db))), "box_z": (float(a[tag][1][:, 2].min()), float(a[tag][1][:, 2].max()))}
     return rep
+
+
+def oracle_contacts_at_current_qpos(osim, touch=1e-9):
+    """(ncon, nself) MuJoCo's collision pass would report at the oracle environment's CURRENT qpos -- what the next mj_step1 will
+    see, the position the kernels' end-of-launch check (csrc/check_team.h) tests.  Computed on a copy of the oracle's data, so
+    that neither the frames get_cartesian_position reads (those of the last mj_step1) nor the collision caches are disturbed."""
+    import ctypes as C
+
+    import rcs_oracle as O
+
+    d = O.OrcData.from_buffer_copy(osim.s.d)
+    L = O.lib()
+    L.orc_kinematics(C.byref(osim.model), C.byref(d))
+    L.orc_collide(C.byref(osim.model), C.byref(d))
+    # "in contact": penetrating by more than a nanometre (csrc/check_team.h: kCheckTouch -- a pair that touches exactly, like the
+    # fingertip pads at finger qpos 0 after every reset, has no reproducible sign)
+    ncon = sum(1 for i in range(d.ncon) if d.contact[i].dist < -touch)
+    nself = sum(1 for i in range(d.nself) if d.self_depth[i] > touch)
+    return ncon, nself
+
+
+def run_headline_contact_check(n_envs=64, n_steps=1000, seed=0, chunk=50):
+    """The headline workload (fr3_empty_world, JOINTS, relative +-5 deg LAST_STEP actions, async 17 substeps, NO resets) run for
+    BASELINE.md's rollout length against the oracle with contacts RESOLVED, as MuJoCo resolves them.  Per env-step the oracle's
+    collision pass on the final position says whether the environment is in contact; the kernel's sticky info["contact_unresolved"]
+    must come on in exactly that step.  Until then an environment must match the oracle to round-off; after that the two differ
+    by construction (the oracle stops on the floor, the lean kernel does not) and only the flag is compared."""
+    import rcs_oracle as O
+
+    venv = make_vec_env(n_envs, True)
+    saved = O.DEFAULT_RESOLVE_CONTACTS
+    O.DEFAULT_RESOLVE_CONTACTS = True
+    try:
+        oenvs = make_oracle_envs(n_envs, True)
+    finally:
+        O.DEFAULT_RESOLVE_CONTACTS = saved
+    joints, grip = synthetic_actions(n_envs, n_steps, seed)
+    venv.reset()
+    for oe in oenvs:
+        oe.reset()
+    first_oracle = np.full(n_envs, -1)
+    first_kernel = np.full(n_envs, -1)
+    rep = {"max_abs_qpos_unflagged": 0.0, "max_abs_qvel_unflagged": 0.0, "flag_mismatch_steps": 0, "kinds": {}}
+    for t in range(n_steps):
+        _, _, _, _, info = venv.step({"joints": joints[t], "gripper": grip[t]})
+        flagged = np.asarray(info["contact_unresolved"], dtype=bool)
+        q, v = venv.sim.qpos, venv.sim.qvel
+        for e, oe in enumerate(oenvs):
+            if first_oracle[e] >= 0:
+                continue  # (sticky on both sides; the trajectories have parted)
+            oe.step({"joints": joints[t, e], "gripper": grip[t, e]})
+            ncon, nself = oracle_contacts_at_current_qpos(oe.sim)
+            if ncon + nself > 0:
+                first_oracle[e] = t
+                rep["kinds"][e] = (ncon, nself)
+            else:
+                rep["max_abs_qpos_unflagged"] = max(rep["max_abs_qpos_unflagged"], float(np.abs(q[e] - oe.sim.qpos[: q.shape[1]]).max()))
+                rep["max_abs_qvel_unflagged"] = max(rep["max_abs_qvel_unflagged"], float(np.abs(v[e] - oe.sim.qvel[: v.shape[1]]).max()))
+        newly = flagged & (first_kernel < 0)
+        first_kernel[newly] = t
+        rep["flag_mismatch_steps"] += int(((first_kernel >= 0) != (first_oracle >= 0)).sum())
+    rep["first_oracle"] = first_oracle
+    rep["first_kernel"] = first_kernel
+    rep["flagged_oracle"] = int((first_oracle >= 0).sum())
+    rep["flagged_kernel"] = int((first_kernel >= 0).sum())
+    rep["sticky_accessor_equal"] = bool(np.array_equal(venv.sim.contact_unresolved(), first_kernel >= 0))
+    venv.close()
+    return rep

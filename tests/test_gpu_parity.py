@@ -1244,9 +1244,10 @@ def test_contact_table_capacity_is_fatal_only_when_contacts_are_resolved(kernel,
     cfg = default_sim_robot_cfg("fr3_empty_world")
     # (advisor, round 3) the overflow is not silent for DETECTION either: the host is told which geoms geom-geom detection
     # cannot see and warns, and a collision callback cannot be registered on one of them
-    with pytest.warns(RuntimeWarning, match="table_block"):
+    # (the block comes first in geom order and takes a box slot: the last finger pad is the geom left out)
+    with pytest.warns(RuntimeWarning, match="fingertip_pad_collision_5_right_0"):
         simu = S.Sim(str(scene), S.SimConfig(), n_envs=4)
-    assert [simu.model.geom_names[g] for g in simu.undetected_collision_geoms] == ["table_block"]
+    assert [simu.model.geom_names[g] for g in simu.undetected_collision_geoms] == ["fingertip_pad_collision_5_right_0"]
     robot = S.SimRobot(simu, None, cfg)
     robot.set_joint_position(np.tile(cfg_home(robot), (4, 1)))
     simu.step_until_convergence()
@@ -1257,7 +1258,7 @@ def test_contact_table_capacity_is_fatal_only_when_contacts_are_resolved(kernel,
     import copy
 
     bad = copy.deepcopy(cfg)
-    bad.arm_collision_geoms = list(bad.arm_collision_geoms) + ["table_block"]
+    bad.arm_collision_geoms = list(bad.arm_collision_geoms) + ["fingertip_pad_collision_5_right_0"]
     with pytest.warns(RuntimeWarning):
         simu = S.Sim(str(scene), S.SimConfig(), n_envs=4)
     with pytest.raises(RuntimeError, match="not in the contact table"):
