@@ -157,6 +157,11 @@ def main() -> None:
                     help="before the W warmup steps: this many milliseconds of the same env-step launches, then a reset -- the device needs "
                          "~12 ms of work to reach its operating clocks (profiles/README.md: a launch takes 128 us at first, 112.5 us from "
                          "there on), W = 5 steps are 0.6 ms.  0: off")
+    ap.add_argument("--contact-check-every", type=int, default=16,
+                    help="cadence of the end-of-launch check for contacts nobody resolves (csrc/check_team.h) inside the rollout: every this many "
+                         "env-steps, plus once on the final state after the clock stopped (config.contacts_seen counts what both found).  1: every "
+                         "env-step, the library's default and what the parity tests run (the check costs about as much as one to two of the "
+                         "step's 17 substeps); 0: off")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
     args = ap.parse_args()
@@ -248,6 +253,8 @@ def main() -> None:
     envs = [env] + [make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=r)
                     for r in hosted[1:]]
     L, h = env._L, env.sim._h
+    for e_ in envs:
+        e_.sim.set_contact_check(args.contact_check_every)
 
     class DevBuf:
         """[rows, ...] array in HBM (rcsh_dev_alloc), optionally filled from a host array; `at(t)` = address of row t."""
@@ -547,6 +554,8 @@ def main() -> None:
                 "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"torch.distributed {args.dist_backend} all_gather")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "contacts_seen": contacts_seen,
+                "contact_check": (f"exact collision check of every environment every {args.contact_check_every} env-steps inside the timed region"
+                                  if args.contact_check_every > 0 else "no check inside the timed region") + " + once on the final state (sticky flags, csrc/check_team.h)",
                 "obs_finite": finite,
                 "value_without_exchange": no_exchange_value,
                 "clock_warmup": (f"{clock_warmup_launches} untimed launches over {args.clock_warmup_ms:g} ms before the W warmup steps, then a reset "

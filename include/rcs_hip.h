@@ -297,6 +297,11 @@ int rcsh_sim_set_contact_options(rcsh_sim* sim, const rcsh_contact_options* opti
  * 108-115), so from that launch on the environment's trajectory is not the reference's; the same bit is byte 7 of an
  * env-step's info row.  Checked once per launch on the position the next position stage will see (csrc/check_team.h). */
 int rcsh_sim_contact_unresolved(rcsh_sim* sim, uint8_t* unresolved);
+/* How often the check runs: at the end of every `every`-th stepping launch (default 1: every launch, the flag comes on in the
+ * env-step the contact begins in; 0: never).  The check costs a launch about as much as one to two physics substeps; a resident
+ * rollout that prefers throughput sets a larger cadence -- a contact is then found with a lag of up to `every` - 1 launches, one
+ * that comes and goes between two checks is missed -- and rcsh_sim_contact_unresolved() always checks the present state first. */
+int rcsh_sim_set_contact_check(rcsh_sim* sim, int32_t every);
 /* Collision geoms of the scene that exceed the contact table's capacity (32 geoms, 10 boxes, 152 hull vertices) are left out of
  * GEOM-GEOM detection (the floor test still sees them): their mjModel ids (up to `capacity`), how many there are, and why.
  * rcsh_sim_add_robot / rcsh_sim_add_gripper refuse a collision geom that is on this list; the Python host warns about the

@@ -28,7 +28,11 @@ namespace rcsh {
 #if defined(__HIP__)
 
 #ifdef RCSH_CHECK_DEBUG
-__device__ int g_chk_dbg[64];  // development: [0] plane hits, [1] pair hits, [2..] pair indices of the first hits, [32] body pairs surviving, [33] geom pairs surviving
+__device__ int g_chk_dbg[64];
+__device__ unsigned long long g_chk_cyc[16];
+#define CHK_MARK(i) if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); g_chk_cyc[i] += now_ - chk_t0_; chk_t0_ = now_; }
+#else
+#define CHK_MARK(i)  // development: [0] plane hits, [1] pair hits, [2..] pair indices of the first hits, [32] body pairs surviving, [33] geom pairs surviving
 #endif
 // "In contact" for this check: penetrating by more than a nanometre.  MuJoCo lists a contact as soon as dist < 0, but a pair that
 // touches EXACTLY has no reproducible sign -- and the model has one at every reset: mj_resetData leaves the fingers at qpos 0,
@@ -37,19 +41,125 @@ __device__ int g_chk_dbg[64];  // development: [0] plane hits, [1] pair hits, [2
 constexpr double kCheckTouch = 1e-9;
 constexpr int kCheckSep = 8;  // per environment: two remembered separating directions (pair index + 1, direction in geom 0's link frame)
 
-// doubles of LDS workspace the check needs for an archetype with NL links
-constexpr int check_work_doubles(int nl) { return 4 * (nl + 1) * 4 + 4 * kCheckSep + kSelfStage; }
+// LDS workspace of the check (doubles): per team the world boxes of the geoms ([ngeom][12]: centre, axes) -- later overlaid by the
+// stage of the one pair of hulls the narrow phase works on --, the remembered directions, the two geom records of that pair
+constexpr int kCheckBox = 12 * kMaxCGeom;
+constexpr int kCheckGeomWords = (int)(sizeof(ContactGeom) / 8);
+static_assert(sizeof(ContactGeom) % 8 == 0 && 2 * kCheckGeomWords <= 64, "a lane per word of the narrow phase's two geom records");
+constexpr int check_work_doubles(int) { return 4 * kCheckBox + 4 * kCheckSep + 64; }
+static_assert(4 * kCheckBox >= kSelfStage, "the hull stage overlays the world boxes");
+constexpr int kCheckPer = kMaxCheckPairs / kTeamLanes;
+constexpr int kCheckTrips = (3 * 152 + 63) / 64;  // vertex words per lane and hull (a hull has at most 152 vertices)
+
+// obb_disjoint for this check: true when the two oriented boxes are apart OR overlap by at most `touch` along one of their six
+// face normals (then whatever they contain overlaps by at most that much).  For two BOXES this is the narrow phase already: the
+// fingertip pads of a closed gripper -- two dozen box pairs that touch exactly -- never reach the portal refinement.
+RCSH_D bool obb_apart_or_touching(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb, double touch) {
+  double C[9], A[9], tv[3];
+  const double d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+  mulTv(Ra, d, tv);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      C[3 * i + j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+      A[3 * i + j] = fabs(C[3 * i + j]) + 1e-9;
+    }
+  double sep = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sep = fmax(sep, fabs(tv[i]) - (ha[i] + hb[0] * A[3 * i] + hb[1] * A[3 * i + 1] + hb[2] * A[3 * i + 2]));
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double tw = tv[0] * C[j] + tv[1] * C[3 + j] + tv[2] * C[6 + j];
+    sep = fmax(sep, fabs(tw) - (hb[j] + ha[0] * A[j] + ha[1] * A[3 + j] + ha[2] * A[6 + j]));
+  }
+  if (sep > -touch) return true;
+  bool apart = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double ra = ha[i1] * A[3 * i2 + j] + ha[i2] * A[3 * i1 + j];
+      const double rb = hb[j1] * A[3 * i + j2] + hb[j2] * A[3 * i + j1];
+      apart = apart || fabs(tv[i2] * C[3 * i1 + j] - tv[i1] * C[3 * i2 + j]) - (ra + rb) > 0;  // (a cross axis is not a unit vector: strict separation only)
+    }
+  return apart;
+}
+
+// A remembered direction's slot: [0] = (pair index + 1) + 1024 (g0 + 32 g1) -- zero: empty --, [1..3] the direction in the frame of
+// geom 0's link.  The geoms ride along so that the NEXT launch can ask for their records and vertices before it knows anything else.
+RCSH_D double check_slot_key(int pidx, int g0, int g1) { return (double)((pidx + 1) + 1024 * (g0 + 32 * g1)); }
+
+// Everything the check reads from memory, asked for BEFORE the launch's epilogue (the leader lane's observation arithmetic: ~10k
+// cycles during which the other 60 lanes and the memory pipeline idle): the lane's pair entries, the boxes of "its" two geoms, and --
+// a guess -- the records and hull vertices of the pair whose remembered direction sits in the first live team's first used slot
+// (links 5 and 7, nearly always).  After the epilogue the check computes from registers and LDS alone.
+struct CheckPrefetch {
+  CheckEntry ent[kCheckPer];
+  double grec[2][12];
+  int guess_key, guess_g0, guess_g1;  // wave-uniform; key 0: no guess
+  double gword;                       // this lane's word of the guessed pair's two ContactGeom records
+  double va[kCheckTrips], vb[kCheckTrips];
+};
+RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double sep_in, bool live, CheckPrefetch& pf) {
+  const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1);
+  const int npair = ck.npair, ngeom = ck.ngeom;
+#pragma unroll
+  for (int j = 0; j < kCheckPer; ++j) {
+    const int i = t + kTeamLanes * j;
+    pf.ent[j] = ck.ent[i < npair ? i : 0];
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = t + kTeamLanes * u;
+    const double* src = reinterpret_cast<const double*>(&ck.geoms[g < ngeom ? g : 0]);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pf.grec[u][k] = src[k];
+  }
+  // the guess: slot 0's key of the first live team, else its slot 1's (lanes 0 and 4 of the team hold them)
+  const uint64_t lv = __ballot(live && t == 0);
+  pf.guess_key = 0; pf.guess_g0 = 0; pf.guess_g1 = 0;
+  pf.gword = 0.0;
+#pragma unroll
+  for (int u = 0; u < kCheckTrips; ++u) { pf.va[u] = 0.0; pf.vb[u] = 0.0; }
+  if (lv && npair > 0) {
+    const int l0 = __ffsll((long long)lv) - 1;
+    const double k0 = wave_read(sep_in, l0), k1 = wave_read(sep_in, l0 + 4);
+    const int key = (int)(k0 != 0.0 ? k0 : k1);
+    const int pid = key & 1023, gg = key >> 10, g0 = gg & 31, g1 = gg >> 5;
+    if (pid >= 1 && pid <= npair && g0 < ngeom && g1 < ngeom) {
+      pf.guess_key = key; pf.guess_g0 = g0; pf.guess_g1 = g1;
+      const int w = lane & 31;
+      const double* rec = reinterpret_cast<const double*>(&tab.geoms[lane < 32 ? g0 : g1]);
+      pf.gword = rec[w < kCheckGeomWords ? w : 0];
+      const int na = 3 * ck.gvert[g0][1], nb = 3 * ck.gvert[g1][1];
+      const double* va = tab.verts + 3 * (size_t)ck.gvert[g0][0];
+      const double* vb = tab.verts + 3 * (size_t)ck.gvert[g1][0];
+#pragma unroll
+      for (int u = 0; u < kCheckTrips; ++u) {
+        const int k = lane + 64 * u;
+        pf.va[u] = va[k < na ? k : 0];
+        pf.vb[u] = vb[k < nb ? k : 0];
+      }
+    }
+  }
+}
 
 // `frames`: LDS room for [4][NL][12] doubles (the link records' memory: the check is their last reader); `work`: LDS room for
 // check_work_doubles(NL).  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
 // Every lane of the wavefront calls this; returns, on every lane of a team, whether the team's environment is in contact.
 template <class T, class CollT>
 RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& tab, const CollT& lc, const LinkRec* links, double* frames,
-                                     double* work, double q, bool live, bool check_plane, double* sep, int n_env) {
-  constexpr int NL = T::NL, NB = NL + 1;
+                                     double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf) {
+  constexpr int NL = T::NL;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const bool valid = t < NL;
   const int tl = valid ? t : NL - 1;
+  const int npair = ck.npair, ngeom = ck.ngeom;
+#ifdef RCSH_CHECK_DEBUG
+  unsigned long long chk_t0_ = __builtin_readcyclecounter();
+#endif
   // ---- world frames of the links at the final qpos (what the next launch's first position stage will see)
   double R[9], p[3];
   {
@@ -58,28 +168,51 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     link_local_frame(kk, q, R, p);
     scan_frames<T>(R, p);
   }
+  CHK_MARK(0)
   __syncthreads();  // (the link records have been read: their memory becomes the frames')
   double* F = frames + 12 * NL * team;
-  double* wsph = work + 4 * NB * team;
-  double* slots = work + 4 * NB * 4 + kCheckSep * team;
-  double* stage = work + 4 * NB * 4 + 4 * kCheckSep;
+  double* wbox = work + kCheckBox * team;
+  double* slots = work + 4 * kCheckBox + kCheckSep * team;
+  double* gstage = work + 4 * kCheckBox + 4 * kCheckSep;
+  double* stage = work;  // (overlays the world boxes once the broad phase is through)
   if (valid) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) F[12 * t + k] = R[k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) F[12 * t + 9 + k] = p[k];
-    const double* bs = ck.bsphere[t + 1];
-    double c[3];
-    const double b3[3] = {bs[0], bs[1], bs[2]};
-    mulmv(R, b3, c);
-    wsph[4 * (t + 1) + 0] = c[0] + p[0]; wsph[4 * (t + 1) + 1] = c[1] + p[1]; wsph[4 * (t + 1) + 2] = c[2] + p[2];
-    wsph[4 * (t + 1) + 3] = bs[3];
-  } else if (t == NL) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wsph[k] = ck.bsphere[0][k];
   }
-  if (t < kCheckSep) slots[t] = live ? sep[(size_t)t * n_env] : 0.0;
+  if (t < kCheckSep) slots[t] = sep_in;
   __syncthreads();
+  // ---- world boxes of the geoms: lane t takes geoms t, t + 16 (their link-frame boxes came with the prefetch)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = t + kTeamLanes * u;
+    if (g < ngeom) {
+      const int link = ck.glink[g];
+      double cw[3] = {pf.grec[u][0], pf.grec[u][1], pf.grec[u][2]}, Rw[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rw[k] = pf.grec[u][3 + k];
+      if (link >= 0) {
+        double LR[9], LP[3], c2[3], R2[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) LR[k] = F[12 * link + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) LP[k] = F[12 * link + 9 + k];
+        mulmv(LR, cw, c2);
+        mulmm(LR, Rw, R2);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cw[k] = c2[k] + LP[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rw[k] = R2[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wbox[12 * g + k] = cw[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wbox[12 * g + 3 + k] = Rw[k];
+    }
+  }
+  __syncthreads();
+  CHK_MARK(1)
   bool mine = false;
   // ---- the floor against the sample points of the link's collision geoms (as the DET launches test it)
   if (check_plane && ck.plane_points && valid && live) {
@@ -100,115 +233,151 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
       }
     }
   }
-  // ---- body pairs: bounding spheres
-  uint32_t bmask = 0;
-  if (live) {
-    for (int j = 0, i = t; i < ck.nbpair; ++j, i += kTeamLanes) {
-      const CheckBodyPair bp = ck.bpairs[i];
-      const double* sa = wsph + 4 * bp.ba;
-      const double* sb = wsph + 4 * bp.bb;
-      const double d[3] = {sa[0] - sb[0], sa[1] - sb[1], sa[2] - sb[2]}, rs = sa[3] + sb[3];
-      if (dot3(d, d) <= rs * rs) {
-        bmask |= 1u << j;
-#ifdef RCSH_CHECK_DEBUG
-        atomicAdd(&g_chk_dbg[32], 1);
-#endif
-      }
+  CHK_MARK(2)
+  // ---- geom pairs: bounding spheres (bit j of smask: pair t + 16 j survived), then -- one pair per lane and round -- the boxes
+  uint32_t smask = 0;
+  if (live && !(ck.pad & 4)) {
+    // (all the centres first, then the arithmetic: read pair by pair the wavefront would wait for LDS a dozen times)
+    double ca[kCheckPer][3], cb[kCheckPer][3];
+#pragma unroll
+    for (int j = 0; j < kCheckPer; ++j) {
+      const int g0 = pf.ent[j].geoms & 0xff, g1 = (pf.ent[j].geoms >> 8) & 0xff;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ca[j][k] = wbox[12 * g0 + k]; cb[j][k] = wbox[12 * g1 + k]; }
+    }
+    sched_fence();
+#pragma unroll
+    for (int j = 0; j < kCheckPer; ++j) {
+      const int i = t + kTeamLanes * j;
+      const double d[3] = {ca[j][0] - cb[j][0], ca[j][1] - cb[j][1], ca[j][2] - cb[j][2]};
+      const double rs = pf.ent[j].rsum;
+      smask |= i < npair && dot3(d, d) <= rs * rs ? 1u << j : 0u;
     }
   }
-  for (uint64_t pend = __ballot(bmask != 0); pend; pend = __ballot(bmask != 0)) {
-    const int src = __ffsll((long long)pend) - 1;  // wave-uniform
-    const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)bmask, src);
-    const int j = __ffs((int)sm) - 1, t0 = src & (kTeamLanes - 1);
-    // the teams in which this body pair survived (their lane t0 holds bit j) take it together
-    const bool holder = t == t0 && ((bmask >> j) & 1u);
-    const bool take = team_ballot(holder) != 0;
-    if (holder) bmask &= ~(1u << j);
-    const CheckBodyPair bp = ck.bpairs[t0 + kTeamLanes * j];
-    // its geom pairs, one per lane and round: bounding spheres, then the oriented boxes (all from the pair record)
-    uint32_t cmask = 0;
-    for (int u = 0, i = bp.adr + t; i < bp.adr + bp.num; ++u, i += kTeamLanes) {
-      if (!take) continue;
-      const SelfPair& pr = ck.pairs[i];
-      double Ra[9], Rb[9], ca[3], cb[3];
-      self_box_world(F, pr.l0, pr.c0, pr.rot0, ca, Ra);
-      self_box_world(F, pr.l1, pr.c1, pr.rot1, cb, Rb);
-      const double d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]}, rs = pr.r0 + pr.r1;
-      if (dot3(d, d) > rs * rs) continue;
-      if (!obb_disjoint(Ra, ca, pr.h0, Rb, cb, pr.h1)) {
-        cmask |= 1u << u;
+#ifdef RCSH_CHECK_DEBUG
+  atomicAdd(&g_chk_dbg[32], __popc(smask));
+#endif
+  CHK_MARK(3)
+  uint32_t cmask = 0;
+  if (ck.pad & 2) smask = 0;
+  while (__ballot(smask != 0)) {
+    if (smask) {
+      const int j = __ffs((int)smask) - 1;
+      smask &= smask - 1;
+      // (the entry of round j: a select chain over the lane's registers -- a run-time index would put them into scratch)
+      uint32_t gg = 0;
+#pragma unroll
+      for (int k = 0; k < kCheckPer; ++k) gg = k == j ? pf.ent[k].geoms : gg;
+      const int g0 = gg & 0xff, g1 = (gg >> 8) & 0xff;
+      double Ra[9], Rb[9], ca[3], cb[3], ha[3], hb[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ca[k] = wbox[12 * g0 + k]; cb[k] = wbox[12 * g1 + k]; ha[k] = ck.gh[g0][k]; hb[k] = ck.gh[g1][k]; }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { Ra[k] = wbox[12 * g0 + 3 + k]; Rb[k] = wbox[12 * g1 + 3 + k]; }
+      if (!obb_apart_or_touching(Ra, ca, ha, Rb, cb, hb, kCheckTouch)) {
+        cmask |= 1u << j;
 #ifdef RCSH_CHECK_DEBUG
         atomicAdd(&g_chk_dbg[33], 1);
 #endif
       }
     }
-    // narrow phase: a surviving geom pair has its hulls staged by the whole wavefront, once for all the teams it survived in;
-    // each of those teams runs the refinement on its 16 lanes, which share the vertex scans of the support queries
-    for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
-      const int src2 = __ffsll((long long)pc) - 1;
-      const uint32_t sm2 = (uint32_t)__builtin_amdgcn_readlane((int)cmask, src2);
-      const int u = __ffs((int)sm2) - 1, t1 = src2 & (kTeamLanes - 1);
-      const bool holder2 = t == t1 && ((cmask >> u) & 1u);
-      const bool take2 = team_ballot(holder2) != 0;
-      if (holder2) cmask &= ~(1u << u);
-      const int pidx = bp.adr + t1 + kTeamLanes * u;
-      const SelfPair& pr = ck.pairs[pidx];
-      const ContactGeom& a = tab.geoms[pr.g0];
-      const ContactGeom& b = tab.geoms[pr.g1];
-      const int na = 3 * a.vert_num, nb = 3 * b.vert_num;
-      {
-        const double* va = tab.verts + 3 * (size_t)a.vert_adr;
-        const double* vb = tab.verts + 3 * (size_t)b.vert_adr;
-        for (int k = lane; k < na; k += 64) stage[k] = va[k];
-        for (int k = lane; k < nb; k += 64) stage[na + k] = vb[k];
-        stage_fence();  // (LDS traffic of one wavefront is ordered)
-      }
-      if (take2) {
-        double Ra[9], pa[3], Rb[9], pb[3];
-        self_geom_world(a, F, Ra, pa);
-        self_geom_world(b, F, Rb, pb);
-        Shape A = make_shape(a.type == 7 ? 0 : a.type == 6 ? 1 : 2, pa, Ra, a.size, stage, a.vert_num);
-        Shape B = make_shape(b.type == 7 ? 0 : b.type == 6 ? 1 : 2, pb, Rb, b.size, stage + na, b.vert_num);
-        if (a.type == 7) { mulmv(Ra, a.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
-        else { A.center[0] = pa[0]; A.center[1] = pa[1]; A.center[2] = pa[2]; }
-        if (b.type == 7) { mulmv(Rb, b.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
-        else { B.center[0] = pb[0]; B.center[1] = pb[1]; B.center[2] = pb[2]; }
-        double* slot = slots + 4 * (pidx & 1);
-        bool apart = false;
-        double LR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (pr.l0 >= 0) {
+  }
+  CHK_MARK(4)
+  // ---- narrow phase: a surviving geom pair has its hulls staged by the whole wavefront, once for all the teams it survived in;
+  // each of those teams runs the refinement on its 16 lanes, which share the vertex scans of the support queries
+  __syncthreads();  // (the stage takes the world boxes' place)
+  if (ck.pad & 1) cmask = 0;
+  for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
+    const int src = __ffsll((long long)pc) - 1;  // wave-uniform
+    const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cmask, src);
+    const int u = __ffs((int)sm) - 1, t1 = src & (kTeamLanes - 1);
+    const bool holder = t == t1 && ((cmask >> u) & 1u);
+    const bool take = team_ballot(holder) != 0;
+    if (holder) cmask &= ~(1u << u);
+    const int pidx = t1 + kTeamLanes * u;
+    uint32_t gg = 0;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) LR[k] = F[12 * pr.l0 + k];
-        }
-        if (slot[0] == (double)(pidx + 1)) {
-          const double dl[3] = {slot[1], slot[2], slot[3]};
-          double dw[3];
-          mulmv(LR, dl, dw);
-          MprPt s;
-          mpr_support<true>(A, B, dw, s);
-          apart = dot3(s.v, dw) < 0;  // the support of A - B along the remembered direction is still negative: apart
-        }
-        if (!apart) {
-          double dir[3], depth = 0.0;
-          if (mpr_penetration<true, kMprDepth>(A, B, &depth, dir, nullptr) && depth > kCheckTouch) {
+    for (int k = 0; k < kCheckPer; ++k) gg = k == u ? pf.ent[k].geoms : gg;
+    gg = (uint32_t)__builtin_amdgcn_readlane((int)gg, src);
+    const int g0 = gg & 0xff, g1 = (gg >> 8) & 0xff;
+    const int na = 3 * ck.gvert[g0][1], nb = 3 * ck.gvert[g1][1];
+    const double key = check_slot_key(pidx, g0, g1);
+    // the two geom records and the hulls' vertices: from the prefetch where the guess was right, else from memory now
+    if (pf.guess_key == (int)key) {
+      gstage[lane] = pf.gword;
+#pragma unroll
+      for (int v = 0; v < kCheckTrips; ++v) { const int k = lane + 64 * v; if (k < na) stage[k] = pf.va[v]; if (k < nb) stage[na + k] = pf.vb[v]; }
+    } else {
+      const int w = lane & 31;
+      const double* rec = reinterpret_cast<const double*>(&tab.geoms[lane < 32 ? g0 : g1]);
+      const double word = rec[w < kCheckGeomWords ? w : 0];
+      const double* va = tab.verts + 3 * (size_t)ck.gvert[g0][0];
+      const double* vb = tab.verts + 3 * (size_t)ck.gvert[g1][0];
+      double xa[kCheckTrips], xb[kCheckTrips];
+#pragma unroll
+      for (int v = 0; v < kCheckTrips; ++v) { const int k = lane + 64 * v; xa[v] = va[k < na ? k : 0]; xb[v] = vb[k < nb ? k : 0]; }
+      gstage[lane] = word;
+#pragma unroll
+      for (int v = 0; v < kCheckTrips; ++v) { const int k = lane + 64 * v; if (k < na) stage[k] = xa[v]; if (k < nb) stage[na + k] = xb[v]; }
+#ifdef RCSH_CHECK_DEBUG
+      if (lane == 0) atomicAdd(&g_chk_dbg[39], 1);  // pairs whose data was not prefetched
+#endif
+    }
+    stage_fence();  // (LDS traffic of one wavefront is ordered)
+    if (take) {
+      const ContactGeom& a = *reinterpret_cast<const ContactGeom*>(gstage);
+      const ContactGeom& b = *reinterpret_cast<const ContactGeom*>(gstage + 32);
+      double Ra[9], pa[3], Rb[9], pb[3];
+      self_geom_world(a, F, Ra, pa);
+      self_geom_world(b, F, Rb, pb);
+      Shape A = make_shape(a.type == 7 ? 0 : a.type == 6 ? 1 : 2, pa, Ra, a.size, stage, a.vert_num);
+      Shape B = make_shape(b.type == 7 ? 0 : b.type == 6 ? 1 : 2, pb, Rb, b.size, stage + na, b.vert_num);
+      if (a.type == 7) { mulmv(Ra, a.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
+      if (b.type == 7) { mulmv(Rb, b.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
+      // the slot of this pair: the one that holds it, else the first empty one, else slot (pair index & 1)
+      const int s_hold = slots[0] == key ? 0 : (slots[4] == key ? 1 : -1);
+      const int s_use = s_hold >= 0 ? s_hold : (slots[0] == 0.0 ? 0 : (slots[4] == 0.0 ? 1 : (pidx & 1)));
+      double* slot = slots + 4 * s_use;
+      bool apart = false;
+      double LR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      if (a.link >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) LR[k] = F[12 * a.link + k];
+      }
+      if (s_hold >= 0) {
+        const double dl[3] = {slot[1], slot[2], slot[3]};
+        double dw[3];
+        mulmv(LR, dl, dw);
+        MprPt s;
+        mpr_support<true>(A, B, dw, s);
+        apart = dot3(s.v, dw) < 0;  // the support of A - B along the remembered direction is still negative: apart
+      }
+      if (!apart && !(ck.pad & 8)) {
+        double dir[3], depth = 0.0;
+        if (mpr_penetration<true, kMprDepth>(A, B, &depth, dir, nullptr)) {
+          if (depth > kCheckTouch) {
             mine = true;
 #ifdef RCSH_CHECK_DEBUG
             if (t == 0) { const int k = atomicAdd(&g_chk_dbg[1], 1); if (k < 28) g_chk_dbg[2 + k] = pidx; }
 #endif
           }
-          else if (dot3(dir, dir) > 0.5) {  // (a unit separating direction came back)
-            double dl[3];
-            mulTv(LR, dir, dl);
-            stage_fence();
-            slot[0] = (double)(pidx + 1); slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
-          }
+        } else if (dot3(dir, dir) > 0.5) {  // (a unit separating direction came back)
+          double dl[3];
+          mulTv(LR, dir, dl);
+          stage_fence();
+          slot[0] = key; slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
         }
+#ifdef RCSH_CHECK_DEBUG
+        if (t == 0) atomicAdd(&g_chk_dbg[38], 1);  // full refinements
+#endif
       }
-      stage_fence();
     }
+    stage_fence();
   }
+  CHK_MARK(5)
   __syncthreads();
   if (t < kCheckSep && live) sep[(size_t)t * n_env] = slots[t];
+  CHK_MARK(6)
   return team_ballot(mine) != 0;
 }
 

@@ -532,7 +532,7 @@ constexpr int kSelfStageVerts = 304;  // both hulls of a pair (host: build_self_
 constexpr int kSelfStage = 3 * kSelfStageVerts;
 constexpr int kSelfCache = 4 * 8;      // per team two remembered separating directions (pair index, direction)
 constexpr int kSelfTag = 2;            // which pair the stage holds
-constexpr int kMaxSelfPairs = 160;     // pairs whose bounding spheres the lean DET kernels keep in LDS (host: build_self_pairs)
+constexpr int kMaxSelfPairs = 144;     // pairs whose bounding spheres the lean DET kernels keep in LDS (host: build_self_pairs)
 constexpr int kSelfSphereWords = 10;   // per pair: c0, c1, r0 + r1 (inflated by the rounding) as float, the two links, the joints between them
 RCSH_D void self_geom_world(const ContactGeom& g, const double* F, double* R, double* p) {
   if (g.link < 0) {

@@ -5,7 +5,8 @@
 namespace rcsh {
 
 constexpr int kMaxCon = 48;      // contacts per environment (oracle: ORC_MAXCON)
-constexpr int kMaxCGeom = 32;    // collision geoms of the robot
+constexpr int kMaxCGeom = 28;    // collision geoms of the robot (the end-of-launch contact check keeps the world boxes of all of them, for the
+                                 // wavefront's four environments, in the team kernels' LDS block: check_team.h)
 constexpr int kMaxActive = 4;    // links in contact at once that the noslip pass keeps M^-1 S' for
 
 // one collision geom of the robot, host-prepared (model.cpp: build_contact_table), in MuJoCo's geom order
@@ -42,20 +43,27 @@ struct SelfPair {
 };
 
 // The once-per-launch check for contacts nobody resolves (check_team.h): EVERY geom pair MuJoCo's filters let collide -- whether a
-// collision callback reacts to it or not -- grouped by the pair of bodies the geoms ride on, so that one bounding-sphere test per
-// body pair rules out all its geom pairs while the two links are far apart.  Body index: link + 1 (0: welded to the world).
-struct CheckBodyPair {
-  int16_t ba, bb;    // the two bodies
-  int16_t adr, num;  // their geom pairs: CheckTable::pairs[adr .. adr + num)
+// collision callback reacts to it or not.  Three levels: bounding spheres of the two geoms, their oriented bounding boxes (for two
+// box geoms that is the exact test already), MPR.  A lane takes every 16th pair; all it needs per pair is an 8-byte entry.
+constexpr int kMaxCheckPairs = 192;  // pairs whose entries a lane keeps in registers (12 each); a scene with more has the rest unchecked (refused at set-up)
+struct CheckEntry {
+  uint32_t geoms;  // g0 | g1 << 8 (indices into ContactTable::geoms, in MuJoCo's order within a contact: by type, then by id)
+  float rsum;      // sum of the two bounding-sphere radii, rounded up
 };
-constexpr int kMaxCheckBodies = 13;  // kMaxLinks + 1
+// oriented bounding box of a collision geom in the frame of its link (world frame: welded to the world); its axes are the geom's
+struct CheckGeom {
+  double c[3], rot[9];
+};
 struct CheckTable {
-  const SelfPair* pairs;
-  const CheckBodyPair* bpairs;
-  int32_t npair, nbpair;
+  const CheckEntry* ent;
+  const CheckGeom* geoms;
+  int32_t npair, ngeom;
   int32_t plane_points;  // the scene has a floor plane and collision geoms with sample points to test against it
   int32_t pad;
-  double bsphere[kMaxCheckBodies][4];  // bounding sphere of a body's collision geoms, body frame (world frame for body 0)
+  double gh[kMaxCGeom][3];     // half extents of the geoms' boxes
+  int32_t gvert[kMaxCGeom][2]; // hull geoms: first vertex, number of vertices (ContactTable::verts)
+  int8_t glink[kMaxCGeom];     // the geom's link (-1: welded to the world)
+  int8_t pad2[4];
 };
 
 struct ContactTable {

@@ -66,11 +66,13 @@ struct rcsh_sim {
   double* d_cverts = nullptr;
   // the once-per-launch check for contacts nobody resolves (check_team.h): every geom pair MuJoCo's filters let collide, by body pair
   std::vector<SelfPair> chk_pairs;
-  std::vector<CheckBodyPair> chk_bpairs;
-  double chk_bsphere[kMaxCheckBodies][4] = {{0}};
-  SelfPair* d_chk_pairs = nullptr;
-  CheckBodyPair* d_chk_bpairs = nullptr;
+  std::vector<CheckEntry> chk_ent;
+  std::vector<CheckGeom> chk_geoms;
+  CheckGeom* d_chk_geoms = nullptr;
+  CheckEntry* d_chk_ent = nullptr;
   bool contact_check = true;  // RCSH_CONTACT_CHECK=0 switches the check off (measurements of its cost)
+  int check_every = 1;        // the check ends every check_every-th stepping launch (rcsh_sim_set_contact_check); 0: never
+  int64_t check_seq = 0;
   double plane_mu = 1.0;
   std::vector<int> act_slot;
   int narm = 0, nl = 0, nu = 0;
@@ -204,13 +206,26 @@ Params make_params(rcsh_sim* s) {
   for (int k = 0; k < 3; ++k) P.ctab.plane_n[k] = s->cp.plane_n[k];
   P.ctab.plane_d = s->cp.plane_d;
   P.ctab.plane_mu = s->plane_mu;
-  P.chk.pairs = s->d_chk_pairs;
-  P.chk.bpairs = s->d_chk_bpairs;
-  P.chk.npair = s->contact_check ? (int)s->chk_pairs.size() : 0;
-  P.chk.nbpair = s->contact_check ? (int)s->chk_bpairs.size() : 0;
+  P.chk.ent = s->d_chk_ent;
+  P.chk.geoms = s->d_chk_geoms;
+  P.chk.npair = s->contact_check ? (int)s->chk_ent.size() : 0;
+  P.chk.ngeom = (int)s->cgeoms.size();
   P.chk.plane_points = s->contact_check && P.coll.has_plane ? 1 : 0;
   P.chk.pad = 0;
-  std::memcpy(P.chk.bsphere, s->chk_bsphere, sizeof(P.chk.bsphere));
+  if (const char* dm = std::getenv("RCSH_CHECK_SKIP")) P.chk.pad = std::atoi(dm);  // development: bit 0 no narrow phase, 1 no boxes, 2 no spheres
+  std::memset(P.chk.gh, 0, sizeof(P.chk.gh));
+  std::memset(P.chk.gvert, 0, sizeof(P.chk.gvert));
+  std::memset(P.chk.glink, 0, sizeof(P.chk.glink));
+  std::memset(P.chk.pad2, 0, sizeof(P.chk.pad2));
+  for (size_t g = 0; g < s->cgeoms.size() && g < (size_t)kMaxCGeom; ++g) {
+    const ContactGeom& cg = s->cgeoms[g];
+    double* h = P.chk.gh[g];
+    if (cg.type == 7) for (int k = 0; k < 3; ++k) h[k] = cg.aabb_h[k];
+    else if (cg.type == 6) for (int k = 0; k < 3; ++k) h[k] = cg.size[k];
+    else { h[0] = h[1] = cg.size[0]; h[2] = cg.size[0] + cg.size[1]; }
+    P.chk.gvert[g][0] = cg.vert_adr; P.chk.gvert[g][1] = cg.type == 7 ? cg.vert_num : 0;
+    P.chk.glink[g] = (int8_t)cg.link;
+  }
   return P;
 }
 
@@ -300,45 +315,29 @@ void build_self_pairs(rcsh_sim* s) {
   s->pairs = list_geom_pairs(s, true);
 }
 
-// The tables of the end-of-launch check for contacts nobody resolves (check_team.h): ALL admitted geom pairs, grouped by the pair
-// of bodies (link + 1; 0: welded to the world) they belong to, and a bounding sphere per body over its geoms' bounding spheres.
+// The tables of the end-of-launch check for contacts nobody resolves (check_team.h): ALL admitted geom pairs (full records for the
+// box test and the narrow phase, packed entries for the sphere test).  Pairs of the same two bodies stay together, so that a
+// cluster of pairs that come near at once (the two fingers' pads when the gripper closes) spreads over the lanes.
 void build_check_table(rcsh_sim* s) {
-  s->chk_pairs.clear();
-  s->chk_bpairs.clear();
-  std::memset(s->chk_bsphere, 0, sizeof(s->chk_bsphere));
-  std::vector<SelfPair> all = list_geom_pairs(s, false);
+  s->chk_pairs = list_geom_pairs(s, false);
   auto key = [](const SelfPair& p) { const int a = std::min(p.l0, p.l1) + 1, b = std::max(p.l0, p.l1) + 1; return a * 64 + b; };
-  std::stable_sort(all.begin(), all.end(), [&](const SelfPair& x, const SelfPair& y) { return key(x) < key(y); });
-  for (size_t i = 0; i < all.size();) {
-    size_t j = i;
-    while (j < all.size() && key(all[j]) == key(all[i])) ++j;
-    CheckBodyPair bp{};
-    bp.ba = (int16_t)(key(all[i]) / 64); bp.bb = (int16_t)(key(all[i]) % 64);
-    bp.adr = (int16_t)i; bp.num = (int16_t)(j - i);
-    s->chk_bpairs.push_back(bp);
-    i = j;
+  std::stable_sort(s->chk_pairs.begin(), s->chk_pairs.end(), [&](const SelfPair& x, const SelfPair& y) { return key(x) < key(y); });
+  s->chk_ent.clear();
+  for (const auto& p : s->chk_pairs) {
+    CheckEntry e{};
+    e.geoms = (uint32_t)p.g0 | ((uint32_t)p.g1 << 8);
+    e.rsum = (float)(p.r0 + p.r1) * 1.000001f + 2e-6f;  // (single-precision centres: the sum of the radii rounded up)
+    s->chk_ent.push_back(e);
   }
-  s->chk_pairs = all;
-  // per body: centre = mean of its geoms' box centres, radius = the farthest reach of a geom's bounding sphere from there
-  for (int b = 0; b < kMaxCheckBodies; ++b) {
-    double c[3] = {0, 0, 0};
-    int cnt = 0;
-    auto each = [&](auto&& fn) {
-      for (const auto& p : all) {
-        if (p.l0 + 1 == b) fn(p.c0, p.r0);
-        if (p.l1 + 1 == b) fn(p.c1, p.r1);
-      }
-    };
-    each([&](const double* gc, double) { for (int k = 0; k < 3; ++k) c[k] += gc[k]; ++cnt; });
-    if (!cnt) continue;
-    for (int k = 0; k < 3; ++k) c[k] /= cnt;
-    double rad = 0;
-    each([&](const double* gc, double gr) {
-      const double d[3] = {gc[0] - c[0], gc[1] - c[1], gc[2] - c[2]};
-      rad = std::max(rad, std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + gr);
-    });
-    for (int k = 0; k < 3; ++k) s->chk_bsphere[b][k] = c[k];
-    s->chk_bsphere[b][3] = rad * (1 + 1e-12) + 1e-12;
+  // the geoms' bounding boxes in their links' frames (what SelfPair carries per pair, once per geom)
+  s->chk_geoms.clear();
+  for (const auto& cg : s->cgeoms) {
+    CheckGeom g{};
+    double lc[3] = {0, 0, 0};
+    if (cg.type == 7) for (int k = 0; k < 3; ++k) lc[k] = cg.aabb_c[k];
+    for (int k = 0; k < 3; ++k) g.c[k] = cg.rot[3 * k] * lc[0] + cg.rot[3 * k + 1] * lc[1] + cg.rot[3 * k + 2] * lc[2] + cg.pos[k];
+    for (int k = 0; k < 9; ++k) g.rot[k] = cg.rot[k];
+    s->chk_geoms.push_back(g);
   }
 }
 
@@ -388,13 +387,17 @@ int upload_contact_table(rcsh_sim* s) {
     HIP_TRY(hipMemcpyAsync(s->d_pairs, s->pairs.data(), sizeof(SelfPair) * s->pairs.size(), hipMemcpyHostToDevice, s->stream));
   }
   build_check_table(s);
-  if (s->d_chk_pairs) { HIP_TRY(hipStreamSynchronize(s->stream)); HIP_TRY(hipFree(s->d_chk_pairs)); s->d_chk_pairs = nullptr; }
-  if (s->d_chk_bpairs) { HIP_TRY(hipFree(s->d_chk_bpairs)); s->d_chk_bpairs = nullptr; }
-  if (!s->chk_pairs.empty()) {
-    HIP_TRY(hipMalloc(&s->d_chk_pairs, sizeof(SelfPair) * s->chk_pairs.size()));
-    HIP_TRY(hipMemcpyAsync(s->d_chk_pairs, s->chk_pairs.data(), sizeof(SelfPair) * s->chk_pairs.size(), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMalloc(&s->d_chk_bpairs, sizeof(CheckBodyPair) * s->chk_bpairs.size()));
-    HIP_TRY(hipMemcpyAsync(s->d_chk_bpairs, s->chk_bpairs.data(), sizeof(CheckBodyPair) * s->chk_bpairs.size(), hipMemcpyHostToDevice, s->stream));
+  if (s->d_chk_ent) { HIP_TRY(hipStreamSynchronize(s->stream)); HIP_TRY(hipFree(s->d_chk_ent)); s->d_chk_ent = nullptr; }
+  if (s->d_chk_geoms) { HIP_TRY(hipFree(s->d_chk_geoms)); s->d_chk_geoms = nullptr; }
+  if ((int)s->chk_ent.size() > kMaxCheckPairs)
+    return fail(RCSH_ERR_MODEL, "more geom pairs than the end-of-launch contact check holds (" + std::to_string(kMaxCheckPairs) + ")");
+  if (!s->chk_ent.empty()) {
+    HIP_TRY(hipMalloc(&s->d_chk_ent, sizeof(CheckEntry) * s->chk_ent.size()));
+    HIP_TRY(hipMemcpyAsync(s->d_chk_ent, s->chk_ent.data(), sizeof(CheckEntry) * s->chk_ent.size(), hipMemcpyHostToDevice, s->stream));
+  }
+  if (!s->chk_geoms.empty()) {
+    HIP_TRY(hipMalloc(&s->d_chk_geoms, sizeof(CheckGeom) * s->chk_geoms.size()));
+    HIP_TRY(hipMemcpyAsync(s->d_chk_geoms, s->chk_geoms.data(), sizeof(CheckGeom) * s->chk_geoms.size(), hipMemcpyHostToDevice, s->stream));
   }
   if (!s->d_cgeoms) HIP_TRY(hipMalloc(&s->d_cgeoms, sizeof(ContactGeom) * s->cgeoms.size()));
   HIP_TRY(hipMemcpyAsync(s->d_cgeoms, s->cgeoms.data(), sizeof(ContactGeom) * s->cgeoms.size(), hipMemcpyHostToDevice, s->stream));
@@ -443,8 +446,12 @@ bool use_occ2(const rcsh_sim* s) {
   return (s->n + 3) / 4 > s->n_simd && occ2_build_pays<T, F>();
 }
 
-int launch_run(rcsh_sim* s, const RunOp& op, bool timed) {
+int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
   Params P = make_params(s);
+  RunOp op = op_in;
+  // the end-of-launch check for contacts nobody resolves: stepping launches at the handle's cadence; a caller may ask for it itself
+  if (!op.check && (op.nsteps != 0 || op.do_reset) && s->contact_check && s->check_every > 0) op.check = (s->check_seq++ % s->check_every) == 0;
+  if (!s->contact_check) op.check = 0;
   hipError_t err = hipSuccess;
   if (timed && s->prof_region) {
     // region mode: one event before the first timed launch, one after the last (rcsh_prof_read): no event traffic in between
@@ -738,7 +745,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   if (s->order_ev) hipEventDestroy(s->order_ev);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
-  hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_pairs); hipFree(s->d_chk_bpairs);
+  hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_geoms); hipFree(s->d_chk_ent);
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_rcolours); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
   hipFree(s->d_redge_planes); hipFree(s->d_redge_verts); hipFree(s->d_rviews);
@@ -1264,7 +1271,22 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
 }
 int rcsh_sim_contact_unresolved(rcsh_sim* s, uint8_t* unresolved) {
   REQUIRE_SIM(s);
+  if (s->contact_check && s->check_every != 1) {
+    // the handle checks less often than every launch: check the present state now, so that the answer is up to date
+    RunOp op{};
+    op.nsteps = 0;
+    op.observe_only = 1;
+    op.check = 1;
+    if (int rc = launch_run(s, op, false)) return rc;
+  }
   return flag_host(s, kContactUnresolved, unresolved);
+}
+int rcsh_sim_set_contact_check(rcsh_sim* s, int32_t every) {
+  REQUIRE_SIM(s);
+  if (every < 0) return fail(RCSH_ERR_ARG, "contact check cadence must be >= 0 (0: off, 1: every stepping launch)");
+  s->check_every = every;
+  s->check_seq = 0;
+  return RCSH_OK;
 }
 int rcsh_sim_contact_table_dropped(rcsh_sim* s, int32_t* geom_ids, int32_t capacity, int32_t* count, char* reason, size_t reason_capacity) {
   REQUIRE_SIM(s);
@@ -1981,8 +2003,14 @@ extern "C" int rcsh_debug_check(int* out64, int clear) {
   if (clear) { int z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rcsh::g_chk_dbg), z, sizeof(z)) != hipSuccess) return 1; }
   return 0;
 }
+extern "C" int rcsh_debug_check_cycles(unsigned long long* out16, int clear) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rcsh::g_chk_cyc), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (clear) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rcsh::g_chk_cyc), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
 extern "C" int rcsh_debug_check_pairs(rcsh_sim* s, int32_t* g0g1 /* [cap][2] */, int32_t cap, int32_t* n, int32_t* nb) {
-  *n = (int)s->chk_pairs.size(); *nb = (int)s->chk_bpairs.size();
+  *n = (int)s->chk_pairs.size(); *nb = 0;
   for (int i = 0; i < *n && i < cap; ++i) { g0g1[2 * i] = s->cgeoms[s->chk_pairs[i].g0].geom_id; g0g1[2 * i + 1] = s->cgeoms[s->chk_pairs[i].g1].geom_id; }
   return 0;
 }

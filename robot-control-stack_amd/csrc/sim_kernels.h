@@ -99,6 +99,7 @@ struct RunOp {
   int32_t nsteps;         // >= 0: Sim.step(nsteps); < 0: Sim.step_until_convergence()
   int32_t write_obs;
   int32_t observe_only;   // an observation-only pass (nsteps = 0) that must leave the rendering records of the last stepping launch alone
+  int32_t check;          // end the launch with the check for contacts nobody resolves (check_team.h; the host decides the cadence)
   const uint8_t* mask;    // optional, device
   const double* action;   // [n][action_width], device
   const float* gripper;   // [n], device
@@ -628,6 +629,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   uint32_t pre_flags = 0;
   int32_t pre_conv = 0;
   double xs_in = 0.0;
+  // the contact check's remembered directions (lanes 0..7 of a team; check_team.h): asked for with the state, used after the last substep
+  const double sep_in = live && t < kCheckSep && !opk.do_reset ? Pk.S[(size_t)(Lay<T>::SEP + t) * Pk.n + e] : 0.0;
   if (live) {
 #pragma unroll
     for (int rd = 0; rd < SF::kRounds; ++rd) {
@@ -982,6 +985,10 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     for (int c = 0; c < rend_ncam; ++c) lp.rend.last[(size_t)c * P.n + e] = lrend[team][c];
     lp.rend.count[e] = (int32_t)lrend[team][kMaxRateCams + 1];
   }
+  // what the end-of-launch contact check reads from memory is asked for now: it arrives while the leader lanes run the epilogue
+  const bool do_check = op.check && (lp.chk.npair > 0 || (!CON && lp.chk.plane_points));  // (wave-uniform)
+  CheckPrefetch chk_pf;
+  if (do_check) check_prefetch(lp.chk, lp.ctab, sep_in, live, chk_pf);
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
     env_epilogue<T, ST, false>(P, op, m, e, r, st, have_frames, nsteps);
@@ -1041,14 +1048,14 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   }
   // ---- contacts nobody resolves (check_team.h): once per stepping launch, on the position the next position stage will see.
   // Everything of the launch is in HBM by now; the LDS block and the link records' memory are the check's workspace.
-  if ((op.nsteps != 0 || op.do_reset) && (lp.chk.nbpair > 0 || (!CON && lp.chk.plane_points))) {  // (wave-uniform)
+  if (do_check) {  // (wave-uniform)
     static_assert(sizeof(LinkRec) * T::NL >= sizeof(double) * 12 * T::NL * kTeams, "the links' world frames fit where their records were");
     const double q_final = live && t < T::NL ? st.q(t) : 0.0;
     __syncthreads();
     double* const sep = P.S + (size_t)Lay<T>::SEP * P.n + (live ? e : 0);
-    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), lds, q_final, live, !CON, sep, P.n);
+    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), lds, q_final, live, !CON, sep_in, sep, P.n, chk_pf);
 #ifdef RCSH_CHECK_DEBUG
-    if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[35], (int)((r.flags >> 16) & 1u)); atomicAdd(&g_chk_dbg[36], (int)((pre_flags >> 16) & 1u)); atomicAdd(&g_chk_dbg[37], 1); }
+    if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif
     if (leader && hit && !(r.flags & kContactUnresolved)) {
       P.flags[e] = r.flags | kContactUnresolved;

@@ -180,6 +180,7 @@ EXPORTS = (
     "rcsh_comm_destroy",
     "rcsh_sim_contact_table_dropped",
     "rcsh_sim_contact_unresolved",
+    "rcsh_sim_set_contact_check",
 )
 
 _lib = None

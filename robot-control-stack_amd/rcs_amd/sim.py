@@ -107,6 +107,11 @@ class Sim:
         self.resolve_robot_contacts = True
         return True
 
+    def set_contact_check(self, every: int) -> None:
+        """Cadence of the end-of-launch check for contacts nobody resolves: every `every`-th stepping launch (default 1 -- exact
+        per env-step; 0: off).  See rcsh_sim_set_contact_check (include/rcs_hip.h) for what a larger cadence trades."""
+        _lib.check(self._L.rcsh_sim_set_contact_check(self._h, int(every)))
+
     def contact_unresolved(self) -> np.ndarray:
         """[N] bool: the environment's geoms were found in a contact this configuration does not resolve, since its last
         Sim.reset (the sticky flag the end-of-launch check sets, csrc/check_team.h; also info["contact_unresolved"])."""

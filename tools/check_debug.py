@@ -30,7 +30,30 @@ for t in range(3):
     _, _, _, _, info = venv.step({"joints": np.zeros((n, 7)), "gripper": np.ones(n)})
     L.rcsh_debug_check(out, 1)
     o = list(out)
-    print("step", t, "flag", info["contact_unresolved"], "plane hits", o[0], "pair hits", o[1], "body pairs surviving", o[32], "geom pairs to MPR", o[33], "leader hits", o[34], "r.flags bit", o[35], "pre_flags bit", o[36], "leaders", o[37])
+    print("step", t, "flag", info["contact_unresolved"], "plane hits", o[0], "pair hits", o[1], "sphere survivors", o[32], "geom pairs to MPR", o[33], "leader hits", o[34], "r.flags bit", o[35], "pre_flags bit", o[36], "leaders", o[37], "full MPR", o[38], "not prefetched", o[39])
     for k in range(min(o[1], 28)):
         i = o[2 + k]
         print("   pair", i, names[pairs[2 * i]], names[pairs[2 * i + 1]])
+
+cyc = (C.c_ulonglong * 16)()
+L.rcsh_debug_check_cycles(cyc, 1)
+N = 50
+for t in range(N):
+    venv.step({"joints": np.random.default_rng(t).uniform(-0.08, 0.08, (n, 7)), "gripper": np.ones(n) * (t % 2)})
+L.rcsh_debug_check_cycles(cyc, 1)
+names_ = ["FK", "frames+boxes", "plane", "spheres", "OBB", "narrow", "sep store"]
+print("cycles per check (workgroup 0):", {nm: int(cyc[i] / N) for i, nm in enumerate(names_)}, "total", int(sum(cyc[:7]) / N))
+
+# statistics of a random walk (the headline's actions) on a bigger batch
+venv.close()
+n = 1024
+venv = PU.make_vec_env(n, True)
+venv.reset()
+joints, grip = PU.synthetic_actions(n, 300, 0)
+L.rcsh_debug_check(out, 1)
+for t in range(300):
+    venv.step({"joints": joints[t], "gripper": grip[t]})
+    if t % 50 == 49:
+        L.rcsh_debug_check(out, 1)
+        o = list(out)
+        print(f"steps {t-49}..{t}: per env-step: sphere survivors {o[32]/n/50:.2f}, pairs to narrow {o[33]/n/50:.2f}, full MPR {o[38]/n/50:.3f}, hits {o[1]/n/50:.4f}; per wave-step not prefetched {o[39]/(n/4)/50:.3f}")
