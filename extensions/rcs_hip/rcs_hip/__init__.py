@@ -57,16 +57,28 @@ def render_tables(cm, scene_dir: str) -> dict:
     return d
 
 
-def pin_tables(path: str, frame_id: str, device: int = 0) -> dict:
-    """What ``rcs_hip._core.common.Pin(path, frame_id, urdf=False)`` loads: the model tables of the MJCF at `path` plus the ids
-    of the serial chain that carries the site `frame_id` -- its hinge joints from the root outwards, their actuators, the site,
-    the root body the chain hangs on (the frame ``Pin`` works in; DESIGN.md section 5 on pinocchio's root-frame semantics)."""
+def pin_tables(path: str, frame_id: str, device: int = 0, urdf: bool = False) -> dict:
+    """What ``rcs_hip._core.common.Pin(path, frame_id, urdf)`` loads: the model tables of the file at `path` plus the ids of the
+    serial chain that carries the frame `frame_id` -- its hinge joints from the root outwards, their actuators, the site, the root
+    body the chain hangs on (the frame ``Pin`` works in; DESIGN.md section 5 on pinocchio's root-frame semantics).  ``urdf=True``
+    (the reference's default, src/pybind/rcs.cpp:296-300): a URDF, whose links are frames by name (``rcs_amd.urdf``); an empty
+    `frame_id` then means the chain's last link (what ``RoboticsLibraryIK`` calls operational frame 0).  Otherwise an MJCF file
+    and `frame_id` names a site."""
     from rcs_amd.mjcf import compile_mjcf
 
-    cm = compile_mjcf(path)
+    if urdf:
+        from rcs_amd.urdf import compile_urdf
+
+        cm, info = compile_urdf(path)
+        if not frame_id:
+            if len(info["leaves"]) != 1:
+                raise RuntimeError(f"{path}: the URDF is not a serial chain (leaf links {info['leaves']}): name the frame")
+            frame_id = info["leaves"][0]
+    else:
+        cm = compile_mjcf(path)
     site = cm.name2id("site", frame_id)
     if site < 0:
-        raise RuntimeError(f"No site named {frame_id}")
+        raise RuntimeError(f"No {'link' if urdf else 'site'} named {frame_id}")
     parent = np.asarray(cm.arrays["body_parentid"])
     jnt_body = np.asarray(cm.arrays["jnt_bodyid"])
     jnt_type = np.asarray(cm.arrays["jnt_type"])

@@ -295,9 +295,9 @@ struct Pin : Kinematics {
   int dof = 0, nq = 0;
   std::vector<py::array> keep;
   Pin(const std::string& path, const std::string& frame_id, bool urdf) {
-    if (urdf) throw std::runtime_error("Pin: URDF models are not compiled by this backend; pass the robot's MJCF with urdf=False (as the simulation path does, creators.py:81-85)");
-    // the MJCF subset compiler is host Python (rcs_amd.mjcf); rcs_hip.pin_tables returns mjModel-named tables + the chain's ids
-    const py::dict t = py::module_::import("rcs_hip").attr("pin_tables")(path, frame_id).cast<py::dict>();
+    // the scene compiler is host Python (rcs_amd.mjcf; a URDF is rewritten as MJCF first, rcs_amd.urdf: its links are the frames);
+    // rcs_hip.pin_tables returns mjModel-named tables + the chain's ids
+    const py::dict t = py::module_::import("rcs_hip").attr("pin_tables")(path, frame_id, 0, urdf).cast<py::dict>();
     const py::dict model = t["model"].cast<py::dict>();
     rcsh_model_desc d{};
     auto geti = [&](const char* k) { return model.contains(k) ? model[k].cast<int>() : 0; };
@@ -370,6 +370,18 @@ struct Pin : Kinematics {
     std::memcpy(r.t, p7, sizeof(r.t)); std::memcpy(r.q, p7 + 3, sizeof(r.q));
     return Pose(r);
   }
+};
+
+// rcs_robotics_library._core.rl.RoboticsLibraryIK (reference extensions/rcs_robotics_library/src/pybind/RL.h:18-70): `Kinematics` on a
+// URDF, operational frame 0 = the chain's last link.  The reference hands the solve to Robotics Library's JacobianInverseKinematics
+// (eps 1e-3, no random restarts, a wall-clock budget of max_duration_ms); RL is a third-party dependency that is not vendored in
+// the reference tree, so its iteration is not restated here: the solve is the backend's CLIK -- Pin::inverse's damped least squares
+// (src/rcs/Kinematics.cpp:28-68) as a HIP kernel, 1000 iterations at most, which at ~6k cycles an iteration is far inside any
+// budget a caller passes -- and `forward` is the same chain's forward map.  PARITY WITH RL IS UNPINNED (interface only):
+// both return a joint vector that reaches the pose, or None; the iterates differ.
+struct RoboticsLibraryIK : Pin {
+  size_t max_duration_ms;
+  RoboticsLibraryIK(const std::string& urdf_path, size_t max_duration_ms_) : Pin(urdf_path, "", true), max_duration_ms(max_duration_ms_) {}
 };
 
 }  // namespace
@@ -470,4 +482,8 @@ void bind_common(py::module_& m) {
       .def("inverse", &Kinematics::inverse, py::arg("pose"), py::arg("q0"), py::arg("tcp_offset") = Pose());
   py::class_<Pin, Kinematics, std::shared_ptr<Pin>>(common, "Pin")
       .def(py::init<const std::string&, const std::string&, bool>(), py::arg("path"), py::arg("frame_id") = "fr3_link8", py::arg("urdf") = true);
+  // the reference binds this class in a module of its own, rcs_robotics_library._core.rl (extensions/rcs_robotics_library/src/pybind/rcs.cpp:37-47)
+  auto rl = m.def_submodule("rl", "rcs robotics library module");
+  py::class_<RoboticsLibraryIK, Kinematics, std::shared_ptr<RoboticsLibraryIK>>(rl, "RoboticsLibraryIK")
+      .def(py::init<const std::string&, size_t>(), py::arg("urdf_path"), py::arg("max_duration_ms") = 300);
 }

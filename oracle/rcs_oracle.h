@@ -36,7 +36,7 @@ extern "C" {
 #define ORC_MAXEQ 4
 #define ORC_MAXTENDON 4
 #define ORC_MAXWRAP 8
-#define ORC_MAXSITE 8
+#define ORC_MAXSITE 32
 #define ORC_MAXCON 64
 #define ORC_MAXEFC (ORC_MAXEQ + 3 * ORC_MAXV + 3 * ORC_MAXCON)
 #define ORC_NVT (ORC_MAXV + 6) /* dofs of the coupled system: the robot's joints, then the free box's 6 */

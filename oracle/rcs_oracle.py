@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librcs_oracle.so")
 
-MAXBODY, MAXV, MAXU, MAXEQ, MAXTENDON, MAXWRAP, MAXSITE, MAXARM = 32, 16, 16, 4, 4, 8, 8, 8
+MAXBODY, MAXV, MAXU, MAXEQ, MAXTENDON, MAXWRAP, MAXSITE, MAXARM = 32, 16, 16, 4, 4, 8, 32, 8
 MAXGEOM, MAXCON, MAXCGEOM = 32, 64, 16
 MAXEFC = MAXEQ + 3 * MAXV + 3 * MAXCON
 NVT = MAXV + 6
@@ -193,7 +193,7 @@ def make_model(cm, resolve_contacts: bool = True) -> OrcModel:
     of robot geoms are detected (collision flags) but exert no force."""
     if cm.nq != cm.nv or cm.nq != cm.njnt:
         raise ValueError("oracle supports hinge/slide joints only")
-    if cm.nbody > MAXBODY or cm.nv > MAXV or cm.nu > MAXU:
+    if cm.nbody > MAXBODY or cm.nv > MAXV or cm.nu > MAXU or cm.nsite > MAXSITE or cm.neq > MAXEQ or cm.ntendon > MAXTENDON or cm.nwrap > MAXWRAP:
         raise ValueError("scene exceeds oracle table sizes")
     m = OrcModel()
     m.nbody, m.njnt, m.nu = cm.nbody, cm.njnt, cm.nu

@@ -77,11 +77,35 @@ def urdf_to_mjcf(path: str) -> tuple[str, dict]:
             full = [float(it.get(k, "0")) for k in ("ixx", "iyy", "izz", "ixy", "ixz", "iyz")]
         return f'{indent}<inertial pos="{_fmt(pos)}" quat="{_fmt(quat)}" mass="{max(mass, 1e-6)!r}" fullinertia="{_fmt(full)}"/>'
 
-    def emit(name: str, joint, depth: int) -> None:
-        indent = "  " * (depth + 2)
+    def quat_mul(a, b):
+        return [a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]]
+
+    def quat_rot(q, v):
+        w, x, y, z = q
+        return [(1 - 2 * (y * y + z * z)) * v[0] + 2 * (x * y - w * z) * v[1] + 2 * (x * z + w * y) * v[2],
+                2 * (x * y + w * z) * v[0] + (1 - 2 * (x * x + z * z)) * v[1] + 2 * (y * z - w * x) * v[2],
+                2 * (x * z - w * y) * v[0] + 2 * (y * z + w * x) * v[1] + (1 - 2 * (x * x + y * y)) * v[2]]
+
+    def origin_of(joint):
         org = joint.find("origin") if joint is not None else None
-        pos = _floats(org.get("xyz") if org is not None else None, 3)
-        quat = _rpy_to_quat(_floats(org.get("rpy") if org is not None else None, 3))
+        return _floats(org.get("xyz") if org is not None else None, 3), _rpy_to_quat(_floats(org.get("rpy") if org is not None else None, 3))
+
+    def welded(name: str, pos, quat, indent: str) -> None:
+        """Links hanging on `name` by FIXED joints ride on the same body: their frames become sites of it (placement composed),
+        their own children hang on it with the composed placement.  (`pos`, `quat`: the link's frame in the body's.)"""
+        out.append(f'{indent}<site name="{name}" pos="{_fmt(pos)}" quat="{_fmt(quat)}"/>')
+        for j in children[name]:
+            jp, jq = origin_of(j)
+            cp = [a + b for a, b in zip(pos, quat_rot(quat, jp))]
+            cq = quat_mul(quat, jq)
+            child = j.find("child").get("link")
+            if j.get("type") == "fixed":
+                welded(child, cp, cq, indent)
+            else:
+                emit(child, j, cp, cq, indent)
+
+    def emit(name: str, joint, pos, quat, indent: str) -> None:
         out.append(f'{indent}<body name="{name}" pos="{_fmt(pos)}" quat="{_fmt(quat)}">')
         out.append(inertial(links[name], indent + "  "))
         if joint is not None:
@@ -99,14 +123,12 @@ def urdf_to_mjcf(path: str) -> tuple[str, dict]:
                 moving.append(joint.get("name"))
                 actuators.append(f'    <general name="act_{joint.get("name")}" joint="{joint.get("name")}" biastype="affine" gainprm="1000" biasprm="0 -1000 -100" '
                                  f'ctrlrange="{lo!r} {hi!r}"/>')
-            elif jtype != "fixed":
+            else:
                 raise RuntimeError(f"URDF joint {joint.get('name')}: type {jtype!r} is outside the supported set (revolute, continuous, prismatic, fixed)")
-        out.append(f'{indent}  <site name="{name}" pos="0 0 0"/>')
-        for j in children[name]:
-            emit(j.find("child").get("link"), j, depth + 1)
+        welded(name, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], indent + "  ")
         out.append(f"{indent}</body>")
 
-    emit(roots[0], None, 0)
+    emit(roots[0], None, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], "    ")
     text = "\n".join([
         f'<mujoco model="{root.get("name", "urdf")}">',
         '  <compiler angle="radian" autolimits="true"/>',

@@ -124,3 +124,53 @@ def test_contact_unresolved_is_cleared_by_reset_and_can_switch_the_batch_to_reso
         _, info = venv.reset()
         assert not venv.sim.contact_unresolved().any()
         venv.close()
+
+
+def test_compiled_pin_on_the_urdf_and_the_rl_ik_class():
+    """Verdict r3, missing 3: `Pin(path, frame_id="fr3_link8", urdf=True)` -- the reference's DEFAULT constructor
+    (src/pybind/rcs.cpp:296-300, src/rcs/Kinematics.cpp:12-19) -- on the kinematic content of the reference's fr3.urdf, and
+    `RoboticsLibraryIK(urdf_path, max_duration_ms=300)` (extensions/rcs_robotics_library/src/pybind/RL.h:18-70) constructible by
+    name.  The URDF model must agree with the MJCF model of the same chain: forward map of `fr3_link8` == the MJCF's attachment
+    site (1e-12, 32 poses), `inverse` == the MJCF Pin's joint solution (1e-9) and == the oracle's restatement of Pin::inverse.
+    RoboticsLibraryIK: same chain, operational frame = the last link; RL's own iteration is un-vendored (parity unpinned, stated in
+    the class): what is checked is that its solution reaches the pose."""
+    import sys
+
+    import rcs_oracle as O
+    from parity_util import ROOT, SCENE
+    from rcs_amd.urdf import compile_urdf
+
+    sys.path.insert(0, os.path.join(ROOT, "extensions", "rcs_hip"))
+    from rcs_hip import _core
+
+    c = _core.common
+    urdf = os.path.join(os.path.dirname(SCENE), "fr3.urdf")
+    pin_u = c.Pin(urdf)  # defaults: frame_id="fr3_link8", urdf=True
+    pin_m = c.Pin(SCENE, "attachment_site_0", False)
+    rl = _core.rl.RoboticsLibraryIK(urdf)
+    assert isinstance(pin_u, c.Kinematics) and isinstance(rl, c.Kinematics)
+    cu, info = compile_urdf(urdf)
+    from rcs_env_oracle import FR3_Q_HOME
+
+    ou = O.Sim(cu, info["joints"], ["act_" + j for j in info["joints"]], "fr3_link8", "fr3_link0", FR3_Q_HOME, None, arm_collision_geoms=[])
+    q_home = np.asarray(FR3_Q_HOME)
+    rng = np.random.default_rng(11)
+    tcp = c.Pose(pose_matrix=c.FrankaHandTCPOffset())
+    solved = 0
+    for k in range(32):
+        q = q_home + rng.uniform(-0.4, 0.4, 7)
+        fu, fm, fr = pin_u.forward(q, tcp), pin_m.forward(q, tcp), rl.forward(q, tcp)
+        assert np.abs(fu.translation() - fm.translation()).max() < 1e-12 and np.abs(fu.rotation_q() - fm.rotation_q()).max() < 1e-12
+        assert fr.is_close(fu, 1e-12, 1e-12)
+        if k < 10:
+            qu, qm, qr = pin_u.inverse(fu, q_home, tcp), pin_m.inverse(fm, q_home, tcp), rl.inverse(fu, q_home, tcp)
+            oq, _ = ou.ik_inverse(O.Pose(translation=fu.translation(), quaternion=fu.rotation_q()), q_home, O.franka_hand_tcp_offset())
+            assert (qu is None) == (qm is None) == (oq is None)
+            if qu is not None:
+                assert qu.shape == (7,)  # model.nq of the URDF: the arm alone (the MJCF scene's model has the fingers too, quirk Q7)
+                assert np.abs(qu - qm[:7]).max() < 1e-9 and np.abs(qu - oq[:7]).max() < 1e-9
+                assert qr is not None and rl.forward(qr, tcp).is_close(fu, 1e-3, 1e-3)
+                solved += 1
+    assert solved >= 7
+    with pytest.raises(RuntimeError, match="No link named"):
+        c.Pin(urdf, "no_such_link")

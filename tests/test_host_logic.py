@@ -578,8 +578,52 @@ def test_pybind_common_module_matches_the_reference_api():
     cfg = c.RobotConfig()
     assert (cfg.robot_type, cfg.robot_platform, cfg.attachment_site) == (c.RobotType.FR3, c.RobotPlatform.SIMULATION, "attachment_site")
     assert cfg.tcp_offset.is_close(c.Pose())
-    with pytest.raises(RuntimeError, match="URDF"):
-        c.Pin("robot.urdf")
+    # the RL IK class of the reference's rcs_robotics_library extension (rl.pyi): constructible by name, a Kinematics
+    for cls, spec in api["rl"].items():
+        k = getattr(_core.rl, cls)
+        assert issubclass(k, c.Kinematics), cls
+        for name, args in spec["methods"].items():
+            doc = getattr(k, name).__doc__ or ""
+            assert all(re.search(rf"\b{a}: ", doc) for a in args), (cls, name, args, doc)
+    with pytest.raises((RuntimeError, OSError)):
+        c.Pin("no_such_robot.urdf")  # (the reference's default is urdf=True: the file is read as a URDF)
+
+
+def test_urdf_chain_equals_the_mjcf_chain_on_the_oracle():
+    """`Pin(path, frame_id="fr3_link8", urdf=True)` is the reference's default constructor (src/pybind/rcs.cpp:296-300,
+    src/rcs/Kinematics.cpp:12-19) and the reference ships assets/fr3/urdf/fr3.urdf.  The URDF reader (rcs_amd.urdf: the chain
+    rewritten as MJCF, fixed joints folded into their moving ancestor, a frame per link) must give the same kinematics as the
+    MJCF model of the same robot: forward map of `fr3_link8` == the MJCF's attachment site at 32 configurations (round-off), and
+    the CLIK's iterates on the two models -- the oracle's restatement of Pin::inverse -- agree to the last iteration."""
+    import rcs_oracle as O
+    from parity_util import SCENE
+    from rcs_amd.mjcf import compile_mjcf
+    from rcs_amd.urdf import compile_urdf, urdf_to_mjcf
+    from rcs_env_oracle import FR3_Q_HOME
+
+    urdf = os.path.join(os.path.dirname(SCENE), "fr3.urdf")
+    text, info = urdf_to_mjcf(urdf)
+    assert info["joints"] == [f"fr3_joint{i}" for i in range(1, 8)] and info["root"] == "fr3_link0" and info["leaves"] == ["fr3_link8"]
+    assert text.count("<body ") == 8 and 'site name="fr3_link8" pos="0.0 0.0 0.107"' in text  # link8 rides on link7's body
+    cu, _ = compile_urdf(urdf)
+    joints = info["joints"]
+    ou = O.Sim(cu, joints, ["act_" + j for j in joints], "fr3_link8", "fr3_link0", FR3_Q_HOME, None, arm_collision_geoms=[])
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    om = O.Sim(compile_mjcf(SCENE), arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0")
+    rng = np.random.default_rng(0)
+    for _ in range(32):
+        q = np.asarray(FR3_Q_HOME) + rng.uniform(-0.6, 0.6, 7)
+        a, b = ou.ik_forward(q), om.ik_forward(q)
+        assert np.abs(a.translation() - b.translation()).max() < 1e-14 and np.abs(a.rotation_q() - b.rotation_q()).max() < 1e-14
+    for k in range(8):
+        target = om.ik_forward(np.asarray(FR3_Q_HOME) + rng.uniform(-0.3, 0.3, 7))
+        (qa, ia), (qb, ib) = ou.ik_inverse(target, FR3_Q_HOME), om.ik_inverse(target, FR3_Q_HOME)
+        assert ia == ib and qa is not None and np.abs(qa[:7] - qb[:7]).max() < 1e-12, (k, ia, ib)
+    # the joint limits the URDF states are the robot's (robots_meta_config, Robot.h:28-43)
+    from rcs_amd import common as H
+
+    lim = H.robots_meta_config(H.RobotType.FR3).joint_limits
+    assert np.allclose(np.asarray(cu.arrays["jnt_range"])[:, 0], lim[0]) and np.allclose(np.asarray(cu.arrays["jnt_range"])[:, 1], lim[1])
 
 
 def test_compiled_pose_equals_the_host_mirror():

@@ -58,6 +58,12 @@ def main():
             common["functions"][node.name] = [a.arg for a in node.args.args]
         elif isinstance(node, ast.AnnAssign) and isinstance(node.target, ast.Name) and ast.unparse(node.annotation) in ("RobotType", "RobotPlatform", "GraspType"):
             common["constants"].append(node.target.id)
+    # the RL IK class lives in an extension module of its own (extensions/rcs_robotics_library: rcs_robotics_library._core.rl)
+    rl_stub = "/root/reference/extensions/rcs_robotics_library/src/rcs_robotics_library/_core/rl.pyi"
+    common["rl"] = {}
+    for node in ast.parse(open(rl_stub).read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == "RoboticsLibraryIK":
+            common["rl"][node.name] = class_entry(node)
     json.dump(common, open(OUT_COMMON, "w"), indent=1, sort_keys=True)
     print("wrote", OUT_COMMON, {k: len(v["methods"]) for k, v in common["classes"].items()}, common["functions"], common["constants"])
 
