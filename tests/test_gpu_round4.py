@@ -169,7 +169,11 @@ def test_compiled_pin_on_the_urdf_and_the_rl_ik_class():
             if qu is not None:
                 assert qu.shape == (7,)  # model.nq of the URDF: the arm alone (the MJCF scene's model has the fingers too, quirk Q7)
                 assert np.abs(qu - qm[:7]).max() < 1e-9 and np.abs(qu - oq[:7]).max() < 1e-9
-                assert qr is not None and rl.forward(qr, tcp).is_close(fu, 1e-3, 1e-3)
+                assert qr is not None and np.array_equal(qr, qu)  # (the same solve behind both classes)
+                # reaching the pose, with an identity offset (with one, forward and inverse apply it on different sides: quirk Q7)
+                target = rl.forward(q)
+                q2 = rl.inverse(target, q_home)
+                assert q2 is not None and rl.forward(q2).is_close(target, 1e-3, 1e-3)
                 solved += 1
     assert solved >= 7
     with pytest.raises(RuntimeError, match="No link named"):
