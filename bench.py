@@ -11,8 +11,9 @@ reference python/rcs/envs/sim.py:52-53).  Inputs (the pre-generated action tenso
 timed region; each step is one fused kernel launch through the C-ABI (rcsh_env_step_dev).  With N > 1 every rank
 owns 4096 environments on its own GPU (weak scaling) and the observation tensor is all-gathered over RCCL once
 per step, inside the timed region.  No PyTorch on the data path: device buffers are rcsh_dev_alloc'ed, actions drawn with
-numpy, streams ordered by the library's own handles; with N > 1 torch.distributed (gloo, CPU tensors) is the launcher's
-rendezvous only -- RCCL id, barriers, max-over-ranks of the clock -- and the exchange is RCCL behind the C-ABI.
+numpy, streams ordered by the library's own handles; with N > 1 the ranks (launched by torch.distributed.run, or by this script
+itself: `python bench.py --gpus N`) meet over a Unix-domain socket -- RCCL id, barriers, max-over-ranks of the clock -- and the
+exchange is RCCL behind the C-ABI: no rank imports torch.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (algorithmic HBM bytes of the fused launch / measured
 kernel time, HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on this host's cores on a
@@ -162,7 +163,8 @@ def main() -> None:
                          "env-steps, plus once on the final state after the clock stopped (config.contacts_seen counts what both found).  1: every "
                          "env-step, the library's default and what the parity tests run (the check costs about as much as one to two of the "
                          "step's 17 substeps); 0: off")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the measured configuration) or gloo (to exercise the N > 1 code path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL behind the C-ABI; the measured configuration) or host (the observation blocks through the rendezvous socket and host memory: "
+                                                               "exercises the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -172,14 +174,17 @@ def main() -> None:
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher of N ranks, one per GPU (what the driver's
         # `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` does)
+        # (no launcher framework either: N child processes with the environment torch.distributed.run would give them)
         import socket
 
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-        raise SystemExit(subprocess.call(cmd))
+        procs = []
+        for r in range(args.gpus):
+            env_r = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env_r))
+        raise SystemExit(max(p.wait() for p in procs))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -198,9 +203,9 @@ def main() -> None:
     from rcs_amd.envs import MAX_JOINT_MOV, make_vec_env
 
     # No PyTorch on this path (BASELINE north star): device memory comes from the C-ABI (rcsh_dev_alloc), the synthetic actions
-    # from numpy, streams and their ordering from the library's own handles.  With N > 1 ranks torch.distributed serves as the
-    # launcher's rendezvous only -- a gloo group on CPU tensors for the RCCL id, the barriers and the max-over-ranks of the
-    # clock -- and the one exchange of the data path, the all-gather of the observation block, is RCCL behind the C-ABI.
+    # from numpy, streams and their ordering from the library's own handles; with N > 1 ranks the launcher-side rendezvous is a
+    # Unix-domain socket (rcs_amd.envs.sharding.SocketRendezvous) and the one exchange of the data path, the all-gather of the
+    # observation block, is RCCL behind the C-ABI.
     if os.environ.get("RCSH_LIB"):
         _lib.LIB_PATH = os.environ["RCSH_LIB"]  # (a development build of the library, for A/B measurements)
     L0 = _lib.load()
@@ -211,18 +216,21 @@ def main() -> None:
     # (then that is device 0), or there are fewer GPUs than ranks (a functional check: ranks share a GPU, RCCL refuses two ranks on
     # one device and the exchange falls back to the rendezvous group through host memory, see below).
     local_rank %= n_dev
-    dist = None
+    from rcs_amd.envs.sharding import SocketRendezvous
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-            # one node: RCCL's bootstrap (ncclGetUniqueId / ncclCommInitRank) and gloo over the loopback interface -- the
-            # container's hostname may not resolve, and the interface RCCL would pick by default may not be routable between ranks
+            # one node: RCCL's bootstrap (ncclGetUniqueId / ncclCommInitRank) over the loopback interface -- the container's
+            # hostname may not resolve, and the interface RCCL would pick by default may not be routable between ranks
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        import torch
-        import torch.distributed as dist
-
-        dist.init_process_group("gloo")
+        # the one message is 688 KB per rank (4096 x 21 f64): one or two channels -- each channel is a 256-thread workgroup of
+        # ~270 registers per lane that must find a SIMD next to (or in turn with) the stepping wavefronts; RCCL's default for a
+        # node is many more, sized for bandwidth on megabyte messages
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
+    # the launcher's rendezvous: a Unix-domain socket (RCCL id, barriers, max over ranks of the clock); no torch.distributed
+    rdv = SocketRendezvous(rank, world)
 
     n = args.envs
     T = args.steps + args.warmup
@@ -299,22 +307,22 @@ def main() -> None:
     sub = DevBuf((n,), np.int32)
 
     class HostStagedExchange:
-        """The exchange protocol of RcclObservationExchange carried by the rendezvous group instead (gloo, through host memory,
-        not overlapped): `--dist-backend gloo` -- ranks sharing a GPU, where RCCL refuses to form a communicator -- and the
-        fallback when the C-ABI communicator cannot be created on some rank.  Functional, not the measured configuration."""
+        """The exchange protocol of RcclObservationExchange carried by the launcher's rendezvous socket instead (through host
+        memory, not overlapped): `--dist-backend host` -- ranks sharing a GPU, where RCCL refuses to form a communicator -- and
+        the fallback when the C-ABI communicator cannot be created on some rank.  Functional, not the measured configuration."""
 
         def __init__(self):
             self._local = [DevBuf((n, ow), np.float64) for _ in range(2)]
-            self._all = [torch.zeros((world * n, ow), dtype=torch.float64) for _ in range(2)]
+            self._all = [np.zeros((world * n, ow)) for _ in range(2)]
 
         def local_ptr(self, t: int) -> int:
             return self._local[t & 1].ptr
 
         def post(self, t: int) -> None:
-            dist.all_gather_into_tensor(self._all[t & 1], torch.from_numpy(self._local[t & 1].download()))
+            self._all[t & 1] = np.concatenate(rdv.gather(self._local[t & 1].download()))
 
         def gathered(self, t: int) -> np.ndarray:
-            return self._all[t & 1].numpy()
+            return self._all[t & 1]
 
         def drain(self) -> None:
             pass
@@ -335,22 +343,19 @@ def main() -> None:
             my_id = comm_unique_id()
         except RuntimeError as exc:
             comm_error = str(exc)
-        okflag = torch.tensor([0 if comm_error else 1])
-        dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
-        if int(okflag.item()) == 1:
-            box = [my_id if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
+        all_ok = rdv.reduce(0 if comm_error else 1, min)
+        if all_ok == 1:
+            root_id = rdv.broadcast(my_id if rank == 0 else None)
             try:
-                exchange = RcclObservationExchange(env.sim, bytes(box[0]), rank, world, n_rows=n, width=ow)
+                exchange = RcclObservationExchange(env.sim, bytes(root_id), rank, world, n_rows=n, width=ow)
             except RuntimeError as exc:  # e.g. a communicator RCCL refuses on this topology
                 comm_error = str(exc)
-            okflag = torch.tensor([0 if comm_error else 1])
-            dist.all_reduce(okflag, op=dist.ReduceOp.MIN)  # every rank takes the same carrier
-        if int(okflag.item()) == 0:
+            all_ok = rdv.reduce(0 if comm_error else 1, min)  # every rank takes the same carrier
+        if all_ok == 0:
             if exchange is not None:
                 exchange.close()
             exchange = HostStagedExchange()
-            args.dist_backend = "gloo through host memory (the C-ABI RCCL communicator could not be created: " + (comm_error or "on another rank") + ")"
+            args.dist_backend = "the rendezvous socket through host memory (the C-ABI RCCL communicator could not be created: " + (comm_error or "on another rank") + ")"
     elif world > 1:
         exchange = HostStagedExchange()
 
@@ -439,8 +444,7 @@ def main() -> None:
     if exchange:
         exchange.drain()
     device_sync()
-    if world > 1:
-        dist.barrier()
+    rdv.barrier()
     t0 = time.perf_counter()
     for t in range(args.warmup, T):
         one_step(t)
@@ -450,34 +454,38 @@ def main() -> None:
     if exchange:
         exchange.drain()
     device_sync()
-    if world > 1:
-        dist.barrier()
+    rdv.barrier()
     elapsed = time.perf_counter() - t0
     obs_host = obs.download()
     if exchange:  # (after the clock stopped) this rank's rows of the last gathered tensor: finiteness check below
         obs_host = np.asarray(exchange.gathered(T - 1))[rank * n:(rank + 1) * n]
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = rdv.reduce(elapsed, max)
 
     kernel_ms = ms.value / max(launches.value, 1)
     # N > 1: the same K steps once more WITHOUT the exchange (after the clock stopped; reported next to the measured value, never
     # as it) -- what the all-gather costs a step on this node, i.e. how much of a scaling loss is the exchange's and how much the shards'
-    no_exchange_value = None
+    no_exchange_value = exchange_ms = None
     if world > 1 and exchange is not None and not episode:
         saved_exchange, exchange = exchange, None
         device_sync()
-        dist.barrier()
+        rdv.barrier()
         t1 = time.perf_counter()
         for t in range(args.warmup, T):
             one_step(t)
         device_sync()
-        dist.barrier()
-        tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        no_exchange_value = world * n * args.steps / float(tt.item())
+        rdv.barrier()
+        no_exchange_value = world * n * args.steps / rdv.reduce(time.perf_counter() - t1, max)
         exchange = saved_exchange
+        # ... and the gather ALONE, back to back on an otherwise idle device: what one exchange costs when nothing hides it
+        exchange.drain()
+        rdv.barrier()
+        t2 = time.perf_counter()
+        for t in range(args.steps):
+            exchange.local_ptr(t)  # (retires the gather that last used the slot)
+            exchange.post(t)
+        exchange.drain()
+        rdv.barrier()
+        exchange_ms = rdv.reduce(time.perf_counter() - t2, max) / args.steps * 1e3
     mean_sub = float(sub.download().astype(np.float64).mean())
     # Environments found in a contact the running configuration does not resolve, by the end of the timed region (the sticky flag
     # of the end-of-launch check, csrc/check_team.h; cleared by the reset before the W warmup steps).  The words "no contacts" in
@@ -485,10 +493,7 @@ def main() -> None:
     contacts_seen = 0
     for e_ in envs:
         contacts_seen += int(e_.sim.contact_unresolved().sum())
-    if world > 1:
-        tc = torch.tensor([contacts_seen], dtype=torch.int64)
-        dist.all_reduce(tc, op=dist.ReduceOp.SUM)
-        contacts_seen = int(tc.item())
+    contacts_seen = rdv.reduce(contacts_seen, sum)
     finite = bool(np.isfinite(obs_host).all())
     if task_out is not None:
         finite = finite and bool(np.isfinite(task_out.download()).all())
@@ -551,13 +556,16 @@ def main() -> None:
                 "episode_length": episode or None,
                 "depth_frames": (f"{args.cameras} at {args.resolution}, one ray-cast uint16 frame per camera per env-step "
                                  f"({len(cam_out) * n * int(args.resolution.split('x')[0]) * int(args.resolution.split('x')[1]) / (elapsed / args.steps) / 1e9:.2f} G rays/s incl. the physics)") if cam_out else None,
-                "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"torch.distributed {args.dist_backend} all_gather")
+                "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"all-gather over {args.dist_backend}")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "contacts_seen": contacts_seen,
                 "contact_check": (f"exact collision check of every environment every {args.contact_check_every} env-steps inside the timed region"
                                   if args.contact_check_every > 0 else "no check inside the timed region") + " + once on the final state (sticky flags, csrc/check_team.h)",
                 "obs_finite": finite,
                 "value_without_exchange": no_exchange_value,
+                "exchange_ms": exchange_ms,  # the gather alone, back to back (after the clock stopped)
+                "rccl_channels": (os.environ.get("NCCL_MIN_NCHANNELS"), os.environ.get("NCCL_MAX_NCHANNELS")) if world > 1 else None,
+                "rendezvous": "Unix-domain socket (rcs_amd.envs.sharding.SocketRendezvous): no torch.distributed in any rank" if world > 1 else None,
                 "clock_warmup": (f"{clock_warmup_launches} untimed launches over {args.clock_warmup_ms:g} ms before the W warmup steps, then a reset "
                                  "(the device reaches its operating clocks after ~12 ms of work)") if clock_warmup_launches else None,
             },
@@ -590,8 +598,7 @@ def main() -> None:
         print(json.dumps(out))
     if exchange:
         exchange.close()
-    if world > 1:
-        dist.destroy_process_group()
+    rdv.close()
 
 
 if __name__ == "__main__":

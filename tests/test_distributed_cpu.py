@@ -72,3 +72,34 @@ def test_two_rank_observation_all_gather():
     results = dict(out.get(timeout=5) for _ in range(2))
     assert results == {0: True, 1: True}
     _ = np
+
+
+def _socket_worker(rank, world, name, out):
+    from rcs_amd.envs.sharding import SocketRendezvous
+
+    rdv = SocketRendezvous(rank, world, name=name, timeout=30)
+    ok = rdv.gather(("r", rank)) == [("r", r) for r in range(world)]
+    ok = ok and rdv.broadcast(b"id-from-rank-0" if rank == 0 else None) == b"id-from-rank-0"
+    ok = ok and rdv.reduce(0.5 + rank, max) == 0.5 + world - 1 and rdv.reduce(rank, sum) == sum(range(world)) and rdv.reduce(1 if rank else 0, min) == 0
+    # an all-gather of array blocks through the rendezvous (the functional fallback of the exchange when RCCL cannot form a communicator)
+    a, b = shard_range(10, rank, world)
+    blocks = rdv.gather(np.arange(a, b, dtype=np.float64))
+    ok = ok and np.array_equal(np.concatenate(blocks), np.arange(10.0))
+    rdv.barrier()
+    rdv.close()
+    out.put((rank, bool(ok)))
+
+
+def test_socket_rendezvous_three_ranks_without_torch():
+    """bench.py's N > 1 launcher rendezvous (RCCL id broadcast, barriers, max over ranks of the clock) over a Unix-domain socket:
+    no torch.distributed process group involved."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    name = f"rcs_amd_test_{os.getpid()}"
+    procs = [ctx.Process(target=_socket_worker, args=(r, 3, name, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert dict(out.get(timeout=5) for _ in range(3)) == {0: True, 1: True, 2: True}
