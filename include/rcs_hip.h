@@ -329,7 +329,8 @@ int rcsh_sim_set_state(rcsh_sim* sim, const void* blob);
  * (obs_width = 14 + dof); info row (uint8[8]): collision, ik_success, is_sim_converged, is_grasped,
  * truncated, gripper_collision, contact_overflow, contact_unresolved (the last two: no reference counterpart -- a contact
  * phase ran out of slots / the environment was found in a contact this configuration does not resolve, sticky until reset,
- * see rcsh_sim_contact_unresolved); gripper_width[N] (double). */
+ * see rcsh_sim_contact_unresolved) -- `info` rows are written as one 8-byte word each: the buffer must be 8-byte aligned --;
+ * gripper_width[N] (double). */
 int rcsh_env_configure(rcsh_sim* sim, const rcsh_env_desc* env);
 int rcsh_env_obs_width(const rcsh_sim* sim);
 int rcsh_env_action_width(const rcsh_sim* sim);

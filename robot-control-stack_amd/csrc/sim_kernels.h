@@ -472,6 +472,73 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
 
 }
 
+// The same on the team's lanes: lane i does joint i of everything that is per joint (the relative action's clamps and
+// remembered vectors, the "did the action move" test, SimRobot::set_joint_position), the leader lane what is per environment
+// (gripper, flags, clocks).  Per-joint inputs arrive in the lane's registers (in_*), the leader's flag word is spread to the team
+// first.  One lane walking the seven joints through LDS took 5.1k cycles of every launch.  Every lane of a live team calls this.
+template <class T, class ST>
+__device__ __forceinline__ void env_prologue_team(const Params& P, const RunOp& op, const DevModelHead& m, int e, int t, EnvRegs<T, ST>& r,
+                                                  double in_action, double in_origin, double in_lasta, double in_preva, float in_grip) {
+  using L = Lay<T>;
+  const int n = P.n;
+  const bool leader = t == 0, joint = t < T::NARM;
+  const int ti = joint ? t : 0, tl = t < T::NL ? t : 0, tu = t < T::NU ? t : 0;
+  uint32_t flags = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)r.flags);  // the leader's word, on every lane
+  if (op.do_reset) {
+    // GripperWrapper.reset -> SimGripper::m_reset (python/rcs/envs/base.py:703-708, SimGripper.cpp:158-165)
+    if (T::GRIP && P.grip.present) {
+      r.last_cmd_width = 0; r.last_width = 0;
+      flags &= ~(kGripMoving | kGripCollision | kHasGripCmd | kGripCmd);
+    }
+    // RobotSimWrapper.reset -> Sim::reset = mj_resetData + reset_callbacks (envs/sim.py:68-76, sim.cpp:117-138);
+    // it overwrites what the gripper reset just wrote to qpos / ctrl
+    if (t < T::NL) { r.st.q(tl) = m.qpos0[tl]; r.st.v(tl) = 0; }
+    if (t < T::NU) r.st.c(tu) = 0;
+    r.time = 0;
+    flags &= ~(kContactOverflow | kContactUnresolved);
+    if (t < 6) r.cb(t) = 0;
+    // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
+    if (joint) { r.st.q(ti) = P.robot.q_home[ti]; r.st.c(ti) = P.robot.q_home[ti]; }
+  }
+  if (op.apply_action) {
+    // ---- RelativeActionSpace.action (python/rcs/envs/base.py:468-488), JOINTS mode
+    double a = in_action;
+    if (P.env.relative_to != 0) {
+      const bool last_step = P.env.relative_to == 1;
+      const bool fresh = last_step || !(flags & kHasLastAction);
+      if (joint) {
+        const double origin = last_step ? r.st.q(ti) : in_origin;
+        const double lim = fresh ? clampd(a, -P.env.max_mov[0], P.env.max_mov[0]) : clampd(a - in_lasta, -P.env.max_mov[0], P.env.max_mov[0]) + in_lasta;
+        if (last_step) P.S[(size_t)(L::ORIGIN + ti) * n + e] = origin;
+        P.S[(size_t)(L::LASTA + ti) * n + e] = lim;
+        a = clampd(origin + lim, P.env.low[ti], P.env.high[ti]);
+      }
+      flags |= kHasLastAction;
+    }
+    // ---- GripperWrapper.action (base.py:721-735)
+    if (T::GRIP && P.grip.present && op.gripper) {
+      float g = in_grip;
+      if (P.env.binary_gripper) g = rintf(g);  // np.round: half to even
+      g = fminf(fmaxf(g, 0.0f), 1.0f);
+      const double w = P.env.binary_gripper ? (g == 0.0f ? 0.0 : 1.0) : (double)g;  // binary: grasp() = shut() : open()
+      if (leader) gripper_set_width<T, ST>(P, r, w);
+      set_flag(flags, kGripCmd, P.env.binary_gripper ? g != 0.0f : g >= 0.5f);
+      flags |= kHasGripCmd;
+    }
+    // ---- RobotEnv.step (base.py:255-288): command only when the action moved by more than atol = 1e-3
+    const bool moved = joint && !(fabs(a - in_preva) <= 1e-3);
+    const bool changed = !(flags & kHasPrevAction) || team_ballot(moved) != 0;
+    if (joint) P.S[(size_t)(L::PREVA + ti) * n + e] = a;
+    if (changed) {
+      // SimRobot::set_joint_position, reference src/sim/SimRobot.cpp:123-131
+      if (joint) { r.target(ti) = a; r.prevq(ti) = r.st.q(ti); r.st.c(ti) = a; }
+      flags = (flags | kIsMoving) & ~kIsArrived;
+    }
+    flags |= kHasPrevAction;
+  }
+  r.flags = flags;  // (every lane carries the word; the leader's copy is the one that lives on)
+}
+
 // After stepping: park the site frame, refresh the relative-action origin on reset, write the state back and
 // produce observation + info (RobotEnv.get_obs, GripperWrapper.observation, RobotSimWrapper.step, GripperWrapperSim).
 template <class T, class ST, bool kStoreStaged = true>
@@ -479,10 +546,8 @@ __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, c
                                              const ST& st, bool have_frames, int nsteps) {
   using L = Lay<T>;
   const int n = P.n;
-  if (have_frames) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) P.S[(L::SITE + k) * n + e] = st.link(k);
-  } else if (op.write_obs) {
+  // (with frames: the team's lanes have parked the site link's frame already, one component per lane -- run_team_body)
+  if (!have_frames && op.write_obs) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) st.link(k) = P.S[(L::SITE + k) * n + e];
   }
@@ -522,8 +587,7 @@ __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, c
     double* o = op.obs + (size_t)e * OW;
     o[0] = tcp.t[0]; o[1] = tcp.t[1]; o[2] = tcp.t[2];
     o[3] = tcp.q[0]; o[4] = tcp.q[1]; o[5] = tcp.q[2]; o[6] = tcp.q[3];
-#pragma unroll
-    for (int i = 0; i < T::NARM; ++i) o[7 + i] = r.st.q(i);
+    // (o[7 .. 7 + NARM): the joints, written by the joints' lanes -- run_team_body)
     double rpy[3];
     pose_rpy(tcp, rpy);
     o[7 + T::NARM + 0] = tcp.t[0]; o[7 + T::NARM + 1] = tcp.t[1]; o[7 + T::NARM + 2] = tcp.t[2];
@@ -537,21 +601,44 @@ __device__ __forceinline__ void env_epilogue(const Params& P, const RunOp& op, c
     }
     o[13 + T::NARM] = gobs;
     if (op.info) {
-      uint8_t* inf = op.info + (size_t)e * 8;
       const bool rc = r.flags & kRobotCollision, ik = r.flags & kIkSuccess, gc = has_g && (r.flags & kGripCollision);
-      inf[0] = rc || gc;
-      inf[1] = ik;
-      inf[2] = (r.flags & kConverged) != 0;
-      inf[3] = has_g && (w > 0.01 && w < 0.99);
-      inf[4] = rc || !ik;
-      inf[5] = gc;
-      inf[6] = (r.flags & kContactOverflow) != 0;  // a contact phase ran out of contact / link slots since the last Sim.reset
-      inf[7] = (r.flags & kContactUnresolved) != 0;  // found in a contact this configuration does not resolve, since the last Sim.reset
+      // the row's eight bytes in one store: collision, ik_success, is_sim_converged, is_grasped, truncated, gripper collision,
+      // contact_overflow (a contact phase ran out of contact / link slots since the last Sim.reset), contact_unresolved (found in a
+      // contact this configuration does not resolve, since the last Sim.reset)
+      const uint64_t row = (uint64_t)(rc || gc) | (uint64_t)ik << 8 | (uint64_t)((r.flags & kConverged) != 0) << 16 | (uint64_t)(has_g && (w > 0.01 && w < 0.99)) << 24 |
+                           (uint64_t)(rc || !ik) << 32 | (uint64_t)gc << 40 | (uint64_t)((r.flags & kContactOverflow) != 0) << 48 |
+                           (uint64_t)((r.flags & kContactUnresolved) != 0) << 56;
+      reinterpret_cast<uint64_t*>(op.info)[e] = row;
     }
     if (op.gripper_width) op.gripper_width[e] = w;
     if (op.substeps) op.substeps[e] = nsteps >= 0 ? nsteps : r.conv_steps;
   }
 }
+
+// Global -> LDS copy of NW 8-byte words by the 64 lanes of a workgroup, in two phases: `load` asks for all of a lane's words at once,
+// `store` writes them.  A loop of load-then-store waits for memory once per trip (~700 cycles each at one wavefront per SIMD: the
+// launch's tables took 8.5k cycles that way); several copies issue their loads together and wait once.
+template <int NW>
+struct LdsCopy {
+  static constexpr int kTrips = (NW + 63) / 64;
+  double w[kTrips];
+  __device__ __forceinline__ void load(const void* src_) {
+    const double* src = reinterpret_cast<const double*>(src_);
+#pragma unroll
+    for (int i = 0; i < kTrips; ++i) {
+      const int k = (int)threadIdx.x + 64 * i;
+      w[i] = src[k < NW ? k : 0];
+    }
+  }
+  __device__ __forceinline__ void store(void* dst_) const {
+    double* dst = reinterpret_cast<double*>(dst_);
+#pragma unroll
+    for (int i = 0; i < kTrips; ++i) {
+      const int k = (int)threadIdx.x + 64 * i;
+      if (k < NW) dst[k] = w[i];
+    }
+  }
+};
 
 // Stages the model into a workgroup's LDS for the team kernels (64 threads): the DevModelHead (what is not per link) and the
 // per-link LinkRec records stored right behind the DevModel.  Every workgroup of the launch fetches these same lines from
@@ -598,13 +685,17 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   // (sized for the end-of-launch contact check too, which takes the block over once the state has been written back)
   constexpr int kLdsDoubles = ST::COUNT * kTeams > check_work_doubles(T::NL) ? ST::COUNT * kTeams : check_work_doubles(T::NL);
   __shared__ __attribute__((aligned(16))) double lds[kLdsDoubles];
-  {
-    static_assert(sizeof(Params) % 8 == 0 && sizeof(RunOp) % 8 == 0, "copied in 8-byte words");
-    for (int k = threadIdx.x; k < (int)(sizeof(Params) / 8); k += 64)
-      reinterpret_cast<double*>(&lp)[k] = reinterpret_cast<const double*>(&Pk)[k];
-    for (int k = threadIdx.x; k < (int)(sizeof(RunOp) / 8); k += 64)
-      reinterpret_cast<double*>(&lop)[k] = reinterpret_cast<const double*>(&opk)[k];
-  }
+  // everything the launch reads from memory at its start is asked for at once -- arguments, model tables and, further down, the
+  // environment's state -- and stored to LDS after one wait
+  static_assert(sizeof(Params) % 8 == 0 && sizeof(RunOp) % 8 == 0 && sizeof(DevModelHead) % 8 == 0 && sizeof(LinkRec) % 8 == 0, "copied in 8-byte words");
+  LdsCopy<sizeof(Params) / 8> cp_params;
+  LdsCopy<sizeof(RunOp) / 8> cp_op;
+  LdsCopy<sizeof(DevModelHead) / 8> cp_head;
+  LdsCopy<sizeof(LinkRec) * T::NL / 8> cp_links;
+  cp_params.load(&Pk);
+  cp_op.load(&opk);
+  cp_head.load(Pk.model);
+  cp_links.load(reinterpret_cast<const char*>(Pk.model) + sizeof(DevModel));
   const Params& P = lp;
   const RunOp& op = lop;
   const CollTable& lc = lp.coll;
@@ -622,9 +713,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   using SF = TeamStagedFields<T, ST>;
   const int nstaged = Pk.keep_qpre ? SF::kCount : SF::kCount - T::NL;  // (the QPRE entries are the list's last)
   double staged[SF::kRounds];
-  constexpr int kInRounds = (StepInGlobal<T>::kCount + kTeamLanes - 1) / kTeamLanes;
-  double step_in[kInRounds] = {};
-  static_assert(StepInGlobal<T>::kCount <= 5 * ST::NLP, "the env-step inputs are parked in the helpers' block of the LDS stage");
+  // env.step()'s inputs, per joint on the joint's lane: the action, the relative action space's remembered vectors, the previous action
+  double in_action = 0.0, in_origin = 0.0, in_lasta = 0.0, in_preva = 0.0;
+  float in_grip = 0.0f;
   double pre_time = 0, pre_cmd = 0, pre_width = 0;
   uint32_t pre_flags = 0;
   int32_t pre_conv = 0;
@@ -643,12 +734,14 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       if (t < T::NL && !opk.do_reset) xs_in = Pk.S[(size_t)(Lay<T>::XS + t) * Pk.n + e];  // (Sim::reset: mj_resetData zeroes the warm start)
     }
     if (opk.apply_action) {
-      const StepInGlobal<T> gin{Pk, opk, e};
-#pragma unroll
-      for (int rd = 0; rd < kInRounds; ++rd) {
-        const int k = t + rd * kTeamLanes;
-        step_in[rd] = gin.fetch(k < StepInGlobal<T>::kCount ? k : 0);
+      using L = Lay<T>;
+      if (t < T::NARM) {
+        in_action = opk.action[(size_t)e * T::NARM + t];
+        // (origin / last action are only read back with RelativeTo.CONFIGURED_ORIGIN: LAST_STEP re-derives both every step)
+        if (Pk.env.relative_to == 2) { in_origin = Pk.S[(size_t)(L::ORIGIN + t) * Pk.n + e]; in_lasta = Pk.S[(size_t)(L::LASTA + t) * Pk.n + e]; }
+        in_preva = Pk.S[(size_t)(L::PREVA + t) * Pk.n + e];
       }
+      if (t == 0 && opk.gripper) in_grip = opk.gripper[e];
     }
     if (t == 0) {
       using L = Lay<T>;
@@ -664,11 +757,15 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   {
     if constexpr (BOX || CON) {
       static_assert(sizeof(BoxTaskCfg) % 8 == 0, "copied in 8-byte words");
-      for (int k = threadIdx.x; k < (int)(sizeof(BoxTaskCfg) / 8); k += 64)
-        reinterpret_cast<double*>(&lbt[0])[k] = reinterpret_cast<const double*>(Pk.boxtask)[k];
+      LdsCopy<sizeof(BoxTaskCfg) / 8> cp_bt;
+      cp_bt.load(Pk.boxtask);
+      cp_bt.store(&lbt[0]);
     }
-    stage_team_model<T::NL>(Pk.model, lm, llinks);
-    for (int k = threadIdx.x; k < ST::COUNT * kTeams; k += 64) lds[k] = 0.0;
+    cp_params.store(&lp);
+    cp_op.store(&lop);
+    cp_head.store(&lm);
+    cp_links.store(&llinks[0]);
+    for (int k = threadIdx.x; k < kLdsDoubles; k += 64) lds[k] = 0.0;
     __syncthreads();
   }
   TEAM_MARK(12)
@@ -697,18 +794,16 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     if constexpr (FRIC) {
       if (t < T::NL) st.xs(t) = xs_in;
     }
-#pragma unroll
-    for (int rd = 0; rd < kInRounds; ++rd) {
-      const int k = t + rd * kTeamLanes;
-      if (k < StepInGlobal<T>::kCount) st.at(ST::Y0 + k) = step_in[rd];  // (the helpers' block is idle until the first substep)
-    }
   }
   __syncthreads();
+  if (leader) { r.time = pre_time; r.last_cmd_width = pre_cmd; r.last_width = pre_width; r.flags = pre_flags; r.conv_steps = pre_conv; }
+  TEAM_MARK(13)
+  if (live) {
+    in_grip = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, __builtin_bit_cast(int, in_grip)));
+    env_prologue_team<T, ST>(Pk, opk, m, e, t, r, in_action, in_origin, in_lasta, in_preva, in_grip);  // (Pk, opk: still in registers here)
+  }
+  TEAM_MARK(14)
   if (leader) {
-    r.time = pre_time; r.last_cmd_width = pre_cmd; r.last_width = pre_width; r.flags = pre_flags; r.conv_steps = pre_conv;
-    TEAM_MARK(13)
-    env_prologue<T, ST>(Pk, opk, m, e, r, StepInStaged<T>{&st.at(ST::Y0)});  // (Pk, opk: still in registers here)
-    TEAM_MARK(14)
     budget = nsteps;
     if (until_conv) {
       r.conv_steps = 0;
@@ -989,6 +1084,13 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   const bool do_check = op.check && (lp.chk.npair > 0 || (!CON && lp.chk.plane_points));  // (wave-uniform)
   CheckPrefetch chk_pf;
   if (do_check) check_prefetch(lp.chk, lp.ctab, sep_in, live, chk_pf);
+  {
+    // per-component stores of the epilogue, one per lane instead of a dozen from the leader: the site link's frame of the last
+    // position stage, the joints of the observation row
+    const bool team_frames = team_ballot(have_frames) != 0;
+    if (live && team_frames && t < 12) P.S[(size_t)(Lay<T>::SITE + t) * P.n + e] = st.link(t);
+    if (live && op.write_obs && t < T::NARM) op.obs[(size_t)e * (14 + T::NARM) + 7 + t] = st.q(t);
+  }
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
     env_epilogue<T, ST, false>(P, op, m, e, r, st, have_frames, nsteps);

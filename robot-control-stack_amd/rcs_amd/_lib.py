@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librcs_hip.so")
+LIB_PATH = os.environ.get("RCSH_LIB") or os.path.join(_HERE, "librcs_hip.so")  # (RCSH_LIB: a development build, for A/B measurements)
 
 RCSH_OK, RCSH_ERR_ARG, RCSH_ERR_NAME, RCSH_ERR_MODEL, RCSH_ERR_DEVICE, RCSH_ERR_STATE = range(6)
 

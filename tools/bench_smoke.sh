@@ -15,6 +15,6 @@ run --steps 100 --warmup 10 --robot xarm7
 run --steps 100 --warmup 10 --robot mixed --envs 4096
 run --steps 100 --warmup 10 --robot mixed --envs 16384
 run --steps 60 --warmup 10 --mode convergence
-run --steps 40 --warmup 5 --gpus 2 --dist-backend gloo --envs 1024
+run --steps 40 --warmup 5 --gpus 2 --dist-backend host --envs 1024
 run --steps 100 --warmup 10 --robot xarm7_pick
 run --steps 40 --warmup 5 --robot xarm7_pick --cameras side_cam --resolution 256x256

@@ -9,6 +9,7 @@ import numpy as np
 from parity_util import make_vec_env, synthetic_actions
 n, T = 4096, 20
 env = make_vec_env(n, True, robot=(sys.argv[1] if len(sys.argv) > 1 else "fr3"))
+env.sim.set_contact_check(int(os.environ.get("CHECK_EVERY", "0")))  # (the end-of-launch contact check would sit in the epilogue mark)
 j, g = synthetic_actions(64 if os.environ.get("TILED", "1") == "1" else n, T, 0, dof=env.dof)
 if j.shape[1] != n: j = np.tile(j, (1, n // 64, 1)); g = np.tile(g, (1, n // 64))
 env.reset()
