@@ -321,6 +321,20 @@ __device__ __forceinline__ bool condition_callbacks(const DevModelHead& m, const
   return any || all;
 }
 
+// The smallest last-call timestamp among the condition callbacks that exist.  A callback fires when time - last > period, so
+// nothing can fire while time - (this minimum) <= the smallest period: the leader lane keeps the minimum in a register and only
+// walks the callbacks (four timestamps in LDS, a dozen compares) in the substeps where that test passes.
+template <class T, class ST>
+__device__ __forceinline__ double condition_callbacks_oldest(const Params& P, const EnvRegs<T, ST>& r) {
+  const bool has_g = T::GRIP && P.grip.present;
+  double lo = INFINITY;
+  if (P.robot.present) lo = fmin(lo, r.cb(2));
+  if (has_g) lo = fmin(lo, r.cb(3));
+  if (P.robot.present && P.robot.conv_registered) lo = fmin(lo, r.cb(4));
+  if (has_g) lo = fmin(lo, r.cb(5));
+  return lo;
+}
+
 // SimRobot::set_joint_position, reference src/sim/SimRobot.cpp:123-131
 template <class T, class ST>
 __device__ __forceinline__ void robot_set_joint_position(EnvRegs<T, ST>& r, const double* a) {
@@ -874,10 +888,14 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   bool box_placed = false;  // env.reset() with RandomCubePos: the box got its pose after the first of the two substeps
   bool more = leader && budget > 0;
   double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
+  // (step_until_convergence: the condition callbacks' oldest timestamp and shortest period, see condition_callbacks_oldest)
+  double cond_lo = leader && until_conv ? condition_callbacks_oldest<T, ST>(P, r) : 0.0;
+  bool cond_first = true;
   const bool has_cb = P.robot.present && P.robot.conv_registered;
   // the few scalars the loop control reads every substep, out of LDS once
   const double robot_period = P.robot.period, grip_period = P.grip.period, timestep = m.timestep;
   const bool robot_present = P.robot.present, grip_present = T::GRIP && P.grip.present, has_plane = lc.has_plane;
+  const double cond_pmin = robot_present ? (grip_present ? fmin(robot_period, grip_period) : robot_period) : (grip_present ? grip_period : INFINITY);
   uint64_t going = __ballot(more);
   const bool gc_is_mass = team_gc_is_mass<T>(llinks, t);
   SubstepK sk;
@@ -911,12 +929,13 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     if constexpr (DET) {
       if (leader && stepping && until_conv && (has_plane || npair > 0)) {
         const double t_next = r.time + timestep;
-        due = (robot_present && t_next - r.cb(2) > robot_period) || (grip_present && t_next - r.cb(3) > grip_period);
+        if (t_next - cond_lo > cond_pmin)  // (necessary for any callback to fire; the exact tests read the timestamps from LDS)
+          due = (robot_present && t_next - r.cb(2) > robot_period) || (grip_present && t_next - r.cb(3) > grip_period);
       }
     }
     const bool team_due = DET && team_ballot(due) != 0;
     const bool want_contacts = DET && __ballot(due) != 0;  // (the wavefront detects together: self_collision_pairs)
-    uint32_t hit = 0, overflow = 0;
+    uint32_t hit = 0, overflow = 0, det_mine = 0;
     bool near = false;  // broad phase of the contact phase: the lane's link may touch the floor or the box
     bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
     team_substep<T, FRIC>(m, sk, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
@@ -983,11 +1002,17 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
             for (int k = 0; k < 3; ++k) selfF[12 * t + 9 + k] = p[k];
           }
           stage_fence();  // (LDS traffic of one wavefront is ordered; the fence is for the compiler)
-          mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, !CON, sph, slack,
-                                       lp.ctab.self_lever, st.q(t < T::NL ? t : T::NL - 1));
-          stage_fence();  // (CON: frames and stage sit in the contact arena, which the contact phase may enter next)
+          if constexpr (CON) {
+            // (frames and stage sit in the contact arena, which the contact phase may enter next: the pairs are tested here)
+            mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, !CON, sph, slack,
+                                         lp.ctab.self_lever, st.q(t < T::NL ? t : T::NL - 1));
+            stage_fence();
+          }
         }
-        hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
+        // (without a contact phase the pair test waits until the substep is through -- below: a non-inlined call HERE, in the
+        // middle of the substep, has ~150 values to carry across it, which shapes the register allocation of the whole loop)
+        if constexpr (CON) hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
+        else det_mine = mine;
       }
     }, [&]() -> bool {
       bool coupled = false;
@@ -1015,6 +1040,20 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       team_coupled = coupled;
       return coupled;
     });
+    if constexpr (DET && !CON) {
+      if (want_contacts) {
+        if (npair > 0) {
+          // the robot's geoms against each other, on the frames the position stage published (and at the joint positions it saw:
+          // the slack cache integrates joint motion between calls)
+          const int tq = t < T::NL ? t : T::NL - 1;
+          const double q_seen = stepping ? st.qpre(tq) : st.q(tq);
+          det_mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, true, sph, slack,
+                                           lp.ctab.self_lever, q_seen);
+          stage_fence();
+        }
+        hit = (team_ballot(det_mine & 1u) ? 1u : 0u) | (team_ballot(det_mine & 2u) ? 2u : 0u);
+      }
+    }
     __syncthreads();
     if constexpr (BOX) {
       if (stepping) {
@@ -1042,7 +1081,13 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       --budget;
       if (until_conv) {
         r.conv_steps++;
-        converged = condition_callbacks<T, ST>(m, P, r, [&] { return hit; });
+        // (the callbacks' verdict only changes when one of them fires -- and is formed once at the launch's first substep, where
+        // "no callback registered" already means converged: the empty all_of, sim.cpp:49-61)
+        if (cond_first || r.time - cond_lo > cond_pmin) {
+          converged = condition_callbacks<T, ST>(m, P, r, [&] { return hit; });
+          cond_lo = condition_callbacks_oldest<T, ST>(P, r);
+          cond_first = false;
+        }
       }
       more = budget > 0 && !converged;
     }
@@ -1155,7 +1200,12 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     const double q_final = live && t < T::NL ? st.q(t) : 0.0;
     __syncthreads();
     double* const sep = P.S + (size_t)Lay<T>::SEP * P.n + (live ? e : 0);
-    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), lds, q_final, live, !CON, sep_in, sep, P.n, chk_pf);
+    // (an environment that carries the flag already has nothing to find out: its team sits the check out -- a pair that stays in
+    // contact has no separating direction to remember and would go through the full refinement in every launch, and the launch
+    // waits for its slowest wavefront)
+    const bool flagged = ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)r.flags) & kContactUnresolved) != 0;
+    const bool checked = live && !flagged;
+    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), lds, q_final, checked, !CON, sep_in, sep, P.n, chk_pf);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif

@@ -8,7 +8,8 @@ lib.LIB_PATH = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "librcs_
 import numpy as np
 from parity_util import make_vec_env, synthetic_actions
 n, T = 4096, 20
-env = make_vec_env(n, True, robot=(sys.argv[1] if len(sys.argv) > 1 else "fr3"))
+ASYNC = os.environ.get("ASYNC", "1") == "1"
+env = make_vec_env(n, ASYNC, robot=(sys.argv[1] if len(sys.argv) > 1 else "fr3"))
 env.sim.set_contact_check(int(os.environ.get("CHECK_EVERY", "0")))  # (the end-of-launch contact check would sit in the epilogue mark)
 j, g = synthetic_actions(64 if os.environ.get("TILED", "1") == "1" else n, T, 0, dof=env.dof)
 if j.shape[1] != n: j = np.tile(j, (1, n // 64, 1)); g = np.tile(g, (1, n // 64))
@@ -16,12 +17,15 @@ env.reset()
 out = (C.c_ulonglong * 24)()
 env._L.rcsh_debug_team_cycles(out)
 base = np.array(out[:], dtype=np.float64)
-for t in range(T): env.step({"joints": j[t], "gripper": g[t]})
+nsub = 0
+for t in range(T):
+    info = env.step({"joints": j[t], "gripper": g[t]})[4]
+    nsub += int(info["substeps"][0:4].max())
 env._L.rcsh_debug_team_cycles(out)
 a = (np.array(out[:], dtype=np.float64) - base)
 names = ["local frame", "frame scan", "axis+vel+acc scans", "inertia+wrench+leaf scans", "M row (S exchange)", "actuation+rows", "factor slot",
          "implicit solve+integrate", "callbacks+sync", "leader post + loop sync", "epilogue", "prologue"]
-sub = T * 17
+sub = nsub  # (substeps workgroup 0 ran: its slowest team's)
 print("team kernel, block 0 lane 0, cycles per substep:")
 for i in range(10): print(f"  {names[i]:28s} {a[i] / sub:9.0f}")
 print(f"  {'substep total':28s} {a[:10].sum() / sub:9.0f}")
