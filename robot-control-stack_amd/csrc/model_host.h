@@ -69,6 +69,10 @@ bool build_hull_edges(const double* planes, int nplanes, std::vector<HullEdge>& 
 // Calls fn(Topo<NARM, GRIP>{}) for the compiled archetype matching (narm, grip); false if none does.
 template <class F>
 bool dispatch_topology(int narm, bool grip, F&& fn) {
+#ifdef RCSH_DEV_ONLY_XARM7  // (development builds: the 7-dof arm without gripper alone)
+  if (narm == 7 && !grip) { fn(Topo<7, false>{}); return true; }
+  return false;
+#endif
   if (narm == 7 && grip) { fn(Topo<7, true>{}); return true; }
 #ifndef RCSH_DEV_ONLY_FR3  // (development builds define it: the FR3 + hand archetype alone, minutes -> seconds)
   if (narm == 7 && !grip) { fn(Topo<7, false>{}); return true; }
