@@ -420,6 +420,11 @@ typedef struct rcsh_render_colours {
 int rcsh_sim_set_render_colours(rcsh_sim* sim, const rcsh_render_colours* colours);
 /* rgb: [N][H][W][3] u8, rows bottom-up (as mjr_readPixels returns them); the depth outputs as above; each may be NULL. */
 int rcsh_camera_render_rgb(rcsh_sim* sim, int32_t cam_id, uint8_t* rgb, float* depth_gl, uint16_t* depth_mm, double* cam_pose);
+/* The ray caster's arithmetic type.  Default (0): float32 -- the reference's depth image is a float32 OpenGL z-buffer read back
+ * and quantised to uint16 millimetres (python/rcs/camera/sim.py:57-86), src/sim/camera.cpp:86-140 computes nothing in double.
+ * 1: every ray in double -- the instantiation whose pixels equal the tests' numpy restatement bit for bit (about 1.4x the time).
+ * (RCSH_RENDER_F64=1 in the environment selects it at rcsh_sim_create.) */
+int rcsh_sim_set_render_f64(rcsh_sim* sim, int32_t on);
 int rcsh_camera_render_rgb_dev(rcsh_sim* sim, int32_t cam_id, uint8_t* rgb_dev, float* depth_gl_dev, uint16_t* depth_mm_dev, double* cam_pose_dev);
 /* Rendering callbacks: SimCameraSet(render_on_demand = false) (src/sim/camera.cpp:23-47,97-102; Sim::register_rendering_callback,
  * invoke_rendering_callbacks, reset_callbacks: src/sim/sim.cpp:63-81,108-115,131-137,160-173).  A camera with a frame rate is due

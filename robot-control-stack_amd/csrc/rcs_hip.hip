@@ -104,6 +104,7 @@ struct rcsh_sim {
   const double* frames_src_base(int slot) const { return rend.snap + (size_t)slot * (size_t)(nl + 9) * (size_t)n; }
   double* d_frames = nullptr;
   double* d_wframes = nullptr;  // world frames of the shapes + camera per environment (k_shape_frames)
+  bool render_f64 = false;      // the ray caster's arithmetic type (rcsh_sim_set_render_f64; RCSH_RENDER_F64=1 at creation)
   std::vector<RenderCam> cams;
   void* d_image = nullptr;  // staging for the host-pointer render call
   size_t image_cap = 0;  // device copy of {box, task} (scenes with a free box)
@@ -730,6 +731,7 @@ int rcsh_sim_create(const rcsh_model_desc* model, int32_t n_envs, int32_t device
   }
   if (upload_model(s)) return cleanup(RCSH_ERR_DEVICE, g_err);
   if (const char* cc = std::getenv("RCSH_CONTACT_CHECK")) s->contact_check = std::atoi(cc) != 0;
+  if (const char* rf = std::getenv("RCSH_RENDER_F64")) s->render_f64 = std::atoi(rf) != 0;
   if (upload_contact_table(s)) return cleanup(RCSH_ERR_DEVICE, g_err);  // (the contact check's pair tables exist before any robot is attached)
 #undef HIP_NEW
   *out = s;
@@ -1795,17 +1797,27 @@ int rcsh_camera_render_rgb_dev(rcsh_sim* s, int32_t cam_id, uint8_t* rgb, float*
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_link_frames launch: ") + hipGetErrorString(err));
   hipLaunchKernelGGL(k_shape_frames, dim3(grid_for(s->n * (s->rscene.nshape + 1))), dim3(kBlock), 0, s->stream, s->rscene, cam, s->d_frames, s->n,
                      s->d_wframes);
-  if (s->rscene.views)
-    hipLaunchKernelGGL(k_hull_views, dim3((unsigned)s->n * (unsigned)s->rscene.nshape), dim3(64), 0, s->stream, s->rscene, cam, s->d_wframes, s->n);
-  const int blocks_per_env = ((cam.width + 15) / 16) * ((cam.height + 15) / 16);
-  const dim3 grid((unsigned)(((size_t)blocks_per_env * (size_t)s->n + 7) / 8 * 8));  // (a multiple of 8: k_render_depth numbers its workgroups per XCD)
-  if (rgb)
-    hipLaunchKernelGGL(k_render_depth<true>, grid, dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n, depth_gl, depth_mm, cam_pose, rgb);
-  else
-    hipLaunchKernelGGL(k_render_depth<false>, grid, dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n, depth_gl, depth_mm, cam_pose,
-                       (uint8_t*)nullptr);
+  // (the rays' arithmetic type: float unless rcsh_sim_set_render_f64 asked for the instantiation that equals the restatement bit for bit)
+  const dim3 grid((unsigned)(((size_t)render_wgs_per_env(cam.width, cam.height) * (size_t)s->n + 7) / 8 * 8));  // (a multiple of 8: k_render_depth numbers its workgroups per XCD)
+  auto cast = [&](auto zero) {
+    using F = decltype(zero);
+    if (s->rscene.views)
+      hipLaunchKernelGGL(k_hull_views<F>, dim3((unsigned)s->n * (unsigned)s->rscene.nshape), dim3(64), 0, s->stream, s->rscene, cam, s->d_wframes, s->n);
+    if (rgb)
+      hipLaunchKernelGGL((k_render_depth<true, F>), grid, dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n, depth_gl, depth_mm, cam_pose, rgb);
+    else
+      hipLaunchKernelGGL((k_render_depth<false, F>), grid, dim3(256), 0, s->stream, s->rscene, cam, s->d_wframes, s->n, depth_gl, depth_mm, cam_pose,
+                         (uint8_t*)nullptr);
+  };
+  if (s->render_f64) cast(0.0); else cast(0.0f);
   err = hipGetLastError();
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_render_depth launch: ") + hipGetErrorString(err));
+  return RCSH_OK;
+}
+
+int rcsh_sim_set_render_f64(rcsh_sim* s, int32_t on) {
+  REQUIRE_SIM(s);
+  s->render_f64 = on != 0;
   return RCSH_OK;
 }
 

@@ -145,8 +145,10 @@ __device__ __forceinline__ void in_world(const double* frames, int link, int nfr
 }
 
 // world frames of the scene's shapes and of one camera for every environment: wf[e][g] = R (9) p (3) sphere centre (3)
-// radius (1), g < nshape; entry nshape is the camera (R, p).  One thread per (environment, entry).
-constexpr int kShapeFrameDoubles = 16;
+// radius (1) half extents (3) box centre in the shape frame (3) unused (2), g < nshape; entry nshape is the camera (R, p).
+// One thread per (environment, entry).  (Everything a ray needs to know about a shape besides its planes is in this row: the
+// ray caster stages an environment's rows in LDS in ITS arithmetic type and reads nothing else per shape.)
+constexpr int kShapeFrameDoubles = 24;
 __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* frames, int n, double* wf) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_env = sc.nshape + 1;
@@ -157,7 +159,7 @@ __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* fram
   double R[9], p[3];
   if (g == sc.nshape) {
     in_world(fe, cam.link, sc.nframes, cam.pos, cam.rot, R, p);
-    for (int k = 0; k < 4; ++k) out[12 + k] = 0.0;
+    for (int k = 12; k < kShapeFrameDoubles; ++k) out[k] = 0.0;
   } else {
     const RenderShape& sh = sc.shapes[g];
     in_world(fe, sh.link, sc.nframes, sh.pos, sh.rot, R, p);
@@ -165,10 +167,26 @@ __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* fram
     mulmv(R, sh.sphere, c);
     for (int k = 0; k < 3; ++k) out[12 + k] = c[k] + p[k];
     out[15] = sh.sphere[3];
+    // slabs: of the box -- or, for a hull / capsule, of its bounding box (centre = the bounding sphere's, half extents in `size`)
+    for (int k = 0; k < 3; ++k) { out[16 + k] = sh.size[k]; out[19 + k] = sh.shape != kShapeBox ? sh.sphere[k] : 0.0; }
+    out[22] = out[23] = 0.0;
   }
   for (int k = 0; k < 9; ++k) out[k] = R[k];
   for (int k = 0; k < 3; ++k) out[9 + k] = p[k];
 }
+
+// The ray caster's arithmetic type.  F = float is the product's (the reference's depth image IS a float32 z-buffer read back
+// and quantised to uint16 millimetres, python/rcs/camera/sim.py:57-86: double precision buys nothing the reference has);
+// F = double is kept as the instantiation whose pixels equal the numpy restatement's bit for bit (rcsh_sim_set_render_f64).
+template <class F> struct RenderNum;
+template <> struct RenderNum<double> {
+  static __device__ __forceinline__ double rcp(double x) { return fast_rcp(x); }
+  static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / sqrt(x); }
+};
+template <> struct RenderNum<float> {
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+};
 
 // The outline method.  All rays of a camera start at one point o.  Seen from o a convex polytope has FRONT faces (o outside
 // their plane: n . o > d) and back faces; a ray can only ENTER through a front face, and it hits the polytope at all exactly
@@ -180,9 +198,11 @@ __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* fram
 // plane, ~220, of walking every face plane for both ends of the ray's interval.  What a ray sees is the same set of points;
 // rays that graze the outline may fall on the other side of it by round-off (as between any two ways of writing the test).
 // One wavefront per (environment, hull); lanes take planes, then edges; ballots compact the survivors into the view record.
+// The record's rows are written in the ray caster's type F (worked out in double here: d - n . o is a difference of metres).
 __device__ __forceinline__ double plane_no(const double* q, const double* lo) {
   return fma(-q[2], lo[2], fma(-q[1], lo[1], fma(-q[0], lo[0], q[3])));  // d - n . o, one rounding order everywhere it is needed
 }
+template <class F>
 __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam, const double* wf, int n) {
   const int e = blockIdx.x / sc.nshape, g = blockIdx.x % sc.nshape;
   if (e >= n) return;
@@ -210,6 +230,7 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
   const double om[3] = {cw[9] - w[9], cw[10] - w[10], cw[11] - w[11]};
   const double lo[3] = {w[0] * om[0] + w[3] * om[1] + w[6] * om[2], w[1] * om[0] + w[4] * om[1] + w[7] * om[2], w[2] * om[0] + w[5] * om[1] + w[8] * om[2]};
   double* out = sc.views + (size_t)e * sc.view_stride + sh.view_adr;
+  F* rows = (F*)(out + kViewHeaderDoubles);
   const double* planes = sc.planes + 4 * (size_t)sh.plane_adr;
   const uint64_t below = (1ull << lane) - 1ull;
   int nfront = 0;
@@ -224,12 +245,12 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
     }
     const uint64_t m = __ballot(front);
     if (front) {
-      double* r = out + kViewHeaderDoubles + 4 * (size_t)(nfront + __popcll(m & below));
-      r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = no;
+      F* r = rows + 4 * (size_t)(nfront + __popcll(m & below));
+      r[0] = (F)q[0]; r[1] = (F)q[1]; r[2] = (F)q[2]; r[3] = (F)no;
     }
     nfront += __popcll(m);
   }
-  double* outline = out + kViewHeaderDoubles + 4 * (size_t)sh.plane_num;
+  F* outline = rows + 4 * (size_t)sh.plane_num;
   const double ci[3] = {sh.centre[0] - lo[0], sh.centre[1] - lo[1], sh.centre[2] - lo[2]};
   int nout = 0;
   for (int base = 0; base < sh.edge_num; base += 64) {
@@ -244,13 +265,18 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
         const double a[3] = {ev[0] - lo[0], ev[1] - lo[1], ev[2] - lo[2]}, b[3] = {ev[3] - lo[0], ev[4] - lo[1], ev[5] - lo[2]};
         mm[0] = a[1] * b[2] - a[2] * b[1]; mm[1] = a[2] * b[0] - a[0] * b[2]; mm[2] = a[0] * b[1] - a[1] * b[0];
         if (mm[0] * ci[0] + mm[1] * ci[1] + mm[2] * ci[2] < 0) { mm[0] = -mm[0]; mm[1] = -mm[1]; mm[2] = -mm[2]; }
+        if (sizeof(F) == 4) {
+          // (float rows: the cross product of two ~metre vectors spans many orders of magnitude; only its direction matters)
+          const double s = 1.0 / sqrt(mm[0] * mm[0] + mm[1] * mm[1] + mm[2] * mm[2] + 1e-300);
+          mm[0] *= s; mm[1] *= s; mm[2] *= s;
+        }
       }
     }
     const uint64_t m = __ballot(sil);
     const int r = nout + __popcll(m & below);
     if (sil && r < kMaxOutline) {
-      double* o = outline + 4 * (size_t)r;
-      o[0] = mm[0]; o[1] = mm[1]; o[2] = mm[2]; o[3] = 0;
+      F* o = outline + 4 * (size_t)r;
+      o[0] = (F)mm[0]; o[1] = (F)mm[1]; o[2] = (F)mm[2]; o[3] = 0;
     }
     nout += __popcll(m);
   }
@@ -266,352 +292,354 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
 // (mjData.cam_xmat / cam_xpos).  Any of the three may be null.
 // COLOR: also rgb [n][H][W][3] uint8, rows bottom-up like the depth buffer: the colour of the shape the ray enters first,
 // lit by the headlight and the scene's directional light on the entry face's normal (flat shading; sc.colours).
-template <bool COLOR>
+//
+// Work decomposition (round 4).  A wavefront renders 8 x 8 pixel sub-tiles, kSubPerWave of them one after the other; a
+// workgroup's four wavefronts share nothing but the environment's shape rows in LDS, staged ONCE per workgroup (round 3: a
+// workgroup per 16 x 16 tile -- the staging, three barriers, a cull by one wavefront while three waited and a ranking through
+// LDS were paid per 256 rays, a million times per 4096 x 256 x 256 batch, and cost more than the rays of a floor-only frame).
+// Everything per sub-tile is the wavefront's own: lane g culls shape g against the sub-tile's pyramid of rays (its sphere's
+// centre in the camera frame and its ranking key stay in the lane's registers for all sub-tiles), a ballot gives the
+// sub-tile's shapes, ranks come from lane reads, the g-th shape to visit from a ballot: no barrier and no LDS traffic.
+constexpr int kSubPerWave = 8;
+__host__ __device__ inline int render_wgs_per_env(int W, int H) { return (((W + 7) / 8) * ((H + 7) / 8) + 4 * kSubPerWave - 1) / (4 * kSubPerWave); }
+
+template <bool COLOR, class F>
 __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam cam, const double* wf, int n, float* depth_gl,
                                                       uint16_t* depth_mm, double* cam_pose, uint8_t* rgb) {
-  __shared__ double lw[(kMaxShapes + 1) * kShapeFrameDoubles];  // this environment's rows of wf (k_shape_frames)
-  __shared__ uint32_t tile_shapes;  // bit g: shape g can be seen from this tile
+  using Num = RenderNum<F>;
+  __shared__ F lw[(kMaxShapes + 1) * kShapeFrameDoubles];  // this environment's rows of wf (k_shape_frames)
   const int W = cam.width, H = cam.height;
-  // a workgroup is a 16 x 16 pixel tile, each of its four wavefronts an 8 x 8 sub-tile: the rays of a wavefront stay
-  // together, so they mostly agree on which shapes they have to look at
-  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-  const int blocks_per_env = tiles_x * tiles_y;
-  // Workgroups go to the chip's 8 XCDs round robin by their index.  The tiles of one environment read the same shape frames and
-  // hull views; numbered so that they follow each other on ONE XCD they find them in that XCD's L2, instead of all eight L2s
-  // fetching every environment's rows.  (The grid is rounded up to a multiple of 8.)
-  const int nblocks = n * blocks_per_env, per_xcd = (nblocks + 7) / 8;
+  const int sub_x = (W + 7) / 8, nsub = sub_x * ((H + 7) / 8);
+  const int wgs_per_env = render_wgs_per_env(W, H);
+  // Workgroups go to the chip's 8 XCDs round robin by their index.  The workgroups of one environment read the same shape frames
+  // and hull views; numbered so that they follow each other on ONE XCD they find them in that XCD's L2, instead of all eight L2s
+  // fetching every environment's rows -- and every XCD gets whole environments, i.e. an even share of the rays that meet a hull.
+  // (The grid is rounded up to a multiple of 8.)
+  const int nblocks = n * wgs_per_env, per_xcd = (nblocks + 7) / 8;
 #ifdef RCSH_NO_XCD_REMAP
   const int block = (int)blockIdx.x;
 #else
   const int block = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
 #endif
   if (block >= nblocks) return;
-  const int e = block / blocks_per_env;
-  const int tile = block % blocks_per_env;
+  const int e = block / wgs_per_env, part = block % wgs_per_env;
   const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
-  const int col = (tile % tiles_x) * 16 + (wave % 2) * 8 + lane % 8;
-  const int row = (tile / tiles_x) * 16 + (wave / 2) * 8 + lane / 8;  // row 0 = bottom of the image (OpenGL window coordinates)
-  const double ty = cam.tan_half_fovy, tx = cam.tx;
+  const F ty = (F)cam.tan_half_fovy, tx = (F)cam.tx, two_over_w = (F)cam.two_over_w, two_over_h = (F)cam.two_over_h;
+  const F znear = (F)sc.znear, zfar = (F)sc.zfar;
   {
     // (this environment's rows of wf, staged in LDS.  Reading them through scalar loads instead -- the row index is the
-    // wavefront's -- was tried and measured slower: 2.90 vs 2.72 ms wrist, 5.26 vs 4.93 ms bird's-eye at 256 x 256: the L2's latency)
+    // wavefront's -- was tried and measured slower: the L2's latency)
     const int words = (sc.nshape + 1) * kShapeFrameDoubles;
     const double* src = wf + (size_t)e * words;
-    for (int k = threadIdx.x; k < words; k += 256) lw[k] = src[k];
+    for (int k = threadIdx.x; k < words; k += 256) lw[k] = (F)src[k];
+    if (cam_pose && part == 0 && threadIdx.x < 12) cam_pose[(size_t)e * 12 + threadIdx.x] = src[sc.nshape * kShapeFrameDoubles + threadIdx.x];
   }
   __syncthreads();
-  const double* cR = lw + sc.nshape * kShapeFrameDoubles;
-  const double* cp = cR + 9;
-  if (threadIdx.x < 64) {
-    // wavefront 0, thread g: does shape g's bounding sphere reach into the pyramid of this tile's rays (four planes
-    // through the camera, and the near plane)?
-    bool visible = false;
-    if (threadIdx.x < sc.nshape) {
-      const double* w = lw + threadIdx.x * kShapeFrameDoubles;
-      const double r = w[15];
-      visible = true;
-      if (r >= 0) {
-        // sphere centre in the camera frame; the tile spans x in [xl, xr] (-z), y in [yb, yt] (-z)
-        const double q[3] = {w[12] - cp[0], w[13] - cp[1], w[14] - cp[2]};
-        const double x = cR[0] * q[0] + cR[3] * q[1] + cR[6] * q[2], y = cR[1] * q[0] + cR[4] * q[1] + cR[7] * q[2], z = cR[2] * q[0] + cR[5] * q[1] + cR[8] * q[2];
-        const int c0 = (tile % tiles_x) * 16, r0 = (tile / tiles_x) * 16;
-        const double xl = (c0 * cam.two_over_w - 1.0) * tx, xr = ((c0 + 16) * cam.two_over_w - 1.0) * tx;
-        const double yb = (r0 * cam.two_over_h - 1.0) * ty, yt = ((r0 + 16) * cam.two_over_h - 1.0) * ty;
-        // signed distance of the centre to each side plane of the pyramid, times that plane's normal's length: on the inner side,
-        // or no further out than the radius (squares: no square root)
-        const double r2 = r * r;
-        const double sl = x + xl * z, sr = -x - xr * z, sb = y + yb * z, st = -y - yt * z;
-        visible = -z + r >= sc.znear && (sl >= 0 || sl * sl <= r2 * (1 + xl * xl)) && (sr >= 0 || sr * sr <= r2 * (1 + xr * xr)) &&
-                  (sb >= 0 || sb * sb <= r2 * (1 + yb * yb)) && (st >= 0 || st * st <= r2 * (1 + yt * yt));
-      }
-    }
-    const uint64_t m = __ballot(visible);
-    if (threadIdx.x == 0) {
-      tile_shapes = (uint32_t)m;
-      if (cam_pose && tile == 0)
-        for (int k = 0; k < 12; ++k) cam_pose[(size_t)e * 12 + k] = cR[k];
-    }
-  }
-  __syncthreads();
-  const uint32_t wave_shapes = tile_shapes;
-  // Front to back.  A ray only needs the NEAREST entry point, and the slab test below starts from t1 = best: a shape whose box
-  // begins behind the nearest hit so far costs three slabs instead of its ~100 face planes.  Seen from above an arm is a stack
-  // of links, each ray's pyramid crossing most of their boxes -- visited base first (index order) every one of them was walked
-  // in full.  The wavefront's shapes are ranked by the view depth of their box's nearest point (lane g ranks shape g; planes
-  // first: one cheap test that bounds `best`), the order goes through LDS.  Which shape is hit does not depend on the order
-  // (ties between two shapes' entry depths aside), the depth never does.
-  __shared__ uint8_t visit[4][kMaxShapes];
-  int nvisit = __popc(wave_shapes);
-  {
-    double key = INFINITY;
-    const bool mine = lane < sc.nshape && ((wave_shapes >> lane) & 1u);
-    if (mine) {
-      const RenderShape& sh = sc.shapes[lane];
-      const double* w = lw + lane * kShapeFrameDoubles;
-      if (sh.shape == kShapePlane) key = -INFINITY;
-      else {
-        // view depth = -(z of the camera frame); the camera's z axis in world coordinates is the third column of cR
-        const double az[3] = {cR[2], cR[5], cR[8]};
-        key = -(az[0] * (w[12] - cp[0]) + az[1] * (w[13] - cp[1]) + az[2] * (w[14] - cp[2]));
+  const F* cR = lw + sc.nshape * kShapeFrameDoubles;
+  const F* cp = cR + 9;
+  // lane g < nshape: shape g as the camera sees it -- its bounding sphere's centre in the camera frame, its radius, and the
+  // key the wavefront's visits are ordered by (below) -- the same for every sub-tile
+  const bool isshape = lane < sc.nshape;
+  F sx = 0, sy = 0, sz = 0, sr = -1, key = (F)INFINITY;
+  if (isshape) {
+    const F* w = lw + lane * kShapeFrameDoubles;
+    sr = w[15];
+    const F q[3] = {w[12] - cp[0], w[13] - cp[1], w[14] - cp[2]};
+    sx = cR[0] * q[0] + cR[3] * q[1] + cR[6] * q[2]; sy = cR[1] * q[0] + cR[4] * q[1] + cR[7] * q[2]; sz = cR[2] * q[0] + cR[5] * q[1] + cR[8] * q[2];
+    // Front to back.  A ray only needs the NEAREST entry point, and the slab test below starts from t1 = best: a shape whose box
+    // begins behind the nearest hit so far costs three slabs instead of its ~100 face planes.  Seen from above an arm is a stack
+    // of links, each ray's pyramid crossing most of their boxes -- visited base first (index order) every one of them was walked
+    // in full.  The shapes are ranked by the view depth of their box's nearest point (planes first: one cheap test that bounds
+    // `best`).  Which shape is hit does not depend on the order (ties between two shapes' entry depths aside), the depth never does.
+    if (sc.shapes[lane].shape == kShapePlane) key = -(F)INFINITY;
+    else {
+      // view depth = -(z of the camera frame); the camera's z axis in world coordinates is the third column of cR
+      const F az[3] = {cR[2], cR[5], cR[8]};
+      key = -sz;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) key -= sh.size[k] * fabs(az[0] * w[k] + az[1] * w[3 + k] + az[2] * w[6 + k]);
-      }
+      for (int k = 0; k < 3; ++k) key -= w[16 + k] * fabs(az[0] * w[k] + az[1] * w[3 + k] + az[2] * w[6 + k]);
     }
+  }
+  const F o[3] = {cp[0], cp[1], cp[2]};
+  for (int si = 0; si < kSubPerWave; ++si) {
+    const int sub = (part * 4 + wave) * kSubPerWave + si;  // (the wavefront's: every test on it is a scalar branch)
+    if (sub >= nsub) break;
+    const int c0 = (sub % sub_x) * 8, r0 = (sub / sub_x) * 8;
+    // does shape g's bounding sphere reach into the pyramid of this sub-tile's rays (four planes through the camera, and the
+    // near plane)?  The sub-tile spans x in [xl, xr] (-z), y in [yb, yt] (-z)
+    bool visible = isshape;
+    if (isshape && sr >= 0) {
+      const F xl = (c0 * two_over_w - 1) * tx, xr = ((c0 + 8) * two_over_w - 1) * tx;
+      const F yb = (r0 * two_over_h - 1) * ty, yt = ((r0 + 8) * two_over_h - 1) * ty;
+      // signed distance of the centre to each side plane of the pyramid, times that plane's normal's length: on the inner side,
+      // or no further out than the radius (squares: no square root)
+      const F r2 = sr * sr;
+      const F sl = sx + xl * sz, srr = -sx - xr * sz, sb = sy + yb * sz, st = -sy - yt * sz;
+      visible = -sz + sr >= znear && (sl >= 0 || sl * sl <= r2 * (1 + xl * xl)) && (srr >= 0 || srr * srr <= r2 * (1 + xr * xr)) &&
+                (sb >= 0 || sb * sb <= r2 * (1 + yb * yb)) && (st >= 0 || st * st <= r2 * (1 + yt * yt));
+    }
+    const uint32_t wave_shapes = (uint32_t)__ballot(visible);
+    const int nvisit = __popc(wave_shapes);
     // (few shapes -- the wrist camera's usual view: floor, cube, finger pads -- are visited in index order: nothing to gain)
     int rank = __popc(wave_shapes & ((1u << (lane & 31)) - 1u));
     if (nvisit > 4) {
       rank = 0;
       for (uint32_t m = wave_shapes; m; m &= m - 1) {
         const int g = __ffs(m) - 1;
-        const double kg = __shfl(key, g);
+        const F kg = __shfl(key, g);
         rank += (kg < key || (kg == key && g < lane)) ? 1 : 0;
       }
     }
-    if (mine) visit[wave][rank] = (uint8_t)lane;
-  }
-  __syncthreads();
-  if (col >= W || row >= H) return;
-  // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
-  const double dc[3] = {((col + 0.5) * cam.two_over_w - 1.0) * tx, ((row + 0.5) * cam.two_over_h - 1.0) * ty, -1.0};
-  double d[3];
-  mulmv(cR, dc, d);
-  const double o[3] = {cp[0], cp[1], cp[2]};
-  const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-  double best = sc.zfar;
-  bool hit = false;
-  // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
-  int hit_g = -1, hit_face = 0;
-  bool hit_outline = false;  // hit_face counts the hull's FRONT planes (its view record), not its planes
-  for (int vi = 0; vi < nvisit; ++vi) {
-    // (the visit list is the wavefront's: saying so lets the shape's constants and its ~100 face planes come through scalar loads)
-    const int g = __builtin_amdgcn_readfirstlane((int)visit[wave][vi]);
-    const RenderShape& sh = sc.shapes[g];
-    const double* w = lw + g * kShapeFrameDoubles;  // R (9) p (3) sphere centre (3) radius
-    if (w[15] >= 0) {
-      // bounding sphere: closest approach of the ray to the centre
-      const double oc[3] = {w[12] - o[0], w[13] - o[1], w[14] - o[2]};
-      const double b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
-      const double c2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
-      if (c2 * dd - b * b > w[15] * w[15] * dd) continue;
-    }
-    // ray in the shape's frame
-    const double* R = w;
-    const double om[3] = {o[0] - w[9], o[1] - w[10], o[2] - w[11]};
-    const double lo[3] = {R[0] * om[0] + R[3] * om[1] + R[6] * om[2], R[1] * om[0] + R[4] * om[1] + R[7] * om[2], R[2] * om[0] + R[5] * om[1] + R[8] * om[2]};
-    const double ld[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2], R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
-    double t0 = sc.znear, t1 = best;
-    if (sh.shape == kShapePlane) {
-      // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
-      if (!(ld[2] < 0 && lo[2] > 0)) continue;
-      const double t = -lo[2] * fast_rcp(ld[2]);
-      if (t >= t0 && t < t1) { best = t; hit = true; if (COLOR) { hit_g = g; hit_face = 0; } }
-      continue;
-    }
-    bool ok = true;
-    // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
-    // `size`): most rays that pass the sphere of an elongated link miss the link
-    const double cen[3] = {sh.shape != kShapeBox ? sh.sphere[0] : 0.0, sh.shape != kShapeBox ? sh.sphere[1] : 0.0, sh.shape != kShapeBox ? sh.sphere[2] : 0.0};
-    int face = 0;
-    {
-      double b0 = t0, b1 = t1;
-      for (int k = 0; k < 3 && ok; ++k) {
-        const double lk = lo[k] - cen[k];
-        if (ld[k] == 0) { ok = fabs(lk) <= sh.size[k]; continue; }
-        const double inv = fast_rcp(ld[k]);
-        double ta = (-sh.size[k] - lk) * inv, tb = (sh.size[k] - lk) * inv;
-        if (ta > tb) { const double x = ta; ta = tb; tb = x; }
-        if (COLOR && ta > b0) face = ld[k] > 0 ? 2 * k : 2 * k + 1;  // entered through the -k (even) or the +k (odd) face
-        b0 = ta > b0 ? ta : b0;
-        b1 = tb < b1 ? tb : b1;
-        ok = b0 <= b1;
+    const int col = c0 + (lane & 7);
+    const int row = r0 + (lane >> 3);  // row 0 = bottom of the image (OpenGL window coordinates)
+    const bool inimg = col < W && row < H;
+    // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
+    const F dc[3] = {((col + (F)0.5) * two_over_w - 1) * tx, ((row + (F)0.5) * two_over_h - 1) * ty, -1};
+    const F d[3] = {cR[0] * dc[0] + cR[1] * dc[1] + cR[2] * dc[2], cR[3] * dc[0] + cR[4] * dc[1] + cR[5] * dc[2], cR[6] * dc[0] + cR[7] * dc[1] + cR[8] * dc[2]};
+    const F dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    F best = zfar;
+    bool hit = false;
+    // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
+    int hit_g = -1, hit_face = 0;
+    bool hit_outline = false;  // hit_face counts the hull's FRONT planes (its view record), not its planes
+    for (int vi = 0; vi < nvisit; ++vi) {
+      // (the visit list is the wavefront's: saying so lets the shape's constants and its ~100 face planes come through scalar loads)
+      const int g = __ffsll((unsigned long long)__ballot(visible && rank == vi)) - 1;
+      const RenderShape& sh = sc.shapes[g];
+      const F* w = lw + g * kShapeFrameDoubles;  // R (9) p (3) sphere centre (3) radius, half extents (3), box centre (3)
+      if (w[15] >= 0) {
+        // bounding sphere: closest approach of the ray to the centre
+        const F oc[3] = {w[12] - o[0], w[13] - o[1], w[14] - o[2]};
+        const F b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
+        const F c2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
+        if (c2 * dd - b * b > w[15] * w[15] * dd) continue;
       }
-      if (sh.shape == kShapeBox) { t0 = b0; t1 = b1; }
-    }
-    if (ok && sh.shape == kShapeCapsule) {
-      // capsule about the shape frame's z axis: the ray's first point on the cylinder's wall between the caps, or on the outer
-      // half of a cap sphere -- the smallest of the (at most three) candidates, the surface being convex
-      const double r = sh.size[0], hl = sh.size[2] - sh.size[0];
-      double te = INFINITY;
-      const double a = ld[0] * ld[0] + ld[1] * ld[1], bq = lo[0] * ld[0] + lo[1] * ld[1], cq = lo[0] * lo[0] + lo[1] * lo[1] - r * r;
-      const double disc = bq * bq - a * cq;
-      if (a > 0 && disc >= 0) {
-        const double t = (-bq - sqrt(disc)) / a;
-        if (fabs(lo[2] + t * ld[2]) <= hl) te = t;
+      // ray in the shape's frame
+      const F* R = w;
+      const F om[3] = {o[0] - w[9], o[1] - w[10], o[2] - w[11]};
+      const F lo[3] = {R[0] * om[0] + R[3] * om[1] + R[6] * om[2], R[1] * om[0] + R[4] * om[1] + R[7] * om[2], R[2] * om[0] + R[5] * om[1] + R[8] * om[2]};
+      const F ld[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2], R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
+      const int shape = __builtin_amdgcn_readfirstlane(sh.shape);
+      F t0 = znear, t1 = best;
+      if (shape == kShapePlane) {
+        // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
+        if (!(ld[2] < 0 && lo[2] > 0)) continue;
+        const F t = -lo[2] * Num::rcp(ld[2]);
+        if (t >= t0 && t < t1) { best = t; hit = true; if (COLOR) { hit_g = g; hit_face = 0; } }
+        continue;
       }
-      const double A = a + ld[2] * ld[2];
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const double zc = side ? hl : -hl, oz = lo[2] - zc;
-        const double B = bq + oz * ld[2], Cq = cq + oz * oz;
-        const double ds = B * B - A * Cq;
-        if (ds >= 0) {
-          const double t = (-B - sqrt(ds)) / A;
-          const double zr = oz + t * ld[2];  // of the point, from the cap's centre
-          if ((side ? zr >= 0 : zr <= 0) && t < te) te = t;
+      bool ok = true;
+      // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
+      // `size`): most rays that pass the sphere of an elongated link miss the link
+      int face = 0;
+      {
+        F b0 = t0, b1 = t1;
+        for (int k = 0; k < 3 && ok; ++k) {
+          const F lk = lo[k] - w[19 + k], sz_k = w[16 + k];
+          if (ld[k] == 0) { ok = fabs(lk) <= sz_k; continue; }
+          const F inv = Num::rcp(ld[k]);
+          F ta = (-sz_k - lk) * inv, tb = (sz_k - lk) * inv;
+          if (ta > tb) { const F x = ta; ta = tb; tb = x; }
+          if (COLOR && ta > b0) face = ld[k] > 0 ? 2 * k : 2 * k + 1;  // entered through the -k (even) or the +k (odd) face
+          b0 = ta > b0 ? ta : b0;
+          b1 = tb < b1 ? tb : b1;
+          ok = b0 <= b1;
         }
+        if (shape == kShapeBox) { t0 = b0; t1 = b1; }
       }
-      ok = te < INFINITY;
-      t0 = ok && te > t0 ? te : t0;
-      ok = ok && te >= sc.znear && t0 <= t1;
-    }
+      if (ok && shape == kShapeCapsule) {
+        // capsule about the shape frame's z axis: the ray's first point on the cylinder's wall between the caps, or on the outer
+        // half of a cap sphere -- the smallest of the (at most three) candidates, the surface being convex
+        const F r = w[16], hl = w[18] - w[16];
+        F te = (F)INFINITY;
+        const F a = ld[0] * ld[0] + ld[1] * ld[1], bq = lo[0] * ld[0] + lo[1] * ld[1], cq = lo[0] * lo[0] + lo[1] * lo[1] - r * r;
+        const F disc = bq * bq - a * cq;
+        if (a > 0 && disc >= 0) {
+          const F t = (-bq - sqrt(disc)) / a;
+          if (fabs(lo[2] + t * ld[2]) <= hl) te = t;
+        }
+        const F A = a + ld[2] * ld[2];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const F zc = side ? hl : -hl, oz = lo[2] - zc;
+          const F B = bq + oz * ld[2], Cq = cq + oz * oz;
+          const F ds = B * B - A * Cq;
+          if (ds >= 0) {
+            const F t = (-B - sqrt(ds)) / A;
+            const F zr = oz + t * ld[2];  // of the point, from the cap's centre
+            if ((side ? zr >= 0 : zr <= 0) && t < te) te = t;
+          }
+        }
+        ok = te < (F)INFINITY;
+        t0 = ok && te > t0 ? te : t0;
+        ok = ok && te >= znear && t0 <= t1;
+      }
 #ifdef RCSH_RENDER_NOWALK
-    if (sh.shape == kShapeHull) ok = false;  // (measurement: everything but the hulls' own tests)
+      if (shape == kShapeHull) ok = false;  // (measurement: everything but the hulls' own tests)
 #endif
 #ifdef RCSH_RENDER_FLOORONLY
-    ok = false;  // (measurement: the floor and the bookkeeping)
+      ok = false;  // (measurement: the floor and the bookkeeping)
 #endif
-    bool by_outline = false;
-    typedef const double __attribute__((address_space(4))) kdouble;
-    if (ok && sh.shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
-      // the outline method (k_hull_views): this environment's record of the hull as the camera sees it.  The address is the
-      // wavefront's (e is the workgroup's, g the wavefront's): header and rows come through scalar loads.
-      kdouble* vw = (kdouble*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr);
-      typedef const int32_t __attribute__((address_space(4))) kint;
-      const int nfront = __builtin_amdgcn_readfirstlane(((kint*)vw)[0]), nout = __builtin_amdgcn_readfirstlane(((kint*)vw)[1]);
-      if (nout >= 0) {
-        by_outline = true;
-        kdouble* ol = vw + kViewHeaderDoubles + 4 * (size_t)__builtin_amdgcn_readfirstlane(sh.plane_num);
-        // inside the cone over the outline?  (kRows rows per round -- their scalar loads go out together and the L2's latency is
-        // paid once per round; the tail round repeats the last row, which changes nothing)
-        constexpr int kRows = 4;
-        ok = ok && nfront > 0 && nout > 0;
-        for (int k = 0; k < nout && ok; k += kRows) {
-          double q[kRows][3];
+      bool by_outline = false;
+      typedef const double __attribute__((address_space(4))) kdouble;
+      typedef const F __attribute__((address_space(4))) kF;
+      const int plane_num = __builtin_amdgcn_readfirstlane(sh.plane_num);
+      if (ok && shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
+        // the outline method (k_hull_views): this environment's record of the hull as the camera sees it.  The address is the
+        // wavefront's (e is the workgroup's, g the wavefront's): header and rows come through scalar loads.
+        kdouble* vw = (kdouble*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr);
+        typedef const int32_t __attribute__((address_space(4))) kint;
+        const int nfront = __builtin_amdgcn_readfirstlane(((kint*)vw)[0]), nout = __builtin_amdgcn_readfirstlane(((kint*)vw)[1]);
+        if (nout >= 0) {
+          by_outline = true;
+          kF* fr = (kF*)(vw + kViewHeaderDoubles);
+          kF* ol = fr + 4 * (size_t)plane_num;
+          // inside the cone over the outline?  (kRows rows per round -- their scalar loads go out together and the L2's latency is
+          // paid once per round; the tail round repeats the last row, which changes nothing)
+          constexpr int kRows = 4;
+          ok = ok && nfront > 0 && nout > 0;
+          for (int k = 0; k < nout && ok; k += kRows) {
+            F q[kRows][3];
 #pragma unroll
-          for (int j = 0; j < kRows; ++j) {
-            kdouble* src = ol + 4 * (size_t)(k + j < nout ? k + j : nout - 1);
-            q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2];
+            for (int j = 0; j < kRows; ++j) {
+              kF* src = ol + 4 * (size_t)(k + j < nout ? k + j : nout - 1);
+              q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2];
+            }
+#pragma unroll
+            for (int j = 0; j < kRows; ++j) ok = ok && q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2] >= 0;
           }
+          // entry depth: the largest no / nd over the front planes (nd < 0 on every one of them for a ray inside the cone)
+          for (int k = 0; k < nfront && ok; k += kRows) {
+            F q[kRows][4];
 #pragma unroll
-          for (int j = 0; j < kRows; ++j) ok = ok && q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2] >= 0;
-        }
-        // entry depth: the largest no / nd over the front planes (nd < 0 on every one of them for a ray inside the cone)
-        kdouble* fr = vw + kViewHeaderDoubles;
-        for (int k = 0; k < nfront && ok; k += kRows) {
-          double q[kRows][4];
+            for (int j = 0; j < kRows; ++j) {
+              kF* src = fr + 4 * (size_t)(k + j < nfront ? k + j : nfront - 1);
+              q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2]; q[j][3] = src[3];
+            }
 #pragma unroll
-          for (int j = 0; j < kRows; ++j) {
-            kdouble* src = fr + 4 * (size_t)(k + j < nfront ? k + j : nfront - 1);
-            q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2]; q[j][3] = src[3];
-          }
-#pragma unroll
-          for (int j = 0; j < kRows; ++j) {
-            const double nd = q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2];
-            if (nd < 0 && q[j][3] < t0 * nd) {  // (the gate of the plane walk below: only a plane that moves t0 pays for the division)
-              const double t = q[j][3] * fast_rcp(nd);
-              if (COLOR && t > t0) face = k + j < nfront ? k + j : nfront - 1;
-              t0 = t > t0 ? t : t0;
+            for (int j = 0; j < kRows; ++j) {
+              const F nd = q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2];
+              if (nd < 0 && q[j][3] < t0 * nd) {  // (the gate of the plane walk below: only a plane that moves t0 pays for the division)
+                const F t = q[j][3] * Num::rcp(nd);
+                if (COLOR && t > t0) face = k + j < nfront ? k + j : nfront - 1;
+                t0 = t > t0 ? t : t0;
+              }
             }
           }
+          ok = ok && t0 <= t1;
         }
-        ok = ok && t0 <= t1;
       }
-    }
-    if (ok && sh.shape == kShapeHull && !by_outline) {
-      // four planes per round: their loads go out together (a plane a round would wait for L1 every time); the tail
-      // round repeats the last plane, which changes nothing
-      // (the planes are read through the constant address space: the address is the wavefront's -- g is -- so they arrive by
-      // scalar loads, 32 bytes per plane per WAVEFRONT instead of per lane, and feed the multiply-adds from scalar registers)
-      kdouble* pl = (kdouble*)(sc.planes + 4 * (size_t)sh.plane_adr);
-      const int plane_num = __builtin_amdgcn_readfirstlane(sh.plane_num);
-      for (int k = 0; k < plane_num && ok; k += 4) {
-        double q4[4][4];
+      if (ok && shape == kShapeHull && !by_outline) {
+        // four planes per round: their loads go out together (a plane a round would wait for L1 every time); the tail
+        // round repeats the last plane, which changes nothing
+        // (the planes are read through the constant address space: the address is the wavefront's -- g is -- so they arrive by
+        // scalar loads, 32 bytes per plane per WAVEFRONT instead of per lane, and feed the multiply-adds from scalar registers)
+        kdouble* pl = (kdouble*)(sc.planes + 4 * (size_t)sh.plane_adr);
+        for (int k = 0; k < plane_num && ok; k += 4) {
+          F q4[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          kdouble* src = pl + 4 * (size_t)(k + j < plane_num ? k + j : plane_num - 1);
-          q4[j][0] = src[0]; q4[j][1] = src[1]; q4[j][2] = src[2]; q4[j][3] = src[3];
+          for (int j = 0; j < 4; ++j) {
+            kdouble* src = pl + 4 * (size_t)(k + j < plane_num ? k + j : plane_num - 1);
+            q4[j][0] = (F)src[0]; q4[j][1] = (F)src[1]; q4[j][2] = (F)src[2]; q4[j][3] = (F)src[3];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const F nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
+            const F no = q4[j][3] - (q4[j][0] * lo[0] + q4[j][1] * lo[1] + q4[j][2] * lo[2]);  // >= 0: origin inside this half space
+            if (nd == 0) { ok = ok && no >= 0; continue; }
+            // Does this plane move the interval at all?  Entering planes (nd < 0) matter when t = no / nd > t0, leaving ones when
+            // t < t1 -- either way  no < bound * nd  -- and after the first few planes of a walk almost none does: the division
+            // (a reciprocal seed and two Newton steps) is spent only on the planes that pass, a third of the instructions of the
+            // walk that three quarters of a bird's-eye frame consist of.
+            const bool front = nd < 0;
+            const F bound = front ? t0 : t1;
+            if (no < bound * nd) {
+              const F t = no * Num::rcp(nd);
+              if (COLOR && front && t > t0) face = k + j < plane_num ? k + j : plane_num - 1;
+              if (front) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
+            }
+          }
+          ok = ok && t0 <= t1;
         }
+      }
+      // a camera inside a shape sees its inside faces culled (back faces): only entry points count
+      if (ok && t0 > znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; hit_outline = by_outline; } }
+    }
+    if (!inimg) continue;
+    // (1/near - 1/z) / (1/near - 1/far): a difference of reciprocals of very different sizes -- the encoding (two instructions a
+    // ray) stays in double whatever the rays' type
+    const float dgl = hit ? (float)((sc.inv_near - fast_rcp((double)best)) * sc.inv_span) : 1.0f;
+    const size_t img = (size_t)e * W * H;
+    if (depth_gl) depth_gl[img + (size_t)row * W + col] = dgl;
+    if (depth_mm) {
+      // python/rcs/camera/sim.py:74-86 in float32: z = near / (1 - d (1 - near / far)); uint16(z * 1000)
+#pragma clang fp contract(off)  // numpy rounds the product before the subtraction: no fused multiply-add here
+      const float nearf = (float)sc.znear;
+      const float k1 = (float)(1.0 - sc.znear / sc.zfar);
+      const float prod = dgl * k1;
+      const float z = nearf / (1.0f - prod);
+      const float mm = z * 1000.0f;
+      depth_mm[img + (size_t)(H - 1 - row) * W + col] = (uint16_t)mm;
+    }
+    if constexpr (COLOR) {
+      if (!rgb) continue;
+      const RenderShade& L = sc.shade;
+      const F inv_len = Num::rsqrt(dd);
+      F out[3];
+      if (!hit) {
+        const F f = (F)0.5 * (d[2] * inv_len + 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
-          const double no = q4[j][3] - (q4[j][0] * lo[0] + q4[j][1] * lo[1] + q4[j][2] * lo[2]);  // >= 0: origin inside this half space
-          if (nd == 0) { ok = ok && no >= 0; continue; }
-          // Does this plane move the interval at all?  Entering planes (nd < 0) matter when t = no / nd > t0, leaving ones when
-          // t < t1 -- either way  no < bound * nd  -- and after the first few planes of a walk almost none does: the division
-          // (a reciprocal seed and two Newton steps) is spent only on the planes that pass, a third of the instructions of the
-          // walk that three quarters of a bird's-eye frame consist of.
-          const bool front = nd < 0;
-          const double bound = front ? t0 : t1;
-          if (no < bound * nd) {
-            const double t = no * fast_rcp(nd);
-            if (COLOR && front && t > t0) face = k + j < plane_num ? k + j : plane_num - 1;
-            if (front) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
+        for (int c = 0; c < 3; ++c) out[c] = (F)L.sky2[c] + f * ((F)L.sky1[c] - (F)L.sky2[c]);
+      } else {
+        const RenderShape& sh = sc.shapes[hit_g];
+        const RenderColour& col_g = sc.colours[hit_g];
+        const F* R = lw + hit_g * kShapeFrameDoubles;
+        F nl[3] = {0, 0, 1};
+        if (sh.shape == kShapeBox) {
+          nl[2] = 0;
+          nl[hit_face >> 1] = (hit_face & 1) ? 1 : -1;
+        } else if (sh.shape == kShapeCapsule) {
+          // the hit point from the nearest point of the axis segment
+          const F om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
+          const F hl = R[18] - R[16];
+          const F hz = R[2] * om[0] + R[5] * om[1] + R[8] * om[2];
+          nl[0] = R[0] * om[0] + R[3] * om[1] + R[6] * om[2];
+          nl[1] = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
+          nl[2] = hz - (hz > hl ? hl : (hz < -hl ? -hl : hz));
+        } else if (sh.shape == kShapeHull) {
+          if (hit_outline) {
+            const F* q = (const F*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles) + 4 * (size_t)hit_face;
+            nl[0] = q[0]; nl[1] = q[1]; nl[2] = q[2];
+          } else {
+            const double* q = sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
+            nl[0] = (F)q[0]; nl[1] = (F)q[1]; nl[2] = (F)q[2];
           }
         }
-        ok = ok && t0 <= t1;
-      }
-    }
-    // a camera inside a shape sees its inside faces culled (back faces): only entry points count
-    if (ok && t0 > sc.znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; hit_outline = by_outline; } }
-  }
-  const float dgl = hit ? (float)((sc.inv_near - fast_rcp(best)) * sc.inv_span) : 1.0f;  // (1/near - 1/z) / (1/near - 1/far)
-  const size_t img = (size_t)e * W * H;
-  if (depth_gl) depth_gl[img + (size_t)row * W + col] = dgl;
-  if (depth_mm) {
-    // python/rcs/camera/sim.py:74-86 in float32: z = near / (1 - d (1 - near / far)); uint16(z * 1000)
-#pragma clang fp contract(off)  // numpy rounds the product before the subtraction: no fused multiply-add here
-    const float nearf = (float)sc.znear;
-    const float k1 = (float)(1.0 - sc.znear / sc.zfar);
-    const float prod = dgl * k1;
-    const float z = nearf / (1.0f - prod);
-    const float mm = z * 1000.0f;
-    depth_mm[img + (size_t)(H - 1 - row) * W + col] = (uint16_t)mm;
-  }
-  if constexpr (COLOR) {
-    if (!rgb) return;
-    const RenderShade& L = sc.shade;
-    const double inv_len = 1.0 / sqrt(dd);
-    double out[3];
-    if (!hit) {
-      const double f = 0.5 * (d[2] * inv_len + 1.0);
+        const F nw[3] = {R[0] * nl[0] + R[1] * nl[1] + R[2] * nl[2], R[3] * nl[0] + R[4] * nl[1] + R[5] * nl[2], R[6] * nl[0] + R[7] * nl[1] + R[8] * nl[2]};
+        const F nn = Num::rsqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+        const F ndv = -(nw[0] * d[0] + nw[1] * d[1] + nw[2] * d[2]) * nn * inv_len;       // towards the camera
+        const F ndl = -(nw[0] * (F)L.light_dir[0] + nw[1] * (F)L.light_dir[1] + nw[2] * (F)L.light_dir[2]) * nn;  // towards the light
+        const F kv = ndv > 0 ? ndv : 0, kl = ndl > 0 ? ndl : 0;
+        bool second = false;
+        if (col_g.checker != 0.0) {
+          // hit point in the shape frame
+          const F om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
+          const F hx = R[0] * om[0] + R[3] * om[1] + R[6] * om[2], hy = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
+          const long long ix = (long long)floor(hx / (F)col_g.square), iy = (long long)floor(hy / (F)col_g.square);
+          second = ((ix + iy) & 1) != 0;
+        }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) out[c] = L.sky2[c] + f * (L.sky1[c] - L.sky2[c]);
-    } else {
-      const RenderShape& sh = sc.shapes[hit_g];
-      const RenderColour& col_g = sc.colours[hit_g];
-      const double* R = lw + hit_g * kShapeFrameDoubles;
-      double nl[3] = {0, 0, 1};
-      if (sh.shape == kShapeBox) {
-        nl[2] = 0;
-        nl[hit_face >> 1] = (hit_face & 1) ? 1.0 : -1.0;
-      } else if (sh.shape == kShapeCapsule) {
-        // the hit point from the nearest point of the axis segment
-        const double om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
-        const double hl = sh.size[2] - sh.size[0];
-        const double hz = R[2] * om[0] + R[5] * om[1] + R[8] * om[2];
-        nl[0] = R[0] * om[0] + R[3] * om[1] + R[6] * om[2];
-        nl[1] = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
-        nl[2] = hz - (hz > hl ? hl : (hz < -hl ? -hl : hz));
-      } else if (sh.shape == kShapeHull) {
-        const double* q = hit_outline ? sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles + 4 * (size_t)hit_face
-                                      : sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
-        nl[0] = q[0]; nl[1] = q[1]; nl[2] = q[2];
+        for (int c = 0; c < 3; ++c) {
+          const F base = (F)(second ? col_g.rgb2[c] : col_g.rgb[c]);
+          out[c] = base * ((F)L.ambient[c] + (F)L.head_diffuse[c] * kv + (F)L.light_diffuse[c] * kl);
+        }
       }
-      double nw[3];
-      mulmv(R, nl, nw);
-      const double nn = 1.0 / sqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
-      const double ndv = -(nw[0] * d[0] + nw[1] * d[1] + nw[2] * d[2]) * nn * inv_len;       // towards the camera
-      const double ndl = -(nw[0] * L.light_dir[0] + nw[1] * L.light_dir[1] + nw[2] * L.light_dir[2]) * nn;  // towards the light
-      const double kv = ndv > 0 ? ndv : 0.0, kl = ndl > 0 ? ndl : 0.0;
-      bool second = false;
-      if (col_g.checker != 0.0) {
-        // hit point in the shape frame
-        const double om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
-        const double hx = R[0] * om[0] + R[3] * om[1] + R[6] * om[2], hy = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
-        const long long ix = (long long)floor(hx / col_g.square), iy = (long long)floor(hy / col_g.square);
-        second = ((ix + iy) & 1) != 0;
-      }
+      uint8_t* px = rgb + 3 * (img + (size_t)row * W + col);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const double base = second ? col_g.rgb2[c] : col_g.rgb[c];
-        out[c] = base * (L.ambient[c] + L.head_diffuse[c] * kv + L.light_diffuse[c] * kl);
+        const F v = out[c] < 0 ? 0 : (out[c] > 1 ? 1 : out[c]);
+        px[c] = (uint8_t)(v * 255 + (F)0.5);
       }
-    }
-    uint8_t* px = rgb + 3 * (img + (size_t)row * W + col);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double v = out[c] < 0 ? 0.0 : (out[c] > 1 ? 1.0 : out[c]);
-      px[c] = (uint8_t)(v * 255.0 + 0.5);
     }
   }
 }

@@ -171,7 +171,7 @@ EXPORTS = (
     "rcsh_sim_set_free_qpos", "rcsh_sim_set_free_qvel", "rcsh_sim_nq", "rcsh_sim_nu", "rcsh_sim_state_bytes", "rcsh_sim_get_state", "rcsh_sim_set_state", "rcsh_env_configure", "rcsh_env_obs_width",
     "rcsh_env_action_width", "rcsh_env_reset", "rcsh_env_step", "rcsh_env_reset_dev", "rcsh_env_step_dev",
     "rcsh_sim_set_render_scene", "rcsh_sim_add_camera", "rcsh_hull_edges", "rcsh_camera_render", "rcsh_camera_render_dev",
-    "rcsh_sim_set_render_colours", "rcsh_camera_render_rgb", "rcsh_camera_render_rgb_dev",
+    "rcsh_sim_set_render_colours", "rcsh_camera_render_rgb", "rcsh_camera_render_rgb_dev", "rcsh_sim_set_render_f64",
     "rcsh_sim_set_render_schedule", "rcsh_render_pending", "rcsh_render_dropped", "rcsh_camera_render_snapshot",
     "rcsh_env_configure_pick_task", "rcsh_env_reset_task", "rcsh_env_step_task", "rcsh_env_reset_task_dev", "rcsh_env_step_task_dev",
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
@@ -236,6 +236,7 @@ def load() -> C.CDLL:
     L.rcsh_camera_render_snapshot.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_sim_set_render_colours.argtypes = [C.c_void_p, C.POINTER(RenderColours)]
     L.rcsh_camera_render_rgb.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rcsh_sim_set_render_f64.argtypes = [C.c_void_p, C.c_int32]
     L.rcsh_camera_render_rgb_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_env_configure_pick_task.argtypes = [C.c_void_p, C.POINTER(PickTaskDesc)]
     L.rcsh_env_reset_task.argtypes = [C.c_void_p] + [C.c_void_p] * 5

@@ -77,6 +77,7 @@ def run_xarm7_box_parity(n_envs=16, n_calls=8, k=25, seed=0, width=48, height=32
     simu = S.Sim(cfg.mjcf_scene_path, S.SimConfig(), n_envs=n_envs)
     robot = S.SimRobot(simu, None, cfg)
     cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", resolution_width=width, resolution_height=height)}, physical_units=True)
+    cs.set_double_precision(True)  # (this comparison is about WHAT is drawn and when: exact pixels against the float64 restatement)
     cm = compile_mjcf(scene)
     osims = [O.Sim(cm, XARM7["joints"], XARM7["actuators"], XARM7["site"], XARM7["base"], XARM7["q_home"], None, arm_collision_geoms=[]) for _ in range(n_envs)]
     rng = np.random.default_rng(seed)
@@ -172,7 +173,7 @@ def run_free_box_parity(n_envs=32, n_calls=10, k=25, seed=0, kick=True):
     return rep
 
 
-def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wrist_0", "bird_eye_cam"), n_calls=3, k=17):
+def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wrist_0", "bird_eye_cam"), n_calls=3, k=17, double_precision=False):
     """Depth images of the pick-up scene (floor, cube, robot hulls) from the wrist and the bird's-eye camera: ray-casting
     kernel vs the numpy restatement on the oracle's frames, after random joint moves and cube placements."""
     from rcs_amd import sim as S
@@ -190,6 +191,7 @@ def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wri
     S.SimGripper(simu, default_sim_gripper_cfg())
     cams = {c: SimCameraConfig(identifier=c, frame_rate=0, resolution_width=width, resolution_height=height) for c in cameras}
     cs = SimCameraSet(simu, cams, physical_units=True, render_on_demand=True)
+    cs.set_double_precision(double_precision)
     cm = compile_mjcf(PICKUP_SCENE)
     arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
     osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]
@@ -202,7 +204,7 @@ def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wri
     for e, o in enumerate(osims):
         o.box_qpos = qb[e]
     capsule_shapes = [g for g in range(len(cs._scene.shape)) if cs._scene.shape[g] == render.SHAPE_CAPSULE]
-    rep = {"pixels": 0, "mismatched_mm": 0, "max_mm_diff": 0, "max_abs_depth_gl": 0.0, "max_abs_extrinsics": 0.0, "robot_pixels": 0,
+    rep = {"pixels": 0, "mismatched_mm": 0, "off_by_more_than_1mm": 0, "max_mm_diff": 0, "max_abs_depth_gl": 0.0, "max_abs_extrinsics": 0.0, "robot_pixels": 0,
            "cube_pixels": 0, "floor_pixels": 0, "background_pixels": 0, "fused_mismatch": 0, "rgb_mismatched_pixels": 0, "rgb_max_level_diff": 0,
            "rgb_off_by_more_than_one": 0, "green_pixels": 0, "white_pixels": 0, "colours_seen": set()}
     for _ in range(n_calls):
@@ -232,6 +234,7 @@ def run_depth_render_parity(n_envs=6, width=64, height=48, seed=0, cameras=("wri
                 diff = np.abs(data[e, ..., 0].astype(np.int64) - mm.astype(np.int64))
                 rep["pixels"] += diff.size
                 rep["mismatched_mm"] += int((diff != 0).sum())
+                rep["off_by_more_than_1mm"] += int((diff > 1).sum())
                 rep["max_mm_diff"] = max(rep["max_mm_diff"], int(diff.max()))
                 rep["max_abs_depth_gl"] = max(rep["max_abs_depth_gl"], float(np.abs(raw[e] - dgl).max()))
                 ext = np.linalg.inv(np.block([[cR @ np.diag([1.0, -1.0, -1.0]), cp[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]]))
@@ -801,6 +804,7 @@ def run_xarm7_links_on_the_floor_parity(n_envs=3, seed=0, substeps=900, width=48
     S.SimGripper(simu, xarm7_pick_sim_gripper_cfg())
     cs = SimCameraSet(simu, {"side": SimCameraConfig(identifier="side_cam", frame_rate=0, resolution_width=width, resolution_height=height)},
                       physical_units=True, render_on_demand=True)
+    cs.set_double_precision(True)  # (this comparison is about WHAT is drawn and when: exact pixels against the float64 restatement)
     cm = compile_mjcf(XARM7_PICK_SCENE)
     R = XARM7_PICK
     osims = [O.Sim(cm, R["joints"], R["actuators"], R["site"], R["base"], R["q_home"], O.Pose(translation=np.array([0.0, 0.0, 0.1034])),
@@ -1186,6 +1190,7 @@ def run_rate_driven_camera_parity(n_envs=4, width=32, height=24, seed=3):
     rates = {"wrist_0": 30, "bird_eye_cam": 10}
     cams = {c: SimCameraConfig(identifier=c, frame_rate=r, resolution_width=width, resolution_height=height) for c, r in rates.items()}
     cs = SimCameraSet(simu, cams, physical_units=True, render_on_demand=False, max_framesets=10000)
+    cs.set_double_precision(True)  # (this comparison is about WHAT is drawn and when: exact pixels against the float64 restatement)
     cm = compile_mjcf(PICKUP_SCENE)
     arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
     osims = [O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0") for _ in range(n_envs)]

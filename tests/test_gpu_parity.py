@@ -476,21 +476,29 @@ def test_pick_task_env_matches_oracle(kernel, async_control):
     assert 0.0 < rep["min_reward"] and rep["max_reward"] < 1.0, rep
 
 
-def test_depth_render_matches_oracle(kernel):
+@pytest.mark.parametrize("double_precision", [False, True], ids=["float32", "float64"])
+def test_depth_render_matches_oracle(kernel, double_precision):
     """SimCameraSet depth images (wrist camera on the moving hand, fixed bird's-eye camera) of the pick-up scene: the
-    ray-casting kernel against the numpy restatement on the oracle's frames.  Pixels on a silhouette edge may fall on
-    either side (a ray grazing a hull face decides by round-off), everything else is identical to the millimetre; the
-    fused uint16 path equals the reference's Python conversion of the raw depth buffer bit for bit."""
+    ray-casting kernel against the numpy restatement (float64) on the oracle's frames.  Pixels on a silhouette edge may fall on
+    either side (a ray grazing a hull face decides by round-off); everything else is identical to the millimetre in the
+    double-precision instantiation, and in the product's float32 rays -- the reference's image is a float32 z-buffer quantised
+    to uint16 millimetres -- within ONE millimetre (a depth within 1e-7 of a millimetre boundary truncates to the other side).
+    The fused uint16 path equals the reference's Python conversion of the raw depth buffer bit for bit in both."""
     import parity_util as pu
 
-    rep = pu.run_depth_render_parity(n_envs=6, width=64, height=48, seed=2)
+    rep = pu.run_depth_render_parity(n_envs=6, width=64, height=48, seed=2, double_precision=double_precision)
     assert rep["fused_mismatch"] == 0, rep
-    assert rep["mismatched_mm"] <= 2e-4 * rep["pixels"], rep
+    if double_precision:
+        assert rep["mismatched_mm"] <= 2e-4 * rep["pixels"], rep
+    else:
+        assert rep["mismatched_mm"] <= 5e-3 * rep["pixels"] and rep["off_by_more_than_1mm"] <= 4e-4 * rep["pixels"], rep
     assert rep["max_abs_extrinsics"] < 1e-12, rep
     assert rep["robot_pixels"] > 100 and rep["wrist_min_mm"] < 700, rep  # robot and cube from above; the floor under the hand in the wrist view
     # colour frames of the same rays: flat-shaded shape colours, identical to the restatement up to the rounding of a level
     # (pixels whose ray fell on the other side of a silhouette edge aside)
-    assert rep["rgb_off_by_more_than_one"] == 0 and rep["rgb_mismatched_pixels"] <= 3e-3 * rep["pixels"], rep
+    # (float32: a ray that meets a hull within 1e-7 of the edge between two faces may take the other face's shade)
+    assert rep["rgb_off_by_more_than_one"] <= (0 if double_precision else 2e-4 * rep["pixels"]), rep
+    assert rep["rgb_mismatched_pixels"] <= (3e-3 if double_precision else 8e-3) * rep["pixels"], rep
     assert rep["green_pixels"] > 20 and rep["white_pixels"] > 100, rep  # the cube and the robot are in the pictures
     assert rep["capsule_pixels"] > 10, rep  # and so is the wrist camera's body (a capsule on the hand), seen from above
 
@@ -1382,7 +1390,8 @@ def test_depth_frames_at_the_size_of_baseline_config_3(kernel):
     """The ray caster at BASELINE configs[3]'s per-GPU size: 4096 environments x one 256 x 256 depth frame of the fixed camera of
     scenes/xarm7_pick_world -- 268 million rays, a million workgroups numbered per XCD, 230 MB of per-environment hull views.  32
     distinct arm poses / cube placements tiled 128x over the batch: every copy of a frame equals the first bit for bit wherever
-    its environment sits, and the first two frames equal the numpy ray caster's on the oracle's kinematics (silhouette pixels aside)."""
+    its environment sits, and the first two frames equal the numpy ray caster's on the oracle's kinematics (silhouette pixels aside;
+    the product's float32 rays: within one millimetre, identical in all but a few pixels per thousand)."""
     import rcs_oracle as O
     import rcs_render_oracle as RO
     from parity_util import XARM7_PICK_SCENE
@@ -1423,8 +1432,8 @@ def test_depth_frames_at_the_size_of_baseline_config_3(kernel):
         o.set_joints_hard(q[e])
         o.step(2)
         _, omm, _, _ = RO.render_depth(cs._scene, (link, pos, rot, fovy, W, W), RO.oracle_frames(o, cm))
-        diff = mm[e].astype(np.int64) != omm.astype(np.int64)
-        assert diff.sum() <= 2e-4 * W * W, int(diff.sum())
+        diff = np.abs(mm[e].astype(np.int64) - omm.astype(np.int64))
+        assert (diff != 0).sum() <= 5e-3 * W * W and (diff > 1).sum() <= 4e-4 * W * W, (int((diff != 0).sum()), int((diff > 1).sum()))
         assert (omm < 1500).sum() > 2000  # the arm fills a good part of the picture
     simu.close()
 
@@ -1454,6 +1463,7 @@ def test_outline_method_and_plane_walk_draw_the_same_frames(kernel, monkeypatch)
         S.SimGripper(simu, default_sim_gripper_cfg())
         cs = SimCameraSet(simu, {c: SimCameraConfig(identifier=c, frame_rate=0, resolution_width=W, resolution_height=H) for c in ("wrist_0", "bird_eye_cam")},
                           physical_units=True, render_on_demand=True)
+        cs.set_double_precision(True)  # (the two methods round differently: compared where round-off is 1e-16, not 1e-7)
         simu.set_free_joint_qpos("box_joint", qb)
         robot.set_joints_hard(q)
         simu.step(2)
