@@ -1555,7 +1555,7 @@ int rcsh_sim_set_render_scene(rcsh_sim* s, const rcsh_render_scene_desc* d) {
       r.edge_adr = (int32_t)(edge_planes.size() / 2);
       r.edge_num = (int32_t)edges.size();
       r.view_adr = view_stride;
-      view_stride += kViewHeaderDoubles + 4 * (int64_t)(r.plane_num + kMaxOutline);
+      view_stride += hull_view_doubles(r.plane_num);
       for (const HullEdge& e : edges) {
         edge_planes.push_back(e.a); edge_planes.push_back(e.b);
         edge_verts.insert(edge_verts.end(), e.v1, e.v1 + 3);

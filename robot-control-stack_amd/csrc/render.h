@@ -70,10 +70,15 @@ struct RenderScene {
   double* views;               // [n][view_stride] per environment and hull: what k_hull_views found for the camera being rendered
   int64_t view_stride;         // in doubles
 };
-// A hull's view record: header (int32 nfront, int32 noutline (-1: not usable, walk the planes), 16 bytes unused), then room for
-// plane_num rows (nx, ny, nz, no) of the planes facing the camera, then kMaxOutline rows (mx, my, mz, 0) of the outline.
+// A hull's view record: header (int32 nfront, int32 noutline (-1: not usable, walk the planes), the rest unused), then room for
+// plane_num + kViewPad rows of the planes facing the camera, then kMaxOutline + kViewPad rows (mx, my, mz, 0) of the outline.
 constexpr int kMaxOutline = 64;
-constexpr int kViewHeaderDoubles = 4;
+constexpr int kViewHeaderDoubles = 8;  // (64 bytes: the rows behind it start on the boundary the 16-dword scalar loads like)
+// Both lists of rows are padded with copies of their last row to a multiple of four (a repeated row changes no minimum): the ray
+// caster reads four rows at a time with ONE scalar load and no clamping of indices.  The outline's rows start kViewPad rows
+// behind the room for plane_num front rows.
+constexpr int kViewPad = 4;
+constexpr int64_t hull_view_doubles(int plane_num) { return (kViewHeaderDoubles + 4 * (int64_t)(plane_num + kViewPad + kMaxOutline + kViewPad) + 7) / 8 * 8; }  // (a multiple of 64 bytes)
 
 #if defined(__HIP__)
 
@@ -144,11 +149,19 @@ __device__ __forceinline__ void in_world(const double* frames, int link, int nfr
   p[0] += f[9]; p[1] += f[10]; p[2] += f[11];
 }
 
-// world frames of the scene's shapes and of one camera for every environment: wf[e][g] = R (9) p (3) sphere centre (3)
-// radius (1) half extents (3) box centre in the shape frame (3) unused (2), g < nshape; entry nshape is the camera (R, p).
-// One thread per (environment, entry).  (Everything a ray needs to know about a shape besides its planes is in this row: the
-// ray caster stages an environment's rows in LDS in ITS arithmetic type and reads nothing else per shape.)
-constexpr int kShapeFrameDoubles = 24;
+// Per environment and camera, one row per shape g < nshape and one for the camera (entry nshape).  One thread per (environment, entry).
+//   shape row: [0..8] R, [9..11] p (world; k_hull_views), [12..14] bounding sphere's centre (world), [15] its radius (< 0: unbounded),
+//     [16..18] half extents, [19..21] centre of the slabs in the shape frame (box: 0; hull / capsule: the bounding sphere's),
+//     and what a RAY of this camera needs -- none of it depends on the pixel, so no ray computes it:
+//     [22..30] M = R' cR with the third column negated: a ray (x, y, -1) of the camera frame has direction
+//              ld_i = M[3i] x + M[3i+1] y + M[3i+2] in the shape frame (two multiply-adds a component),
+//     [31..33] lo = R' (o - p): the camera's position in the shape frame (every ray starts there),
+//     [34..36] the sphere's centre in the camera frame, [37..39] R' light_dir (colour: the directional light in the shape frame),
+//     [40] |centre - o|^2 - radius^2 (the ray-sphere test's constant), [41..43] unused;
+//   camera row: [0..8] cR, [9..11] cp, zeros.
+// The ray caster stages an environment's rows in LDS in ITS arithmetic type and reads nothing else per shape but its planes.
+constexpr int kShapeFrameDoubles = 44;
+constexpr int kRowSize = 16, kRowCen = 19, kRowM = 22, kRowLo = 31, kRowSc = 34, kRowLight = 37, kRowK = 40;
 __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* frames, int n, double* wf) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_env = sc.nshape + 1;
@@ -156,23 +169,40 @@ __global__ void k_shape_frames(RenderScene sc, RenderCam cam, const double* fram
   const int e = idx / per_env, g = idx % per_env;
   const double* fe = frames + (size_t)e * sc.nframes * 12;
   double* out = wf + (size_t)idx * kShapeFrameDoubles;
-  double R[9], p[3];
+  double cR[9], cp[3];
+  in_world(fe, cam.link, sc.nframes, cam.pos, cam.rot, cR, cp);
   if (g == sc.nshape) {
-    in_world(fe, cam.link, sc.nframes, cam.pos, cam.rot, R, p);
+    for (int k = 0; k < 9; ++k) out[k] = cR[k];
+    for (int k = 0; k < 3; ++k) out[9 + k] = cp[k];
     for (int k = 12; k < kShapeFrameDoubles; ++k) out[k] = 0.0;
-  } else {
-    const RenderShape& sh = sc.shapes[g];
-    in_world(fe, sh.link, sc.nframes, sh.pos, sh.rot, R, p);
-    double c[3];
-    mulmv(R, sh.sphere, c);
-    for (int k = 0; k < 3; ++k) out[12 + k] = c[k] + p[k];
-    out[15] = sh.sphere[3];
-    // slabs: of the box -- or, for a hull / capsule, of its bounding box (centre = the bounding sphere's, half extents in `size`)
-    for (int k = 0; k < 3; ++k) { out[16 + k] = sh.size[k]; out[19 + k] = sh.shape != kShapeBox ? sh.sphere[k] : 0.0; }
-    out[22] = out[23] = 0.0;
+    return;
   }
+  const RenderShape& sh = sc.shapes[g];
+  double R[9], p[3];
+  in_world(fe, sh.link, sc.nframes, sh.pos, sh.rot, R, p);
+  double c[3];
+  mulmv(R, sh.sphere, c);
+  for (int k = 0; k < 3; ++k) c[k] += p[k];
   for (int k = 0; k < 9; ++k) out[k] = R[k];
-  for (int k = 0; k < 3; ++k) out[9 + k] = p[k];
+  for (int k = 0; k < 3; ++k) { out[9 + k] = p[k]; out[12 + k] = c[k]; }
+  out[15] = sh.sphere[3];
+  // slabs: of the box -- or, for a hull / capsule, of its bounding box (centre = the bounding sphere's, half extents in `size`)
+  for (int k = 0; k < 3; ++k) { out[kRowSize + k] = sh.size[k]; out[kRowCen + k] = sh.shape != kShapeBox ? sh.sphere[k] : 0.0; }
+  const double om[3] = {cp[0] - p[0], cp[1] - p[1], cp[2] - p[2]}, q[3] = {c[0] - cp[0], c[1] - cp[1], c[2] - cp[2]};
+  double k2 = -sh.sphere[3] * sh.sphere[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      const double m = R[i] * cR[j] + R[3 + i] * cR[3 + j] + R[6 + i] * cR[6 + j];
+      out[kRowM + 3 * i + j] = j == 2 ? -m : m;
+    }
+    out[kRowLo + i] = R[i] * om[0] + R[3 + i] * om[1] + R[6 + i] * om[2];
+    const double sc_i = cR[i] * q[0] + cR[3 + i] * q[1] + cR[6 + i] * q[2];
+    out[kRowSc + i] = sc_i;
+    k2 += sc_i * sc_i;
+    out[kRowLight + i] = R[i] * sc.shade.light_dir[0] + R[3 + i] * sc.shade.light_dir[1] + R[6 + i] * sc.shade.light_dir[2];
+  }
+  out[kRowK] = k2;
+  out[41] = out[42] = out[43] = 0.0;
 }
 
 // The ray caster's arithmetic type.  F = float is the product's (the reference's depth image IS a float32 z-buffer read back
@@ -199,6 +229,10 @@ template <> struct RenderNum<float> {
 // rays that graze the outline may fall on the other side of it by round-off (as between any two ways of writing the test).
 // One wavefront per (environment, hull); lanes take planes, then edges; ballots compact the survivors into the view record.
 // The record's rows are written in the ray caster's type F (worked out in double here: d - n . o is a difference of metres).
+// A front plane's row is m = n / (d - n . o): the INVERSE of the depth at which a ray of direction ld meets the plane is m . ld,
+// and the entry depth of a ray inside the cone -- the largest of the planes' depths -- is 1 / min (m . ld): three multiply-adds
+// and a minimum per plane and ray, one division per ray (round 3 kept (n, d - n . o) and spent two comparisons, a multiplication
+// and now and then a division per plane).
 __device__ __forceinline__ double plane_no(const double* q, const double* lo) {
   return fma(-q[2], lo[2], fma(-q[1], lo[1], fma(-q[0], lo[0], q[3])));  // d - n . o, one rounding order everywhere it is needed
 }
@@ -234,10 +268,11 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
   const double* planes = sc.planes + 4 * (size_t)sh.plane_adr;
   const uint64_t below = (1ull << lane) - 1ull;
   int nfront = 0;
+  double lastf[4] = {0, 0, 0, 0};  // the last front row written (every lane keeps a copy: the padding)
   for (int base = 0; base < sh.plane_num; base += 64) {
     const int i = base + lane;
     bool front = false;
-    double q[4] = {0, 0, 0, 0}, no = 0;
+    double q[4] = {0, 0, 0, 0}, no = 0, row[4] = {0, 0, 0, 0};
     if (i < sh.plane_num) {
       for (int k = 0; k < 4; ++k) q[k] = planes[4 * i + k];
       no = plane_no(q, lo);
@@ -246,13 +281,24 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
     const uint64_t m = __ballot(front);
     if (front) {
       F* r = rows + 4 * (size_t)(nfront + __popcll(m & below));
-      r[0] = (F)q[0]; r[1] = (F)q[1]; r[2] = (F)q[2]; r[3] = (F)no;
+      const double inv = 1.0 / (no < -1e-30 ? no : -1e-30);
+      row[0] = q[0] * inv; row[1] = q[1] * inv; row[2] = q[2] * inv; row[3] = no;
+      r[0] = (F)row[0]; r[1] = (F)row[1]; r[2] = (F)row[2]; r[3] = (F)row[3];
+    }
+    if (m) {
+      const int src = 63 - __clzll((long long)m);
+      for (int k = 0; k < 4; ++k) lastf[k] = __shfl(row[k], src);
     }
     nfront += __popcll(m);
   }
-  F* outline = rows + 4 * (size_t)sh.plane_num;
+  if (lane < kViewPad - 1) {
+    F* r = rows + 4 * (size_t)(nfront + lane);
+    for (int k = 0; k < 4; ++k) r[k] = (F)lastf[k];
+  }
+  F* outline = rows + 4 * (size_t)(sh.plane_num + kViewPad);
   const double ci[3] = {sh.centre[0] - lo[0], sh.centre[1] - lo[1], sh.centre[2] - lo[2]};
   int nout = 0;
+  double lasto[3] = {0, 0, 0};
   for (int base = 0; base < sh.edge_num; base += 64) {
     const int k = base + lane;
     bool sil = false;
@@ -278,7 +324,15 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
       F* o = outline + 4 * (size_t)r;
       o[0] = (F)mm[0]; o[1] = (F)mm[1]; o[2] = (F)mm[2]; o[3] = 0;
     }
+    if (m) {
+      const int src = 63 - __clzll((long long)m);
+      for (int c = 0; c < 3; ++c) lasto[c] = __shfl(mm[c], src);
+    }
     nout += __popcll(m);
+  }
+  if (lane < kViewPad - 1 && nout <= kMaxOutline) {
+    F* o = outline + 4 * (size_t)(nout + lane);
+    o[0] = (F)lasto[0]; o[1] = (F)lasto[1]; o[2] = (F)lasto[2]; o[3] = 0;
   }
   if (lane == 0) {
     int32_t* hdr = (int32_t*)out;
@@ -293,15 +347,43 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
 // COLOR: also rgb [n][H][W][3] uint8, rows bottom-up like the depth buffer: the colour of the shape the ray enters first,
 // lit by the headlight and the scene's directional light on the entry face's normal (flat shading; sc.colours).
 //
-// Work decomposition (round 4).  A wavefront renders 8 x 8 pixel sub-tiles, kSubPerWave of them one after the other; a
-// workgroup's four wavefronts share nothing but the environment's shape rows in LDS, staged ONCE per workgroup (round 3: a
-// workgroup per 16 x 16 tile -- the staging, three barriers, a cull by one wavefront while three waited and a ranking through
-// LDS were paid per 256 rays, a million times per 4096 x 256 x 256 batch, and cost more than the rays of a floor-only frame).
-// Everything per sub-tile is the wavefront's own: lane g culls shape g against the sub-tile's pyramid of rays (its sphere's
-// centre in the camera frame and its ranking key stay in the lane's registers for all sub-tiles), a ballot gives the
-// sub-tile's shapes, ranks come from lane reads, the g-th shape to visit from a ballot: no barrier and no LDS traffic.
-constexpr int kSubPerWave = 8;
-__host__ __device__ inline int render_wgs_per_env(int W, int H) { return (((W + 7) / 8) * ((H + 7) / 8) + 4 * kSubPerWave - 1) / (4 * kSubPerWave); }
+// Work decomposition (round 4).  The kernel is bound by the number of vector instructions it issues (rocprofv3: ~60 % VALU busy at
+// full occupancy, no memory stall to speak of), so the design is about instructions per ray.  A wavefront renders a 16 x 16 pixel
+// tile in four passes of 8 x 8 rays and kTilesPerWave tiles one after the other; a workgroup's four wavefronts share nothing but
+// the environment's shape rows in LDS, staged ONCE per workgroup.  Per tile, the wavefront's own business, no barrier: lane g culls
+// shape g against the tile's pyramid of rays, a ballot gives the tile's shapes, ranks come from lane reads, the next shape to visit
+// from a ballot -- ~100 instructions per 256 rays (round 3: a workgroup per tile, the cull by one wavefront while three waited at
+// one of three barriers; an intermediate version with the cull per 8 x 8 sub-tile spent a quarter of its instructions there).  Per
+// ray and shape nothing is computed that does not depend on the pixel: the camera's position and the ray's direction in the shape
+// frame come from k_shape_frames' row (two multiply-adds per component instead of two rotations), the sphere test runs in the
+// camera frame on three numbers, a hull's front planes cost three multiply-adds and a minimum each (k_hull_views).
+constexpr int kTilesPerWave = 2;
+__host__ __device__ inline int render_wgs_per_env(int W, int H) { return (((W + 15) / 16) * ((H + 15) / 16) + 4 * kTilesPerWave - 1) / (4 * kTilesPerWave); }
+
+// four rows of a view record (4 x (x, y, z, w) of F) through the constant address space: one 16-dword scalar load for floats, two for doubles
+template <class F> struct RowLoad;
+template <> struct RowLoad<float> {
+  typedef float V __attribute__((ext_vector_type(16)));
+  static __device__ __forceinline__ void load4(const float __attribute__((address_space(4)))* p, float (&q)[4][4]) {
+    const V v = *(const V __attribute__((address_space(4)))*)p;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) q[j / 4][j % 4] = v[j];
+  }
+};
+template <> struct RowLoad<double> {
+  typedef double V __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ void load4(const double __attribute__((address_space(4)))* p, double (&q)[4][4]) {
+    const V a = *(const V __attribute__((address_space(4)))*)p, b = *((const V __attribute__((address_space(4)))*)p + 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { q[j / 4][j % 4] = a[j]; q[2 + j / 4][j % 4] = b[j]; }
+  }
+};
+template <class F> __device__ __forceinline__ F render_min(F a, F b);
+template <> __device__ __forceinline__ float render_min<float>(float a, float b) { return __builtin_fminf(a, b); }
+template <> __device__ __forceinline__ double render_min<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <class F> __device__ __forceinline__ F render_max(F a, F b);
+template <> __device__ __forceinline__ float render_max<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <> __device__ __forceinline__ double render_max<double>(double a, double b) { return __builtin_fmax(a, b); }
 
 template <bool COLOR, class F>
 __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam cam, const double* wf, int n, float* depth_gl,
@@ -309,7 +391,7 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   using Num = RenderNum<F>;
   __shared__ F lw[(kMaxShapes + 1) * kShapeFrameDoubles];  // this environment's rows of wf (k_shape_frames)
   const int W = cam.width, H = cam.height;
-  const int sub_x = (W + 7) / 8, nsub = sub_x * ((H + 7) / 8);
+  const int tiles_x = (W + 15) / 16, ntile = tiles_x * ((H + 15) / 16);
   const int wgs_per_env = render_wgs_per_env(W, H);
   // Workgroups go to the chip's 8 XCDs round robin by their index.  The workgroups of one environment read the same shape frames
   // and hull views; numbered so that they follow each other on ONE XCD they find them in that XCD's L2, instead of all eight L2s
@@ -325,52 +407,46 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
   const int e = block / wgs_per_env, part = block % wgs_per_env;
   const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
   const F ty = (F)cam.tan_half_fovy, tx = (F)cam.tx, two_over_w = (F)cam.two_over_w, two_over_h = (F)cam.two_over_h;
-  const F znear = (F)sc.znear, zfar = (F)sc.zfar;
+  const F znear = (F)sc.znear, zfar = (F)sc.zfar, inv_near = (F)sc.inv_near;
   {
-    // (this environment's rows of wf, staged in LDS.  Reading them through scalar loads instead -- the row index is the
-    // wavefront's -- was tried and measured slower: the L2's latency)
     const int words = (sc.nshape + 1) * kShapeFrameDoubles;
     const double* src = wf + (size_t)e * words;
     for (int k = threadIdx.x; k < words; k += 256) lw[k] = (F)src[k];
     if (cam_pose && part == 0 && threadIdx.x < 12) cam_pose[(size_t)e * 12 + threadIdx.x] = src[sc.nshape * kShapeFrameDoubles + threadIdx.x];
   }
   __syncthreads();
-  const F* cR = lw + sc.nshape * kShapeFrameDoubles;
-  const F* cp = cR + 9;
   // lane g < nshape: shape g as the camera sees it -- its bounding sphere's centre in the camera frame, its radius, and the
-  // key the wavefront's visits are ordered by (below) -- the same for every sub-tile
+  // key the wavefront's visits are ordered by (below) -- the same for every tile
   const bool isshape = lane < sc.nshape;
   F sx = 0, sy = 0, sz = 0, sr = -1, key = (F)INFINITY;
   if (isshape) {
     const F* w = lw + lane * kShapeFrameDoubles;
     sr = w[15];
-    const F q[3] = {w[12] - cp[0], w[13] - cp[1], w[14] - cp[2]};
-    sx = cR[0] * q[0] + cR[3] * q[1] + cR[6] * q[2]; sy = cR[1] * q[0] + cR[4] * q[1] + cR[7] * q[2]; sz = cR[2] * q[0] + cR[5] * q[1] + cR[8] * q[2];
+    sx = w[kRowSc]; sy = w[kRowSc + 1]; sz = w[kRowSc + 2];
     // Front to back.  A ray only needs the NEAREST entry point, and the slab test below starts from t1 = best: a shape whose box
-    // begins behind the nearest hit so far costs three slabs instead of its ~100 face planes.  Seen from above an arm is a stack
-    // of links, each ray's pyramid crossing most of their boxes -- visited base first (index order) every one of them was walked
-    // in full.  The shapes are ranked by the view depth of their box's nearest point (planes first: one cheap test that bounds
-    // `best`).  Which shape is hit does not depend on the order (ties between two shapes' entry depths aside), the depth never does.
+    // begins behind the nearest hit so far costs three slabs instead of its outline and front planes.  Seen from above an arm is a
+    // stack of links, each ray's pyramid crossing most of their boxes.  The shapes are ranked by the view depth of their box's
+    // nearest point (planes first: one cheap test that bounds `best`).  Which shape is hit does not depend on the order (ties
+    // between two shapes' entry depths aside), the depth never does.
     if (sc.shapes[lane].shape == kShapePlane) key = -(F)INFINITY;
     else {
-      // view depth = -(z of the camera frame); the camera's z axis in world coordinates is the third column of cR
-      const F az[3] = {cR[2], cR[5], cR[8]};
+      // view depth = -(z of the camera frame); the camera's z axis in the shape frame is the third column of R' cR (stored negated)
       key = -sz;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) key -= w[16 + k] * fabs(az[0] * w[k] + az[1] * w[3 + k] + az[2] * w[6 + k]);
+      for (int k = 0; k < 3; ++k) key -= w[kRowSize + k] * fabs(w[kRowM + 3 * k + 2]);
     }
   }
-  const F o[3] = {cp[0], cp[1], cp[2]};
-  for (int si = 0; si < kSubPerWave; ++si) {
-    const int sub = (part * 4 + wave) * kSubPerWave + si;  // (the wavefront's: every test on it is a scalar branch)
-    if (sub >= nsub) break;
-    const int c0 = (sub % sub_x) * 8, r0 = (sub / sub_x) * 8;
-    // does shape g's bounding sphere reach into the pyramid of this sub-tile's rays (four planes through the camera, and the
-    // near plane)?  The sub-tile spans x in [xl, xr] (-z), y in [yb, yt] (-z)
+  const F* cR = lw + sc.nshape * kShapeFrameDoubles;
+  for (int ti = 0; ti < kTilesPerWave; ++ti) {
+    const int tile = (part * 4 + wave) * kTilesPerWave + ti;  // (the wavefront's: every test on it is a scalar branch)
+    if (tile >= ntile) break;
+    const int c0 = (tile % tiles_x) * 16, r0 = (tile / tiles_x) * 16;
+    // does shape g's bounding sphere reach into the pyramid of this tile's rays (four planes through the camera, and the near
+    // plane)?  The tile spans x in [xl, xr] (-z), y in [yb, yt] (-z)
     bool visible = isshape;
     if (isshape && sr >= 0) {
-      const F xl = (c0 * two_over_w - 1) * tx, xr = ((c0 + 8) * two_over_w - 1) * tx;
-      const F yb = (r0 * two_over_h - 1) * ty, yt = ((r0 + 8) * two_over_h - 1) * ty;
+      const F xl = (c0 * two_over_w - 1) * tx, xr = ((c0 + 16) * two_over_w - 1) * tx;
+      const F yb = (r0 * two_over_h - 1) * ty, yt = ((r0 + 16) * two_over_h - 1) * ty;
       // signed distance of the centre to each side plane of the pyramid, times that plane's normal's length: on the inner side,
       // or no further out than the radius (squares: no square root)
       const F r2 = sr * sr;
@@ -390,255 +466,250 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
         rank += (kg < key || (kg == key && g < lane)) ? 1 : 0;
       }
     }
-    const int col = c0 + (lane & 7);
-    const int row = r0 + (lane >> 3);  // row 0 = bottom of the image (OpenGL window coordinates)
-    const bool inimg = col < W && row < H;
-    // ray through the pixel centre, camera frame: (x, y, -1) scaled so that the ray parameter IS the view depth z
-    const F dc[3] = {((col + (F)0.5) * two_over_w - 1) * tx, ((row + (F)0.5) * two_over_h - 1) * ty, -1};
-    const F d[3] = {cR[0] * dc[0] + cR[1] * dc[1] + cR[2] * dc[2], cR[3] * dc[0] + cR[4] * dc[1] + cR[5] * dc[2], cR[6] * dc[0] + cR[7] * dc[1] + cR[8] * dc[2]};
-    const F dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    F best = zfar;
-    bool hit = false;
-    // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
-    int hit_g = -1, hit_face = 0;
-    bool hit_outline = false;  // hit_face counts the hull's FRONT planes (its view record), not its planes
-    for (int vi = 0; vi < nvisit; ++vi) {
-      // (the visit list is the wavefront's: saying so lets the shape's constants and its ~100 face planes come through scalar loads)
-      const int g = __ffsll((unsigned long long)__ballot(visible && rank == vi)) - 1;
-      const RenderShape& sh = sc.shapes[g];
-      const F* w = lw + g * kShapeFrameDoubles;  // R (9) p (3) sphere centre (3) radius, half extents (3), box centre (3)
-      if (w[15] >= 0) {
-        // bounding sphere: closest approach of the ray to the centre
-        const F oc[3] = {w[12] - o[0], w[13] - o[1], w[14] - o[2]};
-        const F b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
-        const F c2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
-        if (c2 * dd - b * b > w[15] * w[15] * dd) continue;
-      }
-      // ray in the shape's frame
-      const F* R = w;
-      const F om[3] = {o[0] - w[9], o[1] - w[10], o[2] - w[11]};
-      const F lo[3] = {R[0] * om[0] + R[3] * om[1] + R[6] * om[2], R[1] * om[0] + R[4] * om[1] + R[7] * om[2], R[2] * om[0] + R[5] * om[1] + R[8] * om[2]};
-      const F ld[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2], R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
-      const int shape = __builtin_amdgcn_readfirstlane(sh.shape);
-      F t0 = znear, t1 = best;
-      if (shape == kShapePlane) {
-        // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
-        if (!(ld[2] < 0 && lo[2] > 0)) continue;
-        const F t = -lo[2] * Num::rcp(ld[2]);
-        if (t >= t0 && t < t1) { best = t; hit = true; if (COLOR) { hit_g = g; hit_face = 0; } }
-        continue;
-      }
-      bool ok = true;
-      // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
-      // `size`): most rays that pass the sphere of an elongated link miss the link
-      int face = 0;
-      {
-        F b0 = t0, b1 = t1;
-        for (int k = 0; k < 3 && ok; ++k) {
-          const F lk = lo[k] - w[19 + k], sz_k = w[16 + k];
-          if (ld[k] == 0) { ok = fabs(lk) <= sz_k; continue; }
-          const F inv = Num::rcp(ld[k]);
-          F ta = (-sz_k - lk) * inv, tb = (sz_k - lk) * inv;
-          if (ta > tb) { const F x = ta; ta = tb; tb = x; }
-          if (COLOR && ta > b0) face = ld[k] > 0 ? 2 * k : 2 * k + 1;  // entered through the -k (even) or the +k (odd) face
-          b0 = ta > b0 ? ta : b0;
-          b1 = tb < b1 ? tb : b1;
-          ok = b0 <= b1;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+      const int col = c0 + (pass & 1) * 8 + (lane & 7);
+      const int row = r0 + (pass >> 1) * 8 + (lane >> 3);  // row 0 = bottom of the image (OpenGL window coordinates)
+      if (c0 + (pass & 1) * 8 >= W || r0 + (pass >> 1) * 8 >= H) continue;  // (the wavefront's)
+      const bool inimg = col < W && row < H;
+      // ray through the pixel centre, camera frame: (x, y, -1), so that the ray parameter IS the view depth z
+      const F x = ((col + (F)0.5) * two_over_w - 1) * tx, y = ((row + (F)0.5) * two_over_h - 1) * ty;
+      const F dd = x * x + y * y + 1;
+      F best = zfar;
+      bool hit = false;
+      // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
+      int hit_g = -1, hit_face = 0;
+      bool hit_outline = false;  // hit_face counts the hull's FRONT planes (its view record), not its planes
+      for (int vi = 0; vi < nvisit; ++vi) {
+        // (the visit list is the wavefront's: the shape's constants and its rows come through scalar loads)
+        const int g = __ffsll((unsigned long long)__ballot(visible && rank == vi)) - 1;
+        const RenderShape& sh = sc.shapes[g];
+        const F* w = lw + g * kShapeFrameDoubles;
+        if (w[15] >= 0) {
+          // bounding sphere: closest approach of the ray to the centre, in the camera frame
+          const F b = w[kRowSc] * x + w[kRowSc + 1] * y - w[kRowSc + 2];
+          if (w[kRowK] * dd > b * b) continue;
         }
-        if (shape == kShapeBox) { t0 = b0; t1 = b1; }
-      }
-      if (ok && shape == kShapeCapsule) {
-        // capsule about the shape frame's z axis: the ray's first point on the cylinder's wall between the caps, or on the outer
-        // half of a cap sphere -- the smallest of the (at most three) candidates, the surface being convex
-        const F r = w[16], hl = w[18] - w[16];
-        F te = (F)INFINITY;
-        const F a = ld[0] * ld[0] + ld[1] * ld[1], bq = lo[0] * ld[0] + lo[1] * ld[1], cq = lo[0] * lo[0] + lo[1] * lo[1] - r * r;
-        const F disc = bq * bq - a * cq;
-        if (a > 0 && disc >= 0) {
-          const F t = (-bq - sqrt(disc)) / a;
-          if (fabs(lo[2] + t * ld[2]) <= hl) te = t;
+        // ray in the shape's frame
+        const F lo[3] = {w[kRowLo], w[kRowLo + 1], w[kRowLo + 2]};
+        const F ld[3] = {w[kRowM] * x + w[kRowM + 1] * y + w[kRowM + 2], w[kRowM + 3] * x + w[kRowM + 4] * y + w[kRowM + 5],
+                         w[kRowM + 6] * x + w[kRowM + 7] * y + w[kRowM + 8]};
+        const int shape = __builtin_amdgcn_readfirstlane(sh.shape);
+        F t0 = znear, t1 = best;
+        if (shape == kShapePlane) {
+          // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
+          if (!(ld[2] < 0 && lo[2] > 0)) continue;
+          const F t = -lo[2] * Num::rcp(ld[2]);
+          if (t >= t0 && t < t1) { best = t; hit = true; if (COLOR) { hit_g = g; hit_face = 0; } }
+          continue;
         }
-        const F A = a + ld[2] * ld[2];
+        bool ok = true;
+        // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
+        // `size`): most rays that pass the sphere of an elongated link miss the link
+        int face = 0;
+        {
+          // (no branch: an axis the ray runs along -- ld_k = 0 -- gives infinite or undefined bounds, which the minima and maxima
+          // pass over exactly as the test |lk| <= size would)
+          F b0 = t0, b1 = t1;
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-          const F zc = side ? hl : -hl, oz = lo[2] - zc;
-          const F B = bq + oz * ld[2], Cq = cq + oz * oz;
-          const F ds = B * B - A * Cq;
-          if (ds >= 0) {
-            const F t = (-B - sqrt(ds)) / A;
-            const F zr = oz + t * ld[2];  // of the point, from the cap's centre
-            if ((side ? zr >= 0 : zr <= 0) && t < te) te = t;
+          for (int k = 0; k < 3; ++k) {
+            const F lk = lo[k] - w[kRowCen + k], sz_k = w[kRowSize + k];
+            const F inv = Num::rcp(ld[k]);
+            const F tp = (-sz_k - lk) * inv, tq = (sz_k - lk) * inv;
+            const F ta = render_min<F>(tp, tq), tb = render_max<F>(tp, tq);
+            if (COLOR && ta > b0) face = ld[k] > 0 ? 2 * k : 2 * k + 1;  // entered through the -k (even) or the +k (odd) face
+            b0 = render_max<F>(b0, ta);
+            b1 = render_min<F>(b1, tb);
           }
+          ok = b0 <= b1;
+          if (shape == kShapeBox) { t0 = b0; t1 = b1; }
         }
-        ok = te < (F)INFINITY;
-        t0 = ok && te > t0 ? te : t0;
-        ok = ok && te >= znear && t0 <= t1;
-      }
+        if (ok && shape == kShapeCapsule) {
+          // capsule about the shape frame's z axis: the ray's first point on the cylinder's wall between the caps, or on the outer
+          // half of a cap sphere -- the smallest of the (at most three) candidates, the surface being convex
+          const F r = w[kRowSize], hl = w[kRowSize + 2] - w[kRowSize];
+          F te = (F)INFINITY;
+          const F a = ld[0] * ld[0] + ld[1] * ld[1], bq = lo[0] * ld[0] + lo[1] * ld[1], cq = lo[0] * lo[0] + lo[1] * lo[1] - r * r;
+          const F disc = bq * bq - a * cq;
+          if (a > 0 && disc >= 0) {
+            const F t = (-bq - sqrt(disc)) / a;
+            if (fabs(lo[2] + t * ld[2]) <= hl) te = t;
+          }
+          const F A = a + ld[2] * ld[2];
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            const F zc = side ? hl : -hl, oz = lo[2] - zc;
+            const F B = bq + oz * ld[2], Cq = cq + oz * oz;
+            const F ds = B * B - A * Cq;
+            if (ds >= 0) {
+              const F t = (-B - sqrt(ds)) / A;
+              const F zr = oz + t * ld[2];  // of the point, from the cap's centre
+              if ((side ? zr >= 0 : zr <= 0) && t < te) te = t;
+            }
+          }
+          ok = te < (F)INFINITY;
+          t0 = ok && te > t0 ? te : t0;
+          ok = ok && te >= znear && t0 <= t1;
+        }
 #ifdef RCSH_RENDER_NOWALK
-      if (shape == kShapeHull) ok = false;  // (measurement: everything but the hulls' own tests)
+        if (shape == kShapeHull) ok = false;  // (measurement: everything but the hulls' own tests)
 #endif
 #ifdef RCSH_RENDER_FLOORONLY
-      ok = false;  // (measurement: the floor and the bookkeeping)
+        ok = false;  // (measurement: the floor and the bookkeeping)
 #endif
-      bool by_outline = false;
-      typedef const double __attribute__((address_space(4))) kdouble;
-      typedef const F __attribute__((address_space(4))) kF;
-      const int plane_num = __builtin_amdgcn_readfirstlane(sh.plane_num);
-      if (ok && shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
-        // the outline method (k_hull_views): this environment's record of the hull as the camera sees it.  The address is the
-        // wavefront's (e is the workgroup's, g the wavefront's): header and rows come through scalar loads.
-        kdouble* vw = (kdouble*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr);
-        typedef const int32_t __attribute__((address_space(4))) kint;
-        const int nfront = __builtin_amdgcn_readfirstlane(((kint*)vw)[0]), nout = __builtin_amdgcn_readfirstlane(((kint*)vw)[1]);
-        if (nout >= 0) {
-          by_outline = true;
-          kF* fr = (kF*)(vw + kViewHeaderDoubles);
-          kF* ol = fr + 4 * (size_t)plane_num;
-          // inside the cone over the outline?  (kRows rows per round -- their scalar loads go out together and the L2's latency is
-          // paid once per round; the tail round repeats the last row, which changes nothing)
-          constexpr int kRows = 4;
-          ok = ok && nfront > 0 && nout > 0;
-          for (int k = 0; k < nout && ok; k += kRows) {
-            F q[kRows][3];
+        bool by_outline = false;
+        typedef const double __attribute__((address_space(4))) kdouble;
+        typedef const F __attribute__((address_space(4))) kF;
+        const int plane_num = __builtin_amdgcn_readfirstlane(sh.plane_num);
+        if (ok && shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
+          // the outline method (k_hull_views): this environment's record of the hull as the camera sees it.  The address is the
+          // wavefront's (e is the workgroup's, g the wavefront's): header and rows come through scalar loads.
+          kdouble* vw = (kdouble*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr);
+          typedef const int32_t __attribute__((address_space(4))) kint;
+          const int nfront = __builtin_amdgcn_readfirstlane(((kint*)vw)[0]), nout = __builtin_amdgcn_readfirstlane(((kint*)vw)[1]);
+          if (nout >= 0) {
+            by_outline = true;
+            kF* fr = (kF*)(vw + kViewHeaderDoubles);
+            kF* ol = fr + 4 * (size_t)(plane_num + kViewPad);
+            // inside the cone over the outline?  Four rows a round: ONE scalar load (the lists are padded to multiples of four with
+            // copies of their last row), the smallest of the four products decides -- the vector unit takes the minimum, the scalar
+            // unit, which this kernel keeps busier than the vector unit, is asked once per round
+            ok = ok && nfront > 0 && nout > 0;
+            for (int k = 0; k < nout && ok; k += 4) {
+              F q[4][4];
+              RowLoad<F>::load4(ol + 4 * (size_t)k, q);
+              F smin = q[0][0] * ld[0] + q[0][1] * ld[1] + q[0][2] * ld[2];
 #pragma unroll
-            for (int j = 0; j < kRows; ++j) {
-              kF* src = ol + 4 * (size_t)(k + j < nout ? k + j : nout - 1);
-              q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2];
+              for (int j = 1; j < 4; ++j) smin = render_min<F>(smin, q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2]);
+              ok = smin >= 0;
             }
+            // entry depth: 1 / the smallest m . ld over the front planes (every one of them faces a ray inside the cone: m . ld > 0;
+            // a ray that grazes the outline may find one that does not -- it passes for a miss)
+            F umin = inv_near;
+            for (int k = 0; k < nfront && ok; k += 4) {
+              F q[4][4];
+              RowLoad<F>::load4(fr + 4 * (size_t)k, q);
 #pragma unroll
-            for (int j = 0; j < kRows; ++j) ok = ok && q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2] >= 0;
-          }
-          // entry depth: the largest no / nd over the front planes (nd < 0 on every one of them for a ray inside the cone)
-          for (int k = 0; k < nfront && ok; k += kRows) {
-            F q[kRows][4];
-#pragma unroll
-            for (int j = 0; j < kRows; ++j) {
-              kF* src = fr + 4 * (size_t)(k + j < nfront ? k + j : nfront - 1);
-              q[j][0] = src[0]; q[j][1] = src[1]; q[j][2] = src[2]; q[j][3] = src[3];
-            }
-#pragma unroll
-            for (int j = 0; j < kRows; ++j) {
-              const F nd = q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2];
-              if (nd < 0 && q[j][3] < t0 * nd) {  // (the gate of the plane walk below: only a plane that moves t0 pays for the division)
-                const F t = q[j][3] * Num::rcp(nd);
-                if (COLOR && t > t0) face = k + j < nfront ? k + j : nfront - 1;
-                t0 = t > t0 ? t : t0;
+              for (int j = 0; j < 4; ++j) {
+                const F u = q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2];
+                if (COLOR && u < umin) face = k + j < nfront ? k + j : nfront - 1;
+                umin = render_min<F>(umin, u);
               }
             }
+            ok = ok && umin > 0;
+            t0 = Num::rcp(umin);  // (no plane nearer than the near plane: t0 = znear, and the test below says no)
+            ok = ok && t0 <= t1;
           }
-          ok = ok && t0 <= t1;
         }
-      }
-      if (ok && shape == kShapeHull && !by_outline) {
-        // four planes per round: their loads go out together (a plane a round would wait for L1 every time); the tail
-        // round repeats the last plane, which changes nothing
-        // (the planes are read through the constant address space: the address is the wavefront's -- g is -- so they arrive by
-        // scalar loads, 32 bytes per plane per WAVEFRONT instead of per lane, and feed the multiply-adds from scalar registers)
-        kdouble* pl = (kdouble*)(sc.planes + 4 * (size_t)sh.plane_adr);
-        for (int k = 0; k < plane_num && ok; k += 4) {
-          F q4[4][4];
+        if (ok && shape == kShapeHull && !by_outline) {
+          // four planes per round: their loads go out together (a plane a round would wait for L1 every time); the tail
+          // round repeats the last plane, which changes nothing
+          // (the planes are read through the constant address space: the address is the wavefront's -- g is -- so they arrive by
+          // scalar loads, 32 bytes per plane per WAVEFRONT instead of per lane, and feed the multiply-adds from scalar registers)
+          kdouble* pl = (kdouble*)(sc.planes + 4 * (size_t)sh.plane_adr);
+          for (int k = 0; k < plane_num && ok; k += 4) {
+            F q4[4][4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            kdouble* src = pl + 4 * (size_t)(k + j < plane_num ? k + j : plane_num - 1);
-            q4[j][0] = (F)src[0]; q4[j][1] = (F)src[1]; q4[j][2] = (F)src[2]; q4[j][3] = (F)src[3];
+            for (int j = 0; j < 4; ++j) {
+              kdouble* src = pl + 4 * (size_t)(k + j < plane_num ? k + j : plane_num - 1);
+              q4[j][0] = (F)src[0]; q4[j][1] = (F)src[1]; q4[j][2] = (F)src[2]; q4[j][3] = (F)src[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const F nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
+              const F no = q4[j][3] - (q4[j][0] * lo[0] + q4[j][1] * lo[1] + q4[j][2] * lo[2]);  // >= 0: origin inside this half space
+              if (nd == 0) { ok = ok && no >= 0; continue; }
+              // Does this plane move the interval at all?  Entering planes (nd < 0) matter when t = no / nd > t0, leaving ones when
+              // t < t1 -- either way  no < bound * nd  -- and after the first few planes of a walk almost none does: the division
+              // is spent only on the planes that pass
+              const bool front = nd < 0;
+              const F bound = front ? t0 : t1;
+              if (no < bound * nd) {
+                const F t = no * Num::rcp(nd);
+                if (COLOR && front && t > t0) face = k + j < plane_num ? k + j : plane_num - 1;
+                if (front) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
+              }
+            }
+            ok = ok && t0 <= t1;
           }
+        }
+        // a camera inside a shape sees its inside faces culled (back faces): only entry points count
+        if (ok && t0 > znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; hit_outline = by_outline; } }
+      }
+      if (!inimg) continue;
+      // (1/near - 1/z) / (1/near - 1/far): a difference of reciprocals of very different sizes -- the encoding (a few instructions
+      // a ray) stays in double whatever the rays' type
+      const float dgl = hit ? (float)((sc.inv_near - fast_rcp((double)best)) * sc.inv_span) : 1.0f;
+      const size_t img = (size_t)e * W * H;
+      if (depth_gl) depth_gl[img + (size_t)row * W + col] = dgl;
+      if (depth_mm) {
+        // python/rcs/camera/sim.py:74-86 in float32: z = near / (1 - d (1 - near / far)); uint16(z * 1000)
+#pragma clang fp contract(off)  // numpy rounds the product before the subtraction: no fused multiply-add here
+        const float nearf = (float)sc.znear;
+        const float k1 = (float)(1.0 - sc.znear / sc.zfar);
+        const float prod = dgl * k1;
+        const float z = nearf / (1.0f - prod);
+        const float mm = z * 1000.0f;
+        depth_mm[img + (size_t)(H - 1 - row) * W + col] = (uint16_t)mm;
+      }
+      if constexpr (COLOR) {
+        if (!rgb) continue;
+        const RenderShade& L = sc.shade;
+        const F inv_len = Num::rsqrt(dd);
+        F out[3];
+        if (!hit) {
+          const F dz = cR[6] * x + cR[7] * y - cR[8];  // the ray's world z
+          const F f = (F)0.5 * (dz * inv_len + 1);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const F nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
-            const F no = q4[j][3] - (q4[j][0] * lo[0] + q4[j][1] * lo[1] + q4[j][2] * lo[2]);  // >= 0: origin inside this half space
-            if (nd == 0) { ok = ok && no >= 0; continue; }
-            // Does this plane move the interval at all?  Entering planes (nd < 0) matter when t = no / nd > t0, leaving ones when
-            // t < t1 -- either way  no < bound * nd  -- and after the first few planes of a walk almost none does: the division
-            // (a reciprocal seed and two Newton steps) is spent only on the planes that pass, a third of the instructions of the
-            // walk that three quarters of a bird's-eye frame consist of.
-            const bool front = nd < 0;
-            const F bound = front ? t0 : t1;
-            if (no < bound * nd) {
-              const F t = no * Num::rcp(nd);
-              if (COLOR && front && t > t0) face = k + j < plane_num ? k + j : plane_num - 1;
-              if (front) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
+          for (int c = 0; c < 3; ++c) out[c] = (F)L.sky2[c] + f * ((F)L.sky1[c] - (F)L.sky2[c]);
+        } else {
+          // shading in the SHAPE's frame: the face normal is given there, the ray's direction and the light's are in the row
+          const RenderShape& sh = sc.shapes[hit_g];
+          const RenderColour& col_g = sc.colours[hit_g];
+          const F* w = lw + hit_g * kShapeFrameDoubles;
+          const F ld[3] = {w[kRowM] * x + w[kRowM + 1] * y + w[kRowM + 2], w[kRowM + 3] * x + w[kRowM + 4] * y + w[kRowM + 5],
+                           w[kRowM + 6] * x + w[kRowM + 7] * y + w[kRowM + 8]};
+          const F hp[3] = {w[kRowLo] + best * ld[0], w[kRowLo + 1] + best * ld[1], w[kRowLo + 2] + best * ld[2]};  // the hit point
+          F nl[3] = {0, 0, 1};
+          if (sh.shape == kShapeBox) {
+            const int ax = hit_face >> 1;
+            const F sgn = (hit_face & 1) ? 1 : -1;
+            nl[0] = ax == 0 ? sgn : 0; nl[1] = ax == 1 ? sgn : 0; nl[2] = ax == 2 ? sgn : 0;
+          } else if (sh.shape == kShapeCapsule) {
+            // the hit point from the nearest point of the axis segment
+            const F hl = w[kRowSize + 2] - w[kRowSize];
+            nl[0] = hp[0]; nl[1] = hp[1];
+            nl[2] = hp[2] - (hp[2] > hl ? hl : (hp[2] < -hl ? -hl : hp[2]));
+          } else if (sh.shape == kShapeHull) {
+            if (hit_outline) {  // (a front row is n / (d - n . o) with d - n . o < 0: the normal points the other way)
+              const F* q = (const F*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles) + 4 * (size_t)hit_face;
+              nl[0] = -q[0]; nl[1] = -q[1]; nl[2] = -q[2];
+            } else {
+              const double* q = sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
+              nl[0] = (F)q[0]; nl[1] = (F)q[1]; nl[2] = (F)q[2];
             }
           }
-          ok = ok && t0 <= t1;
-        }
-      }
-      // a camera inside a shape sees its inside faces culled (back faces): only entry points count
-      if (ok && t0 > znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; hit_outline = by_outline; } }
-    }
-    if (!inimg) continue;
-    // (1/near - 1/z) / (1/near - 1/far): a difference of reciprocals of very different sizes -- the encoding (two instructions a
-    // ray) stays in double whatever the rays' type
-    const float dgl = hit ? (float)((sc.inv_near - fast_rcp((double)best)) * sc.inv_span) : 1.0f;
-    const size_t img = (size_t)e * W * H;
-    if (depth_gl) depth_gl[img + (size_t)row * W + col] = dgl;
-    if (depth_mm) {
-      // python/rcs/camera/sim.py:74-86 in float32: z = near / (1 - d (1 - near / far)); uint16(z * 1000)
-#pragma clang fp contract(off)  // numpy rounds the product before the subtraction: no fused multiply-add here
-      const float nearf = (float)sc.znear;
-      const float k1 = (float)(1.0 - sc.znear / sc.zfar);
-      const float prod = dgl * k1;
-      const float z = nearf / (1.0f - prod);
-      const float mm = z * 1000.0f;
-      depth_mm[img + (size_t)(H - 1 - row) * W + col] = (uint16_t)mm;
-    }
-    if constexpr (COLOR) {
-      if (!rgb) continue;
-      const RenderShade& L = sc.shade;
-      const F inv_len = Num::rsqrt(dd);
-      F out[3];
-      if (!hit) {
-        const F f = (F)0.5 * (d[2] * inv_len + 1);
+          const F nn = Num::rsqrt(nl[0] * nl[0] + nl[1] * nl[1] + nl[2] * nl[2]);
+          const F ndv = -(nl[0] * ld[0] + nl[1] * ld[1] + nl[2] * ld[2]) * nn * inv_len;                                  // towards the camera
+          const F ndl = -(nl[0] * w[kRowLight] + nl[1] * w[kRowLight + 1] + nl[2] * w[kRowLight + 2]) * nn;  // towards the light
+          const F kv = ndv > 0 ? ndv : 0, kl = ndl > 0 ? ndl : 0;
+          bool second = false;
+          if (col_g.checker != 0.0) {
+            const long long ix = (long long)floor(hp[0] / (F)col_g.square), iy = (long long)floor(hp[1] / (F)col_g.square);
+            second = ((ix + iy) & 1) != 0;
+          }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out[c] = (F)L.sky2[c] + f * ((F)L.sky1[c] - (F)L.sky2[c]);
-      } else {
-        const RenderShape& sh = sc.shapes[hit_g];
-        const RenderColour& col_g = sc.colours[hit_g];
-        const F* R = lw + hit_g * kShapeFrameDoubles;
-        F nl[3] = {0, 0, 1};
-        if (sh.shape == kShapeBox) {
-          nl[2] = 0;
-          nl[hit_face >> 1] = (hit_face & 1) ? 1 : -1;
-        } else if (sh.shape == kShapeCapsule) {
-          // the hit point from the nearest point of the axis segment
-          const F om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
-          const F hl = R[18] - R[16];
-          const F hz = R[2] * om[0] + R[5] * om[1] + R[8] * om[2];
-          nl[0] = R[0] * om[0] + R[3] * om[1] + R[6] * om[2];
-          nl[1] = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
-          nl[2] = hz - (hz > hl ? hl : (hz < -hl ? -hl : hz));
-        } else if (sh.shape == kShapeHull) {
-          if (hit_outline) {
-            const F* q = (const F*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles) + 4 * (size_t)hit_face;
-            nl[0] = q[0]; nl[1] = q[1]; nl[2] = q[2];
-          } else {
-            const double* q = sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
-            nl[0] = (F)q[0]; nl[1] = (F)q[1]; nl[2] = (F)q[2];
+          for (int c = 0; c < 3; ++c) {
+            const F base = (F)(second ? col_g.rgb2[c] : col_g.rgb[c]);
+            out[c] = base * ((F)L.ambient[c] + (F)L.head_diffuse[c] * kv + (F)L.light_diffuse[c] * kl);
           }
         }
-        const F nw[3] = {R[0] * nl[0] + R[1] * nl[1] + R[2] * nl[2], R[3] * nl[0] + R[4] * nl[1] + R[5] * nl[2], R[6] * nl[0] + R[7] * nl[1] + R[8] * nl[2]};
-        const F nn = Num::rsqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
-        const F ndv = -(nw[0] * d[0] + nw[1] * d[1] + nw[2] * d[2]) * nn * inv_len;       // towards the camera
-        const F ndl = -(nw[0] * (F)L.light_dir[0] + nw[1] * (F)L.light_dir[1] + nw[2] * (F)L.light_dir[2]) * nn;  // towards the light
-        const F kv = ndv > 0 ? ndv : 0, kl = ndl > 0 ? ndl : 0;
-        bool second = false;
-        if (col_g.checker != 0.0) {
-          // hit point in the shape frame
-          const F om[3] = {o[0] + best * d[0] - R[9], o[1] + best * d[1] - R[10], o[2] + best * d[2] - R[11]};
-          const F hx = R[0] * om[0] + R[3] * om[1] + R[6] * om[2], hy = R[1] * om[0] + R[4] * om[1] + R[7] * om[2];
-          const long long ix = (long long)floor(hx / (F)col_g.square), iy = (long long)floor(hy / (F)col_g.square);
-          second = ((ix + iy) & 1) != 0;
-        }
+        uint8_t* px = rgb + 3 * (img + (size_t)row * W + col);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const F base = (F)(second ? col_g.rgb2[c] : col_g.rgb[c]);
-          out[c] = base * ((F)L.ambient[c] + (F)L.head_diffuse[c] * kv + (F)L.light_diffuse[c] * kl);
+          const F v = out[c] < 0 ? 0 : (out[c] > 1 ? 1 : out[c]);
+          px[c] = (uint8_t)(v * 255 + (F)0.5);
         }
-      }
-      uint8_t* px = rgb + 3 * (img + (size_t)row * W + col);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const F v = out[c] < 0 ? 0 : (out[c] > 1 ? 1 : out[c]);
-        px[c] = (uint8_t)(v * 255 + (F)0.5);
       }
     }
   }
