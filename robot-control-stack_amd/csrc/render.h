@@ -347,9 +347,10 @@ __global__ void __launch_bounds__(64) k_hull_views(RenderScene sc, RenderCam cam
 // COLOR: also rgb [n][H][W][3] uint8, rows bottom-up like the depth buffer: the colour of the shape the ray enters first,
 // lit by the headlight and the scene's directional light on the entry face's normal (flat shading; sc.colours).
 //
-// Work decomposition (round 4).  The kernel is bound by the number of vector instructions it issues (rocprofv3: ~60 % VALU busy at
-// full occupancy, no memory stall to speak of), so the design is about instructions per ray.  A wavefront renders a 16 x 16 pixel
-// tile in four passes of 8 x 8 rays and kTilesPerWave tiles one after the other; a workgroup's four wavefronts share nothing but
+// Work decomposition (round 4).  The kernel is bound by the number of instructions it issues -- vector AND scalar (rocprofv3: before
+// the round's changes 2132 scalar against 1542 vector instructions per wavefront, no memory stall to speak of) -- so the design is
+// about instructions per ray.  A wavefront renders a 16 x 16 pixel tile in two passes of 16 x 8 rays, two rays a lane, and
+// kTilesPerWave tiles one after the other; a workgroup's four wavefronts share nothing but
 // the environment's shape rows in LDS, staged ONCE per workgroup.  Per tile, the wavefront's own business, no barrier: lane g culls
 // shape g against the tile's pyramid of rays, a ballot gives the tile's shapes, ranks come from lane reads, the next shape to visit
 // from a ballot -- ~100 instructions per 256 rays (round 3: a workgroup per tile, the cull by one wavefront while three waited at
@@ -389,6 +390,10 @@ template <bool COLOR, class F>
 __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam cam, const double* wf, int n, float* depth_gl,
                                                       uint16_t* depth_mm, double* cam_pose, uint8_t* rgb) {
   using Num = RenderNum<F>;
+  // A lane casts TWO rays, through horizontally adjacent pixels, as the halves of two-component vectors: in float the compiler
+  // turns their multiply-adds into packed instructions (v_pk_fma_f32: two rays' worth per issue), and whatever is the wavefront's
+  // or the lane's own -- loop control, scalar loads of rows, the shape's constants from LDS -- is paid once per 128 rays.
+  typedef F V2 __attribute__((ext_vector_type(2)));
   __shared__ F lw[(kMaxShapes + 1) * kShapeFrameDoubles];  // this environment's rows of wf (k_shape_frames)
   const int W = cam.width, H = cam.height;
   const int tiles_x = (W + 15) / 16, ntile = tiles_x * ((H + 15) / 16);
@@ -437,6 +442,8 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
     }
   }
   const F* cR = lw + sc.nshape * kShapeFrameDoubles;
+  auto min2 = [](V2 a, V2 b) { return V2{render_min<F>(a.x, b.x), render_min<F>(a.y, b.y)}; };
+  auto max2 = [](V2 a, V2 b) { return V2{render_max<F>(a.x, b.x), render_max<F>(a.y, b.y)}; };
   for (int ti = 0; ti < kTilesPerWave; ++ti) {
     const int tile = (part * 4 + wave) * kTilesPerWave + ti;  // (the wavefront's: every test on it is a scalar branch)
     if (tile >= ntile) break;
@@ -467,101 +474,115 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
       }
     }
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-      const int col = c0 + (pass & 1) * 8 + (lane & 7);
-      const int row = r0 + (pass >> 1) * 8 + (lane >> 3);  // row 0 = bottom of the image (OpenGL window coordinates)
-      if (c0 + (pass & 1) * 8 >= W || r0 + (pass >> 1) * 8 >= H) continue;  // (the wavefront's)
-      const bool inimg = col < W && row < H;
-      // ray through the pixel centre, camera frame: (x, y, -1), so that the ray parameter IS the view depth z
-      const F x = ((col + (F)0.5) * two_over_w - 1) * tx, y = ((row + (F)0.5) * two_over_h - 1) * ty;
-      const F dd = x * x + y * y + 1;
-      F best = zfar;
-      bool hit = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      // 16 x 8 pixels a pass: lane (i, j) of the 8 x 8 takes the pixels (c0 + 2 i, c0 + 2 i + 1) of row r0 + 8 pass + j
+      if (r0 + pass * 8 >= H) continue;  // (the wavefront's)
+      const int col = c0 + 2 * (lane & 7);
+      const int row = r0 + pass * 8 + (lane >> 3);  // row 0 = bottom of the image (OpenGL window coordinates)
+      const bool in_image[2] = {col < W && row < H, col + 1 < W && row < H};
+      // rays through the pixel centres, camera frame: (x, y, -1), so that the ray parameter IS the view depth z
+      const V2 x = {((col + (F)0.5) * two_over_w - 1) * tx, ((col + (F)1.5) * two_over_w - 1) * tx};
+      const F y = ((row + (F)0.5) * two_over_h - 1) * ty;
+      const V2 dd = x * x + (y * y + 1);
+      V2 best = {zfar, zfar};
+      bool hit[2] = {false, false};
       // COLOR: the shape entered first and where -- a plane index of a hull, axis (0..2) and side of a box
-      int hit_g = -1, hit_face = 0;
-      bool hit_outline = false;  // hit_face counts the hull's FRONT planes (its view record), not its planes
+      int hit_g[2] = {-1, -1}, hit_face[2] = {0, 0};
+      bool hit_outline[2] = {false, false};  // hit_face counts the hull's FRONT planes (its view record), not its planes
       for (int vi = 0; vi < nvisit; ++vi) {
         // (the visit list is the wavefront's: the shape's constants and its rows come through scalar loads)
         const int g = __ffsll((unsigned long long)__ballot(visible && rank == vi)) - 1;
         const RenderShape& sh = sc.shapes[g];
         const F* w = lw + g * kShapeFrameDoubles;
+        bool ok[2] = {true, true};
         if (w[15] >= 0) {
           // bounding sphere: closest approach of the ray to the centre, in the camera frame
-          const F b = w[kRowSc] * x + w[kRowSc + 1] * y - w[kRowSc + 2];
-          if (w[kRowK] * dd > b * b) continue;
+          const V2 b = w[kRowSc] * x + (w[kRowSc + 1] * y - w[kRowSc + 2]);
+          const V2 lhs = w[kRowK] * dd, rhs = b * b;
+          ok[0] = !(lhs.x > rhs.x); ok[1] = !(lhs.y > rhs.y);
+          if (!ok[0] && !ok[1]) continue;
         }
-        // ray in the shape's frame
+        // rays in the shape's frame (they share the origin, and whatever of the direction the row of pixels fixes)
         const F lo[3] = {w[kRowLo], w[kRowLo + 1], w[kRowLo + 2]};
-        const F ld[3] = {w[kRowM] * x + w[kRowM + 1] * y + w[kRowM + 2], w[kRowM + 3] * x + w[kRowM + 4] * y + w[kRowM + 5],
-                         w[kRowM + 6] * x + w[kRowM + 7] * y + w[kRowM + 8]};
+        const V2 ld[3] = {w[kRowM] * x + (w[kRowM + 1] * y + w[kRowM + 2]), w[kRowM + 3] * x + (w[kRowM + 4] * y + w[kRowM + 5]),
+                          w[kRowM + 6] * x + (w[kRowM + 7] * y + w[kRowM + 8])};
         const int shape = __builtin_amdgcn_readfirstlane(sh.shape);
-        F t0 = znear, t1 = best;
         if (shape == kShapePlane) {
           // the plane z = 0 of the shape frame, seen from above (MuJoCo draws planes one-sided)
-          if (!(ld[2] < 0 && lo[2] > 0)) continue;
-          const F t = -lo[2] * Num::rcp(ld[2]);
-          if (t >= t0 && t < t1) { best = t; hit = true; if (COLOR) { hit_g = g; hit_face = 0; } }
+          if (!(lo[2] > 0)) continue;
+          const V2 t = -lo[2] * V2{Num::rcp(ld[2].x), Num::rcp(ld[2].y)};
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            if (ok[c] && ld[2][c] < 0 && t[c] >= znear && t[c] < best[c]) { best[c] = t[c]; hit[c] = true; if (COLOR) { hit_g[c] = g; hit_face[c] = 0; } }
           continue;
         }
-        bool ok = true;
+        V2 t0 = {znear, znear}, t1 = best;
         // slabs of the box -- or, for a hull, of its bounding box first (centre = the bounding sphere's, half extents in
         // `size`): most rays that pass the sphere of an elongated link miss the link
-        int face = 0;
+        int face[2] = {0, 0};
         {
           // (no branch: an axis the ray runs along -- ld_k = 0 -- gives infinite or undefined bounds, which the minima and maxima
           // pass over exactly as the test |lk| <= size would)
-          F b0 = t0, b1 = t1;
+          V2 b0 = t0, b1 = t1;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const F lk = lo[k] - w[kRowCen + k], sz_k = w[kRowSize + k];
-            const F inv = Num::rcp(ld[k]);
-            const F tp = (-sz_k - lk) * inv, tq = (sz_k - lk) * inv;
-            const F ta = render_min<F>(tp, tq), tb = render_max<F>(tp, tq);
-            if (COLOR && ta > b0) face = ld[k] > 0 ? 2 * k : 2 * k + 1;  // entered through the -k (even) or the +k (odd) face
-            b0 = render_max<F>(b0, ta);
-            b1 = render_min<F>(b1, tb);
+            const V2 inv = {Num::rcp(ld[k].x), Num::rcp(ld[k].y)};
+            const V2 tp = (-sz_k - lk) * inv, tq = (sz_k - lk) * inv;
+            const V2 ta = min2(tp, tq), tb = max2(tp, tq);
+            if (COLOR) {
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                if (ta[c] > b0[c]) face[c] = ld[k][c] > 0 ? 2 * k : 2 * k + 1;  // entered through the -k (even) or the +k (odd) face
+            }
+            b0 = max2(b0, ta);
+            b1 = min2(b1, tb);
           }
-          ok = b0 <= b1;
+          ok[0] = ok[0] && b0.x <= b1.x; ok[1] = ok[1] && b0.y <= b1.y;
           if (shape == kShapeBox) { t0 = b0; t1 = b1; }
         }
-        if (ok && shape == kShapeCapsule) {
+        if ((ok[0] || ok[1]) && shape == kShapeCapsule) {
           // capsule about the shape frame's z axis: the ray's first point on the cylinder's wall between the caps, or on the outer
           // half of a cap sphere -- the smallest of the (at most three) candidates, the surface being convex
           const F r = w[kRowSize], hl = w[kRowSize + 2] - w[kRowSize];
-          F te = (F)INFINITY;
-          const F a = ld[0] * ld[0] + ld[1] * ld[1], bq = lo[0] * ld[0] + lo[1] * ld[1], cq = lo[0] * lo[0] + lo[1] * lo[1] - r * r;
-          const F disc = bq * bq - a * cq;
-          if (a > 0 && disc >= 0) {
-            const F t = (-bq - sqrt(disc)) / a;
-            if (fabs(lo[2] + t * ld[2]) <= hl) te = t;
-          }
-          const F A = a + ld[2] * ld[2];
 #pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            const F zc = side ? hl : -hl, oz = lo[2] - zc;
-            const F B = bq + oz * ld[2], Cq = cq + oz * oz;
-            const F ds = B * B - A * Cq;
-            if (ds >= 0) {
-              const F t = (-B - sqrt(ds)) / A;
-              const F zr = oz + t * ld[2];  // of the point, from the cap's centre
-              if ((side ? zr >= 0 : zr <= 0) && t < te) te = t;
+          for (int c = 0; c < 2; ++c) {
+            const F l0 = ld[0][c], l1 = ld[1][c], l2 = ld[2][c];
+            F te = (F)INFINITY;
+            const F a = l0 * l0 + l1 * l1, bq = lo[0] * l0 + lo[1] * l1, cq = lo[0] * lo[0] + lo[1] * lo[1] - r * r;
+            const F disc = bq * bq - a * cq;
+            if (a > 0 && disc >= 0) {
+              const F t = (-bq - sqrt(disc)) / a;
+              if (fabs(lo[2] + t * l2) <= hl) te = t;
             }
+            const F A = a + l2 * l2;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+              const F zc = side ? hl : -hl, oz = lo[2] - zc;
+              const F B = bq + oz * l2, Cq = cq + oz * oz;
+              const F ds = B * B - A * Cq;
+              if (ds >= 0) {
+                const F t = (-B - sqrt(ds)) / A;
+                const F zr = oz + t * l2;  // of the point, from the cap's centre
+                if ((side ? zr >= 0 : zr <= 0) && t < te) te = t;
+              }
+            }
+            bool okc = ok[c] && te < (F)INFINITY;
+            t0[c] = okc && te > t0[c] ? te : t0[c];
+            ok[c] = okc && te >= znear && t0[c] <= t1[c];
           }
-          ok = te < (F)INFINITY;
-          t0 = ok && te > t0 ? te : t0;
-          ok = ok && te >= znear && t0 <= t1;
         }
 #ifdef RCSH_RENDER_NOWALK
-        if (shape == kShapeHull) ok = false;  // (measurement: everything but the hulls' own tests)
+        if (shape == kShapeHull) ok[0] = ok[1] = false;  // (measurement: everything but the hulls' own tests)
 #endif
 #ifdef RCSH_RENDER_FLOORONLY
-        ok = false;  // (measurement: the floor and the bookkeeping)
+        ok[0] = ok[1] = false;  // (measurement: the floor and the bookkeeping)
 #endif
         bool by_outline = false;
         typedef const double __attribute__((address_space(4))) kdouble;
         typedef const F __attribute__((address_space(4))) kF;
         const int plane_num = __builtin_amdgcn_readfirstlane(sh.plane_num);
-        if (ok && shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
+        if ((ok[0] || ok[1]) && shape == kShapeHull && sc.views != nullptr && sh.edge_num > 0) {
           // the outline method (k_hull_views): this environment's record of the hull as the camera sees it.  The address is the
           // wavefront's (e is the workgroup's, g the wavefront's): header and rows come through scalar loads.
           kdouble* vw = (kdouble*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr);
@@ -573,41 +594,44 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
             kF* ol = fr + 4 * (size_t)(plane_num + kViewPad);
             // inside the cone over the outline?  Four rows a round: ONE scalar load (the lists are padded to multiples of four with
             // copies of their last row), the smallest of the four products decides -- the vector unit takes the minimum, the scalar
-            // unit, which this kernel keeps busier than the vector unit, is asked once per round
-            ok = ok && nfront > 0 && nout > 0;
-            for (int k = 0; k < nout && ok; k += 4) {
+            // unit, which this kernel keeps as busy as the vector unit, is asked once per round
+            if (!(nfront > 0 && nout > 0)) ok[0] = ok[1] = false;
+            for (int k = 0; k < nout && (ok[0] || ok[1]); k += 4) {
               F q[4][4];
               RowLoad<F>::load4(ol + 4 * (size_t)k, q);
-              F smin = q[0][0] * ld[0] + q[0][1] * ld[1] + q[0][2] * ld[2];
+              V2 smin = q[0][0] * ld[0] + q[0][1] * ld[1] + q[0][2] * ld[2];
 #pragma unroll
-              for (int j = 1; j < 4; ++j) smin = render_min<F>(smin, q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2]);
-              ok = smin >= 0;
+              for (int j = 1; j < 4; ++j) smin = min2(smin, q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2]);
+              ok[0] = ok[0] && smin.x >= 0; ok[1] = ok[1] && smin.y >= 0;
             }
             // entry depth: 1 / the smallest m . ld over the front planes (every one of them faces a ray inside the cone: m . ld > 0;
             // a ray that grazes the outline may find one that does not -- it passes for a miss)
-            F umin = inv_near;
-            for (int k = 0; k < nfront && ok; k += 4) {
+            V2 umin = {inv_near, inv_near};
+            for (int k = 0; k < nfront && (ok[0] || ok[1]); k += 4) {
               F q[4][4];
               RowLoad<F>::load4(fr + 4 * (size_t)k, q);
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const F u = q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2];
-                if (COLOR && u < umin) face = k + j < nfront ? k + j : nfront - 1;
-                umin = render_min<F>(umin, u);
+                const V2 u = q[j][0] * ld[0] + q[j][1] * ld[1] + q[j][2] * ld[2];
+                if (COLOR) {
+#pragma unroll
+                  for (int c = 0; c < 2; ++c)
+                    if (u[c] < umin[c]) face[c] = k + j < nfront ? k + j : nfront - 1;
+                }
+                umin = min2(umin, u);
               }
             }
-            ok = ok && umin > 0;
-            t0 = Num::rcp(umin);  // (no plane nearer than the near plane: t0 = znear, and the test below says no)
-            ok = ok && t0 <= t1;
+            t0 = V2{Num::rcp(umin.x), Num::rcp(umin.y)};  // (no plane nearer than the near plane: t0 = znear, and the test below says no)
+            ok[0] = ok[0] && umin.x > 0 && t0.x <= t1.x; ok[1] = ok[1] && umin.y > 0 && t0.y <= t1.y;
           }
         }
-        if (ok && shape == kShapeHull && !by_outline) {
+        if ((ok[0] || ok[1]) && shape == kShapeHull && !by_outline) {
           // four planes per round: their loads go out together (a plane a round would wait for L1 every time); the tail
           // round repeats the last plane, which changes nothing
           // (the planes are read through the constant address space: the address is the wavefront's -- g is -- so they arrive by
           // scalar loads, 32 bytes per plane per WAVEFRONT instead of per lane, and feed the multiply-adds from scalar registers)
           kdouble* pl = (kdouble*)(sc.planes + 4 * (size_t)sh.plane_adr);
-          for (int k = 0; k < plane_num && ok; k += 4) {
+          for (int k = 0; k < plane_num && (ok[0] || ok[1]); k += 4) {
             F q4[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -616,99 +640,110 @@ __global__ void __launch_bounds__(256) k_render_depth(RenderScene sc, RenderCam 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const F nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
+              const V2 nd = q4[j][0] * ld[0] + q4[j][1] * ld[1] + q4[j][2] * ld[2];
               const F no = q4[j][3] - (q4[j][0] * lo[0] + q4[j][1] * lo[1] + q4[j][2] * lo[2]);  // >= 0: origin inside this half space
-              if (nd == 0) { ok = ok && no >= 0; continue; }
-              // Does this plane move the interval at all?  Entering planes (nd < 0) matter when t = no / nd > t0, leaving ones when
-              // t < t1 -- either way  no < bound * nd  -- and after the first few planes of a walk almost none does: the division
-              // is spent only on the planes that pass
-              const bool front = nd < 0;
-              const F bound = front ? t0 : t1;
-              if (no < bound * nd) {
-                const F t = no * Num::rcp(nd);
-                if (COLOR && front && t > t0) face = k + j < plane_num ? k + j : plane_num - 1;
-                if (front) t0 = t > t0 ? t : t0; else t1 = t < t1 ? t : t1;
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                if (nd[c] == 0) { ok[c] = ok[c] && no >= 0; continue; }
+                // Does this plane move the interval at all?  Entering planes (nd < 0) matter when t = no / nd > t0, leaving ones when
+                // t < t1 -- either way  no < bound * nd  -- and after the first few planes of a walk almost none does: the division
+                // is spent only on the planes that pass
+                const bool front = nd[c] < 0;
+                const F bound = front ? t0[c] : t1[c];
+                if (no < bound * nd[c]) {
+                  const F t = no * Num::rcp(nd[c]);
+                  if (COLOR && front && t > t0[c]) face[c] = k + j < plane_num ? k + j : plane_num - 1;
+                  if (front) t0[c] = t > t0[c] ? t : t0[c]; else t1[c] = t < t1[c] ? t : t1[c];
+                }
               }
             }
-            ok = ok && t0 <= t1;
+            ok[0] = ok[0] && t0.x <= t1.x; ok[1] = ok[1] && t0.y <= t1.y;
           }
         }
         // a camera inside a shape sees its inside faces culled (back faces): only entry points count
-        if (ok && t0 > znear && t0 < best) { best = t0; hit = true; if (COLOR) { hit_g = g; hit_face = face; hit_outline = by_outline; } }
-      }
-      if (!inimg) continue;
-      // (1/near - 1/z) / (1/near - 1/far): a difference of reciprocals of very different sizes -- the encoding (a few instructions
-      // a ray) stays in double whatever the rays' type
-      const float dgl = hit ? (float)((sc.inv_near - fast_rcp((double)best)) * sc.inv_span) : 1.0f;
-      const size_t img = (size_t)e * W * H;
-      if (depth_gl) depth_gl[img + (size_t)row * W + col] = dgl;
-      if (depth_mm) {
-        // python/rcs/camera/sim.py:74-86 in float32: z = near / (1 - d (1 - near / far)); uint16(z * 1000)
-#pragma clang fp contract(off)  // numpy rounds the product before the subtraction: no fused multiply-add here
-        const float nearf = (float)sc.znear;
-        const float k1 = (float)(1.0 - sc.znear / sc.zfar);
-        const float prod = dgl * k1;
-        const float z = nearf / (1.0f - prod);
-        const float mm = z * 1000.0f;
-        depth_mm[img + (size_t)(H - 1 - row) * W + col] = (uint16_t)mm;
-      }
-      if constexpr (COLOR) {
-        if (!rgb) continue;
-        const RenderShade& L = sc.shade;
-        const F inv_len = Num::rsqrt(dd);
-        F out[3];
-        if (!hit) {
-          const F dz = cR[6] * x + cR[7] * y - cR[8];  // the ray's world z
-          const F f = (F)0.5 * (dz * inv_len + 1);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) out[c] = (F)L.sky2[c] + f * ((F)L.sky1[c] - (F)L.sky2[c]);
-        } else {
-          // shading in the SHAPE's frame: the face normal is given there, the ray's direction and the light's are in the row
-          const RenderShape& sh = sc.shapes[hit_g];
-          const RenderColour& col_g = sc.colours[hit_g];
-          const F* w = lw + hit_g * kShapeFrameDoubles;
-          const F ld[3] = {w[kRowM] * x + w[kRowM + 1] * y + w[kRowM + 2], w[kRowM + 3] * x + w[kRowM + 4] * y + w[kRowM + 5],
-                           w[kRowM + 6] * x + w[kRowM + 7] * y + w[kRowM + 8]};
-          const F hp[3] = {w[kRowLo] + best * ld[0], w[kRowLo + 1] + best * ld[1], w[kRowLo + 2] + best * ld[2]};  // the hit point
-          F nl[3] = {0, 0, 1};
-          if (sh.shape == kShapeBox) {
-            const int ax = hit_face >> 1;
-            const F sgn = (hit_face & 1) ? 1 : -1;
-            nl[0] = ax == 0 ? sgn : 0; nl[1] = ax == 1 ? sgn : 0; nl[2] = ax == 2 ? sgn : 0;
-          } else if (sh.shape == kShapeCapsule) {
-            // the hit point from the nearest point of the axis segment
-            const F hl = w[kRowSize + 2] - w[kRowSize];
-            nl[0] = hp[0]; nl[1] = hp[1];
-            nl[2] = hp[2] - (hp[2] > hl ? hl : (hp[2] < -hl ? -hl : hp[2]));
-          } else if (sh.shape == kShapeHull) {
-            if (hit_outline) {  // (a front row is n / (d - n . o) with d - n . o < 0: the normal points the other way)
-              const F* q = (const F*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles) + 4 * (size_t)hit_face;
-              nl[0] = -q[0]; nl[1] = -q[1]; nl[2] = -q[2];
-            } else {
-              const double* q = sc.planes + 4 * (size_t)(sh.plane_adr + hit_face);
-              nl[0] = (F)q[0]; nl[1] = (F)q[1]; nl[2] = (F)q[2];
+        for (int c = 0; c < 2; ++c)
+          if (ok[c] && t0[c] > znear && t0[c] < best[c]) { best[c] = t0[c]; hit[c] = true; if (COLOR) { hit_g[c] = g; hit_face[c] = face[c]; hit_outline[c] = by_outline; } }
+      }
+      const size_t img = (size_t)e * W * H;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (!in_image[c]) continue;
+        const int colc = col + c;
+        const F xc = x[c], bestc = best[c];
+        // (1/near - 1/z) / (1/near - 1/far): a difference of reciprocals of very different sizes -- the encoding (a few instructions
+        // a ray) stays in double whatever the rays' type
+        const float dgl = hit[c] ? (float)((sc.inv_near - fast_rcp((double)bestc)) * sc.inv_span) : 1.0f;
+        if (depth_gl) depth_gl[img + (size_t)row * W + colc] = dgl;
+        if (depth_mm) {
+          // python/rcs/camera/sim.py:74-86 in float32: z = near / (1 - d (1 - near / far)); uint16(z * 1000)
+#pragma clang fp contract(off)  // numpy rounds the product before the subtraction: no fused multiply-add here
+          const float nearf = (float)sc.znear;
+          const float k1 = (float)(1.0 - sc.znear / sc.zfar);
+          const float prod = dgl * k1;
+          const float z = nearf / (1.0f - prod);
+          const float mm = z * 1000.0f;
+          depth_mm[img + (size_t)(H - 1 - row) * W + colc] = (uint16_t)mm;
+        }
+        if constexpr (COLOR) {
+          if (!rgb) continue;
+          const RenderShade& L = sc.shade;
+          const F inv_len = Num::rsqrt(dd[c]);
+          F out[3];
+          if (!hit[c]) {
+            const F dz = cR[6] * xc + cR[7] * y - cR[8];  // the ray's world z
+            const F f = (F)0.5 * (dz * inv_len + 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out[k] = (F)L.sky2[k] + f * ((F)L.sky1[k] - (F)L.sky2[k]);
+          } else {
+            // shading in the SHAPE's frame: the face normal is given there, the ray's direction and the light's are in the row
+            const int hg = hit_g[c], hf = hit_face[c];
+            const RenderShape& sh = sc.shapes[hg];
+            const RenderColour& col_g = sc.colours[hg];
+            const F* w = lw + hg * kShapeFrameDoubles;
+            const F ld[3] = {w[kRowM] * xc + w[kRowM + 1] * y + w[kRowM + 2], w[kRowM + 3] * xc + w[kRowM + 4] * y + w[kRowM + 5],
+                             w[kRowM + 6] * xc + w[kRowM + 7] * y + w[kRowM + 8]};
+            const F hp[3] = {w[kRowLo] + bestc * ld[0], w[kRowLo + 1] + bestc * ld[1], w[kRowLo + 2] + bestc * ld[2]};  // the hit point
+            F nl[3] = {0, 0, 1};
+            if (sh.shape == kShapeBox) {
+              const int ax = hf >> 1;
+              const F sgn = (hf & 1) ? 1 : -1;
+              nl[0] = ax == 0 ? sgn : 0; nl[1] = ax == 1 ? sgn : 0; nl[2] = ax == 2 ? sgn : 0;
+            } else if (sh.shape == kShapeCapsule) {
+              // the hit point from the nearest point of the axis segment
+              const F hl = w[kRowSize + 2] - w[kRowSize];
+              nl[0] = hp[0]; nl[1] = hp[1];
+              nl[2] = hp[2] - (hp[2] > hl ? hl : (hp[2] < -hl ? -hl : hp[2]));
+            } else if (sh.shape == kShapeHull) {
+              if (hit_outline[c]) {  // (a front row is n / (d - n . o) with d - n . o < 0: the normal points the other way)
+                const F* q = (const F*)(sc.views + (size_t)e * sc.view_stride + sh.view_adr + kViewHeaderDoubles) + 4 * (size_t)hf;
+                nl[0] = -q[0]; nl[1] = -q[1]; nl[2] = -q[2];
+              } else {
+                const double* q = sc.planes + 4 * (size_t)(sh.plane_adr + hf);
+                nl[0] = (F)q[0]; nl[1] = (F)q[1]; nl[2] = (F)q[2];
+              }
+            }
+            const F nn = Num::rsqrt(nl[0] * nl[0] + nl[1] * nl[1] + nl[2] * nl[2]);
+            const F ndv = -(nl[0] * ld[0] + nl[1] * ld[1] + nl[2] * ld[2]) * nn * inv_len;                                  // towards the camera
+            const F ndl = -(nl[0] * w[kRowLight] + nl[1] * w[kRowLight + 1] + nl[2] * w[kRowLight + 2]) * nn;  // towards the light
+            const F kv = ndv > 0 ? ndv : 0, kl = ndl > 0 ? ndl : 0;
+            bool second = false;
+            if (col_g.checker != 0.0) {
+              const long long ix = (long long)floor(hp[0] / (F)col_g.square), iy = (long long)floor(hp[1] / (F)col_g.square);
+              second = ((ix + iy) & 1) != 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const F base = (F)(second ? col_g.rgb2[k] : col_g.rgb[k]);
+              out[k] = base * ((F)L.ambient[k] + (F)L.head_diffuse[k] * kv + (F)L.light_diffuse[k] * kl);
             }
           }
-          const F nn = Num::rsqrt(nl[0] * nl[0] + nl[1] * nl[1] + nl[2] * nl[2]);
-          const F ndv = -(nl[0] * ld[0] + nl[1] * ld[1] + nl[2] * ld[2]) * nn * inv_len;                                  // towards the camera
-          const F ndl = -(nl[0] * w[kRowLight] + nl[1] * w[kRowLight + 1] + nl[2] * w[kRowLight + 2]) * nn;  // towards the light
-          const F kv = ndv > 0 ? ndv : 0, kl = ndl > 0 ? ndl : 0;
-          bool second = false;
-          if (col_g.checker != 0.0) {
-            const long long ix = (long long)floor(hp[0] / (F)col_g.square), iy = (long long)floor(hp[1] / (F)col_g.square);
-            second = ((ix + iy) & 1) != 0;
-          }
+          uint8_t* px = rgb + 3 * (img + (size_t)row * W + colc);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const F base = (F)(second ? col_g.rgb2[c] : col_g.rgb[c]);
-            out[c] = base * ((F)L.ambient[c] + (F)L.head_diffuse[c] * kv + (F)L.light_diffuse[c] * kl);
+          for (int k = 0; k < 3; ++k) {
+            const F v = out[k] < 0 ? 0 : (out[k] > 1 ? 1 : out[k]);
+            px[k] = (uint8_t)(v * 255 + (F)0.5);
           }
-        }
-        uint8_t* px = rgb + 3 * (img + (size_t)row * W + col);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const F v = out[c] < 0 ? 0 : (out[c] > 1 ? 1 : out[c]);
-          px[c] = (uint8_t)(v * 255 + (F)0.5);
         }
       }
     }
