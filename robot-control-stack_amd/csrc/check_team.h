@@ -368,7 +368,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
           slot[0] = key; slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
         }
 #ifdef RCSH_CHECK_DEBUG
-        if (t == 0) atomicAdd(&g_chk_dbg[38], 1);  // full refinements
+        if (t == 0) { atomicAdd(&g_chk_dbg[38], 1); atomicAdd(&g_chk_dbg[s_hold >= 0 ? 41 : 40], 1); }  // full refinements: [40] no slot held the pair, [41] its direction failed
 #endif
       }
     }

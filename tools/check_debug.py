@@ -56,4 +56,4 @@ for t in range(300):
     if t % 50 == 49:
         L.rcsh_debug_check(out, 1)
         o = list(out)
-        print(f"steps {t-49}..{t}: per env-step: sphere survivors {o[32]/n/50:.2f}, pairs to narrow {o[33]/n/50:.2f}, full MPR {o[38]/n/50:.3f}, hits {o[1]/n/50:.4f}; per wave-step not prefetched {o[39]/(n/4)/50:.3f}")
+        print(f"steps {t-49}..{t}: per env-step: sphere survivors {o[32]/n/50:.2f}, pairs to narrow {o[33]/n/50:.2f}, full MPR {o[38]/n/50:.3f} (no slot {o[40]/n/50:.3f}, direction failed {o[41]/n/50:.3f}), hits {o[1]/n/50:.4f}; per wave-step not prefetched {o[39]/(n/4)/50:.3f}")
