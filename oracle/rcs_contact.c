@@ -745,6 +745,10 @@ void orc_collide(const orc_model* m, orc_data* d) {
     }
   }
   d->coupled = m->resolve_contacts && robot_contacts > 0;
+  for (int i = 0; i < d->ncon; i++)
+    if ((d->contact[i].geom[0] < m->ngeom && m->geom_type[d->contact[i].geom[0]] != 0) || (d->contact[i].geom[1] < m->ngeom && m->geom_type[d->contact[i].geom[1]] != 0))
+      d->pen_seen = fmax(d->pen_seen, -d->contact[i].dist);
+  for (int i = 0; i < d->nself; i++) d->pen_seen = fmax(d->pen_seen, d->self_depth[i]);
   g_frames = 0;
 }
 

@@ -221,6 +221,7 @@ typedef struct orc_data {
   int sep_pair[ORC_MAXSEP][2];
   double sep_dir[ORC_MAXSEP][3];
   double self_depth[ORC_MAXSELF]; /* penetration depth of self contact i (MPR) */
+  double pen_seen; /* test support: the deepest penetration of a robot geom (floor / box / self) any collision pass has seen since the caller zeroed it */
   orc_box_data box;
 } orc_data;
 

@@ -107,7 +107,7 @@ class OrcData(C.Structure):
         ("efc_R", D * MAXEFC), ("efc_mu", D * MAXEFC),
         ("qfrc_constraint", D * NVT), ("solver_niter", I), ("noslip_niter", I), ("contact_geom", I * 2 * MAXCON),
         ("contact", OrcContact * MAXCON), ("coupled", I), ("nself", I), ("self_geom", I * 2 * MAXSELF),
-        ("sep_n", I), ("sep_pair", I * 2 * 8), ("sep_dir", D * 3 * 8), ("self_depth", D * MAXSELF),
+        ("sep_n", I), ("sep_pair", I * 2 * 8), ("sep_dir", D * 3 * 8), ("self_depth", D * MAXSELF), ("pen_seen", D),
         ("box", OrcBoxData),
     ]
 

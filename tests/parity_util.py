@@ -1404,10 +1404,17 @@ def oracle_contacts_at_current_qpos(osim, touch=1e-9):
 
 def run_headline_contact_check(n_envs=64, n_steps=1000, seed=0, chunk=50):
     """The headline workload (fr3_empty_world, JOINTS, relative +-5 deg LAST_STEP actions, async 17 substeps, NO resets) run for
-    BASELINE.md's rollout length against the oracle with contacts RESOLVED, as MuJoCo resolves them.  Per env-step the oracle's
-    collision pass on the final position says whether the environment is in contact; the kernel's sticky info["contact_unresolved"]
-    must come on in exactly that step.  Until then an environment must match the oracle to round-off; after that the two differ
-    by construction (the oracle stops on the floor, the lean kernel does not) and only the flag is compared."""
+    BASELINE.md's rollout length against TWO oracle instances per environment:
+
+    * one with contacts RESOLVED, as MuJoCo resolves them: its collision passes -- every substep's -- say in which env-step the
+      environment first touches anything (`first_event`); until then the kernel must match it to round-off, afterwards the two differ by
+      construction (the oracle stops on the floor, the lean kernel does not);
+    * one that, like the lean kernel, resolves nothing: it follows the kernel's trajectory for the whole rollout, and its collision
+      pass on the position an env-step ENDS on is exactly what the kernels' end-of-launch check evaluates: the kernel's sticky
+      info["contact_unresolved"] must come on in exactly the env-step in which that pass first reports a contact (`first_boundary`).
+
+    What the end-of-launch check cannot see is a contact that begins and ends inside one launch (a graze of a few substeps, sub-millimetre
+    in this workload): `first_event < first_boundary` in those environments, counted in `transient_before_flag`."""
     import rcs_oracle as O
 
     venv = make_vec_env(n_envs, True)
@@ -1417,35 +1424,50 @@ def run_headline_contact_check(n_envs=64, n_steps=1000, seed=0, chunk=50):
         oenvs = make_oracle_envs(n_envs, True)
     finally:
         O.DEFAULT_RESOLVE_CONTACTS = saved
+    lean = make_oracle_envs(n_envs, True)
     joints, grip = synthetic_actions(n_envs, n_steps, seed)
     venv.reset()
-    for oe in oenvs:
+    for oe in oenvs + lean:
         oe.reset()
-    first_oracle = np.full(n_envs, -1)
+    first_event = np.full(n_envs, -1)
+    first_boundary = np.full(n_envs, -1)
     first_kernel = np.full(n_envs, -1)
-    rep = {"max_abs_qpos_unflagged": 0.0, "max_abs_qvel_unflagged": 0.0, "flag_mismatch_steps": 0, "kinds": {}}
+    rep = {"max_abs_qpos_unflagged": 0.0, "max_abs_qvel_unflagged": 0.0, "max_abs_qpos_lean": 0.0, "flag_mismatch_steps": 0, "kinds": {}}
     for t in range(n_steps):
         _, _, _, _, info = venv.step({"joints": joints[t], "gripper": grip[t]})
         flagged = np.asarray(info["contact_unresolved"], dtype=bool)
         q, v = venv.sim.qpos, venv.sim.qvel
         for e, oe in enumerate(oenvs):
-            if first_oracle[e] >= 0:
-                continue  # (sticky on both sides; the trajectories have parted)
+            le = lean[e]
+            le.step({"joints": joints[t, e], "gripper": grip[t, e]})
+            rep["max_abs_qpos_lean"] = max(rep["max_abs_qpos_lean"], float(np.abs(q[e] - le.sim.qpos[: q.shape[1]]).max()))
+            if first_boundary[e] < 0:
+                ncon, nself = oracle_contacts_at_current_qpos(le.sim)
+                if ncon + nself > 0:
+                    first_boundary[e] = t
+                    rep["kinds"][e] = (ncon, nself)
+            if first_event[e] >= 0:
+                continue  # (the resolving oracle's trajectory may have parted from the kernel's)
+            oe.sim.s.d.pen_seen = 0.0
             oe.step({"joints": joints[t, e], "gripper": grip[t, e]})
             ncon, nself = oracle_contacts_at_current_qpos(oe.sim)
-            if ncon + nself > 0:
-                first_oracle[e] = t
-                rep["kinds"][e] = (ncon, nself)
+            if oe.sim.s.d.pen_seen > 1e-9 or ncon + nself > 0:
+                first_event[e] = t
             else:
                 rep["max_abs_qpos_unflagged"] = max(rep["max_abs_qpos_unflagged"], float(np.abs(q[e] - oe.sim.qpos[: q.shape[1]]).max()))
                 rep["max_abs_qvel_unflagged"] = max(rep["max_abs_qvel_unflagged"], float(np.abs(v[e] - oe.sim.qvel[: v.shape[1]]).max()))
         newly = flagged & (first_kernel < 0)
         first_kernel[newly] = t
-        rep["flag_mismatch_steps"] += int(((first_kernel >= 0) != (first_oracle >= 0)).sum())
-    rep["first_oracle"] = first_oracle
+        rep["flag_mismatch_steps"] += int(((first_kernel >= 0) != (first_boundary >= 0)).sum())
+    rep["first_oracle"] = first_boundary
+    rep["first_event"] = first_event
     rep["first_kernel"] = first_kernel
-    rep["flagged_oracle"] = int((first_oracle >= 0).sum())
+    rep["flagged_oracle"] = int((first_boundary >= 0).sum())
     rep["flagged_kernel"] = int((first_kernel >= 0).sum())
+    ev = np.where(first_event >= 0, first_event, n_steps + 1)
+    fk = np.where(first_kernel >= 0, first_kernel, n_steps + 1)
+    rep["flag_before_any_contact"] = int((fk < ev).sum())          # false positives: must be 0
+    rep["transient_before_flag"] = int((ev < fk).sum())           # contacts that began and ended inside a launch before the flag came on
     rep["sticky_accessor_equal"] = bool(np.array_equal(venv.sim.contact_unresolved(), first_kernel >= 0))
     venv.close()
     return rep

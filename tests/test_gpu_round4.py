@@ -87,16 +87,19 @@ def test_headline_no_contacts_is_a_checked_property_over_1000_steps():
     """Verdict r3, item 1: the headline's "no contacts" was a premise.  It is a checked property now: every stepping launch ends
     with an exact collision test of the position the next launch starts from (csrc/check_team.h) and raises the environment's
     sticky info["contact_unresolved"].  The headline workload for BASELINE.md's rollout length (1000 env-steps, no resets), 64
-    environments, against the oracle WITH contacts resolved: the flag comes on in exactly the env-step in which the oracle's
-    collision pass first reports a contact (floor or self) at the step's final position; until then positions agree to 1e-9 /
-    velocities to 1e-8; Sim.reset clears it."""
+    environments, against two oracle instances each (parity_util.run_headline_contact_check): the flag comes on in exactly the
+    env-step in which the collision pass on the step's final position first reports a contact (floor or self) -- never before the
+    contact-RESOLVING oracle has seen one --, until an environment's first contact it matches the resolving oracle to 1e-9 / 1e-8,
+    and for the whole rollout the oracle that resolves nothing; Sim.reset clears the flag.  What a test per launch cannot see -- a
+    graze that begins and ends inside one launch -- is counted (tools/contact_check_soak.py: 6 of 512 environments in 1000 steps)."""
     from parity_util import run_headline_contact_check
 
     rep = run_headline_contact_check(n_envs=64, n_steps=1000, seed=0)
     assert rep["flagged_oracle"] >= 3, rep  # (some environments do reach the floor / themselves within 1000 random steps)
     assert np.array_equal(rep["first_kernel"], rep["first_oracle"]), rep
-    assert rep["flag_mismatch_steps"] == 0 and rep["sticky_accessor_equal"], rep
-    assert rep["max_abs_qpos_unflagged"] < 1e-9 and rep["max_abs_qvel_unflagged"] < 1e-8, rep
+    assert rep["flag_mismatch_steps"] == 0 and rep["sticky_accessor_equal"] and rep["flag_before_any_contact"] == 0, rep
+    assert rep["max_abs_qpos_unflagged"] < 1e-9 and rep["max_abs_qvel_unflagged"] < 1e-8 and rep["max_abs_qpos_lean"] < 1e-9, rep
+    assert rep["transient_before_flag"] <= 2, rep
 
 
 def test_contact_unresolved_is_cleared_by_reset_and_can_switch_the_batch_to_resolving_kernels():
