@@ -530,7 +530,8 @@ RCSH_CONTACT_FN int dev_mpr(const Shape& A, const Shape& B, double* depth, doubl
 // Returns the class bits of the overlapping pairs of the calling lane's team.
 constexpr int kSelfStageVerts = 304;  // both hulls of a pair (host: build_self_pairs checks)
 constexpr int kSelfStage = 3 * kSelfStageVerts;
-constexpr int kSelfCache = 4 * 8;      // per team two remembered separating directions (pair index, direction)
+constexpr int kSelfSlots = 4;          // remembered separating directions per team (pair index, direction): a folded arm keeps three or four pairs near
+constexpr int kSelfCache = 4 * 4 * kSelfSlots;
 constexpr int kSelfTag = 2;            // which pair the stage holds
 constexpr int kMaxSelfPairs = 144;     // pairs whose bounding spheres the lean DET kernels keep in LDS (host: build_self_pairs)
 constexpr int kSelfSphereWords = 10;   // per pair: c0, c1, r0 + r1 (inflated by the rounding) as float, the two links, the joints between them
@@ -774,6 +775,9 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
     }
   }
   TEAM_MARK(40)
+#if defined(RCSH_SELF_SKIP) && RCSH_SELF_SKIP >= 2
+  smask = 0;  // (measurement: no box tests, no refinement)
+#endif
   if (__ballot(smask != 0)) { TEAM_COUNT(41) }
   // the oriented boxes of the spheres' survivors (a handful per environment): one per lane and round, so that the wavefront
   // runs the box test once or twice instead of in every iteration of the loop above
@@ -791,6 +795,9 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
     }
   }
   uint32_t mine = 0;
+#if defined(RCSH_SELF_SKIP) && RCSH_SELF_SKIP >= 1
+  cmask = 0;  // (measurement: no refinement)
+#endif
   TEAM_MARK(43)
   TEAM_COUNT(47)
   for (uint64_t pending = __ballot(cmask != 0); pending; pending = __ballot(cmask != 0)) {
@@ -835,14 +842,21 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
       // query along it settles the pair while it still separates.  (Whatever the slot holds, a direction with negative
       // support proves the hulls apart; anything else falls through to the full refinement.)
       TEAM_MARK(37)
-      double* slot = stage + kSelfStage + 8 * team + 4 * (pidx & 1);
+      // (the slot that holds this pair, else the one its index maps to.  Two slots a team thrashed once an arm had wandered into a folded
+      // pose -- step_until_convergence over 300 env-steps without a reset went from 3.6 to 6.0 ms per step, all of it full refinements of
+      // pairs whose direction had just been evicted)
+      double* slots = stage + kSelfStage + 4 * kSelfSlots * team;
+      int held = -1;
+#pragma unroll
+      for (int k = 0; k < kSelfSlots; ++k) held = slots[4 * k] == (double)pidx ? k : held;
+      double* slot = slots + 4 * (held >= 0 ? held : (pidx & (kSelfSlots - 1)));
       bool apart = false;
       double LR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       if (pr.l0 >= 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) LR[k] = F[12 * pr.l0 + k];
       }
-      if (slot[0] == (double)pidx) {
+      if (held >= 0) {
         const double dl[3] = {slot[1], slot[2], slot[3]};
         double dw[3];
         mulmv(LR, dl, dw);
