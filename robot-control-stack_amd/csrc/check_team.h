@@ -344,6 +344,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #pragma unroll
         for (int k = 0; k < 9; ++k) LR[k] = F[12 * a.link + k];
       }
+      double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};  // (a point of A - B)
       if (s_hold >= 0) {
         const double dl[3] = {slot[1], slot[2], slot[3]};
         double dw[3];
@@ -351,7 +352,22 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         MprPt s;
         mpr_support<true>(A, B, dw, s);
         apart = dot3(s.v, dw) < 0;  // the support of A - B along the remembered direction is still negative: apart
+        x0[0] = s.v[0]; x0[1] = s.v[1]; x0[2] = s.v[2];
       }
+#ifndef RCSH_NO_GILBERT
+      if (!apart) {
+        // a few support queries towards a separating direction before the full refinement (contact_team.h: gilbert_apart); the margin
+        // keeps its verdicts far from the nanometre the check calls contact
+        double dg[3], gap = 0.0;
+        if (gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap)) {
+          apart = true;
+          double dl[3];
+          mulTv(LR, dg, dl);
+          stage_fence();
+          slot[0] = key; slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
+        }
+      }
+#endif
       if (!apart && !(ck.pad & 8)) {
         double dir[3], depth = 0.0;
         if (mpr_penetration<true, kMprDepth>(A, B, &depth, dir, nullptr)) {

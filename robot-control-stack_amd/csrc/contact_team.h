@@ -363,6 +363,38 @@ RCSH_D void mpr_support(const Shape& a, const Shape& b, const double* dir, MprPt
   shape_support<TEAM>(b, nd, o.v2);
   for (int k = 0; k < 3; ++k) o.v[k] = o.v1[k] - o.v2[k];
 }
+// Gilbert's iteration for "are the two shapes apart": C = A - B is convex, and a unit direction d with the support of C along it
+// negative proves 0 outside C, the shapes at least that support's size apart.  From a point x of C: d = -x / |x| (towards the
+// origin); s = the support point of C along d; d . s < -margin: proven (dir, gap); else x moves to the point of the segment
+// [x, s] nearest the origin and the step repeats.  One support query a step, where a full refinement (MPR) costs ten to twenty --
+// and the direction it ends on has a larger gap than the one MPR stops at, so the remembered direction survives more motion and
+// the slack credited to the pair is larger.  Used as an accelerator only: a failure (touching, overlapping, or just slow -- the
+// iteration zigzags near contact) falls through to MPR, and `margin` keeps its verdicts away from the band of MPR's own tolerance.
+template <bool TEAM>
+RCSH_D bool gilbert_apart(const Shape& A, const Shape& B, const double* x0, int iters, double margin, double* dir, double* gap) {
+  double x[3] = {x0[0], x0[1], x0[2]};
+  for (int it = 0; it < iters; ++it) {
+    const double n2 = dot3(x, x);
+    if (!(n2 > 1e-16)) return false;
+    const double inv = 1.0 / sqrt(n2);
+    const double d[3] = {-x[0] * inv, -x[1] * inv, -x[2] * inv};
+    MprPt s;
+    mpr_support<TEAM>(A, B, d, s);
+    const double h = dot3(s.v, d);
+    if (h < -margin) {
+      dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2];
+      *gap = -h;
+      return true;
+    }
+    const double e[3] = {s.v[0] - x[0], s.v[1] - x[1], s.v[2] - x[2]};
+    const double ee = dot3(e, e);
+    if (!(ee > 1e-24)) return false;
+    double tt = -dot3(x, e) / ee;
+    tt = tt < 0 ? 0.0 : (tt > 1 ? 1.0 : tt);
+    x[0] += tt * e[0]; x[1] += tt * e[1]; x[2] += tt * e[2];
+  }
+  return false;
+}
 RCSH_D void portal_dir(const MprPt& p1, const MprPt& p2, const MprPt& p3, double* dir) {
   const double e1[3] = {p2.v[0] - p1.v[0], p2.v[1] - p1.v[1], p2.v[2] - p1.v[2]}, e2[3] = {p3.v[0] - p1.v[0], p3.v[1] - p1.v[1], p3.v[2] - p1.v[2]};
   cross3(e1, e2, dir);
@@ -856,6 +888,7 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
 #pragma unroll
         for (int k = 0; k < 9; ++k) LR[k] = F[12 * pr.l0 + k];
       }
+      double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};  // (a point of A - B)
       if (held >= 0) {
         const double dl[3] = {slot[1], slot[2], slot[3]};
         double dw[3];
@@ -865,9 +898,23 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
         const double along = dot3(q.v, dw);  // support of A - B along the (unit) direction: minus a lower bound of the distance
         apart = along < 0;
         if (apart && ss && t == t0) ss->due[team][pidx] += (float)(-along) * 0.999999f - 2e-5f;
+        x0[0] = q.v[0]; x0[1] = q.v[1]; x0[2] = q.v[2];
       }
       TEAM_MARK(38)
       if (apart) { TEAM_COUNT(39) }
+#ifndef RCSH_NO_GILBERT
+      if (!apart) {
+        // no remembered direction, or it separates no longer: a few support queries towards a better one before the full refinement
+        double dg[3], gap = 0.0;
+        if (gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap)) {
+          apart = true;
+          double dl[3];
+          mulTv(LR, dg, dl);
+          slot[0] = (double)pidx; slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
+          if (ss && t == t0) ss->due[team][pidx] += (float)gap * 0.999999f - 2e-5f;
+        }
+      }
+#endif
       if (!apart) {
         double dir[3];
         if (mpr_penetration<true, kMprOverlap>(A, B, nullptr, dir, nullptr)) mine |= (uint32_t)pr.cls;
