@@ -510,6 +510,9 @@ def main() -> None:
         total_env_steps = world * n * args.steps
         value = total_env_steps / elapsed
         algo_bytes = ALGO_BYTES_PER_ENV_STEP * env.n_envs  # (the timed kernel is the first sub-batch's when a rank hosts several)
+        if cam_out:  # (the depth frames the timed region writes: 2 bytes a pixel -- what the ray caster's roofline is about)
+            rw_, rh_ = (int(x) for x in args.resolution.split("x"))
+            algo_bytes += len(cam_out) * env.n_envs * rw_ * rh_ * 2
         achieved_gbs = algo_bytes / (kernel_ms * 1e-3) / 1e9
         substeps_per_launch = mean_sub * env.n_envs
         traffic = None

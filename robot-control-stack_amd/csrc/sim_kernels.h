@@ -975,7 +975,19 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
           }
         }
       }
-      if constexpr (DET) {
+      if constexpr (DET && !CON) {
+        // (flag-only launches: the lane publishes its link's frame and that is all that happens HERE -- the floor test and the pair
+        // test read the frames back after the substep: code in the middle of the substep, taken or not, shapes the register
+        // allocation of the whole loop)
+        if (!want_contacts) return;
+        if (t < T::NL) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) selfF[12 * t + k] = R[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) selfF[12 * t + 9 + k] = p[k];
+        }
+      }
+      if constexpr (DET && CON) {
         if (!want_contacts) return;
         uint32_t mine = 0;
         if (has_plane) {
@@ -1002,17 +1014,12 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
             for (int k = 0; k < 3; ++k) selfF[12 * t + 9 + k] = p[k];
           }
           stage_fence();  // (LDS traffic of one wavefront is ordered; the fence is for the compiler)
-          if constexpr (CON) {
-            // (frames and stage sit in the contact arena, which the contact phase may enter next: the pairs are tested here)
-            mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, !CON, sph, slack,
-                                         lp.ctab.self_lever, st.q(t < T::NL ? t : T::NL - 1));
-            stage_fence();
-          }
+          // (frames and stage sit in the contact arena, which the contact phase may enter next: the pairs are tested here)
+          mine |= self_collision_pairs(lp.ctab.geoms, lp.ctab.verts, lp.ctab.pairs, npair, selfAll, selfAll + kSelfF * kTeams, T::NL, team_due, !CON, sph, slack,
+                                       lp.ctab.self_lever, st.q(t < T::NL ? t : T::NL - 1));
+          stage_fence();
         }
-        // (without a contact phase the pair test waits until the substep is through -- below: a non-inlined call HERE, in the
-        // middle of the substep, has ~150 values to carry across it, which shapes the register allocation of the whole loop)
-        if constexpr (CON) hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
-        else det_mine = mine;
+        hit = (team_ballot(mine & 1u) ? 1u : 0u) | (team_ballot(mine & 2u) ? 2u : 0u);
       }
     }, [&]() -> bool {
       bool coupled = false;
@@ -1042,6 +1049,26 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     });
     if constexpr (DET && !CON) {
       if (want_contacts) {
+        stage_fence();  // (LDS traffic of one wavefront is ordered; the fence is for the compiler)
+        if (has_plane && t < T::NL) {
+          // the floor against the sample points of the lane's link, on the frame the position stage published
+          double R[9], p[3];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) R[k] = selfF[12 * t + k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) p[k] = selfF[12 * t + 9 + k];
+          const double* nrm = lc.plane_n;
+          const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
+                               R[2] * nrm[0] + R[5] * nrm[1] + R[8] * nrm[2]};
+          const double b = dot3(nrm, p) - lc.plane_d;
+          const double* sph = lc.link_sphere[t];
+          if (b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < 0) {
+            for (int k = lc.link_adr[t]; k < lc.link_adr[t + 1]; ++k) {
+              const double* v = lc.xyzr + 4 * (size_t)k;
+              if (b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3] < 0) det_mine |= lc.cls[k];
+            }
+          }
+        }
         if (npair > 0) {
           // the robot's geoms against each other, on the frames the position stage published (and at the joint positions it saw:
           // the slack cache integrates joint motion between calls)
