@@ -591,6 +591,19 @@ static void self_collide(const orc_model* m, orc_data* d) {
       }
       if (orc_dbg_mpr_calls < 256) { orc_dbg_mpr_pairs[2 * orc_dbg_mpr_calls] = ga; orc_dbg_mpr_pairs[2 * orc_dbg_mpr_calls + 1] = gb; }
       orc_dbg_mpr_calls++;
+      if ((m->resolve_contacts & 2) && m->geom_type[ga] == 6 && m->geom_type[gb] == 6) {
+        /* two boxes (the fingertip pads of the two fingers): mjc_BoxBox, up to 8 points; the pair's place in d->contact is
+           settled by sort_contacts (MuJoCo: by body pair, then by geom) */
+        double bpos[24], bnrm[24], bdist[8];
+        const int nc = orc_box_box(p[ga], R[ga], m->geom_size[ga], p[gb], R[gb], m->geom_size[gb], bpos, bnrm, bdist);
+        if (nc == 0) continue;
+        const double mu = fmax(m->geom_friction[ga][0], m->geom_friction[gb][0]);
+        for (int c = 0; c < nc; c++) add_contact(d, ga, gb, m->geom_bodyid[ga], m->geom_bodyid[gb], bpos + 3 * c, bnrm + 3 * c, bdist[c], mu);
+        depth = 0;
+        for (int c = 0; c < nc; c++) depth = fmax(depth, -bdist[c]);
+        if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->self_depth[d->nself] = depth; d->nself++; }
+        continue;
+      }
       if (!mpr_penetration(&A, &B, &depth, dir, pos)) {
         if (dot3(dir, dir) > 0.5) { /* a unit separating direction came back */
           if (slot < 0) { slot = d->sep_n < ORC_MAXSEP ? d->sep_n++ : (ga + gb) % ORC_MAXSEP; d->sep_pair[slot][0] = ga; d->sep_pair[slot][1] = gb; }
@@ -599,8 +612,44 @@ static void self_collide(const orc_model* m, orc_data* d) {
         continue;
       }
       if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->self_depth[d->nself] = depth; d->nself++; }
+      /* self contacts resolved: the pair's contact (mjc_Convex: one point; normal from geom[0] to geom[1]) joins d->contact */
+      if (m->resolve_contacts & 2)
+        add_contact(d, ga, gb, m->geom_bodyid[ga], m->geom_bodyid[gb], pos, dir, -depth, fmax(m->geom_friction[ga][0], m->geom_friction[gb][0]));
     }
   }
+}
+
+/* mjData.contact is ordered by body pair (lower body id first; mj_collision walks the broad phase's sorted body pairs), within a
+   body pair by the geoms of the first body, then of the second.  The free box is the scene's last body and geom.  Contacts of one
+   geom pair keep the order their collider produced them in (stable sort). */
+static void contact_key(const orc_model* m, const orc_contact* c, long* key) {
+  long b[2], g[2];
+  for (int s = 0; s < 2; s++) {
+    b[s] = c->body[s] == ORC_BODY_BOX ? m->nbody : c->body[s];
+    g[s] = c->geom[s];
+  }
+  const int sw = b[0] > b[1] || (b[0] == b[1] && g[0] > g[1]);
+  key[0] = b[sw]; key[1] = b[!sw]; key[2] = g[sw]; key[3] = g[!sw];
+}
+static void sort_contacts(const orc_model* m, orc_data* d) {
+  for (int i = 1; i < d->ncon; i++) {
+    orc_contact c = d->contact[i];
+    long kc[4];
+    contact_key(m, &c, kc);
+    int j = i - 1;
+    for (; j >= 0; j--) {
+      long kj[4];
+      contact_key(m, &d->contact[j], kj);
+      int gt = 0;
+      for (int q = 0; q < 4; q++) {
+        if (kj[q] != kc[q]) { gt = kj[q] > kc[q]; break; }
+      }
+      if (!gt) break;
+      d->contact[j + 1] = d->contact[j];
+    }
+    d->contact[j + 1] = c;
+  }
+  for (int i = 0; i < d->ncon; i++) { d->contact_geom[i][0] = d->contact[i].geom[0]; d->contact_geom[i][1] = d->contact[i].geom[1]; }
 }
 
 void orc_collide(const orc_model* m, orc_data* d) {
@@ -609,10 +658,10 @@ void orc_collide(const orc_model* m, orc_data* d) {
   geom_frames fr;
   for (int g = 0; g < m->ngeom; g++) geom_frame_compute(m, d, g, fr.R[g], fr.p[g]);
   g_frames = &fr;
+  g_contact_cap = ORC_MAXCON;
   self_collide(m, d);
-  g_contact_cap = m->resolve_contacts ? 48 : ORC_MAXCON;
   const int gbox = m->ngeom;
-  int robot_contacts = 0;
+  int robot_contacts = d->ncon; /* (self contacts, where they are resolved) */
   /* ---- floor plane against the robot's geoms */
   for (int pg = 0; pg < m->ngeom; pg++) {
     if (m->geom_type[pg] != 0) continue;
@@ -744,6 +793,9 @@ void orc_collide(const orc_model* m, orc_data* d) {
       robot_contacts += d->ncon - before;
     }
   }
+  if (m->resolve_contacts & 2) sort_contacts(m, d);
+  /* where contacts are resolved the capacity is the HIP backend's (contact_types.h: kMaxCon): the tail of MuJoCo's order is dropped */
+  if (m->resolve_contacts && d->ncon > 48) d->ncon = 48;
   d->coupled = m->resolve_contacts && robot_contacts > 0;
   for (int i = 0; i < d->ncon; i++)
     if ((d->contact[i].geom[0] < m->ngeom && m->geom_type[d->contact[i].geom[0]] != 0) || (d->contact[i].geom[1] < m->ngeom && m->geom_type[d->contact[i].geom[1]] != 0))

@@ -414,3 +414,73 @@ def test_contact_forces_stay_in_their_friction_cones_and_balance_the_cube():
     weight = 9.81 * o.model.box.mass
     assert np.abs(o.box_qvel[:3]).max() < 1e-3 and np.abs(o.box_qvel[3:]).max() < 1e-2
     assert abs(total[2] - weight) < 2e-3 * weight and np.abs(total[:2]).max() < 2e-3 * weight, (total, weight)
+
+
+def _fr3_empty(resolve):
+    from rcs_amd.mjcf import compile_mjcf
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cm = compile_mjcf(os.path.join(os.path.dirname(PICKUP), "..", "fr3_empty_world", "scene.xml"))
+    arm = [f"fr3_joint{i}_0" for i in range(1, 8)]
+    o = O.Sim(cm, arm, arm, "attachment_site_0", "base_0", FR3_Q_HOME, None, "finger_joint1_0", "actuator8_0", resolve_contacts=resolve)
+    o.s.async_control = 1
+    o.reset(); o.robot_reset(); o.gripper_reset(); o.step(1)
+    return cm, o
+
+
+def test_self_contact_rows_stop_the_folded_arm():
+    """Round 5: contacts between two geoms of the robot carry constraint rows (resolve_contacts bit 1), as every entry of
+    mjData.contact does in mj_step2 (reference src/sim/sim.cpp:108-115).  Folded onto itself, the arm's finger comes to rest ON
+    link 1 instead of passing through it; a contact row's Jacobian is J = G (S_B - S_A), so the joints that carry BOTH bodies
+    (here joint 1) feel nothing of it; d->contact is ordered by body pair, then by geom."""
+    q = np.array([-0.48, -0.88, 0.0, -2.98, -0.3, 0.97, 0.79])
+    depth = {}
+    for mode in (1, 3):
+        cm, o = _fr3_empty(mode)
+        o.set_joint_position(q)
+        o.s.d.pen_seen = 0.0
+        frc0 = 0.0
+        for _ in range(60):
+            o.step(17)
+            frc0 = max(frc0, abs(o.s.d.qfrc_constraint[0]))
+        d = o.s.d
+        depth[mode] = float(d.pen_seen)
+        if mode == 3:
+            assert d.ncon >= 2 and d.coupled
+            geoms = [(cm.geom_names[d.contact[c].geom[0]], cm.geom_names[d.contact[c].geom[1]]) for c in range(d.ncon)]
+            assert ("fr3_link1_collision_0", "finger_0_right_0") in geoms, geoms
+            # every contact is between link 1's body and a body of the gripper; its normal force pushes (f >= 0)
+            b = cm.arrays["geom_bodyid"]
+            keys = []
+            for c in range(d.ncon):
+                con = d.contact[c]
+                bb = sorted((int(con.body[0]), int(con.body[1])))
+                gg = (con.geom[0], con.geom[1]) if con.body[0] <= con.body[1] else (con.geom[1], con.geom[0])
+                keys.append((bb[0], bb[1], gg[0], gg[1]))
+                assert bb[0] == b[cm.geom_names.index("fr3_link1_collision_0")] and bb[1] >= 10
+                assert d.efc_force[con.efc_address] >= 0.0
+            assert keys == sorted(keys), keys
+            assert frc0 < 1e-9, frc0  # joint 1 moves link 1 and the gripper alike: no row of these contacts has an entry there
+            assert np.abs(o.qpos[:7] - q).max() > 0.05  # the servo does not reach its target: link 1 is in the way
+            assert max(-d.contact[c].dist for c in range(d.ncon)) < 0.01
+        else:
+            assert d.ncon == 0 and d.nself > 0 and np.abs(o.qpos[:7] - q).max() < 1e-3  # detected, not resolved: it passes through
+    assert depth[3] < 0.02 < depth[1], depth
+
+
+def test_pad_against_pad_contacts_of_the_two_fingers():
+    """Two box geoms of the robot (the fingertip pads of the two fingers, which meet with a gap of exactly 0 when the gripper is
+    shut): mjc_BoxBox contacts, normal from the lower geom id to the higher, between the two finger bodies."""
+    cm, o = _fr3_empty(3)
+    d = o.s.d
+    assert d.ncon == 0 and d.nself == 0  # shut after the reset, gap 0.0: touching is not penetrating
+    d.qpos[7] = -1e-4
+    d.qpos[8] = -1e-4
+    O.lib().orc_step1(C.byref(o.model), C.byref(d))
+    assert d.ncon >= 5 and d.coupled
+    left, right = cm.body_names.index("left_finger_0"), cm.body_names.index("right_finger_0")
+    for c in range(d.ncon):
+        con = d.contact[c]
+        assert (con.body[0], con.body[1]) == (left, right) and con.geom[0] < con.geom[1]
+        assert cm.arrays["geom_type"][con.geom[0]] == 6 and cm.arrays["geom_type"][con.geom[1]] == 6
+        assert abs(con.dist + 2e-4) < 1e-9
