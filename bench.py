@@ -158,11 +158,15 @@ def main() -> None:
                     help="before the W warmup steps: this many milliseconds of the same env-step launches, then a reset -- the device needs "
                          "~12 ms of work to reach its operating clocks (profiles/README.md: a launch takes 128 us at first, 112.5 us from "
                          "there on), W = 5 steps are 0.6 ms.  0: off")
-    ap.add_argument("--contact-check-every", type=int, default=16,
-                    help="cadence of the end-of-launch check for contacts nobody resolves (csrc/check_team.h) inside the rollout: every this many "
-                         "env-steps, plus once on the final state after the clock stopped (config.contacts_seen counts what both found).  1: every "
-                         "env-step, the library's default and what the parity tests run (the check costs about as much as one to two of the "
-                         "step's 17 substeps); 0: off")
+    ap.add_argument("--contact-check-every", type=int, default=1,
+                    help="cadence of the lean launches' end-of-launch collision check (csrc/check_team.h): every this many env-steps.  1 (default, "
+                         "the library's default and what the parity tests run): every env-step.  Where robot contacts are resolved environment by "
+                         "environment (--contacts resolve, the default) the check IS what sends an environment to the contact-resolving kernel and "
+                         "the library runs it in every launch whatever this says; a larger cadence only applies to --contacts flag")
+    ap.add_argument("--contacts", default="resolve", choices=("resolve", "flag"),
+                    help="resolve (default, round 5): every contact of the robot's geoms -- floor and robot <-> robot -- is resolved, environment by "
+                         "environment (Sim(resolve_robot_contacts=None)); flag: the round-4 configuration -- lean kernels only, an environment in "
+                         "contact gets the sticky info.contact_unresolved and steps on unresolved")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL behind the C-ABI; the measured configuration) or host (the observation blocks through the rendezvous socket and host memory: "
                                                                "exercises the N > 1 code path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-baseline-worker", nargs=3, metavar=("ENVS", "STEPS", "SEED"))
@@ -255,7 +259,8 @@ def main() -> None:
         env = make_vec_env(n, async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank,
                            control_mode=ControlMode.CARTESIAN_TRPY, max_relative_movement=(0.2, float(np.deg2rad(45))), robot=args.robot)
     else:
-        env = make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=args.robot)
+        env = make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=args.robot,
+                           resolve_robot_contacts=None if args.contacts == "resolve" else False)
     # a rank that hosts several robot types (mixed, fewer than 4 ranks): one sub-batch per type, each on its handle's own
     # stream, so that the sub-batches' launches (each too small to fill the chip) run side by side
     envs = [env] + [make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=r)
@@ -490,10 +495,49 @@ def main() -> None:
     # Environments found in a contact the running configuration does not resolve, by the end of the timed region (the sticky flag
     # of the end-of-launch check, csrc/check_team.h; cleared by the reset before the W warmup steps).  The words "no contacts" in
     # config.workload are DERIVED from this count being zero on every rank.
-    contacts_seen = 0
+    contacts_seen = contacts_resolved = escalated_now = contacts_unresolved = 0
     for e_ in envs:
-        contacts_seen += int(e_.sim.contact_unresolved().sum())
+        unres = e_.sim.contact_unresolved()
+        now_, ever_ = e_.sim.contact_escalated()
+        contacts_unresolved += int(unres.sum())
+        contacts_resolved += int(ever_.sum())
+        escalated_now += int(now_.sum())
+        contacts_seen += int((unres | ever_ | now_).sum())
     contacts_seen = rdv.reduce(contacts_seen, sum)
+    contacts_resolved = rdv.reduce(contacts_resolved, sum)
+    contacts_unresolved = rdv.reduce(contacts_unresolved, sum)
+    escalated_now = rdv.reduce(escalated_now, sum)
+    resolving = bool(env.sim.resolve_robot_contacts)
+    # What a Gymnasium user calls: the same env-step through the host-array interface (rcsh_env_step: numpy in, numpy out, two PCIe
+    # copies and a stream synchronise per step) -- after the clock stopped, reported next to `value`, never as it.
+    value_host_api = None
+    headline_cfg = (args.mode == "async" and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed and not cam_out and world == 1)
+    if headline_cfg and rank == 0:
+        a_host = (np.random.default_rng(7).random((32, n, env.dof)) * 2 - 1) * MAX_JOINT_MOV
+        g_host = np.random.default_rng(8).random((32, n)).astype(np.float32)
+        for t_ in range(4):
+            env.step({"joints": a_host[t_], "gripper": g_host[t_]})
+        th = time.perf_counter()
+        for t_ in range(4, 32):
+            env.step({"joints": a_host[t_], "gripper": g_host[t_]})
+        value_host_api = n * 28 / (time.perf_counter() - th)
+    # ... and the round-4 configuration of the same workload (lean kernels only, contacts flagged, the check every 16th env-step): what
+    # resolving contacts environment by environment costs a rollout in which nothing touches anything
+    value_flag_only = None
+    if headline_cfg and rank == 0 and resolving:
+        env4 = make_vec_env(n, async_control=True, gripper=True, relative=True, device=local_rank, robot=args.robot, resolve_robot_contacts=False)
+        env4.sim.set_contact_check(16)
+        env4.reset_dev(obs.ptr, info.ptr, gw.ptr)
+        for t_ in range(min(T, 64)):
+            env4.step_dev(joints.at(t_), grip.at(t_), obs.ptr, info.ptr, gw.ptr, sub.ptr)
+        env4.reset_dev(obs.ptr, info.ptr, gw.ptr)
+        env4.sim.synchronize()
+        t4 = time.perf_counter()
+        for t_ in range(args.warmup, T):
+            env4.step_dev(joints.at(t_), grip.at(t_), obs.ptr, info.ptr, gw.ptr, sub.ptr)
+        env4.sim.synchronize()
+        value_flag_only = n * args.steps / (time.perf_counter() - t4)
+        env4.close()
     finite = bool(np.isfinite(obs_host).all())
     if task_out is not None:
         finite = finite and bool(np.isfinite(task_out.download()).all())
@@ -509,7 +553,20 @@ def main() -> None:
     if rank == 0:
         total_env_steps = world * n * args.steps
         value = total_env_steps / elapsed
-        algo_bytes = ALGO_BYTES_PER_ENV_STEP * env.n_envs  # (the timed kernel is the first sub-batch's when a rank hosts several)
+        # SURVEY 8(d)'s per-env-step figure for the configuration actually run (1292 B for the FR3 + hand in JOINTS mode): action in,
+        # physics state (qpos, qvel, warm start per dof + ctrl per actuator + time) and RCS state (target / previous / previous action per
+        # arm joint, 6 callback timestamps, 2 gripper widths, 8 flag bytes) read and written, observation and info out
+        nl_, nu_, narm_ = int(env.sim.model.nv), int(env.sim.model.nu), int(env.dof)
+        act_b = (6 if args.control == "cartesian" else narm_) * 8 + 4
+        phys_b = 2 * 8 * (3 * nl_ + nu_ + 1)
+        rcs_b = 2 * (8 * (3 * narm_ + 8) + 8)
+        per_env = act_b + phys_b + rcs_b + 8 * (14 + narm_) + 8
+        if args.control == "cartesian":
+            per_env += 2 * 8 * 20  # k_cartesian_team: ~20 f64 of state read and written
+        if getattr(env.sim.model, "free_bodies", []):
+            per_env += 2 * 8 * 41 + (9 * 8 if task_out is not None else 0)  # the free body's state r/w, the task's outputs
+        assert not (args.robot == "fr3" and args.control == "joints" and args.task == "none") or per_env == ALGO_BYTES_PER_ENV_STEP
+        algo_bytes = per_env * env.n_envs  # (the timed kernel is the first sub-batch's when a rank hosts several)
         if cam_out:  # (the depth frames the timed region writes: 2 bytes a pixel -- what the ray caster's roofline is about)
             rw_, rh_ = (int(x) for x in args.resolution.split("x"))
             algo_bytes += len(cam_out) * env.n_envs * rw_ * rh_ * 2
@@ -546,8 +603,10 @@ def main() -> None:
             "config": {
                 "workload": (f"{n}x fr3_empty_world batched JOINTS per GPU, relative +-5deg actions, gripper commanded, "
                              + ("robot contacts resolved, IK off" if args.robot == "xarm7_pick" else
-                                ("no contacts (checked: 0 environments touched the floor or themselves), IK off" if contacts_seen == 0 else
-                                 f"{contacts_seen} environments ran into a contact the lean kernels do not resolve (flagged: info.contact_unresolved), IK off"))
+                                ("no contacts (checked every env-step: 0 environments touched the floor or themselves), IK off" if contacts_seen == 0 else
+                                 (f"{contacts_seen} environments touched the floor or themselves: resolved, environment by environment "
+                                  f"({contacts_resolved} resolved, {escalated_now} on the contact-resolving kernel at the end), IK off" if resolving else
+                                  f"{contacts_seen} environments ran into a contact the lean kernels do not resolve (flagged: info.contact_unresolved), IK off")))
                              if args.control == "joints" else
                              f"{n}x fr3_empty_world batched CARTESIAN_TRPY per GPU, relative +-5cm / +-0.1rad actions -> CLIK, gripper commanded"
                              ).replace("fr3_empty_world", (mixed_label if mixed else SCENE_LABEL[args.robot]) if args.task == "none" else
@@ -562,8 +621,17 @@ def main() -> None:
                 "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"all-gather over {args.dist_backend}")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "contacts_seen": contacts_seen,
-                "contact_check": (f"exact collision check of every environment every {args.contact_check_every} env-steps inside the timed region"
-                                  if args.contact_check_every > 0 else "no check inside the timed region") + " + once on the final state (sticky flags, csrc/check_team.h)",
+                "contacts_resolved": contacts_resolved,
+                "contacts_unresolved": contacts_unresolved,
+                "escalated_at_end": escalated_now,
+                "contacts": ("resolved environment by environment (lean launch + contact-resolving launch per env-step; an environment found in contact at "
+                             "the end of a lean launch has that launch redone with its contacts resolved; csrc/sim_kernels.h RunOp::esc_role)" if resolving and not env.sim.model.free_bodies
+                             else ("resolved by the whole batch on the contact-resolving kernels" if resolving else "detected only (sticky info.contact_unresolved)")),
+                "contact_check": ("exact collision check of every lean-kernel environment at the end of EVERY env-step, inside the timed region (csrc/check_team.h)" if resolving and not env.sim.model.free_bodies else
+                                  (f"exact collision check of every environment every {args.contact_check_every} env-steps inside the timed region"
+                                   if args.contact_check_every > 0 else "no check inside the timed region") + " + once on the final state (sticky flags, csrc/check_team.h)"),
+                "value_host_api": value_host_api,  # the same env-step through rcsh_env_step (numpy in / out): what a Gymnasium user calls
+                "value_flag_only_check_every_16": value_flag_only,  # round 4's configuration of this workload (contacts flagged, not resolved)
                 "obs_finite": finite,
                 "value_without_exchange": no_exchange_value,
                 "exchange_ms": exchange_ms,  # the gather alone, back to back (after the clock stopped)
@@ -581,8 +649,13 @@ def main() -> None:
                 "traffic": traffic,
                 "traffic_source": (f"rocprofv3 FETCH_SIZE x 2 (gfx950: counts half the bytes of this access pattern, calibrated in profiles/r2_hbm_calib) + WRITE_SIZE, "
                                    f"separate PMC passes (profiles/{os.path.basename(tpath)}: {tj_extra.get('source', 'profiles/run_profile.sh')})") if traffic else None,
-                "kernel": "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
-                          + (" + free box" if args.task != "none" or args.robot in ("xarm7_box", "xarm7_pick") else ""),
+                "kernel": (("k_render_depth<false, float> (the ray caster: most of this region at this resolution, profiles/r4_render) + " if cam_out and
+                            int(args.resolution.split("x")[0]) * int(args.resolution.split("x")[1]) >= 128 * 128 else "")
+                           + "k_run_team" + f"<Topo<{env.dof},{'true' if env.gripper is not None else 'false'}>> (fused env-step)"
+                           + (" + free box" if args.task != "none" or args.robot in ("xarm7_box", "xarm7_pick") else "")
+                           + (" + k_cartesian_team (CLIK)" if args.control == "cartesian" else "")
+                           + (" [lean launch + contact-resolving launch over the escalated environments]" if resolving and not getattr(env.sim.model, "free_bodies", []) and args.robot == "fr3" else "")),
+                "algorithmic_bytes_per_env_step": per_env,
                 # what the region's event pair brackets: every launch of a step on the handle's stream, not the stepping kernel alone
                 "timed_region": "k_run_team" + (" + k_cartesian_team" if args.control == "cartesian" else "") + (" + the depth frames' kernels (k_link_frames, k_shape_frames, k_hull_views, k_render_depth)" if cam_out else "")
                                 + (" + the reset launches" if episode else "") + ", dispatch gaps included",

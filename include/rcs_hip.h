@@ -288,9 +288,19 @@ typedef struct rcsh_contact_options {
   double impratio, noslip_tolerance;
   int32_t noslip_iterations, cone_elliptic;
   double solref[2], solimp[5];
+  /* bit 0: contacts of the robot's geoms with the floor enter the constraint solve (0: detected only).  Bit 1 (round 5): so do
+   * contacts between two geoms of the robot -- mj_step2 resolves every entry of mjData.contact (reference src/sim/sim.cpp:108-115).
+   * Bit 2 (round 5): environment by environment -- a step is the lean launch over the environments that touch nothing plus the
+   * contact-resolving launch over the others; an environment whose geoms are found in contact at the end of a lean launch has
+   * that launch redone with its contacts resolved from their first substep (csrc/sim_kernels.h: RunOp::esc_role).  Without bit 2
+   * the whole batch runs on the contact-resolving kernel. */
   int32_t resolve_robot_contacts, reserved;
 } rcsh_contact_options;
 int rcsh_sim_set_contact_options(rcsh_sim* sim, const rcsh_contact_options* options);
+/* Per-environment escalation (rcsh_contact_options.resolve_robot_contacts bit 2), [N] flags each, either may be null:
+ * `now`: the environment is stepped by the contact-resolving kernel at present; `ever`: a contact of its robot geoms has been
+ * resolved since its last rcsh_sim_reset.  All zero where escalation is off. */
+int rcsh_sim_contact_escalated(rcsh_sim* sim, uint8_t* now, uint8_t* ever);
 /* [N] flags: the environment's geoms were found in a contact this configuration does not resolve -- robot <-> floor in scenes
  * that only detect contacts (the default without a free body), robot <-> robot everywhere -- at the end of a stepping launch,
  * since its last rcsh_sim_reset.  MuJoCo resolves every contact of d->contact in every mj_step2 (reference src/sim/sim.cpp:

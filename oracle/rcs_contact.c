@@ -550,6 +550,7 @@ static void list_pairs(const orc_model* m) {
   g_pairs_model = m;
   g_pairs_sum = pair_checksum(m);
 }
+#define SELF_TOUCH 1e-9 /* csrc/check_team.h: kCheckTouch */
 static void self_collide(const orc_model* m, orc_data* d) {
   d->nself = 0;
   if (orc_dbg_skip_self) return;
@@ -596,11 +597,16 @@ static void self_collide(const orc_model* m, orc_data* d) {
            settled by sort_contacts (MuJoCo: by body pair, then by geom) */
         double bpos[24], bnrm[24], bdist[8];
         const int nc = orc_box_box(p[ga], R[ga], m->geom_size[ga], p[gb], R[gb], m->geom_size[gb], bpos, bnrm, bdist);
-        if (nc == 0) continue;
         const double mu = fmax(m->geom_friction[ga][0], m->geom_friction[gb][0]);
-        for (int c = 0; c < nc; c++) add_contact(d, ga, gb, m->geom_bodyid[ga], m->geom_bodyid[gb], bpos + 3 * c, bnrm + 3 * c, bdist[c], mu);
         depth = 0;
-        for (int c = 0; c < nc; c++) depth = fmax(depth, -bdist[c]);
+        /* (SELF_TOUCH: a point that touches exactly is no contact -- MuJoCo gives rows to dist < 0 only, and the sign of a distance of
+           0.0 is round-off: the two fingers' pads meet with a gap of exactly 0 at finger qpos 0, i.e. after every reset) */
+        for (int c = 0; c < nc; c++) {
+          if (!(bdist[c] < -SELF_TOUCH)) continue;
+          add_contact(d, ga, gb, m->geom_bodyid[ga], m->geom_bodyid[gb], bpos + 3 * c, bnrm + 3 * c, bdist[c], mu);
+          depth = fmax(depth, -bdist[c]);
+        }
+        if (!(depth > 0)) continue;
         if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->self_depth[d->nself] = depth; d->nself++; }
         continue;
       }
@@ -613,7 +619,7 @@ static void self_collide(const orc_model* m, orc_data* d) {
       }
       if (d->nself < ORC_MAXSELF) { d->self_geom[d->nself][0] = ga; d->self_geom[d->nself][1] = gb; d->self_depth[d->nself] = depth; d->nself++; }
       /* self contacts resolved: the pair's contact (mjc_Convex: one point; normal from geom[0] to geom[1]) joins d->contact */
-      if (m->resolve_contacts & 2)
+      if ((m->resolve_contacts & 2) && depth > SELF_TOUCH)
         add_contact(d, ga, gb, m->geom_bodyid[ga], m->geom_bodyid[gb], pos, dir, -depth, fmax(m->geom_friction[ga][0], m->geom_friction[gb][0]));
     }
   }

@@ -365,10 +365,15 @@ def can_resolve_contacts(cm) -> bool:
     return bool(cm.njnt == 9 and cm.nu == 8 and cm.ngeom > 1)
 
 
-def resolves_contacts(cm) -> bool:
-    """The backend's DEFAULT: resolved in scenes with a free body (the pick-up task), detected only elsewhere (opt-in there:
-    rcs_amd.sim.Sim(..., resolve_robot_contacts=True))."""
-    return can_resolve_contacts(cm) and bool(getattr(cm, "free_bodies", []))
+def resolves_contacts(cm) -> int:
+    """The backend's DEFAULT (orc_model.resolve_contacts: bit 0 robot <-> floor / free body, bit 1 robot <-> robot): every contact
+    resolved, as MuJoCo does, in scenes without a free body (round 5: environment by environment on the HIP side); in scenes with
+    a free body robot <-> floor / free body (the whole batch on the contact-resolving kernels); nothing where the archetype cannot."""
+    if not can_resolve_contacts(cm):
+        return 0
+    if getattr(cm, "free_bodies", []):
+        return 1
+    return 3 if not np.any(np.asarray(cm.arrays["dof_frictionloss"]) > 0) else 0
 
 
 class Sim:
@@ -384,6 +389,8 @@ class Sim:
         self.cm = cm
         if resolve_contacts is None:
             resolve_contacts = resolves_contacts(cm) if DEFAULT_RESOLVE_CONTACTS is None else DEFAULT_RESOLVE_CONTACTS
+        if resolve_contacts is True:  # "everything the backend resolves in this scene" (rcs_amd.sim.Sim(resolve_robot_contacts=True))
+            resolve_contacts = resolves_contacts(cm) or 1
         self.model = make_model(cm, resolve_contacts)
         self.s = OrcSim()
         L.orc_sim_init(C.byref(self.s), C.byref(self.model))

@@ -108,14 +108,15 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 #pragma unroll
   for (int j = 0; j < kCheckPer; ++j) {
     const int i = t + kTeamLanes * j;
-    pf.ent[j] = ck.ent[i < npair ? i : 0];
+    // (a scene with a floor but no admitted geom pair -- a single collision geom -- has no entry table at all: advisor, round 4)
+    pf.ent[j] = npair > 0 ? ck.ent[i < npair ? i : 0] : CheckEntry{0u, 0.0f};
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int g = t + kTeamLanes * u;
     const double* src = reinterpret_cast<const double*>(&ck.geoms[g < ngeom ? g : 0]);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) pf.grec[u][k] = src[k];
+    for (int k = 0; k < 12; ++k) pf.grec[u][k] = ngeom > 0 && ck.geoms ? src[k] : 0.0;
   }
   // the guess: slot 0's key of the first live team, else its slot 1's (lanes 0 and 4 of the team hold them)
   const uint64_t lv = __ballot(live && t == 0);

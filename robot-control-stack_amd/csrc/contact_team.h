@@ -51,20 +51,31 @@ template <class T>
 struct ContactArena {
   static constexpr int NL = T::NL, NB = T::NL + 2, NV = T::NL + 6;
   static constexpr int kBox = NL, kWorld = NL + 1;
-  double F[NL][12];        // world frames of the links: R(9) p(3)
   double V[NB][6];         // spatial velocity of the bodies about the world origin [angular; linear]
   double U[NB][6];         // spatial acceleration for the current iterate
   double Up[NB][6];        // ... for the search direction
   double W[NB][6];         // wrench on every body
   double X[16], A0[16], P[16], Gd[16];
   double H[NV * (NV + 1) / 2];
-  double KA[2 * kMaxActive + 1][21];  // contact stiffness: (link a, box) pairs, (world, link a) pairs, (world, box)
+  static constexpr int kAcc = 2 * kMaxActive + 1 + kMaxPairs;
+  double KA[kAcc][21];     // contact stiffness: (link a, box) pairs, (world, link a) pairs, (world, box), (link, link) pairs
   double rec[kMaxCon][14]; // contact records (con_load): what the phases hand to each other
   double stage[64][8];     // scratch: clipping polygons of the box-box collider / per-contact wrenches / stiffness batches / Y
   int32_t cb[64];          // bodies of contact c: A | B << 8 | class bits << 16
-  int32_t cnt[64][2];      // per geom lane: plane contacts, box contacts
-  int32_t act[kMaxActive]; // links in contact
+  int32_t cnt[64][2];      // per geom lane (a geom table has at most kMaxCGeom <= 32 entries): plane contacts, box contacts; the upper half
+                           // holds the contacts' sort keys (keyp)
+  int32_t act[kMaxActive + 1]; // links in contact
+  int32_t pairs[kMaxPairs];    // pairs of links in contact with each other (self contact): la | lb << 8, la < lb
   int32_t nact, ncon, pad[2];
+  int32_t npairs, pad3;
+  // what the collision phase may use as scratch (nothing of the solve is alive then): V .. KA, contiguous
+  // ... except its last 12 NL doubles: the world frames of the links, R(9) p(3), which only the collision phase reads
+  static constexpr int kScratch = 4 * NB * 6 + 4 * 16 + NV * (NV + 1) / 2 + kAcc * 21 - 12 * NL;
+  __device__ double* scratch() { return &V[0][0]; }
+  __device__ double (*frames())[12] { return reinterpret_cast<double (*)[12]>(&V[0][0] + kScratch); }
+  // contact c's place in mjData.contact: body pair, geom pair, index within the pair (contact_collide's merge)
+  __device__ int32_t* keyp() { return &cnt[32][0]; }
+  static_assert(kMaxCGeom <= 32 && kMaxCon <= 64, "sort keys share the counters' array");
 };
 
 // is joint j an ancestor-or-self joint of link i?
@@ -1194,10 +1205,16 @@ RCSH_CONTACT_FN bool geom_level_near(const ContactGeom* geoms, int g0, int g1, c
 // Lane g tests collision geom g against the floor and the box; the contacts are compacted into MuJoCo's order -- (floor,
 // robot geoms) by geom, (floor, box), (robot geoms, box) by geom -- and left as records in ar.rec / ar.cb.
 // Returns bit 0: a robot geom is in contact; bits 8-9: contact classes of this position stage (arm / gripper collision geoms).
+// "In contact" for two geoms of the robot: penetrating by more than a nanometre (check_team.h: kCheckTouch, where the reason is
+// written down; the oracle's self_collide uses the same bar)
+constexpr double kSelfTouch = 1e-9;
+RCSH_D int contact_key(int b1, int b2, int g1, int g2, int k) { return (b1 << 23) | (b2 << 18) | (g1 << 13) | (g2 << 8) | k; }
+constexpr int kKeyBox = 31;  // the free box: the scene's last body, its last geom (reference assets/scenes/fr3_simple_pick_up/scene.xml:30-33)
 template <class T>
-RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg& b_, const LinkRec* links_, const StageTeam<T>& st_,
+RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTable& ck_, const BoxCfg& b_, const LinkRec* links_, const StageTeam<T>& st_,
                                          const double* bs_, ContactArena<T>& ar_) {
   const ContactTable& tab = *in_lds(&tab_);
+  const CheckTable& ck = *in_lds(&ck_);
   const BoxCfg& b = *in_lds(&b_);
   const LinkRec* links = in_lds(links_);
   const StageTeam<T> st{in_lds(st_.base)};
@@ -1206,6 +1223,8 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
   constexpr int NL = T::NL;
   constexpr int kBox = NL, kWorld = NL + 1;
   const int lane = wave_lane();
+  double (*arF)[12] = ar.frames();
+  int32_t* arkey = ar.keyp();
   TEAM_MARK(24)
   TEAM_COUNT(33)
   // ---- link frames at the pre-step configuration: lane i < NL walks the chain to link i
@@ -1237,9 +1256,9 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       mulmm(R, Rl, R);
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) ar.F[lane][k] = R[k];
+    for (int k = 0; k < 9; ++k) arF[lane][k] = R[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) ar.F[lane][9 + k] = p[k];
+    for (int k = 0; k < 3; ++k) arF[lane][9 + k] = p[k];
   }
   double bp[3], bR[9], bv[6];
   box_frame(bs, bp, bR, bv);
@@ -1255,9 +1274,9 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
     double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0};
     if (cg.link >= 0) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Rl[k] = ar.F[cg.link][k];
+      for (int k = 0; k < 9; ++k) Rl[k] = arF[cg.link][k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) pl[k] = ar.F[cg.link][9 + k];
+      for (int k = 0; k < 3; ++k) pl[k] = arF[cg.link][9 + k];
     }
     double gR[9], gp[3];
     mulmm(Rl, cg.rot, gR);
@@ -1353,9 +1372,9 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0};
       if (hg.link >= 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rl[k] = ar.F[hg.link][k];
+        for (int k = 0; k < 9; ++k) Rl[k] = arF[hg.link][k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pl[k] = ar.F[hg.link][9 + k];
+        for (int k = 0; k < 3; ++k) pl[k] = arF[hg.link][9 + k];
       }
       double gR[9], gp[3];
       mulmm(Rl, hg.rot, gR);
@@ -1440,12 +1459,12 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       ++nBP;
     }
   }
-  if (__ballot(nP > 0 || nB > 0) == 0) {  // nothing of the robot touches anything: the fast path keeps the step
+  const bool self_on = (b.resolve & 2) && ck.npair > 0;  // (wave-uniform) contacts between two geoms of the robot are resolved
+  if (!self_on && __ballot(nP > 0 || nB > 0) == 0) {  // nothing of the robot touches anything: the fast path keeps the step
     TEAM_MARK(25)
     return 0u;
   }
-  ar.cnt[lane][0] = nP;
-  ar.cnt[lane][1] = nB;
+  if (lane < 32) { ar.cnt[lane][0] = nP; ar.cnt[lane][1] = nB; }
   __syncthreads();
   TEAM_MARK(25)
   int offP = 0, offB = 0, totP = 0, totB = 0;
@@ -1454,11 +1473,133 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
     if (g < lane) { offP += a; offB += c; }
     totP += a; totB += c;
   }
-  const int robot_contacts = totP + totB;
   offB += totP + nBP;
-  int ncon = totP + nBP + totB;
-  const bool too_many_contacts = ncon > kMaxCon;  // (the tail of MuJoCo's contact order is dropped: flagged, kContactOverflow)
-  if (ncon > kMaxCon) ncon = kMaxCon;
+  const int nreg_all = totP + nBP + totB;
+  const int nreg = nreg_all > kMaxCon ? kMaxCon : nreg_all;
+  bool too_many_contacts = nreg_all > kMaxCon;  // (the tail of MuJoCo's contact order is dropped: flagged, kContactOverflow)
+  // ---- the robot's geoms against each other (round 5: self contact carries constraint rows, as every entry of mjData.contact does
+  // in mj_step2, reference src/sim/sim.cpp:108-115).  Oracle: self_collide (rcs_contact.c) -- bounding spheres, oriented boxes, then
+  // mjc_BoxBox for two boxes (the two fingers' pads), MPR for everything else: one point, normal from geom[0] to geom[1] (MuJoCo's
+  // order within a pair: by type, then by id -- the pair table's).  The contacts are parked at the END of the record area and
+  // merged into MuJoCo's order below.
+  int nS = 0;  // (wave-uniform)
+  if (self_on) {
+    static_assert(ContactArena<T>::kScratch >= 12 * kMaxCGeom && ContactArena<T>::kScratch >= 3 * 152, "world boxes of the geoms / one hull fit the scratch area");
+    double* wb = ar.scratch();
+    if (has_geom) {
+      double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0};
+      if (cg.link >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rl[k] = arF[cg.link][k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pl[k] = arF[cg.link][9 + k];
+      }
+      double lc[3], hh[3], off[3], cw[3], gR[9];
+      geom_obb(cg, lc, hh);
+      mulmv(cg.rot, lc, off);
+      off[0] += cg.pos[0]; off[1] += cg.pos[1]; off[2] += cg.pos[2];
+      mulmv(Rl, off, cw);
+      mulmm(Rl, cg.rot, gR);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wb[12 * lane + k] = cw[k] + pl[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wb[12 * lane + 3 + k] = gR[k];
+    }
+    __syncthreads();
+    uint32_t cm = 0;  // bit j: pair lane + 64 j survived the bounding tests
+    static_assert(kMaxCheckPairs <= 3 * 64, "three pairs per lane");
+    for (int j = 0; j < 3; ++j) {
+      const int i = lane + 64 * j;
+      if (i >= ck.npair) continue;
+      const CheckEntry en = ck.ent[i];
+      const int g0 = en.geoms & 0xff, g1 = (en.geoms >> 8) & 0xff;
+      double Ra[9], Rb[9], ca[3], cb_[3], ha[3], hb[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ca[k] = wb[12 * g0 + k]; cb_[k] = wb[12 * g1 + k]; ha[k] = ck.gh[g0][k]; hb[k] = ck.gh[g1][k]; }
+      const double dd[3] = {ca[0] - cb_[0], ca[1] - cb_[1], ca[2] - cb_[2]};
+      const double rs = en.rsum;
+      if (dot3(dd, dd) > rs * rs) continue;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { Ra[k] = wb[12 * g0 + 3 + k]; Rb[k] = wb[12 * g1 + 3 + k]; }
+      if (!obb_disjoint(Ra, ca, ha, Rb, cb_, hb)) cm |= 1u << j;
+    }
+    __syncthreads();  // (the world boxes are done with: the scratch area stages hulls from here on)
+    for (uint64_t pend = __ballot(cm != 0); pend; pend = __ballot(cm != 0)) {
+      const int src = __ffsll((long long)pend) - 1;  // wave-uniform
+      const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cm, src);
+      const int j = __ffs((int)sm) - 1;
+      if (lane == src) cm &= ~(1u << j);
+      const CheckEntry en = ck.ent[src + 64 * j];
+      const int g0 = en.geoms & 0xff, g1 = (en.geoms >> 8) & 0xff;
+      const ContactGeom& ga = tab.geoms[g0];
+      const ContactGeom& gb = tab.geoms[g1];
+      double Ra[9], pa[3], Rb[9], pb[3];
+      self_geom_world(ga, &arF[0][0], Ra, pa);
+      self_geom_world(gb, &arF[0][0], Rb, pb);
+      int nc = 0;
+      double spos[8][3], sn[3] = {0, 0, 0}, sdist[8];
+      if (ga.type == 6 && gb.type == 6) {
+        if (lane == 0) {
+          const int nb = dev_box_box(pa, Ra, ga.size, pb, Rb, gb.size, &spos[0][0], sn, sdist, &ar.stage[0][0]);
+          // (a point that touches exactly is no contact: kSelfTouch, oracle SELF_TOUCH)
+          for (int k = 0; k < nb; ++k) {
+            if (!(sdist[k] < -kSelfTouch)) continue;
+            spos[nc][0] = spos[k][0]; spos[nc][1] = spos[k][1]; spos[nc][2] = spos[k][2];
+            sdist[nc] = sdist[k];
+            ++nc;
+          }
+        }
+        nc = __builtin_amdgcn_readfirstlane(nc);
+      } else {
+        double* hA = ar.scratch();
+        double* hB = &ar.stage[0][0];
+        const int na3 = ga.type == 7 ? 3 * ga.vert_num : 0, nb3 = gb.type == 7 ? 3 * gb.vert_num : 0;
+        const double* va = tab.verts + 3 * (size_t)ga.vert_adr;
+        const double* vb = tab.verts + 3 * (size_t)gb.vert_adr;
+        for (int k = lane; k < na3; k += 64) hA[k] = va[k];
+        for (int k = lane; k < nb3; k += 64) hB[k] = vb[k];
+        __syncthreads();
+        Shape A = make_shape(ga.type == 7 ? 0 : ga.type == 6 ? 1 : 2, pa, Ra, ga.size, hA, ga.vert_num);
+        Shape B = make_shape(gb.type == 7 ? 0 : gb.type == 6 ? 1 : 2, pb, Rb, gb.size, hB, gb.vert_num);
+        if (ga.type == 7) { mulmv(Ra, ga.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
+        if (gb.type == 7) { mulmv(Rb, gb.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
+        // a few steps of Gilbert's iteration settle a pair that is clearly apart (links 5 and 7 wrap around the same wrist and pass the
+        // boxes' test in every pose); everything else goes through the full refinement, as in the oracle
+        const double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};
+        double dg[3], gap = 0.0, depth = 0.0;
+        if (!gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap)) nc = mpr_penetration<true>(A, B, &depth, sn, spos[0]);
+        if (!(depth > kSelfTouch)) nc = 0;
+        sdist[0] = -depth;
+        __syncthreads();  // (the stage is free again)
+      }
+      if (nc > 0 && lane == 0) {
+        int c2 = 0;  // what the collision callbacks make of the pair (rcs_hip.hip: list_geom_pairs)
+        if ((ga.cls | gb.cls) & 1) c2 |= 1;
+        if (!((ga.cls & 4) && (gb.cls & 4)) && ((ga.cls | gb.cls) & 16) && !(gb.cls & 8)) c2 |= 2;
+        const int la = ga.link >= 0 ? ga.link : kWorld, lb = gb.link >= 0 ? gb.link : kWorld;
+        const bool fwd = ga.body < gb.body;
+        for (int k = 0; k < nc; ++k) {
+          if (nreg + nS + k >= kMaxCon) break;
+          const int c = kMaxCon - 1 - (nS + k);
+          double* r = ar.rec[c];
+          r[0] = spos[k][0]; r[1] = spos[k][1]; r[2] = spos[k][2];
+          r[3] = sn[0]; r[4] = sn[1]; r[5] = sn[2];
+          r[6] = sdist[k];
+          r[7] = fmax(ga.mu, gb.mu);
+          r[8] = ga.invweight + gb.invweight;
+          ar.cb[c] = la | (lb << 8) | (c2 << 16);
+          arkey[c] = fwd ? contact_key(ga.body, gb.body, g0 + 1, g1 + 1, k) : contact_key(gb.body, ga.body, g1 + 1, g0 + 1, k);
+        }
+      }
+      if (nreg + nS + nc > kMaxCon) { too_many_contacts = true; nc = kMaxCon - nreg - nS; }
+      nS += nc;
+    }
+  }
+  const int robot_contacts = totP + totB + nS;
+  if (robot_contacts == 0) {  // nothing of the robot touches anything: the fast path keeps the step
+    return 0u;
+  }
+  int ncon = nreg + nS;
   if (has_geom) {
     const int lcode = cg.link >= 0 ? cg.link : kWorld;
     for (int k = 0; k < nP; ++k) {
@@ -1471,6 +1612,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       r[7] = fmax(tab.plane_mu, cg.mu);
       r[8] = cg.invweight;
       ar.cb[c] = kWorld | (lcode << 8) | (cg.cls << 16);
+      arkey[c] = contact_key(0, cg.body, 0, lane + 1, k);
     }
     for (int k = 0; k < nB; ++k) {
       const int c = offB + k;
@@ -1482,6 +1624,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       r[7] = fmax(b.geom_mu, cg.mu);
       r[8] = cg.invweight + b.inv_mass;
       ar.cb[c] = (boxfirst ? (kBox | (lcode << 8)) : (lcode | (kBox << 8))) | (cg.cls << 16);
+      arkey[c] = contact_key(cg.body, kKeyBox, lane + 1, kKeyBox, k);
     }
   }
   if (lane == 63) {
@@ -1495,11 +1638,33 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const BoxCfg&
       r[7] = b.fr;
       r[8] = b.inv_mass;
       ar.cb[c] = kWorld | (kBox << 8);
+      arkey[c] = contact_key(0, kKeyBox, 0, kKeyBox, k);
     }
     ar.ncon = ncon;
     ar.pad[0] = too_many_contacts ? 1 : 0;  // capacity overflow of this phase (contact_newton adds the links' share)
   }
   __syncthreads();
+  if (nS > 0) {
+    // merge: the self contacts parked at the end of the record area take their places in mjData.contact's order (by body pair,
+    // then by geom pair; the three groups written above are in that order among themselves).  Every contact through its lane's registers.
+    const int srcc = lane < nreg ? lane : kMaxCon - 1 - (lane - nreg);
+    double rr[9];
+    int cbv = 0, kv = 0, rank = 0;
+    if (lane < ncon) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) rr[k] = ar.rec[srcc][k];
+      cbv = ar.cb[srcc];
+      kv = arkey[srcc];
+      for (int c = 0; c < ncon; ++c) rank += arkey[c < nreg ? c : kMaxCon - 1 - (c - nreg)] < kv ? 1 : 0;
+    }
+    __syncthreads();
+    if (lane < ncon) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) ar.rec[rank][k] = rr[k];
+      ar.cb[rank] = cbv;
+    }
+    __syncthreads();
+  }
   // contact classes of this position stage (what the collision callbacks scan d->contact for).  SimGripper::collision_callback
   // ignores contacts between two finger geoms; none can occur here (no geom-geom pairs of the robot).
   int cls = 0;
@@ -1573,29 +1738,38 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     uint64_t first_of[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) first_of[l] = __ballot(myA == l || myB == l);
-    uint64_t taken = 0;  // contacts whose link is listed already
+    uint32_t listed = 0;  // links listed already (a self contact names two links)
     int na = 0;
     for (int k = 0; k < kMaxActive; ++k) {
       int best_l = -1, best_c = 64;
 #pragma unroll
       for (int l = 0; l < NL; ++l) {
-        const uint64_t m = first_of[l] & ~taken;
-        const int c0 = first_of[l] && !(first_of[l] & taken) ? __ffsll((long long)m) - 1 : 64;
+        const int c0 = first_of[l] && !((listed >> l) & 1u) ? __ffsll((long long)first_of[l]) - 1 : 64;
         if (c0 < best_c) { best_c = c0; best_l = l; }
       }
       if (best_l < 0) break;
-#pragma unroll
-      for (int l = 0; l < NL; ++l) taken |= l == best_l ? first_of[l] : 0ull;
+      listed |= 1u << best_l;
       if (lane == 0) ar.act[na] = best_l;
       ++na;
     }
+    // pairs of links in contact with each other (self contact): each gets a stiffness accumulator of its own
+    const int mycode = (myA < NL && myB < NL) ? ((myA < myB ? myA : myB) | ((myA < myB ? myB : myA) << 8)) : -1;
+    int np = 0;
+    bool pairs_over = false;
+    for (uint64_t rem = __ballot(mycode >= 0); rem;) {
+      const int code = __builtin_amdgcn_readlane(mycode, __ffsll((long long)rem) - 1);
+      if (np < kMaxPairs) { if (lane == 0) ar.pairs[np] = code; ++np; }
+      else pairs_over = true;
+      rem &= ~__ballot(mycode == code);
+    }
     if (lane == 0) {
       ar.nact = na;
+      ar.npairs = np;
       // more links in contact than the stiffness fold / the noslip slots hold: the rest keep their contact forces but drop out
       // of the Hessian and of the noslip update -- a different (slower, for noslip: incomplete) iteration than MuJoCo's: flagged
-      uint64_t left = 0;
+      bool left = pairs_over;
 #pragma unroll
-      for (int l = 0; l < NL; ++l) left |= first_of[l] & ~taken;
+      for (int l = 0; l < NL; ++l) left = left || (first_of[l] && !((listed >> l) & 1u));
       if (left) ar.pad[0] |= 2;
     }
   }
@@ -1728,23 +1902,33 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
   // what does not change over the iterations: the contacts of every body (the generalised force) and of every stiffness
   // accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
   const BodyMasks bmasks = body_masks<NL + 1>(c, lane);
-  uint64_t kmask = 0;
+  // ... and kAcc - kMaxPairs + p: the two links of ar.pairs[p] against each other
+  constexpr int kAcc = ContactArena<T>::kAcc;
+  static_assert(kAcc <= 18, "two accumulators per group of seven lanes");
+  const int npairs = ar.npairs;
+  uint64_t kmask = 0, kmask2 = 0;  // contacts of accumulator lane / 7, and of accumulator 9 + lane / 7
   {
     int slot = -1;
     if (c.on) {
-      const int lk = c.A < NL ? c.A : (c.B < NL ? c.B : -1);
-      const bool with_box = c.A == kBox || c.B == kBox;
-      if (lk < 0) slot = 2 * kMaxActive;
-      else {
-        int a = -1;
-        for (int k = 0; k < nact; ++k) if (ar.act[k] == lk) a = k;
-        slot = a < 0 ? -1 : (with_box ? a : kMaxActive + a);
+      if (c.A < NL && c.B < NL) {
+        const int code = (c.A < c.B ? c.A : c.B) | ((c.A < c.B ? c.B : c.A) << 8);
+        for (int q = 0; q < npairs; ++q) if (ar.pairs[q] == code) slot = 2 * kMaxActive + 1 + q;
+      } else {
+        const int lk = c.A < NL ? c.A : (c.B < NL ? c.B : -1);
+        const bool with_box = c.A == kBox || c.B == kBox;
+        if (lk < 0) slot = 2 * kMaxActive;
+        else {
+          int a = -1;
+          for (int k = 0; k < nact; ++k) if (ar.act[k] == lk) a = k;
+          slot = a < 0 ? -1 : (with_box ? a : kMaxActive + a);
+        }
       }
     }
 #pragma unroll
-    for (int a = 0; a < 2 * kMaxActive + 1; ++a) {
+    for (int a = 0; a < kAcc; ++a) {
       const uint64_t m = __ballot(slot == a);
       if (lane / 7 == a) kmask = m;
+      if (lane / 7 + 9 == a) kmask2 = m;
     }
   }
   bool at_x = false;  // jar / f / Hc are those of ar.X
@@ -1795,10 +1979,15 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
         __syncthreads();
         {
           const int a = lane / 7, e = lane % 7;
-          if (a < 2 * kMaxActive + 1) {
+          if (a < 9) {
             double s = 0;
             for (uint64_t m = kmask; m; m &= m - 1) s += ar.stage[__ffsll((long long)m) - 1][e];
             ar.KA[a][7 * batch + e] = s;
+            if (a + 9 < kAcc) {
+              double s2 = 0;
+              for (uint64_t m = kmask2; m; m &= m - 1) s2 += ar.stage[__ffsll((long long)m) - 1][e];
+              ar.KA[a + 9][7 * batch + e] = s2;
+            }
           }
         }
       }
@@ -1830,11 +2019,46 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
         }
         y[r] = sy; z[r] = sz;
       }
+      // self contact: a pair of links (la, lb) with stiffness K_p contributes (S_lb - S_la)' K_p (S_lb - S_la): the entry of joints
+      // i, j is s_i s_j S_i' K_p S_j with s_j = [j moves lb] - [j moves la] -- the joints BETWEEN the two links
+      double yp[kMaxPairs][6];
+      int sl[kMaxPairs];
+#pragma unroll
+      for (int q = 0; q < kMaxPairs; ++q) {
+        sl[q] = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) yp[q][r] = 0.0;
+        if (q < npairs) {
+          const int la = ar.pairs[q] & 0xff, lb = ar.pairs[q] >> 8;
+          sl[q] = (is_anc<T>(lane, lb) ? 1 : 0) - (is_anc<T>(lane, la) ? 1 : 0);
+          if (sl[q] != 0) {
+            const double* Kp = ar.KA[2 * kMaxActive + 1 + q];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              double sy = 0;
+#pragma unroll
+              for (int k = 0; k < 6; ++k) sy += Kp[r >= k ? tri(r, k) : tri(k, r)] * Sl[k];
+              yp[q][r] = sl[q] * sy;
+            }
+          }
+        }
+      }
       for (int j = 0; j <= lane; ++j) {
         double v = st.M(lane, j);
         if (is_anc<T>(j, lane)) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) v += st.S(j, k) * y[k];
+        }
+#pragma unroll
+        for (int q = 0; q < kMaxPairs; ++q) {
+          if (sl[q] == 0) continue;
+          const int la = ar.pairs[q] & 0xff, lb = ar.pairs[q] >> 8;
+          const int sj = (is_anc<T>(j, lb) ? 1 : 0) - (is_anc<T>(j, la) ? 1 : 0);
+          if (sj == 0) continue;
+          double dv = 0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) dv += st.S(j, k) * yp[q][k];
+          v += sj * dv;
         }
         if (j == lane) {
           const double sgn = st.limS(lane);
@@ -2077,13 +2301,16 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
     // its own inverse inertia only.  An update is then: the owner reads the two bodies' changes across the lanes, solves
     // its friction rows, hands the wrench change back across the lanes, and the slot lanes add their row of K times it:
     // no barrier and no pass over the kinematic tree per contact.
-    double (*Kl)[kMaxActive][6][6] = reinterpret_cast<double (*)[kMaxActive][6][6]>(&ar.rec[0][0]);  // (the records are in the lanes by now)
-    double (*Kbox)[6] = reinterpret_cast<double (*)[6]>(&ar.rec[0][0] + kMaxActive * kMaxActive * 36);  // the cube's own block
-    static_assert(sizeof(ar.rec) >= sizeof(double) * (kMaxActive * kMaxActive + 1) * 36, "K fits the records' area");
+    // K[s][t] = K[t][s]': the blocks t <= s are kept (block s (s + 1) / 2 + t), the others read transposed
+    constexpr int kKBlocks = kMaxActive * (kMaxActive + 1) / 2;
+    double (*Kh)[6][6] = reinterpret_cast<double (*)[6][6]>(&ar.rec[0][0]);  // (the records are in the lanes by now)
+    double (*Kbox)[6] = reinterpret_cast<double (*)[6]>(&ar.rec[0][0] + kKBlocks * 36);  // the cube's own block
+    static_assert(sizeof(ar.rec) >= sizeof(double) * (kKBlocks + 1) * 36, "K fits the records' area");
+    auto kval = [&](int s_, int t_, int k_, int m_) -> double { return s_ >= t_ ? Kh[s_ * (s_ + 1) / 2 + t_][k_][m_] : Kh[t_ * (t_ + 1) / 2 + s_][m_][k_]; };
     double kb[6] = {0, 0, 0, 0, 0, 0};  // slot lanes of the cube: their row of S_box M_box^-1 S_box'
     if (lane < 6 * nact) {
       const int sl = lane / 6, k = lane % 6, lk = ar.act[sl];
-      for (int t = 0; t < nact; ++t) {
+      for (int t = 0; t <= sl; ++t) {
         double row[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
@@ -2093,7 +2320,7 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
           for (int m = 0; m < 6; ++m) row[m] += sjk * Y[t][j][m];
         }
 #pragma unroll
-        for (int m = 0; m < 6; ++m) Kl[sl][t][k][m] = row[m];
+        for (int m = 0; m < 6; ++m) Kh[sl * (sl + 1) / 2 + t][k][m] = row[m];
       }
     } else if (lane >= 6 * kMaxActive && lane < 6 * kMaxActive + 6) {
       const int k = lane - 6 * kMaxActive;
@@ -2129,7 +2356,7 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
       for (int side = 0; side < 2; ++side) {
         const int sl = (my_slots >> (8 * side)) & 0xff;
         if (sl == 0xff) continue;
-        const double (*Km)[6] = sl == kMaxActive ? Kbox : Kl[sl][sl];
+        const double (*Km)[6] = sl == kMaxActive ? Kbox : Kh[sl * (sl + 1) / 2 + sl];
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
           double rel[6];
@@ -2137,6 +2364,23 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
           for (int k = 0; k < 6; ++k) rel[k] = dot6(Km[k], c.G[kk]);
 #pragma unroll
           for (int r = 0; r < 3; ++r) Ac[r][kk] += dot6(c.G[r], rel);
+        }
+      }
+      // two links of the robot (self contact) DO see each other in M^-1: the cross blocks, G (-K_AB - K_BA) G'
+      const int sA_ = my_slots & 0xff, sB_ = (my_slots >> 8) & 0xff;
+      if (sA_ < kMaxActive && sB_ < kMaxActive) {
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          double rel[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            double v = 0;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) v += (kval(sB_, sA_, k, m) + kval(sA_, sB_, k, m)) * c.G[kk][m];
+            rel[k] = v;
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) Ac[r][kk] -= dot6(c.G[r], rel);
         }
       }
     }
@@ -2224,8 +2468,18 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
           for (int k = 0; k < 6; ++k) w[k] = wave_read(dw[k], cc);
           if (lane < 6 * nact) {
             const int sl = lane / 6, k = lane % 6;
-            if (sB < kMaxActive) du += dot6(Kl[sl][sB][k], w);
-            if (sA < kMaxActive) du -= dot6(Kl[sl][sA][k], w);
+            if (sB < kMaxActive) {
+              double acc = 0;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) acc += kval(sl, sB, k, m) * w[m];
+              du += acc;
+            }
+            if (sA < kMaxActive) {
+              double acc = 0;
+#pragma unroll
+              for (int m = 0; m < 6; ++m) acc += kval(sl, sA, k, m) * w[m];
+              du -= acc;
+            }
           } else if (lane >= 6 * kMaxActive && lane < 6 * kMaxActive + 6) {
             const double sg = (sB == kMaxActive ? 1.0 : 0.0) - (sA == kMaxActive ? 1.0 : 0.0);
             du += sg * dot6(kb, w);
@@ -2273,9 +2527,9 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
 // acceleration); bit 4: more than kMaxCon contacts or more than kMaxActive links in contact (results then differ from MuJoCo's);
 // bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
 template <class T, bool FRIC = false>
-RCSH_D uint32_t contact_phase(const ContactTable& tab, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
+RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
                               ContactArena<T>& ar, const double* gravity) {
-  const uint32_t r = contact_collide<T>(tab, b, links, st, bs, ar);
+  const uint32_t r = contact_collide<T>(tab, ck, b, links, st, bs, ar);
   if (!(r & 1u) || !b.resolve) return r & ~1u;
   contact_newton<T, FRIC>(b, st, bs, ar, gravity, links);
   contact_noslip<T>(b, st, bs, ar);

@@ -7,7 +7,8 @@ namespace rcsh {
 constexpr int kMaxCon = 48;      // contacts per environment (oracle: ORC_MAXCON)
 constexpr int kMaxCGeom = 28;    // collision geoms of the robot (the end-of-launch contact check keeps the world boxes of all of them, for the
                                  // wavefront's four environments, in the team kernels' LDS block: check_team.h)
-constexpr int kMaxActive = 4;    // links in contact at once that the noslip pass keeps M^-1 S' for
+constexpr int kMaxActive = 5;    // links in contact at once that the noslip pass keeps M^-1 S' for
+constexpr int kMaxPairs = 4;     // pairs of LINKS in contact with each other at once (self contact: a stiffness accumulator per pair)
 
 // one collision geom of the robot, host-prepared (model.cpp: build_contact_table), in MuJoCo's geom order
 struct ContactGeom {
@@ -19,6 +20,7 @@ struct ContactGeom {
   int32_t geom_id;       // mjModel geom id
   int32_t plane_ok;      // the (floor, geom) pair passes MuJoCo's filters
   int32_t box_slot;      // box geoms: index among the box geoms (LDS slot of the collider's clipping polygons)
+  int32_t body, pad0;    // mjModel body id of the geom (mjData.contact is ordered by body pair, then by geom)
   double pos[3], rot[9]; // geom frame in the link frame
   double size[3];
   double center[3];      // hull: an interior point (vertex mean), geom frame

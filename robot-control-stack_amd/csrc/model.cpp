@@ -558,6 +558,7 @@ std::string build_contact_table(const HostModel& h, const DevModel& m, int plane
     cg.link = owner[b];
     cg.type = type;
     cg.geom_id = g;
+    cg.body = b;
     if (type == 6) {
       int nbox = 0;
       for (const auto& o : geoms) nbox += o.type == 6;

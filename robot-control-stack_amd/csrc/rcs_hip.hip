@@ -70,6 +70,14 @@ struct rcsh_sim {
   std::vector<CheckGeom> chk_geoms;
   CheckGeom* d_chk_geoms = nullptr;
   CheckEntry* d_chk_ent = nullptr;
+  // per-environment escalation (sim_kernels.h: RunOp::esc_role): a step is the lean launch over the environments not in contact plus
+  // the contact-resolving launch over the others
+  bool esc_mode = false;
+  uint64_t* d_esc = nullptr;       // [3][(n + 63) / 64]: escalated, newly flagged, leaving
+  uint32_t* d_esc_ctr = nullptr;   // [2]
+  double* d_snap = nullptr;        // [nfields][n]: what the lean launch of a step read (the step is redone from it on a hit)
+  uint32_t* d_snap_flags = nullptr;
+  int32_t* d_snap_conv = nullptr;
   bool contact_check = true;  // RCSH_CONTACT_CHECK=0 switches the check off (measurements of its cost)
   int check_every = 1;        // the check ends every check_every-th stepping launch (rcsh_sim_set_contact_check); 0: never
   int64_t check_seq = 0;
@@ -209,9 +217,9 @@ Params make_params(rcsh_sim* s) {
   P.ctab.plane_mu = s->plane_mu;
   P.chk.ent = s->d_chk_ent;
   P.chk.geoms = s->d_chk_geoms;
-  P.chk.npair = s->contact_check ? (int)s->chk_ent.size() : 0;
+  P.chk.npair = (int)s->chk_ent.size();  // (also the pair table of the contact phase's self-contact stage)
   P.chk.ngeom = (int)s->cgeoms.size();
-  P.chk.plane_points = s->contact_check && P.coll.has_plane ? 1 : 0;
+  P.chk.plane_points = P.coll.has_plane ? 1 : 0;
   P.chk.pad = 0;
   if (const char* dm = std::getenv("RCSH_CHECK_SKIP")) P.chk.pad = std::atoi(dm);  // development: bit 0 no narrow phase, 1 no boxes, 2 no spheres
   std::memset(P.chk.gh, 0, sizeof(P.chk.gh));
@@ -474,6 +482,12 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
   // DET: launches that run the collision callbacks (step_until_convergence) of a model with collision geoms carry the
   // contact detection of the position stage; Sim::step(k) never looks at the flags (sim.cpp:108-115)
   const bool det = op.nsteps < 0 && (P.coll.has_plane || !s->pairs.empty());
+  // per-environment escalation: stepping launches of a box-less scene whose robot contacts are resolved environment by environment
+  const bool esc = s->esc_mode && s->box.resolve && !s->box.present && (op.nsteps != 0 || op.do_reset) && !op.observe_only;
+  if (esc) {
+    op.esc = s->d_esc; op.esc_ctr = s->d_esc_ctr;
+    op.snap = s->d_snap; op.snap_flags = s->d_snap_flags; op.snap_conv = s->d_snap_conv;
+  }
   bool launched = false;
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
@@ -505,8 +519,21 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
       if constexpr (T::NARM == 7 && T::GRIP) go(N{}, Y{}, N{});
       else if constexpr (T::NARM == 7) go(Y{}, Y{}, N{});
     } else if (s->box.resolve) {
-      // no free body, contacts of the robot with the floor resolved (rcsh_sim_set_contact_options; FR3 + hand)
-      if constexpr (T::NARM == 7 && T::GRIP) go(N{}, N{}, Y{});
+      // no free body, contacts of the robot with the floor and with itself resolved (rcsh_sim_set_contact_options; FR3 + hand):
+      // by the whole batch on the contact-resolving kernel, or environment by environment (RunOp::esc_role)
+      if constexpr (T::NARM == 7 && T::GRIP) {
+        if (esc) {
+          op.esc_role = 1; op.check = 1;
+          go(N{}, N{}, N{});
+          op.esc_role = 2; op.check = 0;
+          static const int leave_quiet = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();
+          op.esc_leave_quiet = leave_quiet;
+          go(N{}, N{}, Y{});
+        } else {
+          op.force_contact = (s->box.resolve & 2) ? 1 : 0;
+          go(N{}, N{}, Y{});
+        }
+      }
     } else if (s->dm.has_friction)
       go(Y{}, N{}, N{});
     else
@@ -748,6 +775,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_geoms); hipFree(s->d_chk_ent);
+  hipFree(s->d_esc); hipFree(s->d_esc_ctr); hipFree(s->d_snap); hipFree(s->d_snap_flags); hipFree(s->d_snap_conv);
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_rcolours); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
   hipFree(s->d_redge_planes); hipFree(s->d_redge_verts); hipFree(s->d_rviews);
@@ -855,8 +883,21 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
   if (!rc) rc = scatter_host(s, field_of(s, "time"), 1, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "cb"), 6, z.data(), mask);
   if (!rc) rc = scatter_host(s, field_of(s, "xs"), s->nl, z.data(), mask);  // (mj_resetData: qacc_warmstart := 0)
-  if (!rc) rc = flags_update_host(s, 0, kContactOverflow | kContactUnresolved, mask);
+  if (!rc) rc = flags_update_host(s, 0, kContactOverflow | kContactUnresolved | kContactResolved | kEscQuiet, mask);
   if (!rc) rc = scatter_host(s, field_of(s, "sep"), kCheckSep, z.data(), mask);
+  if (!rc && s->d_esc) {
+    // per-environment escalation: a reset environment starts over on the lean kernel
+    const size_t nw = ((size_t)s->n + 63) / 64;
+    std::vector<uint64_t> w(3 * nw, 0);
+    if (mask) {
+      HIP_TRY(hipMemcpyAsync(w.data(), s->d_esc, sizeof(uint64_t) * nw, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      for (int e = 0; e < s->n; ++e)
+        if (mask[e]) w[e >> 6] &= ~(1ull << (e & 63));
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_esc, w.data(), sizeof(uint64_t) * 3 * nw, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+  }
   if (!rc && s->box.present) {
     std::vector<double> b0((size_t)s->n * kBoxState, 0.0);
     for (int e = 0; e < s->n; ++e)
@@ -1225,7 +1266,7 @@ int rcsh_sim_add_free_box(rcsh_sim* s, const rcsh_free_box_desc* d) {
   b.geom_mu = d->geom_friction[0] > 0 ? d->geom_friction[0] : d->friction[0];
   // contacts of the robot's geoms with the floor and the box enter one constraint problem with the robot's own rows
   // (limit / equality rows; dry-friction rows in the xArm7 + gripper archetype)
-  b.resolve = d->resolve_robot_contacts && s->grip && !s->cgeoms.empty();
+  b.resolve = (d->resolve_robot_contacts && s->grip && !s->cgeoms.empty()) ? (1 | (d->resolve_robot_contacts & 2)) : 0;  // (bit 1: self contact too)
   if (b.resolve && !s->contact_overflow.empty()) return fail(RCSH_ERR_MODEL, "robot contacts cannot be resolved in this scene: " + s->contact_overflow);
   make_kb(d->solref, d->solimp, s->dm.timestep, b.K, b.B);
   b.imp = make_imp(d->solimp);
@@ -1246,7 +1287,7 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
   REQUIRE_SIM(s);
   if (!o) return fail(RCSH_ERR_ARG, "null contact options");
   if (s->box.present) return fail(RCSH_ERR_STATE, "this scene has a free box: its description (rcsh_sim_add_free_box) carries the contact options");
-  if (!o->resolve_robot_contacts) { s->box = BoxCfg{}; return RCSH_OK; }
+  if (!o->resolve_robot_contacts) { s->box = BoxCfg{}; s->esc_mode = false; return RCSH_OK; }
   if (!(s->narm == 7 && s->grip && !s->dm.has_friction)) return fail(RCSH_ERR_MODEL, "contacts of the robot's geoms are resolved for the FR3 + hand archetype (no dry joint friction)");
   if (!o->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
   if (!(o->impratio > 0)) return fail(RCSH_ERR_ARG, "impratio must be positive");
@@ -1255,7 +1296,19 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
   // the phantom box of the contact phase: unit inertia, zero size, parked 1 km above the scene
   BoxCfg b{};
   b.present = 0;
-  b.resolve = 1;
+  b.resolve = 1 | (o->resolve_robot_contacts & 2);  // (bit 1: contacts between two geoms of the robot too)
+  s->esc_mode = (o->resolve_robot_contacts & 4) != 0;  // (bit 2: environment by environment instead of the whole batch)
+  if (s->esc_mode && !s->d_esc) {
+    const size_t nw = ((size_t)s->n + 63) / 64;
+    HIP_TRY(hipMalloc(&s->d_esc, sizeof(uint64_t) * 3 * nw));
+    HIP_TRY(hipMalloc(&s->d_esc_ctr, sizeof(uint32_t) * 2));
+    HIP_TRY(hipMalloc(&s->d_snap, sizeof(double) * (size_t)(s->nfields + kMaxRateCams) * s->n));  // (+ the rate-driven cameras' clocks)
+    HIP_TRY(hipMalloc(&s->d_snap_flags, sizeof(uint32_t) * s->n));
+    HIP_TRY(hipMalloc(&s->d_snap_conv, sizeof(int32_t) * s->n));
+    HIP_TRY(hipMemsetAsync(s->d_esc, 0, sizeof(uint64_t) * 3 * nw, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_esc_ctr, 0, sizeof(uint32_t) * 2, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_snap, 0, sizeof(double) * (size_t)(s->nfields + kMaxRateCams) * s->n, s->stream));
+  }
   b.noslip_iterations = o->noslip_iterations;
   b.qpos0[2] = 1000.0; b.qpos0[3] = 1.0;
   b.mass = b.inv_mass = 1.0;
@@ -1282,6 +1335,20 @@ int rcsh_sim_contact_unresolved(rcsh_sim* s, uint8_t* unresolved) {
     if (int rc = launch_run(s, op, false)) return rc;
   }
   return flag_host(s, kContactUnresolved, unresolved);
+}
+int rcsh_sim_contact_escalated(rcsh_sim* s, uint8_t* now, uint8_t* ever) {
+  REQUIRE_SIM(s);
+  if (now) {
+    std::memset(now, 0, s->n);
+    if (s->esc_mode && s->d_esc) {
+      const size_t nw = ((size_t)s->n + 63) / 64;
+      std::vector<uint64_t> w(nw);
+      HIP_TRY(hipMemcpyAsync(w.data(), s->d_esc, sizeof(uint64_t) * nw, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      for (int e = 0; e < s->n; ++e) now[e] = (uint8_t)((w[e >> 6] >> (e & 63)) & 1u);
+    }
+  }
+  return flag_host(s, kContactResolved, ever);
 }
 int rcsh_sim_set_contact_check(rcsh_sim* s, int32_t every) {
   REQUIRE_SIM(s);
@@ -1318,7 +1385,9 @@ int rcsh_sim_set_free_qvel(rcsh_sim* s, const double* v, const uint8_t* mask) { 
 
 size_t rcsh_sim_state_bytes(const rcsh_sim* s) {
   if (!s) return 0;
-  return (size_t)s->n * (sizeof(double) * s->nfields + sizeof(uint32_t) + sizeof(int32_t));
+  // (the tail: which environments are on the contact-resolving kernel -- per-environment escalation; a replay from a snapshot takes
+  // the same kernels environment by environment as the rollout it was taken from)
+  return (size_t)s->n * (sizeof(double) * s->nfields + sizeof(uint32_t) + sizeof(int32_t)) + sizeof(uint64_t) * (((size_t)s->n + 63) / 64);
 }
 int rcsh_sim_get_state(rcsh_sim* s, void* blob) {
   REQUIRE_SIM(s);
@@ -1329,6 +1398,9 @@ int rcsh_sim_get_state(rcsh_sim* s, void* blob) {
   HIP_TRY(hipMemcpyAsync(b, s->S, ns, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(b + ns, s->flags, nf, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(b + ns + nf, s->conv, nc, hipMemcpyDeviceToHost, s->stream));
+  const size_t ne = sizeof(uint64_t) * (((size_t)s->n + 63) / 64);
+  if (s->d_esc) HIP_TRY(hipMemcpyAsync(b + ns + nf + nc, s->d_esc, ne, hipMemcpyDeviceToHost, s->stream));
+  else std::memset(b + ns + nf + nc, 0, ne);
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
 }
@@ -1341,6 +1413,11 @@ int rcsh_sim_set_state(rcsh_sim* s, const void* blob) {
   HIP_TRY(hipMemcpyAsync(s->S, b, ns, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->flags, b + ns, nf, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->conv, b + ns + nf, nc, hipMemcpyHostToDevice, s->stream));
+  if (s->d_esc) {
+    const size_t ne = sizeof(uint64_t) * (((size_t)s->n + 63) / 64);
+    HIP_TRY(hipMemcpyAsync(s->d_esc, b + ns + nf + nc, ne, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_esc + ne / sizeof(uint64_t), 0, 2 * ne, s->stream));
+  }
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;
 }

@@ -39,6 +39,9 @@ enum : uint32_t {
   kGripCmd = 1u << 13,
   kHasLastAction = 1u << 14,
   kContactOverflow = 1u << 15,  // sticky until Sim::reset: a contact phase of this environment ran out of contact / link slots
+  kEscQuiet = 1u << 17,         // per-environment escalation: the last contact-resolving launch of this environment met no contact (a second one
+                                // in a row sends it back to the lean kernel)
+  kContactResolved = 1u << 18,  // sticky until Sim::reset: a contact of this environment's robot geoms was resolved (per-environment escalation)
   kContactUnresolved = 1u << 16,  // sticky until Sim::reset: the environment's geoms were found in a contact this configuration does
                                   // not resolve (check_team.h): from then on its trajectory is not what MuJoCo's would be
 };
@@ -109,7 +112,116 @@ struct RunOp {
   int32_t* substeps;      // [n]
   const double* box_qpos; // [n][7] env.reset() of the task env: RandomCubePos places the box (null: it stays at qpos0)
   double* task;           // [n][9] box qpos 7, reward, success (PickCubeSuccessWrapper.step)
+  // Per-environment escalation (round 5; host: launch_run).  MuJoCo resolves every contact of every substep (reference src/sim/sim.cpp:
+  // 108-115); the lean kernels resolve none.  So a step of a scene whose robot contacts are to be resolved is TWO launches over disjoint
+  // sets of environments: role 1, the lean kernel over the environments NOT escalated (workgroup slot r takes the r-th of them), which
+  // keeps a copy of every state field it read (snap) and whose end-of-launch check, on a hit, marks the environment in esc[1] ("new");
+  // then role 2, the contact-resolving kernel with the contact phase in every substep, over the escalated environments esc[0] | esc[1]:
+  // a NEW one is stepped again from the copy -- the launch it was flagged in is redone with its contacts resolved from their first
+  // substep --, the others continue from their state.  An environment whose second contact-resolving launch in a row met no contact is
+  // marked in esc[2] ("leave").  The last workgroup of the role-2 launch merges: esc[0] = (esc[0] & ~esc[2]) | esc[1].
+  int32_t esc_role;
+  int32_t force_contact;  // the contact phase runs in every substep of every environment (a whole batch on the contact-resolving kernel with
+                          // self contacts resolved: exact, and slow -- the fast path's broad phase knows the floor and the free body only)
+  int32_t esc_leave_quiet, esc_pad;  // role 2: an environment leaves after two launches in a row without a contact (default: with its reset only)
+  uint64_t* esc;          // [3][(n + 63) / 64]
+  uint32_t* esc_ctr;      // [0] workgroups of the role-2 launch that are done, [1] environments escalated after the last merge
+  double* snap;           // [Lay::COUNT][n]
+  uint32_t* snap_flags;   // [n]
+  int32_t* snap_conv;     // [n]
 };
+
+// inclusive prefix sum over the 64 lanes of the wavefront
+__device__ __forceinline__ int wave_incl_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+  const int t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+  const int row = (int)(threadIdx.x & 63u) >> 4;
+  return x + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+__device__ __forceinline__ uint64_t wave_read_u64(uint64_t x, int src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), src);
+  return (uint64_t)hi << 32 | lo;
+}
+// The environment workgroup slot r0 + team stands for under RunOp::esc_role (1: the r-th environment that is not escalated; 2: the
+// r-th that is); -1: there is none.  `redo`: role 2, the environment is newly escalated (its step is redone from the copy).
+// Every lane of the wavefront calls this; no LDS.
+// Role 2 SPREADS its environments over the launch's workgroups -- one per workgroup while there are no more of them than workgroups,
+// then two, three, four: workgroup slot r (r0 / 4) takes environments r per, ..., r per + per - 1 on its first teams, the other teams idle -- the contact phase puts all 64 lanes of a wavefront on ONE environment at a
+// time (contact_team.h), so four escalated environments in one wavefront take turns while three quarters of the chip's SIMDs, which the
+// lean launch has just left, stand empty.  (`spread`: r0 is then the workgroup's slot, not four times it.)
+__device__ __forceinline__ int esc_select(const RunOp& op, int n, int r0, int team, bool& redo, bool spread = false) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int nw = (n + 63) >> 6;
+  const uint64_t* A = op.esc;
+  const uint64_t* B = op.esc + nw;
+  int result = -1, base = 0, per = 4;
+  redo = false;
+  if (spread) {
+    // how many are there?  (one pass over the masks; n <= 64 k environments: at most 16 words a lane)
+    int cnt = 0;
+    for (int wi = lane; wi < nw; wi += 64) {
+      const uint64_t valid = (wi == nw - 1 && (n & 63)) ? ((1ull << (n & 63)) - 1) : ~0ull;
+      cnt += __popcll((A[wi] | B[wi]) & valid);
+    }
+    const int total = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63), G = (int)gridDim.x;
+    per = total <= G ? 1 : (total <= 2 * G ? 2 : (total <= 3 * G ? 3 : 4));  // environments per workgroup: as few as the launch's workgroups allow
+    r0 = (r0 / 4) * per;
+  }
+  for (int c0 = 0; c0 < nw; c0 += 64) {
+    const int wi = c0 + lane;
+    uint64_t a = 0, b = 0, valid = 0;
+    if (wi < nw) {
+      a = A[wi];
+      b = op.esc_role == 2 ? B[wi] : 0;
+      valid = (wi == nw - 1 && (n & 63)) ? ((1ull << (n & 63)) - 1) : ~0ull;
+    }
+    const uint64_t w = (op.esc_role == 1 ? ~a : (a | b)) & valid;
+    const int pc = __popcll(w);
+    const int incl = wave_incl_scan(pc);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    for (int k = 0; k < per; ++k) {
+      const int rk = r0 + k - base;
+      if (rk < 0 || rk >= total) continue;  // (wave-uniform)
+      const int L = __ffsll((long long)__ballot(incl > rk)) - 1;
+      const int excl = __builtin_amdgcn_readlane(incl, L) - __builtin_amdgcn_readlane(pc, L);
+      uint64_t wl = wave_read_u64(w, L);
+      for (int q = rk - excl; q > 0; --q) wl &= wl - 1;
+      const int bit = __ffsll((long long)wl) - 1;
+      if (team == k) {
+        result = (c0 + L) * 64 + bit;
+        redo = op.esc_role == 2 && !((wave_read_u64(a, L) >> bit) & 1ull);
+      }
+    }
+    base += total;
+    if (base > r0 + per - 1) break;
+  }
+  return result;
+}
+// role 2, at the very end of a workgroup: the last one to finish merges the masks (nobody reads them any more: the next launch of the
+// stream starts after this one has ended)
+__device__ __forceinline__ void esc_finish(const RunOp& op, int n) {
+  __threadfence();
+  int last = 0;
+  if ((threadIdx.x & 63u) == 0) last = atomicAdd(op.esc_ctr, 1u) == gridDim.x - 1 ? 1 : 0;
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  __threadfence();
+  const int nw = (n + 63) >> 6;
+  int count = 0;
+  for (int wi = (int)(threadIdx.x & 63u); wi < nw; wi += 64) {
+    const uint64_t a = (__hip_atomic_load(op.esc + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~__hip_atomic_load(op.esc + 2 * nw + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) |
+                       __hip_atomic_load(op.esc + nw + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    op.esc[wi] = a;
+    op.esc[nw + wi] = 0;
+    op.esc[2 * nw + wi] = 0;
+    count += __popcll(a);
+  }
+  count = wave_incl_scan(count);
+  if ((threadIdx.x & 63u) == 63) { op.esc_ctr[1] = (uint32_t)count; op.esc_ctr[0] = 0; }
+}
 
 // Contact detection against the scene's static plane (flags only): sample points of the collision geoms, link frame
 struct CollTable {
@@ -697,7 +809,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   __shared__ Params lp;
   __shared__ RunOp lop;
   // (sized for the end-of-launch contact check too, which takes the block over once the state has been written back)
-  constexpr int kLdsDoubles = ST::COUNT * kTeams > check_work_doubles(T::NL) ? ST::COUNT * kTeams : check_work_doubles(T::NL);
+  // (CON: the check's workspace is the contact arena, idle by then -- the instantiation has no LDS to spare)
+  constexpr int kLdsDoubles = (CON || ST::COUNT * kTeams > check_work_doubles(T::NL)) ? ST::COUNT * kTeams : check_work_doubles(T::NL);
   __shared__ __attribute__((aligned(16))) double lds[kLdsDoubles];
   // everything the launch reads from memory at its start is asked for at once -- arguments, model tables and, further down, the
   // environment's state -- and stored to LDS after one wait
@@ -719,9 +832,24 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   // every XCD one contiguous range of environments, so a 128-byte line of a state field ([field][env], 16
   // environments) is fetched into one L2 instead of four.  The grid is rounded up to a multiple of 8.
   const int per_xcd = gridDim.x / 8;
-  const int e = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * kTeams + team;
+  const int e_slot0 = ((blockIdx.x % 8) * per_xcd + blockIdx.x / 8) * kTeams;
+  int e = e_slot0 + team;
+  bool esc_redo = false;  // role 2: this environment was flagged by the lean launch of this step; its step is redone from the copy
+  const int esc_role = opk.esc_role;  // (wave-uniform)
+  if (esc_role != 0) {
+    // (role 2 may spread its environments one per workgroup: every workgroup asks)
+    const int pick = (e_slot0 < Pk.n || esc_role == 2) ? esc_select(opk, Pk.n, e_slot0, team, esc_redo, esc_role == 2) : -1;
+    if (__ballot(pick >= 0) == 0) {  // no environment for any of this workgroup's four slots
+      if (esc_role == 2) esc_finish(opk, Pk.n);
+      return;
+    }
+    e = pick >= 0 ? pick : Pk.n;
+  }
   const bool live = e < Pk.n && !(opk.mask && !opk.mask[e < Pk.n ? e : 0]);
   const bool leader = t == 0 && live;
+  // where this launch reads the environment's state from: its state, or (a step that is redone) the copy the lean launch kept
+  const double* const Sin = esc_redo ? opk.snap : Pk.S;
+  const bool snap_out = esc_role == 1 && live;
   // The environment's state goes out first -- every lane asks for up to three of the fields that are staged in LDS,
   // the leader for the five it keeps in registers -- so that the model staging below hides the round trip to HBM.
   using SF = TeamStagedFields<T, ST>;
@@ -742,28 +870,54 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       const int k = t + rd * kTeamLanes;
       int field = 0, slot = 0;
       SF::locate(k < nstaged ? k : 0, field, slot);
-      staged[rd] = Pk.S[(size_t)field * Pk.n + e];
+      staged[rd] = Sin[(size_t)field * Pk.n + e];
     }
     if constexpr (FRIC) {
-      if (t < T::NL && !opk.do_reset) xs_in = Pk.S[(size_t)(Lay<T>::XS + t) * Pk.n + e];  // (Sim::reset: mj_resetData zeroes the warm start)
+      if (t < T::NL && !opk.do_reset) xs_in = Sin[(size_t)(Lay<T>::XS + t) * Pk.n + e];  // (Sim::reset: mj_resetData zeroes the warm start)
     }
     if (opk.apply_action) {
       using L = Lay<T>;
       if (t < T::NARM) {
         in_action = opk.action[(size_t)e * T::NARM + t];
         // (origin / last action are only read back with RelativeTo.CONFIGURED_ORIGIN: LAST_STEP re-derives both every step)
-        if (Pk.env.relative_to == 2) { in_origin = Pk.S[(size_t)(L::ORIGIN + t) * Pk.n + e]; in_lasta = Pk.S[(size_t)(L::LASTA + t) * Pk.n + e]; }
-        in_preva = Pk.S[(size_t)(L::PREVA + t) * Pk.n + e];
+        if (Pk.env.relative_to == 2) { in_origin = Sin[(size_t)(L::ORIGIN + t) * Pk.n + e]; in_lasta = Sin[(size_t)(L::LASTA + t) * Pk.n + e]; }
+        in_preva = Sin[(size_t)(L::PREVA + t) * Pk.n + e];
       }
       if (t == 0 && opk.gripper) in_grip = opk.gripper[e];
     }
     if (t == 0) {
       using L = Lay<T>;
-      pre_time = Pk.S[(size_t)L::TIME * Pk.n + e];
-      pre_cmd = Pk.S[(size_t)(L::GRIP + 0) * Pk.n + e];
-      pre_width = Pk.S[(size_t)(L::GRIP + 1) * Pk.n + e];
-      pre_flags = Pk.flags[e];
-      pre_conv = Pk.conv_steps[e];
+      pre_time = Sin[(size_t)L::TIME * Pk.n + e];
+      pre_cmd = Sin[(size_t)(L::GRIP + 0) * Pk.n + e];
+      pre_width = Sin[(size_t)(L::GRIP + 1) * Pk.n + e];
+      pre_flags = esc_redo ? opk.snap_flags[e] : Pk.flags[e];
+      pre_conv = esc_redo ? opk.snap_conv[e] : Pk.conv_steps[e];
+    }
+    if (snap_out) {
+      // per-environment escalation, the lean launch: everything just read that this launch will overwrite, kept for the case that
+      // the step has to be redone with its contacts resolved (RunOp::esc_role)
+      using L = Lay<T>;
+#pragma unroll
+      for (int rd = 0; rd < SF::kRounds; ++rd) {
+        const int k = t + rd * kTeamLanes;
+        int field = 0, slot = 0;
+        SF::locate(k < nstaged ? k : 0, field, slot);
+        if (k < nstaged) opk.snap[(size_t)field * Pk.n + e] = staged[rd];
+      }
+      if constexpr (FRIC) {
+        if (t < T::NL && !opk.do_reset) opk.snap[(size_t)(L::XS + t) * Pk.n + e] = xs_in;
+      }
+      if (opk.apply_action && t < T::NARM) {
+        if (Pk.env.relative_to == 2) { opk.snap[(size_t)(L::ORIGIN + t) * Pk.n + e] = in_origin; opk.snap[(size_t)(L::LASTA + t) * Pk.n + e] = in_lasta; }
+        opk.snap[(size_t)(L::PREVA + t) * Pk.n + e] = in_preva;
+      }
+      if (t == 0) {
+        opk.snap[(size_t)L::TIME * Pk.n + e] = pre_time;
+        opk.snap[(size_t)(L::GRIP + 0) * Pk.n + e] = pre_cmd;
+        opk.snap[(size_t)(L::GRIP + 1) * Pk.n + e] = pre_width;
+        opk.snap_flags[e] = pre_flags;
+        opk.snap_conv[e] = pre_conv;
+      }
     }
   }
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
@@ -881,10 +1035,16 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   const bool rend_on = rend_ncam > 0 && !op.observe_only;  // (wave-uniform)
   if (rend_on && leader) {
     // Sim::reset -> reset_callbacks (sim.cpp:131-137): "negative so that we will directly render the cameras in the first step"
-    for (int c = 0; c < rend_ncam; ++c) lrend[team][c] = op.do_reset ? -lp.rend.period[c] : lp.rend.last[(size_t)c * P.n + e];
+    for (int c = 0; c < rend_ncam; ++c) {
+      // (a step that is redone starts from the camera clocks the lean launch started from: kept behind the state's copy)
+      const double last = esc_redo ? lop.snap[(size_t)(Lay<T>::COUNT + c) * P.n + e] : lp.rend.last[(size_t)c * P.n + e];
+      if (esc_role == 1) lop.snap[(size_t)(Lay<T>::COUNT + c) * P.n + e] = last;
+      lrend[team][c] = op.do_reset ? -lp.rend.period[c] : last;
+    }
     lrend[team][kMaxRateCams + 1] = 0.0;
   }
   if (rend_on && t == 0 && e < P.n && !live) lp.rend.count[e] = 0;  // (masked out of this launch: nothing recorded)
+  bool esc_contact = false;  // (leader) a substep of this launch resolved a contact of the robot's geoms
   bool box_placed = false;  // env.reset() with RandomCubePos: the box got its pose after the first of the two substeps
   bool more = leader && budget > 0;
   double cb_due = leader ? fmin(r.cb(0), r.cb(1)) : 0.0;
@@ -1025,7 +1185,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       bool coupled = false;
       if constexpr (CON) {
         // teams whose broad phase fired take turns: the whole wavefront works on one environment's contacts (contact_team.h)
-        const uint64_t nearw = __ballot(near);
+        // (an escalated environment -- RunOp::esc_role 2 -- runs the contact phase in every substep: all of MuJoCo's collision pass,
+        // the robot's geoms against each other included, none of the fast path's broad phase)
+        const uint64_t nearw = __ballot(near || ((esc_role == 2 || lop.force_contact) && stepping && t == 0));
 #ifdef RCSH_PHASE_TIMING
         if (threadIdx.x == 0) {  // (all workgroups) substeps of wavefronts / with a woken contact phase / teams woken
           atomicAdd(&g_team_cycles[41], 1ull);
@@ -1035,7 +1197,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
         if (nearw) {
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
-            const uint32_t r = contact_phase<T, FRIC>(lp.ctab, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity);
+            const uint32_t r = contact_phase<T, FRIC>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity);
             if (team == k) {
               coupled = r & 1u;
               hit |= (r >> 8) & 3u;
@@ -1103,6 +1265,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     }
     if (leader && stepping) {
       if (CON && overflow) r.flags |= kContactOverflow;
+      if (CON && team_coupled) esc_contact = true;
       r.time += timestep;
       have_frames = true;
       --budget;
@@ -1163,8 +1326,21 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     if (live && team_frames && t < 12) P.S[(size_t)(Lay<T>::SITE + t) * P.n + e] = st.link(t);
     if (live && op.write_obs && t < T::NARM) op.obs[(size_t)e * (14 + T::NARM) + 7 + t] = st.q(t);
   }
+  bool esc_leave = false;
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
+    if (CON && esc_role == 2 && have_frames) {
+      // Back to the lean kernel: with Sim::reset (the environment starts over at its home pose), or -- RunOp::esc_leave_quiet -- after
+      // two contact-resolving launches in a row without a contact.  The default keeps an environment that has touched something on
+      // the contact-resolving kernel until its reset: a contact that begins AND ends inside one lean launch is the one thing the lean
+      // launch's end-of-launch check cannot see, and an arm that has just bounced off the floor is the likeliest to do it again.
+      if (esc_contact) { r.flags |= kContactResolved; r.flags &= ~kEscQuiet; }
+      else if (op.do_reset) { esc_leave = true; r.flags &= ~kEscQuiet; }
+      else if (op.esc_leave_quiet) {
+        if (r.flags & kEscQuiet) { esc_leave = true; r.flags &= ~kEscQuiet; }
+        else r.flags |= kEscQuiet;
+      }
+    }
     env_epilogue<T, ST, false>(P, op, m, e, r, st, have_frames, nsteps);
   }
   __syncthreads();
@@ -1231,15 +1407,28 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     // contact has no separating direction to remember and would go through the full refinement in every launch, and the launch
     // waits for its slowest wavefront)
     const bool flagged = ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)r.flags) & kContactUnresolved) != 0;
-    const bool checked = live && !flagged;
-    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), lds, q_final, checked, !CON, sep_in, sep, P.n, chk_pf);
+    // (with per-environment escalation the check is what sends an environment to the contact-resolving kernel: nobody sits it out)
+    const bool checked = live && (!flagged || esc_role == 1);
+    double* check_work = lds;
+    if constexpr (CON) {
+      static_assert(sizeof(ContactArena<T>) >= sizeof(double) * check_work_doubles(T::NL), "the check's workspace fits the contact arena");
+      check_work = reinterpret_cast<double*>(&larena[0]);
+    }
+    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, !CON, sep_in, sep, P.n, chk_pf);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif
-    if (leader && hit && !(r.flags & kContactUnresolved)) {
+    if (esc_role == 1) {
+      // per-environment escalation: the step is redone by the contact-resolving launch that follows (RunOp::esc_role)
+      if (leader && hit) atomicOr(reinterpret_cast<unsigned long long*>(lop.esc + ((P.n + 63) >> 6) + (e >> 6)), 1ull << (e & 63));
+    } else if (leader && hit && !(r.flags & kContactUnresolved)) {
       P.flags[e] = r.flags | kContactUnresolved;
       if (op.write_obs && op.info) op.info[(size_t)e * 8 + 7] = 1;
     }
+  }
+  if (esc_role == 2) {
+    if (esc_leave) atomicOr(reinterpret_cast<unsigned long long*>(lop.esc + 2 * ((P.n + 63) >> 6) + (e >> 6)), 1ull << (e & 63));
+    esc_finish(lop, P.n);
   }
   TEAM_MARK(10)
   TEAM_CLOCK_FLUSH()

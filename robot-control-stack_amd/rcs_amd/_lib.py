@@ -181,6 +181,7 @@ EXPORTS = (
     "rcsh_sim_contact_table_dropped",
     "rcsh_sim_contact_unresolved",
     "rcsh_sim_set_contact_check",
+    "rcsh_sim_contact_escalated",
 )
 
 _lib = None
@@ -219,6 +220,7 @@ def load() -> C.CDLL:
     L.rcsh_sim_create.argtypes = [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.rcsh_sim_add_free_box.argtypes = [C.c_void_p, C.POINTER(FreeBoxDesc)]
     L.rcsh_sim_set_contact_options.argtypes = [C.c_void_p, C.POINTER(ContactOptions)]
+    L.rcsh_sim_contact_escalated.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_sim_reset_free_box.argtypes = [C.c_void_p]
     L.rcsh_sim_contact_table_dropped.argtypes = [C.c_void_p, _I32P, C.c_int32, _I32P, C.c_char_p, C.c_size_t]
     for fn in (L.rcsh_sim_get_free_qpos, L.rcsh_sim_get_free_qvel):

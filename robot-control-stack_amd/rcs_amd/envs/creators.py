@@ -75,12 +75,13 @@ class VecSimEnv:
         # What an environment gets whose geoms are found in a contact this configuration does not resolve (info["contact_unresolved"],
         # sticky until reset; csrc/check_team.h).  The reference resolves every contact in every mode (mj_step2, sim.cpp:112); the
         # lean kernels of scenes without a free body do not, because the capability costs the contact-free rollout ~15 %.
-        #   "flag":    report only -- the environment steps on unresolved (the arm passes through the floor / itself) and the caller
-        #              decides (mask it, reset it, discard the episode);
-        #   "resolve": as soon as a step reports one, the whole batch switches to the contact-resolving kernels for all later steps
-        #              (robot <-> floor resolved from then on; robot <-> robot contacts stay flagged).  Host-array interface only:
-        #              the `*_dev` entry points never read the flags back.
-        self.on_unresolved_contact = "flag"
+        #   "resolve": (default, round 5) nothing stays unresolved: the Sim resolves robot contacts environment by environment
+        #              (Sim(resolve_robot_contacts=None): mode 7 in scenes without a free body), robot <-> robot included.  A Sim that
+        #              was created with resolve_robot_contacts=False is switched to that mode as soon as a step reports a contact
+        #              (host-array interface only: the `*_dev` entry points never read the flags back);
+        #   "flag":    report only -- with a Sim created with resolve_robot_contacts=False the environment steps on unresolved (the arm
+        #              passes through the floor / itself) and the caller decides (mask it, reset it, discard the episode).
+        self.on_unresolved_contact = "resolve"
 
     def _after_step(self, info) -> None:
         if self.on_unresolved_contact == "resolve" and not self.sim.resolve_robot_contacts and info[:, 7].any():
@@ -289,10 +290,11 @@ class SimEnvCreator:
     def __call__(self, control_mode: ControlMode, robot_cfg: sim.SimRobotConfig, collision_guard: bool = False,
                  gripper_cfg: sim.SimGripperConfig | None = None, sim_cfg: sim.SimConfig | None = None,
                  hand_cfg=None, cameras=None, max_relative_movement: float | tuple[float, float] | None = None,
-                 relative_to: RelativeTo = RelativeTo.LAST_STEP, sim_wrapper=None, n_envs: int = 1, device: int = 0) -> VecSimEnv:
+                 relative_to: RelativeTo = RelativeTo.LAST_STEP, sim_wrapper=None, n_envs: int = 1, device: int = 0,
+                 resolve_robot_contacts=None) -> VecSimEnv:
         if hand_cfg is not None or sim_wrapper is not None or collision_guard:
             raise NotImplementedError("hands, sim_wrapper and collision_guard are outside this backend's hot path")
-        simulation = sim.Sim(robot_cfg.mjcf_scene_path, sim_cfg, n_envs=n_envs, device=device)
+        simulation = sim.Sim(robot_cfg.mjcf_scene_path, sim_cfg, n_envs=n_envs, device=device, resolve_robot_contacts=resolve_robot_contacts)
         robot = sim.SimRobot(simulation, None, robot_cfg)
         gripper = sim.SimGripper(simulation, gripper_cfg) if gripper_cfg is not None else None
         camera_set = None

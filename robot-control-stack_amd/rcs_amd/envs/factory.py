@@ -41,7 +41,7 @@ def robot_cfg_for(robot: str) -> sim.SimRobotConfig:
 
 def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relative: bool = True, control_mode=None, device: int = 0,
                  max_relative_movement=None, robot: str = "fr3", relative_to: str = "last_step", frequency: int = 30,
-                 max_convergence_steps: int = 500, robot_cfg: sim.SimRobotConfig | None = None):
+                 max_convergence_steps: int = 500, robot_cfg: sim.SimRobotConfig | None = None, resolve_robot_contacts=None):
     """`n_envs` environments of one robot type on GPU `device`.  `robot_cfg` overrides the robot's default configuration
     (its scene decides the kernel archetype); only the FR3, SO101 and xarm7_pick scenes carry a gripper."""
     cfg = sim.SimConfig(async_control=async_control, realtime=False, frequency=frequency, max_convergence_steps=max_convergence_steps)
@@ -57,5 +57,5 @@ def make_vec_env(n_envs: int, async_control: bool, gripper: bool = True, relativ
         gripper_cfg=gripper_cfg,
         sim_cfg=cfg, max_relative_movement=max_relative_movement if relative else None,
         relative_to=RelativeTo.LAST_STEP if relative_to == "last_step" else RelativeTo.CONFIGURED_ORIGIN,
-        n_envs=n_envs, device=device,
+        n_envs=n_envs, device=device, resolve_robot_contacts=resolve_robot_contacts,
     )

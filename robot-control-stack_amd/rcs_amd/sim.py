@@ -73,14 +73,31 @@ class Sim:
         # callbacks need them) in scenes without -- there the contact-capable kernel costs the no-contact rollout ~15 %, so it
         # is opt-in: Sim(..., resolve_robot_contacts=True) makes the arm stop on the floor instead of passing through it.
         has_free = bool(getattr(self.model, "free_bodies", []))
-        resolve = has_free if resolve_robot_contacts is None else bool(resolve_robot_contacts)
-        self.resolve_robot_contacts = resolve and self.resolves_robot_contacts(self.model)
+        # (an int selects what is resolved and how -- include/rcs_hip.h, rcsh_contact_options: bit 0 robot <-> floor / free body, bit 1
+        # robot <-> robot too, bit 2 environment by environment: the lean kernel for the environments that touch nothing)
+        # Default (round 5): what MuJoCo does -- every contact of the robot's geoms is resolved.  Scenes without a free body do it
+        # environment by environment (mode 7: the lean kernel steps the environments that touch nothing, an environment found in
+        # contact has that launch redone by the contact-resolving kernel and stays on it while the contact lasts); scenes with a
+        # free body run the whole batch on the contact-resolving kernel as before (mode 1).  False: contacts are detected only
+        # (collision flags, info["contact_unresolved"]).
+        resolve = (1 if has_free else 7) if resolve_robot_contacts is None else resolve_robot_contacts
+        mode = ((1 if has_free else 7) if resolve else 0) if isinstance(resolve, bool) else int(resolve)
+        if mode and not mode & 1:
+            mode |= 1
+        self.resolve_robot_contacts = mode if self.resolves_robot_contacts(self.model) else 0
         box = _lib.make_free_box_desc(self.model, self.resolve_robot_contacts)
         if box is not None:
             _lib.check(self._L.rcsh_sim_add_free_box(self._h, C.byref(box)))
         elif self.resolve_robot_contacts:
-            opts = _lib.make_contact_options(self.model, True)
-            _lib.check(self._L.rcsh_sim_set_contact_options(self._h, C.byref(opts)))
+            opts = _lib.make_contact_options(self.model, self.resolve_robot_contacts)
+            try:
+                _lib.check(self._L.rcsh_sim_set_contact_options(self._h, C.byref(opts)))
+            except RuntimeError:
+                if resolve_robot_contacts is not None:
+                    raise
+                # the DEFAULT asks for contacts to be resolved; a scene the contact phase cannot hold (more collision geoms than its
+                # table) still loads and steps -- its contacts are detected only, as the warning above says
+                self.resolve_robot_contacts = 0
         self._cfg = SimConfig()
         if cfg is not None:
             self.set_config(cfg)
@@ -95,6 +112,15 @@ class Sim:
         self._contact_table_reason = reason.value.decode()
         return [int(g) for g in ids[: min(count.value, 64)]]
 
+    def contact_escalated(self):
+        """([N] bool, [N] bool): the environment is on the contact-resolving kernel right now / a contact of its robot geoms has been
+        resolved since its last Sim.reset (per-environment escalation: resolve_robot_contacts bit 2)."""
+        import numpy as np
+
+        now, ever = np.zeros(self.n_envs, dtype=np.uint8), np.zeros(self.n_envs, dtype=np.uint8)
+        _lib.check(self._L.rcsh_sim_contact_escalated(self._h, _lib.ptr(now), _lib.ptr(ever)))
+        return now.astype(bool), ever.astype(bool)
+
     def enable_contact_resolution(self) -> bool:
         """Switch a scene WITHOUT a free body to the contact-resolving kernels from the next launch on (robot <-> floor contacts
         enter the constraint solve; rcsh_sim_set_contact_options).  False where the archetype cannot (see resolves_robot_contacts)."""
@@ -102,9 +128,9 @@ class Sim:
             return True
         if getattr(self.model, "free_bodies", []) or not self.resolves_robot_contacts(self.model):
             return False
-        opts = _lib.make_contact_options(self.model, True)
+        opts = _lib.make_contact_options(self.model, 7)
         _lib.check(self._L.rcsh_sim_set_contact_options(self._h, C.byref(opts)))
-        self.resolve_robot_contacts = True
+        self.resolve_robot_contacts = 7
         return True
 
     def set_contact_check(self, every: int) -> None:

@@ -110,7 +110,7 @@ def test_contact_unresolved_is_cleared_by_reset_and_can_switch_the_batch_to_reso
     n = 4
     down = np.tile([0, 1.7, 0, -1.3, 0, 1.9, 0.8], (n, 1))  # a reach down and forward: hand and forearm go below the floor plane
     for mode in ("flag", "resolve"):
-        venv = make_vec_env(n, True, relative=False)
+        venv = make_vec_env(n, True, relative=False, resolve_robot_contacts=False)  # (round 5: a Sim resolves by default; this one only detects)
         venv.on_unresolved_contact = mode
         venv.reset()
         flagged_at = None
