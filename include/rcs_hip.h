@@ -312,7 +312,12 @@ int rcsh_sim_contact_unresolved(rcsh_sim* sim, uint8_t* unresolved);
  * rollout that prefers throughput sets a larger cadence -- a contact is then found with a lag of up to `every` - 1 launches, one
  * that comes and goes between two checks is missed -- and rcsh_sim_contact_unresolved() always checks the present state first. */
 int rcsh_sim_set_contact_check(rcsh_sim* sim, int32_t every);
-/* Collision geoms of the scene that exceed the contact table's capacity (32 geoms, 10 boxes, 152 hull vertices) are left out of
+/* Admitted geom pairs beyond the 192 the end-of-launch check (and the self-contact stage of the contact-resolving kernels) keeps
+ * entries for: they are neither checked nor resolved; the handle is created all the same and the Python host warns.  0 for every
+ * shipped scene (fr3_empty_world: 137 pairs).  No reference counterpart: MuJoCo has no such capacity. */
+int rcsh_sim_contact_check_unchecked_pairs(rcsh_sim* sim, int32_t* count);
+/* Collision geoms of the scene that exceed the contact table's capacity (28 geoms -- 32 until round 4, when the end-of-launch
+ * check took LDS for the geoms' world boxes --, 10 boxes, 152 hull vertices) are left out of
  * GEOM-GEOM detection (the floor test still sees them): their mjModel ids (up to `capacity`), how many there are, and why.
  * rcsh_sim_add_robot / rcsh_sim_add_gripper refuse a collision geom that is on this list; the Python host warns about the
  * rest (a world-welded obstacle no callback list names would still count for SimRobot::collision_callback,

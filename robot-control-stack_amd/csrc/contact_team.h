@@ -85,6 +85,15 @@ RCSH_D bool is_anc(int j, int i) {
   return j <= i;
 }
 
+// bit j: joint j is an ancestor-or-self joint of link i (i < 0, welded to the world: none)
+template <class T>
+RCSH_D uint32_t anc_mask(int i) {
+  if (i < 0) return 0u;
+  uint32_t m = (2u << i) - 1u;
+  if (T::GRIP && i == T::NARM + 1) m &= ~(1u << T::NARM);
+  return m;
+}
+
 // mju_makeFrame
 RCSH_D void make_frame(const double* n, double* t1, double* t2) {
   double y[3] = {0, 0, 0};
@@ -100,6 +109,31 @@ RCSH_D void make_frame(const double* n, double* t1, double* t2) {
 RCSH_D void mulTv(const double* R, const double* v, double* o) {
   const double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2], z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
   o[0] = x; o[1] = y; o[2] = z;
+}
+
+// The smallest penetration of two boxes along their six face axes -- dev_box_box's own first six tests, same expressions: negative:
+// apart.  Every contact point dev_box_box returns is at most this deep (face case: depths are measured along the face axis of
+// that smallest penetration; edge case: chosen only when its penetration is smaller still), so two boxes whose faces just touch --
+// the two fingers' pads of a closed gripper, in every substep -- are settled by their lane without the serial collider.
+RCSH_D double box_box_face_pen(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2) {
+  double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, t[3], R[3][3], Q[3][3];
+  mulTv(R1, d, t);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      R[i][j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+      Q[i][j] = fabs(R[i][j]);
+    }
+  double best = INFINITY;
+  for (int i = 0; i < 3; ++i) {
+    const double pen = s1[i] + s2[0] * Q[i][0] + s2[1] * Q[i][1] + s2[2] * Q[i][2] - fabs(t[i]);
+    best = pen < best ? pen : best;
+  }
+  for (int j = 0; j < 3; ++j) {
+    const double tb = t[0] * R[0][j] + t[1] * R[1][j] + t[2] * R[2][j];
+    const double pen = s2[j] + s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j] - fabs(tb);
+    best = pen < best ? pen : best;
+  }
+  return best;
 }
 
 // ------------------------------------------------------------------ box - box (oracle: orc_box_box)
@@ -1208,11 +1242,12 @@ RCSH_CONTACT_FN bool geom_level_near(const ContactGeom* geoms, int g0, int g1, c
 // "In contact" for two geoms of the robot: penetrating by more than a nanometre (check_team.h: kCheckTouch, where the reason is
 // written down; the oracle's self_collide uses the same bar)
 constexpr double kSelfTouch = 1e-9;
+constexpr double kNewtonRel = 2e-12;  // oracle: ORC_NEWTON_REL
 RCSH_D int contact_key(int b1, int b2, int g1, int g2, int k) { return (b1 << 23) | (b2 << 18) | (g1 << 13) | (g2 << 8) | k; }
 constexpr int kKeyBox = 31;  // the free box: the scene's last body, its last geom (reference assets/scenes/fr3_simple_pick_up/scene.xml:30-33)
 template <class T>
 RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTable& ck_, const BoxCfg& b_, const LinkRec* links_, const StageTeam<T>& st_,
-                                         const double* bs_, ContactArena<T>& ar_) {
+                                         const double* bs_, ContactArena<T>& ar_, int env) {
   const ContactTable& tab = *in_lds(&tab_);
   const CheckTable& ck = *in_lds(&ck_);
   const BoxCfg& b = *in_lds(&b_);
@@ -1289,7 +1324,13 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       const double cdst = dot3(n, gp) - tab.plane_d;
       if (cdst - cg.rbound <= 0) {
         if (cg.type == 7) {
-          want_plane = true;  // (a hull's support vertices: with the whole wavefront, below)
+          // (a hull's support vertices: with the whole wavefront, below -- if the hull's bounding box reaches the floor at all: link 1's
+          // bounding sphere does in every pose, its box does not, and the staging of its 100-odd vertices cost every substep 11k cycles)
+          double oc[3], nl[3];
+          mulmv(gR, cg.aabb_c, oc);
+          mulTv(gR, n, nl);
+          const double ext = fabs(nl[0]) * cg.aabb_h[0] + fabs(nl[1]) * cg.aabb_h[1] + fabs(nl[2]) * cg.aabb_h[2];
+          want_plane = cdst + dot3(n, oc) - ext <= 0;
         } else if (cg.type == 6) {
           for (int c = 0; c < 8 && nP < 4; ++c) {
             const double loc[3] = {(c & 1 ? cg.size[0] : -cg.size[0]), (c & 2 ? cg.size[1] : -cg.size[1]), (c & 4 ? cg.size[2] : -cg.size[2])};
@@ -1486,6 +1527,55 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
   if (self_on) {
     static_assert(ContactArena<T>::kScratch >= 12 * kMaxCGeom && ContactArena<T>::kScratch >= 3 * 152, "world boxes of the geoms / one hull fit the scratch area");
     double* wb = ar.scratch();
+    // ---- which pairs have to be looked at: a pair found apart by a gap g cannot touch before the joints BETWEEN its two links have moved
+    // the geoms by g (ContactTable::self_lever turns joint motion into a bound on that; the lean DET kernels' SelfSlack, here per
+    // environment in memory because the state has to outlive the launch).  rem[i]: what is left of pair i's gap -- a lower bound of
+    // the geoms' distance NOW; <= 0: look.  In a settled or slowly moving arm nearly every pair is skipped, every substep: the world
+    // boxes, the sphere and box tests and the narrow phase run for the few pairs that are near.  Exact: only pairs proven apart are
+    // skipped (oracle self_collide tests every pair in every substep and finds the same contacts).
+    constexpr int kDp = 12 * kMaxCGeom;  // this substep's joint motion, behind the world boxes
+    static_assert(ContactArena<T>::kScratch >= kDp + 12, "joint motion fits behind the world boxes");
+    TEAM_MARK(16)  // (slots 16-18, 21-23 here: box-less scenes; box_team.h uses them in kernels with a free box)
+    float* const remg = ck.slack ? ck.slack + (size_t)env * kSlackStride : nullptr;
+    float rem[3] = {0.0f, 0.0f, 0.0f};
+    CheckEntry ent[3];
+    if (remg) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int i = lane + 64 * j;
+        rem[j] = i < ck.npair ? remg[i] : 1.0f;
+        ent[j] = ck.ent[i < ck.npair ? i : 0];
+      }
+      double* qpg = reinterpret_cast<double*>(remg + kMaxCheckPairs);
+      if (lane < NL) {
+        const double q = st.q(lane), qp = qpg[lane];
+        qpg[lane] = q;
+        wb[kDp + lane] = tab.self_lever[lane] * fabs(q - qp);
+      }
+      __syncthreads();
+      double dp[NL];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) dp[l] = wb[kDp + l];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int g0 = ent[j].geoms & 0xff, g1 = (ent[j].geoms >> 8) & 0xff;
+        const uint32_t jm = anc_mask<T>(ck.glink[g0]) ^ anc_mask<T>(ck.glink[g1]);
+        double moved = 0.0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) moved += (jm >> l) & 1u ? dp[l] : 0.0;
+        // (rounded up, and by more than the subtraction's own rounding: rem stays a lower bound)
+        if (moved > 0.0) rem[j] -= (float)moved * 1.00001f + 2.5e-7f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ent[j] = ck.ent[lane + 64 * j < ck.npair ? lane + 64 * j : 0];
+    }
+    uint32_t am = 0;  // bit j: pair lane + 64 j has used its slack up
+#pragma unroll
+    for (int j = 0; j < 3; ++j) am |= (lane + 64 * j < ck.npair && !(rem[j] > 0.0f)) ? 1u << j : 0u;
+    uint32_t cm = 0;  // bit j: pair lane + 64 j survived the bounding tests
+    static_assert(kMaxCheckPairs <= 3 * 64, "three pairs per lane");
+    if (__ballot(am != 0)) {
     if (has_geom) {
       double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0};
       if (cg.link >= 0) {
@@ -1506,24 +1596,29 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       for (int k = 0; k < 9; ++k) wb[12 * lane + 3 + k] = gR[k];
     }
     __syncthreads();
-    uint32_t cm = 0;  // bit j: pair lane + 64 j survived the bounding tests
-    static_assert(kMaxCheckPairs <= 3 * 64, "three pairs per lane");
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int i = lane + 64 * j;
-      if (i >= ck.npair) continue;
-      const CheckEntry en = ck.ent[i];
+      if (!((am >> j) & 1u)) continue;
+      const CheckEntry en = ent[j];
       const int g0 = en.geoms & 0xff, g1 = (en.geoms >> 8) & 0xff;
       double Ra[9], Rb[9], ca[3], cb_[3], ha[3], hb[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { ca[k] = wb[12 * g0 + k]; cb_[k] = wb[12 * g1 + k]; ha[k] = ck.gh[g0][k]; hb[k] = ck.gh[g1][k]; }
       const double dd[3] = {ca[0] - cb_[0], ca[1] - cb_[1], ca[2] - cb_[2]};
-      const double rs = en.rsum;
-      if (dot3(dd, dd) > rs * rs) continue;
+      const double rs = en.rsum, d2 = dot3(dd, dd);
+      rem[j] = 0.0f;  // (until one of the tests measures a gap)
+      if (d2 > rs * rs) { rem[j] = (float)(sqrt(d2) - rs) * 0.999999f - 1e-6f; continue; }
 #pragma unroll
       for (int k = 0; k < 9; ++k) { Ra[k] = wb[12 * g0 + 3 + k]; Rb[k] = wb[12 * g1 + 3 + k]; }
-      if (!obb_disjoint(Ra, ca, ha, Rb, cb_, hb)) cm |= 1u << j;
+      double sep = 0.0;
+      if (obb_disjoint(Ra, ca, ha, Rb, cb_, hb, &sep)) { rem[j] = (float)sep * 0.999999f - 1e-6f; continue; }
+      // two boxes (their bounding boxes are the geoms themselves) that do not penetrate by more than the touching bar: no contact
+      if (ck.gtype[g0] == 6 && ck.gtype[g1] == 6 && !(box_box_face_pen(ca, Ra, ha, cb_, Rb, hb) > kSelfTouch)) continue;
+      cm |= 1u << j;
+    }
     }
     __syncthreads();  // (the world boxes are done with: the scratch area stages hulls from here on)
+    TEAM_MARK(17)
     for (uint64_t pend = __ballot(cm != 0); pend; pend = __ballot(cm != 0)) {
       const int src = __ffsll((long long)pend) - 1;  // wave-uniform
       const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cm, src);
@@ -1539,6 +1634,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       int nc = 0;
       double spos[8][3], sn[3] = {0, 0, 0}, sdist[8];
       if (ga.type == 6 && gb.type == 6) {
+        TEAM_COUNT(21)
         if (lane == 0) {
           const int nb = dev_box_box(pa, Ra, ga.size, pb, Rb, gb.size, &spos[0][0], sn, sdist, &ar.stage[0][0]);
           // (a point that touches exactly is no contact: kSelfTouch, oracle SELF_TOUCH)
@@ -1567,7 +1663,12 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
         // boxes' test in every pose); everything else goes through the full refinement, as in the oracle
         const double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};
         double dg[3], gap = 0.0, depth = 0.0;
-        if (!gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap)) nc = mpr_penetration<true>(A, B, &depth, sn, spos[0]);
+        TEAM_COUNT(22)
+        if (!gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap)) { TEAM_COUNT(23) nc = mpr_penetration<true>(A, B, &depth, sn, spos[0]); }
+        else if (lane == src) {  // the pair's slack: the gap Gilbert's direction proves
+          const float gf = (float)gap * 0.999999f - 1e-6f;
+          rem[0] = j == 0 ? gf : rem[0]; rem[1] = j == 1 ? gf : rem[1]; rem[2] = j == 2 ? gf : rem[2];
+        }
         if (!(depth > kSelfTouch)) nc = 0;
         sdist[0] = -depth;
         __syncthreads();  // (the stage is free again)
@@ -1594,6 +1695,12 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       if (nreg + nS + nc > kMaxCon) { too_many_contacts = true; nc = kMaxCon - nreg - nS; }
       nS += nc;
     }
+    if (remg) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (lane + 64 * j < ck.npair) remg[lane + 64 * j] = rem[j];
+    }
+    TEAM_MARK(18)
   }
   const int robot_contacts = totP + totB + nS;
   if (robot_contacts == 0) {  // nothing of the robot touches anything: the fast path keeps the step
@@ -1946,7 +2053,11 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     const double qf = contact_qfrc<T>(ar, st, c, f, bmasks, bR, bp, lane);
     if (lane < NV) { gl -= qf; ar.Gd[lane] = gl; }
     const double g2 = wave_sum(lane < NV ? gl * gl : 0.0);
-    if (b.scale * sqrt(g2) < 1e-12) { newton_done = newton_it; break; }
+    // Converged: the gradient below the absolute bar, or at its round-off floor relative to the contacts' generalised force (the
+    // gradient is the difference of two terms of that size; a contact force of 1e3 N puts the floor above the absolute bar, and the
+    // loop spun at a fixed point until its cap in 2 % of the headline workload's solves: oracle orc_solve_coupled, ORC_NEWTON_REL)
+    const double q2 = wave_sum(lane < NV ? qf * qf : 0.0);
+    if (b.scale * sqrt(g2) < 1e-12 || g2 <= kNewtonRel * kNewtonRel * q2) { newton_done = newton_it; break; }
     TEAM_MARK(48)
     // ---- contact stiffness K_c = G' Hc G (6 x 6 symmetric, 21 entries), summed per body pair through LDS in three
     // batches of seven entries: accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
@@ -2227,13 +2338,20 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     }
     TEAM_MARK(54)
     __syncthreads();
-    if (lane < NV) ar.X[lane] += best * ar.P[lane];
+    bool moved = false;
+    if (lane < NV) {
+      const double xo = ar.X[lane], xn = xo + best * ar.P[lane];
+      moved = xn != xo;
+      ar.X[lane] = xn;
+    }
     if (lane < NL + 1) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) ar.U[lane][k] += best * ar.Up[lane][k];
     }
     at_x = false;
     __syncthreads();
+    // (a step that no longer moves the iterate: a fixed point of the iteration in floating point)
+    if (!__ballot(moved)) { newton_done = newton_it + 1; break; }
   }
 #ifdef RCSH_PHASE_TIMING
   if (lane == 0) {  // (every workgroup) worst iteration count, solves over 20 iterations, capped solves, solves that left on a non-descent direction
@@ -2528,8 +2646,8 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
 // bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
 template <class T, bool FRIC = false>
 RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
-                              ContactArena<T>& ar, const double* gravity) {
-  const uint32_t r = contact_collide<T>(tab, ck, b, links, st, bs, ar);
+                              ContactArena<T>& ar, const double* gravity, int env) {
+  const uint32_t r = contact_collide<T>(tab, ck, b, links, st, bs, ar, env);
   if (!(r & 1u) || !b.resolve) return r & ~1u;
   contact_newton<T, FRIC>(b, st, bs, ar, gravity, links);
   contact_noslip<T>(b, st, bs, ar);

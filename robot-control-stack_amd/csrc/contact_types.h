@@ -56,9 +56,11 @@ struct CheckEntry {
 struct CheckGeom {
   double c[3], rot[9];
 };
+constexpr int kSlackStride = kMaxCheckPairs + 24;  // floats per environment: the pairs' remaining gaps, then the joints seen last (12 doubles)
 struct CheckTable {
   const CheckEntry* ent;
   const CheckGeom* geoms;
+  float* slack;    // [n][kSlackStride] self-contact stage of the contact phase (contact_team.h: contact_collide); null: every pair, every substep
   int32_t npair, ngeom;
   int32_t plane_points;  // the scene has a floor plane and collision geoms with sample points to test against it
   int32_t pad;
@@ -66,6 +68,8 @@ struct CheckTable {
   int32_t gvert[kMaxCGeom][2]; // hull geoms: first vertex, number of vertices (ContactTable::verts)
   int8_t glink[kMaxCGeom];     // the geom's link (-1: welded to the world)
   int8_t pad2[4];
+  int8_t gtype[kMaxCGeom];     // mjtGeom of the geom (ContactGeom::type)
+  int8_t pad3[4];
 };
 
 struct ContactTable {

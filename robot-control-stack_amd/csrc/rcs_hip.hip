@@ -70,11 +70,13 @@ struct rcsh_sim {
   std::vector<CheckGeom> chk_geoms;
   CheckGeom* d_chk_geoms = nullptr;
   CheckEntry* d_chk_ent = nullptr;
+  float* d_slack = nullptr;          // [n][kSlackStride]: the self-contact stage's remaining gaps per pair + the joints it saw last (CheckTable::slack)
+  int chk_unchecked = 0;             // admitted geom pairs past kMaxCheckPairs: neither checked at the end of a launch nor resolved as self contacts
   // per-environment escalation (sim_kernels.h: RunOp::esc_role): a step is the lean launch over the environments not in contact plus
   // the contact-resolving launch over the others
   bool esc_mode = false;
   uint64_t* d_esc = nullptr;       // [3][(n + 63) / 64]: escalated, newly flagged, leaving
-  uint32_t* d_esc_ctr = nullptr;   // [2]
+  uint32_t* d_esc_ctr = nullptr;   // [4] (sim_kernels.h: RunOp::esc_ctr)
   double* d_snap = nullptr;        // [nfields][n]: what the lean launch of a step read (the step is redone from it on a hit)
   uint32_t* d_snap_flags = nullptr;
   int32_t* d_snap_conv = nullptr;
@@ -217,6 +219,7 @@ Params make_params(rcsh_sim* s) {
   P.ctab.plane_mu = s->plane_mu;
   P.chk.ent = s->d_chk_ent;
   P.chk.geoms = s->d_chk_geoms;
+  P.chk.slack = s->d_slack;
   P.chk.npair = (int)s->chk_ent.size();  // (also the pair table of the contact phase's self-contact stage)
   P.chk.ngeom = (int)s->cgeoms.size();
   P.chk.plane_points = P.coll.has_plane ? 1 : 0;
@@ -226,6 +229,8 @@ Params make_params(rcsh_sim* s) {
   std::memset(P.chk.gvert, 0, sizeof(P.chk.gvert));
   std::memset(P.chk.glink, 0, sizeof(P.chk.glink));
   std::memset(P.chk.pad2, 0, sizeof(P.chk.pad2));
+  std::memset(P.chk.gtype, 0, sizeof(P.chk.gtype));
+  std::memset(P.chk.pad3, 0, sizeof(P.chk.pad3));
   for (size_t g = 0; g < s->cgeoms.size() && g < (size_t)kMaxCGeom; ++g) {
     const ContactGeom& cg = s->cgeoms[g];
     double* h = P.chk.gh[g];
@@ -234,6 +239,7 @@ Params make_params(rcsh_sim* s) {
     else { h[0] = h[1] = cg.size[0]; h[2] = cg.size[0] + cg.size[1]; }
     P.chk.gvert[g][0] = cg.vert_adr; P.chk.gvert[g][1] = cg.type == 7 ? cg.vert_num : 0;
     P.chk.glink[g] = (int8_t)cg.link;
+    P.chk.gtype[g] = (int8_t)cg.type;
   }
   return P;
 }
@@ -398,8 +404,14 @@ int upload_contact_table(rcsh_sim* s) {
   build_check_table(s);
   if (s->d_chk_ent) { HIP_TRY(hipStreamSynchronize(s->stream)); HIP_TRY(hipFree(s->d_chk_ent)); s->d_chk_ent = nullptr; }
   if (s->d_chk_geoms) { HIP_TRY(hipFree(s->d_chk_geoms)); s->d_chk_geoms = nullptr; }
-  if ((int)s->chk_ent.size() > kMaxCheckPairs)
-    return fail(RCSH_ERR_MODEL, "more geom pairs than the end-of-launch contact check holds (" + std::to_string(kMaxCheckPairs) + ")");
+  // (a scene with more admitted pairs than a lane keeps entries for is NOT refused -- plain Sim.step users never read the flag --: the
+  // pairs past the capacity stay unchecked, counted and reported: rcsh_sim_contact_check_unchecked_pairs; advisor, round 4)
+  s->chk_unchecked = 0;
+  if ((int)s->chk_ent.size() > kMaxCheckPairs) {
+    s->chk_unchecked = (int)s->chk_ent.size() - kMaxCheckPairs;
+    s->chk_ent.resize(kMaxCheckPairs);
+    s->chk_pairs.resize(kMaxCheckPairs);
+  }
   if (!s->chk_ent.empty()) {
     HIP_TRY(hipMalloc(&s->d_chk_ent, sizeof(CheckEntry) * s->chk_ent.size()));
     HIP_TRY(hipMemcpyAsync(s->d_chk_ent, s->chk_ent.data(), sizeof(CheckEntry) * s->chk_ent.size(), hipMemcpyHostToDevice, s->stream));
@@ -775,6 +787,7 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_geoms); hipFree(s->d_chk_ent);
+  hipFree(s->d_slack);
   hipFree(s->d_esc); hipFree(s->d_esc_ctr); hipFree(s->d_snap); hipFree(s->d_snap_flags); hipFree(s->d_snap_conv);
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_rcolours); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
@@ -896,6 +909,9 @@ int rcsh_sim_reset(rcsh_sim* s, const uint8_t* mask) {
         if (mask[e]) w[e >> 6] &= ~(1ull << (e & 63));
     }
     HIP_TRY(hipMemcpyAsync(s->d_esc, w.data(), sizeof(uint64_t) * 3 * nw, hipMemcpyHostToDevice, s->stream));
+    uint32_t ctr[4] = {0, 0, 0, 0};  // (RunOp::esc_ctr: [1] has to say how many are escalated -- a role-2 launch trusts a zero)
+    for (size_t i = 0; i < nw; ++i) ctr[1] += (uint32_t)__builtin_popcountll(w[i]);
+    HIP_TRY(hipMemcpyAsync(s->d_esc_ctr, ctr, sizeof(ctr), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
   }
   if (!rc && s->box.present) {
@@ -1301,13 +1317,17 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
   if (s->esc_mode && !s->d_esc) {
     const size_t nw = ((size_t)s->n + 63) / 64;
     HIP_TRY(hipMalloc(&s->d_esc, sizeof(uint64_t) * 3 * nw));
-    HIP_TRY(hipMalloc(&s->d_esc_ctr, sizeof(uint32_t) * 2));
+    HIP_TRY(hipMalloc(&s->d_esc_ctr, sizeof(uint32_t) * 4));
     HIP_TRY(hipMalloc(&s->d_snap, sizeof(double) * (size_t)(s->nfields + kMaxRateCams) * s->n));  // (+ the rate-driven cameras' clocks)
     HIP_TRY(hipMalloc(&s->d_snap_flags, sizeof(uint32_t) * s->n));
     HIP_TRY(hipMalloc(&s->d_snap_conv, sizeof(int32_t) * s->n));
     HIP_TRY(hipMemsetAsync(s->d_esc, 0, sizeof(uint64_t) * 3 * nw, s->stream));
-    HIP_TRY(hipMemsetAsync(s->d_esc_ctr, 0, sizeof(uint32_t) * 2, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_esc_ctr, 0, sizeof(uint32_t) * 4, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_snap, 0, sizeof(double) * (size_t)(s->nfields + kMaxRateCams) * s->n, s->stream));
+  }
+  if ((b.resolve & 2) && !s->d_slack) {
+    HIP_TRY(hipMalloc(&s->d_slack, sizeof(float) * (size_t)kSlackStride * s->n));
+    HIP_TRY(hipMemsetAsync(s->d_slack, 0, sizeof(float) * (size_t)kSlackStride * s->n, s->stream));  // (no gap known: every pair is looked at)
   }
   b.noslip_iterations = o->noslip_iterations;
   b.qpos0[2] = 1000.0; b.qpos0[3] = 1.0;
@@ -1355,6 +1375,12 @@ int rcsh_sim_set_contact_check(rcsh_sim* s, int32_t every) {
   if (every < 0) return fail(RCSH_ERR_ARG, "contact check cadence must be >= 0 (0: off, 1: every stepping launch)");
   s->check_every = every;
   s->check_seq = 0;
+  return RCSH_OK;
+}
+int rcsh_sim_contact_check_unchecked_pairs(rcsh_sim* s, int32_t* count) {
+  REQUIRE_SIM(s);
+  if (!count) return fail(RCSH_ERR_ARG, "count is null");
+  *count = s->chk_unchecked;
   return RCSH_OK;
 }
 int rcsh_sim_contact_table_dropped(rcsh_sim* s, int32_t* geom_ids, int32_t capacity, int32_t* count, char* reason, size_t reason_capacity) {
@@ -1417,6 +1443,10 @@ int rcsh_sim_set_state(rcsh_sim* s, const void* blob) {
     const size_t ne = sizeof(uint64_t) * (((size_t)s->n + 63) / 64);
     HIP_TRY(hipMemcpyAsync(s->d_esc, b + ns + nf + nc, ne, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_esc + ne / sizeof(uint64_t), 0, 2 * ne, s->stream));
+    uint32_t ctr[4] = {0, 0, 0, 0};  // (RunOp::esc_ctr[1]: how many are escalated)
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(b + ns + nf + nc);
+    for (size_t i = 0; i < ne / sizeof(uint64_t); ++i) { uint64_t v; std::memcpy(&v, w + i, sizeof(v)); ctr[1] += (uint32_t)__builtin_popcountll(v); }
+    HIP_TRY(hipMemcpyAsync(s->d_esc_ctr, ctr, sizeof(ctr), hipMemcpyHostToDevice, s->stream));
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RCSH_OK;

@@ -125,7 +125,8 @@ struct RunOp {
                           // self contacts resolved: exact, and slow -- the fast path's broad phase knows the floor and the free body only)
   int32_t esc_leave_quiet, esc_pad;  // role 2: an environment leaves after two launches in a row without a contact (default: with its reset only)
   uint64_t* esc;          // [3][(n + 63) / 64]
-  uint32_t* esc_ctr;      // [0] workgroups of the role-2 launch that are done, [1] environments escalated after the last merge
+  uint32_t* esc_ctr;      // [0] workgroups of the role-2 launch that are done, [1] environments escalated after the last merge,
+                          // [2] environments the role-1 launch of this step has flagged (a role-2 launch that finds [1] = [2] = 0 ends at once)
   double* snap;           // [Lay::COUNT][n]
   uint32_t* snap_flags;   // [n]
   int32_t* snap_conv;     // [n]
@@ -220,7 +221,7 @@ __device__ __forceinline__ void esc_finish(const RunOp& op, int n) {
     count += __popcll(a);
   }
   count = wave_incl_scan(count);
-  if ((threadIdx.x & 63u) == 63) { op.esc_ctr[1] = (uint32_t)count; op.esc_ctr[0] = 0; }
+  if ((threadIdx.x & 63u) == 63) { op.esc_ctr[1] = (uint32_t)count; op.esc_ctr[0] = 0; op.esc_ctr[2] = 0; }
 }
 
 // Contact detection against the scene's static plane (flags only): sample points of the collision geoms, link frame
@@ -837,6 +838,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   bool esc_redo = false;  // role 2: this environment was flagged by the lean launch of this step; its step is redone from the copy
   const int esc_role = opk.esc_role;  // (wave-uniform)
   if (esc_role != 0) {
+    // (the contact-resolving launch of a step in which no environment is escalated and none has just been flagged -- every step of a
+    // rollout that touches nothing -- ends here: two scalar loads instead of the masks' scan and the merge, 22 us -> the launch itself)
+    if (esc_role == 2 && opk.esc_ctr[1] == 0 && opk.esc_ctr[2] == 0) return;
     // (role 2 may spread its environments one per workgroup: every workgroup asks)
     const int pick = (e_slot0 < Pk.n || esc_role == 2) ? esc_select(opk, Pk.n, e_slot0, team, esc_redo, esc_role == 2) : -1;
     if (__ballot(pick >= 0) == 0) {  // no environment for any of this workgroup's four slots
@@ -1197,7 +1201,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
         if (nearw) {
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
-            const uint32_t r = contact_phase<T, FRIC>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity);
+            const uint32_t r = contact_phase<T, FRIC>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity,
+                                                      __builtin_amdgcn_readlane(e, k * kTeamLanes));
             if (team == k) {
               coupled = r & 1u;
               hit |= (r >> 8) & 3u;
@@ -1420,7 +1425,10 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
 #endif
     if (esc_role == 1) {
       // per-environment escalation: the step is redone by the contact-resolving launch that follows (RunOp::esc_role)
-      if (leader && hit) atomicOr(reinterpret_cast<unsigned long long*>(lop.esc + ((P.n + 63) >> 6) + (e >> 6)), 1ull << (e & 63));
+      if (leader && hit) {
+        atomicOr(reinterpret_cast<unsigned long long*>(lop.esc + ((P.n + 63) >> 6) + (e >> 6)), 1ull << (e & 63));
+        atomicAdd(lop.esc_ctr + 2, 1u);
+      }
     } else if (leader && hit && !(r.flags & kContactUnresolved)) {
       P.flags[e] = r.flags | kContactUnresolved;
       if (op.write_obs && op.info) op.info[(size_t)e * 8 + 7] = 1;

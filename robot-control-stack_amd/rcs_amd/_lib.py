@@ -179,6 +179,7 @@ EXPORTS = (
     "rcsh_comm_get_unique_id", "rcsh_comm_init", "rcsh_comm_rank", "rcsh_env_allgather_obs_dev", "rcsh_comm_allgather_dev", "rcsh_comm_wait",
     "rcsh_comm_destroy",
     "rcsh_sim_contact_table_dropped",
+    "rcsh_sim_contact_check_unchecked_pairs",
     "rcsh_sim_contact_unresolved",
     "rcsh_sim_set_contact_check",
     "rcsh_sim_contact_escalated",
@@ -222,6 +223,7 @@ def load() -> C.CDLL:
     L.rcsh_sim_set_contact_options.argtypes = [C.c_void_p, C.POINTER(ContactOptions)]
     L.rcsh_sim_contact_escalated.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.rcsh_sim_reset_free_box.argtypes = [C.c_void_p]
+    L.rcsh_sim_contact_check_unchecked_pairs.argtypes = [C.c_void_p, _I32P]
     L.rcsh_sim_contact_table_dropped.argtypes = [C.c_void_p, _I32P, C.c_int32, _I32P, C.c_char_p, C.c_size_t]
     for fn in (L.rcsh_sim_get_free_qpos, L.rcsh_sim_get_free_qvel):
         fn.argtypes = [C.c_void_p, C.c_void_p]

@@ -68,6 +68,14 @@ class Sim:
             names = [self.model.geom_names[g] or f"#{g}" for g in self.undetected_collision_geoms]
             warnings.warn(f"collision geoms {names} exceed the contact table's capacity ({self._contact_table_reason}): their collisions "
                           "with other geoms are NOT detected (the floor test still sees them)", RuntimeWarning, stacklevel=2)
+        unchecked = C.c_int32(0)
+        _lib.check(self._L.rcsh_sim_contact_check_unchecked_pairs(self._h, C.byref(unchecked)))
+        self.unchecked_geom_pairs = int(unchecked.value)
+        if self.unchecked_geom_pairs:
+            import warnings
+
+            warnings.warn(f"{self.unchecked_geom_pairs} admitted geom pairs exceed what the end-of-launch contact check holds: a contact of "
+                          "one of them raises no contact_unresolved flag and is not resolved as a self contact", RuntimeWarning, stacklevel=2)
         # Contacts of the robot's collision geoms (with the floor, with a free body): RESOLVED by default where there is
         # something to manipulate (scenes with a free body: the pick-up task), DETECTED only (collision flags, as the
         # callbacks need them) in scenes without -- there the contact-capable kernel costs the no-contact rollout ~15 %, so it

@@ -1,0 +1,39 @@
+"""dev tool: where an escalated environment's contact-resolving launch spends its cycles (library built with tools/build_timing.sh).
+    python tools/esc_timing.py [n_envs] [n_steps] [window]
+Only workgroup 0 records: of the lean launch (slot 0-15 phases of its four environments) and of the contact-resolving launch (the
+first escalated environment).  Windows without an escalated environment give the lean kernel's own numbers to subtract."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "robot-control-stack_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import rcs_amd._lib as lib
+lib.LIB_PATH = os.path.join(ROOT, "robot-control-stack_amd", "rcs_amd", "librcs_hip_timing.so")
+import numpy as np
+import parity_util as PU
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
+win = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+venv = PU.make_vec_env(n, True)
+joints, grip = PU.synthetic_actions(n, steps, 0)
+venv.reset()
+L = venv.sim._L
+out = (C.c_ulonglong * 64)()
+def read():
+    L.rcsh_debug_team_cycles64(out)
+    return np.array(out[:], dtype=np.float64)
+NAMES = {0: "pos stage", 1: "1", 2: "2", 3: "3", 4: "4", 15: "15", 5: "5", 6: "6", 7: "7", 8: "8", 9: "loop tail", 10: "epilogue+check", 11: "11", 12: "prologue12", 13: "13", 14: "14",
+         16: "collide before self", 17: "self broad", 18: "self narrow", 24: "before collide", 37: "link frames", 38: "lane per geom", 39: "hulls wavefront", 25: "floor/fastpath", 26: "compaction", 27: "rows/qacc_smooth/M", 28: "newton pre", 55: "x update", 48: "rows+grad",
+         49: "stiffness", 50: "Hessian", 51: "row loads", 52: "LDL+solves", 53: "pre linesearch", 54: "linesearch", 30: "forces/Y/K", 31: "noslip rest", 40: "ns rel", 41: "ns owner", 44: "ns slots", 32: "results"}
+base = read()
+t0 = time.time()
+for t in range(steps):
+    venv.step({"joints": joints[t], "gripper": grip[t]})
+    if (t + 1) % win == 0:
+        a = read(); d = a - base; base = a
+        now, ever = venv.sim.contact_escalated()
+        dt = (time.time() - t0) / win; t0 = time.time()
+        print(f"steps {t + 1 - win}..{t}: escalated now {int(now.sum())}, ever {int(ever.sum())}; host {dt * 1e3:.2f} ms/step; contact phases (wg0) {d[33]:.0f}, coupled {d[34]:.0f}, newton its {d[29]:.0f}, ls evals {d[35]:.0f}, noslip sweeps {d[36]:.0f} contacts {d[45]:.0f}")
+        print(f"    Newton (all workgroups): solves {d[60]:.0f}, worst iteration count so far {a[56]:.0f}, solves over 20 iterations {d[57]:.0f}, capped at 100 {d[58]:.0f}, left on a non-descent direction {d[59]:.0f}")
+        print(f"    self stage (wg0): box-box narrow {d[21]:.0f}, hull narrow {d[22]:.0f} of which full MPR {d[23]:.0f}")
+        tot = sum(d[i] for i in NAMES)
+        print("    total marked cycles per step %.0f: " % (tot / win) + ", ".join(f"{NAMES[i]} {d[i] / win:.0f}" for i in NAMES if d[i] > 0))
