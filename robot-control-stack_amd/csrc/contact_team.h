@@ -2360,6 +2360,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
     if (newton_done == 100) atomicAdd(&g_team_cycles[58], 1ull);
     if (newton_done >= 1000) atomicAdd(&g_team_cycles[59], 1ull);
     atomicAdd(&g_team_cycles[60], 1ull);
+    atomicAdd(&g_team_cycles[67], (unsigned long long)(newton_done % 1000));
   }
 #endif
   (void)newton_done;
@@ -2639,21 +2640,7 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
   TEAM_MARK(32)
 }
 
-// The contact phase of one environment, executed by the whole wavefront.  `st` / `bs`: the environment's LDS blocks
-// (robot: pre-step q, qd, motion axes S, mass matrix, qfrc_smooth, limit / equality rows of this substep; box: state).
-// Returns bit 0: coupled (a robot geom is in contact: st.fcon holds the robot's constraint force, bs[kBoxA..] the box's
-// acceleration); bit 4: more than kMaxCon contacts or more than kMaxActive links in contact (results then differ from MuJoCo's);
-// bits 8-9: contact classes (bit 8 arm collision geoms, bit 9 gripper collision geoms) of this position stage.
-template <class T, bool FRIC = false>
-RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
-                              ContactArena<T>& ar, const double* gravity, int env) {
-  const uint32_t r = contact_collide<T>(tab, ck, b, links, st, bs, ar, env);
-  if (!(r & 1u) || !b.resolve) return r & ~1u;
-  contact_newton<T, FRIC>(b, st, bs, ar, gravity, links);
-  contact_noslip<T>(b, st, bs, ar);
-  return r | (in_lds(&ar)->pad[0] ? 16u : 0u);  // bit 4: a capacity of the contact phase overflowed in this substep
-}
-
 #endif  // __HIP__
 
 }  // namespace rcsh
+#include "contact_dense.h"

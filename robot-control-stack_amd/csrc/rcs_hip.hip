@@ -2143,6 +2143,16 @@ extern "C" int rcsh_debug_team_cycles48(unsigned long long* out48) {
   hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : 1;
 }
+extern "C" int rcsh_debug_team_cycles96(unsigned long long* out96, int clear_max) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out96, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 96) != hipSuccess) return 1;
+  if (clear_max) {  // (the maxima are per window)
+    unsigned long long z = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_team_cycles), &z, sizeof(z), sizeof(z) * 66);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_team_cycles), &z, sizeof(z), sizeof(z) * 68);
+  }
+  return 0;
+}
 extern "C" int rcsh_debug_team_cycles64(unsigned long long* out64) {
   hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;

@@ -828,6 +828,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   const RunOp& op = lop;
   const CollTable& lc = lp.coll;
   TEAM_CLOCK_START()
+#ifdef RCSH_PHASE_TIMING
+  const unsigned long long wg_clock0 = __builtin_readcyclecounter();
+#endif
   const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
   // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  Give
   // every XCD one contiguous range of environments, so a 128-byte line of a state field ([field][env], 16
@@ -1201,7 +1204,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
         if (nearw) {
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
-            const uint32_t r = contact_phase<T, FRIC>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity,
+            const uint32_t r = contact_phase<T, FRIC, BOX>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity,
                                                       __builtin_amdgcn_readlane(e, k * kTeamLanes));
             if (team == k) {
               coupled = r & 1u;
@@ -1440,6 +1443,12 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   }
   TEAM_MARK(10)
   TEAM_CLOCK_FLUSH()
+#ifdef RCSH_PHASE_TIMING
+  if (CON && esc_role == 2 && threadIdx.x == 0) {  // this workgroup's share of the contact-resolving launch: sum, count, worst
+    const unsigned long long dt = __builtin_readcyclecounter() - wg_clock0;
+    atomicAdd(&g_team_cycles[64], dt); atomicAdd(&g_team_cycles[65], 1ull); atomicMax(&g_team_cycles[66], dt);
+  }
+#endif
 }
 template <class T, bool FRIC, bool BOX = false, bool CON = false, bool DET = false>
 __global__ void __launch_bounds__(64) k_run_team(Params Pk, RunOp opk) {

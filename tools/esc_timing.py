@@ -17,9 +17,9 @@ venv = PU.make_vec_env(n, True)
 joints, grip = PU.synthetic_actions(n, steps, 0)
 venv.reset()
 L = venv.sim._L
-out = (C.c_ulonglong * 64)()
+out = (C.c_ulonglong * 96)()
 def read():
-    L.rcsh_debug_team_cycles64(out)
+    L.rcsh_debug_team_cycles96(out, 1)
     return np.array(out[:], dtype=np.float64)
 NAMES = {0: "pos stage", 1: "1", 2: "2", 3: "3", 4: "4", 15: "15", 5: "5", 6: "6", 7: "7", 8: "8", 9: "loop tail", 10: "epilogue+check", 11: "11", 12: "prologue12", 13: "13", 14: "14",
          16: "collide before self", 17: "self broad", 18: "self narrow", 24: "before collide", 37: "link frames", 38: "lane per geom", 39: "hulls wavefront", 25: "floor/fastpath", 26: "compaction", 27: "rows/qacc_smooth/M", 28: "newton pre", 55: "x update", 48: "rows+grad",
@@ -35,5 +35,12 @@ for t in range(steps):
         print(f"steps {t + 1 - win}..{t}: escalated now {int(now.sum())}, ever {int(ever.sum())}; host {dt * 1e3:.2f} ms/step; contact phases (wg0) {d[33]:.0f}, coupled {d[34]:.0f}, newton its {d[29]:.0f}, ls evals {d[35]:.0f}, noslip sweeps {d[36]:.0f} contacts {d[45]:.0f}")
         print(f"    Newton (all workgroups): solves {d[60]:.0f}, worst iteration count so far {a[56]:.0f}, solves over 20 iterations {d[57]:.0f}, capped at 100 {d[58]:.0f}, left on a non-descent direction {d[59]:.0f}")
         print(f"    self stage (wg0): box-box narrow {d[21]:.0f}, hull narrow {d[22]:.0f} of which full MPR {d[23]:.0f}")
+        if d[65]:
+            print(f"    contact-resolving launches, all workgroups: {d[65] / win:.1f} workgroups with work per step, mean {d[64] / d[65]:.0f} cycles each, worst {a[66]:.0f}; "
+                  f"contact phases {d[71]:.0f}, coupled {d[72]:.0f} ({d[70] / max(d[72], 1):.2f} contacts each, most {a[68]:.0f}; {d[69]:.0f} on the tree formulation), "
+                  f"Newton iterations per solve {d[67] / max(d[60], 1):.2f}")
+        if d[81] or d[76]:
+            print(f"    per coupled phase, all workgroups: few contacts ({d[81]:.0f}): collide {d[78] / max(d[81], 1):.0f}, Newton {d[79] / max(d[81], 1):.0f}, noslip {d[80] / max(d[81], 1):.0f} cycles; "
+                  f"many ({d[76]:.0f}): collide {d[73] / max(d[76], 1):.0f}, Newton {d[74] / max(d[76], 1):.0f}, noslip {d[75] / max(d[76], 1):.0f}; quiet collision passes {d[82] / max(d[71] - d[72], 1):.0f}")
         tot = sum(d[i] for i in NAMES)
         print("    total marked cycles per step %.0f: " % (tot / win) + ", ".join(f"{NAMES[i]} {d[i] / win:.0f}" for i in NAMES if d[i] > 0))
