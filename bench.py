@@ -574,9 +574,10 @@ def main() -> None:
         substeps_per_launch = mean_sub * env.n_envs
         traffic = None
         tj_extra = {}
-        tpath = os.path.join(ROOT, "profiles", "r4_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r3_traffic.json")
+        import glob
+
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_traffic.json")), key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+        tpath = tfiles[-1] if tfiles else os.path.join(ROOT, "profiles", "r4_traffic.json")  # (the latest round's PMC passes)
         headline = args.mode == "async" and n == N_ENVS and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed
         if os.path.exists(tpath) and headline:  # the PMC passes profiled exactly this workload (profiles/run_profile.sh)
             tj = json.load(open(tpath))  # PMC pass of this same command (profiles/run_profile.sh), bytes per launch

@@ -46,7 +46,7 @@ constexpr int kCheckSep = 8;  // per environment: two remembered separating dire
 constexpr int kCheckBox = 12 * kMaxCGeom;
 constexpr int kCheckGeomWords = (int)(sizeof(ContactGeom) / 8);
 static_assert(sizeof(ContactGeom) % 8 == 0 && 2 * kCheckGeomWords <= 64, "a lane per word of the narrow phase's two geom records");
-constexpr int check_work_doubles(int) { return 4 * kCheckBox + 4 * kCheckSep + 64; }
+constexpr int check_work_doubles(int) { return 4 * kCheckBox + 4 * kCheckSep + 64 + 4 * 12; }  // (+ the teams' joint travel, certifying mode)
 static_assert(4 * kCheckBox >= kSelfStage, "the hull stage overlays the world boxes");
 constexpr int kCheckPer = kMaxCheckPairs / kTeamLanes;
 constexpr int kCheckTrips = (3 * 152 + 63) / 64;  // vertex words per lane and hull (a hull has at most 152 vertices)
@@ -54,7 +54,9 @@ constexpr int kCheckTrips = (3 * 152 + 63) / 64;  // vertex words per lane and h
 // obb_disjoint for this check: true when the two oriented boxes are apart OR overlap by at most `touch` along one of their six
 // face normals (then whatever they contain overlaps by at most that much).  For two BOXES this is the narrow phase already: the
 // fingertip pads of a closed gripper -- two dozen box pairs that touch exactly -- never reach the portal refinement.
-RCSH_D bool obb_apart_or_touching(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb, double touch) {
+// `margin` > 0 (certifying mode): true only when one of the six face normals separates the boxes by MORE than the margin.
+RCSH_D bool obb_apart_or_touching(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb, double touch,
+                                  double margin = 0.0) {
   double C[9], A[9], tv[3];
   const double d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
   mulTv(Ra, d, tv);
@@ -73,6 +75,7 @@ RCSH_D bool obb_apart_or_touching(const double* Ra, const double* ca, const doub
     const double tw = tv[0] * C[j] + tv[1] * C[3 + j] + tv[2] * C[6 + j];
     sep = fmax(sep, fabs(tw) - (hb[j] + ha[0] * A[j] + ha[1] * A[3 + j] + ha[2] * A[6 + j]));
   }
+  if (margin > 0.0) return sep > margin - touch;
   if (sep > -touch) return true;
   bool apart = false;
 #pragma unroll
@@ -152,7 +155,8 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 // Every lane of the wavefront calls this; returns, on every lane of a team, whether the team's environment is in contact.
 template <class T, class CollT>
 RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& tab, const CollT& lc, const LinkRec* links, double* frames,
-                                     double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf) {
+                                     double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf,
+                                     double mpath = 0.0) {
   constexpr int NL = T::NL;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const bool valid = t < NL;
@@ -175,6 +179,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   double* wbox = work + kCheckBox * team;
   double* slots = work + 4 * kCheckBox + kCheckSep * team;
   double* gstage = work + 4 * kCheckBox + 4 * kCheckSep;
+  double* travel = gstage + 64 + 12 * team;  // lever x travel of the team's joints over the launch (certifying mode; zeros otherwise)
   double* stage = work;  // (overlays the world boxes once the broad phase is through)
   if (valid) {
 #pragma unroll
@@ -183,7 +188,24 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     for (int k = 0; k < 3; ++k) F[12 * t + 9 + k] = p[k];
   }
   if (t < kCheckSep) slots[t] = sep_in;
+  if (t < 12) travel[t] = valid ? mpath : 0.0;
   __syncthreads();
+  // Certifying mode (RunOp::check 2; per-environment escalation): a pair counts as apart only if it is PROVEN apart by more than
+  // its margin -- the most the joints between its two links can have moved the geoms relative to each other during the launch
+  // (ContactTable::self_lever x the joints' travel).  A contact at any substep of the launch needs the gap to have been zero then,
+  // and the final gap can exceed the gap at that substep by at most the margin: final gap > margin certifies the WHOLE launch, the
+  // contacts that begin and end inside it included (the blind spot of a check of the final position alone: 8 of 1024 rollouts,
+  // round 4).  Whatever is not proven apart sends the environment to the contact-resolving kernel, which looks in every substep.
+  double mp[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) mp[l] = travel[l];
+  auto margin_of = [&](int la, int lb) -> double {
+    const uint32_t jm = anc_mask<T>(la) ^ anc_mask<T>(lb);
+    double m = 0.0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) m += (jm >> l) & 1u ? mp[l] : 0.0;
+    return m;
+  };
   // ---- world boxes of the geoms: lane t takes geoms t, t + 16 (their link-frame boxes came with the prefetch)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -222,10 +244,12 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
                          R[2] * nrm[0] + R[5] * nrm[1] + R[8] * nrm[2]};
     const double b = dot3(nrm, p) - lc.plane_d;
     const double* sph = lc.link_sphere[t];
-    if (b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < -kCheckTouch) {
+    const double mfl = margin_of(-1, t);
+    const double thr = mfl - kCheckTouch;  // (a contact is a penetration by more than kCheckTouch; nothing moved: the exact test)
+    if (b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < thr) {
       for (int k = lc.link_adr[t]; k < lc.link_adr[t + 1]; ++k) {
         const double* v = lc.xyzr + 4 * (size_t)k;
-        if (b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3] < -kCheckTouch) {
+        if (b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3] < thr) {
           mine = true;
 #ifdef RCSH_CHECK_DEBUG
           atomicAdd(&g_chk_dbg[0], 1);
@@ -237,6 +261,12 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   CHK_MARK(2)
   // ---- geom pairs: bounding spheres (bit j of smask: pair t + 16 j survived), then -- one pair per lane and round -- the boxes
   uint32_t smask = 0;
+  double mj[kCheckPer];  // the margins of the lane's pairs
+#pragma unroll
+  for (int j = 0; j < kCheckPer; ++j) {
+    const int g0 = pf.ent[j].geoms & 0xff, g1 = (pf.ent[j].geoms >> 8) & 0xff;
+    mj[j] = margin_of(ck.glink[g0], ck.glink[g1]);
+  }
   if (live && !(ck.pad & 4)) {
     // (all the centres first, then the arithmetic: read pair by pair the wavefront would wait for LDS a dozen times)
     double ca[kCheckPer][3], cb[kCheckPer][3];
@@ -251,7 +281,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     for (int j = 0; j < kCheckPer; ++j) {
       const int i = t + kTeamLanes * j;
       const double d[3] = {ca[j][0] - cb[j][0], ca[j][1] - cb[j][1], ca[j][2] - cb[j][2]};
-      const double rs = pf.ent[j].rsum;
+      const double rs = pf.ent[j].rsum + mj[j];
       smask |= i < npair && dot3(d, d) <= rs * rs ? 1u << j : 0u;
     }
   }
@@ -267,15 +297,16 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
       smask &= smask - 1;
       // (the entry of round j: a select chain over the lane's registers -- a run-time index would put them into scratch)
       uint32_t gg = 0;
+      double mm = 0.0;
 #pragma unroll
-      for (int k = 0; k < kCheckPer; ++k) gg = k == j ? pf.ent[k].geoms : gg;
+      for (int k = 0; k < kCheckPer; ++k) { gg = k == j ? pf.ent[k].geoms : gg; mm = k == j ? mj[k] : mm; }
       const int g0 = gg & 0xff, g1 = (gg >> 8) & 0xff;
       double Ra[9], Rb[9], ca[3], cb[3], ha[3], hb[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { ca[k] = wbox[12 * g0 + k]; cb[k] = wbox[12 * g1 + k]; ha[k] = ck.gh[g0][k]; hb[k] = ck.gh[g1][k]; }
 #pragma unroll
       for (int k = 0; k < 9; ++k) { Ra[k] = wbox[12 * g0 + 3 + k]; Rb[k] = wbox[12 * g1 + 3 + k]; }
-      if (!obb_apart_or_touching(Ra, ca, ha, Rb, cb, hb, kCheckTouch)) {
+      if (!obb_apart_or_touching(Ra, ca, ha, Rb, cb, hb, kCheckTouch, mm)) {
         cmask |= 1u << j;
 #ifdef RCSH_CHECK_DEBUG
         atomicAdd(&g_chk_dbg[33], 1);
@@ -297,8 +328,10 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     if (holder) cmask &= ~(1u << u);
     const int pidx = t1 + kTeamLanes * u;
     uint32_t gg = 0;
+    double mu_ = 0.0;
 #pragma unroll
-    for (int k = 0; k < kCheckPer; ++k) gg = k == u ? pf.ent[k].geoms : gg;
+    for (int k = 0; k < kCheckPer; ++k) { gg = k == u ? pf.ent[k].geoms : gg; mu_ = k == u ? mj[k] : mu_; }
+    const double mteam = lane_get(mu_, (lane & 48) + t1);  // the margin of this pair in the lane's team (its lane t1 holds it)
     gg = (uint32_t)__builtin_amdgcn_readlane((int)gg, src);
     const int g0 = gg & 0xff, g1 = (gg >> 8) & 0xff;
     const int na = 3 * ck.gvert[g0][1], nb = 3 * ck.gvert[g1][1];
@@ -352,7 +385,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         mulmv(LR, dl, dw);
         MprPt s;
         mpr_support<true>(A, B, dw, s);
-        apart = dot3(s.v, dw) < 0;  // the support of A - B along the remembered direction is still negative: apart
+        apart = dot3(s.v, dw) < (mteam > 0.0 ? kCheckTouch - mteam : 0.0);  // the support of A - B along the remembered direction is still negative (by more than the margin): apart
         x0[0] = s.v[0]; x0[1] = s.v[1]; x0[2] = s.v[2];
       }
 #ifndef RCSH_NO_GILBERT
@@ -360,7 +393,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         // a few support queries towards a separating direction before the full refinement (contact_team.h: gilbert_apart); the margin
         // keeps its verdicts far from the nanometre the check calls contact
         double dg[3], gap = 0.0;
-        if (gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap)) {
+        if (gilbert_apart<true>(A, B, x0, 5, fmax(1e-5, mteam), dg, &gap)) {
           apart = true;
           double dl[3];
           mulTv(LR, dg, dl);
@@ -369,7 +402,8 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         }
       }
 #endif
-      if (!apart && !(ck.pad & 8)) {
+      if (!apart && mteam > 0.0) mine = true;  // (certifying mode: not proven apart by more than the margin)
+      else if (!apart && !(ck.pad & 8)) {
         double dir[3], depth = 0.0;
         if (mpr_penetration<true, kMprDepth>(A, B, &depth, dir, nullptr)) {
           if (depth > kCheckTouch) {

@@ -681,7 +681,9 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
       if (nc_ > (unsigned long long)kDenseCon) atomicAdd(&g_team_cycles[69], 1ull);
     } else {
       atomicAdd(&g_team_cycles[82], pc1 - pc0);  // collision passes that found nothing
+      s_wg_acc[7] += pc1 - pc0;
     }
+    s_wg_acc[3] += 1;
   }
 #endif
   if (!(r & 1u) || !b.resolve) return r & ~1u;
@@ -694,7 +696,10 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
     contact_noslip_dense<T, BOXD>(b, st, bs, ar);
     PHASE_CLOCK(pc3)
 #ifdef RCSH_PHASE_TIMING
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_team_cycles[78], pc1 - pc0); atomicAdd(&g_team_cycles[79], pc2 - pc1); atomicAdd(&g_team_cycles[80], pc3 - pc2); atomicAdd(&g_team_cycles[81], 1ull); }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&g_team_cycles[78], pc1 - pc0); atomicAdd(&g_team_cycles[79], pc2 - pc1); atomicAdd(&g_team_cycles[80], pc3 - pc2); atomicAdd(&g_team_cycles[81], 1ull);
+      s_wg_acc[0] += pc1 - pc0; s_wg_acc[1] += pc2 - pc1; s_wg_acc[2] += pc3 - pc2; s_wg_acc[4] += 1; s_wg_acc[5] += (unsigned long long)in_lds(&ar)->ncon;
+    }
 #endif
     return r | (in_lds(&ar)->pad[0] ? 16u : 0u);
   }
@@ -704,7 +709,10 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
   contact_noslip<T>(b, st, bs, ar);
   PHASE_CLOCK(pc3)
 #ifdef RCSH_PHASE_TIMING
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_team_cycles[73], pc1 - pc0); atomicAdd(&g_team_cycles[74], pc2 - pc1); atomicAdd(&g_team_cycles[75], pc3 - pc2); atomicAdd(&g_team_cycles[76], 1ull); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&g_team_cycles[73], pc1 - pc0); atomicAdd(&g_team_cycles[74], pc2 - pc1); atomicAdd(&g_team_cycles[75], pc3 - pc2); atomicAdd(&g_team_cycles[76], 1ull);
+    s_wg_acc[0] += pc1 - pc0; s_wg_acc[1] += pc2 - pc1; s_wg_acc[2] += pc3 - pc2; s_wg_acc[4] += 1; s_wg_acc[5] += (unsigned long long)in_lds(&ar)->ncon; s_wg_acc[6] += 1;
+  }
 #endif
   (void)few;
   return r | (in_lds(&ar)->pad[0] ? 16u : 0u);  // bit 4: a capacity of the contact phase overflowed in this substep

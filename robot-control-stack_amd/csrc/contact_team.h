@@ -1619,6 +1619,74 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
     }
     __syncthreads();  // (the world boxes are done with: the scratch area stages hulls from here on)
     TEAM_MARK(17)
+    // ---- pairs of two BOXES (the fingers' pads against each other: a gripper pressed shut brings two dozen of them, four to eight
+    // points each): every lane runs the collider for its own pair -- the serial loop below spent 40k cycles of one lane per pair, 570k
+    // per substep of such an environment.  A lane needs 48 doubles of LDS for its clipping polygons: kBoxPool lanes at a time.
+    {
+      constexpr int kPoolA = ContactArena<T>::kScratch / 48, kPoolB = (64 * 8) / 48, kBoxPool = kPoolA + kPoolB;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int g0 = ent[j].geoms & 0xff, g1 = (ent[j].geoms >> 8) & 0xff;
+        bool want = ((cm >> j) & 1u) && ck.gtype[g0] == 6 && ck.gtype[g1] == 6;
+        for (uint64_t wm = __ballot(want); wm; wm = __ballot(want)) {
+          const int rank = __popcll(wm & ((1ull << lane) - 1ull));
+          const bool run = want && rank < kBoxPool;
+          int nc = 0;
+          double spos[8][3], sn[3] = {0, 0, 0}, sdist[8];
+          if (run) {
+            TEAM_COUNT(21)
+            const ContactGeom& ga = tab.geoms[g0];
+            const ContactGeom& gb = tab.geoms[g1];
+            double Ra[9], pa[3], Rb[9], pb[3];
+            self_geom_world(ga, &arF[0][0], Ra, pa);
+            self_geom_world(gb, &arF[0][0], Rb, pb);
+            double* poly = rank < kPoolA ? ar.scratch() + 48 * rank : &ar.stage[0][0] + 48 * (rank - kPoolA);
+            const int nb = dev_box_box(pa, Ra, ga.size, pb, Rb, gb.size, &spos[0][0], sn, sdist, poly);
+            // (a point that touches exactly is no contact: kSelfTouch, oracle SELF_TOUCH)
+            for (int k = 0; k < nb; ++k) {
+              if (!(sdist[k] < -kSelfTouch)) continue;
+              spos[nc][0] = spos[k][0]; spos[nc][1] = spos[k][1]; spos[nc][2] = spos[k][2];
+              sdist[nc] = sdist[k];
+              ++nc;
+            }
+          }
+          // their places at the end of the record area: a running count over the lanes
+          int incl = nc;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int up = __builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, incl);
+            incl += lane >= d ? up : 0;
+          }
+          const int total = __builtin_amdgcn_readlane(incl, 63), first = nS + incl - nc;
+          if (run && nc > 0) {
+            const ContactGeom& ga = tab.geoms[g0];
+            const ContactGeom& gb = tab.geoms[g1];
+            int c2 = 0;  // what the collision callbacks make of the pair (rcs_hip.hip: list_geom_pairs)
+            if ((ga.cls | gb.cls) & 1) c2 |= 1;
+            if (!((ga.cls & 4) && (gb.cls & 4)) && ((ga.cls | gb.cls) & 16) && !(gb.cls & 8)) c2 |= 2;
+            const int la = ga.link >= 0 ? ga.link : kWorld, lb = gb.link >= 0 ? gb.link : kWorld;
+            const bool fwd = ga.body < gb.body;
+            for (int k = 0; k < nc; ++k) {
+              if (nreg + first + k >= kMaxCon) break;
+              const int c = kMaxCon - 1 - (first + k);
+              double* r = ar.rec[c];
+              r[0] = spos[k][0]; r[1] = spos[k][1]; r[2] = spos[k][2];
+              r[3] = sn[0]; r[4] = sn[1]; r[5] = sn[2];
+              r[6] = sdist[k];
+              r[7] = fmax(ga.mu, gb.mu);
+              r[8] = ga.invweight + gb.invweight;
+              ar.cb[c] = la | (lb << 8) | (c2 << 16);
+              arkey[c] = fwd ? contact_key(ga.body, gb.body, g0 + 1, g1 + 1, k) : contact_key(gb.body, ga.body, g1 + 1, g0 + 1, k);
+            }
+          }
+          int add = total;
+          if (nreg + nS + add > kMaxCon) { too_many_contacts = true; add = kMaxCon - nreg - nS; }
+          nS += add;
+          if (run) { cm &= ~(1u << j); want = false; }
+        }
+      }
+      __syncthreads();  // (the polygons' LDS goes back to the hulls)
+    }
     for (uint64_t pend = __ballot(cm != 0); pend; pend = __ballot(cm != 0)) {
       const int src = __ffsll((long long)pend) - 1;  // wave-uniform
       const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cm, src);

@@ -86,6 +86,7 @@ struct StageTeam {
 __device__ unsigned long long g_team_cycles[96];  // 64..95: statistics over ALL workgroups (the contact-resolving launch of an escalated step)
 __shared__ unsigned long long s_team_cycles[64];
 __shared__ unsigned long long s_team_mark;
+__shared__ unsigned long long s_wg_acc[8];  // this workgroup's contact phases: collide / Newton / noslip cycles, phases, coupled, contacts, tree-formulation solves
 #define TEAM_MARK(idx)                                            \
   if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
     const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -97,6 +98,7 @@ __shared__ unsigned long long s_team_mark;
 #define TEAM_CLOCK_START()                                        \
   if (blockIdx.x == 0 && threadIdx.x == 0) {                      \
     for (int k_ = 0; k_ < 64; ++k_) s_team_cycles[k_] = 0;        \
+    for (int k_ = 0; k_ < 8; ++k_) s_wg_acc[k_] = 0;              \
     s_team_mark = __builtin_readcyclecounter();                   \
   }
 #define TEAM_CLOCK_FLUSH()                                        \

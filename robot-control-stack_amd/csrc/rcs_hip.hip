@@ -535,7 +535,8 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
       // by the whole batch on the contact-resolving kernel, or environment by environment (RunOp::esc_role)
       if constexpr (T::NARM == 7 && T::GRIP) {
         if (esc) {
-          op.esc_role = 1; op.check = 1;
+          static const int certify = [] { const char* e = std::getenv("RCSH_CHECK_CERTIFY"); return e ? std::atoi(e) : 0; }();
+          op.esc_role = 1; op.check = certify ? 2 : 1;
           go(N{}, N{}, N{});
           op.esc_role = 2; op.check = 0;
           static const int leave_quiet = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();

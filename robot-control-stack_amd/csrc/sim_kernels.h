@@ -102,7 +102,8 @@ struct RunOp {
   int32_t nsteps;         // >= 0: Sim.step(nsteps); < 0: Sim.step_until_convergence()
   int32_t write_obs;
   int32_t observe_only;   // an observation-only pass (nsteps = 0) that must leave the rendering records of the last stepping launch alone
-  int32_t check;          // end the launch with the check for contacts nobody resolves (check_team.h; the host decides the cadence)
+  int32_t check;          // end the launch with the check for contacts nobody resolves (check_team.h; the host decides the cadence);
+                          // 2: certifying -- whatever cannot be PROVEN apart by more than it travelled during the launch counts as a hit
   const uint8_t* mask;    // optional, device
   const double* action;   // [n][action_width], device
   const float* gripper;   // [n], device
@@ -830,6 +831,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   TEAM_CLOCK_START()
 #ifdef RCSH_PHASE_TIMING
   const unsigned long long wg_clock0 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) s_wg_acc[k_] = 0;
 #endif
   const int team = threadIdx.x / kTeamLanes, t = threadIdx.x % kTeamLanes;
   // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  Give
@@ -1082,8 +1084,18 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     box_r2 = bc.size[0] * bc.size[0] + bc.size[1] * bc.size[1] + bc.size[2] * bc.size[2];
   }
   TEAM_MARK(11)
+  // how far every joint travels over this launch's substeps (the certifying check, check_team.h: a contact that begins AND ends inside
+  // the launch needs the geoms to cover their final gap on the way)
+  double chk_path = 0.0, chk_qlast = 0.0;
+  bool chk_first = true;
   while (going) {
     const bool stepping = (going >> (threadIdx.x & 48)) & 1u;
+    if (op.check == 2 && t < T::NL) {
+      const double qn = st.q(t);
+      chk_path += chk_first ? 0.0 : fabs(qn - chk_qlast);
+      chk_qlast = qn;
+      chk_first = false;
+    }
     if (leader && stepping && has_cb && r.time - cb_due > robot_period) {
       plain_callbacks<T, ST>(P, r);
       cb_due = fmin(r.cb(0), r.cb(1));
@@ -1409,6 +1421,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   if (do_check) {  // (wave-uniform)
     static_assert(sizeof(LinkRec) * T::NL >= sizeof(double) * 12 * T::NL * kTeams, "the links' world frames fit where their records were");
     const double q_final = live && t < T::NL ? st.q(t) : 0.0;
+    // (certifying check: lever x travel of the lane's joint, the last substep's included; 0: the check of the final position alone)
+    const double chk_mpath = op.check == 2 && live && t < T::NL ? lp.ctab.self_lever[t] * (chk_path + (chk_first ? 0.0 : fabs(q_final - chk_qlast))) : 0.0;
     __syncthreads();
     double* const sep = P.S + (size_t)Lay<T>::SEP * P.n + (live ? e : 0);
     // (an environment that carries the flag already has nothing to find out: its team sits the check out -- a pair that stays in
@@ -1422,7 +1436,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       static_assert(sizeof(ContactArena<T>) >= sizeof(double) * check_work_doubles(T::NL), "the check's workspace fits the contact arena");
       check_work = reinterpret_cast<double*>(&larena[0]);
     }
-    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, !CON, sep_in, sep, P.n, chk_pf);
+    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, !CON, sep_in, sep, P.n, chk_pf,
+                                                 chk_mpath);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif
@@ -1446,7 +1461,11 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
 #ifdef RCSH_PHASE_TIMING
   if (CON && esc_role == 2 && threadIdx.x == 0) {  // this workgroup's share of the contact-resolving launch: sum, count, worst
     const unsigned long long dt = __builtin_readcyclecounter() - wg_clock0;
-    atomicAdd(&g_team_cycles[64], dt); atomicAdd(&g_team_cycles[65], 1ull); atomicMax(&g_team_cycles[66], dt);
+    atomicAdd(&g_team_cycles[64], dt); atomicAdd(&g_team_cycles[65], 1ull);
+    if (atomicMax(&g_team_cycles[66], dt) < dt) {  // the worst workgroup so far: what it did (racy among near-ties: a development figure)
+      for (int k_ = 0; k_ < 8; ++k_) g_team_cycles[83 + k_] = s_wg_acc[k_];
+      g_team_cycles[91] = (unsigned long long)e;
+    }
   }
 #endif
 }

@@ -42,5 +42,8 @@ for t in range(steps):
         if d[81] or d[76]:
             print(f"    per coupled phase, all workgroups: few contacts ({d[81]:.0f}): collide {d[78] / max(d[81], 1):.0f}, Newton {d[79] / max(d[81], 1):.0f}, noslip {d[80] / max(d[81], 1):.0f} cycles; "
                   f"many ({d[76]:.0f}): collide {d[73] / max(d[76], 1):.0f}, Newton {d[74] / max(d[76], 1):.0f}, noslip {d[75] / max(d[76], 1):.0f}; quiet collision passes {d[82] / max(d[71] - d[72], 1):.0f}")
+        if a[66]:
+            print(f"    worst workgroup of the window (environment {a[91]:.0f}): {a[66]:.0f} cycles; contact phases {a[86]:.0f}, coupled {a[87]:.0f} with {a[88] / max(a[87], 1):.1f} contacts each "
+                  f"({a[89]:.0f} on the tree formulation); collide {a[83]:.0f}, Newton {a[84]:.0f}, noslip {a[85]:.0f}, quiet collision passes {a[90]:.0f}")
         tot = sum(d[i] for i in NAMES)
         print("    total marked cycles per step %.0f: " % (tot / win) + ", ".join(f"{NAMES[i]} {d[i] / win:.0f}" for i in NAMES if d[i] > 0))
