@@ -361,6 +361,12 @@ def main() -> None:
                 exchange.close()
             exchange = HostStagedExchange()
             args.dist_backend = "the rendezvous socket through host memory (the C-ABI RCCL communicator could not be created: " + (comm_error or "on another rank") + ")"
+    elif world > 1 and args.dist_backend == "sdma":
+        # the same slot protocol over copy engines (rcsh_comm_copy_*): blocks written into the peers' IPC-mapped receive buffers, no
+        # collective kernel (rcs_amd.envs.sharding.CopyObservationExchange).  One rank per process; ranks may share a device.
+        from rcs_amd.envs.sharding import CopyObservationExchange
+
+        exchange = CopyObservationExchange(env.sim, rank, world, lambda blob: [bytes(b) for b in rdv.gather(blob)], n_rows=n, width=ow)
     elif world > 1:
         exchange = HostStagedExchange()
 
@@ -541,7 +547,7 @@ def main() -> None:
     finite = bool(np.isfinite(obs_host).all())
     if task_out is not None:
         finite = finite and bool(np.isfinite(task_out.download()).all())
-    rccl_exchange = exchange is not None and args.dist_backend == "nccl"
+    rccl_exchange = exchange is not None and args.dist_backend in ("nccl", "sdma")  # (device-side carriers: posted and waited for on streams)
 
     SCENE_OF = {"fr3": "fr3_empty_world", "xarm7": "xarm7_empty_world", "xarm7_box": "xarm7_box_world", "xarm7_pick": "xarm7_pick_world", "arm6": "arm6_empty_world",
                 "ur5e": "ur5e_empty_world", "so101": "so101_empty_world"}
@@ -619,7 +625,7 @@ def main() -> None:
                 "episode_length": episode or None,
                 "depth_frames": (f"{args.cameras} at {args.resolution}, one ray-cast uint16 frame per camera per env-step "
                                  f"({len(cam_out) * n * int(args.resolution.split('x')[0]) * int(args.resolution.split('x')[1]) / (elapsed / args.steps) / 1e9:.2f} G rays/s incl. the physics)") if cam_out else None,
-                "exchange": (("RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)" if rccl_exchange else f"all-gather over {args.dist_backend}")
+                "exchange": ((("copy engines behind the C-ABI (rcsh_comm_copy_*: every rank writes its block into the peers' IPC-mapped receive buffers, one wavefront waits for the flag words)" if args.dist_backend == "sdma" else "RCCL ncclAllGather behind the C-ABI (rcsh_env_allgather_obs_dev)") if rccl_exchange else f"all-gather over {args.dist_backend}")
                              + f" of obs [N,{ow}] f64 per step, double-buffered, overlapped with the next env-step") if world > 1 else "none (1 GPU)",
                 "contacts_seen": contacts_seen,
                 "contacts_resolved": contacts_resolved,

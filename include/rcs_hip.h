@@ -477,6 +477,19 @@ int rcsh_env_allgather_obs_dev(rcsh_sim* sim, int32_t slot, const double* local_
 int rcsh_comm_allgather_dev(rcsh_sim* sim, int32_t slot, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
 int rcsh_comm_wait(rcsh_sim* sim, int32_t slot, int32_t block_host); /* 0: the handle's stream waits for the slot's gather; 1: the host does */
 int rcsh_comm_destroy(rcsh_sim* sim);
+/* The same exchange over COPY ENGINES instead of RCCL's collective kernel (which needs 261-280 registers a lane and finds no SIMD free
+ * beside a full batch's stepping wavefronts: its gather then starts when the env-step ends).  Every rank writes its block into the
+ * receive buffer of every peer with asynchronous copies (SDMA over xGMI, one stream per peer), followed by an 8-byte sequence number
+ * into a flag word of the peer; one 64-lane wavefront per gather waits for the flag words.  Set-up:
+ *   every rank: rcsh_comm_copy_create(sim, rank, world, bytes_per_rank, blob)  -- allocates the two receive buffers and the flags,
+ *   exports them; all-gather the blobs over any side channel; every rank: rcsh_comm_copy_connect(sim, blobs[world]).
+ * Then rcsh_comm_allgather_dev / rcsh_env_allgather_obs_dev / rcsh_comm_wait / rcsh_comm_destroy as with RCCL, with ONE difference:
+ * the receive buffer of a slot is the carrier's (rcsh_comm_copy_recv_buffer), since peers have to have it mapped.  World <= 16,
+ * one rank per process. */
+#define RCSH_COMM_COPY_BLOB_BYTES 256
+int rcsh_comm_copy_create(rcsh_sim* sim, int32_t rank, int32_t world, size_t bytes_per_rank, uint8_t blob[RCSH_COMM_COPY_BLOB_BYTES]);
+int rcsh_comm_copy_connect(rcsh_sim* sim, const uint8_t* blobs /* [world][RCSH_COMM_COPY_BLOB_BYTES], by rank */);
+int rcsh_comm_copy_recv_buffer(rcsh_sim* sim, int32_t slot, void** recv_dev);
 
 /* device allocation helpers so a host language without a HIP binding can keep rollouts resident */
 int rcsh_dev_alloc(rcsh_sim* sim, size_t bytes, void** ptr);

@@ -415,30 +415,35 @@ RCSH_D void mpr_support(const Shape& a, const Shape& b, const double* dir, MprPt
 // and the direction it ends on has a larger gap than the one MPR stops at, so the remembered direction survives more motion and
 // the slack credited to the pair is larger.  Used as an accelerator only: a failure (touching, overlapping, or just slow -- the
 // iteration zigzags near contact) falls through to MPR, and `margin` keeps its verdicts away from the band of MPR's own tolerance.
+// `extra`: support queries spent AFTER the first proof on a better one (a larger gap: the slack a caller credits the pair with -- the
+// first direction that separates often proves a millimetre where the shapes are centimetres apart, and the pair is back a substep later).
 template <bool TEAM>
-RCSH_D bool gilbert_apart(const Shape& A, const Shape& B, const double* x0, int iters, double margin, double* dir, double* gap) {
+RCSH_D bool gilbert_apart(const Shape& A, const Shape& B, const double* x0, int iters, double margin, double* dir, double* gap, int extra = 0) {
   double x[3] = {x0[0], x0[1], x0[2]};
+  bool proven = false;
   for (int it = 0; it < iters; ++it) {
     const double n2 = dot3(x, x);
-    if (!(n2 > 1e-16)) return false;
+    if (!(n2 > 1e-16)) return proven;
     const double inv = 1.0 / sqrt(n2);
     const double d[3] = {-x[0] * inv, -x[1] * inv, -x[2] * inv};
     MprPt s;
     mpr_support<TEAM>(A, B, d, s);
     const double h = dot3(s.v, d);
     if (h < -margin) {
-      dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2];
-      *gap = -h;
-      return true;
-    }
+      const bool better = !proven || -h > *gap, much = !proven || -h > 1.2 * *gap;
+      if (better) { dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2]; *gap = -h; }
+      proven = true;
+      if (extra <= 0 || !much) return true;
+      --extra;
+    } else if (proven) return true;
     const double e[3] = {s.v[0] - x[0], s.v[1] - x[1], s.v[2] - x[2]};
     const double ee = dot3(e, e);
-    if (!(ee > 1e-24)) return false;
+    if (!(ee > 1e-24)) return proven;
     double tt = -dot3(x, e) / ee;
     tt = tt < 0 ? 0.0 : (tt > 1 ? 1.0 : tt);
     x[0] += tt * e[0]; x[1] += tt * e[1]; x[2] += tt * e[2];
   }
-  return false;
+  return proven;
 }
 RCSH_D void portal_dir(const MprPt& p1, const MprPt& p2, const MprPt& p3, double* dir) {
   const double e1[3] = {p2.v[0] - p1.v[0], p2.v[1] - p1.v[1], p2.v[2] - p1.v[2]}, e2[3] = {p3.v[0] - p1.v[0], p3.v[1] - p1.v[1], p3.v[2] - p1.v[2]};
@@ -497,7 +502,8 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   double l = sqrt(dot3(p0.v, p0.v));
   for (int k = 0; k < 3; ++k) dir[k] = -p0.v[k] / l;
   mpr_support<TEAM>(A, B, dir, p1);
-  if (dot3(p1.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; return 0; }
+  // (a separating direction: `depth`, where the caller gave one, takes the support of A - B along it -- minus a lower bound of the distance)
+  if (dot3(p1.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; if (WANT == kMprFull && depth) *depth = dot3(p1.v, dir); return 0; }
   cross3(p0.v, p1.v, dir);
   l = sqrt(dot3(dir, dir));
   if (l < 1e-12) {
@@ -510,7 +516,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   }
   for (int k = 0; k < 3; ++k) dir[k] /= l;
   mpr_support<TEAM>(A, B, dir, p2);
-  if (dot3(p2.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; return 0; }
+  if (dot3(p2.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; if (WANT == kMprFull && depth) *depth = dot3(p2.v, dir); return 0; }
   for (int k = 0; k < 3; ++k) { va[k] = p1.v[k] - p0.v[k]; vb[k] = p2.v[k] - p0.v[k]; }
   cross3(va, vb, dir);
   l = sqrt(dot3(dir, dir));
@@ -522,7 +528,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   for (int guard = 0;; ++guard) {
     if (guard > 100) { dir_out[0] = dir_out[1] = dir_out[2] = 0.0; return 0; }
     mpr_support<TEAM>(A, B, dir, p3);
-    if (dot3(p3.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; return 0; }
+    if (dot3(p3.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; if (WANT == kMprFull && depth) *depth = dot3(p3.v, dir); return 0; }
     bool cont = false;
     cross3(p1.v, p3.v, va);
     if (dot3(va, p0.v) < -kMinVal) { p2 = p3; cont = true; }
@@ -545,6 +551,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
     if (dv4 < 0 || dv4 - dmax <= kTol || it > kIter) {
       const double keep = dv4 < 0 ? 1.0 : 0.0;
       dir_out[0] = keep * dir[0]; dir_out[1] = keep * dir[1]; dir_out[2] = keep * dir[2];
+      if (WANT == kMprFull && depth && dv4 < 0) *depth = dv4;
       return 0;
     }
     expand_portal(p0, p1, p2, p3, p4);
@@ -1262,6 +1269,116 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
   int32_t* arkey = ar.keyp();
   TEAM_MARK(24)
   TEAM_COUNT(33)
+  const bool self_on = (b.resolve & 2) && ck.npair > 0;  // (wave-uniform) contacts between two geoms of the robot are resolved
+  // ---- which geom pairs (and which geoms against the floor) have to be looked at AT ALL in this substep: a pair found apart by a gap g
+  // cannot touch before the joints BETWEEN its two links have moved the geoms by g, a geom found above the floor by h not before the
+  // joints on its chain have moved it by h (ContactTable::self_lever turns joint motion into a bound on that; the lean DET kernels'
+  // SelfSlack, here per environment in memory because the state has to outlive the launch).  rem[i] / remf: what is left of pair i's gap
+  // / of the lane's geom's height -- lower bounds of the distances NOW; <= 0: look.  An escalated environment that touches nothing (six
+  // of seven, at any substep of the headline rollout) has every gap left and leaves here: no link frames, no geom tests -- 39.5k cycles
+  // of every substep before.  Exact: only what is proven apart is skipped (oracle self_collide / plane tests look at everything in every
+  // substep and find the same contacts).
+  constexpr int kDp = 12 * kMaxCGeom;  // this substep's joint motion, behind the world boxes
+  static_assert(ContactArena<T>::kScratch >= kDp + 12, "joint motion fits behind the world boxes");
+  float rem[3] = {0.0f, 0.0f, 0.0f}, remf = 0.0f;
+  CheckEntry ent[3] = {};
+  uint32_t am = 0;  // bit j: pair lane + 64 j has used its slack up
+  float* const remg = self_on && ck.slack ? ck.slack + (size_t)env * kSlackStride : nullptr;
+  if (self_on) {
+    double* wb = ar.scratch();
+    if (remg) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int i = lane + 64 * j;
+        rem[j] = i < ck.npair ? remg[i] : 1.0f;
+        ent[j] = ck.ent[i < ck.npair ? i : 0];
+      }
+      remf = lane < tab.ngeom ? remg[kSlackFloor + lane] : 1.0f;
+      double* qpg = reinterpret_cast<double*>(remg + kMaxCheckPairs);
+      if (lane < NL) {
+        const double q = st.q(lane), qp = qpg[lane];
+        qpg[lane] = q;
+        wb[kDp + lane] = fabs(q - qp);
+      }
+      // moved[l][c]: how far this substep's joint motion can have moved a point of a geom ON link l relative to the frame of link c (an
+      // ancestor-or-self of l; c = -1: the world) -- the joints of l's chain below c, each with ITS lever for link l (CheckTable::lev).
+      // A pair is charged moved[la][c] + moved[lb][c], c the deepest common ancestor of its two links; a geom above the floor moved[l][-1].
+      constexpr int kMv = NL * (NL + 1);
+      double* mv = &ar.stage[0][0];
+      static_assert(sizeof(ar.stage) >= sizeof(double) * kMv && kMv <= 128, "the table fits the stage area, two entries a lane");
+      float lv[2][NL];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u, l = e < kMv ? e / (NL + 1) : 0;
+#pragma unroll
+        for (int jn = 0; jn < NL; ++jn) lv[u][jn] = ck.lev[12 * jn + l];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u;
+        if (e < kMv) {
+          const int l = e / (NL + 1), c = e % (NL + 1) - 1;
+          const uint32_t jm = anc_mask<T>(l) & ~anc_mask<T>(c);
+          double m = 0.0;
+#pragma unroll
+          for (int jn = 0; jn < NL; ++jn) m += (jm >> jn) & 1u ? wb[kDp + jn] * (double)lv[u][jn] : 0.0;
+          mv[e] = m;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int g0 = ent[j].geoms & 0xff, g1 = (ent[j].geoms >> 8) & 0xff, c = (int)((ent[j].geoms >> 16) & 0xff);
+        const int la = ck.glink[g0], lb = ck.glink[g1];
+        const double moved = (la >= 0 ? mv[la * (NL + 1) + c] : 0.0) + (lb >= 0 ? mv[lb * (NL + 1) + c] : 0.0);
+        // (rounded up, and by more than the subtraction's own rounding: rem stays a lower bound)
+        if (moved > 0.0) rem[j] -= (float)moved * 1.00001f + 2.5e-7f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ent[j] = ck.ent[lane + 64 * j < ck.npair ? lane + 64 * j : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) am |= (lane + 64 * j < ck.npair && !(rem[j] > 0.0f)) ? 1u << j : 0u;
+    if (remg && tab.has_plane && !b.present) {
+      // the lane's geom against the floor: its height above it less its bounding radius, less what its chain has moved it since
+      const bool mine = lane < tab.ngeom;
+      {
+        const int lk = mine ? ck.glink[lane] : -1;
+        const double moved = lk >= 0 ? (&ar.stage[0][0])[lk * (NL + 1)] : 0.0;  // (moved[l][-1]: against the world)
+        if (moved > 0.0) remf -= (float)moved * 1.00001f + 2.5e-7f;
+      }
+#ifdef RCSH_PHASE_TIMING
+      {  // why an escalated environment's pass is not quiet: passes / with a pair due / with a geom due against the floor / an example
+        const uint64_t wa = __ballot(am != 0), wf = __ballot(mine && !(remf > 0.0f));
+        if (lane == 0) {
+          atomicAdd(&g_team_cycles[92], 1ull);
+          if (wa) atomicAdd(&g_team_cycles[93], 1ull);
+          if (wf) atomicAdd(&g_team_cycles[94], 1ull);
+        }
+        if (wa && lane == __ffsll((long long)wa) - 1) {
+          const int jb = __ffs((int)am) - 1;
+          g_slack_dbg[0] = lane + 64 * jb; g_slack_dbg[1] = jb == 0 ? rem[0] : (jb == 1 ? rem[1] : rem[2]);
+          g_slack_dbg[2] = (double)(jb == 0 ? ent[0].geoms : (jb == 1 ? ent[1].geoms : ent[2].geoms));
+          g_slack_dbg[3] = remg[lane + 64 * jb];  // (what the last pass left)
+          g_slack_dbg[4] = env;
+        }
+        if (wa && lane == __ffsll((long long)wa) - 1) g_team_cycles[95] = (g_team_cycles[95] / 1000ull) * 1000ull + (unsigned long long)(lane + 64 * (__ffs((int)am) - 1) + 1);
+        if (wf && lane == __ffsll((long long)wf) - 1) g_team_cycles[95] = (g_team_cycles[95] % 1000ull) + 1000ull * (unsigned long long)(lane + 1);
+      }
+#endif
+      if (__ballot(am != 0 || (mine && !(remf > 0.0f))) == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (lane + 64 * j < ck.npair) remg[lane + 64 * j] = rem[j];
+        if (mine) remg[kSlackFloor + lane] = remf;
+        TEAM_MARK(25)
+        return 0u;
+      }
+    }
+    __syncthreads();  // (the scratch area goes to the stages below)
+  }
   // ---- link frames at the pre-step configuration: lane i < NL walks the chain to link i
   // (every lane its own joint's local frame once, through the stage area; then the products down the chain)
   double (*loc)[12] = reinterpret_cast<double (*)[12]>(&ar.stage[0][0]);
@@ -1319,9 +1436,20 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
     gp[0] += pl[0]; gp[1] += pl[1]; gp[2] += pl[2];
     const double* V = tab.verts + 3 * (size_t)cg.vert_adr;
     // ---- floor
+    remf = 1e30f;  // (a geom the floor does not collide with)
     if (tab.has_plane && cg.plane_ok) {
       const double n[3] = {tab.plane_n[0], tab.plane_n[1], tab.plane_n[2]};
       const double cdst = dot3(n, gp) - tab.plane_d;
+      {
+        // the geom's slack against the floor, measured anew: the lowest point of its oriented bounding box (the bounding sphere of
+        // link 1's hull reaches the floor in every pose, its box in none)
+        double lc3[3], hh3[3], oc3[3], nl3[3];
+        geom_obb(cg, lc3, hh3);
+        mulmv(gR, lc3, oc3);
+        mulTv(gR, n, nl3);
+        const double low = cdst + dot3(n, oc3) - (fabs(nl3[0]) * hh3[0] + fabs(nl3[1]) * hh3[1] + fabs(nl3[2]) * hh3[2]);
+        remf = fmaxf((float)low * 0.999999f - 1e-6f, 0.0f);
+      }
       if (cdst - cg.rbound <= 0) {
         if (cg.type == 7) {
           // (a hull's support vertices: with the whole wavefront, below -- if the hull's bounding box reaches the floor at all: link 1's
@@ -1500,7 +1628,6 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       ++nBP;
     }
   }
-  const bool self_on = (b.resolve & 2) && ck.npair > 0;  // (wave-uniform) contacts between two geoms of the robot are resolved
   if (!self_on && __ballot(nP > 0 || nB > 0) == 0) {  // nothing of the robot touches anything: the fast path keeps the step
     TEAM_MARK(25)
     return 0u;
@@ -1533,46 +1660,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
     // the geoms' distance NOW; <= 0: look.  In a settled or slowly moving arm nearly every pair is skipped, every substep: the world
     // boxes, the sphere and box tests and the narrow phase run for the few pairs that are near.  Exact: only pairs proven apart are
     // skipped (oracle self_collide tests every pair in every substep and finds the same contacts).
-    constexpr int kDp = 12 * kMaxCGeom;  // this substep's joint motion, behind the world boxes
-    static_assert(ContactArena<T>::kScratch >= kDp + 12, "joint motion fits behind the world boxes");
     TEAM_MARK(16)  // (slots 16-18, 21-23 here: box-less scenes; box_team.h uses them in kernels with a free box)
-    float* const remg = ck.slack ? ck.slack + (size_t)env * kSlackStride : nullptr;
-    float rem[3] = {0.0f, 0.0f, 0.0f};
-    CheckEntry ent[3];
-    if (remg) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int i = lane + 64 * j;
-        rem[j] = i < ck.npair ? remg[i] : 1.0f;
-        ent[j] = ck.ent[i < ck.npair ? i : 0];
-      }
-      double* qpg = reinterpret_cast<double*>(remg + kMaxCheckPairs);
-      if (lane < NL) {
-        const double q = st.q(lane), qp = qpg[lane];
-        qpg[lane] = q;
-        wb[kDp + lane] = tab.self_lever[lane] * fabs(q - qp);
-      }
-      __syncthreads();
-      double dp[NL];
-#pragma unroll
-      for (int l = 0; l < NL; ++l) dp[l] = wb[kDp + l];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int g0 = ent[j].geoms & 0xff, g1 = (ent[j].geoms >> 8) & 0xff;
-        const uint32_t jm = anc_mask<T>(ck.glink[g0]) ^ anc_mask<T>(ck.glink[g1]);
-        double moved = 0.0;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) moved += (jm >> l) & 1u ? dp[l] : 0.0;
-        // (rounded up, and by more than the subtraction's own rounding: rem stays a lower bound)
-        if (moved > 0.0) rem[j] -= (float)moved * 1.00001f + 2.5e-7f;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) ent[j] = ck.ent[lane + 64 * j < ck.npair ? lane + 64 * j : 0];
-    }
-    uint32_t am = 0;  // bit j: pair lane + 64 j has used its slack up
-#pragma unroll
-    for (int j = 0; j < 3; ++j) am |= (lane + 64 * j < ck.npair && !(rem[j] > 0.0f)) ? 1u << j : 0u;
     uint32_t cm = 0;  // bit j: pair lane + 64 j survived the bounding tests
     static_assert(kMaxCheckPairs <= 3 * 64, "three pairs per lane");
     if (__ballot(am != 0)) {
@@ -1687,21 +1775,29 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       }
       __syncthreads();  // (the polygons' LDS goes back to the hulls)
     }
+    // ---- everything else: Gilbert's iteration, then the portal refinement.  The refinement is written for a TEAM of 16 lanes (they share
+    // the vertex scans of a hull's support queries), and the wavefront has four: up to FOUR pairs are refined side by side, a team each --
+    // the lead pair (the first one pending) and pending pairs that need no hull but the lead's, in the lead's places (a hand pressed
+    // against link 0 or 1 brings its ten pad boxes and two finger hulls near that link's hull at once: twelve refinements of 40k cycles
+    // one after the other were 500k of a substep's 800k).  Which pairs are refined together changes no pair's result.
     for (uint64_t pend = __ballot(cm != 0); pend; pend = __ballot(cm != 0)) {
       const int src = __ffsll((long long)pend) - 1;  // wave-uniform
       const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cm, src);
       const int j = __ffs((int)sm) - 1;
       if (lane == src) cm &= ~(1u << j);
-      const CheckEntry en = ck.ent[src + 64 * j];
-      const int g0 = en.geoms & 0xff, g1 = (en.geoms >> 8) & 0xff;
-      const ContactGeom& ga = tab.geoms[g0];
-      const ContactGeom& gb = tab.geoms[g1];
-      double Ra[9], pa[3], Rb[9], pb[3];
-      self_geom_world(ga, &arF[0][0], Ra, pa);
-      self_geom_world(gb, &arF[0][0], Rb, pb);
-      int nc = 0;
-      double spos[8][3], sn[3] = {0, 0, 0}, sdist[8];
-      if (ga.type == 6 && gb.type == 6) {
+      const uint32_t eg_lead = j == 0 ? ent[0].geoms : (j == 1 ? ent[1].geoms : ent[2].geoms);
+      const uint32_t gg_lead = (uint32_t)__builtin_amdgcn_readlane((int)eg_lead, src);
+      const int g0 = gg_lead & 0xff, g1 = (gg_lead >> 8) & 0xff;
+      const int ty0 = ck.gtype[g0], ty1 = ck.gtype[g1];
+      if (ty0 == 6 && ty1 == 6) {
+        // two boxes beyond the parallel stage's pool: one lane
+        const ContactGeom& ga = tab.geoms[g0];
+        const ContactGeom& gb = tab.geoms[g1];
+        double Ra[9], pa[3], Rb[9], pb[3];
+        self_geom_world(ga, &arF[0][0], Ra, pa);
+        self_geom_world(gb, &arF[0][0], Rb, pb);
+        int nc = 0;
+        double spos[8][3], sn[3] = {0, 0, 0}, sdist[8];
         TEAM_COUNT(21)
         if (lane == 0) {
           const int nb = dev_box_box(pa, Ra, ga.size, pb, Rb, gb.size, &spos[0][0], sn, sdist, &ar.stage[0][0]);
@@ -1714,59 +1810,138 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
           }
         }
         nc = __builtin_amdgcn_readfirstlane(nc);
-      } else {
-        double* hA = ar.scratch();
-        double* hB = &ar.stage[0][0];
-        const int na3 = ga.type == 7 ? 3 * ga.vert_num : 0, nb3 = gb.type == 7 ? 3 * gb.vert_num : 0;
+        if (nc > 0 && lane == 0) {
+          int c2 = 0;  // what the collision callbacks make of the pair (rcs_hip.hip: list_geom_pairs)
+          if ((ga.cls | gb.cls) & 1) c2 |= 1;
+          if (!((ga.cls & 4) && (gb.cls & 4)) && ((ga.cls | gb.cls) & 16) && !(gb.cls & 8)) c2 |= 2;
+          const int la = ga.link >= 0 ? ga.link : kWorld, lb = gb.link >= 0 ? gb.link : kWorld;
+          const bool fwd = ga.body < gb.body;
+          for (int k = 0; k < nc; ++k) {
+            if (nreg + nS + k >= kMaxCon) break;
+            const int c = kMaxCon - 1 - (nS + k);
+            double* r = ar.rec[c];
+            r[0] = spos[k][0]; r[1] = spos[k][1]; r[2] = spos[k][2];
+            r[3] = sn[0]; r[4] = sn[1]; r[5] = sn[2];
+            r[6] = sdist[k];
+            r[7] = fmax(ga.mu, gb.mu);
+            r[8] = ga.invweight + gb.invweight;
+            ar.cb[c] = la | (lb << 8) | (c2 << 16);
+            arkey[c] = fwd ? contact_key(ga.body, gb.body, g0 + 1, g1 + 1, k) : contact_key(gb.body, ga.body, g1 + 1, g0 + 1, k);
+          }
+        }
+        if (nreg + nS + nc > kMaxCon) { too_many_contacts = true; nc = kMaxCon - nreg - nS; }
+        nS += nc;
+        continue;
+      }
+      // the lead's companions: up to three more pending pairs (not two boxes) whose hulls are the lead's, place by place
+      int grp_src[4] = {src, -1, -1, -1}, grp_j[4] = {j, 0, 0, 0};
+      uint32_t grp_g[4] = {gg_lead, 0u, 0u, 0u};
+      int ngrp = 1;
+      {
+        uint32_t ok = 0;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          const int c0 = ent[jj].geoms & 0xff, c1 = (ent[jj].geoms >> 8) & 0xff;
+          const int u0 = ck.gtype[c0], u1 = ck.gtype[c1];
+          const bool fits = (u0 != 7 || c0 == g0) && (u1 != 7 || c1 == g1) && !(u0 == 6 && u1 == 6);
+          ok |= ((cm >> jj) & 1u) && fits ? 1u << jj : 0u;
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const uint64_t w = __ballot(ok != 0);
+          if (!w) break;
+          const int L = __ffsll((long long)w) - 1;
+          const int jj = __ffs(__builtin_amdgcn_readlane((int)ok, L)) - 1;
+          const uint32_t eg = jj == 0 ? ent[0].geoms : (jj == 1 ? ent[1].geoms : ent[2].geoms);
+          grp_g[k] = (uint32_t)__builtin_amdgcn_readlane((int)eg, L);
+          grp_src[k] = L; grp_j[k] = jj;
+          if (lane == L) { ok &= ~(1u << jj); cm &= ~(1u << jj); }
+          ngrp = k + 1;
+        }
+      }
+      // the lead's hulls -> LDS (the companions' hulls are the same ones)
+      double* hA = ar.scratch();
+      double* hB = &ar.stage[0][0];
+      {
+        const ContactGeom& ga = tab.geoms[g0];
+        const ContactGeom& gb = tab.geoms[g1];
+        const int na3 = ty0 == 7 ? 3 * ga.vert_num : 0, nb3 = ty1 == 7 ? 3 * gb.vert_num : 0;
         const double* va = tab.verts + 3 * (size_t)ga.vert_adr;
         const double* vb = tab.verts + 3 * (size_t)gb.vert_adr;
         for (int k = lane; k < na3; k += 64) hA[k] = va[k];
         for (int k = lane; k < nb3; k += 64) hB[k] = vb[k];
-        __syncthreads();
-        Shape A = make_shape(ga.type == 7 ? 0 : ga.type == 6 ? 1 : 2, pa, Ra, ga.size, hA, ga.vert_num);
-        Shape B = make_shape(gb.type == 7 ? 0 : gb.type == 6 ? 1 : 2, pb, Rb, gb.size, hB, gb.vert_num);
-        if (ga.type == 7) { mulmv(Ra, ga.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
-        if (gb.type == 7) { mulmv(Rb, gb.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
+      }
+      __syncthreads();
+      const int team = lane >> 4;
+      const bool mine_pair = team < ngrp;
+      const uint32_t mg = team == 0 ? grp_g[0] : (team == 1 ? grp_g[1] : (team == 2 ? grp_g[2] : grp_g[3]));
+      const int m0 = mine_pair ? (int)(mg & 0xff) : g0, m1 = mine_pair ? (int)((mg >> 8) & 0xff) : g1;
+      const ContactGeom& ga = tab.geoms[m0];
+      const ContactGeom& gb = tab.geoms[m1];
+      int nc = 0;
+      double spos0[3] = {0, 0, 0}, sn[3] = {0, 0, 0}, depth = 0.0, gap = 0.0;
+      bool apart = false;
+      TEAM_COUNT(22)
+      if (mine_pair) {
+        double Ra[9], pa[3], Rb[9], pb[3];
+        self_geom_world(ga, &arF[0][0], Ra, pa);
+        self_geom_world(gb, &arF[0][0], Rb, pb);
+        const int ta = ga.type, tb = gb.type;
+        Shape A = make_shape(ta == 7 ? 0 : ta == 6 ? 1 : 2, pa, Ra, ga.size, hA, ga.vert_num);
+        Shape B = make_shape(tb == 7 ? 0 : tb == 6 ? 1 : 2, pb, Rb, gb.size, hB, gb.vert_num);
+        if (ta == 7) { mulmv(Ra, ga.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
+        if (tb == 7) { mulmv(Rb, gb.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
         // a few steps of Gilbert's iteration settle a pair that is clearly apart (links 5 and 7 wrap around the same wrist and pass the
         // boxes' test in every pose); everything else goes through the full refinement, as in the oracle
         const double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};
-        double dg[3], gap = 0.0, depth = 0.0;
-        TEAM_COUNT(22)
-        if (!gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap)) { TEAM_COUNT(23) nc = mpr_penetration<true>(A, B, &depth, sn, spos[0]); }
-        else if (lane == src) {  // the pair's slack: the gap Gilbert's direction proves
-          const float gf = (float)gap * 0.999999f - 1e-6f;
-          rem[0] = j == 0 ? gf : rem[0]; rem[1] = j == 1 ? gf : rem[1]; rem[2] = j == 2 ? gf : rem[2];
+        double dg[3];
+        apart = gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap);
+        if (!apart) {
+          TEAM_COUNT(23)
+          nc = mpr_penetration<true>(A, B, &depth, sn, spos0);
+          // (apart after all: the refinement's separating direction proves a gap too -- without it the pair came back in every substep)
+          if (nc == 0 && depth < 0.0) { apart = true; gap = -depth; }
         }
         if (!(depth > kSelfTouch)) nc = 0;
-        sdist[0] = -depth;
-        __syncthreads();  // (the stage is free again)
       }
-      if (nc > 0 && lane == 0) {
-        int c2 = 0;  // what the collision callbacks make of the pair (rcs_hip.hip: list_geom_pairs)
-        if ((ga.cls | gb.cls) & 1) c2 |= 1;
-        if (!((ga.cls & 4) && (gb.cls & 4)) && ((ga.cls | gb.cls) & 16) && !(gb.cls & 8)) c2 |= 2;
-        const int la = ga.link >= 0 ? ga.link : kWorld, lb = gb.link >= 0 ? gb.link : kWorld;
-        const bool fwd = ga.body < gb.body;
-        for (int k = 0; k < nc; ++k) {
-          if (nreg + nS + k >= kMaxCon) break;
-          const int c = kMaxCon - 1 - (nS + k);
+      // the pairs' slack (the gap Gilbert's direction proves) goes to the lanes that hold them; the contacts to the record area's end
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k >= ngrp) break;  // (wave-uniform)
+        const bool apart_k = __builtin_amdgcn_readlane((int)apart, 16 * k) != 0;
+        const double gap_k = wave_read(gap, 16 * k);
+        if (apart_k && lane == grp_src[k]) {
+          const float gf = (float)gap_k * 0.999999f - 1e-6f;
+          const int jk = grp_j[k];
+          rem[0] = jk == 0 ? gf : rem[0]; rem[1] = jk == 1 ? gf : rem[1]; rem[2] = jk == 2 ? gf : rem[2];
+        }
+        int nck = __builtin_amdgcn_readlane(nc, 16 * k);
+        if (nck > 0 && lane == 16 * k && nreg + nS < kMaxCon) {
+          int c2 = 0;  // what the collision callbacks make of the pair (rcs_hip.hip: list_geom_pairs)
+          if ((ga.cls | gb.cls) & 1) c2 |= 1;
+          if (!((ga.cls & 4) && (gb.cls & 4)) && ((ga.cls | gb.cls) & 16) && !(gb.cls & 8)) c2 |= 2;
+          const int la = ga.link >= 0 ? ga.link : kWorld, lb = gb.link >= 0 ? gb.link : kWorld;
+          const bool fwd = ga.body < gb.body;
+          const int c = kMaxCon - 1 - nS;
           double* r = ar.rec[c];
-          r[0] = spos[k][0]; r[1] = spos[k][1]; r[2] = spos[k][2];
+          r[0] = spos0[0]; r[1] = spos0[1]; r[2] = spos0[2];
           r[3] = sn[0]; r[4] = sn[1]; r[5] = sn[2];
-          r[6] = sdist[k];
+          r[6] = -depth;
           r[7] = fmax(ga.mu, gb.mu);
           r[8] = ga.invweight + gb.invweight;
           ar.cb[c] = la | (lb << 8) | (c2 << 16);
-          arkey[c] = fwd ? contact_key(ga.body, gb.body, g0 + 1, g1 + 1, k) : contact_key(gb.body, ga.body, g1 + 1, g0 + 1, k);
+          arkey[c] = fwd ? contact_key(ga.body, gb.body, m0 + 1, m1 + 1, 0) : contact_key(gb.body, ga.body, m1 + 1, m0 + 1, 0);
         }
+        if (nreg + nS + nck > kMaxCon) { too_many_contacts = true; nck = kMaxCon - nreg - nS; }
+        nS += nck;
       }
-      if (nreg + nS + nc > kMaxCon) { too_many_contacts = true; nc = kMaxCon - nreg - nS; }
-      nS += nc;
+      __syncthreads();  // (the stage is free again)
     }
     if (remg) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if (lane + 64 * j < ck.npair) remg[lane + 64 * j] = rem[j];
+      if (has_geom) remg[kSlackFloor + lane] = remf;
     }
     TEAM_MARK(18)
   }

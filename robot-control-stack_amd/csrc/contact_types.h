@@ -49,17 +49,20 @@ struct SelfPair {
 // box geoms that is the exact test already), MPR.  A lane takes every 16th pair; all it needs per pair is an 8-byte entry.
 constexpr int kMaxCheckPairs = 192;  // pairs whose entries a lane keeps in registers (12 each); a scene with more has the rest unchecked (refused at set-up)
 struct CheckEntry {
-  uint32_t geoms;  // g0 | g1 << 8 (indices into ContactTable::geoms, in MuJoCo's order within a contact: by type, then by id)
+  uint32_t geoms;  // g0 | g1 << 8 (indices into ContactTable::geoms, in MuJoCo's order within a contact: by type, then by id) | (1 + common ancestor link) << 16
   float rsum;      // sum of the two bounding-sphere radii, rounded up
 };
 // oriented bounding box of a collision geom in the frame of its link (world frame: welded to the world); its axes are the geom's
 struct CheckGeom {
   double c[3], rot[9];
 };
-constexpr int kSlackStride = kMaxCheckPairs + 24;  // floats per environment: the pairs' remaining gaps, then the joints seen last (12 doubles)
+constexpr int kSlackFloor = kMaxCheckPairs + 24;  // ... then the geoms' remaining heights above the floor
+constexpr int kSlackStride = kSlackFloor + 32;    // floats per environment: the pairs' remaining gaps, then the joints seen last (12 doubles), ...
+static_assert(kMaxCGeom <= 32, "a float per collision geom");
 struct CheckTable {
   const CheckEntry* ent;
   const CheckGeom* geoms;
+  const float* lev; // [12][12] lev[j][l]: how far one radian (hinge) / metre (slide) of joint j moves a point of a geom ON link l (host: build_self_levers)
   float* slack;    // [n][kSlackStride] self-contact stage of the contact phase (contact_team.h: contact_collide); null: every pair, every substep
   int32_t npair, ngeom;
   int32_t plane_points;  // the scene has a floor plane and collision geoms with sample points to test against it

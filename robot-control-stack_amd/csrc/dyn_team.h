@@ -83,6 +83,7 @@ struct StageTeam {
 #ifdef RCSH_PHASE_TIMING
 // Development instrumentation (tools/team_timing.py): cycle counter deltas between marks, accumulated in LDS by lane
 // 0 of workgroup 0 (an LDS round trip per mark, ~100 cycles) and flushed to global memory once per launch.
+__device__ double g_slack_dbg[16];  // the contact phase's slack test: an example (contact_team.h)
 __device__ unsigned long long g_team_cycles[96];  // 64..95: statistics over ALL workgroups (the contact-resolving launch of an escalated step)
 __shared__ unsigned long long s_team_cycles[64];
 __shared__ unsigned long long s_team_mark;

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -39,6 +40,7 @@ constexpr int kProfRing = 4096;
 
 }  // namespace
 
+struct CopyCarrier;
 struct rcsh_sim {
   int device = 0;
   int kernel = RCSH_KERNEL_AUTO;
@@ -70,6 +72,8 @@ struct rcsh_sim {
   std::vector<CheckGeom> chk_geoms;
   CheckGeom* d_chk_geoms = nullptr;
   CheckEntry* d_chk_ent = nullptr;
+  float link_lever[12 * 12] = {0};  // contact_types.h: CheckTable::lev
+  float* d_lev = nullptr;
   float* d_slack = nullptr;          // [n][kSlackStride]: the self-contact stage's remaining gaps per pair + the joints it saw last (CheckTable::slack)
   int chk_unchecked = 0;             // admitted geom pairs past kMaxCheckPairs: neither checked at the end of a launch nor resolved as self contacts
   // per-environment escalation (sim_kernels.h: RunOp::esc_role): a step is the lean launch over the environments not in contact plus
@@ -132,6 +136,7 @@ struct rcsh_sim {
   hipEvent_t comm_ready = nullptr, comm_done[2] = {nullptr, nullptr};
   bool comm_pending[2] = {false, false};
   int comm_rank = 0, comm_world = 1;
+  struct CopyCarrier* copy = nullptr;  // the all-gather's second carrier: copy engines + flags in peer memory (rcsh_comm_copy_*)
   // profiling
   hipEvent_t order_ev = nullptr;       // rcsh_sim_wait_for: marks this handle's stream for another handle's stream to wait on
   bool prof = false;
@@ -218,6 +223,7 @@ Params make_params(rcsh_sim* s) {
   P.ctab.plane_d = s->cp.plane_d;
   P.ctab.plane_mu = s->plane_mu;
   P.chk.ent = s->d_chk_ent;
+  P.chk.lev = s->d_lev;
   P.chk.geoms = s->d_chk_geoms;
   P.chk.slack = s->d_slack;
   P.chk.npair = (int)s->chk_ent.size();  // (also the pair table of the contact phase's self-contact stage)
@@ -277,6 +283,48 @@ int upload_coll_classes(rcsh_sim* s) {
 // gripper collision geom, geom[1] is not in the ignore list -- quirk Q6).  Pairs nobody reacts to are dropped.
 constexpr int kSelfStageVertsHost = 304;  // contact_team.h: kSelfStageVerts
 // all pairs MuJoCo's filters admit; `reacting_only`: drop those no collision callback reacts to (cls == 0)
+// A geom welded to the world against a geom of the arm's first link (MuJoCo's parent-child filter lets the pair through: the parent is
+// static): ONE hinge moves them relative to each other, and a rotation leaves every point's coordinate ALONG the hinge's axis alone.  If
+// the two geoms' extents along that axis do not overlap, no joint angle brings them into contact -- the pair is dropped from the tables
+// (the FR3's link 1 sits on link 0 with 0.1 mm between the hulls: the pair survived every bounding test in every pose, and the contact
+// phase refined it in every substep of every escalated environment).
+bool never_touch_across_first_hinge(const rcsh_sim* s, const ContactGeom& a, const ContactGeom& b) {
+  const ContactGeom* w = a.link < 0 ? &a : (b.link < 0 ? &b : nullptr);
+  const ContactGeom* l = a.link == 0 ? &a : (b.link == 0 ? &b : nullptr);
+  if (!w || !l || s->dm.jtype[0] == kSlide) return false;
+  const DevModel& m = s->dm;
+  double ax[3] = {m.axis[0][0], m.axis[0][1], m.axis[0][2]}, aw[3];
+  for (int k = 0; k < 3; ++k) aw[k] = m.rot0[0][3 * k] * ax[0] + m.rot0[0][3 * k + 1] * ax[1] + m.rot0[0][3 * k + 2] * ax[2];
+  auto extent = [&](const ContactGeom& g, const double* u, double& lo, double& hi) {
+    // of the geom along u, both in the frame of the geom's link
+    double ug[3];  // u in the geom's frame
+    for (int k = 0; k < 3; ++k) ug[k] = g.rot[k] * u[0] + g.rot[3 + k] * u[1] + g.rot[6 + k] * u[2];
+    const double c = u[0] * g.pos[0] + u[1] * g.pos[1] + u[2] * g.pos[2];
+    if (g.type == 7) {
+      lo = 1e300; hi = -1e300;
+      for (int v = 0; v < g.vert_num; ++v) {
+        const double* x = &s->cverts[3 * (size_t)(g.vert_adr + v)];
+        const double d = c + ug[0] * x[0] + ug[1] * x[1] + ug[2] * x[2];
+        lo = std::min(lo, d); hi = std::max(hi, d);
+      }
+    } else {
+      double e;
+      if (g.type == 6) e = std::fabs(ug[0]) * g.size[0] + std::fabs(ug[1]) * g.size[1] + std::fabs(ug[2]) * g.size[2];
+      else if (g.type == 3) e = std::fabs(ug[2]) * g.size[1] + g.size[0];
+      else e = g.size[0];
+      lo = c - e; hi = c + e;
+    }
+  };
+  double wlo, whi, llo, lhi;
+  extent(*w, aw, wlo, whi);
+  extent(*l, ax, llo, lhi);
+  const double off = aw[0] * m.pos0[0][0] + aw[1] * m.pos0[0][1] + aw[2] * m.pos0[0][2];
+  llo += off; lhi += off;
+  if (w->type == 7 && w->vert_num == 0) return false;
+  if (l->type == 7 && l->vert_num == 0) return false;
+  return llo - whi > 1e-7 || wlo - lhi > 1e-7;
+}
+
 std::vector<SelfPair> list_geom_pairs(const rcsh_sim* s, bool reacting_only) {
   std::vector<SelfPair> out;
   const int ng = (int)s->cgeoms.size();
@@ -288,6 +336,7 @@ std::vector<SelfPair> list_geom_pairs(const rcsh_sim* s, bool reacting_only) {
       if (a.link >= 0 && b.link >= 0 && (parent(a.link) == b.link || parent(b.link) == a.link)) continue;
       if ((a.type == 7 && a.vert_num == 0) || (b.type == 7 && b.vert_num == 0)) continue;  // mesh blob missing from the checkout
       if (a.vert_num + b.vert_num > kSelfStageVertsHost) continue;  // (the contact table admits hulls of at most 152 vertices each: model.cpp build_contact_table)
+      if (never_touch_across_first_hinge(s, a, b)) continue;
       const bool swap = a.type > b.type;  // geom[0] / geom[1] of the contact: by type, then by id (the table is in id order)
       const ContactGeom &g0 = swap ? b : a, &g1 = swap ? a : b;
       int cls = 0;
@@ -340,7 +389,16 @@ void build_check_table(rcsh_sim* s) {
   s->chk_ent.clear();
   for (const auto& p : s->chk_pairs) {
     CheckEntry e{};
-    e.geoms = (uint32_t)p.g0 | ((uint32_t)p.g1 << 8);
+    // (bits 16-23: 1 + the deepest link both geoms' links descend from or are -- 0: none, the world; the slack test charges each geom
+    // with the joints below it)
+    int ca = -1;
+    {
+      const int na = s->narm;
+      auto parent = [&](int link) { return link < na ? link - 1 : na - 1; };
+      auto is_anc = [&](int a, int l) { for (int k = l; k >= 0; k = parent(k)) if (k == a) return true; return false; };
+      for (int k = p.l0; k >= 0 && ca < 0; k = parent(k)) if (p.l1 >= 0 && is_anc(k, p.l1)) ca = k;
+    }
+    e.geoms = (uint32_t)p.g0 | ((uint32_t)p.g1 << 8) | ((uint32_t)(ca + 1) << 16);
     e.rsum = (float)(p.r0 + p.r1) * 1.000001f + 2e-6f;  // (single-precision centres: the sum of the radii rounded up)
     s->chk_ent.push_back(e);
   }
@@ -390,6 +448,19 @@ void build_self_levers(rcsh_sim* s) {
   }
   for (int j = 0; j < 12; ++j) s->self_lever[j] = 0.0;
   for (int j = 0; j < nl; ++j) s->self_lever[j] = m.jtype[j] == kSlide ? 1.0 : 1.01 * far[j] + 1e-3;
+  // link_lever[j][l]: the same bound for the geoms ON link l alone (j an ancestor-or-self joint of l) -- what the contact phase's slack
+  // test charges a geom pair / a geom above the floor with.  The isotropic lever above takes the whole arm's reach for joint 1; the pair
+  // (link 0, link 2), whose hulls stay a centimetre apart in every pose, sits 0.2 m from that axis: charged with 1.2 m per radian it was
+  // due in nearly every substep, and with it the whole collision pass.
+  for (int k = 0; k < 144; ++k) s->link_lever[k] = 0.0f;
+  for (int l = 0; l < nl; ++l) {
+    double acc = reach[l];  // from link l's anchor to the farthest point of a geom on l
+    for (int j = l; j >= 0; j = parent(j)) {
+      // acc: from joint j's anchor to the farthest point of a geom on l, over every configuration of the joints in between
+      s->link_lever[j * 12 + l] = (float)(m.jtype[j] == kSlide ? 1.0 : (1.01 * (acc + stroke[l]) + 1e-3) * 1.000001);
+      acc += hop[j] + stroke[j];
+    }
+  }
 }
 
 int upload_contact_table(rcsh_sim* s) {
@@ -416,6 +487,8 @@ int upload_contact_table(rcsh_sim* s) {
     HIP_TRY(hipMalloc(&s->d_chk_ent, sizeof(CheckEntry) * s->chk_ent.size()));
     HIP_TRY(hipMemcpyAsync(s->d_chk_ent, s->chk_ent.data(), sizeof(CheckEntry) * s->chk_ent.size(), hipMemcpyHostToDevice, s->stream));
   }
+  if (!s->d_lev) HIP_TRY(hipMalloc(&s->d_lev, sizeof(s->link_lever)));
+  HIP_TRY(hipMemcpyAsync(s->d_lev, s->link_lever, sizeof(s->link_lever), hipMemcpyHostToDevice, s->stream));
   if (!s->chk_geoms.empty()) {
     HIP_TRY(hipMalloc(&s->d_chk_geoms, sizeof(CheckGeom) * s->chk_geoms.size()));
     HIP_TRY(hipMemcpyAsync(s->d_chk_geoms, s->chk_geoms.data(), sizeof(CheckGeom) * s->chk_geoms.size(), hipMemcpyHostToDevice, s->stream));
@@ -782,12 +855,12 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   if (!s) return;
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
-  if (s->comm) rcsh_comm_destroy(s);
+  if (s->comm || s->copy) rcsh_comm_destroy(s);
   for (auto e : s->ev_start) hipEventDestroy(e);
   if (s->order_ev) hipEventDestroy(s->order_ev);
   for (auto e : s->ev_stop) hipEventDestroy(e);
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
-  hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_geoms); hipFree(s->d_chk_ent);
+  hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_geoms); hipFree(s->d_chk_ent); hipFree(s->d_lev);
   hipFree(s->d_slack);
   hipFree(s->d_esc); hipFree(s->d_esc_ctr); hipFree(s->d_snap); hipFree(s->d_snap_flags); hipFree(s->d_snap_conv);
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
@@ -1966,6 +2039,207 @@ int rcsh_camera_render(rcsh_sim* s, int32_t cam_id, float* depth_gl, uint16_t* d
   return rcsh_camera_render_rgb(s, cam_id, nullptr, depth_gl, depth_mm, cam_pose);
 }
 
+// ---- The all-gather's second carrier: copy engines instead of a collective kernel.
+// RCCL's all-gather is a KERNEL (261-280 registers a lane in this image's librccl.so): next to a stepping wavefront of 424 registers it
+// finds no SIMD to run on, so on a full batch the gather starts when the env-step ends instead of overlapping it.  Here every rank
+// WRITES its block into the receive buffer of each peer (IPC-mapped) with plain asynchronous copies -- SDMA engines over xGMI, one
+// stream per peer so the seven links work in parallel -- and says so with an 8-byte copy of the step's sequence number into a flag
+// word of the peer.  The only thing that runs on a CU is one single wavefront of 16 registers per gather that waits for the flag words
+// (k_wait_flags): it fits beside a stepping wavefront.  Same slot protocol, same entry points for posting and waiting
+// (rcsh_comm_allgather_dev / rcsh_comm_wait); the receive buffers belong to the carrier (they have to be exported), see rcs_hip.h.
+//   flags[kind][slot][rank]: kind 0 "ack" -- rank says its receive buffer of `slot` is free for sequence number q (its consumer is done
+//   with what the buffer held); kind 1 "got" -- rank's block of sequence q has arrived in this rank's receive buffer of `slot`.
+namespace {
+constexpr int kCopyMaxWorld = 16;
+constexpr int kCopySeqRing = 256;
+struct CopyBlob {  // what a rank exports (RCSH_COMM_COPY_BLOB_BYTES >= sizeof)
+  uint32_t magic, rank;
+  uint64_t bytes_per_rank;
+  int32_t device, pid;
+  hipIpcMemHandle_t recv[2], flags;
+};
+static_assert(sizeof(CopyBlob) <= RCSH_COMM_COPY_BLOB_BYTES, "the blob fits what the header promises");
+}  // namespace
+struct CopyCarrier {
+  int rank = 0, world = 1;
+  size_t bytes = 0;
+  void* recv[2] = {nullptr, nullptr};   // [world * bytes] each, this rank's
+  uint64_t* flags = nullptr;            // [2][2][kCopyMaxWorld], this rank's (fine-grained: peers write it, a waiting wavefront reads it)
+  void* peer_recv[kCopyMaxWorld][2] = {};
+  uint64_t* peer_flags[kCopyMaxWorld] = {};
+  bool opened[kCopyMaxWorld] = {};
+  hipStream_t cs[kCopyMaxWorld] = {};   // one copy stream per peer (own rank: the local block)
+  hipEvent_t cs_done[kCopyMaxWorld] = {}, acked = nullptr;
+  uint64_t* seq_ring = nullptr;         // pinned: the sequence numbers the flag copies read
+  uint64_t seq[2] = {0, 0};
+  int ring_pos = 0;
+  uint32_t* timeout_flag = nullptr;     // pinned: a wait gave up (a peer died)
+  bool connected = false;
+};
+namespace {
+// one wavefront: waits until the `n` words at `w` (skipping index `skip`) have all reached `q`; gives up after ~20 s
+__global__ void __launch_bounds__(64) k_wait_flags(const uint64_t* w, int n, int skip, uint64_t q, uint32_t* timeout_flag) {
+  const int lane = threadIdx.x;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+    if (lane < n && lane != skip) ok = __hip_atomic_load(w + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= q;
+    if (__ballot(!ok) == 0) break;
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > 2000000000ull) {  // (100 MHz constant clock)
+      if (lane == 0) __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+void copy_carrier_free(rcsh_sim* s) {
+  CopyCarrier* c = s->copy;
+  if (!c) return;
+  for (int p = 0; p < c->world; ++p) {
+    if (c->cs[p]) hipStreamSynchronize(c->cs[p]);
+  }
+  for (int p = 0; p < c->world; ++p) {
+    if (c->opened[p]) {
+      for (int k = 0; k < 2; ++k) if (c->peer_recv[p][k]) hipIpcCloseMemHandle(c->peer_recv[p][k]);
+      if (c->peer_flags[p]) hipIpcCloseMemHandle(c->peer_flags[p]);
+    }
+    if (c->cs[p]) hipStreamDestroy(c->cs[p]);
+    if (c->cs_done[p]) hipEventDestroy(c->cs_done[p]);
+  }
+  if (c->acked) hipEventDestroy(c->acked);
+  for (int k = 0; k < 2; ++k) if (c->recv[k]) hipFree(c->recv[k]);
+  if (c->flags) hipFree(c->flags);
+  if (c->seq_ring) hipHostFree(c->seq_ring);
+  if (c->timeout_flag) hipHostFree(c->timeout_flag);
+  delete c;
+  s->copy = nullptr;
+}
+}  // namespace
+
+int rcsh_comm_copy_create(rcsh_sim* s, int32_t rank, int32_t world, size_t bytes_per_rank, uint8_t blob[RCSH_COMM_COPY_BLOB_BYTES]) {
+  REQUIRE_SIM(s);
+  if (!blob || world < 1 || world > kCopyMaxWorld || rank < 0 || rank >= world || bytes_per_rank == 0 || bytes_per_rank % 8)
+    return fail(RCSH_ERR_ARG, "copy carrier: need 0 <= rank < world <= 16 and a block size that is a multiple of 8 bytes");
+  if (s->comm || s->copy) return fail(RCSH_ERR_STATE, "a communicator is already attached to this sim");
+  CopyCarrier* c = new CopyCarrier;
+  s->copy = c;
+  c->rank = rank; c->world = world; c->bytes = bytes_per_rank;
+  hipError_t he = hipSuccess;
+  auto ok = [&](hipError_t e) { if (he == hipSuccess) he = e; return he == hipSuccess; };
+  for (int k = 0; k < 2 && he == hipSuccess; ++k) ok(hipMalloc(&c->recv[k], bytes_per_rank * world));
+  // (fine-grained: the words are written by copies other processes start and polled by a wavefront of this one)
+  void* fl = nullptr;
+  if (ok(hipExtMallocWithFlags(&fl, sizeof(uint64_t) * 2 * 2 * kCopyMaxWorld, hipDeviceMallocFinegrained))) {
+    c->flags = (uint64_t*)fl;
+    ok(hipMemset(c->flags, 0, sizeof(uint64_t) * 2 * 2 * kCopyMaxWorld));
+  }
+  if (he == hipSuccess) ok(hipHostMalloc((void**)&c->seq_ring, sizeof(uint64_t) * kCopySeqRing, hipHostMallocDefault));
+  if (he == hipSuccess) ok(hipHostMalloc((void**)&c->timeout_flag, sizeof(uint32_t), hipHostMallocDefault));
+  if (he == hipSuccess) *c->timeout_flag = 0;
+  if (he == hipSuccess) ok(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+  if (he == hipSuccess) ok(hipEventCreateWithFlags(&s->comm_ready, hipEventDisableTiming));
+  for (int k = 0; k < 2 && he == hipSuccess; ++k) ok(hipEventCreateWithFlags(&s->comm_done[k], hipEventDisableTiming));
+  if (he == hipSuccess) ok(hipEventCreateWithFlags(&c->acked, hipEventDisableTiming));
+  for (int p = 0; p < world && he == hipSuccess; ++p) {
+    ok(hipStreamCreateWithFlags(&c->cs[p], hipStreamNonBlocking));
+    if (he == hipSuccess) ok(hipEventCreateWithFlags(&c->cs_done[p], hipEventDisableTiming));
+  }
+  CopyBlob b{};
+  b.magic = 0x52435348u; b.rank = (uint32_t)rank; b.bytes_per_rank = bytes_per_rank; b.device = s->device; b.pid = (int32_t)getpid();
+  for (int k = 0; k < 2 && he == hipSuccess; ++k) ok(hipIpcGetMemHandle(&b.recv[k], c->recv[k]));
+  if (he == hipSuccess) ok(hipIpcGetMemHandle(&b.flags, c->flags));
+  if (he != hipSuccess) {
+    if (s->comm_stream) hipStreamDestroy(s->comm_stream);
+    if (s->comm_ready) hipEventDestroy(s->comm_ready);
+    for (int k = 0; k < 2; ++k) if (s->comm_done[k]) hipEventDestroy(s->comm_done[k]);
+    s->comm_stream = nullptr; s->comm_ready = s->comm_done[0] = s->comm_done[1] = nullptr;
+    copy_carrier_free(s);
+    return fail(RCSH_ERR_DEVICE, std::string("copy carrier: ") + hipGetErrorString(he));
+  }
+  std::memset(blob, 0, RCSH_COMM_COPY_BLOB_BYTES);
+  std::memcpy(blob, &b, sizeof(b));
+  s->comm_pending[0] = s->comm_pending[1] = false;
+  s->comm_rank = rank; s->comm_world = world;
+  return RCSH_OK;
+}
+
+int rcsh_comm_copy_connect(rcsh_sim* s, const uint8_t* blobs) {
+  REQUIRE_SIM(s);
+  CopyCarrier* c = s->copy;
+  if (!c) return fail(RCSH_ERR_STATE, "no copy carrier: call rcsh_comm_copy_create first");
+  if (c->connected) return fail(RCSH_ERR_STATE, "the copy carrier is connected already");
+  if (!blobs) return fail(RCSH_ERR_ARG, "null blobs");
+  for (int p = 0; p < c->world; ++p) {
+    CopyBlob b;
+    std::memcpy(&b, blobs + (size_t)p * RCSH_COMM_COPY_BLOB_BYTES, sizeof(b));
+    if (b.magic != 0x52435348u || (int)b.rank != p || b.bytes_per_rank != c->bytes)
+      return fail(RCSH_ERR_ARG, "copy carrier: blob " + std::to_string(p) + " is not rank " + std::to_string(p) + "'s, or the ranks disagree on the block size");
+    if (p == c->rank) {
+      c->peer_recv[p][0] = c->recv[0]; c->peer_recv[p][1] = c->recv[1]; c->peer_flags[p] = c->flags;
+      continue;
+    }
+    if (b.pid == (int32_t)getpid()) return fail(RCSH_ERR_ARG, "copy carrier: two ranks in one process (IPC handles open in another process only)");
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipIpcOpenMemHandle(&c->peer_recv[p][k], b.recv[k], hipIpcMemLazyEnablePeerAccess));
+    void* fl = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&fl, b.flags, hipIpcMemLazyEnablePeerAccess));
+    c->peer_flags[p] = (uint64_t*)fl;
+    c->opened[p] = true;
+  }
+  c->connected = true;
+  return RCSH_OK;
+}
+
+int rcsh_comm_copy_recv_buffer(rcsh_sim* s, int32_t slot, void** recv_dev) {
+  REQUIRE_SIM(s);
+  if (!s->copy) return fail(RCSH_ERR_STATE, "no copy carrier: call rcsh_comm_copy_create first");
+  if (slot < 0 || slot > 1 || !recv_dev) return fail(RCSH_ERR_ARG, "exchange slot is 0 or 1");
+  *recv_dev = s->copy->recv[slot];
+  return RCSH_OK;
+}
+
+namespace {
+int copy_allgather(rcsh_sim* s, int32_t slot, const void* send_dev, void* recv_dev, size_t bytes_per_rank) {
+  CopyCarrier* c = s->copy;
+  if (!c->connected) return fail(RCSH_ERR_STATE, "copy carrier: call rcsh_comm_copy_connect first");
+  if (recv_dev != c->recv[slot] || bytes_per_rank != c->bytes)
+    return fail(RCSH_ERR_ARG, "copy carrier: the receive buffer of a slot is the carrier's (rcsh_comm_copy_recv_buffer), the block size the one it was created with");
+  if (*c->timeout_flag) return fail(RCSH_ERR_DEVICE, "copy carrier: an earlier gather gave up waiting for a peer");
+  const uint64_t q = ++c->seq[slot];
+  uint64_t* qsrc = c->seq_ring + (c->ring_pos++ % kCopySeqRing);
+  *qsrc = q;
+  const int me = c->rank, W = c->world;
+  auto flag = [&](uint64_t* base, int kind, int sl, int r) { return base + ((size_t)kind * 2 + sl) * kCopyMaxWorld + r; };
+  // after what the handle's stream holds so far: the env-step that wrote the send buffer, the consumer of this slot's last gather
+  HIP_TRY(hipEventRecord(s->comm_ready, s->stream));
+  HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->comm_ready, 0));
+  // 1. tell every peer that this rank's receive buffer of the slot is free for q; wait until every peer has said so
+  for (int p = 0; p < W; ++p)
+    if (p != me) HIP_TRY(hipMemcpyAsync(flag(c->peer_flags[p], 0, slot, me), qsrc, sizeof(uint64_t), hipMemcpyHostToDevice, s->comm_stream));
+  if (W > 1) {
+    hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, s->comm_stream, flag(c->flags, 0, slot, 0), W, me, q, c->timeout_flag);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(c->acked, s->comm_stream));
+  // 2. the block to every peer, each over its own stream (its own link), followed by the word that says it has arrived
+  for (int p = 0; p < W; ++p) {
+    HIP_TRY(hipStreamWaitEvent(c->cs[p], c->acked, 0));
+    HIP_TRY(hipMemcpyAsync((char*)c->peer_recv[p][slot] + (size_t)me * c->bytes, send_dev, c->bytes, hipMemcpyDeviceToDevice, c->cs[p]));
+    if (p != me) HIP_TRY(hipMemcpyAsync(flag(c->peer_flags[p], 1, slot, me), qsrc, sizeof(uint64_t), hipMemcpyHostToDevice, c->cs[p]));
+    HIP_TRY(hipEventRecord(c->cs_done[p], c->cs[p]));
+    HIP_TRY(hipStreamWaitEvent(s->comm_stream, c->cs_done[p], 0));  // (the send buffer is free once these have run)
+  }
+  // 3. the slot is gathered when every peer's block has arrived here
+  if (W > 1) {
+    hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, s->comm_stream, flag(c->flags, 1, slot, 0), W, me, q, c->timeout_flag);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(s->comm_done[slot], s->comm_stream));
+  s->comm_pending[slot] = true;
+  return RCSH_OK;
+}
+}  // namespace
+
+
 // ---- RCCL behind the C-ABI.  The library is dlopen'ed so that single-GPU users neither link nor load it.
 namespace {
 struct Rccl {
@@ -2051,9 +2325,10 @@ int rcsh_comm_rank(const rcsh_sim* s, int32_t* rank, int32_t* world) {
 
 int rcsh_comm_allgather_dev(rcsh_sim* s, int32_t slot, const void* send_dev, void* recv_dev, size_t bytes_per_rank) {
   REQUIRE_SIM(s);
-  if (!s->comm) return fail(RCSH_ERR_STATE, "no communicator: call rcsh_comm_init first");
+  if (!s->comm && !s->copy) return fail(RCSH_ERR_STATE, "no communicator: call rcsh_comm_init (or rcsh_comm_copy_create) first");
   if (!send_dev || !recv_dev) return fail(RCSH_ERR_ARG, "null buffer");
   if (slot < 0 || slot > 1) return fail(RCSH_ERR_ARG, "exchange slot is 0 or 1");
+  if (s->copy) return copy_allgather(s, slot, send_dev, recv_dev, bytes_per_rank);
   // after what the handle's stream holds so far (the env-step that wrote the observations), on the communicator's stream
   HIP_TRY(hipEventRecord(s->comm_ready, s->stream));
   HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->comm_ready, 0));
@@ -2070,11 +2345,12 @@ int rcsh_env_allgather_obs_dev(rcsh_sim* s, int32_t slot, const double* local_ob
 
 int rcsh_comm_wait(rcsh_sim* s, int32_t slot, int32_t block_host) {
   REQUIRE_SIM(s);
-  if (!s->comm) return fail(RCSH_ERR_STATE, "no communicator: call rcsh_comm_init first");
+  if (!s->comm && !s->copy) return fail(RCSH_ERR_STATE, "no communicator: call rcsh_comm_init (or rcsh_comm_copy_create) first");
   if (slot < 0 || slot > 1) return fail(RCSH_ERR_ARG, "exchange slot is 0 or 1");
   if (!s->comm_pending[slot]) return RCSH_OK;
   if (block_host) {
     HIP_TRY(hipEventSynchronize(s->comm_done[slot]));
+    if (s->copy && *s->copy->timeout_flag) return fail(RCSH_ERR_DEVICE, "copy carrier: gave up waiting for a peer's block (a rank died?)");
     s->comm_pending[slot] = false;  // (a stream-side wait leaves it set: a later host-side wait must still see the event)
   } else HIP_TRY(hipStreamWaitEvent(s->stream, s->comm_done[slot], 0));
   return RCSH_OK;
@@ -2082,15 +2358,17 @@ int rcsh_comm_wait(rcsh_sim* s, int32_t slot, int32_t block_host) {
 
 int rcsh_comm_destroy(rcsh_sim* s) {
   REQUIRE_SIM(s);
-  if (!s->comm) return RCSH_OK;
+  if (!s->comm && !s->copy) return RCSH_OK;
   hipStreamSynchronize(s->comm_stream);
-  rccl().CommDestroy(s->comm);
+  if (s->copy) copy_carrier_free(s);
+  else rccl().CommDestroy(s->comm);
   hipEventDestroy(s->comm_ready); hipEventDestroy(s->comm_done[0]); hipEventDestroy(s->comm_done[1]);
   hipStreamDestroy(s->comm_stream);
   s->comm = nullptr; s->comm_stream = nullptr; s->comm_ready = s->comm_done[0] = s->comm_done[1] = nullptr; s->comm_pending[0] = s->comm_pending[1] = false;
   s->comm_rank = 0; s->comm_world = 1;
   return RCSH_OK;
 }
+
 
 int rcsh_dev_alloc(rcsh_sim* s, size_t bytes, void** ptr) {
   REQUIRE_SIM(s);
@@ -2136,6 +2414,10 @@ extern "C" int rcsh_debug_check_pairs(rcsh_sim* s, int32_t* g0g1 /* [cap][2] */,
 }
 #endif
 #ifdef RCSH_PHASE_TIMING
+extern "C" int rcsh_debug_slack(double* out16) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(rcsh::g_slack_dbg), sizeof(double) * 16) != hipSuccess;
+}
 extern "C" int rcsh_debug_team_cycles(unsigned long long* out16 /* 24 slots */) {
   hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_team_cycles), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : 1;

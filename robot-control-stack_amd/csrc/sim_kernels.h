@@ -846,19 +846,26 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     // (the contact-resolving launch of a step in which no environment is escalated and none has just been flagged -- every step of a
     // rollout that touches nothing -- ends here: two scalar loads instead of the masks' scan and the merge, 22 us -> the launch itself)
     if (esc_role == 2 && opk.esc_ctr[1] == 0 && opk.esc_ctr[2] == 0) return;
-    // (role 2 may spread its environments one per workgroup: every workgroup asks)
-    const int pick = (e_slot0 < Pk.n || esc_role == 2) ? esc_select(opk, Pk.n, e_slot0, team, esc_redo, esc_role == 2) : -1;
-    if (__ballot(pick >= 0) == 0) {  // no environment for any of this workgroup's four slots
-      if (esc_role == 2) esc_finish(opk, Pk.n);
-      return;
+    if (esc_role == 2) {
+      // (role 2 may spread its environments one per workgroup: every workgroup asks)
+      const int pick = esc_select(opk, Pk.n, e_slot0, team, esc_redo, true);
+      if (__ballot(pick >= 0) == 0) {  // no environment for any of this workgroup's four slots
+        esc_finish(opk, Pk.n);
+        return;
+      }
+      e = pick >= 0 ? pick : Pk.n;
     }
-    e = pick >= 0 ? pick : Pk.n;
   }
-  const bool live = e < Pk.n && !(opk.mask && !opk.mask[e < Pk.n ? e : 0]);
-  const bool leader = t == 0 && live;
+  // Role 1 (the lean launch) keeps the plain slot -> environment map and sits an escalated environment's team out: the word of the
+  // escalated mask is asked for together with the state, so the launch does not begin with a memory round trip of its own (ranking the
+  // environments that are not escalated, as role 2 ranks those that are, cost the headline 10 us a step: one dependent load before the
+  // state could be asked for, and the copy's stores -- which need the state -- ahead of the model staging).  The team's loads go out
+  // whether or not it is escalated; `live` is settled when they come back.
+  const bool in_range = e < Pk.n && !(opk.mask && !opk.mask[e < Pk.n ? e : 0]);
+  uint64_t esc_word = 0;
+  if (esc_role == 1 && in_range) esc_word = opk.esc[e >> 6];
   // where this launch reads the environment's state from: its state, or (a step that is redone) the copy the lean launch kept
   const double* const Sin = esc_redo ? opk.snap : Pk.S;
-  const bool snap_out = esc_role == 1 && live;
   // The environment's state goes out first -- every lane asks for up to three of the fields that are staged in LDS,
   // the leader for the five it keeps in registers -- so that the model staging below hides the round trip to HBM.
   using SF = TeamStagedFields<T, ST>;
@@ -872,8 +879,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   int32_t pre_conv = 0;
   double xs_in = 0.0;
   // the contact check's remembered directions (lanes 0..7 of a team; check_team.h): asked for with the state, used after the last substep
-  const double sep_in = live && t < kCheckSep && !opk.do_reset ? Pk.S[(size_t)(Lay<T>::SEP + t) * Pk.n + e] : 0.0;
-  if (live) {
+  const double sep_in = in_range && t < kCheckSep && !opk.do_reset ? Pk.S[(size_t)(Lay<T>::SEP + t) * Pk.n + e] : 0.0;
+  if (in_range) {
 #pragma unroll
     for (int rd = 0; rd < SF::kRounds; ++rd) {
       const int k = t + rd * kTeamLanes;
@@ -902,32 +909,6 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       pre_flags = esc_redo ? opk.snap_flags[e] : Pk.flags[e];
       pre_conv = esc_redo ? opk.snap_conv[e] : Pk.conv_steps[e];
     }
-    if (snap_out) {
-      // per-environment escalation, the lean launch: everything just read that this launch will overwrite, kept for the case that
-      // the step has to be redone with its contacts resolved (RunOp::esc_role)
-      using L = Lay<T>;
-#pragma unroll
-      for (int rd = 0; rd < SF::kRounds; ++rd) {
-        const int k = t + rd * kTeamLanes;
-        int field = 0, slot = 0;
-        SF::locate(k < nstaged ? k : 0, field, slot);
-        if (k < nstaged) opk.snap[(size_t)field * Pk.n + e] = staged[rd];
-      }
-      if constexpr (FRIC) {
-        if (t < T::NL && !opk.do_reset) opk.snap[(size_t)(L::XS + t) * Pk.n + e] = xs_in;
-      }
-      if (opk.apply_action && t < T::NARM) {
-        if (Pk.env.relative_to == 2) { opk.snap[(size_t)(L::ORIGIN + t) * Pk.n + e] = in_origin; opk.snap[(size_t)(L::LASTA + t) * Pk.n + e] = in_lasta; }
-        opk.snap[(size_t)(L::PREVA + t) * Pk.n + e] = in_preva;
-      }
-      if (t == 0) {
-        opk.snap[(size_t)L::TIME * Pk.n + e] = pre_time;
-        opk.snap[(size_t)(L::GRIP + 0) * Pk.n + e] = pre_cmd;
-        opk.snap[(size_t)(L::GRIP + 1) * Pk.n + e] = pre_width;
-        opk.snap_flags[e] = pre_flags;
-        opk.snap_conv[e] = pre_conv;
-      }
-    }
   }
   __shared__ LinkRec llinks[T::NL];  // per-link records, stored behind the DevModel (model.h)
   __shared__ std::conditional_t<(BOX || CON), BoxTaskCfg, char> lbt[1];
@@ -946,6 +927,35 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     __syncthreads();
   }
   TEAM_MARK(12)
+  const bool live = in_range && !((esc_word >> (e & 63)) & 1ull);
+  const bool leader = t == 0 && live;
+  if (esc_role == 1 && __ballot(live) == 0) return;  // (every environment of this workgroup is on the contact-resolving kernel, or out of range)
+  if (esc_role == 1 && live) {
+    // per-environment escalation, the lean launch: everything just read that this launch will overwrite, kept for the case that
+    // the step has to be redone with its contacts resolved (RunOp::esc_role)
+    using L = Lay<T>;
+#pragma unroll
+    for (int rd = 0; rd < SF::kRounds; ++rd) {
+      const int k = t + rd * kTeamLanes;
+      int field = 0, slot = 0;
+      SF::locate(k < nstaged ? k : 0, field, slot);
+      if (k < nstaged) opk.snap[(size_t)field * Pk.n + e] = staged[rd];
+    }
+    if constexpr (FRIC) {
+      if (t < T::NL && !opk.do_reset) opk.snap[(size_t)(L::XS + t) * Pk.n + e] = xs_in;
+    }
+    if (opk.apply_action && t < T::NARM) {
+      if (Pk.env.relative_to == 2) { opk.snap[(size_t)(L::ORIGIN + t) * Pk.n + e] = in_origin; opk.snap[(size_t)(L::LASTA + t) * Pk.n + e] = in_lasta; }
+      opk.snap[(size_t)(L::PREVA + t) * Pk.n + e] = in_preva;
+    }
+    if (t == 0) {
+      opk.snap[(size_t)L::TIME * Pk.n + e] = pre_time;
+      opk.snap[(size_t)(L::GRIP + 0) * Pk.n + e] = pre_cmd;
+      opk.snap[(size_t)(L::GRIP + 1) * Pk.n + e] = pre_width;
+      opk.snap_flags[e] = pre_flags;
+      opk.snap_conv[e] = pre_conv;
+    }
+  }
   const DevModelHead& m = lm;
   const ST st{lds + team * ST::COUNT};
   EnvRegs<T, ST> r;  // meaningful on the leader only

@@ -177,7 +177,7 @@ EXPORTS = (
     "rcsh_dev_alloc", "rcsh_dev_free", "rcsh_dev_upload", "rcsh_dev_download", "rcsh_prof_enable", "rcsh_prof_read",
     "rcsh_debug_dump_model",
     "rcsh_comm_get_unique_id", "rcsh_comm_init", "rcsh_comm_rank", "rcsh_env_allgather_obs_dev", "rcsh_comm_allgather_dev", "rcsh_comm_wait",
-    "rcsh_comm_destroy",
+    "rcsh_comm_destroy", "rcsh_comm_copy_create", "rcsh_comm_copy_connect", "rcsh_comm_copy_recv_buffer",
     "rcsh_sim_contact_table_dropped",
     "rcsh_sim_contact_check_unchecked_pairs",
     "rcsh_sim_contact_unresolved",
@@ -213,6 +213,9 @@ def load() -> C.CDLL:
     L.rcsh_comm_allgather_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t]
     L.rcsh_comm_wait.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.rcsh_comm_destroy.argtypes = [C.c_void_p]
+    L.rcsh_comm_copy_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_size_t, C.c_char_p]
+    L.rcsh_comm_copy_connect.argtypes = [C.c_void_p, C.c_char_p]
+    L.rcsh_comm_copy_recv_buffer.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
     L.rcsh_sim_set_kernel.argtypes = [C.c_void_p, C.c_int32]
     L.rcsh_sim_state_bytes.restype = C.c_size_t
     L.rcsh_sim_state_bytes.argtypes = [C.c_void_p]

@@ -279,3 +279,53 @@ class RcclObservationExchange:
                 self.close()
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
+
+
+class CopyObservationExchange(RcclObservationExchange):
+    """The same slot protocol over COPY ENGINES instead of RCCL's collective kernel (``rcsh_comm_copy_*``): every rank writes its
+    block into each peer's IPC-mapped receive buffer with asynchronous copies (SDMA over xGMI, a stream per peer) and follows it
+    with the step's sequence number into a flag word of the peer; one 64-lane wavefront per gather waits for the words.  RCCL's
+    all-gather kernel needs 261-280 registers a lane and cannot share a SIMD with a stepping wavefront of 424, so on a full
+    batch it starts when the env-step ends; nothing here needs more than 16 registers on a CU.
+
+    `gather_blobs(blob) -> list[bytes]` is the side channel (every rank's 256-byte export, in rank order): e.g.
+    ``SocketRendezvous.gather`` + ``broadcast``.  One rank per process.  Interface and semantics otherwise as the base class.
+    """
+
+    BLOB_BYTES = 256
+
+    def __init__(self, sim, rank: int, world: int, gather_blobs, n_rows: int | None = None, width: int | None = None):
+        import ctypes as C
+
+        from .. import _lib
+
+        self._C, self._lib, self._L, self._h = C, _lib, _lib.load(), sim._h
+        self._sim = sim
+        self.rank, self.world = rank, world
+        own = (sim.n_envs, int(self._L.rcsh_env_obs_width(sim._h)))
+        self.n, self.width = (n_rows or own[0]), (width or own[1])
+        self._plain = False  # (the block size is the carrier's; rcsh_comm_allgather_dev takes it explicitly)
+        self._bytes = 8 * self.n * self.width
+        blob = C.create_string_buffer(self.BLOB_BYTES)
+        _lib.check(self._L.rcsh_comm_copy_create(self._h, rank, world, self._bytes, blob))
+        blobs = gather_blobs(blob.raw)
+        if len(blobs) != world or any(len(b) != self.BLOB_BYTES for b in blobs):
+            raise RuntimeError("CopyObservationExchange: the side channel must return every rank's blob, in rank order")
+        _lib.check(self._L.rcsh_comm_copy_connect(self._h, b"".join(blobs)))
+        self._local, self._all = [], []
+        for slot in range(2):
+            p = C.c_void_p()
+            _lib.check(self._L.rcsh_dev_alloc(self._h, self._bytes, C.byref(p)))
+            self._local.append(p)
+            r = C.c_void_p()
+            _lib.check(self._L.rcsh_comm_copy_recv_buffer(self._h, slot, C.byref(r)))
+            self._all.append(r)  # (the carrier's: freed with it)
+
+    def close(self) -> None:
+        if self._h is not None:
+            self.drain()
+            for p in self._local:
+                self._L.rcsh_dev_free(self._h, p)
+            self._L.rcsh_comm_destroy(self._h)
+            self._h = None
+            self._sim = None

@@ -27,7 +27,7 @@ def _dev_upload(L, h, arr):
     return p
 
 
-def _exchange_worker(rank, world, uid_q, out_q, n_steps):
+def _exchange_worker(rank, world, uid_q, out_q, n_steps, carrier="rccl", same_device=False):
     """One rank of the slot protocol: step, post slot t & 1, keep stepping into the other slot, read the gathered block two steps
     later (the overlap bench.py relies on).  Every rank's rows must be that rank's observations, in rank order."""
     try:
@@ -36,15 +36,32 @@ def _exchange_worker(rank, world, uid_q, out_q, n_steps):
         from rcs_amd.envs.sharding import RcclObservationExchange, comm_unique_id
 
         n = 96
-        env = make_vec_env(n, True, device=rank)
-        if rank == 0:
-            uid = comm_unique_id()
-            for _ in range(world - 1):
-                uid_q.put(uid)
-        else:
-            uid = uid_q.get(timeout=120)
+        env = make_vec_env(n, True, device=0 if same_device else rank)
         L, h = env._L, env.sim._h
-        with RcclObservationExchange(env.sim, uid, rank, world) as ex:
+        if carrier == "copy":
+            from rcs_amd.envs.sharding import CopyObservationExchange
+
+            def gather_blobs(blob):
+                # (the test's side channel: every rank puts its blob on its peers' queues -- uid_q is a list of per-rank queues here)
+                for r in range(world):
+                    if r != rank:
+                        uid_q[r].put((rank, blob))
+                blobs = {rank: blob}
+                while len(blobs) < world:
+                    r, b = uid_q[rank].get(timeout=120)
+                    blobs[r] = b
+                return [blobs[r] for r in range(world)]
+
+            make = lambda: CopyObservationExchange(env.sim, rank, world, gather_blobs)  # noqa: E731
+        else:
+            if rank == 0:
+                uid = comm_unique_id()
+                for _ in range(world - 1):
+                    uid_q.put(uid)
+            else:
+                uid = uid_q.get(timeout=120)
+            make = lambda: RcclObservationExchange(env.sim, uid, rank, world)  # noqa: E731
+        with make() as ex:
             env.reset()
             rng = np.random.default_rng(100 + rank)
             acts = rng.uniform(-0.05, 0.05, (n_steps, n, env.dof))
@@ -68,12 +85,12 @@ def _exchange_worker(rank, world, uid_q, out_q, n_steps):
         out_q.put((rank, False, repr(exc)))
 
 
-def _run_exchange(world):
+def _run_exchange(world, carrier="rccl", same_device=False, n_steps=6):
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
-    uid_q, out_q = ctx.Queue(), ctx.Queue()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, world, uid_q, out_q, 6)) for r in range(world)]
+    uid_q, out_q = (ctx.Queue() if carrier == "rccl" else [ctx.Queue() for _ in range(world)]), ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, uid_q, out_q, n_steps, carrier, same_device)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(out_q.get(timeout=300) for _ in range(world))
@@ -93,6 +110,26 @@ def test_rccl_exchange_slot_protocol_one_rank_per_gpu():
     if ndev < 2:
         pytest.skip("one GPU: RCCL refuses two ranks on one device (covered over gloo in tests/test_distributed_cpu.py)")
     _run_exchange(2)  # (two ranks exercise everything the protocol has; the full node is the driver's scaling run)
+
+
+def test_copy_engine_exchange_single_rank():
+    """The copy-engine carrier of the all-gather (rcsh_comm_copy_*) with one rank: local block only, the slot protocol unchanged."""
+    _run_exchange(1, carrier="copy")
+
+
+def test_copy_engine_exchange_two_processes_on_one_gpu():
+    """Two ranks in two processes on ONE device: every rank's block arrives in the other's IPC-mapped receive buffer, in rank
+    order, with the two-slot overlap (a gather is read while the next env-step writes the other slot); 12 steps, so that every
+    flag word is reused several times.  (The same code path a node's 8 processes take; there the copies run over xGMI.)"""
+    _run_exchange(2, carrier="copy", same_device=True, n_steps=12)
+
+
+def test_copy_engine_exchange_one_rank_per_gpu():
+    from rcs_amd import _lib
+
+    if int(_lib.load().rcsh_device_count()) < 2:
+        pytest.skip("one GPU (the two-process test above covers the protocol)")
+    _run_exchange(2, carrier="copy")
 
 
 def test_mixed_robot_shards_of_baseline_config_4():

@@ -24,6 +24,15 @@ def read():
 NAMES = {0: "pos stage", 1: "1", 2: "2", 3: "3", 4: "4", 15: "15", 5: "5", 6: "6", 7: "7", 8: "8", 9: "loop tail", 10: "epilogue+check", 11: "11", 12: "prologue12", 13: "13", 14: "14",
          16: "collide before self", 17: "self broad", 18: "self narrow", 24: "before collide", 37: "link frames", 38: "lane per geom", 39: "hulls wavefront", 25: "floor/fastpath", 26: "compaction", 27: "rows/qacc_smooth/M", 28: "newton pre", 55: "x update", 48: "rows+grad",
          49: "stiffness", 50: "Hessian", 51: "row loads", 52: "LDL+solves", 53: "pre linesearch", 54: "linesearch", 30: "forces/Y/K", 31: "noslip rest", 40: "ns rel", 41: "ns owner", 44: "ns slots", 32: "results"}
+try:  # the geom pairs of the self-contact stage (index -> geoms), for the slack test's examples
+    import ctypes as _C
+    g01 = (_C.c_int32 * (2 * 256))(); npair_ = _C.c_int32(); nb_ = _C.c_int32()
+    L.rcsh_debug_check_pairs(venv.sim._h, g01, 256, _C.byref(npair_), _C.byref(nb_))
+    PAIRS = [(g01[2 * i], g01[2 * i + 1]) for i in range(npair_.value)]
+    print("pairs:", len(PAIRS))
+except Exception as exc:  # noqa: BLE001
+    PAIRS = []
+    print("no pair table:", exc)
 base = read()
 t0 = time.time()
 for t in range(steps):
@@ -42,6 +51,12 @@ for t in range(steps):
         if d[81] or d[76]:
             print(f"    per coupled phase, all workgroups: few contacts ({d[81]:.0f}): collide {d[78] / max(d[81], 1):.0f}, Newton {d[79] / max(d[81], 1):.0f}, noslip {d[80] / max(d[81], 1):.0f} cycles; "
                   f"many ({d[76]:.0f}): collide {d[73] / max(d[76], 1):.0f}, Newton {d[74] / max(d[76], 1):.0f}, noslip {d[75] / max(d[76], 1):.0f}; quiet collision passes {d[82] / max(d[71] - d[72], 1):.0f}")
+        if d[92]:
+            print(f"    slack test at the top of the collision pass: {d[92]:.0f} passes, {d[93]:.0f} with a geom pair due, {d[94]:.0f} with a geom due against the floor; last examples: pair {int(a[95]) % 1000 - 1} {PAIRS[int(a[95]) % 1000 - 1] if 0 < int(a[95]) % 1000 <= len(PAIRS) else ''}, floor geom {int(a[95]) // 1000 - 1}")
+        if d[92]:
+            sd = (C.c_double * 16)(); L.rcsh_debug_slack(sd)
+            gg = int(sd[2])
+            print(f"      example: env {int(sd[4])} pair {int(sd[0])} geoms {gg & 255},{(gg >> 8) & 255} common ancestor {((gg >> 16) & 255) - 1}: remaining gap after this substep's motion {sd[1]:.3e}, stored by the last pass {sd[3]:.3e}")
         if a[66]:
             print(f"    worst workgroup of the window (environment {a[91]:.0f}): {a[66]:.0f} cycles; contact phases {a[86]:.0f}, coupled {a[87]:.0f} with {a[88] / max(a[87], 1):.1f} contacts each "
                   f"({a[89]:.0f} on the tree formulation); collide {a[83]:.0f}, Newton {a[84]:.0f}, noslip {a[85]:.0f}, quiet collision passes {a[90]:.0f}")
