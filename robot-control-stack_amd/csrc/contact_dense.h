@@ -22,11 +22,13 @@ namespace rcsh {
 
 #if defined(__HIP__)
 
-constexpr int kDenseCon = 14;
+// (with a free box the rows have 15 entries and Y fits behind 14 records; without one 9, and 21 contacts are 63 rows: a lane each)
+constexpr int kDenseConBox = 14, kDenseConNoBox = 21;
 
 template <class T, bool BOXD>
 struct DenseLds {
   static constexpr int NL = T::NL, NVD = BOXD ? T::NL + 6 : T::NL;
+  static constexpr int kDenseCon = BOXD ? kDenseConBox : kDenseConNoBox;
   static constexpr int kRows = 3 * kDenseCon;
   static constexpr int kRowsInStage = (64 * 8) / NVD;
   using AR = ContactArena<T>;
@@ -678,7 +680,7 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
     if (r & 1u) {
       const unsigned long long nc_ = (unsigned long long)in_lds(&ar)->ncon;
       atomicAdd(&g_team_cycles[72], 1ull); atomicAdd(&g_team_cycles[70], nc_); atomicMax(&g_team_cycles[68], nc_);
-      if (nc_ > (unsigned long long)kDenseCon) atomicAdd(&g_team_cycles[69], 1ull);
+      if (nc_ > (unsigned long long)DenseLds<T, BOXD>::kDenseCon) atomicAdd(&g_team_cycles[69], 1ull);
     } else {
       atomicAdd(&g_team_cycles[82], pc1 - pc0);  // collision passes that found nothing
       s_wg_acc[7] += pc1 - pc0;
@@ -687,7 +689,7 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
   }
 #endif
   if (!(r & 1u) || !b.resolve) return r & ~1u;
-  const bool few = in_lds(&ar)->ncon <= kDenseCon;
+  const bool few = in_lds(&ar)->ncon <= DenseLds<T, BOXD>::kDenseCon;
 #ifndef RCSH_NO_DENSE
   if (few) {
     // few contacts (the headline's one or two, a pinch's dozen): the rows written out

@@ -610,7 +610,14 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
         if (esc) {
           static const int certify = [] { const char* e = std::getenv("RCSH_CHECK_CERTIFY"); return e ? std::atoi(e) : 0; }();
           op.esc_role = 1; op.check = certify ? 2 : 1;
+          // (measurement switches: what the copy of the state / the end-of-launch check cost a step -- results are wrong with either)
+          static const int no_snap = [] { const char* e = std::getenv("RCSH_ESC_MEASURE_NO_SNAP"); return e ? std::atoi(e) : 0; }();
+          static const int no_check = [] { const char* e = std::getenv("RCSH_ESC_MEASURE_NO_CHECK"); return e ? std::atoi(e) : 0; }();
+          double* const snap_keep = op.snap;
+          if (no_snap) op.snap = nullptr;
+          if (no_check) op.check = 0;
           go(N{}, N{}, N{});
+          op.snap = snap_keep;
           op.esc_role = 2; op.check = 0;
           static const int leave_quiet = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();
           op.esc_leave_quiet = leave_quiet;

@@ -484,3 +484,30 @@ def test_pad_against_pad_contacts_of_the_two_fingers():
         assert (con.body[0], con.body[1]) == (left, right) and con.geom[0] < con.geom[1]
         assert cm.arrays["geom_type"][con.geom[0]] == 6 and cm.arrays["geom_type"][con.geom[1]] == 6
         assert abs(con.dist + 2e-4) < 1e-9
+
+
+def test_link0_and_link1_never_touch_over_joint_1s_range():
+    """Round 5: the HIP side drops geom pairs that cannot touch across the arm's first hinge (csrc/rcs_hip.hip:
+    never_touch_across_first_hinge -- a geom welded to the world against a geom of link 1: a rotation about joint 1 leaves every
+    point's coordinate along the axis alone, and the two hulls' extents along it do not overlap).  MuJoCo's filters admit the pair
+    (the parent is static), and the oracle tests it in every substep: over joint 1's whole range, every other joint swept too, it
+    never yields a contact -- so dropping it changes no result."""
+    from rcs_env_oracle import FR3_Q_HOME
+
+    cm, o = _fr3_empty(3)
+    lo, hi = (float(x) for x in cm.arrays["jnt_range"].reshape(-1, 2)[0])
+    names = cm.geom_names
+    rng = np.random.default_rng(5)
+    ranges = cm.arrays["jnt_range"].reshape(-1, 2)[:7]
+    seen = set()
+    for k, q1 in enumerate(np.linspace(lo, hi, 97)):
+        q = np.array(FR3_Q_HOME, dtype=float)
+        if k % 2:  # the other joints anywhere in their ranges: they do not move link 1
+            q = ranges[:, 0] + rng.random(7) * (ranges[:, 1] - ranges[:, 0])
+        q[0] = q1
+        o.set_joints_hard(q)
+        o.step(1)
+        d = o.s.d
+        for c in range(d.ncon):
+            seen.add(tuple(sorted((names[d.contact[c].geom[0]], names[d.contact[c].geom[1]]))))
+    assert ("fr3_link0_collision_0", "fr3_link1_collision_0") not in seen, seen

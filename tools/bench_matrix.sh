@@ -4,7 +4,11 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/bench_matrix.jsonl
 : > $OUT
 run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $OUT; }
+run --steps 20 --warmup 5                                     # headline at the driver's length
 run --steps 300 --warmup 30                                   # headline: 4096 x fr3_empty_world JOINTS async
+run --steps 1000 --warmup 50                                  # BASELINE.md's rollout length
+run --steps 300 --warmup 30 --contacts flag --contact-check-every 16   # the round-4 configuration
+run --steps 300 --warmup 5 --mode convergence                 # ... 300 steps without a reset
 run --steps 30 --warmup 5 --mode convergence                  # reference default: step_until_convergence
 run --steps 200 --warmup 20 --control cartesian               # BASELINE configs[2]: CARTESIAN_TRPY -> CLIK + gripper
 run --steps 200 --warmup 20 --robot xarm7
