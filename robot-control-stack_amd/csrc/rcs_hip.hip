@@ -334,6 +334,15 @@ std::vector<SelfPair> list_geom_pairs(const rcsh_sim* s, bool reacting_only) {
       const ContactGeom &a = s->cgeoms[i], &b = s->cgeoms[j];
       if (a.link == b.link) continue;
       if (a.link >= 0 && b.link >= 0 && (parent(a.link) == b.link || parent(b.link) == a.link)) continue;
+      {
+        // MuJoCo's mask filter: the pair collides if (contype0 & conaffinity1) || (contype1 & conaffinity0) (advisor, round 4: pairs the
+        // masks exclude raised the sticky flags -- and, since round 5, would send an environment to the contact-resolving launch)
+        const auto& ct = s->hm.geom_contype;
+        const auto& ca = s->hm.geom_conaffinity;
+        if (a.geom_id < (int)ct.size() && b.geom_id < (int)ct.size() && a.geom_id < (int)ca.size() && b.geom_id < (int)ca.size() &&
+            !((ct[a.geom_id] & ca[b.geom_id]) || (ct[b.geom_id] & ca[a.geom_id])))
+          continue;
+      }
       if ((a.type == 7 && a.vert_num == 0) || (b.type == 7 && b.vert_num == 0)) continue;  // mesh blob missing from the checkout
       if (a.vert_num + b.vert_num > kSelfStageVertsHost) continue;  // (the contact table admits hulls of at most 152 vertices each: model.cpp build_contact_table)
       if (never_touch_across_first_hinge(s, a, b)) continue;

@@ -89,7 +89,8 @@ class SocketRendezvous:
     """The launcher-side rendezvous of an N-rank rollout on ONE node without any framework: rank 0 listens on a Unix-domain
     socket in the abstract namespace (named after MASTER_PORT, so that concurrent jobs do not meet), the other ranks connect, and
     the handful of control-plane collectives a rollout needs -- broadcast of the RCCL id, barrier, max / min / sum of a number,
-    gather of small byte strings -- go through rank 0 as length-prefixed pickles.  Nothing of the data path comes near it (that
+    gather of small byte strings -- go through rank 0 as length-prefixed JSON (bytes and arrays as tagged base64; peers are checked to
+    run under the same user, ranks to be in range and distinct).  Nothing of the data path comes near it (that
     is RCCL behind the C-ABI); it replaces the gloo process group ``bench.py`` used through round 3 (verdict r3, weak 13: "no
     PyTorch" also for the N > 1 launcher).  Blocking, in-order, one call at a time on every rank."""
 
@@ -114,7 +115,14 @@ class SocketRendezvous:
             while len(peers) < world - 1:
                 c, _ = srv.accept()
                 c.settimeout(timeout)
-                peers[self._recv(c)] = c
+                if not self._same_user(c):  # (another user's process: not one of this job's ranks)
+                    c.close()
+                    continue
+                r = self._recv(c)
+                if not isinstance(r, int) or isinstance(r, bool) or not 1 <= r < world or r in peers:
+                    c.close()
+                    raise RuntimeError(f"rendezvous: a peer announced rank {r!r} (world {world}, already here: {sorted(peers)})")
+                peers[r] = c
             srv.close()
             self._peers = [peers[r] for r in range(1, world)]
         else:
@@ -130,20 +138,64 @@ class SocketRendezvous:
                         raise RuntimeError(f"rank {rank}: no rendezvous socket {name!r} after {timeout} s") from None
                     time.sleep(0.05)
             s.settimeout(timeout)
+            if not self._same_user(s):
+                s.close()
+                raise RuntimeError(f"rank {rank}: the rendezvous socket {name!r} is held by another user's process")
             self._send(s, rank)
             self._sock = s
 
+    # Wire format: length-prefixed JSON of None / bool / int / float / str / lists, with bytes and numpy arrays as tagged base64 --
+    # nothing that executes on decoding (the rendezvous carried pickles through round 4: advisor).
+    @staticmethod
+    def _to_wire(obj):
+        import base64
+
+        import numpy as np
+
+        if obj is None or isinstance(obj, (bool, int, float, str)):
+            return obj
+        if isinstance(obj, (bytes, bytearray, memoryview)):
+            return {"b": base64.b64encode(bytes(obj)).decode("ascii")}
+        if isinstance(obj, np.ndarray):
+            a = np.ascontiguousarray(obj)
+            return {"nd": [a.dtype.str, list(a.shape), base64.b64encode(a.tobytes()).decode("ascii")]}
+        if isinstance(obj, np.generic):
+            return obj.item()
+        if isinstance(obj, (list, tuple)):
+            return [SocketRendezvous._to_wire(x) for x in obj]
+        raise TypeError(f"SocketRendezvous carries numbers, strings, bytes, numpy arrays and lists of them, not {type(obj).__name__}")
+
+    @staticmethod
+    def _from_wire(j):
+        import base64
+
+        import numpy as np
+
+        if isinstance(j, list):
+            return [SocketRendezvous._from_wire(x) for x in j]
+        if isinstance(j, dict):
+            if set(j) == {"b"}:
+                return base64.b64decode(j["b"])
+            if set(j) == {"nd"}:
+                dt, shape, data = j["nd"]
+                dtype = np.dtype(dt)
+                if dtype.hasobject:
+                    raise RuntimeError("rendezvous: object arrays are not carried")
+                return np.frombuffer(base64.b64decode(data), dtype=dtype).reshape([int(x) for x in shape]).copy()
+            raise RuntimeError("rendezvous: malformed message")
+        return j
+
     @staticmethod
     def _send(sock, obj) -> None:
-        import pickle
+        import json
         import struct
 
-        data = pickle.dumps(obj)
+        data = json.dumps(SocketRendezvous._to_wire(obj)).encode("utf-8")
         sock.sendall(struct.pack("<Q", len(data)) + data)
 
     @staticmethod
     def _recv(sock):
-        import pickle
+        import json
         import struct
 
         def exactly(n):
@@ -156,7 +208,23 @@ class SocketRendezvous:
             return buf
 
         (n,) = struct.unpack("<Q", exactly(8))
-        return pickle.loads(exactly(n))
+        if n > (1 << 32):
+            raise RuntimeError("rendezvous: message length out of range")
+        return SocketRendezvous._from_wire(json.loads(exactly(n).decode("utf-8")))
+
+    @staticmethod
+    def _same_user(sock) -> bool:
+        """The peer of a Unix-domain socket runs under this process's user (SO_PEERCRED): the abstract namespace has no file
+        permissions, any local process can connect to (or pre-bind) the name."""
+        import os
+        import socket
+        import struct
+
+        try:
+            _pid, uid, _gid = struct.unpack("3i", sock.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+        except OSError:
+            return False
+        return uid == os.getuid()
 
     def gather(self, value) -> list:
         """Every rank's `value`, in rank order, on every rank."""

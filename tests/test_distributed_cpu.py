@@ -78,7 +78,7 @@ def _socket_worker(rank, world, name, out):
     from rcs_amd.envs.sharding import SocketRendezvous
 
     rdv = SocketRendezvous(rank, world, name=name, timeout=30)
-    ok = rdv.gather(("r", rank)) == [("r", r) for r in range(world)]
+    ok = rdv.gather(["r", rank]) == [["r", r] for r in range(world)]  # (lists: the wire format is JSON, a tuple comes back as a list)
     ok = ok and rdv.broadcast(b"id-from-rank-0" if rank == 0 else None) == b"id-from-rank-0"
     ok = ok and rdv.reduce(0.5 + rank, max) == 0.5 + world - 1 and rdv.reduce(rank, sum) == sum(range(world)) and rdv.reduce(1 if rank else 0, min) == 0
     # an all-gather of array blocks through the rendezvous (the functional fallback of the exchange when RCCL cannot form a communicator)
