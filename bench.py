@@ -678,7 +678,13 @@ def main() -> None:
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
-        print(json.dumps(out))
+        # (librccl prints its version banner through C stdio, which is flushed at exit -- behind this line; the JSON line is the LAST line)
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if exchange:
         exchange.close()
     rdv.close()

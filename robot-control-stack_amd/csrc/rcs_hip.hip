@@ -2091,6 +2091,10 @@ struct CopyCarrier {
   int ring_pos = 0;
   uint32_t* timeout_flag = nullptr;     // pinned: a wait gave up (a peer died)
   bool connected = false;
+  // how the flag words are written and waited for: stream memory operations (hipStreamWriteValue64 / hipStreamWaitValue64: the
+  // command processor does both, nothing runs on a CU and nothing goes through a copy engine) with RCSH_COPY_CARRIER_FLAGS=value where
+  // the device has them; by default an 8-byte copy and the waiting wavefront.
+  bool stream_values = false;
 };
 namespace {
 // one wavefront: waits until the `n` words at `w` (skipping index `skip`) have all reached `q`; gives up after ~20 s
@@ -2160,6 +2164,14 @@ int rcsh_comm_copy_create(rcsh_sim* s, int32_t rank, int32_t world, size_t bytes
     ok(hipStreamCreateWithFlags(&c->cs[p], hipStreamNonBlocking));
     if (he == hipSuccess) ok(hipEventCreateWithFlags(&c->cs_done[p], hipEventDisableTiming));
   }
+  {
+    // (default: the 8-byte copies and ONE waiting wavefront per wait -- a wait on W - 1 words is W - 1 stream operations, and at 8 ranks the
+    // host's calls per gather are what limits this carrier; both ways pass the two-process test and measure the same on one device)
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, s->device) != hipSuccess) can = 0;
+    c->stream_values = false;
+    if (const char* e = std::getenv("RCSH_COPY_CARRIER_FLAGS")) c->stream_values = can != 0 && std::string(e) == "value";
+  }
   CopyBlob b{};
   b.magic = 0x52435348u; b.rank = (uint32_t)rank; b.bytes_per_rank = bytes_per_rank; b.device = s->device; b.pid = (int32_t)getpid();
   for (int k = 0; k < 2 && he == hipSuccess; ++k) ok(hipIpcGetMemHandle(&b.recv[k], c->recv[k]));
@@ -2228,27 +2240,38 @@ int copy_allgather(rcsh_sim* s, int32_t slot, const void* send_dev, void* recv_d
   // after what the handle's stream holds so far: the env-step that wrote the send buffer, the consumer of this slot's last gather
   HIP_TRY(hipEventRecord(s->comm_ready, s->stream));
   HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->comm_ready, 0));
+  auto write_word = [&](hipStream_t st, uint64_t* dst) -> hipError_t {
+    if (c->stream_values) return hipStreamWriteValue64(st, dst, q, 0);
+    return hipMemcpyAsync(dst, qsrc, sizeof(uint64_t), hipMemcpyHostToDevice, st);
+  };
+  auto wait_words = [&](hipStream_t st, uint64_t* base) -> hipError_t {  // every peer's word of this rank's flags has reached q
+    if (W < 2) return hipSuccess;
+    if (c->stream_values) {
+      for (int p = 0; p < W; ++p) {
+        if (p == me) continue;
+        const hipError_t e = hipStreamWaitValue64(st, base + p, q, hipStreamWaitValueGte, ~0ull);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, st, base, W, me, q, c->timeout_flag);
+    return hipGetLastError();
+  };
   // 1. tell every peer that this rank's receive buffer of the slot is free for q; wait until every peer has said so
   for (int p = 0; p < W; ++p)
-    if (p != me) HIP_TRY(hipMemcpyAsync(flag(c->peer_flags[p], 0, slot, me), qsrc, sizeof(uint64_t), hipMemcpyHostToDevice, s->comm_stream));
-  if (W > 1) {
-    hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, s->comm_stream, flag(c->flags, 0, slot, 0), W, me, q, c->timeout_flag);
-    HIP_TRY(hipGetLastError());
-  }
+    if (p != me) HIP_TRY(write_word(s->comm_stream, flag(c->peer_flags[p], 0, slot, me)));
+  HIP_TRY(wait_words(s->comm_stream, flag(c->flags, 0, slot, 0)));
   HIP_TRY(hipEventRecord(c->acked, s->comm_stream));
   // 2. the block to every peer, each over its own stream (its own link), followed by the word that says it has arrived
   for (int p = 0; p < W; ++p) {
     HIP_TRY(hipStreamWaitEvent(c->cs[p], c->acked, 0));
     HIP_TRY(hipMemcpyAsync((char*)c->peer_recv[p][slot] + (size_t)me * c->bytes, send_dev, c->bytes, hipMemcpyDeviceToDevice, c->cs[p]));
-    if (p != me) HIP_TRY(hipMemcpyAsync(flag(c->peer_flags[p], 1, slot, me), qsrc, sizeof(uint64_t), hipMemcpyHostToDevice, c->cs[p]));
+    if (p != me) HIP_TRY(write_word(c->cs[p], flag(c->peer_flags[p], 1, slot, me)));
     HIP_TRY(hipEventRecord(c->cs_done[p], c->cs[p]));
     HIP_TRY(hipStreamWaitEvent(s->comm_stream, c->cs_done[p], 0));  // (the send buffer is free once these have run)
   }
   // 3. the slot is gathered when every peer's block has arrived here
-  if (W > 1) {
-    hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, s->comm_stream, flag(c->flags, 1, slot, 0), W, me, q, c->timeout_flag);
-    HIP_TRY(hipGetLastError());
-  }
+  HIP_TRY(wait_words(s->comm_stream, flag(c->flags, 1, slot, 0)));
   HIP_TRY(hipEventRecord(s->comm_done[slot], s->comm_stream));
   s->comm_pending[slot] = true;
   return RCSH_OK;

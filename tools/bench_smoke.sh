@@ -18,3 +18,5 @@ run --steps 60 --warmup 10 --mode convergence
 run --steps 40 --warmup 5 --gpus 2 --dist-backend host --envs 1024
 run --steps 100 --warmup 10 --robot xarm7_pick
 run --steps 40 --warmup 5 --robot xarm7_pick --cameras side_cam --resolution 256x256
+run --steps 40 --warmup 5 --gpus 2 --dist-backend sdma --envs 1024
+run --steps 40 --warmup 5 --gpus 2 --envs 1024
