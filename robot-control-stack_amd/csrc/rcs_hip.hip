@@ -81,6 +81,17 @@ struct rcsh_sim {
   bool esc_mode = false;
   uint64_t* d_esc = nullptr;       // [3][(n + 63) / 64]: escalated, newly flagged, leaving
   uint32_t* d_esc_ctr = nullptr;   // [4] (sim_kernels.h: RunOp::esc_ctr)
+  // the contact-resolving launch in two parts (RunOp::esc_part): the already escalated environments next to the lean launch, on a stream
+  // of their own; chosen per step from what the device last reported (h_esc_hint: the lean launch's step number and the escalated count)
+  hipStream_t esc_stream = nullptr;
+  hipEvent_t esc_ev_prev = nullptr, esc_ev_old = nullptr, esc_ev_started = nullptr;
+  int esc_split_max = 128;          // split while at most this many environments are escalated (RCSH_ESC_SPLIT_MAX)
+  volatile uint32_t* h_esc_hint = nullptr;  // [2] host memory the lean launch writes (RunOp::esc_host)
+  uint32_t esc_seq = 0;
+  int esc_split = 0;                // 1: split (RCSH_ESC_SPLIT=1).  OFF by default -- measured (profiles/r5_v2/split_ab.txt): with the escalated
+                                    // environments' launch dispatched first and the lean launch beside it a 300-step rollout takes 0.496 ms a step
+                                    // against 0.433 one launch after the other, the 1000-step rollout 3.96 against 3.87: two kernels of different
+                                    // scratch / LDS footprints from two queues do not share the chip the way the arithmetic (max instead of sum) promises
   double* d_snap = nullptr;        // [nfields][n]: what the lean launch of a step read (the step is redone from it on a hit)
   uint32_t* d_snap_flags = nullptr;
   int32_t* d_snap_conv = nullptr;
@@ -583,6 +594,7 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
     op.snap = s->d_snap; op.snap_flags = s->d_snap_flags; op.snap_conv = s->d_snap_conv;
   }
   bool launched = false;
+  hipError_t esc_err = hipSuccess;  // (stream / event calls of the split contact-resolving launch)
   bool ok = dispatch_topology(s->narm, s->grip, [&](auto topo) {
     using T = decltype(topo);
     const dim3 grid(((s->n + 31) / 32) * 8), block(64);
@@ -618,6 +630,42 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
       if constexpr (T::NARM == 7 && T::GRIP) {
         if (esc) {
           static const int certify = [] { const char* e = std::getenv("RCSH_CHECK_CERTIFY"); return e ? std::atoi(e) : 0; }();
+          // How this step's contact-resolving work is enqueued.  The environments that are escalated already do not depend on the step's
+          // lean launch: with any of them around (as far as the host knows: the device's last report, at most two steps old -- the host
+          // does not run further ahead than that) they go FIRST, on a stream of their own, and the lean launch fills the rest of the chip
+          // beside them; the newly flagged ones follow behind both.  The step then takes max(escalated, ~2 x lean) instead of their sum
+          // (the lean launch's last workgroups wait for a SIMD: 4096 environments are one wavefront per SIMD).
+          auto esc_chk = [&](hipError_t e_) { if (e_ != hipSuccess && esc_err == hipSuccess) esc_err = e_; };
+          bool split = false;
+          if (s->h_esc_hint && s->esc_split) {
+            ++s->esc_seq;
+            if (s->esc_seq > 2) {  // (throttle: the lean launch of step seq - 2 has ended)
+              const uint32_t want = s->esc_seq - 2;
+              for (long spins = 0; (int32_t)(s->h_esc_hint[0] - want) < 0; ++spins) {
+                if (spins > 2000000) { esc_chk(hipStreamSynchronize(s->stream)); break; }  // (a hint that never comes: wait the plain way)
+                __builtin_ia32_pause();
+              }
+            }
+            // (few escalated environments: their workgroups leave the lean launch nearly the whole chip.  Many: the two kernels' wavefronts
+            // share CUs for milliseconds and both run slower -- measured on the 1000-step rollout, 3.87 -> 4.53 ms a step -- so not then.)
+            split = s->h_esc_hint[1] > 0 && s->h_esc_hint[1] <= (uint32_t)s->esc_split_max;
+            op.esc_seq = (int32_t)s->esc_seq;
+            op.esc_host = const_cast<uint32_t*>(s->h_esc_hint);
+          }
+          if (split) {
+            esc_chk(hipEventRecord(s->esc_ev_prev, s->stream));
+            esc_chk(hipStreamWaitEvent(s->esc_stream, s->esc_ev_prev, 0));
+            RunOp op_old = op;
+            op_old.esc_role = 2; op_old.esc_part = 1; op_old.check = 0;
+            static const int leave_quiet0 = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();
+            op_old.esc_leave_quiet = leave_quiet0;
+            // (the lean launch must not win the race for the SIMDs: it waits until the other stream has got as far as its kernel)
+            esc_chk(hipEventRecord(s->esc_ev_started, s->esc_stream));
+            esc_chk(hipStreamWaitEvent(s->stream, s->esc_ev_started, 0));
+            hipLaunchKernelGGL((k_run_team<T, false, false, true, false>), grid, block, 0, s->esc_stream, P, op_old);
+            esc_chk(hipGetLastError());
+            esc_chk(hipEventRecord(s->esc_ev_old, s->esc_stream));
+          }
           op.esc_role = 1; op.check = certify ? 2 : 1;
           // (measurement switches: what the copy of the state / the end-of-launch check cost a step -- results are wrong with either)
           static const int no_snap = [] { const char* e = std::getenv("RCSH_ESC_MEASURE_NO_SNAP"); return e ? std::atoi(e) : 0; }();
@@ -628,6 +676,8 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
           go(N{}, N{}, N{});
           op.snap = snap_keep;
           op.esc_role = 2; op.check = 0;
+          op.esc_part = split ? 2 : 0;
+          if (split) esc_chk(hipStreamWaitEvent(s->stream, s->esc_ev_old, 0));
           static const int leave_quiet = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();
           op.esc_leave_quiet = leave_quiet;
           go(N{}, N{}, Y{});
@@ -645,6 +695,7 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
   });
   if (!ok || !launched) return fail(RCSH_ERR_MODEL, "no kernel instantiated for this archetype");
   if (err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("k_run launch: ") + hipGetErrorString(err));
+  if (esc_err != hipSuccess) return fail(RCSH_ERR_DEVICE, std::string("contact-resolving launch (streams / events): ") + hipGetErrorString(esc_err));
   if (sample) {
     HIP_TRY(hipEventRecord(s->ev_stop[s->prof_pending], s->stream));
     s->prof_pending++;
@@ -878,6 +929,11 @@ void rcsh_sim_destroy(rcsh_sim* s) {
   hipFree(s->d_model); hipFree(s->d_coll_xyzr); hipFree(s->d_coll_cls); hipFree(s->S); hipFree(s->flags); hipFree(s->conv);
   hipFree(s->d_cgeoms); hipFree(s->d_cverts); hipFree(s->d_pairs); hipFree(s->d_chk_geoms); hipFree(s->d_chk_ent); hipFree(s->d_lev);
   hipFree(s->d_slack);
+  if (s->esc_stream) { hipStreamSynchronize(s->esc_stream); hipStreamDestroy(s->esc_stream); }
+  if (s->esc_ev_prev) hipEventDestroy(s->esc_ev_prev);
+  if (s->esc_ev_old) hipEventDestroy(s->esc_ev_old);
+  if (s->esc_ev_started) hipEventDestroy(s->esc_ev_started);
+  if (s->h_esc_hint) hipHostFree((void*)s->h_esc_hint);
   hipFree(s->d_esc); hipFree(s->d_esc_ctr); hipFree(s->d_snap); hipFree(s->d_snap_flags); hipFree(s->d_snap_conv);
   hipFree(s->rend.last); hipFree(s->rend.snap); hipFree(s->rend.count);
   hipFree(s->d_boxtask); hipFree(s->d_rshapes); hipFree(s->d_rplanes); hipFree(s->d_rcolours); hipFree(s->d_frames); hipFree(s->d_wframes); hipFree(s->d_image);
@@ -1411,6 +1467,21 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
     HIP_TRY(hipMalloc(&s->d_snap, sizeof(double) * (size_t)(s->nfields + kMaxRateCams) * s->n));  // (+ the rate-driven cameras' clocks)
     HIP_TRY(hipMalloc(&s->d_snap_flags, sizeof(uint32_t) * s->n));
     HIP_TRY(hipMalloc(&s->d_snap_conv, sizeof(int32_t) * s->n));
+    {
+      int lo = 0, hi = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi: the numerically lowest = the highest priority)
+      HIP_TRY(hipStreamCreateWithPriority(&s->esc_stream, hipStreamNonBlocking, hi));
+      HIP_TRY(hipEventCreateWithFlags(&s->esc_ev_prev, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&s->esc_ev_old, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&s->esc_ev_started, hipEventDisableTiming));
+      if (const char* e = std::getenv("RCSH_ESC_SPLIT_MAX")) s->esc_split_max = std::atoi(e);
+      void* hp = nullptr;
+      HIP_TRY(hipHostMalloc(&hp, 2 * sizeof(uint32_t), hipHostMallocDefault));
+      s->h_esc_hint = (volatile uint32_t*)hp;
+      s->h_esc_hint[0] = 0; s->h_esc_hint[1] = 0;
+      s->esc_seq = 0;
+      if (const char* e = std::getenv("RCSH_ESC_SPLIT")) s->esc_split = std::atoi(e);
+    }
     HIP_TRY(hipMemsetAsync(s->d_esc, 0, sizeof(uint64_t) * 3 * nw, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_esc_ctr, 0, sizeof(uint32_t) * 4, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_snap, 0, sizeof(double) * (size_t)(s->nfields + kMaxRateCams) * s->n, s->stream));

@@ -124,7 +124,13 @@ struct RunOp {
   int32_t esc_role;
   int32_t force_contact;  // the contact phase runs in every substep of every environment (a whole batch on the contact-resolving kernel with
                           // self contacts resolved: exact, and slow -- the fast path's broad phase knows the floor and the free body only)
-  int32_t esc_leave_quiet, esc_pad;  // role 2: an environment leaves after two launches in a row without a contact (default: with its reset only)
+  int32_t esc_leave_quiet;  // role 2: an environment leaves after two launches in a row without a contact (default: with its reset only)
+  // Role 2 in two parts (esc_part): the environments that WERE escalated when the step began do not depend on the step's lean launch --
+  // part 1 steps them on a stream of its own, next to the lean launch, and leaves the masks alone; part 2, behind both, redoes the newly
+  // flagged ones and merges.  0: one launch does both (behind the lean one).  The host splits when it knows of escalated environments.
+  int32_t esc_part;
+  int32_t esc_seq, esc_pad2;  // role 1: the step's number, for esc_host
+  uint32_t* esc_host;     // [2] host memory: the last step whose lean launch has (all but) ended, the escalated count it started with
   uint64_t* esc;          // [3][(n + 63) / 64]
   uint32_t* esc_ctr;      // [0] workgroups of the role-2 launch that are done, [1] environments escalated after the last merge,
                           // [2] environments the role-1 launch of this step has flagged (a role-2 launch that finds [1] = [2] = 0 ends at once)
@@ -166,7 +172,7 @@ __device__ __forceinline__ int esc_select(const RunOp& op, int n, int r0, int te
     int cnt = 0;
     for (int wi = lane; wi < nw; wi += 64) {
       const uint64_t valid = (wi == nw - 1 && (n & 63)) ? ((1ull << (n & 63)) - 1) : ~0ull;
-      cnt += __popcll((A[wi] | B[wi]) & valid);
+      cnt += __popcll(((op.esc_part == 2 ? 0ull : A[wi]) | (op.esc_part == 1 ? 0ull : B[wi])) & valid);
     }
     const int total = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63), G = (int)gridDim.x;
     per = total <= G ? 1 : (total <= 2 * G ? 2 : (total <= 3 * G ? 3 : 4));  // environments per workgroup: as few as the launch's workgroups allow
@@ -177,10 +183,10 @@ __device__ __forceinline__ int esc_select(const RunOp& op, int n, int r0, int te
     uint64_t a = 0, b = 0, valid = 0;
     if (wi < nw) {
       a = A[wi];
-      b = op.esc_role == 2 ? B[wi] : 0;
+      b = op.esc_role == 2 && op.esc_part != 1 ? B[wi] : 0;
       valid = (wi == nw - 1 && (n & 63)) ? ((1ull << (n & 63)) - 1) : ~0ull;
     }
-    const uint64_t w = (op.esc_role == 1 ? ~a : (a | b)) & valid;
+    const uint64_t w = (op.esc_role == 1 ? ~a : ((op.esc_part == 2 ? 0ull : a) | b)) & valid;
     const int pc = __popcll(w);
     const int incl = wave_incl_scan(pc);
     const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -821,7 +827,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   // rollout that touches nothing -- ends here, before a single load has gone out: two scalar loads; a wavefront that has asked for
   // its tables waits for them before it may end, 4.5 us for the launch instead of 1.5)
   if constexpr (CON) {
-    if (opk.esc_role == 2 && opk.esc_ctr[1] == 0 && opk.esc_ctr[2] == 0) return;
+    if (opk.esc_role == 2 && opk.esc_ctr[1] == 0 && (opk.esc_part == 1 || opk.esc_ctr[2] == 0)) return;
   }
   LdsCopy<sizeof(Params) / 8> cp_params;
   LdsCopy<sizeof(RunOp) / 8> cp_op;
@@ -853,7 +859,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       // (role 2 may spread its environments one per workgroup: every workgroup asks)
       const int pick = esc_select(opk, Pk.n, e_slot0, team, esc_redo, true);
       if (__ballot(pick >= 0) == 0) {  // no environment for any of this workgroup's four slots
-        esc_finish(opk, Pk.n);
+        if (opk.esc_part != 1) esc_finish(opk, Pk.n);
         return;
       }
       e = pick >= 0 ? pick : Pk.n;
@@ -932,7 +938,13 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   TEAM_MARK(12)
   const bool live = in_range && !((esc_word >> (e & 63)) & 1ull);
   const bool leader = t == 0 && live;
-  if (esc_role == 1 && __ballot(live) == 0) return;  // (every environment of this workgroup is on the contact-resolving kernel, or out of range)
+  if (esc_role == 1 && __ballot(live) == 0) {  // (every environment of this workgroup is on the contact-resolving kernel, or out of range)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && opk.esc_host) {  // (the host's hint: see the launch's end)
+      __hip_atomic_store(opk.esc_host + 1, opk.esc_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(opk.esc_host, (uint32_t)opk.esc_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   if (esc_role == 1 && live && opk.snap) {
     // per-environment escalation, the lean launch: everything just read that this launch will overwrite, kept for the case that
     // the step has to be redone with its contacts resolved (RunOp::esc_role)
@@ -1467,7 +1479,13 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   }
   if (esc_role == 2) {
     if (esc_leave) atomicOr(reinterpret_cast<unsigned long long*>(lop.esc + 2 * ((P.n + 63) >> 6) + (e >> 6)), 1ull << (e & 63));
-    esc_finish(lop, P.n);
+    if (lop.esc_part != 1) esc_finish(lop, P.n);
+  }
+  if (esc_role == 1 && blockIdx.x == 0 && threadIdx.x == 0 && lop.esc_host) {
+    // for the host, which runs ahead of the device: which step's lean launch has (all but) ended, and how many environments were
+    // escalated when it began (host memory; read without synchronisation: a hint for how the next steps are enqueued, nothing more)
+    __hip_atomic_store(lop.esc_host + 1, lop.esc_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(lop.esc_host, (uint32_t)lop.esc_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   TEAM_MARK(10)
   TEAM_CLOCK_FLUSH()
