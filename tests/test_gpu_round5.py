@@ -40,3 +40,19 @@ def test_headline_rollout_matches_the_resolving_oracle_for_1000_steps():
     assert (rep["held"] & touched).sum() >= 7, rep  # the bars DID apply to environments in contact (floor, link 0 / 1 / 2 against fingers and hand)
     assert np.array_equal(rep["resolved_ever"][rep["held"]], (rep["contact_steps"] > 0)[rep["held"]]), rep
     assert not rep["unresolved"].any(), rep
+
+
+def test_split_contact_resolving_launch_gives_the_same_rollout(monkeypatch):
+    """The contact-resolving launch in two parts (RunOp::esc_part; RCSH_ESC_SPLIT=1, off by default because it measures slower:
+    profiles/r5_v2/split_ab.txt): already escalated environments on a stream of their own beside the lean launch, the newly flagged ones
+    behind both, the form chosen per step from the hint the lean launch writes to host memory.  Same bars as the default form, over the
+    700 steps in which the first environments of this seed run into a contact and stay on the contact-resolving launch."""
+    from parity_util import run_headline_resolved_parity
+
+    monkeypatch.setenv("RCSH_ESC_SPLIT", "1")
+    monkeypatch.setenv("RCSH_ESC_SPLIT_MAX", "4096")
+    rep = run_headline_resolved_parity(n_envs=64, n_steps=700, seed=0)
+    touched = rep["first_contact"] >= 0
+    assert touched.sum() >= 3, rep
+    assert rep["max_abs_qpos"] < 1e-9 and rep["max_abs_qvel"] < 1e-8 and rep["flag_mismatches"] == 0, rep
+    assert (rep["held"] & touched).sum() >= 2 and not rep["unresolved"].any(), rep
