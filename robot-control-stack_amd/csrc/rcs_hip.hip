@@ -1467,7 +1467,10 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
     HIP_TRY(hipMalloc(&s->d_snap, sizeof(double) * (size_t)(s->nfields + kMaxRateCams) * s->n));  // (+ the rate-driven cameras' clocks)
     HIP_TRY(hipMalloc(&s->d_snap_flags, sizeof(uint32_t) * s->n));
     HIP_TRY(hipMalloc(&s->d_snap_conv, sizeof(int32_t) * s->n));
-    {
+    if (const char* e = std::getenv("RCSH_ESC_SPLIT")) s->esc_split = std::atoi(e);
+    // (the split form's stream exists only where it is asked for: one more stream in the process changes how the runtime maps streams
+    // to hardware queues -- the four sub-batches of `bench.py --robot mixed`, a stream each, ran one after the other with it: 18 -> 8 M)
+    if (s->esc_split) {
       int lo = 0, hi = 0;
       HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi: the numerically lowest = the highest priority)
       HIP_TRY(hipStreamCreateWithPriority(&s->esc_stream, hipStreamNonBlocking, hi));
@@ -1480,7 +1483,6 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
       s->h_esc_hint = (volatile uint32_t*)hp;
       s->h_esc_hint[0] = 0; s->h_esc_hint[1] = 0;
       s->esc_seq = 0;
-      if (const char* e = std::getenv("RCSH_ESC_SPLIT")) s->esc_split = std::atoi(e);
     }
     HIP_TRY(hipMemsetAsync(s->d_esc, 0, sizeof(uint64_t) * 3 * nw, s->stream));
     HIP_TRY(hipMemsetAsync(s->d_esc_ctr, 0, sizeof(uint32_t) * 4, s->stream));
