@@ -22,8 +22,9 @@ namespace rcsh {
 
 #if defined(__HIP__)
 
-// (with a free box the rows have 15 entries and Y fits behind 14 records; without one 9, and 21 contacts are 63 rows: a lane each)
-constexpr int kDenseConBox = 14, kDenseConNoBox = 21;
+// (with a free box the rows have 15 entries: J's 54 rows of 18 contacts fill the stage and the stiffness accumulators' area, Y the records'
+// tail and -- during the noslip pass, when nobody needs it -- the Hessian's; without one 9 entries, and 21 contacts are 63 rows: a lane each)
+constexpr int kDenseConBox = 18, kDenseConNoBox = 21;
 
 template <class T, bool BOXD>
 struct DenseLds {
@@ -37,12 +38,16 @@ struct DenseLds {
   // Y_r = (M^-1 J_r')' of the FRICTION rows (k = 1, 2) of contact c: the records' area behind the kDenseCon records in use.  (The noslip
   // pass changes normal forces only where the Newton solution left none -- by less than kMinVal = 1e-15 N: that change's effect on the
   // other rows' residuals is dropped, and the normal rows' Y, needed for the contact's own 3 x 3 block only, stay in registers.)
-  RCSH_D static double* yrow(AR& ar, int c, int k) { return &ar.rec[kDenseCon][0] + (2 * c + k - 1) * NVD; }
+  static constexpr int kYRowsBehindRecords = ((kMaxCon - kDenseCon) * 14) / NVD, kYRowsInHessian = (AR::NV * (AR::NV + 1) / 2) / NVD;
+  RCSH_D static double* yrow(AR& ar, int c, int k) {
+    const int i = 2 * c + k - 1;
+    return i < kYRowsBehindRecords ? &ar.rec[kDenseCon][0] + i * NVD : &ar.H[0] + (i - kYRowsBehindRecords) * NVD;
+  }
   // the rows' forces, the contacts' cone Hessians (00 10 11 20 21 22): the bodies' accelerations' area (U, Up, W)
   RCSH_D static double* frow(AR& ar) { return &ar.U[0][0]; }
   RCSH_D static double* hcone(AR& ar, int c) { return &ar.U[0][0] + kRows + 6 * c; }
   static_assert(kRows <= kRowsInStage || (kRows - kRowsInStage) * NVD <= AR::kAcc * 21, "J fits stage + KA");
-  static_assert(2 * kDenseCon * NVD <= (kMaxCon - kDenseCon) * 14, "Y fits behind the records");
+  static_assert(2 * kDenseCon <= kYRowsBehindRecords + kYRowsInHessian, "Y fits behind the records and into the Hessian's area (free during the noslip pass)");
   static_assert(kRows + 6 * kDenseCon <= 3 * AR::NB * 6, "forces and cone Hessians fit U, Up, W");
   static_assert(kRows <= 64, "a lane per row");
 };
