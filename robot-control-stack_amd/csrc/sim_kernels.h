@@ -546,7 +546,7 @@ __device__ __forceinline__ void env_prologue(const Params& P, const RunOp& op, c
 #pragma unroll
     for (int i = 0; i < T::NU; ++i) r.st.c(i) = 0;
     r.time = 0;
-    r.flags &= ~(kContactOverflow | kContactUnresolved);
+    r.flags &= ~(kContactOverflow | kContactUnresolved | kContactResolved | kEscQuiet);  // (sticky until Sim::reset: this is it)
 #pragma unroll
     for (int i = 0; i < 6; ++i) r.cb(i) = 0;
     // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
@@ -629,7 +629,7 @@ __device__ __forceinline__ void env_prologue_team(const Params& P, const RunOp& 
     if (t < T::NL) { r.st.q(tl) = m.qpos0[tl]; r.st.v(tl) = 0; }
     if (t < T::NU) r.st.c(tu) = 0;
     r.time = 0;
-    flags &= ~(kContactOverflow | kContactUnresolved);
+    flags &= ~(kContactOverflow | kContactUnresolved | kContactResolved | kEscQuiet);  // (sticky until Sim::reset: this is it)
     if (t < 6) r.cb(t) = 0;
     // RobotEnv.reset -> SimRobot::m_reset -> set_joints_hard(q_home) (base.py:290-304, SimRobot.cpp:193-205)
     if (joint) { r.st.q(ti) = P.robot.q_home[ti]; r.st.c(ti) = P.robot.q_home[ti]; }
