@@ -736,12 +736,16 @@ RCSH_D void self_sphere_table_fill(const SelfPair* pairs, int npair, float* tab,
 // lever[j] * |dq_j| over the calls (prefix[] its running sums along the arm), and due[i] is the value the pair's sum of
 // path[] must reach before the pair is looked at again: the sum when its gap was measured, plus the gap.  In a settled or
 // slowly moving arm every pair is skipped, every call.
+// (kSlackJ entries per team: joints 0 .. NL - 1 and one more prefix sum.  Ten, not kMaxLinks: with twelve the lean DET kernel of the
+// 9-joint robots took 41,144 bytes of LDS -- 184 more than let FOUR workgroups share a CU -- and a batch of 4096 environments ran as
+// 768 + 256 workgroups, one round after the other: step_until_convergence at HALF its speed.  tests/test_host_logic.py keeps watch.)
+constexpr int kSlackJ = 10;
 struct SelfSlack {
-  double qprev[4][12], path[4][12], prefix[4][12];
+  double qprev[4][kSlackJ], path[4][kSlackJ], prefix[4][kSlackJ];
   float due[4][kMaxSelfPairs];
 };
 RCSH_D void self_slack_clear(SelfSlack& ss) {
-  for (int k = threadIdx.x; k < 4 * 12; k += 64) { (&ss.qprev[0][0])[k] = 0.0; (&ss.path[0][0])[k] = 0.0; (&ss.prefix[0][0])[k] = 0.0; }
+  for (int k = threadIdx.x; k < 4 * kSlackJ; k += 64) { (&ss.qprev[0][0])[k] = 0.0; (&ss.path[0][0])[k] = 0.0; (&ss.prefix[0][0])[k] = 0.0; }
   for (int k = threadIdx.x; k < 4 * kMaxSelfPairs; k += 64) (&ss.due[0][0])[k] = 0.0f;
 }
 RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const double* verts, const SelfPair* pairs, int npair, const double* Fall_,
@@ -757,7 +761,7 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
   if (team_due && sph_ && ss) {
     // how far the joints have come since the last call
     double mine_path = 0.0;
-    if (t < nl) {
+    if (t < nl && t < kSlackJ) {
       const double lever = in_lds(lever_)[t];
       mine_path = ss->path[team][t] + lever * fabs(q_lane - ss->qprev[team][t]);
       ss->path[team][t] = mine_path;
@@ -768,7 +772,7 @@ RCSH_CONTACT_FN uint32_t self_collision_pairs(const ContactGeom* geoms, const do
     incl += row_up<1>(incl);
     incl += row_up<2>(incl);
     incl += row_up<4>(incl);
-    if (t < 11) ss->prefix[team][t + 1] = incl;
+    if (t + 1 < kSlackJ) ss->prefix[team][t + 1] = incl;
     stage_fence();
   }
   if (team_due && sph_) {

@@ -1031,6 +1031,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   const int npair = DET ? lp.ctab.npair : 0;
   // (lean kernels without a free box only: the others have no LDS to spare and read the pair records from memory)
   constexpr bool kSelfLds = DET && !CON && !BOX;
+  static_assert(!kSelfLds || T::NL < kSlackJ, "the slack cache keeps NL joints and NL + 1 prefix sums per team");
   __shared__ float lsph[kSelfLds ? kMaxSelfPairs * kSelfSphereWords : 1];
   const float* const sph = (kSelfLds && npair <= kMaxSelfPairs) ? lsph : nullptr;
   __shared__ std::conditional_t<kSelfLds, SelfSlack, char> lslack[1];

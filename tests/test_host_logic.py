@@ -724,3 +724,31 @@ def test_hull_edges_and_the_outline_method_against_the_plane_walk():
                 rays += len(D)
             n_hulls += 1
     assert n_hulls == 19 and rays > 100000
+
+
+def test_stepping_kernels_leave_room_for_four_workgroups_per_cu():
+    """A CU of the MI355X has 160 KB of LDS and four SIMDs; the stepping kernels run one wavefront per SIMD, so a batch of 4096
+    environments is exactly one round of 1024 workgroups -- IF four of them fit a CU's LDS.  Round 5 found the lean detection kernel of
+    the 9-joint robots at 41,144 bytes (184 too many): 768 + 256 workgroups in two rounds, step_until_convergence at half speed.  Every
+    k_run_team instantiation of the built library stays at or under 160 KB / 4."""
+    import re
+    import subprocess
+    import tempfile
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("no ROCm LLVM tools to read the code object with")
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"])
+        notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", co], text=True)
+    sizes = {}
+    for m in re.finditer(r"- \.agpr_count:\s+(\d+)(.*?)\.wavefront_size", notes, re.S):
+        f = dict(re.findall(r"\.(\w+):\s+(\S+)", m.group(0)))
+        if "k_run_team" in f.get("name", ""):
+            sizes[f["name"]] = int(f["group_segment_fixed_size"])
+    assert len(sizes) >= 20, len(sizes)
+    too_big = {k: v for k, v in sizes.items() if v > 160 * 1024 // 4}
+    assert not too_big, too_big
