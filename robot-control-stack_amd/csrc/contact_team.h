@@ -1666,6 +1666,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
     // skipped (oracle self_collide tests every pair in every substep and finds the same contacts).
     TEAM_MARK(16)  // (slots 16-18, 21-23 here: box-less scenes; box_team.h uses them in kernels with a free box)
     uint32_t cm = 0;  // bit j: pair lane + 64 j survived the bounding tests
+    uint32_t hot = 0;  // bit j: ... and was in contact the last time it was looked at (rem = -1): Gilbert's iteration would only fail again
     static_assert(kMaxCheckPairs <= 3 * 64, "three pairs per lane");
     if (__ballot(am != 0)) {
     if (has_geom) {
@@ -1698,6 +1699,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       for (int k = 0; k < 3; ++k) { ca[k] = wb[12 * g0 + k]; cb_[k] = wb[12 * g1 + k]; ha[k] = ck.gh[g0][k]; hb[k] = ck.gh[g1][k]; }
       const double dd[3] = {ca[0] - cb_[0], ca[1] - cb_[1], ca[2] - cb_[2]};
       const double rs = en.rsum, d2 = dot3(dd, dd);
+      if (rem[j] <= -0.5f) hot |= 1u << j;
       rem[j] = 0.0f;  // (until one of the tests measures a gap)
       if (d2 > rs * rs) { rem[j] = (float)(sqrt(d2) - rs) * 0.999999f - 1e-6f; continue; }
 #pragma unroll
@@ -1840,6 +1842,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       // the lead's companions: up to three more pending pairs (not two boxes) whose hulls are the lead's, place by place
       int grp_src[4] = {src, -1, -1, -1}, grp_j[4] = {j, 0, 0, 0};
       uint32_t grp_g[4] = {gg_lead, 0u, 0u, 0u};
+      int grp_hot[4] = {(__builtin_amdgcn_readlane((int)hot, src) >> j) & 1, 0, 0, 0};
       int ngrp = 1;
       {
         uint32_t ok = 0;
@@ -1859,6 +1862,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
           const uint32_t eg = jj == 0 ? ent[0].geoms : (jj == 1 ? ent[1].geoms : ent[2].geoms);
           grp_g[k] = (uint32_t)__builtin_amdgcn_readlane((int)eg, L);
           grp_src[k] = L; grp_j[k] = jj;
+          grp_hot[k] = (__builtin_amdgcn_readlane((int)hot, L) >> jj) & 1;
           if (lane == L) { ok &= ~(1u << jj); cm &= ~(1u << jj); }
           ngrp = k + 1;
         }
@@ -1899,7 +1903,9 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
         // boxes' test in every pose); everything else goes through the full refinement, as in the oracle
         const double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};
         double dg[3];
-        apart = gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap);
+        // (a pair that was in contact a substep ago goes straight to the refinement: five support queries saved)
+        const int hot_mine = team == 0 ? grp_hot[0] : (team == 1 ? grp_hot[1] : (team == 2 ? grp_hot[2] : grp_hot[3]));
+        apart = hot_mine ? false : gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap);
         if (!apart) {
           TEAM_COUNT(23)
           nc = mpr_penetration<true>(A, B, &depth, sn, spos0);
@@ -1914,12 +1920,12 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
         if (k >= ngrp) break;  // (wave-uniform)
         const bool apart_k = __builtin_amdgcn_readlane((int)apart, 16 * k) != 0;
         const double gap_k = wave_read(gap, 16 * k);
-        if (apart_k && lane == grp_src[k]) {
-          const float gf = (float)gap_k * 0.999999f - 1e-6f;
+        int nck = __builtin_amdgcn_readlane(nc, 16 * k);
+        if ((apart_k || nck > 0) && lane == grp_src[k]) {
+          const float gf = apart_k ? (float)gap_k * 0.999999f - 1e-6f : -1.0f;  // (-1: in contact -- due in every substep, and marked)
           const int jk = grp_j[k];
           rem[0] = jk == 0 ? gf : rem[0]; rem[1] = jk == 1 ? gf : rem[1]; rem[2] = jk == 2 ? gf : rem[2];
         }
-        int nck = __builtin_amdgcn_readlane(nc, 16 * k);
         if (nck > 0 && lane == 16 * k && nreg + nS < kMaxCon) {
           int c2 = 0;  // what the collision callbacks make of the pair (rcs_hip.hip: list_geom_pairs)
           if ((ga.cls | gb.cls) & 1) c2 |= 1;
