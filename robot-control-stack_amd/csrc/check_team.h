@@ -39,14 +39,18 @@ __device__ unsigned long long g_chk_cyc[16];
 // where the left and right fingertip pads meet face to face with a gap of 0.0; whether a collider then reports a penetration of
 // 1e-17 m or none is round-off (it exerts no force either way).  The oracle-side restatement of this check uses the same bar.
 constexpr double kCheckTouch = 1e-9;
-constexpr int kCheckSep = 8;  // per environment: two remembered separating directions (pair index + 1, direction in geom 0's link frame)
+constexpr int kCheckSep = 16;  // per environment: FOUR remembered separating directions (pair index + 1, direction in geom 0's link frame) -- two
+                                // through round 5's last session: a folded arm keeps three or four pairs near, the xArm7's gripper linkage more, and a pair
+                                // without its direction costs Gilbert steps or a full refinement in every launch
+constexpr int kCheckSlots = kCheckSep / 4;
+static_assert(kCheckSep <= kTeamLanes && kCheckSep % 4 == 0, "a lane of the team per word");
 
 // LDS workspace of the check (doubles): per team the world boxes of the geoms ([ngeom][12]: centre, axes) -- later overlaid by the
 // stage of the one pair of hulls the narrow phase works on --, the remembered directions, the two geom records of that pair
 constexpr int kCheckBox = 12 * kMaxCGeom;
 constexpr int kCheckGeomWords = (int)(sizeof(ContactGeom) / 8);
 static_assert(sizeof(ContactGeom) % 8 == 0 && 2 * kCheckGeomWords <= 64, "a lane per word of the narrow phase's two geom records");
-constexpr int check_work_doubles(int) { return 4 * kCheckBox + 4 * kCheckSep + 64 + 4 * 12; }  // (+ the teams' joint travel, certifying mode)
+constexpr int check_work_doubles(int) { return 4 * kCheckBox + 64 + 4 * 12; }  // (+ the teams' joint travel, certifying mode)
 static_assert(4 * kCheckBox >= kSelfStage, "the hull stage overlays the world boxes");
 constexpr int kCheckPer = kMaxCheckPairs / kTeamLanes;
 constexpr int kCheckTrips = (3 * 152 + 63) / 64;  // vertex words per lane and hull (a hull has at most 152 vertices)
@@ -177,8 +181,11 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   __syncthreads();  // (the link records have been read: their memory becomes the frames')
   double* F = frames + 12 * NL * team;
   double* wbox = work + kCheckBox * team;
-  double* slots = work + 4 * kCheckBox + kCheckSep * team;
-  double* gstage = work + 4 * kCheckBox + 4 * kCheckSep;
+  // (the remembered directions stay in the lanes that loaded them -- lane t of a team holds word t of its four slots; reads and updates go
+  // across the team's lanes: no LDS, which the lean detection kernel has none of to spare)
+  double sepw = sep_in;
+  const int tbase = lane & ~(kTeamLanes - 1);
+  double* gstage = work + 4 * kCheckBox;
   double* travel = gstage + 64 + 12 * team;  // lever x travel of the team's joints over the launch (certifying mode; zeros otherwise)
   double* stage = work;  // (overlays the world boxes once the broad phase is through)
   if (valid) {
@@ -187,7 +194,6 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #pragma unroll
     for (int k = 0; k < 3; ++k) F[12 * t + 9 + k] = p[k];
   }
-  if (t < kCheckSep) slots[t] = sep_in;
   if (t < 12) travel[t] = valid ? mpath : 0.0;
   __syncthreads();
   // Certifying mode (RunOp::check 2; per-environment escalation): a pair counts as apart only if it is PROVEN apart by more than
@@ -368,10 +374,19 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
       Shape B = make_shape(b.type == 7 ? 0 : b.type == 6 ? 1 : 2, pb, Rb, b.size, stage + na, b.vert_num);
       if (a.type == 7) { mulmv(Ra, a.center, A.center); A.center[0] += pa[0]; A.center[1] += pa[1]; A.center[2] += pa[2]; }
       if (b.type == 7) { mulmv(Rb, b.center, B.center); B.center[0] += pb[0]; B.center[1] += pb[1]; B.center[2] += pb[2]; }
-      // the slot of this pair: the one that holds it, else the first empty one, else slot (pair index & 1)
-      const int s_hold = slots[0] == key ? 0 : (slots[4] == key ? 1 : -1);
-      const int s_use = s_hold >= 0 ? s_hold : (slots[0] == 0.0 ? 0 : (slots[4] == 0.0 ? 1 : (pidx & 1)));
-      double* slot = slots + 4 * s_use;
+      // the slot of this pair: the one that holds it, else the first empty one, else slot (pair index mod the number of slots)
+      int s_hold = -1, s_free = -1;
+#pragma unroll
+      for (int k = kCheckSlots - 1; k >= 0; --k) {
+        const double kk = lane_get(sepw, tbase + 4 * k);
+        s_hold = kk == key ? k : s_hold;
+        s_free = kk == 0.0 ? k : s_free;  // (the first empty one)
+      }
+      const int s_use = s_hold >= 0 ? s_hold : (s_free >= 0 ? s_free : (pidx & (kCheckSlots - 1)));
+      auto slot_store = [&](const double* dl_) {  // the pair's direction into slot s_use: its four lanes take their words
+        const int w_ = t - 4 * s_use;
+        if (w_ >= 0 && w_ < 4) sepw = w_ == 0 ? key : (w_ == 1 ? dl_[0] : (w_ == 2 ? dl_[1] : dl_[2]));
+      };
       bool apart = false;
       double LR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       if (a.link >= 0) {
@@ -380,7 +395,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
       }
       double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};  // (a point of A - B)
       if (s_hold >= 0) {
-        const double dl[3] = {slot[1], slot[2], slot[3]};
+        const double dl[3] = {lane_get(sepw, tbase + 4 * s_use + 1), lane_get(sepw, tbase + 4 * s_use + 2), lane_get(sepw, tbase + 4 * s_use + 3)};
         double dw[3];
         mulmv(LR, dl, dw);
         MprPt s;
@@ -398,7 +413,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
           double dl[3];
           mulTv(LR, dg, dl);
           stage_fence();
-          slot[0] = key; slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
+          slot_store(dl);
         }
       }
 #endif
@@ -416,7 +431,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
           double dl[3];
           mulTv(LR, dir, dl);
           stage_fence();
-          slot[0] = key; slot[1] = dl[0]; slot[2] = dl[1]; slot[3] = dl[2];
+          slot_store(dl);
         }
 #ifdef RCSH_CHECK_DEBUG
         if (t == 0) { atomicAdd(&g_chk_dbg[38], 1); atomicAdd(&g_chk_dbg[s_hold >= 0 ? 41 : 40], 1); }  // full refinements: [40] no slot held the pair, [41] its direction failed
@@ -427,7 +442,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   }
   CHK_MARK(5)
   __syncthreads();
-  if (t < kCheckSep && live) sep[(size_t)t * n_env] = slots[t];
+  if (t < kCheckSep && live) sep[(size_t)t * n_env] = sepw;
   CHK_MARK(6)
   return team_ballot(mine) != 0;
 }
