@@ -2216,6 +2216,14 @@ struct CopyCarrier {
   // command processor does both, nothing runs on a CU and nothing goes through a copy engine) with RCSH_COPY_CARRIER_FLAGS=value where
   // the device has them; by default an 8-byte copy and the waiting wavefront.
   bool stream_values = false;
+  // The whole gather of a slot as ONE captured graph (the default): per post the host records an event, makes the communicator's stream
+  // wait for it and launches the graph -- four calls instead of ~5 W + 4.  The sequence number then lives on the device (qdev[slot],
+  // bumped by the graph's first node); the flag words are 8-byte device-to-device copies of it, the waiting wavefronts read it.
+  bool use_graph = true;
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  const void* gsend[2] = {nullptr, nullptr};
+  uint64_t* qdev = nullptr;             // [2] the slots' sequence numbers (graph form)
 };
 namespace {
 // one wavefront: waits until the `n` words at `w` (skipping index `skip`) have all reached `q`; gives up after ~20 s
@@ -2233,9 +2241,31 @@ __global__ void __launch_bounds__(64) k_wait_flags(const uint64_t* w, int n, int
     }
   }
 }
+// (graph form) the sequence number is read from device memory; the slot's number is bumped by the graph's first node
+__global__ void __launch_bounds__(64) k_wait_flags_at(const uint64_t* w, int n, int skip, const uint64_t* qptr, uint32_t* timeout_flag) {
+  const int lane = threadIdx.x;
+  const uint64_t q = *qptr;
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+    if (lane < n && lane != skip) ok = __hip_atomic_load(w + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= q;
+    if (__ballot(!ok) == 0) break;
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > 2000000000ull) {
+      if (lane == 0) __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+__global__ void k_bump(uint64_t* q) { *q += 1; }
 void copy_carrier_free(rcsh_sim* s) {
   CopyCarrier* c = s->copy;
   if (!c) return;
+  for (int k = 0; k < 2; ++k) {
+    if (c->gexec[k]) hipGraphExecDestroy(c->gexec[k]);
+    if (c->graph[k]) hipGraphDestroy(c->graph[k]);
+  }
+  if (c->qdev) hipFree(c->qdev);
   for (int p = 0; p < c->world; ++p) {
     if (c->cs[p]) hipStreamSynchronize(c->cs[p]);
   }
@@ -2274,6 +2304,8 @@ int rcsh_comm_copy_create(rcsh_sim* s, int32_t rank, int32_t world, size_t bytes
     c->flags = (uint64_t*)fl;
     ok(hipMemset(c->flags, 0, sizeof(uint64_t) * 2 * 2 * kCopyMaxWorld));
   }
+  if (he == hipSuccess && ok(hipMalloc((void**)&c->qdev, 2 * sizeof(uint64_t)))) ok(hipMemset(c->qdev, 0, 2 * sizeof(uint64_t)));
+  if (const char* e = std::getenv("RCSH_COPY_CARRIER_GRAPH")) c->use_graph = std::atoi(e) != 0;
   if (he == hipSuccess) ok(hipHostMalloc((void**)&c->seq_ring, sizeof(uint64_t) * kCopySeqRing, hipHostMallocDefault));
   if (he == hipSuccess) ok(hipHostMalloc((void**)&c->timeout_flag, sizeof(uint32_t), hipHostMallocDefault));
   if (he == hipSuccess) *c->timeout_flag = 0;
@@ -2353,14 +2385,66 @@ int copy_allgather(rcsh_sim* s, int32_t slot, const void* send_dev, void* recv_d
   if (recv_dev != c->recv[slot] || bytes_per_rank != c->bytes)
     return fail(RCSH_ERR_ARG, "copy carrier: the receive buffer of a slot is the carrier's (rcsh_comm_copy_recv_buffer), the block size the one it was created with");
   if (*c->timeout_flag) return fail(RCSH_ERR_DEVICE, "copy carrier: an earlier gather gave up waiting for a peer");
-  const uint64_t q = ++c->seq[slot];
-  uint64_t* qsrc = c->seq_ring + (c->ring_pos++ % kCopySeqRing);
-  *qsrc = q;
   const int me = c->rank, W = c->world;
   auto flag = [&](uint64_t* base, int kind, int sl, int r) { return base + ((size_t)kind * 2 + sl) * kCopyMaxWorld + r; };
   // after what the handle's stream holds so far: the env-step that wrote the send buffer, the consumer of this slot's last gather
   HIP_TRY(hipEventRecord(s->comm_ready, s->stream));
   HIP_TRY(hipStreamWaitEvent(s->comm_stream, s->comm_ready, 0));
+  if (c->use_graph && !c->stream_values) {
+    if (c->gexec[slot] && c->gsend[slot] != send_dev) {  // (another send buffer: the copies' source is part of the graph)
+      hipGraphExecDestroy(c->gexec[slot]); hipGraphDestroy(c->graph[slot]);
+      c->gexec[slot] = nullptr; c->graph[slot] = nullptr;
+    }
+    if (!c->gexec[slot]) {
+      uint64_t* qd = c->qdev + slot;
+      hipError_t ge = hipStreamBeginCapture(s->comm_stream, hipStreamCaptureModeThreadLocal);
+      auto g = [&](hipError_t e_) { if (ge == hipSuccess) ge = e_; };
+      if (ge == hipSuccess) {
+        hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s->comm_stream, qd);
+        g(hipGetLastError());
+        for (int p = 0; p < W; ++p)
+          if (p != me) g(hipMemcpyAsync(flag(c->peer_flags[p], 0, slot, me), qd, sizeof(uint64_t), hipMemcpyDeviceToDevice, s->comm_stream));
+        if (W > 1) {
+          hipLaunchKernelGGL(k_wait_flags_at, dim3(1), dim3(64), 0, s->comm_stream, flag(c->flags, 0, slot, 0), W, me, qd, c->timeout_flag);
+          g(hipGetLastError());
+        }
+        g(hipEventRecord(c->acked, s->comm_stream));
+        for (int p = 0; p < W; ++p) {
+          g(hipStreamWaitEvent(c->cs[p], c->acked, 0));
+          g(hipMemcpyAsync((char*)c->peer_recv[p][slot] + (size_t)me * c->bytes, send_dev, c->bytes, hipMemcpyDeviceToDevice, c->cs[p]));
+          if (p != me) g(hipMemcpyAsync(flag(c->peer_flags[p], 1, slot, me), qd, sizeof(uint64_t), hipMemcpyDeviceToDevice, c->cs[p]));
+          g(hipEventRecord(c->cs_done[p], c->cs[p]));
+          g(hipStreamWaitEvent(s->comm_stream, c->cs_done[p], 0));
+        }
+        if (W > 1) {
+          hipLaunchKernelGGL(k_wait_flags_at, dim3(1), dim3(64), 0, s->comm_stream, flag(c->flags, 1, slot, 0), W, me, qd, c->timeout_flag);
+          g(hipGetLastError());
+        }
+        hipGraph_t gr = nullptr;
+        const hipError_t ee = hipStreamEndCapture(s->comm_stream, &gr);
+        if (ge == hipSuccess) ge = ee;
+        if (ge == hipSuccess) ge = hipGraphInstantiate(&c->gexec[slot], gr, nullptr, nullptr, 0);
+        if (ge == hipSuccess) { c->graph[slot] = gr; c->gsend[slot] = send_dev; }
+        else if (gr) hipGraphDestroy(gr);
+      }
+      if (ge != hipSuccess) {  // (no graph on this runtime: the calls one by one, below)
+        (void)hipGetLastError();
+        c->use_graph = false;
+        c->gexec[slot] = nullptr;
+        if (c->seq[0] || c->seq[1]) return fail(RCSH_ERR_DEVICE, std::string("copy carrier: graph capture failed after gathers had run as graphs: ") + hipGetErrorString(ge));
+      }
+    }
+    if (c->gexec[slot]) {
+      ++c->seq[slot];
+      HIP_TRY(hipGraphLaunch(c->gexec[slot], s->comm_stream));
+      HIP_TRY(hipEventRecord(s->comm_done[slot], s->comm_stream));
+      s->comm_pending[slot] = true;
+      return RCSH_OK;
+    }
+  }
+  const uint64_t q = ++c->seq[slot];
+  uint64_t* qsrc = c->seq_ring + (c->ring_pos++ % kCopySeqRing);
+  *qsrc = q;
   auto write_word = [&](hipStream_t st, uint64_t* dst) -> hipError_t {
     if (c->stream_values) return hipStreamWriteValue64(st, dst, q, 0);
     return hipMemcpyAsync(dst, qsrc, sizeof(uint64_t), hipMemcpyHostToDevice, st);
