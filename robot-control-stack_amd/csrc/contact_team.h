@@ -1383,38 +1383,21 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
     }
     __syncthreads();  // (the scratch area goes to the stages below)
   }
-  // ---- link frames at the pre-step configuration: lane i < NL walks the chain to link i
-  // (every lane its own joint's local frame once, through the stage area; then the products down the chain)
-  double (*loc)[12] = reinterpret_cast<double (*)[12]>(&ar.stage[0][0]);
-  static_assert(sizeof(ar.stage) >= sizeof(double) * 12 * NL, "the links' local frames fit the stage area");
-  if (lane < NL) {
+  // ---- link frames at the pre-step configuration: every lane its own joint's local frame, composed down the chain by the position
+  // stage's scan (three or four rounds across the lanes; a lane walking the chain to its link alone took 6k cycles of every pass)
+  {
+    const int tl = lane < NL ? lane : NL - 1;
     KinK kk;
-    kk.load(links[lane]);
-    double Rl[9], pl[3];
-    link_local_frame(kk, st.q(lane), Rl, pl);
+    kk.load(links[tl]);
+    double R[9], p[3];
+    link_local_frame(kk, st.q(tl), R, p);
+    scan_frames<T>(R, p);
+    if (lane < NL) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) loc[lane][k] = Rl[k];
+      for (int k = 0; k < 9; ++k) arF[lane][k] = R[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) loc[lane][9 + k] = pl[k];
-  }
-  __syncthreads();
-  if (lane < NL) {
-    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
-    for (int i = 0; i < NL; ++i) {
-      if (!is_anc<T>(i, lane)) continue;
-      double Rl[9], pl[3], pn[3];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Rl[k] = loc[i][k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pl[k] = loc[i][9 + k];
-      mulmv(R, pl, pn);
-      p[0] += pn[0]; p[1] += pn[1]; p[2] += pn[2];
-      mulmm(R, Rl, R);
+      for (int k = 0; k < 3; ++k) arF[lane][9 + k] = p[k];
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) arF[lane][k] = R[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) arF[lane][9 + k] = p[k];
   }
   double bp[3], bR[9], bv[6];
   box_frame(bs, bp, bR, bv);
