@@ -263,7 +263,8 @@ def main() -> None:
                            resolve_robot_contacts=None if args.contacts == "resolve" else False)
     # a rank that hosts several robot types (mixed, fewer than 4 ranks): one sub-batch per type, each on its handle's own
     # stream, so that the sub-batches' launches (each too small to fill the chip) run side by side
-    envs = [env] + [make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=r)
+    envs = [env] + [make_vec_env(n // len(hosted), async_control=(args.mode == "async"), gripper=True, relative=True, device=local_rank, robot=r,
+                                 resolve_robot_contacts=None if args.contacts == "resolve" else False)
                     for r in hosted[1:]]
     L, h = env._L, env.sim._h
     for e_ in envs:
@@ -544,6 +545,35 @@ def main() -> None:
         env4.sim.synchronize()
         value_flag_only = n * args.steps / (time.perf_counter() - t4)
         env4.close()
+    # ... and the two figures BASELINE.md / SURVEY 8(d) quote next to the driver's K steps, on the same workload (after the clock stopped):
+    # * BASELINE.md section 3's rollout length -- T = 1000 env-steps after 50 warm-up, no resets -- by which a quarter of the batch has
+    #   folded onto the floor or itself and every step carries the contact-resolving launch of those environments;
+    # * the reference's default mode, Sim.step_until_convergence (cap 500), 30 env-steps after 5.
+    value_rollout = value_until_conv = None
+    rollout_info = {}
+    if headline_cfg and rank == 0 and resolving and args.contacts == "resolve":
+        def extra_run(envx, steps_, warm_):
+            acts = DevBuf((steps_ + warm_, n, envx.dof), np.float64, (np.random.default_rng(4321).random((steps_ + warm_, n, envx.dof)) * 2 - 1) * MAX_JOINT_MOV)
+            grp = DevBuf((steps_ + warm_, n), np.float32, np.random.default_rng(4322).random((steps_ + warm_, n), dtype=np.float32))
+            envx.reset_dev(obs.ptr, info.ptr, gw.ptr)
+            for t_ in range(warm_):
+                envx.step_dev(acts.at(t_), grp.at(t_), obs.ptr, info.ptr, gw.ptr, sub.ptr)
+            envx.sim.synchronize()
+            tx = time.perf_counter()
+            for t_ in range(warm_, warm_ + steps_):
+                envx.step_dev(acts.at(t_), grp.at(t_), obs.ptr, info.ptr, gw.ptr, sub.ptr)
+            envx.sim.synchronize()
+            return n * steps_ / (time.perf_counter() - tx)
+
+        if (args.steps, args.warmup) == (1000, 50):
+            value_rollout = None  # (this run IS that rollout: `value`)
+        else:
+            value_rollout = extra_run(env, 1000, 50)
+            now_, ever_ = env.sim.contact_escalated()
+            rollout_info = {"contacts_resolved": int(ever_.sum()), "escalated_at_end": int(now_.sum()), "contacts_unresolved": int(env.sim.contact_unresolved().sum())}
+        envc = make_vec_env(n, async_control=False, gripper=True, relative=True, device=local_rank, robot=args.robot)
+        value_until_conv = extra_run(envc, 30, 5)
+        envc.close()
     finite = bool(np.isfinite(obs_host).all())
     if task_out is not None:
         finite = finite and bool(np.isfinite(task_out.download()).all())
@@ -639,6 +669,9 @@ def main() -> None:
                                    if args.contact_check_every > 0 else "no check inside the timed region") + " + once on the final state (sticky flags, csrc/check_team.h)"),
                 "value_host_api": value_host_api,  # the same env-step through rcsh_env_step (numpy in / out): what a Gymnasium user calls
                 "value_flag_only_check_every_16": value_flag_only,  # round 4's configuration of this workload (contacts flagged, not resolved)
+                "value_rollout_1000_50": value_rollout,  # BASELINE.md section 3's rollout of this workload: T = 1000 after 50 warm-up, no resets
+                "rollout_1000_50": rollout_info or None,  # ... environments whose contacts were resolved / on the contact-resolving launch at its end
+                "value_until_convergence_30": value_until_conv,  # the reference's default mode (step_until_convergence, cap 500): 30 env-steps after 5
                 "obs_finite": finite,
                 "value_without_exchange": no_exchange_value,
                 "exchange_ms": exchange_ms,  # the gather alone, back to back (after the clock stopped)

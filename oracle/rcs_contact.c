@@ -455,9 +455,12 @@ static void geom_frame_compute(const orc_model* m, const orc_data* d, int g, dou
   p[0] = v[0] + d->xpos[b][0]; p[1] = v[1] + d->xpos[b][1]; p[2] = v[2] + d->xpos[b][2];
 }
 static double geom_rbound(const orc_model* m, int g) { return m->geom_rbound[g]; }
-/* contacts beyond the capacity are dropped in detection order; where contacts are resolved the capacity is the HIP
-   backend's (contact_types.h: kMaxCon), so that an overflowing scene overflows alike on both sides */
+/* MuJoCo's contact list has no fixed bound and neither has this restatement's (ORC_MAXCON is storage, far above what the scenes
+   produce).  orc_set_contact_cap(): a test may ask for the first `cap` contacts of MuJoCo's order only, to see what a backend with a
+   bounded contact phase does when it overflows -- never the default. */
 static int g_contact_cap = ORC_MAXCON;
+static int g_resolve_cap = 0;
+void orc_set_contact_cap(int cap) { g_resolve_cap = cap; }
 static orc_contact* add_contact(orc_data* d, int g1, int g2, int b1, int b2, const double* pos, const double* n, double dist, double mu) {
   if (d->ncon >= g_contact_cap) return 0;
   orc_contact* c = &d->contact[d->ncon];
@@ -801,8 +804,7 @@ void orc_collide(const orc_model* m, orc_data* d) {
     }
   }
   if (m->resolve_contacts & 2) sort_contacts(m, d);
-  /* where contacts are resolved the capacity is the HIP backend's (contact_types.h: kMaxCon): the tail of MuJoCo's order is dropped */
-  if (m->resolve_contacts && d->ncon > 48) d->ncon = 48;
+  if (m->resolve_contacts && g_resolve_cap > 0 && d->ncon > g_resolve_cap) d->ncon = g_resolve_cap; /* (orc_set_contact_cap: tests only) */
   d->coupled = m->resolve_contacts && robot_contacts > 0;
   for (int i = 0; i < d->ncon; i++)
     if ((d->contact[i].geom[0] < m->ngeom && m->geom_type[d->contact[i].geom[0]] != 0) || (d->contact[i].geom[1] < m->ngeom && m->geom_type[d->contact[i].geom[1]] != 0))

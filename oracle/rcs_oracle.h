@@ -37,7 +37,7 @@ extern "C" {
 #define ORC_MAXTENDON 4
 #define ORC_MAXWRAP 8
 #define ORC_MAXSITE 32
-#define ORC_MAXCON 64
+#define ORC_MAXCON 256 /* storage only: MuJoCo's contact list has no fixed bound; orc_set_contact_cap() truncates for tests that mirror a backend's capacity */
 #define ORC_MAXEFC (ORC_MAXEQ + 3 * ORC_MAXV + 3 * ORC_MAXCON)
 #define ORC_NVT (ORC_MAXV + 6) /* dofs of the coupled system: the robot's joints, then the free box's 6 */
 #define ORC_MAXARM 8
@@ -228,6 +228,8 @@ typedef struct orc_data {
 void orc_set0(orc_model* m);
 /* rcs_contact.c: contacts of the robot's geoms and the coupled constraint problem */
 void orc_collide(const orc_model* m, orc_data* d);
+/* test support: keep only the first `cap` contacts of MuJoCo's order where contacts are resolved (0: all, the default) */
+void orc_set_contact_cap(int cap);
 void orc_make_coupled_rows(const orc_model* m, orc_data* d);
 void orc_solve_coupled(const orc_model* m, orc_data* d);
 double orc_impedance(const double* solimp, double pos, double margin);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librcs_oracle.so")
 
 MAXBODY, MAXV, MAXU, MAXEQ, MAXTENDON, MAXWRAP, MAXSITE, MAXARM = 32, 16, 16, 4, 4, 8, 32, 8
-MAXGEOM, MAXCON, MAXCGEOM = 32, 64, 16
+MAXGEOM, MAXCON, MAXCGEOM = 32, 256, 16
 MAXEFC = MAXEQ + 3 * MAXV + 3 * MAXCON
 NVT = MAXV + 6
 BODY_BOX = -2

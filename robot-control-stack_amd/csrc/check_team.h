@@ -29,6 +29,7 @@ namespace rcsh {
 
 #ifdef RCSH_CHECK_DEBUG
 __device__ int g_chk_dbg[64];
+__device__ double g_chk_dbgf[128];  // certificate failures of the narrow phase: (pair, margin, gap at the end, gap at the start) x 32
 __device__ unsigned long long g_chk_cyc[16];
 #define CHK_MARK(i) if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); g_chk_cyc[i] += now_ - chk_t0_; chk_t0_ = now_; }
 #else
@@ -51,6 +52,11 @@ constexpr int kCheckBox = 12 * kMaxCGeom;
 constexpr int kCheckGeomWords = (int)(sizeof(ContactGeom) / 8);
 static_assert(sizeof(ContactGeom) % 8 == 0 && 2 * kCheckGeomWords <= 64, "a lane per word of the narrow phase's two geom records");
 constexpr int check_work_doubles(int) { return 4 * kCheckBox + 64 + 4 * 12; }  // (+ the teams' joint travel, certifying mode)
+// certifying mode: the teams' tables of how far that travel can have moved a geom on link l relative to the frame of an ancestor link
+// c, moved[l][c + 1] -- room of its own (`mv`), which the caller finds where its kernel has some to spare
+// -- plus the links' world frames at the launch's START position ([4][nl][12]) and the geoms' boxes in their links' frames ([kMaxCGeom][12])
+// (two such tables -- one per kind of margin, see unresolved_contact_check -- in single precision, rounded up) and the teams' second travel vector
+constexpr int check_mv_doubles(int nl) { return 4 * nl * (nl + 1) + 4 * 12 * nl + 12 * kMaxCGeom + 4 * 12; }
 static_assert(4 * kCheckBox >= kSelfStage, "the hull stage overlays the world boxes");
 constexpr int kCheckPer = kMaxCheckPairs / kTeamLanes;
 constexpr int kCheckTrips = (3 * 152 + 63) / 64;  // vertex words per lane and hull (a hull has at most 152 vertices)
@@ -94,6 +100,30 @@ RCSH_D bool obb_apart_or_touching(const double* Ra, const double* ca, const doub
   return apart;
 }
 
+// The largest separation of two oriented boxes along one of their six face normals (negative: they overlap along all six): a lower
+// bound of the distance between the boxes, and of whatever they contain.
+RCSH_D double obb_face_sep(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb) {
+  double C[9], A[9], tv[3];
+  const double d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+  mulTv(Ra, d, tv);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      C[3 * i + j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+      A[3 * i + j] = fabs(C[3 * i + j]) + 1e-9;
+    }
+  double sep = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sep = fmax(sep, fabs(tv[i]) - (ha[i] + hb[0] * A[3 * i] + hb[1] * A[3 * i + 1] + hb[2] * A[3 * i + 2]));
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double tw = tv[0] * C[j] + tv[1] * C[3 + j] + tv[2] * C[6 + j];
+    sep = fmax(sep, fabs(tw) - (hb[j] + ha[0] * A[j] + ha[1] * A[3 + j] + ha[2] * A[6 + j]));
+  }
+  return sep;
+}
+
 // A remembered direction's slot: [0] = (pair index + 1) + 1024 (g0 + 32 g1) -- zero: empty --, [1..3] the direction in the frame of
 // geom 0's link.  The geoms ride along so that the NEXT launch can ask for their records and vertices before it knows anything else.
 RCSH_D double check_slot_key(int pidx, int g0, int g1) { return (double)((pidx + 1) + 1024 * (g0 + 32 * g1)); }
@@ -108,6 +138,7 @@ struct CheckPrefetch {
   int guess_key, guess_g0, guess_g1;  // wave-uniform; key 0: no guess
   double gword;                       // this lane's word of the guessed pair's two ContactGeom records
   double va[kCheckTrips], vb[kCheckTrips];
+  float lev[12];                      // CheckTable::lev[j][t]: what a radian / metre of joint j does to a point of a geom on the lane's link
 };
 RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double sep_in, bool live, CheckPrefetch& pf) {
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1);
@@ -125,6 +156,8 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 #pragma unroll
     for (int k = 0; k < 12; ++k) pf.grec[u][k] = ngeom > 0 && ck.geoms ? src[k] : 0.0;
   }
+#pragma unroll
+  for (int j = 0; j < 12; ++j) pf.lev[j] = ck.lev && t < 12 ? ck.lev[12 * j + t] : 0.0f;
   // the guess: slot 0's key of the first live team, else its slot 1's (lanes 0 and 4 of the team hold them)
   const uint64_t lv = __ballot(live && t == 0);
   pf.guess_key = 0; pf.guess_g0 = 0; pf.guess_g1 = 0;
@@ -155,12 +188,14 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 }
 
 // `frames`: LDS room for [4][NL][12] doubles (the link records' memory: the check is their last reader); `work`: LDS room for
-// check_work_doubles(NL).  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
+// check_work_doubles(NL); `mv`: for check_mv_doubles(NL); dend / psum: how far the lane's joint has been from where the launch ended, at
+// most / its effective path over the launch (see below; 0: it did not move -- or the check of the final position alone is asked for)
+// and q0 its position when the launch began.  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
 // Every lane of the wavefront calls this; returns, on every lane of a team, whether the team's environment is in contact.
 template <class T, class CollT>
 RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& tab, const CollT& lc, const LinkRec* links, double* frames,
                                      double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf,
-                                     double mpath = 0.0) {
+                                     double dend, double psum, double* mv, double q0) {
   constexpr int NL = T::NL;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const bool valid = t < NL;
@@ -170,12 +205,15 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   unsigned long long chk_t0_ = __builtin_readcyclecounter();
 #endif
   // ---- world frames of the links at the final qpos (what the next launch's first position stage will see)
-  double R[9], p[3];
+  double R[9], p[3], R0[9], p0[3];
   {
     KinK kk;
     kk.load(links[tl]);
     link_local_frame(kk, q, R, p);
     scan_frames<T>(R, p);
+    // ... and where the launch began (certifying mode: a gap at BOTH ends of the launch's path certifies more than one at its end)
+    link_local_frame(kk, q0, R0, p0);
+    scan_frames<T>(R0, p0);
   }
   CHK_MARK(0)
   __syncthreads();  // (the link records have been read: their memory becomes the frames')
@@ -194,24 +232,66 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #pragma unroll
     for (int k = 0; k < 3; ++k) F[12 * t + 9 + k] = p[k];
   }
-  if (t < 12) travel[t] = valid ? mpath : 0.0;
+  double* travelP = mv + 4 * NL * (NL + 1) + 4 * 12 * NL + 12 * kMaxCGeom + 12 * team;
+  if (t < 12) { travel[t] = valid ? dend : 0.0; travelP[t] = valid ? psum : 0.0; }
   __syncthreads();
   // Certifying mode (RunOp::check 2; per-environment escalation): a pair counts as apart only if it is PROVEN apart by more than
-  // its margin -- the most the joints between its two links can have moved the geoms relative to each other during the launch
-  // (ContactTable::self_lever x the joints' travel).  A contact at any substep of the launch needs the gap to have been zero then,
-  // and the final gap can exceed the gap at that substep by at most the margin: final gap > margin certifies the WHOLE launch, the
-  // contacts that begin and end inside it included (the blind spot of a check of the final position alone: 8 of 1024 rollouts,
-  // round 4).  Whatever is not proven apart sends the environment to the contact-resolving kernel, which looks in every substep.
-  double mp[NL];
+  // its margin -- the most the joints between its two links can have moved the two geoms relative to each other, the sum over those
+  // joints of (a travel of the joint) x (CheckTable::lev[joint][link]: how far a radian / metre of it moves a point of a geom ON that
+  // link, in any configuration of the joints in between).  Two travels, two margins, two tests (q: a position the joint took):
+  //  * `dend` >= |q - q_end|: the widest the joint has been from where the launch ended.  A contact at some substep needs the gap
+  //    to have been zero then, and the final gap can exceed the gap at that substep by at most the margin of dend:
+  //    gap at the end > that margin certifies the WHOLE launch, the contacts that begin and end inside it included (the blind spot of
+  //    a check of the final position alone: 6 of 512 rollouts of 1000 steps, round 5);
+  //  * `psum` >= |q - q_start| + |q - q_end|: the joint's effective path (twice the width of the interval it has been in less its net
+  //    displacement).  A pair that is d0 apart when the launch begins and d1 apart when it ends cannot have touched in between unless
+  //    some position on the way is d0 from the first AND d1 from the last: d0 + d1 > the margin of psum certifies too (both lower
+  //    bounds of the gaps, both positive).  Closing fingers, an arm sinking towards the floor: the gap shrinks by exactly what the
+  //    joints travel, the first test fails for the last step or two before every meeting, this one does not.
+  // Whatever is not proven apart sends the environment to the contact-resolving kernel, which looks in every substep.  (Round 5
+  // charged every joint with the reach of the whole arm below it
+  // moved[l][c + 1]: the geoms ON link l relative to the frame of link c (an ancestor-or-self of l; c = -1: the world).  A pair is
+  // charged moved[la][c] + moved[lb][c], c the deepest common ancestor of its links (CheckEntry); the floor moved[l][-1].
+  float* mvD = reinterpret_cast<float*>(mv) + NL * (NL + 1) * team;            // margins of dend
+  float* mvP = reinterpret_cast<float*>(mv) + NL * (NL + 1) * (4 + team);      // margins of psum
+  double* F0 = mv + 4 * NL * (NL + 1) + 12 * NL * team;   // the links' world frames where the launch began
+  double* gbox = mv + 4 * NL * (NL + 1) + 4 * 12 * NL;    // the geoms' boxes in their links' frames (one copy: the teams share the model)
+  if (valid) {
 #pragma unroll
-  for (int l = 0; l < NL; ++l) mp[l] = travel[l];
-  auto margin_of = [&](int la, int lb) -> double {
-    const uint32_t jm = anc_mask<T>(la) ^ anc_mask<T>(lb);
-    double m = 0.0;
+    for (int k = 0; k < 9; ++k) F0[12 * t + k] = R0[k];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) m += (jm >> l) & 1u ? mp[l] : 0.0;
-    return m;
-  };
+    for (int k = 0; k < 3; ++k) F0[12 * t + 9 + k] = p0[k];
+  }
+  if (team == 0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int g = t + kTeamLanes * u;
+      if (g < ngeom) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gbox[12 * g + k] = pf.grec[u][k];
+      }
+    }
+  }
+  if (valid) {
+    double x[NL], y[NL];
+    const uint32_t am = anc_mask<T>(t);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      x[j] = (am >> j) & 1u ? (double)pf.lev[j] * travel[j] : 0.0;
+      y[j] = (am >> j) & 1u ? (double)pf.lev[j] * travelP[j] : 0.0;
+    }
+#pragma unroll
+    for (int c = -1; c < NL; ++c) {
+      const uint32_t jm = am & ~anc_mask<T>(c);
+      double m = 0.0, mp_ = 0.0;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) { m += (jm >> j) & 1u ? x[j] : 0.0; mp_ += (jm >> j) & 1u ? y[j] : 0.0; }
+      // (single precision, rounded up: a margin errs on the large side)
+      mvD[t * (NL + 1) + c + 1] = m > 0.0 ? (float)m * 1.000001f + 1e-12f : 0.0f;
+      mvP[t * (NL + 1) + c + 1] = mp_ > 0.0 ? (float)mp_ * 1.000001f + 1e-12f : 0.0f;
+    }
+  }
+  __syncthreads();
   // ---- world boxes of the geoms: lane t takes geoms t, t + 16 (their link-frame boxes came with the prefetch)
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -250,12 +330,19 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
                          R[2] * nrm[0] + R[5] * nrm[1] + R[8] * nrm[2]};
     const double b = dot3(nrm, p) - lc.plane_d;
     const double* sph = lc.link_sphere[t];
-    const double mfl = margin_of(-1, t);
+    const double mfl = mvD[t * (NL + 1)], mflP = mvP[t * (NL + 1)];
     const double thr = mfl - kCheckTouch;  // (a contact is a penetration by more than kCheckTouch; nothing moved: the exact test)
+    const double a0[3] = {R0[0] * nrm[0] + R0[3] * nrm[1] + R0[6] * nrm[2], R0[1] * nrm[0] + R0[4] * nrm[1] + R0[7] * nrm[2],
+                          R0[2] * nrm[0] + R0[5] * nrm[1] + R0[8] * nrm[2]};
+    const double b0 = dot3(nrm, p0) - lc.plane_d;
     if (b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < thr) {
       for (int k = lc.link_adr[t]; k < lc.link_adr[t + 1]; ++k) {
         const double* v = lc.xyzr + 4 * (size_t)k;
-        if (b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3] < thr) {
+        const double h1 = b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3];
+        if (h1 < thr) {
+          // (the point's height where the launch began: the path-length form)
+          const double h0 = b0 + a0[0] * v[0] + a0[1] * v[1] + a0[2] * v[2] - v[3];
+          if (mfl > 0.0 && h1 > 0.0 && h0 > 0.0 && h0 + h1 > mflP) continue;
           mine = true;
 #ifdef RCSH_CHECK_DEBUG
           atomicAdd(&g_chk_dbg[0], 1);
@@ -267,11 +354,13 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   CHK_MARK(2)
   // ---- geom pairs: bounding spheres (bit j of smask: pair t + 16 j survived), then -- one pair per lane and round -- the boxes
   uint32_t smask = 0;
-  double mj[kCheckPer];  // the margins of the lane's pairs
+  double mj[kCheckPer], mjP[kCheckPer];  // the margins of the lane's pairs (of dend, of psum)
 #pragma unroll
   for (int j = 0; j < kCheckPer; ++j) {
-    const int g0 = pf.ent[j].geoms & 0xff, g1 = (pf.ent[j].geoms >> 8) & 0xff;
-    mj[j] = margin_of(ck.glink[g0], ck.glink[g1]);
+    const int g0 = pf.ent[j].geoms & 0xff, g1 = (pf.ent[j].geoms >> 8) & 0xff, cc = (pf.ent[j].geoms >> 16) & 0xff;
+    const int la = ck.glink[g0], lb = ck.glink[g1];
+    mj[j] = (double)(la >= 0 ? mvD[la * (NL + 1) + cc] : 0.0f) + (double)(lb >= 0 ? mvD[lb * (NL + 1) + cc] : 0.0f);
+    mjP[j] = (double)(la >= 0 ? mvP[la * (NL + 1) + cc] : 0.0f) + (double)(lb >= 0 ? mvP[lb * (NL + 1) + cc] : 0.0f);
   }
   if (live && !(ck.pad & 4)) {
     // (all the centres first, then the arithmetic: read pair by pair the wavefront would wait for LDS a dozen times)
@@ -303,16 +392,32 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
       smask &= smask - 1;
       // (the entry of round j: a select chain over the lane's registers -- a run-time index would put them into scratch)
       uint32_t gg = 0;
-      double mm = 0.0;
+      double mm = 0.0, mmP = 0.0;
 #pragma unroll
-      for (int k = 0; k < kCheckPer; ++k) { gg = k == j ? pf.ent[k].geoms : gg; mm = k == j ? mj[k] : mm; }
+      for (int k = 0; k < kCheckPer; ++k) { gg = k == j ? pf.ent[k].geoms : gg; mm = k == j ? mj[k] : mm; mmP = k == j ? mjP[k] : mmP; }
       const int g0 = gg & 0xff, g1 = (gg >> 8) & 0xff;
       double Ra[9], Rb[9], ca[3], cb[3], ha[3], hb[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { ca[k] = wbox[12 * g0 + k]; cb[k] = wbox[12 * g1 + k]; ha[k] = ck.gh[g0][k]; hb[k] = ck.gh[g1][k]; }
 #pragma unroll
       for (int k = 0; k < 9; ++k) { Ra[k] = wbox[12 * g0 + 3 + k]; Rb[k] = wbox[12 * g1 + 3 + k]; }
-      if (!obb_apart_or_touching(Ra, ca, ha, Rb, cb, hb, kCheckTouch, mm)) {
+      bool settled;
+      if (mm > 0.0) {
+        const double sep1 = obb_face_sep(Ra, ca, ha, Rb, cb, hb);
+        settled = sep1 > mm - kCheckTouch;
+        if (!settled && sep1 > 0.0) {
+          // the same boxes where the launch began (their links' frames then, the boxes in their links' frames)
+          const int la = ck.glink[g0], lb = ck.glink[g1];
+          double Ra0[9], Rb0[9], ca0[3], cb0[3];
+          self_box_world(F0, la, gbox + 12 * g0, gbox + 12 * g0 + 3, ca0, Ra0);
+          self_box_world(F0, lb, gbox + 12 * g1, gbox + 12 * g1 + 3, cb0, Rb0);
+          const double sep0 = obb_face_sep(Ra0, ca0, ha, Rb0, cb0, hb);
+          settled = sep0 > 0.0 && sep0 + sep1 > mmP;
+        }
+      } else {
+        settled = obb_apart_or_touching(Ra, ca, ha, Rb, cb, hb, kCheckTouch, 0.0);
+      }
+      if (!settled) {
         cmask |= 1u << j;
 #ifdef RCSH_CHECK_DEBUG
         atomicAdd(&g_chk_dbg[33], 1);
@@ -334,10 +439,11 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     if (holder) cmask &= ~(1u << u);
     const int pidx = t1 + kTeamLanes * u;
     uint32_t gg = 0;
-    double mu_ = 0.0;
+    double mu_ = 0.0, muP_ = 0.0;
 #pragma unroll
-    for (int k = 0; k < kCheckPer; ++k) { gg = k == u ? pf.ent[k].geoms : gg; mu_ = k == u ? mj[k] : mu_; }
-    const double mteam = lane_get(mu_, (lane & 48) + t1);  // the margin of this pair in the lane's team (its lane t1 holds it)
+    for (int k = 0; k < kCheckPer; ++k) { gg = k == u ? pf.ent[k].geoms : gg; mu_ = k == u ? mj[k] : mu_; muP_ = k == u ? mjP[k] : muP_; }
+    const double mteam = lane_get(mu_, (lane & 48) + t1);  // the margins of this pair in the lane's team (its lane t1 holds them)
+    const double mteamP = lane_get(muP_, (lane & 48) + t1);
     gg = (uint32_t)__builtin_amdgcn_readlane((int)gg, src);
     const int g0 = gg & 0xff, g1 = (gg >> 8) & 0xff;
     const int na = 3 * ck.gvert[g0][1], nb = 3 * ck.gvert[g1][1];
@@ -393,6 +499,29 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #pragma unroll
         for (int k = 0; k < 9; ++k) LR[k] = F[12 * a.link + k];
       }
+      // certifying mode: is a gap g1 (> 0, proven along the link-frame direction dl at the launch's end) enough -- by itself, or together
+      // with the gap the same direction proves where the launch began (the path-length form; one more support query, at the start frames)
+      double dbg_g1 = -1.0, dbg_g0 = -1.0;
+      (void)dbg_g1; (void)dbg_g0;
+      auto certified = [&](double g1, const double* dl) -> bool {
+        dbg_g1 = g1;
+        if (g1 > mteam - kCheckTouch) return true;
+        if (!(g1 > 0.0)) return false;
+        double Ra0[9], pa0[3], Rb0[9], pb0[3], LR0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, dw0[3];
+        self_geom_world(a, F0, Ra0, pa0);
+        self_geom_world(b, F0, Rb0, pb0);
+        const Shape A0 = make_shape(A.type, pa0, Ra0, a.size, A.verts, A.nvert), B0 = make_shape(B.type, pb0, Rb0, b.size, B.verts, B.nvert);
+        if (a.link >= 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) LR0[k] = F0[12 * a.link + k];
+        }
+        mulmv(LR0, dl, dw0);
+        MprPt s0;
+        mpr_support<true>(A0, B0, dw0, s0);
+        const double g0 = -dot3(s0.v, dw0);
+        dbg_g0 = g0;
+        return g0 > 0.0 && g0 + g1 > mteamP;
+      };
       double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};  // (a point of A - B)
       if (s_hold >= 0) {
         const double dl[3] = {lane_get(sepw, tbase + 4 * s_use + 1), lane_get(sepw, tbase + 4 * s_use + 2), lane_get(sepw, tbase + 4 * s_use + 3)};
@@ -400,24 +529,36 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         mulmv(LR, dl, dw);
         MprPt s;
         mpr_support<true>(A, B, dw, s);
-        apart = dot3(s.v, dw) < (mteam > 0.0 ? kCheckTouch - mteam : 0.0);  // the support of A - B along the remembered direction is still negative (by more than the margin): apart
+        // the support of A - B along the remembered direction is still negative: apart (certifying mode: by enough)
+        const double g1 = -dot3(s.v, dw);
+        apart = mteam > 0.0 ? certified(g1, dl) : g1 > 0.0;
         x0[0] = s.v[0]; x0[1] = s.v[1]; x0[2] = s.v[2];
       }
 #ifndef RCSH_NO_GILBERT
       if (!apart) {
         // a few support queries towards a separating direction before the full refinement (contact_team.h: gilbert_apart); the margin
-        // keeps its verdicts far from the nanometre the check calls contact
+        // keeps its verdicts far from the nanometre the check calls contact.  Certifying mode: a few more, after the first proof, for a
+        // direction with a larger gap -- it is the gap that certifies, and the direction is remembered
         double dg[3], gap = 0.0;
-        if (gilbert_apart<true>(A, B, x0, 5, fmax(1e-5, mteam), dg, &gap)) {
-          apart = true;
+        if (gilbert_apart<true>(A, B, x0, mteam > 0.0 ? 8 : 5, 1e-5, dg, &gap, mteam > 0.0 ? 3 : 0)) {
           double dl[3];
           mulTv(LR, dg, dl);
+          apart = mteam > 0.0 ? certified(gap, dl) : true;
           stage_fence();
           slot_store(dl);
         }
       }
 #endif
-      if (!apart && mteam > 0.0) mine = true;  // (certifying mode: not proven apart by more than the margin)
+      if (!apart && mteam > 0.0) {
+        mine = true;  // (certifying mode: not proven apart by enough)
+#ifdef RCSH_CHECK_DEBUG
+        if (t == 0) {
+          const int k = atomicAdd(&g_chk_dbg[1], 1);
+          if (k < 28) g_chk_dbg[2 + k] = pidx;
+          if (k < 32) { g_chk_dbgf[4 * k] = pidx; g_chk_dbgf[4 * k + 1] = mteam; g_chk_dbgf[4 * k + 2] = dbg_g1; g_chk_dbgf[4 * k + 3] = dbg_g0; }
+        }
+#endif
+      }
       else if (!apart && !(ck.pad & 8)) {
         double dir[3], depth = 0.0;
         if (mpr_penetration<true, kMprDepth>(A, B, &depth, dir, nullptr)) {

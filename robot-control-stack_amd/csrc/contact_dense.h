@@ -26,19 +26,19 @@ namespace rcsh {
 // tail and -- during the noslip pass, when nobody needs it -- the Hessian's; without one 9 entries, and 21 contacts are 63 rows: a lane each)
 constexpr int kDenseConBox = 18, kDenseConNoBox = 21;
 
-template <class T, bool BOXD>
+template <class T, bool BOXD, class AR_>
 struct DenseLds {
   static constexpr int NL = T::NL, NVD = BOXD ? T::NL + 6 : T::NL;
   static constexpr int kDenseCon = BOXD ? kDenseConBox : kDenseConNoBox;
   static constexpr int kRows = 3 * kDenseCon;
   static constexpr int kRowsInStage = (64 * 8) / NVD;
-  using AR = ContactArena<T>;
+  using AR = AR_;
   // row r of J: the stage area first, the stiffness accumulators' area for the rest
   RCSH_D static double* jrow(AR& ar, int r) { return r < kRowsInStage ? &ar.stage[0][0] + r * NVD : &ar.KA[0][0] + (r - kRowsInStage) * NVD; }
   // Y_r = (M^-1 J_r')' of the FRICTION rows (k = 1, 2) of contact c: the records' area behind the kDenseCon records in use.  (The noslip
   // pass changes normal forces only where the Newton solution left none -- by less than kMinVal = 1e-15 N: that change's effect on the
   // other rows' residuals is dropped, and the normal rows' Y, needed for the contact's own 3 x 3 block only, stay in registers.)
-  static constexpr int kYRowsBehindRecords = ((kMaxCon - kDenseCon) * 14) / NVD, kYRowsInHessian = (AR::NV * (AR::NV + 1) / 2) / NVD;
+  static constexpr int kYRowsBehindRecords = ((AR::kCap - kDenseCon) * 14) / NVD, kYRowsInHessian = (AR::NV * (AR::NV + 1) / 2) / NVD;
   RCSH_D static double* yrow(AR& ar, int c, int k) {
     const int i = 2 * c + k - 1;
     return i < kYRowsBehindRecords ? &ar.rec[kDenseCon][0] + i * NVD : &ar.H[0] + (i - kYRowsBehindRecords) * NVD;
@@ -55,17 +55,17 @@ struct DenseLds {
 // Rows + Newton.  In: the contact records of contact_collide (at most kDenseCon).  Out, as contact_newton: the minimiser in ar.X
 // (and bs[kBoxX..]), qacc_smooth in ar.A0, M's factor in ar.V, reference accelerations / regularisers / forces in the records --
 // and J in LDS (DenseLds::jrow) for the noslip pass.
-template <class T, bool FRIC, bool BOXD>
-RCSH_CONTACT_FN void contact_newton_dense(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_, const double* gravity_,
+template <class T, bool FRIC, bool BOXD, class AR>
+RCSH_CONTACT_FN void contact_newton_dense(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, AR& ar_, const double* gravity_,
                                           const LinkRec* links_) {
   const LinkRec* links = in_lds(links_);
   (void)links;
   const BoxCfg& b = *in_lds(&b_);
   const StageTeam<T> st{in_lds(st_.base)};
   double* bs = in_lds(bs_);
-  ContactArena<T>& ar = *in_lds(&ar_);
+  AR& ar = *in_lds(&ar_);
   const double* gravity = in_lds(gravity_);
-  using DL = DenseLds<T, BOXD>;
+  using DL = DenseLds<T, BOXD, AR>;
   constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6, NVD = DL::NVD, NTRID = NVD * (NVD + 1) / 2;
   constexpr int kBox = NL, kWorld = NL + 1;
   const int lane = wave_lane();
@@ -467,13 +467,13 @@ RCSH_CONTACT_FN void contact_newton_dense(const BoxCfg& b_, const StageTeam<T>& 
 }
 
 // noslip + results for the explicit rows.  In: ar.X (the Newton minimiser), M's factor in ar.V, J in LDS, the records.
-template <class T, bool BOXD>
-RCSH_CONTACT_FN void contact_noslip_dense(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_) {
+template <class T, bool BOXD, class AR>
+RCSH_CONTACT_FN void contact_noslip_dense(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, AR& ar_) {
   const BoxCfg& b = *in_lds(&b_);
   const StageTeam<T> st{in_lds(st_.base)};
   double* bs = in_lds(bs_);
-  ContactArena<T>& ar = *in_lds(&ar_);
-  using DL = DenseLds<T, BOXD>;
+  AR& ar = *in_lds(&ar_);
+  using DL = DenseLds<T, BOXD, AR>;
   constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6, NVD = DL::NVD;
   constexpr int kWorld = NL + 1;
   const int lane = wave_lane();
@@ -673,11 +673,11 @@ RCSH_CONTACT_FN void contact_noslip_dense(const BoxCfg& b_, const StageTeam<T>& 
 #else
 #define PHASE_CLOCK(var)
 #endif
-template <class T, bool FRIC = false, bool BOXD = true>
+template <class T, bool FRIC = false, bool BOXD = true, class AR>
 RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
-                              ContactArena<T>& ar, const double* gravity, int env) {
+                              AR& ar, const double* gravity, int env) {
   PHASE_CLOCK(pc0)
-  const uint32_t r = contact_collide<T>(tab, ck, b, links, st, bs, ar, env);
+  const uint32_t r = contact_collide<T, AR>(tab, ck, b, links, st, bs, ar, env);
   PHASE_CLOCK(pc1)
 #ifdef RCSH_PHASE_TIMING
   if ((threadIdx.x & 63) == 0) {  // (all workgroups) contact phases / coupled / contacts / most contacts / solves on the tree formulation
@@ -685,7 +685,7 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
     if (r & 1u) {
       const unsigned long long nc_ = (unsigned long long)in_lds(&ar)->ncon;
       atomicAdd(&g_team_cycles[72], 1ull); atomicAdd(&g_team_cycles[70], nc_); atomicMax(&g_team_cycles[68], nc_);
-      if (nc_ > (unsigned long long)DenseLds<T, BOXD>::kDenseCon) atomicAdd(&g_team_cycles[69], 1ull);
+      if (nc_ > (unsigned long long)DenseLds<T, BOXD, AR>::kDenseCon) atomicAdd(&g_team_cycles[69], 1ull);
     } else {
       atomicAdd(&g_team_cycles[82], pc1 - pc0);  // collision passes that found nothing
       s_wg_acc[7] += pc1 - pc0;
@@ -694,13 +694,13 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
   }
 #endif
   if (!(r & 1u) || !b.resolve) return r & ~1u;
-  const bool few = in_lds(&ar)->ncon <= DenseLds<T, BOXD>::kDenseCon;
+  const bool few = in_lds(&ar)->ncon <= DenseLds<T, BOXD, AR>::kDenseCon;
 #ifndef RCSH_NO_DENSE
   if (few) {
     // few contacts (the headline's one or two, a pinch's dozen): the rows written out
-    contact_newton_dense<T, FRIC, BOXD>(b, st, bs, ar, gravity, links);
+    contact_newton_dense<T, FRIC, BOXD, AR>(b, st, bs, ar, gravity, links);
     PHASE_CLOCK(pc2)
-    contact_noslip_dense<T, BOXD>(b, st, bs, ar);
+    contact_noslip_dense<T, BOXD, AR>(b, st, bs, ar);
     PHASE_CLOCK(pc3)
 #ifdef RCSH_PHASE_TIMING
     if ((threadIdx.x & 63) == 0) {
@@ -711,9 +711,9 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
     return r | (in_lds(&ar)->pad[0] ? 16u : 0u);
   }
 #endif
-  contact_newton<T, FRIC>(b, st, bs, ar, gravity, links);
+  contact_newton<T, FRIC, AR>(b, st, bs, ar, gravity, links);
   PHASE_CLOCK(pc2)
-  contact_noslip<T>(b, st, bs, ar);
+  contact_noslip<T, AR>(b, st, bs, ar);
   PHASE_CLOCK(pc3)
 #ifdef RCSH_PHASE_TIMING
   if ((threadIdx.x & 63) == 0) {

@@ -47,8 +47,11 @@ RCSH_D double wave_sum(double x) {
 }
 RCSH_D int wave_lane() { return threadIdx.x & 63; }
 
-template <class T>
+// CAP: contacts per environment this arena has records for (contact_types.h: kMaxCon with a free box in the scene -- that kernel's LDS
+// must let four workgroups share a CU --, kMaxConNoBox without one: the kernel of per-environment escalation)
+template <class T, int CAP = kMaxCon>
 struct ContactArena {
+  static constexpr int kCap = CAP;
   static constexpr int NL = T::NL, NB = T::NL + 2, NV = T::NL + 6;
   static constexpr int kBox = NL, kWorld = NL + 1;
   double V[NB][6];         // spatial velocity of the bodies about the world origin [angular; linear]
@@ -59,7 +62,7 @@ struct ContactArena {
   double H[NV * (NV + 1) / 2];
   static constexpr int kAcc = 2 * kMaxActive + 1 + kMaxPairs;
   double KA[kAcc][21];     // contact stiffness: (link a, box) pairs, (world, link a) pairs, (world, box), (link, link) pairs
-  double rec[kMaxCon][14]; // contact records (con_load): what the phases hand to each other
+  double rec[CAP][14];     // contact records (con_load): what the phases hand to each other
   double stage[64][8];     // scratch: clipping polygons of the box-box collider / per-contact wrenches / stiffness batches / Y
   int32_t cb[64];          // bodies of contact c: A | B << 8 | class bits << 16
   int32_t cnt[64][2];      // per geom lane (a geom table has at most kMaxCGeom <= 32 entries): plane contacts, box contacts; the upper half
@@ -75,7 +78,7 @@ struct ContactArena {
   __device__ double (*frames())[12] { return reinterpret_cast<double (*)[12]>(&V[0][0] + kScratch); }
   // contact c's place in mjData.contact: body pair, geom pair, index within the pair (contact_collide's merge)
   __device__ int32_t* keyp() { return &cnt[32][0]; }
-  static_assert(kMaxCGeom <= 32 && kMaxCon <= 64, "sort keys share the counters' array");
+  static_assert(kMaxCGeom <= 32 && CAP <= 64, "sort keys share the counters' array; a lane per contact");
 };
 
 // is joint j an ancestor-or-self joint of link i?
@@ -1165,7 +1168,7 @@ RCSH_D BodyMasks body_masks(const ConLane& c, int lane) {
 template <class T, class AR>
 RCSH_D double contact_qfrc(AR& ar, const StageTeam<T>& st, const ConLane& c, const double* fc, const BodyMasks& bm, const double* bR, const double* bp, int lane) {
   constexpr int NL = T::NL, NV = NL + 6, NB = NL + 2, kBox = NL;
-  if (lane < kMaxCon) {
+  if (lane < AR::kCap) {
     double* wr = ar.stage[lane];
 #pragma unroll
     for (int k = 0; k < 6; ++k) wr[k] = c.on ? c.G[0][k] * fc[0] + c.G[1][k] * fc[1] + c.G[2][k] * fc[2] : 0.0;
@@ -1256,16 +1259,17 @@ constexpr double kSelfTouch = 1e-9;
 constexpr double kNewtonRel = 2e-12;  // oracle: ORC_NEWTON_REL
 RCSH_D int contact_key(int b1, int b2, int g1, int g2, int k) { return (b1 << 23) | (b2 << 18) | (g1 << 13) | (g2 << 8) | k; }
 constexpr int kKeyBox = 31;  // the free box: the scene's last body, its last geom (reference assets/scenes/fr3_simple_pick_up/scene.xml:30-33)
-template <class T>
+template <class T, class AR>
 RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTable& ck_, const BoxCfg& b_, const LinkRec* links_, const StageTeam<T>& st_,
-                                         const double* bs_, ContactArena<T>& ar_, int env) {
+                                         const double* bs_, AR& ar_, int env) {
+  constexpr int kMaxCon = AR::kCap;  // (this arena's capacity)
   const ContactTable& tab = *in_lds(&tab_);
   const CheckTable& ck = *in_lds(&ck_);
   const BoxCfg& b = *in_lds(&b_);
   const LinkRec* links = in_lds(links_);
   const StageTeam<T> st{in_lds(st_.base)};
   const double* bs = in_lds(bs_);
-  ContactArena<T>& ar = *in_lds(&ar_);
+  AR& ar = *in_lds(&ar_);
   constexpr int NL = T::NL;
   constexpr int kBox = NL, kWorld = NL + 1;
   const int lane = wave_lane();
@@ -1283,7 +1287,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
   // of every substep before.  Exact: only what is proven apart is skipped (oracle self_collide / plane tests look at everything in every
   // substep and find the same contacts).
   constexpr int kDp = 12 * kMaxCGeom;  // this substep's joint motion, behind the world boxes
-  static_assert(ContactArena<T>::kScratch >= kDp + 12, "joint motion fits behind the world boxes");
+  static_assert(AR::kScratch >= kDp + 12, "joint motion fits behind the world boxes");
   float rem[3] = {0.0f, 0.0f, 0.0f}, remf = 0.0f;
   CheckEntry ent[3] = {};
   uint32_t am = 0;  // bit j: pair lane + 64 j has used its slack up
@@ -1408,6 +1412,9 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
   bool want_plane = false, want_box = false;  // hull geoms: vertex work left for the cooperative stage
   ContactGeom cg;
   const bool has_geom = lane < tab.ngeom;
+  // (a pass that is here for a geom PAIR only -- every geom still has height left above the floor -- skips the floor tests: nothing can
+  // touch it, and the heights keep what the slack test left of them)
+  const bool floor_due = !remg || b.present || __ballot(has_geom && !(remf > 0.0f)) != 0;
   if (has_geom) {
     cg = tab.geoms[lane];
     double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0};
@@ -1423,8 +1430,8 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
     gp[0] += pl[0]; gp[1] += pl[1]; gp[2] += pl[2];
     const double* V = tab.verts + 3 * (size_t)cg.vert_adr;
     // ---- floor
-    remf = 1e30f;  // (a geom the floor does not collide with)
-    if (tab.has_plane && cg.plane_ok) {
+    if (floor_due) remf = 1e30f;  // (a geom the floor does not collide with)
+    if (tab.has_plane && cg.plane_ok && floor_due) {
       const double n[3] = {tab.plane_n[0], tab.plane_n[1], tab.plane_n[2]};
       const double cdst = dot3(n, gp) - tab.plane_d;
       {
@@ -1639,7 +1646,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
   // merged into MuJoCo's order below.
   int nS = 0;  // (wave-uniform)
   if (self_on) {
-    static_assert(ContactArena<T>::kScratch >= 12 * kMaxCGeom && ContactArena<T>::kScratch >= 3 * 152, "world boxes of the geoms / one hull fit the scratch area");
+    static_assert(AR::kScratch >= 12 * kMaxCGeom && AR::kScratch >= 3 * 152, "world boxes of the geoms / one hull fit the scratch area");
     double* wb = ar.scratch();
     // ---- which pairs have to be looked at: a pair found apart by a gap g cannot touch before the joints BETWEEN its two links have moved
     // the geoms by g (ContactTable::self_lever turns joint motion into a bound on that; the lean DET kernels' SelfSlack, here per
@@ -1700,7 +1707,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
     // points each): every lane runs the collider for its own pair -- the serial loop below spent 40k cycles of one lane per pair, 570k
     // per substep of such an environment.  A lane needs 48 doubles of LDS for its clipping polygons: kBoxPool lanes at a time.
     {
-      constexpr int kPoolA = ContactArena<T>::kScratch / 48, kPoolB = (64 * 8) / 48, kBoxPool = kPoolA + kPoolB;
+      constexpr int kPoolA = AR::kScratch / 48, kPoolB = (64 * 8) / 48, kBoxPool = kPoolA + kPoolB;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int g0 = ent[j].geoms & 0xff, g1 = (ent[j].geoms >> 8) & 0xff;
@@ -1888,7 +1895,10 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
         double dg[3];
         // (a pair that was in contact a substep ago goes straight to the refinement: five support queries saved)
         const int hot_mine = team == 0 ? grp_hot[0] : (team == 1 ? grp_hot[1] : (team == 2 ? grp_hot[2] : grp_hot[3]));
-        apart = hot_mine ? false : gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap);
+        // (... and a few more queries after the first proof, for a direction with a larger gap: the gap is the slack the pair is credited
+        // with -- the first direction that separates often proves a millimetre where the hulls are centimetres apart, and the pair, and
+        // with it the whole pass, was due again a substep later: 97 % of an escalated environment's passes, round 5)
+        apart = hot_mine ? false : gilbert_apart<true>(A, B, x0, 8, 1e-5, dg, &gap, 3);
         if (!apart) {
           TEAM_COUNT(23)
           nc = mpr_penetration<true>(A, B, &depth, sn, spos0);
@@ -2024,15 +2034,15 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
 // |qacc_i - aref_i| < R frictionloss, linear with force -+frictionloss outside (oracle primal(): ORC_EFC_FRICTION) -- are rows of
 // the coupled problem like the limit rows: a term of the lane's cost / gradient entry, of its diagonal Hessian entry and of
 // phi', phi'' along the search line.
-template <class T, bool FRIC>
-RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_, const double* gravity_,
+template <class T, bool FRIC, class AR>
+RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, AR& ar_, const double* gravity_,
                                     const LinkRec* links_) {
   const LinkRec* links = in_lds(links_);
   (void)links;
   const BoxCfg& b = *in_lds(&b_);
   const StageTeam<T> st{in_lds(st_.base)};
   double* bs = in_lds(bs_);
-  ContactArena<T>& ar = *in_lds(&ar_);
+  AR& ar = *in_lds(&ar_);
   const double* gravity = in_lds(gravity_);
   constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6;
   constexpr int kBox = NL, kWorld = NL + 1;
@@ -2246,7 +2256,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
   // accumulator a < nact: (link act[a], box); kMaxActive + a: (world, link act[a]); last: (world, box)
   const BodyMasks bmasks = body_masks<NL + 1>(c, lane);
   // ... and kAcc - kMaxPairs + p: the two links of ar.pairs[p] against each other
-  constexpr int kAcc = ContactArena<T>::kAcc;
+  constexpr int kAcc = AR::kAcc;
   static_assert(kAcc <= 18, "two accumulators per group of seven lanes");
   const int npairs = ar.npairs;
   uint64_t kmask = 0, kmask2 = 0;  // contacts of accumulator lane / 7, and of accumulator 9 + lane / 7
@@ -2318,7 +2328,7 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
 #pragma unroll
       for (int batch = 0; batch < 3; ++batch) {
         __syncthreads();
-        if (lane < kMaxCon) {
+        if (lane < AR::kCap) {
           double* wr = ar.stage[lane];
 #pragma unroll
           for (int e = 0; e < 7; ++e) wr[e] = Kc[7 * batch + e];
@@ -2615,12 +2625,12 @@ RCSH_CONTACT_FN void contact_newton(const BoxCfg& b_, const StageTeam<T>& st_, d
 // mj_solNoSlip over the contacts' friction rows (Gauss-Seidel in contact order, no regulariser), then the robot's
 // qfrc_constraint -> st.fcon and the box's acceleration -> bs[kBoxA..].  In: the bodies' accelerations ar.U at the Newton
 // solution ar.X, the records.
-template <class T>
-RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, ContactArena<T>& ar_) {
+template <class T, class AR>
+RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, double* bs_, AR& ar_) {
   const BoxCfg& b = *in_lds(&b_);
   const StageTeam<T> st{in_lds(st_.base)};
   double* bs = in_lds(bs_);
-  ContactArena<T>& ar = *in_lds(&ar_);
+  AR& ar = *in_lds(&ar_);
   constexpr int NL = T::NL, NA = T::NARM, NV = NL + 6, NB = NL + 2;
   constexpr int kBox = NL, kWorld = NL + 1;
   const int lane = wave_lane();

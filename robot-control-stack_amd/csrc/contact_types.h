@@ -4,7 +4,10 @@
 
 namespace rcsh {
 
-constexpr int kMaxCon = 48;      // contacts per environment (oracle: ORC_MAXCON)
+constexpr int kMaxCon = 48;      // contacts per environment, scenes with a free box (its kernel's LDS must let four workgroups share a CU)
+constexpr int kMaxConNoBox = 64; // ... without one (the contact-resolving kernel of per-environment escalation: a closed gripper pressed into the
+                                 // arm brings 50-64 contacts, tools/oracle_ncon_probe.py; the contact phase gives a lane to each).  MuJoCo's list has
+                                 // no bound: a phase that runs out sets kContactOverflow
 constexpr int kMaxCGeom = 28;    // collision geoms of the robot (the end-of-launch contact check keeps the world boxes of all of them, for the
                                  // wavefront's four environments, in the team kernels' LDS block: check_team.h)
 constexpr int kMaxActive = 5;    // links in contact at once that the noslip pass keeps M^-1 S' for

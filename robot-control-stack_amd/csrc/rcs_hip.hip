@@ -633,7 +633,8 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
       // by the whole batch on the contact-resolving kernel, or environment by environment (RunOp::esc_role)
       if constexpr (T::NARM == 7 && T::GRIP) {
         if (esc) {
-          static const int certify = [] { const char* e = std::getenv("RCSH_CHECK_CERTIFY"); return e ? std::atoi(e) : 0; }();
+          // (the certifying check -- check_team.h -- is the default; RCSH_CHECK_CERTIFY=0: the check of the final position alone, round 5's)
+          static const int certify = [] { const char* e = std::getenv("RCSH_CHECK_CERTIFY"); return e ? std::atoi(e) : 1; }();
           // How this step's contact-resolving work is enqueued.  The environments that are escalated already do not depend on the step's
           // lean launch: with any of them around (as far as the host knows: the device's last report, at most two steps old -- the host
           // does not run further ahead than that) they go FIRST, on a stream of their own, and the lean launch fills the rest of the chip
@@ -679,7 +680,7 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
           if (no_check) op.check = 0;
           go(N{}, N{}, N{});
           op.snap = snap_keep;
-          op.esc_role = 2; op.check = 0;
+          op.esc_role = 2; op.check = certify ? 2 : 0;
           op.esc_part = split ? 2 : 0;
           if (split) esc_chk(hipStreamWaitEvent(s->stream, s->esc_ev_old, 0));
           static const int leave_quiet = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();
@@ -2644,6 +2645,9 @@ extern "C" int rcsh_debug_check(int* out64, int clear) {
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(rcsh::g_chk_dbg), sizeof(int) * 64) != hipSuccess) return 1;
   if (clear) { int z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rcsh::g_chk_dbg), z, sizeof(z)) != hipSuccess) return 1; }
   return 0;
+}
+extern "C" int rcsh_debug_check_f(double* out128) {
+  return hipMemcpyFromSymbol(out128, HIP_SYMBOL(rcsh::g_chk_dbgf), sizeof(double) * 128) != hipSuccess;
 }
 extern "C" int rcsh_debug_check_cycles(unsigned long long* out16, int clear) {
   hipDeviceSynchronize();

@@ -818,7 +818,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   __shared__ RunOp lop;
   // (sized for the end-of-launch contact check too, which takes the block over once the state has been written back)
   // (CON: the check's workspace is the contact arena, idle by then -- the instantiation has no LDS to spare)
-  constexpr int kLdsDoubles = (CON || ST::COUNT * kTeams > check_work_doubles(T::NL)) ? ST::COUNT * kTeams : check_work_doubles(T::NL);
+  // (... and, kernels that carry neither the contact arena nor the detection's frames, for the certifying check's travel tables behind it)
+  constexpr int kLdsMain = (CON || ST::COUNT * kTeams > check_work_doubles(T::NL)) ? ST::COUNT * kTeams : check_work_doubles(T::NL);
+  constexpr int kLdsDoubles = kLdsMain + ((CON || DET) ? 0 : check_mv_doubles(T::NL));
   __shared__ __attribute__((aligned(16))) double lds[kLdsDoubles];
   // everything the launch reads from memory at its start is asked for at once -- arguments, model tables and, further down, the
   // environment's state -- and stored to LDS after one wait
@@ -1019,13 +1021,14 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   // of their two timestamps is due.
   // the free box of the scene: its state sits in the team's LDS block between substeps (box_team.h)
   __shared__ double lbox[(BOX || CON) ? kBoxLds * kTeams : 1];
-  __shared__ std::conditional_t<CON, ContactArena<T>, char> larena[1];  // the contact phase's workspace: one per wavefront
+  using Arena = ContactArena<T, BOX ? kMaxCon : kMaxConNoBox>;
+  __shared__ std::conditional_t<CON, Arena, char> larena[1];  // the contact phase's workspace: one per wavefront
   // self collision (DET): the world frames of every team's links for the pair tests.  The contact phase's workspace is idle
   // while the position stage runs (it is rebuilt from scratch whenever the contact phase starts), so with CON the frames
   // borrow it: that instantiation has no LDS to spare (38.7 of the 40 KB that let four workgroups share a CU).
   constexpr int kSelfF = 12 * T::NL;
   __shared__ double lself[(DET && !CON) ? kSelfF * kTeams + kSelfStage + kSelfCache + kSelfTag : 1];
-  static_assert(!CON || sizeof(ContactArena<T>) >= sizeof(double) * (kSelfF * kTeams + kSelfStage + kSelfCache + kSelfTag), "link frames and hull stage fit into the contact arena");
+  static_assert(!CON || sizeof(Arena) >= sizeof(double) * (kSelfF * kTeams + kSelfStage + kSelfCache + kSelfTag), "link frames and hull stage fit into the contact arena");
   double* const selfAll = (DET && CON) ? reinterpret_cast<double*>(&larena[0]) : lself;
   double* const selfF = selfAll + (DET ? team * kSelfF : 0);
   const int npair = DET ? lp.ctab.npair : 0;
@@ -1110,16 +1113,17 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     box_r2 = bc.size[0] * bc.size[0] + bc.size[1] * bc.size[1] + bc.size[2] * bc.size[2];
   }
   TEAM_MARK(11)
-  // how far every joint travels over this launch's substeps (the certifying check, check_team.h: a contact that begins AND ends inside
-  // the launch needs the geoms to cover their final gap on the way)
-  double chk_path = 0.0, chk_qlast = 0.0;
+  // where every joint has been over this launch's substeps -- first position, lowest, highest (the certifying check, check_team.h: a
+  // contact that begins AND ends inside the launch needs the geoms to cover their gaps on the way)
+  double chk_qmin = 0.0, chk_qmax = 0.0, chk_q0 = 0.0;
   bool chk_first = true;
   while (going) {
     const bool stepping = (going >> (threadIdx.x & 48)) & 1u;
     if (op.check == 2 && t < T::NL) {
       const double qn = st.q(t);
-      chk_path += chk_first ? 0.0 : fabs(qn - chk_qlast);
-      chk_qlast = qn;
+      chk_q0 = chk_first ? qn : chk_q0;
+      chk_qmin = chk_first ? qn : fmin(chk_qmin, qn);
+      chk_qmax = chk_first ? qn : fmax(chk_qmax, qn);
       chk_first = false;
     }
     if (leader && stepping && has_cb && r.time - cb_due > robot_period) {
@@ -1362,7 +1366,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     lp.rend.count[e] = (int32_t)lrend[team][kMaxRateCams + 1];
   }
   // what the end-of-launch contact check reads from memory is asked for now: it arrives while the leader lanes run the epilogue
-  const bool do_check = op.check && (lp.chk.npair > 0 || (!CON && lp.chk.plane_points));  // (wave-uniform)
+  // (the contact-resolving launch of per-environment escalation asks for its environments' way BACK: the floor counts there too)
+  const bool chk_plane = !CON || esc_role == 2;
+  const bool do_check = op.check && (lp.chk.npair > 0 || (chk_plane && lp.chk.plane_points));  // (wave-uniform)
   CheckPrefetch chk_pf;
   if (do_check) check_prefetch(lp.chk, lp.ctab, sep_in, live, chk_pf);
   {
@@ -1375,18 +1381,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   bool esc_leave = false;
   if (leader) {
     if (until_conv) set_flag(r.flags, kConverged, converged);
-    if (CON && esc_role == 2 && have_frames) {
-      // Back to the lean kernel: with Sim::reset (the environment starts over at its home pose), or -- RunOp::esc_leave_quiet -- after
-      // two contact-resolving launches in a row without a contact.  The default keeps an environment that has touched something on
-      // the contact-resolving kernel until its reset: a contact that begins AND ends inside one lean launch is the one thing the lean
-      // launch's end-of-launch check cannot see, and an arm that has just bounced off the floor is the likeliest to do it again.
-      if (esc_contact) { r.flags |= kContactResolved; r.flags &= ~kEscQuiet; }
-      else if (op.do_reset) { esc_leave = true; r.flags &= ~kEscQuiet; }
-      else if (op.esc_leave_quiet) {
-        if (r.flags & kEscQuiet) { esc_leave = true; r.flags &= ~kEscQuiet; }
-        else r.flags |= kEscQuiet;
-      }
-    }
+    // (per-environment escalation, the contact-resolving launch: whether the environment goes BACK to the lean launch is settled after
+    // the end-of-launch check below)
+    if (CON && esc_role == 2 && have_frames && esc_contact) r.flags |= kContactResolved;
     env_epilogue<T, ST, false>(P, op, m, e, r, st, have_frames, nsteps);
   }
   __syncthreads();
@@ -1447,8 +1444,18 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   if (do_check) {  // (wave-uniform)
     static_assert(sizeof(LinkRec) * T::NL >= sizeof(double) * 12 * T::NL * kTeams, "the links' world frames fit where their records were");
     const double q_final = live && t < T::NL ? st.q(t) : 0.0;
-    // (certifying check: lever x travel of the lane's joint, the last substep's included; 0: the check of the final position alone)
-    const double chk_mpath = op.check == 2 && live && t < T::NL ? lp.ctab.self_lever[t] * (chk_path + (chk_first ? 0.0 : fabs(q_final - chk_qlast))) : 0.0;
+    // (certifying check, check_team.h: how far the lane's joint has been from where the launch ends, at most -- and its "effective
+    // path" over the launch, twice the width of the interval it has been in less its net displacement: for every position q it took,
+    // |q - q_start| + |q - q_end| is at most that; a joint that moved one way: its displacement; one that chattered around a value, as the
+    // fingers' servo does for a dozen steps after a reset: twice the band, where the summed substep-to-substep travel is ten times that.
+    // 0: the check of the final position alone.  The contact-resolving launch asks the same questions with twice the travel: an
+    // environment goes back to the lean launch when its geoms are apart by a margin the lean launch's certificate will not fail on at once)
+    double chk_dend = 0.0, chk_psum = 0.0;
+    if (op.check == 2 && live && t < T::NL && !chk_first) {
+      const double lo = fmin(chk_qmin, q_final), hi = fmax(chk_qmax, q_final), sc = esc_role == 2 ? 2.0 : 1.0;
+      chk_dend = sc * fmax(hi - q_final, q_final - lo);
+      chk_psum = sc * (2.0 * (hi - lo) - fabs(q_final - chk_q0));
+    }
     __syncthreads();
     double* const sep = P.S + (size_t)Lay<T>::SEP * P.n + (live ? e : 0);
     // (an environment that carries the flag already has nothing to find out: its team sits the check out -- a pair that stays in
@@ -1456,14 +1463,20 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     // waits for its slowest wavefront)
     const bool flagged = ((uint32_t)__builtin_amdgcn_ds_bpermute((int)(threadIdx.x & 48u) << 2, (int)r.flags) & kContactUnresolved) != 0;
     // (with per-environment escalation the check is what sends an environment to the contact-resolving kernel: nobody sits it out)
-    const bool checked = live && (!flagged || esc_role == 1);
+    const bool checked = live && (!flagged || esc_role != 0);
     double* check_work = lds;
+    double* check_mv = lds + kLdsMain;
     if constexpr (CON) {
-      static_assert(sizeof(ContactArena<T>) >= sizeof(double) * check_work_doubles(T::NL), "the check's workspace fits the contact arena");
+      static_assert(sizeof(Arena) >= sizeof(double) * check_work_doubles(T::NL), "the check's workspace fits the contact arena");
+      static_assert(kLdsMain >= check_mv_doubles(T::NL), "... and its travel tables the teams' state block (written back by now)");
       check_work = reinterpret_cast<double*>(&larena[0]);
+      check_mv = lds;
+    } else if constexpr (DET) {
+      static_assert(kSelfF * kTeams + kSelfStage + kSelfCache + kSelfTag >= check_mv_doubles(T::NL), "the travel tables fit where the detection kept its frames");
+      check_mv = lself;  // (the detection of the substep loop is over)
     }
-    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, !CON, sep_in, sep, P.n, chk_pf,
-                                                 chk_mpath);
+    const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, chk_plane, sep_in, sep, P.n, chk_pf,
+                                                 chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif
@@ -1473,10 +1486,18 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
         atomicOr(reinterpret_cast<unsigned long long*>(lop.esc + ((P.n + 63) >> 6) + (e >> 6)), 1ull << (e & 63));
         atomicAdd(lop.esc_ctr + 2, 1u);
       }
+    } else if (esc_role == 2) {
+      // Back to the lean launch: an environment none of whose substeps met a contact AND whose geoms (and the floor) are proven apart
+      // by more than twice what this launch's joint travel could have closed -- the lean launch's certificate (the same test with the
+      // travel itself) then has room.  Whoever is in contact or near one stays: here every substep looks.  (Round 5 kept an
+      // environment here until its reset: 1146 of 4096 by step 1000 of the headline rollout, 87 % of their collision passes quiet.)
+      if (leader && have_frames && !esc_contact && !hit) esc_leave = true;
     } else if (leader && hit && !(r.flags & kContactUnresolved)) {
       P.flags[e] = r.flags | kContactUnresolved;
       if (op.write_obs && op.info) op.info[(size_t)e * 8 + 7] = 1;
     }
+  } else if (esc_role == 2 && leader && have_frames && !esc_contact) {
+    esc_leave = true;  // (no check in this launch: quiet is enough)
   }
   if (esc_role == 2) {
     if (esc_leave) atomicOr(reinterpret_cast<unsigned long long*>(lop.esc + 2 * ((P.n + 63) >> 6) + (e >> 6)), 1ull << (e & 63));

@@ -730,7 +730,9 @@ def test_stepping_kernels_leave_room_for_four_workgroups_per_cu():
     """A CU of the MI355X has 160 KB of LDS and four SIMDs; the stepping kernels run one wavefront per SIMD, so a batch of 4096
     environments is exactly one round of 1024 workgroups -- IF four of them fit a CU's LDS.  Round 5 found the lean detection kernel of
     the 9-joint robots at 41,144 bytes (184 too many): 768 + 256 workgroups in two rounds, step_until_convergence at half speed.  Every
-    k_run_team instantiation of the built library stays at or under 160 KB / 4."""
+    k_run_team instantiation of the built library stays at or under 160 KB / 4 -- except the contact-resolving kernel of per-environment
+    escalation (no free box, contacts resolved: <T, *, false, true, *>), which since round 6 keeps records for 64 contacts instead of
+    48 and runs one workgroup per escalated environment, never the whole batch: three per CU are what it gets."""
     import re
     import subprocess
     import tempfile
@@ -750,5 +752,12 @@ def test_stepping_kernels_leave_room_for_four_workgroups_per_cu():
         if "k_run_team" in f.get("name", ""):
             sizes[f["name"]] = int(f["group_segment_fixed_size"])
     assert len(sizes) >= 20, len(sizes)
-    too_big = {k: v for k, v in sizes.items() if v > 160 * 1024 // 4}
+    names = subprocess.check_output(["c++filt"] + list(sizes), text=True).split("\n")
+    too_big = {}
+    for (k, v), nm in zip(sizes.items(), names):
+        args_ = re.search(r"k_run_team(?:_occ2)?<rcsh::Topo<\d+, (?:true|false)>, (true|false), (true|false), (true|false), (true|false)>", nm)
+        assert args_, nm
+        boxless_contact = args_.group(2) == "false" and args_.group(3) == "true"
+        if v > (160 * 1024 // 3 if boxless_contact else 160 * 1024 // 4):
+            too_big[nm] = v
     assert not too_big, too_big

@@ -1,4 +1,6 @@
-"""dev tool: the 1000-step headline rollout with contacts resolved environment by environment, per-environment report.
+"""dev tool (GPU): the 1000-step headline rollout with contacts resolved environment by environment, every environment against its own
+oracle (and the oracle's twin nudged by 1e-13 rad: the rollout's own conditioning) -- tests/parity_util.run_headline_resolved_parity,
+per-environment report.
     python tools/headline_resolved_probe.py [n_envs] [n_steps] [seed]"""
 import os
 import sys
@@ -12,36 +14,16 @@ import parity_util as PU  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-venv = PU.make_vec_env(n, True)
-oenvs = PU.make_oracle_envs(n, True)
-cm = oenvs[0].sim.cm
-joints, grip = PU.synthetic_actions(n, steps, seed)
-venv.reset()
-for oe in oenvs:
-    oe.reset()
-first = np.full(n, -1)
-bad = np.full(n, -1)
-err = np.zeros(n)
-kinds = {}
-log = {}
-for t in range(steps):
-    venv.step({"joints": joints[t], "gripper": grip[t]})
-    q = venv.sim.qpos
-    now, ever = venv.sim.contact_escalated()
-    for e, oe in enumerate(oenvs):
-        oe.sim.s.d.pen_seen = 0.0
-        oe.step({"joints": joints[t, e], "gripper": grip[t, e]})
-        d = oe.sim.s.d
-        if d.pen_seen > 0 and first[e] < 0:
-            first[e] = t
-        if d.ncon:
-            kinds.setdefault(e, set()).update((cm.geom_names[d.contact[c].geom[0]] if d.contact[c].geom[0] < cm.ngeom else "box", cm.geom_names[d.contact[c].geom[1]]) for c in range(d.ncon))
-        dq = float(np.abs(q[e] - oe.sim.qpos[: q.shape[1]]).max())
-        err[e] = max(err[e], dq)
-        if dq > 1e-9 and bad[e] < 0:
-            bad[e] = t
-            log[e] = (t, dq, d.ncon, d.solver_niter, d.noslip_niter, bool(now[e]), float(d.pen_seen))
+rep = PU.run_headline_resolved_parity(n_envs=n, n_steps=steps, seed=seed)
+touched = rep["first_contact"] >= 0
 for e in range(n):
-    if first[e] >= 0 or bad[e] >= 0:
-        print(e, "first contact step", first[e], "first bad step", bad[e], "max err %.2e" % err[e], log.get(e), sorted(kinds.get(e, []))[:4])
-print("overall", err.max())
+    if rep["err_env"][e] > 1e-9 or rep["flag_env"][e] or rep["overflow_envs"][e] or rep["graze_steps"][e]:
+        print(f"env {e}: first contact step {rep['first_contact'][e]}, first step over 1e-9: {rep['first_bad'][e]}, max err {rep['err_env'][e]:.2e} "
+              f"(twins {rep['twin_err_env'][e]:.2e}, excess {rep['excess_env'][e]:.2e}), most contacts {rep['max_ncon'][e]}, grazes {rep['graze_steps'][e]}, "
+              f"flag mismatches {rep['flag_env'][e]}, overflow {bool(rep['overflow_envs'][e])}")
+plain = rep["twin_err_env"] < 1e-10
+print(f"{n} environments x {steps} steps, seed {seed}: {int(touched.sum())} ran into a contact ({int((rep['graze_steps'] > 0).sum())} with a contact that began and "
+      f"ended inside one env-step); within 1e-9 of the oracle at every step: {int((rep['err_env'] < 1e-9).sum())}; within max(1e-9, 100 x twins' distance): "
+      f"{int((rep['excess_env'] < 1e-9).sum())}; twins within 1e-10 of each other: {int(plain.sum())}, worst error among those {rep['err_env'][plain].max():.2e}; "
+      f"flag mismatches {int(rep['flag_env'].sum())}; overflow {int(rep['overflow_envs'].sum())}; on the contact-resolving launch at the end {int(rep['escalated_now'].sum())} "
+      f"(most at once {int(rep['escalated_per_step'].max())}); resolved == touched: {bool(np.array_equal(rep['resolved_ever'], rep['contact_steps'] > 0))}")
