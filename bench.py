@@ -154,6 +154,7 @@ def main() -> None:
                                                  "env-step, inside the timed region (SimCameraSet, render on demand); not the headline")
     ap.add_argument("--resolution", default="256x256", help="WxH of the depth frames (FR3SimplePickUpSimEnvCreator default 256x256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the figures taken after the clock stops (host API, round-4 configuration, BASELINE.md's 1000-step rollout, step_until_convergence): profiling runs")
     ap.add_argument("--clock-warmup-ms", type=float, default=25.0,
                     help="before the W warmup steps: this many milliseconds of the same env-step launches, then a reset -- the device needs "
                          "~12 ms of work to reach its operating clocks (profiles/README.md: a launch takes 128 us at first, 112.5 us from "
@@ -519,6 +520,7 @@ def main() -> None:
     # copies and a stream synchronise per step) -- after the clock stopped, reported next to `value`, never as it.
     value_host_api = None
     headline_cfg = (args.mode == "async" and args.task == "none" and args.robot == "fr3" and args.control == "joints" and not mixed and not cam_out and world == 1)
+    headline_cfg = headline_cfg and not args.no_extras
     if headline_cfg and rank == 0:
         a_host = (np.random.default_rng(7).random((32, n, env.dof)) * 2 - 1) * MAX_JOINT_MOV
         g_host = np.random.default_rng(8).random((32, n)).astype(np.float32)

@@ -56,7 +56,8 @@ constexpr int check_work_doubles(int) { return 4 * kCheckBox + 64 + 4 * 12; }  /
 // c, moved[l][c + 1] -- room of its own (`mv`), which the caller finds where its kernel has some to spare
 // -- plus the links' world frames at the launch's START position ([4][nl][12]) and the geoms' boxes in their links' frames ([kMaxCGeom][12])
 // (two such tables -- one per kind of margin, see unresolved_contact_check -- in single precision, rounded up) and the teams' second travel vector
-constexpr int check_mv_doubles(int nl) { return 4 * nl * (nl + 1) + 4 * 12 * nl + 12 * kMaxCGeom + 4 * 12; }
+// ... and the fingers' slide axes (world) with the travel of the gripper's opening / common shift: [4][12]
+constexpr int check_mv_doubles(int nl) { return 4 * nl * (nl + 1) + 4 * 12 * nl + 12 * kMaxCGeom + 4 * 12 + 4 * 12; }
 static_assert(4 * kCheckBox >= kSelfStage, "the hull stage overlays the world boxes");
 constexpr int kCheckPer = kMaxCheckPairs / kTeamLanes;
 constexpr int kCheckTrips = (3 * 152 + 63) / 64;  // vertex words per lane and hull (a hull has at most 152 vertices)
@@ -124,6 +125,61 @@ RCSH_D double obb_face_sep(const double* Ra, const double* ca, const double* ha,
   return sep;
 }
 
+// Two boxes on the two FINGERS of a gripper: only the fingers' slides move them relative to each other -- a pure translation, along
+// known axes, and the separation along a face normal n changes by exactly n . (that translation).  The largest, over the six face
+// normals, of (separation along n) - (the most the slides' travel can have taken from it): positive certifies the launch.  The travel
+// that counts is the OPENING's (q0 + q1 for mirrored axes): after a reset, and whenever the arm accelerates, two shut fingers shift
+// TOGETHER by 100-400 um a step against their soft coupling -- the pads stay 30 um apart, each finger's own travel is ten times that, and
+// charged with it half the batch failed the certificate for a dozen steps after every reset.
+// the six face-normal separations of two oriented boxes, and |n . e| for two vectors e (world) per normal
+RCSH_D void obb_face_seps6(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb, double* sep,
+                           const double* ep, const double* em, double* np6, double* nm6) {
+  double C[9], A[9], tv[3];
+  const double d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+  mulTv(Ra, d, tv);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      C[3 * i + j] = Ra[i] * Rb[j] + Ra[3 + i] * Rb[3 + j] + Ra[6 + i] * Rb[6 + j];
+      A[3 * i + j] = fabs(C[3 * i + j]) + 1e-9;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sep[i] = fabs(tv[i]) - (ha[i] + hb[0] * A[3 * i] + hb[1] * A[3 * i + 1] + hb[2] * A[3 * i + 2]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double tw = tv[0] * C[j] + tv[1] * C[3 + j] + tv[2] * C[6 + j];
+    sep[3 + j] = fabs(tw) - (hb[j] + ha[0] * A[j] + ha[1] * A[3 + j] + ha[2] * A[6 + j]);
+  }
+  if (ep) {
+    double u0[3], u1[3], w0[3], w1[3];
+    mulTv(Ra, ep, u0); mulTv(Ra, em, u1); mulTv(Rb, ep, w0); mulTv(Rb, em, w1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { np6[i] = fabs(u0[i]); nm6[i] = fabs(u1[i]); np6[3 + i] = fabs(w0[i]); nm6[3 + i] = fabs(w1[i]); }
+  }
+}
+// sl: the two fingers' slide axes (world, at the launch's end) a0 = sl[0..2], a1 = sl[4..6]; how far the opening o+ = q0 + q1 / the common
+// shift o- = q0 - q1 have been from their values at the launch's end: sl[3], sl[7]; their effective paths: sl[8], sl[9].  The geoms'
+// relative translation is o+ (a1 - a0) / 2 - o- (a1 + a0) / 2.  Certified: along one of the six face normals either the separation at
+// the launch's end exceeds what the slides can have taken from it, or the separations at its two ends together exceed their effective
+// path along it (touching at an end, to within `touch`, is no contact).  Double precision throughout and the slides' own axes, no lever:
+// fingers that open from pads touching EXACTLY -- every reset leaves them so -- end the first step with a gap that EQUALS the opening's
+// travel; a margin rounded up by one part in a million failed half the batch there.
+RCSH_D bool finger_boxes_certified(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb,
+                                   const double* Ra0, const double* ca0, const double* Rb0, const double* cb0, const double* sl, double touch) {
+  const double ep[3] = {0.5 * (sl[4] - sl[0]), 0.5 * (sl[5] - sl[1]), 0.5 * (sl[6] - sl[2])}, em[3] = {0.5 * (sl[4] + sl[0]), 0.5 * (sl[5] + sl[1]), 0.5 * (sl[6] + sl[2])};
+  double s1[6], s0[6], np6[6], nm6[6];
+  obb_face_seps6(Ra, ca, ha, Rb, cb, hb, s1, ep, em, np6, nm6);
+  obb_face_seps6(Ra0, ca0, ha, Rb0, cb0, hb, s0, nullptr, nullptr, nullptr, nullptr);
+  bool ok = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double mD = np6[k] * sl[3] + nm6[k] * sl[7], mP = np6[k] * sl[8] + nm6[k] * sl[9];
+    ok = ok || s1[k] - mD > -touch || (s0[k] > -touch && s1[k] > -touch && s0[k] + s1[k] > mP - 2.0 * touch);
+  }
+  return ok;
+}
+
 // A remembered direction's slot: [0] = (pair index + 1) + 1024 (g0 + 32 g1) -- zero: empty --, [1..3] the direction in the frame of
 // geom 0's link.  The geoms ride along so that the NEXT launch can ask for their records and vertices before it knows anything else.
 RCSH_D double check_slot_key(int pidx, int g0, int g1) { return (double)((pidx + 1) + 1024 * (g0 + 32 * g1)); }
@@ -139,8 +195,10 @@ struct CheckPrefetch {
   double gword;                       // this lane's word of the guessed pair's two ContactGeom records
   double va[kCheckTrips], vb[kCheckTrips];
   float lev[12];                      // CheckTable::lev[j][t]: what a radian / metre of joint j does to a point of a geom on the lane's link
+  float rem[kCheckPer], remL;         // what is left of the lane's pairs' gaps / of its link's height above the floor (CheckTable::slack)
 };
-RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double sep_in, bool live, CheckPrefetch& pf) {
+// slack_env: the environment's record of CheckTable::slack (null: none kept -- every pair is looked at)
+RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double sep_in, bool live, CheckPrefetch& pf, const float* slack_env) {
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1);
   const int npair = ck.npair, ngeom = ck.ngeom;
 #pragma unroll
@@ -158,6 +216,9 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
   }
 #pragma unroll
   for (int j = 0; j < 12; ++j) pf.lev[j] = ck.lev && t < 12 ? ck.lev[12 * j + t] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < kCheckPer; ++j) pf.rem[j] = slack_env && t + kTeamLanes * j < npair ? slack_env[t + kTeamLanes * j] : 0.0f;
+  pf.remL = slack_env ? slack_env[kSlackLink + t] : 0.0f;
   // the guess: slot 0's key of the first live team, else its slot 1's (lanes 0 and 4 of the team hold them)
   const uint64_t lv = __ballot(live && t == 0);
   pf.guess_key = 0; pf.guess_g0 = 0; pf.guess_g1 = 0;
@@ -190,12 +251,14 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 // `frames`: LDS room for [4][NL][12] doubles (the link records' memory: the check is their last reader); `work`: LDS room for
 // check_work_doubles(NL); `mv`: for check_mv_doubles(NL); dend / psum: how far the lane's joint has been from where the launch ended, at
 // most / its effective path over the launch (see below; 0: it did not move -- or the check of the final position alone is asked for)
-// and q0 its position when the launch began.  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
+// and q0 its position when the launch began.  slack_env: the environment's record of CheckTable::slack (null: none), use_slack: the
+// gaps it holds are valid lower bounds for the position the launch began on (see "the slack" below), keep_slack: the pairs' gaps
+// this check ends with are written back (the lean launch; the contact-resolving launch keeps them itself).  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
 // Every lane of the wavefront calls this; returns, on every lane of a team, whether the team's environment is in contact.
 template <class T, class CollT>
 RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& tab, const CollT& lc, const LinkRec* links, double* frames,
                                      double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf,
-                                     double dend, double psum, double* mv, double q0) {
+                                     double dend, double psum, double* mv, double q0, float* slack_env, bool use_slack, bool keep_slack) {
   constexpr int NL = T::NL;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const bool valid = t < NL;
@@ -204,36 +267,25 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #ifdef RCSH_CHECK_DEBUG
   unsigned long long chk_t0_ = __builtin_readcyclecounter();
 #endif
-  // ---- world frames of the links at the final qpos (what the next launch's first position stage will see)
-  double R[9], p[3], R0[9], p0[3];
-  {
-    KinK kk;
-    kk.load(links[tl]);
-    link_local_frame(kk, q, R, p);
-    scan_frames<T>(R, p);
-    // ... and where the launch began (certifying mode: a gap at BOTH ends of the launch's path certifies more than one at its end)
-    link_local_frame(kk, q0, R0, p0);
-    scan_frames<T>(R0, p0);
-  }
-  CHK_MARK(0)
-  __syncthreads();  // (the link records have been read: their memory becomes the frames')
-  double* F = frames + 12 * NL * team;
   double* wbox = work + kCheckBox * team;
   // (the remembered directions stay in the lanes that loaded them -- lane t of a team holds word t of its four slots; reads and updates go
   // across the team's lanes: no LDS, which the lean detection kernel has none of to spare)
   double sepw = sep_in;
   const int tbase = lane & ~(kTeamLanes - 1);
   double* gstage = work + 4 * kCheckBox;
-  double* travel = gstage + 64 + 12 * team;  // lever x travel of the team's joints over the launch (certifying mode; zeros otherwise)
+  double* travel = gstage + 64 + 12 * team;  // travel of the team's joints over the launch (certifying mode; zeros otherwise)
   double* stage = work;  // (overlays the world boxes once the broad phase is through)
-  if (valid) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) F[12 * t + k] = R[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) F[12 * t + 9 + k] = p[k];
-  }
   double* travelP = mv + 4 * NL * (NL + 1) + 4 * 12 * NL + 12 * kMaxCGeom + 12 * team;
-  if (t < 12) { travel[t] = valid ? dend : 0.0; travelP[t] = valid ? psum : 0.0; }
+  // (the two fingers' lanes carry the travel of the gripper's opening q0 + q1 / of the fingers' common shift q0 - q1 -- sim_kernels.h --:
+  // either finger's own travel is at most half their sum)
+  double dend_j = dend, psum_j = psum;
+  if (T::GRIP) {
+    const double da = lane_get(dend, tbase + T::NARM), db = lane_get(dend, tbase + T::NARM + 1);
+    const double pa_ = lane_get(psum, tbase + T::NARM), pb_ = lane_get(psum, tbase + T::NARM + 1);
+    if (t == T::NARM || t == T::NARM + 1) { dend_j = 0.5 * (da + db); psum_j = 0.5 * (pa_ + pb_); }
+  }
+  if (t < 12) { travel[t] = valid ? dend_j : 0.0; travelP[t] = valid ? psum_j : 0.0; }
+  double* slides = mv + 4 * NL * (NL + 1) + 4 * 12 * NL + 12 * kMaxCGeom + 4 * 12 + 12 * team;  // finger_boxes_certified's `sl`
   __syncthreads();
   // Certifying mode (RunOp::check 2; per-environment escalation): a pair counts as apart only if it is PROVEN apart by more than
   // its margin -- the most the joints between its two links can have moved the two geoms relative to each other, the sum over those
@@ -257,10 +309,108 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   double* F0 = mv + 4 * NL * (NL + 1) + 12 * NL * team;   // the links' world frames where the launch began
   double* gbox = mv + 4 * NL * (NL + 1) + 4 * 12 * NL;    // the geoms' boxes in their links' frames (one copy: the teams share the model)
   if (valid) {
+    double x[NL], y[NL];
+    const uint32_t am = anc_mask<T>(t);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) F0[12 * t + k] = R0[k];
+    for (int j = 0; j < NL; ++j) {
+      x[j] = (am >> j) & 1u ? (double)pf.lev[j] * travel[j] : 0.0;
+      y[j] = (am >> j) & 1u ? (double)pf.lev[j] * travelP[j] : 0.0;
+    }
+    // (the arm is a chain: the joints of l's chain that are not on c's are those above c -- running sums from the chain's end; only
+    // the fingers' own entries need the masks)
+    double m = 0.0, mp_ = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) F0[12 * t + 9 + k] = p0[k];
+    for (int c = NL - 1; c >= -1; --c) {
+      if (c >= T::NARM) {
+        const uint32_t jm = am & ~anc_mask<T>(c);
+        double m2 = 0.0, mp2 = 0.0;
+#pragma unroll
+        for (int j = T::NARM; j < NL; ++j) { m2 += (jm >> j) & 1u ? x[j] : 0.0; mp2 += (jm >> j) & 1u ? y[j] : 0.0; }
+        mvD[t * (NL + 1) + c + 1] = m2 > 0.0 ? (float)m2 * 1.000001f + 1e-12f : 0.0f;
+        mvP[t * (NL + 1) + c + 1] = mp2 > 0.0 ? (float)mp2 * 1.000001f + 1e-12f : 0.0f;
+        if (c == T::NARM) {  // (from here down every finger joint of the lane's chain counts)
+#pragma unroll
+          for (int j = T::NARM; j < NL; ++j) { m += x[j]; mp_ += y[j]; }
+        }
+        continue;
+      }
+      // (single precision, rounded up: a margin errs on the large side)
+      mvD[t * (NL + 1) + c + 1] = m > 0.0 ? (float)m * 1.000001f + 1e-12f : 0.0f;
+      mvP[t * (NL + 1) + c + 1] = mp_ > 0.0 ? (float)mp_ * 1.000001f + 1e-12f : 0.0f;
+      if (c >= 0) { m += x[c]; mp_ += y[c]; }
+    }
+  }
+  __syncthreads();
+  double mj[kCheckPer], mjP[kCheckPer];  // the margins of the lane's pairs (of dend, of psum)
+#pragma unroll
+  for (int j = 0; j < kCheckPer; ++j) {
+    const int g0 = pf.ent[j].geoms & 0xff, g1 = (pf.ent[j].geoms >> 8) & 0xff, cc = (pf.ent[j].geoms >> 16) & 0xff;
+    const int la = ck.glink[g0], lb = ck.glink[g1];
+    mj[j] = (double)(la >= 0 ? mvD[la * (NL + 1) + cc] : 0.0f) + (double)(lb >= 0 ? mvD[lb * (NL + 1) + cc] : 0.0f);
+    mjP[j] = (double)(la >= 0 ? mvP[la * (NL + 1) + cc] : 0.0f) + (double)(lb >= 0 ? mvP[lb * (NL + 1) + cc] : 0.0f);
+  }
+  const double mfl = mvD[tl * (NL + 1)], mflP = mvP[tl * (NL + 1)];
+  // ---- THE SLACK.  A pair proven g apart at the position the launch BEGAN on cannot have touched during it unless some position on
+  // the way is g from that first one -- |q - q_start| is at most the joints' effective path: g > the margin of psum certifies the pair
+  // for this launch with no geometry at all, and g less that margin is a lower bound of its gap where the launch ended, the next
+  // launch's g (CheckTable::slack, per environment; the contact-resolving launch keeps the same record substep by substep,
+  // contact_team.h: contact_collide).  Only the pairs whose slack is used up are LOOKED at -- link frames, boxes, support queries -- and
+  // come back with a fresh gap; in a rollout that touches nothing that is a pair every few launches, and most launches end right here.
+  // (Round 5 looked at every pair in every launch: 11.5 us of 121; the certifying tests on top of that: 25 of 137.)
+  float rem[kCheckPer], remL = use_slack ? pf.remL : 0.0f;
+  uint32_t due = 0;
+#pragma unroll
+  for (int j = 0; j < kCheckPer; ++j) {
+    rem[j] = use_slack ? pf.rem[j] : 0.0f;
+    const bool d = live && t + kTeamLanes * j < npair && !((double)rem[j] > mjP[j]);
+    due |= d ? 1u << j : 0u;
+    if (!d && mjP[j] > 0.0) rem[j] -= (float)mjP[j] * 1.00001f + 2.5e-7f;  // (rounded up, and by more than the subtraction's own rounding)
+  }
+  const bool floor_on = check_plane && ck.plane_points && valid && live;
+  const bool dueL = floor_on && !((double)remL > mflP);
+  if (floor_on && !dueL && mflP > 0.0) remL -= (float)mflP * 1.00001f + 2.5e-7f;
+#ifdef RCSH_CHECK_DEBUG
+  atomicAdd(&g_chk_dbg[44], __popc(due) + (dueL ? 1 : 0));
+  if (lane == 0) { atomicAdd(&g_chk_dbg[43], 1); if (__ballot(due != 0 || dueL) == 0) atomicAdd(&g_chk_dbg[42], 1); }
+  if (dueL) atomicAdd(&g_chk_dbg[45], 1);
+#endif
+  if (__ballot(due != 0 || dueL) == 0) {  // nobody of the wavefront's four environments has anything to look at
+    if (keep_slack && slack_env && live) {
+#pragma unroll
+      for (int j = 0; j < kCheckPer; ++j)
+        if (t + kTeamLanes * j < npair) slack_env[t + kTeamLanes * j] = rem[j];
+      if (valid) slack_env[kSlackLink + t] = remL;
+    }
+    return false;
+  }
+  // ---- world frames of the links at the final qpos (what the next launch's first position stage will see)
+  double R[9], p[3], R0[9], p0[3], axw[3];
+  bool is_slide = false;
+  {
+    KinK kk;
+    kk.load(links[tl]);
+    link_local_frame(kk, q, R, p);
+    scan_frames<T>(R, p);
+    // ... and where the launch began (certifying mode: a gap at BOTH ends of the launch's path certifies more than one at its end)
+    link_local_frame(kk, q0, R0, p0);
+    scan_frames<T>(R0, p0);
+    mulmv(R, kk.axis, axw);  // (a finger's lane: its slide's axis, world frame, at the launch's end)
+    is_slide = kk.jtype == kSlide;
+  }
+  CHK_MARK(0)
+  __syncthreads();  // (the link records have been read: their memory becomes the frames')
+  double* F = frames + 12 * NL * team;
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { F[12 * t + k] = R[k]; F0[12 * t + k] = R0[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { F[12 * t + 9 + k] = p[k]; F0[12 * t + 9 + k] = p0[k]; }
+  }
+  if (T::GRIP && (t == T::NARM || t == T::NARM + 1)) {
+    double* sl = slides + 4 * (t - T::NARM);
+    sl[0] = axw[0]; sl[1] = axw[1]; sl[2] = axw[2];
+    sl[3] = is_slide ? dend : INFINITY;  // (a hinged finger: no such certificate)
+    slides[8 + t - T::NARM] = is_slide ? psum : INFINITY;
   }
   if (team == 0) {
 #pragma unroll
@@ -270,25 +420,6 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #pragma unroll
         for (int k = 0; k < 12; ++k) gbox[12 * g + k] = pf.grec[u][k];
       }
-    }
-  }
-  if (valid) {
-    double x[NL], y[NL];
-    const uint32_t am = anc_mask<T>(t);
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      x[j] = (am >> j) & 1u ? (double)pf.lev[j] * travel[j] : 0.0;
-      y[j] = (am >> j) & 1u ? (double)pf.lev[j] * travelP[j] : 0.0;
-    }
-#pragma unroll
-    for (int c = -1; c < NL; ++c) {
-      const uint32_t jm = am & ~anc_mask<T>(c);
-      double m = 0.0, mp_ = 0.0;
-#pragma unroll
-      for (int j = 0; j < NL; ++j) { m += (jm >> j) & 1u ? x[j] : 0.0; mp_ += (jm >> j) & 1u ? y[j] : 0.0; }
-      // (single precision, rounded up: a margin errs on the large side)
-      mvD[t * (NL + 1) + c + 1] = m > 0.0 ? (float)m * 1.000001f + 1e-12f : 0.0f;
-      mvP[t * (NL + 1) + c + 1] = mp_ > 0.0 ? (float)mp_ * 1.000001f + 1e-12f : 0.0f;
     }
   }
   __syncthreads();
@@ -324,25 +455,27 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   CHK_MARK(1)
   bool mine = false;
   // ---- the floor against the sample points of the link's collision geoms (as the DET launches test it)
-  if (check_plane && ck.plane_points && valid && live) {
+  if (dueL) {
     const double* nrm = lc.plane_n;
     const double a[3] = {R[0] * nrm[0] + R[3] * nrm[1] + R[6] * nrm[2], R[1] * nrm[0] + R[4] * nrm[1] + R[7] * nrm[2],
                          R[2] * nrm[0] + R[5] * nrm[1] + R[8] * nrm[2]};
     const double b = dot3(nrm, p) - lc.plane_d;
     const double* sph = lc.link_sphere[t];
-    const double mfl = mvD[t * (NL + 1)], mflP = mvP[t * (NL + 1)];
     const double thr = mfl - kCheckTouch;  // (a contact is a penetration by more than kCheckTouch; nothing moved: the exact test)
     const double a0[3] = {R0[0] * nrm[0] + R0[3] * nrm[1] + R0[6] * nrm[2], R0[1] * nrm[0] + R0[4] * nrm[1] + R0[7] * nrm[2],
                           R0[2] * nrm[0] + R0[5] * nrm[1] + R0[8] * nrm[2]};
     const double b0 = dot3(nrm, p0) - lc.plane_d;
-    if (b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3] < thr) {
+    double low = b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3];  // (the lowest any of the link's points can be)
+    if (low < thr) {
+      low = INFINITY;
       for (int k = lc.link_adr[t]; k < lc.link_adr[t + 1]; ++k) {
         const double* v = lc.xyzr + 4 * (size_t)k;
         const double h1 = b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3];
+        low = fmin(low, h1);
         if (h1 < thr) {
           // (the point's height where the launch began: the path-length form)
           const double h0 = b0 + a0[0] * v[0] + a0[1] * v[1] + a0[2] * v[2] - v[3];
-          if (mfl > 0.0 && h1 > 0.0 && h0 > 0.0 && h0 + h1 > mflP) continue;
+          if (mfl > 0.0 && h1 > -kCheckTouch && h0 > -kCheckTouch && h0 + h1 > mflP - 2.0 * kCheckTouch) continue;
           mine = true;
 #ifdef RCSH_CHECK_DEBUG
           atomicAdd(&g_chk_dbg[0], 1);
@@ -350,18 +483,11 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         }
       }
     }
+    remL = low < 1e30 ? fmaxf((float)low * 0.999999f - 1e-6f, 0.0f) : 1e30f;  // (a link without sample points: nothing to touch the floor with)
   }
   CHK_MARK(2)
   // ---- geom pairs: bounding spheres (bit j of smask: pair t + 16 j survived), then -- one pair per lane and round -- the boxes
   uint32_t smask = 0;
-  double mj[kCheckPer], mjP[kCheckPer];  // the margins of the lane's pairs (of dend, of psum)
-#pragma unroll
-  for (int j = 0; j < kCheckPer; ++j) {
-    const int g0 = pf.ent[j].geoms & 0xff, g1 = (pf.ent[j].geoms >> 8) & 0xff, cc = (pf.ent[j].geoms >> 16) & 0xff;
-    const int la = ck.glink[g0], lb = ck.glink[g1];
-    mj[j] = (double)(la >= 0 ? mvD[la * (NL + 1) + cc] : 0.0f) + (double)(lb >= 0 ? mvD[lb * (NL + 1) + cc] : 0.0f);
-    mjP[j] = (double)(la >= 0 ? mvP[la * (NL + 1) + cc] : 0.0f) + (double)(lb >= 0 ? mvP[lb * (NL + 1) + cc] : 0.0f);
-  }
   if (live && !(ck.pad & 4)) {
     // (all the centres first, then the arithmetic: read pair by pair the wavefront would wait for LDS a dozen times)
     double ca[kCheckPer][3], cb[kCheckPer][3];
@@ -376,8 +502,10 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     for (int j = 0; j < kCheckPer; ++j) {
       const int i = t + kTeamLanes * j;
       const double d[3] = {ca[j][0] - cb[j][0], ca[j][1] - cb[j][1], ca[j][2] - cb[j][2]};
-      const double rs = pf.ent[j].rsum + mj[j];
-      smask |= i < npair && dot3(d, d) <= rs * rs ? 1u << j : 0u;
+      const double rs = pf.ent[j].rsum + mj[j], d2 = dot3(d, d);
+      const bool dj = (due >> j) & 1u;
+      smask |= dj && i < npair && d2 <= rs * rs ? 1u << j : 0u;
+      if (dj && d2 > rs * rs) rem[j] = fmaxf((float)(sqrt(d2) - (double)pf.ent[j].rsum) * 0.999999f - 1e-6f, 0.0f);  // (settled by the spheres: their gap)
     }
   }
 #ifdef RCSH_CHECK_DEBUG
@@ -402,20 +530,33 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #pragma unroll
       for (int k = 0; k < 9; ++k) { Ra[k] = wbox[12 * g0 + 3 + k]; Rb[k] = wbox[12 * g1 + 3 + k]; }
       bool settled;
+      double sep_end = 0.0;
+      const bool finger_pair = T::GRIP && ck.glink[g0] >= T::NARM && ck.glink[g1] >= T::NARM;  // (only the two slides between them)
       if (mm > 0.0) {
         const double sep1 = obb_face_sep(Ra, ca, ha, Rb, cb, hb);
+        sep_end = sep1;
         settled = sep1 > mm - kCheckTouch;
-        if (!settled && sep1 > 0.0) {
+        if (!settled && (sep1 > -kCheckTouch || finger_pair)) {
           // the same boxes where the launch began (their links' frames then, the boxes in their links' frames)
           const int la = ck.glink[g0], lb = ck.glink[g1];
           double Ra0[9], Rb0[9], ca0[3], cb0[3];
           self_box_world(F0, la, gbox + 12 * g0, gbox + 12 * g0 + 3, ca0, Ra0);
           self_box_world(F0, lb, gbox + 12 * g1, gbox + 12 * g1 + 3, cb0, Rb0);
-          const double sep0 = obb_face_sep(Ra0, ca0, ha, Rb0, cb0, hb);
-          settled = sep0 > 0.0 && sep0 + sep1 > mmP;
+          if (finger_pair) {
+            settled = finger_boxes_certified(Ra, ca, ha, Rb, cb, hb, Ra0, ca0, Rb0, cb0, slides, kCheckTouch);
+          } else {
+            const double sep0 = obb_face_sep(Ra0, ca0, ha, Rb0, cb0, hb);
+            settled = sep0 > -kCheckTouch && sep0 + sep1 > mmP - 2.0 * kCheckTouch;
+          }
         }
       } else {
         settled = obb_apart_or_touching(Ra, ca, ha, Rb, cb, hb, kCheckTouch, 0.0);
+      }
+      {
+        // (settled: what the boxes prove of the pair's gap at the launch's end is its new slack)
+        const float nr = settled ? fmaxf((float)sep_end * 0.999999f - 1e-6f, 0.0f) : 0.0f;
+#pragma unroll
+        for (int k = 0; k < kCheckPer; ++k) rem[k] = k == j ? nr : rem[k];
       }
       if (!settled) {
         cmask |= 1u << j;
@@ -470,6 +611,8 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #endif
     }
     stage_fence();  // (LDS traffic of one wavefront is ordered)
+    bool apart_out = false;
+    double gcert_out = 0.0;
     if (take) {
       const ContactGeom& a = *reinterpret_cast<const ContactGeom*>(gstage);
       const ContactGeom& b = *reinterpret_cast<const ContactGeom*>(gstage + 32);
@@ -494,6 +637,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         if (w_ >= 0 && w_ < 4) sepw = w_ == 0 ? key : (w_ == 1 ? dl_[0] : (w_ == 2 ? dl_[1] : dl_[2]));
       };
       bool apart = false;
+      double gcert = 0.0;  // the gap the pair is found apart by (its new slack)
       double LR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       if (a.link >= 0) {
 #pragma unroll
@@ -503,10 +647,20 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
       // with the gap the same direction proves where the launch began (the path-length form; one more support query, at the start frames)
       double dbg_g1 = -1.0, dbg_g0 = -1.0;
       (void)dbg_g1; (void)dbg_g0;
+      const bool finger_pair = T::GRIP && a.link >= T::NARM && b.link >= T::NARM;  // (only the two slides between the geoms: a translation)
       auto certified = [&](double g1, const double* dl) -> bool {
         dbg_g1 = g1;
-        if (g1 > mteam - kCheckTouch) return true;
-        if (!(g1 > 0.0)) return false;
+        double mD = mteam, mP = mteamP;
+        if (finger_pair) {
+          // the gap along a direction changes by exactly that direction's component of the slides' translation (finger_boxes_certified)
+          double dwn[3];
+          mulmv(LR, dl, dwn);
+          const double np_ = fabs(0.5 * (dot3(dwn, slides + 4) - dot3(dwn, slides))), nm_ = fabs(0.5 * (dot3(dwn, slides + 4) + dot3(dwn, slides)));
+          const double mDd = np_ * slides[3] + nm_ * slides[7], mPd = np_ * slides[8] + nm_ * slides[9];
+          if (mDd < mD) { mD = mDd; mP = mPd; }  // (a hinged finger: infinite -- the levers' margins stay)
+        }
+        if (g1 > mD - kCheckTouch) return true;
+        if (!(g1 > -kCheckTouch)) return false;
         double Ra0[9], pa0[3], Rb0[9], pb0[3], LR0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, dw0[3];
         self_geom_world(a, F0, Ra0, pa0);
         self_geom_world(b, F0, Rb0, pb0);
@@ -520,7 +674,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         mpr_support<true>(A0, B0, dw0, s0);
         const double g0 = -dot3(s0.v, dw0);
         dbg_g0 = g0;
-        return g0 > 0.0 && g0 + g1 > mteamP;
+        return g0 > -kCheckTouch && g0 + g1 > mP - 2.0 * kCheckTouch;
       };
       double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};  // (a point of A - B)
       if (s_hold >= 0) {
@@ -532,6 +686,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         // the support of A - B along the remembered direction is still negative: apart (certifying mode: by enough)
         const double g1 = -dot3(s.v, dw);
         apart = mteam > 0.0 ? certified(g1, dl) : g1 > 0.0;
+        gcert = g1;
         x0[0] = s.v[0]; x0[1] = s.v[1]; x0[2] = s.v[2];
       }
 #ifndef RCSH_NO_GILBERT
@@ -540,10 +695,11 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         // keeps its verdicts far from the nanometre the check calls contact.  Certifying mode: a few more, after the first proof, for a
         // direction with a larger gap -- it is the gap that certifies, and the direction is remembered
         double dg[3], gap = 0.0;
-        if (gilbert_apart<true>(A, B, x0, mteam > 0.0 ? 8 : 5, 1e-5, dg, &gap, mteam > 0.0 ? 3 : 0)) {
+        if (gilbert_apart<true>(A, B, x0, mteam > 0.0 ? 6 : 5, 1e-5, dg, &gap, mteam > 0.0 ? 1 : 0)) {
           double dl[3];
           mulTv(LR, dg, dl);
           apart = mteam > 0.0 ? certified(gap, dl) : true;
+          gcert = gap;
           stage_fence();
           slot_store(dl);
         }
@@ -578,14 +734,36 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         if (t == 0) { atomicAdd(&g_chk_dbg[38], 1); atomicAdd(&g_chk_dbg[s_hold >= 0 ? 41 : 40], 1); }  // full refinements: [40] no slot held the pair, [41] its direction failed
 #endif
       }
+      apart_out = apart;
+      gcert_out = gcert;
+    }
+    {
+      // the pair's new slack, on the lane that holds the pair (the team's lanes agree on it)
+      const float nr = apart_out ? fmaxf((float)gcert_out * 0.999999f - 1e-6f, 0.0f) : 0.0f;
+      if (holder) {
+#pragma unroll
+        for (int k = 0; k < kCheckPer; ++k) rem[k] = k == u ? nr : rem[k];
+      }
     }
     stage_fence();
   }
   CHK_MARK(5)
   __syncthreads();
   if (t < kCheckSep && live) sep[(size_t)t * n_env] = sepw;
+  const bool hit = team_ballot(mine) != 0;
+  // the slack goes back -- unless the environment is flagged: its launch is redone from the position it BEGAN on, which is what the
+  // record as it stands describes.  (The contact-resolving launch keeps the pairs' gaps itself, substep by substep; it leaves the
+  // links' heights, which only this check reads, as it found them at its end.)
+  if (slack_env && live && !hit) {
+    if (keep_slack) {
+#pragma unroll
+      for (int j = 0; j < kCheckPer; ++j)
+        if (t + kTeamLanes * j < npair) slack_env[t + kTeamLanes * j] = rem[j];
+    }
+    if (valid && check_plane) slack_env[kSlackLink + t] = remL;
+  }
   CHK_MARK(6)
-  return team_ballot(mine) != 0;
+  return hit;
 }
 
 #endif  // __HIP__

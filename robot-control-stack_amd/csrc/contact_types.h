@@ -60,7 +60,8 @@ struct CheckGeom {
   double c[3], rot[9];
 };
 constexpr int kSlackFloor = kMaxCheckPairs + 24;  // ... then the geoms' remaining heights above the floor
-constexpr int kSlackStride = kSlackFloor + 32;    // floats per environment: the pairs' remaining gaps, then the joints seen last (12 doubles), ...
+constexpr int kSlackLink = kSlackFloor + 32;      // ... then, per LINK, what is left of its sample points' height above the floor (the lean launch's check)
+constexpr int kSlackStride = kSlackLink + 16;     // floats per environment: the pairs' remaining gaps, then the joints seen last (12 doubles), ...
 static_assert(kMaxCGeom <= 32, "a float per collision geom");
 struct CheckTable {
   const CheckEntry* ent;

@@ -756,6 +756,9 @@ int scatter_host(rcsh_sim* s, int field0, int width, const double* src, const ui
   int rc = upload_mask(s, mask, &dm);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(s->d_stage, src, sizeof(double) * s->n * width, hipMemcpyHostToDevice, s->stream));
+  // (a write into the state from outside the stepping launches -- set_joints_hard, mjData.qpos = ... -- may move the robot: the gaps the
+  // contact check and the contact phase remember for the old position are void; zero = "look at everything")
+  if (s->d_slack) HIP_TRY(hipMemsetAsync(s->d_slack, 0, sizeof(float) * (size_t)kSlackStride * s->n, s->stream));
   hipLaunchKernelGGL(k_scatter, dim3(grid_for(s->n)), dim3(kBlock), 0, s->stream, s->S, s->n, field0, width, s->d_stage, dm);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1455,6 +1458,18 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
   REQUIRE_SIM(s);
   if (!o) return fail(RCSH_ERR_ARG, "null contact options");
   if (s->box.present) return fail(RCSH_ERR_STATE, "this scene has a free box: its description (rcsh_sim_add_free_box) carries the contact options");
+  // (whenever the option is switched -- off, on, or between its forms -- the escalation masks, their counters and the phantom box's warm
+  // start begin empty: stale bits of a rollout under another option would send environments to a launch that no longer knows them;
+  // advisor, round 5)
+  if (s->d_esc) {
+    const size_t nw = ((size_t)s->n + 63) / 64;
+    HIP_TRY(hipMemsetAsync(s->d_esc, 0, sizeof(uint64_t) * 3 * nw, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_esc_ctr, 0, sizeof(uint32_t) * 4, s->stream));
+    int f_box = -1;
+    dispatch_topology(s->narm, s->grip, [&](auto topo) { f_box = (int)Lay<decltype(topo)>::BOX; });
+    if (f_box >= 0) HIP_TRY(hipMemsetAsync(s->S + (size_t)(f_box + kBoxX) * s->n, 0, sizeof(double) * (size_t)(kBoxState - kBoxX) * s->n, s->stream));
+    if (s->d_slack) HIP_TRY(hipMemsetAsync(s->d_slack, 0, sizeof(float) * (size_t)kSlackStride * s->n, s->stream));
+  }
   if (!o->resolve_robot_contacts) { s->box = BoxCfg{}; s->esc_mode = false; return RCSH_OK; }
   if (!(s->narm == 7 && s->grip && !s->dm.has_friction)) return fail(RCSH_ERR_MODEL, "contacts of the robot's geoms are resolved for the FR3 + hand archetype (no dry joint friction)");
   if (!o->cone_elliptic) return fail(RCSH_ERR_MODEL, "contacts use elliptic friction cones (option cone=\"elliptic\")");
@@ -1605,6 +1620,7 @@ int rcsh_sim_set_state(rcsh_sim* s, const void* blob) {
   HIP_TRY(hipSetDevice(s->device));
   const char* b = static_cast<const char*>(blob);
   const size_t ns = sizeof(double) * (size_t)s->n * s->nfields, nf = sizeof(uint32_t) * (size_t)s->n, nc = sizeof(int32_t) * (size_t)s->n;
+  if (s->d_slack) HIP_TRY(hipMemsetAsync(s->d_slack, 0, sizeof(float) * (size_t)kSlackStride * s->n, s->stream));  // (see scatter_host)
   HIP_TRY(hipMemcpyAsync(s->S, b, ns, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->flags, b + ns, nf, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipMemcpyAsync(s->conv, b + ns + nf, nc, hipMemcpyHostToDevice, s->stream));

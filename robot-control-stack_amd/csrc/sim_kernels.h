@@ -1122,8 +1122,12 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     if (op.check == 2 && t < T::NL) {
       const double qn = st.q(t);
       chk_q0 = chk_first ? qn : chk_q0;
-      chk_qmin = chk_first ? qn : fmin(chk_qmin, qn);
-      chk_qmax = chk_first ? qn : fmax(chk_qmax, qn);
+      // (the two fingers' lanes follow the gripper's opening q0 + q1 and the fingers' common shift q0 - q1 instead of their own joints:
+      // shut fingers shift together by far more than the gap between their pads changes -- check_team.h: obb_face_sep_slides)
+      double wn = qn;
+      if (T::GRIP && t >= T::NARM) wn = t == T::NARM ? st.q(T::NARM) + st.q(T::NARM + 1) : st.q(T::NARM) - st.q(T::NARM + 1);
+      chk_qmin = chk_first ? wn : fmin(chk_qmin, wn);
+      chk_qmax = chk_first ? wn : fmax(chk_qmax, wn);
       chk_first = false;
     }
     if (leader && stepping && has_cb && r.time - cb_due > robot_period) {
@@ -1370,7 +1374,11 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   const bool chk_plane = !CON || esc_role == 2;
   const bool do_check = op.check && (lp.chk.npair > 0 || (chk_plane && lp.chk.plane_points));  // (wave-uniform)
   CheckPrefetch chk_pf;
-  if (do_check) check_prefetch(lp.chk, lp.ctab, sep_in, live, chk_pf);
+  // (the environment's record of remaining gaps -- check_team.h: "the slack" --: valid for the position this launch began on unless a
+  // reset moved the robot; a step that is redone started from the copy's position, which is what the record still describes)
+  float* const chk_slack = lp.chk.slack && live ? lp.chk.slack + (size_t)e * kSlackStride : nullptr;
+  const bool chk_use_slack = esc_role == 1 && !op.do_reset && op.check == 2;
+  if (do_check) check_prefetch(lp.chk, lp.ctab, sep_in, live, chk_pf, chk_use_slack ? chk_slack : nullptr);
   {
     // per-component stores of the epilogue, one per lane instead of a dozen from the leader: the site link's frame of the last
     // position stage, the joints of the observation row
@@ -1448,13 +1456,25 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     // path" over the launch, twice the width of the interval it has been in less its net displacement: for every position q it took,
     // |q - q_start| + |q - q_end| is at most that; a joint that moved one way: its displacement; one that chattered around a value, as the
     // fingers' servo does for a dozen steps after a reset: twice the band, where the summed substep-to-substep travel is ten times that.
-    // 0: the check of the final position alone.  The contact-resolving launch asks the same questions with twice the travel: an
-    // environment goes back to the lean launch when its geoms are apart by a margin the lean launch's certificate will not fail on at once)
+    // 0: the check of the final position alone.  The contact-resolving launch asks the SAME questions of its own launch: an environment
+    // goes back to the lean launch when the lean launch's certificate would have passed this one -- no wider margin: an environment that
+    // goes back one step too early costs its redone step what staying would have cost, and a gripper opening from shut pads (gap at the
+    // start exactly 0, gap at the end exactly its travel) passes a test with the travel itself and never one with twice the travel)
     double chk_dend = 0.0, chk_psum = 0.0;
-    if (op.check == 2 && live && t < T::NL && !chk_first) {
-      const double lo = fmin(chk_qmin, q_final), hi = fmax(chk_qmax, q_final), sc = esc_role == 2 ? 2.0 : 1.0;
-      chk_dend = sc * fmax(hi - q_final, q_final - lo);
-      chk_psum = sc * (2.0 * (hi - lo) - fabs(q_final - chk_q0));
+    {
+      // (the fingers' lanes: the same for the opening / the common shift -- their values at the launch's two ends from both fingers' lanes)
+      double w_final = q_final, w0 = chk_q0;
+      if (T::GRIP) {
+        const int fb = (int)(threadIdx.x & 48u) + T::NARM;
+        const double qa = lane_get(q_final, fb), qb = lane_get(q_final, fb + 1), sa = lane_get(chk_q0, fb), sb = lane_get(chk_q0, fb + 1);
+        if (t == T::NARM) { w_final = qa + qb; w0 = sa + sb; }
+        if (t == T::NARM + 1) { w_final = qa - qb; w0 = sa - sb; }
+      }
+      if (op.check == 2 && live && t < T::NL && !chk_first) {
+        const double lo = fmin(chk_qmin, w_final), hi = fmax(chk_qmax, w_final);
+        chk_dend = fmax(hi - w_final, w_final - lo);
+        chk_psum = 2.0 * (hi - lo) - fabs(w_final - w0);
+      }
     }
     __syncthreads();
     double* const sep = P.S + (size_t)Lay<T>::SEP * P.n + (live ? e : 0);
@@ -1476,7 +1496,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       check_mv = lself;  // (the detection of the substep loop is over)
     }
     const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, chk_plane, sep_in, sep, P.n, chk_pf,
-                                                 chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0);
+                                                 chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0, esc_role != 0 ? chk_slack : nullptr, chk_use_slack, esc_role == 1 && op.check == 2);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif
@@ -1487,9 +1507,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
         atomicAdd(lop.esc_ctr + 2, 1u);
       }
     } else if (esc_role == 2) {
-      // Back to the lean launch: an environment none of whose substeps met a contact AND whose geoms (and the floor) are proven apart
-      // by more than twice what this launch's joint travel could have closed -- the lean launch's certificate (the same test with the
-      // travel itself) then has room.  Whoever is in contact or near one stays: here every substep looks.  (Round 5 kept an
+      // Back to the lean launch: an environment none of whose substeps met a contact AND whose launch passes the lean launch's own
+      // certificate.  Whoever is in contact or near one stays: here every substep looks.  (Round 5 kept an
       // environment here until its reset: 1146 of 4096 by step 1000 of the headline rollout, 87 % of their collision passes quiet.)
       if (leader && have_frames && !esc_contact && !hit) esc_leave = true;
     } else if (leader && hit && !(r.flags & kContactUnresolved)) {

@@ -27,7 +27,7 @@ def _dev_upload(L, h, arr):
     return p
 
 
-def _exchange_worker(rank, world, uid_q, out_q, n_steps, carrier="rccl", same_device=False):
+def _exchange_worker(rank, world, uid_q, out_q, n_steps, carrier="rccl", same_device=False, fold=False):
     """One rank of the slot protocol: step, post slot t & 1, keep stepping into the other slot, read the gathered block two steps
     later (the overlap bench.py relies on).  Every rank's rows must be that rank's observations, in rank order."""
     try:
@@ -65,6 +65,9 @@ def _exchange_worker(rank, world, uid_q, out_q, n_steps, carrier="rccl", same_de
             env.reset()
             rng = np.random.default_rng(100 + rank)
             acts = rng.uniform(-0.05, 0.05, (n_steps, n, env.dof))
+            if fold:  # half of the environments lean forward until hand and wrist lie on the floor (from step ~95): escalation on every rank
+                acts[:, : n // 2, 1] = 0.08
+                acts[:, : n // 2, 3] = 0.08
             dact, dgrip = _dev_upload(L, h, acts), _dev_upload(L, h, np.ones(n, dtype=np.float32))
             ok, own = True, {}
             for t in range(n_steps):
@@ -79,18 +82,21 @@ def _exchange_worker(rank, world, uid_q, out_q, n_steps, carrier="rccl", same_de
                         other = (rank + 1) % world
                         ok = ok and float(np.abs(g[other * n:(other + 1) * n] - g[rank * n:(rank + 1) * n]).max()) > 1e-6
             ex.drain()
+            if fold:  # (both launches of a step ran, both slots were reused, while environments went to the contact-resolving launch and came back)
+                now, ever = env.sim.contact_escalated()
+                ok = ok and int(ever.sum()) >= n // 4 and int(now.sum()) >= n // 4 and not env.sim.contact_unresolved().any()
         env.close()
         out_q.put((rank, bool(ok), ""))
     except Exception as exc:  # noqa: BLE001
         out_q.put((rank, False, repr(exc)))
 
 
-def _run_exchange(world, carrier="rccl", same_device=False, n_steps=6):
+def _run_exchange(world, carrier="rccl", same_device=False, n_steps=6, fold=False):
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     uid_q, out_q = (ctx.Queue() if carrier == "rccl" else [ctx.Queue() for _ in range(world)]), ctx.Queue()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, world, uid_q, out_q, n_steps, carrier, same_device)) for r in range(world)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, uid_q, out_q, n_steps, carrier, same_device, fold)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(out_q.get(timeout=300) for _ in range(world))
@@ -122,6 +128,13 @@ def test_copy_engine_exchange_two_processes_on_one_gpu():
     order, with the two-slot overlap (a gather is read while the next env-step writes the other slot); 12 steps, so that every
     flag word is reused several times.  (The same code path a node's 8 processes take; there the copies run over xGMI.)"""
     _run_exchange(2, carrier="copy", same_device=True, n_steps=12)
+
+
+def test_copy_engine_exchange_two_processes_with_escalating_environments():
+    """Verdict r5, next 9: the copy carrier across 300 env-steps in which half of every rank's environments fold onto the floor -- every
+    step is a lean launch AND a contact-resolving launch on the handle's stream, both slots of the exchange are reused 150 times, the
+    gathered rows stay every rank's own observations of the step before."""
+    _run_exchange(2, carrier="copy", same_device=True, n_steps=300, fold=True)
 
 
 def test_copy_engine_exchange_one_rank_per_gpu():

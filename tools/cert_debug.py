@@ -14,7 +14,7 @@ import parity_util as PU
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-venv = PU.make_vec_env(n, True)
+venv = PU.make_vec_env(n, os.environ.get("RCSH_ASYNC", "1") != "0")
 L = venv._L
 out = (C.c_int * 64)()
 pairs = (C.c_int32 * 2048)()
