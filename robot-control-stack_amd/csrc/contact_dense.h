@@ -694,6 +694,21 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
   }
 #endif
   if (!(r & 1u) || !b.resolve) return r & ~1u;
+  if constexpr (!BOXD) {
+    // no free box: a lane per contact, its rows in registers, whatever the number of contacts (contact_wide.h)
+    contact_newton_wide<T, FRIC, AR>(b, st, bs, ar, gravity, links);
+    PHASE_CLOCK(pc2)
+    contact_noslip_wide<T, AR>(b, st, bs, ar);
+    PHASE_CLOCK(pc3)
+#ifdef RCSH_PHASE_TIMING
+    if ((threadIdx.x & 63) == 0) {
+      const bool few_ = in_lds(&ar)->ncon <= 21;
+      atomicAdd(&g_team_cycles[few_ ? 78 : 73], pc1 - pc0); atomicAdd(&g_team_cycles[few_ ? 79 : 74], pc2 - pc1); atomicAdd(&g_team_cycles[few_ ? 80 : 75], pc3 - pc2); atomicAdd(&g_team_cycles[few_ ? 81 : 76], 1ull);
+      s_wg_acc[0] += pc1 - pc0; s_wg_acc[1] += pc2 - pc1; s_wg_acc[2] += pc3 - pc2; s_wg_acc[4] += 1; s_wg_acc[5] += (unsigned long long)in_lds(&ar)->ncon;
+    }
+#endif
+    return r | (in_lds(&ar)->pad[0] ? 16u : 0u);
+  }
   const bool few = in_lds(&ar)->ncon <= DenseLds<T, BOXD, AR>::kDenseCon;
 #ifndef RCSH_NO_DENSE
   if (few) {

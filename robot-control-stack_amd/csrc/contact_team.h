@@ -2888,4 +2888,5 @@ RCSH_CONTACT_FN void contact_noslip(const BoxCfg& b_, const StageTeam<T>& st_, d
 #endif  // __HIP__
 
 }  // namespace rcsh
+#include "contact_wide.h"
 #include "contact_dense.h"
