@@ -27,6 +27,17 @@ namespace rcsh {
 
 #if defined(__HIP__)
 
+#ifdef RCSH_CHECK_TAIL
+// development: how long the check takes per wavefront -- [0] sum of cycles, [1] wavefronts, [2] the longest, [3] wavefronts that left at the slack
+// test, then what the longest one did: [4] narrow-phase rounds, [5] Gilbert runs, [6] support queries at the start frames, [7] full refinements, [8] box rounds
+__device__ unsigned long long g_chk_tail[16];
+#define TAIL_COUNT(i) { if ((threadIdx.x & 63) == 0) ++tail_n_[i]; }
+#define TAIL_END(early) { if ((threadIdx.x & 63) == 0) { const unsigned long long dt_ = __builtin_readcyclecounter() - tail_t0_; atomicAdd(&g_chk_tail[0], dt_); atomicAdd(&g_chk_tail[1], 1ull); \
+    if (early) atomicAdd(&g_chk_tail[3], 1ull); if (atomicMax(&g_chk_tail[2], dt_) < dt_) { for (int k_ = 0; k_ < 5; ++k_) g_chk_tail[4 + k_] = tail_n_[k_]; } } }
+#else
+#define TAIL_COUNT(i)
+#define TAIL_END(early)
+#endif
 #ifdef RCSH_CHECK_DEBUG
 __device__ int g_chk_dbg[64];
 __device__ double g_chk_dbgf[128];  // certificate failures of the narrow phase: (pair, margin, gap at the end, gap at the start) x 32
@@ -267,6 +278,10 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #ifdef RCSH_CHECK_DEBUG
   unsigned long long chk_t0_ = __builtin_readcyclecounter();
 #endif
+#ifdef RCSH_CHECK_TAIL
+  const unsigned long long tail_t0_ = __builtin_readcyclecounter();
+  unsigned long long tail_n_[5] = {0, 0, 0, 0, 0};
+#endif
   double* wbox = work + kCheckBox * team;
   // (the remembered directions stay in the lanes that loaded them -- lane t of a team holds word t of its four slots; reads and updates go
   // across the team's lanes: no LDS, which the lean detection kernel has none of to spare)
@@ -381,6 +396,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         if (t + kTeamLanes * j < npair) slack_env[t + kTeamLanes * j] = rem[j];
       if (valid) slack_env[kSlackLink + t] = remL;
     }
+    TAIL_END(true)
     return false;
   }
   // ---- world frames of the links at the final qpos (what the next launch's first position stage will see)
@@ -515,6 +531,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   uint32_t cmask = 0;
   if (ck.pad & 2) smask = 0;
   while (__ballot(smask != 0)) {
+    TAIL_COUNT(4)
     if (smask) {
       const int j = __ffs((int)smask) - 1;
       smask &= smask - 1;
@@ -573,6 +590,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   if (ck.pad & 1) cmask = 0;
   for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
     const int src = __ffsll((long long)pc) - 1;  // wave-uniform
+    TAIL_COUNT(0)
     const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cmask, src);
     const int u = __ffs((int)sm) - 1, t1 = src & (kTeamLanes - 1);
     const bool holder = t == t1 && ((cmask >> u) & 1u);
@@ -670,6 +688,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
           for (int k = 0; k < 9; ++k) LR0[k] = F0[12 * a.link + k];
         }
         mulmv(LR0, dl, dw0);
+        TAIL_COUNT(2)
         MprPt s0;
         mpr_support<true>(A0, B0, dw0, s0);
         const double g0 = -dot3(s0.v, dw0);
@@ -695,6 +714,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         // keeps its verdicts far from the nanometre the check calls contact.  Certifying mode: a few more, after the first proof, for a
         // direction with a larger gap -- it is the gap that certifies, and the direction is remembered
         double dg[3], gap = 0.0;
+        TAIL_COUNT(1)
         if (gilbert_apart<true>(A, B, x0, mteam > 0.0 ? 6 : 5, 1e-5, dg, &gap, mteam > 0.0 ? 1 : 0)) {
           double dl[3];
           mulTv(LR, dg, dl);
@@ -763,6 +783,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     if (valid && check_plane) slack_env[kSlackLink + t] = remL;
   }
   CHK_MARK(6)
+  TAIL_END(false)
   return hit;
 }
 

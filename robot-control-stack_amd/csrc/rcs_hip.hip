@@ -2656,6 +2656,14 @@ int rcsh_dev_download(rcsh_sim* s, void* dst, const void* src, size_t bytes) {
   return RCSH_OK;
 }
 
+#ifdef RCSH_CHECK_TAIL
+extern "C" int rcsh_debug_check_tail(unsigned long long* out16, int clear) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rcsh::g_chk_tail), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (clear) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rcsh::g_chk_tail), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 #ifdef RCSH_CHECK_DEBUG
 extern "C" int rcsh_debug_check(int* out64, int clear) {
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(rcsh::g_chk_dbg), sizeof(int) * 64) != hipSuccess) return 1;
