@@ -695,7 +695,10 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
 #endif
   if (!(r & 1u) || !b.resolve) return r & ~1u;
   if constexpr (!BOXD) {
-    // no free box: a lane per contact, its rows in registers, whatever the number of contacts (contact_wide.h)
+    if (in_lds(&ar)->ncon > DenseLds<T, BOXD, AR>::kDenseCon || (ck.pad & 32)) {
+    // no free box, many contacts: a lane per contact, its rows in registers, whatever their number (contact_wide.h).  (With few -- the
+    // one or two of a link on the floor -- the rows-in-LDS form below is the cheaper one: its sums run over the rows there are, the
+    // wide form's reductions over all 64 lanes whatever the count.)
     contact_newton_wide<T, FRIC, AR>(b, st, bs, ar, gravity, links);
     PHASE_CLOCK(pc2)
     contact_noslip_wide<T, AR>(b, st, bs, ar);
@@ -708,6 +711,7 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
     }
 #endif
     return r | (in_lds(&ar)->pad[0] ? 16u : 0u);
+    }
   }
   const bool few = in_lds(&ar)->ncon <= DenseLds<T, BOXD, AR>::kDenseCon;
 #ifndef RCSH_NO_DENSE
@@ -726,6 +730,7 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
     return r | (in_lds(&ar)->pad[0] ? 16u : 0u);
   }
 #endif
+  if constexpr (BOXD) {  // (without a free box many contacts went to the wide form above)
   contact_newton<T, FRIC, AR>(b, st, bs, ar, gravity, links);
   PHASE_CLOCK(pc2)
   contact_noslip<T, AR>(b, st, bs, ar);
@@ -737,6 +742,7 @@ RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, con
   }
 #endif
   (void)few;
+  }
   return r | (in_lds(&ar)->pad[0] ? 16u : 0u);  // bit 4: a capacity of the contact phase overflowed in this substep
 }
 
