@@ -31,9 +31,11 @@ namespace rcsh {
 // development: how long the check takes per wavefront -- [0] sum of cycles, [1] wavefronts, [2] the longest, [3] wavefronts that left at the slack
 // test, then what the longest one did: [4] narrow-phase rounds, [5] Gilbert runs, [6] support queries at the start frames, [7] full refinements, [8] box rounds
 __device__ unsigned long long g_chk_tail[16];
-#define TAIL_COUNT(i) { if ((threadIdx.x & 63) == 0) ++tail_n_[i]; }
+__device__ unsigned long long g_chk_hist[64];  // [0..15] wavefronts by total cycles (8k bins), [16..31] by narrow-phase cycles (4k bins), [32..47] by cycles before the narrow phase (4k bins)
+#define TAIL_COUNT(i) { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&tail_sh_[i], 1u); }
 #define TAIL_END(early) { if ((threadIdx.x & 63) == 0) { const unsigned long long dt_ = __builtin_readcyclecounter() - tail_t0_; atomicAdd(&g_chk_tail[0], dt_); atomicAdd(&g_chk_tail[1], 1ull); \
-    if (early) atomicAdd(&g_chk_tail[3], 1ull); if (atomicMax(&g_chk_tail[2], dt_) < dt_) { for (int k_ = 0; k_ < 5; ++k_) g_chk_tail[4 + k_] = tail_n_[k_]; } } }
+    { unsigned long long b_ = dt_ / 8192; atomicAdd(&g_chk_hist[b_ > 15 ? 15 : b_], 1ull); b_ = tail_nar_ / 4096; atomicAdd(&g_chk_hist[16 + (b_ > 15 ? 15 : b_)], 1ull); b_ = tail_pre_ / 4096; atomicAdd(&g_chk_hist[32 + (b_ > 15 ? 15 : b_)], 1ull); } \
+    if (early) atomicAdd(&g_chk_tail[3], 1ull); if (atomicMax(&g_chk_tail[2], dt_) < dt_) { for (int k_ = 0; k_ < 5; ++k_) g_chk_tail[4 + k_] = tail_sh_[k_]; g_chk_tail[9] = tail_stage_; g_chk_tail[10] = tail_miss_; g_chk_tail[11] = tail_nar_; g_chk_tail[12] = tail_pre_; g_chk_tail[13] = tail_sh_[5]; g_chk_tail[14] = tail_sh_[6]; g_chk_tail[15] = tail_sh_[7]; } } }
 #else
 #define TAIL_COUNT(i)
 #define TAIL_END(early)
@@ -191,6 +193,47 @@ RCSH_D bool finger_boxes_certified(const double* Ra, const double* ca, const dou
   return ok;
 }
 
+// The support VALUE of a shape along a direction -- the largest x . dir over its points -- computed by the 16 lanes of a team on
+// vertices staged in LDS.  The check's certificates read nothing else of a support query: the support of A - B along d is
+// h_A(d) + h_B(-d), its negative the gap d proves.  (shape_support also finds WHICH vertex, lowest index among ties, in a second pass
+// over the hull, and fetches and transforms it: what the refinement that builds contact points needs, twice the cost.)
+RCSH_D double shape_support_value(const Shape& s, const double* dir) {
+  double l[3];
+  mulTv(s.R, dir, l);
+  double h;
+  if (s.type == 0) {
+    const double* verts = in_lds(s.verts);
+    const int t = threadIdx.x & (kTeamLanes - 1);
+    double best = -INFINITY;
+    for (int i0 = t; i0 < s.nvert; i0 += 4 * kTeamLanes) {
+      double x[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kTeamLanes < s.nvert ? i0 + u * kTeamLanes : i0;
+        x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
+      }
+      sched_fence();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) best = fmax(best, x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2]);
+    }
+    best = fmax(best, row_rotate<8>(best));
+    best = fmax(best, row_rotate<4>(best));
+    best = fmax(best, row_rotate<2>(best));
+    best = fmax(best, row_rotate<1>(best));
+    h = best;
+  } else if (s.type == 1) {
+    h = fabs(l[0]) * s.size[0] + fabs(l[1]) * s.size[1] + fabs(l[2]) * s.size[2];
+  } else {
+    h = fabs(l[2]) * s.size[1] + s.size[0] * sqrt(dot3(l, l));
+  }
+  return h + dot3(s.p, dir);
+}
+// the gap a unit direction d proves between A and B (negative: none): minus the support of A - B along d
+RCSH_D double support_gap(const Shape& A, const Shape& B, const double* d) {
+  const double nd[3] = {-d[0], -d[1], -d[2]};
+  return -(shape_support_value(A, d) + shape_support_value(B, nd));
+}
+
 // A remembered direction's slot: [0] = (pair index + 1) + 1024 (g0 + 32 g1) -- zero: empty --, [1..3] the direction in the frame of
 // geom 0's link.  The geoms ride along so that the NEXT launch can ask for their records and vertices before it knows anything else.
 RCSH_D double check_slot_key(int pidx, int g0, int g1) { return (double)((pidx + 1) + 1024 * (g0 + 32 * g1)); }
@@ -280,7 +323,10 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #endif
 #ifdef RCSH_CHECK_TAIL
   const unsigned long long tail_t0_ = __builtin_readcyclecounter();
-  unsigned long long tail_n_[5] = {0, 0, 0, 0, 0};
+  __shared__ unsigned tail_sh_[8];
+  if ((threadIdx.x & 63) < 8) tail_sh_[threadIdx.x & 63] = 0;
+  __syncthreads();
+  unsigned long long tail_nar_ = 0, tail_pre_ = 0, tail_stage_ = 0, tail_miss_ = 0;
 #endif
   double* wbox = work + kCheckBox * team;
   // (the remembered directions stay in the lanes that loaded them -- lane t of a team holds word t of its four slots; reads and updates go
@@ -587,6 +633,10 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   // ---- narrow phase: a surviving geom pair has its hulls staged by the whole wavefront, once for all the teams it survived in;
   // each of those teams runs the refinement on its 16 lanes, which share the vertex scans of the support queries
   __syncthreads();  // (the stage takes the world boxes' place)
+#ifdef RCSH_CHECK_TAIL
+  const unsigned long long tail_t1_ = __builtin_readcyclecounter();
+  tail_pre_ = tail_t1_ - tail_t0_;
+#endif
   if (ck.pad & 1) cmask = 0;
   for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
     const int src = __ffsll((long long)pc) - 1;  // wave-uniform
@@ -608,6 +658,10 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     const int na = 3 * ck.gvert[g0][1], nb = 3 * ck.gvert[g1][1];
     const double key = check_slot_key(pidx, g0, g1);
     // the two geom records and the hulls' vertices: from the prefetch where the guess was right, else from memory now
+#ifdef RCSH_CHECK_TAIL
+    const unsigned long long tail_s0_ = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0 && pf.guess_key != (int)key) tail_miss_ += 1;
+#endif
     if (pf.guess_key == (int)key) {
       gstage[lane] = pf.gword;
 #pragma unroll
@@ -629,6 +683,9 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #endif
     }
     stage_fence();  // (LDS traffic of one wavefront is ordered)
+#ifdef RCSH_CHECK_TAIL
+    if ((threadIdx.x & 63) == 0) tail_stage_ += __builtin_readcyclecounter() - tail_s0_;
+#endif
     bool apart_out = false;
     double gcert_out = 0.0;
     if (take) {
@@ -689,9 +746,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         }
         mulmv(LR0, dl, dw0);
         TAIL_COUNT(2)
-        MprPt s0;
-        mpr_support<true>(A0, B0, dw0, s0);
-        const double g0 = -dot3(s0.v, dw0);
+        const double g0 = support_gap(A0, B0, dw0);
         dbg_g0 = g0;
         return g0 > -kCheckTouch && g0 + g1 > mP - 2.0 * kCheckTouch;
       };
@@ -700,13 +755,29 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         const double dl[3] = {lane_get(sepw, tbase + 4 * s_use + 1), lane_get(sepw, tbase + 4 * s_use + 2), lane_get(sepw, tbase + 4 * s_use + 3)};
         double dw[3];
         mulmv(LR, dl, dw);
-        MprPt s;
-        mpr_support<true>(A, B, dw, s);
         // the support of A - B along the remembered direction is still negative: apart (certifying mode: by enough)
-        const double g1 = -dot3(s.v, dw);
+        const double g1 = support_gap(A, B, dw);
         apart = mteam > 0.0 ? certified(g1, dl) : g1 > 0.0;
         gcert = g1;
-        x0[0] = s.v[0]; x0[1] = s.v[1]; x0[2] = s.v[2];
+      }
+      if (!apart && s_hold < 0 && finger_pair && slides[3] < 1e300) {
+        // two geoms on the two fingers without a remembered direction (a shut or shutting gripper brings eleven hull pairs near at
+        // once -- each pad against the other finger's hull, the two hulls -- and an environment remembers four): what separates them is
+        // the slides' own axis, nearly always -- one support query along it before any iteration.  (Without it every such pair ran
+        // Gilbert's iteration in every launch in which the fingers moved: the one wavefront in a hundred the whole launch then waits for,
+        // tools/check_tail.py.)
+        double e[3] = {slides[4] - slides[0], slides[5] - slides[1], slides[6] - slides[2]};
+        const double en = sqrt(dot3(e, e));
+        if (en > 1e-9) {
+          const double sg = (e[0] * (B.center[0] - A.center[0]) + e[1] * (B.center[1] - A.center[1]) + e[2] * (B.center[2] - A.center[2]) >= 0.0 ? 1.0 : -1.0) / en;
+          const double dw[3] = {sg * e[0], sg * e[1], sg * e[2]};
+          double dl[3];
+          mulTv(LR, dw, dl);
+          const double g1 = support_gap(A, B, dw);
+          apart = mteam > 0.0 ? certified(g1, dl) : g1 > 0.0;
+          gcert = g1;
+          if (apart) { stage_fence(); slot_store(dl); }
+        }
       }
 #ifndef RCSH_NO_GILBERT
       if (!apart) {
@@ -715,6 +786,9 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         // direction with a larger gap -- it is the gap that certifies, and the direction is remembered
         double dg[3], gap = 0.0;
         TAIL_COUNT(1)
+#ifdef RCSH_CHECK_TAIL
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { tail_sh_[5] = (unsigned)pidx; tail_sh_[6] = (unsigned)(mteam * 1e6); tail_sh_[7] = (unsigned)(s_hold >= 0 ? (gcert > 0 ? gcert * 1e6 : 0) : 999999999u); }
+#endif
         if (gilbert_apart<true>(A, B, x0, mteam > 0.0 ? 6 : 5, 1e-5, dg, &gap, mteam > 0.0 ? 1 : 0)) {
           double dl[3];
           mulTv(LR, dg, dl);
@@ -736,6 +810,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #endif
       }
       else if (!apart && !(ck.pad & 8)) {
+        TAIL_COUNT(3)
         double dir[3], depth = 0.0;
         if (mpr_penetration<true, kMprDepth>(A, B, &depth, dir, nullptr)) {
           if (depth > kCheckTouch) {
@@ -768,6 +843,9 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     stage_fence();
   }
   CHK_MARK(5)
+#ifdef RCSH_CHECK_TAIL
+  tail_nar_ = __builtin_readcyclecounter() - tail_t1_;
+#endif
   __syncthreads();
   if (t < kCheckSep && live) sep[(size_t)t * n_env] = sepw;
   const bool hit = team_ballot(mine) != 0;

@@ -2664,6 +2664,14 @@ extern "C" int rcsh_debug_check_tail(unsigned long long* out16, int clear) {
   return 0;
 }
 #endif
+#ifdef RCSH_CHECK_TAIL
+extern "C" int rcsh_debug_check_hist(unsigned long long* out64, int clear) {
+  hipDeviceSynchronize();
+  if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(rcsh::g_chk_hist), sizeof(unsigned long long) * 64) != hipSuccess) return 1;
+  if (clear) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rcsh::g_chk_hist), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 #ifdef RCSH_CHECK_DEBUG
 extern "C" int rcsh_debug_check(int* out64, int clear) {
   if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(rcsh::g_chk_dbg), sizeof(int) * 64) != hipSuccess) return 1;

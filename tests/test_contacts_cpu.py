@@ -511,3 +511,44 @@ def test_link0_and_link1_never_touch_over_joint_1s_range():
         for c in range(d.ncon):
             seen.add(tuple(sorted((names[d.contact[c].geom[0]], names[d.contact[c].geom[1]]))))
     assert ("fr3_link0_collision_0", "fr3_link1_collision_0") not in seen, seen
+
+
+def test_oracle_contact_list_is_unbounded_and_the_cap_is_a_test_knob():
+    """Round 6 (advisor, round 5): the oracle no longer cuts mjData.contact to the HIP backend's capacity.  Two shut fingers pushed
+    0.1 mm into each other make 16 contacts here (50-64 with the arm pressing on a finger: tools/oracle_ncon_probe.py);
+    orc_set_contact_cap keeps the first `cap` of MuJoCo's order for tests that want to see a bounded backend overflow, and 0 takes
+    the bound away again."""
+    cm, o = _fr3_empty(3)
+    d = o.s.d
+    d.qpos[7] = -1e-4
+    d.qpos[8] = -1e-4
+    L = O.lib()
+    L.orc_step1(C.byref(o.model), C.byref(d))
+    full = d.ncon
+    order = [(d.contact[c].geom[0], d.contact[c].geom[1]) for c in range(full)]
+    assert full > 8, full
+    L.orc_set_contact_cap(8)
+    try:
+        L.orc_step1(C.byref(o.model), C.byref(d))
+        assert d.ncon == 8
+        assert [(d.contact[c].geom[0], d.contact[c].geom[1]) for c in range(8)] == order[:8]
+    finally:
+        L.orc_set_contact_cap(0)
+    L.orc_step1(C.byref(o.model), C.byref(d))
+    assert d.ncon == full
+
+
+def test_effective_path_bounds_every_position_a_joint_took():
+    """The certifying check's two travels (csrc/check_team.h, sim_kernels.h: chk_dend, chk_psum) from the first, lowest and highest
+    value of a joint over a launch: for EVERY position q it took, |q - q_end| <= dend and |q - q_start| + |q - q_end| <= psum -- for
+    monotone motion with equality at the far end (psum = the net displacement), which is what lets closing fingers pass."""
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        q = np.cumsum(rng.normal(0, 1, 18)) if rng.random() < 0.7 else np.sort(rng.normal(0, 1, 18))
+        lo, hi, q0, q1 = q.min(), q.max(), q[0], q[-1]
+        dend = max(hi - q1, q1 - lo)
+        psum = 2 * (hi - lo) - abs(q1 - q0)
+        assert (np.abs(q - q1) <= dend + 1e-15).all()
+        assert (np.abs(q - q0) + np.abs(q - q1) <= psum + 1e-12).all()
+    q = np.linspace(0.3, -0.1, 18)  # monotone: the bound is attained, nothing is given away
+    assert abs((2 * (q.max() - q.min()) - abs(q[-1] - q[0])) - abs(q[-1] - q[0])) < 1e-15

@@ -17,17 +17,26 @@ venv = PU.make_vec_env(n, True)
 L = venv._L
 joints, grip = PU.synthetic_actions(n, skip + steps, 0)
 venv.reset()
+pairs_ = (C.c_int32 * 2048)(); np_, nb_ = C.c_int32(0), C.c_int32(0)
 out = (C.c_ulonglong * 16)()
 for t in range(skip):
     venv.step({"joints": joints[t], "gripper": grip[t]})
 L.rcsh_debug_check_tail(out, 1)
+hist = (C.c_ulonglong * 64)()
+L.rcsh_debug_check_hist(hist, 1)
 worst = []
 for t in range(skip, skip + steps):
     venv.step({"joints": joints[t], "gripper": grip[t]})
     L.rcsh_debug_check_tail(out, 1)
     o = list(out)
-    worst.append((o[2], o[0] / max(o[1], 1), o[3], o[1], o[4:9]))
+    worst.append((o[2], o[0] / max(o[1], 1), o[3], o[1], o[4:9], o[9:13], o[13:16]))
 w = np.array([x[0] for x in worst]); m = np.array([x[1] for x in worst])
 print(f"per launch: mean wavefront {m.mean():.0f} cycles, longest wavefront mean {w.mean():.0f} (max {w.max()}); wavefronts leaving at the slack test {np.mean([x[2] / x[3] for x in worst]):.2f}")
 for x in worst[:12]:
-    print("  longest %d cycles: narrow rounds %d, Gilbert runs %d, start-frame queries %d, (refinements %d), box rounds %d" % (x[0], *x[4]))
+    print("  longest %d cycles: narrow rounds %d, Gilbert runs %d, start-frame queries %d, refinements %d, box rounds %d; staging %d cycles (%d rounds not prefetched), narrow phase %d, before it %d; last Gilbert run: pair %d margin %d um, remembered direction's gap %d um (999999999: none remembered)" % (x[0], *x[4], *x[5], *x[6]))
+
+L.rcsh_debug_check_hist(hist, 1)
+h = np.array(hist[:], dtype=np.float64) / steps
+print("wavefronts per launch by total cycles (8k bins):      ", " ".join("%d" % round(x) for x in h[:16]))
+print("wavefronts per launch by narrow-phase cycles (4k bins):", " ".join("%d" % round(x) for x in h[16:32]))
+print("wavefronts per launch by cycles before it (4k bins):   ", " ".join("%d" % round(x) for x in h[32:48]))
