@@ -35,10 +35,11 @@ def test_headline_rollout_matches_the_resolving_oracle_for_1000_steps():
     touched = rep["first_contact"] >= 0
     assert touched.sum() >= 8, rep  # (some environments do reach the floor / themselves)
     assert rep["overflow_envs"].sum() == 0 and not rep["unresolved"].any(), rep
-    # the bar: 1e-9 / 1e-8, or -- where the oracle itself is that ill-conditioned -- 100 x the distance between the environment's oracle
-    # and its twin nudged by 1e-13 rad (shut fingers pressed into each other: parity_util.run_headline_resolved_parity)
+    # the bars: 1e-9 / 1e-8 and flags bit-equal at every step before an environment's ORACLE stops reproducing itself (its twin, nudged by
+    # 1e-13 rad, parts from it: shut fingers pressed into each other -- parity_util.run_headline_resolved_parity); 100 x the twins'
+    # distance in that step; nearly all environments never get there
     assert rep["excess_env"].max() < 1e-9 and rep["vexcess_env"].max() < 1e-8 and rep["flag_env"].sum() == 0, rep
-    assert (rep["twin_err_env"] < 1e-10).sum() >= 56 and rep["err_env"][rep["twin_err_env"] < 1e-10].max() < 1e-9, rep  # (the plain bar for nearly all)
+    assert (rep["twin_split"] < 0).sum() >= 56 and rep["err_env"][rep["twin_split"] < 0].max() < 1e-9, rep  # (the plain bars, start to end)
     assert np.array_equal(rep["resolved_ever"], rep["contact_steps"] > 0), rep  # resolved: exactly the environments the oracle saw contacts in
     # de-escalation: environments go back to the lean launch when they have moved clear (sticky until reset through round 5)
     assert (rep["resolved_ever"] & ~rep["escalated_now"]).sum() >= 1, rep

@@ -19,11 +19,11 @@ touched = rep["first_contact"] >= 0
 for e in range(n):
     if rep["err_env"][e] > 1e-9 or rep["flag_env"][e] or rep["overflow_envs"][e] or rep["graze_steps"][e]:
         print(f"env {e}: first contact step {rep['first_contact'][e]}, first step over 1e-9: {rep['first_bad'][e]}, max err {rep['err_env'][e]:.2e} "
-              f"(twins {rep['twin_err_env'][e]:.2e}, excess {rep['excess_env'][e]:.2e}), most contacts {rep['max_ncon'][e]}, grazes {rep['graze_steps'][e]}, "
+              f"(twins part at step {rep['twin_split'][e]}, by {rep['twin_err_env'][e]:.2e} in the end; error before that {rep['excess_env'][e]:.2e}, after {rep['post_split_err'][e]:.2e}), most contacts {rep['max_ncon'][e]}, grazes {rep['graze_steps'][e]}, "
               f"flag mismatches {rep['flag_env'][e]}, overflow {bool(rep['overflow_envs'][e])}")
-plain = rep["twin_err_env"] < 1e-10
+plain = rep["twin_split"] < 0
 print(f"{n} environments x {steps} steps, seed {seed}: {int(touched.sum())} ran into a contact ({int((rep['graze_steps'] > 0).sum())} with a contact that began and "
-      f"ended inside one env-step); within 1e-9 of the oracle at every step: {int((rep['err_env'] < 1e-9).sum())}; within max(1e-9, 100 x twins' distance): "
-      f"{int((rep['excess_env'] < 1e-9).sum())}; twins within 1e-10 of each other: {int(plain.sum())}, worst error among those {rep['err_env'][plain].max():.2e}; "
+      f"ended inside one env-step); within 1e-9 of the oracle at every step: {int((rep['err_env'] < 1e-9).sum())}; within 1e-9 at every step before their oracle stops reproducing itself (100 x the twins' distance in that step): "
+      f"{int((rep['excess_env'] < 1e-9).sum())}; environments whose twins never part: {int(plain.sum())}, worst error among those {rep['err_env'][plain].max():.2e}; "
       f"flag mismatches {int(rep['flag_env'].sum())}; overflow {int(rep['overflow_envs'].sum())}; on the contact-resolving launch at the end {int(rep['escalated_now'].sum())} "
       f"(most at once {int(rep['escalated_per_step'].max())}); resolved == touched: {bool(np.array_equal(rep['resolved_ever'], rep['contact_steps'] > 0))}")
