@@ -662,8 +662,6 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
             esc_chk(hipStreamWaitEvent(s->esc_stream, s->esc_ev_prev, 0));
             RunOp op_old = op;
             op_old.esc_role = 2; op_old.esc_part = 1; op_old.check = 0;
-            static const int leave_quiet0 = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();
-            op_old.esc_leave_quiet = leave_quiet0;
             // (the lean launch must not win the race for the SIMDs: it waits until the other stream has got as far as its kernel)
             esc_chk(hipEventRecord(s->esc_ev_started, s->esc_stream));
             esc_chk(hipStreamWaitEvent(s->stream, s->esc_ev_started, 0));
@@ -683,8 +681,6 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
           op.esc_role = 2; op.check = certify ? 2 : 0;
           op.esc_part = split ? 2 : 0;
           if (split) esc_chk(hipStreamWaitEvent(s->stream, s->esc_ev_old, 0));
-          static const int leave_quiet = [] { const char* e = std::getenv("RCSH_ESC_LEAVE_QUIET"); return e ? std::atoi(e) : 0; }();
-          op.esc_leave_quiet = leave_quiet;
           go(N{}, N{}, Y{});
         } else {
           op.force_contact = (s->box.resolve & 2) ? 1 : 0;

@@ -39,8 +39,7 @@ enum : uint32_t {
   kGripCmd = 1u << 13,
   kHasLastAction = 1u << 14,
   kContactOverflow = 1u << 15,  // sticky until Sim::reset: a contact phase of this environment ran out of contact / link slots
-  kEscQuiet = 1u << 17,         // per-environment escalation: the last contact-resolving launch of this environment met no contact (a second one
-                                // in a row sends it back to the lean kernel)
+  kEscQuiet = 1u << 17,         // (unused since round 6: an environment goes back to the lean launch by the certificate, not by a count of quiet launches)
   kContactResolved = 1u << 18,  // sticky until Sim::reset: a contact of this environment's robot geoms was resolved (per-environment escalation)
   kContactUnresolved = 1u << 16,  // sticky until Sim::reset: the environment's geoms were found in a contact this configuration does
                                   // not resolve (check_team.h): from then on its trajectory is not what MuJoCo's would be
@@ -113,18 +112,19 @@ struct RunOp {
   int32_t* substeps;      // [n]
   const double* box_qpos; // [n][7] env.reset() of the task env: RandomCubePos places the box (null: it stays at qpos0)
   double* task;           // [n][9] box qpos 7, reward, success (PickCubeSuccessWrapper.step)
-  // Per-environment escalation (round 5; host: launch_run).  MuJoCo resolves every contact of every substep (reference src/sim/sim.cpp:
-  // 108-115); the lean kernels resolve none.  So a step of a scene whose robot contacts are to be resolved is TWO launches over disjoint
-  // sets of environments: role 1, the lean kernel over the environments NOT escalated (workgroup slot r takes the r-th of them), which
-  // keeps a copy of every state field it read (snap) and whose end-of-launch check, on a hit, marks the environment in esc[1] ("new");
-  // then role 2, the contact-resolving kernel with the contact phase in every substep, over the escalated environments esc[0] | esc[1]:
-  // a NEW one is stepped again from the copy -- the launch it was flagged in is redone with its contacts resolved from their first
-  // substep --, the others continue from their state.  An environment whose second contact-resolving launch in a row met no contact is
-  // marked in esc[2] ("leave").  The last workgroup of the role-2 launch merges: esc[0] = (esc[0] & ~esc[2]) | esc[1].
+  // Per-environment escalation (round 5; the certificate and the way back: round 6; host: launch_run).  MuJoCo resolves every contact
+  // of every substep (reference src/sim/sim.cpp:108-115); the lean kernels resolve none.  So a step of a scene whose robot contacts are
+  // to be resolved is TWO launches over disjoint sets of environments: role 1, the lean kernel over the environments NOT escalated,
+  // which keeps a copy of every state field it read (snap) and whose end-of-launch check (check_team.h) marks an environment it cannot
+  // CERTIFY -- no substep of the launch can have been in contact -- in esc[1] ("new"); then role 2, the contact-resolving kernel with
+  // the contact phase in every substep, over the escalated environments esc[0] | esc[1]: a NEW one is stepped again from the copy --
+  // the launch it was flagged in is redone with its contacts resolved from their first substep --, the others continue from their
+  // state.  An environment none of whose substeps met a contact and whose launch passes the same certificate is marked in esc[2]
+  // ("leave").  The last workgroup of the role-2 launch merges: esc[0] = (esc[0] & ~esc[2]) | esc[1].
   int32_t esc_role;
   int32_t force_contact;  // the contact phase runs in every substep of every environment (a whole batch on the contact-resolving kernel with
                           // self contacts resolved: exact, and slow -- the fast path's broad phase knows the floor and the free body only)
-  int32_t esc_leave_quiet;  // role 2: an environment leaves after two launches in a row without a contact (default: with its reset only)
+  int32_t esc_pad0;         // (round 5: esc_leave_quiet)
   // Role 2 in two parts (esc_part): the environments that WERE escalated when the step began do not depend on the step's lean launch --
   // part 1 steps them on a stream of its own, next to the lean launch, and leaves the masks alone; part 2, behind both, redoes the newly
   // flagged ones and merges.  0: one launch does both (behind the lean one).  The host splits when it knows of escalated environments.
