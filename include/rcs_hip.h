@@ -332,8 +332,9 @@ int rcsh_sim_set_free_qvel(rcsh_sim* sim, const double* qvel, const uint8_t* mas
 /* Snapshot / restore of EVERYTHING that evolves (the mjData fields above, the callback scheduler's timestamps and
  * return values, SimRobot / SimGripper state, the wrappers' prev_action / origin / last_action, flags): the reference's
  * closest facility is the GUI bridge's mjSTATE_FULLPHYSICS copy (src/sim/gui_server.cpp:49-60).  The blob is opaque,
- * `rcsh_sim_state_bytes` long, and valid for handles created from the same scene with the same n_envs; restoring
- * and re-running the same calls reproduces the continuation bit for bit. */
+ * `rcsh_sim_state_bytes` long, and valid for handles created from the same scene with the same n_envs (it begins with a
+ * 16-byte header -- layout version, n_envs, number of state fields -- and rcsh_sim_set_state refuses a blob whose header says
+ * otherwise: RCSH_ERR_ARG); restoring and re-running the same calls reproduces the continuation bit for bit. */
 size_t rcsh_sim_state_bytes(const rcsh_sim* sim);
 int rcsh_sim_get_state(rcsh_sim* sim, void* blob);
 int rcsh_sim_set_state(rcsh_sim* sim, const void* blob);

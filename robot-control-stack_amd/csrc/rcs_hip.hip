@@ -1589,17 +1589,26 @@ int rcsh_sim_get_free_qvel(rcsh_sim* s, double* v) { REQUIRE_SIM(s); REQUIRE_BOX
 int rcsh_sim_set_free_qpos(rcsh_sim* s, const double* q, const uint8_t* mask) { REQUIRE_SIM(s); REQUIRE_BOX(s); return scatter_host(s, field_of(s, "box") + kBoxQ, 7, q, mask); }
 int rcsh_sim_set_free_qvel(rcsh_sim* s, const double* v, const uint8_t* mask) { REQUIRE_SIM(s); REQUIRE_BOX(s); return scatter_host(s, field_of(s, "box") + kBoxV, 6, v, mask); }
 
+// (the blob begins with a header -- a magic word with the layout's version, n_envs, the number of state fields: a blob of another
+// build or handle is refused by what it says, not only when its size happens to differ; advisor, round 5)
+constexpr size_t kStateHeader = 16;
+constexpr char kStateMagic[8] = {'R', 'C', 'S', 'H', 'S', 'T', '0', '2'};
 size_t rcsh_sim_state_bytes(const rcsh_sim* s) {
   if (!s) return 0;
   // (the tail: which environments are on the contact-resolving kernel -- per-environment escalation; a replay from a snapshot takes
   // the same kernels environment by environment as the rollout it was taken from)
-  return (size_t)s->n * (sizeof(double) * s->nfields + sizeof(uint32_t) + sizeof(int32_t)) + sizeof(uint64_t) * (((size_t)s->n + 63) / 64);
+  return kStateHeader + (size_t)s->n * (sizeof(double) * s->nfields + sizeof(uint32_t) + sizeof(int32_t)) + sizeof(uint64_t) * (((size_t)s->n + 63) / 64);
 }
 int rcsh_sim_get_state(rcsh_sim* s, void* blob) {
   REQUIRE_SIM(s);
   if (!blob) return fail(RCSH_ERR_ARG, "null state blob");
   HIP_TRY(hipSetDevice(s->device));
   char* b = static_cast<char*>(blob);
+  {
+    const uint32_t hn = (uint32_t)s->n, hf = (uint32_t)s->nfields;
+    std::memcpy(b, kStateMagic, 8); std::memcpy(b + 8, &hn, 4); std::memcpy(b + 12, &hf, 4);
+    b += kStateHeader;
+  }
   const size_t ns = sizeof(double) * (size_t)s->n * s->nfields, nf = sizeof(uint32_t) * (size_t)s->n, nc = sizeof(int32_t) * (size_t)s->n;
   HIP_TRY(hipMemcpyAsync(b, s->S, ns, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipMemcpyAsync(b + ns, s->flags, nf, hipMemcpyDeviceToHost, s->stream));
@@ -1615,6 +1624,13 @@ int rcsh_sim_set_state(rcsh_sim* s, const void* blob) {
   if (!blob) return fail(RCSH_ERR_ARG, "null state blob");
   HIP_TRY(hipSetDevice(s->device));
   const char* b = static_cast<const char*>(blob);
+  {
+    uint32_t hn = 0, hf = 0;
+    std::memcpy(&hn, b + 8, 4); std::memcpy(&hf, b + 12, 4);
+    if (std::memcmp(b, kStateMagic, 8) != 0 || hn != (uint32_t)s->n || hf != (uint32_t)s->nfields)
+      return fail(RCSH_ERR_ARG, "state blob of another layout (taken by another build, or from a handle with another scene / n_envs)");
+    b += kStateHeader;
+  }
   const size_t ns = sizeof(double) * (size_t)s->n * s->nfields, nf = sizeof(uint32_t) * (size_t)s->n, nc = sizeof(int32_t) * (size_t)s->n;
   if (s->d_slack) HIP_TRY(hipMemsetAsync(s->d_slack, 0, sizeof(float) * (size_t)kSlackStride * s->n, s->stream));  // (see scatter_host)
   HIP_TRY(hipMemcpyAsync(s->S, b, ns, hipMemcpyHostToDevice, s->stream));
@@ -2609,7 +2625,13 @@ int rcsh_comm_wait(rcsh_sim* s, int32_t slot, int32_t block_host) {
     HIP_TRY(hipEventSynchronize(s->comm_done[slot]));
     if (s->copy && *s->copy->timeout_flag) return fail(RCSH_ERR_DEVICE, "copy carrier: gave up waiting for a peer's block (a rank died?)");
     s->comm_pending[slot] = false;  // (a stream-side wait leaves it set: a later host-side wait must still see the event)
-  } else HIP_TRY(hipStreamWaitEvent(s->stream, s->comm_done[slot], 0));
+  } else {
+    // (a stream-side wait cannot see a gather give up while it is in flight; it refuses to order consumers behind a carrier that HAS
+    // given up on a peer -- the pinned flag, host-readable at any time: every later wait and post fails until the carrier is rebuilt;
+    // advisor, round 5)
+    if (s->copy && *s->copy->timeout_flag) return fail(RCSH_ERR_DEVICE, "copy carrier: an earlier gather gave up waiting for a peer's block (a rank died?)");
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->comm_done[slot], 0));
+  }
   return RCSH_OK;
 }
 

@@ -328,12 +328,14 @@ class RcclObservationExchange:
 
     def close(self) -> None:
         if self._h is not None:
-            self.drain()
-            for p in self._local + self._all:
-                self._L.rcsh_dev_free(self._h, p)
-            self._L.rcsh_comm_destroy(self._h)
-            self._h = None
-            self._sim = None
+            try:
+                self.drain()
+            finally:  # (a drain that raises -- a peer died -- must not leak the buffers and the communicator)
+                for p in self._local + self._all:
+                    self._L.rcsh_dev_free(self._h, p)
+                self._L.rcsh_comm_destroy(self._h)
+                self._h = None
+                self._sim = None
 
     def __enter__(self):
         return self
@@ -391,9 +393,11 @@ class CopyObservationExchange(RcclObservationExchange):
 
     def close(self) -> None:
         if self._h is not None:
-            self.drain()
-            for p in self._local:
-                self._L.rcsh_dev_free(self._h, p)
-            self._L.rcsh_comm_destroy(self._h)
-            self._h = None
-            self._sim = None
+            try:
+                self.drain()
+            finally:  # (a drain that raises -- the carrier gave up on a peer -- must not leak the IPC mappings, streams and buffers)
+                for p in self._local:
+                    self._L.rcsh_dev_free(self._h, p)
+                self._L.rcsh_comm_destroy(self._h)
+                self._h = None
+                self._sim = None

@@ -300,6 +300,11 @@ def test_snapshot_restore_replays_bit_for_bit(async_control):
             assert np.array_equal(x, y)
     with pytest.raises(ValueError):
         venv.sim.set_state(snap[:-8])
+    # (round 6: the blob begins with a header -- layout version, n_envs, number of state fields; one that says otherwise is refused)
+    bad = snap.copy()
+    bad[8] ^= 1
+    with pytest.raises((ValueError, RuntimeError)):
+        venv.sim.set_state(bad)
     venv.close()
 
 
