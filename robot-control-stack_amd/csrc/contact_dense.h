@@ -654,7 +654,7 @@ RCSH_CONTACT_FN void contact_noslip_dense(const BoxCfg& b_, const StageTeam<T>& 
       }
       st.fcon(lane) = fc;
       st.xs(lane) = ar.X[lane];
-    } else if (lane < NV) {
+    } else if (BOXD && lane < NV) {  // (without a free box the phantom's block in LDS ends with its state: sim_kernels.h, kBoxStride)
       const int k = lane - NL;
       bs[kBoxA + k] = ar.A0[lane] + Mbi[k] * qf;
     }

@@ -416,7 +416,6 @@ RCSH_CONTACT_FN void contact_noslip_wide(const BoxCfg& b_, const StageTeam<T>& s
   constexpr int kWorld = NL + 1;
   const int lane = wave_lane();
   const int ncon = ar.ncon;
-  const double Mbi[6] = {b.inv_mass, b.inv_mass, b.inv_mass, b.inv_inertia[0], b.inv_inertia[1], b.inv_inertia[2]};
   ConLane c;
   con_load(ar, b, lane, ncon, kWorld, c);
   const bool on = c.on;
@@ -577,10 +576,8 @@ RCSH_CONTACT_FN void contact_noslip_wide(const BoxCfg& b_, const StageTeam<T>& s
       }
       st.fcon(lane) = fc;
       st.xs(lane) = ar.X[lane];
-    } else if (lane < NV) {
-      const int k = lane - NL;
-      bs[kBoxA + k] = ar.A0[lane] + Mbi[k] * 0.0;
     }
+    // (the phantom box's acceleration is nobody's to read: its block in LDS ends with its state -- sim_kernels.h: kBoxStride)
   }
   __syncthreads();
   TEAM_MARK(32)

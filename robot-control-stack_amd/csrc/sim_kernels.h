@@ -1020,7 +1020,11 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   // two plain callbacks fire every `period` of simulated time, so the leader only looks at them when the earlier
   // of their two timestamps is due.
   // the free box of the scene: its state sits in the team's LDS block between substeps (box_team.h)
-  __shared__ double lbox[(BOX || CON) ? kBoxLds * kTeams : 1];
+  // (a free box's block: its state, the rows of its floor contacts, its acceleration; the PHANTOM box of a scene without one -- zero size,
+  // parked a kilometre up, there so that one formulation serves both -- keeps its state only: 2.4 KB that let four workgroups of the
+  // contact-resolving kernel share a CU again with 64 contact slots)
+  constexpr int kBoxStride = BOX ? kBoxLds : kBoxState + 1;
+  __shared__ double lbox[(BOX || CON) ? kBoxStride * kTeams : 1];
   using Arena = ContactArena<T, BOX ? kMaxCon : kMaxConNoBox>;
   __shared__ std::conditional_t<CON, Arena, char> larena[1];  // the contact phase's workspace: one per wavefront
   // self collision (DET): the world frames of every team's links for the pair tests.  The contact phase's workspace is idle
@@ -1049,7 +1053,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   if constexpr (DET && !CON) {
     if (threadIdx.x == 0) lself[kSelfF * kTeams + kSelfStage + kSelfCache] = 0.0;  // nothing staged yet
   }
-  double* const bs = lbox + ((BOX || CON) ? team * kBoxLds : 0);
+  double* const bs = lbox + ((BOX || CON) ? team * kBoxStride : 0);
   if constexpr (CON && !BOX) {
     // the phantom box: at rest where the host parked it; what it carries from launch to launch is the minimiser of the last coupled
     // solve (kBoxX: the warm start of the next one -- mjData.qacc_warmstart outlives a Sim.step call, only Sim::reset zeroes it)
@@ -1250,7 +1254,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
         if (nearw) {
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
-            const uint32_t r = contact_phase<T, FRIC, BOX>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxLds, larena[0], lm.gravity,
+            const uint32_t r = contact_phase<T, FRIC, BOX>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxStride, larena[0], lm.gravity,
                                                       __builtin_amdgcn_readlane(e, k * kTeamLanes));
             if (team == k) {
               coupled = r & 1u;
