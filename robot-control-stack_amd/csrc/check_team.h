@@ -31,10 +31,10 @@ namespace rcsh {
 // development: how long the check takes per wavefront -- [0] sum of cycles, [1] wavefronts, [2] the longest, [3] wavefronts that left at the slack
 // test, then what the longest one did: [4] narrow-phase rounds, [5] Gilbert runs, [6] support queries at the start frames, [7] full refinements, [8] box rounds
 __device__ unsigned long long g_chk_tail[16];
-__device__ unsigned long long g_chk_hist[64];  // [0..15] wavefronts by total cycles (8k bins), [16..31] by narrow-phase cycles (4k bins), [32..47] by cycles before the narrow phase (4k bins)
+__device__ unsigned long long g_chk_hist[64];  // [0..15] wavefronts by total cycles (8k bins), [16..31] by narrow-phase cycles (4k bins), [32..47] by cycles before the narrow phase (4k bins), [48..55] by narrow-phase rounds (0..7+), [56..63] their narrow-phase cycles summed
 #define TAIL_COUNT(i) { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&tail_sh_[i], 1u); }
 #define TAIL_END(early) { if ((threadIdx.x & 63) == 0) { const unsigned long long dt_ = __builtin_readcyclecounter() - tail_t0_; atomicAdd(&g_chk_tail[0], dt_); atomicAdd(&g_chk_tail[1], 1ull); \
-    { unsigned long long b_ = dt_ / 8192; atomicAdd(&g_chk_hist[b_ > 15 ? 15 : b_], 1ull); b_ = tail_nar_ / 4096; atomicAdd(&g_chk_hist[16 + (b_ > 15 ? 15 : b_)], 1ull); b_ = tail_pre_ / 4096; atomicAdd(&g_chk_hist[32 + (b_ > 15 ? 15 : b_)], 1ull); } \
+    { unsigned long long b_ = dt_ / 8192; atomicAdd(&g_chk_hist[b_ > 15 ? 15 : b_], 1ull); b_ = tail_nar_ / 4096; atomicAdd(&g_chk_hist[16 + (b_ > 15 ? 15 : b_)], 1ull); b_ = tail_pre_ / 4096; atomicAdd(&g_chk_hist[32 + (b_ > 15 ? 15 : b_)], 1ull); b_ = tail_rounds_ > 7 ? 7 : tail_rounds_; atomicAdd(&g_chk_hist[48 + b_], 1ull); atomicAdd(&g_chk_hist[56 + b_], tail_nar_); } \
     if (early) atomicAdd(&g_chk_tail[3], 1ull); if (atomicMax(&g_chk_tail[2], dt_) < dt_) { for (int k_ = 0; k_ < 5; ++k_) g_chk_tail[4 + k_] = tail_sh_[k_]; g_chk_tail[9] = tail_stage_; g_chk_tail[10] = tail_miss_; g_chk_tail[11] = tail_nar_; g_chk_tail[12] = tail_pre_; g_chk_tail[13] = tail_sh_[5]; g_chk_tail[14] = tail_sh_[6]; g_chk_tail[15] = tail_sh_[7]; } } }
 #else
 #define TAIL_COUNT(i)
@@ -306,13 +306,14 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 // check_work_doubles(NL); `mv`: for check_mv_doubles(NL); dend / psum: how far the lane's joint has been from where the launch ended, at
 // most / its effective path over the launch (see below; 0: it did not move -- or the check of the final position alone is asked for)
 // and q0 its position when the launch began.  slack_env: the environment's record of CheckTable::slack (null: none), use_slack: the
-// gaps it holds are valid lower bounds for the position the launch began on (see "the slack" below), keep_slack: the pairs' gaps
-// this check ends with are written back (the lean launch; the contact-resolving launch keeps them itself).  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
+// gaps it holds are valid lower bounds for a position of this launch (see "the slack" below: the one it began on -- the lean launch --
+// or the one its last substep began on -- the contact-resolving launch, whose collision passes keep the record), keep_slack: the
+// pairs' gaps this check ends with are written back (1: unless the environment is found in contact, the lean launch; 2: always).  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
 // Every lane of the wavefront calls this; returns, on every lane of a team, whether the team's environment is in contact.
 template <class T, class CollT>
 RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& tab, const CollT& lc, const LinkRec* links, double* frames,
                                      double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf,
-                                     double dend, double psum, double* mv, double q0, float* slack_env, bool use_slack, bool keep_slack) {
+                                     double dend, double psum, double* mv, double q0, float* slack_env, bool use_slack, int keep_slack) {
   constexpr int NL = T::NL;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const bool valid = t < NL;
@@ -326,7 +327,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   __shared__ unsigned tail_sh_[8];
   if ((threadIdx.x & 63) < 8) tail_sh_[threadIdx.x & 63] = 0;
   __syncthreads();
-  unsigned long long tail_nar_ = 0, tail_pre_ = 0, tail_stage_ = 0, tail_miss_ = 0;
+  unsigned long long tail_nar_ = 0, tail_pre_ = 0, tail_stage_ = 0, tail_miss_ = 0, tail_rounds_ = 0;
 #endif
   double* wbox = work + kCheckBox * team;
   // (the remembered directions stay in the lanes that loaded them -- lane t of a team holds word t of its four slots; reads and updates go
@@ -411,7 +412,8 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     mjP[j] = (double)(la >= 0 ? mvP[la * (NL + 1) + cc] : 0.0f) + (double)(lb >= 0 ? mvP[lb * (NL + 1) + cc] : 0.0f);
   }
   const double mfl = mvD[tl * (NL + 1)], mflP = mvP[tl * (NL + 1)];
-  // ---- THE SLACK.  A pair proven g apart at the position the launch BEGAN on cannot have touched during it unless some position on
+  // ---- THE SLACK.  A pair proven g apart at the position the launch BEGAN on (or at any other position of its path: any two are at
+  // most the effective path apart) cannot have touched during it unless some position on
   // the way is g from that first one -- |q - q_start| is at most the joints' effective path: g > the margin of psum certifies the pair
   // for this launch with no geometry at all, and g less that margin is a lower bound of its gap where the launch ended, the next
   // launch's g (CheckTable::slack, per environment; the contact-resolving launch keeps the same record substep by substep,
@@ -436,7 +438,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   if (dueL) atomicAdd(&g_chk_dbg[45], 1);
 #endif
   if (__ballot(due != 0 || dueL) == 0) {  // nobody of the wavefront's four environments has anything to look at
-    if (keep_slack && slack_env && live) {
+    if (keep_slack && slack_env && live && !(ck.pad & 16)) {
 #pragma unroll
       for (int j = 0; j < kCheckPer; ++j)
         if (t + kTeamLanes * j < npair) slack_env[t + kTeamLanes * j] = rem[j];
@@ -641,6 +643,9 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
     const int src = __ffsll((long long)pc) - 1;  // wave-uniform
     TAIL_COUNT(0)
+#ifdef RCSH_CHECK_TAIL
+    tail_rounds_ += 1;
+#endif
     const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cmask, src);
     const int u = __ffs((int)sm) - 1, t1 = src & (kTeamLanes - 1);
     const bool holder = t == t1 && ((cmask >> u) & 1u);
@@ -688,6 +693,9 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #endif
     bool apart_out = false;
     double gcert_out = 0.0;
+#ifdef RCSH_CHECK_TAIL
+    const unsigned long long tail_c0_ = __builtin_readcyclecounter();
+#endif
     if (take) {
       const ContactGeom& a = *reinterpret_cast<const ContactGeom*>(gstage);
       const ContactGeom& b = *reinterpret_cast<const ContactGeom*>(gstage + 32);
@@ -751,6 +759,10 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         return g0 > -kCheckTouch && g0 + g1 > mP - 2.0 * kCheckTouch;
       };
       double x0[3] = {A.center[0] - B.center[0], A.center[1] - B.center[1], A.center[2] - B.center[2]};  // (a point of A - B)
+#ifdef RCSH_CHECK_TAIL
+      const unsigned long long tail_c1_ = __builtin_readcyclecounter();
+      if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&tail_sh_[6], (unsigned)(tail_c1_ - tail_c0_));
+#endif
       if (s_hold >= 0) {
         const double dl[3] = {lane_get(sepw, tbase + 4 * s_use + 1), lane_get(sepw, tbase + 4 * s_use + 2), lane_get(sepw, tbase + 4 * s_use + 3)};
         double dw[3];
@@ -760,6 +772,9 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         apart = mteam > 0.0 ? certified(g1, dl) : g1 > 0.0;
         gcert = g1;
       }
+#ifdef RCSH_CHECK_TAIL
+      if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&tail_sh_[5], (unsigned)(__builtin_readcyclecounter() - tail_c1_));
+#endif
       if (!apart && s_hold < 0 && finger_pair && slides[3] < 1e300) {
         // two geoms on the two fingers without a remembered direction (a shut or shutting gripper brings eleven hull pairs near at
         // once -- each pad against the other finger's hull, the two hulls -- and an environment remembers four): what separates them is
@@ -786,9 +801,6 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
         // direction with a larger gap -- it is the gap that certifies, and the direction is remembered
         double dg[3], gap = 0.0;
         TAIL_COUNT(1)
-#ifdef RCSH_CHECK_TAIL
-        if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { tail_sh_[5] = (unsigned)pidx; tail_sh_[6] = (unsigned)(mteam * 1e6); tail_sh_[7] = (unsigned)(s_hold >= 0 ? (gcert > 0 ? gcert * 1e6 : 0) : 999999999u); }
-#endif
         if (gilbert_apart<true>(A, B, x0, mteam > 0.0 ? 6 : 5, 1e-5, dg, &gap, mteam > 0.0 ? 1 : 0)) {
           double dl[3];
           mulTv(LR, dg, dl);
@@ -832,6 +844,9 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
       apart_out = apart;
       gcert_out = gcert;
     }
+#ifdef RCSH_CHECK_TAIL
+    if ((threadIdx.x & 63) == 0) atomicAdd(&tail_sh_[7], (unsigned)(__builtin_readcyclecounter() - tail_c0_));
+#endif
     {
       // the pair's new slack, on the lane that holds the pair (the team's lanes agree on it)
       const float nr = apart_out ? fmaxf((float)gcert_out * 0.999999f - 1e-6f, 0.0f) : 0.0f;
@@ -849,10 +864,11 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   __syncthreads();
   if (t < kCheckSep && live) sep[(size_t)t * n_env] = sepw;
   const bool hit = team_ballot(mine) != 0;
-  // the slack goes back -- unless the environment is flagged: its launch is redone from the position it BEGAN on, which is what the
-  // record as it stands describes.  (The contact-resolving launch keeps the pairs' gaps itself, substep by substep; it leaves the
-  // links' heights, which only this check reads, as it found them at its end.)
-  if (slack_env && live && !hit) {
+  // the slack goes back -- unless the lean launch's environment is flagged: its launch is redone from the position it BEGAN on, which is
+  // what the record as it stands describes.  (The contact-resolving launch, keep_slack 2, redoes nothing: what its check ends with --
+  // every pair either charged the launch's whole path or looked at where the launch ended -- describes its last position, which the
+  // record its collision passes keep, valid where the last SUBSTEP began, does not.)
+  if (slack_env && live && (!hit || keep_slack == 2) && !(ck.pad & 16)) {  // (pad bit 4: a timing experiment -- RCSH_CHECK_SKIP, rcs_hip.hip)
     if (keep_slack) {
 #pragma unroll
       for (int j = 0; j < kCheckPer; ++j)

@@ -322,7 +322,7 @@ constexpr double kSupportTie = 1e-10;
 // LDS, scan every 16th vertex each, agree on the largest projection with four row rotations, then each lane looks for its
 // first vertex inside the band and the team takes the lowest index -- a lane scanning global memory alone pays a full round
 // trip per vertex, its wavefront having nothing else to run.
-template <bool TEAM>
+template <bool TEAM, bool ONE = false>
 RCSH_D int hull_support_index(const double* verts_, int nvert, const double* l) {
   double bestv = -INFINITY;
   int bi = 0;
@@ -340,40 +340,82 @@ RCSH_D int hull_support_index(const double* verts_, int nvert, const double* l) 
   }
   const double* verts = in_lds(verts_);
   const int t = threadIdx.x & (kTeamLanes - 1);
-  for (int i0 = t; i0 < nvert; i0 += 4 * kTeamLanes) {
-    // four vertices per trip: their reads go out together
-    double x[4][3];
+  if constexpr (ONE) {
+    // ONE pass over the vertices: the lane's projections stay in registers (a hull has at most kHullMaxVerts vertices: twelve a lane),
+    // and the second question -- the first vertex inside the tie band -- is asked of them, not of LDS again (through round 6's first
+    // half the scan ran twice: two thirds of a support query's instructions, and the support queries are four fifths of a portal
+    // refinement's 43k cycles).  The same products, rounded the same way: the same index.
+    constexpr int kTrips = (kHullMaxVerts + 4 * kTeamLanes - 1) / (4 * kTeamLanes);
+    double pv[kTrips][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * kTeamLanes < nvert ? i0 + u * kTeamLanes : i0;
-      x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
+    for (int r = 0; r < kTrips; ++r) {
+      const int i0 = t + 4 * kTeamLanes * r;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pv[r][u] = -INFINITY;
+      if (4 * kTeamLanes * r < nvert) {
+        // four vertices per trip: their reads go out together
+        double x[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kTeamLanes < nvert ? i0 + u * kTeamLanes : 0;
+          x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
+        }
+        sched_fence();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];
+          pv[r][u] = i0 + u * kTeamLanes < nvert ? v : -INFINITY;
+          if (pv[r][u] > bestv) bestv = pv[r][u];
+        }
+      }
     }
-    sched_fence();
+    bestv = fmax(bestv, row_rotate<8>(bestv));
+    bestv = fmax(bestv, row_rotate<4>(bestv));
+    bestv = fmax(bestv, row_rotate<2>(bestv));
+    bestv = fmax(bestv, row_rotate<1>(bestv));
+    const double band = bestv - kSupportTie;
+    bi = 0x7fffffff;  // (a lane without a vertex in the band: the largest index, never wins)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];  // (a clamped duplicate of vertex i0 changes no maximum)
-      if (v > bestv) bestv = v;
+    for (int r = kTrips - 1; r >= 0; --r)
+#pragma unroll
+      for (int u = 3; u >= 0; --u)
+        if (pv[r][u] >= band) bi = t + 4 * kTeamLanes * r + u * kTeamLanes;  // descending: the lane's lowest index is kept
+  } else {
+    for (int i0 = t; i0 < nvert; i0 += 4 * kTeamLanes) {
+      // four vertices per trip: their reads go out together
+      double x[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kTeamLanes < nvert ? i0 + u * kTeamLanes : i0;
+        x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
+      }
+      sched_fence();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];  // (a clamped duplicate of vertex i0 changes no maximum)
+        if (v > bestv) bestv = v;
+      }
     }
-  }
-  bestv = fmax(bestv, row_rotate<8>(bestv));
-  bestv = fmax(bestv, row_rotate<4>(bestv));
-  bestv = fmax(bestv, row_rotate<2>(bestv));
-  bestv = fmax(bestv, row_rotate<1>(bestv));
-  const double band = bestv - kSupportTie;
-  bi = 0x7fffffff;  // (a lane without a vertex in the band: the largest index, never wins)
-  for (int i0 = t; i0 < nvert && bi == 0x7fffffff; i0 += 4 * kTeamLanes) {
-    double x[4][3];
+    bestv = fmax(bestv, row_rotate<8>(bestv));
+    bestv = fmax(bestv, row_rotate<4>(bestv));
+    bestv = fmax(bestv, row_rotate<2>(bestv));
+    bestv = fmax(bestv, row_rotate<1>(bestv));
+    const double band = bestv - kSupportTie;
+    bi = 0x7fffffff;  // (a lane without a vertex in the band: the largest index, never wins)
+    for (int i0 = t; i0 < nvert && bi == 0x7fffffff; i0 += 4 * kTeamLanes) {
+      double x[4][3];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * kTeamLanes < nvert ? i0 + u * kTeamLanes : i0;
-      x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
-    }
-    sched_fence();
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * kTeamLanes < nvert ? i0 + u * kTeamLanes : i0;
+        x[u][0] = verts[3 * i]; x[u][1] = verts[3 * i + 1]; x[u][2] = verts[3 * i + 2];
+      }
+      sched_fence();
 #pragma unroll
-    for (int u = 3; u >= 0; --u) {
-      const int i = i0 + u * kTeamLanes;
-      const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];
-      if (i < nvert && v >= band) bi = i;  // descending u: the lowest index of the trip is kept
+      for (int u = 3; u >= 0; --u) {
+        const int i = i0 + u * kTeamLanes;
+        const double v = x[u][0] * l[0] + x[u][1] * l[1] + x[u][2] * l[2];
+        if (i < nvert && v >= band) bi = i;  // descending u: the lowest index of the trip is kept
+      }
     }
   }
 #define RCSH_ROT_MIN(N)                                                            \
@@ -385,12 +427,12 @@ RCSH_D int hull_support_index(const double* verts_, int nvert, const double* l) 
 #undef RCSH_ROT_MIN
   return bi;
 }
-template <bool TEAM = false>
+template <bool TEAM = false, bool ONE = false>
 RCSH_D void shape_support(const Shape& s, const double* dir, double* out) {
   double l[3], w[3] = {0, 0, 0};
   mulTv(s.R, dir, l);
   if (s.type == 0) {
-    const int bi = hull_support_index<TEAM>(s.verts, s.nvert, l);
+    const int bi = hull_support_index<TEAM, ONE>(s.verts, s.nvert, l);
     const double* vv = TEAM ? in_lds(s.verts) : s.verts;
     w[0] = vv[3 * bi]; w[1] = vv[3 * bi + 1]; w[2] = vv[3 * bi + 2];
   } else if (s.type == 1) {
@@ -404,11 +446,11 @@ RCSH_D void shape_support(const Shape& s, const double* dir, double* out) {
   out[0] += s.p[0]; out[1] += s.p[1]; out[2] += s.p[2];
 }
 struct MprPt { double v[3], v1[3], v2[3]; };
-template <bool TEAM = false>
+template <bool TEAM = false, bool ONE = false>
 RCSH_D void mpr_support(const Shape& a, const Shape& b, const double* dir, MprPt& o) {
   const double nd[3] = {-dir[0], -dir[1], -dir[2]};
-  shape_support<TEAM>(a, dir, o.v1);
-  shape_support<TEAM>(b, nd, o.v2);
+  shape_support<TEAM, ONE>(a, dir, o.v1);
+  shape_support<TEAM, ONE>(b, nd, o.v2);
   for (int k = 0; k < 3; ++k) o.v[k] = o.v1[k] - o.v2[k];
 }
 // Gilbert's iteration for "are the two shapes apart": C = A - B is convex, and a unit direction d with the support of C along it
@@ -420,7 +462,7 @@ RCSH_D void mpr_support(const Shape& a, const Shape& b, const double* dir, MprPt
 // iteration zigzags near contact) falls through to MPR, and `margin` keeps its verdicts away from the band of MPR's own tolerance.
 // `extra`: support queries spent AFTER the first proof on a better one (a larger gap: the slack a caller credits the pair with -- the
 // first direction that separates often proves a millimetre where the shapes are centimetres apart, and the pair is back a substep later).
-template <bool TEAM>
+template <bool TEAM, bool ONE = false>
 RCSH_D bool gilbert_apart(const Shape& A, const Shape& B, const double* x0, int iters, double margin, double* dir, double* gap, int extra = 0) {
   double x[3] = {x0[0], x0[1], x0[2]};
   bool proven = false;
@@ -430,7 +472,7 @@ RCSH_D bool gilbert_apart(const Shape& A, const Shape& B, const double* x0, int 
     const double inv = 1.0 / sqrt(n2);
     const double d[3] = {-x[0] * inv, -x[1] * inv, -x[2] * inv};
     MprPt s;
-    mpr_support<TEAM>(A, B, d, s);
+    mpr_support<TEAM, ONE>(A, B, d, s);
     const double h = dot3(s.v, d);
     if (h < -margin) {
       const bool better = !proven || -h > *gap, much = !proven || -h > 1.2 * *gap;
@@ -493,7 +535,7 @@ RCSH_D double origin_tri_dist2(const double* a, const double* b, const double* c
 // detection): depth and position are not computed -- the third phase of the refinement, which only sharpens them, is skipped --
 // and may be null.  kMprDepth: the depth too, not the position (the unresolved-contact check: pos may be null).
 constexpr int kMprFull = 0, kMprOverlap = 1, kMprDepth = 2;
-template <bool TEAM, int WANT = kMprFull>
+template <bool TEAM, int WANT = kMprFull, bool ONE = false>
 RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double* dir_out, double* pos) {
   constexpr bool OVERLAP_ONLY = WANT == kMprOverlap;
   constexpr double kTol = 1e-6;
@@ -504,7 +546,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   if (fabs(p0.v[0]) < kMinVal && fabs(p0.v[1]) < kMinVal && fabs(p0.v[2]) < kMinVal) p0.v[0] = 1e-5;
   double l = sqrt(dot3(p0.v, p0.v));
   for (int k = 0; k < 3; ++k) dir[k] = -p0.v[k] / l;
-  mpr_support<TEAM>(A, B, dir, p1);
+  mpr_support<TEAM, ONE>(A, B, dir, p1);
   // (a separating direction: `depth`, where the caller gave one, takes the support of A - B along it -- minus a lower bound of the distance)
   if (dot3(p1.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; if (WANT == kMprFull && depth) *depth = dot3(p1.v, dir); return 0; }
   cross3(p0.v, p1.v, dir);
@@ -518,7 +560,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
     return 1;
   }
   for (int k = 0; k < 3; ++k) dir[k] /= l;
-  mpr_support<TEAM>(A, B, dir, p2);
+  mpr_support<TEAM, ONE>(A, B, dir, p2);
   if (dot3(p2.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; if (WANT == kMprFull && depth) *depth = dot3(p2.v, dir); return 0; }
   for (int k = 0; k < 3; ++k) { va[k] = p1.v[k] - p0.v[k]; vb[k] = p2.v[k] - p0.v[k]; }
   cross3(va, vb, dir);
@@ -530,7 +572,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   }
   for (int guard = 0;; ++guard) {
     if (guard > 100) { dir_out[0] = dir_out[1] = dir_out[2] = 0.0; return 0; }
-    mpr_support<TEAM>(A, B, dir, p3);
+    mpr_support<TEAM, ONE>(A, B, dir, p3);
     if (dot3(p3.v, dir) <= 0) { dir_out[0] = dir[0]; dir_out[1] = dir[1]; dir_out[2] = dir[2]; if (WANT == kMprFull && depth) *depth = dot3(p3.v, dir); return 0; }
     bool cont = false;
     cross3(p1.v, p3.v, va);
@@ -548,7 +590,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   for (int it = 0;; ++it) {
     portal_dir(p1, p2, p3, dir);
     if (dot3(dir, p1.v) >= 0) break;
-    mpr_support<TEAM>(A, B, dir, p4);
+    mpr_support<TEAM, ONE>(A, B, dir, p4);
     const double dv4 = dot3(p4.v, dir);
     const double dmax = fmax(dot3(p1.v, dir), fmax(dot3(p2.v, dir), dot3(p3.v, dir)));
     if (dv4 < 0 || dv4 - dmax <= kTol || it > kIter) {
@@ -562,7 +604,7 @@ RCSH_D int mpr_penetration(const Shape& A, const Shape& B, double* depth, double
   if (OVERLAP_ONLY) return 1;  // (the origin is inside the portal: every exit of the loop below reports a penetration)
   for (int it = 0;; ++it) {
     portal_dir(p1, p2, p3, dir);
-    mpr_support<TEAM>(A, B, dir, p4);
+    mpr_support<TEAM, ONE>(A, B, dir, p4);
     const double dv4 = dot3(p4.v, dir);
     const double dmax = fmax(dot3(p1.v, dir), fmax(dot3(p2.v, dir), dot3(p3.v, dir)));
     if (dv4 - dmax <= kTol || it > kIter) {
@@ -1771,6 +1813,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
       }
       __syncthreads();  // (the polygons' LDS goes back to the hulls)
     }
+    TEAM_MARK(19)
     // ---- everything else: Gilbert's iteration, then the portal refinement.  The refinement is written for a TEAM of 16 lanes (they share
     // the vertex scans of a hull's support queries), and the wavefront has four: up to FOUR pairs are refined side by side, a team each --
     // the lead pair (the first one pending) and pending pairs that need no hull but the lead's, in the lead's places (a hand pressed
@@ -1870,6 +1913,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
         for (int k = lane; k < nb3; k += 64) hB[k] = vb[k];
       }
       __syncthreads();
+      TEAM_MARK(20)
       const int team = lane >> 4;
       const bool mine_pair = team < ngrp;
       const uint32_t mg = team == 0 ? grp_g[0] : (team == 1 ? grp_g[1] : (team == 2 ? grp_g[2] : grp_g[3]));
@@ -1897,15 +1941,17 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
         const int hot_mine = team == 0 ? grp_hot[0] : (team == 1 ? grp_hot[1] : (team == 2 ? grp_hot[2] : grp_hot[3]));
         // (more queries after the first proof, for a direction with a larger gap and so more slack, were tried in round 6: an escalated
         // environment is near contact, its pairs are due again whatever the direction proves -- 1.010 against 1.025 M on the 1000-step rollout)
-        apart = hot_mine ? false : gilbert_apart<true>(A, B, x0, 5, 1e-5, dg, &gap);
+        apart = hot_mine ? false : gilbert_apart<true, true>(A, B, x0, 5, 1e-5, dg, &gap);
+        TEAM_MARK(61)
         if (!apart) {
           TEAM_COUNT(23)
-          nc = mpr_penetration<true>(A, B, &depth, sn, spos0);
+          nc = mpr_penetration<true, kMprFull, true>(A, B, &depth, sn, spos0);
           // (apart after all: the refinement's separating direction proves a gap too -- without it the pair came back in every substep)
           if (nc == 0 && depth < 0.0) { apart = true; gap = -depth; }
         }
         if (!(depth > kSelfTouch)) nc = 0;
       }
+      TEAM_MARK(62)
       // the pairs' slack (the gap Gilbert's direction proves) goes to the lanes that hold them; the contacts to the record area's end
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1938,6 +1984,7 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
         nS += nck;
       }
       __syncthreads();  // (the stage is free again)
+      TEAM_MARK(63)
     }
     if (remg) {
 #pragma unroll

@@ -4,6 +4,7 @@
 
 namespace rcsh {
 
+constexpr int kHullMaxVerts = 152;  // a collision hull the contact table admits has at most this many vertices (model.cpp: build_contact_table)
 constexpr int kMaxCon = 48;      // contacts per environment, scenes with a free box (its kernel's LDS must let four workgroups share a CU)
 constexpr int kMaxConNoBox = 64; // ... without one (the contact-resolving kernel of per-environment escalation: a closed gripper pressed into the
                                  // arm brings 50-64 contacts, tools/oracle_ncon_probe.py; the contact phase gives a lane to each).  MuJoCo's list has

@@ -567,7 +567,7 @@ std::string build_contact_table(const HostModel& h, const DevModel& m, int plane
     }
     cg.vert_adr = h.geom_vertadr[g];
     cg.vert_num = type == 7 ? h.geom_vertnum[g] : 0;
-    if (cg.vert_num > 152) { drop(g, "collision hull with more than 152 vertices (the self-collision test stages two hulls in LDS)"); continue; }
+    if (cg.vert_num > kHullMaxVerts) { drop(g, "collision hull with more than 152 vertices (the self-collision test stages two hulls in LDS)"); continue; }
     const Xf t = xf_mul(rel[b], xf_from(&h.geom_pos[3 * g], &h.geom_quat[4 * g]));
     for (int k = 0; k < 3; ++k) { cg.pos[k] = t.p[k]; cg.size[k] = h.geom_size[3 * g + k]; }
     for (int k = 0; k < 9; ++k) cg.rot[k] = t.R[k];

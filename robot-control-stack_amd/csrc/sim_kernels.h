@@ -1381,7 +1381,10 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   // (the environment's record of remaining gaps -- check_team.h: "the slack" --: valid for the position this launch began on unless a
   // reset moved the robot; a step that is redone started from the copy's position, which is what the record still describes)
   float* const chk_slack = lp.chk.slack && live ? lp.chk.slack + (size_t)e * kSlackStride : nullptr;
-  const bool chk_use_slack = esc_role == 1 && !op.do_reset && op.check == 2;
+  // (the contact-resolving launch: its collision passes keep the same record, valid where the last substep began -- a position of this
+  // launch's path, which is all the check's slack test asks for; round 6 first looked at every pair there, 300-500k cycles of every
+  // escalated environment's launch, a quarter of a quiet one's)
+  const bool chk_use_slack = esc_role != 0 && !op.do_reset && op.check == 2;
   if (do_check) check_prefetch(lp.chk, lp.ctab, sep_in, live, chk_pf, chk_use_slack ? chk_slack : nullptr);
   {
     // per-component stores of the epilogue, one per lane instead of a dozen from the leader: the site link's frame of the last
@@ -1500,7 +1503,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       check_mv = lself;  // (the detection of the substep loop is over)
     }
     const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, chk_plane, sep_in, sep, P.n, chk_pf,
-                                                 chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0, esc_role != 0 ? chk_slack : nullptr, chk_use_slack, esc_role == 1 && op.check == 2);
+                                                 chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0, esc_role != 0 ? chk_slack : nullptr, chk_use_slack, op.check == 2 ? esc_role : 0);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif

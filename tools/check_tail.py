@@ -33,10 +33,12 @@ for t in range(skip, skip + steps):
 w = np.array([x[0] for x in worst]); m = np.array([x[1] for x in worst])
 print(f"per launch: mean wavefront {m.mean():.0f} cycles, longest wavefront mean {w.mean():.0f} (max {w.max()}); wavefronts leaving at the slack test {np.mean([x[2] / x[3] for x in worst]):.2f}")
 for x in worst[:12]:
-    print("  longest %d cycles: narrow rounds %d, Gilbert runs %d, start-frame queries %d, refinements %d, box rounds %d; staging %d cycles (%d rounds not prefetched), narrow phase %d, before it %d; last Gilbert run: pair %d margin %d um, remembered direction's gap %d um (999999999: none remembered)" % (x[0], *x[4], *x[5], *x[6]))
+    print("  longest %d cycles: narrow rounds %d, Gilbert runs %d, start-frame queries %d, refinements %d, box rounds %d; staging %d cycles (%d rounds not prefetched), narrow phase %d, before it %d; remembered direction's test %d cycles, shapes and slots before it %d, the taking teams' part of the rounds %d" % (x[0], *x[4], *x[5], *x[6]))
 
 L.rcsh_debug_check_hist(hist, 1)
 h = np.array(hist[:], dtype=np.float64) / steps
 print("wavefronts per launch by total cycles (8k bins):      ", " ".join("%d" % round(x) for x in h[:16]))
 print("wavefronts per launch by narrow-phase cycles (4k bins):", " ".join("%d" % round(x) for x in h[16:32]))
 print("wavefronts per launch by cycles before it (4k bins):   ", " ".join("%d" % round(x) for x in h[32:48]))
+print("wavefronts per launch by narrow-phase rounds (0..7+):  ", " ".join("%d" % round(x) for x in h[48:56]))
+print("  mean narrow-phase cycles of those:                  ", " ".join("%d" % round(h[56 + k] / max(h[48 + k], 1e-9)) for k in range(8)))

@@ -14,7 +14,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 win = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 venv = PU.make_vec_env(n, True)
-joints, grip = PU.synthetic_actions(n, steps, 0)
+joints, grip = PU.synthetic_actions(n, steps, int(os.environ.get("ESC_TIMING_SEED", "0")))  # (seed e: environment e of the 4096-environment rollout first)
+if os.environ.get("ESC_TIMING_GRIP"):  # e.g. 0: every gripper commanded shut (pads pressed together: the many-contact case in workgroup 0)
+    grip[:] = float(os.environ["ESC_TIMING_GRIP"])
 venv.reset()
 L = venv.sim._L
 out = (C.c_ulonglong * 96)()
@@ -22,7 +24,7 @@ def read():
     L.rcsh_debug_team_cycles96(out, 1)
     return np.array(out[:], dtype=np.float64)
 NAMES = {0: "pos stage", 1: "1", 2: "2", 3: "3", 4: "4", 15: "15", 5: "5", 6: "6", 7: "7", 8: "8", 9: "loop tail", 10: "epilogue+check", 11: "11", 12: "prologue12", 13: "13", 14: "14",
-         16: "collide before self", 17: "self broad", 18: "self narrow", 24: "before collide", 37: "link frames", 38: "lane per geom", 39: "hulls wavefront", 25: "floor/fastpath", 26: "compaction", 27: "rows/qacc_smooth/M", 28: "newton pre", 55: "x update", 48: "rows+grad",
+         16: "collide before self", 17: "self broad", 18: "self narrow rest", 19: "self box-box", 20: "hull staging", 61: "Gilbert", 62: "portal refinement", 63: "hull records", 24: "before collide", 37: "link frames", 38: "lane per geom", 39: "hulls wavefront", 25: "floor/fastpath", 26: "compaction", 27: "rows/qacc_smooth/M", 28: "newton pre", 55: "x update", 48: "rows+grad",
          49: "stiffness", 50: "Hessian", 51: "row loads", 52: "LDL+solves", 53: "pre linesearch", 54: "linesearch", 30: "forces/Y/K", 31: "noslip rest", 40: "ns rel", 41: "ns owner", 44: "ns slots", 32: "results"}
 try:  # the geom pairs of the self-contact stage (index -> geoms), for the slack test's examples
     import ctypes as _C
