@@ -27,6 +27,9 @@ namespace rcsh {
 
 #if defined(__HIP__)
 
+#ifdef RCSH_WAVE_TIMES
+__device__ unsigned long long g_wave_times[4][4096];  // sim_kernels.h: the lean launch's wavefronts, 100 MHz clock
+#endif
 #ifdef RCSH_CHECK_TAIL
 // development: how long the check takes per wavefront -- [0] sum of cycles, [1] wavefronts, [2] the longest, [3] wavefronts that left at the slack
 // test, then what the longest one did: [4] narrow-phase rounds, [5] Gilbert runs, [6] support queries at the start frames, [7] full refinements, [8] box rounds

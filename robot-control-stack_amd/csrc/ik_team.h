@@ -19,6 +19,7 @@ namespace rcsh {
 template <class T>
 struct IkTeamBlock {
   double J[T::NARM][6];
+  double A[22];  // the lower triangle of J J' + damping, an entry (or two) per lane
 };
 
 // desired site placement in world coordinates for a TCP target in robot coordinates: base * (target * tcp^-1)
@@ -135,6 +136,16 @@ RCSH_D bool clik_team(const DevModelHead& m, const LinkRec* links, IkTeamBlock<T
 #pragma unroll
   for (int k = 0; k < 3; ++k) site_pos[k] = m.site_pos[k];
   const int site_lane = (threadIdx.x & ~(kTeamLanes - 1)) + m.site_link;
+  // the lane's one or two entries of the normal equations' lower triangle (21 entries, row-major; 16 lanes)
+  int er[2] = {0, 0}, ec[2] = {0, 0};
+  static_assert(kTeamLanes == 16, "21 entries over 16 lanes: two trips");
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int k = t + kTeamLanes * u < 21 ? t + kTeamLanes * u : 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+      if (k >= r * (r + 1) / 2) { er[u] = r; ec[u] = k - r * (r + 1) / 2; }
+  }
   bool active = run, success = false;
   int it = 0;
   for (int i = 0; __ballot(active) != 0; ++i) {
@@ -183,11 +194,13 @@ RCSH_D bool clik_team(const DevModelHead& m, const LinkRec* links, IkTeamBlock<T
         col[k] = Rs[k] * lin[0] + Rs[3 + k] * lin[1] + Rs[6 + k] * lin[2];
         col[3 + k] = Rs[k] * ax[0] + Rs[3 + k] * ax[1] + Rs[6 + k] * ax[2];
       }
+      // (Jlog = [[A, B], [0, A]]: the zero block's nine products, which IEEE arithmetic would not let the compiler drop, are left out --
+      // each added an exact zero)
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         double s = 0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s += Jlog[6 * r + k] * col[k];
+        for (int k = r < 3 ? 0 : 3; k < 6; ++k) s += Jlog[6 * r + k] * col[k];
         JJ[r] = -s;
       }
     }
@@ -196,21 +209,27 @@ RCSH_D bool clik_team(const DevModelHead& m, const LinkRec* links, IkTeamBlock<T
       for (int r = 0; r < 6; ++r) blk.J[tl][r] = JJ[r];
     }
     team_sync();
+    // J J' + damping: 21 sums of NARM products.  Every lane formed all of them through round 6's first half (147 multiply-adds and 42
+    // LDS reads a lane and iteration, a seventh of the iteration's instructions); now a lane forms its one or two entries -- the same
+    // products summed in the same order -- and the triangle goes round through LDS.
+    {
+      double e0 = 0.0, e1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        e0 += blk.J[j][er[0]] * blk.J[j][ec[0]];
+        e1 += blk.J[j][er[1]] * blk.J[j][ec[1]];
+      }
+      if (er[0] == ec[0]) e0 += kIkDamp;
+      if (er[1] == ec[1]) e1 += kIkDamp;
+      blk.A[t] = e0;
+      if (t + kTeamLanes < 21) blk.A[t + kTeamLanes] = e1;
+    }
+    team_sync();
     double JJt[36];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) JJt[k] = 0.0;
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      double c6[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) c6[r] = blk.J[j][r];
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c <= r; ++c) JJt[6 * r + c] += c6[r] * c6[c];
-    }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) JJt[6 * r + r] += kIkDamp;
+      for (int c = 0; c <= r; ++c) JJt[6 * r + c] = blk.A[r * (r + 1) / 2 + c];
     double y[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) y[k] = err[k];

@@ -2682,6 +2682,12 @@ extern "C" int rcsh_debug_check_tail(unsigned long long* out16, int clear) {
   return 0;
 }
 #endif
+#ifdef RCSH_WAVE_TIMES
+extern "C" int rcsh_debug_wave_times(unsigned long long* out4x4096) {
+  hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out4x4096, HIP_SYMBOL(rcsh::g_wave_times), sizeof(unsigned long long) * 4 * 4096) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef RCSH_CHECK_TAIL
 extern "C" int rcsh_debug_check_hist(unsigned long long* out64, int clear) {
   hipDeviceSynchronize();

@@ -843,6 +843,12 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   const RunOp& op = lop;
   const CollTable& lc = lp.coll;
   TEAM_CLOCK_START()
+#ifdef RCSH_WAVE_TIMES
+  // development (tools/wave_times.py): when this wavefront started, left its substep loop, entered the end-of-launch check and ended --
+  // the constant 100 MHz clock all XCDs share
+  const unsigned long long wt0_ = __builtin_amdgcn_s_memrealtime();
+  unsigned long long wt1_ = 0, wt2_ = 0;
+#endif
 #ifdef RCSH_PHASE_TIMING
   const unsigned long long wg_clock0 = __builtin_readcyclecounter();
   if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) s_wg_acc[k_] = 0;
@@ -1373,6 +1379,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     for (int c = 0; c < rend_ncam; ++c) lp.rend.last[(size_t)c * P.n + e] = lrend[team][c];
     lp.rend.count[e] = (int32_t)lrend[team][kMaxRateCams + 1];
   }
+#ifdef RCSH_WAVE_TIMES
+  wt1_ = __builtin_amdgcn_s_memrealtime();
+#endif
   // what the end-of-launch contact check reads from memory is asked for now: it arrives while the leader lanes run the epilogue
   // (the contact-resolving launch of per-environment escalation asks for its environments' way BACK: the floor counts there too)
   const bool chk_plane = !CON || esc_role == 2;
@@ -1502,6 +1511,9 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       static_assert(kSelfF * kTeams + kSelfStage + kSelfCache + kSelfTag >= check_mv_doubles(T::NL), "the travel tables fit where the detection kept its frames");
       check_mv = lself;  // (the detection of the substep loop is over)
     }
+#ifdef RCSH_WAVE_TIMES
+    wt2_ = __builtin_amdgcn_s_memrealtime();
+#endif
     const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, chk_plane, sep_in, sep, P.n, chk_pf,
                                                  chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0, esc_role != 0 ? chk_slack : nullptr, chk_use_slack, op.check == 2 ? esc_role : 0);
 #ifdef RCSH_CHECK_DEBUG
@@ -1537,6 +1549,12 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   }
   TEAM_MARK(10)
   TEAM_CLOCK_FLUSH()
+#ifdef RCSH_WAVE_TIMES
+  if (esc_role == 1 && threadIdx.x == 0 && blockIdx.x < 4096) {
+    g_wave_times[0][blockIdx.x] = wt0_; g_wave_times[1][blockIdx.x] = wt1_; g_wave_times[2][blockIdx.x] = wt2_;
+    g_wave_times[3][blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 #ifdef RCSH_PHASE_TIMING
   if (CON && esc_role == 2 && threadIdx.x == 0) {  // this workgroup's share of the contact-resolving launch: sum, count, worst
     const unsigned long long dt = __builtin_readcyclecounter() - wg_clock0;
