@@ -34,10 +34,10 @@ __device__ unsigned long long g_wave_times[4][4096];  // sim_kernels.h: the lean
 // development: how long the check takes per wavefront -- [0] sum of cycles, [1] wavefronts, [2] the longest, [3] wavefronts that left at the slack
 // test, then what the longest one did: [4] narrow-phase rounds, [5] Gilbert runs, [6] support queries at the start frames, [7] full refinements, [8] box rounds
 __device__ unsigned long long g_chk_tail[16];
-__device__ unsigned long long g_chk_hist[64];  // [0..15] wavefronts by total cycles (8k bins), [16..31] by narrow-phase cycles (4k bins), [32..47] by cycles before the narrow phase (4k bins), [48..55] by narrow-phase rounds (0..7+), [56..63] their narrow-phase cycles summed
+__device__ unsigned long long g_chk_hist[64];  // [0..15] wavefronts by total cycles (8k bins), [16..31] by narrow-phase cycles (4k bins), [32..47] by cycles before the narrow phase (4k bins), [48..63] ENVIRONMENTS of the lean launch by the narrow-phase rounds their team took part in (0..15+)
 #define TAIL_COUNT(i) { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&tail_sh_[i], 1u); }
 #define TAIL_END(early) { if ((threadIdx.x & 63) == 0) { const unsigned long long dt_ = __builtin_readcyclecounter() - tail_t0_; atomicAdd(&g_chk_tail[0], dt_); atomicAdd(&g_chk_tail[1], 1ull); \
-    { unsigned long long b_ = dt_ / 8192; atomicAdd(&g_chk_hist[b_ > 15 ? 15 : b_], 1ull); b_ = tail_nar_ / 4096; atomicAdd(&g_chk_hist[16 + (b_ > 15 ? 15 : b_)], 1ull); b_ = tail_pre_ / 4096; atomicAdd(&g_chk_hist[32 + (b_ > 15 ? 15 : b_)], 1ull); b_ = tail_rounds_ > 7 ? 7 : tail_rounds_; atomicAdd(&g_chk_hist[48 + b_], 1ull); atomicAdd(&g_chk_hist[56 + b_], tail_nar_); } \
+    { unsigned long long b_ = dt_ / 8192; atomicAdd(&g_chk_hist[b_ > 15 ? 15 : b_], 1ull); b_ = tail_nar_ / 4096; atomicAdd(&g_chk_hist[16 + (b_ > 15 ? 15 : b_)], 1ull); b_ = tail_pre_ / 4096; atomicAdd(&g_chk_hist[32 + (b_ > 15 ? 15 : b_)], 1ull); } \
     if (early) atomicAdd(&g_chk_tail[3], 1ull); if (atomicMax(&g_chk_tail[2], dt_) < dt_) { for (int k_ = 0; k_ < 5; ++k_) g_chk_tail[4 + k_] = tail_sh_[k_]; g_chk_tail[9] = tail_stage_; g_chk_tail[10] = tail_miss_; g_chk_tail[11] = tail_nar_; g_chk_tail[12] = tail_pre_; g_chk_tail[13] = tail_sh_[5]; g_chk_tail[14] = tail_sh_[6]; g_chk_tail[15] = tail_sh_[7]; } } }
 #else
 #define TAIL_COUNT(i)
@@ -646,13 +646,14 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
     const int src = __ffsll((long long)pc) - 1;  // wave-uniform
     TAIL_COUNT(0)
-#ifdef RCSH_CHECK_TAIL
-    tail_rounds_ += 1;
-#endif
+
     const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cmask, src);
     const int u = __ffs((int)sm) - 1, t1 = src & (kTeamLanes - 1);
     const bool holder = t == t1 && ((cmask >> u) & 1u);
     const bool take = team_ballot(holder) != 0;
+#ifdef RCSH_CHECK_TAIL
+    tail_rounds_ += take ? 1 : 0;
+#endif
     if (holder) cmask &= ~(1u << u);
     const int pidx = t1 + kTeamLanes * u;
     uint32_t gg = 0;
@@ -863,6 +864,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   CHK_MARK(5)
 #ifdef RCSH_CHECK_TAIL
   tail_nar_ = __builtin_readcyclecounter() - tail_t1_;
+  if (keep_slack == 1 && live && t == 0) atomicAdd(&g_chk_hist[48 + (tail_rounds_ > 15 ? 15 : tail_rounds_)], 1ull);
 #endif
   __syncthreads();
   if (t < kCheckSep && live) sep[(size_t)t * n_env] = sepw;

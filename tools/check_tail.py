@@ -40,5 +40,4 @@ h = np.array(hist[:], dtype=np.float64) / steps
 print("wavefronts per launch by total cycles (8k bins):      ", " ".join("%d" % round(x) for x in h[:16]))
 print("wavefronts per launch by narrow-phase cycles (4k bins):", " ".join("%d" % round(x) for x in h[16:32]))
 print("wavefronts per launch by cycles before it (4k bins):   ", " ".join("%d" % round(x) for x in h[32:48]))
-print("wavefronts per launch by narrow-phase rounds (0..7+):  ", " ".join("%d" % round(x) for x in h[48:56]))
-print("  mean narrow-phase cycles of those:                  ", " ".join("%d" % round(h[56 + k] / max(h[48 + k], 1e-9)) for k in range(8)))
+print("environments of the lean launch per launch by narrow-phase rounds (0..15+):", " ".join("%.1f" % x for x in h[48:64]))
