@@ -311,12 +311,14 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 // and q0 its position when the launch began.  slack_env: the environment's record of CheckTable::slack (null: none), use_slack: the
 // gaps it holds are valid lower bounds for a position of this launch (see "the slack" below: the one it began on -- the lean launch --
 // or the one its last substep began on -- the contact-resolving launch, whose collision passes keep the record), keep_slack: the
-// pairs' gaps this check ends with are written back (1: unless the environment is found in contact, the lean launch; 2: always).  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
+// pairs' gaps this check ends with are written back (1: the lean launch; 2: the contact-resolving launch -- both unless the
+// environment is found in contact; 2 also stops looking once every environment of the wavefront is: the answer is all it is asked for).
+// known_hit (team-uniform): the caller knows the answer already -- a substep of this launch resolved a contact.  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
 // Every lane of the wavefront calls this; returns, on every lane of a team, whether the team's environment is in contact.
 template <class T, class CollT>
 RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& tab, const CollT& lc, const LinkRec* links, double* frames,
                                      double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf,
-                                     double dend, double psum, double* mv, double q0, float* slack_env, bool use_slack, int keep_slack) {
+                                     double dend, double psum, double* mv, double q0, float* slack_env, bool use_slack, int keep_slack, bool known_hit = false) {
   constexpr int NL = T::NL;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const bool valid = t < NL;
@@ -406,6 +408,14 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     }
   }
   __syncthreads();
+  if (keep_slack == 2 && __ballot(live && !known_hit) == 0) {
+    // the contact-resolving launch, every environment of the wavefront in contact during the launch: it stays whatever a certificate
+    // says.  The pairs' record is the collision passes' (valid where the last substep began, which is where their next pass charges
+    // from); the links' heights above the floor, which only this check keeps, are unknown from here on
+    if (slack_env && live && t < NL && check_plane) slack_env[kSlackLink + t] = 0.0f;
+    TAIL_END(true)
+    return known_hit;
+  }
   double mj[kCheckPer], mjP[kCheckPer];  // the margins of the lane's pairs (of dend, of psum)
 #pragma unroll
   for (int j = 0; j < kCheckPer; ++j) {
@@ -520,7 +530,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   }
   __syncthreads();
   CHK_MARK(1)
-  bool mine = false;
+  bool mine = known_hit && live;
   // ---- the floor against the sample points of the link's collision geoms (as the DET launches test it)
   if (dueL) {
     const double* nrm = lc.plane_n;
@@ -581,7 +591,11 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   CHK_MARK(3)
   uint32_t cmask = 0;
   if (ck.pad & 2) smask = 0;
+  // (the contact-resolving launch is asked one thing -- may the environment go back -- and has its answer with the first pair that
+  // fails: every live team has one -> nothing more to look at; what was not looked at is not written back, see the end)
+  auto all_hit = [&]() { return keep_slack == 2 && __ballot(live && team_ballot(mine) == 0) == 0; };
   while (__ballot(smask != 0)) {
+    if (all_hit()) break;
     TAIL_COUNT(4)
     if (smask) {
       const int j = __ffs((int)smask) - 1;
@@ -644,6 +658,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
 #endif
   if (ck.pad & 1) cmask = 0;
   for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
+    if (all_hit()) break;
     const int src = __ffsll((long long)pc) - 1;  // wave-uniform
     TAIL_COUNT(0)
 
@@ -869,12 +884,14 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   __syncthreads();
   if (t < kCheckSep && live) sep[(size_t)t * n_env] = sepw;
   const bool hit = team_ballot(mine) != 0;
-  // the slack goes back -- unless the lean launch's environment is flagged: its launch is redone from the position it BEGAN on, which is
-  // what the record as it stands describes.  (The contact-resolving launch, keep_slack 2, redoes nothing: what its check ends with --
-  // every pair either charged the launch's whole path or looked at where the launch ended -- describes its last position, which the
-  // record its collision passes keep, valid where the last SUBSTEP began, does not.)
+  // the slack goes back -- unless the environment is found in contact.  The lean launch's is then redone from the position the launch
+  // BEGAN on, which is what the record as it stands describes; the contact-resolving launch's stays there, and the record its collision
+  // passes keep (valid where the last SUBSTEP began, and charged from there by their next pass) is the one to go on with -- this check may
+  // not even have looked at every due pair (all_hit).  An environment that goes BACK has had every due pair looked at where the launch
+  // ended and every other one charged the launch's whole path: that describes the launch's last position, which is what the lean launch
+  // will read it as.  The links' heights above the floor only this check keeps: they go back either way.
   if (slack_env && live && (!hit || keep_slack == 2) && !(ck.pad & 16)) {  // (pad bit 4: a timing experiment -- RCSH_CHECK_SKIP, rcs_hip.hip)
-    if (keep_slack) {
+    if (keep_slack && !hit) {
 #pragma unroll
       for (int j = 0; j < kCheckPer; ++j)
         if (t + kTeamLanes * j < npair) slack_env[t + kTeamLanes * j] = rem[j];

@@ -1515,7 +1515,8 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     wt2_ = __builtin_amdgcn_s_memrealtime();
 #endif
     const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, chk_plane, sep_in, sep, P.n, chk_pf,
-                                                 chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0, esc_role != 0 ? chk_slack : nullptr, chk_use_slack, op.check == 2 ? esc_role : 0);
+                                                 chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0, esc_role != 0 ? chk_slack : nullptr, chk_use_slack, op.check == 2 ? esc_role : 0,
+                                                 CON && esc_role == 2 && team_ballot(esc_contact) != 0);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif
