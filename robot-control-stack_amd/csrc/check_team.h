@@ -149,7 +149,7 @@ RCSH_D double obb_face_sep(const double* Ra, const double* ca, const double* ha,
 // charged with it half the batch failed the certificate for a dozen steps after every reset.
 // the six face-normal separations of two oriented boxes, and |n . e| for two vectors e (world) per normal
 RCSH_D void obb_face_seps6(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb, double* sep,
-                           const double* ep, const double* em, double* np6, double* nm6) {
+                           const double* ep, const double* em, double* np6, double* nm6, double* cs6 = nullptr) {
   double C[9], A[9], tv[3];
   const double d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
   mulTv(Ra, d, tv);
@@ -172,6 +172,17 @@ RCSH_D void obb_face_seps6(const double* Ra, const double* ca, const double* ha,
     mulTv(Ra, ep, u0); mulTv(Ra, em, u1); mulTv(Rb, ep, w0); mulTv(Rb, em, w1);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { np6[i] = fabs(u0[i]); nm6[i] = fabs(u1[i]); np6[3 + i] = fabs(w0[i]); nm6[3 + i] = fabs(w1[i]); }
+    if (cs6) {
+      // what a unit of translation of B against A along ep adds to each separation: the normal's component of ep, the normal pointing
+      // from A to B (|x| >= sgn(x0) x: the straight line through the separation now is a lower bound of it after any translation)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) cs6[i] = tv[i] >= 0.0 ? u0[i] : -u0[i];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double tw = tv[0] * C[j] + tv[1] * C[3 + j] + tv[2] * C[6 + j];
+        cs6[3 + j] = tw >= 0.0 ? w0[j] : -w0[j];
+      }
+    }
   }
 }
 // sl: the two fingers' slide axes (world, at the launch's end) a0 = sl[0..2], a1 = sl[4..6]; how far the opening o+ = q0 + q1 / the common
@@ -181,11 +192,21 @@ RCSH_D void obb_face_seps6(const double* Ra, const double* ca, const double* ha,
 // path along it (touching at an end, to within `touch`, is no contact).  Double precision throughout and the slides' own axes, no lever:
 // fingers that open from pads touching EXACTLY -- every reset leaves them so -- end the first step with a gap that EQUALS the opening's
 // travel; a margin rounded up by one part in a million failed half the batch there.
+// ... or -- the ENVELOPE -- no single normal does, but at every opening the launch went through some normal separates the boxes:
+// the geoms' relative motion is a translation along ep by the change of the opening (and along em by that of the common shift, charged
+// as a margin), so each normal's separation is a straight line in the opening -- its value at the launch's end, slope cs6 --, the
+// largest of the six a convex function of it, and its minimum over the interval of openings the launch covered (sl[10], sl[11]: how
+// far below / above its final value the opening has been) sits at an end of the interval or where two lines cross.  (Adjacent pads of
+// the two fingertips, tilted a little against the slides: their facing edges touch -- a separation of 0.0 along the finger at rest, and
+// what the slides' jitter takes from it -- while tens of micrometres separate them ACROSS the gap whenever it does; in
+// step_until_convergence, whose launches are hundreds of substeps long, no single normal certified them and 1900 of 4096 environments
+// stayed on the contact-resolving launch without ever meeting a contact.)  sAB: +1 when A hangs on the first finger's slide (a0) and B on
+// the second's, -1 the other way round.
 RCSH_D bool finger_boxes_certified(const double* Ra, const double* ca, const double* ha, const double* Rb, const double* cb, const double* hb,
-                                   const double* Ra0, const double* ca0, const double* Rb0, const double* cb0, const double* sl, double touch) {
+                                   const double* Ra0, const double* ca0, const double* Rb0, const double* cb0, const double* sl, double touch, double sAB) {
   const double ep[3] = {0.5 * (sl[4] - sl[0]), 0.5 * (sl[5] - sl[1]), 0.5 * (sl[6] - sl[2])}, em[3] = {0.5 * (sl[4] + sl[0]), 0.5 * (sl[5] + sl[1]), 0.5 * (sl[6] + sl[2])};
-  double s1[6], s0[6], np6[6], nm6[6];
-  obb_face_seps6(Ra, ca, ha, Rb, cb, hb, s1, ep, em, np6, nm6);
+  double s1[6], s0[6], np6[6], nm6[6], cs6[6];
+  obb_face_seps6(Ra, ca, ha, Rb, cb, hb, s1, ep, em, np6, nm6, cs6);
   obb_face_seps6(Ra0, ca0, ha, Rb0, cb0, hb, s0, nullptr, nullptr, nullptr, nullptr);
   bool ok = false;
 #pragma unroll
@@ -193,7 +214,30 @@ RCSH_D bool finger_boxes_certified(const double* Ra, const double* ca, const dou
     const double mD = np6[k] * sl[3] + nm6[k] * sl[7], mP = np6[k] * sl[8] + nm6[k] * sl[9];
     ok = ok || s1[k] - mD > -touch || (s0[k] > -touch && s1[k] > -touch && s0[k] + s1[k] > mP - 2.0 * touch);
   }
-  return ok;
+  if (ok) return true;
+  const double lo = sl[10], hi = sl[11];
+  if (!(lo > -1e300 && hi < 1e300 && sl[7] < 1e300)) return false;
+  double b[6], c[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { b[k] = s1[k] - nm6[k] * sl[7]; c[k] = sAB * cs6[k]; }
+  auto env = [&](double x) {
+    double f = b[0] + c[0] * x;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) f = fmax(f, b[k] + c[k] * x);
+    return f;
+  };
+  double fmin_ = fmin(env(lo), env(hi));
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) {
+      const double dc = c[i] - c[j];
+      if (fabs(dc) > 1e-12) {
+        const double x = (b[j] - b[i]) / dc;
+        if (x > lo && x < hi) fmin_ = fmin(fmin_, env(x));
+      }
+    }
+  return fmin_ > -touch;
 }
 
 // The support VALUE of a shape along a direction -- the largest x . dir over its points -- computed by the 16 lanes of a team on
@@ -313,12 +357,14 @@ RCSH_D void check_prefetch(const CheckTable& ck, const ContactTable& tab, double
 // or the one its last substep began on -- the contact-resolving launch, whose collision passes keep the record), keep_slack: the
 // pairs' gaps this check ends with are written back (1: the lean launch; 2: the contact-resolving launch -- both unless the
 // environment is found in contact; 2 also stops looking once every environment of the wavefront is: the answer is all it is asked for).
-// known_hit (team-uniform): the caller knows the answer already -- a substep of this launch resolved a contact.  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
+// known_hit (team-uniform): the caller knows the answer already -- a substep of this launch resolved a contact.  dlo / dhi: how far
+// below / above its value at the launch's end the lane's joint has been (<= 0, >= 0; dend is the larger of the two sizes).  q: the lane's joint position (lane t < NL).  sep: the environment's SEP fields in the state ([8][n], at e).
 // Every lane of the wavefront calls this; returns, on every lane of a team, whether the team's environment is in contact.
 template <class T, class CollT>
 RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& tab, const CollT& lc, const LinkRec* links, double* frames,
                                      double* work, double q, bool live, bool check_plane, double sep_in, double* sep, int n_env, const CheckPrefetch& pf,
-                                     double dend, double psum, double* mv, double q0, float* slack_env, bool use_slack, int keep_slack, bool known_hit = false) {
+                                     double dend, double psum, double* mv, double q0, float* slack_env, bool use_slack, int keep_slack, bool known_hit = false,
+                                     double dlo = 0.0, double dhi = 0.0) {
   constexpr int NL = T::NL;
   const int lane = threadIdx.x & 63, t = lane & (kTeamLanes - 1), team = lane / kTeamLanes;
   const bool valid = t < NL;
@@ -488,6 +534,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     sl[0] = axw[0]; sl[1] = axw[1]; sl[2] = axw[2];
     sl[3] = is_slide ? dend : INFINITY;  // (a hinged finger: no such certificate)
     slides[8 + t - T::NARM] = is_slide ? psum : INFINITY;
+    if (t == T::NARM) { slides[10] = is_slide ? dlo : -INFINITY; slides[11] = is_slide ? dhi : INFINITY; }  // (the opening's lane)
   }
   if (team == 0) {
 #pragma unroll
@@ -625,7 +672,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
           self_box_world(F0, la, gbox + 12 * g0, gbox + 12 * g0 + 3, ca0, Ra0);
           self_box_world(F0, lb, gbox + 12 * g1, gbox + 12 * g1 + 3, cb0, Rb0);
           if (finger_pair) {
-            settled = finger_boxes_certified(Ra, ca, ha, Rb, cb, hb, Ra0, ca0, Rb0, cb0, slides, kCheckTouch);
+            settled = finger_boxes_certified(Ra, ca, ha, Rb, cb, hb, Ra0, ca0, Rb0, cb0, slides, kCheckTouch, la == T::NARM ? 1.0 : -1.0);
           } else {
             const double sep0 = obb_face_sep(Ra0, ca0, ha, Rb0, cb0, hb);
             settled = sep0 > -kCheckTouch && sep0 + sep1 > mmP - 2.0 * kCheckTouch;
@@ -760,6 +807,25 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
           const double np_ = fabs(0.5 * (dot3(dwn, slides + 4) - dot3(dwn, slides))), nm_ = fabs(0.5 * (dot3(dwn, slides + 4) + dot3(dwn, slides)));
           const double mDd = np_ * slides[3] + nm_ * slides[7], mPd = np_ * slides[8] + nm_ * slides[9];
           if (mDd < mD) { mD = mDd; mP = mPd; }  // (a hinged finger: infinite -- the levers' margins stay)
+        }
+        else if (mteam > 0.0 && !(g1 > mD - kCheckTouch)) {
+          // second chance: the levers of these two GEOMS instead of their links' (a link's lever is its farthest geom's; kLevGeom).  The
+          // joints between the two links, each charged its travel: not for chains through the fingers' slides, whose travel entries are
+          // the gripper's opening and shift
+          const int cc_ = (int)((gg >> 16) & 0xff) - 1;
+          const uint32_t ja = a.link >= 0 ? anc_mask<T>(a.link) & ~anc_mask<T>(cc_) : 0u, jb = b.link >= 0 ? anc_mask<T>(b.link) & ~anc_mask<T>(cc_) : 0u;
+          if (!T::GRIP || ((ja | jb) >> T::NARM) == 0u) {
+            const float* lg = ck.lev + kLevGeom;
+            const int ga_ = (int)(gg & 0xff), gb_ = (int)((gg >> 8) & 0xff);
+            double sD = 0.0, sP = 0.0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+              const double w = ((ja >> j) & 1u ? (double)lg[32 * j + ga_] : 0.0) + ((jb >> j) & 1u ? (double)lg[32 * j + gb_] : 0.0);
+              sD += w * travel[j]; sP += w * travelP[j];
+            }
+            sD = sD * 1.000001 + 1e-12; sP = sP * 1.000001 + 1e-12;
+            mD = fmin(mD, sD); mP = fmin(mP, sP);
+          }
         }
         if (g1 > mD - kCheckTouch) return true;
         if (!(g1 > -kCheckTouch)) return false;

@@ -64,10 +64,12 @@ constexpr int kSlackFloor = kMaxCheckPairs + 24;  // ... then the geoms' remaini
 constexpr int kSlackLink = kSlackFloor + 32;      // ... then, per LINK, what is left of its sample points' height above the floor (the lean launch's check)
 constexpr int kSlackStride = kSlackLink + 16;     // floats per environment: the pairs' remaining gaps, then the joints seen last (12 doubles), ...
 static_assert(kMaxCGeom <= 32, "a float per collision geom");
+constexpr int kLevGeom = 144;  // CheckTable::lev: where the per-geom levers begin
 struct CheckTable {
   const CheckEntry* ent;
   const CheckGeom* geoms;
-  const float* lev; // [12][12] lev[j][l]: how far one radian (hinge) / metre (slide) of joint j moves a point of a geom ON link l (host: build_self_levers)
+  const float* lev; // [12][12] lev[j][l]: how far one radian (hinge) / metre (slide) of joint j moves a point of a geom ON link l (host: build_self_levers);
+                    // behind it (kLevGeom) [12][32]: the same for the points of geom g alone
   float* slack;    // [n][kSlackStride] self-contact stage of the contact phase (contact_team.h: contact_collide); null: every pair, every substep
   int32_t npair, ngeom;
   int32_t plane_points;  // the scene has a floor plane and collision geoms with sample points to test against it

@@ -72,7 +72,7 @@ struct rcsh_sim {
   std::vector<CheckGeom> chk_geoms;
   CheckGeom* d_chk_geoms = nullptr;
   CheckEntry* d_chk_ent = nullptr;
-  float link_lever[12 * 12] = {0};  // contact_types.h: CheckTable::lev
+  float link_lever[12 * 12 + 12 * 32] = {0};  // contact_types.h: CheckTable::lev ([joint][link]), then the same per GEOM ([joint][geom], kLevGeom)
   float* d_lev = nullptr;
   float* d_slack = nullptr;          // [n][kSlackStride]: the self-contact stage's remaining gaps per pair + the joints it saw last (CheckTable::slack)
   int chk_unchecked = 0;             // admitted geom pairs past kMaxCheckPairs: neither checked at the end of a launch nor resolved as self contacts
@@ -476,12 +476,31 @@ void build_self_levers(rcsh_sim* s) {
   // test charges a geom pair / a geom above the floor with.  The isotropic lever above takes the whole arm's reach for joint 1; the pair
   // (link 0, link 2), whose hulls stay a centimetre apart in every pose, sits 0.2 m from that axis: charged with 1.2 m per radian it was
   // due in nearly every substep, and with it the whole collision pass.
-  for (int k = 0; k < 144; ++k) s->link_lever[k] = 0.0f;
+  for (int k = 0; k < 144 + 12 * 32; ++k) s->link_lever[k] = 0.0f;
   for (int l = 0; l < nl; ++l) {
     double acc = reach[l];  // from link l's anchor to the farthest point of a geom on l
     for (int j = l; j >= 0; j = parent(j)) {
       // acc: from joint j's anchor to the farthest point of a geom on l, over every configuration of the joints in between
       s->link_lever[j * 12 + l] = (float)(m.jtype[j] == kSlide ? 1.0 : (1.01 * (acc + stroke[l]) + 1e-3) * 1.000001);
+      acc += hop[j] + stroke[j];
+    }
+  }
+  // ... and per GEOM (kLevGeom + j * 32 + g): the same bound for the points of geom g alone.  A link's lever is its farthest geom's: link 7
+  // carries the flange's hull AND the hand's, 0.2 m from its joint, and the pair (link 5's hull, the flange's hull) -- 14-17 mm apart in
+  // every pose -- was charged the hand's reach: in step_until_convergence, whose launches move a joint by up to five degrees, its
+  // certificate failed in a third of the batch at every step (check_team.h: the narrow phase's second chance).
+  static_assert(kMaxCGeom <= 32, "a column per collision geom");
+  for (size_t gi = 0; gi < s->cgeoms.size() && gi < 32; ++gi) {
+    const auto& g = s->cgeoms[gi];
+    if (g.link < 0) continue;
+    double c[3], h[3] = {g.size[0], g.size[1], g.size[2]}, lc[3] = {0, 0, 0};
+    if (g.type == 7) for (int k = 0; k < 3; ++k) { lc[k] = g.aabb_c[k]; h[k] = g.aabb_h[k]; }
+    else if (g.type == 3) { h[0] = h[1] = g.size[0]; h[2] = g.size[0] + g.size[1]; }
+    for (int k = 0; k < 3; ++k) c[k] = g.rot[3 * k] * lc[0] + g.rot[3 * k + 1] * lc[1] + g.rot[3 * k + 2] * lc[2] + g.pos[k] - m.jpos[g.link][k];
+    double acc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + std::sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+    const int l = g.link;
+    for (int j = l; j >= 0; j = parent(j)) {
+      s->link_lever[144 + j * 32 + (int)gi] = (float)(m.jtype[j] == kSlide ? 1.0 : (1.01 * (acc + stroke[l]) + 1e-3) * 1.000001);
       acc += hop[j] + stroke[j];
     }
   }

@@ -1476,7 +1476,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     // goes back to the lean launch when the lean launch's certificate would have passed this one -- no wider margin: an environment that
     // goes back one step too early costs its redone step what staying would have cost, and a gripper opening from shut pads (gap at the
     // start exactly 0, gap at the end exactly its travel) passes a test with the travel itself and never one with twice the travel)
-    double chk_dend = 0.0, chk_psum = 0.0;
+    double chk_dend = 0.0, chk_psum = 0.0, chk_dlo = 0.0, chk_dhi = 0.0;
     {
       // (the fingers' lanes: the same for the opening / the common shift -- their values at the launch's two ends from both fingers' lanes)
       double w_final = q_final, w0 = chk_q0;
@@ -1489,6 +1489,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
       if (op.check == 2 && live && t < T::NL && !chk_first) {
         const double lo = fmin(chk_qmin, w_final), hi = fmax(chk_qmax, w_final);
         chk_dend = fmax(hi - w_final, w_final - lo);
+        chk_dlo = lo - w_final; chk_dhi = hi - w_final;
         chk_psum = 2.0 * (hi - lo) - fabs(w_final - w0);
       }
     }
@@ -1516,7 +1517,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
 #endif
     const bool hit = unresolved_contact_check<T>(lp.chk, lp.ctab, lp.coll, llinks, reinterpret_cast<double*>(&llinks[0]), check_work, q_final, checked, chk_plane, sep_in, sep, P.n, chk_pf,
                                                  chk_dend, chk_psum, check_mv, chk_first ? q_final : chk_q0, esc_role != 0 ? chk_slack : nullptr, chk_use_slack, op.check == 2 ? esc_role : 0,
-                                                 CON && esc_role == 2 && team_ballot(esc_contact) != 0);
+                                                 CON && esc_role == 2 && team_ballot(esc_contact) != 0, chk_dlo, chk_dhi);
 #ifdef RCSH_CHECK_DEBUG
     if (leader) { atomicAdd(&g_chk_dbg[34], hit ? 1 : 0); atomicAdd(&g_chk_dbg[37], 1); }
 #endif

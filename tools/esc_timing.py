@@ -13,7 +13,7 @@ import parity_util as PU
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 win = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-venv = PU.make_vec_env(n, True)
+venv = PU.make_vec_env(n, os.environ.get("ESC_TIMING_ASYNC", "1") != "0")  # (ESC_TIMING_ASYNC=0: step_until_convergence)
 joints, grip = PU.synthetic_actions(n, steps, int(os.environ.get("ESC_TIMING_SEED", "0")))  # (seed e: environment e of the 4096-environment rollout first)
 if os.environ.get("ESC_TIMING_GRIP"):  # e.g. 0: every gripper commanded shut (pads pressed together: the many-contact case in workgroup 0)
     grip[:] = float(os.environ["ESC_TIMING_GRIP"])
