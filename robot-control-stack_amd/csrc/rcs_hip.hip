@@ -499,8 +499,22 @@ void build_self_levers(rcsh_sim* s) {
     for (int k = 0; k < 3; ++k) c[k] = g.rot[3 * k] * lc[0] + g.rot[3 * k + 1] * lc[1] + g.rot[3 * k + 2] * lc[2] + g.pos[k] - m.jpos[g.link][k];
     double acc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + std::sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
     const int l = g.link;
+    // (the geom's OWN hinge: what a radian of it moves is a point's distance from the AXIS, not from the anchor -- the largest over the
+    // eight corners of the geom's box; a flange that is a cylinder about its joint's axis: its radius instead of its length)
+    double radial = 0.0;
+    for (int corner = 0; corner < 8; ++corner) {
+      const double sg[3] = {corner & 1 ? h[0] : -h[0], corner & 2 ? h[1] : -h[1], corner & 4 ? h[2] : -h[2]};
+      double v[3];
+      for (int k = 0; k < 3; ++k) v[k] = c[k] + g.rot[3 * k] * sg[0] + g.rot[3 * k + 1] * sg[1] + g.rot[3 * k + 2] * sg[2];
+      const double* ax = m.axis[l];
+      const double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+      const double al = an > 0 ? (v[0] * ax[0] + v[1] * ax[1] + v[2] * ax[2]) / an : 0.0;
+      const double r2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] - al * al;
+      radial = std::max(radial, std::sqrt(std::max(r2, 0.0)));
+    }
     for (int j = l; j >= 0; j = parent(j)) {
-      s->link_lever[144 + j * 32 + (int)gi] = (float)(m.jtype[j] == kSlide ? 1.0 : (1.01 * (acc + stroke[l]) + 1e-3) * 1.000001);
+      const double arm = j == l && m.jtype[j] != kSlide ? std::min(radial, acc) : acc + stroke[l];
+      s->link_lever[144 + j * 32 + (int)gi] = (float)(m.jtype[j] == kSlide ? 1.0 : (1.01 * arm + 1e-3) * 1.000001);
       acc += hop[j] + stroke[j];
     }
   }
