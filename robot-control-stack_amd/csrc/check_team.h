@@ -56,6 +56,7 @@ __device__ unsigned long long g_chk_cyc[16];
 // where the left and right fingertip pads meet face to face with a gap of 0.0; whether a collider then reports a penetration of
 // 1e-17 m or none is round-off (it exerts no force either way).  The oracle-side restatement of this check uses the same bar.
 constexpr double kCheckTouch = 1e-9;
+constexpr int kCheckRoundBudget = 12;  // narrow-phase rounds a certificate may take (certifying mode; unresolved_contact_check: THE BUDGET)
 constexpr int kCheckSep = 16;  // per environment: FOUR remembered separating directions (pair index + 1, direction in geom 0's link frame) -- two
                                 // through round 5's last session: a folded arm keeps three or four pairs near, the xArm7's gripper linkage more, and a pair
                                 // without its direction costs Gilbert steps or a full refinement in every launch
@@ -592,18 +593,32 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     double low = b + a[0] * sph[0] + a[1] * sph[1] + a[2] * sph[2] - sph[3];  // (the lowest any of the link's points can be)
     if (low < thr) {
       low = INFINITY;
-      for (int k = lc.link_adr[t]; k < lc.link_adr[t + 1]; ++k) {
-        const double* v = lc.xyzr + 4 * (size_t)k;
-        const double h1 = b + a[0] * v[0] + a[1] * v[1] + a[2] * v[2] - v[3];
-        low = fmin(low, h1);
-        if (h1 < thr) {
-          // (the point's height where the launch began: the path-length form)
-          const double h0 = b0 + a0[0] * v[0] + a0[1] * v[1] + a0[2] * v[2] - v[3];
-          if (mfl > 0.0 && h1 > -kCheckTouch && h0 > -kCheckTouch && h0 + h1 > mflP - 2.0 * kCheckTouch) continue;
-          mine = true;
+      // (four points a trip, their sixteen words asked for together: the points live in global memory, and a loop that asked for one,
+      // waited, tested and asked for the next spent a memory round trip per point -- a link has up to 150 -- on the one lane whose
+      // link hangs low, with its wavefront and, late in a long rollout when many arms hang low, the whole launch waiting)
+      const int k1 = lc.link_adr[t + 1];
+      for (int k0 = lc.link_adr[t]; k0 < k1; k0 += 4) {
+        double v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* src = lc.xyzr + 4 * (size_t)(k0 + u < k1 ? k0 + u : k0);
+          v[u][0] = src[0]; v[u][1] = src[1]; v[u][2] = src[2]; v[u][3] = src[3];
+        }
+        sched_fence();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (k0 + u >= k1) continue;
+          const double h1 = b + a[0] * v[u][0] + a[1] * v[u][1] + a[2] * v[u][2] - v[u][3];
+          low = fmin(low, h1);
+          if (h1 < thr) {
+            // (the point's height where the launch began: the path-length form)
+            const double h0 = b0 + a0[0] * v[u][0] + a0[1] * v[u][1] + a0[2] * v[u][2] - v[u][3];
+            if (mfl > 0.0 && h1 > -kCheckTouch && h0 > -kCheckTouch && h0 + h1 > mflP - 2.0 * kCheckTouch) continue;
+            mine = true;
 #ifdef RCSH_CHECK_DEBUG
-          atomicAdd(&g_chk_dbg[0], 1);
+            atomicAdd(&g_chk_dbg[0], 1);
 #endif
+          }
         }
       }
     }
@@ -704,6 +719,7 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
   tail_pre_ = tail_t1_ - tail_t0_;
 #endif
   if (ck.pad & 1) cmask = 0;
+  int nround = 0;  // (team-uniform) narrow-phase rounds this team's environment has taken part in
   for (uint64_t pc = __ballot(cmask != 0); pc; pc = __ballot(cmask != 0)) {
     if (all_hit()) break;
     const int src = __ffsll((long long)pc) - 1;  // wave-uniform
@@ -712,11 +728,20 @@ RCSH_D bool unresolved_contact_check(const CheckTable& ck, const ContactTable& t
     const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)cmask, src);
     const int u = __ffs((int)sm) - 1, t1 = src & (kTeamLanes - 1);
     const bool holder = t == t1 && ((cmask >> u) & 1u);
-    const bool take = team_ballot(holder) != 0;
+    bool take = team_ballot(holder) != 0;
 #ifdef RCSH_CHECK_TAIL
     tail_rounds_ += take ? 1 : 0;
 #endif
     if (holder) cmask &= ~(1u << u);
+    if (keep_slack != 0 && take) {
+      // THE BUDGET.  A launch waits for its slowest wavefront, and late in a long rollout that is one with an environment NEAR contact
+      // whose certificate takes ten to twenty of these rounds (13k cycles each: at launch 1000 of the headline rollout the lean launch
+      // took 300 us instead of 137, `profiles/r6_escalated3`).  Such an environment is where the contact-resolving launch looks in every
+      // substep anyway: past the budget it is not certified -- conservative, like every other way of failing -- and stays there until
+      // its certificate fits the budget again (the same rule on both launches: no going back and forth).
+      nround += 1;
+      if (nround > kCheckRoundBudget) { mine = true; cmask = 0; take = false; }
+    }
     const int pidx = t1 + kTeamLanes * u;
     uint32_t gg = 0;
     double mu_ = 0.0, muP_ = 0.0;
