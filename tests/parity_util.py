@@ -1608,6 +1608,10 @@ def run_headline_resolved_parity(n_envs=64, n_steps=1000, seed=0):
             twin_verr[e] = max(twin_verr[e], float(np.abs(np.asarray(tw.sim.qvel) - np.asarray(oe.sim.qvel)).max()))
             dq = float(np.abs(q[e] - oe.sim.qpos[: q.shape[1]]).max())
             dv = float(np.abs(v[e] - oe.sim.qvel[: v.shape[1]]).max())
+            if os.environ.get("RCS_TWIN_TRACE"):  # dev: "lo:hi" -- the steps to print the kernel's and the twins' distances for
+                lo_, hi_ = (int(x) for x in os.environ["RCS_TWIN_TRACE"].split(":"))
+                if lo_ <= t <= hi_:
+                    print(f"step {t} env {e}: |dq| {dq:.2e} |dv| {dv:.2e} twins |dq| {twin_err[e]:.2e} |dv| {twin_verr[e]:.2e} contacts {int(oe.sim.s.d.ncon)}")
             if dq > 1e-9 and first_bad[e] < 0:
                 first_bad[e] = t
             err_env[e] = max(err_env[e], dq)
