@@ -88,6 +88,7 @@ struct rcsh_sim {
   int esc_split_max = 128;          // split while at most this many environments are escalated (RCSH_ESC_SPLIT_MAX)
   volatile uint32_t* h_esc_hint = nullptr;  // [2] host memory the lean launch writes (RunOp::esc_host)
   uint32_t esc_seq = 0;
+  int conv_chunk = 48;              // step_until_convergence in pieces of this many substeps when contacts are resolved per environment (launch_run; RCSH_CONV_CHUNK)
   int esc_split = 0;                // 1: split (RCSH_ESC_SPLIT=1).  OFF by default -- measured (profiles/r5_v2/split_ab.txt): with the escalated
                                     // environments' launch dispatched first and the lean launch beside it a 300-step rollout takes 0.496 ms a step
                                     // against 0.433 one launch after the other, the 1000-step rollout 3.96 against 3.87: two kernels of different
@@ -597,7 +598,28 @@ bool use_occ2(const rcsh_sim* s) {
   return (s->n + 3) / 4 > s->n_simd && occ2_build_pays<T, F>();
 }
 
+int launch_run_once(rcsh_sim* s, const RunOp& op_in, bool timed);
+
+// step_until_convergence with the robot's contacts resolved environment by environment runs in PIECES of conv_chunk substeps (RunOp::
+// conv_chunk; RCSH_CONV_CHUNK, 0: one launch as before): a pair of launches per piece, each lean launch with its own copy of the state and
+// its own certificate over the piece's travel alone.  Every piece is enqueued -- the host does not know who has converged --: a
+// workgroup whose environments all have leaves after its prologue.
 int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
+  const int cap = s->sim.max_convergence_steps;
+  const bool esc = s->esc_mode && s->box.resolve && !s->box.present && !op_in.observe_only;
+  if (op_in.nsteps < 0 && !op_in.do_reset && esc && s->conv_chunk > 0 && cap > s->conv_chunk) {
+    for (int done = 0; done < cap; done += s->conv_chunk) {
+      RunOp op = op_in;
+      op.conv_chunk = s->conv_chunk;
+      if (done > 0) { op.conv_resume = 1; op.apply_action = 0; }
+      if (int rc = launch_run_once(s, op, timed)) return rc;
+    }
+    return RCSH_OK;
+  }
+  return launch_run_once(s, op_in, timed);
+}
+
+int launch_run_once(rcsh_sim* s, const RunOp& op_in, bool timed) {
   Params P = make_params(s);
   RunOp op = op_in;
   // the end-of-launch check for contacts nobody resolves: stepping launches at the handle's cadence; a caller may ask for it itself
@@ -1518,6 +1540,7 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
     HIP_TRY(hipMalloc(&s->d_snap_flags, sizeof(uint32_t) * s->n));
     HIP_TRY(hipMalloc(&s->d_snap_conv, sizeof(int32_t) * s->n));
     if (const char* e = std::getenv("RCSH_ESC_SPLIT")) s->esc_split = std::atoi(e);
+    if (const char* e = std::getenv("RCSH_CONV_CHUNK")) s->conv_chunk = std::atoi(e);
     // (the split form's stream exists only where it is asked for: one more stream in the process changes how the runtime maps streams
     // to hardware queues -- the four sub-batches of `bench.py --robot mixed`, a stream each, ran one after the other with it: 18 -> 8 M)
     if (s->esc_split) {

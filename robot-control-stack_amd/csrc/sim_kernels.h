@@ -124,12 +124,16 @@ struct RunOp {
   int32_t esc_role;
   int32_t force_contact;  // the contact phase runs in every substep of every environment (a whole batch on the contact-resolving kernel with
                           // self contacts resolved: exact, and slow -- the fast path's broad phase knows the floor and the free body only)
-  int32_t esc_pad0;         // (round 5: esc_leave_quiet)
+  int32_t conv_chunk;     // step_until_convergence in PIECES (host: launch_run): at most this many substeps in this launch (0: all of them).  The
+                          // certificate's margins are the joints' travel over ONE launch: a 500-substep launch that moves a joint five degrees
+                          // cannot clear pairs that are 15 mm apart in every pose, a quarter of it can -- and an environment that fails is
+                          // redone for that piece only
   // Role 2 in two parts (esc_part): the environments that WERE escalated when the step began do not depend on the step's lean launch --
   // part 1 steps them on a stream of its own, next to the lean launch, and leaves the masks alone; part 2, behind both, redoes the newly
   // flagged ones and merges.  0: one launch does both (behind the lean one).  The host splits when it knows of escalated environments.
   int32_t esc_part;
-  int32_t esc_seq, esc_pad2;  // role 1: the step's number, for esc_host
+  int32_t esc_seq;        // role 1: the step's number, for esc_host
+  int32_t conv_resume;    // this launch CONTINUES a step_until_convergence begun by an earlier one: substep count, verdicts and the cap carry over
   uint32_t* esc_host;     // [2] host memory: the last step whose lean launch has (all but) ended, the escalated count it started with
   uint64_t* esc;          // [3][(n + 63) / 64]
   uint32_t* esc_ctr;      // [0] workgroups of the role-2 launch that are done, [1] environments escalated after the last merge,
@@ -1016,10 +1020,17 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
   if (leader) {
     budget = nsteps;
     if (until_conv) {
-      r.conv_steps = 0;
-      r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
       const int cap = P.sim.max_convergence_steps;
-      budget = cap == -1 ? 0x7fffffff : cap;
+      if (!opk.conv_resume) {
+        r.conv_steps = 0;
+        r.flags &= ~(kConverged | kAnyRet0 | kAnyRet1 | kAllRet0 | kAllRet1);
+        budget = cap == -1 ? 0x7fffffff : cap;
+      } else {
+        // (a later piece: whoever converged stays put, the others go on with what the cap leaves them)
+        converged = (r.flags & kConverged) != 0;
+        budget = converged ? 0 : (cap == -1 ? 0x7fffffff : cap - r.conv_steps);
+      }
+      if (opk.conv_chunk > 0 && budget > opk.conv_chunk) budget = opk.conv_chunk;
     }
   }
   // Which teams still step is decided by their leaders and spread with a ballot (no LDS flag, no barrier); the

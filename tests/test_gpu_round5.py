@@ -87,3 +87,29 @@ def test_until_convergence_false_alarms_of_the_certificate_stay_bounded():
             assert np.abs(q[e][:7] - oe.sim.qpos[:7]).max() < 1e-9, (t, e)
             assert int(info["substeps"][e]) == int(oe.sim.s.convergence_steps), (t, e)
     assert max(held[1:]) < 0.2, held
+
+
+def test_until_convergence_in_pieces_equals_one_launch_bit_for_bit(monkeypatch):
+    """`step_until_convergence` with contacts resolved per environment runs in pieces of `RCSH_CONV_CHUNK` substeps (csrc/rcs_hip.hip:
+    launch_run -- each piece certified over its own travel, an environment that fails redone for that piece only): the pieces carry the
+    substep count, the callbacks' verdicts and the cap over, so positions, velocities, substep counts and flags equal the one-launch
+    form's to the last bit."""
+    from parity_util import make_vec_env, synthetic_actions
+
+    n, steps = 64, 4
+    joints, grip = synthetic_actions(n, steps, 5)
+    out = []
+    for chunk in ("0", "48", "16"):
+        monkeypatch.setenv("RCSH_CONV_CHUNK", chunk)
+        venv = make_vec_env(n, False)
+        venv.reset()
+        rec = []
+        for t in range(steps):
+            obs, _, _, trunc, info = venv.step({"joints": joints[t], "gripper": grip[t]})
+            rec.append((np.array(venv.sim.qpos), np.array(venv.sim.qvel), np.array(info["substeps"]), np.array(info["is_sim_converged"]), np.array(info["collision"]), np.array(obs["joints"])))
+        out.append(rec)
+        venv.close()
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
