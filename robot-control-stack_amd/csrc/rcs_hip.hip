@@ -88,6 +88,7 @@ struct rcsh_sim {
   int esc_split_max = 128;          // split while at most this many environments are escalated (RCSH_ESC_SPLIT_MAX)
   volatile uint32_t* h_esc_hint = nullptr;  // [2] host memory the lean launch writes (RunOp::esc_host)
   uint32_t esc_seq = 0;
+  int conv_grow = 0;                // ... growing (RCSH_CONV_GROW=1)
   int conv_chunk = 48;              // step_until_convergence in pieces of this many substeps when contacts are resolved per environment (launch_run; RCSH_CONV_CHUNK)
   int esc_split = 0;                // 1: split (RCSH_ESC_SPLIT=1).  OFF by default -- measured (profiles/r5_v2/split_ab.txt): with the escalated
                                     // environments' launch dispatched first and the lean launch beside it a 300-step rollout takes 0.496 ms a step
@@ -608,9 +609,13 @@ int launch_run(rcsh_sim* s, const RunOp& op_in, bool timed) {
   const int cap = s->sim.max_convergence_steps;
   const bool esc = s->esc_mode && s->box.resolve && !s->box.present && !op_in.observe_only;
   if (op_in.nsteps < 0 && !op_in.do_reset && esc && s->conv_chunk > 0 && cap > s->conv_chunk) {
-    for (int done = 0; done < cap; done += s->conv_chunk) {
+    // (a servo's travel is front-loaded: the first pieces are the ones whose certificates fail, the last ones only cost their launches'
+    // fixed parts -- with conv_grow the piece doubles after every second one, up to 128 substeps)
+    int piece = s->conv_chunk, k = 0;
+    for (int done = 0; done < cap; done += piece, ++k) {
+      if (s->conv_grow && k > 0 && k % 2 == 0 && piece < 128) piece = std::min(2 * piece, 128);
       RunOp op = op_in;
-      op.conv_chunk = s->conv_chunk;
+      op.conv_chunk = piece;
       if (done > 0) { op.conv_resume = 1; op.apply_action = 0; }
       if (int rc = launch_run_once(s, op, timed)) return rc;
     }
@@ -1541,6 +1546,7 @@ int rcsh_sim_set_contact_options(rcsh_sim* s, const rcsh_contact_options* o) {
     HIP_TRY(hipMalloc(&s->d_snap_conv, sizeof(int32_t) * s->n));
     if (const char* e = std::getenv("RCSH_ESC_SPLIT")) s->esc_split = std::atoi(e);
     if (const char* e = std::getenv("RCSH_CONV_CHUNK")) s->conv_chunk = std::atoi(e);
+    if (const char* e = std::getenv("RCSH_CONV_GROW")) s->conv_grow = std::atoi(e);
     // (the split form's stream exists only where it is asked for: one more stream in the process changes how the runtime maps streams
     // to hardware queues -- the four sub-batches of `bench.py --robot mixed`, a stream each, ran one after the other with it: 18 -> 8 M)
     if (s->esc_split) {
