@@ -675,9 +675,9 @@ RCSH_CONTACT_FN void contact_noslip_dense(const BoxCfg& b_, const StageTeam<T>& 
 #endif
 template <class T, bool FRIC = false, bool BOXD = true, class AR>
 RCSH_D uint32_t contact_phase(const ContactTable& tab, const CheckTable& ck, const BoxCfg& b, const LinkRec* links, const StageTeam<T>& st, double* bs,
-                              AR& ar, const double* gravity, int env) {
+                              AR& ar, const double* gravity, int env, bool frames_ready = false) {
   PHASE_CLOCK(pc0)
-  const uint32_t r = contact_collide<T, AR>(tab, ck, b, links, st, bs, ar, env);
+  const uint32_t r = contact_collide<T, AR>(tab, ck, b, links, st, bs, ar, env, frames_ready);
   PHASE_CLOCK(pc1)
 #ifdef RCSH_PHASE_TIMING
   if ((threadIdx.x & 63) == 0) {  // (all workgroups) contact phases / coupled / contacts / most contacts / solves on the tree formulation

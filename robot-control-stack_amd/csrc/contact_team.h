@@ -1303,7 +1303,7 @@ RCSH_D int contact_key(int b1, int b2, int g1, int g2, int k) { return (b1 << 23
 constexpr int kKeyBox = 31;  // the free box: the scene's last body, its last geom (reference assets/scenes/fr3_simple_pick_up/scene.xml:30-33)
 template <class T, class AR>
 RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTable& ck_, const BoxCfg& b_, const LinkRec* links_, const StageTeam<T>& st_,
-                                         const double* bs_, AR& ar_, int env) {
+                                         const double* bs_, AR& ar_, int env, bool frames_ready = false) {
   constexpr int kMaxCon = AR::kCap;  // (this arena's capacity)
   const ContactTable& tab = *in_lds(&tab_);
   const CheckTable& ck = *in_lds(&ck_);
@@ -1431,7 +1431,10 @@ RCSH_CONTACT_FN uint32_t contact_collide(const ContactTable& tab_, const CheckTa
   }
   // ---- link frames at the pre-step configuration: every lane its own joint's local frame, composed down the chain by the position
   // stage's scan (three or four rounds across the lanes; a lane walking the chain to its link alone took 6k cycles of every pass)
-  {
+  // (frames_ready, wave-uniform: the substep's position stage has put them there already -- the same frames from the same functions --:
+  // the contact-resolving launch of per-environment escalation, whose wavefront has one environment and nothing else in the arena
+  // between the position stage and this pass; sim_kernels.h)
+  if (!frames_ready) {
     const int tl = lane < NL ? lane : NL - 1;
     KinK kk;
     kk.load(links[tl]);

@@ -1173,6 +1173,18 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
     bool near = false;  // broad phase of the contact phase: the lane's link may touch the floor or the box
     bool team_coupled = false;  // the contact phase solved this substep's constraints for robot and box together
     team_substep<T, FRIC>(m, sk, llinks, st, t, stepping, gc_is_mass, [&](const double* R, const double* p) {
+      if constexpr (CON && !DET) {
+        // (the contact-resolving launch of per-environment escalation: team 0's environment is the first -- in a spread launch the only --
+        // one the contact phase takes, and the link frames its collision pass begins with are these: parked where it reads them, the
+        // pass skips its own forward kinematics.  Nothing uses the arena between here and that pass.)
+        if (esc_role == 2 && team == 0 && t < T::NL && stepping) {
+          double (*F)[12] = larena[0].frames();
+#pragma unroll
+          for (int k = 0; k < 9; ++k) F[t][k] = R[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) F[t][9 + k] = p[k];
+        }
+      }
       if constexpr (CON) {
         if (stepping && con_lane && t < T::NL) {
           // the link's bounding box (link frame) against the floor -- its support along the plane normal -- and against
@@ -1272,7 +1284,7 @@ __device__ __attribute__((always_inline)) inline void run_team_body(const Params
           for (int k = 0; k < kTeams; ++k) {
             if (!((nearw >> (k * kTeamLanes)) & 0xffffu)) continue;
             const uint32_t r = contact_phase<T, FRIC, BOX>(lp.ctab, lp.chk, lbt[0].box, llinks, ST{lds + k * ST::COUNT}, lbox + k * kBoxStride, larena[0], lm.gravity,
-                                                      __builtin_amdgcn_readlane(e, k * kTeamLanes));
+                                                      __builtin_amdgcn_readlane(e, k * kTeamLanes), !DET && esc_role == 2 && k == 0);
             if (team == k) {
               coupled = r & 1u;
               hit |= (r >> 8) & 3u;
